@@ -1,0 +1,131 @@
+/* pit_hip.h -- C ABI of the MI355X-native PiT position-attention hot path.
+ *
+ * The reference (junfeng-chen/position_induced_transformer) has no FFI: its hot path
+ * is a sequence of torch ops inside pit.py.  Each entry point below replaces one such
+ * sequence (cited as pit.py:line) and is what a ctypes / pybind / cgo binding for this
+ * path would bind.  Conventions:
+ *   - plain `extern "C"`, raw DEVICE pointers (fp32 unless stated), int sizes, strides
+ *     in ELEMENTS; `stream` is a hipStream_t passed as void* (NULL = default stream);
+ *   - every function returns 0 on success, a negative PIT_ERR_* for an argument error,
+ *     or a positive hipError_t; nothing allocates, frees, synchronises or keeps global
+ *     state, so every call can be captured into a hipGraph;
+ *   - outputs and workspaces are caller-owned (the PyTorch host code allocates them).
+ *
+ * Mesh conventions: `mesh_batch` = 1 for the batch-free (fixed) meshes of
+ * posatt_fixed / _periodic1d / _periodic2d (pit.py:129-144,186-200,243-258) where
+ * the attention weights are shared by the whole batch, and = b for the per-sample
+ * meshes of posatt (pit.py:46-52).  Meshes are (mesh_batch, n, space_dim) contiguous,
+ * space_dim in {1,2,3}.
+ */
+#ifndef PIT_HIP_H
+#define PIT_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PIT_ABI_VERSION 1
+
+/* distance metric (dist2att variants) */
+#define PIT_METRIC_EUCLID     0   /* pit.py:47,134  sum_c (xo_c-xi_c)^2                         */
+#define PIT_METRIC_PERIODIC1D 1   /* pit.py:190-194 wrap |dx| to min(|dx|, l-|dx|), coordinate 0 */
+#define PIT_METRIC_PERIODIC2D 2   /* pit.py:248-253 per-coordinate wrap, then sum of squares     */
+
+/* argument errors */
+#define PIT_ERR_NULL     -1
+#define PIT_ERR_SIZE     -2
+#define PIT_ERR_METRIC   -3
+#define PIT_ERR_UNSUPPORTED -4
+
+int pit_version(void);
+/* human-readable text for a return code of any function below */
+const char* pit_error_string(int code);
+
+/* pit.py:48 (and :135,:196,:254): c_h = tan(0.25*pi*(1-1e-7)*(1+sin(lmda_h))).
+ * Evaluated through fp64 with the reference's fp32 intermediate roundings. */
+int pit_head_scale(const float* lmda, int n_head, float* scale_out, void* stream);
+
+/* Selection pre-pass replacing the sort inside torch.quantile (pit.py:49,136,197,255).
+ * For every row (mesh_batch*n_out rows of length n_in) of the UNSCALED squared distance
+ * writes stats[0][row] = m_(k), stats[1][row] = m_(k+1) (k+1 clipped to n_in-1) and
+ * stats[2][row] = min_j m.  rank_k = floor(fl32(q)*fl32(n_in-1)) (0-based).  With
+ * need_kth = 0 only the row minimum is computed (locality 1.0: nothing is masked).
+ * stats is 3*mesh_batch*n_out floats. */
+int pit_select_fwd(const float* mesh_out, const float* mesh_in, int mesh_batch, int n_out, int n_in,
+                   int space_dim, int metric, float period, int rank_k, int need_kth,
+                   float* stats, void* stream);
+
+/* Fused dist2att + convolution forward (pit.py:46-57 / 133-144 and the periodic
+ * variants; posatt.forward :37-44 with copy_inputs, posatt_cross*.forward :63-71).
+ *   values   (batch, n_in, dim)   rows ld_values apart, samples values_bstride apart
+ *   head     n_head floats: lmda (head_is_scale=0) or the scale c itself (=1)
+ *   stats    from pit_select_fwd (may be NULL when masked=0 and self_attn=1: min is 0)
+ *   rank_w   fractional part of the quantile rank (fp32), used when masked=1
+ *   out      (batch, n_out, ...) rows ld_out apart; head h / channel d is written at
+ *            column out_col0 + h*dim + d; with copy_inputs=1 (self attention, n_out ==
+ *            n_in) values[b,n,:] is also copied to columns [0,dim) -> torch.cat of :44
+ *   rowstat  (mesh_batch, n_head, n_out, 4) = {T, S_min, 1/rowsum, sum_j P*m} saved for
+ *            the backward; scale_out (n_head) receives the c that was used. */
+int pit_posatt_fwd(const float* mesh_out, const float* mesh_in, int mesh_batch, int n_out, int n_in,
+                   int space_dim, int metric, float period,
+                   const float* values, int batch, int dim, long ld_values, long values_bstride,
+                   const float* head, int n_head, int head_is_scale,
+                   const float* stats, float rank_w, int masked, int self_attn,
+                   float* out, long ld_out, long out_bstride, int out_col0, int copy_inputs,
+                   float* rowstat, float* scale_out, void* stream);
+
+/* Backward of pit_posatt_fwd (closed form; the reference uses
+ * autograd).  d_out has the layout of `out` (columns out_col0 + h*dim + d).
+ *   d_values (batch, n_in, dim): written.  With add_residual=1 (self attention) the
+ *            gradient of the copied inputs, d_out[b,j,0:dim], is added.
+ *   d_head   n_head floats: gradient w.r.t. lmda (head_is_scale=0) or w.r.t. c (=1)
+ *   workspace: n_head doubles (fp64 accumulators for d c), zeroed by this call. */
+int pit_posatt_bwd(const float* mesh_out, const float* mesh_in, int mesh_batch, int n_out, int n_in,
+                   int space_dim, int metric, float period,
+                   const float* values, int batch, int dim, long ld_values, long values_bstride,
+                   const float* head, int n_head, int head_is_scale,
+                   const float* rowstat, int masked,
+                   const float* d_out, long ld_dout, long dout_bstride, int out_col0,
+                   float* d_values, long ld_dvalues, long dvalues_bstride, int add_residual,
+                   float* d_head, double* workspace, void* stream);
+
+/* kaiming_mlp.forward (pit.py:21-26): y = W2 * gelu_erf(W1 x + b1) + b2, optionally
+ * followed by the trailing gelu of pit.py:111,121 (out_gelu=1).
+ *   x (rows, n0) rows ldx apart; w1 (n1,n0), b1 (n1), w2 (n2,n1), b2 (n2) contiguous;
+ *   z1 (rows,n1) and h (rows,n1) are saved for the backward (pre-activation and
+ *   gelu(z1)); z2 (rows,n2) is the pre-activation of the trailing gelu (out_gelu=1,
+ *   else may be NULL); y (rows, n2) rows ldy apart. */
+int pit_mlp_fwd(const float* x, long ldx, int rows, int n0, int n1, int n2,
+                const float* w1, const float* b1, const float* w2, const float* b2, int out_gelu,
+                float* z1, float* h, float* z2, float* y, long ldy, void* stream);
+
+/* Backward of pit_mlp_fwd.  d_y (rows,n2) rows ld_dy apart.  d_x (rows,n0) rows ld_dx
+ * apart (NULL = not needed).  d_w1,d_b1,d_w2,d_b2 are WRITTEN (zeroed here, then
+ * accumulated with fp32 atomics over row slabs).  scratch: rows*(n1+n2) floats. */
+int pit_mlp_bwd(const float* x, long ldx, int rows, int n0, int n1, int n2,
+                const float* w1, const float* w2, const float* z1, const float* h, const float* z2,
+                int out_gelu, const float* d_y, long ld_dy,
+                float* d_x, long ld_dx, float* d_w1, float* d_b1, float* d_w2, float* d_b2,
+                float* scratch, void* stream);
+
+/* RelLpNorm (utils.py:80-98): loss = sum_b mean_c ||true - pred'||_p / ||true||_p with norms
+ * over the point axis of (batch, npts, nch) contiguous tensors, pred' = pred*scale + shift when
+ * the optional per-pixel (npts, nch) affine of PixelWiseNormalization.denormalize
+ * (utils.py:25-34, train_darcy.py:129) is given (both NULL = identity).
+ * norms (batch, nch, 2) = {||true-pred'||_p, ||true||_p} is saved for the backward; loss is one
+ * float (zeroed here).  grad_loss: device pointer to the upstream scalar (NULL = 1). */
+int pit_rel_lp_loss_fwd(const float* tru, const float* pred, const float* pred_scale,
+                        const float* pred_shift, int batch, int npts, int nch, int p,
+                        float* norms, float* loss, void* stream);
+int pit_rel_lp_loss_bwd(const float* tru, const float* pred, const float* pred_scale,
+                        const float* pred_shift, int batch, int npts, int nch, int p,
+                        const float* norms, const float* grad_loss, float* d_pred, void* stream);
+
+/* Layout probe used by the tests: D = A(32x8) * B(8x32) through the same
+ * v_mfma_f32_32x32x2_f32 fragment maps the kernels use. */
+int pit_debug_mfma_tile(const float* a, const float* b, float* d, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PIT_HIP_H */

@@ -1,0 +1,78 @@
+"""ctypes binding of csrc/libpit_hip.so (C ABI declared in include/pit_hip.h).
+
+There is no fallback: if the library is missing or a symbol is absent this raises, and
+every op in this package goes through it.  torch is imported first so that the HIP
+runtime already loaded by PyTorch-ROCm is the one the library binds to."""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import torch  # noqa: F401  (must precede the CDLL load)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libpit_hip.so")
+
+_P = ctypes.c_void_p
+_I = ctypes.c_int
+_L = ctypes.c_long
+_F = ctypes.c_float
+
+# name -> argtypes, mirrors include/pit_hip.h one to one
+SIGNATURES = {
+    "pit_version": [],
+    "pit_error_string": [_I],
+    "pit_head_scale": [_P, _I, _P, _P],
+    "pit_select_fwd": [_P, _P, _I, _I, _I, _I, _I, _F, _I, _I, _P, _P],
+    "pit_posatt_fwd": [_P, _P, _I, _I, _I, _I, _I, _F,
+                       _P, _I, _I, _L, _L,
+                       _P, _I, _I,
+                       _P, _F, _I, _I,
+                       _P, _L, _L, _I, _I,
+                       _P, _P, _P],
+    "pit_posatt_bwd": [_P, _P, _I, _I, _I, _I, _I, _F,
+                       _P, _I, _I, _L, _L,
+                       _P, _I, _I,
+                       _P, _I,
+                       _P, _L, _L, _I,
+                       _P, _L, _L, _I,
+                       _P, _P, _P],
+    "pit_mlp_fwd": [_P, _L, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _L, _P],
+    "pit_mlp_bwd": [_P, _L, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _L,
+                    _P, _L, _P, _P, _P, _P, _P, _P],
+    "pit_rel_lp_loss_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P],
+    "pit_rel_lp_loss_bwd": [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P],
+    "pit_debug_mfma_tile": [_P, _P, _P, _P],
+}
+
+_lib = None
+
+
+def lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: build it with `python -m position_induced_transformer_amd.build` "
+                "(hipcc --offload-arch=gfx950). There is no CPU or PyTorch fallback for the PiT hot path.")
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, argtypes in SIGNATURES.items():
+            fn = getattr(handle, name)       # AttributeError if the ABI lost a symbol
+            fn.argtypes = argtypes
+            fn.restype = ctypes.c_char_p if name == "pit_error_string" else _I
+        _lib = handle
+    return _lib
+
+
+def check(code: int, what: str) -> None:
+    if code != 0:
+        msg = lib().pit_error_string(code)
+        raise RuntimeError(f"{what} failed ({code}): {msg.decode() if msg else '?'}")
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t) -> int:
+    return 0 if t is None else t.data_ptr()

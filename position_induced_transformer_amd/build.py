@@ -1,0 +1,40 @@
+"""Build the gfx950 shared library (csrc/*.hip -> csrc/libpit_hip.so) with hipcc.
+
+In-tree so the .so travels with the repo snapshot to the GPU box.  hipcc cross-compiles
+without a GPU.  `-ffp-contract=off`: the mask decision must reproduce the reference's
+un-fused fp32 arithmetic; fmas are written explicitly where wanted.
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+
+CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+LIB = os.path.join(CSRC, "libpit_hip.so")
+SOURCES = ("pit_abi.hip", "pit_select.hip", "pit_posatt.hip", "pit_mlp.hip", "pit_loss.hip")
+HEADERS = ("pit_common.h", os.path.join("..", "..", "include", "pit_hip.h"))
+FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17"]
+
+
+def _stale() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS]
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile if missing or out of date; returns the library path."""
+    srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    if force or _stale():
+        hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+        cmd = [hipcc] + FLAGS + ["-o", LIB] + srcs
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.run(cmd, check=True, cwd=CSRC)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force=True, verbose=True))

@@ -1,0 +1,81 @@
+// Shared device helpers for the PiT hot-path kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <algorithm>
+#include "../../include/pit_hip.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define PIT_WAVE 64
+
+// v_mfma_f32_32x32x2_f32: D(32x32) += A(32x2) * B(2x32), exact fp32 fma chain.
+// Fragment maps (cdna guide section 3): lane l holds A[i = l&31][k = l>>5] and
+// B[k = l>>5][j = l&31]; accumulator register r of lane l is
+// D[row = (r&3) + 8*(r>>2) + 4*(l>>5)][col = l&31].
+__device__ __forceinline__ f32x16 mfma_32x32x2(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ int acc_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
+
+// Squared distance exactly as the reference forms it in fp32:
+// separate multiplies and adds, never an fma, never the |x|^2+|y|^2-2xy expansion.
+// Coordinates are zero-padded to 3, which leaves the value unchanged bit for bit
+// (x + (+0) == x).  Periodic variants wrap each coordinate first (pit.py:192-193,
+// 251-252): d = |d|; d = min(d, l - d).
+__device__ __forceinline__ float sq_dist3(float ox, float oy, float oz, float ix, float iy, float iz,
+                                          bool periodic, float period) {
+    float dx = __fsub_rn(ox, ix), dy = __fsub_rn(oy, iy), dz = __fsub_rn(oz, iz);
+    if (periodic) {
+        dx = fabsf(dx); dx = fminf(dx, __fsub_rn(period, dx));
+        dy = fabsf(dy); dy = fminf(dy, __fsub_rn(period, dy));
+        dz = fabsf(dz); dz = fminf(dz, __fsub_rn(period, dz));
+    }
+    return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+}
+
+// ATen's lerp as torch.quantile applies it.
+__device__ __forceinline__ float quantile_lerp(float a, float b, float w) {
+    float diff = __fsub_rn(b, a);
+    return (w < 0.5f) ? __fmaf_rn(w, diff, a) : __fmaf_rn(-diff, __fsub_rn(1.0f, w), b);
+}
+
+// c = tan(0.25*pi*(1-1e-7)*(1+sin(lmda))) with the reference's fp32 roundings of the
+// intermediate results (pit.py:48) and correctly rounded sin/tan (evaluated in fp64).
+#define PIT_SCALE_K 0x1.921fb2a19bef9p-1  /* 0.25*pi*(1-1e-7) evaluated in double = 0.785398084857632 */
+__device__ __forceinline__ float head_scale_from_lmda(float lmda) {
+    float s = (float)sin((double)lmda);
+    float u = __fmul_rn((float)PIT_SCALE_K, __fadd_rn(1.0f, s));
+    return (float)tan((double)u);
+}
+// d c / d lmda = (1 + c^2) * K * cos(lmda)
+__device__ __forceinline__ double head_scale_grad(float lmda, float c) {
+    return (1.0 + (double)c * (double)c) * PIT_SCALE_K * cos((double)lmda);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+__device__ __forceinline__ float gelu_erf(float x) {
+    return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+    const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+
+#define PIT_CHECK_LAUNCH()                                   \
+    do {                                                     \
+        hipError_t e__ = hipGetLastError();                  \
+        if (e__ != hipSuccess) return (int)e__;              \
+    } while (0)

@@ -1,0 +1,104 @@
+// Relative Lp loss on device (RelLpNorm, utils.py:80-98) with the optional per-pixel
+// affine de-normalisation the Darcy loop applies first (train_darcy.py:129,
+// utils.py:25-34):   pred' = pred*scale + shift;
+//   loss = sum_b mean_c ||true - pred'||_p / ||true||_p      (norms over the point axis)
+// One workgroup per (sample, channel) owns both norms, so a single launch produces the
+// loss (one atomicAdd per workgroup) and the two norms the backward needs.
+#include "pit_common.h"
+
+namespace {
+
+__device__ __forceinline__ float pow_abs(float x, int p) {
+    const float ax = fabsf(x);
+    if (p == 1) return ax;
+    if (p == 2) return ax * ax;
+    return powf(ax, (float)p);
+}
+
+__global__ __launch_bounds__(256) void rel_lp_fwd_kernel(const float* __restrict__ tru, const float* __restrict__ pred,
+                                                          const float* __restrict__ scale, const float* __restrict__ shift,
+                                                          int npts, int nch, int p, float* __restrict__ norms,
+                                                          float* __restrict__ loss) {
+    __shared__ double s_num[4], s_den[4];
+    const int c = blockIdx.x, b = blockIdx.y;
+    const long base = (long)b * npts * nch + c;
+    double num = 0.0, den = 0.0;
+    for (int l = threadIdx.x; l < npts; l += blockDim.x) {
+        const long e = base + (long)l * nch;
+        float q = pred[e];
+        if (scale) q = q * scale[(long)l * nch + c] + shift[(long)l * nch + c];
+        const float t = tru[e];
+        num += (double)pow_abs(t - q, p);
+        den += (double)pow_abs(t, p);
+    }
+    num = wave_sum_d(num);
+    den = wave_sum_d(den);
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { s_num[wave] = num; s_den[wave] = den; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        num = s_num[0] + s_num[1] + s_num[2] + s_num[3];
+        den = s_den[0] + s_den[1] + s_den[2] + s_den[3];
+        const double nn = (p == 1) ? num : (p == 2 ? sqrt(num) : pow(num, 1.0 / p));
+        const double dn = (p == 1) ? den : (p == 2 ? sqrt(den) : pow(den, 1.0 / p));
+        norms[((long)b * nch + c) * 2 + 0] = (float)nn;
+        norms[((long)b * nch + c) * 2 + 1] = (float)dn;
+        atomicAdd(loss, (float)(nn / dn / nch));
+    }
+}
+
+__global__ __launch_bounds__(256) void rel_lp_bwd_kernel(const float* __restrict__ tru, const float* __restrict__ pred,
+                                                          const float* __restrict__ scale, const float* __restrict__ shift,
+                                                          int batch, int npts, int nch, int p,
+                                                          const float* __restrict__ norms, const float* __restrict__ gloss,
+                                                          float* __restrict__ d_pred) {
+    const long total = (long)batch * npts * nch;
+    const float g = gloss ? gloss[0] : 1.0f;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(e % nch);
+        const long bl = e / nch;
+        const int l = (int)(bl % npts);
+        const int b = (int)(bl / npts);
+        float q = pred[e];
+        float sc = 1.0f;
+        if (scale) { sc = scale[(long)l * nch + c]; q = q * sc + shift[(long)l * nch + c]; }
+        const float d = q - tru[e];
+        const float nn = norms[((long)b * nch + c) * 2 + 0];
+        const float dn = norms[((long)b * nch + c) * 2 + 1];
+        float dnorm;                                    // d ||d||_p / d d
+        if (p == 1) dnorm = (d > 0.0f) ? 1.0f : (d < 0.0f ? -1.0f : 0.0f);
+        else if (p == 2) dnorm = (nn > 0.0f) ? d / nn : 0.0f;
+        else dnorm = (nn > 0.0f) ? copysignf(powf(fabsf(d) / nn, (float)(p - 1)), d) : 0.0f;
+        d_pred[e] = g * dnorm * sc / (dn * nch);
+    }
+}
+
+}  // namespace
+
+extern "C" int pit_rel_lp_loss_fwd(const float* tru, const float* pred, const float* pred_scale,
+                                   const float* pred_shift, int batch, int npts, int nch, int p,
+                                   float* norms, float* loss, void* stream) {
+    if (!tru || !pred || !norms || !loss) return PIT_ERR_NULL;
+    if ((pred_scale == nullptr) != (pred_shift == nullptr)) return PIT_ERR_NULL;
+    if (batch <= 0 || npts <= 0 || nch <= 0 || p < 1 || batch > 65535) return PIT_ERR_SIZE;
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(loss, 0, sizeof(float), s);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(rel_lp_fwd_kernel, dim3(nch, batch), dim3(256), 0, s, tru, pred, pred_scale, pred_shift, npts,
+                       nch, p, norms, loss);
+    PIT_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pit_rel_lp_loss_bwd(const float* tru, const float* pred, const float* pred_scale,
+                                   const float* pred_shift, int batch, int npts, int nch, int p,
+                                   const float* norms, const float* grad_loss, float* d_pred, void* stream) {
+    if (!tru || !pred || !norms || !d_pred) return PIT_ERR_NULL;
+    if (batch <= 0 || npts <= 0 || nch <= 0 || p < 1) return PIT_ERR_SIZE;
+    const long total = (long)batch * npts * nch;
+    const int blocks = (int)std::min<long>((total + 255) / 256, 2048L);
+    hipLaunchKernelGGL(rel_lp_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, tru, pred, pred_scale,
+                       pred_shift, batch, npts, nch, p, norms, grad_loss, d_pred);
+    PIT_CHECK_LAUNCH();
+    return 0;
+}

@@ -1,0 +1,551 @@
+// Fused position-attention kernels: distance -> head scale -> locality mask -> softmax
+// -> weighted-value reduction, forward and backward, for gfx950.
+//
+// The reference materialises the (b,H,N,J) attention tensor and runs ~8 elementwise
+// passes plus a row sort over it (pit.py:46-57, 133-144, 190-200, 248-258).  Here the
+// weights live only in registers: a wavefront forms a 32(row) x 2(key) slab of
+// P = exp(S_min - S)[S <= T] per v_mfma_f32_32x32x2_f32 and feeds it straight in as the
+// A operand; the value rows are the B operand, read coalesced (32 consecutive channels
+// per half-wave).  Thresholds T come from the order statistics of pit_select_fwd, the
+// row maximum of the logits is -c*m_min, so no online-softmax rescale is needed and the
+// sum is normalised once in the epilogue.
+//
+//   rows kernel  (MODE 0 forward, MODE 1 d(scale)): a workgroup owns 32 output rows of
+//       one head and a group of 32*CT value columns; its W waves split the key range
+//       and are reduced through LDS.  For batch-free meshes the batch is folded into
+//       the column axis, so P is formed once for all samples.
+//   cols kernel  (d values): a workgroup owns 32 KEYS and a column group; its waves
+//       split the (head, row) range: dU[j,:] = sum_{h,n} P[h,n,j] dO[n,h,:].
+//
+// d(scale) uses  dc_h = -sum_{n,col} dO[n,col] * sum_j P[n,j] (m[n,j]-mbar_n) U[j,col]
+// (SURVEY appendix B rearranged so that it is column-separable and centred:
+// mbar_n = sum_j P m is saved by the forward), accumulated in fp64.
+#include "pit_common.h"
+
+namespace {
+
+struct AttArgs {
+    const float* mesh_out; const float* mesh_in;
+    int mesh_batch, n_out, n_in, sdim, periodic, coords_used;
+    float period;
+    const float* values; int batch, dim; long ld_values, values_bstride;
+    const float* head; int n_head, head_is_scale;
+    const float* stats; float rank_w; int masked;
+    float* out; long ld_out, out_bstride; int out_col0, copy_inputs;
+    float* rowstat; float* scale_out;
+    const float* d_out; long ld_dout, dout_bstride;
+    float* d_values; long ld_dvalues, dvalues_bstride; int add_residual;
+    double* dscale_acc;
+    int ncols, colgroups;
+};
+
+constexpr int KEY_CHUNK = 2048;   // keys staged in LDS per pass (float4 each = 32 KiB)
+constexpr int ROW_CHUNK = 1024;   // row records staged per pass in the cols kernel (32 KiB)
+
+__device__ __forceinline__ float4 load_point4(const float* p, int used) {
+    float4 v;
+    v.x = p[0];
+    v.y = (used > 1) ? p[1] : 0.0f;
+    v.z = (used > 2) ? p[2] : 0.0f;
+    v.w = 0.0f;
+    return v;
+}
+
+// Tree-reduce the per-wave accumulators (and NX extra per-lane scalars) into wave 0.
+template <int CT, int NX>
+__device__ __forceinline__ void reduce_waves(f32x16 (&acc)[CT], float (&extra)[NX > 0 ? NX : 1], float* red,
+                                             int wave, int nwaves, int lane) {
+    constexpr int SLOT = (CT * 16 + NX) * 64;
+    for (int stride = nwaves >> 1; stride >= 1; stride >>= 1) {
+        if (wave >= stride && wave < 2 * stride) {
+            float* dst = red + (long)(wave - stride) * SLOT + lane;
+#pragma unroll
+            for (int t = 0; t < CT; ++t)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) dst[(t * 16 + i) * 64] = acc[t][i];
+#pragma unroll
+            for (int x = 0; x < NX; ++x) dst[(CT * 16 + x) * 64] = extra[x];
+        }
+        __syncthreads();
+        if (wave < stride) {
+            const float* src = red + (long)wave * SLOT + lane;
+#pragma unroll
+            for (int t = 0; t < CT; ++t)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[t][i] += src[(t * 16 + i) * 64];
+#pragma unroll
+            for (int x = 0; x < NX; ++x) extra[x] += src[(CT * 16 + x) * 64];
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// rows kernel
+// ------------------------------------------------------------------------------------
+template <int CT, int MODE, bool MASKED>
+__global__ __launch_bounds__(512) void posatt_rows_kernel(AttArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float4* s_xi = reinterpret_cast<float4*>(smem);
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int n0 = blockIdx.x * 32;
+    const int h = blockIdx.y;
+    const int mb = blockIdx.z / a.colgroups, cg = blockIdx.z % a.colgroups;
+    const long rows_total = (long)a.mesh_batch * a.n_out;
+
+    const float c = a.head_is_scale ? a.head[h] : head_scale_from_lmda(a.head[h]);
+
+    // ---- per-lane row constants (row = n0 + lane&31, both half-waves hold the same row)
+    const int n = n0 + l31;
+    const bool nvalid = n < a.n_out;
+    const long rowid = (long)mb * a.n_out + (nvalid ? n : a.n_out - 1);
+    const float4 xo = load_point4(a.mesh_out + rowid * a.sdim, a.coords_used);
+    float T = __builtin_inff(), s_min = 0.0f, inv_l = 0.0f, mbar = 0.0f;
+    if (MODE == 0) {
+        if (MASKED) {
+            const float sa = __fmul_rn(c, a.stats[rowid]);
+            const float sb = __fmul_rn(c, a.stats[rows_total + rowid]);
+            T = quantile_lerp(sa, sb, a.rank_w);
+        }
+        if (a.stats) s_min = __fmul_rn(c, a.stats[2 * rows_total + rowid]);
+    } else {
+        // backward: row constants saved by the forward {T, S_min, 1/rowsum, mbar}
+        const float4 rs4 = *reinterpret_cast<const float4*>(
+            a.rowstat + (((long)mb * a.n_head + h) * a.n_out + (nvalid ? n : a.n_out - 1)) * 4);
+        T = rs4.x; s_min = rs4.y; inv_l = rs4.z; mbar = rs4.w;
+    }
+
+    // ---- per-lane column constants
+    const float* ucol[CT];
+    bool cvalid[CT];
+    int cb[CT], cd[CT];
+#pragma unroll
+    for (int t = 0; t < CT; ++t) {
+        const int col = (cg * CT + t) * 32 + l31;
+        cvalid[t] = col < a.ncols;
+        const int cc = cvalid[t] ? col : 0;
+        cb[t] = (a.mesh_batch == 1) ? cc / a.dim : mb;
+        cd[t] = (a.mesh_batch == 1) ? cc % a.dim : cc;
+        ucol[t] = a.values + (long)cb[t] * a.values_bstride + cd[t];
+    }
+
+    f32x16 acc[CT];
+#pragma unroll
+    for (int t = 0; t < CT; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
+    float rsum = 0.0f, qsum = 0.0f;
+    const bool per = a.periodic != 0;
+
+    for (int jc0 = 0; jc0 < a.n_in; jc0 += KEY_CHUNK) {
+        const int len = min(KEY_CHUNK, a.n_in - jc0);
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < len; idx += blockDim.x)
+            s_xi[idx] = load_point4(a.mesh_in + ((long)mb * a.n_in + jc0 + idx) * a.sdim, a.coords_used);
+        __syncthreads();
+        // this wave's slice of the chunk (multiple of 8 keys)
+        const int per_wave = ((len + nwaves * 8 - 1) / (nwaves * 8)) * 8;
+        const int jb = wave * per_wave;
+        const int je = min(len, jb + per_wave);
+        if (jb >= je) continue;
+
+        float bnext[4][CT];
+        if (!MASKED) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int jl = jb + 2 * u + half;
+                const bool jv = jl < je;
+                const long jrow = jc0 + (jv ? jl : jb);
+#pragma unroll
+                for (int t = 0; t < CT; ++t) {
+                    const float v = ucol[t][jrow * a.ld_values];
+                    bnext[u][t] = (jv && cvalid[t]) ? v : 0.0f;
+                }
+            }
+        }
+        for (int jj = jb; jj < je; jj += 8) {
+            float bcur[4][CT];
+            if (!MASKED) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int t = 0; t < CT; ++t) bcur[u][t] = bnext[u][t];
+                // prefetch the next 8 keys (clamped, unconditional: keeps the loads in
+                // flight across this iteration's MFMAs)
+                const int jn = jj + 8;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int jl = jn + 2 * u + half;
+                    const bool jv = jl < je;
+                    const long jrow = jc0 + (jv ? jl : jb);
+#pragma unroll
+                    for (int t = 0; t < CT; ++t) {
+                        const float v = ucol[t][jrow * a.ld_values];
+                        bnext[u][t] = (jv && cvalid[t]) ? v : 0.0f;
+                    }
+                }
+            }
+            float pw[4];
+            bool anyk = false;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int jl = jj + 2 * u + half;
+                const bool jv = jl < je;
+                const float4 xi = s_xi[jv ? jl : jb];
+                const float m = sq_dist3(xo.x, xo.y, xo.z, xi.x, xi.y, xi.z, per, a.period);
+                const float s = __fmul_rn(m, c);
+                const bool keep = jv && nvalid && (s <= T);
+                const float p = keep ? __expf(s_min - s) : 0.0f;
+                if (MODE == 0) {
+                    rsum += p;
+                    qsum += p * m;
+                    pw[u] = p;
+                } else {
+                    pw[u] = p * (m - mbar) * inv_l;
+                }
+                anyk |= keep;
+            }
+            if (MASKED) {
+                if (__builtin_amdgcn_ballot_w64(anyk) == 0ull) continue;   // wave-uniform skip
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int jl = jj + 2 * u + half;
+                    const bool jv = jl < je;
+                    const long jrow = jc0 + (jv ? jl : jb);
+#pragma unroll
+                    for (int t = 0; t < CT; ++t) {
+                        const float v = ucol[t][jrow * a.ld_values];
+                        bcur[u][t] = (jv && cvalid[t]) ? v : 0.0f;
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int t = 0; t < CT; ++t) acc[t] = mfma_32x32x2(pw[u], bcur[u][t], acc[t]);
+        }
+    }
+
+    if (MODE == 1) {
+        // dc_h -= sum acc[n,col] * dO[n,col]   (fp64 accumulation)
+        double part = 0.0;
+#pragma unroll
+        for (int t = 0; t < CT; ++t) {
+            const float* dcol = a.d_out + (long)cb[t] * a.dout_bstride + a.out_col0 + (long)h * a.dim + cd[t];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int nr = n0 + acc_row(i, half);
+                if (cvalid[t] && nr < a.n_out) part += (double)acc[t][i] * (double)dcol[(long)nr * a.ld_dout];
+            }
+        }
+        part = wave_sum_d(part);
+        if (lane == 0) atomicAdd(a.dscale_acc + h, -part);
+        return;
+    }
+
+    // ---- forward epilogue: reduce waves, normalise, store
+    float extra[2];
+    extra[0] = rsum + __shfl_xor(rsum, 32);
+    extra[1] = qsum + __shfl_xor(qsum, 32);
+    __syncthreads();
+    reduce_waves<CT, 2>(acc, extra, reinterpret_cast<float*>(smem), wave, nwaves, lane);
+    if (wave != 0) return;
+    const float inv = extra[0] > 0.0f ? 1.0f / extra[0] : 0.0f;
+    float inv_row[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) inv_row[i] = __shfl(inv, acc_row(i, half));
+#pragma unroll
+    for (int t = 0; t < CT; ++t) {
+        float* ocol = a.out + (long)cb[t] * a.out_bstride + a.out_col0 + (long)h * a.dim + cd[t];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int nr = n0 + acc_row(i, half);
+            if (cvalid[t] && nr < a.n_out) ocol[(long)nr * a.ld_out] = acc[t][i] * inv_row[i];
+        }
+    }
+    if (a.copy_inputs && h == 0) {       // torch.cat((inputs, conv), -1) of pit.py:44
+#pragma unroll
+        for (int t = 0; t < CT; ++t) {
+            float* icol = a.out + (long)cb[t] * a.out_bstride + cd[t];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int nr = n0 + acc_row(i, half);
+                if (cvalid[t] && nr < a.n_out) icol[(long)nr * a.ld_out] = ucol[t][(long)nr * a.ld_values];
+            }
+        }
+    }
+    if (cg == 0 && half == 0 && nvalid) {
+        float4 st; st.x = T; st.y = s_min; st.z = inv; st.w = extra[1] * inv;
+        *reinterpret_cast<float4*>(a.rowstat + (((long)mb * a.n_head + h) * a.n_out + n) * 4) = st;
+    }
+    if (a.scale_out && blockIdx.x == 0 && blockIdx.z == 0 && lane == 0) a.scale_out[h] = c;
+}
+
+// ------------------------------------------------------------------------------------
+// cols kernel: d values
+// ------------------------------------------------------------------------------------
+template <int CT, bool MASKED>
+__global__ __launch_bounds__(512) void posatt_cols_kernel(AttArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float4* s_rec = reinterpret_cast<float4*>(smem);     // [ROW_CHUNK][2]: {xo.xyz, T}, {S_min, 1/L, -, -}
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int j0 = blockIdx.x * 32;
+    const int cg = blockIdx.y;
+    const int mb = blockIdx.z;
+
+    const int j = j0 + l31;
+    const bool jvalid = j < a.n_in;
+    const float4 xi = load_point4(a.mesh_in + ((long)mb * a.n_in + (jvalid ? j : a.n_in - 1)) * a.sdim, a.coords_used);
+
+    const float* dcol[CT];
+    bool cvalid[CT];
+    int cb[CT], cd[CT];
+#pragma unroll
+    for (int t = 0; t < CT; ++t) {
+        const int col = (cg * CT + t) * 32 + l31;
+        cvalid[t] = col < a.ncols;
+        const int cc = cvalid[t] ? col : 0;
+        cb[t] = (a.mesh_batch == 1) ? cc / a.dim : mb;
+        cd[t] = (a.mesh_batch == 1) ? cc % a.dim : cc;
+        dcol[t] = a.d_out + (long)cb[t] * a.dout_bstride + a.out_col0 + cd[t];
+    }
+    f32x16 acc[CT];
+#pragma unroll
+    for (int t = 0; t < CT; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
+    const bool per = a.periodic != 0;
+
+    for (int h = 0; h < a.n_head; ++h) {
+        const float c = a.head_is_scale ? a.head[h] : head_scale_from_lmda(a.head[h]);
+        const long hoff = (long)h * a.dim;
+        for (int nc0 = 0; nc0 < a.n_out; nc0 += ROW_CHUNK) {
+            const int len = min(ROW_CHUNK, a.n_out - nc0);
+            __syncthreads();
+            for (int idx = threadIdx.x; idx < len; idx += blockDim.x) {
+                const long rowid = (long)mb * a.n_out + nc0 + idx;
+                const float4 xo = load_point4(a.mesh_out + rowid * a.sdim, a.coords_used);
+                const float4 rs4 = *reinterpret_cast<const float4*>(
+                    a.rowstat + (((long)mb * a.n_head + h) * a.n_out + nc0 + idx) * 4);
+                float4 r0; r0.x = xo.x; r0.y = xo.y; r0.z = xo.z; r0.w = rs4.x;
+                float4 r1; r1.x = rs4.y; r1.y = rs4.z; r1.z = 0.0f; r1.w = 0.0f;
+                s_rec[2 * idx] = r0;
+                s_rec[2 * idx + 1] = r1;
+            }
+            __syncthreads();
+            const int per_wave = ((len + nwaves * 8 - 1) / (nwaves * 8)) * 8;
+            const int nb = wave * per_wave;
+            const int ne = min(len, nb + per_wave);
+            for (int nn = nb; nn < ne; nn += 8) {
+                float pw[4];
+                bool anyk = false;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int nl = nn + 2 * u + half;
+                    const bool nv = nl < ne;
+                    const float4 r0 = s_rec[2 * (nv ? nl : nb)];
+                    const float4 r1 = s_rec[2 * (nv ? nl : nb) + 1];
+                    const float m = sq_dist3(r0.x, r0.y, r0.z, xi.x, xi.y, xi.z, per, a.period);
+                    const float s = __fmul_rn(m, c);
+                    const bool keep = nv && jvalid && (s <= r0.w);
+                    pw[u] = keep ? __expf(r1.x - s) * r1.y : 0.0f;
+                    anyk |= keep;
+                }
+                if (MASKED && __builtin_amdgcn_ballot_w64(anyk) == 0ull) continue;
+                float bv[4][CT];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int nl = nn + 2 * u + half;
+                    const bool nv = nl < ne;
+                    const long nrow = nc0 + (nv ? nl : nb);
+#pragma unroll
+                    for (int t = 0; t < CT; ++t) {
+                        const float v = dcol[t][nrow * a.ld_dout + hoff];
+                        bv[u][t] = (nv && cvalid[t]) ? v : 0.0f;
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int t = 0; t < CT; ++t) acc[t] = mfma_32x32x2(pw[u], bv[u][t], acc[t]);
+            }
+        }
+    }
+    float extra[1] = {0.0f};
+    __syncthreads();
+    reduce_waves<CT, 0>(acc, extra, reinterpret_cast<float*>(smem), wave, nwaves, lane);
+    if (wave != 0) return;
+#pragma unroll
+    for (int t = 0; t < CT; ++t) {
+        float* gcol = a.d_values + (long)cb[t] * a.dvalues_bstride + cd[t];
+        const float* rcol = a.d_out + (long)cb[t] * a.dout_bstride + cd[t];   // residual: columns [0,dim)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int jr = j0 + acc_row(i, half);
+            if (cvalid[t] && jr < a.n_in) {
+                float v = acc[t][i];
+                if (a.add_residual) v += rcol[(long)jr * a.ld_dout];
+                gcol[(long)jr * a.ld_dvalues] = v;
+            }
+        }
+    }
+}
+
+__global__ void posatt_dhead_finish(const double* acc, const float* head, int n_head, int head_is_scale,
+                                    float* d_head) {
+    const int h = blockIdx.x * blockDim.x + threadIdx.x;
+    if (h >= n_head) return;
+    double g = acc[h];
+    if (!head_is_scale) {
+        const float lm = head[h];
+        g *= head_scale_grad(lm, head_scale_from_lmda(lm));
+    }
+    d_head[h] = (float)g;
+}
+
+int pow2_floor(int v) { int p = 1; while (p * 2 <= v) p *= 2; return p; }
+
+// column-tile count per workgroup: least padding, then enough workgroups to cover the chip
+int choose_ct(int ncols, long other_wgs) {
+    int best = 4;
+    long best_pad = -1;
+    for (int ct = 4; ct >= 1; ct >>= 1) {
+        const long pad = ((ncols + 32 * ct - 1) / (32 * ct)) * 32L * ct;
+        if (best_pad < 0 || pad < best_pad) { best_pad = pad; best = ct; }
+    }
+    while (best > 1 && other_wgs * ((ncols + 32 * best - 1) / (32 * best)) < 256) best >>= 1;
+    return best;
+}
+
+size_t rows_smem(int ct, int nwaves, int n_in) {
+    const size_t stage = (size_t)min(KEY_CHUNK, n_in) * sizeof(float4);
+    const size_t red = (size_t)(nwaves / 2) * (ct * 16 + 2) * 64 * sizeof(float);
+    return stage > red ? stage : red;
+}
+size_t cols_smem(int ct, int nwaves, int n_out) {
+    const size_t stage = (size_t)min(ROW_CHUNK, n_out) * 2 * sizeof(float4);
+    const size_t red = (size_t)(nwaves / 2) * (ct * 16) * 64 * sizeof(float);
+    return stage > red ? stage : red;
+}
+
+template <int MODE>
+void launch_rows(const AttArgs& a0, hipStream_t s) {
+    AttArgs a = a0;
+    const int n_tiles = (a.n_out + 31) / 32;
+    const int ct = choose_ct(a.ncols, (long)n_tiles * a.n_head * a.mesh_batch);
+    a.colgroups = (a.ncols + 32 * ct - 1) / (32 * ct);
+    const int nwaves = max(1, min(ct == 4 ? 4 : 8, pow2_floor(a.n_in / 64)));   // LDS reduce buffer <= 64 KiB
+    dim3 grid(n_tiles, a.n_head, a.mesh_batch * a.colgroups), block(64 * nwaves);
+    const size_t sm = rows_smem(ct, nwaves, a.n_in);
+#define PIT_ROWS(CT_)                                                                                  \
+    do {                                                                                               \
+        if (a.masked) hipLaunchKernelGGL((posatt_rows_kernel<CT_, MODE, true>), grid, block, sm, s, a); \
+        else hipLaunchKernelGGL((posatt_rows_kernel<CT_, MODE, false>), grid, block, sm, s, a);        \
+    } while (0)
+    if (ct == 4) PIT_ROWS(4);
+    else if (ct == 2) PIT_ROWS(2);
+    else PIT_ROWS(1);
+#undef PIT_ROWS
+}
+
+void launch_cols(const AttArgs& a0, hipStream_t s) {
+    AttArgs a = a0;
+    const int j_tiles = (a.n_in + 31) / 32;
+    const int ct = choose_ct(a.ncols, (long)j_tiles * a.mesh_batch);
+    a.colgroups = (a.ncols + 32 * ct - 1) / (32 * ct);
+    const int nwaves = max(1, min(ct == 4 ? 4 : 8, pow2_floor(a.n_out / 64)));
+    dim3 grid(j_tiles, a.colgroups, a.mesh_batch), block(64 * nwaves);
+    const size_t sm = cols_smem(ct, nwaves, a.n_out);
+#define PIT_COLS(CT_)                                                                             \
+    do {                                                                                          \
+        if (a.masked) hipLaunchKernelGGL((posatt_cols_kernel<CT_, true>), grid, block, sm, s, a);  \
+        else hipLaunchKernelGGL((posatt_cols_kernel<CT_, false>), grid, block, sm, s, a);         \
+    } while (0)
+    if (ct == 4) PIT_COLS(4);
+    else if (ct == 2) PIT_COLS(2);
+    else PIT_COLS(1);
+#undef PIT_COLS
+}
+
+int fill_common(AttArgs& a, const float* mesh_out, const float* mesh_in, int mesh_batch, int n_out, int n_in,
+                int space_dim, int metric, float period, const float* values, int batch, int dim,
+                long ld_values, long values_bstride, const float* head, int n_head, int head_is_scale) {
+    if (!mesh_out || !mesh_in || !values || !head) return PIT_ERR_NULL;
+    if (mesh_batch <= 0 || n_out <= 0 || n_in <= 0 || batch <= 0 || dim <= 0 || n_head <= 0) return PIT_ERR_SIZE;
+    if (space_dim < 1 || space_dim > 3) return PIT_ERR_SIZE;
+    if (metric < PIT_METRIC_EUCLID || metric > PIT_METRIC_PERIODIC2D) return PIT_ERR_METRIC;
+    if (mesh_batch != 1 && mesh_batch != batch) return PIT_ERR_SIZE;
+    if (n_head > 65535 || (long)batch * dim > 0x7fffffffL) return PIT_ERR_UNSUPPORTED;
+    a = AttArgs();
+    a.mesh_out = mesh_out; a.mesh_in = mesh_in; a.mesh_batch = mesh_batch; a.n_out = n_out; a.n_in = n_in;
+    a.sdim = space_dim; a.periodic = (metric != PIT_METRIC_EUCLID);
+    a.coords_used = (metric == PIT_METRIC_PERIODIC1D) ? 1 : space_dim;
+    a.period = period;
+    a.values = values; a.batch = batch; a.dim = dim; a.ld_values = ld_values; a.values_bstride = values_bstride;
+    a.head = head; a.n_head = n_head; a.head_is_scale = head_is_scale;
+    a.ncols = (mesh_batch == 1) ? batch * dim : dim;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int pit_posatt_fwd(const float* mesh_out, const float* mesh_in, int mesh_batch, int n_out, int n_in,
+                              int space_dim, int metric, float period,
+                              const float* values, int batch, int dim, long ld_values, long values_bstride,
+                              const float* head, int n_head, int head_is_scale,
+                              const float* stats, float rank_w, int masked, int self_attn,
+                              float* out, long ld_out, long out_bstride, int out_col0, int copy_inputs,
+                              float* rowstat, float* scale_out, void* stream) {
+    AttArgs a;
+    int rc = fill_common(a, mesh_out, mesh_in, mesh_batch, n_out, n_in, space_dim, metric, period, values, batch,
+                         dim, ld_values, values_bstride, head, n_head, head_is_scale);
+    if (rc) return rc;
+    if (!out || !rowstat) return PIT_ERR_NULL;
+    if (!stats && (masked || !self_attn)) return PIT_ERR_NULL;
+    if (copy_inputs && n_out != n_in) return PIT_ERR_SIZE;
+    a.stats = stats; a.rank_w = rank_w; a.masked = masked;
+    a.out = out; a.ld_out = ld_out; a.out_bstride = out_bstride; a.out_col0 = out_col0; a.copy_inputs = copy_inputs;
+    a.rowstat = rowstat; a.scale_out = scale_out;
+    launch_rows<0>(a, (hipStream_t)stream);
+    PIT_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pit_posatt_bwd(const float* mesh_out, const float* mesh_in, int mesh_batch, int n_out, int n_in,
+                              int space_dim, int metric, float period,
+                              const float* values, int batch, int dim, long ld_values, long values_bstride,
+                              const float* head, int n_head, int head_is_scale,
+                              const float* rowstat, int masked,
+                              const float* d_out, long ld_dout, long dout_bstride, int out_col0,
+                              float* d_values, long ld_dvalues, long dvalues_bstride, int add_residual,
+                              float* d_head, double* workspace, void* stream) {
+    AttArgs a;
+    int rc = fill_common(a, mesh_out, mesh_in, mesh_batch, n_out, n_in, space_dim, metric, period, values, batch,
+                         dim, ld_values, values_bstride, head, n_head, head_is_scale);
+    if (rc) return rc;
+    if (!rowstat || !d_out || !workspace) return PIT_ERR_NULL;
+    if (add_residual && n_out != n_in) return PIT_ERR_SIZE;
+    hipStream_t s = (hipStream_t)stream;
+    a.masked = masked; a.rowstat = const_cast<float*>(rowstat);
+    a.d_out = d_out; a.ld_dout = ld_dout; a.dout_bstride = dout_bstride; a.out_col0 = out_col0;
+    a.d_values = d_values; a.ld_dvalues = ld_dvalues; a.dvalues_bstride = dvalues_bstride;
+    a.add_residual = add_residual; a.dscale_acc = workspace;
+    if (d_head) {
+        hipError_t e = hipMemsetAsync(workspace, 0, sizeof(double) * n_head, s);
+        if (e != hipSuccess) return (int)e;
+        launch_rows<1>(a, s);
+        PIT_CHECK_LAUNCH();
+        hipLaunchKernelGGL(posatt_dhead_finish, dim3((n_head + 63) / 64), dim3(64), 0, s, workspace, head, n_head,
+                           head_is_scale, d_head);
+        PIT_CHECK_LAUNCH();
+    }
+    if (d_values) {
+        launch_cols(a, s);
+        PIT_CHECK_LAUNCH();
+    }
+    return 0;
+}

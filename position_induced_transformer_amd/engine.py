@@ -1,0 +1,67 @@
+"""Sync-free training step: forward -> RelLp loss -> backward -> (grad all-reduce) -> (Adam),
+captured once into a hipGraph and replayed.
+
+The reference loop calls ``loss.item()`` every step and creates tensors inside forward
+(train_darcy.py:124-134, pit.py:50), both capture-hostile; here the loss stays on the
+device, every launch goes to the capture stream through the C ABI, and the gradients live
+in one flat buffer (ddp.FlatGradients) so a data-parallel step is ONE all-reduce.
+"""
+from __future__ import annotations
+
+from typing import Optional, Sequence
+
+import torch
+
+from . import ops
+from .ddp import FlatGradients
+
+
+class TrainStep:
+    def __init__(self, model: torch.nn.Module, batch: Sequence[torch.Tensor], out_dim: int, p: int,
+                 pred_affine: Optional[Sequence[torch.Tensor]] = None, all_reduce: bool = False,
+                 optimizer: Optional[torch.optim.Optimizer] = None, flat: Optional[FlatGradients] = None):
+        self.model = model
+        self.mesh_in, self.func_in, self.mesh_out, self.target = batch
+        self.out_dim, self.p = out_dim, p
+        self.affine = pred_affine
+        self.all_reduce = all_reduce
+        self.optimizer = optimizer
+        self.flat = flat if flat is not None else FlatGradients(model.parameters())
+        self.loss = torch.zeros((), device=self.func_in.device)
+        self.graph: Optional[torch.cuda.CUDAGraph] = None
+
+    def _step(self) -> None:
+        self.flat.zero_()
+        out = self.model(self.mesh_in, self.func_in, self.mesh_out)
+        sc, sh = self.affine if self.affine is not None else (None, None)
+        loss = ops.rel_lp_loss(self.target, out, self.out_dim, self.p, sc, sh)
+        loss.backward()
+        self.loss.copy_(loss.detach())
+        if self.all_reduce:
+            self.flat.all_reduce()
+        if self.optimizer is not None:
+            self.optimizer.step()
+
+    def run_eager(self) -> None:
+        self._step()
+
+    def capture(self, warmup: int = 3) -> None:
+        """Warm up on a side stream (allocator + mesh-plan caches), then capture."""
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self._step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self._step()
+
+    def replay(self) -> None:
+        self.graph.replay()
+
+    def set_batch(self, func_in: torch.Tensor, target: torch.Tensor) -> None:
+        """Copy a new batch into the captured static buffers."""
+        self.func_in.copy_(func_in)
+        self.target.copy_(target)

@@ -1,0 +1,290 @@
+"""Host-side operators of the PiT hot path: thin autograd wrappers over the C ABI.
+
+Each wrapper allocates outputs / workspaces with torch (caller-owned memory, see
+include/pit_hip.h), launches on torch's current HIP stream and never synchronises, so a
+whole training step can be captured into a hipGraph (torch.cuda.graph).  There is no
+CPU or eager-PyTorch path: tensors must live on the GPU and the shared library must load.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+
+METRIC_ID = {"euclid": 0, "periodic1d": 1, "periodic2d": 2}
+
+
+def _need_gpu(*tensors) -> None:
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("position_induced_transformer_amd: the PiT hot path runs on the HIP device only; "
+                               "got a CPU tensor (move the model and its inputs to 'cuda')")
+        if t is not None and t.dtype != torch.float32:
+            raise RuntimeError(f"position_induced_transformer_amd: fp32 tensors expected, got {t.dtype}")
+
+
+def quantile_rank(locality: float, n_in: int):
+    """(k, w) of torch.quantile's linear interpolation in ATen's fp32 arithmetic
+    (SURVEY appendix A.3): rank = fl32(q)*fl32(n-1), k = floor(rank), w = rank - k."""
+    rank = np.float32(locality) * np.float32(n_in - 1)
+    k = int(np.floor(rank))
+    w = np.float32(rank - np.float32(k))
+    return k, float(w)
+
+
+def mesh_period(metric: str, mesh_in: torch.Tensor) -> float:
+    """Period of the periodic metrics, evaluated with the reference's own torch ops
+    (pit.py:190-191 / 248-250).  One host sync; callers cache it per mesh."""
+    if metric == "periodic1d":
+        return float(torch.abs(mesh_in[1, 0] - mesh_in[0, 0]) * mesh_in.shape[0])
+    if metric == "periodic2d":
+        res = int(mesh_in.shape[0] ** 0.5)
+        dx = (torch.max(mesh_in[:, 0]) - torch.min(mesh_in[:, 0])) / (res - 1)
+        return float(dx * res)
+    return 0.0
+
+
+class MeshPlan:
+    """Everything about a (mesh_out, mesh_in, metric, locality) pair that does not depend on
+    lmda: contiguous 3-d meshes, period, quantile rank and the selection statistics
+    (m_(k), m_(k+1), m_min per row).  Fixed meshes build it once and reuse it every step."""
+
+    __slots__ = ("mesh_out", "mesh_in", "mesh_batch", "n_out", "n_in", "sdim", "metric", "metric_id", "period",
+                 "rank_k", "rank_w", "masked", "self_attn", "stats")
+
+    def __init__(self, metric: str, mesh_out: torch.Tensor, mesh_in: torch.Tensor, locality: float,
+                 self_attn: bool, period: Optional[float] = None):
+        _need_gpu(mesh_out, mesh_in)
+        if metric not in METRIC_ID:
+            raise ValueError(f"unknown metric {metric!r}")
+        if mesh_out.dim() != mesh_in.dim() or mesh_out.dim() not in (2, 3):
+            raise RuntimeError(f"mesh shapes {tuple(mesh_out.shape)} / {tuple(mesh_in.shape)} not supported")
+        if mesh_out.shape[-1] != mesh_in.shape[-1]:
+            raise RuntimeError("mesh_out and mesh_in must have the same number of coordinates")
+        batched = mesh_out.dim() == 3
+        if batched and metric != "euclid":
+            raise RuntimeError("periodic metrics are defined for batch-free meshes only (pit.py:186-258)")
+        if batched and mesh_out.shape[0] != mesh_in.shape[0]:
+            raise RuntimeError("batched meshes must share the batch size")
+        self.metric = metric
+        self.metric_id = METRIC_ID[metric]
+        self.mesh_out = mesh_out.detach().contiguous()
+        self.mesh_in = self.mesh_out if (self_attn and mesh_in is mesh_out) else mesh_in.detach().contiguous()
+        self.mesh_batch = mesh_out.shape[0] if batched else 1
+        self.n_out, self.n_in, self.sdim = mesh_out.shape[-2], mesh_in.shape[-2], mesh_out.shape[-1]
+        if not 1 <= self.sdim <= 3:
+            raise RuntimeError("space_dim must be 1, 2 or 3")
+        self.period = mesh_period(metric, self.mesh_in) if period is None else float(period)
+        self.rank_k, self.rank_w = quantile_rank(locality, self.n_in)
+        self.masked = bool(locality < 1.0)
+        self.self_attn = bool(self_attn)
+        self.stats = None
+        if self.masked or not self.self_attn:
+            self.stats = torch.empty((3, self.mesh_batch, self.n_out), device=mesh_out.device, dtype=torch.float32)
+            rc = _lib.lib().pit_select_fwd(self.mesh_out.data_ptr(), self.mesh_in.data_ptr(), self.mesh_batch,
+                                           self.n_out, self.n_in, self.sdim, self.metric_id, self.period,
+                                           self.rank_k, 1 if self.masked else 0, self.stats.data_ptr(),
+                                           _lib.stream_ptr())
+            _lib.check(rc, "pit_select_fwd")
+
+
+def _row_view(t: torch.Tensor) -> torch.Tensor:
+    """(b, L, D) tensor with unit channel stride (copy only if it is not already so)."""
+    if t.dim() != 3:
+        raise RuntimeError(f"expected a (batch, points, channels) tensor, got {tuple(t.shape)}")
+    if t.stride(2) != 1 or t.stride(1) < t.shape[2]:
+        t = t.contiguous()
+    return t
+
+
+class _PosAtt(torch.autograd.Function):
+    """dist2att + convolution (+ the self-attention concat) as one op."""
+
+    @staticmethod
+    def forward(ctx, values, head, plan: MeshPlan, n_head: int, concat: bool, head_is_scale: bool):
+        _need_gpu(values, head)
+        values = _row_view(values)
+        b, j, d = values.shape
+        if j != plan.n_in:
+            raise RuntimeError(f"inputs have {j} points but mesh_in has {plan.n_in}")
+        if plan.mesh_batch not in (1, b):
+            raise RuntimeError("mesh batch and input batch differ")
+        head = head.detach().reshape(-1).contiguous()
+        if head.numel() != n_head:
+            raise RuntimeError("lmda must hold one value per head")
+        width = (n_head + (1 if concat else 0)) * d
+        out = torch.empty((b, plan.n_out, width), device=values.device, dtype=torch.float32)
+        rowstat = torch.empty((plan.mesh_batch, n_head, plan.n_out, 4), device=values.device, dtype=torch.float32)
+        scale = torch.empty((n_head,), device=values.device, dtype=torch.float32)
+        rc = _lib.lib().pit_posatt_fwd(
+            plan.mesh_out.data_ptr(), plan.mesh_in.data_ptr(), plan.mesh_batch, plan.n_out, plan.n_in, plan.sdim,
+            plan.metric_id, plan.period,
+            values.data_ptr(), b, d, values.stride(1), values.stride(0),
+            head.data_ptr(), n_head, 1 if head_is_scale else 0,
+            _lib.ptr(plan.stats), plan.rank_w, 1 if plan.masked else 0, 1 if plan.self_attn else 0,
+            out.data_ptr(), out.stride(1), out.stride(0), d if concat else 0, 1 if concat else 0,
+            rowstat.data_ptr(), scale.data_ptr(), _lib.stream_ptr())
+        _lib.check(rc, "pit_posatt_fwd")
+        ctx.plan, ctx.n_head, ctx.concat, ctx.head_is_scale = plan, n_head, concat, head_is_scale
+        ctx.head_shape = None
+        ctx.save_for_backward(values, head, rowstat)
+        ctx.scale = scale
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        values, head, rowstat = ctx.saved_tensors
+        plan, n_head, concat = ctx.plan, ctx.n_head, ctx.concat
+        b, j, d = values.shape
+        d_out = _row_view(d_out)
+        need_v, need_h = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        d_values = torch.empty((b, j, d), device=values.device, dtype=torch.float32) if need_v else None
+        d_head = torch.empty((n_head,), device=values.device, dtype=torch.float32) if need_h else None
+        work = torch.empty((n_head,), device=values.device, dtype=torch.float64)
+        rc = _lib.lib().pit_posatt_bwd(
+            plan.mesh_out.data_ptr(), plan.mesh_in.data_ptr(), plan.mesh_batch, plan.n_out, plan.n_in, plan.sdim,
+            plan.metric_id, plan.period,
+            values.data_ptr(), b, d, values.stride(1), values.stride(0),
+            head.data_ptr(), n_head, 1 if ctx.head_is_scale else 0,
+            rowstat.data_ptr(), 1 if plan.masked else 0,
+            d_out.data_ptr(), d_out.stride(1), d_out.stride(0), d if concat else 0,
+            _lib.ptr(d_values), d_values.stride(1) if need_v else 0, d_values.stride(0) if need_v else 0,
+            1 if concat else 0,
+            _lib.ptr(d_head), work.data_ptr(), _lib.stream_ptr())
+        _lib.check(rc, "pit_posatt_bwd")
+        return d_values, d_head, None, None, None, None
+
+
+def posatt_apply(values: torch.Tensor, lmda: torch.Tensor, plan: MeshPlan, n_head: int, concat: bool,
+                 head_is_scale: bool = False) -> torch.Tensor:
+    """out[b,n,h*D+d] = sum_j softmax_j(-c_h m[n,j] | quantile mask)[n,j] * values[b,j,d]
+    (pit.py:46-57); with ``concat`` the inputs are prepended (pit.py:44).  ``lmda`` is the
+    (H,1,1) parameter, or the scale c itself when ``head_is_scale`` (tests inject it)."""
+    out = _PosAtt.apply(values, lmda.reshape(-1), plan, n_head, concat, head_is_scale)
+    return out
+
+
+class _Mlp(torch.autograd.Function):
+    """kaiming_mlp forward/backward, optionally with the trailing gelu of pit.py:111,121."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, out_gelu: bool):
+        _need_gpu(x, w1, b1, w2, b2)
+        shape = x.shape
+        n0 = shape[-1]
+        x2 = x.reshape(-1, n0)
+        if x2.stride(1) != 1 or x2.stride(0) < n0:
+            x2 = x2.contiguous()
+        rows = x2.shape[0]
+        n1, n2 = w1.shape[0], w2.shape[0]
+        if w1.shape[1] != n0 or w2.shape[1] != n1:
+            raise RuntimeError(f"mlp shapes do not chain: x[...,{n0}], w1{tuple(w1.shape)}, w2{tuple(w2.shape)}")
+        w1c, b1c, w2c, b2c = (t.detach().contiguous() for t in (w1, b1, w2, b2))
+        dev = x.device
+        z1 = torch.empty((rows, n1), device=dev, dtype=torch.float32)
+        h = torch.empty((rows, n1), device=dev, dtype=torch.float32)
+        z2 = torch.empty((rows, n2), device=dev, dtype=torch.float32) if out_gelu else None
+        y = torch.empty((rows, n2), device=dev, dtype=torch.float32)
+        rc = _lib.lib().pit_mlp_fwd(x2.data_ptr(), x2.stride(0), rows, n0, n1, n2, w1c.data_ptr(), b1c.data_ptr(),
+                                    w2c.data_ptr(), b2c.data_ptr(), 1 if out_gelu else 0, z1.data_ptr(),
+                                    h.data_ptr(), _lib.ptr(z2), y.data_ptr(), y.stride(0), _lib.stream_ptr())
+        _lib.check(rc, "pit_mlp_fwd")
+        ctx.out_gelu, ctx.dims, ctx.in_shape = out_gelu, (rows, n0, n1, n2), shape
+        ctx.save_for_backward(x2, w1c, w2c, z1, h, z2 if out_gelu else z1)
+        return y.reshape(*shape[:-1], n2)
+
+    @staticmethod
+    def backward(ctx, d_y):
+        x2, w1, w2, z1, h, z2 = ctx.saved_tensors
+        rows, n0, n1, n2 = ctx.dims
+        dev = x2.device
+        d_y2 = d_y.reshape(rows, n2)
+        if d_y2.stride(1) != 1 or d_y2.stride(0) < n2:
+            d_y2 = d_y2.contiguous()
+        need_x = ctx.needs_input_grad[0]
+        d_x = torch.empty((rows, n0), device=dev, dtype=torch.float32) if need_x else None
+        d_w1 = torch.empty((n1, n0), device=dev, dtype=torch.float32)
+        d_b1 = torch.empty((n1,), device=dev, dtype=torch.float32)
+        d_w2 = torch.empty((n2, n1), device=dev, dtype=torch.float32)
+        d_b2 = torch.empty((n2,), device=dev, dtype=torch.float32)
+        scratch = torch.empty((rows * (n1 + n2),), device=dev, dtype=torch.float32)
+        rc = _lib.lib().pit_mlp_bwd(x2.data_ptr(), x2.stride(0), rows, n0, n1, n2, w1.data_ptr(), w2.data_ptr(),
+                                    z1.data_ptr(), h.data_ptr(), z2.data_ptr() if ctx.out_gelu else 0,
+                                    1 if ctx.out_gelu else 0, d_y2.data_ptr(), d_y2.stride(0),
+                                    _lib.ptr(d_x), n0, d_w1.data_ptr(), d_b1.data_ptr(), d_w2.data_ptr(),
+                                    d_b2.data_ptr(), scratch.data_ptr(), _lib.stream_ptr())
+        _lib.check(rc, "pit_mlp_bwd")
+        return (d_x.reshape(ctx.in_shape) if need_x else None), d_w1, d_b1, d_w2, d_b2, None
+
+
+def mlp_apply(x, w1, b1, w2, b2, out_gelu: bool = False) -> torch.Tensor:
+    return _Mlp.apply(x, w1, b1, w2, b2, out_gelu)
+
+
+class _RelLpLoss(torch.autograd.Function):
+    """RelLpNorm (utils.py:80-98), optionally fused with the per-pixel affine
+    de-normalisation of the prediction (utils.py:25-34)."""
+
+    @staticmethod
+    def forward(ctx, pred, true, out_dim: int, p: int, scale, shift):
+        _need_gpu(pred, true, scale, shift)
+        b = true.size(0)
+        t = true.reshape(b, -1, out_dim).contiguous()
+        q = pred.reshape(b, -1, out_dim).contiguous()
+        if t.shape != q.shape:
+            raise RuntimeError(f"true {tuple(true.shape)} and pred {tuple(pred.shape)} do not match")
+        npts = t.shape[1]
+        sc = scale.reshape(npts, out_dim).contiguous() if scale is not None else None
+        sh = shift.reshape(npts, out_dim).contiguous() if shift is not None else None
+        norms = torch.empty((b, out_dim, 2), device=t.device, dtype=torch.float32)
+        loss = torch.empty((), device=t.device, dtype=torch.float32)
+        rc = _lib.lib().pit_rel_lp_loss_fwd(t.data_ptr(), q.data_ptr(), _lib.ptr(sc), _lib.ptr(sh), b, npts,
+                                            out_dim, int(p), norms.data_ptr(), loss.data_ptr(), _lib.stream_ptr())
+        _lib.check(rc, "pit_rel_lp_loss_fwd")
+        ctx.meta = (b, npts, out_dim, int(p), pred.shape)
+        ctx.save_for_backward(t, q, norms, sc if sc is not None else norms, sh if sh is not None else norms)
+        ctx.affine = sc is not None
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        t, q, norms, sc, sh = ctx.saved_tensors
+        b, npts, out_dim, p, shape = ctx.meta
+        g = g.contiguous()
+        d_pred = torch.empty_like(q)
+        rc = _lib.lib().pit_rel_lp_loss_bwd(t.data_ptr(), q.data_ptr(), sc.data_ptr() if ctx.affine else 0,
+                                            sh.data_ptr() if ctx.affine else 0, b, npts, out_dim, p,
+                                            norms.data_ptr(), g.data_ptr(), d_pred.data_ptr(), _lib.stream_ptr())
+        _lib.check(rc, "pit_rel_lp_loss_bwd")
+        return d_pred.reshape(shape), None, None, None, None, None
+
+
+def rel_lp_loss(true, pred, out_dim: int, p: int, pred_scale=None, pred_shift=None) -> torch.Tensor:
+    """sum_b mean_c ||true - pred'||_p / ||true||_p with pred' = pred*pred_scale + pred_shift."""
+    return _RelLpLoss.apply(pred, true, out_dim, p, pred_scale, pred_shift)
+
+
+def head_scale(lmda: torch.Tensor) -> torch.Tensor:
+    """c = tan(0.25*pi*(1-1e-7)*(1+sin(lmda))) on device (pit.py:48)."""
+    _need_gpu(lmda)
+    flat = lmda.detach().reshape(-1).contiguous()
+    out = torch.empty_like(flat)
+    _lib.check(_lib.lib().pit_head_scale(flat.data_ptr(), flat.numel(), out.data_ptr(), _lib.stream_ptr()),
+               "pit_head_scale")
+    return out.reshape(lmda.shape)
+
+
+def debug_mfma_tile(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """D = A(32x8) @ B(8x32) through the kernels' MFMA fragment maps (layout self-test)."""
+    _need_gpu(a, b)
+    d = torch.empty((32, 32), device=a.device, dtype=torch.float32)
+    _lib.check(_lib.lib().pit_debug_mfma_tile(a.contiguous().data_ptr(), b.contiguous().data_ptr(), d.data_ptr(),
+                                              _lib.stream_ptr()), "pit_debug_mfma_tile")
+    return d
+
+
+_ = ctypes  # keep the import explicit: pointers cross the ABI as plain integers
