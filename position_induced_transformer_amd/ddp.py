@@ -39,7 +39,7 @@ class FlatGradients:
 
     def all_reduce(self, average: bool = False, group=None) -> None:
         """Sum (or average) the flat buffer over the ranks; no-op without a process group."""
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        if not (dist.is_available() and dist.is_initialized()):
             return
         dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
         if average:
