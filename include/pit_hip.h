@@ -76,10 +76,13 @@ int pit_posatt_fwd(const float* mesh_out, const float* mesh_in, int mesh_batch, 
 
 /* Backward of pit_posatt_fwd (closed form; the reference uses
  * autograd).  d_out has the layout of `out` (columns out_col0 + h*dim + d).
- *   d_values (batch, n_in, dim): written.  With add_residual=1 (self attention) the
- *            gradient of the copied inputs, d_out[b,j,0:dim], is added.
- *   d_head   n_head floats: gradient w.r.t. lmda (head_is_scale=0) or w.r.t. c (=1)
- *   workspace: n_head doubles (fp64 accumulators for d c), zeroed by this call. */
+ *   d_values (batch, n_in, dim): written (NULL = not needed).  With add_residual=1 (self
+ *            attention) the gradient of the copied inputs, d_out[b,j,0:dim], is added.
+ *   d_head   n_head floats (NULL = not needed): gradient w.r.t. lmda (head_is_scale=0) or
+ *            w.r.t. c (=1); accumulate_head=1 adds to the current contents instead of writing.
+ *   workspace: n_head doubles, fp64 accumulators for d c.  They must be ZERO on entry and
+ *            are left zero on exit (the finishing kernel clears what it consumed), so a
+ *            caller allocates and zeroes them once and no per-call memset is needed. */
 int pit_posatt_bwd(const float* mesh_out, const float* mesh_in, int mesh_batch, int n_out, int n_in,
                    int space_dim, int metric, float period,
                    const float* values, int batch, int dim, long ld_values, long values_bstride,
@@ -87,7 +90,7 @@ int pit_posatt_bwd(const float* mesh_out, const float* mesh_in, int mesh_batch, 
                    const float* rowstat, int masked,
                    const float* d_out, long ld_dout, long dout_bstride, int out_col0,
                    float* d_values, long ld_dvalues, long dvalues_bstride, int add_residual,
-                   float* d_head, double* workspace, void* stream);
+                   float* d_head, int accumulate_head, double* workspace, void* stream);
 
 /* kaiming_mlp.forward (pit.py:21-26): y = W2 * gelu_erf(W1 x + b1) + b2, optionally
  * followed by the trailing gelu of pit.py:111,121 (out_gelu=1).
@@ -99,14 +102,17 @@ int pit_mlp_fwd(const float* x, long ldx, int rows, int n0, int n1, int n2,
                 const float* w1, const float* b1, const float* w2, const float* b2, int out_gelu,
                 float* z1, float* h, float* z2, float* y, long ldy, void* stream);
 
-/* Backward of pit_mlp_fwd.  d_y (rows,n2) rows ld_dy apart.  d_x (rows,n0) rows ld_dx
- * apart (NULL = not needed).  d_w1,d_b1,d_w2,d_b2 are WRITTEN (zeroed here, then
- * accumulated with fp32 atomics over row slabs).  scratch: rows*(n1+n2) floats. */
+/* Backward of pit_mlp_fwd.  d_y (rows,n2) rows ld_dy apart (ld_dy == n2 when out_gelu).
+ * d_x (rows,n0) rows ld_dx apart (NULL = not needed).  d_w1,d_b1,d_w2,d_b2 receive the
+ * parameter gradients through fp32 atomics over row slabs: accumulate=0 zeroes them first
+ * (plain gradient), accumulate=1 adds into their current contents (e.g. the parameters'
+ * .grad inside a flat gradient buffer - no memset, no separate add).
+ * scratch: rows*(n1+n2) floats. */
 int pit_mlp_bwd(const float* x, long ldx, int rows, int n0, int n1, int n2,
                 const float* w1, const float* w2, const float* z1, const float* h, const float* z2,
                 int out_gelu, const float* d_y, long ld_dy,
                 float* d_x, long ld_dx, float* d_w1, float* d_b1, float* d_w2, float* d_b2,
-                float* scratch, void* stream);
+                int accumulate, float* scratch, void* stream);
 
 /* RelLpNorm (utils.py:80-98): loss = sum_b mean_c ||true - pred'||_p / ||true||_p with norms
  * over the point axis of (batch, npts, nch) contiguous tensors, pred' = pred*scale + shift when

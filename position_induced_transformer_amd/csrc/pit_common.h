@@ -74,6 +74,24 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
     return cdf + x * pdf;
 }
 
+// Raw buffer loads (T8): out-of-range offsets return 0 in hardware, so row / column / tail
+// predication costs an integer select on the OFFSET instead of a branch around the load
+// (hipcc otherwise sinks a predicated global load into an exec-masked block followed by
+// s_waitcnt vmcnt(0), which serialises every load of a prefetch group).
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ float buf_load(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+    return __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)byte_off, 0, 0));
+}
+__device__ __forceinline__ void buf_load4(__amdgpu_buffer_rsrc_t r, unsigned byte_off, float (&v)[4]) {
+    const i32x4 q = __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0);
+    v[0] = __int_as_float(q.x); v[1] = __int_as_float(q.y); v[2] = __int_as_float(q.z); v[3] = __int_as_float(q.w);
+}
+// largest tensor a 32-bit buffer offset can address (with slack for offset arithmetic)
+#define PIT_MAX_BUFFER_BYTES 0xF0000000ull
+
 #define PIT_CHECK_LAUNCH()                                   \
     do {                                                     \
         hipError_t e__ = hipGetLastError();                  \

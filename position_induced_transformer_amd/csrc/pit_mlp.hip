@@ -1,18 +1,27 @@
 // Pointwise MLP (kaiming_mlp, pit.py:13-26) forward and backward on fp32 MFMA.
 //
-// One LDS-tiled GEMM template (v_mfma_f32_32x32x2_f32, exact fp32 fma chains) with
-// strided operand views and fused epilogues covers every contraction of the layer:
+// One GEMM template (v_mfma_f32_32x32x2_f32, exact fp32 fma chains) with strided operand
+// views and fused prologue / epilogues covers every contraction of the layer:
 //   forward   Z1 = X W1^T + b1, H = gelu(Z1);   Y = H W2^T + b2 (optionally gelu, Z2 kept)
-//   backward  dZ1 = (dZ2 W2) * gelu'(Z1);  dX = dZ1 W1;
-//             dW2 = dZ2^T H, db2 = colsum(dZ2);  dW1 = dZ1^T X, db1 = colsum(dZ1)
-// The weight-gradient GEMMs reduce over the row axis: they are split over row slabs
-// (blockIdx.z) and accumulated with fp32 atomics; the bias gradient rides along as a
-// virtual all-ones column of the B operand.
+//   backward  dZ2 = dY * gelu'(Z2) (prologue, when the layer ends in a gelu)
+//             dZ1 = (dZ2 W2) * gelu'(Z1);  dX = dZ1 W1;
+//             dW2 += dZ2^T H, db2 += colsum(dZ2);  dW1 += dZ1^T X, db1 += colsum(dZ1)
 //
-// Tiles: both operands are staged k-major in LDS (As[k][m], Bs[k][n]) so a fragment read
-// is 32 consecutive floats per half-wave (conflict-free ds_read_b32); the next k-slab is
-// prefetched into registers while the current one feeds the MFMAs.
+// The PiT layers are small (rows 2k-80k, widths 1-768): at these sizes a GEMM is bound by
+// dependent-latency chains, not by MFMA rate, so the kernel is organised for memory-level
+// parallelism rather than operand reuse:
+//   * a workgroup owns one 32 x (32*TN) output tile and its W waves split the K range
+//     (in-workgroup split-K, LDS tree reduction at the end) - many short independent chains;
+//   * operand fragments go global -> registers directly in MFMA layout, 4 consecutive k per
+//     lane (one 16-B load when K is the contiguous axis, four coalesced 128-B row reads
+//     otherwise); the k order inside a step is permuted identically for A and B, which a
+//     contraction does not care about.  No LDS staging, no barrier in the main loop, so the
+//     compiler keeps several steps of loads in flight.
+// The weight-gradient GEMMs reduce over the row axis: additionally split over row slabs
+// (blockIdx.z) and accumulated with fp32 atomics straight into the destination (which may be
+// the parameter's .grad); the bias gradient rides along as a virtual all-ones B column.
 #include "pit_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -20,167 +29,203 @@ struct GemmArgs {
     const float* A; long a_rs, a_cs;     // A(m,k) = A[m*a_rs + k*a_cs]
     const float* B; long b_rs, b_cs;     // B(k,n) = B[k*b_rs + n*b_cs]
     int M, N, K;
+    unsigned a_bytes, b_bytes;           // extents for the raw-buffer descriptors
+    int a_vec, b_vec;                    // 16-B fragment loads legal (unit k stride, aligned rows)
     int k_slab;                          // K range per blockIdx.z
+    const float* a_gz;                   // optional prologue: A(m,k) *= gelu'(a_gz[same index as A])
+    float* a_out; long a_out_rs, a_out_cs;  // optional: write the prologue result (blockIdx.x == 0 only)
     const float* bias;                   // [N] or null
     float* C; long ldc;
     float* Z; long ldz;                  // optional pre-activation copy
     const float* G; long ldg;            // optional: multiply result by gelu'(G[m,n])
-    int act;                             // 1: C = gelu(.)
-    int atomic;                          // 1: atomicAdd into C / C2
+    int epi;                             // EPI_* epilogue flavour
+    int atomic;                          // 1: row-reducing GEMM, also split over blockIdx.z
     int ones_col;                        // >= 0: B(k, ones_col) == 1, that output column goes to C2[m]
     float* C2;
 };
 
-constexpr int BK = 16;
-
-template <int WM, int WN, int TM, int TN>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
-    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-    constexpr int LDA = BM + 1, LDB = BN + 1;
-    constexpr int RA = BM * BK / 256, RB = BN * BK / 256;
-    __shared__ float As[BK * LDA];
-    __shared__ float Bs[BK * LDB];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int half = lane >> 5, l31 = lane & 31;
-    const int wm = wave / WN, wn = wave % WN;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-    const int kbeg = blockIdx.z * g.k_slab;
-    const int kend = min(g.K, kbeg + g.k_slab);
-
-    const bool a_kfast = (g.a_cs == 1);     // k contiguous in memory -> k fastest over threads
-    const bool b_kfast = (g.b_rs == 1);
-
-    float ra[RA], rb[RB];
-    auto fetch = [&](int k0) {
-#pragma unroll
-        for (int r = 0; r < RA; ++r) {
-            const int e = tid + r * 256;
-            const int mm = a_kfast ? e / BK : e % BM;
-            const int kk = a_kfast ? e % BK : e / BM;
-            const int m = m0 + mm, k = k0 + kk;
-            ra[r] = (m < g.M && k < kend) ? g.A[(long)m * g.a_rs + (long)k * g.a_cs] : 0.0f;
-        }
-#pragma unroll
-        for (int r = 0; r < RB; ++r) {
-            const int e = tid + r * 256;
-            const int nn = b_kfast ? e / BK : e % BN;
-            const int kk = b_kfast ? e % BK : e / BN;
-            const int n = n0 + nn, k = k0 + kk;
-            float v = 0.0f;
-            if (n < g.N && k < kend) v = (n == g.ones_col) ? 1.0f : g.B[(long)k * g.b_rs + (long)n * g.b_cs];
-            rb[r] = v;
-        }
-    };
-    auto stash = [&]() {
-#pragma unroll
-        for (int r = 0; r < RA; ++r) {
-            const int e = tid + r * 256;
-            const int mm = a_kfast ? e / BK : e % BM;
-            const int kk = a_kfast ? e % BK : e / BM;
-            As[kk * LDA + mm] = ra[r];
-        }
-#pragma unroll
-        for (int r = 0; r < RB; ++r) {
-            const int e = tid + r * 256;
-            const int nn = b_kfast ? e / BK : e % BN;
-            const int kk = b_kfast ? e % BK : e / BN;
-            Bs[kk * LDB + nn] = rb[r];
-        }
-    };
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-
-    if (kbeg < kend) {
-        fetch(kbeg);
-        for (int k0 = kbeg; k0 < kend; k0 += BK) {
-            __syncthreads();
-            stash();
-            __syncthreads();
-            if (k0 + BK < kend) fetch(k0 + BK);
-#pragma unroll
-            for (int kk = 0; kk < BK; kk += 2) {
-                float af[TM], bf[TN];
-#pragma unroll
-                for (int i = 0; i < TM; ++i) af[i] = As[(kk + half) * LDA + (wm * TM + i) * 32 + l31];
-#pragma unroll
-                for (int j = 0; j < TN; ++j) bf[j] = Bs[(kk + half) * LDB + (wn * TN + j) * 32 + l31];
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) acc[i][j] = mfma_32x32x2(af[i], bf[j], acc[i][j]);
-            }
-        }
+// 4 k-values of one operand for this lane: X(i, kk+e), e = 0..3, through a raw buffer
+// (invalid i / k -> offset out of range -> 0).  VEC: one 16-B load (k is the unit-stride axis
+// and rows are 16-B aligned); FULL: the 4 k are known to be in range.
+template <bool FULL>
+__device__ __forceinline__ void load_frag(__amdgpu_buffer_rsrc_t r, unsigned bytes, unsigned ibase, bool ivalid,
+                                          unsigned kstride4, bool vec, int kk, int kend, float (&v)[4]) {
+    if (FULL && vec) {
+        buf_load4(r, ivalid ? ibase + (unsigned)kk * 4u : bytes, v);
+        return;
     }
-
-    // ---- epilogue
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int col = n0 + (wn * TN + j) * 32 + l31;
-            if (col >= g.N) continue;
-            const float bv = g.bias ? g.bias[col] : 0.0f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + (wm * TM + i) * 32 + acc_row(r, half);
-                if (row >= g.M) continue;
-                float v = acc[i][j][r] + bv;
-                if (g.Z) g.Z[(long)row * g.ldz + col] = v;
-                if (g.act) v = gelu_erf(v);
-                if (g.G) v *= gelu_erf_grad(g.G[(long)row * g.ldg + col]);
-                if (col == g.ones_col) {
-                    if (g.atomic) atomicAdd(g.C2 + row, v); else g.C2[row] = v;
-                } else {
-                    float* dst = g.C + (long)row * g.ldc + col;
-                    if (g.atomic) atomicAdd(dst, v); else *dst = v;
-                }
-            }
-        }
+    for (int e = 0; e < 4; ++e) {
+        const bool ok = ivalid && (FULL || kk + e < kend);
+        v[e] = buf_load(r, ok ? ibase + (unsigned)(kk + e) * kstride4 : bytes);
+    }
 }
 
-void launch_gemm(GemmArgs g, int target_wgs, hipStream_t s) {
-    // tile shape by output width
-    int bm, bn;
-    if (g.N > 64) { bm = 64; bn = 128; }
-    else if (g.N > 32) { bm = 64; bn = 64; }
-    else { bm = 128; bn = 32; }
-    const int tiles = ((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn);
-    int splits = 1;
-    if (g.atomic) {
-        splits = max(1, min((g.K + 4 * BK - 1) / (4 * BK), (target_wgs + tiles - 1) / tiles));
+// epilogue flavours (compile-time, so the per-element code is branch-free)
+constexpr int EPI_STORE = 0;      // C = acc
+constexpr int EPI_BIAS = 1;       // C = acc + bias
+constexpr int EPI_BIAS_GELU = 2;  // Z = acc + bias; C = gelu(Z)
+constexpr int EPI_MUL_GELU_GRAD = 3;  // C = acc * gelu'(G)
+constexpr int EPI_ATOMIC = 4;     // C += acc (fp32 atomics), ones column -> C2
+
+template <int TN, int EPI>
+__global__ __launch_bounds__(512) void gemm_rd_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) float red[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32 * TN;
+    const int kbeg = blockIdx.z * g.k_slab;
+    const int kend = min(g.K, kbeg + g.k_slab);
+    // this wave's k range: multiples of 8
+    const int span = kend - kbeg;
+    const int per_wave = ((span + nwaves * 8 - 1) / (nwaves * 8)) * 8;
+    const int wk0 = kbeg + wave * per_wave;
+    const int wk1 = min(kend, wk0 + per_wave);
+
+    const __amdgpu_buffer_rsrc_t ra = make_rsrc(g.A, g.a_bytes);
+    const __amdgpu_buffer_rsrc_t rz = make_rsrc(g.a_gz ? g.a_gz : g.A, g.a_bytes);
+    const __amdgpu_buffer_rsrc_t rb = make_rsrc(g.B, g.b_bytes);
+    const int m = m0 + l31;
+    const bool mvalid = m < g.M;
+    const unsigned abase = (unsigned)m * (unsigned)g.a_rs * 4u;
+    const unsigned akstride = (unsigned)g.a_cs * 4u, bkstride = (unsigned)g.b_rs * 4u;
+    int ncol[TN];
+    bool nvalid[TN], nones[TN];
+    unsigned bbase[TN];
+#pragma unroll
+    for (int t = 0; t < TN; ++t) {
+        ncol[t] = n0 + t * 32 + l31;
+        nones[t] = (EPI == EPI_ATOMIC) && ncol[t] == g.ones_col;
+        nvalid[t] = ncol[t] < g.N && !nones[t];
+        bbase[t] = (unsigned)ncol[t] * (unsigned)g.b_cs * 4u;
     }
+
+    f32x16 acc[TN];
+#pragma unroll
+    for (int t = 0; t < TN; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+
+    auto step = [&](int k0, auto full_tag) {
+        constexpr bool FULL = decltype(full_tag)::value;
+        const int kk = k0 + 4 * half;            // this half-wave's 4 k values
+        float av[4], bv[TN][4];
+        load_frag<FULL>(ra, g.a_bytes, abase, mvalid, akstride, g.a_vec != 0, kk, wk1, av);
+        if (g.a_gz) {
+            float zv[4];
+            load_frag<FULL>(rz, g.a_bytes, abase, mvalid, akstride, g.a_vec != 0, kk, wk1, zv);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) av[e] *= gelu_erf_grad(zv[e]);
+            if (g.a_out && blockIdx.x == 0 && mvalid) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (FULL || kk + e < wk1) g.a_out[(long)m * g.a_out_rs + (long)(kk + e) * g.a_out_cs] = av[e];
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < TN; ++t) {
+            load_frag<FULL>(rb, g.b_bytes, bbase[t], nvalid[t], bkstride, g.b_vec != 0, kk, wk1, bv[t]);
+            if (EPI == EPI_ATOMIC && nones[t]) {      // virtual all-ones column (bias gradient)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) bv[t][e] = (FULL || kk + e < wk1) ? 1.0f : 0.0f;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int t = 0; t < TN; ++t) acc[t] = mfma_32x32x2(av[e], bv[t][e], acc[t]);
+    };
+
+    int k0 = wk0;
+    for (; k0 + 16 <= wk1; k0 += 16) {           // two steps per trip: 4+ fragment loads in flight
+        step(k0, std::true_type{});
+        step(k0 + 8, std::true_type{});
+    }
+    if (k0 + 8 <= wk1) { step(k0, std::true_type{}); k0 += 8; }
+    if (k0 < wk1) step(k0, std::false_type{});
+
+    // ---- in-workgroup split-K reduction as a reduce-scatter through LDS: every wave parks its
+    // partial tile, then each wave sums and finishes its own share of the 16*TN accumulator
+    // registers, so the (erf-heavy) epilogue is spread over all waves and costs one barrier.
+    constexpr int NQ = TN * 16;
+    const int share = NQ / nwaves;               // nwaves in {1,2,4,8} divides 16
+    {
+        float* dst = red + (long)wave * NQ * 64 + lane;
+#pragma unroll
+        for (int t = 0; t < TN; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dst[(t * 16 + r) * 64] = acc[t][r];
+        __syncthreads();
+    }
+    const int q0 = wave * share;
+#pragma unroll 1
+    for (int qq = 0; qq < share; ++qq) {
+        const int q = q0 + qq;
+        const int t = q >> 4, r = q & 15;
+        float v = 0.0f;
+        for (int w = 0; w < nwaves; ++w) v += red[((long)w * NQ + q) * 64 + lane];
+        const int col = n0 + t * 32 + l31;
+        const int row = m0 + acc_row(r, half);
+        if (col >= g.N || row >= g.M) continue;
+        if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) v += g.bias[col];
+        if (EPI == EPI_BIAS_GELU) { g.Z[(long)row * g.ldz + col] = v; v = gelu_erf(v); }
+        if (EPI == EPI_MUL_GELU_GRAD) v *= gelu_erf_grad(g.G[(long)row * g.ldg + col]);
+        if (EPI == EPI_ATOMIC) {
+            if (col == g.ones_col) atomicAdd(g.C2 + row, v);
+            else atomicAdd(g.C + (long)row * g.ldc + col, v);
+        } else {
+            g.C[(long)row * g.ldc + col] = v;
+        }
+    }
+}
+
+int pow2_floor_i(int v) { int p = 1; while (p * 2 <= v) p *= 2; return p; }
+
+bool vec_ok(const float* p, long i_stride, long k_stride) {
+    return k_stride == 1 && (reinterpret_cast<uintptr_t>(p) & 15) == 0 && (i_stride % 4) == 0;
+}
+
+int launch_gemm(GemmArgs g, hipStream_t s) {
+    const unsigned long long ab = ((unsigned long long)(g.M - 1) * g.a_rs + (unsigned long long)(g.K - 1) * g.a_cs + 1) * 4ull;
+    const int nb_cols = (g.ones_col >= 0) ? g.N - 1 : g.N;       // the ones column is virtual
+    const unsigned long long bb = ((unsigned long long)(g.K - 1) * g.b_rs + (unsigned long long)(std::max(nb_cols, 1) - 1) * g.b_cs + 1) * 4ull;
+    if (ab > PIT_MAX_BUFFER_BYTES || bb > PIT_MAX_BUFFER_BYTES) return PIT_ERR_UNSUPPORTED;
+    g.a_bytes = (unsigned)ab; g.b_bytes = (unsigned)bb;
+    g.a_vec = vec_ok(g.A, g.a_rs, g.a_cs) && (!g.a_gz || vec_ok(g.a_gz, g.a_rs, g.a_cs));
+    g.b_vec = vec_ok(g.B, g.b_cs, g.b_rs);
+    // two column tiles per wave (A fragment reused) only when that still leaves plenty of workgroups
+    const int tn = (g.N > 32 && (long)((g.M + 31) / 32) * ((g.N + 63) / 64) >= 512) ? 2 : 1;
+    const int tiles = ((g.M + 31) / 32) * ((g.N + 32 * tn - 1) / (32 * tn));
+    // waves per workgroup: each wave wants >= 16 k; slabs over blockIdx.z only for the atomic
+    // (row-reducing) GEMMs, sized so the launch has a few hundred workgroups
+    int splits = 1;
+    if (g.atomic) splits = std::max(1, std::min((g.K + 127) / 128, (768 + tiles - 1) / tiles));
     int slab = (g.K + splits - 1) / splits;
-    slab = ((slab + BK - 1) / BK) * BK;
+    slab = ((slab + 7) / 8) * 8;
     splits = (g.K + slab - 1) / slab;
     g.k_slab = slab;
-    dim3 grid((g.N + bn - 1) / bn, (g.M + bm - 1) / bm, splits), block(256);
-    if (g.N > 64) hipLaunchKernelGGL((gemm_kernel<2, 2, 1, 2>), grid, block, 0, s, g);
-    else if (g.N > 32) hipLaunchKernelGGL((gemm_kernel<2, 2, 1, 1>), grid, block, 0, s, g);
-    else hipLaunchKernelGGL((gemm_kernel<4, 1, 1, 1>), grid, block, 0, s, g);
+    // >= 2 waves always: the reduce-scatter epilogue indexes the parked tile in LDS
+    const int nwaves = std::max(2, std::min(8, pow2_floor_i(slab / 16)));
+    dim3 grid((g.N + 32 * tn - 1) / (32 * tn), (g.M + 31) / 32, splits), block(64 * nwaves);
+    const size_t sm = (size_t)nwaves * tn * 16 * 64 * sizeof(float);
+#define PIT_GEMM(TN_, EPI_) hipLaunchKernelGGL((gemm_rd_kernel<TN_, EPI_>), grid, block, sm, s, g)
+#define PIT_GEMM_TN(EPI_) do { if (tn == 2) PIT_GEMM(2, EPI_); else PIT_GEMM(1, EPI_); } while (0)
+    switch (g.epi) {
+        case EPI_STORE: PIT_GEMM_TN(EPI_STORE); break;
+        case EPI_BIAS: PIT_GEMM_TN(EPI_BIAS); break;
+        case EPI_BIAS_GELU: PIT_GEMM_TN(EPI_BIAS_GELU); break;
+        case EPI_MUL_GELU_GRAD: PIT_GEMM_TN(EPI_MUL_GELU_GRAD); break;
+        default: PIT_GEMM_TN(EPI_ATOMIC); break;
+    }
+#undef PIT_GEMM_TN
+#undef PIT_GEMM
+    return 0;
 }
 
 GemmArgs blank() {
     GemmArgs g{};
     g.ones_col = -1;
     return g;
-}
-
-__global__ void gelu_bwd_kernel(const float* __restrict__ dy, long ld_dy, const float* __restrict__ z, int rows,
-                                int n, float* __restrict__ dz) {
-    const long total = (long)rows * n;
-    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-        const long r = e / n;
-        const int c = (int)(e - r * n);
-        dz[e] = dy[r * ld_dy + c] * gelu_erf_grad(z[e]);
-    }
 }
 
 }  // namespace
@@ -196,16 +241,16 @@ extern "C" int pit_mlp_fwd(const float* x, long ldx, int rows, int n0, int n1, i
     g.A = x; g.a_rs = ldx; g.a_cs = 1;
     g.B = w1; g.b_rs = 1; g.b_cs = n0;            // B(k,n) = w1[n][k]
     g.M = rows; g.N = n1; g.K = n0;
-    g.bias = b1; g.Z = z1; g.ldz = n1; g.act = 1; g.C = h; g.ldc = n1;
-    launch_gemm(g, 0, s);
+    g.bias = b1; g.Z = z1; g.ldz = n1; g.epi = EPI_BIAS_GELU; g.C = h; g.ldc = n1;
+    if (int rc = launch_gemm(g, s)) return rc;
     PIT_CHECK_LAUNCH();
     g = blank();
     g.A = h; g.a_rs = n1; g.a_cs = 1;
     g.B = w2; g.b_rs = 1; g.b_cs = n1;
     g.M = rows; g.N = n2; g.K = n1;
-    g.bias = b2; g.C = y; g.ldc = ldy;
-    if (out_gelu) { g.Z = z2; g.ldz = n2; g.act = 1; }
-    launch_gemm(g, 0, s);
+    g.bias = b2; g.C = y; g.ldc = ldy; g.epi = EPI_BIAS;
+    if (out_gelu) { g.Z = z2; g.ldz = n2; g.epi = EPI_BIAS_GELU; }
+    if (int rc = launch_gemm(g, s)) return rc;
     PIT_CHECK_LAUNCH();
     return 0;
 }
@@ -214,43 +259,41 @@ extern "C" int pit_mlp_bwd(const float* x, long ldx, int rows, int n0, int n1, i
                            const float* w1, const float* w2, const float* z1, const float* h, const float* z2,
                            int out_gelu, const float* d_y, long ld_dy,
                            float* d_x, long ld_dx, float* d_w1, float* d_b1, float* d_w2, float* d_b2,
-                           float* scratch, void* stream) {
+                           int accumulate, float* scratch, void* stream) {
     if (!x || !w1 || !w2 || !z1 || !h || !d_y || !d_w1 || !d_b1 || !d_w2 || !d_b2 || !scratch) return PIT_ERR_NULL;
     if (out_gelu && !z2) return PIT_ERR_NULL;
     if (rows <= 0 || n0 <= 0 || n1 <= 0 || n2 <= 0) return PIT_ERR_SIZE;
     hipStream_t s = (hipStream_t)stream;
     float* dz1 = scratch;                       // rows * n1
     float* dz2buf = scratch + (long)rows * n1;  // rows * n2
-    const float* dz2 = d_y;
-    long ld_dz2 = ld_dy;
-    if (out_gelu) {
-        const long total = (long)rows * n2;
-        const int blocks = (int)std::min<long>((total + 255) / 256, 2048L);
-        hipLaunchKernelGGL(gelu_bwd_kernel, dim3(blocks), dim3(256), 0, s, d_y, ld_dy, z2, rows, n2, dz2buf);
-        PIT_CHECK_LAUNCH();
-        dz2 = dz2buf; ld_dz2 = n2;
+    if (!accumulate) {
+        hipError_t e;
+        if ((e = hipMemsetAsync(d_w1, 0, sizeof(float) * (size_t)n1 * n0, s)) != hipSuccess) return (int)e;
+        if ((e = hipMemsetAsync(d_b1, 0, sizeof(float) * (size_t)n1, s)) != hipSuccess) return (int)e;
+        if ((e = hipMemsetAsync(d_w2, 0, sizeof(float) * (size_t)n2 * n1, s)) != hipSuccess) return (int)e;
+        if ((e = hipMemsetAsync(d_b2, 0, sizeof(float) * (size_t)n2, s)) != hipSuccess) return (int)e;
     }
-    hipError_t e;
-    if ((e = hipMemsetAsync(d_w1, 0, sizeof(float) * (size_t)n1 * n0, s)) != hipSuccess) return (int)e;
-    if ((e = hipMemsetAsync(d_b1, 0, sizeof(float) * (size_t)n1, s)) != hipSuccess) return (int)e;
-    if ((e = hipMemsetAsync(d_w2, 0, sizeof(float) * (size_t)n2 * n1, s)) != hipSuccess) return (int)e;
-    if ((e = hipMemsetAsync(d_b2, 0, sizeof(float) * (size_t)n2, s)) != hipSuccess) return (int)e;
-
-    // dZ1 = (dZ2 W2) * gelu'(Z1)
+    // dZ1 = (dZ2 W2) * gelu'(Z1), with dZ2 = dY * gelu'(Z2) formed in the A prologue and kept
     GemmArgs g = blank();
-    g.A = dz2; g.a_rs = ld_dz2; g.a_cs = 1;
+    g.A = d_y; g.a_rs = ld_dy; g.a_cs = 1;
+    if (out_gelu) {
+        if (ld_dy != n2) return PIT_ERR_SIZE;     // prologue reads z2 with d_y's indexing
+        g.a_gz = z2; g.a_out = dz2buf; g.a_out_rs = n2; g.a_out_cs = 1;
+    }
     g.B = w2; g.b_rs = n1; g.b_cs = 1;            // B(k,n) = w2[k][n]
     g.M = rows; g.N = n1; g.K = n2;
-    g.G = z1; g.ldg = n1; g.C = dz1; g.ldc = n1;
-    launch_gemm(g, 0, s);
+    g.G = z1; g.ldg = n1; g.C = dz1; g.ldc = n1; g.epi = EPI_MUL_GELU_GRAD;
+    if (int rc = launch_gemm(g, s)) return rc;
     PIT_CHECK_LAUNCH();
-    // dW2 = dZ2^T H (+ db2 as the ones column)
+    const float* dz2 = out_gelu ? dz2buf : d_y;
+    const long ld_dz2 = out_gelu ? n2 : ld_dy;
+    // dW2 += dZ2^T H (+ db2 as the ones column)
     g = blank();
     g.A = dz2; g.a_rs = 1; g.a_cs = ld_dz2;        // A(m,k) = dz2[k][m]
     g.B = h; g.b_rs = n1; g.b_cs = 1;
     g.M = n2; g.N = n1 + 1; g.K = rows; g.ones_col = n1;
-    g.C = d_w2; g.ldc = n1; g.C2 = d_b2; g.atomic = 1;
-    launch_gemm(g, 512, s);
+    g.C = d_w2; g.ldc = n1; g.C2 = d_b2; g.atomic = 1; g.epi = EPI_ATOMIC;
+    if (int rc = launch_gemm(g, s)) return rc;
     PIT_CHECK_LAUNCH();
     // dX = dZ1 W1
     if (d_x) {
@@ -258,17 +301,17 @@ extern "C" int pit_mlp_bwd(const float* x, long ldx, int rows, int n0, int n1, i
         g.A = dz1; g.a_rs = n1; g.a_cs = 1;
         g.B = w1; g.b_rs = n0; g.b_cs = 1;
         g.M = rows; g.N = n0; g.K = n1;
-        g.C = d_x; g.ldc = ld_dx;
-        launch_gemm(g, 0, s);
+        g.C = d_x; g.ldc = ld_dx; g.epi = EPI_STORE;
+        if (int rc = launch_gemm(g, s)) return rc;
         PIT_CHECK_LAUNCH();
     }
-    // dW1 = dZ1^T X (+ db1)
+    // dW1 += dZ1^T X (+ db1)
     g = blank();
     g.A = dz1; g.a_rs = 1; g.a_cs = n1;
     g.B = x; g.b_rs = ldx; g.b_cs = 1;
     g.M = n1; g.N = n0 + 1; g.K = rows; g.ones_col = n0;
-    g.C = d_w1; g.ldc = n0; g.C2 = d_b1; g.atomic = 1;
-    launch_gemm(g, 512, s);
+    g.C = d_w1; g.ldc = n0; g.C2 = d_b1; g.atomic = 1; g.epi = EPI_ATOMIC;
+    if (int rc = launch_gemm(g, s)) return rc;
     PIT_CHECK_LAUNCH();
     return 0;
 }

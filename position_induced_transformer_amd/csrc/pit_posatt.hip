@@ -21,6 +21,7 @@
 // (SURVEY appendix B rearranged so that it is column-separable and centred:
 // mbar_n = sum_j P m is saved by the forward), accumulated in fp64.
 #include "pit_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -37,16 +38,20 @@ struct AttArgs {
     float* d_values; long ld_dvalues, dvalues_bstride; int add_residual;
     double* dscale_acc;
     int ncols, colgroups;
+    unsigned values_bytes, dout_bytes;    // extents for the raw-buffer descriptors
 };
 
 constexpr int KEY_CHUNK = 2048;   // keys staged in LDS per pass (float4 each = 32 KiB)
 constexpr int ROW_CHUNK = 1024;   // row records staged per pass in the cols kernel (32 KiB)
 
-__device__ __forceinline__ float4 load_point4(const float* p, int used) {
+// Point `idx` of a contiguous (n, sdim) mesh as (x, y, z, 0): coordinates beyond `used` read
+// as 0 through the buffer's range check (three independent loads, no branches).
+__device__ __forceinline__ float4 load_point4(__amdgpu_buffer_rsrc_t r, unsigned bytes, long idx, int sdim, int used) {
+    const unsigned base = (unsigned)(idx * sdim) * 4u;
     float4 v;
-    v.x = p[0];
-    v.y = (used > 1) ? p[1] : 0.0f;
-    v.z = (used > 2) ? p[2] : 0.0f;
+    v.x = buf_load(r, base);
+    v.y = buf_load(r, used > 1 ? base + 4u : bytes);
+    v.z = buf_load(r, used > 2 ? base + 8u : bytes);
     v.w = 0.0f;
     return v;
 }
@@ -101,7 +106,11 @@ __global__ __launch_bounds__(512) void posatt_rows_kernel(AttArgs a) {
     const int n = n0 + l31;
     const bool nvalid = n < a.n_out;
     const long rowid = (long)mb * a.n_out + (nvalid ? n : a.n_out - 1);
-    const float4 xo = load_point4(a.mesh_out + rowid * a.sdim, a.coords_used);
+    const unsigned mo_bytes = (unsigned)((long)a.mesh_batch * a.n_out * a.sdim * 4);
+    const unsigned mi_bytes = (unsigned)((long)a.mesh_batch * a.n_in * a.sdim * 4);
+    const __amdgpu_buffer_rsrc_t rmo = make_rsrc(a.mesh_out, mo_bytes);
+    const __amdgpu_buffer_rsrc_t rmi = make_rsrc(a.mesh_in, mi_bytes);
+    const float4 xo = load_point4(rmo, mo_bytes, rowid, a.sdim, a.coords_used);
     float T = __builtin_inff(), s_min = 0.0f, inv_l = 0.0f, mbar = 0.0f;
     if (MODE == 0) {
         if (MASKED) {
@@ -118,7 +127,10 @@ __global__ __launch_bounds__(512) void posatt_rows_kernel(AttArgs a) {
     }
 
     // ---- per-lane column constants
+    const __amdgpu_buffer_rsrc_t rvals = make_rsrc(a.values, a.values_bytes);
+    const unsigned ld4 = (unsigned)a.ld_values * 4u;
     const float* ucol[CT];
+    unsigned uoff[CT];                     // byte offset of this lane's column inside `values`
     bool cvalid[CT];
     int cb[CT], cd[CT];
 #pragma unroll
@@ -129,6 +141,7 @@ __global__ __launch_bounds__(512) void posatt_rows_kernel(AttArgs a) {
         cb[t] = (a.mesh_batch == 1) ? cc / a.dim : mb;
         cd[t] = (a.mesh_batch == 1) ? cc % a.dim : cc;
         ucol[t] = a.values + (long)cb[t] * a.values_bstride + cd[t];
+        uoff[t] = (unsigned)(((long)cb[t] * a.values_bstride + cd[t]) * 4);
     }
 
     f32x16 acc[CT];
@@ -139,65 +152,58 @@ __global__ __launch_bounds__(512) void posatt_rows_kernel(AttArgs a) {
     float rsum = 0.0f, qsum = 0.0f;
     const bool per = a.periodic != 0;
 
+    // Value rows for the NEXT step are always in flight while the current step computes its
+    // weights and MFMAs (the loads do not depend on the weights); a masked step whose 8 keys
+    // are all dropped only skips its MFMAs.  NP key pairs per step.
+    constexpr int NP = (CT == 4) ? 4 : 8;
+    float bnext[NP][CT];
+    auto prefetch = [&](int jc0, int jstart, int jb, int je) {
+        (void)jb;
+#pragma unroll
+        for (int u = 0; u < NP; ++u) {
+            const int jl = jstart + 2 * u + half;
+            const bool jv = jl < je;
+            const unsigned rowoff = (unsigned)(jc0 + jl) * ld4;
+#pragma unroll
+            for (int t = 0; t < CT; ++t)     // out-of-range offset -> hardware returns 0, no branch
+                bnext[u][t] = buf_load(rvals, (jv && cvalid[t]) ? uoff[t] + rowoff : a.values_bytes);
+        }
+    };
+
     for (int jc0 = 0; jc0 < a.n_in; jc0 += KEY_CHUNK) {
         const int len = min(KEY_CHUNK, a.n_in - jc0);
-        __syncthreads();
-        for (int idx = threadIdx.x; idx < len; idx += blockDim.x)
-            s_xi[idx] = load_point4(a.mesh_in + ((long)mb * a.n_in + jc0 + idx) * a.sdim, a.coords_used);
-        __syncthreads();
-        // this wave's slice of the chunk (multiple of 8 keys)
-        const int per_wave = ((len + nwaves * 8 - 1) / (nwaves * 8)) * 8;
+        // this wave's slice of the chunk (multiple of 2*NP keys)
+        const int per_wave = ((len + nwaves * 2 * NP - 1) / (nwaves * 2 * NP)) * 2 * NP;
         const int jb = wave * per_wave;
         const int je = min(len, jb + per_wave);
+        if (jb < je) prefetch(jc0, jb, jb, je);          // in flight during staging / barrier
+        __syncthreads();
+#pragma unroll 4
+        for (int idx = threadIdx.x; idx < len; idx += blockDim.x)
+            s_xi[idx] = load_point4(rmi, mi_bytes, (long)mb * a.n_in + jc0 + idx, a.sdim, a.coords_used);
+        __syncthreads();
         if (jb >= je) continue;
 
-        float bnext[4][CT];
-        if (!MASKED) {
+        for (int jj = jb; jj < je; jj += 2 * NP) {
+            float bcur[NP][CT];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int jl = jb + 2 * u + half;
-                const bool jv = jl < je;
-                const long jrow = jc0 + (jv ? jl : jb);
+            for (int u = 0; u < NP; ++u)
 #pragma unroll
-                for (int t = 0; t < CT; ++t) {
-                    const float v = ucol[t][jrow * a.ld_values];
-                    bnext[u][t] = (jv && cvalid[t]) ? v : 0.0f;
-                }
-            }
-        }
-        for (int jj = jb; jj < je; jj += 8) {
-            float bcur[4][CT];
-            if (!MASKED) {
+                for (int t = 0; t < CT; ++t) bcur[u][t] = bnext[u][t];
+            prefetch(jc0, jj + 2 * NP, jb, je);            // clamped, unconditional
+            float pw[NP];
+            bool anyk[NP / 4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u)
+            for (int q = 0; q < NP / 4; ++q) anyk[q] = false;
 #pragma unroll
-                    for (int t = 0; t < CT; ++t) bcur[u][t] = bnext[u][t];
-                // prefetch the next 8 keys (clamped, unconditional: keeps the loads in
-                // flight across this iteration's MFMAs)
-                const int jn = jj + 8;
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int jl = jn + 2 * u + half;
-                    const bool jv = jl < je;
-                    const long jrow = jc0 + (jv ? jl : jb);
-#pragma unroll
-                    for (int t = 0; t < CT; ++t) {
-                        const float v = ucol[t][jrow * a.ld_values];
-                        bnext[u][t] = (jv && cvalid[t]) ? v : 0.0f;
-                    }
-                }
-            }
-            float pw[4];
-            bool anyk = false;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < NP; ++u) {
                 const int jl = jj + 2 * u + half;
                 const bool jv = jl < je;
                 const float4 xi = s_xi[jv ? jl : jb];
                 const float m = sq_dist3(xo.x, xo.y, xo.z, xi.x, xi.y, xi.z, per, a.period);
-                const float s = __fmul_rn(m, c);
-                const bool keep = jv && nvalid && (s <= T);
-                const float p = keep ? __expf(s_min - s) : 0.0f;
+                const float sv = __fmul_rn(m, c);
+                const bool keep = jv && nvalid && (sv <= T);
+                const float p = keep ? __expf(s_min - sv) : 0.0f;
                 if (MODE == 0) {
                     rsum += p;
                     qsum += p * m;
@@ -205,41 +211,38 @@ __global__ __launch_bounds__(512) void posatt_rows_kernel(AttArgs a) {
                 } else {
                     pw[u] = p * (m - mbar) * inv_l;
                 }
-                anyk |= keep;
-            }
-            if (MASKED) {
-                if (__builtin_amdgcn_ballot_w64(anyk) == 0ull) continue;   // wave-uniform skip
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int jl = jj + 2 * u + half;
-                    const bool jv = jl < je;
-                    const long jrow = jc0 + (jv ? jl : jb);
-#pragma unroll
-                    for (int t = 0; t < CT; ++t) {
-                        const float v = ucol[t][jrow * a.ld_values];
-                        bcur[u][t] = (jv && cvalid[t]) ? v : 0.0f;
-                    }
-                }
+                anyk[u / 4] |= keep;
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+            for (int q = 0; q < NP / 4; ++q) {
+                if (MASKED && __builtin_amdgcn_ballot_w64(anyk[q]) == 0ull) continue;   // wave-uniform skip
 #pragma unroll
-                for (int t = 0; t < CT; ++t) acc[t] = mfma_32x32x2(pw[u], bcur[u][t], acc[t]);
+                for (int u = 4 * q; u < 4 * q + 4; ++u)
+#pragma unroll
+                    for (int t = 0; t < CT; ++t) acc[t] = mfma_32x32x2(pw[u], bcur[u][t], acc[t]);
+            }
         }
     }
 
     if (MODE == 1) {
-        // dc_h -= sum acc[n,col] * dO[n,col]   (fp64 accumulation)
-        double part = 0.0;
+        // dc_h -= sum acc[n,col] * dO[n,col]   (fp64 accumulation); all 16*CT loads in flight at once
+        const __amdgpu_buffer_rsrc_t rdo = make_rsrc(a.d_out, a.dout_bytes);
+        float dov[CT][16];
 #pragma unroll
         for (int t = 0; t < CT; ++t) {
-            const float* dcol = a.d_out + (long)cb[t] * a.dout_bstride + a.out_col0 + (long)h * a.dim + cd[t];
+            const unsigned cbase = (unsigned)(((long)cb[t] * a.dout_bstride + a.out_col0 + (long)h * a.dim + cd[t]) * 4);
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int nr = n0 + acc_row(i, half);
-                if (cvalid[t] && nr < a.n_out) part += (double)acc[t][i] * (double)dcol[(long)nr * a.ld_dout];
+                dov[t][i] = buf_load(rdo, (cvalid[t] && nr < a.n_out) ? cbase + (unsigned)nr * (unsigned)a.ld_dout * 4u
+                                                                      : a.dout_bytes);
             }
         }
+        double part = 0.0;
+#pragma unroll
+        for (int t = 0; t < CT; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) part += (double)acc[t][i] * (double)dov[t][i];
         part = wave_sum_d(part);
         if (lane == 0) atomicAdd(a.dscale_acc + h, -part);
         return;
@@ -268,11 +271,17 @@ __global__ __launch_bounds__(512) void posatt_rows_kernel(AttArgs a) {
     if (a.copy_inputs && h == 0) {       // torch.cat((inputs, conv), -1) of pit.py:44
 #pragma unroll
         for (int t = 0; t < CT; ++t) {
+            float iv[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int nr = n0 + acc_row(i, half);
+                iv[i] = buf_load(rvals, (cvalid[t] && nr < a.n_out) ? uoff[t] + (unsigned)nr * ld4 : a.values_bytes);
+            }
             float* icol = a.out + (long)cb[t] * a.out_bstride + cd[t];
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int nr = n0 + acc_row(i, half);
-                if (cvalid[t] && nr < a.n_out) icol[(long)nr * a.ld_out] = ucol[t][(long)nr * a.ld_values];
+                if (cvalid[t] && nr < a.n_out) icol[(long)nr * a.ld_out] = iv[i];
             }
         }
     }
@@ -299,9 +308,15 @@ __global__ __launch_bounds__(512) void posatt_cols_kernel(AttArgs a) {
 
     const int j = j0 + l31;
     const bool jvalid = j < a.n_in;
-    const float4 xi = load_point4(a.mesh_in + ((long)mb * a.n_in + (jvalid ? j : a.n_in - 1)) * a.sdim, a.coords_used);
+    const unsigned mo_bytes = (unsigned)((long)a.mesh_batch * a.n_out * a.sdim * 4);
+    const unsigned mi_bytes = (unsigned)((long)a.mesh_batch * a.n_in * a.sdim * 4);
+    const __amdgpu_buffer_rsrc_t rmo = make_rsrc(a.mesh_out, mo_bytes);
+    const __amdgpu_buffer_rsrc_t rmi = make_rsrc(a.mesh_in, mi_bytes);
+    const float4 xi = load_point4(rmi, mi_bytes, (long)mb * a.n_in + (jvalid ? j : a.n_in - 1), a.sdim, a.coords_used);
 
-    const float* dcol[CT];
+    const __amdgpu_buffer_rsrc_t rdout = make_rsrc(a.d_out, a.dout_bytes);
+    const unsigned ldd4 = (unsigned)a.ld_dout * 4u;
+    unsigned doff[CT];
     bool cvalid[CT];
     int cb[CT], cd[CT];
 #pragma unroll
@@ -311,7 +326,7 @@ __global__ __launch_bounds__(512) void posatt_cols_kernel(AttArgs a) {
         const int cc = cvalid[t] ? col : 0;
         cb[t] = (a.mesh_batch == 1) ? cc / a.dim : mb;
         cd[t] = (a.mesh_batch == 1) ? cc % a.dim : cc;
-        dcol[t] = a.d_out + (long)cb[t] * a.dout_bstride + a.out_col0 + cd[t];
+        doff[t] = (unsigned)(((long)cb[t] * a.dout_bstride + a.out_col0 + cd[t]) * 4);
     }
     f32x16 acc[CT];
 #pragma unroll
@@ -320,15 +335,35 @@ __global__ __launch_bounds__(512) void posatt_cols_kernel(AttArgs a) {
         for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
     const bool per = a.periodic != 0;
 
+    constexpr int NP = (CT == 4) ? 4 : 8;
+    float bnext[NP][CT];
+    auto prefetch = [&](long hoff, int nc0, int nstart, int nb, int ne) {
+        (void)nb;
+#pragma unroll
+        for (int u = 0; u < NP; ++u) {
+            const int nl = nstart + 2 * u + half;
+            const bool nv = nl < ne;
+            const unsigned rowoff = (unsigned)(nc0 + nl) * ldd4 + (unsigned)hoff * 4u;
+#pragma unroll
+            for (int t = 0; t < CT; ++t)
+                bnext[u][t] = buf_load(rdout, (nv && cvalid[t]) ? doff[t] + rowoff : a.dout_bytes);
+        }
+    };
+
     for (int h = 0; h < a.n_head; ++h) {
         const float c = a.head_is_scale ? a.head[h] : head_scale_from_lmda(a.head[h]);
         const long hoff = (long)h * a.dim;
         for (int nc0 = 0; nc0 < a.n_out; nc0 += ROW_CHUNK) {
             const int len = min(ROW_CHUNK, a.n_out - nc0);
+            const int per_wave = ((len + nwaves * 2 * NP - 1) / (nwaves * 2 * NP)) * 2 * NP;
+            const int nb = wave * per_wave;
+            const int ne = min(len, nb + per_wave);
+            if (nb < ne) prefetch(hoff, nc0, nb, nb, ne);
             __syncthreads();
+#pragma unroll 2
             for (int idx = threadIdx.x; idx < len; idx += blockDim.x) {
                 const long rowid = (long)mb * a.n_out + nc0 + idx;
-                const float4 xo = load_point4(a.mesh_out + rowid * a.sdim, a.coords_used);
+                const float4 xo = load_point4(rmo, mo_bytes, rowid, a.sdim, a.coords_used);
                 const float4 rs4 = *reinterpret_cast<const float4*>(
                     a.rowstat + (((long)mb * a.n_head + h) * a.n_out + nc0 + idx) * 4);
                 float4 r0; r0.x = xo.x; r0.y = xo.y; r0.z = xo.z; r0.w = rs4.x;
@@ -337,41 +372,37 @@ __global__ __launch_bounds__(512) void posatt_cols_kernel(AttArgs a) {
                 s_rec[2 * idx + 1] = r1;
             }
             __syncthreads();
-            const int per_wave = ((len + nwaves * 8 - 1) / (nwaves * 8)) * 8;
-            const int nb = wave * per_wave;
-            const int ne = min(len, nb + per_wave);
-            for (int nn = nb; nn < ne; nn += 8) {
-                float pw[4];
-                bool anyk = false;
+            for (int nn = nb; nn < ne; nn += 2 * NP) {
+                float bcur[NP][CT];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < NP; ++u)
+#pragma unroll
+                    for (int t = 0; t < CT; ++t) bcur[u][t] = bnext[u][t];
+                prefetch(hoff, nc0, nn + 2 * NP, nb, ne);
+                float pw[NP];
+                bool anyk[NP / 4];
+#pragma unroll
+                for (int q = 0; q < NP / 4; ++q) anyk[q] = false;
+#pragma unroll
+                for (int u = 0; u < NP; ++u) {
                     const int nl = nn + 2 * u + half;
                     const bool nv = nl < ne;
                     const float4 r0 = s_rec[2 * (nv ? nl : nb)];
                     const float4 r1 = s_rec[2 * (nv ? nl : nb) + 1];
                     const float m = sq_dist3(r0.x, r0.y, r0.z, xi.x, xi.y, xi.z, per, a.period);
-                    const float s = __fmul_rn(m, c);
-                    const bool keep = nv && jvalid && (s <= r0.w);
-                    pw[u] = keep ? __expf(r1.x - s) * r1.y : 0.0f;
-                    anyk |= keep;
-                }
-                if (MASKED && __builtin_amdgcn_ballot_w64(anyk) == 0ull) continue;
-                float bv[4][CT];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int nl = nn + 2 * u + half;
-                    const bool nv = nl < ne;
-                    const long nrow = nc0 + (nv ? nl : nb);
-#pragma unroll
-                    for (int t = 0; t < CT; ++t) {
-                        const float v = dcol[t][nrow * a.ld_dout + hoff];
-                        bv[u][t] = (nv && cvalid[t]) ? v : 0.0f;
-                    }
+                    const float sv = __fmul_rn(m, c);
+                    const bool keep = nv && jvalid && (sv <= r0.w);
+                    pw[u] = keep ? __expf(r1.x - sv) * r1.y : 0.0f;
+                    anyk[u / 4] |= keep;
                 }
 #pragma unroll
-                for (int u = 0; u < 4; ++u)
+                for (int q = 0; q < NP / 4; ++q) {
+                    if (MASKED && __builtin_amdgcn_ballot_w64(anyk[q]) == 0ull) continue;
 #pragma unroll
-                    for (int t = 0; t < CT; ++t) acc[t] = mfma_32x32x2(pw[u], bv[u][t], acc[t]);
+                    for (int u = 4 * q; u < 4 * q + 4; ++u)
+#pragma unroll
+                        for (int t = 0; t < CT; ++t) acc[t] = mfma_32x32x2(pw[u], bcur[u][t], acc[t]);
+                }
             }
         }
     }
@@ -382,32 +413,43 @@ __global__ __launch_bounds__(512) void posatt_cols_kernel(AttArgs a) {
 #pragma unroll
     for (int t = 0; t < CT; ++t) {
         float* gcol = a.d_values + (long)cb[t] * a.dvalues_bstride + cd[t];
-        const float* rcol = a.d_out + (long)cb[t] * a.dout_bstride + cd[t];   // residual: columns [0,dim)
+        // residual (self attention): d_out columns [0,dim) of the same row
+        const unsigned rbase = (unsigned)(((long)cb[t] * a.dout_bstride + cd[t]) * 4);
+        float rv[16];
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int jr = j0 + acc_row(i, half);
-            if (cvalid[t] && jr < a.n_in) {
-                float v = acc[t][i];
-                if (a.add_residual) v += rcol[(long)jr * a.ld_dout];
-                gcol[(long)jr * a.ld_dvalues] = v;
-            }
+            rv[i] = buf_load(rdout, (a.add_residual && cvalid[t] && jr < a.n_in) ? rbase + (unsigned)jr * ldd4
+                                                                                 : a.dout_bytes);
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int jr = j0 + acc_row(i, half);
+            if (cvalid[t] && jr < a.n_in) gcol[(long)jr * a.ld_dvalues] = acc[t][i] + rv[i];
         }
     }
 }
 
-__global__ void posatt_dhead_finish(const double* acc, const float* head, int n_head, int head_is_scale,
-                                    float* d_head) {
+__global__ void posatt_dhead_finish(double* acc, const float* head, int n_head, int head_is_scale,
+                                    int accumulate, float* d_head) {
     const int h = blockIdx.x * blockDim.x + threadIdx.x;
     if (h >= n_head) return;
     double g = acc[h];
+    acc[h] = 0.0;                 // leave the accumulators clean for the next call
     if (!head_is_scale) {
         const float lm = head[h];
         g *= head_scale_grad(lm, head_scale_from_lmda(lm));
     }
-    d_head[h] = (float)g;
+    d_head[h] = accumulate ? d_head[h] + (float)g : (float)g;
 }
 
 int pow2_floor(int v) { int p = 1; while (p * 2 <= v) p *= 2; return p; }
+
+// tuning overrides for experiments (tools/microbench.py): PIT_FORCE_CT, PIT_FORCE_WAVES
+int env_int(const char* name) {
+    const char* v = getenv(name);
+    return v ? atoi(v) : 0;
+}
 
 // column-tile count per workgroup: least padding, then enough workgroups to cover the chip
 int choose_ct(int ncols, long other_wgs) {
@@ -436,9 +478,11 @@ template <int MODE>
 void launch_rows(const AttArgs& a0, hipStream_t s) {
     AttArgs a = a0;
     const int n_tiles = (a.n_out + 31) / 32;
-    const int ct = choose_ct(a.ncols, (long)n_tiles * a.n_head * a.mesh_batch);
+    int ct = choose_ct(a.ncols, (long)n_tiles * a.n_head * a.mesh_batch);
+    if (int f = env_int("PIT_FORCE_CT")) ct = f;
     a.colgroups = (a.ncols + 32 * ct - 1) / (32 * ct);
-    const int nwaves = max(1, min(ct == 4 ? 4 : 8, pow2_floor(a.n_in / 64)));   // LDS reduce buffer <= 64 KiB
+    int nwaves = max(1, min(ct == 4 ? 4 : 8, pow2_floor(a.n_in / 64)));   // LDS reduce buffer <= 64 KiB
+    if (int f = env_int("PIT_FORCE_WAVES")) nwaves = min(f, ct == 4 ? 4 : 8);
     dim3 grid(n_tiles, a.n_head, a.mesh_batch * a.colgroups), block(64 * nwaves);
     const size_t sm = rows_smem(ct, nwaves, a.n_in);
 #define PIT_ROWS(CT_)                                                                                  \
@@ -455,9 +499,11 @@ void launch_rows(const AttArgs& a0, hipStream_t s) {
 void launch_cols(const AttArgs& a0, hipStream_t s) {
     AttArgs a = a0;
     const int j_tiles = (a.n_in + 31) / 32;
-    const int ct = choose_ct(a.ncols, (long)j_tiles * a.mesh_batch);
+    int ct = choose_ct(a.ncols, (long)j_tiles * a.mesh_batch);
+    if (int f = env_int("PIT_FORCE_CT")) ct = f;
     a.colgroups = (a.ncols + 32 * ct - 1) / (32 * ct);
-    const int nwaves = max(1, min(ct == 4 ? 4 : 8, pow2_floor(a.n_out / 64)));
+    int nwaves = max(1, min(ct == 4 ? 4 : 8, pow2_floor(a.n_out / 64)));
+    if (int f = env_int("PIT_FORCE_WAVES")) nwaves = min(f, ct == 4 ? 4 : 8);
     dim3 grid(j_tiles, a.colgroups, a.mesh_batch), block(64 * nwaves);
     const size_t sm = cols_smem(ct, nwaves, a.n_out);
 #define PIT_COLS(CT_)                                                                             \
@@ -488,6 +534,10 @@ int fill_common(AttArgs& a, const float* mesh_out, const float* mesh_in, int mes
     a.values = values; a.batch = batch; a.dim = dim; a.ld_values = ld_values; a.values_bstride = values_bstride;
     a.head = head; a.n_head = n_head; a.head_is_scale = head_is_scale;
     a.ncols = (mesh_batch == 1) ? batch * dim : dim;
+    const unsigned long long vb = ((unsigned long long)(batch - 1) * values_bstride +
+                                   (unsigned long long)(n_in - 1) * ld_values + dim) * 4ull;
+    if (vb > PIT_MAX_BUFFER_BYTES) return PIT_ERR_UNSUPPORTED;
+    a.values_bytes = (unsigned)vb;
     return 0;
 }
 
@@ -522,7 +572,7 @@ extern "C" int pit_posatt_bwd(const float* mesh_out, const float* mesh_in, int m
                               const float* rowstat, int masked,
                               const float* d_out, long ld_dout, long dout_bstride, int out_col0,
                               float* d_values, long ld_dvalues, long dvalues_bstride, int add_residual,
-                              float* d_head, double* workspace, void* stream) {
+                              float* d_head, int accumulate_head, double* workspace, void* stream) {
     AttArgs a;
     int rc = fill_common(a, mesh_out, mesh_in, mesh_batch, n_out, n_in, space_dim, metric, period, values, batch,
                          dim, ld_values, values_bstride, head, n_head, head_is_scale);
@@ -534,13 +584,18 @@ extern "C" int pit_posatt_bwd(const float* mesh_out, const float* mesh_in, int m
     a.d_out = d_out; a.ld_dout = ld_dout; a.dout_bstride = dout_bstride; a.out_col0 = out_col0;
     a.d_values = d_values; a.ld_dvalues = ld_dvalues; a.dvalues_bstride = dvalues_bstride;
     a.add_residual = add_residual; a.dscale_acc = workspace;
+    {
+        const int width = out_col0 + n_head * dim;
+        const unsigned long long db = ((unsigned long long)(batch - 1) * dout_bstride +
+                                       (unsigned long long)(n_out - 1) * ld_dout + width) * 4ull;
+        if (db > PIT_MAX_BUFFER_BYTES) return PIT_ERR_UNSUPPORTED;
+        a.dout_bytes = (unsigned)db;
+    }
     if (d_head) {
-        hipError_t e = hipMemsetAsync(workspace, 0, sizeof(double) * n_head, s);
-        if (e != hipSuccess) return (int)e;
         launch_rows<1>(a, s);
         PIT_CHECK_LAUNCH();
         hipLaunchKernelGGL(posatt_dhead_finish, dim3((n_head + 63) / 64), dim3(64), 0, s, workspace, head, n_head,
-                           head_is_scale, d_head);
+                           head_is_scale, accumulate_head, d_head);
         PIT_CHECK_LAUNCH();
     }
     if (d_values) {

@@ -17,6 +17,35 @@ from . import _lib
 
 METRIC_ID = {"euclid": 0, "periodic1d": 1, "periodic2d": 2}
 
+# When a parameter already owns a contiguous fp32 ``.grad`` (e.g. a view into
+# ddp.FlatGradients' buffer, or after ``zero_grad(set_to_none=False)``) the backward kernels
+# accumulate straight into it and autograd receives ``None`` for that input: no memset of a
+# temporary, no separate ``grad += tmp`` launch.  Set to False to always return gradients.
+FUSED_GRAD_ACCUMULATION = True
+
+_DSCALE_WS = {}
+
+
+def _dscale_workspace(device, n_head: int) -> torch.Tensor:
+    """fp64 accumulators for d(scale): zero on entry and left zero by pit_posatt_bwd, so one
+    zeroed buffer per device serves every layer (launches are stream-ordered)."""
+    key = device.index
+    ws = _DSCALE_WS.get(key)
+    if ws is None or ws.numel() < n_head:
+        ws = torch.zeros(max(64, n_head), device=device, dtype=torch.float64)
+        _DSCALE_WS[key] = ws
+    return ws
+
+
+def _grad_slot(param) -> Optional[torch.Tensor]:
+    """The parameter's own .grad if the kernels may accumulate into it in place."""
+    if not FUSED_GRAD_ACCUMULATION or param is None:
+        return None
+    g = getattr(param, "grad", None)
+    if g is None or not g.is_cuda or g.dtype != torch.float32 or not g.is_contiguous():
+        return None
+    return g
+
 
 def _need_gpu(*tensors) -> None:
     for t in tensors:
@@ -105,7 +134,8 @@ class _PosAtt(torch.autograd.Function):
     """dist2att + convolution (+ the self-attention concat) as one op."""
 
     @staticmethod
-    def forward(ctx, values, head, plan: MeshPlan, n_head: int, concat: bool, head_is_scale: bool):
+    def forward(ctx, values, head, plan: MeshPlan, n_head: int, concat: bool, head_is_scale: bool,
+                head_param=None):
         _need_gpu(values, head)
         values = _row_view(values)
         b, j, d = values.shape
@@ -130,7 +160,7 @@ class _PosAtt(torch.autograd.Function):
             rowstat.data_ptr(), scale.data_ptr(), _lib.stream_ptr())
         _lib.check(rc, "pit_posatt_fwd")
         ctx.plan, ctx.n_head, ctx.concat, ctx.head_is_scale = plan, n_head, concat, head_is_scale
-        ctx.head_shape = None
+        ctx.head_param = head_param
         ctx.save_for_backward(values, head, rowstat)
         ctx.scale = scale
         return out
@@ -143,8 +173,13 @@ class _PosAtt(torch.autograd.Function):
         d_out = _row_view(d_out)
         need_v, need_h = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         d_values = torch.empty((b, j, d), device=values.device, dtype=torch.float32) if need_v else None
-        d_head = torch.empty((n_head,), device=values.device, dtype=torch.float32) if need_h else None
-        work = torch.empty((n_head,), device=values.device, dtype=torch.float64)
+        slot = _grad_slot(ctx.head_param) if need_h else None
+        if slot is not None:
+            d_head, acc_head = slot, 1                  # accumulate into lmda.grad in place
+        else:
+            d_head = torch.empty((n_head,), device=values.device, dtype=torch.float32) if need_h else None
+            acc_head = 0
+        work = _dscale_workspace(values.device, n_head)
         rc = _lib.lib().pit_posatt_bwd(
             plan.mesh_out.data_ptr(), plan.mesh_in.data_ptr(), plan.mesh_batch, plan.n_out, plan.n_in, plan.sdim,
             plan.metric_id, plan.period,
@@ -154,9 +189,9 @@ class _PosAtt(torch.autograd.Function):
             d_out.data_ptr(), d_out.stride(1), d_out.stride(0), d if concat else 0,
             _lib.ptr(d_values), d_values.stride(1) if need_v else 0, d_values.stride(0) if need_v else 0,
             1 if concat else 0,
-            _lib.ptr(d_head), work.data_ptr(), _lib.stream_ptr())
+            _lib.ptr(d_head), acc_head, work.data_ptr(), _lib.stream_ptr())
         _lib.check(rc, "pit_posatt_bwd")
-        return d_values, d_head, None, None, None, None
+        return d_values, (None if slot is not None else d_head), None, None, None, None, None
 
 
 def posatt_apply(values: torch.Tensor, lmda: torch.Tensor, plan: MeshPlan, n_head: int, concat: bool,
@@ -164,8 +199,8 @@ def posatt_apply(values: torch.Tensor, lmda: torch.Tensor, plan: MeshPlan, n_hea
     """out[b,n,h*D+d] = sum_j softmax_j(-c_h m[n,j] | quantile mask)[n,j] * values[b,j,d]
     (pit.py:46-57); with ``concat`` the inputs are prepended (pit.py:44).  ``lmda`` is the
     (H,1,1) parameter, or the scale c itself when ``head_is_scale`` (tests inject it)."""
-    out = _PosAtt.apply(values, lmda.reshape(-1), plan, n_head, concat, head_is_scale)
-    return out
+    param = lmda if isinstance(lmda, torch.nn.Parameter) else None
+    return _PosAtt.apply(values, lmda.reshape(-1), plan, n_head, concat, head_is_scale, param)
 
 
 class _Mlp(torch.autograd.Function):
@@ -194,6 +229,7 @@ class _Mlp(torch.autograd.Function):
                                     h.data_ptr(), _lib.ptr(z2), y.data_ptr(), y.stride(0), _lib.stream_ptr())
         _lib.check(rc, "pit_mlp_fwd")
         ctx.out_gelu, ctx.dims, ctx.in_shape = out_gelu, (rows, n0, n1, n2), shape
+        ctx.params = (w1, b1, w2, b2)
         ctx.save_for_backward(x2, w1c, w2c, z1, h, z2 if out_gelu else z1)
         return y.reshape(*shape[:-1], n2)
 
@@ -207,18 +243,26 @@ class _Mlp(torch.autograd.Function):
             d_y2 = d_y2.contiguous()
         need_x = ctx.needs_input_grad[0]
         d_x = torch.empty((rows, n0), device=dev, dtype=torch.float32) if need_x else None
-        d_w1 = torch.empty((n1, n0), device=dev, dtype=torch.float32)
-        d_b1 = torch.empty((n1,), device=dev, dtype=torch.float32)
-        d_w2 = torch.empty((n2, n1), device=dev, dtype=torch.float32)
-        d_b2 = torch.empty((n2,), device=dev, dtype=torch.float32)
+        slots = [_grad_slot(p) if isinstance(p, torch.nn.Parameter) else None for p in ctx.params]
+        inplace = all(s is not None for s in slots) and all(ctx.needs_input_grad[1:5])
+        if inplace:
+            d_w1, d_b1, d_w2, d_b2 = slots
+        else:
+            d_w1 = torch.empty((n1, n0), device=dev, dtype=torch.float32)
+            d_b1 = torch.empty((n1,), device=dev, dtype=torch.float32)
+            d_w2 = torch.empty((n2, n1), device=dev, dtype=torch.float32)
+            d_b2 = torch.empty((n2,), device=dev, dtype=torch.float32)
         scratch = torch.empty((rows * (n1 + n2),), device=dev, dtype=torch.float32)
         rc = _lib.lib().pit_mlp_bwd(x2.data_ptr(), x2.stride(0), rows, n0, n1, n2, w1.data_ptr(), w2.data_ptr(),
                                     z1.data_ptr(), h.data_ptr(), z2.data_ptr() if ctx.out_gelu else 0,
                                     1 if ctx.out_gelu else 0, d_y2.data_ptr(), d_y2.stride(0),
                                     _lib.ptr(d_x), n0, d_w1.data_ptr(), d_b1.data_ptr(), d_w2.data_ptr(),
-                                    d_b2.data_ptr(), scratch.data_ptr(), _lib.stream_ptr())
+                                    d_b2.data_ptr(), 1 if inplace else 0, scratch.data_ptr(), _lib.stream_ptr())
         _lib.check(rc, "pit_mlp_bwd")
-        return (d_x.reshape(ctx.in_shape) if need_x else None), d_w1, d_b1, d_w2, d_b2, None
+        dx = d_x.reshape(ctx.in_shape) if need_x else None
+        if inplace:
+            return dx, None, None, None, None, None
+        return dx, d_w1, d_b1, d_w2, d_b2, None
 
 
 def mlp_apply(x, w1, b1, w2, b2, out_gelu: bool = False) -> torch.Tensor:

@@ -87,3 +87,25 @@ def test_task_wrappers_run(task):
     assert torch.isfinite(loss)
     for k, p in model.named_parameters():
         assert p.grad is not None and torch.isfinite(p.grad).all(), k
+
+
+def test_inplace_gradient_accumulation_matches_returned_gradients():
+    """ops.FUSED_GRAD_ACCUMULATION: kernels adding straight into existing .grad buffers (flat
+    gradient buffer) must give the same gradients as the autograd-returned ones, and must
+    ACCUMULATE (two backward passes = twice the gradient)."""
+    from position_induced_transformer_amd import ops, tasks, utils
+    from position_induced_transformer_amd.ddp import FlatGradients
+    model, sample, meta = tasks.make_task("darcy", seed=5)
+    mesh_in, func_in, mesh_out, target = sample(3)
+    loss_fn = utils.RelLpNorm(meta["out_dim"], meta["p"])
+
+    loss_fn(target, model(mesh_in, func_in, mesh_out)).backward()          # .grad is None -> returned path
+    ref = torch.cat([p.grad.reshape(-1) for p in model.parameters()]).clone()
+    for p in model.parameters():
+        p.grad = None
+    flat = FlatGradients(model.parameters())
+    assert ops.FUSED_GRAD_ACCUMULATION
+    loss_fn(target, model(mesh_in, func_in, mesh_out)).backward()
+    assert gio.rel_l2(ref.cpu().numpy(), flat.flat.cpu().numpy()) <= 1e-5
+    loss_fn(target, model(mesh_in, func_in, mesh_out)).backward()
+    assert gio.rel_l2(2.0 * ref.cpu().numpy(), flat.flat.cpu().numpy()) <= 1e-5
