@@ -24,7 +24,8 @@
 extern "C" {
 #endif
 
-#define PIT_ABI_VERSION 1
+#define PIT_ABI_VERSION 2
+#define PIT_DSCALE_SLOTS 32   /* fp64 accumulators per head in pit_posatt_bwd's workspace */
 
 /* distance metric (dist2att variants) */
 #define PIT_METRIC_EUCLID     0   /* pit.py:47,134  sum_c (xo_c-xi_c)^2                         */
@@ -80,9 +81,11 @@ int pit_posatt_fwd(const float* mesh_out, const float* mesh_in, int mesh_batch, 
  *            attention) the gradient of the copied inputs, d_out[b,j,0:dim], is added.
  *   d_head   n_head floats (NULL = not needed): gradient w.r.t. lmda (head_is_scale=0) or
  *            w.r.t. c (=1); accumulate_head=1 adds to the current contents instead of writing.
- *   workspace: n_head doubles, fp64 accumulators for d c.  They must be ZERO on entry and
- *            are left zero on exit (the finishing kernel clears what it consumed), so a
- *            caller allocates and zeroes them once and no per-call memset is needed. */
+ *   workspace: n_head*PIT_DSCALE_SLOTS doubles, fp64 accumulators for d c.  They must be ZERO
+ *            on entry and are left zero on exit (the finishing kernel clears what it
+ *            consumed), so a caller allocates and zeroes them once; no per-call memset.
+ * d_values and d_head are computed by independent kernels: a caller may issue two calls (one
+ * with d_values == NULL, one with d_head == NULL) on different streams to overlap them. */
 int pit_posatt_bwd(const float* mesh_out, const float* mesh_in, int mesh_batch, int n_out, int n_in,
                    int space_dim, int metric, float period,
                    const float* values, int batch, int dim, long ld_values, long values_bstride,
@@ -113,6 +116,18 @@ int pit_mlp_bwd(const float* x, long ldx, int rows, int n0, int n1, int n2,
                 int out_gelu, const float* d_y, long ld_dy,
                 float* d_x, long ld_dx, float* d_w1, float* d_b1, float* d_w2, float* d_b2,
                 int accumulate, float* scratch, void* stream);
+
+/* The two halves of pit_mlp_bwd as separate entry points, so a caller can put the
+ * parameter-gradient GEMMs (which nothing downstream in the backward pass depends on) on a
+ * second stream: _data computes dZ1 (and dZ2 when out_gelu) into scratch and d_x; _params
+ * consumes scratch and must be ordered after _data (event / same stream). */
+int pit_mlp_bwd_data(int rows, int n0, int n1, int n2, const float* w1, const float* w2,
+                     const float* z1, const float* z2, int out_gelu, const float* d_y, long ld_dy,
+                     float* d_x, long ld_dx, float* scratch, void* stream);
+int pit_mlp_bwd_params(const float* x, long ldx, int rows, int n0, int n1, int n2, const float* h,
+                       int out_gelu, const float* d_y, long ld_dy,
+                       float* d_w1, float* d_b1, float* d_w2, float* d_b2,
+                       int accumulate, const float* scratch, void* stream);
 
 /* RelLpNorm (utils.py:80-98): loss = sum_b mean_c ||true - pred'||_p / ||true||_p with norms
  * over the point axis of (batch, npts, nch) contiguous tensors, pred' = pred*scale + shift when

@@ -322,6 +322,25 @@ def make_model_cases():
                    cs["p_norm"], cfg["n_blocks"], cfg["en_loc"], cfg["de_loc"], 0)
 
 
+def init_case():
+    """Seed-for-seed initialisation of the reference (pit.py:35 torch.rand, :18-19 kaiming_normal_,
+    nn.Linear default biases, and the extra draws of pit_fixed re-creating down/conv/up,
+    pit.py:182-184): digest of every parameter for torch.manual_seed(0)."""
+    st = {}
+    for tag, build in (("fixed", lambda: ref.pit_fixed(2, 1, 1, 64, 2, 4, orc.grid_mesh_2d(16), 0.02, 0.02)),
+                       ("base", lambda: ref.pit(2, 12, 1, 32, 2, 2, None, 0.05, 0.05)),
+                       ("p1d", lambda: ref.pit_periodic1d(1, 1, 1, 32, 2, 3, orc.line_mesh_1d(64), 0.02, 0.02))):
+        torch.manual_seed(0)
+        sd = build().state_dict()
+        st[tag + "/names"] = np.asarray(list(sd.keys()))
+        for k, v in sd.items():
+            st[f"{tag}/head/{k}"] = npf(v.flatten()[:4])
+            st[f"{tag}/sum/{k}"] = np.float64(v.double().sum().item())
+            st[f"{tag}/shape/{k}"] = np.asarray(v.shape, dtype=np.int64)
+    np.savez_compressed(os.path.join(OUT, "F13_init_parity.npz"), **st)
+    print("F13_init_parity              ", len(st), "entries")
+
+
 if __name__ == "__main__":
     for f in os.listdir(OUT):
         if f.endswith(".npz"):
@@ -333,5 +352,6 @@ if __name__ == "__main__":
     mlp_case("F8_mlp_6_64_64", 6, 64, 64, (3, 50), 204)
     mlp_case("F8_mlp_88_256_3", 88, 256, 3, (1, 77), 205)
     make_model_cases()
+    init_case()
     tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
     print(f"total golden bytes: {tot}")

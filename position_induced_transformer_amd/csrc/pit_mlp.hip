@@ -255,24 +255,15 @@ extern "C" int pit_mlp_fwd(const float* x, long ldx, int rows, int n0, int n1, i
     return 0;
 }
 
-extern "C" int pit_mlp_bwd(const float* x, long ldx, int rows, int n0, int n1, int n2,
-                           const float* w1, const float* w2, const float* z1, const float* h, const float* z2,
-                           int out_gelu, const float* d_y, long ld_dy,
-                           float* d_x, long ld_dx, float* d_w1, float* d_b1, float* d_w2, float* d_b2,
-                           int accumulate, float* scratch, void* stream) {
-    if (!x || !w1 || !w2 || !z1 || !h || !d_y || !d_w1 || !d_b1 || !d_w2 || !d_b2 || !scratch) return PIT_ERR_NULL;
+extern "C" int pit_mlp_bwd_data(int rows, int n0, int n1, int n2, const float* w1, const float* w2,
+                                const float* z1, const float* z2, int out_gelu, const float* d_y, long ld_dy,
+                                float* d_x, long ld_dx, float* scratch, void* stream) {
+    if (!w1 || !w2 || !z1 || !d_y || !scratch) return PIT_ERR_NULL;
     if (out_gelu && !z2) return PIT_ERR_NULL;
     if (rows <= 0 || n0 <= 0 || n1 <= 0 || n2 <= 0) return PIT_ERR_SIZE;
     hipStream_t s = (hipStream_t)stream;
     float* dz1 = scratch;                       // rows * n1
     float* dz2buf = scratch + (long)rows * n1;  // rows * n2
-    if (!accumulate) {
-        hipError_t e;
-        if ((e = hipMemsetAsync(d_w1, 0, sizeof(float) * (size_t)n1 * n0, s)) != hipSuccess) return (int)e;
-        if ((e = hipMemsetAsync(d_b1, 0, sizeof(float) * (size_t)n1, s)) != hipSuccess) return (int)e;
-        if ((e = hipMemsetAsync(d_w2, 0, sizeof(float) * (size_t)n2 * n1, s)) != hipSuccess) return (int)e;
-        if ((e = hipMemsetAsync(d_b2, 0, sizeof(float) * (size_t)n2, s)) != hipSuccess) return (int)e;
-    }
     // dZ1 = (dZ2 W2) * gelu'(Z1), with dZ2 = dY * gelu'(Z2) formed in the A prologue and kept
     GemmArgs g = blank();
     g.A = d_y; g.a_rs = ld_dy; g.a_cs = 1;
@@ -285,16 +276,6 @@ extern "C" int pit_mlp_bwd(const float* x, long ldx, int rows, int n0, int n1, i
     g.G = z1; g.ldg = n1; g.C = dz1; g.ldc = n1; g.epi = EPI_MUL_GELU_GRAD;
     if (int rc = launch_gemm(g, s)) return rc;
     PIT_CHECK_LAUNCH();
-    const float* dz2 = out_gelu ? dz2buf : d_y;
-    const long ld_dz2 = out_gelu ? n2 : ld_dy;
-    // dW2 += dZ2^T H (+ db2 as the ones column)
-    g = blank();
-    g.A = dz2; g.a_rs = 1; g.a_cs = ld_dz2;        // A(m,k) = dz2[k][m]
-    g.B = h; g.b_rs = n1; g.b_cs = 1;
-    g.M = n2; g.N = n1 + 1; g.K = rows; g.ones_col = n1;
-    g.C = d_w2; g.ldc = n1; g.C2 = d_b2; g.atomic = 1; g.epi = EPI_ATOMIC;
-    if (int rc = launch_gemm(g, s)) return rc;
-    PIT_CHECK_LAUNCH();
     // dX = dZ1 W1
     if (d_x) {
         g = blank();
@@ -305,6 +286,34 @@ extern "C" int pit_mlp_bwd(const float* x, long ldx, int rows, int n0, int n1, i
         if (int rc = launch_gemm(g, s)) return rc;
         PIT_CHECK_LAUNCH();
     }
+    return 0;
+}
+
+extern "C" int pit_mlp_bwd_params(const float* x, long ldx, int rows, int n0, int n1, int n2, const float* h,
+                                  int out_gelu, const float* d_y, long ld_dy,
+                                  float* d_w1, float* d_b1, float* d_w2, float* d_b2,
+                                  int accumulate, const float* scratch, void* stream) {
+    if (!x || !h || !d_y || !d_w1 || !d_b1 || !d_w2 || !d_b2 || !scratch) return PIT_ERR_NULL;
+    if (rows <= 0 || n0 <= 0 || n1 <= 0 || n2 <= 0) return PIT_ERR_SIZE;
+    hipStream_t s = (hipStream_t)stream;
+    const float* dz1 = scratch;
+    const float* dz2 = out_gelu ? scratch + (long)rows * n1 : d_y;
+    const long ld_dz2 = out_gelu ? n2 : ld_dy;
+    if (!accumulate) {
+        hipError_t e;
+        if ((e = hipMemsetAsync(d_w1, 0, sizeof(float) * (size_t)n1 * n0, s)) != hipSuccess) return (int)e;
+        if ((e = hipMemsetAsync(d_b1, 0, sizeof(float) * (size_t)n1, s)) != hipSuccess) return (int)e;
+        if ((e = hipMemsetAsync(d_w2, 0, sizeof(float) * (size_t)n2 * n1, s)) != hipSuccess) return (int)e;
+        if ((e = hipMemsetAsync(d_b2, 0, sizeof(float) * (size_t)n2, s)) != hipSuccess) return (int)e;
+    }
+    // dW2 += dZ2^T H (+ db2 as the ones column)
+    GemmArgs g = blank();
+    g.A = dz2; g.a_rs = 1; g.a_cs = ld_dz2;        // A(m,k) = dz2[k][m]
+    g.B = h; g.b_rs = n1; g.b_cs = 1;
+    g.M = n2; g.N = n1 + 1; g.K = rows; g.ones_col = n1;
+    g.C = d_w2; g.ldc = n1; g.C2 = d_b2; g.atomic = 1; g.epi = EPI_ATOMIC;
+    if (int rc = launch_gemm(g, s)) return rc;
+    PIT_CHECK_LAUNCH();
     // dW1 += dZ1^T X (+ db1)
     g = blank();
     g.A = dz1; g.a_rs = 1; g.a_cs = n1;
@@ -314,4 +323,15 @@ extern "C" int pit_mlp_bwd(const float* x, long ldx, int rows, int n0, int n1, i
     if (int rc = launch_gemm(g, s)) return rc;
     PIT_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int pit_mlp_bwd(const float* x, long ldx, int rows, int n0, int n1, int n2,
+                           const float* w1, const float* w2, const float* z1, const float* h, const float* z2,
+                           int out_gelu, const float* d_y, long ld_dy,
+                           float* d_x, long ld_dx, float* d_w1, float* d_b1, float* d_w2, float* d_b2,
+                           int accumulate, float* scratch, void* stream) {
+    int rc = pit_mlp_bwd_data(rows, n0, n1, n2, w1, w2, z1, z2, out_gelu, d_y, ld_dy, d_x, ld_dx, scratch, stream);
+    if (rc) return rc;
+    return pit_mlp_bwd_params(x, ldx, rows, n0, n1, n2, h, out_gelu, d_y, ld_dy, d_w1, d_b1, d_w2, d_b2,
+                              accumulate, scratch, stream);
 }

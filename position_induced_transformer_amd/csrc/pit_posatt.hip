@@ -244,7 +244,9 @@ __global__ __launch_bounds__(512) void posatt_rows_kernel(AttArgs a) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) part += (double)acc[t][i] * (double)dov[t][i];
         part = wave_sum_d(part);
-        if (lane == 0) atomicAdd(a.dscale_acc + h, -part);
+        // PIT_DSCALE_SLOTS accumulators per head keep the fp64 atomics off a single address
+        const int slot = (blockIdx.x + 5 * blockIdx.z + wave) & (PIT_DSCALE_SLOTS - 1);
+        if (lane == 0) atomicAdd(a.dscale_acc + h * PIT_DSCALE_SLOTS + slot, -part);
         return;
     }
 
@@ -434,8 +436,11 @@ __global__ void posatt_dhead_finish(double* acc, const float* head, int n_head, 
                                     int accumulate, float* d_head) {
     const int h = blockIdx.x * blockDim.x + threadIdx.x;
     if (h >= n_head) return;
-    double g = acc[h];
-    acc[h] = 0.0;                 // leave the accumulators clean for the next call
+    double g = 0.0;
+    for (int sl = 0; sl < PIT_DSCALE_SLOTS; ++sl) {
+        g += acc[h * PIT_DSCALE_SLOTS + sl];
+        acc[h * PIT_DSCALE_SLOTS + sl] = 0.0;     // leave the accumulators clean for the next call
+    }
     if (!head_is_scale) {
         const float lm = head[h];
         g *= head_scale_grad(lm, head_scale_from_lmda(lm));

@@ -23,7 +23,43 @@ METRIC_ID = {"euclid": 0, "periodic1d": 1, "periodic2d": 2}
 # temporary, no separate ``grad += tmp`` launch.  Set to False to always return gradients.
 FUSED_GRAD_ACCUMULATION = True
 
+# Backward kernels that nothing later in the backward pass depends on - the d(scale) reduction
+# of an attention layer and the weight/bias-gradient GEMMs of an MLP - are issued on a second
+# HIP stream (fork after their inputs exist, one join when the backward pass ends), so they
+# overlap the critical d-values / d-x chain.  Only used together with in-place accumulation
+# (their results then go nowhere but the .grad buffers).  Captured into hipGraphs as parallel
+# branches.
+OVERLAP_BACKWARD = True
+
 _DSCALE_WS = {}
+_SIDE = {}          # device index -> {"stream", "pending", "keep"}
+
+
+def _side_state(device):
+    st = _SIDE.get(device.index)
+    if st is None:
+        st = {"stream": torch.cuda.Stream(device=device), "pending": False, "keep": []}
+        _SIDE[device.index] = st
+    return st
+
+
+def _fork_side(device, *keep_alive):
+    """Make the side stream wait for everything enqueued so far on the current stream, register
+    the end-of-backward join once, keep ``keep_alive`` tensors referenced until then (they are
+    read by side-stream kernels after autograd would have released them)."""
+    st = _side_state(device)
+    st["stream"].wait_stream(torch.cuda.current_stream(device))
+    st["keep"].extend(keep_alive)
+    if not st["pending"]:
+        st["pending"] = True
+
+        def _join():
+            torch.cuda.current_stream(device).wait_stream(st["stream"])
+            st["keep"].clear()
+            st["pending"] = False
+        torch.autograd.Variable._execution_engine.queue_callback(_join)
+    return st["stream"]
+
 
 
 def _dscale_workspace(device, n_head: int) -> torch.Tensor:
@@ -32,7 +68,7 @@ def _dscale_workspace(device, n_head: int) -> torch.Tensor:
     key = device.index
     ws = _DSCALE_WS.get(key)
     if ws is None or ws.numel() < n_head:
-        ws = torch.zeros(max(64, n_head), device=device, dtype=torch.float64)
+        ws = torch.zeros(max(64, n_head) * 32, device=device, dtype=torch.float64)   # PIT_DSCALE_SLOTS = 32
         _DSCALE_WS[key] = ws
     return ws
 
@@ -180,17 +216,27 @@ class _PosAtt(torch.autograd.Function):
             d_head = torch.empty((n_head,), device=values.device, dtype=torch.float32) if need_h else None
             acc_head = 0
         work = _dscale_workspace(values.device, n_head)
-        rc = _lib.lib().pit_posatt_bwd(
-            plan.mesh_out.data_ptr(), plan.mesh_in.data_ptr(), plan.mesh_batch, plan.n_out, plan.n_in, plan.sdim,
-            plan.metric_id, plan.period,
-            values.data_ptr(), b, d, values.stride(1), values.stride(0),
-            head.data_ptr(), n_head, 1 if ctx.head_is_scale else 0,
-            rowstat.data_ptr(), 1 if plan.masked else 0,
-            d_out.data_ptr(), d_out.stride(1), d_out.stride(0), d if concat else 0,
-            _lib.ptr(d_values), d_values.stride(1) if need_v else 0, d_values.stride(0) if need_v else 0,
-            1 if concat else 0,
-            _lib.ptr(d_head), acc_head, work.data_ptr(), _lib.stream_ptr())
-        _lib.check(rc, "pit_posatt_bwd")
+
+        def launch(dv, dh, stream_ptr):
+            rc = _lib.lib().pit_posatt_bwd(
+                plan.mesh_out.data_ptr(), plan.mesh_in.data_ptr(), plan.mesh_batch, plan.n_out, plan.n_in,
+                plan.sdim, plan.metric_id, plan.period,
+                values.data_ptr(), b, d, values.stride(1), values.stride(0),
+                head.data_ptr(), n_head, 1 if ctx.head_is_scale else 0,
+                rowstat.data_ptr(), 1 if plan.masked else 0,
+                d_out.data_ptr(), d_out.stride(1), d_out.stride(0), d if concat else 0,
+                _lib.ptr(dv), dv.stride(1) if dv is not None else 0, dv.stride(0) if dv is not None else 0,
+                1 if concat else 0,
+                _lib.ptr(dh), acc_head, work.data_ptr(), stream_ptr)
+            _lib.check(rc, "pit_posatt_bwd")
+
+        if OVERLAP_BACKWARD and slot is not None:
+            side = _fork_side(values.device, values, head, rowstat, d_out, plan)
+            launch(None, d_head, side.cuda_stream)          # d(scale) -> lmda.grad, off the critical path
+            if d_values is not None:
+                launch(d_values, None, _lib.stream_ptr())
+        else:
+            launch(d_values, d_head, _lib.stream_ptr())
         return d_values, (None if slot is not None else d_head), None, None, None, None, None
 
 
@@ -253,12 +299,21 @@ class _Mlp(torch.autograd.Function):
             d_w2 = torch.empty((n2, n1), device=dev, dtype=torch.float32)
             d_b2 = torch.empty((n2,), device=dev, dtype=torch.float32)
         scratch = torch.empty((rows * (n1 + n2),), device=dev, dtype=torch.float32)
-        rc = _lib.lib().pit_mlp_bwd(x2.data_ptr(), x2.stride(0), rows, n0, n1, n2, w1.data_ptr(), w2.data_ptr(),
-                                    z1.data_ptr(), h.data_ptr(), z2.data_ptr() if ctx.out_gelu else 0,
-                                    1 if ctx.out_gelu else 0, d_y2.data_ptr(), d_y2.stride(0),
-                                    _lib.ptr(d_x), n0, d_w1.data_ptr(), d_b1.data_ptr(), d_w2.data_ptr(),
-                                    d_b2.data_ptr(), 1 if inplace else 0, scratch.data_ptr(), _lib.stream_ptr())
-        _lib.check(rc, "pit_mlp_bwd")
+        L = _lib.lib()
+        z2p = z2.data_ptr() if ctx.out_gelu else 0
+        og = 1 if ctx.out_gelu else 0
+        rc = L.pit_mlp_bwd_data(rows, n0, n1, n2, w1.data_ptr(), w2.data_ptr(), z1.data_ptr(), z2p, og,
+                                d_y2.data_ptr(), d_y2.stride(0), _lib.ptr(d_x), n0, scratch.data_ptr(),
+                                _lib.stream_ptr())
+        _lib.check(rc, "pit_mlp_bwd_data")
+        if OVERLAP_BACKWARD and inplace:
+            stream_p = _fork_side(dev, x2, h, d_y2, scratch).cuda_stream     # weight grads off the critical path
+        else:
+            stream_p = _lib.stream_ptr()
+        rc = L.pit_mlp_bwd_params(x2.data_ptr(), x2.stride(0), rows, n0, n1, n2, h.data_ptr(), og,
+                                  d_y2.data_ptr(), d_y2.stride(0), d_w1.data_ptr(), d_b1.data_ptr(),
+                                  d_w2.data_ptr(), d_b2.data_ptr(), 1 if inplace else 0, scratch.data_ptr(), stream_p)
+        _lib.check(rc, "pit_mlp_bwd_params")
         dx = d_x.reshape(ctx.in_shape) if need_x else None
         if inplace:
             return dx, None, None, None, None, None

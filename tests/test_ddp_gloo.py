@@ -1,0 +1,96 @@
+"""CPU, world_size 2 over gloo: the batch-axis data-parallel path (ddp.FlatGradients).
+
+The compute of each rank is done by the CPU oracle (the HIP path needs a GPU); what is under
+test is the sharding + the single flat all-reduce: the W-rank gradient after the all-reduce
+must equal the 1-rank gradient of the concatenated batch (RelLpNorm sums
+over the batch, so the reduction is SUM)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _oracle_grads(params, x, y):
+    import pit_oracle as orc
+    mesh, ltt = orc.grid_mesh_2d(12), orc.grid_mesh_2d(5)
+    p = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    f = orc.with_coords(mesh, x.reshape(x.shape[0], -1, 1))
+    out = orc.pit_apply(p, "euclid", False, 2, 0.1, 0.1, mesh, f, ltt, mesh)
+    orc.rel_lp_loss(y, out, 1, 2).backward()
+    return p
+
+
+def _worker(rank, world, port, out_dir):
+    for pth in (ROOT, HERE, os.path.join(ROOT, "oracle")):
+        sys.path.insert(0, pth)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    import golden_io as gio
+    import pit_oracle as orc
+    from position_induced_transformer_amd.ddp import FlatGradients, broadcast_parameters, shard_batch
+
+    shapes = orc.param_shapes(2, 1, 1, 16, 2, 2)
+    # every rank starts from different parameters; broadcast makes them rank 0's
+    params = {k: torch.nn.Parameter(torch.from_numpy(v)) for k, v in gio.synth_params(shapes, 10 + rank).items()}
+    holder = torch.nn.ParameterDict({k.replace(".", "_"): v for k, v in params.items()})
+    broadcast_parameters(holder)
+    ref0 = {k: torch.from_numpy(v) for k, v in gio.synth_params(shapes, 10).items()}
+    for k in params:
+        assert torch.equal(params[k].data, ref0[k]), k
+
+    gb = 6                                                        # global batch, uneven split for world=4
+    x = torch.from_numpy(gio.synth((gb, 144, 1), 77))
+    y = torch.from_numpy(gio.synth((gb, 144, 1), 78))
+    sl = shard_batch(gb, rank, world)
+    flat = FlatGradients(params.values())
+    flat.zero_()
+    g = _oracle_grads({k: v.data for k, v in params.items()}, x[sl], y[sl])
+    for k, p in params.items():
+        p.grad.add_(g[k].grad)                                    # accumulates into the flat buffer views
+    assert flat.flat.abs().sum() > 0
+    flat.all_reduce()                                             # ONE collective for all parameters
+    if rank == 0:
+        full = _oracle_grads(ref0, x, y)
+        want = torch.cat([full[k].grad.reshape(-1) for k in params])
+        err = float((flat.flat - want).norm() / want.norm())
+        np.save(os.path.join(out_dir, "err.npy"), np.asarray([err, float(flat.flat.numel())]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_flat_allreduce_equals_single_rank_gradient(tmp_path, world):
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    err, n = np.load(os.path.join(tmp_path, "err.npy"))
+    assert n > 1000
+    assert err <= 1e-6, err
+
+
+def test_shard_batch_partitions_exactly():
+    sys.path.insert(0, ROOT)
+    from position_induced_transformer_amd.ddp import shard_batch
+    for n in (1, 7, 8, 64):
+        for w in (1, 2, 3, 8):
+            idx = []
+            for r in range(w):
+                s = shard_batch(n, r, w)
+                idx += list(range(n))[s]
+            assert idx == list(range(n))
