@@ -144,6 +144,8 @@ def roofline_probe(model, batch, iters=200):
     from position_induced_transformer_amd import ops
     layer = model.conv[0]
     mesh = model.mesh_ltt
+    if mesh is None:                     # per-sample meshes: a synthetic cloud of the Elasticity size
+        mesh = torch.rand(batch, 972, model.space_dim, device="cuda")
     plan = layer._plan(mesh, mesh, True)
     d = model.hid_dim
     u = torch.randn(batch, plan.n_in, d, device="cuda")
@@ -160,7 +162,7 @@ def roofline_probe(model, batch, iters=200):
     us = e0.elapsed_time(e1) * 1e3 / iters
     flops = 2.0 * layer.n_head * plan.n_out * plan.n_in * d * batch
     achieved = flops / (us * 1e-6) / 1e12
-    return {"bound": "mfma", "kernel": "posatt_rows_kernel(fwd, processor 256x256, D=64, H=2)",
+    return {"bound": "mfma", "kernel": f"posatt_rows_kernel(fwd, processor {plan.n_out}x{plan.n_in}, D={d}, H={layer.n_head})",
             "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
             "us_per_launch": round(us, 3), "flops_per_launch": flops,

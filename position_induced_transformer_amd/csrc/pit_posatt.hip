@@ -56,33 +56,29 @@ __device__ __forceinline__ float4 load_point4(__amdgpu_buffer_rsrc_t r, unsigned
     return v;
 }
 
-// Tree-reduce the per-wave accumulators (and NX extra per-lane scalars) into wave 0.
+// Cross-wave reduction as a reduce-scatter through LDS: every wave parks its partial tile (and NX
+// per-lane scalars), one barrier, then wave w sums and owns accumulator registers
+// [w*16*CT/nwaves, ...) - so the epilogue (normalise, stores, residual loads) is spread over all
+// waves instead of being serialised on wave 0.  Scalars are summed by every wave (all need them).
+// `part` receives this wave's share (up to 16*CT registers, index q = t*16 + r).
 template <int CT, int NX>
-__device__ __forceinline__ void reduce_waves(f32x16 (&acc)[CT], float (&extra)[NX > 0 ? NX : 1], float* red,
-                                             int wave, int nwaves, int lane) {
+__device__ __forceinline__ void park_tiles(const f32x16 (&acc)[CT], const float (&extra)[NX > 0 ? NX : 1], float* red,
+                                           int wave, int lane) {
     constexpr int SLOT = (CT * 16 + NX) * 64;
-    for (int stride = nwaves >> 1; stride >= 1; stride >>= 1) {
-        if (wave >= stride && wave < 2 * stride) {
-            float* dst = red + (long)(wave - stride) * SLOT + lane;
+    float* dst = red + (long)wave * SLOT + lane;
 #pragma unroll
-            for (int t = 0; t < CT; ++t)
+    for (int t = 0; t < CT; ++t)
 #pragma unroll
-                for (int i = 0; i < 16; ++i) dst[(t * 16 + i) * 64] = acc[t][i];
+        for (int i = 0; i < 16; ++i) dst[(t * 16 + i) * 64] = acc[t][i];
 #pragma unroll
-            for (int x = 0; x < NX; ++x) dst[(CT * 16 + x) * 64] = extra[x];
-        }
-        __syncthreads();
-        if (wave < stride) {
-            const float* src = red + (long)wave * SLOT + lane;
-#pragma unroll
-            for (int t = 0; t < CT; ++t)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) acc[t][i] += src[(t * 16 + i) * 64];
-#pragma unroll
-            for (int x = 0; x < NX; ++x) extra[x] += src[(CT * 16 + x) * 64];
-        }
-        __syncthreads();
-    }
+    for (int x = 0; x < NX; ++x) dst[(CT * 16 + x) * 64] = extra[x];
+}
+template <int CT, int NX>
+__device__ __forceinline__ float summed(const float* red, int nwaves, int q, int lane) {
+    constexpr int SLOT = (CT * 16 + NX) * 64;
+    float v = 0.0f;
+    for (int w = 0; w < nwaves; ++w) v += red[(long)w * SLOT + q * 64 + lane];
+    return v;
 }
 
 // ------------------------------------------------------------------------------------
@@ -129,7 +125,6 @@ __global__ __launch_bounds__(512) void posatt_rows_kernel(AttArgs a) {
     // ---- per-lane column constants
     const __amdgpu_buffer_rsrc_t rvals = make_rsrc(a.values, a.values_bytes);
     const unsigned ld4 = (unsigned)a.ld_values * 4u;
-    const float* ucol[CT];
     unsigned uoff[CT];                     // byte offset of this lane's column inside `values`
     bool cvalid[CT];
     int cb[CT], cd[CT];
@@ -140,7 +135,6 @@ __global__ __launch_bounds__(512) void posatt_rows_kernel(AttArgs a) {
         const int cc = cvalid[t] ? col : 0;
         cb[t] = (a.mesh_batch == 1) ? cc / a.dim : mb;
         cd[t] = (a.mesh_batch == 1) ? cc % a.dim : cc;
-        ucol[t] = a.values + (long)cb[t] * a.values_bstride + cd[t];
         uoff[t] = (unsigned)(((long)cb[t] * a.values_bstride + cd[t]) * 4);
     }
 
@@ -250,48 +244,45 @@ __global__ __launch_bounds__(512) void posatt_rows_kernel(AttArgs a) {
         return;
     }
 
-    // ---- forward epilogue: reduce waves, normalise, store
+    // ---- forward epilogue: reduce-scatter over the waves, normalise, store
     float extra[2];
     extra[0] = rsum + __shfl_xor(rsum, 32);
     extra[1] = qsum + __shfl_xor(qsum, 32);
+    float* red = reinterpret_cast<float*>(smem);
+    __syncthreads();                                   // staging region is free
+    park_tiles<CT, 2>(acc, extra, red, wave, lane);
     __syncthreads();
-    reduce_waves<CT, 2>(acc, extra, reinterpret_cast<float*>(smem), wave, nwaves, lane);
-    if (wave != 0) return;
-    const float inv = extra[0] > 0.0f ? 1.0f / extra[0] : 0.0f;
-    float inv_row[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) inv_row[i] = __shfl(inv, acc_row(i, half));
-#pragma unroll
-    for (int t = 0; t < CT; ++t) {
-        float* ocol = a.out + (long)cb[t] * a.out_bstride + a.out_col0 + (long)h * a.dim + cd[t];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int nr = n0 + acc_row(i, half);
-            if (cvalid[t] && nr < a.n_out) ocol[(long)nr * a.ld_out] = acc[t][i] * inv_row[i];
+    const float rs_tot = summed<CT, 2>(red, nwaves, CT * 16, lane);       // row = lane & 31
+    const float qs_tot = summed<CT, 2>(red, nwaves, CT * 16 + 1, lane);
+    const float inv = rs_tot > 0.0f ? 1.0f / rs_tot : 0.0f;
+    const int share = CT * 16 / nwaves;               // nwaves in {1,2,4,8}
+    const int q0 = wave * share;
+#pragma unroll 1
+    for (int qq = 0; qq < share; ++qq) {
+        const int q = q0 + qq;
+        const int t = q >> 4, i = q & 15;
+        const int row = acc_row(i, half);
+        const int nr = n0 + row;
+        const float v = summed<CT, 2>(red, nwaves, q, lane) * __shfl(inv, row);
+        // column constants of tile t (t is wave-uniform but dynamic: recompute instead of indexing)
+        const int col = (cg * CT + t) * 32 + l31;
+        const bool cv = col < a.ncols;
+        const int cc = cv ? col : 0;
+        const int bb = (a.mesh_batch == 1) ? cc / a.dim : mb;
+        const int dd = (a.mesh_batch == 1) ? cc % a.dim : cc;
+        const bool ok = cv && nr < a.n_out;
+        if (ok) a.out[(long)bb * a.out_bstride + (long)nr * a.ld_out + a.out_col0 + (long)h * a.dim + dd] = v;
+        if (a.copy_inputs && h == 0) {                 // torch.cat((inputs, conv), -1) of pit.py:44
+            const unsigned off = (unsigned)(((long)bb * a.values_bstride + dd) * 4) + (unsigned)nr * ld4;
+            const float iv = buf_load(rvals, ok ? off : a.values_bytes);
+            if (ok) a.out[(long)bb * a.out_bstride + (long)nr * a.ld_out + dd] = iv;
         }
     }
-    if (a.copy_inputs && h == 0) {       // torch.cat((inputs, conv), -1) of pit.py:44
-#pragma unroll
-        for (int t = 0; t < CT; ++t) {
-            float iv[16];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int nr = n0 + acc_row(i, half);
-                iv[i] = buf_load(rvals, (cvalid[t] && nr < a.n_out) ? uoff[t] + (unsigned)nr * ld4 : a.values_bytes);
-            }
-            float* icol = a.out + (long)cb[t] * a.out_bstride + cd[t];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int nr = n0 + acc_row(i, half);
-                if (cvalid[t] && nr < a.n_out) icol[(long)nr * a.ld_out] = iv[i];
-            }
-        }
-    }
-    if (cg == 0 && half == 0 && nvalid) {
-        float4 st; st.x = T; st.y = s_min; st.z = inv; st.w = extra[1] * inv;
+    if (wave == 0 && cg == 0 && half == 0 && nvalid) {
+        float4 st; st.x = T; st.y = s_min; st.z = inv; st.w = qs_tot * inv;
         *reinterpret_cast<float4*>(a.rowstat + (((long)mb * a.n_head + h) * a.n_out + n) * 4) = st;
     }
-    if (a.scale_out && blockIdx.x == 0 && blockIdx.z == 0 && lane == 0) a.scale_out[h] = c;
+    if (a.scale_out && wave == 0 && blockIdx.x == 0 && blockIdx.z == 0 && lane == 0) a.scale_out[h] = c;
 }
 
 // ------------------------------------------------------------------------------------
@@ -409,26 +400,28 @@ __global__ __launch_bounds__(512) void posatt_cols_kernel(AttArgs a) {
         }
     }
     float extra[1] = {0.0f};
+    float* red = reinterpret_cast<float*>(smem);
     __syncthreads();
-    reduce_waves<CT, 0>(acc, extra, reinterpret_cast<float*>(smem), wave, nwaves, lane);
-    if (wave != 0) return;
-#pragma unroll
-    for (int t = 0; t < CT; ++t) {
-        float* gcol = a.d_values + (long)cb[t] * a.dvalues_bstride + cd[t];
+    park_tiles<CT, 0>(acc, extra, red, wave, lane);
+    __syncthreads();
+    const int share = CT * 16 / nwaves;
+    const int q0 = wave * share;
+#pragma unroll 1
+    for (int qq = 0; qq < share; ++qq) {
+        const int q = q0 + qq;
+        const int t = q >> 4, i = q & 15;
+        const int jr = j0 + acc_row(i, half);
+        const int col = (cg * CT + t) * 32 + l31;
+        const bool cv = col < a.ncols;
+        const int cc = cv ? col : 0;
+        const int bb = (a.mesh_batch == 1) ? cc / a.dim : mb;
+        const int dd = (a.mesh_batch == 1) ? cc % a.dim : cc;
+        const bool ok = cv && jr < a.n_in;
+        float v = summed<CT, 0>(red, nwaves, q, lane);
         // residual (self attention): d_out columns [0,dim) of the same row
-        const unsigned rbase = (unsigned)(((long)cb[t] * a.dout_bstride + cd[t]) * 4);
-        float rv[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int jr = j0 + acc_row(i, half);
-            rv[i] = buf_load(rdout, (a.add_residual && cvalid[t] && jr < a.n_in) ? rbase + (unsigned)jr * ldd4
-                                                                                 : a.dout_bytes);
-        }
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int jr = j0 + acc_row(i, half);
-            if (cvalid[t] && jr < a.n_in) gcol[(long)jr * a.ld_dvalues] = acc[t][i] + rv[i];
-        }
+        const unsigned roff = (unsigned)(((long)bb * a.dout_bstride + dd) * 4) + (unsigned)jr * ldd4;
+        v += buf_load(rdout, (a.add_residual && ok) ? roff : a.dout_bytes);
+        if (ok) a.d_values[(long)bb * a.dvalues_bstride + (long)jr * a.ld_dvalues + dd] = v;
     }
 }
 
@@ -470,12 +463,12 @@ int choose_ct(int ncols, long other_wgs) {
 
 size_t rows_smem(int ct, int nwaves, int n_in) {
     const size_t stage = (size_t)min(KEY_CHUNK, n_in) * sizeof(float4);
-    const size_t red = (size_t)(nwaves / 2) * (ct * 16 + 2) * 64 * sizeof(float);
+    const size_t red = (size_t)nwaves * (ct * 16 + 2) * 64 * sizeof(float);
     return stage > red ? stage : red;
 }
 size_t cols_smem(int ct, int nwaves, int n_out) {
     const size_t stage = (size_t)min(ROW_CHUNK, n_out) * 2 * sizeof(float4);
-    const size_t red = (size_t)(nwaves / 2) * (ct * 16) * 64 * sizeof(float);
+    const size_t red = (size_t)nwaves * (ct * 16) * 64 * sizeof(float);
     return stage > red ? stage : red;
 }
 
@@ -486,12 +479,18 @@ void launch_rows(const AttArgs& a0, hipStream_t s) {
     int ct = choose_ct(a.ncols, (long)n_tiles * a.n_head * a.mesh_batch);
     if (int f = env_int("PIT_FORCE_CT")) ct = f;
     a.colgroups = (a.ncols + 32 * ct - 1) / (32 * ct);
-    int nwaves = max(1, min(ct == 4 ? 4 : 8, pow2_floor(a.n_in / 64)));   // LDS reduce buffer <= 64 KiB
-    if (int f = env_int("PIT_FORCE_WAVES")) nwaves = min(f, ct == 4 ? 4 : 8);
+    const int wmax = (ct == 4) ? 4 : 8;                                  // parked tiles must fit 96 KiB of LDS
+    int nwaves = max(1, min(wmax, pow2_floor(a.n_in / 32)));
+    if (int f = env_int("PIT_FORCE_WAVES")) nwaves = min(f, wmax);
     dim3 grid(n_tiles, a.n_head, a.mesh_batch * a.colgroups), block(64 * nwaves);
     const size_t sm = rows_smem(ct, nwaves, a.n_in);
 #define PIT_ROWS(CT_)                                                                                  \
     do {                                                                                               \
+        static bool once = (hipFuncSetAttribute((const void*)posatt_rows_kernel<CT_, MODE, true>,      \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, 98304),    \
+                            hipFuncSetAttribute((const void*)posatt_rows_kernel<CT_, MODE, false>,     \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, 98304), true); \
+        (void)once;                                                                                    \
         if (a.masked) hipLaunchKernelGGL((posatt_rows_kernel<CT_, MODE, true>), grid, block, sm, s, a); \
         else hipLaunchKernelGGL((posatt_rows_kernel<CT_, MODE, false>), grid, block, sm, s, a);        \
     } while (0)
@@ -507,12 +506,18 @@ void launch_cols(const AttArgs& a0, hipStream_t s) {
     int ct = choose_ct(a.ncols, (long)j_tiles * a.mesh_batch);
     if (int f = env_int("PIT_FORCE_CT")) ct = f;
     a.colgroups = (a.ncols + 32 * ct - 1) / (32 * ct);
-    int nwaves = max(1, min(ct == 4 ? 4 : 8, pow2_floor(a.n_out / 64)));
-    if (int f = env_int("PIT_FORCE_WAVES")) nwaves = min(f, ct == 4 ? 4 : 8);
+    const int wmax = (ct == 4) ? 4 : 8;
+    int nwaves = max(1, min(wmax, pow2_floor(a.n_out * a.n_head / 32)));
+    if (int f = env_int("PIT_FORCE_WAVES")) nwaves = min(f, wmax);
     dim3 grid(j_tiles, a.colgroups, a.mesh_batch), block(64 * nwaves);
     const size_t sm = cols_smem(ct, nwaves, a.n_out);
 #define PIT_COLS(CT_)                                                                             \
     do {                                                                                          \
+        static bool once = (hipFuncSetAttribute((const void*)posatt_cols_kernel<CT_, true>,       \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, 98304), \
+                            hipFuncSetAttribute((const void*)posatt_cols_kernel<CT_, false>,      \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, 98304), true); \
+        (void)once;                                                                               \
         if (a.masked) hipLaunchKernelGGL((posatt_cols_kernel<CT_, true>), grid, block, sm, s, a);  \
         else hipLaunchKernelGGL((posatt_cols_kernel<CT_, false>), grid, block, sm, s, a);         \
     } while (0)

@@ -254,3 +254,27 @@ def test_full_size_properties(ops, task, batch):
     lhs = float((d_o.double() * o.detach().double()).sum())
     rhs = float((u.grad.double() * u.detach().double()).sum())
     assert abs(lhs - rhs) <= 1e-5 * max(abs(lhs), 1.0)
+
+
+@pytest.mark.parametrize("n_out,n_in,q", [(70, 5000, 0.01), (40, 9000, 0.002)])
+def test_long_rows_stream_select_and_chunked_keys(ops, n_out, n_in, q):
+    """J > 4096 (zero-shot super-resolution regime, train_darcy.py:152-178): the streaming
+    select kernel and the multi-chunk key loop, against the oracle on the same inputs."""
+    mo = torch.from_numpy(gio.synth((n_out, 2), 41, 0.0, 1.0))
+    mi = torch.from_numpy(gio.synth((n_in, 2), 42, 0.0, 1.0))
+    u = torch.from_numpy(gio.synth((2, n_in, 5), 43))
+    c = torch.tensor([1.7, 4.2]).reshape(2, 1, 1)
+    plan = ops.MeshPlan("euclid", mo.cuda(), mi.cuda(), q, False)
+    m = orc.sqdist_euclid(mo, mi)
+    mk, mk1, mmin = orc.row_order_stats(m, q)
+    st = plan.stats.cpu()
+    assert torch.equal(st[0, 0], mk) and torch.equal(st[1, 0], mk1) and torch.equal(st[2, 0], mmin)
+    ug = u.cuda().requires_grad_(True)
+    out = ops.posatt_apply(ug, c.reshape(-1).cuda(), plan, 2, False, head_is_scale=True)
+    uc = u.clone().requires_grad_(True)
+    ref = orc.posatt_cross("euclid", False, mo, mi, uc, None, q, c=c)
+    d_out = torch.from_numpy(gio.synth(tuple(ref.shape), 44))
+    ref.backward(d_out)
+    out.backward(d_out.cuda())
+    assert gio.rel_l2(ref.detach().numpy(), out.detach().cpu().numpy()) <= TOL_FWD
+    assert gio.rel_l2(uc.grad.numpy(), ug.grad.cpu().numpy()) <= TOL_GRAD
