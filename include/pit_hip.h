@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define PIT_ABI_VERSION 2
+#define PIT_ABI_VERSION 3
 #define PIT_DSCALE_SLOTS 32   /* fp64 accumulators per head in pit_posatt_bwd's workspace */
 
 /* distance metric (dist2att variants) */
@@ -56,6 +56,20 @@ int pit_select_fwd(const float* mesh_out, const float* mesh_in, int mesh_batch, 
                    int space_dim, int metric, float period, int rank_k, int need_kth,
                    float* stats, void* stream);
 
+/* Candidate lists for the masked layers (sparse path).  For every row: the keys with
+ * m <= m_(k+1)*(1+2^-21) - a superset of the kept set of pit.py:50 for ANY head scale (k+2 keys
+ * plus ties), so it depends on the meshes only.  nbr_idx (rows, cap) int32, nbr_cnt (rows) int32
+ * holds the TRUE count (a row with count > cap is truncated and consumers scan all keys for it).
+ * stats: from pit_select_fwd with need_kth=1. */
+int pit_neighbors_fwd(const float* mesh_out, const float* mesh_in, int mesh_batch, int n_out, int n_in,
+                      int space_dim, int metric, float period, const float* stats, int cap,
+                      int* nbr_idx, int* nbr_cnt, void* stream);
+/* Transposed lists (key -> rows listing it) as CSR per mesh sample, for d(values):
+ * rev_ptr (mesh_batch, n_in+1), rev_row (mesh_batch, n_out*cap) row indices local to the sample;
+ * workspace: 2*mesh_batch*n_in ints.  Rows with count > cap are left out (handled densely). */
+int pit_neighbors_transpose(const int* nbr_idx, const int* nbr_cnt, int mesh_batch, int n_out, int n_in,
+                            int cap, int* rev_ptr, int* rev_row, int* workspace, void* stream);
+
 /* Fused dist2att + convolution forward (pit.py:46-57 / 133-144 and the periodic
  * variants; posatt.forward :37-44 with copy_inputs, posatt_cross*.forward :63-71).
  *   values   (batch, n_in, dim)   rows ld_values apart, samples values_bstride apart
@@ -66,14 +80,17 @@ int pit_select_fwd(const float* mesh_out, const float* mesh_in, int mesh_batch, 
  *            column out_col0 + h*dim + d; with copy_inputs=1 (self attention, n_out ==
  *            n_in) values[b,n,:] is also copied to columns [0,dim) -> torch.cat of :44
  *   rowstat  (mesh_batch, n_head, n_out, 4) = {T, S_min, 1/rowsum, sum_j P*m} saved for
- *            the backward; scale_out (n_head) receives the c that was used. */
+ *            the backward; scale_out (n_head) receives the c that was used.
+ *   nbr_idx/nbr_cnt/nbr_cap: candidate lists from pit_neighbors_fwd (masked layers); NULL = the
+ *            dense MFMA kernel.  With lists the layer costs O(n_out * k * columns). */
 int pit_posatt_fwd(const float* mesh_out, const float* mesh_in, int mesh_batch, int n_out, int n_in,
                    int space_dim, int metric, float period,
                    const float* values, int batch, int dim, long ld_values, long values_bstride,
                    const float* head, int n_head, int head_is_scale,
                    const float* stats, float rank_w, int masked, int self_attn,
                    float* out, long ld_out, long out_bstride, int out_col0, int copy_inputs,
-                   float* rowstat, float* scale_out, void* stream);
+                   float* rowstat, float* scale_out,
+                   const int* nbr_idx, const int* nbr_cnt, int nbr_cap, void* stream);
 
 /* Backward of pit_posatt_fwd (closed form; the reference uses
  * autograd).  d_out has the layout of `out` (columns out_col0 + h*dim + d).
@@ -93,7 +110,9 @@ int pit_posatt_bwd(const float* mesh_out, const float* mesh_in, int mesh_batch, 
                    const float* rowstat, int masked,
                    const float* d_out, long ld_dout, long dout_bstride, int out_col0,
                    float* d_values, long ld_dvalues, long dvalues_bstride, int add_residual,
-                   float* d_head, int accumulate_head, double* workspace, void* stream);
+                   float* d_head, int accumulate_head, double* workspace,
+                   const int* nbr_idx, const int* nbr_cnt, int nbr_cap,
+                   const int* rev_ptr, const int* rev_row, void* stream);
 
 /* kaiming_mlp.forward (pit.py:21-26): y = W2 * gelu_erf(W1 x + b1) + b2, optionally
  * followed by the trailing gelu of pit.py:111,121 (out_gelu=1).

@@ -527,6 +527,320 @@ void launch_cols(const AttArgs& a0, hipStream_t s) {
 #undef PIT_COLS
 }
 
+// ------------------------------------------------------------------------------------
+// Sparse path for the masked (locality < 1) layers: O(N*k) instead of O(N*J).
+//
+// pit_neighbors_fwd gives every row a candidate list that is a superset of its kept set for any
+// head scale (k+2 keys plus ties).  One wavefront owns one output row: lanes evaluate the exact
+// mask / weights on the candidates (lane = candidate), then the kept candidates are walked in
+// groups of G with lane = value column (64*CR columns per wave, all loads of a group in flight),
+// accumulating with plain FMAs - with ~10-40 keys per row there is no contraction worth an MFMA.
+// Rows whose list overflowed (count > cap: heavy ties / duplicate points) scan all keys instead.
+// d(values) walks the transposed lists (key -> rows); overflowed rows are added with atomics.
+struct SparseArgs {
+    const int* nbr_idx; const int* nbr_cnt; int cap;
+    const int* rev_ptr; const int* rev_row; long rev_stride;
+};
+
+template <int NH, int CR, int MODE>
+__global__ __launch_bounds__(256) void posatt_sparse_rows(AttArgs a, SparseArgs sp) {
+    constexpr int G = (CR >= 4) ? 4 : 8;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long rows_total = (long)a.mesh_batch * a.n_out;
+    const long row = (long)blockIdx.x * 4 + wave;
+    if (row >= rows_total) return;
+    const int mb = (int)(row / a.n_out), n = (int)(row - (long)mb * a.n_out);
+    const int cblk = blockIdx.y, h0 = blockIdx.z * NH;
+
+    const unsigned mo_bytes = (unsigned)((long)a.mesh_batch * a.n_out * a.sdim * 4);
+    const unsigned mi_bytes = (unsigned)((long)a.mesh_batch * a.n_in * a.sdim * 4);
+    const __amdgpu_buffer_rsrc_t rmo = make_rsrc(a.mesh_out, mo_bytes);
+    const __amdgpu_buffer_rsrc_t rmi = make_rsrc(a.mesh_in, mi_bytes);
+    const __amdgpu_buffer_rsrc_t rvals = make_rsrc(a.values, a.values_bytes);
+    const unsigned ld4 = (unsigned)a.ld_values * 4u;
+    const float4 xo = load_point4(rmo, mo_bytes, row, a.sdim, a.coords_used);
+
+    float c[NH], T[NH], smin[NH], invl[NH], mbar[NH];
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+        c[h] = a.head_is_scale ? a.head[h0 + h] : head_scale_from_lmda(a.head[h0 + h]);
+        if (MODE == 0) {
+            T[h] = quantile_lerp(__fmul_rn(c[h], a.stats[row]), __fmul_rn(c[h], a.stats[rows_total + row]), a.rank_w);
+            smin[h] = __fmul_rn(c[h], a.stats[2 * rows_total + row]);
+            invl[h] = 0.0f; mbar[h] = 0.0f;
+        } else {
+            const float4 rs4 = *reinterpret_cast<const float4*>(a.rowstat + (((long)mb * a.n_head + h0 + h) * a.n_out + n) * 4);
+            T[h] = rs4.x; smin[h] = rs4.y; invl[h] = rs4.z; mbar[h] = rs4.w;
+        }
+    }
+    unsigned uoff[CR];
+    bool cvalid[CR];
+    int cb[CR], cd[CR];
+#pragma unroll
+    for (int r = 0; r < CR; ++r) {
+        const int col = cblk * 64 * CR + r * 64 + lane;
+        cvalid[r] = col < a.ncols;
+        const int cc = cvalid[r] ? col : 0;
+        cb[r] = (a.mesh_batch == 1) ? cc / a.dim : mb;
+        cd[r] = (a.mesh_batch == 1) ? cc % a.dim : cc;
+        uoff[r] = (unsigned)(((long)cb[r] * a.values_bstride + cd[r]) * 4);
+    }
+    float acc[NH][CR];
+    float rsum[NH], qsum[NH];
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+        rsum[h] = 0.0f; qsum[h] = 0.0f;
+#pragma unroll
+        for (int r = 0; r < CR; ++r) acc[h][r] = 0.0f;
+    }
+    const bool per = a.periodic != 0;
+    const int cnt = sp.nbr_cnt[row];
+    const bool scan_all = cnt > sp.cap;
+    const int total = scan_all ? a.n_in : cnt;
+    const int* list = sp.nbr_idx + row * sp.cap;
+
+    for (int base = 0; base < total; base += 64) {
+        const int i = base + lane;
+        const bool valid = i < total;
+        const int j = valid ? (scan_all ? i : list[i]) : 0;
+        const float4 xi = load_point4(rmi, mi_bytes, (long)mb * a.n_in + j, a.sdim, a.coords_used);
+        const float m = sq_dist3(xo.x, xo.y, xo.z, xi.x, xi.y, xi.z, per, a.period);
+        float p[NH];
+        bool any = false;
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+            const float sv = __fmul_rn(m, c[h]);
+            const bool keep = valid && (sv <= T[h]);
+            float pv = keep ? __expf(smin[h] - sv) : 0.0f;
+            if (MODE == 0) { rsum[h] += pv; qsum[h] += pv * m; }
+            else pv = pv * (m - mbar[h]) * invl[h];
+            p[h] = pv;
+            any |= keep;
+        }
+        unsigned long long mask = __builtin_amdgcn_ballot_w64(any);
+        while (mask) {
+            int ji[G];
+            float pi[NH][G];
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const bool has = mask != 0ull;
+                const int src = has ? __builtin_ctzll(mask) : 0;
+                if (has) mask &= mask - 1ull;
+                ji[g] = has ? __builtin_amdgcn_readlane(j, src) : -1;
+#pragma unroll
+                for (int h = 0; h < NH; ++h) {
+                    const float pv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p[h]), src));
+                    pi[h][g] = has ? pv : 0.0f;
+                }
+            }
+            float v[G][CR];
+#pragma unroll
+            for (int g = 0; g < G; ++g)
+#pragma unroll
+                for (int r = 0; r < CR; ++r)
+                    v[g][r] = buf_load(rvals, (ji[g] >= 0 && cvalid[r]) ? uoff[r] + (unsigned)ji[g] * ld4 : a.values_bytes);
+#pragma unroll
+            for (int g = 0; g < G; ++g)
+#pragma unroll
+                for (int h = 0; h < NH; ++h)
+#pragma unroll
+                    for (int r = 0; r < CR; ++r) acc[h][r] += pi[h][g] * v[g][r];
+        }
+    }
+
+    if (MODE == 1) {
+        const __amdgpu_buffer_rsrc_t rdo = make_rsrc(a.d_out, a.dout_bytes);
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+            double part = 0.0;
+#pragma unroll
+            for (int r = 0; r < CR; ++r) {
+                const unsigned off = (unsigned)(((long)cb[r] * a.dout_bstride + a.out_col0 + (long)(h0 + h) * a.dim + cd[r]) * 4) +
+                                     (unsigned)n * (unsigned)a.ld_dout * 4u;
+                part += (double)acc[h][r] * (double)buf_load(rdo, cvalid[r] ? off : a.dout_bytes);
+            }
+            part = wave_sum_d(part);
+            const int slot = (int)(row & (PIT_DSCALE_SLOTS - 1));
+            if (lane == 0) atomicAdd(a.dscale_acc + (h0 + h) * PIT_DSCALE_SLOTS + slot, -part);
+        }
+        return;
+    }
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+        const float rs = wave_sum(rsum[h]);
+        const float qs = wave_sum(qsum[h]);
+        const float inv = rs > 0.0f ? 1.0f / rs : 0.0f;
+#pragma unroll
+        for (int r = 0; r < CR; ++r)
+            if (cvalid[r])
+                a.out[(long)cb[r] * a.out_bstride + (long)n * a.ld_out + a.out_col0 + (long)(h0 + h) * a.dim + cd[r]] = acc[h][r] * inv;
+        if (cblk == 0 && lane == 0) {
+            float4 st; st.x = T[h]; st.y = smin[h]; st.z = inv; st.w = qs * inv;
+            *reinterpret_cast<float4*>(a.rowstat + (((long)mb * a.n_head + h0 + h) * a.n_out + n) * 4) = st;
+            if (a.scale_out && row == 0) a.scale_out[h0 + h] = c[h];
+        }
+    }
+    if (a.copy_inputs && h0 == 0) {
+#pragma unroll
+        for (int r = 0; r < CR; ++r) {
+            const float iv = buf_load(rvals, cvalid[r] ? uoff[r] + (unsigned)n * ld4 : a.values_bytes);
+            if (cvalid[r]) a.out[(long)cb[r] * a.out_bstride + (long)n * a.ld_out + cd[r]] = iv;
+        }
+    }
+}
+
+template <int CR>
+__global__ __launch_bounds__(256) void posatt_sparse_cols(AttArgs a, SparseArgs sp) {
+    constexpr int G = (CR >= 4) ? 4 : 8;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long keys_total = (long)a.mesh_batch * a.n_in;
+    const long kid = (long)blockIdx.x * 4 + wave;
+    if (kid >= keys_total) return;
+    const int mb = (int)(kid / a.n_in), j = (int)(kid - (long)mb * a.n_in);
+    const int cblk = blockIdx.y;
+    const unsigned mo_bytes = (unsigned)((long)a.mesh_batch * a.n_out * a.sdim * 4);
+    const unsigned mi_bytes = (unsigned)((long)a.mesh_batch * a.n_in * a.sdim * 4);
+    const __amdgpu_buffer_rsrc_t rmo = make_rsrc(a.mesh_out, mo_bytes);
+    const __amdgpu_buffer_rsrc_t rmi = make_rsrc(a.mesh_in, mi_bytes);
+    const __amdgpu_buffer_rsrc_t rdout = make_rsrc(a.d_out, a.dout_bytes);
+    const unsigned ldd4 = (unsigned)a.ld_dout * 4u;
+    const float4 xi = load_point4(rmi, mi_bytes, kid, a.sdim, a.coords_used);
+    unsigned doff[CR];
+    bool cvalid[CR];
+    int cb[CR], cd[CR];
+#pragma unroll
+    for (int r = 0; r < CR; ++r) {
+        const int col = cblk * 64 * CR + r * 64 + lane;
+        cvalid[r] = col < a.ncols;
+        const int cc = cvalid[r] ? col : 0;
+        cb[r] = (a.mesh_batch == 1) ? cc / a.dim : mb;
+        cd[r] = (a.mesh_batch == 1) ? cc % a.dim : cc;
+        doff[r] = (unsigned)(((long)cb[r] * a.dout_bstride + a.out_col0 + cd[r]) * 4);
+    }
+    float acc[CR];
+#pragma unroll
+    for (int r = 0; r < CR; ++r) acc[r] = 0.0f;
+    const bool per = a.periodic != 0;
+    const int beg = sp.rev_ptr[(long)mb * (a.n_in + 1) + j], end = sp.rev_ptr[(long)mb * (a.n_in + 1) + j + 1];
+    const int* rrow = sp.rev_row + (long)mb * sp.rev_stride;
+
+    for (int h = 0; h < a.n_head; ++h) {
+        const float c = a.head_is_scale ? a.head[h] : head_scale_from_lmda(a.head[h]);
+        const unsigned hoff = (unsigned)h * (unsigned)a.dim * 4u;
+        for (int base = beg; base < end; base += 64) {
+            const int e = base + lane;
+            const bool valid = e < end;
+            const int nrow = valid ? rrow[e] : 0;
+            const float4 xo = load_point4(rmo, mo_bytes, (long)mb * a.n_out + nrow, a.sdim, a.coords_used);
+            const float4 rs4 = *reinterpret_cast<const float4*>(a.rowstat + (((long)mb * a.n_head + h) * a.n_out + nrow) * 4);
+            const float m = sq_dist3(xo.x, xo.y, xo.z, xi.x, xi.y, xi.z, per, a.period);
+            const float sv = __fmul_rn(m, c);
+            const bool keep = valid && (sv <= rs4.x);
+            const float p = keep ? __expf(rs4.y - sv) * rs4.z : 0.0f;
+            unsigned long long mask = __builtin_amdgcn_ballot_w64(keep);
+            while (mask) {
+                int ni[G];
+                float pi[G];
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    const bool has = mask != 0ull;
+                    const int src = has ? __builtin_ctzll(mask) : 0;
+                    if (has) mask &= mask - 1ull;
+                    ni[g] = has ? __builtin_amdgcn_readlane(nrow, src) : -1;
+                    const float pv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p), src));
+                    pi[g] = has ? pv : 0.0f;
+                }
+                float v[G][CR];
+#pragma unroll
+                for (int g = 0; g < G; ++g)
+#pragma unroll
+                    for (int r = 0; r < CR; ++r)
+                        v[g][r] = buf_load(rdout, (ni[g] >= 0 && cvalid[r]) ? doff[r] + hoff + (unsigned)ni[g] * ldd4 : a.dout_bytes);
+#pragma unroll
+                for (int g = 0; g < G; ++g)
+#pragma unroll
+                    for (int r = 0; r < CR; ++r) acc[r] += pi[g] * v[g][r];
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < CR; ++r) {
+        const unsigned roff = (unsigned)(((long)cb[r] * a.dout_bstride + cd[r]) * 4) + (unsigned)j * ldd4;
+        const float res = buf_load(rdout, (a.add_residual && cvalid[r]) ? roff : a.dout_bytes);
+        if (cvalid[r]) a.d_values[(long)cb[r] * a.dvalues_bstride + (long)j * a.ld_dvalues + cd[r]] = acc[r] + res;
+    }
+}
+
+// rows whose candidate list overflowed are not in the transposed lists: add their contribution
+// to d(values) with atomics (rare: duplicated points / massive ties).
+__global__ __launch_bounds__(256) void posatt_sparse_overflow_cols(AttArgs a, SparseArgs sp) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long rows_total = (long)a.mesh_batch * a.n_out;
+    const long row = (long)blockIdx.x * 4 + wave;
+    if (row >= rows_total) return;
+    if (sp.nbr_cnt[row] <= sp.cap) return;
+    const int mb = (int)(row / a.n_out), n = (int)(row - (long)mb * a.n_out);
+    const unsigned mo_bytes = (unsigned)((long)a.mesh_batch * a.n_out * a.sdim * 4);
+    const unsigned mi_bytes = (unsigned)((long)a.mesh_batch * a.n_in * a.sdim * 4);
+    const __amdgpu_buffer_rsrc_t rmo = make_rsrc(a.mesh_out, mo_bytes);
+    const __amdgpu_buffer_rsrc_t rmi = make_rsrc(a.mesh_in, mi_bytes);
+    const float4 xo = load_point4(rmo, mo_bytes, row, a.sdim, a.coords_used);
+    const bool per = a.periodic != 0;
+    for (int h = 0; h < a.n_head; ++h) {
+        const float c = a.head_is_scale ? a.head[h] : head_scale_from_lmda(a.head[h]);
+        const float4 rs4 = *reinterpret_cast<const float4*>(a.rowstat + (((long)mb * a.n_head + h) * a.n_out + n) * 4);
+        for (int base = 0; base < a.n_in; base += 64) {
+            const int j = base + lane;
+            const bool valid = j < a.n_in;
+            const float4 xi = load_point4(rmi, mi_bytes, (long)mb * a.n_in + (valid ? j : 0), a.sdim, a.coords_used);
+            const float m = sq_dist3(xo.x, xo.y, xo.z, xi.x, xi.y, xi.z, per, a.period);
+            const float sv = __fmul_rn(m, c);
+            const bool keep = valid && (sv <= rs4.x);
+            const float p = keep ? __expf(rs4.y - sv) * rs4.z : 0.0f;
+            unsigned long long mask = __builtin_amdgcn_ballot_w64(keep);
+            while (mask) {
+                const int src = __builtin_ctzll(mask);
+                mask &= mask - 1ull;
+                const int jj = __builtin_amdgcn_readlane(j, src);
+                const float pv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p), src));
+                for (int col = lane; col < a.ncols; col += 64) {
+                    const int bb = (a.mesh_batch == 1) ? col / a.dim : mb;
+                    const int dd = (a.mesh_batch == 1) ? col % a.dim : col;
+                    const float g = a.d_out[(long)bb * a.dout_bstride + (long)n * a.ld_dout + a.out_col0 + (long)h * a.dim + dd];
+                    atomicAdd(a.d_values + (long)bb * a.dvalues_bstride + (long)jj * a.ld_dvalues + dd, pv * g);
+                }
+            }
+        }
+    }
+}
+
+int cr_for(int ncols) { return ncols > 256 ? 8 : (ncols > 128 ? 4 : (ncols > 64 ? 2 : 1)); }
+
+template <int MODE>
+void launch_sparse_rows(const AttArgs& a, const SparseArgs& sp, hipStream_t s) {
+    const int cr = cr_for(a.ncols);
+    const int nh = (a.n_head % 2 == 0) ? 2 : 1;
+    const long rows = (long)a.mesh_batch * a.n_out;
+    dim3 grid((unsigned)((rows + 3) / 4), (a.ncols + 64 * cr - 1) / (64 * cr), a.n_head / nh), block(256);
+#define PIT_SR(NH_, CR_) hipLaunchKernelGGL((posatt_sparse_rows<NH_, CR_, MODE>), grid, block, 0, s, a, sp)
+#define PIT_SR_CR(NH_) do { if (cr == 8) PIT_SR(NH_, 8); else if (cr == 4) PIT_SR(NH_, 4); else if (cr == 2) PIT_SR(NH_, 2); else PIT_SR(NH_, 1); } while (0)
+    if (nh == 2) PIT_SR_CR(2); else PIT_SR_CR(1);
+#undef PIT_SR_CR
+#undef PIT_SR
+}
+
+void launch_sparse_cols(const AttArgs& a, const SparseArgs& sp, hipStream_t s) {
+    const int cr = cr_for(a.ncols);
+    const long keys = (long)a.mesh_batch * a.n_in;
+    dim3 grid((unsigned)((keys + 3) / 4), (a.ncols + 64 * cr - 1) / (64 * cr)), block(256);
+    if (cr == 8) hipLaunchKernelGGL((posatt_sparse_cols<8>), grid, block, 0, s, a, sp);
+    else if (cr == 4) hipLaunchKernelGGL((posatt_sparse_cols<4>), grid, block, 0, s, a, sp);
+    else if (cr == 2) hipLaunchKernelGGL((posatt_sparse_cols<2>), grid, block, 0, s, a, sp);
+    else hipLaunchKernelGGL((posatt_sparse_cols<1>), grid, block, 0, s, a, sp);
+    const long rows = (long)a.mesh_batch * a.n_out;
+    hipLaunchKernelGGL(posatt_sparse_overflow_cols, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, a, sp);
+}
+
 int fill_common(AttArgs& a, const float* mesh_out, const float* mesh_in, int mesh_batch, int n_out, int n_in,
                 int space_dim, int metric, float period, const float* values, int batch, int dim,
                 long ld_values, long values_bstride, const float* head, int n_head, int head_is_scale) {
@@ -559,7 +873,8 @@ extern "C" int pit_posatt_fwd(const float* mesh_out, const float* mesh_in, int m
                               const float* head, int n_head, int head_is_scale,
                               const float* stats, float rank_w, int masked, int self_attn,
                               float* out, long ld_out, long out_bstride, int out_col0, int copy_inputs,
-                              float* rowstat, float* scale_out, void* stream) {
+                              float* rowstat, float* scale_out,
+                              const int* nbr_idx, const int* nbr_cnt, int nbr_cap, void* stream) {
     AttArgs a;
     int rc = fill_common(a, mesh_out, mesh_in, mesh_batch, n_out, n_in, space_dim, metric, period, values, batch,
                          dim, ld_values, values_bstride, head, n_head, head_is_scale);
@@ -570,7 +885,12 @@ extern "C" int pit_posatt_fwd(const float* mesh_out, const float* mesh_in, int m
     a.stats = stats; a.rank_w = rank_w; a.masked = masked;
     a.out = out; a.ld_out = ld_out; a.out_bstride = out_bstride; a.out_col0 = out_col0; a.copy_inputs = copy_inputs;
     a.rowstat = rowstat; a.scale_out = scale_out;
-    launch_rows<0>(a, (hipStream_t)stream);
+    if (nbr_idx && nbr_cnt && masked) {
+        SparseArgs sp{nbr_idx, nbr_cnt, nbr_cap, nullptr, nullptr, 0};
+        launch_sparse_rows<0>(a, sp, (hipStream_t)stream);
+    } else {
+        launch_rows<0>(a, (hipStream_t)stream);
+    }
     PIT_CHECK_LAUNCH();
     return 0;
 }
@@ -582,7 +902,9 @@ extern "C" int pit_posatt_bwd(const float* mesh_out, const float* mesh_in, int m
                               const float* rowstat, int masked,
                               const float* d_out, long ld_dout, long dout_bstride, int out_col0,
                               float* d_values, long ld_dvalues, long dvalues_bstride, int add_residual,
-                              float* d_head, int accumulate_head, double* workspace, void* stream) {
+                              float* d_head, int accumulate_head, double* workspace,
+                              const int* nbr_idx, const int* nbr_cnt, int nbr_cap,
+                              const int* rev_ptr, const int* rev_row, void* stream) {
     AttArgs a;
     int rc = fill_common(a, mesh_out, mesh_in, mesh_batch, n_out, n_in, space_dim, metric, period, values, batch,
                          dim, ld_values, values_bstride, head, n_head, head_is_scale);
@@ -601,15 +923,17 @@ extern "C" int pit_posatt_bwd(const float* mesh_out, const float* mesh_in, int m
         if (db > PIT_MAX_BUFFER_BYTES) return PIT_ERR_UNSUPPORTED;
         a.dout_bytes = (unsigned)db;
     }
+    const bool sparse = masked && nbr_idx && nbr_cnt;
+    SparseArgs sp{nbr_idx, nbr_cnt, nbr_cap, rev_ptr, rev_row, (long)n_out * nbr_cap};
     if (d_head) {
-        launch_rows<1>(a, s);
+        if (sparse) launch_sparse_rows<1>(a, sp, s); else launch_rows<1>(a, s);
         PIT_CHECK_LAUNCH();
         hipLaunchKernelGGL(posatt_dhead_finish, dim3((n_head + 63) / 64), dim3(64), 0, s, workspace, head, n_head,
                            head_is_scale, accumulate_head, d_head);
         PIT_CHECK_LAUNCH();
     }
     if (d_values) {
-        launch_cols(a, s);
+        if (sparse && rev_ptr && rev_row) launch_sparse_cols(a, sp, s); else launch_cols(a, s);
         PIT_CHECK_LAUNCH();
     }
     return 0;

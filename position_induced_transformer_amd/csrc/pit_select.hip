@@ -169,6 +169,106 @@ void launch_reg(const SelectArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(select_rows_reg<ITEMS>, dim3(grid), dim3(256), 0, s, a);
 }
 
+// ------------------------------------------------------------------------------------
+// Candidate lists for the masked (locality < 1) layers.
+//
+// kept  <=>  fl(c*m) <= T  and  T <= fl(c*m_(k+1)),  so every kept key satisfies
+// fl(c*m) <= fl(c*m_(k+1)); with m > m_(k+1) that needs both products to round to the same
+// float, i.e. m <= m_(k+1)*(1+2^-22).  The list of keys with m <= m_(k+1)*(1+2^-21) is
+// therefore a superset of the kept set for EVERY head scale c, depends only on the meshes, and
+// has k+2 entries plus ties.  The sparse attention kernels evaluate the exact mask on it.
+// A row whose count exceeds `cap` keeps its true count (list truncated): consumers treat
+// count > cap as "scan all keys".
+__global__ __launch_bounds__(256) void neighbors_kernel(SelectArgs a, int cap, int* __restrict__ nbr_idx,
+                                                        int* __restrict__ nbr_cnt) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const long rows = (long)a.mesh_batch * a.n_out;
+    const long row = (long)blockIdx.x * 4 + wave;
+    if (row >= rows) return;
+    const int mb = (int)(row / a.n_out);
+    const float* po = a.mesh_out + row * a.sdim;
+    const float* pin = a.mesh_in + (long)mb * a.n_in * a.sdim;
+    float ox, oy, oz;
+    load_point(po, a.sdim, a.coords_used, ox, oy, oz);
+    const float bound = a.stats[rows + row] * 1.00000047683715820312f;     // m_(k+1) * (1 + 2^-21)
+    int total = 0;
+    int* out = nbr_idx + row * cap;
+    for (int j0 = 0; j0 < a.n_in; j0 += 64) {
+        const int j = j0 + lane;
+        bool in = false;
+        if (j < a.n_in) {
+            float ix, iy, iz;
+            load_point(pin + (long)j * a.sdim, a.sdim, a.coords_used, ix, iy, iz);
+            in = sq_dist3(ox, oy, oz, ix, iy, iz, a.periodic != 0, a.period) <= bound;
+        }
+        const unsigned long long mask = __builtin_amdgcn_ballot_w64(in);
+        const int pos = total + __popcll(mask & ((1ull << lane) - 1ull));
+        if (in && pos < cap) out[pos] = j;
+        total += __popcll(mask);
+    }
+    if (lane == 0) nbr_cnt[row] = total;
+}
+
+// reverse lists (key -> rows that list it), CSR per mesh sample: count, scan, fill
+__global__ void nbr_count_kernel(const int* __restrict__ nbr_idx, const int* __restrict__ nbr_cnt, long rows,
+                                 int n_out, int n_in, int cap, int* __restrict__ counts) {
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= rows * cap) return;
+    const long row = e / cap;
+    const int i = (int)(e - row * cap);
+    const int cnt = nbr_cnt[row];
+    if (cnt > cap || i >= cnt) return;                    // overflow rows are handled densely
+    const int mb = (int)(row / n_out);
+    atomicAdd(counts + (long)mb * n_in + nbr_idx[e], 1);
+}
+
+__global__ __launch_bounds__(256) void nbr_scan_kernel(const int* __restrict__ counts, int n_in,
+                                                       int* __restrict__ rev_ptr, int* __restrict__ cursor) {
+    // one workgroup per mesh sample: exclusive scan of counts[mb][0..n_in) -> rev_ptr[mb][0..n_in]
+    __shared__ int s_part[256];
+    __shared__ int s_carry;
+    const int mb = blockIdx.x;
+    const int* c = counts + (long)mb * n_in;
+    int* p = rev_ptr + (long)mb * (n_in + 1);
+    int* cur = cursor + (long)mb * n_in;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    for (int base = 0; base < n_in; base += 256) {
+        const int j = base + threadIdx.x;
+        const int v = (j < n_in) ? c[j] : 0;
+        s_part[threadIdx.x] = v;
+        __syncthreads();
+        for (int off = 1; off < 256; off <<= 1) {          // Hillis-Steele inclusive scan
+            const int t = (threadIdx.x >= off) ? s_part[threadIdx.x - off] : 0;
+            __syncthreads();
+            s_part[threadIdx.x] += t;
+            __syncthreads();
+        }
+        const int incl = s_part[threadIdx.x];
+        const int carry = s_carry;
+        if (j < n_in) { p[j] = carry + incl - v; cur[j] = carry + incl - v; }
+        __syncthreads();
+        if (threadIdx.x == 255) s_carry = carry + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) p[n_in] = s_carry;
+}
+
+__global__ void nbr_fill_kernel(const int* __restrict__ nbr_idx, const int* __restrict__ nbr_cnt, long rows,
+                                int n_out, int n_in, int cap, int* __restrict__ cursor, int* __restrict__ rev_row,
+                                long rev_stride) {
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= rows * cap) return;
+    const long row = e / cap;
+    const int i = (int)(e - row * cap);
+    const int cnt = nbr_cnt[row];
+    if (cnt > cap || i >= cnt) return;
+    const int mb = (int)(row / n_out);
+    const int pos = atomicAdd(cursor + (long)mb * n_in + nbr_idx[e], 1);
+    rev_row[(long)mb * rev_stride + pos] = (int)(row - (long)mb * n_out);
+}
+
 __global__ void head_scale_kernel(const float* lmda, int n_head, float* out) {
     const int h = blockIdx.x * blockDim.x + threadIdx.x;
     if (h < n_head) out[h] = head_scale_from_lmda(lmda[h]);
@@ -211,6 +311,46 @@ extern "C" int pit_select_fwd(const float* mesh_out, const float* mesh_in, int m
         const long rows = (long)mesh_batch * n_out;
         hipLaunchKernelGGL(select_rows_stream, dim3((unsigned)rows), dim3(256), 0, s, a);
     }
+    PIT_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pit_neighbors_fwd(const float* mesh_out, const float* mesh_in, int mesh_batch, int n_out, int n_in,
+                                 int space_dim, int metric, float period, const float* stats, int cap,
+                                 int* nbr_idx, int* nbr_cnt, void* stream) {
+    if (!mesh_out || !mesh_in || !stats || !nbr_idx || !nbr_cnt) return PIT_ERR_NULL;
+    if (mesh_batch <= 0 || n_out <= 0 || n_in <= 0 || space_dim < 1 || space_dim > 3 || cap <= 0) return PIT_ERR_SIZE;
+    if (metric < PIT_METRIC_EUCLID || metric > PIT_METRIC_PERIODIC2D) return PIT_ERR_METRIC;
+    SelectArgs a;
+    a.mesh_out = mesh_out; a.mesh_in = mesh_in; a.stats = const_cast<float*>(stats);
+    a.mesh_batch = mesh_batch; a.n_out = n_out; a.n_in = n_in; a.sdim = space_dim;
+    a.periodic = (metric != PIT_METRIC_EUCLID);
+    a.coords_used = (metric == PIT_METRIC_PERIODIC1D) ? 1 : space_dim;
+    a.period = period; a.rank_k = 0; a.need_kth = 1;
+    const long rows = (long)mesh_batch * n_out;
+    hipLaunchKernelGGL(neighbors_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a, cap,
+                       nbr_idx, nbr_cnt);
+    PIT_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pit_neighbors_transpose(const int* nbr_idx, const int* nbr_cnt, int mesh_batch, int n_out, int n_in,
+                                       int cap, int* rev_ptr, int* rev_row, int* workspace, void* stream) {
+    if (!nbr_idx || !nbr_cnt || !rev_ptr || !rev_row || !workspace) return PIT_ERR_NULL;
+    if (mesh_batch <= 0 || n_out <= 0 || n_in <= 0 || cap <= 0) return PIT_ERR_SIZE;
+    hipStream_t s = (hipStream_t)stream;
+    const long rows = (long)mesh_batch * n_out;
+    int* counts = workspace;                              // mesh_batch * n_in
+    int* cursor = workspace + (long)mesh_batch * n_in;    // mesh_batch * n_in
+    hipError_t e = hipMemsetAsync(counts, 0, sizeof(int) * (size_t)mesh_batch * n_in, s);
+    if (e != hipSuccess) return (int)e;
+    const unsigned blocks = (unsigned)((rows * cap + 255) / 256);
+    hipLaunchKernelGGL(nbr_count_kernel, dim3(blocks), dim3(256), 0, s, nbr_idx, nbr_cnt, rows, n_out, n_in, cap, counts);
+    PIT_CHECK_LAUNCH();
+    hipLaunchKernelGGL(nbr_scan_kernel, dim3(mesh_batch), dim3(256), 0, s, counts, n_in, rev_ptr, cursor);
+    PIT_CHECK_LAUNCH();
+    hipLaunchKernelGGL(nbr_fill_kernel, dim3(blocks), dim3(256), 0, s, nbr_idx, nbr_cnt, rows, n_out, n_in, cap, cursor,
+                       rev_row, (long)n_out * cap);
     PIT_CHECK_LAUNCH();
     return 0;
 }

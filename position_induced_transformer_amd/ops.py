@@ -31,6 +31,10 @@ FUSED_GRAD_ACCUMULATION = True
 # branches.
 OVERLAP_BACKWARD = True
 
+# Masked (locality < 1) layers run on per-row candidate lists (O(N*k) work) when the lists are
+# much shorter than the key axis; False forces the dense MFMA kernels everywhere.
+SPARSE_MASKED = True
+
 _DSCALE_WS = {}
 _SIDE = {}          # device index -> {"stream", "pending", "keep"}
 
@@ -119,7 +123,8 @@ class MeshPlan:
     (m_(k), m_(k+1), m_min per row).  Fixed meshes build it once and reuse it every step."""
 
     __slots__ = ("mesh_out", "mesh_in", "mesh_batch", "n_out", "n_in", "sdim", "metric", "metric_id", "period",
-                 "rank_k", "rank_w", "masked", "self_attn", "stats")
+                 "rank_k", "rank_w", "masked", "self_attn", "stats", "nbr_idx", "nbr_cnt", "nbr_cap", "rev_ptr",
+                 "rev_row")
 
     def __init__(self, metric: str, mesh_out: torch.Tensor, mesh_in: torch.Tensor, locality: float,
                  self_attn: bool, period: Optional[float] = None):
@@ -155,6 +160,33 @@ class MeshPlan:
                                            self.rank_k, 1 if self.masked else 0, self.stats.data_ptr(),
                                            _lib.stream_ptr())
             _lib.check(rc, "pit_select_fwd")
+        self.nbr_idx = self.nbr_cnt = self.rev_ptr = self.rev_row = None
+        self.nbr_cap = 0
+        if self.masked and SPARSE_MASKED:
+            want = self.rank_k + 2
+            cap = ((want + max(16, want // 4) + 15) // 16) * 16        # k+2 keys plus room for ties
+            if cap * 3 <= self.n_in:
+                self._build_lists(cap)
+
+    def _build_lists(self, cap: int) -> None:
+        """Candidate lists (row -> keys) and their transpose (key -> rows) for the sparse kernels."""
+        dev = self.mesh_out.device
+        rows = self.mesh_batch * self.n_out
+        L = _lib.lib()
+        self.nbr_cap = cap
+        self.nbr_idx = torch.empty((rows, cap), device=dev, dtype=torch.int32)
+        self.nbr_cnt = torch.empty((rows,), device=dev, dtype=torch.int32)
+        rc = L.pit_neighbors_fwd(self.mesh_out.data_ptr(), self.mesh_in.data_ptr(), self.mesh_batch, self.n_out,
+                                 self.n_in, self.sdim, self.metric_id, self.period, self.stats.data_ptr(), cap,
+                                 self.nbr_idx.data_ptr(), self.nbr_cnt.data_ptr(), _lib.stream_ptr())
+        _lib.check(rc, "pit_neighbors_fwd")
+        self.rev_ptr = torch.empty((self.mesh_batch, self.n_in + 1), device=dev, dtype=torch.int32)
+        self.rev_row = torch.empty((self.mesh_batch, self.n_out * cap), device=dev, dtype=torch.int32)
+        work = torch.empty((2 * self.mesh_batch * self.n_in,), device=dev, dtype=torch.int32)
+        rc = L.pit_neighbors_transpose(self.nbr_idx.data_ptr(), self.nbr_cnt.data_ptr(), self.mesh_batch, self.n_out,
+                                       self.n_in, cap, self.rev_ptr.data_ptr(), self.rev_row.data_ptr(),
+                                       work.data_ptr(), _lib.stream_ptr())
+        _lib.check(rc, "pit_neighbors_transpose")
 
 
 def _row_view(t: torch.Tensor) -> torch.Tensor:
@@ -193,7 +225,8 @@ class _PosAtt(torch.autograd.Function):
             head.data_ptr(), n_head, 1 if head_is_scale else 0,
             _lib.ptr(plan.stats), plan.rank_w, 1 if plan.masked else 0, 1 if plan.self_attn else 0,
             out.data_ptr(), out.stride(1), out.stride(0), d if concat else 0, 1 if concat else 0,
-            rowstat.data_ptr(), scale.data_ptr(), _lib.stream_ptr())
+            rowstat.data_ptr(), scale.data_ptr(),
+            _lib.ptr(plan.nbr_idx), _lib.ptr(plan.nbr_cnt), plan.nbr_cap, _lib.stream_ptr())
         _lib.check(rc, "pit_posatt_fwd")
         ctx.plan, ctx.n_head, ctx.concat, ctx.head_is_scale = plan, n_head, concat, head_is_scale
         ctx.head_param = head_param
@@ -227,7 +260,9 @@ class _PosAtt(torch.autograd.Function):
                 d_out.data_ptr(), d_out.stride(1), d_out.stride(0), d if concat else 0,
                 _lib.ptr(dv), dv.stride(1) if dv is not None else 0, dv.stride(0) if dv is not None else 0,
                 1 if concat else 0,
-                _lib.ptr(dh), acc_head, work.data_ptr(), stream_ptr)
+                _lib.ptr(dh), acc_head, work.data_ptr(),
+                _lib.ptr(plan.nbr_idx), _lib.ptr(plan.nbr_cnt), plan.nbr_cap,
+                _lib.ptr(plan.rev_ptr), _lib.ptr(plan.rev_row), stream_ptr)
             _lib.check(rc, "pit_posatt_bwd")
 
         if OVERLAP_BACKWARD and slot is not None:

@@ -20,11 +20,16 @@ MLP_CASES = gio.list_cases(("F8_",))
 TOL_FWD, TOL_GRAD, TOL_HEAD = 1e-6, 1e-5, 1e-4
 
 
-@pytest.fixture(scope="module")
-def ops():
+@pytest.fixture(scope="module", params=["sparse-masked", "dense-only"])
+def ops(request):
+    """Every test runs twice: masked layers on the candidate-list (sparse) kernels, and with the
+    dense MFMA kernels forced everywhere."""
     from position_induced_transformer_amd import ops as _ops
     assert torch.cuda.is_available()
-    return _ops
+    old = _ops.SPARSE_MASKED
+    _ops.SPARSE_MASKED = request.param == "sparse-masked"
+    yield _ops
+    _ops.SPARSE_MASKED = old
 
 
 def dev(x):
@@ -59,6 +64,11 @@ def test_mfma_fragment_layout(ops):
 def test_select_order_statistics(ops, name):
     fx, cs = load_case(name)
     plan = make_plan(ops, cs)
+    if plan.nbr_idx is not None:          # candidate lists: superset of every head's keep-set, k+2 + ties
+        cnt = plan.nbr_cnt.cpu().numpy().reshape(plan.mesh_batch, plan.n_out)
+        kc = fx["keep_count"].reshape(plan.mesh_batch, -1, plan.n_out)
+        assert (cnt[:, None, :] >= kc).all()
+        assert cnt.min() >= min(plan.rank_k + 2, plan.n_in)
     assert plan.rank_k == int(fx["rank_k"]) and np.float32(plan.rank_w) == fx["rank_w"]
     if cs["metric"] != "euclid":
         assert np.float32(plan.period) == fx["period"]
