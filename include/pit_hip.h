@@ -25,7 +25,7 @@ extern "C" {
 #endif
 
 #define PIT_ABI_VERSION 3
-#define PIT_DSCALE_SLOTS 32   /* fp64 accumulators per head in pit_posatt_bwd's workspace */
+#define PIT_DSCALE_SLOTS 1024 /* fp64 accumulators per head in pit_posatt_bwd's workspace */
 
 /* distance metric (dist2att variants) */
 #define PIT_METRIC_EUCLID     0   /* pit.py:47,134  sum_c (xo_c-xi_c)^2                         */
@@ -60,15 +60,14 @@ int pit_select_fwd(const float* mesh_out, const float* mesh_in, int mesh_batch, 
  * m <= m_(k+1)*(1+2^-21) - a superset of the kept set of pit.py:50 for ANY head scale (k+2 keys
  * plus ties), so it depends on the meshes only.  nbr_idx (rows, cap) int32, nbr_cnt (rows) int32
  * holds the TRUE count (a row with count > cap is truncated and consumers scan all keys for it).
- * stats: from pit_select_fwd with need_kth=1. */
+ * stats: from pit_select_fwd with need_kth=1.
+ * Optionally (rev_ptr != NULL) also the transposed lists (key -> rows listing it) as CSR per mesh
+ * sample, for d(values): rev_ptr (mesh_batch, n_in+1), rev_row (mesh_batch, n_out*cap) row
+ * indices local to the sample, -1 = unused slot; workspace: 2*mesh_batch*n_in ints.  Rows with
+ * count > cap are left out of the transpose (pit_posatt_bwd adds them densely). */
 int pit_neighbors_fwd(const float* mesh_out, const float* mesh_in, int mesh_batch, int n_out, int n_in,
                       int space_dim, int metric, float period, const float* stats, int cap,
-                      int* nbr_idx, int* nbr_cnt, void* stream);
-/* Transposed lists (key -> rows listing it) as CSR per mesh sample, for d(values):
- * rev_ptr (mesh_batch, n_in+1), rev_row (mesh_batch, n_out*cap) row indices local to the sample;
- * workspace: 2*mesh_batch*n_in ints.  Rows with count > cap are left out (handled densely). */
-int pit_neighbors_transpose(const int* nbr_idx, const int* nbr_cnt, int mesh_batch, int n_out, int n_in,
-                            int cap, int* rev_ptr, int* rev_row, int* workspace, void* stream);
+                      int* nbr_idx, int* nbr_cnt, int* rev_ptr, int* rev_row, int* workspace, void* stream);
 
 /* Fused dist2att + convolution forward (pit.py:46-57 / 133-144 and the periodic
  * variants; posatt.forward :37-44 with copy_inputs, posatt_cross*.forward :63-71).
@@ -96,6 +95,7 @@ int pit_posatt_fwd(const float* mesh_out, const float* mesh_in, int mesh_batch, 
  * autograd).  d_out has the layout of `out` (columns out_col0 + h*dim + d).
  *   d_values (batch, n_in, dim): written (NULL = not needed).  With add_residual=1 (self
  *            attention) the gradient of the copied inputs, d_out[b,j,0:dim], is added.
+ *   scale    the c written to scale_out by the forward (NULL = recompute from head)
  *   d_head   n_head floats (NULL = not needed): gradient w.r.t. lmda (head_is_scale=0) or
  *            w.r.t. c (=1); accumulate_head=1 adds to the current contents instead of writing.
  *   workspace: n_head*PIT_DSCALE_SLOTS doubles, fp64 accumulators for d c.  They must be ZERO
@@ -106,7 +106,7 @@ int pit_posatt_fwd(const float* mesh_out, const float* mesh_in, int mesh_batch, 
 int pit_posatt_bwd(const float* mesh_out, const float* mesh_in, int mesh_batch, int n_out, int n_in,
                    int space_dim, int metric, float period,
                    const float* values, int batch, int dim, long ld_values, long values_bstride,
-                   const float* head, int n_head, int head_is_scale,
+                   const float* head, int n_head, int head_is_scale, const float* scale,
                    const float* rowstat, int masked,
                    const float* d_out, long ld_dout, long dout_bstride, int out_col0,
                    float* d_values, long ld_dvalues, long dvalues_bstride, int add_residual,

@@ -24,8 +24,7 @@ SIGNATURES = {
     "pit_error_string": [_I],
     "pit_head_scale": [_P, _I, _P, _P],
     "pit_select_fwd": [_P, _P, _I, _I, _I, _I, _I, _F, _I, _I, _P, _P],
-    "pit_neighbors_fwd": [_P, _P, _I, _I, _I, _I, _I, _F, _P, _I, _P, _P, _P],
-    "pit_neighbors_transpose": [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P],
+    "pit_neighbors_fwd": [_P, _P, _I, _I, _I, _I, _I, _F, _P, _I, _P, _P, _P, _P, _P, _P],
     "pit_posatt_fwd": [_P, _P, _I, _I, _I, _I, _I, _F,
                        _P, _I, _I, _L, _L,
                        _P, _I, _I,
@@ -34,7 +33,7 @@ SIGNATURES = {
                        _P, _P, _P, _P, _I, _P],
     "pit_posatt_bwd": [_P, _P, _I, _I, _I, _I, _I, _F,
                        _P, _I, _I, _L, _L,
-                       _P, _I, _I,
+                       _P, _I, _I, _P,
                        _P, _I,
                        _P, _L, _L, _I,
                        _P, _L, _L, _I,

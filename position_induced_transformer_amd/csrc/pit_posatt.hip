@@ -239,7 +239,7 @@ __global__ __launch_bounds__(512) void posatt_rows_kernel(AttArgs a) {
             for (int i = 0; i < 16; ++i) part += (double)acc[t][i] * (double)dov[t][i];
         part = wave_sum_d(part);
         // PIT_DSCALE_SLOTS accumulators per head keep the fp64 atomics off a single address
-        const int slot = (blockIdx.x + 5 * blockIdx.z + wave) & (PIT_DSCALE_SLOTS - 1);
+        const int slot = (int)((blockIdx.x + 131u * blockIdx.z + 977u * wave) & (PIT_DSCALE_SLOTS - 1));
         if (lane == 0) atomicAdd(a.dscale_acc + h * PIT_DSCALE_SLOTS + slot, -part);
         return;
     }
@@ -425,18 +425,24 @@ __global__ __launch_bounds__(512) void posatt_cols_kernel(AttArgs a) {
     }
 }
 
-__global__ void posatt_dhead_finish(double* acc, const float* head, int n_head, int head_is_scale,
-                                    int accumulate, float* d_head) {
-    const int h = blockIdx.x * blockDim.x + threadIdx.x;
-    if (h >= n_head) return;
+__global__ __launch_bounds__(256) void posatt_dhead_finish(double* acc, const float* head, const float* scale,
+                                                           int head_is_scale, int accumulate, float* d_head) {
+    // one workgroup per head: sum (and clear) its PIT_DSCALE_SLOTS fp64 accumulators
+    __shared__ double s_part[4];
+    const int h = blockIdx.x;
     double g = 0.0;
-    for (int sl = 0; sl < PIT_DSCALE_SLOTS; ++sl) {
+    for (int sl = threadIdx.x; sl < PIT_DSCALE_SLOTS; sl += 256) {
         g += acc[h * PIT_DSCALE_SLOTS + sl];
         acc[h * PIT_DSCALE_SLOTS + sl] = 0.0;     // leave the accumulators clean for the next call
     }
+    g = wave_sum_d(g);
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = g;
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    g = s_part[0] + s_part[1] + s_part[2] + s_part[3];
     if (!head_is_scale) {
         const float lm = head[h];
-        g *= head_scale_grad(lm, head_scale_from_lmda(lm));
+        g *= head_scale_grad(lm, scale ? scale[h] : head_scale_from_lmda(lm));
     }
     d_head[h] = accumulate ? d_head[h] + (float)g : (float)g;
 }
@@ -660,7 +666,7 @@ __global__ __launch_bounds__(256) void posatt_sparse_rows(AttArgs a, SparseArgs 
                 part += (double)acc[h][r] * (double)buf_load(rdo, cvalid[r] ? off : a.dout_bytes);
             }
             part = wave_sum_d(part);
-            const int slot = (int)(row & (PIT_DSCALE_SLOTS - 1));
+            const int slot = (int)((blockIdx.x + 131u * blockIdx.y) & (PIT_DSCALE_SLOTS - 1));
             if (lane == 0) atomicAdd(a.dscale_acc + (h0 + h) * PIT_DSCALE_SLOTS + slot, -part);
         }
         return;
@@ -729,8 +735,9 @@ __global__ __launch_bounds__(256) void posatt_sparse_cols(AttArgs a, SparseArgs 
         const unsigned hoff = (unsigned)h * (unsigned)a.dim * 4u;
         for (int base = beg; base < end; base += 64) {
             const int e = base + lane;
-            const bool valid = e < end;
-            const int nrow = valid ? rrow[e] : 0;
+            int nrow = (e < end) ? rrow[e] : -1;
+            const bool valid = nrow >= 0;                   // -1: slot of a row that overflowed its list
+            nrow = valid ? nrow : 0;
             const float4 xo = load_point4(rmo, mo_bytes, (long)mb * a.n_out + nrow, a.sdim, a.coords_used);
             const float4 rs4 = *reinterpret_cast<const float4*>(a.rowstat + (((long)mb * a.n_head + h) * a.n_out + nrow) * 4);
             const float m = sq_dist3(xo.x, xo.y, xo.z, xi.x, xi.y, xi.z, per, a.period);
@@ -814,13 +821,19 @@ __global__ __launch_bounds__(256) void posatt_sparse_overflow_cols(AttArgs a, Sp
     }
 }
 
-int cr_for(int ncols) { return ncols > 256 ? 8 : (ncols > 128 ? 4 : (ncols > 64 ? 2 : 1)); }
+// columns per lane: as many as the column count allows, fewer when the launch would otherwise
+// have too few wavefronts to hide the gather latency (one wave = one row / key)
+int cr_for(int ncols, long units) {
+    int cr = ncols > 256 ? 8 : (ncols > 128 ? 4 : (ncols > 64 ? 2 : 1));
+    while (cr > 1 && units * ((ncols + 64 * cr - 1) / (64 * cr)) < 2048) cr >>= 1;
+    return cr;
+}
 
 template <int MODE>
 void launch_sparse_rows(const AttArgs& a, const SparseArgs& sp, hipStream_t s) {
-    const int cr = cr_for(a.ncols);
     const int nh = (a.n_head % 2 == 0) ? 2 : 1;
     const long rows = (long)a.mesh_batch * a.n_out;
+    const int cr = cr_for(a.ncols, rows * (a.n_head / nh));
     dim3 grid((unsigned)((rows + 3) / 4), (a.ncols + 64 * cr - 1) / (64 * cr), a.n_head / nh), block(256);
 #define PIT_SR(NH_, CR_) hipLaunchKernelGGL((posatt_sparse_rows<NH_, CR_, MODE>), grid, block, 0, s, a, sp)
 #define PIT_SR_CR(NH_) do { if (cr == 8) PIT_SR(NH_, 8); else if (cr == 4) PIT_SR(NH_, 4); else if (cr == 2) PIT_SR(NH_, 2); else PIT_SR(NH_, 1); } while (0)
@@ -830,8 +843,8 @@ void launch_sparse_rows(const AttArgs& a, const SparseArgs& sp, hipStream_t s) {
 }
 
 void launch_sparse_cols(const AttArgs& a, const SparseArgs& sp, hipStream_t s) {
-    const int cr = cr_for(a.ncols);
     const long keys = (long)a.mesh_batch * a.n_in;
+    const int cr = cr_for(a.ncols, keys);
     dim3 grid((unsigned)((keys + 3) / 4), (a.ncols + 64 * cr - 1) / (64 * cr)), block(256);
     if (cr == 8) hipLaunchKernelGGL((posatt_sparse_cols<8>), grid, block, 0, s, a, sp);
     else if (cr == 4) hipLaunchKernelGGL((posatt_sparse_cols<4>), grid, block, 0, s, a, sp);
@@ -887,6 +900,11 @@ extern "C" int pit_posatt_fwd(const float* mesh_out, const float* mesh_in, int m
     a.rowstat = rowstat; a.scale_out = scale_out;
     if (nbr_idx && nbr_cnt && masked) {
         SparseArgs sp{nbr_idx, nbr_cnt, nbr_cap, nullptr, nullptr, 0};
+        if (!head_is_scale && scale_out && (long)mesh_batch * n_out > 8192) {
+            // one wave per row: evaluate c once up front instead of fp64 sin/tan in every wave
+            if (int rc2 = pit_head_scale(head, n_head, scale_out, stream)) return rc2;
+            a.head = scale_out; a.head_is_scale = 1;
+        }
         launch_sparse_rows<0>(a, sp, (hipStream_t)stream);
     } else {
         launch_rows<0>(a, (hipStream_t)stream);
@@ -898,7 +916,7 @@ extern "C" int pit_posatt_fwd(const float* mesh_out, const float* mesh_in, int m
 extern "C" int pit_posatt_bwd(const float* mesh_out, const float* mesh_in, int mesh_batch, int n_out, int n_in,
                               int space_dim, int metric, float period,
                               const float* values, int batch, int dim, long ld_values, long values_bstride,
-                              const float* head, int n_head, int head_is_scale,
+                              const float* head, int n_head, int head_is_scale, const float* scale,
                               const float* rowstat, int masked,
                               const float* d_out, long ld_dout, long dout_bstride, int out_col0,
                               float* d_values, long ld_dvalues, long dvalues_bstride, int add_residual,
@@ -912,6 +930,7 @@ extern "C" int pit_posatt_bwd(const float* mesh_out, const float* mesh_in, int m
     if (!rowstat || !d_out || !workspace) return PIT_ERR_NULL;
     if (add_residual && n_out != n_in) return PIT_ERR_SIZE;
     hipStream_t s = (hipStream_t)stream;
+    if (scale) { a.head = scale; a.head_is_scale = 1; }     // c saved by the forward: no fp64 sin/tan here
     a.masked = masked; a.rowstat = const_cast<float*>(rowstat);
     a.d_out = d_out; a.ld_dout = ld_dout; a.dout_bstride = dout_bstride; a.out_col0 = out_col0;
     a.d_values = d_values; a.ld_dvalues = ld_dvalues; a.dvalues_bstride = dvalues_bstride;
@@ -928,7 +947,7 @@ extern "C" int pit_posatt_bwd(const float* mesh_out, const float* mesh_in, int m
     if (d_head) {
         if (sparse) launch_sparse_rows<1>(a, sp, s); else launch_rows<1>(a, s);
         PIT_CHECK_LAUNCH();
-        hipLaunchKernelGGL(posatt_dhead_finish, dim3((n_head + 63) / 64), dim3(64), 0, s, workspace, head, n_head,
+        hipLaunchKernelGGL(posatt_dhead_finish, dim3(n_head), dim3(256), 0, s, workspace, head, scale,
                            head_is_scale, accumulate_head, d_head);
         PIT_CHECK_LAUNCH();
     }

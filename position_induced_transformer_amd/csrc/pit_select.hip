@@ -180,7 +180,7 @@ void launch_reg(const SelectArgs& a, hipStream_t s) {
 // A row whose count exceeds `cap` keeps its true count (list truncated): consumers treat
 // count > cap as "scan all keys".
 __global__ __launch_bounds__(256) void neighbors_kernel(SelectArgs a, int cap, int* __restrict__ nbr_idx,
-                                                        int* __restrict__ nbr_cnt) {
+                                                        int* __restrict__ nbr_cnt, int* __restrict__ counts) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const long rows = (long)a.mesh_batch * a.n_out;
@@ -204,25 +204,17 @@ __global__ __launch_bounds__(256) void neighbors_kernel(SelectArgs a, int cap, i
         }
         const unsigned long long mask = __builtin_amdgcn_ballot_w64(in);
         const int pos = total + __popcll(mask & ((1ull << lane) - 1ull));
-        if (in && pos < cap) out[pos] = j;
+        if (in && pos < cap) {
+            out[pos] = j;
+            if (counts) atomicAdd(counts + (long)mb * a.n_in + j, 1);     // per-key counts for the transpose
+        }
         total += __popcll(mask);
     }
     if (lane == 0) nbr_cnt[row] = total;
 }
 
-// reverse lists (key -> rows that list it), CSR per mesh sample: count, scan, fill
-__global__ void nbr_count_kernel(const int* __restrict__ nbr_idx, const int* __restrict__ nbr_cnt, long rows,
-                                 int n_out, int n_in, int cap, int* __restrict__ counts) {
-    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= rows * cap) return;
-    const long row = e / cap;
-    const int i = (int)(e - row * cap);
-    const int cnt = nbr_cnt[row];
-    if (cnt > cap || i >= cnt) return;                    // overflow rows are handled densely
-    const int mb = (int)(row / n_out);
-    atomicAdd(counts + (long)mb * n_in + nbr_idx[e], 1);
-}
-
+// reverse lists (key -> rows that list it), CSR per mesh sample: counts come from
+// neighbors_kernel, then scan and fill (slots of overflowed rows stay -1)
 __global__ __launch_bounds__(256) void nbr_scan_kernel(const int* __restrict__ counts, int n_in,
                                                        int* __restrict__ rev_ptr, int* __restrict__ cursor) {
     // one workgroup per mesh sample: exclusive scan of counts[mb][0..n_in) -> rev_ptr[mb][0..n_in]
@@ -317,10 +309,13 @@ extern "C" int pit_select_fwd(const float* mesh_out, const float* mesh_in, int m
 
 extern "C" int pit_neighbors_fwd(const float* mesh_out, const float* mesh_in, int mesh_batch, int n_out, int n_in,
                                  int space_dim, int metric, float period, const float* stats, int cap,
-                                 int* nbr_idx, int* nbr_cnt, void* stream) {
+                                 int* nbr_idx, int* nbr_cnt, int* rev_ptr, int* rev_row, int* workspace,
+                                 void* stream) {
     if (!mesh_out || !mesh_in || !stats || !nbr_idx || !nbr_cnt) return PIT_ERR_NULL;
+    if (rev_ptr && (!rev_row || !workspace)) return PIT_ERR_NULL;
     if (mesh_batch <= 0 || n_out <= 0 || n_in <= 0 || space_dim < 1 || space_dim > 3 || cap <= 0) return PIT_ERR_SIZE;
     if (metric < PIT_METRIC_EUCLID || metric > PIT_METRIC_PERIODIC2D) return PIT_ERR_METRIC;
+    hipStream_t s = (hipStream_t)stream;
     SelectArgs a;
     a.mesh_out = mesh_out; a.mesh_in = mesh_in; a.stats = const_cast<float*>(stats);
     a.mesh_batch = mesh_batch; a.n_out = n_out; a.n_in = n_in; a.sdim = space_dim;
@@ -328,29 +323,23 @@ extern "C" int pit_neighbors_fwd(const float* mesh_out, const float* mesh_in, in
     a.coords_used = (metric == PIT_METRIC_PERIODIC1D) ? 1 : space_dim;
     a.period = period; a.rank_k = 0; a.need_kth = 1;
     const long rows = (long)mesh_batch * n_out;
-    hipLaunchKernelGGL(neighbors_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a, cap,
-                       nbr_idx, nbr_cnt);
+    int* counts = rev_ptr ? workspace : nullptr;                       // mesh_batch * n_in
+    int* cursor = rev_ptr ? workspace + (long)mesh_batch * n_in : nullptr;
+    hipError_t e;
+    if (rev_ptr) {
+        if ((e = hipMemsetAsync(counts, 0, sizeof(int) * (size_t)mesh_batch * n_in, s)) != hipSuccess) return (int)e;
+        if ((e = hipMemsetAsync(rev_row, 0xFF, sizeof(int) * (size_t)rows * cap, s)) != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(neighbors_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, a, cap, nbr_idx, nbr_cnt,
+                       counts);
     PIT_CHECK_LAUNCH();
-    return 0;
-}
-
-extern "C" int pit_neighbors_transpose(const int* nbr_idx, const int* nbr_cnt, int mesh_batch, int n_out, int n_in,
-                                       int cap, int* rev_ptr, int* rev_row, int* workspace, void* stream) {
-    if (!nbr_idx || !nbr_cnt || !rev_ptr || !rev_row || !workspace) return PIT_ERR_NULL;
-    if (mesh_batch <= 0 || n_out <= 0 || n_in <= 0 || cap <= 0) return PIT_ERR_SIZE;
-    hipStream_t s = (hipStream_t)stream;
-    const long rows = (long)mesh_batch * n_out;
-    int* counts = workspace;                              // mesh_batch * n_in
-    int* cursor = workspace + (long)mesh_batch * n_in;    // mesh_batch * n_in
-    hipError_t e = hipMemsetAsync(counts, 0, sizeof(int) * (size_t)mesh_batch * n_in, s);
-    if (e != hipSuccess) return (int)e;
-    const unsigned blocks = (unsigned)((rows * cap + 255) / 256);
-    hipLaunchKernelGGL(nbr_count_kernel, dim3(blocks), dim3(256), 0, s, nbr_idx, nbr_cnt, rows, n_out, n_in, cap, counts);
-    PIT_CHECK_LAUNCH();
-    hipLaunchKernelGGL(nbr_scan_kernel, dim3(mesh_batch), dim3(256), 0, s, counts, n_in, rev_ptr, cursor);
-    PIT_CHECK_LAUNCH();
-    hipLaunchKernelGGL(nbr_fill_kernel, dim3(blocks), dim3(256), 0, s, nbr_idx, nbr_cnt, rows, n_out, n_in, cap, cursor,
-                       rev_row, (long)n_out * cap);
-    PIT_CHECK_LAUNCH();
+    if (rev_ptr) {
+        hipLaunchKernelGGL(nbr_scan_kernel, dim3(mesh_batch), dim3(256), 0, s, counts, n_in, rev_ptr, cursor);
+        PIT_CHECK_LAUNCH();
+        const unsigned blocks = (unsigned)((rows * cap + 255) / 256);
+        hipLaunchKernelGGL(nbr_fill_kernel, dim3(blocks), dim3(256), 0, s, nbr_idx, nbr_cnt, rows, n_out, n_in, cap,
+                           cursor, rev_row, (long)n_out * cap);
+        PIT_CHECK_LAUNCH();
+    }
     return 0;
 }

@@ -71,8 +71,8 @@ def _dscale_workspace(device, n_head: int) -> torch.Tensor:
     zeroed buffer per device serves every layer (launches are stream-ordered)."""
     key = device.index
     ws = _DSCALE_WS.get(key)
-    if ws is None or ws.numel() < n_head:
-        ws = torch.zeros(max(64, n_head) * 32, device=device, dtype=torch.float64)   # PIT_DSCALE_SLOTS = 32
+    if ws is None or ws.numel() < n_head * 1024:
+        ws = torch.zeros(max(8, n_head) * 1024, device=device, dtype=torch.float64)   # PIT_DSCALE_SLOTS = 1024
         _DSCALE_WS[key] = ws
     return ws
 
@@ -176,17 +176,14 @@ class MeshPlan:
         self.nbr_cap = cap
         self.nbr_idx = torch.empty((rows, cap), device=dev, dtype=torch.int32)
         self.nbr_cnt = torch.empty((rows,), device=dev, dtype=torch.int32)
-        rc = L.pit_neighbors_fwd(self.mesh_out.data_ptr(), self.mesh_in.data_ptr(), self.mesh_batch, self.n_out,
-                                 self.n_in, self.sdim, self.metric_id, self.period, self.stats.data_ptr(), cap,
-                                 self.nbr_idx.data_ptr(), self.nbr_cnt.data_ptr(), _lib.stream_ptr())
-        _lib.check(rc, "pit_neighbors_fwd")
         self.rev_ptr = torch.empty((self.mesh_batch, self.n_in + 1), device=dev, dtype=torch.int32)
         self.rev_row = torch.empty((self.mesh_batch, self.n_out * cap), device=dev, dtype=torch.int32)
         work = torch.empty((2 * self.mesh_batch * self.n_in,), device=dev, dtype=torch.int32)
-        rc = L.pit_neighbors_transpose(self.nbr_idx.data_ptr(), self.nbr_cnt.data_ptr(), self.mesh_batch, self.n_out,
-                                       self.n_in, cap, self.rev_ptr.data_ptr(), self.rev_row.data_ptr(),
-                                       work.data_ptr(), _lib.stream_ptr())
-        _lib.check(rc, "pit_neighbors_transpose")
+        rc = L.pit_neighbors_fwd(self.mesh_out.data_ptr(), self.mesh_in.data_ptr(), self.mesh_batch, self.n_out,
+                                 self.n_in, self.sdim, self.metric_id, self.period, self.stats.data_ptr(), cap,
+                                 self.nbr_idx.data_ptr(), self.nbr_cnt.data_ptr(), self.rev_ptr.data_ptr(),
+                                 self.rev_row.data_ptr(), work.data_ptr(), _lib.stream_ptr())
+        _lib.check(rc, "pit_neighbors_fwd")
 
 
 def _row_view(t: torch.Tensor) -> torch.Tensor:
@@ -230,13 +227,12 @@ class _PosAtt(torch.autograd.Function):
         _lib.check(rc, "pit_posatt_fwd")
         ctx.plan, ctx.n_head, ctx.concat, ctx.head_is_scale = plan, n_head, concat, head_is_scale
         ctx.head_param = head_param
-        ctx.save_for_backward(values, head, rowstat)
-        ctx.scale = scale
+        ctx.save_for_backward(values, head, rowstat, scale)
         return out
 
     @staticmethod
     def backward(ctx, d_out):
-        values, head, rowstat = ctx.saved_tensors
+        values, head, rowstat, scale = ctx.saved_tensors
         plan, n_head, concat = ctx.plan, ctx.n_head, ctx.concat
         b, j, d = values.shape
         d_out = _row_view(d_out)
@@ -255,7 +251,7 @@ class _PosAtt(torch.autograd.Function):
                 plan.mesh_out.data_ptr(), plan.mesh_in.data_ptr(), plan.mesh_batch, plan.n_out, plan.n_in,
                 plan.sdim, plan.metric_id, plan.period,
                 values.data_ptr(), b, d, values.stride(1), values.stride(0),
-                head.data_ptr(), n_head, 1 if ctx.head_is_scale else 0,
+                head.data_ptr(), n_head, 1 if ctx.head_is_scale else 0, scale.data_ptr(),
                 rowstat.data_ptr(), 1 if plan.masked else 0,
                 d_out.data_ptr(), d_out.stride(1), d_out.stride(0), d if concat else 0,
                 _lib.ptr(dv), dv.stride(1) if dv is not None else 0, dv.stride(0) if dv is not None else 0,
@@ -266,7 +262,7 @@ class _PosAtt(torch.autograd.Function):
             _lib.check(rc, "pit_posatt_bwd")
 
         if OVERLAP_BACKWARD and slot is not None:
-            side = _fork_side(values.device, values, head, rowstat, d_out, plan)
+            side = _fork_side(values.device, values, head, rowstat, scale, d_out, plan)
             launch(None, d_head, side.cuda_stream)          # d(scale) -> lmda.grad, off the critical path
             if d_values is not None:
                 launch(d_values, None, _lib.stream_ptr())
