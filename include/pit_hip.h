@@ -153,13 +153,23 @@ int pit_mlp_bwd_params(const float* x, long ldx, int rows, int n0, int n1, int n
  * the optional per-pixel (npts, nch) affine of PixelWiseNormalization.denormalize
  * (utils.py:25-34, train_darcy.py:129) is given (both NULL = identity).
  * norms (batch, nch, 2) = {||true-pred'||_p, ||true||_p} is saved for the backward; loss is one
- * float (zeroed here).  grad_loss: device pointer to the upstream scalar (NULL = 1). */
+ * float (zeroed here).  grad_loss: device pointer to the upstream scalar (NULL = 1).
+ * The backward writes d loss/d pred and/or d loss/d true (either may be NULL): the scripts pass
+ * the model output as `pred` (train_darcy.py:130) or as `true` (train_vorticity.py:124). */
 int pit_rel_lp_loss_fwd(const float* tru, const float* pred, const float* pred_scale,
                         const float* pred_shift, int batch, int npts, int nch, int p,
                         float* norms, float* loss, void* stream);
 int pit_rel_lp_loss_bwd(const float* tru, const float* pred, const float* pred_scale,
                         const float* pred_shift, int batch, int npts, int nch, int p,
-                        const float* norms, const float* grad_loss, float* d_pred, void* stream);
+                        const float* norms, const float* grad_loss, float* d_pred, float* d_true, void* stream);
+
+/* torch.optim.Adam step (no amsgrad) over FLAT fp32 buffers of n elements, learning rate following
+ * CosineAnnealingLR(T_max=cosine_t_max, eta_min) when cosine_t_max > 0 (train_darcy.py:115-116),
+ * else constant lr0.  `step` (device int64, starts at 0) is incremented here; `scalars` is 3
+ * floats of device scratch.  Two launches, no host sync: replayable from a hipGraph. */
+int pit_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long n,
+                  long long* step, float lr0, float eta_min, int cosine_t_max, float beta1, float beta2,
+                  float eps, float weight_decay, float* scalars, void* stream);
 
 /* Layout probe used by the tests: D = A(32x8) * B(8x32) through the same
  * v_mfma_f32_32x32x2_f32 fragment maps the kernels use. */

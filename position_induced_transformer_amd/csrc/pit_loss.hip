@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void rel_lp_bwd_kernel(const float* __restrict
                                                           const float* __restrict__ scale, const float* __restrict__ shift,
                                                           int batch, int npts, int nch, int p,
                                                           const float* __restrict__ norms, const float* __restrict__ gloss,
-                                                          float* __restrict__ d_pred) {
+                                                          float* __restrict__ d_pred, float* __restrict__ d_true) {
     const long total = (long)batch * npts * nch;
     const float g = gloss ? gloss[0] : 1.0f;
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
@@ -69,7 +69,16 @@ __global__ __launch_bounds__(256) void rel_lp_bwd_kernel(const float* __restrict
         if (p == 1) dnorm = (d > 0.0f) ? 1.0f : (d < 0.0f ? -1.0f : 0.0f);
         else if (p == 2) dnorm = (nn > 0.0f) ? d / nn : 0.0f;
         else dnorm = (nn > 0.0f) ? copysignf(powf(fabsf(d) / nn, (float)(p - 1)), d) : 0.0f;
-        d_pred[e] = g * dnorm * sc / (dn * nch);
+        if (d_pred) d_pred[e] = g * dnorm * sc / (dn * nch);
+        if (d_true) {
+            // d/dt [ ||t - q|| / ||t|| ] = -dnorm/||t|| - ||t-q||/||t||^2 * d||t||/dt
+            const float t = tru[e];
+            float tnorm;
+            if (p == 1) tnorm = (t > 0.0f) ? 1.0f : (t < 0.0f ? -1.0f : 0.0f);
+            else if (p == 2) tnorm = (dn > 0.0f) ? t / dn : 0.0f;
+            else tnorm = (dn > 0.0f) ? copysignf(powf(fabsf(t) / dn, (float)(p - 1)), t) : 0.0f;
+            d_true[e] = g * (-dnorm / dn - nn / (dn * dn) * tnorm) / nch;
+        }
     }
 }
 
@@ -92,13 +101,14 @@ extern "C" int pit_rel_lp_loss_fwd(const float* tru, const float* pred, const fl
 
 extern "C" int pit_rel_lp_loss_bwd(const float* tru, const float* pred, const float* pred_scale,
                                    const float* pred_shift, int batch, int npts, int nch, int p,
-                                   const float* norms, const float* grad_loss, float* d_pred, void* stream) {
-    if (!tru || !pred || !norms || !d_pred) return PIT_ERR_NULL;
+                                   const float* norms, const float* grad_loss, float* d_pred, float* d_true,
+                                   void* stream) {
+    if (!tru || !pred || !norms || (!d_pred && !d_true)) return PIT_ERR_NULL;
     if (batch <= 0 || npts <= 0 || nch <= 0 || p < 1) return PIT_ERR_SIZE;
     const long total = (long)batch * npts * nch;
     const int blocks = (int)std::min<long>((total + 255) / 256, 2048L);
     hipLaunchKernelGGL(rel_lp_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, tru, pred, pred_scale,
-                       pred_shift, batch, npts, nch, p, norms, grad_loss, d_pred);
+                       pred_shift, batch, npts, nch, p, norms, grad_loss, d_pred, d_true);
     PIT_CHECK_LAUNCH();
     return 0;
 }

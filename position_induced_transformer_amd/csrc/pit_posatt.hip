@@ -91,9 +91,11 @@ __global__ __launch_bounds__(512) void posatt_rows_kernel(AttArgs a) {
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
     const int half = lane >> 5, l31 = lane & 31;
-    const int n0 = blockIdx.x * 32;
+    // blockIdx.x = (sample, column group) so that workgroups dealt round-robin to the 8 XCDs
+    // (id % 8) share value columns per XCD: each L2 then fetches only its own column slices
+    const int n0 = blockIdx.z * 32;
     const int h = blockIdx.y;
-    const int mb = blockIdx.z / a.colgroups, cg = blockIdx.z % a.colgroups;
+    const int mb = blockIdx.x / a.colgroups, cg = blockIdx.x % a.colgroups;
     const long rows_total = (long)a.mesh_batch * a.n_out;
 
     const float c = a.head_is_scale ? a.head[h] : head_scale_from_lmda(a.head[h]);
@@ -239,7 +241,7 @@ __global__ __launch_bounds__(512) void posatt_rows_kernel(AttArgs a) {
             for (int i = 0; i < 16; ++i) part += (double)acc[t][i] * (double)dov[t][i];
         part = wave_sum_d(part);
         // PIT_DSCALE_SLOTS accumulators per head keep the fp64 atomics off a single address
-        const int slot = (int)((blockIdx.x + 131u * blockIdx.z + 977u * wave) & (PIT_DSCALE_SLOTS - 1));
+        const int slot = (int)((blockIdx.z + 131u * blockIdx.x + 977u * wave) & (PIT_DSCALE_SLOTS - 1));
         if (lane == 0) atomicAdd(a.dscale_acc + h * PIT_DSCALE_SLOTS + slot, -part);
         return;
     }
@@ -295,8 +297,8 @@ __global__ __launch_bounds__(512) void posatt_cols_kernel(AttArgs a) {
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
     const int half = lane >> 5, l31 = lane & 31;
-    const int j0 = blockIdx.x * 32;
-    const int cg = blockIdx.y;
+    const int j0 = blockIdx.y * 32;      // blockIdx.x = column group: XCD-local reuse of the d_out columns
+    const int cg = blockIdx.x;
     const int mb = blockIdx.z;
 
     const int j = j0 + l31;
@@ -488,7 +490,7 @@ void launch_rows(const AttArgs& a0, hipStream_t s) {
     const int wmax = (ct == 4) ? 4 : 8;                                  // parked tiles must fit 96 KiB of LDS
     int nwaves = max(1, min(wmax, pow2_floor(a.n_in / 32)));
     if (int f = env_int("PIT_FORCE_WAVES")) nwaves = min(f, wmax);
-    dim3 grid(n_tiles, a.n_head, a.mesh_batch * a.colgroups), block(64 * nwaves);
+    dim3 grid(a.mesh_batch * a.colgroups, a.n_head, n_tiles), block(64 * nwaves);
     const size_t sm = rows_smem(ct, nwaves, a.n_in);
 #define PIT_ROWS(CT_)                                                                                  \
     do {                                                                                               \
@@ -515,7 +517,7 @@ void launch_cols(const AttArgs& a0, hipStream_t s) {
     const int wmax = (ct == 4) ? 4 : 8;
     int nwaves = max(1, min(wmax, pow2_floor(a.n_out * a.n_head / 32)));
     if (int f = env_int("PIT_FORCE_WAVES")) nwaves = min(f, wmax);
-    dim3 grid(j_tiles, a.colgroups, a.mesh_batch), block(64 * nwaves);
+    dim3 grid(a.colgroups, j_tiles, a.mesh_batch), block(64 * nwaves);
     const size_t sm = cols_smem(ct, nwaves, a.n_out);
 #define PIT_COLS(CT_)                                                                             \
     do {                                                                                          \

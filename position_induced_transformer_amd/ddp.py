@@ -19,19 +19,25 @@ import torch.distributed as dist
 
 
 class FlatGradients:
-    """Owns a flat gradient buffer and points every parameter's ``.grad`` into it."""
+    """Owns a flat gradient buffer and points every parameter's ``.grad`` into it.  With
+    ``flatten_params=True`` the parameters themselves are also re-homed into one flat buffer
+    (``flat_params``; values preserved), which is what the fused optimizer step works on."""
 
-    def __init__(self, params: Iterable[torch.nn.Parameter]):
+    def __init__(self, params: Iterable[torch.nn.Parameter], flatten_params: bool = False):
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
         if not self.params:
             raise ValueError("no trainable parameters")
         dev, dt = self.params[0].device, self.params[0].dtype
         total = sum(p.numel() for p in self.params)
         self.flat = torch.zeros(total, device=dev, dtype=dt)
+        self.flat_params = torch.empty(total, device=dev, dtype=dt) if flatten_params else None
         off = 0
         for p in self.params:
             n = p.numel()
             p.grad = self.flat[off:off + n].view_as(p)
+            if flatten_params:
+                self.flat_params[off:off + n].copy_(p.data.reshape(-1))
+                p.data = self.flat_params[off:off + n].view_as(p)
             off += n
 
     def zero_(self) -> None:
@@ -59,3 +65,31 @@ def shard_batch(n_items: int, rank: int, world: int) -> slice:
     base, rem = divmod(n_items, world)
     start = rank * base + min(rank, rem)
     return slice(start, start + base + (1 if rank < rem else 0))
+
+
+class FlatAdam:
+    """Adam (+ optional CosineAnnealingLR) as ONE fused update over FlatGradients' flat buffers
+    (pit_adam_step): same arithmetic as torch.optim.Adam(lr, betas, eps, weight_decay) followed by
+    scheduler.step(), with the step counter on the device (hipGraph-replayable, no host sync)."""
+
+    def __init__(self, flat: FlatGradients, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
+                 weight_decay: float = 0.0, cosine_t_max: int = 0, eta_min: float = 0.0):
+        if flat.flat_params is None:
+            raise ValueError("FlatAdam needs FlatGradients(..., flatten_params=True)")
+        self.flat = flat
+        self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
+        self.cosine_t_max, self.eta_min = cosine_t_max, eta_min
+        dev = flat.flat.device
+        self.exp_avg = torch.zeros_like(flat.flat)
+        self.exp_avg_sq = torch.zeros_like(flat.flat)
+        self.step_count = torch.zeros((), device=dev, dtype=torch.int64)
+        self.scalars = torch.zeros(3, device=dev, dtype=torch.float32)
+
+    def step(self) -> None:
+        from . import _lib
+        f = self.flat
+        rc = _lib.lib().pit_adam_step(f.flat_params.data_ptr(), f.flat.data_ptr(), self.exp_avg.data_ptr(),
+                                      self.exp_avg_sq.data_ptr(), f.flat.numel(), self.step_count.data_ptr(),
+                                      self.lr, self.eta_min, self.cosine_t_max, self.betas[0], self.betas[1],
+                                      self.eps, self.weight_decay, self.scalars.data_ptr(), _lib.stream_ptr())
+        _lib.check(rc, "pit_adam_step")

@@ -40,7 +40,7 @@ class TrainStep:
         if self.all_reduce:
             self.flat.all_reduce()
         if self.optimizer is not None:
-            self.optimizer.step()
+            self.optimizer.step()          # torch optimizer (capturable) or ddp.FlatAdam (fused HIP step)
 
     def run_eager(self) -> None:
         self._step()

@@ -375,7 +375,7 @@ class _RelLpLoss(torch.autograd.Function):
         rc = _lib.lib().pit_rel_lp_loss_fwd(t.data_ptr(), q.data_ptr(), _lib.ptr(sc), _lib.ptr(sh), b, npts,
                                             out_dim, int(p), norms.data_ptr(), loss.data_ptr(), _lib.stream_ptr())
         _lib.check(rc, "pit_rel_lp_loss_fwd")
-        ctx.meta = (b, npts, out_dim, int(p), pred.shape)
+        ctx.meta = (b, npts, out_dim, int(p), pred.shape, true.shape)
         ctx.save_for_backward(t, q, norms, sc if sc is not None else norms, sh if sh is not None else norms)
         ctx.affine = sc is not None
         return loss
@@ -383,14 +383,20 @@ class _RelLpLoss(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         t, q, norms, sc, sh = ctx.saved_tensors
-        b, npts, out_dim, p, shape = ctx.meta
+        b, npts, out_dim, p, shape, tshape = ctx.meta
         g = g.contiguous()
-        d_pred = torch.empty_like(q)
+        need_p, need_t = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        d_pred = torch.empty_like(q) if need_p else None
+        d_true = torch.empty_like(t) if need_t else None
+        if not (need_p or need_t):
+            return None, None, None, None, None, None
         rc = _lib.lib().pit_rel_lp_loss_bwd(t.data_ptr(), q.data_ptr(), sc.data_ptr() if ctx.affine else 0,
                                             sh.data_ptr() if ctx.affine else 0, b, npts, out_dim, p,
-                                            norms.data_ptr(), g.data_ptr(), d_pred.data_ptr(), _lib.stream_ptr())
+                                            norms.data_ptr(), g.data_ptr(), _lib.ptr(d_pred), _lib.ptr(d_true),
+                                            _lib.stream_ptr())
         _lib.check(rc, "pit_rel_lp_loss_bwd")
-        return d_pred.reshape(shape), None, None, None, None, None
+        return (d_pred.reshape(shape) if need_p else None), (d_true.reshape(tshape) if need_t else None), \
+            None, None, None, None
 
 
 def rel_lp_loss(true, pred, out_dim: int, p: int, pred_scale=None, pred_shift=None) -> torch.Tensor:

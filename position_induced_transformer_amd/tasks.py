@@ -124,6 +124,19 @@ class pit_naca(P.pit):
         return self.decoder(mesh_ltt, ltt, mesh_flat).reshape(*size, self.out_dim)
 
 
+def rollout_loss(model, mesh, x, y, steps: int, loss_fn):
+    """Autoregressive training objective of train_vorticity.py:118-126: ``steps`` successive
+    predictions, each appended to the input history (oldest frame dropped), loss summed over the
+    steps with the arguments in the script's order ``loss_fn(out, y_t)``; back-propagates through
+    the whole rollout."""
+    loss = 0.0
+    for t in range(steps):
+        out = model(mesh, x, mesh)
+        loss = loss + loss_fn(out, y[..., t:t + 1])
+        x = torch.cat((x[..., 1:], out), dim=-1)
+    return loss
+
+
 # ----------------------------------------------------------------------------- configs
 def make_task(name: str, device="cuda", seed: int = 0):
     """Build (model, sample_fn) for a named configuration of the reference.

@@ -17,6 +17,17 @@ from . import ops
 __all__ = ["PixelWiseNormalization", "count_params", "RelMaxNorm", "RelLpNorm", "F", "reduce", "operator", "torch"]
 
 
+def load_reference_checkpoint(model, checkpoint, strict: bool = True):
+    """Load a checkpoint written by the reference scripts: ``torch.save({'model_state':
+    model.state_dict()}, 'model.pth')`` (train_darcy.py:150), whose keys carry the ``_orig_mod.``
+    prefix of the torch.compile wrapper.  ``checkpoint`` is a path or the loaded dict."""
+    if isinstance(checkpoint, (str, bytes)) or hasattr(checkpoint, "__fspath__"):
+        checkpoint = torch.load(checkpoint, map_location="cpu")
+    state = checkpoint.get("model_state", checkpoint)
+    state = {(k[len("_orig_mod."):] if k.startswith("_orig_mod.") else k): v for k, v in state.items()}
+    return model.load_state_dict(state, strict=strict)
+
+
 class PixelWiseNormalization:
     """Per-pixel mean/std over the sample axis (utils.py:6-50); bilinear resampling of the
     statistics when the resolution differs (zero-shot super-resolution)."""

@@ -154,3 +154,19 @@ def test_rel_lp_norm_cpu_path_matches_reference_formula():
     assert torch.allclose(n.denormalize(n.normalize(x)), x, atol=1e-6)
     sc, sh = n.affine()
     assert torch.allclose(x * sc + sh, n.denormalize(x))
+
+
+def test_reference_checkpoint_loader_strips_compile_prefix(tmp_path):
+    """train_darcy.py:150 saves {'model_state': state_dict} of a torch.compile-wrapped model:
+    keys start with '_orig_mod.'."""
+    from position_induced_transformer_amd import pit as P, utils
+    torch.manual_seed(3)
+    src = P.pit_fixed(2, 1, 1, 16, 2, 2, torch.zeros(4, 4, 2), 0.1, 0.1)
+    ckpt = {"model_state": {"_orig_mod." + k: v.clone() for k, v in src.state_dict().items()}}
+    path = tmp_path / "model.pth"
+    torch.save(ckpt, path)
+    dst = P.pit_fixed(2, 1, 1, 16, 2, 2, torch.zeros(4, 4, 2), 0.1, 0.1)
+    res = utils.load_reference_checkpoint(dst, str(path))
+    assert not res.missing_keys and not res.unexpected_keys
+    for k, v in src.state_dict().items():
+        assert torch.equal(dst.state_dict()[k], v)

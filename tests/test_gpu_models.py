@@ -109,3 +109,64 @@ def test_inplace_gradient_accumulation_matches_returned_gradients():
     assert gio.rel_l2(ref.cpu().numpy(), flat.flat.cpu().numpy()) <= 1e-5
     loss_fn(target, model(mesh_in, func_in, mesh_out)).backward()
     assert gio.rel_l2(2.0 * ref.cpu().numpy(), flat.flat.cpu().numpy()) <= 1e-5
+
+
+def test_fused_adam_matches_torch_adam_with_cosine_schedule():
+    """ddp.FlatAdam (pit_adam_step) against torch.optim.Adam + CosineAnnealingLR on the CPU, ten
+    steps with fresh gradients each step (train_darcy.py:115-116,131-134)."""
+    from position_induced_transformer_amd.ddp import FlatAdam, FlatGradients
+    shapes = [(17, 5), (33,), (4, 1, 1), (129, 64)]
+    cpu = [torch.nn.Parameter(torch.from_numpy(gio.synth(s, 60 + i))) for i, s in enumerate(shapes)]
+    gpu = [torch.nn.Parameter(p.detach().clone().cuda()) for p in cpu]
+    opt = torch.optim.Adam(cpu, lr=1e-3)
+    sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=25)
+    flat = FlatGradients(gpu, flatten_params=True)
+    fused = FlatAdam(flat, lr=1e-3, cosine_t_max=25)
+    for step in range(10):
+        for i, (pc, pg) in enumerate(zip(cpu, gpu)):
+            g = torch.from_numpy(gio.synth(tuple(pc.shape), 100 * step + i)) * (1.0 + step)
+            pc.grad = g.clone()
+            pg.grad.copy_(g.cuda())
+        opt.step()
+        sched.step()
+        fused.step()
+    torch.cuda.synchronize()
+    assert int(fused.step_count) == 10
+    for pc, pg in zip(cpu, gpu):
+        assert gio.rel_l2(pc.detach().numpy(), pg.detach().cpu().numpy()) <= 2e-6
+    assert abs(float(fused.scalars[0]) - sched.get_last_lr()[0]) > 0          # scalars hold the rate of step 10 ...
+    lr10 = 0.5 * 1e-3 * (1 + np.cos(np.pi * 9 / 25))
+    assert abs(float(fused.scalars[0]) - lr10) <= 1e-9
+
+
+def test_vorticity_rollout_matches_oracle():
+    """3-step autoregressive rollout with BPTT (train_vorticity.py:118-126) of a reduced
+    pit_vorticity (InstanceNorm after encoder and processor) against the CPU oracle."""
+    from position_induced_transformer_amd import tasks, utils
+    s_in, s_ltt, mem, hid, steps, b = 16, 8, 4, 32, 3, 2
+    mesh = tasks.grid_mesh_2d(s_in, False, "cuda")
+    ltt = tasks.grid_mesh_2d(s_ltt, False, "cuda")
+    model = tasks.pit_vorticity(2, mem, 1, hid, 2, 2, ltt, 0.05, 0.05).cuda()
+    shapes = orc.param_shapes(2, mem, 1, hid, 2, 2)
+    params = gio.synth_params(shapes, 3)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
+    x = torch.from_numpy(gio.synth((b, s_in, s_in, mem), 71))
+    y = torch.from_numpy(gio.synth((b, s_in, s_in, steps), 72))
+    loss = tasks.rollout_loss(model, mesh, x.cuda(), y.cuda(), steps, utils.RelLpNorm(1, 2))
+    loss.backward()
+
+    p = {k: torch.from_numpy(v).requires_grad_(True) for k, v in params.items()}
+    mi = orc.grid_mesh_2d(s_in, False)
+    lt = orc.grid_mesh_2d(s_ltt, False)
+    xx, ref = x, 0.0
+    for t in range(steps):
+        f = orc.with_coords(mi, xx.reshape(b, -1, mem))
+        out = orc.pit_apply(p, "periodic2d", False, 2, 0.05, 0.05, mi, f, lt, mi, norm_after_enc_proc=True)
+        out = out.reshape(b, s_in, s_in, 1)
+        ref = ref + orc.rel_lp_loss(out, y[..., t:t + 1], 1, 2)          # script order: loss(out, y)
+        xx = torch.cat((xx[..., 1:], out), dim=-1)
+    ref.backward()
+    assert abs(float(loss.detach()) - float(ref.detach())) <= 2e-5 * abs(float(ref.detach()))
+    for k, q in model.named_parameters():
+        tol = 5e-4 if k.endswith("lmda") else 1e-4
+        assert gio.rel_l2(p[k].grad.numpy(), q.grad.cpu().numpy()) <= tol, k

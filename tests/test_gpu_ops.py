@@ -213,6 +213,23 @@ def test_rel_lp_loss(ops, p, affine):
     assert gio.rel_l2(q.grad.numpy(), qg.grad.cpu().numpy()) <= TOL_GRAD
 
 
+@pytest.mark.parametrize("p", [1, 2, 3])
+def test_rel_lp_loss_gradient_wrt_true_argument(ops, p):
+    """train_vorticity.py:124 / train_cylinder.py:101 call myloss(out, y): the model output is the
+    FIRST ('true') argument, so the loss must differentiate through the denominator too."""
+    t = torch.from_numpy(gio.synth((3, 40, 2), 35)).requires_grad_(True)
+    q = torch.from_numpy(gio.synth((3, 40, 2), 36)).requires_grad_(True)
+    ref = orc.rel_lp_loss(t, q, 2, p)
+    ref.backward()
+    tg = t.detach().cuda().requires_grad_(True)
+    qg = q.detach().cuda().requires_grad_(True)
+    got = ops.rel_lp_loss(tg, qg, 2, p)
+    got.backward()
+    assert abs(float(got.detach()) - float(ref.detach())) <= 2e-6 * abs(float(ref.detach()))
+    assert gio.rel_l2(t.grad.numpy(), tg.grad.cpu().numpy()) <= TOL_GRAD
+    assert gio.rel_l2(q.grad.numpy(), qg.grad.cpu().numpy()) <= TOL_GRAD
+
+
 def test_cpu_tensors_fail_loudly(ops):
     with pytest.raises(RuntimeError):
         ops.MeshPlan("euclid", torch.zeros(4, 2), torch.zeros(5, 2), 0.5, False)
