@@ -269,12 +269,16 @@ def main():
         raise SystemExit("bench.py needs a GPU (the HIP hot path has no CPU fallback)")
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    if world > 1:
+    distributed = world > 1 or "RANK" in os.environ           # under torch.distributed.run even with 1 rank
+    if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=device)
 
     log(f"rank {rank}/{world} on {torch.cuda.get_device_name(local)}")
-    step, model, meta = build_step(args, device, rank, world, args.batch)
+    step, model, meta = build_step(args, device, rank, world, args.batch, all_reduce=distributed)
     run, mode = prepare(step, not args.no_graph)
     log(f"step prepared ({mode})")
     dt = timed(run, args.steps, args.warmup, world)
@@ -325,7 +329,7 @@ def main():
             rec["cpu_baseline"] = cpu_baseline(args.batch, args.cpu_iters)
             rec["speedup_vs_cpu_baseline"] = round(rec["value"] / rec["cpu_baseline"]["value"], 1)
         print(json.dumps(rec), flush=True)
-    if world > 1:
+    if distributed:
         dist.barrier()
         dist.destroy_process_group()
 

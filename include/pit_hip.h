@@ -98,9 +98,10 @@ int pit_posatt_fwd(const float* mesh_out, const float* mesh_in, int mesh_batch, 
  *   scale    the c written to scale_out by the forward (NULL = recompute from head)
  *   d_head   n_head floats (NULL = not needed): gradient w.r.t. lmda (head_is_scale=0) or
  *            w.r.t. c (=1); accumulate_head=1 adds to the current contents instead of writing.
- *   workspace: n_head*PIT_DSCALE_SLOTS doubles, fp64 accumulators for d c.  They must be ZERO
- *            on entry and are left zero on exit (the finishing kernel clears what it
- *            consumed), so a caller allocates and zeroes them once; no per-call memset.
+ *   workspace: n_head*PIT_DSCALE_SLOTS + 1 doubles: fp64 accumulators for d c and an arrival
+ *            counter.  They must be ZERO on entry and are left zero on exit (the last
+ *            workgroup of the d-scale kernel drains them, applies d c/d lmda and writes d_head),
+ *            so a caller allocates and zeroes them once; no per-call memset or extra launch.
  * d_values and d_head are computed by independent kernels: a caller may issue two calls (one
  * with d_values == NULL, one with d_head == NULL) on different streams to overlap them. */
 int pit_posatt_bwd(const float* mesh_out, const float* mesh_in, int mesh_batch, int n_out, int n_in,
@@ -153,12 +154,13 @@ int pit_mlp_bwd_params(const float* x, long ldx, int rows, int n0, int n1, int n
  * the optional per-pixel (npts, nch) affine of PixelWiseNormalization.denormalize
  * (utils.py:25-34, train_darcy.py:129) is given (both NULL = identity).
  * norms (batch, nch, 2) = {||true-pred'||_p, ||true||_p} is saved for the backward; loss is one
- * float (zeroed here).  grad_loss: device pointer to the upstream scalar (NULL = 1).
+ * float.  workspace: 2 floats (accumulator + arrival counter), zero before the first call and
+ * left zero by every call.  grad_loss: device pointer to the upstream scalar (NULL = 1).
  * The backward writes d loss/d pred and/or d loss/d true (either may be NULL): the scripts pass
  * the model output as `pred` (train_darcy.py:130) or as `true` (train_vorticity.py:124). */
 int pit_rel_lp_loss_fwd(const float* tru, const float* pred, const float* pred_scale,
                         const float* pred_shift, int batch, int npts, int nch, int p,
-                        float* norms, float* loss, void* stream);
+                        float* norms, float* loss, float* workspace, void* stream);
 int pit_rel_lp_loss_bwd(const float* tru, const float* pred, const float* pred_scale,
                         const float* pred_shift, int batch, int npts, int nch, int p,
                         const float* norms, const float* grad_loss, float* d_pred, float* d_true, void* stream);

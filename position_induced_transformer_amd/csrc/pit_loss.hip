@@ -18,7 +18,7 @@ __device__ __forceinline__ float pow_abs(float x, int p) {
 __global__ __launch_bounds__(256) void rel_lp_fwd_kernel(const float* __restrict__ tru, const float* __restrict__ pred,
                                                           const float* __restrict__ scale, const float* __restrict__ shift,
                                                           int npts, int nch, int p, float* __restrict__ norms,
-                                                          float* __restrict__ loss) {
+                                                          float* __restrict__ loss, float* __restrict__ ws) {
     __shared__ double s_num[4], s_den[4];
     const int c = blockIdx.x, b = blockIdx.y;
     const long base = (long)b * npts * nch + c;
@@ -43,7 +43,16 @@ __global__ __launch_bounds__(256) void rel_lp_fwd_kernel(const float* __restrict
         const double dn = (p == 1) ? den : (p == 2 ? sqrt(den) : pow(den, 1.0 / p));
         norms[((long)b * nch + c) * 2 + 0] = (float)nn;
         norms[((long)b * nch + c) * 2 + 1] = (float)dn;
-        atomicAdd(loss, (float)(nn / dn / nch));
+        // sum over (sample, channel) in a persistent accumulator; the last workgroup publishes the
+        // loss and leaves accumulator and arrival counter zero for the next call (no memset launch)
+        const float old = atomicAdd(ws, (float)(nn / dn / nch));
+        asm volatile("" ::"v"(old));              // returning atomic: performed before the ticket below
+        unsigned* counter = reinterpret_cast<unsigned*>(ws + 1);
+        const unsigned ticket = atomicAdd(counter, 1u);
+        if (ticket == gridDim.x * gridDim.y - 1u) {
+            *loss = atomicExch(ws, 0.0f);
+            atomicExch(counter, 0u);
+        }
     }
 }
 
@@ -86,15 +95,13 @@ __global__ __launch_bounds__(256) void rel_lp_bwd_kernel(const float* __restrict
 
 extern "C" int pit_rel_lp_loss_fwd(const float* tru, const float* pred, const float* pred_scale,
                                    const float* pred_shift, int batch, int npts, int nch, int p,
-                                   float* norms, float* loss, void* stream) {
-    if (!tru || !pred || !norms || !loss) return PIT_ERR_NULL;
+                                   float* norms, float* loss, float* workspace, void* stream) {
+    if (!tru || !pred || !norms || !loss || !workspace) return PIT_ERR_NULL;
     if ((pred_scale == nullptr) != (pred_shift == nullptr)) return PIT_ERR_NULL;
     if (batch <= 0 || npts <= 0 || nch <= 0 || p < 1 || batch > 65535) return PIT_ERR_SIZE;
     hipStream_t s = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(loss, 0, sizeof(float), s);
-    if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(rel_lp_fwd_kernel, dim3(nch, batch), dim3(256), 0, s, tru, pred, pred_scale, pred_shift, npts,
-                       nch, p, norms, loss);
+                       nch, p, norms, loss, workspace);
     PIT_CHECK_LAUNCH();
     return 0;
 }

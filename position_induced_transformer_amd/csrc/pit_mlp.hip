@@ -69,12 +69,12 @@ constexpr int EPI_MUL_GELU_GRAD = 3;  // C = acc * gelu'(G)
 constexpr int EPI_ATOMIC = 4;     // C += acc (fp32 atomics), ones column -> C2
 
 template <int TN, int EPI>
-__global__ __launch_bounds__(512) void gemm_rd_kernel(GemmArgs g) {
+__device__ __forceinline__ void gemm_rd_body(const GemmArgs& g, int bx, int by, int bz) {
     extern __shared__ __attribute__((aligned(16))) float red[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
     const int half = lane >> 5, l31 = lane & 31;
-    const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32 * TN;
-    const int kbeg = blockIdx.z * g.k_slab;
+    const int m0 = by * 32, n0 = bx * 32 * TN;
+    const int kbeg = bz * g.k_slab;
     const int kend = min(g.K, kbeg + g.k_slab);
     // this wave's k range: multiples of 8
     const int span = kend - kbeg;
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(512) void gemm_rd_kernel(GemmArgs g) {
             load_frag<FULL>(rz, g.a_bytes, abase, mvalid, akstride, g.a_vec != 0, kk, wk1, zv);
 #pragma unroll
             for (int e = 0; e < 4; ++e) av[e] *= gelu_erf_grad(zv[e]);
-            if (g.a_out && blockIdx.x == 0 && mvalid) {
+            if (g.a_out && bx == 0 && mvalid) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
                     if (FULL || kk + e < wk1) g.a_out[(long)m * g.a_out_rs + (long)(kk + e) * g.a_out_cs] = av[e];
@@ -179,13 +179,34 @@ __global__ __launch_bounds__(512) void gemm_rd_kernel(GemmArgs g) {
     }
 }
 
+template <int TN, int EPI>
+__global__ __launch_bounds__(512) void gemm_rd_kernel(GemmArgs g) {
+    gemm_rd_body<TN, EPI>(g, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// two independent GEMMs (the dW2 and dW1 reductions of one MLP) in ONE launch: workgroups
+// [0, nblk1) run the first, the rest the second; each decodes its own (x, y, z) tile index.
+template <int TN, int EPI>
+__global__ __launch_bounds__(512) void gemm_rd_pair_kernel(GemmArgs g1, GemmArgs g2, int nblk1, int gx1, int gy1,
+                                                           int gx2, int gy2) {
+    int id = blockIdx.x;
+    if (id < nblk1) {
+        gemm_rd_body<TN, EPI>(g1, id % gx1, (id / gx1) % gy1, id / (gx1 * gy1));
+    } else {
+        id -= nblk1;
+        gemm_rd_body<TN, EPI>(g2, id % gx2, (id / gx2) % gy2, id / (gx2 * gy2));
+    }
+}
+
 int pow2_floor_i(int v) { int p = 1; while (p * 2 <= v) p *= 2; return p; }
 
 bool vec_ok(const float* p, long i_stride, long k_stride) {
     return k_stride == 1 && (reinterpret_cast<uintptr_t>(p) & 15) == 0 && (i_stride % 4) == 0;
 }
 
-int launch_gemm(GemmArgs g, hipStream_t s) {
+struct GemmLaunch { int tn, nwaves; dim3 grid; };
+
+int prepare_gemm(GemmArgs& g, GemmLaunch& L, int force_tn = 0, int force_waves = 0) {
     const unsigned long long ab = ((unsigned long long)(g.M - 1) * g.a_rs + (unsigned long long)(g.K - 1) * g.a_cs + 1) * 4ull;
     const int nb_cols = (g.ones_col >= 0) ? g.N - 1 : g.N;       // the ones column is virtual
     const unsigned long long bb = ((unsigned long long)(g.K - 1) * g.b_rs + (unsigned long long)(std::max(nb_cols, 1) - 1) * g.b_cs + 1) * 4ull;
@@ -194,7 +215,8 @@ int launch_gemm(GemmArgs g, hipStream_t s) {
     g.a_vec = vec_ok(g.A, g.a_rs, g.a_cs) && (!g.a_gz || vec_ok(g.a_gz, g.a_rs, g.a_cs));
     g.b_vec = vec_ok(g.B, g.b_cs, g.b_rs);
     // two column tiles per wave (A fragment reused) only when that still leaves plenty of workgroups
-    const int tn = (g.N > 32 && (long)((g.M + 31) / 32) * ((g.N + 63) / 64) >= 512) ? 2 : 1;
+    int tn = (g.N > 32 && (long)((g.M + 31) / 32) * ((g.N + 63) / 64) >= 512) ? 2 : 1;
+    if (force_tn) tn = force_tn;
     const int tiles = ((g.M + 31) / 32) * ((g.N + 32 * tn - 1) / (32 * tn));
     // waves per workgroup: each wave wants >= 16 k; slabs over blockIdx.z only for the atomic
     // (row-reducing) GEMMs, sized so the launch has a few hundred workgroups
@@ -205,9 +227,18 @@ int launch_gemm(GemmArgs g, hipStream_t s) {
     splits = (g.K + slab - 1) / slab;
     g.k_slab = slab;
     // >= 2 waves always: the reduce-scatter epilogue indexes the parked tile in LDS
-    const int nwaves = std::max(2, std::min(8, pow2_floor_i(slab / 16)));
-    dim3 grid((g.N + 32 * tn - 1) / (32 * tn), (g.M + 31) / 32, splits), block(64 * nwaves);
-    const size_t sm = (size_t)nwaves * tn * 16 * 64 * sizeof(float);
+    L.nwaves = force_waves ? force_waves : std::max(2, std::min(8, pow2_floor_i(slab / 16)));
+    L.tn = tn;
+    L.grid = dim3((g.N + 32 * tn - 1) / (32 * tn), (g.M + 31) / 32, splits);
+    return 0;
+}
+
+int launch_gemm(GemmArgs g, hipStream_t s) {
+    GemmLaunch L;
+    if (int rc = prepare_gemm(g, L)) return rc;
+    const int tn = L.tn;
+    dim3 grid = L.grid, block(64 * L.nwaves);
+    const size_t sm = (size_t)L.nwaves * tn * 16 * 64 * sizeof(float);
 #define PIT_GEMM(TN_, EPI_) hipLaunchKernelGGL((gemm_rd_kernel<TN_, EPI_>), grid, block, sm, s, g)
 #define PIT_GEMM_TN(EPI_) do { if (tn == 2) PIT_GEMM(2, EPI_); else PIT_GEMM(1, EPI_); } while (0)
     switch (g.epi) {
@@ -219,6 +250,23 @@ int launch_gemm(GemmArgs g, hipStream_t s) {
     }
 #undef PIT_GEMM_TN
 #undef PIT_GEMM
+    return 0;
+}
+
+// both weight-gradient reductions of an MLP in one launch (EPI_ATOMIC) when they are small;
+// big reductions keep their own launches (and their own tile shapes)
+int launch_gemm_pair_atomic(GemmArgs g1, GemmArgs g2, hipStream_t s) {
+    if ((long)g1.M * g1.N * g1.K + (long)g2.M * g2.N * g2.K > (1L << 28)) {
+        if (int rc = launch_gemm(g1, s)) return rc;
+        return launch_gemm(g2, s);
+    }
+    GemmLaunch L1, L2;
+    if (int rc = prepare_gemm(g1, L1, 1, 8)) return rc;
+    if (int rc = prepare_gemm(g2, L2, 1, 8)) return rc;
+    const int n1 = L1.grid.x * L1.grid.y * L1.grid.z, n2 = L2.grid.x * L2.grid.y * L2.grid.z;
+    const size_t sm = (size_t)8 * 16 * 64 * sizeof(float);
+    hipLaunchKernelGGL((gemm_rd_pair_kernel<1, EPI_ATOMIC>), dim3(n1 + n2), dim3(512), sm, s, g1, g2, n1,
+                       (int)L1.grid.x, (int)L1.grid.y, (int)L2.grid.x, (int)L2.grid.y);
     return 0;
 }
 
@@ -306,21 +354,18 @@ extern "C" int pit_mlp_bwd_params(const float* x, long ldx, int rows, int n0, in
         if ((e = hipMemsetAsync(d_w2, 0, sizeof(float) * (size_t)n2 * n1, s)) != hipSuccess) return (int)e;
         if ((e = hipMemsetAsync(d_b2, 0, sizeof(float) * (size_t)n2, s)) != hipSuccess) return (int)e;
     }
-    // dW2 += dZ2^T H (+ db2 as the ones column)
+    // dW2 += dZ2^T H (+ db2 as the ones column)  and  dW1 += dZ1^T X (+ db1): one launch
     GemmArgs g = blank();
     g.A = dz2; g.a_rs = 1; g.a_cs = ld_dz2;        // A(m,k) = dz2[k][m]
     g.B = h; g.b_rs = n1; g.b_cs = 1;
     g.M = n2; g.N = n1 + 1; g.K = rows; g.ones_col = n1;
     g.C = d_w2; g.ldc = n1; g.C2 = d_b2; g.atomic = 1; g.epi = EPI_ATOMIC;
-    if (int rc = launch_gemm(g, s)) return rc;
-    PIT_CHECK_LAUNCH();
-    // dW1 += dZ1^T X (+ db1)
-    g = blank();
-    g.A = dz1; g.a_rs = 1; g.a_cs = n1;
-    g.B = x; g.b_rs = ldx; g.b_cs = 1;
-    g.M = n1; g.N = n0 + 1; g.K = rows; g.ones_col = n0;
-    g.C = d_w1; g.ldc = n0; g.C2 = d_b1; g.atomic = 1; g.epi = EPI_ATOMIC;
-    if (int rc = launch_gemm(g, s)) return rc;
+    GemmArgs g2 = blank();
+    g2.A = dz1; g2.a_rs = 1; g2.a_cs = n1;
+    g2.B = x; g2.b_rs = ldx; g2.b_cs = 1;
+    g2.M = n1; g2.N = n0 + 1; g2.K = rows; g2.ones_col = n0;
+    g2.C = d_w1; g2.ldc = n0; g2.C2 = d_b1; g2.atomic = 1; g2.epi = EPI_ATOMIC;
+    if (int rc = launch_gemm_pair_atomic(g, g2, s)) return rc;
     PIT_CHECK_LAUNCH();
     return 0;
 }

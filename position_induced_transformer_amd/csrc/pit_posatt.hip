@@ -37,9 +37,68 @@ struct AttArgs {
     const float* d_out; long ld_dout, dout_bstride;
     float* d_values; long ld_dvalues, dvalues_bstride; int add_residual;
     double* dscale_acc;
+    float* d_head; const float* dhead_src; int dhead_is_scale, accumulate_head, finish_inline;   // d(scale) finish
     int ncols, colgroups;
     unsigned values_bytes, dout_bytes;    // extents for the raw-buffer descriptors
 };
+
+// d(scale) epilogue shared by the dense and sparse kernels.  Every wave adds its fp64 partial to a
+// slotted accumulator with a RETURNING device-scope atomic (the wave waits for the returned value,
+// so the add has been performed at the memory side before the wave goes on - no cache write-back
+// is involved because only atomics touch these words, hence no __threadfence, which costs ~3.5 us
+// per workgroup on this chip).  The workgroup then takes a ticket; the LAST workgroup of the launch
+// drains the accumulators with atomic exchanges (leaving them zero for the next call), applies
+// d c / d lmda and writes / accumulates d_head: no finishing launch, no memset.  Launches with many
+// workgroups use the separate finishing kernel instead (one hot ticket word would serialise them).
+// `s_red`: 10 doubles of static LDS (80 B keeps the dynamic region 16-B aligned).
+__device__ __forceinline__ void dscale_add(double* slot, double v, bool doit) {
+    if (doit) {
+        const double old = atomicAdd(slot, v);
+        asm volatile("" ::"v"(old));             // consume the return value: forces the wait
+    }
+}
+
+__device__ __forceinline__ void dscale_drain_head(const AttArgs& a, int h, double* s_red) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    double g = 0.0;
+    for (int sl = threadIdx.x; sl < PIT_DSCALE_SLOTS; sl += blockDim.x) {
+        unsigned long long* w = reinterpret_cast<unsigned long long*>(a.dscale_acc + (long)h * PIT_DSCALE_SLOTS + sl);
+        g += __longlong_as_double((long long)atomicExch(w, 0ull));
+    }
+    g = wave_sum_d(g);
+    __syncthreads();
+    if (lane == 0) s_red[wave] = g;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double tot = 0.0;
+        for (int w = 0; w < nwaves; ++w) tot += s_red[w];
+        if (!a.dhead_is_scale) {
+            const float lm = a.dhead_src[h];
+            tot *= head_scale_grad(lm, a.head_is_scale ? a.head[h] : head_scale_from_lmda(lm));
+        }
+        a.d_head[h] = a.accumulate_head ? a.d_head[h] + (float)tot : (float)tot;
+    }
+}
+
+__device__ __forceinline__ void dscale_finish(const AttArgs& a, double* s_red) {
+    if (!a.finish_inline) return;
+    unsigned* counter = reinterpret_cast<unsigned*>(a.dscale_acc + (long)a.n_head * PIT_DSCALE_SLOTS);
+    __syncthreads();                               // every wave's returning atomic has completed
+    if (threadIdx.x == 0) {
+        const unsigned total = gridDim.x * gridDim.y * gridDim.z;
+        const unsigned ticket = atomicAdd(counter, 1u);
+        s_red[9] = (ticket == total - 1u) ? 1.0 : 0.0;
+    }
+    __syncthreads();
+    if (s_red[9] == 0.0) return;
+    for (int h = 0; h < a.n_head; ++h) dscale_drain_head(a, h, s_red);
+    if (threadIdx.x == 0) atomicExch(counter, 0u);
+}
+
+__global__ __launch_bounds__(256) void posatt_dhead_finish(AttArgs a) {
+    __shared__ double s_red[10];
+    dscale_drain_head(a, blockIdx.x, s_red);
+}
 
 constexpr int KEY_CHUNK = 2048;   // keys staged in LDS per pass (float4 each = 32 KiB)
 constexpr int ROW_CHUNK = 1024;   // row records staged per pass in the cols kernel (32 KiB)
@@ -242,7 +301,9 @@ __global__ __launch_bounds__(512) void posatt_rows_kernel(AttArgs a) {
         part = wave_sum_d(part);
         // PIT_DSCALE_SLOTS accumulators per head keep the fp64 atomics off a single address
         const int slot = (int)((blockIdx.z + 131u * blockIdx.x + 977u * wave) & (PIT_DSCALE_SLOTS - 1));
-        if (lane == 0) atomicAdd(a.dscale_acc + h * PIT_DSCALE_SLOTS + slot, -part);
+        dscale_add(a.dscale_acc + h * PIT_DSCALE_SLOTS + slot, -part, lane == 0);
+        __shared__ double s_red[10];
+        dscale_finish(a, s_red);
         return;
     }
 
@@ -427,28 +488,6 @@ __global__ __launch_bounds__(512) void posatt_cols_kernel(AttArgs a) {
     }
 }
 
-__global__ __launch_bounds__(256) void posatt_dhead_finish(double* acc, const float* head, const float* scale,
-                                                           int head_is_scale, int accumulate, float* d_head) {
-    // one workgroup per head: sum (and clear) its PIT_DSCALE_SLOTS fp64 accumulators
-    __shared__ double s_part[4];
-    const int h = blockIdx.x;
-    double g = 0.0;
-    for (int sl = threadIdx.x; sl < PIT_DSCALE_SLOTS; sl += 256) {
-        g += acc[h * PIT_DSCALE_SLOTS + sl];
-        acc[h * PIT_DSCALE_SLOTS + sl] = 0.0;     // leave the accumulators clean for the next call
-    }
-    g = wave_sum_d(g);
-    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = g;
-    __syncthreads();
-    if (threadIdx.x != 0) return;
-    g = s_part[0] + s_part[1] + s_part[2] + s_part[3];
-    if (!head_is_scale) {
-        const float lm = head[h];
-        g *= head_scale_grad(lm, scale ? scale[h] : head_scale_from_lmda(lm));
-    }
-    d_head[h] = accumulate ? d_head[h] + (float)g : (float)g;
-}
-
 int pow2_floor(int v) { int p = 1; while (p * 2 <= v) p *= 2; return p; }
 
 // tuning overrides for experiments (tools/microbench.py): PIT_FORCE_CT, PIT_FORCE_WAVES
@@ -555,8 +594,9 @@ __global__ __launch_bounds__(256) void posatt_sparse_rows(AttArgs a, SparseArgs 
     constexpr int G = (CR >= 4) ? 4 : 8;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long rows_total = (long)a.mesh_batch * a.n_out;
-    const long row = (long)blockIdx.x * 4 + wave;
-    if (row >= rows_total) return;
+    const long row_raw = (long)blockIdx.x * 4 + wave;
+    const bool active = row_raw < rows_total;          // tail waves recompute the last row, write nothing
+    const long row = active ? row_raw : rows_total - 1;
     const int mb = (int)(row / a.n_out), n = (int)(row - (long)mb * a.n_out);
     const int cblk = blockIdx.y, h0 = blockIdx.z * NH;
 
@@ -668,9 +708,11 @@ __global__ __launch_bounds__(256) void posatt_sparse_rows(AttArgs a, SparseArgs 
                 part += (double)acc[h][r] * (double)buf_load(rdo, cvalid[r] ? off : a.dout_bytes);
             }
             part = wave_sum_d(part);
-            const int slot = (int)((blockIdx.x + 131u * blockIdx.y) & (PIT_DSCALE_SLOTS - 1));
-            if (lane == 0) atomicAdd(a.dscale_acc + (h0 + h) * PIT_DSCALE_SLOTS + slot, -part);
+            const int slot = (int)((blockIdx.x + 131u * blockIdx.y + 977u * wave) & (PIT_DSCALE_SLOTS - 1));
+            dscale_add(a.dscale_acc + (h0 + h) * PIT_DSCALE_SLOTS + slot, -part, lane == 0 && active);
         }
+        __shared__ double s_red[10];
+        dscale_finish(a, s_red);
         return;
     }
 #pragma unroll
@@ -680,9 +722,9 @@ __global__ __launch_bounds__(256) void posatt_sparse_rows(AttArgs a, SparseArgs 
         const float inv = rs > 0.0f ? 1.0f / rs : 0.0f;
 #pragma unroll
         for (int r = 0; r < CR; ++r)
-            if (cvalid[r])
+            if (cvalid[r] && active)
                 a.out[(long)cb[r] * a.out_bstride + (long)n * a.ld_out + a.out_col0 + (long)(h0 + h) * a.dim + cd[r]] = acc[h][r] * inv;
-        if (cblk == 0 && lane == 0) {
+        if (cblk == 0 && lane == 0 && active) {
             float4 st; st.x = T[h]; st.y = smin[h]; st.z = inv; st.w = qs * inv;
             *reinterpret_cast<float4*>(a.rowstat + (((long)mb * a.n_head + h0 + h) * a.n_out + n) * 4) = st;
             if (a.scale_out && row == 0) a.scale_out[h0 + h] = c[h];
@@ -692,7 +734,7 @@ __global__ __launch_bounds__(256) void posatt_sparse_rows(AttArgs a, SparseArgs 
 #pragma unroll
         for (int r = 0; r < CR; ++r) {
             const float iv = buf_load(rvals, cvalid[r] ? uoff[r] + (unsigned)n * ld4 : a.values_bytes);
-            if (cvalid[r]) a.out[(long)cb[r] * a.out_bstride + (long)n * a.ld_out + cd[r]] = iv;
+            if (cvalid[r] && active) a.out[(long)cb[r] * a.out_bstride + (long)n * a.ld_out + cd[r]] = iv;
         }
     }
 }
@@ -947,11 +989,17 @@ extern "C" int pit_posatt_bwd(const float* mesh_out, const float* mesh_in, int m
     const bool sparse = masked && nbr_idx && nbr_cnt;
     SparseArgs sp{nbr_idx, nbr_cnt, nbr_cap, rev_ptr, rev_row, (long)n_out * nbr_cap};
     if (d_head) {
+        a.d_head = d_head; a.dhead_src = head; a.dhead_is_scale = head_is_scale; a.accumulate_head = accumulate_head;
+        // one hot ticket word is fine for a few thousand workgroups; beyond that finish separately
+        const long approx_wgs = sparse ? ((long)mesh_batch * n_out + 3) / 4 * std::max(1, a.ncols / 512) * n_head
+                                       : (long)((n_out + 31) / 32) * n_head * mesh_batch * std::max(1, a.ncols / 128);
+        a.finish_inline = approx_wgs <= 4096;
         if (sparse) launch_sparse_rows<1>(a, sp, s); else launch_rows<1>(a, s);
         PIT_CHECK_LAUNCH();
-        hipLaunchKernelGGL(posatt_dhead_finish, dim3(n_head), dim3(256), 0, s, workspace, head, scale,
-                           head_is_scale, accumulate_head, d_head);
-        PIT_CHECK_LAUNCH();
+        if (!a.finish_inline) {
+            hipLaunchKernelGGL(posatt_dhead_finish, dim3(n_head), dim3(256), 0, s, a);
+            PIT_CHECK_LAUNCH();
+        }
     }
     if (d_values) {
         if (sparse && rev_ptr && rev_row) launch_sparse_cols(a, sp, s); else launch_cols(a, s);

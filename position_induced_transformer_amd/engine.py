@@ -28,6 +28,7 @@ class TrainStep:
         self.optimizer = optimizer
         self.flat = flat if flat is not None else FlatGradients(model.parameters())
         self.loss = torch.zeros((), device=self.func_in.device)
+        self._seed = torch.ones((), device=self.func_in.device)      # d loss / d loss, allocated once
         self.graph: Optional[torch.cuda.CUDAGraph] = None
 
     def _step(self) -> None:
@@ -35,8 +36,8 @@ class TrainStep:
         out = self.model(self.mesh_in, self.func_in, self.mesh_out)
         sc, sh = self.affine if self.affine is not None else (None, None)
         loss = ops.rel_lp_loss(self.target, out, self.out_dim, self.p, sc, sh)
-        loss.backward()
-        self.loss.copy_(loss.detach())
+        torch.autograd.backward(loss, grad_tensors=self._seed)        # no ones_like fill per step
+        self.loss = loss.detach()            # same storage every replay (graph-private pool): no copy
         if self.all_reduce:
             self.flat.all_reduce()
         if self.optimizer is not None:

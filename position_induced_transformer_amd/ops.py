@@ -8,6 +8,7 @@ CPU or eager-PyTorch path: tensors must live on the GPU and the shared library m
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Optional
 
 import numpy as np
@@ -28,14 +29,17 @@ FUSED_GRAD_ACCUMULATION = True
 # HIP stream (fork after their inputs exist, one join when the backward pass ends), so they
 # overlap the critical d-values / d-x chain.  Only used together with in-place accumulation
 # (their results then go nowhere but the .grad buffers).  Captured into hipGraphs as parallel
-# branches.
-OVERLAP_BACKWARD = True
+# branches.  OFF by default: measured on MI355X (Darcy b=8) a graph with cross-stream edges replays
+# slower than the linear one once the kernels are ~5 us (0.524 vs 0.485 ms/step); it pays only for
+# long kernels.  Enable with PIT_OVERLAP_BACKWARD=1.
+OVERLAP_BACKWARD = os.environ.get("PIT_OVERLAP_BACKWARD", "0") != "0"
 
 # Masked (locality < 1) layers run on per-row candidate lists (O(N*k) work) when the lists are
 # much shorter than the key axis; False forces the dense MFMA kernels everywhere.
 SPARSE_MASKED = True
 
 _DSCALE_WS = {}
+_LOSS_WS = {}
 _SIDE = {}          # device index -> {"stream", "pending", "keep"}
 
 
@@ -71,8 +75,8 @@ def _dscale_workspace(device, n_head: int) -> torch.Tensor:
     zeroed buffer per device serves every layer (launches are stream-ordered)."""
     key = device.index
     ws = _DSCALE_WS.get(key)
-    if ws is None or ws.numel() < n_head * 1024:
-        ws = torch.zeros(max(8, n_head) * 1024, device=device, dtype=torch.float64)   # PIT_DSCALE_SLOTS = 1024
+    if ws is None or ws.numel() < n_head * 1024 + 8:
+        ws = torch.zeros(max(8, n_head) * 1024 + 8, device=device, dtype=torch.float64)   # slots + counter
         _DSCALE_WS[key] = ws
     return ws
 
@@ -372,8 +376,12 @@ class _RelLpLoss(torch.autograd.Function):
         sh = shift.reshape(npts, out_dim).contiguous() if shift is not None else None
         norms = torch.empty((b, out_dim, 2), device=t.device, dtype=torch.float32)
         loss = torch.empty((), device=t.device, dtype=torch.float32)
+        ws = _LOSS_WS.get(t.device.index)
+        if ws is None:
+            ws = _LOSS_WS[t.device.index] = torch.zeros(2, device=t.device, dtype=torch.float32)
         rc = _lib.lib().pit_rel_lp_loss_fwd(t.data_ptr(), q.data_ptr(), _lib.ptr(sc), _lib.ptr(sh), b, npts,
-                                            out_dim, int(p), norms.data_ptr(), loss.data_ptr(), _lib.stream_ptr())
+                                            out_dim, int(p), norms.data_ptr(), loss.data_ptr(), ws.data_ptr(),
+                                            _lib.stream_ptr())
         _lib.check(rc, "pit_rel_lp_loss_fwd")
         ctx.meta = (b, npts, out_dim, int(p), pred.shape, true.shape)
         ctx.save_for_backward(t, q, norms, sc if sc is not None else norms, sh if sh is not None else norms)

@@ -178,7 +178,8 @@ def test_mlp_forward_backward(ops, name):
         assert gio.rel_l2(e, g) <= (TOL_FWD if key == "y" else TOL_GRAD), key
 
 
-@pytest.mark.parametrize("rows,n0,n1,n2", [(300, 24, 32, 32), (1000, 192, 64, 64), (77, 5, 130, 3)])
+@pytest.mark.parametrize("rows,n0,n1,n2", [(300, 24, 32, 32), (1000, 192, 64, 64), (77, 5, 130, 3),
+                                            (3000, 200, 130, 70), (2304, 768, 256, 256)])   # last two: LDS-tiled GEMM
 def test_mlp_trailing_gelu_vs_oracle(ops, rows, n0, n1, n2):
     """The fused trailing gelu of pit.py:111,121 (out_gelu=True) against torch on the CPU."""
     shapes = [("mlp1.weight", (n1, n0)), ("mlp1.bias", (n1,)), ("mlp2.weight", (n2, n1)), ("mlp2.bias", (n2,))]
