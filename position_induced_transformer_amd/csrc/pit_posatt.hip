@@ -37,7 +37,7 @@ struct AttArgs {
     const float* d_out; long ld_dout, dout_bstride;
     float* d_values; long ld_dvalues, dvalues_bstride; int add_residual;
     double* dscale_acc;
-    float* d_head; const float* dhead_src; int dhead_is_scale, accumulate_head, finish_inline;   // d(scale) finish
+    float* d_head; const float* dhead_src; int dhead_is_scale, accumulate_head, finish_inline, nslots;   // d(scale) finish
     int ncols, colgroups;
     unsigned values_bytes, dout_bytes;    // extents for the raw-buffer descriptors
 };
@@ -61,7 +61,7 @@ __device__ __forceinline__ void dscale_add(double* slot, double v, bool doit) {
 __device__ __forceinline__ void dscale_drain_head(const AttArgs& a, int h, double* s_red) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
     double g = 0.0;
-    for (int sl = threadIdx.x; sl < PIT_DSCALE_SLOTS; sl += blockDim.x) {
+    for (int sl = threadIdx.x; sl < a.nslots; sl += blockDim.x) {      // only the slots this launch used
         unsigned long long* w = reinterpret_cast<unsigned long long*>(a.dscale_acc + (long)h * PIT_DSCALE_SLOTS + sl);
         g += __longlong_as_double((long long)atomicExch(w, 0ull));
     }
@@ -300,7 +300,7 @@ __global__ __launch_bounds__(512) void posatt_rows_kernel(AttArgs a) {
             for (int i = 0; i < 16; ++i) part += (double)acc[t][i] * (double)dov[t][i];
         part = wave_sum_d(part);
         // PIT_DSCALE_SLOTS accumulators per head keep the fp64 atomics off a single address
-        const int slot = (int)((blockIdx.z + 131u * blockIdx.x + 977u * wave) & (PIT_DSCALE_SLOTS - 1));
+        const int slot = (int)((blockIdx.z + 131u * blockIdx.x + 977u * wave) & (a.nslots - 1));
         dscale_add(a.dscale_acc + h * PIT_DSCALE_SLOTS + slot, -part, lane == 0);
         __shared__ double s_red[10];
         dscale_finish(a, s_red);
@@ -708,7 +708,7 @@ __global__ __launch_bounds__(256) void posatt_sparse_rows(AttArgs a, SparseArgs 
                 part += (double)acc[h][r] * (double)buf_load(rdo, cvalid[r] ? off : a.dout_bytes);
             }
             part = wave_sum_d(part);
-            const int slot = (int)((blockIdx.x + 131u * blockIdx.y + 977u * wave) & (PIT_DSCALE_SLOTS - 1));
+            const int slot = (int)((blockIdx.x + 131u * blockIdx.y + 977u * wave) & (a.nslots - 1));
             dscale_add(a.dscale_acc + (h0 + h) * PIT_DSCALE_SLOTS + slot, -part, lane == 0 && active);
         }
         __shared__ double s_red[10];
@@ -994,6 +994,11 @@ extern "C" int pit_posatt_bwd(const float* mesh_out, const float* mesh_in, int m
         const long approx_wgs = sparse ? ((long)mesh_batch * n_out + 3) / 4 * std::max(1, a.ncols / 512) * n_head
                                        : (long)((n_out + 31) / 32) * n_head * mesh_batch * std::max(1, a.ncols / 128);
         a.finish_inline = approx_wgs <= 4096;
+        // accumulator slots in use: ~32 adds per slot keeps the fp64 atomics uncontended while the
+        // drain (one exchange per slot and head) stays short for small launches
+        int ns = 32;
+        while (ns < PIT_DSCALE_SLOTS && (long)ns * 32 < approx_wgs * 4) ns <<= 1;
+        a.nslots = ns;
         if (sparse) launch_sparse_rows<1>(a, sp, s); else launch_rows<1>(a, s);
         PIT_CHECK_LAUNCH();
         if (!a.finish_inline) {
