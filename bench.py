@@ -36,6 +36,8 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 FP32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+# dense, reference-equivalent fwd+bwd GFLOP per sample
+GFLOP_PER_SAMPLE = {"darcy": 0.781, "burgers": 0.643, "vorticity": 9.126, "elasticity": 22.406, "naca": 10.005}
 
 
 T_START = time.perf_counter()
@@ -299,6 +301,10 @@ def main():
                        "parallelism": f"dp{world}" if world > 1 else "single", "launch": mode},
             "loss": round(loss_val, 6),
         }
+        if args.task in GFLOP_PER_SAMPLE:      # whole-step algorithmic rate against the fp32 MFMA peak
+            tf = value * GFLOP_PER_SAMPLE[args.task] / 1e3
+            rec["step_tflops"] = {"achieved": round(tf, 2), "frac_of_fp32_mfma_peak": round(tf / FP32_MFMA_PEAK_TFLOPS / world, 4),
+                                  "gflop_per_sample": GFLOP_PER_SAMPLE[args.task]}
     extras = {}
     if world == 1 and not args.no_extras:
         # (a) the same step with Adam (capturable) inside the graph
@@ -316,6 +322,8 @@ def main():
             n3 = max(args.steps // 4, 10)
             dt3 = timed(run3, n3, 5, world)
             sweep[str(b)] = round(b * n3 / dt3, 1)
+            if args.task in GFLOP_PER_SAMPLE:
+                sweep[str(b) + "_step_tflops"] = round(sweep[str(b)] * GFLOP_PER_SAMPLE[args.task] / 1e3, 2)
             log(f"batch {b}: {sweep[str(b)]} samples/s")
             del st3, run3
             torch.cuda.empty_cache()

@@ -170,3 +170,61 @@ def test_vorticity_rollout_matches_oracle():
     for k, q in model.named_parameters():
         tol = 5e-4 if k.endswith("lmda") else 1e-4
         assert gio.rel_l2(p[k].grad.numpy(), q.grad.cpu().numpy()) <= tol, k
+
+
+def _oracle_params(model):
+    return {k: v.detach().cpu().clone().requires_grad_(True) for k, v in model.state_dict().items()}
+
+
+def test_naca_wrapper_matches_oracle():
+    """pit_naca forward (train_naca.py:47-65): latent mesh = strided sub-grid of the body-fitted
+    output grid, per-sample meshes; reduced grid, against the oracle with the same slicing."""
+    from position_induced_transformer_amd import tasks, utils
+    torch.manual_seed(11)
+    model = tasks.pit_naca(2, 2, 4, 32, 1, 2, None, 4, 4, 0.05, 0.05).cuda()
+    model.x_res, model.y_res = 12, 5                                  # 45 x 19 grid -> 12 x 5 latent
+    b = 2
+    th = torch.linspace(0, 6.2, 40)
+    outline = torch.stack((torch.cos(th), 0.3 * torch.sin(th)), -1).unsqueeze(0).repeat(b, 1, 1)
+    outline = outline + 0.01 * torch.from_numpy(gio.synth((b, 40, 2), 81))
+    gx, gy = torch.meshgrid(torch.linspace(-2, 2, 45), torch.linspace(-1, 1, 19), indexing="ij")
+    grid = torch.stack((gx, gy), -1).unsqueeze(0).repeat(b, 1, 1, 1) + 0.01 * torch.from_numpy(gio.synth((b, 45, 19, 2), 82))
+    y = torch.from_numpy(gio.synth((b, 45, 19, 4), 83))
+    out = model(outline.cuda(), outline.cuda(), grid.cuda())
+    loss = utils.RelLpNorm(4, 2)(y.cuda(), out)
+    loss.backward()
+    p = _oracle_params(model)
+    ltt = grid[:, ::4, ::4][:, :12, :5].reshape(b, -1, 2)
+    flat = grid.reshape(b, -1, 2)
+    ref = orc.pit_apply(p, "euclid", True, 2, 0.05, 0.05, outline, outline, ltt, flat).reshape(b, 45, 19, 4)
+    rl = orc.rel_lp_loss(y, ref, 4, 2)
+    rl.backward()
+    assert gio.rel_l2(ref.detach().numpy(), out.detach().cpu().numpy()) <= TOL_OUT
+    for k, q in model.named_parameters():
+        tol = TOL_HEAD if k.endswith("lmda") else TOL_GRAD
+        assert gio.rel_l2(p[k].grad.numpy(), q.grad.cpu().numpy()) <= tol, k
+
+
+def test_cylinder_wrapper_residual_matches_oracle():
+    """pit_cylinder forward (train_cylinder.py:40-52): unstructured fixed mesh, one head, the
+    input added back onto the prediction; loss called as myloss(out, y) (train_cylinder.py:101)."""
+    from position_induced_transformer_amd import tasks, utils
+    torch.manual_seed(12)
+    mesh = torch.from_numpy(gio.synth((300, 2), 84, 0.0, 2.0))
+    ltt = mesh[::4].contiguous()
+    model = tasks.pit_cylinder(2, 3, 3, 32, 1, 2, ltt.cuda(), 0.05, 0.05).cuda()
+    x = torch.from_numpy(gio.synth((3, 300, 3), 85))
+    y = torch.from_numpy(gio.synth((3, 300, 3), 86))
+    out = model(mesh.cuda(), x.cuda(), mesh.cuda())
+    loss = utils.RelLpNorm(3, 2)(out, y.cuda())
+    loss.backward()
+    p = _oracle_params(model)
+    f = orc.with_coords(mesh, x)
+    ref = orc.pit_apply(p, "euclid", False, 2, 0.05, 0.05, mesh, f, ltt, mesh) + x
+    rl = orc.rel_lp_loss(ref, y, 3, 2)
+    rl.backward()
+    assert gio.rel_l2(ref.detach().numpy(), out.detach().cpu().numpy()) <= TOL_OUT
+    assert abs(float(loss.detach()) - float(rl.detach())) <= 1e-5 * abs(float(rl.detach()))
+    for k, q in model.named_parameters():
+        tol = TOL_HEAD if k.endswith("lmda") else TOL_GRAD
+        assert gio.rel_l2(p[k].grad.numpy(), q.grad.cpu().numpy()) <= tol, k
