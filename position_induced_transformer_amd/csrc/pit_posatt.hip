@@ -38,7 +38,7 @@ struct AttArgs {
     float* d_values; long ld_dvalues, dvalues_bstride; int add_residual;
     double* dscale_acc;
     float* d_head; const float* dhead_src; int dhead_is_scale, accumulate_head, finish_inline, nslots;   // d(scale) finish
-    int ncols, colgroups;
+    int ncols, colgroups, tiles_per_wg;
     unsigned values_bytes, dout_bytes;    // extents for the raw-buffer descriptors
 };
 
@@ -488,13 +488,383 @@ __global__ __launch_bounds__(512) void posatt_cols_kernel(AttArgs a) {
     }
 }
 
-int pow2_floor(int v) { int p = 1; while (p * 2 <= v) p *= 2; return p; }
+// ------------------------------------------------------------------------------------
+// Large-regime kernels (>= 8 column tiles per row tile): weights in LDS, whole tiles per wave.
+//
+// The J-split kernels above recompute the 32 x J weight tile for every group of 128 columns and
+// pay a cross-wave reduction plus a prologue per 128 columns - fine when the layer is tiny, the
+// dominant cost at batch 256 (MFMA busy 24-30 %).  Here a workgroup (8 waves) forms the weight
+// tile ONCE per 256-key chunk into LDS (k-major, so an A fragment is a conflict-free 32-lane
+// read), and every wave owns up to 4 whole 32-column tiles of the output: no reduction between
+// waves, the weights are reused by up to 32 column tiles, value rows are read once per tile.
+constexpr int TK_CHUNK = 256;
 
-// tuning overrides for experiments (tools/microbench.py): PIT_FORCE_CT, PIT_FORCE_WAVES
+// RT = 32-row tiles per workgroup: every value (B) fragment fetched from L2 feeds RT MFMAs, which
+// is what bounds these kernels at scale (16*RT flop per operand byte).
+template <int RT, int TPW, int MODE, bool MASKED>
+__global__ __launch_bounds__(512) void posatt_rows_tiles(AttArgs a) {
+    constexpr int KC = TK_CHUNK / RT;                     // keys per LDS pass: Ps is always 32 KiB
+    constexpr int GW = KC / 64;                           // 8-key groups filled per wave per pass
+    __shared__ float Ps[KC * 32 * RT];
+    __shared__ float4 s_xi[KC];
+    __shared__ int s_flag[KC / 8];
+    __shared__ float s_rs[2][16][32 * RT];
+    __shared__ double s_red[10];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int n0 = blockIdx.z * 32 * RT;
+    const int h = blockIdx.y;
+    const int mb = blockIdx.x / a.colgroups, cs = blockIdx.x % a.colgroups;
+    const long rows_total = (long)a.mesh_batch * a.n_out;
+    const float c = a.head_is_scale ? a.head[h] : head_scale_from_lmda(a.head[h]);
+    const unsigned mo_bytes = (unsigned)((long)a.mesh_batch * a.n_out * a.sdim * 4);
+    const unsigned mi_bytes = (unsigned)((long)a.mesh_batch * a.n_in * a.sdim * 4);
+    const __amdgpu_buffer_rsrc_t rmo = make_rsrc(a.mesh_out, mo_bytes);
+    const __amdgpu_buffer_rsrc_t rmi = make_rsrc(a.mesh_in, mi_bytes);
+
+    // per-lane row constants for each of the RT row tiles (row = n0 + rt*32 + lane&31)
+    float4 xo[RT];
+    float T[RT], s_min[RT], inv_l[RT], mbar[RT];
+    bool nvalid[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        const int n = n0 + rt * 32 + l31;
+        nvalid[rt] = n < a.n_out;
+        const int nc = nvalid[rt] ? n : a.n_out - 1;
+        const long rowid = (long)mb * a.n_out + nc;
+        xo[rt] = load_point4(rmo, mo_bytes, rowid, a.sdim, a.coords_used);
+        T[rt] = __builtin_inff(); s_min[rt] = 0.0f; inv_l[rt] = 0.0f; mbar[rt] = 0.0f;
+        if (MODE == 0) {
+            if (MASKED) T[rt] = quantile_lerp(__fmul_rn(c, a.stats[rowid]), __fmul_rn(c, a.stats[rows_total + rowid]), a.rank_w);
+            if (a.stats) s_min[rt] = __fmul_rn(c, a.stats[2 * rows_total + rowid]);
+        } else {
+            const float4 rs4 = *reinterpret_cast<const float4*>(a.rowstat + (((long)mb * a.n_head + h) * a.n_out + nc) * 4);
+            T[rt] = rs4.x; s_min[rt] = rs4.y; inv_l[rt] = rs4.z; mbar[rt] = rs4.w;
+        }
+    }
+
+    // this wave's column tiles: interleaved over the workgroup's tile range
+    const __amdgpu_buffer_rsrc_t rvals = make_rsrc(a.values, a.values_bytes);
+    const unsigned ld4 = (unsigned)a.ld_values * 4u;
+    const int ntiles = (a.ncols + 31) / 32;
+    const int tile_end = min(ntiles, (cs + 1) * a.tiles_per_wg);
+    unsigned uoff[TPW];
+    bool cvalid[TPW];
+    int cb[TPW], cd[TPW];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+        const int tile = cs * a.tiles_per_wg + wave + 8 * t;
+        const int col = tile * 32 + l31;
+        cvalid[t] = tile < tile_end && col < a.ncols;
+        const int cc = cvalid[t] ? col : 0;
+        cb[t] = (a.mesh_batch == 1) ? cc / a.dim : mb;
+        cd[t] = (a.mesh_batch == 1) ? cc % a.dim : cc;
+        uoff[t] = (unsigned)(((long)cb[t] * a.values_bstride + cd[t]) * 4);
+    }
+    f32x16 acc[RT][TPW];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int t = 0; t < TPW; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[rt][t][i] = 0.0f;
+    float rsum[RT], qsum[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) { rsum[rt] = 0.0f; qsum[rt] = 0.0f; }
+    const bool per = a.periodic != 0;
+
+    for (int c0 = 0; c0 < a.n_in; c0 += KC) {
+        const int len = min(KC, a.n_in - c0);
+        const int ngroups = (len + 7) / 8;
+        float bnext[4][TPW];
+        auto prefetch = [&](int g) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int jl = g * 8 + 2 * u + half;
+                const bool jv = g < ngroups && jl < len;
+                const unsigned rowoff = (unsigned)(c0 + jl) * ld4;
+#pragma unroll
+                for (int t = 0; t < TPW; ++t)
+                    bnext[u][t] = buf_load(rvals, (jv && cvalid[t]) ? uoff[t] + rowoff : a.values_bytes);
+            }
+        };
+        prefetch(0);                                          // value rows in flight during the weight phase
+        __syncthreads();                                      // previous chunk fully consumed
+        for (int idx = tid; idx < len; idx += 512)
+            s_xi[idx] = load_point4(rmi, mi_bytes, (long)mb * a.n_in + c0 + idx, a.sdim, a.coords_used);
+        __syncthreads();
+        // ---- weight phase: this wave fills keys [8*GW*wave, 8*GW*(wave+1)) of the chunk, all RT row tiles
+#pragma unroll
+        for (int it = 0; it < GW; ++it) {
+            const int g = wave * GW + it;
+            bool anyk = false;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int jl = g * 8 + 2 * u + half;
+                const bool jv = jl < len;
+                const float4 xi = s_xi[jv ? jl : 0];
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) {
+                    const float m = sq_dist3(xo[rt].x, xo[rt].y, xo[rt].z, xi.x, xi.y, xi.z, per, a.period);
+                    const float sv = __fmul_rn(m, c);
+                    const bool keep = jv && nvalid[rt] && (sv <= T[rt]);
+                    const float p = keep ? __expf(s_min[rt] - sv) : 0.0f;
+                    float w = p;
+                    if (MODE == 0) { rsum[rt] += p; qsum[rt] += p * m; }
+                    else w = p * (m - mbar[rt]) * inv_l[rt];
+                    Ps[(jl * RT + rt) * 32 + l31] = w;
+                    anyk |= keep;
+                }
+            }
+            const bool flag = __builtin_amdgcn_ballot_w64(anyk) != 0ull;
+            if (lane == 0) s_flag[g] = flag ? 1 : 0;
+        }
+        __syncthreads();
+        // ---- contraction phase: every wave walks the whole chunk for its own tiles
+        for (int g = 0; g < ngroups; ++g) {
+            float bcur[4][TPW];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int t = 0; t < TPW; ++t) bcur[u][t] = bnext[u][t];
+            prefetch(g + 1);
+            if (MASKED && s_flag[g] == 0) continue;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                float af[RT];
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) af[rt] = Ps[((g * 8 + 2 * u + half) * RT + rt) * 32 + l31];
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                    for (int t = 0; t < TPW; ++t) acc[rt][t] = mfma_32x32x2(af[rt], bcur[u][t], acc[rt][t]);
+            }
+        }
+    }
+
+    if (MODE == 1) {
+        const __amdgpu_buffer_rsrc_t rdo = make_rsrc(a.d_out, a.dout_bytes);
+        double part = 0.0;
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int t = 0; t < TPW; ++t) {
+                const unsigned cbase = (unsigned)(((long)cb[t] * a.dout_bstride + a.out_col0 + (long)h * a.dim + cd[t]) * 4);
+                float dov[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int nr = n0 + rt * 32 + acc_row(i, half);
+                    dov[i] = buf_load(rdo, (cvalid[t] && nr < a.n_out) ? cbase + (unsigned)nr * (unsigned)a.ld_dout * 4u
+                                                                       : a.dout_bytes);
+                }
+#pragma unroll
+                for (int i = 0; i < 16; ++i) part += (double)acc[rt][t][i] * (double)dov[i];
+            }
+        part = wave_sum_d(part);
+        const int slot = (int)((blockIdx.z + 131u * blockIdx.x + 977u * wave) & (a.nslots - 1));
+        dscale_add(a.dscale_acc + h * PIT_DSCALE_SLOTS + slot, -part, lane == 0);
+        dscale_finish(a, s_red);
+        return;
+    }
+    // ---- forward epilogue: row sums over the 16 (wave, half) partials, normalise, store
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        s_rs[0][wave * 2 + half][rt * 32 + l31] = rsum[rt];
+        s_rs[1][wave * 2 + half][rt * 32 + l31] = qsum[rt];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        float rs_tot = 0.0f, qs_tot = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { rs_tot += s_rs[0][k][rt * 32 + l31]; qs_tot += s_rs[1][k][rt * 32 + l31]; }
+        const float inv = rs_tot > 0.0f ? 1.0f / rs_tot : 0.0f;
+        float inv_row[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) inv_row[i] = __shfl(inv, acc_row(i, half));
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) {
+            float* ocol = a.out + (long)cb[t] * a.out_bstride + a.out_col0 + (long)h * a.dim + cd[t];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int nr = n0 + rt * 32 + acc_row(i, half);
+                if (cvalid[t] && nr < a.n_out) ocol[(long)nr * a.ld_out] = acc[rt][t][i] * inv_row[i];
+            }
+            if (a.copy_inputs && h == 0) {
+                float iv[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int nr = n0 + rt * 32 + acc_row(i, half);
+                    iv[i] = buf_load(rvals, (cvalid[t] && nr < a.n_out) ? uoff[t] + (unsigned)nr * ld4 : a.values_bytes);
+                }
+                float* icol = a.out + (long)cb[t] * a.out_bstride + cd[t];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int nr = n0 + rt * 32 + acc_row(i, half);
+                    if (cvalid[t] && nr < a.n_out) icol[(long)nr * a.ld_out] = iv[i];
+                }
+            }
+        }
+        if (wave == 0 && cs == 0 && half == 0 && nvalid[rt]) {
+            float4 st; st.x = T[rt]; st.y = s_min[rt]; st.z = inv; st.w = qs_tot * inv;
+            *reinterpret_cast<float4*>(a.rowstat + (((long)mb * a.n_head + h) * a.n_out + n0 + rt * 32 + l31) * 4) = st;
+        }
+    }
+    if (a.scale_out && tid == 0 && blockIdx.x == 0 && blockIdx.z == 0) a.scale_out[h] = c;
+}
+
+template <int TPW, bool MASKED>
+__global__ __launch_bounds__(512) void posatt_cols_tiles(AttArgs a) {
+    __shared__ float Ps[TK_CHUNK * 32];
+    __shared__ float4 s_rec[TK_CHUNK * 2];
+    __shared__ int s_flag[TK_CHUNK / 8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int j0 = blockIdx.y * 32;
+    const int cs = blockIdx.x;
+    const int mb = blockIdx.z;
+    const int j = j0 + l31;
+    const bool jvalid = j < a.n_in;
+    const unsigned mo_bytes = (unsigned)((long)a.mesh_batch * a.n_out * a.sdim * 4);
+    const unsigned mi_bytes = (unsigned)((long)a.mesh_batch * a.n_in * a.sdim * 4);
+    const __amdgpu_buffer_rsrc_t rmo = make_rsrc(a.mesh_out, mo_bytes);
+    const __amdgpu_buffer_rsrc_t rmi = make_rsrc(a.mesh_in, mi_bytes);
+    const float4 xi = load_point4(rmi, mi_bytes, (long)mb * a.n_in + (jvalid ? j : a.n_in - 1), a.sdim, a.coords_used);
+    const __amdgpu_buffer_rsrc_t rdout = make_rsrc(a.d_out, a.dout_bytes);
+    const unsigned ldd4 = (unsigned)a.ld_dout * 4u;
+    const int ntiles = (a.ncols + 31) / 32;
+    const int tile_end = min(ntiles, (cs + 1) * a.tiles_per_wg);
+    unsigned doff[TPW];
+    bool cvalid[TPW];
+    int cb[TPW], cd[TPW];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+        const int tile = cs * a.tiles_per_wg + wave + 8 * t;
+        const int col = tile * 32 + l31;
+        cvalid[t] = tile < tile_end && col < a.ncols;
+        const int cc = cvalid[t] ? col : 0;
+        cb[t] = (a.mesh_batch == 1) ? cc / a.dim : mb;
+        cd[t] = (a.mesh_batch == 1) ? cc % a.dim : cc;
+        doff[t] = (unsigned)(((long)cb[t] * a.dout_bstride + a.out_col0 + cd[t]) * 4);
+    }
+    f32x16 acc[TPW];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
+    const bool per = a.periodic != 0;
+
+    for (int h = 0; h < a.n_head; ++h) {
+        const float c = a.head_is_scale ? a.head[h] : head_scale_from_lmda(a.head[h]);
+        const unsigned hoff = (unsigned)h * (unsigned)a.dim * 4u;
+        for (int c0 = 0; c0 < a.n_out; c0 += TK_CHUNK) {
+            const int len = min(TK_CHUNK, a.n_out - c0);
+            const int ngroups = (len + 7) / 8;
+            float bnext[4][TPW];
+            auto prefetch = [&](int g) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int nl = g * 8 + 2 * u + half;
+                    const bool nv = g < ngroups && nl < len;
+                    const unsigned rowoff = (unsigned)(c0 + nl) * ldd4 + hoff;
+#pragma unroll
+                    for (int t = 0; t < TPW; ++t)
+                        bnext[u][t] = buf_load(rdout, (nv && cvalid[t]) ? doff[t] + rowoff : a.dout_bytes);
+                }
+            };
+            prefetch(0);
+            __syncthreads();
+            for (int idx = tid; idx < len; idx += 512) {
+                const long rowid = (long)mb * a.n_out + c0 + idx;
+                const float4 xo = load_point4(rmo, mo_bytes, rowid, a.sdim, a.coords_used);
+                const float4 rs4 = *reinterpret_cast<const float4*>(
+                    a.rowstat + (((long)mb * a.n_head + h) * a.n_out + c0 + idx) * 4);
+                float4 r0; r0.x = xo.x; r0.y = xo.y; r0.z = xo.z; r0.w = rs4.x;
+                float4 r1; r1.x = rs4.y; r1.y = rs4.z; r1.z = 0.0f; r1.w = 0.0f;
+                s_rec[2 * idx] = r0;
+                s_rec[2 * idx + 1] = r1;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int g = wave * 4 + it;
+                bool anyk = false;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int nl = g * 8 + 2 * u + half;
+                    const bool nv = nl < len;
+                    const float4 r0 = s_rec[2 * (nv ? nl : 0)];
+                    const float4 r1 = s_rec[2 * (nv ? nl : 0) + 1];
+                    const float m = sq_dist3(r0.x, r0.y, r0.z, xi.x, xi.y, xi.z, per, a.period);
+                    const float sv = __fmul_rn(m, c);
+                    const bool keep = nv && jvalid && (sv <= r0.w);
+                    Ps[nl * 32 + l31] = keep ? __expf(r1.x - sv) * r1.y : 0.0f;
+                    anyk |= keep;
+                }
+                const bool flag = __builtin_amdgcn_ballot_w64(anyk) != 0ull;
+                if (lane == 0) s_flag[g] = flag ? 1 : 0;
+            }
+            __syncthreads();
+            for (int g = 0; g < ngroups; ++g) {
+                float bcur[4][TPW];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int t = 0; t < TPW; ++t) bcur[u][t] = bnext[u][t];
+                prefetch(g + 1);
+                if (MASKED && s_flag[g] == 0) continue;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float af = Ps[(g * 8 + 2 * u + half) * 32 + l31];
+#pragma unroll
+                    for (int t = 0; t < TPW; ++t) acc[t] = mfma_32x32x2(af, bcur[u][t], acc[t]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+        const unsigned rbase = (unsigned)(((long)cb[t] * a.dout_bstride + cd[t]) * 4);
+        float rv[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int jr = j0 + acc_row(i, half);
+            rv[i] = buf_load(rdout, (a.add_residual && cvalid[t] && jr < a.n_in) ? rbase + (unsigned)jr * ldd4
+                                                                                 : a.dout_bytes);
+        }
+        float* gcol = a.d_values + (long)cb[t] * a.dvalues_bstride + cd[t];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int jr = j0 + acc_row(i, half);
+            if (cvalid[t] && jr < a.n_in) gcol[(long)jr * a.ld_dvalues] = acc[t][i] + rv[i];
+        }
+    }
+}
+
+// tuning overrides for experiments (tools/microbench.py): PIT_FORCE_CT, PIT_FORCE_WAVES, PIT_NO_TILES_KERNEL
 int env_int(const char* name) {
     const char* v = getenv(name);
     return v ? atoi(v) : 0;
 }
+
+// tiles per workgroup for the large-regime kernels (0 = use the J-split kernels): they pay off
+// only when the launch has real work (MFMA-instruction count), small layers stay latency-bound
+int tiles_per_wg_for(int ncols, long units, long work_mfma, int mesh_batch) {
+    if (env_int("PIT_NO_TILES_KERNEL")) return 0;
+    const int ntiles = (ncols + 31) / 32;
+    if (ntiles < 8) return 0;
+    // measured (MI355X): wins for batch-free meshes with the batch folded into >= 32 column tiles
+    // (Darcy b=256: 106 -> 55 us per processor layer); per-sample meshes with 8 tiles are faster
+    // on the J-split kernels
+    if (!env_int("PIT_FORCE_TILES") && (mesh_batch != 1 || ntiles < 32 || work_mfma < (1L << 19))) return 0;
+    int tpw = 32;                                              // 4 tiles per wave
+    while (tpw > 8 && (ntiles < tpw || units * ((ntiles + tpw - 1) / tpw) < 512)) tpw >>= 1;
+    return tpw;
+}
+
+int pow2_floor(int v) { int p = 1; while (p * 2 <= v) p *= 2; return p; }
+
+
 
 // column-tile count per workgroup: least padding, then enough workgroups to cover the chip
 int choose_ct(int ncols, long other_wgs) {
@@ -523,6 +893,29 @@ template <int MODE>
 void launch_rows(const AttArgs& a0, hipStream_t s) {
     AttArgs a = a0;
     const int n_tiles = (a.n_out + 31) / 32;
+    const long work = (long)n_tiles * a.n_head * a.mesh_batch * ((a.ncols + 31) / 32) * ((a.n_in + 1) / 2);
+    // row tiles per workgroup: more reuse of every value fragment, as long as the grid still fills the chip
+    int rt = 4;
+    while (rt > 1 && (n_tiles < rt || (long)((n_tiles + rt - 1) / rt) * a.n_head * a.mesh_batch * ((a.ncols + 255) / 256) < 256)) rt >>= 1;
+    if (int f = env_int("PIT_FORCE_RT")) rt = f;
+    if (const int tpwg0 = tiles_per_wg_for(a.ncols, (long)((n_tiles + rt - 1) / rt) * a.n_head * a.mesh_batch, work, a.mesh_batch)) {
+        int tpwg = tpwg0;
+        if (rt == 4) tpwg = 8;                                 // registers: RT*TPW accumulator tiles <= 4
+        else if (rt == 2 && tpwg > 16) tpwg = 16;
+        a.tiles_per_wg = tpwg;
+        a.colgroups = ((a.ncols + 31) / 32 + tpwg - 1) / tpwg;
+        dim3 grid(a.mesh_batch * a.colgroups, a.n_head, (n_tiles + rt - 1) / rt), block(512);
+#define PIT_RT(RT_, TPW_)                                                                                   \
+        do {                                                                                                \
+            if (a.masked) hipLaunchKernelGGL((posatt_rows_tiles<RT_, TPW_, MODE, true>), grid, block, 0, s, a); \
+            else hipLaunchKernelGGL((posatt_rows_tiles<RT_, TPW_, MODE, false>), grid, block, 0, s, a);     \
+        } while (0)
+        if (rt == 4) PIT_RT(4, 1);
+        else if (rt == 2) { if (tpwg == 16) PIT_RT(2, 2); else PIT_RT(2, 1); }
+        else { if (tpwg == 32) PIT_RT(1, 4); else if (tpwg == 16) PIT_RT(1, 2); else PIT_RT(1, 1); }
+#undef PIT_RT
+        return;
+    }
     int ct = choose_ct(a.ncols, (long)n_tiles * a.n_head * a.mesh_batch);
     if (int f = env_int("PIT_FORCE_CT")) ct = f;
     a.colgroups = (a.ncols + 32 * ct - 1) / (32 * ct);
@@ -550,6 +943,20 @@ void launch_rows(const AttArgs& a0, hipStream_t s) {
 void launch_cols(const AttArgs& a0, hipStream_t s) {
     AttArgs a = a0;
     const int j_tiles = (a.n_in + 31) / 32;
+    const long work = (long)j_tiles * a.mesh_batch * ((a.ncols + 31) / 32) * ((a.n_out + 1) / 2) * a.n_head;
+    if (const int tpwg = tiles_per_wg_for(a.ncols, (long)j_tiles * a.mesh_batch, work, a.mesh_batch)) {
+        a.tiles_per_wg = tpwg;
+        a.colgroups = ((a.ncols + 31) / 32 + tpwg - 1) / tpwg;
+        dim3 grid(a.colgroups, j_tiles, a.mesh_batch), block(512);
+#define PIT_CT(TPW_)                                                                                \
+        do {                                                                                        \
+            if (a.masked) hipLaunchKernelGGL((posatt_cols_tiles<TPW_, true>), grid, block, 0, s, a); \
+            else hipLaunchKernelGGL((posatt_cols_tiles<TPW_, false>), grid, block, 0, s, a);        \
+        } while (0)
+        if (tpwg == 32) PIT_CT(4); else if (tpwg == 16) PIT_CT(2); else PIT_CT(1);
+#undef PIT_CT
+        return;
+    }
     int ct = choose_ct(a.ncols, (long)j_tiles * a.mesh_batch);
     if (int f = env_int("PIT_FORCE_CT")) ct = f;
     a.colgroups = (a.ncols + 32 * ct - 1) / (32 * ct);

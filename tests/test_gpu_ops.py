@@ -306,3 +306,38 @@ def test_long_rows_stream_select_and_chunked_keys(ops, n_out, n_in, q):
     out.backward(d_out.cuda())
     assert gio.rel_l2(ref.detach().numpy(), out.detach().cpu().numpy()) <= TOL_FWD
     assert gio.rel_l2(uc.grad.numpy(), ug.grad.cpu().numpy()) <= TOL_GRAD
+
+
+@pytest.mark.parametrize("batched,q,self_attn,d,b", [(False, 1.0, True, 70, 6), (False, 0.3, False, 70, 6),
+                                                      (True, 1.0, True, 300, 2), (True, 0.4, False, 260, 2),
+                                                      (False, 1.0, False, 64, 20)])
+@pytest.mark.parametrize("force_rt", ["1", "2", "4"])
+def test_wide_column_kernels_vs_oracle(ops, monkeypatch, batched, q, self_attn, d, b, force_rt):
+    """>= 8 column tiles per row tile: the large-regime kernels (weights in LDS, whole tiles per
+    wave, 1/2/4 row tiles per workgroup), forward, d(values) and d(scale), against the oracle;
+    ragged sizes, 3 heads.  (The work threshold is bypassed so small test shapes take this path.)"""
+    monkeypatch.setenv("PIT_FORCE_TILES", "1")
+    monkeypatch.setenv("PIT_FORCE_RT", force_rt)
+    n_out, n_in = (150, 150) if self_attn else (100, 310)
+    shape_o = (b, n_out, 2) if batched else (n_out, 2)
+    shape_i = (b, n_in, 2) if batched else (n_in, 2)
+    mo = torch.from_numpy(gio.synth(shape_o, 51, 0.0, 1.0))
+    mi = mo if self_attn else torch.from_numpy(gio.synth(shape_i, 52, 0.0, 1.0))
+    u = torch.from_numpy(gio.synth((b, n_in, d), 53))
+    c = torch.tensor([0.8, 2.1, 4.4]).reshape(3, 1, 1)
+    plan = ops.MeshPlan("euclid", mo.cuda(), (mo if self_attn else mi).cuda(), q, self_attn)
+    ug = u.cuda().requires_grad_(True)
+    cg = c.reshape(-1).cuda().requires_grad_(True)
+    out = ops.posatt_apply(ug, cg, plan, 3, concat=self_attn, head_is_scale=True)
+    uc = u.clone().requires_grad_(True)
+    cc = c.clone().requires_grad_(True)
+    if self_attn:
+        ref = orc.posatt_self("euclid", batched, mo, uc, None, q, c=cc)
+    else:
+        ref = orc.posatt_cross("euclid", batched, mo, mi, uc, None, q, c=cc)
+    d_out = torch.from_numpy(gio.synth(tuple(ref.shape), 54))
+    ref.backward(d_out)
+    out.backward(d_out.cuda())
+    assert gio.rel_l2(ref.detach().numpy(), out.detach().cpu().numpy()) <= TOL_FWD
+    assert gio.rel_l2(uc.grad.numpy(), ug.grad.cpu().numpy()) <= TOL_GRAD
+    assert gio.rel_l2(cc.grad.reshape(-1).numpy(), cg.grad.cpu().numpy()) <= TOL_HEAD
