@@ -98,10 +98,10 @@ int pit_posatt_fwd(const float* mesh_out, const float* mesh_in, int mesh_batch, 
  *   scale    the c written to scale_out by the forward (NULL = recompute from head)
  *   d_head   n_head floats (NULL = not needed): gradient w.r.t. lmda (head_is_scale=0) or
  *            w.r.t. c (=1); accumulate_head=1 adds to the current contents instead of writing.
- *   workspace: n_head*PIT_DSCALE_SLOTS + 1 doubles: fp64 accumulators for d c and an arrival
- *            counter.  They must be ZERO on entry and are left zero on exit (the last
- *            workgroup of the d-scale kernel drains them, applies d c/d lmda and writes d_head),
- *            so a caller allocates and zeroes them once; no per-call memset or extra launch.
+ *   workspace: n_head*PIT_DSCALE_SLOTS doubles: fp64 accumulators for d c.  They must be ZERO
+ *            on entry and are left zero on exit (the finishing kernel drains them with atomic
+ *            exchanges, applies d c/d lmda and writes d_head), so a caller allocates and zeroes
+ *            them once; no per-call memset.
  * d_values and d_head are computed by independent kernels: a caller may issue two calls (one
  * with d_values == NULL, one with d_head == NULL) on different streams to overlap them. */
 int pit_posatt_bwd(const float* mesh_out, const float* mesh_in, int mesh_batch, int n_out, int n_in,

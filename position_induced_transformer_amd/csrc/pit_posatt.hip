@@ -37,25 +37,18 @@ struct AttArgs {
     const float* d_out; long ld_dout, dout_bstride;
     float* d_values; long ld_dvalues, dvalues_bstride; int add_residual;
     double* dscale_acc;
-    float* d_head; const float* dhead_src; int dhead_is_scale, accumulate_head, finish_inline, nslots;   // d(scale) finish
+    float* d_head; const float* dhead_src; int dhead_is_scale, accumulate_head, nslots;   // d(scale) finish
     int ncols, colgroups, tiles_per_wg;
     unsigned values_bytes, dout_bytes;    // extents for the raw-buffer descriptors
 };
 
-// d(scale) epilogue shared by the dense and sparse kernels.  Every wave adds its fp64 partial to a
-// slotted accumulator with a RETURNING device-scope atomic (the wave waits for the returned value,
-// so the add has been performed at the memory side before the wave goes on - no cache write-back
-// is involved because only atomics touch these words, hence no __threadfence, which costs ~3.5 us
-// per workgroup on this chip).  The workgroup then takes a ticket; the LAST workgroup of the launch
-// drains the accumulators with atomic exchanges (leaving them zero for the next call), applies
-// d c / d lmda and writes / accumulates d_head: no finishing launch, no memset.  Launches with many
-// workgroups use the separate finishing kernel instead (one hot ticket word would serialise them).
-// `s_red`: 10 doubles of static LDS (80 B keeps the dynamic region 16-B aligned).
+// d(scale): every wave adds its fp64 partial to one of `nslots` accumulators per head (spreading
+// the atomics over addresses); a small finishing kernel (one workgroup per head) drains them with
+// atomic exchanges - leaving them zero for the next call, so no memset is ever needed - applies
+// d c / d lmda and writes or accumulates d_head.  (Folding the drain into the last workgroup of the
+// main kernel via a ticket was measured slower: 0.479 vs 0.469 ms/step on Darcy b=8.)
 __device__ __forceinline__ void dscale_add(double* slot, double v, bool doit) {
-    if (doit) {
-        const double old = atomicAdd(slot, v);
-        asm volatile("" ::"v"(old));             // consume the return value: forces the wait
-    }
+    if (doit) atomicAdd(slot, v);
 }
 
 __device__ __forceinline__ void dscale_drain_head(const AttArgs& a, int h, double* s_red) {
@@ -78,21 +71,6 @@ __device__ __forceinline__ void dscale_drain_head(const AttArgs& a, int h, doubl
         }
         a.d_head[h] = a.accumulate_head ? a.d_head[h] + (float)tot : (float)tot;
     }
-}
-
-__device__ __forceinline__ void dscale_finish(const AttArgs& a, double* s_red) {
-    if (!a.finish_inline) return;
-    unsigned* counter = reinterpret_cast<unsigned*>(a.dscale_acc + (long)a.n_head * PIT_DSCALE_SLOTS);
-    __syncthreads();                               // every wave's returning atomic has completed
-    if (threadIdx.x == 0) {
-        const unsigned total = gridDim.x * gridDim.y * gridDim.z;
-        const unsigned ticket = atomicAdd(counter, 1u);
-        s_red[9] = (ticket == total - 1u) ? 1.0 : 0.0;
-    }
-    __syncthreads();
-    if (s_red[9] == 0.0) return;
-    for (int h = 0; h < a.n_head; ++h) dscale_drain_head(a, h, s_red);
-    if (threadIdx.x == 0) atomicExch(counter, 0u);
 }
 
 __global__ __launch_bounds__(256) void posatt_dhead_finish(AttArgs a) {
@@ -302,8 +280,6 @@ __global__ __launch_bounds__(512) void posatt_rows_kernel(AttArgs a) {
         // PIT_DSCALE_SLOTS accumulators per head keep the fp64 atomics off a single address
         const int slot = (int)((blockIdx.z + 131u * blockIdx.x + 977u * wave) & (a.nslots - 1));
         dscale_add(a.dscale_acc + h * PIT_DSCALE_SLOTS + slot, -part, lane == 0);
-        __shared__ double s_red[10];
-        dscale_finish(a, s_red);
         return;
     }
 
@@ -509,7 +485,6 @@ __global__ __launch_bounds__(512) void posatt_rows_tiles(AttArgs a) {
     __shared__ float4 s_xi[KC];
     __shared__ int s_flag[KC / 8];
     __shared__ float s_rs[2][16][32 * RT];
-    __shared__ double s_red[10];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, l31 = lane & 31;
     const int n0 = blockIdx.z * 32 * RT;
@@ -663,7 +638,6 @@ __global__ __launch_bounds__(512) void posatt_rows_tiles(AttArgs a) {
         part = wave_sum_d(part);
         const int slot = (int)((blockIdx.z + 131u * blockIdx.x + 977u * wave) & (a.nslots - 1));
         dscale_add(a.dscale_acc + h * PIT_DSCALE_SLOTS + slot, -part, lane == 0);
-        dscale_finish(a, s_red);
         return;
     }
     // ---- forward epilogue: row sums over the 16 (wave, half) partials, normalise, store
@@ -1118,8 +1092,6 @@ __global__ __launch_bounds__(256) void posatt_sparse_rows(AttArgs a, SparseArgs 
             const int slot = (int)((blockIdx.x + 131u * blockIdx.y + 977u * wave) & (a.nslots - 1));
             dscale_add(a.dscale_acc + (h0 + h) * PIT_DSCALE_SLOTS + slot, -part, lane == 0 && active);
         }
-        __shared__ double s_red[10];
-        dscale_finish(a, s_red);
         return;
     }
 #pragma unroll
@@ -1397,10 +1369,8 @@ extern "C" int pit_posatt_bwd(const float* mesh_out, const float* mesh_in, int m
     SparseArgs sp{nbr_idx, nbr_cnt, nbr_cap, rev_ptr, rev_row, (long)n_out * nbr_cap};
     if (d_head) {
         a.d_head = d_head; a.dhead_src = head; a.dhead_is_scale = head_is_scale; a.accumulate_head = accumulate_head;
-        // one hot ticket word is fine for a few thousand workgroups; beyond that finish separately
         const long approx_wgs = sparse ? ((long)mesh_batch * n_out + 3) / 4 * std::max(1, a.ncols / 512) * n_head
                                        : (long)((n_out + 31) / 32) * n_head * mesh_batch * std::max(1, a.ncols / 128);
-        a.finish_inline = approx_wgs <= 4096;
         // accumulator slots in use: ~32 adds per slot keeps the fp64 atomics uncontended while the
         // drain (one exchange per slot and head) stays short for small launches
         int ns = 32;
@@ -1408,10 +1378,8 @@ extern "C" int pit_posatt_bwd(const float* mesh_out, const float* mesh_in, int m
         a.nslots = ns;
         if (sparse) launch_sparse_rows<1>(a, sp, s); else launch_rows<1>(a, s);
         PIT_CHECK_LAUNCH();
-        if (!a.finish_inline) {
-            hipLaunchKernelGGL(posatt_dhead_finish, dim3(n_head), dim3(256), 0, s, a);
-            PIT_CHECK_LAUNCH();
-        }
+        hipLaunchKernelGGL(posatt_dhead_finish, dim3(n_head), dim3(256), 0, s, a);
+        PIT_CHECK_LAUNCH();
     }
     if (d_values) {
         if (sparse && rev_ptr && rev_row) launch_sparse_cols(a, sp, s); else launch_cols(a, s);
