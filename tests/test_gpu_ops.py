@@ -341,3 +341,41 @@ def test_wide_column_kernels_vs_oracle(ops, monkeypatch, batched, q, self_attn, 
     assert gio.rel_l2(ref.detach().numpy(), out.detach().cpu().numpy()) <= TOL_FWD
     assert gio.rel_l2(uc.grad.numpy(), ug.grad.cpu().numpy()) <= TOL_GRAD
     assert gio.rel_l2(cc.grad.reshape(-1).numpy(), cg.grad.cpu().numpy()) <= TOL_HEAD
+
+
+def test_raw_ctypes_binding_as_in_integration_md():
+    """The stub of INTEGRATION.md section 2, verbatim in spirit: bind libpit_hip.so with plain
+    ctypes (no ops.py), run posatt_cross_fixed.forward through pit_select_fwd + pit_posatt_fwd
+    and compare with the oracle."""
+    import ctypes
+    from position_induced_transformer_amd import _lib
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    P, I, F, LG = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_long
+    L.pit_select_fwd.argtypes = [P, P, I, I, I, I, I, F, I, I, P, P]
+    L.pit_posatt_fwd.argtypes = [P, P, I, I, I, I, I, F, P, I, I, LG, LG, P, I, I, P, F, I, I,
+                                 P, LG, LG, I, I, P, P, P, P, I, P]
+    fx, cs = load_case("F1_darcy_enc")
+    mesh_out, mesh_in = dev(cs["mesh_out"]).contiguous(), dev(cs["mesh_in"]).contiguous()   # the ABI takes dense rows
+    inputs, lmda = dev(cs["values"]).contiguous(), dev(cs["lmda"]).contiguous()
+    n, j, s = mesh_out.shape[0], mesh_in.shape[0], mesh_out.shape[1]
+    b, _, d = inputs.shape
+    h, q = lmda.shape[0], cs["q"]
+    rank = torch.tensor(q, dtype=torch.float32) * torch.tensor(j - 1, dtype=torch.float32)
+    k = int(rank.floor())
+    w = float(rank - k)
+    stream = torch.cuda.current_stream().cuda_stream
+    stats = torch.empty(3, 1, n, device="cuda")
+    assert L.pit_select_fwd(mesh_out.data_ptr(), mesh_in.data_ptr(), 1, n, j, s, 0, 0.0, k, 1, stats.data_ptr(), stream) == 0
+    out = torch.empty(b, n, h * d, device="cuda")
+    rowstat = torch.empty(1, h, n, 4, device="cuda")
+    scale = torch.empty(h, device="cuda")
+    rc = L.pit_posatt_fwd(mesh_out.data_ptr(), mesh_in.data_ptr(), 1, n, j, s, 0, 0.0,
+                          inputs.data_ptr(), b, d, inputs.stride(1), inputs.stride(0),
+                          lmda.data_ptr(), h, 0, stats.data_ptr(), w, 1, 0,
+                          out.data_ptr(), out.stride(1), out.stride(0), 0, 0,
+                          rowstat.data_ptr(), scale.data_ptr(), None, None, 0, stream)
+    assert rc == 0
+    torch.cuda.synchronize()
+    ulp = np.abs(scale.cpu().numpy().view(np.int32).astype(np.int64) - cs["c"].reshape(-1).view(np.int32).astype(np.int64)).max()
+    e, g, _, _ = gio.expect(fx, "out", out.cpu().numpy())
+    assert ulp <= 1 and gio.rel_l2(e, g) <= (TOL_FWD if ulp == 0 else 5e-3)
