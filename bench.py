@@ -58,6 +58,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip batch sweep / optimizer / roofline probes")
     ap.add_argument("--cpu-iters", type=int, default=100)
+    ap.add_argument("--math", choices=("fp32", "bf16"), default="fp32",
+                    help="MFMA math mode of the contractions (pit_set_math_mode); fp32 = the reference's arithmetic")
     return ap.parse_args()
 
 
@@ -280,6 +282,8 @@ def main():
         dist.init_process_group("nccl", device_id=device)
 
     log(f"rank {rank}/{world} on {torch.cuda.get_device_name(local)}")
+    from position_induced_transformer_amd import ops
+    ops.set_math_mode(args.math)
     step, model, meta = build_step(args, device, rank, world, args.batch, all_reduce=distributed)
     run, mode = prepare(step, not args.no_graph)
     log(f"step prepared ({mode})")
@@ -293,7 +297,8 @@ def main():
         rec = {
             "metric": "PiT fwd+bwd samples/sec on Darcy2D", "value": round(value, 1), "unit": "samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if args.math == "fp32" else "bf16 MFMA operands, f32 accumulate",
             "data": "synthetic",
             "config": {"workload": f"{args.task}2d 43x43 grid->16x16 latent, pit_fixed hid64 H2 blocks4 loc0.02, "
                                    f"fwd+RelL2 loss+bwd, per-GPU batch {args.batch} (train_darcy.py:64-111)",
@@ -328,6 +333,18 @@ def main():
             del st3, run3
             torch.cuda.empty_cache()
         extras["batch_sweep_samples_per_s"] = sweep
+        if args.math == "fp32":            # the opt-in bf16 math mode on the same steps (informational)
+            bf = {}
+            with ops.math_mode("bf16"):
+                for b in (args.batch, 256):
+                    st4, _, _ = build_step(args, device, rank, world, b)
+                    run4, _ = prepare(st4, not args.no_graph)
+                    n4 = max(args.steps // 4, 10)
+                    bf[str(b)] = round(b * n4 / timed(run4, n4, 5, world), 1)
+                    log(f"bf16 math mode, batch {b}: {bf[str(b)]} samples/s")
+                    del st4, run4
+                    torch.cuda.empty_cache()
+            extras["bf16_math_mode_samples_per_s"] = bf
         extras["roofline_saturated"] = roofline_probe(model, 256)
     if rank == 0:
         rec["roofline"] = roofline_probe(model, args.batch)

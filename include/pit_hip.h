@@ -7,8 +7,8 @@
  *   - plain `extern "C"`, raw DEVICE pointers (fp32 unless stated), int sizes, strides
  *     in ELEMENTS; `stream` is a hipStream_t passed as void* (NULL = default stream);
  *   - every function returns 0 on success, a negative PIT_ERR_* for an argument error,
- *     or a positive hipError_t; nothing allocates, frees, synchronises or keeps global
- *     state, so every call can be captured into a hipGraph;
+ *     or a positive hipError_t; nothing allocates, frees or synchronises, so every call can
+ *     be captured into a hipGraph; the only process-global state is the math mode below;
  *   - outputs and workspaces are caller-owned (the PyTorch host code allocates them).
  *
  * Mesh conventions: `mesh_batch` = 1 for the batch-free (fixed) meshes of
@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define PIT_ABI_VERSION 3
+#define PIT_ABI_VERSION 4
 #define PIT_DSCALE_SLOTS 1024 /* fp64 accumulators per head in pit_posatt_bwd's workspace */
 
 /* distance metric (dist2att variants) */
@@ -41,6 +41,20 @@ extern "C" {
 int pit_version(void);
 /* human-readable text for a return code of any function below */
 const char* pit_error_string(int code);
+
+/* Math mode of the MFMA contractions (attention forward and d(values), MLP GEMMs), process-wide,
+ * read at launch time.  The reference computes in fp32 (pit.py has no autocast), so
+ *   PIT_MATH_FP32 (default): v_mfma_f32_32x32x2_f32, exact fp32 products - the parity mode;
+ *   PIT_MATH_BF16: operands rounded to bf16 (RNE) in registers, v_mfma_f32_32x32x8_bf16, fp32
+ *     accumulation; tensors in memory stay fp32.  Distances, head scale, quantile thresholds,
+ *     mask, softmax weights, the d(scale) reduction, loss and optimiser stay fp32 in both modes,
+ *     so the kept sets are identical; outputs agree with the fp32 mode to ~1e-2 relative L2
+ *     (tests/test_gpu_bf16.py states the tolerance).
+ * Returns PIT_ERR_UNSUPPORTED for an unknown mode. */
+#define PIT_MATH_FP32 0
+#define PIT_MATH_BF16 1
+int pit_set_math_mode(int mode);
+int pit_get_math_mode(void);
 
 /* pit.py:48 (and :135,:196,:254): c_h = tan(0.25*pi*(1-1e-7)*(1+sin(lmda_h))).
  * Evaluated through fp64 with the reference's fp32 intermediate roundings. */

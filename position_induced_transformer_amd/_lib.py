@@ -22,6 +22,8 @@ _F = ctypes.c_float
 SIGNATURES = {
     "pit_version": [],
     "pit_error_string": [_I],
+    "pit_set_math_mode": [_I],
+    "pit_get_math_mode": [],
     "pit_head_scale": [_P, _I, _P, _P],
     "pit_select_fwd": [_P, _P, _I, _I, _I, _I, _I, _F, _I, _I, _P, _P],
     "pit_neighbors_fwd": [_P, _P, _I, _I, _I, _I, _I, _F, _P, _I, _P, _P, _P, _P, _P, _P],

@@ -19,6 +19,25 @@ __device__ __forceinline__ f32x16 mfma_32x32x2(float a, float b, f32x16 c) {
 }
 __device__ __forceinline__ int acc_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
 
+// Math mode (pit_set_math_mode): the contractions consume operand groups of 8 along the reduced
+// axis, 4 per half-wave.  PIT_MATH_FP32 issues four exact v_mfma_f32_32x32x2_f32 (lane holds
+// position 2u+half of the group for u = 0..3); PIT_MATH_BF16 rounds both operands to bf16 (RNE)
+// and issues ONE v_mfma_f32_32x32x8_bf16 (lane holds positions 4*half+u, fp32 accumulation).
+// group_pos() is the position a lane must fetch for slot u so that both modes share all the
+// load / weight code.
+typedef short bf16x4 __attribute__((ext_vector_type(4)));
+extern int pit_math_mode_value;          // host side, set through pit_set_math_mode
+__device__ __forceinline__ int group_pos(bool bf16, int u, int half) { return bf16 ? 4 * half + u : 2 * u + half; }
+__device__ __forceinline__ short bf16_bits(float x) { return __builtin_bit_cast(short, (__bf16)x); }
+__device__ __forceinline__ bf16x4 pack_bf16(float a0, float a1, float a2, float a3) {
+    bf16x4 v;
+    v[0] = bf16_bits(a0); v[1] = bf16_bits(a1); v[2] = bf16_bits(a2); v[3] = bf16_bits(a3);
+    return v;
+}
+__device__ __forceinline__ f32x16 mfma_32x32x8_bf16(bf16x4 a, bf16x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(a, b, c, 0, 0, 0);
+}
+
 // Squared distance exactly as the reference forms it in fp32:
 // separate multiplies and adds, never an fma, never the |x|^2+|y|^2-2xy expansion.
 // Coordinates are zero-padded to 3, which leaves the value unchanged bit for bit

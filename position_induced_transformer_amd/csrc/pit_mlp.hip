@@ -42,6 +42,7 @@ struct GemmArgs {
     int atomic;                          // 1: row-reducing GEMM, also split over blockIdx.z
     int ones_col;                        // >= 0: B(k, ones_col) == 1, that output column goes to C2[m]
     float* C2;
+    int bf16;                            // PIT_MATH_BF16: one v_mfma_f32_32x32x8_bf16 per 4 k instead of 4 fp32 MFMAs
 };
 
 // 4 k-values of one operand for this lane: X(i, kk+e), e = 0..3, through a raw buffer
@@ -130,6 +131,13 @@ __device__ __forceinline__ void gemm_rd_body(const GemmArgs& g, int bx, int by, 
                 for (int e = 0; e < 4; ++e) bv[t][e] = (FULL || kk + e < wk1) ? 1.0f : 0.0f;
             }
         }
+        if (g.bf16) {                            // the lane's 4 consecutive k are exactly one bf16 fragment
+            const bf16x4 ap = pack_bf16(av[0], av[1], av[2], av[3]);
+#pragma unroll
+            for (int t = 0; t < TN; ++t)
+                acc[t] = mfma_32x32x8_bf16(ap, pack_bf16(bv[t][0], bv[t][1], bv[t][2], bv[t][3]), acc[t]);
+            return;
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -212,6 +220,7 @@ int prepare_gemm(GemmArgs& g, GemmLaunch& L, int force_tn = 0, int force_waves =
     const unsigned long long bb = ((unsigned long long)(g.K - 1) * g.b_rs + (unsigned long long)(std::max(nb_cols, 1) - 1) * g.b_cs + 1) * 4ull;
     if (ab > PIT_MAX_BUFFER_BYTES || bb > PIT_MAX_BUFFER_BYTES) return PIT_ERR_UNSUPPORTED;
     g.a_bytes = (unsigned)ab; g.b_bytes = (unsigned)bb;
+    g.bf16 = (pit_math_mode_value == PIT_MATH_BF16);
     g.a_vec = vec_ok(g.A, g.a_rs, g.a_cs) && (!g.a_gz || vec_ok(g.a_gz, g.a_rs, g.a_cs));
     g.b_vec = vec_ok(g.B, g.b_cs, g.b_rs);
     // two column tiles per wave (A fragment reused) only when that still leaves plenty of workgroups

@@ -39,6 +39,7 @@ struct AttArgs {
     double* dscale_acc;
     float* d_head; const float* dhead_src; int dhead_is_scale, accumulate_head, nslots;   // d(scale) finish
     int ncols, colgroups, tiles_per_wg;
+    int bf16;                             // PIT_MATH_BF16 for the forward and d(values) contractions
     unsigned values_bytes, dout_bytes;    // extents for the raw-buffer descriptors
 };
 
@@ -121,7 +122,7 @@ __device__ __forceinline__ float summed(const float* red, int nwaves, int q, int
 // ------------------------------------------------------------------------------------
 // rows kernel
 // ------------------------------------------------------------------------------------
-template <int CT, int MODE, bool MASKED>
+template <int CT, int MODE, bool MASKED, bool BF>
 __global__ __launch_bounds__(512) void posatt_rows_kernel(AttArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float4* s_xi = reinterpret_cast<float4*>(smem);
@@ -184,6 +185,10 @@ __global__ __launch_bounds__(512) void posatt_rows_kernel(AttArgs a) {
         for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
     float rsum = 0.0f, qsum = 0.0f;
     const bool per = a.periodic != 0;
+    constexpr bool bf = BF;                        // math mode (d(scale), MODE 1, is always exact fp32)
+    int kpos[4];                                   // key position inside a group of 8 for slot u (math mode)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) kpos[u] = group_pos(bf, u, half);
 
     // Value rows for the NEXT step are always in flight while the current step computes its
     // weights and MFMAs (the loads do not depend on the weights); a masked step whose 8 keys
@@ -194,7 +199,7 @@ __global__ __launch_bounds__(512) void posatt_rows_kernel(AttArgs a) {
         (void)jb;
 #pragma unroll
         for (int u = 0; u < NP; ++u) {
-            const int jl = jstart + 2 * u + half;
+            const int jl = jstart + 8 * (u / 4) + kpos[u % 4];
             const bool jv = jl < je;
             const unsigned rowoff = (unsigned)(jc0 + jl) * ld4;
 #pragma unroll
@@ -230,7 +235,7 @@ __global__ __launch_bounds__(512) void posatt_rows_kernel(AttArgs a) {
             for (int q = 0; q < NP / 4; ++q) anyk[q] = false;
 #pragma unroll
             for (int u = 0; u < NP; ++u) {
-                const int jl = jj + 2 * u + half;
+                const int jl = jj + 8 * (u / 4) + kpos[u % 4];
                 const bool jv = jl < je;
                 const float4 xi = s_xi[jv ? jl : jb];
                 const float m = sq_dist3(xo.x, xo.y, xo.z, xi.x, xi.y, xi.z, per, a.period);
@@ -249,6 +254,13 @@ __global__ __launch_bounds__(512) void posatt_rows_kernel(AttArgs a) {
 #pragma unroll
             for (int q = 0; q < NP / 4; ++q) {
                 if (MASKED && __builtin_amdgcn_ballot_w64(anyk[q]) == 0ull) continue;   // wave-uniform skip
+                if (bf) {
+                    const bf16x4 ap = pack_bf16(pw[4 * q], pw[4 * q + 1], pw[4 * q + 2], pw[4 * q + 3]);
+#pragma unroll
+                    for (int t = 0; t < CT; ++t)
+                        acc[t] = mfma_32x32x8_bf16(ap, pack_bf16(bcur[4 * q][t], bcur[4 * q + 1][t], bcur[4 * q + 2][t], bcur[4 * q + 3][t]), acc[t]);
+                    continue;
+                }
 #pragma unroll
                 for (int u = 4 * q; u < 4 * q + 4; ++u)
 #pragma unroll
@@ -327,7 +339,7 @@ __global__ __launch_bounds__(512) void posatt_rows_kernel(AttArgs a) {
 // ------------------------------------------------------------------------------------
 // cols kernel: d values
 // ------------------------------------------------------------------------------------
-template <int CT, bool MASKED>
+template <int CT, bool MASKED, bool BF>
 __global__ __launch_bounds__(512) void posatt_cols_kernel(AttArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float4* s_rec = reinterpret_cast<float4*>(smem);     // [ROW_CHUNK][2]: {xo.xyz, T}, {S_min, 1/L, -, -}
@@ -366,6 +378,10 @@ __global__ __launch_bounds__(512) void posatt_cols_kernel(AttArgs a) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
     const bool per = a.periodic != 0;
+    constexpr bool bf = BF;
+    int kpos[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) kpos[u] = group_pos(bf, u, half);
 
     constexpr int NP = (CT == 4) ? 4 : 8;
     float bnext[NP][CT];
@@ -373,7 +389,7 @@ __global__ __launch_bounds__(512) void posatt_cols_kernel(AttArgs a) {
         (void)nb;
 #pragma unroll
         for (int u = 0; u < NP; ++u) {
-            const int nl = nstart + 2 * u + half;
+            const int nl = nstart + 8 * (u / 4) + kpos[u % 4];
             const bool nv = nl < ne;
             const unsigned rowoff = (unsigned)(nc0 + nl) * ldd4 + (unsigned)hoff * 4u;
 #pragma unroll
@@ -417,7 +433,7 @@ __global__ __launch_bounds__(512) void posatt_cols_kernel(AttArgs a) {
                 for (int q = 0; q < NP / 4; ++q) anyk[q] = false;
 #pragma unroll
                 for (int u = 0; u < NP; ++u) {
-                    const int nl = nn + 2 * u + half;
+                    const int nl = nn + 8 * (u / 4) + kpos[u % 4];
                     const bool nv = nl < ne;
                     const float4 r0 = s_rec[2 * (nv ? nl : nb)];
                     const float4 r1 = s_rec[2 * (nv ? nl : nb) + 1];
@@ -430,6 +446,13 @@ __global__ __launch_bounds__(512) void posatt_cols_kernel(AttArgs a) {
 #pragma unroll
                 for (int q = 0; q < NP / 4; ++q) {
                     if (MASKED && __builtin_amdgcn_ballot_w64(anyk[q]) == 0ull) continue;
+                    if (bf) {
+                        const bf16x4 ap = pack_bf16(pw[4 * q], pw[4 * q + 1], pw[4 * q + 2], pw[4 * q + 3]);
+#pragma unroll
+                        for (int t = 0; t < CT; ++t)
+                            acc[t] = mfma_32x32x8_bf16(ap, pack_bf16(bcur[4 * q][t], bcur[4 * q + 1][t], bcur[4 * q + 2][t], bcur[4 * q + 3][t]), acc[t]);
+                        continue;
+                    }
 #pragma unroll
                     for (int u = 4 * q; u < 4 * q + 4; ++u)
 #pragma unroll
@@ -477,7 +500,7 @@ constexpr int TK_CHUNK = 256;
 
 // RT = 32-row tiles per workgroup: every value (B) fragment fetched from L2 feeds RT MFMAs, which
 // is what bounds these kernels at scale (16*RT flop per operand byte).
-template <int RT, int TPW, int MODE, bool MASKED>
+template <int RT, int TPW, int MODE, bool MASKED, bool BF>
 __global__ __launch_bounds__(512) void posatt_rows_tiles(AttArgs a) {
     constexpr int KC = TK_CHUNK / RT;                     // keys per LDS pass: Ps is always 32 KiB
     constexpr int GW = KC / 64;                           // 8-key groups filled per wave per pass
@@ -547,6 +570,10 @@ __global__ __launch_bounds__(512) void posatt_rows_tiles(AttArgs a) {
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) { rsum[rt] = 0.0f; qsum[rt] = 0.0f; }
     const bool per = a.periodic != 0;
+    constexpr bool bf = BF;
+    int kpos[4];                                   // contraction-phase key position for slot u (math mode)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) kpos[u] = group_pos(bf, u, half);
 
     for (int c0 = 0; c0 < a.n_in; c0 += KC) {
         const int len = min(KC, a.n_in - c0);
@@ -555,7 +582,7 @@ __global__ __launch_bounds__(512) void posatt_rows_tiles(AttArgs a) {
         auto prefetch = [&](int g) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const int jl = g * 8 + 2 * u + half;
+                const int jl = g * 8 + kpos[u];
                 const bool jv = g < ngroups && jl < len;
                 const unsigned rowoff = (unsigned)(c0 + jl) * ld4;
 #pragma unroll
@@ -604,6 +631,21 @@ __global__ __launch_bounds__(512) void posatt_rows_tiles(AttArgs a) {
                 for (int t = 0; t < TPW; ++t) bcur[u][t] = bnext[u][t];
             prefetch(g + 1);
             if (MASKED && s_flag[g] == 0) continue;
+            if (bf) {
+                bf16x4 bp[TPW];
+#pragma unroll
+                for (int t = 0; t < TPW; ++t) bp[t] = pack_bf16(bcur[0][t], bcur[1][t], bcur[2][t], bcur[3][t]);
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) {
+                    float af[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) af[u] = Ps[((g * 8 + kpos[u]) * RT + rt) * 32 + l31];
+                    const bf16x4 ap = pack_bf16(af[0], af[1], af[2], af[3]);
+#pragma unroll
+                    for (int t = 0; t < TPW; ++t) acc[rt][t] = mfma_32x32x8_bf16(ap, bp[t], acc[rt][t]);
+                }
+                continue;
+            }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 float af[RT];
@@ -687,7 +729,7 @@ __global__ __launch_bounds__(512) void posatt_rows_tiles(AttArgs a) {
     if (a.scale_out && tid == 0 && blockIdx.x == 0 && blockIdx.z == 0) a.scale_out[h] = c;
 }
 
-template <int TPW, bool MASKED>
+template <int TPW, bool MASKED, bool BF>
 __global__ __launch_bounds__(512) void posatt_cols_tiles(AttArgs a) {
     __shared__ float Ps[TK_CHUNK * 32];
     __shared__ float4 s_rec[TK_CHUNK * 2];
@@ -727,6 +769,10 @@ __global__ __launch_bounds__(512) void posatt_cols_tiles(AttArgs a) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
     const bool per = a.periodic != 0;
+    constexpr bool bf = BF;
+    int kpos[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) kpos[u] = group_pos(bf, u, half);
 
     for (int h = 0; h < a.n_head; ++h) {
         const float c = a.head_is_scale ? a.head[h] : head_scale_from_lmda(a.head[h]);
@@ -738,7 +784,7 @@ __global__ __launch_bounds__(512) void posatt_cols_tiles(AttArgs a) {
             auto prefetch = [&](int g) {
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    const int nl = g * 8 + 2 * u + half;
+                    const int nl = g * 8 + kpos[u];
                     const bool nv = g < ngroups && nl < len;
                     const unsigned rowoff = (unsigned)(c0 + nl) * ldd4 + hoff;
 #pragma unroll
@@ -787,6 +833,16 @@ __global__ __launch_bounds__(512) void posatt_cols_tiles(AttArgs a) {
                     for (int t = 0; t < TPW; ++t) bcur[u][t] = bnext[u][t];
                 prefetch(g + 1);
                 if (MASKED && s_flag[g] == 0) continue;
+                if (bf) {
+                    float af[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) af[u] = Ps[(g * 8 + kpos[u]) * 32 + l31];
+                    const bf16x4 ap = pack_bf16(af[0], af[1], af[2], af[3]);
+#pragma unroll
+                    for (int t = 0; t < TPW; ++t)
+                        acc[t] = mfma_32x32x8_bf16(ap, pack_bf16(bcur[0][t], bcur[1][t], bcur[2][t], bcur[3][t]), acc[t]);
+                    continue;
+                }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const float af = Ps[(g * 8 + 2 * u + half) * 32 + l31];
@@ -866,6 +922,7 @@ size_t cols_smem(int ct, int nwaves, int n_out) {
 template <int MODE>
 void launch_rows(const AttArgs& a0, hipStream_t s) {
     AttArgs a = a0;
+    const bool bf = (MODE == 0) && a.bf16 != 0;
     const int n_tiles = (a.n_out + 31) / 32;
     const long work = (long)n_tiles * a.n_head * a.mesh_batch * ((a.ncols + 31) / 32) * ((a.n_in + 1) / 2);
     // row tiles per workgroup: more reuse of every value fragment, as long as the grid still fills the chip
@@ -879,15 +936,17 @@ void launch_rows(const AttArgs& a0, hipStream_t s) {
         a.tiles_per_wg = tpwg;
         a.colgroups = ((a.ncols + 31) / 32 + tpwg - 1) / tpwg;
         dim3 grid(a.mesh_batch * a.colgroups, a.n_head, (n_tiles + rt - 1) / rt), block(512);
-#define PIT_RT(RT_, TPW_)                                                                                   \
-        do {                                                                                                \
-            if (a.masked) hipLaunchKernelGGL((posatt_rows_tiles<RT_, TPW_, MODE, true>), grid, block, 0, s, a); \
-            else hipLaunchKernelGGL((posatt_rows_tiles<RT_, TPW_, MODE, false>), grid, block, 0, s, a);     \
+#define PIT_RT_BF(RT_, TPW_, BF_)                                                                                 \
+        do {                                                                                                      \
+            if (a.masked) hipLaunchKernelGGL((posatt_rows_tiles<RT_, TPW_, MODE, true, BF_>), grid, block, 0, s, a); \
+            else hipLaunchKernelGGL((posatt_rows_tiles<RT_, TPW_, MODE, false, BF_>), grid, block, 0, s, a);      \
         } while (0)
+#define PIT_RT(RT_, TPW_) do { if (bf) PIT_RT_BF(RT_, TPW_, (MODE == 0)); else PIT_RT_BF(RT_, TPW_, false); } while (0)
         if (rt == 4) PIT_RT(4, 1);
         else if (rt == 2) { if (tpwg == 16) PIT_RT(2, 2); else PIT_RT(2, 1); }
         else { if (tpwg == 32) PIT_RT(1, 4); else if (tpwg == 16) PIT_RT(1, 2); else PIT_RT(1, 1); }
 #undef PIT_RT
+#undef PIT_RT_BF
         return;
     }
     int ct = choose_ct(a.ncols, (long)n_tiles * a.n_head * a.mesh_batch);
@@ -898,37 +957,42 @@ void launch_rows(const AttArgs& a0, hipStream_t s) {
     if (int f = env_int("PIT_FORCE_WAVES")) nwaves = min(f, wmax);
     dim3 grid(a.mesh_batch * a.colgroups, a.n_head, n_tiles), block(64 * nwaves);
     const size_t sm = rows_smem(ct, nwaves, a.n_in);
-#define PIT_ROWS(CT_)                                                                                  \
-    do {                                                                                               \
-        static bool once = (hipFuncSetAttribute((const void*)posatt_rows_kernel<CT_, MODE, true>,      \
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, 98304),    \
-                            hipFuncSetAttribute((const void*)posatt_rows_kernel<CT_, MODE, false>,     \
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, 98304), true); \
-        (void)once;                                                                                    \
-        if (a.masked) hipLaunchKernelGGL((posatt_rows_kernel<CT_, MODE, true>), grid, block, sm, s, a); \
-        else hipLaunchKernelGGL((posatt_rows_kernel<CT_, MODE, false>), grid, block, sm, s, a);        \
+#define PIT_ROWS_BF(CT_, BF_)                                                                               \
+    do {                                                                                                    \
+        static bool once = (hipFuncSetAttribute((const void*)posatt_rows_kernel<CT_, MODE, true, BF_>,      \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, 98304),         \
+                            hipFuncSetAttribute((const void*)posatt_rows_kernel<CT_, MODE, false, BF_>,     \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, 98304), true);  \
+        (void)once;                                                                                         \
+        if (a.masked) hipLaunchKernelGGL((posatt_rows_kernel<CT_, MODE, true, BF_>), grid, block, sm, s, a); \
+        else hipLaunchKernelGGL((posatt_rows_kernel<CT_, MODE, false, BF_>), grid, block, sm, s, a);        \
     } while (0)
+#define PIT_ROWS(CT_) do { if (bf) PIT_ROWS_BF(CT_, (MODE == 0)); else PIT_ROWS_BF(CT_, false); } while (0)
     if (ct == 4) PIT_ROWS(4);
     else if (ct == 2) PIT_ROWS(2);
     else PIT_ROWS(1);
 #undef PIT_ROWS
+#undef PIT_ROWS_BF
 }
 
 void launch_cols(const AttArgs& a0, hipStream_t s) {
     AttArgs a = a0;
+    const bool bf = a.bf16 != 0;
     const int j_tiles = (a.n_in + 31) / 32;
     const long work = (long)j_tiles * a.mesh_batch * ((a.ncols + 31) / 32) * ((a.n_out + 1) / 2) * a.n_head;
     if (const int tpwg = tiles_per_wg_for(a.ncols, (long)j_tiles * a.mesh_batch, work, a.mesh_batch)) {
         a.tiles_per_wg = tpwg;
         a.colgroups = ((a.ncols + 31) / 32 + tpwg - 1) / tpwg;
         dim3 grid(a.colgroups, j_tiles, a.mesh_batch), block(512);
-#define PIT_CT(TPW_)                                                                                \
-        do {                                                                                        \
-            if (a.masked) hipLaunchKernelGGL((posatt_cols_tiles<TPW_, true>), grid, block, 0, s, a); \
-            else hipLaunchKernelGGL((posatt_cols_tiles<TPW_, false>), grid, block, 0, s, a);        \
+#define PIT_CT_BF(TPW_, BF_)                                                                             \
+        do {                                                                                             \
+            if (a.masked) hipLaunchKernelGGL((posatt_cols_tiles<TPW_, true, BF_>), grid, block, 0, s, a); \
+            else hipLaunchKernelGGL((posatt_cols_tiles<TPW_, false, BF_>), grid, block, 0, s, a);        \
         } while (0)
+#define PIT_CT(TPW_) do { if (bf) PIT_CT_BF(TPW_, true); else PIT_CT_BF(TPW_, false); } while (0)
         if (tpwg == 32) PIT_CT(4); else if (tpwg == 16) PIT_CT(2); else PIT_CT(1);
 #undef PIT_CT
+#undef PIT_CT_BF
         return;
     }
     int ct = choose_ct(a.ncols, (long)j_tiles * a.mesh_batch);
@@ -939,20 +1003,22 @@ void launch_cols(const AttArgs& a0, hipStream_t s) {
     if (int f = env_int("PIT_FORCE_WAVES")) nwaves = min(f, wmax);
     dim3 grid(a.colgroups, j_tiles, a.mesh_batch), block(64 * nwaves);
     const size_t sm = cols_smem(ct, nwaves, a.n_out);
-#define PIT_COLS(CT_)                                                                             \
-    do {                                                                                          \
-        static bool once = (hipFuncSetAttribute((const void*)posatt_cols_kernel<CT_, true>,       \
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, 98304), \
-                            hipFuncSetAttribute((const void*)posatt_cols_kernel<CT_, false>,      \
+#define PIT_COLS_BF(CT_, BF_)                                                                          \
+    do {                                                                                               \
+        static bool once = (hipFuncSetAttribute((const void*)posatt_cols_kernel<CT_, true, BF_>,       \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, 98304),    \
+                            hipFuncSetAttribute((const void*)posatt_cols_kernel<CT_, false, BF_>,      \
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 98304), true); \
-        (void)once;                                                                               \
-        if (a.masked) hipLaunchKernelGGL((posatt_cols_kernel<CT_, true>), grid, block, sm, s, a);  \
-        else hipLaunchKernelGGL((posatt_cols_kernel<CT_, false>), grid, block, sm, s, a);         \
+        (void)once;                                                                                    \
+        if (a.masked) hipLaunchKernelGGL((posatt_cols_kernel<CT_, true, BF_>), grid, block, sm, s, a);  \
+        else hipLaunchKernelGGL((posatt_cols_kernel<CT_, false, BF_>), grid, block, sm, s, a);         \
     } while (0)
+#define PIT_COLS(CT_) do { if (bf) PIT_COLS_BF(CT_, true); else PIT_COLS_BF(CT_, false); } while (0)
     if (ct == 4) PIT_COLS(4);
     else if (ct == 2) PIT_COLS(2);
     else PIT_COLS(1);
 #undef PIT_COLS
+#undef PIT_COLS_BF
 }
 
 // ------------------------------------------------------------------------------------
@@ -1298,6 +1364,7 @@ int fill_common(AttArgs& a, const float* mesh_out, const float* mesh_in, int mes
                                    (unsigned long long)(n_in - 1) * ld_values + dim) * 4ull;
     if (vb > PIT_MAX_BUFFER_BYTES) return PIT_ERR_UNSUPPORTED;
     a.values_bytes = (unsigned)vb;
+    a.bf16 = (pit_math_mode_value == PIT_MATH_BF16);
     return 0;
 }
 

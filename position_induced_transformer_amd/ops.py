@@ -412,6 +412,39 @@ def rel_lp_loss(true, pred, out_dim: int, p: int, pred_scale=None, pred_shift=No
     return _RelLpLoss.apply(pred, true, out_dim, p, pred_scale, pred_shift)
 
 
+MATH_MODES = {"fp32": 0, "bf16": 1}      # PIT_MATH_* of include/pit_hip.h
+
+
+def set_math_mode(mode: str) -> None:
+    """'fp32' (default, the reference's arithmetic) or 'bf16' (bf16 MFMA operands, fp32 accumulate) for
+    the attention / MLP contractions; process-wide, read when a kernel is launched (so a captured
+    hipGraph keeps the mode it was captured with)."""
+    if mode not in MATH_MODES:
+        raise ValueError(f"math mode must be one of {sorted(MATH_MODES)}, got {mode!r}")
+    _lib.check(_lib.lib().pit_set_math_mode(MATH_MODES[mode]), "pit_set_math_mode")
+
+
+def get_math_mode() -> str:
+    code = _lib.lib().pit_get_math_mode()
+    return next(k for k, v in MATH_MODES.items() if v == code)
+
+
+class math_mode:
+    """`with ops.math_mode('bf16'): ...` - scoped set_math_mode."""
+
+    def __init__(self, mode: str):
+        self.mode, self.prev = mode, None
+
+    def __enter__(self):
+        self.prev = get_math_mode()
+        set_math_mode(self.mode)
+        return self
+
+    def __exit__(self, *exc):
+        set_math_mode(self.prev)
+        return False
+
+
 def head_scale(lmda: torch.Tensor) -> torch.Tensor:
     """c = tan(0.25*pi*(1-1e-7)*(1+sin(lmda))) on device (pit.py:48)."""
     _need_gpu(lmda)
