@@ -123,17 +123,17 @@ __device__ __forceinline__ float summed(const float* red, int nwaves, int q, int
 // rows kernel
 // ------------------------------------------------------------------------------------
 template <int CT, int MODE, bool MASKED, bool BF>
-__global__ __launch_bounds__(512) void posatt_rows_kernel(AttArgs a) {
+__device__ __forceinline__ void posatt_rows_body(const AttArgs& a, const int bx, const int by, const int bz) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float4* s_xi = reinterpret_cast<float4*>(smem);
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
     const int half = lane >> 5, l31 = lane & 31;
-    // blockIdx.x = (sample, column group) so that workgroups dealt round-robin to the 8 XCDs
+    // bx = blockIdx.x = (sample, column group) so that workgroups dealt round-robin to the 8 XCDs
     // (id % 8) share value columns per XCD: each L2 then fetches only its own column slices
-    const int n0 = blockIdx.z * 32;
-    const int h = blockIdx.y;
-    const int mb = blockIdx.x / a.colgroups, cg = blockIdx.x % a.colgroups;
+    const int n0 = bz * 32;
+    const int h = by;
+    const int mb = bx / a.colgroups, cg = bx % a.colgroups;
     const long rows_total = (long)a.mesh_batch * a.n_out;
 
     const float c = a.head_is_scale ? a.head[h] : head_scale_from_lmda(a.head[h]);
@@ -290,7 +290,7 @@ __global__ __launch_bounds__(512) void posatt_rows_kernel(AttArgs a) {
             for (int i = 0; i < 16; ++i) part += (double)acc[t][i] * (double)dov[t][i];
         part = wave_sum_d(part);
         // PIT_DSCALE_SLOTS accumulators per head keep the fp64 atomics off a single address
-        const int slot = (int)((blockIdx.z + 131u * blockIdx.x + 977u * wave) & (a.nslots - 1));
+        const int slot = (int)((bz + 131u * bx + 977u * wave) & (a.nslots - 1));
         dscale_add(a.dscale_acc + h * PIT_DSCALE_SLOTS + slot, -part, lane == 0);
         return;
     }
@@ -333,22 +333,27 @@ __global__ __launch_bounds__(512) void posatt_rows_kernel(AttArgs a) {
         float4 st; st.x = T; st.y = s_min; st.z = inv; st.w = qs_tot * inv;
         *reinterpret_cast<float4*>(a.rowstat + (((long)mb * a.n_head + h) * a.n_out + n) * 4) = st;
     }
-    if (a.scale_out && wave == 0 && blockIdx.x == 0 && blockIdx.z == 0 && lane == 0) a.scale_out[h] = c;
+    if (a.scale_out && wave == 0 && bx == 0 && bz == 0 && lane == 0) a.scale_out[h] = c;
+}
+
+template <int CT, int MODE, bool MASKED, bool BF>
+__global__ __launch_bounds__(512) void posatt_rows_kernel(AttArgs a) {
+    posatt_rows_body<CT, MODE, MASKED, BF>(a, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
 // ------------------------------------------------------------------------------------
 // cols kernel: d values
 // ------------------------------------------------------------------------------------
 template <int CT, bool MASKED, bool BF>
-__global__ __launch_bounds__(512) void posatt_cols_kernel(AttArgs a) {
+__device__ __forceinline__ void posatt_cols_body(const AttArgs& a, const int bx, const int by, const int bz) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float4* s_rec = reinterpret_cast<float4*>(smem);     // [ROW_CHUNK][2]: {xo.xyz, T}, {S_min, 1/L, -, -}
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
     const int half = lane >> 5, l31 = lane & 31;
-    const int j0 = blockIdx.y * 32;      // blockIdx.x = column group: XCD-local reuse of the d_out columns
-    const int cg = blockIdx.x;
-    const int mb = blockIdx.z;
+    const int j0 = by * 32;      // bx = blockIdx.x = column group: XCD-local reuse of the d_out columns
+    const int cg = bx;
+    const int mb = bz;
 
     const int j = j0 + l31;
     const bool jvalid = j < a.n_in;
@@ -484,6 +489,28 @@ __global__ __launch_bounds__(512) void posatt_cols_kernel(AttArgs a) {
         const unsigned roff = (unsigned)(((long)bb * a.dout_bstride + dd) * 4) + (unsigned)jr * ldd4;
         v += buf_load(rdout, (a.add_residual && ok) ? roff : a.dout_bytes);
         if (ok) a.d_values[(long)bb * a.dvalues_bstride + (long)jr * a.ld_dvalues + dd] = v;
+    }
+}
+
+template <int CT, bool MASKED, bool BF>
+__global__ __launch_bounds__(512) void posatt_cols_kernel(AttArgs a) {
+    posatt_cols_body<CT, MASKED, BF>(a, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// d(scale) and d(values) of one layer in ONE launch: the two are independent (both read d_out,
+// the row constants and the values), each is a few hundred latency-bound workgroups, and merged
+// they share the chip instead of running back to back.  Workgroups [0, n_cols_wgs) run the
+// d(values) tiles (on the critical path of the backward pass: dispatched first), the rest the
+// d(scale) tiles; `ar` / `ac` carry each part's own column grouping.
+template <int CT, bool MASKED, bool BF>
+__global__ __launch_bounds__(512) void posatt_bwd_pair_kernel(AttArgs ar, AttArgs ac, int n_cols_wgs, int cgx, int cgy,
+                                                               int rgx, int rgy) {
+    int id = blockIdx.x;
+    if (id < n_cols_wgs) {
+        posatt_cols_body<CT, MASKED, BF>(ac, id % cgx, (id / cgx) % cgy, id / (cgx * cgy));
+    } else {
+        id -= n_cols_wgs;
+        posatt_rows_body<CT, 1, MASKED, false>(ar, id % rgx, (id / rgx) % rgy, id / (rgx * rgy));
     }
 }
 
@@ -1021,6 +1048,53 @@ void launch_cols(const AttArgs& a0, hipStream_t s) {
 #undef PIT_COLS_BF
 }
 
+// d(scale) + d(values) in one launch (posatt_bwd_pair_kernel) when both are in the small regime
+// with the same column-tile count; returns false when the pair does not apply (caller launches
+// the two kernels separately).
+bool launch_bwd_pair(const AttArgs& a0, hipStream_t s) {
+    if (env_int("PIT_NO_BWD_PAIR") || env_int("PIT_FORCE_CT") || env_int("PIT_FORCE_WAVES")) return false;
+    const int n_tiles = (a0.n_out + 31) / 32, j_tiles = (a0.n_in + 31) / 32;
+    {   // either part would take the large-regime kernels: keep them separate
+        const long work_r = (long)n_tiles * a0.n_head * a0.mesh_batch * ((a0.ncols + 31) / 32) * ((a0.n_in + 1) / 2);
+        const long work_c = (long)j_tiles * a0.mesh_batch * ((a0.ncols + 31) / 32) * ((a0.n_out + 1) / 2) * a0.n_head;
+        int rt = 4;
+        while (rt > 1 && (n_tiles < rt || (long)((n_tiles + rt - 1) / rt) * a0.n_head * a0.mesh_batch * ((a0.ncols + 255) / 256) < 256)) rt >>= 1;
+        if (tiles_per_wg_for(a0.ncols, (long)((n_tiles + rt - 1) / rt) * a0.n_head * a0.mesh_batch, work_r, a0.mesh_batch)) return false;
+        if (tiles_per_wg_for(a0.ncols, (long)j_tiles * a0.mesh_batch, work_c, a0.mesh_batch)) return false;
+    }
+    const int ct = choose_ct(a0.ncols, (long)n_tiles * a0.n_head * a0.mesh_batch);
+    if (ct != choose_ct(a0.ncols, (long)j_tiles * a0.mesh_batch)) return false;
+    AttArgs ar = a0, ac = a0;
+    ar.colgroups = ac.colgroups = (a0.ncols + 32 * ct - 1) / (32 * ct);
+    const int wmax = (ct == 4) ? 4 : 8;
+    const int nw_r = max(1, min(wmax, pow2_floor(a0.n_in / 32)));
+    const int nw_c = max(1, min(wmax, pow2_floor(a0.n_out * a0.n_head / 32)));
+    const int nwaves = min(nw_r, nw_c);
+    const long rows_wgs = (long)a0.mesh_batch * ar.colgroups * a0.n_head * n_tiles;
+    const long cols_wgs = (long)ac.colgroups * j_tiles * a0.mesh_batch;
+    // merged launches pay off while the parts are latency-bound; big grids gain nothing
+    if (rows_wgs + cols_wgs > 4096 || rows_wgs + cols_wgs > 0x7fffffffL) return false;
+    const size_t sm = std::max(rows_smem(ct, nwaves, a0.n_in), cols_smem(ct, nwaves, a0.n_out));
+    dim3 grid((unsigned)(rows_wgs + cols_wgs)), block(64 * nwaves);
+#define PIT_PAIR_K(CT_, M_, BF_)                                                                              \
+    do {                                                                                                      \
+        static bool once = (hipFuncSetAttribute((const void*)posatt_bwd_pair_kernel<CT_, M_, BF_>,            \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, 98304), true);    \
+        (void)once;                                                                                           \
+        hipLaunchKernelGGL((posatt_bwd_pair_kernel<CT_, M_, BF_>), grid, block, sm, s, ar, ac, (int)cols_wgs, \
+                           ac.colgroups, j_tiles, a0.mesh_batch * ar.colgroups, a0.n_head);                   \
+    } while (0)
+#define PIT_PAIR_M(CT_, BF_) do { if (a0.masked) PIT_PAIR_K(CT_, true, BF_); else PIT_PAIR_K(CT_, false, BF_); } while (0)
+#define PIT_PAIR(CT_) do { if (a0.bf16) PIT_PAIR_M(CT_, true); else PIT_PAIR_M(CT_, false); } while (0)
+    if (ct == 4) PIT_PAIR(4);
+    else if (ct == 2) PIT_PAIR(2);
+    else PIT_PAIR(1);
+#undef PIT_PAIR
+#undef PIT_PAIR_M
+#undef PIT_PAIR_K
+    return true;
+}
+
 // ------------------------------------------------------------------------------------
 // Sparse path for the masked (locality < 1) layers: O(N*k) instead of O(N*J).
 //
@@ -1443,10 +1517,13 @@ extern "C" int pit_posatt_bwd(const float* mesh_out, const float* mesh_in, int m
         int ns = 32;
         while (ns < PIT_DSCALE_SLOTS && (long)ns * 32 < approx_wgs * 4) ns <<= 1;
         a.nslots = ns;
-        if (sparse) launch_sparse_rows<1>(a, sp, s); else launch_rows<1>(a, s);
+        bool paired = false;
+        if (!sparse && d_values) paired = launch_bwd_pair(a, s);       // d(scale) + d(values) in one launch
+        if (!paired) { if (sparse) launch_sparse_rows<1>(a, sp, s); else launch_rows<1>(a, s); }
         PIT_CHECK_LAUNCH();
         hipLaunchKernelGGL(posatt_dhead_finish, dim3(n_head), dim3(256), 0, s, a);
         PIT_CHECK_LAUNCH();
+        if (paired) return 0;
     }
     if (d_values) {
         if (sparse && rev_ptr && rev_row) launch_sparse_cols(a, sp, s); else launch_cols(a, s);
