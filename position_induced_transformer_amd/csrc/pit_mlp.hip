@@ -21,6 +21,7 @@
 // (blockIdx.z) and accumulated with fp32 atomics straight into the destination (which may be
 // the parameter's .grad); the bias gradient rides along as a virtual all-ones B column.
 #include "pit_common.h"
+#include <cstdlib>
 #include <type_traits>
 
 namespace {
@@ -206,6 +207,26 @@ __global__ __launch_bounds__(512) void gemm_rd_pair_kernel(GemmArgs g1, GemmArgs
     }
 }
 
+// the three GEMMs that follow dZ1 in an MLP backward - dX = dZ1 W1 (EPI_STORE, on the critical path:
+// its workgroups come first) and the two weight-gradient reductions - are independent of each
+// other: one launch, so the small latency-bound grids share the chip
+template <int TN>
+__global__ __launch_bounds__(512) void gemm_rd_triple_kernel(GemmArgs gx, GemmArgs g1, GemmArgs g2, int nblkx, int gxx,
+                                                             int nblk1, int gx1, int gy1, int gx2, int gy2) {
+    int id = blockIdx.x;
+    if (id < nblkx) {
+        gemm_rd_body<TN, EPI_STORE>(gx, id % gxx, id / gxx, 0);
+        return;
+    }
+    id -= nblkx;
+    if (id < nblk1) {
+        gemm_rd_body<1, EPI_ATOMIC>(g1, id % gx1, (id / gx1) % gy1, id / (gx1 * gy1));
+    } else {
+        id -= nblk1;
+        gemm_rd_body<1, EPI_ATOMIC>(g2, id % gx2, (id / gx2) % gy2, id / (gx2 * gy2));
+    }
+}
+
 int pow2_floor_i(int v) { int p = 1; while (p * 2 <= v) p *= 2; return p; }
 
 bool vec_ok(const float* p, long i_stride, long k_stride) {
@@ -279,10 +300,87 @@ int launch_gemm_pair_atomic(GemmArgs g1, GemmArgs g2, hipStream_t s) {
     return 0;
 }
 
+// dX GEMM + both weight-gradient reductions in one launch when everything is small; otherwise the
+// dX GEMM alone followed by launch_gemm_pair_atomic
+int launch_gemm_bwd_tail(GemmArgs gx, GemmArgs g1, GemmArgs g2, hipStream_t s) {
+    static const bool off = getenv("PIT_NO_BWD_PAIR") != nullptr;
+    const long work = (long)gx.M * gx.N * gx.K + (long)g1.M * g1.N * g1.K + (long)g2.M * g2.N * g2.K;
+    if (off || work > (1L << 28)) {
+        if (int rc = launch_gemm(gx, s)) return rc;
+        return launch_gemm_pair_atomic(g1, g2, s);
+    }
+    GemmLaunch Lx, L1, L2;
+    if (int rc = prepare_gemm(gx, Lx, 0, 8)) return rc;
+    if (int rc = prepare_gemm(g1, L1, 1, 8)) return rc;
+    if (int rc = prepare_gemm(g2, L2, 1, 8)) return rc;
+    const int nx = Lx.grid.x * Lx.grid.y;                 // not split over z (non-atomic)
+    const int n1 = L1.grid.x * L1.grid.y * L1.grid.z, n2 = L2.grid.x * L2.grid.y * L2.grid.z;
+    const size_t sm = (size_t)8 * Lx.tn * 16 * 64 * sizeof(float);
+    if (Lx.tn == 2)
+        hipLaunchKernelGGL((gemm_rd_triple_kernel<2>), dim3(nx + n1 + n2), dim3(512), sm, s, gx, g1, g2, nx, (int)Lx.grid.x,
+                           n1, (int)L1.grid.x, (int)L1.grid.y, (int)L2.grid.x, (int)L2.grid.y);
+    else
+        hipLaunchKernelGGL((gemm_rd_triple_kernel<1>), dim3(nx + n1 + n2), dim3(512), sm, s, gx, g1, g2, nx, (int)Lx.grid.x,
+                           n1, (int)L1.grid.x, (int)L1.grid.y, (int)L2.grid.x, (int)L2.grid.y);
+    return 0;
+}
+
 GemmArgs blank() {
     GemmArgs g{};
     g.ones_col = -1;
     return g;
+}
+
+// dX = dZ1 W1
+GemmArgs make_dx(const float* dz1, const float* w1, int rows, int n0, int n1, float* d_x, long ld_dx) {
+    GemmArgs g = blank();
+    g.A = dz1; g.a_rs = n1; g.a_cs = 1;
+    g.B = w1; g.b_rs = n0; g.b_cs = 1;
+    g.M = rows; g.N = n0; g.K = n1;
+    g.C = d_x; g.ldc = ld_dx; g.epi = EPI_STORE;
+    return g;
+}
+// dW2 += dZ2^T H (+ db2 as the ones column)
+GemmArgs make_dw2(const float* dz2, long ld_dz2, const float* h, int rows, int n1, int n2, float* d_w2, float* d_b2) {
+    GemmArgs g = blank();
+    g.A = dz2; g.a_rs = 1; g.a_cs = ld_dz2;        // A(m,k) = dz2[k][m]
+    g.B = h; g.b_rs = n1; g.b_cs = 1;
+    g.M = n2; g.N = n1 + 1; g.K = rows; g.ones_col = n1;
+    g.C = d_w2; g.ldc = n1; g.C2 = d_b2; g.atomic = 1; g.epi = EPI_ATOMIC;
+    return g;
+}
+// dW1 += dZ1^T X (+ db1)
+GemmArgs make_dw1(const float* dz1, const float* x, long ldx, int rows, int n0, int n1, float* d_w1, float* d_b1) {
+    GemmArgs g = blank();
+    g.A = dz1; g.a_rs = 1; g.a_cs = n1;
+    g.B = x; g.b_rs = ldx; g.b_cs = 1;
+    g.M = n1; g.N = n0 + 1; g.K = rows; g.ones_col = n0;
+    g.C = d_w1; g.ldc = n0; g.C2 = d_b1; g.atomic = 1; g.epi = EPI_ATOMIC;
+    return g;
+}
+
+int zero_param_grads(float* d_w1, float* d_b1, float* d_w2, float* d_b2, int n0, int n1, int n2, hipStream_t s) {
+    hipError_t e;
+    if ((e = hipMemsetAsync(d_w1, 0, sizeof(float) * (size_t)n1 * n0, s)) != hipSuccess) return (int)e;
+    if ((e = hipMemsetAsync(d_b1, 0, sizeof(float) * (size_t)n1, s)) != hipSuccess) return (int)e;
+    if ((e = hipMemsetAsync(d_w2, 0, sizeof(float) * (size_t)n2 * n1, s)) != hipSuccess) return (int)e;
+    if ((e = hipMemsetAsync(d_b2, 0, sizeof(float) * (size_t)n2, s)) != hipSuccess) return (int)e;
+    return 0;
+}
+
+// dZ1 = (dZ2 W2) * gelu'(Z1), with dZ2 = dY * gelu'(Z2) formed in the A prologue and kept
+int launch_dz1(int rows, int n1, int n2, const float* w2, const float* z1, const float* z2, int out_gelu,
+               const float* d_y, long ld_dy, float* dz1, float* dz2buf, hipStream_t s) {
+    GemmArgs g = blank();
+    g.A = d_y; g.a_rs = ld_dy; g.a_cs = 1;
+    if (out_gelu) {
+        if (ld_dy != n2) return PIT_ERR_SIZE;     // prologue reads z2 with d_y's indexing
+        g.a_gz = z2; g.a_out = dz2buf; g.a_out_rs = n2; g.a_out_cs = 1;
+    }
+    g.B = w2; g.b_rs = n1; g.b_cs = 1;            // B(k,n) = w2[k][n]
+    g.M = rows; g.N = n1; g.K = n2;
+    g.G = z1; g.ldg = n1; g.C = dz1; g.ldc = n1; g.epi = EPI_MUL_GELU_GRAD;
+    return launch_gemm(g, s);
 }
 
 }  // namespace
@@ -321,26 +419,10 @@ extern "C" int pit_mlp_bwd_data(int rows, int n0, int n1, int n2, const float* w
     hipStream_t s = (hipStream_t)stream;
     float* dz1 = scratch;                       // rows * n1
     float* dz2buf = scratch + (long)rows * n1;  // rows * n2
-    // dZ1 = (dZ2 W2) * gelu'(Z1), with dZ2 = dY * gelu'(Z2) formed in the A prologue and kept
-    GemmArgs g = blank();
-    g.A = d_y; g.a_rs = ld_dy; g.a_cs = 1;
-    if (out_gelu) {
-        if (ld_dy != n2) return PIT_ERR_SIZE;     // prologue reads z2 with d_y's indexing
-        g.a_gz = z2; g.a_out = dz2buf; g.a_out_rs = n2; g.a_out_cs = 1;
-    }
-    g.B = w2; g.b_rs = n1; g.b_cs = 1;            // B(k,n) = w2[k][n]
-    g.M = rows; g.N = n1; g.K = n2;
-    g.G = z1; g.ldg = n1; g.C = dz1; g.ldc = n1; g.epi = EPI_MUL_GELU_GRAD;
-    if (int rc = launch_gemm(g, s)) return rc;
+    if (int rc = launch_dz1(rows, n1, n2, w2, z1, z2, out_gelu, d_y, ld_dy, dz1, dz2buf, s)) return rc;
     PIT_CHECK_LAUNCH();
-    // dX = dZ1 W1
     if (d_x) {
-        g = blank();
-        g.A = dz1; g.a_rs = n1; g.a_cs = 1;
-        g.B = w1; g.b_rs = n0; g.b_cs = 1;
-        g.M = rows; g.N = n0; g.K = n1;
-        g.C = d_x; g.ldc = ld_dx; g.epi = EPI_STORE;
-        if (int rc = launch_gemm(g, s)) return rc;
+        if (int rc = launch_gemm(make_dx(dz1, w1, rows, n0, n1, d_x, ld_dx), s)) return rc;
         PIT_CHECK_LAUNCH();
     }
     return 0;
@@ -356,25 +438,10 @@ extern "C" int pit_mlp_bwd_params(const float* x, long ldx, int rows, int n0, in
     const float* dz1 = scratch;
     const float* dz2 = out_gelu ? scratch + (long)rows * n1 : d_y;
     const long ld_dz2 = out_gelu ? n2 : ld_dy;
-    if (!accumulate) {
-        hipError_t e;
-        if ((e = hipMemsetAsync(d_w1, 0, sizeof(float) * (size_t)n1 * n0, s)) != hipSuccess) return (int)e;
-        if ((e = hipMemsetAsync(d_b1, 0, sizeof(float) * (size_t)n1, s)) != hipSuccess) return (int)e;
-        if ((e = hipMemsetAsync(d_w2, 0, sizeof(float) * (size_t)n2 * n1, s)) != hipSuccess) return (int)e;
-        if ((e = hipMemsetAsync(d_b2, 0, sizeof(float) * (size_t)n2, s)) != hipSuccess) return (int)e;
-    }
-    // dW2 += dZ2^T H (+ db2 as the ones column)  and  dW1 += dZ1^T X (+ db1): one launch
-    GemmArgs g = blank();
-    g.A = dz2; g.a_rs = 1; g.a_cs = ld_dz2;        // A(m,k) = dz2[k][m]
-    g.B = h; g.b_rs = n1; g.b_cs = 1;
-    g.M = n2; g.N = n1 + 1; g.K = rows; g.ones_col = n1;
-    g.C = d_w2; g.ldc = n1; g.C2 = d_b2; g.atomic = 1; g.epi = EPI_ATOMIC;
-    GemmArgs g2 = blank();
-    g2.A = dz1; g2.a_rs = 1; g2.a_cs = n1;
-    g2.B = x; g2.b_rs = ldx; g2.b_cs = 1;
-    g2.M = n1; g2.N = n0 + 1; g2.K = rows; g2.ones_col = n0;
-    g2.C = d_w1; g2.ldc = n0; g2.C2 = d_b1; g2.atomic = 1; g2.epi = EPI_ATOMIC;
-    if (int rc = launch_gemm_pair_atomic(g, g2, s)) return rc;
+    if (!accumulate)
+        if (int rc = zero_param_grads(d_w1, d_b1, d_w2, d_b2, n0, n1, n2, s)) return rc;
+    if (int rc = launch_gemm_pair_atomic(make_dw2(dz2, ld_dz2, h, rows, n1, n2, d_w2, d_b2),
+                                         make_dw1(dz1, x, ldx, rows, n0, n1, d_w1, d_b1), s)) return rc;
     PIT_CHECK_LAUNCH();
     return 0;
 }
@@ -384,8 +451,23 @@ extern "C" int pit_mlp_bwd(const float* x, long ldx, int rows, int n0, int n1, i
                            int out_gelu, const float* d_y, long ld_dy,
                            float* d_x, long ld_dx, float* d_w1, float* d_b1, float* d_w2, float* d_b2,
                            int accumulate, float* scratch, void* stream) {
-    int rc = pit_mlp_bwd_data(rows, n0, n1, n2, w1, w2, z1, z2, out_gelu, d_y, ld_dy, d_x, ld_dx, scratch, stream);
-    if (rc) return rc;
-    return pit_mlp_bwd_params(x, ldx, rows, n0, n1, n2, h, out_gelu, d_y, ld_dy, d_w1, d_b1, d_w2, d_b2,
-                              accumulate, scratch, stream);
+    if (!x || !w1 || !w2 || !z1 || !h || !d_y || !d_w1 || !d_b1 || !d_w2 || !d_b2 || !scratch) return PIT_ERR_NULL;
+    if (out_gelu && !z2) return PIT_ERR_NULL;
+    if (rows <= 0 || n0 <= 0 || n1 <= 0 || n2 <= 0) return PIT_ERR_SIZE;
+    hipStream_t s = (hipStream_t)stream;
+    float* dz1 = scratch;
+    float* dz2buf = scratch + (long)rows * n1;
+    if (!accumulate)
+        if (int rc = zero_param_grads(d_w1, d_b1, d_w2, d_b2, n0, n1, n2, s)) return rc;
+    if (int rc = launch_dz1(rows, n1, n2, w2, z1, z2, out_gelu, d_y, ld_dy, dz1, dz2buf, s)) return rc;
+    PIT_CHECK_LAUNCH();
+    const float* dz2 = out_gelu ? dz2buf : d_y;
+    const long ld_dz2 = out_gelu ? n2 : ld_dy;
+    const GemmArgs g2 = make_dw2(dz2, ld_dz2, h, rows, n1, n2, d_w2, d_b2);
+    const GemmArgs g1 = make_dw1(dz1, x, ldx, rows, n0, n1, d_w1, d_b1);
+    // everything after dZ1 is mutually independent: one launch when small
+    if (d_x) { if (int rc = launch_gemm_bwd_tail(make_dx(dz1, w1, rows, n0, n1, d_x, ld_dx), g2, g1, s)) return rc; }
+    else if (int rc = launch_gemm_pair_atomic(g2, g1, s)) return rc;
+    PIT_CHECK_LAUNCH();
+    return 0;
 }

@@ -1111,15 +1111,15 @@ struct SparseArgs {
 };
 
 template <int NH, int CR, int MODE>
-__global__ __launch_bounds__(256) void posatt_sparse_rows(AttArgs a, SparseArgs sp) {
+__device__ __forceinline__ void sparse_rows_body(const AttArgs& a, const SparseArgs& sp, const int bx, const int by, const int bz) {
     constexpr int G = (CR >= 4) ? 4 : 8;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long rows_total = (long)a.mesh_batch * a.n_out;
-    const long row_raw = (long)blockIdx.x * 4 + wave;
+    const long row_raw = (long)bx * 4 + wave;
     const bool active = row_raw < rows_total;          // tail waves recompute the last row, write nothing
     const long row = active ? row_raw : rows_total - 1;
     const int mb = (int)(row / a.n_out), n = (int)(row - (long)mb * a.n_out);
-    const int cblk = blockIdx.y, h0 = blockIdx.z * NH;
+    const int cblk = by, h0 = bz * NH;
 
     const unsigned mo_bytes = (unsigned)((long)a.mesh_batch * a.n_out * a.sdim * 4);
     const unsigned mi_bytes = (unsigned)((long)a.mesh_batch * a.n_in * a.sdim * 4);
@@ -1229,7 +1229,7 @@ __global__ __launch_bounds__(256) void posatt_sparse_rows(AttArgs a, SparseArgs 
                 part += (double)acc[h][r] * (double)buf_load(rdo, cvalid[r] ? off : a.dout_bytes);
             }
             part = wave_sum_d(part);
-            const int slot = (int)((blockIdx.x + 131u * blockIdx.y + 977u * wave) & (a.nslots - 1));
+            const int slot = (int)((bx + 131u * by + 977u * wave) & (a.nslots - 1));
             dscale_add(a.dscale_acc + (h0 + h) * PIT_DSCALE_SLOTS + slot, -part, lane == 0 && active);
         }
         return;
@@ -1258,15 +1258,20 @@ __global__ __launch_bounds__(256) void posatt_sparse_rows(AttArgs a, SparseArgs 
     }
 }
 
+template <int NH, int CR, int MODE>
+__global__ __launch_bounds__(256) void posatt_sparse_rows(AttArgs a, SparseArgs sp) {
+    sparse_rows_body<NH, CR, MODE>(a, sp, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
 template <int CR>
-__global__ __launch_bounds__(256) void posatt_sparse_cols(AttArgs a, SparseArgs sp) {
+__device__ __forceinline__ void sparse_cols_body(const AttArgs& a, const SparseArgs& sp, const int bx, const int by) {
     constexpr int G = (CR >= 4) ? 4 : 8;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long keys_total = (long)a.mesh_batch * a.n_in;
-    const long kid = (long)blockIdx.x * 4 + wave;
+    const long kid = (long)bx * 4 + wave;
     if (kid >= keys_total) return;
     const int mb = (int)(kid / a.n_in), j = (int)(kid - (long)mb * a.n_in);
-    const int cblk = blockIdx.y;
+    const int cblk = by;
     const unsigned mo_bytes = (unsigned)((long)a.mesh_batch * a.n_out * a.sdim * 4);
     const unsigned mi_bytes = (unsigned)((long)a.mesh_batch * a.n_in * a.sdim * 4);
     const __amdgpu_buffer_rsrc_t rmo = make_rsrc(a.mesh_out, mo_bytes);
@@ -1341,12 +1346,17 @@ __global__ __launch_bounds__(256) void posatt_sparse_cols(AttArgs a, SparseArgs 
     }
 }
 
+template <int CR>
+__global__ __launch_bounds__(256) void posatt_sparse_cols(AttArgs a, SparseArgs sp) {
+    sparse_cols_body<CR>(a, sp, blockIdx.x, blockIdx.y);
+}
+
 // rows whose candidate list overflowed are not in the transposed lists: add their contribution
 // to d(values) with atomics (rare: duplicated points / massive ties).
-__global__ __launch_bounds__(256) void posatt_sparse_overflow_cols(AttArgs a, SparseArgs sp) {
+__device__ __forceinline__ void sparse_overflow_body(const AttArgs& a, const SparseArgs& sp, const int bx) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long rows_total = (long)a.mesh_batch * a.n_out;
-    const long row = (long)blockIdx.x * 4 + wave;
+    const long row = (long)bx * 4 + wave;
     if (row >= rows_total) return;
     if (sp.nbr_cnt[row] <= sp.cap) return;
     const int mb = (int)(row / a.n_out), n = (int)(row - (long)mb * a.n_out);
@@ -1384,6 +1394,26 @@ __global__ __launch_bounds__(256) void posatt_sparse_overflow_cols(AttArgs a, Sp
     }
 }
 
+__global__ __launch_bounds__(256) void posatt_sparse_overflow_cols(AttArgs a, SparseArgs sp) {
+    sparse_overflow_body(a, sp, blockIdx.x);
+}
+
+// d(values) over the transposed lists and d(scale) over the rows of a sparse layer in ONE launch:
+// workgroups [0, n_cols) walk the transposed lists (critical path first), the rest the d(scale)
+// rows.  The overflow pass stays a separate, later launch: it ADDS to d(values) with atomics and
+// must come after the plain stores of the key-owning waves.
+template <int NH, int CR>
+__global__ __launch_bounds__(256) void posatt_sparse_bwd_kernel(AttArgs a, SparseArgs sp, int n_cols, int cgx,
+                                                                 int rgx, int rgy) {
+    int id = blockIdx.x;
+    if (id < n_cols) {
+        sparse_cols_body<CR>(a, sp, id % cgx, id / cgx);
+    } else {
+        id -= n_cols;
+        sparse_rows_body<NH, CR, 1>(a, sp, id % rgx, (id / rgx) % rgy, id / (rgx * rgy));
+    }
+}
+
 // columns per lane: as many as the column count allows, fewer when the launch would otherwise
 // have too few wavefronts to hide the gather latency (one wave = one row / key)
 int cr_for(int ncols, long units) {
@@ -1403,6 +1433,28 @@ void launch_sparse_rows(const AttArgs& a, const SparseArgs& sp, hipStream_t s) {
     if (nh == 2) PIT_SR_CR(2); else PIT_SR_CR(1);
 #undef PIT_SR_CR
 #undef PIT_SR
+}
+
+// merged d(values) + d(scale) launch for a sparse layer; false when the two parts want different
+// columns-per-lane (caller launches them separately)
+bool launch_sparse_bwd_pair(const AttArgs& a, const SparseArgs& sp, hipStream_t s) {
+    if (env_int("PIT_NO_BWD_PAIR")) return false;
+    const int nh = (a.n_head % 2 == 0) ? 2 : 1;
+    const long rows = (long)a.mesh_batch * a.n_out, keys = (long)a.mesh_batch * a.n_in;
+    const int cr = cr_for(a.ncols, rows * (a.n_head / nh));
+    if (cr != cr_for(a.ncols, keys)) return false;
+    const int cblocks = (a.ncols + 64 * cr - 1) / (64 * cr);
+    const long rgx = (rows + 3) / 4, cgx = (keys + 3) / 4;
+    const long n_rows = rgx * cblocks * (a.n_head / nh), n_cols = cgx * cblocks;
+    if (n_rows + n_cols > 16384) return false;            // big launches gain nothing from merging
+    dim3 grid((unsigned)(n_rows + n_cols)), block(256);
+#define PIT_SB(NH_, CR_) hipLaunchKernelGGL((posatt_sparse_bwd_kernel<NH_, CR_>), grid, block, 0, s, a, sp, (int)n_cols, (int)cgx, (int)rgx, cblocks)
+#define PIT_SB_CR(NH_) do { if (cr == 8) PIT_SB(NH_, 8); else if (cr == 4) PIT_SB(NH_, 4); else if (cr == 2) PIT_SB(NH_, 2); else PIT_SB(NH_, 1); } while (0)
+    if (nh == 2) PIT_SB_CR(2); else PIT_SB_CR(1);
+#undef PIT_SB_CR
+#undef PIT_SB
+    hipLaunchKernelGGL(posatt_sparse_overflow_cols, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, a, sp);
+    return true;
 }
 
 void launch_sparse_cols(const AttArgs& a, const SparseArgs& sp, hipStream_t s) {
@@ -1518,7 +1570,10 @@ extern "C" int pit_posatt_bwd(const float* mesh_out, const float* mesh_in, int m
         while (ns < PIT_DSCALE_SLOTS && (long)ns * 32 < approx_wgs * 4) ns <<= 1;
         a.nslots = ns;
         bool paired = false;
-        if (!sparse && d_values) paired = launch_bwd_pair(a, s);       // d(scale) + d(values) in one launch
+        if (d_values) {                                                // d(scale) + d(values) in one launch
+            if (!sparse) paired = launch_bwd_pair(a, s);
+            else if (rev_ptr && rev_row) paired = launch_sparse_bwd_pair(a, sp, s);
+        }
         if (!paired) { if (sparse) launch_sparse_rows<1>(a, sp, s); else launch_rows<1>(a, s); }
         PIT_CHECK_LAUNCH();
         hipLaunchKernelGGL(posatt_dhead_finish, dim3(n_head), dim3(256), 0, s, a);

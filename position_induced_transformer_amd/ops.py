@@ -337,18 +337,23 @@ class _Mlp(torch.autograd.Function):
         L = _lib.lib()
         z2p = z2.data_ptr() if ctx.out_gelu else 0
         og = 1 if ctx.out_gelu else 0
-        rc = L.pit_mlp_bwd_data(rows, n0, n1, n2, w1.data_ptr(), w2.data_ptr(), z1.data_ptr(), z2p, og,
-                                d_y2.data_ptr(), d_y2.stride(0), _lib.ptr(d_x), n0, scratch.data_ptr(),
-                                _lib.stream_ptr())
-        _lib.check(rc, "pit_mlp_bwd_data")
         if OVERLAP_BACKWARD and inplace:
+            rc = L.pit_mlp_bwd_data(rows, n0, n1, n2, w1.data_ptr(), w2.data_ptr(), z1.data_ptr(), z2p, og,
+                                    d_y2.data_ptr(), d_y2.stride(0), _lib.ptr(d_x), n0, scratch.data_ptr(),
+                                    _lib.stream_ptr())
+            _lib.check(rc, "pit_mlp_bwd_data")
             stream_p = _fork_side(dev, x2, h, d_y2, scratch).cuda_stream     # weight grads off the critical path
+            rc = L.pit_mlp_bwd_params(x2.data_ptr(), x2.stride(0), rows, n0, n1, n2, h.data_ptr(), og,
+                                      d_y2.data_ptr(), d_y2.stride(0), d_w1.data_ptr(), d_b1.data_ptr(),
+                                      d_w2.data_ptr(), d_b2.data_ptr(), 1, scratch.data_ptr(), stream_p)
+            _lib.check(rc, "pit_mlp_bwd_params")
         else:
-            stream_p = _lib.stream_ptr()
-        rc = L.pit_mlp_bwd_params(x2.data_ptr(), x2.stride(0), rows, n0, n1, n2, h.data_ptr(), og,
-                                  d_y2.data_ptr(), d_y2.stride(0), d_w1.data_ptr(), d_b1.data_ptr(),
-                                  d_w2.data_ptr(), d_b2.data_ptr(), 1 if inplace else 0, scratch.data_ptr(), stream_p)
-        _lib.check(rc, "pit_mlp_bwd_params")
+            # one call: dZ1, then dX and both weight-gradient reductions (merged into one launch when small)
+            rc = L.pit_mlp_bwd(x2.data_ptr(), x2.stride(0), rows, n0, n1, n2, w1.data_ptr(), w2.data_ptr(),
+                               z1.data_ptr(), h.data_ptr(), z2p, og, d_y2.data_ptr(), d_y2.stride(0),
+                               _lib.ptr(d_x), n0, d_w1.data_ptr(), d_b1.data_ptr(), d_w2.data_ptr(), d_b2.data_ptr(),
+                               1 if inplace else 0, scratch.data_ptr(), _lib.stream_ptr())
+            _lib.check(rc, "pit_mlp_bwd")
         dx = d_x.reshape(ctx.in_shape) if need_x else None
         if inplace:
             return dx, None, None, None, None, None
