@@ -251,7 +251,11 @@ int prepare_gemm(GemmArgs& g, GemmLaunch& L, int force_tn = 0, int force_waves =
     // waves per workgroup: each wave wants >= 16 k; slabs over blockIdx.z only for the atomic
     // (row-reducing) GEMMs, sized so the launch has a few hundred workgroups
     int splits = 1;
-    if (g.atomic) splits = std::max(1, std::min((g.K + 127) / 128, (768 + tiles - 1) / tiles));
+    if (g.atomic) {
+        splits = std::max(1, std::min((g.K + 127) / 128, (768 + tiles - 1) / tiles));
+        // every split costs one fp32 atomic per output element: long reductions keep slabs >= 512
+        if (g.K > 4096) splits = std::max(1, std::min(splits, g.K / 512));
+    }
     int slab = (g.K + splits - 1) / splits;
     slab = ((slab + 7) / 8) * 8;
     splits = (g.K + slab - 1) / slab;
@@ -305,7 +309,8 @@ int launch_gemm_pair_atomic(GemmArgs g1, GemmArgs g2, hipStream_t s) {
 int launch_gemm_bwd_tail(GemmArgs gx, GemmArgs g1, GemmArgs g2, hipStream_t s) {
     static const bool off = getenv("PIT_NO_BWD_PAIR") != nullptr;
     const long work = (long)gx.M * gx.N * gx.K + (long)g1.M * g1.N * g1.K + (long)g2.M * g2.N * g2.K;
-    if (off || work > (1L << 28)) {
+    // the dX GEMM runs with 8 k-splitting waves here: only worth it while it is itself tiny
+    if (off || work > (1L << 28) || (long)gx.M * gx.N * gx.K > (1L << 27)) {
         if (int rc = launch_gemm(gx, s)) return rc;
         return launch_gemm_pair_atomic(g1, g2, s);
     }

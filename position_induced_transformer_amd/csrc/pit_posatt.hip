@@ -1402,15 +1402,15 @@ __global__ __launch_bounds__(256) void posatt_sparse_overflow_cols(AttArgs a, Sp
 // workgroups [0, n_cols) walk the transposed lists (critical path first), the rest the d(scale)
 // rows.  The overflow pass stays a separate, later launch: it ADDS to d(values) with atomics and
 // must come after the plain stores of the key-owning waves.
-template <int NH, int CR>
+template <int NH, int CRR, int CRC>
 __global__ __launch_bounds__(256) void posatt_sparse_bwd_kernel(AttArgs a, SparseArgs sp, int n_cols, int cgx,
                                                                  int rgx, int rgy) {
     int id = blockIdx.x;
     if (id < n_cols) {
-        sparse_cols_body<CR>(a, sp, id % cgx, id / cgx);
+        sparse_cols_body<CRC>(a, sp, id % cgx, id / cgx);
     } else {
         id -= n_cols;
-        sparse_rows_body<NH, CR, 1>(a, sp, id % rgx, (id / rgx) % rgy, id / (rgx * rgy));
+        sparse_rows_body<NH, CRR, 1>(a, sp, id % rgx, (id / rgx) % rgy, id / (rgx * rgy));
     }
 }
 
@@ -1435,23 +1435,27 @@ void launch_sparse_rows(const AttArgs& a, const SparseArgs& sp, hipStream_t s) {
 #undef PIT_SR
 }
 
-// merged d(values) + d(scale) launch for a sparse layer; false when the two parts want different
-// columns-per-lane (caller launches them separately)
+// merged d(values) + d(scale) launch for a sparse layer; false when the launch would be large or
+// the parts' columns-per-lane are a combination that is not instantiated (caller launches the
+// parts separately)
 bool launch_sparse_bwd_pair(const AttArgs& a, const SparseArgs& sp, hipStream_t s) {
     if (env_int("PIT_NO_BWD_PAIR")) return false;
     const int nh = (a.n_head % 2 == 0) ? 2 : 1;
     const long rows = (long)a.mesh_batch * a.n_out, keys = (long)a.mesh_batch * a.n_in;
-    const int cr = cr_for(a.ncols, rows * (a.n_head / nh));
-    if (cr != cr_for(a.ncols, keys)) return false;
-    const int cblocks = (a.ncols + 64 * cr - 1) / (64 * cr);
+    const int crr = cr_for(a.ncols, rows * (a.n_head / nh));
+    int crc = cr_for(a.ncols, keys);
+    if (crc != crr && crc != 1) crc = (crc > crr) ? crr : 1;     // instantiated: equal, or 1 column per lane for d(values)
+    const int rblocks = (a.ncols + 64 * crr - 1) / (64 * crr), cblocks = (a.ncols + 64 * crc - 1) / (64 * crc);
     const long rgx = (rows + 3) / 4, cgx = (keys + 3) / 4;
-    const long n_rows = rgx * cblocks * (a.n_head / nh), n_cols = cgx * cblocks;
+    const long n_rows = rgx * rblocks * (a.n_head / nh), n_cols = cgx * cblocks;
     if (n_rows + n_cols > 16384) return false;            // big launches gain nothing from merging
     dim3 grid((unsigned)(n_rows + n_cols)), block(256);
-#define PIT_SB(NH_, CR_) hipLaunchKernelGGL((posatt_sparse_bwd_kernel<NH_, CR_>), grid, block, 0, s, a, sp, (int)n_cols, (int)cgx, (int)rgx, cblocks)
-#define PIT_SB_CR(NH_) do { if (cr == 8) PIT_SB(NH_, 8); else if (cr == 4) PIT_SB(NH_, 4); else if (cr == 2) PIT_SB(NH_, 2); else PIT_SB(NH_, 1); } while (0)
+#define PIT_SB(NH_, CRR_, CRC_) hipLaunchKernelGGL((posatt_sparse_bwd_kernel<NH_, CRR_, CRC_>), grid, block, 0, s, a, sp, (int)n_cols, (int)cgx, (int)rgx, rblocks)
+#define PIT_SB_C(NH_, CRR_) do { if (crc == CRR_) PIT_SB(NH_, CRR_, CRR_); else PIT_SB(NH_, CRR_, 1); } while (0)
+#define PIT_SB_CR(NH_) do { if (crr == 8) PIT_SB_C(NH_, 8); else if (crr == 4) PIT_SB_C(NH_, 4); else if (crr == 2) PIT_SB_C(NH_, 2); else PIT_SB(NH_, 1, 1); } while (0)
     if (nh == 2) PIT_SB_CR(2); else PIT_SB_CR(1);
 #undef PIT_SB_CR
+#undef PIT_SB_C
 #undef PIT_SB
     hipLaunchKernelGGL(posatt_sparse_overflow_cols, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, a, sp);
     return true;
