@@ -190,6 +190,25 @@ __device__ __forceinline__ void posatt_rows_body(const AttArgs& a, const int bx,
 #pragma unroll
     for (int u = 0; u < 4; ++u) kpos[u] = group_pos(bf, u, half);
 
+    // d(scale): the d_out tile this workgroup contracts with at the end; with few column tiles it is
+    // fetched up front (16*CT registers) so its latency hides behind the whole key loop
+    constexpr bool DOV_EARLY = (MODE == 1) && (CT <= 2);
+    float dov[MODE == 1 ? CT : 1][16];
+    auto load_dov = [&]() {
+        const __amdgpu_buffer_rsrc_t rdo = make_rsrc(a.d_out, a.dout_bytes);
+#pragma unroll
+        for (int t = 0; t < (MODE == 1 ? CT : 0); ++t) {
+            const unsigned cbase = (unsigned)(((long)cb[t] * a.dout_bstride + a.out_col0 + (long)h * a.dim + cd[t]) * 4);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int nr = n0 + acc_row(i, half);
+                dov[t][i] = buf_load(rdo, (cvalid[t] && nr < a.n_out) ? cbase + (unsigned)nr * (unsigned)a.ld_dout * 4u
+                                                                      : a.dout_bytes);
+            }
+        }
+    };
+    if (DOV_EARLY) load_dov();
+
     // Value rows for the NEXT step are always in flight while the current step computes its
     // weights and MFMAs (the loads do not depend on the weights); a masked step whose 8 keys
     // are all dropped only skips its MFMAs.  NP key pairs per step.
@@ -270,28 +289,26 @@ __device__ __forceinline__ void posatt_rows_body(const AttArgs& a, const int bx,
     }
 
     if (MODE == 1) {
-        // dc_h -= sum acc[n,col] * dO[n,col]   (fp64 accumulation); all 16*CT loads in flight at once
-        const __amdgpu_buffer_rsrc_t rdo = make_rsrc(a.d_out, a.dout_bytes);
-        float dov[CT][16];
-#pragma unroll
-        for (int t = 0; t < CT; ++t) {
-            const unsigned cbase = (unsigned)(((long)cb[t] * a.dout_bstride + a.out_col0 + (long)h * a.dim + cd[t]) * 4);
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int nr = n0 + acc_row(i, half);
-                dov[t][i] = buf_load(rdo, (cvalid[t] && nr < a.n_out) ? cbase + (unsigned)nr * (unsigned)a.ld_dout * 4u
-                                                                      : a.dout_bytes);
-            }
-        }
+        // dc_h -= sum acc[n,col] * dO[n,col]   (fp64 accumulation)
+        if (!DOV_EARLY) load_dov();
         double part = 0.0;
 #pragma unroll
         for (int t = 0; t < CT; ++t)
 #pragma unroll
             for (int i = 0; i < 16; ++i) part += (double)acc[t][i] * (double)dov[t][i];
         part = wave_sum_d(part);
-        // PIT_DSCALE_SLOTS accumulators per head keep the fp64 atomics off a single address
-        const int slot = (int)((bz + 131u * bx + 977u * wave) & (a.nslots - 1));
-        dscale_add(a.dscale_acc + h * PIT_DSCALE_SLOTS + slot, -part, lane == 0);
+        // one fp64 atomic per workgroup (waves combine through LDS first), spread over
+        // PIT_DSCALE_SLOTS accumulators per head to keep them off a single address
+        double* wred = reinterpret_cast<double*>(smem);
+        __syncthreads();                                   // staging region is free
+        if (lane == 0) wred[wave] = part;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double tot = 0.0;
+            for (int w = 0; w < nwaves; ++w) tot += wred[w];
+            const int slot = (int)((bz + 131u * bx) & (a.nslots - 1));
+            dscale_add(a.dscale_acc + h * PIT_DSCALE_SLOTS + slot, -tot, true);
+        }
         return;
     }
 
@@ -344,7 +361,7 @@ __global__ __launch_bounds__(512) void posatt_rows_kernel(AttArgs a) {
 // ------------------------------------------------------------------------------------
 // cols kernel: d values
 // ------------------------------------------------------------------------------------
-template <int CT, bool MASKED, bool BF>
+template <int CT, bool MASKED, bool BF, int NPX = 0>
 __device__ __forceinline__ void posatt_cols_body(const AttArgs& a, const int bx, const int by, const int bz) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float4* s_rec = reinterpret_cast<float4*>(smem);     // [ROW_CHUNK][2]: {xo.xyz, T}, {S_min, 1/L, -, -}
@@ -388,7 +405,7 @@ __device__ __forceinline__ void posatt_cols_body(const AttArgs& a, const int bx,
 #pragma unroll
     for (int u = 0; u < 4; ++u) kpos[u] = group_pos(bf, u, half);
 
-    constexpr int NP = (CT == 4) ? 4 : 8;
+    constexpr int NP = NPX ? NPX : ((CT == 4) ? 4 : 8);      // key pairs per step (NPX: override for the merged launch)
     float bnext[NP][CT];
     auto prefetch = [&](long hoff, int nc0, int nstart, int nb, int ne) {
         (void)nb;
@@ -502,15 +519,17 @@ __global__ __launch_bounds__(512) void posatt_cols_kernel(AttArgs a) {
 // they share the chip instead of running back to back.  Workgroups [0, n_cols_wgs) run the
 // d(values) tiles (on the critical path of the backward pass: dispatched first), the rest the
 // d(scale) tiles; `ar` / `ac` carry each part's own column grouping.
-template <int CT, bool MASKED, bool BF>
-__global__ __launch_bounds__(512) void posatt_bwd_pair_kernel(AttArgs ar, AttArgs ac, int n_cols_wgs, int cgx, int cgy,
-                                                               int rgx, int rgy) {
+// (one column tile per workgroup only - the small, latency-bound regime; >= 4 waves per SIMD so that
+// two 8-wave workgroups share a CU: all d(values) and d(scale) tiles are resident at once)
+template <bool MASKED, bool BF>
+__global__ __launch_bounds__(512, 4) void posatt_bwd_pair_kernel(AttArgs ar, AttArgs ac, int n_cols_wgs, int cgx, int cgy,
+                                                                  int rgx, int rgy) {
     int id = blockIdx.x;
     if (id < n_cols_wgs) {
-        posatt_cols_body<CT, MASKED, BF>(ac, id % cgx, (id / cgx) % cgy, id / (cgx * cgy));
+        posatt_cols_body<1, MASKED, BF, 4>(ac, id % cgx, (id / cgx) % cgy, id / (cgx * cgy));
     } else {
         id -= n_cols_wgs;
-        posatt_rows_body<CT, 1, MASKED, false>(ar, id % rgx, (id / rgx) % rgy, id / (rgx * rgy));
+        posatt_rows_body<1, 1, MASKED, false>(ar, id % rgx, (id / rgx) % rgy, id / (rgx * rgy));
     }
 }
 
@@ -1063,7 +1082,7 @@ bool launch_bwd_pair(const AttArgs& a0, hipStream_t s) {
         if (tiles_per_wg_for(a0.ncols, (long)j_tiles * a0.mesh_batch, work_c, a0.mesh_batch)) return false;
     }
     const int ct = choose_ct(a0.ncols, (long)n_tiles * a0.n_head * a0.mesh_batch);
-    if (ct != choose_ct(a0.ncols, (long)j_tiles * a0.mesh_batch)) return false;
+    if (ct != 1 || choose_ct(a0.ncols, (long)j_tiles * a0.mesh_batch) != 1) return false;
     AttArgs ar = a0, ac = a0;
     ar.colgroups = ac.colgroups = (a0.ncols + 32 * ct - 1) / (32 * ct);
     const int wmax = (ct == 4) ? 4 : 8;
@@ -1076,21 +1095,16 @@ bool launch_bwd_pair(const AttArgs& a0, hipStream_t s) {
     if (rows_wgs + cols_wgs > 4096 || rows_wgs + cols_wgs > 0x7fffffffL) return false;
     const size_t sm = std::max(rows_smem(ct, nwaves, a0.n_in), cols_smem(ct, nwaves, a0.n_out));
     dim3 grid((unsigned)(rows_wgs + cols_wgs)), block(64 * nwaves);
-#define PIT_PAIR_K(CT_, M_, BF_)                                                                              \
+#define PIT_PAIR_K(M_, BF_)                                                                                   \
     do {                                                                                                      \
-        static bool once = (hipFuncSetAttribute((const void*)posatt_bwd_pair_kernel<CT_, M_, BF_>,            \
+        static bool once = (hipFuncSetAttribute((const void*)posatt_bwd_pair_kernel<M_, BF_>,                 \
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 98304), true);    \
         (void)once;                                                                                           \
-        hipLaunchKernelGGL((posatt_bwd_pair_kernel<CT_, M_, BF_>), grid, block, sm, s, ar, ac, (int)cols_wgs, \
+        hipLaunchKernelGGL((posatt_bwd_pair_kernel<M_, BF_>), grid, block, sm, s, ar, ac, (int)cols_wgs,      \
                            ac.colgroups, j_tiles, a0.mesh_batch * ar.colgroups, a0.n_head);                   \
     } while (0)
-#define PIT_PAIR_M(CT_, BF_) do { if (a0.masked) PIT_PAIR_K(CT_, true, BF_); else PIT_PAIR_K(CT_, false, BF_); } while (0)
-#define PIT_PAIR(CT_) do { if (a0.bf16) PIT_PAIR_M(CT_, true); else PIT_PAIR_M(CT_, false); } while (0)
-    if (ct == 4) PIT_PAIR(4);
-    else if (ct == 2) PIT_PAIR(2);
-    else PIT_PAIR(1);
-#undef PIT_PAIR
-#undef PIT_PAIR_M
+    if (a0.masked) { if (a0.bf16) PIT_PAIR_K(true, true); else PIT_PAIR_K(true, false); }
+    else { if (a0.bf16) PIT_PAIR_K(false, true); else PIT_PAIR_K(false, false); }
 #undef PIT_PAIR_K
     return true;
 }
