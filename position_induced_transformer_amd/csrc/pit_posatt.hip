@@ -917,6 +917,20 @@ __global__ __launch_bounds__(512) void posatt_cols_tiles(AttArgs a) {
     }
 }
 
+// the same merge for 2 / 4 column tiles per workgroup (bigger layers: Elasticity, Vorticity), without
+// the register cap - these bodies need their registers, one workgroup per CU
+template <int CT, bool MASKED, bool BF>
+__global__ __launch_bounds__(512) void posatt_bwd_pair_wide_kernel(AttArgs ar, AttArgs ac, int n_cols_wgs, int cgx, int cgy,
+                                                                    int rgx, int rgy) {
+    int id = blockIdx.x;
+    if (id < n_cols_wgs) {
+        posatt_cols_body<CT, MASKED, BF>(ac, id % cgx, (id / cgx) % cgy, id / (cgx * cgy));
+    } else {
+        id -= n_cols_wgs;
+        posatt_rows_body<CT, 1, MASKED, false>(ar, id % rgx, (id / rgx) % rgy, id / (rgx * rgy));
+    }
+}
+
 // tuning overrides for experiments (tools/microbench.py): PIT_FORCE_CT, PIT_FORCE_WAVES, PIT_NO_TILES_KERNEL
 int env_int(const char* name) {
     const char* v = getenv(name);
@@ -1082,7 +1096,7 @@ bool launch_bwd_pair(const AttArgs& a0, hipStream_t s) {
         if (tiles_per_wg_for(a0.ncols, (long)j_tiles * a0.mesh_batch, work_c, a0.mesh_batch)) return false;
     }
     const int ct = choose_ct(a0.ncols, (long)n_tiles * a0.n_head * a0.mesh_batch);
-    if (ct != 1 || choose_ct(a0.ncols, (long)j_tiles * a0.mesh_batch) != 1) return false;
+    if (ct != choose_ct(a0.ncols, (long)j_tiles * a0.mesh_batch)) return false;
     AttArgs ar = a0, ac = a0;
     ar.colgroups = ac.colgroups = (a0.ncols + 32 * ct - 1) / (32 * ct);
     const int wmax = (ct == 4) ? 4 : 8;
@@ -1103,8 +1117,19 @@ bool launch_bwd_pair(const AttArgs& a0, hipStream_t s) {
         hipLaunchKernelGGL((posatt_bwd_pair_kernel<M_, BF_>), grid, block, sm, s, ar, ac, (int)cols_wgs,      \
                            ac.colgroups, j_tiles, a0.mesh_batch * ar.colgroups, a0.n_head);                   \
     } while (0)
-    if (a0.masked) { if (a0.bf16) PIT_PAIR_K(true, true); else PIT_PAIR_K(true, false); }
-    else { if (a0.bf16) PIT_PAIR_K(false, true); else PIT_PAIR_K(false, false); }
+#define PIT_PAIR_W(CT_, M_, BF_)                                                                              \
+    do {                                                                                                      \
+        static bool once = (hipFuncSetAttribute((const void*)posatt_bwd_pair_wide_kernel<CT_, M_, BF_>,       \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, 98304), true);    \
+        (void)once;                                                                                           \
+        hipLaunchKernelGGL((posatt_bwd_pair_wide_kernel<CT_, M_, BF_>), grid, block, sm, s, ar, ac, (int)cols_wgs, \
+                           ac.colgroups, j_tiles, a0.mesh_batch * ar.colgroups, a0.n_head);                   \
+    } while (0)
+#define PIT_PAIR_CT(M_, BF_) do { if (ct == 1) PIT_PAIR_K(M_, BF_); else if (ct == 2) PIT_PAIR_W(2, M_, BF_); else PIT_PAIR_W(4, M_, BF_); } while (0)
+    if (a0.masked) { if (a0.bf16) PIT_PAIR_CT(true, true); else PIT_PAIR_CT(true, false); }
+    else { if (a0.bf16) PIT_PAIR_CT(false, true); else PIT_PAIR_CT(false, false); }
+#undef PIT_PAIR_CT
+#undef PIT_PAIR_W
 #undef PIT_PAIR_K
     return true;
 }
