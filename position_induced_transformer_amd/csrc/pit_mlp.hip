@@ -227,6 +227,213 @@ __global__ __launch_bounds__(512) void gemm_rd_triple_kernel(GemmArgs gx, GemmAr
     }
 }
 
+// ------------------------------------------------------------------------------------
+// Large-regime GEMM: operands staged through LDS.
+//
+// The register-direct kernel above has every lane fetch its own fragment: a wave-level 16-B load
+// touches 32 different cache lines (32 rows x 32 B), so at scale it is bound by the L1 tag rate,
+// not by bytes or MFMA (measured 20-40 TF/s on 5120 x 768 x 256).  Here a 256-thread workgroup
+// owns a 128 x 64 output tile and walks K in chunks of 32: both operand chunks are fetched with
+// fully coalesced 16-B loads (8 full lines per wave instruction) into registers one chunk ahead,
+// written to LDS, and every wave (32 rows x 64 columns, two accumulator tiles) reads its MFMA
+// fragments from there.  No split-K inside the workgroup, so no reduction; the weight-gradient
+// GEMMs split K over blockIdx.z with fp32 atomics as before.
+// An operand is either k-contiguous in memory (KC: LDS [i][k], fragment = one 16-B LDS read) or
+// i-contiguous (IC: LDS [k][i], fragment = 4 conflict-free 4-B reads).
+constexpr int LBM = 128, LBN = 64, LBK = 32;
+constexpr int LPK = LBK + 4;      // row pitch of the [i][k] layouts (floats): 144 B, 16-B aligned, bank-skewed
+constexpr int LPM = LBM + 4;      // [k][m]
+constexpr int LPN = LBN + 4;      // [k][n]
+
+template <bool A_KC, bool B_KC, int EPI>
+__global__ __launch_bounds__(256) void gemm_lds_kernel(GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) float As[A_KC ? LBM * LPK : LBK * LPM];
+    __shared__ __attribute__((aligned(16))) float Bs[B_KC ? LBN * LPK : LBK * LPN];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int m0 = blockIdx.y * LBM, n0 = blockIdx.x * LBN;
+    const int kbeg = blockIdx.z * g.k_slab;
+    const int kend = min(g.K, kbeg + g.k_slab);
+    const __amdgpu_buffer_rsrc_t ra = make_rsrc(g.A, g.a_bytes);
+    const __amdgpu_buffer_rsrc_t rz = make_rsrc(g.a_gz ? g.a_gz : g.A, g.a_bytes);
+    const __amdgpu_buffer_rsrc_t rb = make_rsrc(g.B, g.b_bytes);
+    const int n_real = (EPI == EPI_ATOMIC && g.ones_col >= 0) ? g.N - 1 : g.N;   // columns that exist in memory
+
+    float sa[4][4], sb[2][4];          // staging registers: next chunk in flight during the MFMAs
+    auto gload = [&](int kc) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            unsigned off;
+            bool ok;
+            if (A_KC) {                // 8 threads cover the 32 k of one row
+                const int row = m0 + p * 32 + (tid >> 3), k = kc + (tid & 7) * 4;
+                ok = row < g.M && k < kend;
+                off = ((unsigned)row * (unsigned)g.a_rs + (unsigned)k) * 4u;
+            } else {                   // 32 threads cover the 128 m of one k
+                const int k = kc + p * 8 + (tid >> 5), m = m0 + (tid & 31) * 4;
+                ok = k < kend && m < g.M;
+                off = ((unsigned)k * (unsigned)g.a_cs + (unsigned)m) * 4u;
+            }
+            buf_load4(ra, ok ? off : g.a_bytes, sa[p]);
+            if (A_KC && g.a_gz) {      // prologue: A *= gelu'(Z), optionally kept (dZ2)
+                float zv[4];
+                buf_load4(rz, ok ? off : g.a_bytes, zv);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) sa[p][e] *= gelu_erf_grad(zv[e]);
+                if (g.a_out && blockIdx.x == 0 && ok) {
+                    const int row = m0 + p * 32 + (tid >> 3), k = kc + (tid & 7) * 4;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) g.a_out[(long)row * g.a_out_rs + (long)(k + e) * g.a_out_cs] = sa[p][e];
+                }
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            if (B_KC) {                // 8 threads cover the 32 k of one column's row
+                const int n = n0 + p * 32 + (tid >> 3), k = kc + (tid & 7) * 4;
+                const bool ok = n < n_real && k < kend;
+                buf_load4(rb, ok ? ((unsigned)n * (unsigned)g.b_cs + (unsigned)k) * 4u : g.b_bytes, sb[p]);
+            } else {                   // 16 threads cover the 64 n of one k
+                const int k = kc + p * 16 + (tid >> 4), n = n0 + (tid & 15) * 4;
+                const bool ok = k < kend && n < n_real;
+                buf_load4(rb, ok ? ((unsigned)k * (unsigned)g.b_rs + (unsigned)n) * 4u : g.b_bytes, sb[p]);
+            }
+        }
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            float* dst = A_KC ? As + (p * 32 + (tid >> 3)) * LPK + (tid & 7) * 4
+                              : As + (p * 8 + (tid >> 5)) * LPM + (tid & 31) * 4;
+            *reinterpret_cast<float4*>(dst) = make_float4(sa[p][0], sa[p][1], sa[p][2], sa[p][3]);
+        }
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            float* dst = B_KC ? Bs + (p * 32 + (tid >> 3)) * LPK + (tid & 7) * 4
+                              : Bs + (p * 16 + (tid >> 4)) * LPN + (tid & 15) * 4;
+            *reinterpret_cast<float4*>(dst) = make_float4(sb[p][0], sb[p][1], sb[p][2], sb[p][3]);
+        }
+    };
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+    // the bias gradient (the "ones column" of the register-direct kernel) is the row sum of the A
+    // operand: accumulated from the fragments by the first column block, no extra MFMA tile
+    const bool want_rowsum = (EPI == EPI_ATOMIC) && g.ones_col >= 0 && blockIdx.x == 0;
+    float rsum = 0.0f;
+
+    gload(kbeg);
+    for (int kc = kbeg; kc < kend; kc += LBK) {
+        lstore();
+        __syncthreads();
+        if (kc + LBK < kend) gload(kc + LBK);
+#pragma unroll
+        for (int sub = 0; sub < 4; ++sub) {
+            const int ks = sub * 8 + half * 4;          // this half-wave's 4 k of the sub-step
+            float av[4], bv[2][4];
+            if (A_KC) {
+                const float4 q = *reinterpret_cast<const float4*>(As + (wave * 32 + l31) * LPK + ks);
+                av[0] = q.x; av[1] = q.y; av[2] = q.z; av[3] = q.w;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) av[e] = As[(ks + e) * LPM + wave * 32 + l31];
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                if (B_KC) {
+                    const float4 q = *reinterpret_cast<const float4*>(Bs + (t * 32 + l31) * LPK + ks);
+                    bv[t][0] = q.x; bv[t][1] = q.y; bv[t][2] = q.z; bv[t][3] = q.w;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) bv[t][e] = Bs[(ks + e) * LPN + t * 32 + l31];
+                }
+            }
+            if (want_rowsum) rsum += (av[0] + av[1]) + (av[2] + av[3]);
+            if (g.bf16) {
+                const bf16x4 ap = pack_bf16(av[0], av[1], av[2], av[3]);
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+                    acc[t] = mfma_32x32x8_bf16(ap, pack_bf16(bv[t][0], bv[t][1], bv[t][2], bv[t][3]), acc[t]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) acc[t] = mfma_32x32x2(av[e], bv[t][e], acc[t]);
+            }
+        }
+        __syncthreads();
+    }
+
+    // epilogue: every wave owns its 32 x 64 block outright
+    if (want_rowsum) {
+        rsum += __shfl_xor(rsum, 32);
+        const int row = m0 + wave * 32 + l31;
+        if (half == 0 && row < g.M) atomicAdd(g.C2 + row, rsum);
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int col = n0 + t * 32 + l31;
+        if (col >= n_real) continue;
+        float bias = 0.0f;
+        if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) bias = g.bias[col];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = m0 + wave * 32 + acc_row(r, half);
+            if (row >= g.M) continue;
+            float v = acc[t][r] + bias;
+            if (EPI == EPI_BIAS_GELU) { g.Z[(long)row * g.ldz + col] = v; v = gelu_erf(v); }
+            if (EPI == EPI_MUL_GELU_GRAD) v *= gelu_erf_grad(g.G[(long)row * g.ldg + col]);
+            if (EPI == EPI_ATOMIC) atomicAdd(g.C + (long)row * g.ldc + col, v);
+            else g.C[(long)row * g.ldc + col] = v;
+        }
+    }
+}
+
+bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// 0 = not eligible; otherwise launches the LDS-staged kernel (called after prepare_gemm filled the
+// buffer extents).  Eligibility: layouts that allow 16-B coalesced staging, and enough work that
+// the tile pipeline pays (small layers stay on the latency-optimised register-direct kernel).
+bool try_launch_gemm_lds(GemmArgs g, hipStream_t s) {
+    static const int mode = getenv("PIT_LDS_GEMM") ? atoi(getenv("PIT_LDS_GEMM")) : 1;   // 0 off, 1 auto, 2 always when legal
+    if (mode == 0) return false;
+    const int n_real = (g.ones_col >= 0) ? g.N - 1 : g.N;
+    const bool a_kc = g.a_cs == 1 && g.a_rs % 4 == 0 && g.K % 4 == 0;
+    const bool a_ic = g.a_rs == 1 && g.a_cs % 4 == 0 && g.M % 4 == 0;
+    const bool b_kc = g.b_rs == 1 && g.b_cs % 4 == 0 && g.K % 4 == 0;
+    const bool b_ic = g.b_cs == 1 && g.b_rs % 4 == 0 && n_real % 4 == 0;
+    if (!aligned16(g.A) || !aligned16(g.B) || (g.a_gz && !aligned16(g.a_gz))) return false;
+    const long work = (long)g.M * g.N * g.K;
+    if (mode == 1 && (work < (1L << 27) || g.N < 48)) return false;
+    int kind = -1;                                   // which instantiation
+    if (g.epi == EPI_ATOMIC) { if (a_ic && b_ic && !g.a_gz) kind = 4; }
+    else if (a_kc && b_kc && !g.a_gz && (g.epi == EPI_BIAS || g.epi == EPI_BIAS_GELU)) kind = (g.epi == EPI_BIAS) ? 0 : 1;
+    else if (a_kc && b_ic && (g.epi == EPI_MUL_GELU_GRAD || g.epi == EPI_STORE)) kind = (g.epi == EPI_MUL_GELU_GRAD) ? 2 : 3;
+    if (kind < 0) return false;
+    const int gx = (n_real + LBN - 1) / LBN, gy = (g.M + LBM - 1) / LBM;
+    int splits = 1;
+    g.k_slab = ((g.K + LBK - 1) / LBK) * LBK;
+    if (g.epi == EPI_ATOMIC) {                        // K slabs: >= 256 deep, enough workgroups to fill the chip twice
+        splits = std::max(1, std::min(g.K / 256, (512 + gx * gy - 1) / (gx * gy)));
+        int slab = (g.K + splits - 1) / splits;
+        slab = ((slab + LBK - 1) / LBK) * LBK;
+        splits = (g.K + slab - 1) / slab;
+        g.k_slab = slab;
+    }
+    dim3 grid(gx, gy, splits), block(256);
+    switch (kind) {
+        case 0: hipLaunchKernelGGL((gemm_lds_kernel<true, true, EPI_BIAS>), grid, block, 0, s, g); break;
+        case 1: hipLaunchKernelGGL((gemm_lds_kernel<true, true, EPI_BIAS_GELU>), grid, block, 0, s, g); break;
+        case 2: hipLaunchKernelGGL((gemm_lds_kernel<true, false, EPI_MUL_GELU_GRAD>), grid, block, 0, s, g); break;
+        case 3: hipLaunchKernelGGL((gemm_lds_kernel<true, false, EPI_STORE>), grid, block, 0, s, g); break;
+        default: hipLaunchKernelGGL((gemm_lds_kernel<false, false, EPI_ATOMIC>), grid, block, 0, s, g); break;
+    }
+    return true;
+}
+
 int pow2_floor_i(int v) { int p = 1; while (p * 2 <= v) p *= 2; return p; }
 
 bool vec_ok(const float* p, long i_stride, long k_stride) {
@@ -267,9 +474,12 @@ int prepare_gemm(GemmArgs& g, GemmLaunch& L, int force_tn = 0, int force_waves =
     return 0;
 }
 
+bool try_launch_gemm_lds(GemmArgs g, hipStream_t s);
+
 int launch_gemm(GemmArgs g, hipStream_t s) {
     GemmLaunch L;
     if (int rc = prepare_gemm(g, L)) return rc;
+    if (try_launch_gemm_lds(g, s)) return 0;
     const int tn = L.tn;
     dim3 grid = L.grid, block(64 * L.nwaves);
     const size_t sm = (size_t)L.nwaves * tn * 16 * 64 * sizeof(float);
