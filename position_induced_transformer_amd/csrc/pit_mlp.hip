@@ -240,18 +240,24 @@ __global__ __launch_bounds__(512) void gemm_rd_triple_kernel(GemmArgs gx, GemmAr
 // GEMMs split K over blockIdx.z with fp32 atomics as before.
 // An operand is either k-contiguous in memory (KC: LDS [i][k], fragment = one 16-B LDS read) or
 // i-contiguous (IC: LDS [k][i], fragment = 4 conflict-free 4-B reads).
-constexpr int LBM = 128, LBN = 64, LBK = 32;
+// Tile height LBM = 128 (wave = 32 rows x 64 columns) when that still gives >= 2 workgroups per CU,
+// else 64 (wave = 32 rows x 32 columns: twice the workgroups for the mid-sized layers).
+constexpr int LBN = 64, LBK = 32;
 constexpr int LPK = LBK + 4;      // row pitch of the [i][k] layouts (floats): 144 B, 16-B aligned, bank-skewed
-constexpr int LPM = LBM + 4;      // [k][m]
 constexpr int LPN = LBN + 4;      // [k][n]
 
-template <bool A_KC, bool B_KC, int EPI>
+template <int LBM, bool A_KC, bool B_KC, int EPI>
 __global__ __launch_bounds__(256) void gemm_lds_kernel(GemmArgs g) {
+    constexpr int LPM = LBM + 4;      // [k][m]
+    constexpr int TN = LBM / 64;      // accumulator tiles per wave
+    constexpr int PA = LBM / 32;      // staging passes for A (4 floats per thread and pass)
     __shared__ __attribute__((aligned(16))) float As[A_KC ? LBM * LPK : LBK * LPM];
     __shared__ __attribute__((aligned(16))) float Bs[B_KC ? LBN * LPK : LBK * LPN];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, l31 = lane & 31;
     const int m0 = blockIdx.y * LBM, n0 = blockIdx.x * LBN;
+    const int wrow = (LBM == 128) ? wave * 32 : (wave & 1) * 32;    // this wave's rows / first column inside the tile
+    const int wcol = (LBM == 128) ? 0 : (wave >> 1) * 32;
     const int kbeg = blockIdx.z * g.k_slab;
     const int kend = min(g.K, kbeg + g.k_slab);
     const __amdgpu_buffer_rsrc_t ra = make_rsrc(g.A, g.a_bytes);
@@ -259,18 +265,19 @@ __global__ __launch_bounds__(256) void gemm_lds_kernel(GemmArgs g) {
     const __amdgpu_buffer_rsrc_t rb = make_rsrc(g.B, g.b_bytes);
     const int n_real = (EPI == EPI_ATOMIC && g.ones_col >= 0) ? g.N - 1 : g.N;   // columns that exist in memory
 
-    float sa[4][4], sb[2][4];          // staging registers: next chunk in flight during the MFMAs
+    float sa[PA][4], sb[2][4];         // staging registers: next chunk in flight during the MFMAs
     auto gload = [&](int kc) {
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
+        for (int p = 0; p < PA; ++p) {
             unsigned off;
             bool ok;
             if (A_KC) {                // 8 threads cover the 32 k of one row
                 const int row = m0 + p * 32 + (tid >> 3), k = kc + (tid & 7) * 4;
                 ok = row < g.M && k < kend;
                 off = ((unsigned)row * (unsigned)g.a_rs + (unsigned)k) * 4u;
-            } else {                   // 32 threads cover the 128 m of one k
-                const int k = kc + p * 8 + (tid >> 5), m = m0 + (tid & 31) * 4;
+            } else {                   // LBM/4 threads cover the m of one k
+                constexpr int TPR = LBM / 4, KPP = 256 / TPR;
+                const int k = kc + p * KPP + tid / TPR, m = m0 + (tid % TPR) * 4;
                 ok = k < kend && m < g.M;
                 off = ((unsigned)k * (unsigned)g.a_cs + (unsigned)m) * 4u;
             }
@@ -302,9 +309,10 @@ __global__ __launch_bounds__(256) void gemm_lds_kernel(GemmArgs g) {
     };
     auto lstore = [&]() {
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
+        for (int p = 0; p < PA; ++p) {
+            constexpr int TPR = LBM / 4, KPP = 256 / TPR;
             float* dst = A_KC ? As + (p * 32 + (tid >> 3)) * LPK + (tid & 7) * 4
-                              : As + (p * 8 + (tid >> 5)) * LPM + (tid & 31) * 4;
+                              : As + (p * KPP + tid / TPR) * LPM + (tid % TPR) * 4;
             *reinterpret_cast<float4*>(dst) = make_float4(sa[p][0], sa[p][1], sa[p][2], sa[p][3]);
         }
 #pragma unroll
@@ -315,14 +323,14 @@ __global__ __launch_bounds__(256) void gemm_lds_kernel(GemmArgs g) {
         }
     };
 
-    f32x16 acc[2];
+    f32x16 acc[TN];
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < TN; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
     // the bias gradient (the "ones column" of the register-direct kernel) is the row sum of the A
     // operand: accumulated from the fragments by the first column block, no extra MFMA tile
-    const bool want_rowsum = (EPI == EPI_ATOMIC) && g.ones_col >= 0 && blockIdx.x == 0;
+    const bool want_rowsum = (EPI == EPI_ATOMIC) && g.ones_col >= 0 && blockIdx.x == 0 && wcol == 0;
     float rsum = 0.0f;
 
     gload(kbeg);
@@ -333,35 +341,35 @@ __global__ __launch_bounds__(256) void gemm_lds_kernel(GemmArgs g) {
 #pragma unroll
         for (int sub = 0; sub < 4; ++sub) {
             const int ks = sub * 8 + half * 4;          // this half-wave's 4 k of the sub-step
-            float av[4], bv[2][4];
+            float av[4], bv[TN][4];
             if (A_KC) {
-                const float4 q = *reinterpret_cast<const float4*>(As + (wave * 32 + l31) * LPK + ks);
+                const float4 q = *reinterpret_cast<const float4*>(As + (wrow + l31) * LPK + ks);
                 av[0] = q.x; av[1] = q.y; av[2] = q.z; av[3] = q.w;
             } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) av[e] = As[(ks + e) * LPM + wave * 32 + l31];
+                for (int e = 0; e < 4; ++e) av[e] = As[(ks + e) * LPM + wrow + l31];
             }
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
+            for (int t = 0; t < TN; ++t) {
                 if (B_KC) {
-                    const float4 q = *reinterpret_cast<const float4*>(Bs + (t * 32 + l31) * LPK + ks);
+                    const float4 q = *reinterpret_cast<const float4*>(Bs + (wcol + t * 32 + l31) * LPK + ks);
                     bv[t][0] = q.x; bv[t][1] = q.y; bv[t][2] = q.z; bv[t][3] = q.w;
                 } else {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) bv[t][e] = Bs[(ks + e) * LPN + t * 32 + l31];
+                    for (int e = 0; e < 4; ++e) bv[t][e] = Bs[(ks + e) * LPN + wcol + t * 32 + l31];
                 }
             }
             if (want_rowsum) rsum += (av[0] + av[1]) + (av[2] + av[3]);
             if (g.bf16) {
                 const bf16x4 ap = pack_bf16(av[0], av[1], av[2], av[3]);
 #pragma unroll
-                for (int t = 0; t < 2; ++t)
+                for (int t = 0; t < TN; ++t)
                     acc[t] = mfma_32x32x8_bf16(ap, pack_bf16(bv[t][0], bv[t][1], bv[t][2], bv[t][3]), acc[t]);
             } else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
 #pragma unroll
-                    for (int t = 0; t < 2; ++t) acc[t] = mfma_32x32x2(av[e], bv[t][e], acc[t]);
+                    for (int t = 0; t < TN; ++t) acc[t] = mfma_32x32x2(av[e], bv[t][e], acc[t]);
             }
         }
         __syncthreads();
@@ -370,18 +378,18 @@ __global__ __launch_bounds__(256) void gemm_lds_kernel(GemmArgs g) {
     // epilogue: every wave owns its 32 x 64 block outright
     if (want_rowsum) {
         rsum += __shfl_xor(rsum, 32);
-        const int row = m0 + wave * 32 + l31;
+        const int row = m0 + wrow + l31;
         if (half == 0 && row < g.M) atomicAdd(g.C2 + row, rsum);
     }
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        const int col = n0 + t * 32 + l31;
+    for (int t = 0; t < TN; ++t) {
+        const int col = n0 + wcol + t * 32 + l31;
         if (col >= n_real) continue;
         float bias = 0.0f;
         if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) bias = g.bias[col];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int row = m0 + wave * 32 + acc_row(r, half);
+            const int row = m0 + wrow + acc_row(r, half);
             if (row >= g.M) continue;
             float v = acc[t][r] + bias;
             if (EPI == EPI_BIAS_GELU) { g.Z[(long)row * g.ldz + col] = v; v = gelu_erf(v); }
@@ -389,6 +397,25 @@ __global__ __launch_bounds__(256) void gemm_lds_kernel(GemmArgs g) {
             if (EPI == EPI_ATOMIC) atomicAdd(g.C + (long)row * g.ldc + col, v);
             else g.C[(long)row * g.ldc + col] = v;
         }
+    }
+}
+
+// out[m][k] = a[m][k] * gelu'(z[m][k]) (rows a_rs / out_rs apart, K % 4 == 0, 16-B aligned): the
+// trailing-gelu prologue as its own pass when the GEMM behind it is large - inside the GEMM every
+// column block would redo the erf for the whole A tile
+__global__ __launch_bounds__(256) void mul_gelu_grad_kernel(const float* a, long a_rs, const float* z, float* out,
+                                                            long out_rs, int M, int K) {
+    const int kq = K / 4;
+    const long total = (long)M * kq;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long m = i / kq;
+        const int k = (int)(i - m * kq) * 4;
+        const float4 av = *reinterpret_cast<const float4*>(a + m * a_rs + k);
+        const float4 zv = *reinterpret_cast<const float4*>(z + m * a_rs + k);
+        float4 o;
+        o.x = av.x * gelu_erf_grad(zv.x); o.y = av.y * gelu_erf_grad(zv.y);
+        o.z = av.z * gelu_erf_grad(zv.z); o.w = av.w * gelu_erf_grad(zv.w);
+        *reinterpret_cast<float4*>(out + m * out_rs + k) = o;
     }
 }
 
@@ -413,7 +440,19 @@ bool try_launch_gemm_lds(GemmArgs g, hipStream_t s) {
     else if (a_kc && b_kc && !g.a_gz && (g.epi == EPI_BIAS || g.epi == EPI_BIAS_GELU)) kind = (g.epi == EPI_BIAS) ? 0 : 1;
     else if (a_kc && b_ic && (g.epi == EPI_MUL_GELU_GRAD || g.epi == EPI_STORE)) kind = (g.epi == EPI_MUL_GELU_GRAD) ? 2 : 3;
     if (kind < 0) return false;
-    const int gx = (n_real + LBN - 1) / LBN, gy = (g.M + LBM - 1) / LBM;
+    if (g.a_gz) {                                    // trailing-gelu prologue as its own elementwise pass
+        if (!g.a_out || g.a_out_cs != 1 || g.a_out_rs % 4 != 0 || !aligned16(g.a_out)) return false;
+        const long quads = (long)g.M * (g.K / 4);
+        hipLaunchKernelGGL(mul_gelu_grad_kernel, dim3((unsigned)std::min<long>((quads + 255) / 256, 4096)), dim3(256), 0, s,
+                           g.A, g.a_rs, g.a_gz, g.a_out, g.a_out_rs, g.M, g.K);
+        g.A = g.a_out; g.a_rs = g.a_out_rs;
+        g.a_bytes = (unsigned)((((unsigned long long)(g.M - 1) * g.a_rs) + g.K) * 4ull);
+        g.a_gz = nullptr; g.a_out = nullptr;
+    }
+    const int gx = (n_real + LBN - 1) / LBN;
+    // 128-row tiles while they still give two workgroups per CU (or when K slabs add parallelism)
+    const int bm = ((long)gx * ((g.M + 127) / 128) >= 512 || g.epi == EPI_ATOMIC) ? 128 : 64;
+    const int gy = (g.M + bm - 1) / bm;
     int splits = 1;
     g.k_slab = ((g.K + LBK - 1) / LBK) * LBK;
     if (g.epi == EPI_ATOMIC) {                        // K slabs: >= 256 deep, enough workgroups to fill the chip twice
@@ -424,13 +463,19 @@ bool try_launch_gemm_lds(GemmArgs g, hipStream_t s) {
         g.k_slab = slab;
     }
     dim3 grid(gx, gy, splits), block(256);
+#define PIT_LDS(A_, B_, EPI_)                                                                              \
+    do {                                                                                                   \
+        if (bm == 128) hipLaunchKernelGGL((gemm_lds_kernel<128, A_, B_, EPI_>), grid, block, 0, s, g);     \
+        else hipLaunchKernelGGL((gemm_lds_kernel<64, A_, B_, EPI_>), grid, block, 0, s, g);                \
+    } while (0)
     switch (kind) {
-        case 0: hipLaunchKernelGGL((gemm_lds_kernel<true, true, EPI_BIAS>), grid, block, 0, s, g); break;
-        case 1: hipLaunchKernelGGL((gemm_lds_kernel<true, true, EPI_BIAS_GELU>), grid, block, 0, s, g); break;
-        case 2: hipLaunchKernelGGL((gemm_lds_kernel<true, false, EPI_MUL_GELU_GRAD>), grid, block, 0, s, g); break;
-        case 3: hipLaunchKernelGGL((gemm_lds_kernel<true, false, EPI_STORE>), grid, block, 0, s, g); break;
-        default: hipLaunchKernelGGL((gemm_lds_kernel<false, false, EPI_ATOMIC>), grid, block, 0, s, g); break;
+        case 0: PIT_LDS(true, true, EPI_BIAS); break;
+        case 1: PIT_LDS(true, true, EPI_BIAS_GELU); break;
+        case 2: PIT_LDS(true, false, EPI_MUL_GELU_GRAD); break;
+        case 3: PIT_LDS(true, false, EPI_STORE); break;
+        default: hipLaunchKernelGGL((gemm_lds_kernel<128, false, false, EPI_ATOMIC>), grid, block, 0, s, g); break;
     }
+#undef PIT_LDS
     return true;
 }
 
