@@ -41,7 +41,21 @@ struct AttArgs {
     int ncols, colgroups, tiles_per_wg;
     int bf16;                             // PIT_MATH_BF16 for the forward and d(values) contractions
     unsigned values_bytes, dout_bytes;    // extents for the raw-buffer descriptors
+    unsigned dim_magic;                   // floor(2^32 / dim): column -> (sample, channel) without an integer division
 };
+
+// Folded column index -> (sample, channel).  For batch-free meshes the batch is folded into the
+// column axis (col = sample*dim + channel); a runtime integer division costs ~35 VALU
+// instructions on CDNA, this is a multiply-high plus one correction (exact for col < 2^31).
+__device__ __forceinline__ void col_split(const AttArgs& a, int col, int mb, int& sample, int& chan) {
+    if (a.mesh_batch != 1) { sample = mb; chan = col; return; }
+    unsigned q = __umulhi((unsigned)col, a.dim_magic);
+    unsigned r = (unsigned)col - q * (unsigned)a.dim;
+    if (r >= (unsigned)a.dim) { ++q; r -= (unsigned)a.dim; }
+    sample = (int)q; chan = (int)r;
+}
+// ceil(len / d) for a power-of-two d
+__device__ __forceinline__ int ceil_div_pow2(int len, int d) { return (len + d - 1) >> (31 - __clz(d)); }
 
 // d(scale): every wave adds its fp64 partial to one of `nslots` accumulators per head (spreading
 // the atomics over addresses); a small finishing kernel (one workgroup per head) drains them with
@@ -173,8 +187,7 @@ __device__ __forceinline__ void posatt_rows_body(const AttArgs& a, const int bx,
         const int col = (cg * CT + t) * 32 + l31;
         cvalid[t] = col < a.ncols;
         const int cc = cvalid[t] ? col : 0;
-        cb[t] = (a.mesh_batch == 1) ? cc / a.dim : mb;
-        cd[t] = (a.mesh_batch == 1) ? cc % a.dim : cc;
+        col_split(a, cc, mb, cb[t], cd[t]);
         uoff[t] = (unsigned)(((long)cb[t] * a.values_bstride + cd[t]) * 4);
     }
 
@@ -230,7 +243,7 @@ __device__ __forceinline__ void posatt_rows_body(const AttArgs& a, const int bx,
     for (int jc0 = 0; jc0 < a.n_in; jc0 += KEY_CHUNK) {
         const int len = min(KEY_CHUNK, a.n_in - jc0);
         // this wave's slice of the chunk (multiple of 2*NP keys)
-        const int per_wave = ((len + nwaves * 2 * NP - 1) / (nwaves * 2 * NP)) * 2 * NP;
+        const int per_wave = ceil_div_pow2(len, nwaves * 2 * NP) * 2 * NP;
         const int jb = wave * per_wave;
         const int je = min(len, jb + per_wave);
         if (jb < je) prefetch(jc0, jb, jb, je);          // in flight during staging / barrier
@@ -336,8 +349,8 @@ __device__ __forceinline__ void posatt_rows_body(const AttArgs& a, const int bx,
         const int col = (cg * CT + t) * 32 + l31;
         const bool cv = col < a.ncols;
         const int cc = cv ? col : 0;
-        const int bb = (a.mesh_batch == 1) ? cc / a.dim : mb;
-        const int dd = (a.mesh_batch == 1) ? cc % a.dim : cc;
+        int bb, dd;
+        col_split(a, cc, mb, bb, dd);
         const bool ok = cv && nr < a.n_out;
         if (ok) a.out[(long)bb * a.out_bstride + (long)nr * a.ld_out + a.out_col0 + (long)h * a.dim + dd] = v;
         if (a.copy_inputs && h == 0) {                 // torch.cat((inputs, conv), -1) of pit.py:44
@@ -390,8 +403,7 @@ __device__ __forceinline__ void posatt_cols_body(const AttArgs& a, const int bx,
         const int col = (cg * CT + t) * 32 + l31;
         cvalid[t] = col < a.ncols;
         const int cc = cvalid[t] ? col : 0;
-        cb[t] = (a.mesh_batch == 1) ? cc / a.dim : mb;
-        cd[t] = (a.mesh_batch == 1) ? cc % a.dim : cc;
+        col_split(a, cc, mb, cb[t], cd[t]);
         doff[t] = (unsigned)(((long)cb[t] * a.dout_bstride + a.out_col0 + cd[t]) * 4);
     }
     f32x16 acc[CT];
@@ -425,7 +437,7 @@ __device__ __forceinline__ void posatt_cols_body(const AttArgs& a, const int bx,
         const long hoff = (long)h * a.dim;
         for (int nc0 = 0; nc0 < a.n_out; nc0 += ROW_CHUNK) {
             const int len = min(ROW_CHUNK, a.n_out - nc0);
-            const int per_wave = ((len + nwaves * 2 * NP - 1) / (nwaves * 2 * NP)) * 2 * NP;
+            const int per_wave = ceil_div_pow2(len, nwaves * 2 * NP) * 2 * NP;
             const int nb = wave * per_wave;
             const int ne = min(len, nb + per_wave);
             if (nb < ne) prefetch(hoff, nc0, nb, nb, ne);
@@ -498,8 +510,8 @@ __device__ __forceinline__ void posatt_cols_body(const AttArgs& a, const int bx,
         const int col = (cg * CT + t) * 32 + l31;
         const bool cv = col < a.ncols;
         const int cc = cv ? col : 0;
-        const int bb = (a.mesh_batch == 1) ? cc / a.dim : mb;
-        const int dd = (a.mesh_batch == 1) ? cc % a.dim : cc;
+        int bb, dd;
+        col_split(a, cc, mb, bb, dd);
         const bool ok = cv && jr < a.n_in;
         float v = summed<CT, 0>(red, nwaves, q, lane);
         // residual (self attention): d_out columns [0,dim) of the same row
@@ -601,8 +613,7 @@ __global__ __launch_bounds__(512) void posatt_rows_tiles(AttArgs a) {
         const int col = tile * 32 + l31;
         cvalid[t] = tile < tile_end && col < a.ncols;
         const int cc = cvalid[t] ? col : 0;
-        cb[t] = (a.mesh_batch == 1) ? cc / a.dim : mb;
-        cd[t] = (a.mesh_batch == 1) ? cc % a.dim : cc;
+        col_split(a, cc, mb, cb[t], cd[t]);
         uoff[t] = (unsigned)(((long)cb[t] * a.values_bstride + cd[t]) * 4);
     }
     f32x16 acc[RT][TPW];
@@ -805,8 +816,7 @@ __global__ __launch_bounds__(512) void posatt_cols_tiles(AttArgs a) {
         const int col = tile * 32 + l31;
         cvalid[t] = tile < tile_end && col < a.ncols;
         const int cc = cvalid[t] ? col : 0;
-        cb[t] = (a.mesh_batch == 1) ? cc / a.dim : mb;
-        cd[t] = (a.mesh_batch == 1) ? cc % a.dim : cc;
+        col_split(a, cc, mb, cb[t], cd[t]);
         doff[t] = (unsigned)(((long)cb[t] * a.dout_bstride + a.out_col0 + cd[t]) * 4);
     }
     f32x16 acc[TPW];
@@ -1189,8 +1199,7 @@ __device__ __forceinline__ void sparse_rows_body(const AttArgs& a, const SparseA
         const int col = cblk * 64 * CR + r * 64 + lane;
         cvalid[r] = col < a.ncols;
         const int cc = cvalid[r] ? col : 0;
-        cb[r] = (a.mesh_batch == 1) ? cc / a.dim : mb;
-        cd[r] = (a.mesh_batch == 1) ? cc % a.dim : cc;
+        col_split(a, cc, mb, cb[r], cd[r]);
         uoff[r] = (unsigned)(((long)cb[r] * a.values_bstride + cd[r]) * 4);
     }
     float acc[NH][CR];
@@ -1326,8 +1335,7 @@ __device__ __forceinline__ void sparse_cols_body(const AttArgs& a, const SparseA
         const int col = cblk * 64 * CR + r * 64 + lane;
         cvalid[r] = col < a.ncols;
         const int cc = cvalid[r] ? col : 0;
-        cb[r] = (a.mesh_batch == 1) ? cc / a.dim : mb;
-        cd[r] = (a.mesh_batch == 1) ? cc % a.dim : cc;
+        col_split(a, cc, mb, cb[r], cd[r]);
         doff[r] = (unsigned)(((long)cb[r] * a.dout_bstride + a.out_col0 + cd[r]) * 4);
     }
     float acc[CR];
@@ -1423,8 +1431,8 @@ __device__ __forceinline__ void sparse_overflow_body(const AttArgs& a, const Spa
                 const int jj = __builtin_amdgcn_readlane(j, src);
                 const float pv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p), src));
                 for (int col = lane; col < a.ncols; col += 64) {
-                    const int bb = (a.mesh_batch == 1) ? col / a.dim : mb;
-                    const int dd = (a.mesh_batch == 1) ? col % a.dim : col;
+                    int bb, dd;
+                    col_split(a, col, mb, bb, dd);
                     const float g = a.d_out[(long)bb * a.dout_bstride + (long)n * a.ld_dout + a.out_col0 + (long)h * a.dim + dd];
                     atomicAdd(a.d_values + (long)bb * a.dvalues_bstride + (long)jj * a.ld_dvalues + dd, pv * g);
                 }
@@ -1534,6 +1542,7 @@ int fill_common(AttArgs& a, const float* mesh_out, const float* mesh_in, int mes
     if (vb > PIT_MAX_BUFFER_BYTES) return PIT_ERR_UNSUPPORTED;
     a.values_bytes = (unsigned)vb;
     a.bf16 = (pit_math_mode_value == PIT_MATH_BF16);
+    a.dim_magic = (dim == 1) ? 0xFFFFFFFFu : (unsigned)(0x100000000ull / (unsigned long long)dim);
     return 0;
 }
 
