@@ -54,6 +54,18 @@ __device__ __forceinline__ float sq_dist3(float ox, float oy, float oz, float ix
     return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
 }
 
+// the same with the wrap as a compile-time variant (hot loops pick it once per launch)
+template <bool PERIODIC>
+__device__ __forceinline__ float sq_dist3t(float ox, float oy, float oz, float ix, float iy, float iz, float period) {
+    float dx = __fsub_rn(ox, ix), dy = __fsub_rn(oy, iy), dz = __fsub_rn(oz, iz);
+    if (PERIODIC) {
+        dx = fabsf(dx); dx = fminf(dx, __fsub_rn(period, dx));
+        dy = fabsf(dy); dy = fminf(dy, __fsub_rn(period, dy));
+        dz = fabsf(dz); dz = fminf(dz, __fsub_rn(period, dz));
+    }
+    return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+}
+
 // ATen's lerp as torch.quantile applies it.
 __device__ __forceinline__ float quantile_lerp(float a, float b, float w) {
     float diff = __fsub_rn(b, a);

@@ -22,6 +22,7 @@
 // mbar_n = sum_j P m is saved by the forward), accumulated in fp64.
 #include "pit_common.h"
 #include <cstdlib>
+#include <type_traits>
 
 namespace {
 
@@ -136,7 +137,7 @@ __device__ __forceinline__ float summed(const float* red, int nwaves, int q, int
 // ------------------------------------------------------------------------------------
 // rows kernel
 // ------------------------------------------------------------------------------------
-template <int CT, int MODE, bool MASKED, bool BF>
+template <int CT, int MODE, bool MASKED, bool BF, int NPX = 0>
 __device__ __forceinline__ void posatt_rows_body(const AttArgs& a, const int bx, const int by, const int bz) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float4* s_xi = reinterpret_cast<float4*>(smem);
@@ -222,84 +223,136 @@ __device__ __forceinline__ void posatt_rows_body(const AttArgs& a, const int bx,
     };
     if (DOV_EARLY) load_dov();
 
-    // Value rows for the NEXT step are always in flight while the current step computes its
-    // weights and MFMAs (the loads do not depend on the weights); a masked step whose 8 keys
-    // are all dropped only skips its MFMAs.  NP key pairs per step.
-    constexpr int NP = (CT == 4) ? 4 : 8;
-    float bnext[NP][CT];
-    auto prefetch = [&](int jc0, int jstart, int jb, int je) {
-        (void)jb;
+    // Main loop.  A step covers 2*NP keys (NP per half-wave); the value rows of the NEXT step are in
+    // flight while the current step forms its weights and issues its MFMAs (ping-pong register
+    // buffers, two steps per trip).  The loop is issue-bound at PiT sizes (the weights cost ~15 VALU
+    // instructions per element against one 64-cycle MFMA per CT elements), so everything that is
+    // loop-invariant or wave-uniform is kept off the vector ALU:
+    //   * value-row loads: per-lane offset = column + this half-wave's key (fixed), the row enters as
+    //     the instruction's SCALAR offset - no per-load address arithmetic;
+    //   * steps that are entirely inside the wave's key slice ("full": all but possibly the last)
+    //     carry no range checks; only the tail step uses the checked variant;
+    //   * the periodic wrap is a compile-time variant of the step, chosen once per launch;
+    //   * rows beyond n_out evaluate the clamped duplicate of the last row (results never stored).
+    constexpr int NP = NPX ? NPX : ((CT == 4) ? 4 : 8);
+    constexpr int HS = BF ? 4 : 1;                       // key distance between the half-waves in a group of 8
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int hk = half * HS;
+    const bool fast_ok = a.values_bytes < 0x80000000u;   // scalar + vector offset cannot wrap
+    unsigned voff[CT];
 #pragma unroll
-        for (int u = 0; u < NP; ++u) {
-            const int jl = jstart + 8 * (u / 4) + kpos[u % 4];
-            const bool jv = jl < je;
-            const unsigned rowoff = (unsigned)(jc0 + jl) * ld4;
+    for (int t = 0; t < CT; ++t) voff[t] = cvalid[t] ? uoff[t] + (unsigned)hk * ld4 : a.values_bytes;
+
+    auto run = [&](auto per_tag) {
+        constexpr bool PER = decltype(per_tag)::value;
+        for (int jc0 = 0; jc0 < a.n_in; jc0 += KEY_CHUNK) {
+            const int len = min(KEY_CHUNK, a.n_in - jc0);
+            // this wave's slice of the chunk (multiple of 2*NP keys)
+            const int per_wave = ceil_div_pow2(len, nwaves * 2 * NP) * 2 * NP;
+            const int jb = wave_u * per_wave;
+            const int je = min(len, jb + per_wave);
+            const int nkeys = max(je - jb, 0);
+            const int nfull = nkeys / (2 * NP);                       // steps without any range check
+            const int nsteps = (nkeys + 2 * NP - 1) / (2 * NP);
+
+            auto load_step = [&](float (&dst)[NP][CT], int st) {
+                const int jj = jb + st * 2 * NP;
+                if (st < nfull && fast_ok) {
 #pragma unroll
-            for (int t = 0; t < CT; ++t)     // out-of-range offset -> hardware returns 0, no branch
-                bnext[u][t] = buf_load(rvals, (jv && cvalid[t]) ? uoff[t] + rowoff : a.values_bytes);
+                    for (int u = 0; u < NP; ++u) {
+                        constexpr int dummy = 0; (void)dummy;
+                        const int koff = 8 * (u / 4) + (BF ? (u % 4) : 2 * (u % 4));
+                        const int soff = (jc0 + jj + koff) * (int)ld4;  // wave-uniform: scalar offset operand
+#pragma unroll
+                        for (int t = 0; t < CT; ++t)
+                            dst[u][t] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rvals, (int)voff[t], soff, 0));
+                    }
+                } else if (st < nsteps) {
+#pragma unroll
+                    for (int u = 0; u < NP; ++u) {
+                        const int jl = jj + 8 * (u / 4) + kpos[u % 4];
+                        const bool jv = jl < je;
+                        const unsigned rowoff = (unsigned)(jc0 + jl) * ld4;
+#pragma unroll
+                        for (int t = 0; t < CT; ++t)     // out-of-range offset -> hardware returns 0, no branch
+                            dst[u][t] = buf_load(rvals, (jv && cvalid[t]) ? uoff[t] + rowoff : a.values_bytes);
+                    }
+                }
+            };
+            auto compute = [&](const float (&src)[NP][CT], int jj, auto full_tag) {
+                constexpr bool FULL = decltype(full_tag)::value;
+                const float4* xk = s_xi + hk;                          // this half-wave's keys: s_xi[jj + koff + hk]
+                float pw[NP];
+                bool anyk[NP / 4];
+#pragma unroll
+                for (int q = 0; q < NP / 4; ++q) anyk[q] = false;
+#pragma unroll
+                for (int u = 0; u < NP; ++u) {
+                    const int koff = 8 * (u / 4) + (BF ? (u % 4) : 2 * (u % 4));
+                    bool jv = true;
+                    float4 xi;
+                    if (FULL) {
+                        xi = xk[jj + koff];
+                    } else {
+                        const int jl = jj + koff + hk;
+                        jv = jl < je;
+                        xi = s_xi[jv ? jl : jb];
+                    }
+                    const float m = sq_dist3t<PER>(xo.x, xo.y, xo.z, xi.x, xi.y, xi.z, a.period);
+                    const float sv = __fmul_rn(m, c);
+                    bool keep = jv;
+                    if (MASKED) keep = keep && (sv <= T);
+                    float p = __expf(s_min - sv);
+                    if (MASKED || !FULL) p = keep ? p : 0.0f;
+                    if (MODE == 0) {
+                        rsum += p;
+                        qsum += p * m;
+                        pw[u] = p;
+                    } else {
+                        pw[u] = p * (m - mbar) * inv_l;
+                    }
+                    if (MASKED) anyk[u / 4] |= keep;
+                }
+#pragma unroll
+                for (int q = 0; q < NP / 4; ++q) {
+                    if (MASKED && __builtin_amdgcn_ballot_w64(anyk[q]) == 0ull) continue;   // wave-uniform skip
+                    if (bf) {
+                        const bf16x4 ap = pack_bf16(pw[4 * q], pw[4 * q + 1], pw[4 * q + 2], pw[4 * q + 3]);
+#pragma unroll
+                        for (int t = 0; t < CT; ++t)
+                            acc[t] = mfma_32x32x8_bf16(ap, pack_bf16(src[4 * q][t], src[4 * q + 1][t], src[4 * q + 2][t], src[4 * q + 3][t]), acc[t]);
+                        continue;
+                    }
+#pragma unroll
+                    for (int u = 4 * q; u < 4 * q + 4; ++u)
+#pragma unroll
+                        for (int t = 0; t < CT; ++t) acc[t] = mfma_32x32x2(pw[u], src[u][t], acc[t]);
+                }
+            };
+            auto compute_step = [&](const float (&src)[NP][CT], int st) {
+                const int jj = jb + st * 2 * NP;
+                if (st < nfull) compute(src, jj, std::true_type{});
+                else compute(src, jj, std::false_type{});
+            };
+
+            float b0[NP][CT], b1[NP][CT];
+            load_step(b0, 0);                                  // in flight during staging / barrier
+            __syncthreads();
+#pragma unroll 4
+            for (int idx = threadIdx.x; idx < len; idx += blockDim.x)
+                s_xi[idx] = load_point4(rmi, mi_bytes, (long)mb * a.n_in + jc0 + idx, a.sdim, a.coords_used);
+            __syncthreads();
+            int st = 0;
+            for (; st + 1 < nsteps; st += 2) {
+                load_step(b1, st + 1);
+                compute_step(b0, st);
+                load_step(b0, st + 2);
+                compute_step(b1, st + 1);
+            }
+            if (st < nsteps) compute_step(b0, st);
         }
     };
-
-    for (int jc0 = 0; jc0 < a.n_in; jc0 += KEY_CHUNK) {
-        const int len = min(KEY_CHUNK, a.n_in - jc0);
-        // this wave's slice of the chunk (multiple of 2*NP keys)
-        const int per_wave = ceil_div_pow2(len, nwaves * 2 * NP) * 2 * NP;
-        const int jb = wave * per_wave;
-        const int je = min(len, jb + per_wave);
-        if (jb < je) prefetch(jc0, jb, jb, je);          // in flight during staging / barrier
-        __syncthreads();
-#pragma unroll 4
-        for (int idx = threadIdx.x; idx < len; idx += blockDim.x)
-            s_xi[idx] = load_point4(rmi, mi_bytes, (long)mb * a.n_in + jc0 + idx, a.sdim, a.coords_used);
-        __syncthreads();
-        if (jb >= je) continue;
-
-        for (int jj = jb; jj < je; jj += 2 * NP) {
-            float bcur[NP][CT];
-#pragma unroll
-            for (int u = 0; u < NP; ++u)
-#pragma unroll
-                for (int t = 0; t < CT; ++t) bcur[u][t] = bnext[u][t];
-            prefetch(jc0, jj + 2 * NP, jb, je);            // clamped, unconditional
-            float pw[NP];
-            bool anyk[NP / 4];
-#pragma unroll
-            for (int q = 0; q < NP / 4; ++q) anyk[q] = false;
-#pragma unroll
-            for (int u = 0; u < NP; ++u) {
-                const int jl = jj + 8 * (u / 4) + kpos[u % 4];
-                const bool jv = jl < je;
-                const float4 xi = s_xi[jv ? jl : jb];
-                const float m = sq_dist3(xo.x, xo.y, xo.z, xi.x, xi.y, xi.z, per, a.period);
-                const float sv = __fmul_rn(m, c);
-                const bool keep = jv && nvalid && (sv <= T);
-                const float p = keep ? __expf(s_min - sv) : 0.0f;
-                if (MODE == 0) {
-                    rsum += p;
-                    qsum += p * m;
-                    pw[u] = p;
-                } else {
-                    pw[u] = p * (m - mbar) * inv_l;
-                }
-                anyk[u / 4] |= keep;
-            }
-#pragma unroll
-            for (int q = 0; q < NP / 4; ++q) {
-                if (MASKED && __builtin_amdgcn_ballot_w64(anyk[q]) == 0ull) continue;   // wave-uniform skip
-                if (bf) {
-                    const bf16x4 ap = pack_bf16(pw[4 * q], pw[4 * q + 1], pw[4 * q + 2], pw[4 * q + 3]);
-#pragma unroll
-                    for (int t = 0; t < CT; ++t)
-                        acc[t] = mfma_32x32x8_bf16(ap, pack_bf16(bcur[4 * q][t], bcur[4 * q + 1][t], bcur[4 * q + 2][t], bcur[4 * q + 3][t]), acc[t]);
-                    continue;
-                }
-#pragma unroll
-                for (int u = 4 * q; u < 4 * q + 4; ++u)
-#pragma unroll
-                    for (int t = 0; t < CT; ++t) acc[t] = mfma_32x32x2(pw[u], bcur[u][t], acc[t]);
-            }
-        }
-    }
+    if (per) run(std::true_type{}); else run(std::false_type{});
 
     if (MODE == 1) {
         // dc_h -= sum acc[n,col] * dO[n,col]   (fp64 accumulation)
@@ -541,7 +594,7 @@ __global__ __launch_bounds__(512, 4) void posatt_bwd_pair_kernel(AttArgs ar, Att
         posatt_cols_body<1, MASKED, BF, 4>(ac, id % cgx, (id / cgx) % cgy, id / (cgx * cgy));
     } else {
         id -= n_cols_wgs;
-        posatt_rows_body<1, 1, MASKED, false>(ar, id % rgx, (id / rgx) % rgy, id / (rgx * rgy));
+        posatt_rows_body<1, 1, MASKED, false, 4>(ar, id % rgx, (id / rgx) % rgy, id / (rgx * rgy));
     }
 }
 
