@@ -430,7 +430,8 @@ __global__ __launch_bounds__(512) void posatt_rows_kernel(AttArgs a) {
 template <int CT, bool MASKED, bool BF, int NPX = 0>
 __device__ __forceinline__ void posatt_cols_body(const AttArgs& a, const int bx, const int by, const int bz) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float4* s_rec = reinterpret_cast<float4*>(smem);     // [ROW_CHUNK][2]: {xo.xyz, T}, {S_min, 1/L, -, -}
+    float4* s_rec = reinterpret_cast<float4*>(smem);                   // [ROW_CHUNK] {xo.xyz, T}
+    float2* s_nrm = reinterpret_cast<float2*>(smem + ROW_CHUNK * sizeof(float4));   // [ROW_CHUNK] {S_min, 1/L}
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
     const int half = lane >> 5, l31 = lane & 31;
@@ -470,84 +471,136 @@ __device__ __forceinline__ void posatt_cols_body(const AttArgs& a, const int bx,
 #pragma unroll
     for (int u = 0; u < 4; ++u) kpos[u] = group_pos(bf, u, half);
 
-    constexpr int NP = NPX ? NPX : ((CT == 4) ? 4 : 8);      // key pairs per step (NPX: override for the merged launch)
-    float bnext[NP][CT];
-    auto prefetch = [&](long hoff, int nc0, int nstart, int nb, int ne) {
-        (void)nb;
+    // Main loop: same organisation as the rows kernel (scalar-offset d_out loads, unchecked full
+    // steps + checked tail, compile-time periodic variant, ping-pong prefetch); the reduced axis is
+    // (head, row), the per-row constants {xo, T} / {S_min, 1/L} come from LDS.
+    constexpr int NP = NPX ? NPX : ((CT == 4) ? 4 : 8);      // row pairs per step (NPX: override for the merged launch)
+    constexpr int HS = BF ? 4 : 1;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int hk = half * HS;
+    const bool fast_ok = a.dout_bytes < 0x80000000u;
+    unsigned voff[CT];
 #pragma unroll
-        for (int u = 0; u < NP; ++u) {
-            const int nl = nstart + 8 * (u / 4) + kpos[u % 4];
-            const bool nv = nl < ne;
-            const unsigned rowoff = (unsigned)(nc0 + nl) * ldd4 + (unsigned)hoff * 4u;
-#pragma unroll
-            for (int t = 0; t < CT; ++t)
-                bnext[u][t] = buf_load(rdout, (nv && cvalid[t]) ? doff[t] + rowoff : a.dout_bytes);
-        }
-    };
+    for (int t = 0; t < CT; ++t) voff[t] = cvalid[t] ? doff[t] + (unsigned)hk * ldd4 : a.dout_bytes;
 
-    for (int h = 0; h < a.n_head; ++h) {
-        const float c = a.head_is_scale ? a.head[h] : head_scale_from_lmda(a.head[h]);
-        const long hoff = (long)h * a.dim;
-        for (int nc0 = 0; nc0 < a.n_out; nc0 += ROW_CHUNK) {
-            const int len = min(ROW_CHUNK, a.n_out - nc0);
-            const int per_wave = ceil_div_pow2(len, nwaves * 2 * NP) * 2 * NP;
-            const int nb = wave * per_wave;
-            const int ne = min(len, nb + per_wave);
-            if (nb < ne) prefetch(hoff, nc0, nb, nb, ne);
-            __syncthreads();
-#pragma unroll 2
-            for (int idx = threadIdx.x; idx < len; idx += blockDim.x) {
-                const long rowid = (long)mb * a.n_out + nc0 + idx;
-                const float4 xo = load_point4(rmo, mo_bytes, rowid, a.sdim, a.coords_used);
-                const float4 rs4 = *reinterpret_cast<const float4*>(
-                    a.rowstat + (((long)mb * a.n_head + h) * a.n_out + nc0 + idx) * 4);
-                float4 r0; r0.x = xo.x; r0.y = xo.y; r0.z = xo.z; r0.w = rs4.x;
-                float4 r1; r1.x = rs4.y; r1.y = rs4.z; r1.z = 0.0f; r1.w = 0.0f;
-                s_rec[2 * idx] = r0;
-                s_rec[2 * idx + 1] = r1;
-            }
-            __syncthreads();
-            for (int nn = nb; nn < ne; nn += 2 * NP) {
-                float bcur[NP][CT];
+    auto run = [&](auto per_tag) {
+        constexpr bool PER = decltype(per_tag)::value;
+        for (int h = 0; h < a.n_head; ++h) {
+            const float c = a.head_is_scale ? a.head[h] : head_scale_from_lmda(a.head[h]);
+            const unsigned hoff4 = (unsigned)h * (unsigned)a.dim * 4u;
+            for (int nc0 = 0; nc0 < a.n_out; nc0 += ROW_CHUNK) {
+                const int len = min(ROW_CHUNK, a.n_out - nc0);
+                const int per_wave = ceil_div_pow2(len, nwaves * 2 * NP) * 2 * NP;
+                const int nb = wave_u * per_wave;
+                const int ne = min(len, nb + per_wave);
+                const int nrows = max(ne - nb, 0);
+                const int nfull = nrows / (2 * NP);
+                const int nsteps = (nrows + 2 * NP - 1) / (2 * NP);
+
+                auto load_step = [&](float (&dst)[NP][CT], int st) {
+                    const int nn = nb + st * 2 * NP;
+                    if (st < nfull && fast_ok) {
 #pragma unroll
-                for (int u = 0; u < NP; ++u)
+                        for (int u = 0; u < NP; ++u) {
+                            const int koff = 8 * (u / 4) + (BF ? (u % 4) : 2 * (u % 4));
+                            const int soff = (nc0 + nn + koff) * (int)ldd4 + (int)hoff4;   // wave-uniform
 #pragma unroll
-                    for (int t = 0; t < CT; ++t) bcur[u][t] = bnext[u][t];
-                prefetch(hoff, nc0, nn + 2 * NP, nb, ne);
-                float pw[NP];
-                bool anyk[NP / 4];
+                            for (int t = 0; t < CT; ++t)
+                                dst[u][t] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rdout, (int)voff[t], soff, 0));
+                        }
+                    } else if (st < nsteps) {
 #pragma unroll
-                for (int q = 0; q < NP / 4; ++q) anyk[q] = false;
+                        for (int u = 0; u < NP; ++u) {
+                            const int nl = nn + 8 * (u / 4) + kpos[u % 4];
+                            const bool nv = nl < ne;
+                            const unsigned rowoff = (unsigned)(nc0 + nl) * ldd4 + hoff4;
 #pragma unroll
-                for (int u = 0; u < NP; ++u) {
-                    const int nl = nn + 8 * (u / 4) + kpos[u % 4];
-                    const bool nv = nl < ne;
-                    const float4 r0 = s_rec[2 * (nv ? nl : nb)];
-                    const float4 r1 = s_rec[2 * (nv ? nl : nb) + 1];
-                    const float m = sq_dist3(r0.x, r0.y, r0.z, xi.x, xi.y, xi.z, per, a.period);
-                    const float sv = __fmul_rn(m, c);
-                    const bool keep = nv && jvalid && (sv <= r0.w);
-                    pw[u] = keep ? __expf(r1.x - sv) * r1.y : 0.0f;
-                    anyk[u / 4] |= keep;
-                }
+                            for (int t = 0; t < CT; ++t)
+                                dst[u][t] = buf_load(rdout, (nv && cvalid[t]) ? doff[t] + rowoff : a.dout_bytes);
+                        }
+                    }
+                };
+                auto compute = [&](const float (&src)[NP][CT], int nn, auto full_tag) {
+                    constexpr bool FULL = decltype(full_tag)::value;
+                    const float4* rk = s_rec + hk;
+                    const float2* nk = s_nrm + hk;
+                    float pw[NP];
+                    bool anyk[NP / 4];
 #pragma unroll
-                for (int q = 0; q < NP / 4; ++q) {
-                    if (MASKED && __builtin_amdgcn_ballot_w64(anyk[q]) == 0ull) continue;
-                    if (bf) {
-                        const bf16x4 ap = pack_bf16(pw[4 * q], pw[4 * q + 1], pw[4 * q + 2], pw[4 * q + 3]);
+                    for (int q = 0; q < NP / 4; ++q) anyk[q] = false;
 #pragma unroll
-                        for (int t = 0; t < CT; ++t)
-                            acc[t] = mfma_32x32x8_bf16(ap, pack_bf16(bcur[4 * q][t], bcur[4 * q + 1][t], bcur[4 * q + 2][t], bcur[4 * q + 3][t]), acc[t]);
-                        continue;
+                    for (int u = 0; u < NP; ++u) {
+                        const int koff = 8 * (u / 4) + (BF ? (u % 4) : 2 * (u % 4));
+                        bool nv = true;
+                        float4 r0;
+                        float2 r1;
+                        if (FULL) {
+                            r0 = rk[nn + koff];
+                            r1 = nk[nn + koff];
+                        } else {
+                            const int nl = nn + koff + hk;
+                            nv = nl < ne;
+                            r0 = s_rec[nv ? nl : nb];
+                            r1 = s_nrm[nv ? nl : nb];
+                        }
+                        const float m = sq_dist3t<PER>(r0.x, r0.y, r0.z, xi.x, xi.y, xi.z, a.period);
+                        const float sv = __fmul_rn(m, c);
+                        bool keep = nv;
+                        if (MASKED) keep = keep && (sv <= r0.w);
+                        float p = __expf(r1.x - sv) * r1.y;
+                        if (MASKED || !FULL) p = keep ? p : 0.0f;
+                        pw[u] = p;
+                        if (MASKED) anyk[u / 4] |= keep;
                     }
 #pragma unroll
-                    for (int u = 4 * q; u < 4 * q + 4; ++u)
+                    for (int q = 0; q < NP / 4; ++q) {
+                        if (MASKED && __builtin_amdgcn_ballot_w64(anyk[q]) == 0ull) continue;
+                        if (bf) {
+                            const bf16x4 ap = pack_bf16(pw[4 * q], pw[4 * q + 1], pw[4 * q + 2], pw[4 * q + 3]);
 #pragma unroll
-                        for (int t = 0; t < CT; ++t) acc[t] = mfma_32x32x2(pw[u], bcur[u][t], acc[t]);
+                            for (int t = 0; t < CT; ++t)
+                                acc[t] = mfma_32x32x8_bf16(ap, pack_bf16(src[4 * q][t], src[4 * q + 1][t], src[4 * q + 2][t], src[4 * q + 3][t]), acc[t]);
+                            continue;
+                        }
+#pragma unroll
+                        for (int u = 4 * q; u < 4 * q + 4; ++u)
+#pragma unroll
+                            for (int t = 0; t < CT; ++t) acc[t] = mfma_32x32x2(pw[u], src[u][t], acc[t]);
+                    }
+                };
+                auto compute_step = [&](const float (&src)[NP][CT], int st) {
+                    const int nn = nb + st * 2 * NP;
+                    if (st < nfull) compute(src, nn, std::true_type{});
+                    else compute(src, nn, std::false_type{});
+                };
+
+                float b0[NP][CT], b1[NP][CT];
+                load_step(b0, 0);
+                __syncthreads();
+#pragma unroll 2
+                for (int idx = threadIdx.x; idx < len; idx += blockDim.x) {
+                    const long rowid = (long)mb * a.n_out + nc0 + idx;
+                    const float4 xo = load_point4(rmo, mo_bytes, rowid, a.sdim, a.coords_used);
+                    const float4 rs4 = *reinterpret_cast<const float4*>(
+                        a.rowstat + (((long)mb * a.n_head + h) * a.n_out + nc0 + idx) * 4);
+                    float4 r0; r0.x = xo.x; r0.y = xo.y; r0.z = xo.z; r0.w = rs4.x;
+                    s_rec[idx] = r0;
+                    s_nrm[idx] = make_float2(rs4.y, rs4.z);
+                }
+                __syncthreads();
+                for (int st = 0; st < nsteps; ++st) {
+#pragma unroll
+                    for (int u = 0; u < NP; ++u)
+#pragma unroll
+                        for (int t = 0; t < CT; ++t) b1[u][t] = b0[u][t];
+                    load_step(b0, st + 1);
+                    compute_step(b1, st);
                 }
             }
         }
-    }
+    };
+    if (per) run(std::true_type{}); else run(std::false_type{});
+
     float extra[1] = {0.0f};
     float* red = reinterpret_cast<float*>(smem);
     __syncthreads();
@@ -1037,7 +1090,8 @@ size_t rows_smem(int ct, int nwaves, int n_in) {
     return stage > red ? stage : red;
 }
 size_t cols_smem(int ct, int nwaves, int n_out) {
-    const size_t stage = (size_t)min(ROW_CHUNK, n_out) * 2 * sizeof(float4);
+    (void)n_out;
+    const size_t stage = (size_t)ROW_CHUNK * (sizeof(float4) + sizeof(float2));     // {xo,T} and {S_min,1/L} arrays
     const size_t red = (size_t)nwaves * (ct * 16) * 64 * sizeof(float);
     return stage > red ? stage : red;
 }
