@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define PIT_ABI_VERSION 4
+#define PIT_ABI_VERSION 5
 #define PIT_DSCALE_SLOTS 1024 /* fp64 accumulators per head in pit_posatt_bwd's workspace */
 
 /* distance metric (dist2att variants) */
@@ -111,13 +111,19 @@ int pit_posatt_fwd(const float* mesh_out, const float* mesh_in, int mesh_batch, 
  *            attention) the gradient of the copied inputs, d_out[b,j,0:dim], is added.
  *   scale    the c written to scale_out by the forward (NULL = recompute from head)
  *   d_head   n_head floats (NULL = not needed): gradient w.r.t. lmda (head_is_scale=0) or
- *            w.r.t. c (=1); accumulate_head=1 adds to the current contents instead of writing.
+ *            w.r.t. c (=1); accumulate_head is a bit set: PIT_HEAD_ACCUMULATE adds to the current
+ *            contents instead of writing; PIT_HEAD_DEFER leaves the fp64 accumulators LOADED and
+ *            skips the finishing kernel - the caller later drains several layers at once with
+ *            pit_posatt_dhead_finish (each deferred layer then needs its own workspace).
  *   workspace: n_head*PIT_DSCALE_SLOTS doubles: fp64 accumulators for d c.  They must be ZERO
  *            on entry and are left zero on exit (the finishing kernel drains them with atomic
  *            exchanges, applies d c/d lmda and writes d_head), so a caller allocates and zeroes
  *            them once; no per-call memset.
  * d_values and d_head are computed by independent kernels: a caller may issue two calls (one
  * with d_values == NULL, one with d_head == NULL) on different streams to overlap them. */
+#define PIT_HEAD_ACCUMULATE 1
+#define PIT_HEAD_DEFER      2
+#define PIT_HEAD_IS_SCALE   4   /* pit_posatt_dhead_finish only: d_head is w.r.t. c, no chain rule */
 int pit_posatt_bwd(const float* mesh_out, const float* mesh_in, int mesh_batch, int n_out, int n_in,
                    int space_dim, int metric, float period,
                    const float* values, int batch, int dim, long ld_values, long values_bstride,
@@ -128,6 +134,15 @@ int pit_posatt_bwd(const float* mesh_out, const float* mesh_in, int mesh_batch, 
                    float* d_head, int accumulate_head, double* workspace,
                    const int* nbr_idx, const int* nbr_cnt, int nbr_cap,
                    const int* rev_ptr, const int* rev_row, void* stream);
+
+/* Finishing step of n_layers (<= 32) pit_posatt_bwd calls issued with PIT_HEAD_DEFER, in ONE
+ * launch: per layer l drains workspaces[l] (n_heads[l]*PIT_DSCALE_SLOTS doubles, left zero), applies
+ * d c / d lmda (heads[l] = lmda, scales[l] = the forward's c or NULL to recompute; with
+ * PIT_HEAD_IS_SCALE in flags[l] the result is d c itself) and writes or (PIT_HEAD_ACCUMULATE) adds to
+ * d_heads[l].  The arrays are HOST arrays of device pointers / ints, read during the call. */
+int pit_posatt_dhead_finish(int n_layers, double* const* workspaces, float* const* d_heads,
+                            const float* const* heads, const float* const* scales, const int* n_heads,
+                            const int* flags, void* stream);
 
 /* kaiming_mlp.forward (pit.py:21-26): y = W2 * gelu_erf(W1 x + b1) + b2, optionally
  * followed by the trailing gelu of pit.py:111,121 (out_gelu=1).

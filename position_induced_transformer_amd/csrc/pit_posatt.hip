@@ -94,6 +94,36 @@ __global__ __launch_bounds__(256) void posatt_dhead_finish(AttArgs a) {
     dscale_drain_head(a, blockIdx.x, s_red);
 }
 
+// The same for several layers in ONE launch (pit_posatt_dhead_finish): the backward calls ran with
+// PIT_HEAD_DEFER and left their accumulators loaded; one workgroup per (layer, head) drains all
+// PIT_DSCALE_SLOTS slots.
+constexpr int FINISH_MAX_LAYERS = 32;
+struct FinishBatch {
+    int n;
+    double* ws[FINISH_MAX_LAYERS];
+    float* d_head[FINISH_MAX_LAYERS];
+    const float* head[FINISH_MAX_LAYERS];
+    const float* scale[FINISH_MAX_LAYERS];
+    int n_head[FINISH_MAX_LAYERS];
+    int flags[FINISH_MAX_LAYERS];            // PIT_HEAD_ACCUMULATE | PIT_HEAD_IS_SCALE
+    int wg_base[FINISH_MAX_LAYERS + 1];
+};
+__global__ __launch_bounds__(256) void posatt_dhead_finish_batch(FinishBatch fb) {
+    __shared__ double s_red[10];
+    int l = 0;
+    while (l + 1 < fb.n && (int)blockIdx.x >= fb.wg_base[l + 1]) ++l;
+    AttArgs a = AttArgs();
+    a.dscale_acc = fb.ws[l];
+    a.nslots = PIT_DSCALE_SLOTS;
+    a.d_head = fb.d_head[l];
+    a.dhead_src = fb.head[l];
+    a.dhead_is_scale = (fb.flags[l] & PIT_HEAD_IS_SCALE) ? 1 : 0;
+    a.accumulate_head = (fb.flags[l] & PIT_HEAD_ACCUMULATE) ? 1 : 0;
+    a.head = fb.scale[l] ? fb.scale[l] : fb.head[l];
+    a.head_is_scale = (fb.scale[l] || a.dhead_is_scale) ? 1 : 0;
+    dscale_drain_head(a, (int)blockIdx.x - fb.wg_base[l], s_red);
+}
+
 constexpr int KEY_CHUNK = 2048;   // keys staged in LDS per pass (float4 each = 32 KiB)
 constexpr int ROW_CHUNK = 1024;   // row records staged per pass in the cols kernel (32 KiB)
 
@@ -1720,7 +1750,9 @@ extern "C" int pit_posatt_bwd(const float* mesh_out, const float* mesh_in, int m
     const bool sparse = masked && nbr_idx && nbr_cnt;
     SparseArgs sp{nbr_idx, nbr_cnt, nbr_cap, rev_ptr, rev_row, (long)n_out * nbr_cap};
     if (d_head) {
-        a.d_head = d_head; a.dhead_src = head; a.dhead_is_scale = head_is_scale; a.accumulate_head = accumulate_head;
+        a.d_head = d_head; a.dhead_src = head; a.dhead_is_scale = head_is_scale;
+        a.accumulate_head = (accumulate_head & PIT_HEAD_ACCUMULATE) ? 1 : 0;
+        const bool defer = (accumulate_head & PIT_HEAD_DEFER) != 0;     // caller drains later (pit_posatt_dhead_finish)
         const long approx_wgs = sparse ? ((long)mesh_batch * n_out + 3) / 4 * std::max(1, a.ncols / 512) * n_head
                                        : (long)((n_out + 31) / 32) * n_head * mesh_batch * std::max(1, a.ncols / 128);
         // accumulator slots in use: ~32 adds per slot keeps the fp64 atomics uncontended while the
@@ -1735,13 +1767,38 @@ extern "C" int pit_posatt_bwd(const float* mesh_out, const float* mesh_in, int m
         }
         if (!paired) { if (sparse) launch_sparse_rows<1>(a, sp, s); else launch_rows<1>(a, s); }
         PIT_CHECK_LAUNCH();
-        hipLaunchKernelGGL(posatt_dhead_finish, dim3(n_head), dim3(256), 0, s, a);
-        PIT_CHECK_LAUNCH();
+        if (!defer) {
+            hipLaunchKernelGGL(posatt_dhead_finish, dim3(n_head), dim3(256), 0, s, a);
+            PIT_CHECK_LAUNCH();
+        }
         if (paired) return 0;
     }
     if (d_values) {
         if (sparse && rev_ptr && rev_row) launch_sparse_cols(a, sp, s); else launch_cols(a, s);
         PIT_CHECK_LAUNCH();
     }
+    return 0;
+}
+
+extern "C" int pit_posatt_dhead_finish(int n_layers, double* const* workspaces, float* const* d_heads,
+                                       const float* const* heads, const float* const* scales, const int* n_heads,
+                                       const int* flags, void* stream) {
+    if (n_layers <= 0) return 0;
+    if (n_layers > FINISH_MAX_LAYERS) return PIT_ERR_SIZE;
+    if (!workspaces || !d_heads || !heads || !scales || !n_heads || !flags) return PIT_ERR_NULL;
+    FinishBatch fb;
+    fb.n = n_layers;
+    int total = 0;
+    for (int l = 0; l < n_layers; ++l) {
+        if (!workspaces[l] || !d_heads[l] || !heads[l]) return PIT_ERR_NULL;
+        if (n_heads[l] <= 0) return PIT_ERR_SIZE;
+        fb.ws[l] = workspaces[l]; fb.d_head[l] = d_heads[l]; fb.head[l] = heads[l]; fb.scale[l] = scales[l];
+        fb.n_head[l] = n_heads[l]; fb.flags[l] = flags[l];
+        fb.wg_base[l] = total;
+        total += n_heads[l];
+    }
+    fb.wg_base[n_layers] = total;
+    hipLaunchKernelGGL(posatt_dhead_finish_batch, dim3(total), dim3(256), 0, (hipStream_t)stream, fb);
+    PIT_CHECK_LAUNCH();
     return 0;
 }

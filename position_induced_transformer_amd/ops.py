@@ -81,6 +81,48 @@ def _dscale_workspace(device, n_head: int) -> torch.Tensor:
     return ws
 
 
+# d(lmda) of every attention layer of a backward pass is finished by ONE launch at the end of the
+# pass (pit_posatt_dhead_finish) instead of one small kernel per layer; applies when the gradient
+# goes in place into lmda.grad (the training path), needs one accumulator buffer per layer.
+DEFER_HEAD_FINISH = os.environ.get("PIT_DEFER_HEAD_FINISH", "1") != "0"
+_PENDING_HEADS = []      # (workspace, d_head, lmda, scale, n_head, flags) of the running backward pass
+_LAYER_WS = {}
+
+
+def _layer_workspace(slot: torch.Tensor, n_head: int) -> torch.Tensor:
+    key = (slot.device.index, slot.data_ptr(), n_head)
+    ws = _LAYER_WS.get(key)
+    if ws is None:
+        ws = _LAYER_WS[key] = torch.zeros(n_head * 1024, device=slot.device, dtype=torch.float64)
+    return ws
+
+
+def _flush_head_finishes() -> None:
+    """End-of-backward callback: one launch finishing d(lmda) of all deferred layers."""
+    pend = list(_PENDING_HEADS)
+    _PENDING_HEADS.clear()
+    for dev in sorted({p[0].device.index for p in pend}):
+        grp = [p for p in pend if p[0].device.index == dev]
+        for i in range(0, len(grp), 32):
+            part = grp[i:i + 32]
+            n = len(part)
+            ws = (ctypes.c_void_p * n)(*[p[0].data_ptr() for p in part])
+            dh = (ctypes.c_void_p * n)(*[p[1].data_ptr() for p in part])
+            hd = (ctypes.c_void_p * n)(*[p[2].data_ptr() for p in part])
+            sc = (ctypes.c_void_p * n)(*[p[3].data_ptr() for p in part])
+            nh = (ctypes.c_int * n)(*[p[4] for p in part])
+            fl = (ctypes.c_int * n)(*[p[5] for p in part])
+            with torch.cuda.device(dev):
+                rc = _lib.lib().pit_posatt_dhead_finish(n, ws, dh, hd, sc, nh, fl, _lib.stream_ptr())
+            _lib.check(rc, "pit_posatt_dhead_finish")
+
+
+def _defer_head_finish(work, d_head, head, scale, n_head: int, flags: int) -> None:
+    if not _PENDING_HEADS:
+        torch.autograd.Variable._execution_engine.queue_callback(_flush_head_finishes)
+    _PENDING_HEADS.append((work, d_head, head, scale, n_head, flags))
+
+
 def _grad_slot(param) -> Optional[torch.Tensor]:
     """The parameter's own .grad if the kernels may accumulate into it in place."""
     if not FUSED_GRAD_ACCUMULATION or param is None:
@@ -248,7 +290,10 @@ class _PosAtt(torch.autograd.Function):
         else:
             d_head = torch.empty((n_head,), device=values.device, dtype=torch.float32) if need_h else None
             acc_head = 0
-        work = _dscale_workspace(values.device, n_head)
+        defer = DEFER_HEAD_FINISH and slot is not None and not OVERLAP_BACKWARD
+        work = _layer_workspace(slot, n_head) if defer else _dscale_workspace(values.device, n_head)
+        if defer:
+            acc_head |= 2                               # PIT_HEAD_DEFER: finished by _flush_head_finishes
 
         def launch(dv, dh, stream_ptr):
             rc = _lib.lib().pit_posatt_bwd(
@@ -272,6 +317,8 @@ class _PosAtt(torch.autograd.Function):
                 launch(d_values, None, _lib.stream_ptr())
         else:
             launch(d_values, d_head, _lib.stream_ptr())
+        if defer:
+            _defer_head_finish(work, d_head, head, scale, n_head, 1 | (4 if ctx.head_is_scale else 0))
         return d_values, (None if slot is not None else d_head), None, None, None, None, None
 
 
