@@ -119,6 +119,9 @@ int pit_posatt_fwd(const float* mesh_out, const float* mesh_in, int mesh_batch, 
  *            on entry and are left zero on exit (the finishing kernel drains them with atomic
  *            exchanges, applies d c/d lmda and writes d_head), so a caller allocates and zeroes
  *            them once; no per-call memset.
+ *   nbr_complete: 1 = the caller knows that no row's candidate list overflowed (nbr_cnt <= nbr_cap
+ *            everywhere, e.g. checked once for a cached fixed-mesh plan): the pass that adds the
+ *            overflowed rows to d_values is not launched.  0 = unknown (always correct).
  * d_values and d_head are computed by independent kernels: a caller may issue two calls (one
  * with d_values == NULL, one with d_head == NULL) on different streams to overlap them. */
 #define PIT_HEAD_ACCUMULATE 1
@@ -132,7 +135,7 @@ int pit_posatt_bwd(const float* mesh_out, const float* mesh_in, int mesh_batch, 
                    const float* d_out, long ld_dout, long dout_bstride, int out_col0,
                    float* d_values, long ld_dvalues, long dvalues_bstride, int add_residual,
                    float* d_head, int accumulate_head, double* workspace,
-                   const int* nbr_idx, const int* nbr_cnt, int nbr_cap,
+                   const int* nbr_idx, const int* nbr_cnt, int nbr_cap, int nbr_complete,
                    const int* rev_ptr, const int* rev_row, void* stream);
 
 /* Finishing step of n_layers (<= 32) pit_posatt_bwd calls issued with PIT_HEAD_DEFER, in ONE

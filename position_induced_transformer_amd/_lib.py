@@ -39,7 +39,7 @@ SIGNATURES = {
                        _P, _I,
                        _P, _L, _L, _I,
                        _P, _L, _L, _I,
-                       _P, _I, _P, _P, _P, _I, _P, _P, _P],
+                       _P, _I, _P, _P, _P, _I, _I, _P, _P, _P],
     "pit_posatt_dhead_finish": [_I, _P, _P, _P, _P, _P, _P, _P],
     "pit_mlp_fwd": [_P, _L, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _L, _P],
     "pit_mlp_bwd": [_P, _L, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _L,

@@ -1622,7 +1622,7 @@ void launch_sparse_rows(const AttArgs& a, const SparseArgs& sp, hipStream_t s) {
 // merged d(values) + d(scale) launch for a sparse layer; false when the launch would be large or
 // the parts' columns-per-lane are a combination that is not instantiated (caller launches the
 // parts separately)
-bool launch_sparse_bwd_pair(const AttArgs& a, const SparseArgs& sp, hipStream_t s) {
+bool launch_sparse_bwd_pair(const AttArgs& a, const SparseArgs& sp, bool complete, hipStream_t s) {
     if (env_int("PIT_NO_BWD_PAIR")) return false;
     const int nh = (a.n_head % 2 == 0) ? 2 : 1;
     const long rows = (long)a.mesh_batch * a.n_out, keys = (long)a.mesh_batch * a.n_in;
@@ -1641,11 +1641,11 @@ bool launch_sparse_bwd_pair(const AttArgs& a, const SparseArgs& sp, hipStream_t 
 #undef PIT_SB_CR
 #undef PIT_SB_C
 #undef PIT_SB
-    hipLaunchKernelGGL(posatt_sparse_overflow_cols, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, a, sp);
+    if (!complete) hipLaunchKernelGGL(posatt_sparse_overflow_cols, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, a, sp);
     return true;
 }
 
-void launch_sparse_cols(const AttArgs& a, const SparseArgs& sp, hipStream_t s) {
+void launch_sparse_cols(const AttArgs& a, const SparseArgs& sp, bool complete, hipStream_t s) {
     const long keys = (long)a.mesh_batch * a.n_in;
     const int cr = cr_for(a.ncols, keys);
     dim3 grid((unsigned)((keys + 3) / 4), (a.ncols + 64 * cr - 1) / (64 * cr)), block(256);
@@ -1654,7 +1654,7 @@ void launch_sparse_cols(const AttArgs& a, const SparseArgs& sp, hipStream_t s) {
     else if (cr == 2) hipLaunchKernelGGL((posatt_sparse_cols<2>), grid, block, 0, s, a, sp);
     else hipLaunchKernelGGL((posatt_sparse_cols<1>), grid, block, 0, s, a, sp);
     const long rows = (long)a.mesh_batch * a.n_out;
-    hipLaunchKernelGGL(posatt_sparse_overflow_cols, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, a, sp);
+    if (!complete) hipLaunchKernelGGL(posatt_sparse_overflow_cols, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, a, sp);
 }
 
 int fill_common(AttArgs& a, const float* mesh_out, const float* mesh_in, int mesh_batch, int n_out, int n_in,
@@ -1726,7 +1726,7 @@ extern "C" int pit_posatt_bwd(const float* mesh_out, const float* mesh_in, int m
                               const float* d_out, long ld_dout, long dout_bstride, int out_col0,
                               float* d_values, long ld_dvalues, long dvalues_bstride, int add_residual,
                               float* d_head, int accumulate_head, double* workspace,
-                              const int* nbr_idx, const int* nbr_cnt, int nbr_cap,
+                              const int* nbr_idx, const int* nbr_cnt, int nbr_cap, int nbr_complete,
                               const int* rev_ptr, const int* rev_row, void* stream) {
     AttArgs a;
     int rc = fill_common(a, mesh_out, mesh_in, mesh_batch, n_out, n_in, space_dim, metric, period, values, batch,
@@ -1763,7 +1763,7 @@ extern "C" int pit_posatt_bwd(const float* mesh_out, const float* mesh_in, int m
         bool paired = false;
         if (d_values) {                                                // d(scale) + d(values) in one launch
             if (!sparse) paired = launch_bwd_pair(a, s);
-            else if (rev_ptr && rev_row) paired = launch_sparse_bwd_pair(a, sp, s);
+            else if (rev_ptr && rev_row) paired = launch_sparse_bwd_pair(a, sp, nbr_complete != 0, s);
         }
         if (!paired) { if (sparse) launch_sparse_rows<1>(a, sp, s); else launch_rows<1>(a, s); }
         PIT_CHECK_LAUNCH();
@@ -1774,7 +1774,7 @@ extern "C" int pit_posatt_bwd(const float* mesh_out, const float* mesh_in, int m
         if (paired) return 0;
     }
     if (d_values) {
-        if (sparse && rev_ptr && rev_row) launch_sparse_cols(a, sp, s); else launch_cols(a, s);
+        if (sparse && rev_ptr && rev_row) launch_sparse_cols(a, sp, nbr_complete != 0, s); else launch_cols(a, s);
         PIT_CHECK_LAUNCH();
     }
     return 0;

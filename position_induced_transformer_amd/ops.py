@@ -170,7 +170,7 @@ class MeshPlan:
 
     __slots__ = ("mesh_out", "mesh_in", "mesh_batch", "n_out", "n_in", "sdim", "metric", "metric_id", "period",
                  "rank_k", "rank_w", "masked", "self_attn", "stats", "nbr_idx", "nbr_cnt", "nbr_cap", "rev_ptr",
-                 "rev_row")
+                 "rev_row", "_complete")
 
     def __init__(self, metric: str, mesh_out: torch.Tensor, mesh_in: torch.Tensor, locality: float,
                  self_attn: bool, period: Optional[float] = None):
@@ -208,11 +208,23 @@ class MeshPlan:
             _lib.check(rc, "pit_select_fwd")
         self.nbr_idx = self.nbr_cnt = self.rev_ptr = self.rev_row = None
         self.nbr_cap = 0
+        self._complete = None
         if self.masked and SPARSE_MASKED:
             want = self.rank_k + 2
             cap = ((want + max(16, want // 4) + 15) // 16) * 16        # k+2 keys plus room for ties
             if cap * 3 <= self.n_in:
                 self._build_lists(cap)
+
+    def lists_complete(self) -> int:
+        """1 if no row's candidate list overflowed its capacity (checked once, for batch-free meshes
+        whose plan is cached; never during stream capture - the check synchronises), else 0."""
+        if self.nbr_cnt is None or self.mesh_batch != 1:
+            return 0
+        if self._complete is None:
+            if torch.cuda.is_current_stream_capturing():
+                return 0
+            self._complete = int(bool((self.nbr_cnt <= self.nbr_cap).all().item()))
+        return self._complete
 
     def _build_lists(self, cap: int) -> None:
         """Candidate lists (row -> keys) and their transpose (key -> rows) for the sparse kernels."""
@@ -306,7 +318,7 @@ class _PosAtt(torch.autograd.Function):
                 _lib.ptr(dv), dv.stride(1) if dv is not None else 0, dv.stride(0) if dv is not None else 0,
                 1 if concat else 0,
                 _lib.ptr(dh), acc_head, work.data_ptr(),
-                _lib.ptr(plan.nbr_idx), _lib.ptr(plan.nbr_cnt), plan.nbr_cap,
+                _lib.ptr(plan.nbr_idx), _lib.ptr(plan.nbr_cnt), plan.nbr_cap, plan.lists_complete(),
                 _lib.ptr(plan.rev_ptr), _lib.ptr(plan.rev_row), stream_ptr)
             _lib.check(rc, "pit_posatt_bwd")
 

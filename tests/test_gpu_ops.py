@@ -379,3 +379,38 @@ def test_raw_ctypes_binding_as_in_integration_md():
     ulp = np.abs(scale.cpu().numpy().view(np.int32).astype(np.int64) - cs["c"].reshape(-1).view(np.int32).astype(np.int64)).max()
     e, g, _, _ = gio.expect(fx, "out", out.cpu().numpy())
     assert ulp <= 1 and gio.rel_l2(e, g) <= (TOL_FWD if ulp == 0 else 5e-3)
+
+
+def test_overflowed_candidate_lists_take_the_overflow_pass():
+    """MeshPlan.lists_complete(): 1 for a mesh without ties (the d(values) overflow pass is skipped),
+    0 when rows overflow their list capacity (many coincident keys) - and then the sparse backward
+    must still equal the dense one."""
+    from position_induced_transformer_amd import ops as O
+    g = torch.Generator().manual_seed(5)
+    n_out, n_in, dim, n_head = 96, 400, 16, 2
+    mesh_out = torch.rand(n_out, 2, generator=g).cuda()
+    clean = torch.rand(n_in, 2, generator=g)
+    dup = clean.clone()
+    dup[:120] = dup[0]                                  # 120 coincident keys: ties far beyond any capacity
+    old = O.SPARSE_MASKED
+    try:
+        res = {}
+        for label, mesh_in in (("clean", clean.cuda()), ("dup", dup.cuda())):
+            for sparse in (True, False):
+                O.SPARSE_MASKED = sparse
+                plan = O.MeshPlan("euclid", mesh_out, mesh_in, 0.05, False)
+                if sparse:
+                    assert plan.nbr_idx is not None
+                    assert plan.lists_complete() == (1 if label == "clean" else 0)
+                    assert (plan.nbr_cnt > plan.nbr_cap).any().item() == (label == "dup")
+                values = torch.from_numpy(gio.synth((3, n_in, dim), 77)).cuda().requires_grad_(True)
+                lm = torch.from_numpy(gio.synth((n_head,), 78)).cuda().requires_grad_(True)
+                out = O.posatt_apply(values, lm, plan, n_head, concat=False)
+                out.backward(torch.from_numpy(gio.synth(tuple(out.shape), 79)).cuda())
+                res[(label, sparse)] = (out.detach().cpu().numpy(), values.grad.cpu().numpy(), lm.grad.cpu().numpy())
+        for label in ("clean", "dup"):
+            s, d = res[(label, True)], res[(label, False)]
+            assert gio.rel_l2(d[0], s[0]) <= TOL_FWD and gio.rel_l2(d[1], s[1]) <= TOL_GRAD
+            assert gio.rel_l2(d[2], s[2]) <= TOL_HEAD
+    finally:
+        O.SPARSE_MASKED = old
