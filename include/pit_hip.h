@@ -197,6 +197,17 @@ int pit_rel_lp_loss_bwd(const float* tru, const float* pred, const float* pred_s
                         const float* pred_shift, int batch, int npts, int nch, int p,
                         const float* norms, const float* grad_loss, float* d_pred, float* d_true, void* stream);
 
+/* nn.InstanceNorm1d over the point axis as train_vorticity.py:43,56,59 applies it
+ * (norm(x.permute(0,2,1)).permute(0,2,1); no affine, no running statistics, biased variance),
+ * computed directly on the (batch, points, channels) layout:
+ *   y[b,l,c] = (x[b,l,c] - mean_l x[b,:,c]) * rstd[b,c],  rstd = 1/sqrt(var_l + eps).
+ * x rows ldx apart, samples x_bstride apart; y (batch,npts,nch) and rstd (batch,nch) contiguous. */
+int pit_instance_norm_fwd(const float* x, long ldx, long x_bstride, int batch, int npts, int nch, float eps,
+                          float* y, float* rstd, void* stream);
+/* d_x = rstd * (d_y - mean_l d_y - y * mean_l(d_y * y)); all (batch,npts,nch) contiguous. */
+int pit_instance_norm_bwd(const float* d_y, const float* y, const float* rstd, int batch, int npts, int nch,
+                          float* d_x, void* stream);
+
 /* torch.optim.Adam step (no amsgrad) over FLAT fp32 buffers of n elements, learning rate following
  * CosineAnnealingLR(T_max=cosine_t_max, eta_min) when cosine_t_max > 0 (train_darcy.py:115-116),
  * else constant lr0.  `step` (device int64, starts at 0) is incremented here; `scalars` is 3

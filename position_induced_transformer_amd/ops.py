@@ -476,6 +476,40 @@ def rel_lp_loss(true, pred, out_dim: int, p: int, pred_scale=None, pred_shift=No
     return _RelLpLoss.apply(pred, true, out_dim, p, pred_scale, pred_shift)
 
 
+class _InstanceNorm(torch.autograd.Function):
+    """nn.InstanceNorm1d over the point axis on the (batch, points, channels) layout
+    (train_vorticity.py:43,56,59), no permutes."""
+
+    @staticmethod
+    def forward(ctx, x, eps: float):
+        _need_gpu(x)
+        x = _row_view(x)
+        b, npts, nch = x.shape
+        y = torch.empty((b, npts, nch), device=x.device, dtype=torch.float32)
+        rstd = torch.empty((b, nch), device=x.device, dtype=torch.float32)
+        rc = _lib.lib().pit_instance_norm_fwd(x.data_ptr(), x.stride(1), x.stride(0), b, npts, nch, float(eps),
+                                              y.data_ptr(), rstd.data_ptr(), _lib.stream_ptr())
+        _lib.check(rc, "pit_instance_norm_fwd")
+        ctx.save_for_backward(y, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, d_y):
+        y, rstd = ctx.saved_tensors
+        b, npts, nch = y.shape
+        d_y = d_y.contiguous()
+        d_x = torch.empty_like(y)
+        rc = _lib.lib().pit_instance_norm_bwd(d_y.data_ptr(), y.data_ptr(), rstd.data_ptr(), b, npts, nch,
+                                              d_x.data_ptr(), _lib.stream_ptr())
+        _lib.check(rc, "pit_instance_norm_bwd")
+        return d_x, None
+
+
+def instance_norm_points(x: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
+    """(x - mean over points) / sqrt(var over points + eps) per (sample, channel) of a (b, L, C) tensor."""
+    return _InstanceNorm.apply(x, eps)
+
+
 MATH_MODES = {"fp32": 0, "bf16": 1}      # PIT_MATH_* of include/pit_hip.h
 
 

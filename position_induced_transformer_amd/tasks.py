@@ -12,6 +12,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+from . import ops
 from . import pit as P
 
 
@@ -82,7 +83,10 @@ class pit_vorticity(_FixedMeshForward, P.pit_periodic2d):
         self.norm = nn.InstanceNorm1d(self.hid_dim)
 
     def _between(self, x):
-        return self.norm(x.permute(0, 2, 1)).permute(0, 2, 1)
+        n = self.norm
+        if x.is_cuda and isinstance(n, nn.InstanceNorm1d) and not n.affine and not n.track_running_stats:
+            return ops.instance_norm_points(x, n.eps)          # HIP kernel on the (b, L, C) layout, no permutes
+        return n(x.permute(0, 2, 1)).permute(0, 2, 1)
 
 
 class pit_elasticity(P.pit):

@@ -414,3 +414,24 @@ def test_overflowed_candidate_lists_take_the_overflow_pass():
             assert gio.rel_l2(d[2], s[2]) <= TOL_HEAD
     finally:
         O.SPARSE_MASKED = old
+
+
+@pytest.mark.parametrize("b,npts,nch", [(3, 256, 256), (2, 100, 70), (1, 7, 1)])
+def test_instance_norm_points_vs_torch(b, npts, nch):
+    """pit_instance_norm_fwd/bwd against nn.InstanceNorm1d applied as train_vorticity.py:56 does
+    (permute - norm - permute), on the CPU."""
+    from position_induced_transformer_amd import ops as O
+    xc = torch.from_numpy(gio.synth((b, npts, nch), 31) * 3.0 + 0.5).requires_grad_(True)
+    dy = torch.from_numpy(gio.synth((b, npts, nch), 32))
+    ref = torch.nn.InstanceNorm1d(nch)(xc.permute(0, 2, 1)).permute(0, 2, 1)
+    ref.backward(dy)
+    xg = xc.detach().cuda().requires_grad_(True)
+    got = O.instance_norm_points(xg, 1e-5)
+    got.backward(dy.cuda())
+    assert gio.rel_l2(ref.detach().numpy(), got.detach().cpu().numpy()) <= TOL_FWD
+    assert gio.rel_l2(xc.grad.numpy(), xg.grad.cpu().numpy()) <= TOL_GRAD
+    # a strided view (columns of a wider buffer) goes through the row stride, not a copy
+    wide = torch.zeros(b, npts, nch + 5, device="cuda")
+    wide[..., 2:2 + nch] = xc.detach().cuda()
+    got2 = O.instance_norm_points(wide[..., 2:2 + nch], 1e-5)
+    assert torch.equal(got2, got.detach())
