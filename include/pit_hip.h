@@ -70,6 +70,14 @@ int pit_select_fwd(const float* mesh_out, const float* mesh_in, int mesh_batch, 
                    int space_dim, int metric, float period, int rank_k, int need_kth,
                    float* stats, void* stream);
 
+/* pit_select_fwd (need_kth = 1) and pit_neighbors_fwd in ONE pass over the rows: the distances of
+ * a row stay in registers, the order statistics are searched on a narrowed candidate set and the
+ * lists are emitted from the same registers (rows longer than 4096 keys fall back to the two
+ * streaming passes).  Arguments as in those two functions; stats is written, then used. */
+int pit_plan_fwd(const float* mesh_out, const float* mesh_in, int mesh_batch, int n_out, int n_in,
+                 int space_dim, int metric, float period, int rank_k, float* stats, int cap,
+                 int* nbr_idx, int* nbr_cnt, int* rev_ptr, int* rev_row, int* workspace, void* stream);
+
 /* Candidate lists for the masked layers (sparse path).  For every row: the keys with
  * m <= m_(k+1)*(1+2^-21) - a superset of the kept set of pit.py:50 for ANY head scale (k+2 keys
  * plus ties), so it depends on the meshes only.  nbr_idx (rows, cap) int32, nbr_cnt (rows) int32

@@ -11,6 +11,7 @@
 // (long rows, e.g. zero-shot super-resolution J = 177k) recomputes the distances from
 // the coordinates on every pass with one 256-thread workgroup per row.
 #include "pit_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -92,6 +93,123 @@ __global__ __launch_bounds__(256) void select_rows_reg(SelectArgs a) {
         a.stats[rows + row] = __uint_as_float(vk1);
         a.stats[2 * rows + row] = __uint_as_float(kmin);
     }
+}
+
+// MSB-first bitwise search over NI keys per lane: the key of 0-based rank k in the wave's multiset
+template <int NI>
+__device__ __forceinline__ uint32_t wave_kth(const uint32_t (&key)[NI], int k) {
+    uint32_t prefix = 0;
+    for (int bit = 30; bit >= 0; --bit) {       // bit 31 (sign) is never set on real keys
+        const uint32_t cand = prefix | (1u << bit);
+        int cnt = 0;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) cnt += __popcll(__builtin_amdgcn_ballot_w64(key[i] < cand));
+        if (cnt <= k) prefix = cand;            // the k-th key has this bit set
+    }
+    return prefix;
+}
+
+// Selection AND candidate lists in one pass over the row (pit_plan_fwd): the keys stay in registers,
+// so the lists cost one more compare per key instead of a second distance pass.  The search itself
+// is narrowed first: the (k+2)-th smallest of the 64 lane minima is an upper bound U of m_(k+1)
+// (at least k+2 keys are <= U), typically only a few more than k+2 keys are <= U, and when they fit
+// one per lane the exact order statistics come from a search over ONE key per lane (31 passes x 1
+// compare instead of x ITEMS).
+template <int ITEMS>
+__global__ __launch_bounds__(256) void plan_rows_reg(SelectArgs a, int cap, int* __restrict__ nbr_idx,
+                                                     int* __restrict__ nbr_cnt, int* __restrict__ counts) {
+    __shared__ uint32_t s_cand[4][64];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const long rows = (long)a.mesh_batch * a.n_out;
+    const long row = (long)blockIdx.x * 4 + wave;
+    if (row >= rows) return;                      // whole wave exits together (no block barrier below)
+    const int mb = (int)(row / a.n_out);
+    const float* po = a.mesh_out + row * a.sdim;
+    const float* pin = a.mesh_in + (long)mb * a.n_in * a.sdim;
+    float ox, oy, oz;
+    load_point(po, a.sdim, a.coords_used, ox, oy, oz);
+
+    uint32_t key[ITEMS];
+    uint32_t lmin = 0xFFFFFFFFu;
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+        const int j = lane + 64 * i;
+        uint32_t k = 0xFFFFFFFFu;                 // padding sorts last
+        if (j < a.n_in) {
+            float ix, iy, iz;
+            load_point(pin + (long)j * a.sdim, a.sdim, a.coords_used, ix, iy, iz);
+            k = __float_as_uint(sq_dist3(ox, oy, oz, ix, iy, iz, a.periodic != 0, a.period));
+        }
+        key[i] = k;
+        lmin = min(lmin, k);
+    }
+    uint32_t kmin = lmin;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) kmin = min(kmin, (uint32_t)__shfl_xor((int)kmin, o));
+
+    const int k = a.rank_k;
+    uint32_t vk;
+    bool narrowed = false;
+    if (ITEMS >= 4 && k + 2 <= 32) {
+        const uint32_t one[1] = {lmin};
+        const uint32_t U = wave_kth<1>(one, k + 1);            // (k+2)-th smallest lane minimum >= m_(k+1)
+        int total = 0;
+        bool fits = (U != 0xFFFFFFFFu);
+        if (fits) {
+#pragma unroll
+            for (int i = 0; i < ITEMS; ++i) total += __popcll(__builtin_amdgcn_ballot_w64(key[i] <= U));
+            fits = total <= 64;
+        }
+        if (fits) {                                            // wave-uniform
+            s_cand[wave][lane] = 0xFFFFFFFFu;
+            int base = 0;
+#pragma unroll
+            for (int i = 0; i < ITEMS; ++i) {
+                const bool in = key[i] <= U;
+                const unsigned long long m = __builtin_amdgcn_ballot_w64(in);
+                if (in) s_cand[wave][base + __popcll(m & ((1ull << lane) - 1ull))] = key[i];
+                base += __popcll(m);
+            }
+            // same-wave LDS traffic only: the LDS pipeline executes a wave's accesses in program order
+            const uint32_t cnd[1] = {s_cand[wave][lane]};
+            vk = wave_kth<1>(cnd, k);
+            narrowed = true;
+        }
+    }
+    if (!narrowed) vk = wave_kth<ITEMS>(key, k);
+    int cnt_le = 0;
+    uint32_t next = 0xFFFFFFFFu;
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+        cnt_le += __popcll(__builtin_amdgcn_ballot_w64(key[i] <= vk));
+        if (key[i] > vk) next = min(next, key[i]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) next = min(next, (uint32_t)__shfl_xor((int)next, o));
+    const uint32_t vk1 = (cnt_le >= k + 2 || k + 1 > a.n_in - 1) ? vk : next;
+    if (lane == 0) {
+        a.stats[row] = __uint_as_float(vk);
+        a.stats[rows + row] = __uint_as_float(vk1);
+        a.stats[2 * rows + row] = __uint_as_float(kmin);
+    }
+    // ---- candidate list: keys with m <= m_(k+1) * (1 + 2^-21), in key order (as neighbors_kernel)
+    const float bound = __uint_as_float(vk1) * 1.00000047683715820312f;
+    int total = 0;
+    int* out = nbr_idx + row * cap;
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+        const int j = lane + 64 * i;
+        const bool in = (j < a.n_in) && (__uint_as_float(key[i]) <= bound);
+        const unsigned long long mask = __builtin_amdgcn_ballot_w64(in);
+        const int pos = total + __popcll(mask & ((1ull << lane) - 1ull));
+        if (in && pos < cap) {
+            out[pos] = j;
+            if (counts) atomicAdd(counts + (long)mb * a.n_in + j, 1);
+        }
+        total += __popcll(mask);
+    }
+    if (lane == 0) nbr_cnt[row] = total;
 }
 
 // one workgroup per row, distances recomputed per pass
@@ -304,6 +422,65 @@ extern "C" int pit_select_fwd(const float* mesh_out, const float* mesh_in, int m
         hipLaunchKernelGGL(select_rows_stream, dim3((unsigned)rows), dim3(256), 0, s, a);
     }
     PIT_CHECK_LAUNCH();
+    return 0;
+}
+
+// transposed lists from nbr_idx / counts: scan + fill
+static int launch_transpose(const int* nbr_idx, const int* nbr_cnt, int mesh_batch, int n_out, int n_in, int cap,
+                     int* rev_ptr, int* rev_row, int* counts, int* cursor, hipStream_t s) {
+    const long rows = (long)mesh_batch * n_out;
+    hipLaunchKernelGGL(nbr_scan_kernel, dim3(mesh_batch), dim3(256), 0, s, counts, n_in, rev_ptr, cursor);
+    PIT_CHECK_LAUNCH();
+    const unsigned blocks = (unsigned)((rows * cap + 255) / 256);
+    hipLaunchKernelGGL(nbr_fill_kernel, dim3(blocks), dim3(256), 0, s, nbr_idx, nbr_cnt, rows, n_out, n_in, cap, cursor,
+                       rev_row, (long)n_out * cap);
+    PIT_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pit_plan_fwd(const float* mesh_out, const float* mesh_in, int mesh_batch, int n_out, int n_in,
+                            int space_dim, int metric, float period, int rank_k, float* stats, int cap,
+                            int* nbr_idx, int* nbr_cnt, int* rev_ptr, int* rev_row, int* workspace, void* stream) {
+    if (!mesh_out || !mesh_in || !stats || !nbr_idx || !nbr_cnt) return PIT_ERR_NULL;
+    if (rev_ptr && (!rev_row || !workspace)) return PIT_ERR_NULL;
+    if (mesh_batch <= 0 || n_out <= 0 || n_in <= 0 || space_dim < 1 || space_dim > 3 || cap <= 0) return PIT_ERR_SIZE;
+    if (metric < PIT_METRIC_EUCLID || metric > PIT_METRIC_PERIODIC2D) return PIT_ERR_METRIC;
+    if (rank_k < 0 || rank_k > n_in - 1) return PIT_ERR_SIZE;
+    const int items = (n_in + 63) / 64;
+    if (items > 64 || getenv("PIT_NO_FUSED_PLAN")) {          // long rows: the two streaming passes
+        int rc = pit_select_fwd(mesh_out, mesh_in, mesh_batch, n_out, n_in, space_dim, metric, period, rank_k, 1, stats,
+                                stream);
+        if (rc) return rc;
+        return pit_neighbors_fwd(mesh_out, mesh_in, mesh_batch, n_out, n_in, space_dim, metric, period, stats, cap,
+                                 nbr_idx, nbr_cnt, rev_ptr, rev_row, workspace, stream);
+    }
+    hipStream_t s = (hipStream_t)stream;
+    SelectArgs a;
+    a.mesh_out = mesh_out; a.mesh_in = mesh_in; a.stats = stats;
+    a.mesh_batch = mesh_batch; a.n_out = n_out; a.n_in = n_in; a.sdim = space_dim;
+    a.periodic = (metric != PIT_METRIC_EUCLID);
+    a.coords_used = (metric == PIT_METRIC_PERIODIC1D) ? 1 : space_dim;
+    a.period = period; a.rank_k = rank_k; a.need_kth = 1;
+    const long rows = (long)mesh_batch * n_out;
+    int* counts = rev_ptr ? workspace : nullptr;
+    int* cursor = rev_ptr ? workspace + (long)mesh_batch * n_in : nullptr;
+    hipError_t e;
+    if (rev_ptr) {
+        if ((e = hipMemsetAsync(counts, 0, sizeof(int) * (size_t)mesh_batch * n_in, s)) != hipSuccess) return (int)e;
+        if ((e = hipMemsetAsync(rev_row, 0xFF, sizeof(int) * (size_t)rows * cap, s)) != hipSuccess) return (int)e;
+    }
+    const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+#define PIT_PLAN(I_) hipLaunchKernelGGL(plan_rows_reg<I_>, grid, block, 0, s, a, cap, nbr_idx, nbr_cnt, counts)
+    if (items <= 1) PIT_PLAN(1);
+    else if (items <= 2) PIT_PLAN(2);
+    else if (items <= 4) PIT_PLAN(4);
+    else if (items <= 8) PIT_PLAN(8);
+    else if (items <= 16) PIT_PLAN(16);
+    else if (items <= 32) PIT_PLAN(32);
+    else PIT_PLAN(64);
+#undef PIT_PLAN
+    PIT_CHECK_LAUNCH();
+    if (rev_ptr) return launch_transpose(nbr_idx, nbr_cnt, mesh_batch, n_out, n_in, cap, rev_ptr, rev_row, counts, cursor, s);
     return 0;
 }
 

@@ -199,21 +199,25 @@ class MeshPlan:
         self.masked = bool(locality < 1.0)
         self.self_attn = bool(self_attn)
         self.stats = None
+        self.nbr_idx = self.nbr_cnt = self.rev_ptr = self.rev_row = None
+        self.nbr_cap = 0
+        self._complete = None
+        cap = 0
+        if self.masked and SPARSE_MASKED:
+            want = self.rank_k + 2
+            cap = ((want + max(16, want // 4) + 15) // 16) * 16        # k+2 keys plus room for ties
+            if cap * 3 > self.n_in:
+                cap = 0                                                 # lists not much shorter than the row: dense
         if self.masked or not self.self_attn:
             self.stats = torch.empty((3, self.mesh_batch, self.n_out), device=mesh_out.device, dtype=torch.float32)
+        if cap:
+            self._build_lists(cap)                                      # selection + lists in one pass
+        elif self.stats is not None:
             rc = _lib.lib().pit_select_fwd(self.mesh_out.data_ptr(), self.mesh_in.data_ptr(), self.mesh_batch,
                                            self.n_out, self.n_in, self.sdim, self.metric_id, self.period,
                                            self.rank_k, 1 if self.masked else 0, self.stats.data_ptr(),
                                            _lib.stream_ptr())
             _lib.check(rc, "pit_select_fwd")
-        self.nbr_idx = self.nbr_cnt = self.rev_ptr = self.rev_row = None
-        self.nbr_cap = 0
-        self._complete = None
-        if self.masked and SPARSE_MASKED:
-            want = self.rank_k + 2
-            cap = ((want + max(16, want // 4) + 15) // 16) * 16        # k+2 keys plus room for ties
-            if cap * 3 <= self.n_in:
-                self._build_lists(cap)
 
     def lists_complete(self) -> int:
         """1 if no row's candidate list overflowed its capacity (checked once, for batch-free meshes
@@ -227,7 +231,8 @@ class MeshPlan:
         return self._complete
 
     def _build_lists(self, cap: int) -> None:
-        """Candidate lists (row -> keys) and their transpose (key -> rows) for the sparse kernels."""
+        """Order statistics, candidate lists (row -> keys) and their transpose (key -> rows) for the
+        sparse kernels, one pass over the rows (pit_plan_fwd)."""
         dev = self.mesh_out.device
         rows = self.mesh_batch * self.n_out
         L = _lib.lib()
@@ -237,11 +242,11 @@ class MeshPlan:
         self.rev_ptr = torch.empty((self.mesh_batch, self.n_in + 1), device=dev, dtype=torch.int32)
         self.rev_row = torch.empty((self.mesh_batch, self.n_out * cap), device=dev, dtype=torch.int32)
         work = torch.empty((2 * self.mesh_batch * self.n_in,), device=dev, dtype=torch.int32)
-        rc = L.pit_neighbors_fwd(self.mesh_out.data_ptr(), self.mesh_in.data_ptr(), self.mesh_batch, self.n_out,
-                                 self.n_in, self.sdim, self.metric_id, self.period, self.stats.data_ptr(), cap,
-                                 self.nbr_idx.data_ptr(), self.nbr_cnt.data_ptr(), self.rev_ptr.data_ptr(),
-                                 self.rev_row.data_ptr(), work.data_ptr(), _lib.stream_ptr())
-        _lib.check(rc, "pit_neighbors_fwd")
+        rc = L.pit_plan_fwd(self.mesh_out.data_ptr(), self.mesh_in.data_ptr(), self.mesh_batch, self.n_out,
+                            self.n_in, self.sdim, self.metric_id, self.period, self.rank_k, self.stats.data_ptr(), cap,
+                            self.nbr_idx.data_ptr(), self.nbr_cnt.data_ptr(), self.rev_ptr.data_ptr(),
+                            self.rev_row.data_ptr(), work.data_ptr(), _lib.stream_ptr())
+        _lib.check(rc, "pit_plan_fwd")
 
 
 def _row_view(t: torch.Tensor) -> torch.Tensor:
