@@ -43,6 +43,7 @@ struct AttArgs {
     int bf16;                             // PIT_MATH_BF16 for the forward and d(values) contractions
     unsigned values_bytes, dout_bytes;    // extents for the raw-buffer descriptors
     unsigned dim_magic;                   // floor(2^32 / dim): column -> (sample, channel) without an integer division
+    int no_fast_loads;                    // PIT_NO_FAST_LOADS=1: checked loads everywhere (tests the >= 2 GiB path)
 };
 
 // Folded column index -> (sample, channel).  For batch-free meshes the batch is folded into the
@@ -268,7 +269,7 @@ __device__ __forceinline__ void posatt_rows_body(const AttArgs& a, const int bx,
     constexpr int HS = BF ? 4 : 1;                       // key distance between the half-waves in a group of 8
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const int hk = half * HS;
-    const bool fast_ok = a.values_bytes < 0x80000000u;   // scalar + vector offset cannot wrap
+    const bool fast_ok = a.values_bytes < 0x80000000u && !a.no_fast_loads;   // scalar + vector offset cannot wrap
     unsigned voff[CT];
 #pragma unroll
     for (int t = 0; t < CT; ++t) voff[t] = cvalid[t] ? uoff[t] + (unsigned)hk * ld4 : a.values_bytes;
@@ -508,7 +509,7 @@ __device__ __forceinline__ void posatt_cols_body(const AttArgs& a, const int bx,
     constexpr int HS = BF ? 4 : 1;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const int hk = half * HS;
-    const bool fast_ok = a.dout_bytes < 0x80000000u;
+    const bool fast_ok = a.dout_bytes < 0x80000000u && !a.no_fast_loads;
     unsigned voff[CT];
 #pragma unroll
     for (int t = 0; t < CT; ++t) voff[t] = cvalid[t] ? doff[t] + (unsigned)hk * ldd4 : a.dout_bytes;
@@ -1680,6 +1681,7 @@ int fill_common(AttArgs& a, const float* mesh_out, const float* mesh_in, int mes
     a.values_bytes = (unsigned)vb;
     a.bf16 = (pit_math_mode_value == PIT_MATH_BF16);
     a.dim_magic = (dim == 1) ? 0xFFFFFFFFu : (unsigned)(0x100000000ull / (unsigned long long)dim);
+    a.no_fast_loads = env_int("PIT_NO_FAST_LOADS");
     return 0;
 }
 

@@ -435,3 +435,17 @@ def test_instance_norm_points_vs_torch(b, npts, nch):
     wide[..., 2:2 + nch] = xc.detach().cuda()
     got2 = O.instance_norm_points(wide[..., 2:2 + nch], 1e-5)
     assert torch.equal(got2, got.detach())
+
+
+def test_checked_load_variant_in_a_subprocess():
+    """Tensors of 2 GiB and more cannot use the scalar-offset value loads (offset wrap); that variant
+    of the dense kernels is forced with PIT_NO_FAST_LOADS=1 and must pass the same operator parity
+    tests (run in a child process: the library reads the variable per call, the parent stays clean)."""
+    import os, subprocess, sys
+    env = dict(os.environ, PIT_NO_FAST_LOADS="1")
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_ops.py"), "-q", "-m", "gpu", "-x",
+                        "-k", "posatt_forward_backward_injected_scale and dense-only or mask_keep_sets_exact and dense-only"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
