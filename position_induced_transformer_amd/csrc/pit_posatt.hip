@@ -310,11 +310,11 @@ __device__ __forceinline__ void posatt_rows_body(const AttArgs& a, const int bx,
                     }
                 }
             };
-            auto compute = [&](const float (&src)[NP][CT], int jj, auto full_tag) {
+            // weights of one step (VALU) ...
+            auto weights = [&](float (&pw)[NP], bool (&anyk)[NP / 4], int st, auto full_tag) {
                 constexpr bool FULL = decltype(full_tag)::value;
+                const int jj = jb + st * 2 * NP;
                 const float4* xk = s_xi + hk;                          // this half-wave's keys: s_xi[jj + koff + hk]
-                float pw[NP];
-                bool anyk[NP / 4];
 #pragma unroll
                 for (int q = 0; q < NP / 4; ++q) anyk[q] = false;
 #pragma unroll
@@ -344,6 +344,9 @@ __device__ __forceinline__ void posatt_rows_body(const AttArgs& a, const int bx,
                     }
                     if (MASKED) anyk[u / 4] |= keep;
                 }
+            };
+            // ... and its contraction with the value rows (MFMA)
+            auto contract = [&](const float (&pw)[NP], const bool (&anyk)[NP / 4], const float (&src)[NP][CT]) {
 #pragma unroll
                 for (int q = 0; q < NP / 4; ++q) {
                     if (MASKED && __builtin_amdgcn_ballot_w64(anyk[q]) == 0ull) continue;   // wave-uniform skip
@@ -360,27 +363,63 @@ __device__ __forceinline__ void posatt_rows_body(const AttArgs& a, const int bx,
                         for (int t = 0; t < CT; ++t) acc[t] = mfma_32x32x2(pw[u], src[u][t], acc[t]);
                 }
             };
-            auto compute_step = [&](const float (&src)[NP][CT], int st) {
+            auto load_full = [&](float (&dst)[NP][CT], int st) {          // branch-free: steady state only
                 const int jj = jb + st * 2 * NP;
-                if (st < nfull) compute(src, jj, std::true_type{});
-                else compute(src, jj, std::false_type{});
+#pragma unroll
+                for (int u = 0; u < NP; ++u) {
+                    const int koff = 8 * (u / 4) + (BF ? (u % 4) : 2 * (u % 4));
+                    const int soff = (jc0 + jj + koff) * (int)ld4;
+#pragma unroll
+                    for (int t = 0; t < CT; ++t)
+                        dst[u][t] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rvals, (int)voff[t], soff, 0));
+                }
             };
 
             float b0[NP][CT], b1[NP][CT];
+            float p0[NP], p1[NP];
+            bool k0[NP / 4], k1[NP / 4];
             load_step(b0, 0);                                  // in flight during staging / barrier
             __syncthreads();
 #pragma unroll 4
             for (int idx = threadIdx.x; idx < len; idx += blockDim.x)
                 s_xi[idx] = load_point4(rmi, mi_bytes, (long)mb * a.n_in + jc0 + idx, a.sdim, a.coords_used);
             __syncthreads();
+            // Software pipeline: while the MFMAs of step st run, the vector ALU already forms the weights
+            // of step st+1 (independent work in ONE basic block, so the scheduler interleaves them) and the
+            // value rows of step st+1 / st+2 are in flight.
             int st = 0;
-            for (; st + 1 < nsteps; st += 2) {
+            if (nfull > 0 && fast_ok) {
+                weights(p0, k0, 0, std::true_type{});
+                for (; st + 1 < nfull; ++st) {                 // steady state: steps st and st+1 are both full
+                    load_full(b1, st + 1);
+                    weights(p1, k1, st + 1, std::true_type{});
+                    contract(p0, k0, b0);
+#pragma unroll
+                    for (int u = 0; u < NP; ++u) {
+                        p0[u] = p1[u];
+#pragma unroll
+                        for (int t = 0; t < CT; ++t) b0[u][t] = b1[u][t];
+                    }
+#pragma unroll
+                    for (int q = 0; q < NP / 4; ++q) k0[q] = k1[q];
+                }
+                // p0 / b0 hold the last full step; then possibly the checked tail step
                 load_step(b1, st + 1);
-                compute_step(b0, st);
-                load_step(b0, st + 2);
-                compute_step(b1, st + 1);
+                contract(p0, k0, b0);
+                st += 1;
+                if (st < nsteps) { weights(p1, k1, st, std::false_type{}); contract(p1, k1, b1); }
+            } else {                                           // short slices / >= 2 GiB tensors: plain loop
+                for (; st < nsteps; ++st) {
+#pragma unroll
+                    for (int u = 0; u < NP; ++u)
+#pragma unroll
+                        for (int t = 0; t < CT; ++t) b1[u][t] = b0[u][t];
+                    load_step(b0, st + 1);
+                    if (st < nfull) weights(p0, k0, st, std::true_type{});
+                    else weights(p0, k0, st, std::false_type{});
+                    contract(p0, k0, b1);
+                }
             }
-            if (st < nsteps) compute_step(b0, st);
         }
     };
     if (per) run(std::true_type{}); else run(std::false_type{});
