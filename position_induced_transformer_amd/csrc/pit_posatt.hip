@@ -590,12 +590,11 @@ __device__ __forceinline__ void posatt_cols_body(const AttArgs& a, const int bx,
                         }
                     }
                 };
-                auto compute = [&](const float (&src)[NP][CT], int nn, auto full_tag) {
+                auto weights = [&](float (&pw)[NP], bool (&anyk)[NP / 4], int st, auto full_tag) {
                     constexpr bool FULL = decltype(full_tag)::value;
+                    const int nn = nb + st * 2 * NP;
                     const float4* rk = s_rec + hk;
                     const float2* nk = s_nrm + hk;
-                    float pw[NP];
-                    bool anyk[NP / 4];
 #pragma unroll
                     for (int q = 0; q < NP / 4; ++q) anyk[q] = false;
 #pragma unroll
@@ -622,6 +621,8 @@ __device__ __forceinline__ void posatt_cols_body(const AttArgs& a, const int bx,
                         pw[u] = p;
                         if (MASKED) anyk[u / 4] |= keep;
                     }
+                };
+                auto contract = [&](const float (&pw)[NP], const bool (&anyk)[NP / 4], const float (&src)[NP][CT]) {
 #pragma unroll
                     for (int q = 0; q < NP / 4; ++q) {
                         if (MASKED && __builtin_amdgcn_ballot_w64(anyk[q]) == 0ull) continue;
@@ -638,13 +639,21 @@ __device__ __forceinline__ void posatt_cols_body(const AttArgs& a, const int bx,
                             for (int t = 0; t < CT; ++t) acc[t] = mfma_32x32x2(pw[u], src[u][t], acc[t]);
                     }
                 };
-                auto compute_step = [&](const float (&src)[NP][CT], int st) {
+                auto load_full = [&](float (&dst)[NP][CT], int st) {          // branch-free: steady state only
                     const int nn = nb + st * 2 * NP;
-                    if (st < nfull) compute(src, nn, std::true_type{});
-                    else compute(src, nn, std::false_type{});
+#pragma unroll
+                    for (int u = 0; u < NP; ++u) {
+                        const int koff = 8 * (u / 4) + (BF ? (u % 4) : 2 * (u % 4));
+                        const int soff = (nc0 + nn + koff) * (int)ldd4 + (int)hoff4;
+#pragma unroll
+                        for (int t = 0; t < CT; ++t)
+                            dst[u][t] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rdout, (int)voff[t], soff, 0));
+                    }
                 };
 
                 float b0[NP][CT], b1[NP][CT];
+                float p0[NP], p1[NP];
+                bool k0[NP / 4], k1[NP / 4];
                 load_step(b0, 0);
                 __syncthreads();
 #pragma unroll 2
@@ -658,13 +667,38 @@ __device__ __forceinline__ void posatt_cols_body(const AttArgs& a, const int bx,
                     s_nrm[idx] = make_float2(rs4.y, rs4.z);
                 }
                 __syncthreads();
-                for (int st = 0; st < nsteps; ++st) {
+                int st = 0;
+                if (NPX == 0 && nfull > 0 && fast_ok) {        // software pipeline as in the rows kernel (not in the
+                                                               // register-capped merged launch)
+                    weights(p0, k0, 0, std::true_type{});
+                    for (; st + 1 < nfull; ++st) {
+                        load_full(b1, st + 1);
+                        weights(p1, k1, st + 1, std::true_type{});
+                        contract(p0, k0, b0);
 #pragma unroll
-                    for (int u = 0; u < NP; ++u)
+                        for (int u = 0; u < NP; ++u) {
+                            p0[u] = p1[u];
 #pragma unroll
-                        for (int t = 0; t < CT; ++t) b1[u][t] = b0[u][t];
-                    load_step(b0, st + 1);
-                    compute_step(b1, st);
+                            for (int t = 0; t < CT; ++t) b0[u][t] = b1[u][t];
+                        }
+#pragma unroll
+                        for (int q = 0; q < NP / 4; ++q) k0[q] = k1[q];
+                    }
+                    load_step(b1, st + 1);
+                    contract(p0, k0, b0);
+                    st += 1;
+                    if (st < nsteps) { weights(p1, k1, st, std::false_type{}); contract(p1, k1, b1); }
+                } else {
+                    for (; st < nsteps; ++st) {
+#pragma unroll
+                        for (int u = 0; u < NP; ++u)
+#pragma unroll
+                            for (int t = 0; t < CT; ++t) b1[u][t] = b0[u][t];
+                        load_step(b0, st + 1);
+                        if (st < nfull) weights(p0, k0, st, std::true_type{});
+                        else weights(p0, k0, st, std::false_type{});
+                        contract(p0, k0, b1);
+                    }
                 }
             }
         }
