@@ -246,7 +246,7 @@ constexpr int LBN = 64, LBK = 32;
 constexpr int LPK = LBK + 4;      // row pitch of the [i][k] layouts (floats): 144 B, 16-B aligned, bank-skewed
 constexpr int LPN = LBN + 4;      // [k][n]
 
-template <int LBM, bool A_KC, bool B_KC, int EPI>
+template <int LBM, bool A_KC, bool B_KC, int EPI, bool BF>
 __global__ __launch_bounds__(256) void gemm_lds_kernel(GemmArgs g) {
     constexpr int LPM = LBM + 4;      // [k][m]
     constexpr int TN = LBM / 64;      // accumulator tiles per wave
@@ -261,7 +261,6 @@ __global__ __launch_bounds__(256) void gemm_lds_kernel(GemmArgs g) {
     const int kbeg = blockIdx.z * g.k_slab;
     const int kend = min(g.K, kbeg + g.k_slab);
     const __amdgpu_buffer_rsrc_t ra = make_rsrc(g.A, g.a_bytes);
-    const __amdgpu_buffer_rsrc_t rz = make_rsrc(g.a_gz ? g.a_gz : g.A, g.a_bytes);
     const __amdgpu_buffer_rsrc_t rb = make_rsrc(g.B, g.b_bytes);
     const int n_real = (EPI == EPI_ATOMIC && g.ones_col >= 0) ? g.N - 1 : g.N;   // columns that exist in memory
 
@@ -281,18 +280,7 @@ __global__ __launch_bounds__(256) void gemm_lds_kernel(GemmArgs g) {
                 ok = k < kend && m < g.M;
                 off = ((unsigned)k * (unsigned)g.a_cs + (unsigned)m) * 4u;
             }
-            buf_load4(ra, ok ? off : g.a_bytes, sa[p]);
-            if (A_KC && g.a_gz) {      // prologue: A *= gelu'(Z), optionally kept (dZ2)
-                float zv[4];
-                buf_load4(rz, ok ? off : g.a_bytes, zv);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) sa[p][e] *= gelu_erf_grad(zv[e]);
-                if (g.a_out && blockIdx.x == 0 && ok) {
-                    const int row = m0 + p * 32 + (tid >> 3), k = kc + (tid & 7) * 4;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) g.a_out[(long)row * g.a_out_rs + (long)(k + e) * g.a_out_cs] = sa[p][e];
-                }
-            }
+            buf_load4(ra, ok ? off : g.a_bytes, sa[p]);     // (a trailing-gelu prologue runs as its own pass before this kernel)
         }
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
@@ -360,7 +348,7 @@ __global__ __launch_bounds__(256) void gemm_lds_kernel(GemmArgs g) {
                 }
             }
             if (want_rowsum) rsum += (av[0] + av[1]) + (av[2] + av[3]);
-            if (g.bf16) {
+            if (BF) {                  // compile-time: a runtime branch here shuttles the accumulators between register files
                 const bf16x4 ap = pack_bf16(av[0], av[1], av[2], av[3]);
 #pragma unroll
                 for (int t = 0; t < TN; ++t)
@@ -463,19 +451,24 @@ bool try_launch_gemm_lds(GemmArgs g, hipStream_t s) {
         g.k_slab = slab;
     }
     dim3 grid(gx, gy, splits), block(256);
-#define PIT_LDS(A_, B_, EPI_)                                                                              \
-    do {                                                                                                   \
-        if (bm == 128) hipLaunchKernelGGL((gemm_lds_kernel<128, A_, B_, EPI_>), grid, block, 0, s, g);     \
-        else hipLaunchKernelGGL((gemm_lds_kernel<64, A_, B_, EPI_>), grid, block, 0, s, g);                \
+#define PIT_LDS_BF(A_, B_, EPI_, BF_)                                                                         \
+    do {                                                                                                       \
+        if (bm == 128) hipLaunchKernelGGL((gemm_lds_kernel<128, A_, B_, EPI_, BF_>), grid, block, 0, s, g);    \
+        else hipLaunchKernelGGL((gemm_lds_kernel<64, A_, B_, EPI_, BF_>), grid, block, 0, s, g);               \
     } while (0)
+#define PIT_LDS(A_, B_, EPI_) do { if (g.bf16) PIT_LDS_BF(A_, B_, EPI_, true); else PIT_LDS_BF(A_, B_, EPI_, false); } while (0)
     switch (kind) {
         case 0: PIT_LDS(true, true, EPI_BIAS); break;
         case 1: PIT_LDS(true, true, EPI_BIAS_GELU); break;
         case 2: PIT_LDS(true, false, EPI_MUL_GELU_GRAD); break;
         case 3: PIT_LDS(true, false, EPI_STORE); break;
-        default: hipLaunchKernelGGL((gemm_lds_kernel<128, false, false, EPI_ATOMIC>), grid, block, 0, s, g); break;
+        default:
+            if (g.bf16) hipLaunchKernelGGL((gemm_lds_kernel<128, false, false, EPI_ATOMIC, true>), grid, block, 0, s, g);
+            else hipLaunchKernelGGL((gemm_lds_kernel<128, false, false, EPI_ATOMIC, false>), grid, block, 0, s, g);
+            break;
     }
 #undef PIT_LDS
+#undef PIT_LDS_BF
     return true;
 }
 
