@@ -407,6 +407,173 @@ __global__ __launch_bounds__(256) void mul_gelu_grad_kernel(const float* a, long
     }
 }
 
+// ------------------------------------------------------------------------------------
+// Thin contractions of the output layer (out_dim = n2 in {1..4}: pit.py:106 `de`): with one
+// dimension that small an MFMA tile is 31/32 padding and the operation is a memory-bound
+// elementwise / row-dot / column-sum pass.  Used for large row counts only (the small regime stays
+// on the latency-optimised GEMM).
+constexpr int THIN_MAX = 4;
+
+// dZ1[m,n] = (sum_k dY[m,k] * W2[k,n]) * gelu'(Z1[m,n]),  K = n2 <= 4   (optionally dY *= gelu'(Z2), kept)
+__global__ __launch_bounds__(256) void thin_dz1_kernel(GemmArgs g) {
+    const int nq = g.N / 4;
+    const long total = (long)g.M * nq;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long m = i / nq;
+        const int n = (int)(i - m * nq) * 4;
+        float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        for (int k = 0; k < g.K; ++k) {
+            float a = g.A[m * g.a_rs + k];
+            if (g.a_gz) {
+                a *= gelu_erf_grad(g.a_gz[m * g.a_rs + k]);
+                if (g.a_out && n == 0) g.a_out[m * g.a_out_rs + k * g.a_out_cs] = a;
+            }
+            const float4 w = *reinterpret_cast<const float4*>(g.B + (long)k * g.b_rs + n);
+            acc[0] += a * w.x; acc[1] += a * w.y; acc[2] += a * w.z; acc[3] += a * w.w;
+        }
+        const float4 z = *reinterpret_cast<const float4*>(g.G + m * g.ldg + n);
+        float4 o;
+        o.x = acc[0] * gelu_erf_grad(z.x); o.y = acc[1] * gelu_erf_grad(z.y);
+        o.z = acc[2] * gelu_erf_grad(z.z); o.w = acc[3] * gelu_erf_grad(z.w);
+        *reinterpret_cast<float4*>(g.C + m * g.ldc + n) = o;
+    }
+}
+
+// Y[m,n] = sum_k H[m,k] * W2[n,k] + b[n] (optionally gelu, Z kept),  N = n2 <= 4: tpr = K/4 (<= 64)
+// lanes share a row (one 16-B load each per 4*tpr columns), 64/tpr rows per wavefront and pass
+__global__ __launch_bounds__(256) void thin_fwd_kernel(GemmArgs g, int tpr) {
+    const int lane = threadIdx.x & 63;
+    const int q = lane % tpr, sub = lane / tpr, rpw = 64 / tpr;
+    const long wave0 = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((long)gridDim.x * blockDim.x) >> 6;
+    for (long mbase = wave0 * rpw; mbase < g.M; mbase += nwaves * rpw) {
+        const long m = mbase + sub;
+        const bool mv = m < g.M;
+        float acc[THIN_MAX] = {0.0f, 0.0f, 0.0f, 0.0f};
+        for (int k = q * 4; k < g.K; k += tpr * 4) {
+            const float4 h = mv ? *reinterpret_cast<const float4*>(g.A + m * g.a_rs + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int n = 0; n < THIN_MAX; ++n) {
+                if (n >= g.N) break;
+                const float4 w = *reinterpret_cast<const float4*>(g.B + (long)n * g.b_cs + k);
+                acc[n] += (h.x * w.x + h.y * w.y) + (h.z * w.z + h.w * w.w);
+            }
+        }
+#pragma unroll
+        for (int n = 0; n < THIN_MAX; ++n)
+            if (n < g.N)                                          // wave-uniform
+                for (int o = tpr >> 1; o > 0; o >>= 1) acc[n] += __shfl_xor(acc[n], o);
+        if (mv && q < g.N) {
+            float v = (q == 0 ? acc[0] : q == 1 ? acc[1] : q == 2 ? acc[2] : acc[3]) + g.bias[q];
+            if (g.epi == EPI_BIAS_GELU) { g.Z[m * g.ldz + q] = v; v = gelu_erf(v); }
+            g.C[m * g.ldc + q] = v;
+        }
+    }
+}
+
+// dW[j,n] += sum_m dZ[m,j] * X[m,n],  db[j] += sum_m dZ[m,j],  j < n2 <= 4: a workgroup owns a slab of
+// rows, thread t the columns [4t, 4t+4) (and its copies for wider rows); fp32 atomics at the end
+__global__ __launch_bounds__(256) void thin_dw_kernel(GemmArgs g, int slab) {
+    __shared__ float s_red[256 * 4 * THIN_MAX];                   // [group][j][column] partial sums
+    __shared__ float s_bias[4][THIN_MAX];
+    const int n_real = g.N - 1;                                   // last "column" is the virtual ones column (bias)
+    const long k0 = (long)blockIdx.x * slab, k1 = min((long)g.K, k0 + slab);
+    // tpr threads cover one row (4 columns each), the 256/tpr thread groups interleave the slab's rows;
+    // partial sums meet in LDS so that the workgroup issues ONE atomic per output element
+    int tpr = 1;
+    while (tpr < 256 && tpr * 4 < n_real) tpr <<= 1;
+    const int groups = 256 / tpr, q = threadIdx.x % tpr, grp = threadIdx.x / tpr;
+    const int ncov = tpr * 4;                                     // columns covered per pass
+    for (int nb = 0; nb < n_real; nb += ncov) {
+        const int n = nb + q * 4;
+        float acc[THIN_MAX][4];
+#pragma unroll
+        for (int j = 0; j < THIN_MAX; ++j) { acc[j][0] = acc[j][1] = acc[j][2] = acc[j][3] = 0.0f; }
+        if (n < n_real) {
+            long k = k0 + grp;
+            for (; k + 3L * groups < k1; k += 4L * groups) {      // four rows in flight per thread
+                float4 x[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) x[r] = *reinterpret_cast<const float4*>(g.B + (k + (long)r * groups) * g.b_rs + n);
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int j = 0; j < THIN_MAX; ++j) {
+                        if (j >= g.M) break;
+                        const float d = g.A[(k + (long)r * groups) * g.a_cs + j];
+                        acc[j][0] += d * x[r].x; acc[j][1] += d * x[r].y; acc[j][2] += d * x[r].z; acc[j][3] += d * x[r].w;
+                    }
+            }
+            for (; k < k1; k += groups) {
+                const float4 x = *reinterpret_cast<const float4*>(g.B + k * g.b_rs + n);
+#pragma unroll
+                for (int j = 0; j < THIN_MAX; ++j) {
+                    if (j >= g.M) break;
+                    const float d = g.A[k * g.a_cs + j];
+                    acc[j][0] += d * x.x; acc[j][1] += d * x.y; acc[j][2] += d * x.z; acc[j][3] += d * x.w;
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < THIN_MAX; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s_red[(grp * THIN_MAX + j) * ncov + q * 4 + e] = acc[j][e];
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < g.M * ncov; idx += 256) {
+            const int j = idx / ncov, col = idx - j * ncov;
+            if (nb + col >= n_real) continue;
+            float v = 0.0f;
+            for (int gq = 0; gq < groups; ++gq) v += s_red[(gq * THIN_MAX + j) * ncov + col];
+            atomicAdd(g.C + (long)j * g.ldc + nb + col, v);
+        }
+    }
+    if (g.C2) {                                                   // bias gradient: column sums of dZ over the slab
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        for (int j = 0; j < g.M; ++j) {
+            float sum = 0.0f;
+            for (long k = k0 + threadIdx.x; k < k1; k += 256) sum += g.A[k * g.a_cs + j];
+            sum = wave_sum(sum);
+            if (lane == 0) s_bias[wave][j] = sum;
+        }
+        __syncthreads();
+        if (threadIdx.x < g.M)
+            atomicAdd(g.C2 + threadIdx.x, s_bias[0][threadIdx.x] + s_bias[1][threadIdx.x] + s_bias[2][threadIdx.x] + s_bias[3][threadIdx.x]);
+    }
+}
+
+bool aligned16(const void* p);
+
+// true if one of the thin kernels took the contraction
+bool try_launch_thin(const GemmArgs& g, hipStream_t s) {
+    static const bool off = getenv("PIT_NO_THIN_GEMM") != nullptr;
+    if (off) return false;
+    if (g.epi == EPI_MUL_GELU_GRAD && g.K <= THIN_MAX && g.a_cs == 1 && g.b_cs == 1 && g.N % 4 == 0 && g.b_rs % 4 == 0 &&
+        g.ldg % 4 == 0 && g.ldc % 4 == 0 && aligned16(g.B) && aligned16(g.G) && aligned16(g.C) &&
+        (long)g.M * g.N >= (1L << 20)) {
+        const long quads = (long)g.M * (g.N / 4);
+        hipLaunchKernelGGL(thin_dz1_kernel, dim3((unsigned)std::min<long>((quads + 255) / 256, 8192)), dim3(256), 0, s, g);
+        return true;
+    }
+    if ((g.epi == EPI_BIAS || g.epi == EPI_BIAS_GELU) && g.N <= THIN_MAX && g.a_cs == 1 && g.b_rs == 1 && g.K % 4 == 0 &&
+        g.a_rs % 4 == 0 && g.b_cs % 4 == 0 && aligned16(g.A) && aligned16(g.B) && !g.a_gz && (long)g.M * g.K >= (1L << 20)) {
+        int tpr = 4;                                              // lanes per row: >= n2 (one output column each), <= 64
+        while (tpr < 64 && tpr * 4 < g.K) tpr <<= 1;
+        const long rows_per_wg = 4L * (64 / tpr);
+        hipLaunchKernelGGL(thin_fwd_kernel, dim3((unsigned)std::min<long>((g.M + rows_per_wg - 1) / rows_per_wg, 16384)),
+                           dim3(256), 0, s, g, tpr);
+        return true;
+    }
+    if (g.epi == EPI_ATOMIC && g.M <= THIN_MAX && g.ones_col == g.N - 1 && g.a_rs == 1 && g.b_cs == 1 && (g.N - 1) % 4 == 0 &&
+        g.b_rs % 4 == 0 && aligned16(g.B) && !g.a_gz && g.K >= 8192) {
+        // one workgroup per CU: every workgroup ends with one atomic per output element, and atomics on
+        // one address serialise in L2 (~40 ns each) - 256 of them cost less than the pass over the rows
+        const int slab = std::max(256, ((g.K + 255) / 256 + 15) / 16 * 16);
+        hipLaunchKernelGGL(thin_dw_kernel, dim3((unsigned)((g.K + slab - 1) / slab)), dim3(256), 0, s, g, slab);
+        return true;
+    }
+    return false;
+}
+
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 // 0 = not eligible; otherwise launches the LDS-staged kernel (called after prepare_gemm filled the
@@ -517,6 +684,7 @@ bool try_launch_gemm_lds(GemmArgs g, hipStream_t s);
 int launch_gemm(GemmArgs g, hipStream_t s) {
     GemmLaunch L;
     if (int rc = prepare_gemm(g, L)) return rc;
+    if (try_launch_thin(g, s)) return 0;
     if (try_launch_gemm_lds(g, s)) return 0;
     const int tn = L.tn;
     dim3 grid = L.grid, block(64 * L.nwaves);

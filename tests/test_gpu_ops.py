@@ -179,7 +179,9 @@ def test_mlp_forward_backward(ops, name):
 
 
 @pytest.mark.parametrize("rows,n0,n1,n2", [(300, 24, 32, 32), (1000, 192, 64, 64), (77, 5, 130, 3),
-                                            (3000, 200, 130, 70), (2304, 768, 256, 256)])   # last two: LDS-tiled GEMM
+                                            (3000, 200, 130, 70), (2304, 768, 256, 256),    # LDS-tiled GEMM
+                                            (20000, 128, 64, 1), (9000, 64, 128, 4),        # thin output layer (n2 <= 4)
+                                            (8200, 32, 256, 3)])
 def test_mlp_trailing_gelu_vs_oracle(ops, rows, n0, n1, n2):
     """The fused trailing gelu of pit.py:111,121 (out_gelu=True) against torch on the CPU."""
     shapes = [("mlp1.weight", (n1, n0)), ("mlp1.bias", (n1,)), ("mlp2.weight", (n2, n1)), ("mlp2.bias", (n2,))]
@@ -449,3 +451,23 @@ def test_checked_load_variant_in_a_subprocess():
                        env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert " passed" in r.stdout
+
+
+@pytest.mark.parametrize("rows,n0,n1,n2", [(20000, 128, 64, 1), (16400, 256, 128, 4)])
+def test_mlp_thin_output_layer_vs_oracle(ops, rows, n0, n1, n2):
+    """The decoder's output MLP (pit.py:106, out_dim in {1,4}) at large row counts takes the thin
+    kernels (row dots / outer product / column sums instead of MFMA tiles); no trailing gelu."""
+    shapes = [("mlp1.weight", (n1, n0)), ("mlp1.bias", (n1,)), ("mlp2.weight", (n2, n1)), ("mlp2.bias", (n2,))]
+    pc = {k: torch.from_numpy(v).requires_grad_(True) for k, v in gio.synth_params(shapes, 17).items()}
+    pg = {k: v.detach().cuda().requires_grad_(True) for k, v in pc.items()}
+    xc = torch.from_numpy(gio.synth((rows, n0), 18)).requires_grad_(True)
+    xg = xc.detach().cuda().requires_grad_(True)
+    dy = torch.from_numpy(gio.synth((rows, n2), 19))
+    yc = orc.mlp(xc, pc["mlp1.weight"], pc["mlp1.bias"], pc["mlp2.weight"], pc["mlp2.bias"])
+    yc.backward(dy)
+    yg = ops.mlp_apply(xg, pg["mlp1.weight"], pg["mlp1.bias"], pg["mlp2.weight"], pg["mlp2.bias"], False)
+    yg.backward(dy.cuda())
+    assert gio.rel_l2(yc.detach().numpy(), yg.detach().cpu().numpy()) <= TOL_FWD
+    assert gio.rel_l2(xc.grad.numpy(), xg.grad.cpu().numpy()) <= TOL_GRAD
+    for k in pc:
+        assert gio.rel_l2(pc[k].grad.numpy(), pg[k].grad.cpu().numpy()) <= TOL_GRAD, k
