@@ -863,31 +863,36 @@ __global__ __launch_bounds__(512) void posatt_rows_tiles(AttArgs a) {
             s_xi[idx] = load_point4(rmi, mi_bytes, (long)mb * a.n_in + c0 + idx, a.sdim, a.coords_used);
         __syncthreads();
         // ---- weight phase: this wave fills keys [8*GW*wave, 8*GW*(wave+1)) of the chunk, all RT row tiles
+        // (the periodic wrap is a compile-time variant: as a runtime flag it is if-converted into every distance)
+        auto fill = [&](auto per_tag) {
+            constexpr bool PER = decltype(per_tag)::value;
 #pragma unroll
-        for (int it = 0; it < GW; ++it) {
-            const int g = wave * GW + it;
-            bool anyk = false;
+            for (int it = 0; it < GW; ++it) {
+                const int g = wave * GW + it;
+                bool anyk = false;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int jl = g * 8 + 2 * u + half;
-                const bool jv = jl < len;
-                const float4 xi = s_xi[jv ? jl : 0];
+                for (int u = 0; u < 4; ++u) {
+                    const int jl = g * 8 + 2 * u + half;
+                    const bool jv = jl < len;
+                    const float4 xi = s_xi[jv ? jl : 0];
 #pragma unroll
-                for (int rt = 0; rt < RT; ++rt) {
-                    const float m = sq_dist3(xo[rt].x, xo[rt].y, xo[rt].z, xi.x, xi.y, xi.z, per, a.period);
-                    const float sv = __fmul_rn(m, c);
-                    const bool keep = jv && nvalid[rt] && (sv <= T[rt]);
-                    const float p = keep ? __expf(s_min[rt] - sv) : 0.0f;
-                    float w = p;
-                    if (MODE == 0) { rsum[rt] += p; qsum[rt] += p * m; }
-                    else w = p * (m - mbar[rt]) * inv_l[rt];
-                    Ps[(jl * RT + rt) * 32 + l31] = w;
-                    anyk |= keep;
+                    for (int rt = 0; rt < RT; ++rt) {
+                        const float m = sq_dist3t<PER>(xo[rt].x, xo[rt].y, xo[rt].z, xi.x, xi.y, xi.z, a.period);
+                        const float sv = __fmul_rn(m, c);
+                        const bool keep = jv && nvalid[rt] && (sv <= T[rt]);
+                        const float p = keep ? __expf(s_min[rt] - sv) : 0.0f;
+                        float w = p;
+                        if (MODE == 0) { rsum[rt] += p; qsum[rt] += p * m; }
+                        else w = p * (m - mbar[rt]) * inv_l[rt];
+                        Ps[(jl * RT + rt) * 32 + l31] = w;
+                        anyk |= keep;
+                    }
                 }
+                const bool flag = __builtin_amdgcn_ballot_w64(anyk) != 0ull;
+                if (lane == 0) s_flag[g] = flag ? 1 : 0;
             }
-            const bool flag = __builtin_amdgcn_ballot_w64(anyk) != 0ull;
-            if (lane == 0) s_flag[g] = flag ? 1 : 0;
-        }
+        };
+        if (per) fill(std::true_type{}); else fill(std::false_type{});
         __syncthreads();
         // ---- contraction phase: every wave walks the whole chunk for its own tiles
         for (int g = 0; g < ngroups; ++g) {
@@ -1071,25 +1076,29 @@ __global__ __launch_bounds__(512) void posatt_cols_tiles(AttArgs a) {
                 s_rec[2 * idx + 1] = r1;
             }
             __syncthreads();
+            auto fill = [&](auto per_tag) {
+                constexpr bool PER = decltype(per_tag)::value;
 #pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                const int g = wave * 4 + it;
-                bool anyk = false;
+                for (int it = 0; it < 4; ++it) {
+                    const int g = wave * 4 + it;
+                    bool anyk = false;
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int nl = g * 8 + 2 * u + half;
-                    const bool nv = nl < len;
-                    const float4 r0 = s_rec[2 * (nv ? nl : 0)];
-                    const float4 r1 = s_rec[2 * (nv ? nl : 0) + 1];
-                    const float m = sq_dist3(r0.x, r0.y, r0.z, xi.x, xi.y, xi.z, per, a.period);
-                    const float sv = __fmul_rn(m, c);
-                    const bool keep = nv && jvalid && (sv <= r0.w);
-                    Ps[nl * 32 + l31] = keep ? __expf(r1.x - sv) * r1.y : 0.0f;
-                    anyk |= keep;
+                    for (int u = 0; u < 4; ++u) {
+                        const int nl = g * 8 + 2 * u + half;
+                        const bool nv = nl < len;
+                        const float4 r0 = s_rec[2 * (nv ? nl : 0)];
+                        const float4 r1 = s_rec[2 * (nv ? nl : 0) + 1];
+                        const float m = sq_dist3t<PER>(r0.x, r0.y, r0.z, xi.x, xi.y, xi.z, a.period);
+                        const float sv = __fmul_rn(m, c);
+                        const bool keep = nv && jvalid && (sv <= r0.w);
+                        Ps[nl * 32 + l31] = keep ? __expf(r1.x - sv) * r1.y : 0.0f;
+                        anyk |= keep;
+                    }
+                    const bool flag = __builtin_amdgcn_ballot_w64(anyk) != 0ull;
+                    if (lane == 0) s_flag[g] = flag ? 1 : 0;
                 }
-                const bool flag = __builtin_amdgcn_ballot_w64(anyk) != 0ull;
-                if (lane == 0) s_flag[g] = flag ? 1 : 0;
-            }
+            };
+            if (per) fill(std::true_type{}); else fill(std::false_type{});
             __syncthreads();
             for (int g = 0; g < ngroups; ++g) {
                 float bcur[4][TPW];
