@@ -25,11 +25,27 @@ def _stale() -> bool:
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
-    """Compile if missing or out of date; returns the library path."""
-    srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    """Compile if missing or out of date; returns the library path.  The translation units are
+    compiled in parallel (objects under csrc/_obj, not tracked) and linked into one library."""
+    srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
     if force or _stale():
+        from concurrent.futures import ThreadPoolExecutor
         hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-        cmd = [hipcc] + FLAGS + ["-o", LIB] + srcs
+        objdir = os.path.join(CSRC, "_obj")
+        os.makedirs(objdir, exist_ok=True)
+        cflags = [f for f in FLAGS if f != "-shared"]
+
+        def compile_one(src: str) -> str:
+            obj = os.path.join(objdir, src.replace(".hip", ".o"))
+            cmd = [hipcc] + cflags + ["-c", os.path.join(CSRC, src), "-o", obj]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.run(cmd, check=True, cwd=CSRC)
+            return obj
+
+        with ThreadPoolExecutor(max_workers=min(len(srcs), os.cpu_count() or 1)) as pool:
+            objs = list(pool.map(compile_one, srcs))
+        cmd = [hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", LIB] + objs
         if verbose:
             print(" ".join(cmd))
         subprocess.run(cmd, check=True, cwd=CSRC)
