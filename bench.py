@@ -40,6 +40,15 @@ FP32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32,
 GFLOP_PER_SAMPLE = {"darcy": 0.781, "burgers": 0.643, "vorticity": 9.126, "elasticity": 22.406, "naca": 10.005}
 
 
+WORKLOADS = {
+    "darcy": "darcy2d 43x43 grid->16x16 latent, pit_fixed hid64 H2 blocks4 loc0.02, RelL2 (train_darcy.py:64-111)",
+    "burgers": "burgers1d 1024->256 latent, pit_periodic1d hid64 H2 blocks5 loc0.02, RelL1 (train_burgers.py:51-78)",
+    "sod": "sod1d 1024->256 latent, pit_fixed hid32 H1 blocks2 (train_sod.py:55-76)",
+    "vorticity": "vorticity2d 64x64->16x16 latent, pit_periodic2d hid256 H2 blocks4 + InstanceNorm, RelL2 (train_vorticity.py:65-106)",
+    "elasticity": "elasticity 972-point clouds, pit hid256 H2 blocks4, per-sample meshes (train_elasticity.py:56-75)",
+    "naca": "naca 120->728->221x51, pit hid128 H1 blocks4, per-sample meshes (train_naca.py:68-89)",
+    "cylinder": "cylinder 4390->896->4390, pit_fixed hid256 H1 blocks4 loc0.01 (train_cylinder.py:55-84)",
+}
 T_START = time.perf_counter()
 
 
@@ -295,13 +304,13 @@ def main():
 
     if rank == 0:
         rec = {
-            "metric": "PiT fwd+bwd samples/sec on Darcy2D", "value": round(value, 1), "unit": "samples/s",
+            "metric": "PiT fwd+bwd samples/sec on Darcy2D" if args.task == "darcy" else f"PiT fwd+bwd samples/sec on {args.task}",
+            "value": round(value, 1), "unit": "samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if args.math == "fp32" else "bf16 MFMA operands, f32 accumulate",
             "data": "synthetic",
-            "config": {"workload": f"{args.task}2d 43x43 grid->16x16 latent, pit_fixed hid64 H2 blocks4 loc0.02, "
-                                   f"fwd+RelL2 loss+bwd, per-GPU batch {args.batch} (train_darcy.py:64-111)",
+            "config": {"workload": WORKLOADS.get(args.task, args.task) + f", fwd+loss+bwd, per-GPU batch {args.batch}",
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world,
                        "parallelism": f"dp{world}" if world > 1 else "single", "launch": mode},
             "loss": round(loss_val, 6),
