@@ -1531,6 +1531,26 @@ __global__ __launch_bounds__(256) void posatt_sparse_rows(AttArgs a, SparseArgs 
     sparse_rows_body<NH, CR, MODE>(a, sp, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
+// XCD-aware launch order for many column blocks (batch folded into the columns): workgroups are dealt
+// round-robin to the 8 XCDs by their linear id, so id % 8 selects the column block residue - every
+// XCD's L2 then holds only its own column slices of the gathered rows instead of all of them.
+// 1-D grid of 8 * gx * ceil(gy/8) * gz workgroups; (gx, gy) = row groups, column blocks.
+__device__ __forceinline__ bool xcd_remap(int id, int gx, int gy, int& bx, int& by, int& bz) {
+    const int gyc = (gy + 7) / 8;
+    const int xcd = id & 7, t = id >> 3;
+    bx = t % gx;
+    const int u = t / gx;
+    by = (u % gyc) * 8 + xcd;
+    bz = u / gyc;
+    return by < gy;
+}
+template <int NH, int CR, int MODE>
+__global__ __launch_bounds__(256) void posatt_sparse_rows_x(AttArgs a, SparseArgs sp, int gx, int gy) {
+    int bx, by, bz;
+    if (!xcd_remap((int)blockIdx.x, gx, gy, bx, by, bz)) return;
+    sparse_rows_body<NH, CR, MODE>(a, sp, bx, by, bz);
+}
+
 template <int CR>
 __device__ __forceinline__ void sparse_cols_body(const AttArgs& a, const SparseArgs& sp, const int bx, const int by) {
     constexpr int G = (CR >= 4) ? 4 : 8;
@@ -1617,6 +1637,12 @@ template <int CR>
 __global__ __launch_bounds__(256) void posatt_sparse_cols(AttArgs a, SparseArgs sp) {
     sparse_cols_body<CR>(a, sp, blockIdx.x, blockIdx.y);
 }
+template <int CR>
+__global__ __launch_bounds__(256) void posatt_sparse_cols_x(AttArgs a, SparseArgs sp, int gx, int gy) {
+    int bx, by, bz;
+    if (!xcd_remap((int)blockIdx.x, gx, gy, bx, by, bz)) return;
+    sparse_cols_body<CR>(a, sp, bx, by);
+}
 
 // rows whose candidate list overflowed are not in the transposed lists: add their contribution
 // to d(values) with atomics (rare: duplicated points / massive ties).
@@ -1695,7 +1721,14 @@ void launch_sparse_rows(const AttArgs& a, const SparseArgs& sp, hipStream_t s) {
     const long rows = (long)a.mesh_batch * a.n_out;
     const int cr = cr_for(a.ncols, rows * (a.n_head / nh));
     dim3 grid((unsigned)((rows + 3) / 4), (a.ncols + 64 * cr - 1) / (64 * cr), a.n_head / nh), block(256);
-#define PIT_SR(NH_, CR_) hipLaunchKernelGGL((posatt_sparse_rows<NH_, CR_, MODE>), grid, block, 0, s, a, sp)
+    const long xtotal = 8L * grid.x * ((grid.y + 7) / 8) * grid.z;
+    const bool remap = grid.y >= 16 && xtotal < 0x7fffffffL && !env_int("PIT_NO_XCD_REMAP");   // (few blocks: padding costs more than locality gains)
+#define PIT_SR(NH_, CR_)                                                                                              \
+    do {                                                                                                              \
+        if (remap) hipLaunchKernelGGL((posatt_sparse_rows_x<NH_, CR_, MODE>), dim3((unsigned)xtotal), block, 0, s, a, sp, \
+                                      (int)grid.x, (int)grid.y);                                                      \
+        else hipLaunchKernelGGL((posatt_sparse_rows<NH_, CR_, MODE>), grid, block, 0, s, a, sp);                      \
+    } while (0)
 #define PIT_SR_CR(NH_) do { if (cr == 8) PIT_SR(NH_, 8); else if (cr == 4) PIT_SR(NH_, 4); else if (cr == 2) PIT_SR(NH_, 2); else PIT_SR(NH_, 1); } while (0)
     if (nh == 2) PIT_SR_CR(2); else PIT_SR_CR(1);
 #undef PIT_SR_CR
@@ -1732,10 +1765,16 @@ void launch_sparse_cols(const AttArgs& a, const SparseArgs& sp, bool complete, h
     const long keys = (long)a.mesh_batch * a.n_in;
     const int cr = cr_for(a.ncols, keys);
     dim3 grid((unsigned)((keys + 3) / 4), (a.ncols + 64 * cr - 1) / (64 * cr)), block(256);
-    if (cr == 8) hipLaunchKernelGGL((posatt_sparse_cols<8>), grid, block, 0, s, a, sp);
-    else if (cr == 4) hipLaunchKernelGGL((posatt_sparse_cols<4>), grid, block, 0, s, a, sp);
-    else if (cr == 2) hipLaunchKernelGGL((posatt_sparse_cols<2>), grid, block, 0, s, a, sp);
-    else hipLaunchKernelGGL((posatt_sparse_cols<1>), grid, block, 0, s, a, sp);
+    const long xtotal = 8L * grid.x * ((grid.y + 7) / 8);
+    const bool remap = grid.y >= 16 && xtotal < 0x7fffffffL && !env_int("PIT_NO_XCD_REMAP");   // (few blocks: padding costs more than locality gains)
+#define PIT_SC(CR_)                                                                                                   \
+    do {                                                                                                              \
+        if (remap) hipLaunchKernelGGL((posatt_sparse_cols_x<CR_>), dim3((unsigned)xtotal), block, 0, s, a, sp,        \
+                                      (int)grid.x, (int)grid.y);                                                      \
+        else hipLaunchKernelGGL((posatt_sparse_cols<CR_>), grid, block, 0, s, a, sp);                                 \
+    } while (0)
+    if (cr == 8) PIT_SC(8); else if (cr == 4) PIT_SC(4); else if (cr == 2) PIT_SC(2); else PIT_SC(1);
+#undef PIT_SC
     const long rows = (long)a.mesh_batch * a.n_out;
     if (!complete) hipLaunchKernelGGL(posatt_sparse_overflow_cols, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, a, sp);
 }
