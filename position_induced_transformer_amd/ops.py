@@ -93,6 +93,8 @@ def _layer_workspace(slot: torch.Tensor, n_head: int) -> torch.Tensor:
     key = (slot.device.index, slot.data_ptr(), n_head)
     ws = _LAYER_WS.get(key)
     if ws is None:
+        if len(_LAYER_WS) >= 1024:            # gradient buffers were re-created many times: drop stale entries
+            _LAYER_WS.clear()
         ws = _LAYER_WS[key] = torch.zeros(n_head * 1024, device=slot.device, dtype=torch.float64)
     return ws
 
