@@ -410,7 +410,7 @@ __global__ __launch_bounds__(256) void mul_gelu_grad_kernel(const float* a, long
 // ------------------------------------------------------------------------------------
 // Thin contractions of the output layer (out_dim = n2 in {1..4}: pit.py:106 `de`): with one
 // dimension that small an MFMA tile is 31/32 padding and the operation is a memory-bound
-// elementwise / row-dot / column-sum pass.  Used for large row counts only (the small regime stays
+// elementwise / row-dot / column-sum pass.  Used from 2^19 outputs / 8192 reduced rows (the small regime stays
 // on the latency-optimised GEMM).
 constexpr int THIN_MAX = 4;
 
@@ -547,15 +547,17 @@ bool aligned16(const void* p);
 bool try_launch_thin(const GemmArgs& g, hipStream_t s) {
     static const bool off = getenv("PIT_NO_THIN_GEMM") != nullptr;
     if (off) return false;
+    static const long min_out = getenv("PIT_THIN_MIN") ? atol(getenv("PIT_THIN_MIN")) : (1L << 19);
+    static const long min_rows = getenv("PIT_THIN_MIN_ROWS") ? atol(getenv("PIT_THIN_MIN_ROWS")) : 8192;
     if (g.epi == EPI_MUL_GELU_GRAD && g.K <= THIN_MAX && g.a_cs == 1 && g.b_cs == 1 && g.N % 4 == 0 && g.b_rs % 4 == 0 &&
         g.ldg % 4 == 0 && g.ldc % 4 == 0 && aligned16(g.B) && aligned16(g.G) && aligned16(g.C) &&
-        (long)g.M * g.N >= (1L << 20)) {
+        (long)g.M * g.N >= min_out) {
         const long quads = (long)g.M * (g.N / 4);
         hipLaunchKernelGGL(thin_dz1_kernel, dim3((unsigned)std::min<long>((quads + 255) / 256, 8192)), dim3(256), 0, s, g);
         return true;
     }
     if ((g.epi == EPI_BIAS || g.epi == EPI_BIAS_GELU) && g.N <= THIN_MAX && g.a_cs == 1 && g.b_rs == 1 && g.K % 4 == 0 &&
-        g.a_rs % 4 == 0 && g.b_cs % 4 == 0 && aligned16(g.A) && aligned16(g.B) && !g.a_gz && (long)g.M * g.K >= (1L << 20)) {
+        g.a_rs % 4 == 0 && g.b_cs % 4 == 0 && aligned16(g.A) && aligned16(g.B) && !g.a_gz && (long)g.M * g.K >= min_out) {
         int tpr = 4;                                              // lanes per row: >= n2 (one output column each), <= 64
         while (tpr < 64 && tpr * 4 < g.K) tpr <<= 1;
         const long rows_per_wg = 4L * (64 / tpr);
@@ -564,7 +566,7 @@ bool try_launch_thin(const GemmArgs& g, hipStream_t s) {
         return true;
     }
     if (g.epi == EPI_ATOMIC && g.M <= THIN_MAX && g.ones_col == g.N - 1 && g.a_rs == 1 && g.b_cs == 1 && (g.N - 1) % 4 == 0 &&
-        g.b_rs % 4 == 0 && aligned16(g.B) && !g.a_gz && g.K >= 8192) {
+        g.b_rs % 4 == 0 && aligned16(g.B) && !g.a_gz && g.K >= min_rows) {
         // one workgroup per CU: every workgroup ends with one atomic per output element, and atomics on
         // one address serialise in L2 (~40 ns each) - 256 of them cost less than the pass over the rows
         const int slab = std::max(256, ((g.K + 255) / 256 + 15) / 16 * 16);
