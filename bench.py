@@ -98,7 +98,7 @@ def build_step(args, device, rank, world, batch, with_optimizer=False, all_reduc
     if with_optimizer:                    # Adam(1e-3) + CosineAnnealingLR as train_darcy.py:115-116, fused
         from position_induced_transformer_amd.ddp import FlatAdam, FlatGradients
         flat = FlatGradients(model.parameters(), flatten_params=True)
-        opt = FlatAdam(flat, lr=1e-3, cosine_t_max=30 * (1024 // 8))
+        opt = FlatAdam(flat, lr=1e-3, cosine_t_max=30 * (1024 // 8), zero_grads=True)
     use_ar = (world > 1) if all_reduce is None else all_reduce
     step = TrainStep(model, (mesh_in, func_in, mesh_out, target), meta["out_dim"], meta["p"], affine,
                      all_reduce=use_ar, optimizer=opt, flat=flat)

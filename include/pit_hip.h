@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define PIT_ABI_VERSION 5
+#define PIT_ABI_VERSION 6
 #define PIT_DSCALE_SLOTS 1024 /* fp64 accumulators per head in pit_posatt_bwd's workspace */
 
 /* distance metric (dist2att variants) */
@@ -218,11 +218,14 @@ int pit_instance_norm_bwd(const float* d_y, const float* y, const float* rstd, i
 
 /* torch.optim.Adam step (no amsgrad) over FLAT fp32 buffers of n elements, learning rate following
  * CosineAnnealingLR(T_max=cosine_t_max, eta_min) when cosine_t_max > 0 (train_darcy.py:115-116),
- * else constant lr0.  `step` (device int64, starts at 0) is incremented here; `scalars` is 3
- * floats of device scratch.  Two launches, no host sync: replayable from a hipGraph. */
-int pit_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long n,
+ * else constant lr0.  `step` (device int64, starts at 0) is incremented here; `scalars` is 4
+ * floats of device scratch, ZERO before the first call (slot 3 is an arrival ticket; slots 0-2
+ * receive lr_t and the bias corrections of the step taken).  With zero_grads=1 the gradients are
+ * cleared as they are consumed (the next backward pass accumulates into zeros: no memset launch).
+ * One launch, no host sync: replayable from a hipGraph. */
+int pit_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, long n,
                   long long* step, float lr0, float eta_min, int cosine_t_max, float beta1, float beta2,
-                  float eps, float weight_decay, float* scalars, void* stream);
+                  float eps, float weight_decay, int zero_grads, float* scalars, void* stream);
 
 /* Layout probe used by the tests: D = A(32x8) * B(8x32) through the same
  * v_mfma_f32_32x32x2_f32 fragment maps the kernels use. */

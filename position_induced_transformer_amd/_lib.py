@@ -51,7 +51,7 @@ SIGNATURES = {
     "pit_rel_lp_loss_bwd": [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P],
     "pit_instance_norm_fwd": [_P, _L, _L, _I, _I, _I, _F, _P, _P, _P],
     "pit_instance_norm_bwd": [_P, _P, _P, _I, _I, _I, _P, _P],
-    "pit_adam_step": [_P, _P, _P, _P, _L, _P, _F, _F, _I, _F, _F, _F, _F, _P, _P],
+    "pit_adam_step": [_P, _P, _P, _P, _L, _P, _F, _F, _I, _F, _F, _F, _F, _I, _P, _P],
     "pit_debug_mfma_tile": [_P, _P, _P, _P],
 }
 

@@ -28,20 +28,28 @@ class FlatGradients:
         if not self.params:
             raise ValueError("no trainable parameters")
         dev, dt = self.params[0].device, self.params[0].dtype
-        total = sum(p.numel() for p in self.params)
-        self.flat = torch.zeros(total, device=dev, dtype=dt)
-        self.flat_params = torch.empty(total, device=dev, dtype=dt) if flatten_params else None
-        off = 0
+        # every parameter starts on a 64-byte boundary of the flat buffers (zero padding in between):
+        # the GEMM kernels use 16-byte operand loads only on aligned weight matrices
+        align = 16
+        offsets, total = [], 0
         for p in self.params:
+            offsets.append(total)
+            total += (p.numel() + align - 1) // align * align
+        self.flat = torch.zeros(total, device=dev, dtype=dt)
+        self.flat_params = torch.zeros(total, device=dev, dtype=dt) if flatten_params else None
+        for p, off in zip(self.params, offsets):
             n = p.numel()
             p.grad = self.flat[off:off + n].view_as(p)
             if flatten_params:
                 self.flat_params[off:off + n].copy_(p.data.reshape(-1))
                 p.data = self.flat_params[off:off + n].view_as(p)
-            off += n
 
     def zero_(self) -> None:
         self.flat.zero_()
+
+    def dense(self) -> torch.Tensor:
+        """The gradients concatenated in parameter order WITHOUT the alignment padding (a copy)."""
+        return torch.cat([p.grad.reshape(-1) for p in self.params])
 
     def all_reduce(self, average: bool = False, group=None) -> None:
         """Sum (or average) the flat buffer over the ranks; no-op without a process group."""
@@ -73,17 +81,20 @@ class FlatAdam:
     scheduler.step(), with the step counter on the device (hipGraph-replayable, no host sync)."""
 
     def __init__(self, flat: FlatGradients, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
-                 weight_decay: float = 0.0, cosine_t_max: int = 0, eta_min: float = 0.0):
+                 weight_decay: float = 0.0, cosine_t_max: int = 0, eta_min: float = 0.0, zero_grads: bool = False):
         if flat.flat_params is None:
             raise ValueError("FlatAdam needs FlatGradients(..., flatten_params=True)")
         self.flat = flat
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
         self.cosine_t_max, self.eta_min = cosine_t_max, eta_min
+        # zero_grads: the update clears each gradient as it consumes it (= optimizer.zero_grad() fused in);
+        # engine.TrainStep then skips its own zeroing launch
+        self.zero_grads = bool(zero_grads)
         dev = flat.flat.device
         self.exp_avg = torch.zeros_like(flat.flat)
         self.exp_avg_sq = torch.zeros_like(flat.flat)
         self.step_count = torch.zeros((), device=dev, dtype=torch.int64)
-        self.scalars = torch.zeros(3, device=dev, dtype=torch.float32)
+        self.scalars = torch.zeros(4, device=dev, dtype=torch.float32)
 
     def step(self) -> None:
         from . import _lib
@@ -91,5 +102,6 @@ class FlatAdam:
         rc = _lib.lib().pit_adam_step(f.flat_params.data_ptr(), f.flat.data_ptr(), self.exp_avg.data_ptr(),
                                       self.exp_avg_sq.data_ptr(), f.flat.numel(), self.step_count.data_ptr(),
                                       self.lr, self.eta_min, self.cosine_t_max, self.betas[0], self.betas[1],
-                                      self.eps, self.weight_decay, self.scalars.data_ptr(), _lib.stream_ptr())
+                                      self.eps, self.weight_decay, 1 if self.zero_grads else 0,
+                                      self.scalars.data_ptr(), _lib.stream_ptr())
         _lib.check(rc, "pit_adam_step")

@@ -32,7 +32,8 @@ class TrainStep:
         self.graph: Optional[torch.cuda.CUDAGraph] = None
 
     def _step(self) -> None:
-        self.flat.zero_()
+        if not getattr(self.optimizer, "zero_grads", False):      # FlatAdam(zero_grads=True) clears them itself
+            self.flat.zero_()
         out = self.model(self.mesh_in, self.func_in, self.mesh_out)
         sc, sh = self.affine if self.affine is not None else (None, None)
         loss = ops.rel_lp_loss(self.target, out, self.out_dim, self.p, sc, sh)

@@ -106,22 +106,25 @@ def test_inplace_gradient_accumulation_matches_returned_gradients():
     flat = FlatGradients(model.parameters())
     assert ops.FUSED_GRAD_ACCUMULATION
     loss_fn(target, model(mesh_in, func_in, mesh_out)).backward()
-    assert gio.rel_l2(ref.cpu().numpy(), flat.flat.cpu().numpy()) <= 1e-5
+    assert gio.rel_l2(ref.cpu().numpy(), flat.dense().cpu().numpy()) <= 1e-5
     loss_fn(target, model(mesh_in, func_in, mesh_out)).backward()
-    assert gio.rel_l2(2.0 * ref.cpu().numpy(), flat.flat.cpu().numpy()) <= 1e-5
+    assert gio.rel_l2(2.0 * ref.cpu().numpy(), flat.dense().cpu().numpy()) <= 1e-5
 
 
-def test_fused_adam_matches_torch_adam_with_cosine_schedule():
+@pytest.mark.parametrize("zero_grads", [False, True])
+def test_fused_adam_matches_torch_adam_with_cosine_schedule(zero_grads):
     """ddp.FlatAdam (pit_adam_step) against torch.optim.Adam + CosineAnnealingLR on the CPU, ten
-    steps with fresh gradients each step (train_darcy.py:115-116,131-134)."""
+    steps with fresh gradients each step (train_darcy.py:115-116,131-134); with zero_grads the
+    update also clears the gradients it consumed.  Large enough for several workgroups (the step
+    counter is advanced by the last one to finish)."""
     from position_induced_transformer_amd.ddp import FlatAdam, FlatGradients
-    shapes = [(17, 5), (33,), (4, 1, 1), (129, 64)]
+    shapes = [(17, 5), (33,), (4, 1, 1), (129, 64), (700, 300)]
     cpu = [torch.nn.Parameter(torch.from_numpy(gio.synth(s, 60 + i))) for i, s in enumerate(shapes)]
     gpu = [torch.nn.Parameter(p.detach().clone().cuda()) for p in cpu]
     opt = torch.optim.Adam(cpu, lr=1e-3)
     sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=25)
     flat = FlatGradients(gpu, flatten_params=True)
-    fused = FlatAdam(flat, lr=1e-3, cosine_t_max=25)
+    fused = FlatAdam(flat, lr=1e-3, cosine_t_max=25, zero_grads=zero_grads)
     for step in range(10):
         for i, (pc, pg) in enumerate(zip(cpu, gpu)):
             g = torch.from_numpy(gio.synth(tuple(pc.shape), 100 * step + i)) * (1.0 + step)
@@ -130,6 +133,8 @@ def test_fused_adam_matches_torch_adam_with_cosine_schedule():
         opt.step()
         sched.step()
         fused.step()
+        if zero_grads:
+            assert float(flat.flat.abs().max()) == 0.0
     torch.cuda.synchronize()
     assert int(fused.step_count) == 10
     for pc, pg in zip(cpu, gpu):
