@@ -48,6 +48,7 @@ SIGNATURES = {
     "pit_mlp_bwd_data": [_I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _L, _P, _L, _P, _P],
     "pit_mlp_bwd_params": [_P, _L, _I, _I, _I, _I, _P, _I, _P, _L, _P, _P, _P, _P, _I, _P, _P],
     "pit_rel_lp_loss_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P],
+    "pit_rel_lp_loss_fwd_grad": [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _L, _P],
     "pit_rel_lp_loss_bwd": [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P],
     "pit_instance_norm_fwd": [_P, _L, _L, _I, _I, _I, _F, _P, _P, _P],
     "pit_instance_norm_bwd": [_P, _P, _P, _I, _I, _I, _P, _P],

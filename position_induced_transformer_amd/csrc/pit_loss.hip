@@ -18,8 +18,16 @@ __device__ __forceinline__ float pow_abs(float x, int p) {
 __global__ __launch_bounds__(256) void rel_lp_fwd_kernel(const float* __restrict__ tru, const float* __restrict__ pred,
                                                           const float* __restrict__ scale, const float* __restrict__ shift,
                                                           int npts, int nch, int p, float* __restrict__ norms,
-                                                          float* __restrict__ loss, float* __restrict__ ws) {
+                                                          float* __restrict__ loss, float* __restrict__ ws,
+                                                          float* __restrict__ d_pred_unit, float* __restrict__ d_true_unit,
+                                                          float* __restrict__ clear_buf, long clear_n) {
     __shared__ double s_num[4], s_den[4];
+    __shared__ float s_norm[2];
+    if (clear_buf) {                                  // fused memset of a caller buffer (gradient accumulators)
+        const long nthreads = (long)gridDim.x * gridDim.y * blockDim.x;
+        for (long i = ((long)blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x; i < clear_n; i += nthreads)
+            clear_buf[i] = 0.0f;
+    }
     const int c = blockIdx.x, b = blockIdx.y;
     const long base = (long)b * npts * nch + c;
     double num = 0.0, den = 0.0;
@@ -43,6 +51,7 @@ __global__ __launch_bounds__(256) void rel_lp_fwd_kernel(const float* __restrict
         const double dn = (p == 1) ? den : (p == 2 ? sqrt(den) : pow(den, 1.0 / p));
         norms[((long)b * nch + c) * 2 + 0] = (float)nn;
         norms[((long)b * nch + c) * 2 + 1] = (float)dn;
+        s_norm[0] = (float)nn; s_norm[1] = (float)dn;
         // sum over (sample, channel) in a persistent accumulator; the last workgroup publishes the
         // loss and leaves accumulator and arrival counter zero for the next call (no memset launch)
         const float old = atomicAdd(ws, (float)(nn / dn / nch));
@@ -52,6 +61,31 @@ __global__ __launch_bounds__(256) void rel_lp_fwd_kernel(const float* __restrict
         if (ticket == gridDim.x * gridDim.y - 1u) {
             *loss = atomicExch(ws, 0.0f);
             atomicExch(counter, 0u);
+        }
+    }
+    if (!d_pred_unit && !d_true_unit) return;
+    // gradients for an upstream gradient of 1 (this workgroup owns both norms of its (sample, channel)):
+    // the training step then needs no separate backward launch for the loss
+    __syncthreads();
+    const float nn = s_norm[0], dn = s_norm[1];
+    for (int l = threadIdx.x; l < npts; l += blockDim.x) {
+        const long e = base + (long)l * nch;
+        float q = pred[e];
+        float sc = 1.0f;
+        if (scale) { sc = scale[(long)l * nch + c]; q = q * sc + shift[(long)l * nch + c]; }
+        const float t = tru[e];
+        const float d = q - t;
+        float dnorm;
+        if (p == 1) dnorm = (d > 0.0f) ? 1.0f : (d < 0.0f ? -1.0f : 0.0f);
+        else if (p == 2) dnorm = (nn > 0.0f) ? d / nn : 0.0f;
+        else dnorm = (nn > 0.0f) ? copysignf(powf(fabsf(d) / nn, (float)(p - 1)), d) : 0.0f;
+        if (d_pred_unit) d_pred_unit[e] = dnorm * sc / (dn * nch);
+        if (d_true_unit) {
+            float tnorm;
+            if (p == 1) tnorm = (t > 0.0f) ? 1.0f : (t < 0.0f ? -1.0f : 0.0f);
+            else if (p == 2) tnorm = (dn > 0.0f) ? t / dn : 0.0f;
+            else tnorm = (dn > 0.0f) ? copysignf(powf(fabsf(t) / dn, (float)(p - 1)), t) : 0.0f;
+            d_true_unit[e] = (-dnorm / dn - nn / (dn * dn) * tnorm) / nch;
         }
     }
 }
@@ -101,7 +135,22 @@ extern "C" int pit_rel_lp_loss_fwd(const float* tru, const float* pred, const fl
     if (batch <= 0 || npts <= 0 || nch <= 0 || p < 1 || batch > 65535) return PIT_ERR_SIZE;
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(rel_lp_fwd_kernel, dim3(nch, batch), dim3(256), 0, s, tru, pred, pred_scale, pred_shift, npts,
-                       nch, p, norms, loss, workspace);
+                       nch, p, norms, loss, workspace, (float*)nullptr, (float*)nullptr, (float*)nullptr, 0L);
+    PIT_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pit_rel_lp_loss_fwd_grad(const float* tru, const float* pred, const float* pred_scale,
+                                        const float* pred_shift, int batch, int npts, int nch, int p,
+                                        float* norms, float* loss, float* workspace, float* d_pred_unit,
+                                        float* d_true_unit, float* clear_buf, long clear_n, void* stream) {
+    if (!tru || !pred || !norms || !loss || !workspace) return PIT_ERR_NULL;
+    if ((pred_scale == nullptr) != (pred_shift == nullptr)) return PIT_ERR_NULL;
+    if (batch <= 0 || npts <= 0 || nch <= 0 || p < 1 || batch > 65535 || clear_n < 0) return PIT_ERR_SIZE;
+    if (clear_n > 0 && !clear_buf) return PIT_ERR_NULL;
+    hipLaunchKernelGGL(rel_lp_fwd_kernel, dim3(nch, batch), dim3(256), 0, (hipStream_t)stream, tru, pred, pred_scale,
+                       pred_shift, npts, nch, p, norms, loss, workspace, d_pred_unit, d_true_unit,
+                       clear_n > 0 ? clear_buf : nullptr, clear_n);
     PIT_CHECK_LAUNCH();
     return 0;
 }

@@ -32,11 +32,13 @@ class TrainStep:
         self.graph: Optional[torch.cuda.CUDAGraph] = None
 
     def _step(self) -> None:
-        if not getattr(self.optimizer, "zero_grads", False):      # FlatAdam(zero_grads=True) clears them itself
-            self.flat.zero_()
         out = self.model(self.mesh_in, self.func_in, self.mesh_out)
         sc, sh = self.affine if self.affine is not None else (None, None)
-        loss = ops.rel_lp_loss(self.target, out, self.out_dim, self.p, sc, sh)
+        # the loss launch also writes its own gradient for the seed of ones below and clears the flat
+        # gradient accumulators (unless FlatAdam(zero_grads=True) already did): no loss-backward launch,
+        # no memset launch
+        clear = None if getattr(self.optimizer, "zero_grads", False) else self.flat.flat
+        loss = ops.rel_lp_loss(self.target, out, self.out_dim, self.p, sc, sh, unit_seed=self._seed, clear=clear)
         torch.autograd.backward(loss, grad_tensors=self._seed)        # no ones_like fill per step
         self.loss = loss.detach()            # same storage every replay (graph-private pool): no copy
         if self.all_reduce:

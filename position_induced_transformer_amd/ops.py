@@ -432,10 +432,15 @@ def mlp_apply(x, w1, b1, w2, b2, out_gelu: bool = False) -> torch.Tensor:
 
 class _RelLpLoss(torch.autograd.Function):
     """RelLpNorm (utils.py:80-98), optionally fused with the per-pixel affine
-    de-normalisation of the prediction (utils.py:25-34)."""
+    de-normalisation of the prediction (utils.py:25-34).
+
+    With ``unit_seed`` (the tensor of ones a training step seeds its backward pass with) the forward
+    launch also writes the gradients for d loss = 1; backward returns them without a launch when
+    it is indeed handed that seed, and falls back to the general backward kernel otherwise.
+    ``clear`` is a tensor the same launch zeroes (the step's flat gradient accumulators)."""
 
     @staticmethod
-    def forward(ctx, pred, true, out_dim: int, p: int, scale, shift):
+    def forward(ctx, pred, true, out_dim: int, p: int, scale, shift, unit_seed=None, clear=None):
         _need_gpu(pred, true, scale, shift)
         b = true.size(0)
         t = true.reshape(b, -1, out_dim).contiguous()
@@ -450,37 +455,59 @@ class _RelLpLoss(torch.autograd.Function):
         ws = _LOSS_WS.get(t.device.index)
         if ws is None:
             ws = _LOSS_WS[t.device.index] = torch.zeros(2, device=t.device, dtype=torch.float32)
-        rc = _lib.lib().pit_rel_lp_loss_fwd(t.data_ptr(), q.data_ptr(), _lib.ptr(sc), _lib.ptr(sh), b, npts,
-                                            out_dim, int(p), norms.data_ptr(), loss.data_ptr(), ws.data_ptr(),
-                                            _lib.stream_ptr())
-        _lib.check(rc, "pit_rel_lp_loss_fwd")
+        unit_p = unit_t = None
+        if unit_seed is not None or clear is not None:
+            if unit_seed is not None:
+                unit_p = torch.empty_like(q) if pred.requires_grad else None
+                unit_t = torch.empty_like(t) if true.requires_grad else None
+            if clear is not None and (not clear.is_contiguous() or clear.dtype != torch.float32):
+                raise RuntimeError("clear must be a contiguous fp32 tensor")
+            rc = _lib.lib().pit_rel_lp_loss_fwd_grad(t.data_ptr(), q.data_ptr(), _lib.ptr(sc), _lib.ptr(sh), b, npts,
+                                                     out_dim, int(p), norms.data_ptr(), loss.data_ptr(), ws.data_ptr(),
+                                                     _lib.ptr(unit_p), _lib.ptr(unit_t), _lib.ptr(clear),
+                                                     clear.numel() if clear is not None else 0, _lib.stream_ptr())
+            _lib.check(rc, "pit_rel_lp_loss_fwd_grad")
+        else:
+            rc = _lib.lib().pit_rel_lp_loss_fwd(t.data_ptr(), q.data_ptr(), _lib.ptr(sc), _lib.ptr(sh), b, npts,
+                                                out_dim, int(p), norms.data_ptr(), loss.data_ptr(), ws.data_ptr(),
+                                                _lib.stream_ptr())
+            _lib.check(rc, "pit_rel_lp_loss_fwd")
         ctx.meta = (b, npts, out_dim, int(p), pred.shape, true.shape)
         ctx.save_for_backward(t, q, norms, sc if sc is not None else norms, sh if sh is not None else norms)
         ctx.affine = sc is not None
+        ctx.unit = (unit_seed.data_ptr() if unit_seed is not None else 0, unit_p, unit_t)
         return loss
 
     @staticmethod
     def backward(ctx, g):
         t, q, norms, sc, sh = ctx.saved_tensors
         b, npts, out_dim, p, shape, tshape = ctx.meta
-        g = g.contiguous()
         need_p, need_t = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        if not (need_p or need_t):
+            return None, None, None, None, None, None, None, None
+        seed_ptr, unit_p, unit_t = ctx.unit
+        if seed_ptr and g.data_ptr() == seed_ptr and (unit_p is not None or not need_p) and \
+                (unit_t is not None or not need_t):
+            # d loss is the step's tensor of ones: the forward launch already wrote these gradients
+            return (unit_p.reshape(shape) if need_p else None), (unit_t.reshape(tshape) if need_t else None), \
+                None, None, None, None, None, None
+        g = g.contiguous()
         d_pred = torch.empty_like(q) if need_p else None
         d_true = torch.empty_like(t) if need_t else None
-        if not (need_p or need_t):
-            return None, None, None, None, None, None
         rc = _lib.lib().pit_rel_lp_loss_bwd(t.data_ptr(), q.data_ptr(), sc.data_ptr() if ctx.affine else 0,
                                             sh.data_ptr() if ctx.affine else 0, b, npts, out_dim, p,
                                             norms.data_ptr(), g.data_ptr(), _lib.ptr(d_pred), _lib.ptr(d_true),
                                             _lib.stream_ptr())
         _lib.check(rc, "pit_rel_lp_loss_bwd")
         return (d_pred.reshape(shape) if need_p else None), (d_true.reshape(tshape) if need_t else None), \
-            None, None, None, None
+            None, None, None, None, None, None
 
 
-def rel_lp_loss(true, pred, out_dim: int, p: int, pred_scale=None, pred_shift=None) -> torch.Tensor:
-    """sum_b mean_c ||true - pred'||_p / ||true||_p with pred' = pred*pred_scale + pred_shift."""
-    return _RelLpLoss.apply(pred, true, out_dim, p, pred_scale, pred_shift)
+def rel_lp_loss(true, pred, out_dim: int, p: int, pred_scale=None, pred_shift=None, unit_seed=None,
+                clear=None) -> torch.Tensor:
+    """sum_b mean_c ||true - pred'||_p / ||true||_p with pred' = pred*pred_scale + pred_shift.
+    ``unit_seed`` / ``clear``: see _RelLpLoss (used by engine.TrainStep to save two launches)."""
+    return _RelLpLoss.apply(pred, true, out_dim, p, pred_scale, pred_shift, unit_seed, clear)
 
 
 class _InstanceNorm(torch.autograd.Function):

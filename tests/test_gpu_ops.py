@@ -471,3 +471,35 @@ def test_mlp_thin_output_layer_vs_oracle(ops, rows, n0, n1, n2):
     assert gio.rel_l2(xc.grad.numpy(), xg.grad.cpu().numpy()) <= TOL_GRAD
     for k in pc:
         assert gio.rel_l2(pc[k].grad.numpy(), pg[k].grad.cpu().numpy()) <= TOL_GRAD, k
+
+
+@pytest.mark.parametrize("p,affine", [(2, True), (1, False), (3, False)])
+def test_rel_lp_loss_unit_seed_and_clear(p, affine):
+    """pit_rel_lp_loss_fwd_grad: gradients written by the forward launch for a seed of ones equal the
+    general backward's, a different upstream gradient falls back to the backward kernel, and the
+    `clear` buffer is zeroed."""
+    from position_induced_transformer_amd import ops as O
+    true = torch.from_numpy(gio.synth((3, 50, 2), 41)).cuda().requires_grad_(True)
+    pred0 = torch.from_numpy(gio.synth((3, 50, 2), 42)).cuda()
+    sc = (torch.from_numpy(gio.synth((50, 2), 43)).abs() + 0.5).cuda() if affine else None
+    sh = torch.from_numpy(gio.synth((50, 2), 44)).cuda() if affine else None
+    seed = torch.ones((), device="cuda")
+
+    def grads(**kw):
+        pred = pred0.clone().requires_grad_(True)
+        t = true.detach().clone().requires_grad_(True)
+        loss = O.rel_lp_loss(t, pred, 2, p, sc, sh, **kw)
+        torch.autograd.backward(loss, grad_tensors=seed)
+        return float(loss), pred.grad.clone(), t.grad.clone()
+
+    buf = torch.full((1000,), 3.0, device="cuda")
+    l0, gp0, gt0 = grads()
+    l1, gp1, gt1 = grads(unit_seed=seed, clear=buf)
+    assert l0 == l1 and float(buf.abs().max()) == 0.0
+    assert gio.rel_l2(gp0.cpu().numpy(), gp1.cpu().numpy()) <= 1e-6
+    assert gio.rel_l2(gt0.cpu().numpy(), gt1.cpu().numpy()) <= 1e-6
+    # a different upstream gradient must not use the stored unit gradients
+    pred = pred0.clone().requires_grad_(True)
+    loss = O.rel_lp_loss(true.detach(), pred, 2, p, sc, sh, unit_seed=seed)
+    torch.autograd.backward(loss, grad_tensors=torch.full((), 2.5, device="cuda"))
+    assert gio.rel_l2(2.5 * gp0.cpu().numpy(), pred.grad.cpu().numpy()) <= 1e-6
