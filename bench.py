@@ -273,6 +273,11 @@ def cpu_baseline(batch, iters):
 # ------------------------------------------------------------------------------------------
 def main():
     args = parse()
+    # stdout carries exactly ONE line (the JSON record): libraries that print to stdout on their own
+    # (RCCL's version banner at communicator creation) are routed to stderr for the whole run
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -362,7 +367,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline(args.batch, args.cpu_iters)
             rec["speedup_vs_cpu_baseline"] = round(rec["value"] / rec["cpu_baseline"]["value"], 1)
-        print(json.dumps(rec), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(rec) + "\n").encode())
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
