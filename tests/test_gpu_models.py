@@ -267,3 +267,25 @@ def test_deferred_head_finish_matches_per_layer_finish():
     twice = grads(True, 2)
     for k in heads:
         assert gio.rel_l2(2.0 * ref[k], twice[k]) <= 1e-5, k
+
+
+def test_bench_prints_exactly_one_json_line():
+    """bench.py's contract with the driver: stdout is ONE JSON line with the agreed keys (logs and
+    library banners go to stderr)."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "20", "--warmup", "3",
+                        "--no-extras", "--cpu-iters", "3"], capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[:2000]
+    rec = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in rec, key
+    assert rec["steps"] == 20 and rec["warmup"] == 3 and rec["n_gpus"] == 1 and rec["vs_baseline"] is None
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in rec["roofline"], key
+    for key in ("value", "unit", "cores", "kind", "sample"):
+        assert key in rec["cpu_baseline"], key
+    assert "workload" in rec["config"] and rec["value"] > 0
