@@ -189,16 +189,6 @@ int pit_mlp_bwd_params(const float* x, long ldx, int rows, int n0, int n1, int n
                        float* d_w1, float* d_b1, float* d_w2, float* d_b2,
                        int accumulate, const float* scratch, void* stream);
 
-/* pit_rel_lp_loss_fwd that ALSO writes, in the same launch, the gradients for an upstream gradient
- * of 1 - d_pred_unit and/or d_true_unit, (batch,npts,nch), NULL = not wanted - and clears clear_n
- * floats at clear_buf (e.g. the flat gradient accumulators of the step whose backward pass follows;
- * clear_n = 0: nothing).  A training step seeded with d loss = 1 then needs neither the loss
- * backward launch nor a memset. */
-int pit_rel_lp_loss_fwd_grad(const float* tru, const float* pred, const float* pred_scale,
-                             const float* pred_shift, int batch, int npts, int nch, int p,
-                             float* norms, float* loss, float* workspace, float* d_pred_unit,
-                             float* d_true_unit, float* clear_buf, long clear_n, void* stream);
-
 /* RelLpNorm (utils.py:80-98): loss = sum_b mean_c ||true - pred'||_p / ||true||_p with norms
  * over the point axis of (batch, npts, nch) contiguous tensors, pred' = pred*scale + shift when
  * the optional per-pixel (npts, nch) affine of PixelWiseNormalization.denormalize
@@ -214,6 +204,16 @@ int pit_rel_lp_loss_fwd(const float* tru, const float* pred, const float* pred_s
 int pit_rel_lp_loss_bwd(const float* tru, const float* pred, const float* pred_scale,
                         const float* pred_shift, int batch, int npts, int nch, int p,
                         const float* norms, const float* grad_loss, float* d_pred, float* d_true, void* stream);
+
+/* pit_rel_lp_loss_fwd that ALSO writes, in the same launch, the gradients for an upstream gradient
+ * of 1 - d_pred_unit and/or d_true_unit, (batch,npts,nch), NULL = not wanted - and clears clear_n
+ * floats at clear_buf (e.g. the flat gradient accumulators of the step whose backward pass follows;
+ * clear_n = 0: nothing).  A training step seeded with d loss = 1 then needs neither the loss
+ * backward launch nor a memset. */
+int pit_rel_lp_loss_fwd_grad(const float* tru, const float* pred, const float* pred_scale,
+                             const float* pred_shift, int batch, int npts, int nch, int p,
+                             float* norms, float* loss, float* workspace, float* d_pred_unit,
+                             float* d_true_unit, float* clear_buf, long clear_n, void* stream);
 
 /* nn.InstanceNorm1d over the point axis as train_vorticity.py:43,56,59 applies it
  * (norm(x.permute(0,2,1)).permute(0,2,1); no affine, no running statistics, biased variance),
