@@ -169,7 +169,7 @@ def test_graph_keeps_the_mode_it_was_captured_with(bf16):
     loss_bf = float(step.loss)
     with bf16.math_mode("fp32"):
         step.replay(); torch.cuda.synchronize()
-        assert float(step.loss) == loss_bf
+        assert abs(float(step.loss) - loss_bf) <= 1e-6 * abs(loss_bf)          # still the bf16 kernels (fp32 differs by ~1e-3)
         eager = TrainStep(model, batch, meta["out_dim"], meta["p"])
         eager.run_eager()
         loss_32 = float(eager.loss)
