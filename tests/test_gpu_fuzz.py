@@ -111,3 +111,48 @@ def test_random_mlp_case_vs_torch(seed):
     assert gio.rel_l2(xc.grad.numpy(), xg.grad.cpu().numpy()) <= 1e-5, info
     for k in pc:
         assert gio.rel_l2(pc[k].grad.numpy(), pg[k].grad.cpu().numpy()) <= 1e-5, (info, k)
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_random_model_vs_oracle(seed):
+    """Whole models with random hyper-parameters (heads, blocks, widths, localities, mesh kinds) and
+    random-cloud meshes (no ties, so a 1-ulp difference in the head scale cannot move the mask):
+    output, loss and every parameter gradient against the CPU oracle."""
+    from position_induced_transformer_amd import pit as P
+    from position_induced_transformer_amd import utils
+    r = np.random.RandomState(9000 + seed)
+    g = torch.Generator().manual_seed(9000 + seed)
+    batched = bool(r.randint(2))
+    sdim = int(r.choice([1, 2, 3]))
+    in_dim, out_dim = int(r.choice([1, 3, 5])), int(r.choice([1, 2, 4]))
+    hid, n_head, n_blocks = int(r.choice([16, 32, 48])), int(r.choice([1, 2, 3])), int(r.choice([1, 2, 3]))
+    n_in, n_ltt, n_out = int(r.choice([60, 131, 300])), int(r.choice([24, 50, 97])), int(r.choice([45, 131, 257]))
+    en_loc, de_loc = float(r.choice([0.05, 0.2, 1.0])), float(r.choice([0.05, 0.3]))
+    b = int(r.choice([1, 2, 3]))
+    lead = (b,) if batched else ()
+    mesh_in = torch.rand(*lead, n_in, sdim, generator=g)
+    mesh_ltt = torch.rand(*lead, n_ltt, sdim, generator=g)
+    mesh_out = torch.rand(*lead, n_out, sdim, generator=g)
+    func_in = torch.randn(b, n_in, in_dim + sdim, generator=g)      # the task forwards concatenate the coordinates (pit.py:100)
+    target = torch.randn(b, n_out, out_dim, generator=g)
+    cls = P.pit if batched else P.pit_fixed
+    torch.manual_seed(100 + seed)
+    model = cls(sdim, in_dim, out_dim, hid, n_head, n_blocks, None if batched else mesh_ltt.cuda(), en_loc, de_loc).cuda()
+    ltt_dev = mesh_ltt.cuda()
+    f = model.encoder(mesh_in.cuda(), func_in.cuda(), ltt_dev)
+    f = model.processor(f, ltt_dev)
+    out = model.decoder(ltt_dev, f, mesh_out.cuda())
+    loss = utils.RelLpNorm(out_dim, 2)(target.cuda(), out)
+    loss.backward()
+
+    p = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in model.state_dict().items()}
+    ref = orc.pit_apply(p, "euclid", batched, n_blocks, en_loc, de_loc, mesh_in, func_in, mesh_ltt, mesh_out)
+    rl = orc.rel_lp_loss(target, ref, out_dim, 2)
+    rl.backward()
+    info = dict(batched=batched, sdim=sdim, in_dim=in_dim, out_dim=out_dim, hid=hid, H=n_head, blocks=n_blocks,
+                n=(n_in, n_ltt, n_out), loc=(en_loc, de_loc), b=b)
+    assert gio.rel_l2(ref.detach().numpy(), out.detach().cpu().numpy()) <= 1e-5, info
+    assert abs(float(loss.detach()) - float(rl.detach())) <= 1e-5 * abs(float(rl.detach())), info
+    for k, q in model.named_parameters():
+        tol = 5e-4 if k.endswith("lmda") else 5e-5
+        assert gio.rel_l2(p[k].grad.numpy(), q.grad.cpu().numpy()) <= tol, (k, info)
