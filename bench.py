@@ -37,6 +37,9 @@ import torch.distributed as dist  # noqa: E402
 
 FP32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 # dense, reference-equivalent fwd+bwd GFLOP per sample
+# algorithmic activation bytes per sample, forward; HBM3E peak from MI355X_MICROARCH.md
+MB_PER_SAMPLE_FWD = {"darcy": 2.10, "burgers": 1.92, "vorticity": 13.08, "elasticity": 19.43, "naca": 10.80}
+HBM_PEAK_GBPS = 8000.0
 GFLOP_PER_SAMPLE = {"darcy": 0.781, "burgers": 0.643, "vorticity": 9.126, "elasticity": 22.406, "naca": 10.005}
 
 
@@ -320,6 +323,10 @@ def main():
                        "parallelism": f"dp{world}" if world > 1 else "single", "launch": mode},
             "loss": round(loss_val, 6),
         }
+        if args.task in MB_PER_SAMPLE_FWD:     # whole-step algorithmic activation traffic (fwd+bwd = 3x fwd)
+            gbps = value * MB_PER_SAMPLE_FWD[args.task] * 3.0 / 1e3
+            rec["step_hbm"] = {"algorithmic_GBps": round(gbps, 1), "frac_of_hbm_peak": round(gbps / HBM_PEAK_GBPS / world, 4),
+                               "mb_per_sample_fwd": MB_PER_SAMPLE_FWD[args.task]}
         if args.task in GFLOP_PER_SAMPLE:      # whole-step algorithmic rate against the fp32 MFMA peak
             tf = value * GFLOP_PER_SAMPLE[args.task] / 1e3
             rec["step_tflops"] = {"achieved": round(tf, 2), "frac_of_fp32_mfma_peak": round(tf / FP32_MFMA_PEAK_TFLOPS / world, 4),
