@@ -490,17 +490,21 @@ __global__ __launch_bounds__(256) void thin_dw_kernel(GemmArgs g, int slab) {
         for (int j = 0; j < THIN_MAX; ++j) { acc[j][0] = acc[j][1] = acc[j][2] = acc[j][3] = 0.0f; }
         if (n < n_real) {
             long k = k0 + grp;
-            for (; k + 3L * groups < k1; k += 4L * groups) {      // four rows in flight per thread
-                float4 x[4];
+            for (; k + 7L * groups < k1; k += 8L * groups) {      // eight rows (and their dZ values) in flight per thread
+                float4 x[8];
+                float d[8][THIN_MAX];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) x[r] = *reinterpret_cast<const float4*>(g.B + (k + (long)r * groups) * g.b_rs + n);
+                for (int r = 0; r < 8; ++r) {
+                    x[r] = *reinterpret_cast<const float4*>(g.B + (k + (long)r * groups) * g.b_rs + n);
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
+                    for (int j = 0; j < THIN_MAX; ++j) d[r][j] = (j < g.M) ? g.A[(k + (long)r * groups) * g.a_cs + j] : 0.0f;
+                }
+#pragma unroll
+                for (int r = 0; r < 8; ++r)
 #pragma unroll
                     for (int j = 0; j < THIN_MAX; ++j) {
-                        if (j >= g.M) break;
-                        const float d = g.A[(k + (long)r * groups) * g.a_cs + j];
-                        acc[j][0] += d * x[r].x; acc[j][1] += d * x[r].y; acc[j][2] += d * x[r].z; acc[j][3] += d * x[r].w;
+                        acc[j][0] += d[r][j] * x[r].x; acc[j][1] += d[r][j] * x[r].y;
+                        acc[j][2] += d[r][j] * x[r].z; acc[j][3] += d[r][j] * x[r].w;
                     }
             }
             for (; k < k1; k += groups) {
