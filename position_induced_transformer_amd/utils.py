@@ -93,8 +93,13 @@ class RelLpNorm:
         self._ord = p
 
     def __call__(self, true, pred):
-        if pred.is_cuda and float(self._ord) == int(self._ord) and int(self._ord) >= 1:
+        if pred.is_cuda or true.is_cuda:
+            # device tensors always go through the HIP kernels (no eager-PyTorch path on the GPU)
+            if float(self._ord) != int(self._ord) or int(self._ord) < 1:
+                raise NotImplementedError("RelLpNorm on device tensors: the HIP kernels cover integer p >= 1 "
+                                          f"(the reference uses p = 1 and 2), got p = {self._ord}")
             return ops.rel_lp_loss(true, pred, self._out_dim, int(self._ord))
+        # host tensors only (the scripts' offline evaluation of saved predictions, train_darcy.py:178)
         t = true.reshape(true.size(0), -1, self._out_dim)
         q = pred.reshape(pred.size(0), -1, self._out_dim)
         num = torch.norm(t - q, p=self._ord, dim=1)
