@@ -91,27 +91,20 @@ class posatt(nn.Module):
         return ops.posatt_apply(inputs, self.lmda, plan, self.n_head, concat=False)
 
     # -- dense helpers kept for API compatibility with the reference (not used by forward)
-    def _sqdist(self, mesh_out, mesh_in):
-        diff = mesh_out.unsqueeze(-2) - mesh_in.unsqueeze(-3)
-        if self._metric != "euclid":
-            period = ops.mesh_period(self._metric, mesh_in)
-            diff = torch.abs(diff)
-            diff = torch.minimum(diff, period - diff)
-            if self._metric == "periodic1d":
-                return diff[..., 0] ** 2
-        return torch.sum(diff ** 2, dim=-1)
-
     def dist2att(self, mesh_out, mesh_in, scale, locality):
-        """Dense attention weights as a tensor ((b,)H,L_out,L_in) - pit.py:46-52.  Provided so
-        code that inspects the weights keeps working; ``forward`` never builds this tensor."""
-        m = self._sqdist(mesh_out, mesh_in)
-        c = ops.head_scale(scale) if scale.is_cuda else torch.tan(0.25 * pi * (1 - 1e-7) * (1.0 + torch.sin(scale)))
-        s = (m.unsqueeze(1) * c) if self._batched else (m * c)
-        thr = torch.quantile(s, locality, dim=-1, keepdim=True)
-        s = torch.where(s <= thr, s, torch.full_like(s, torch.finfo(torch.float32).max))
-        return torch.softmax(-s, dim=-1)
+        """Dense attention weights ((b,)H,L_out,L_in) of pit.py:46-52 for code that inspects them
+        (``scale`` is the lmda parameter, as in the reference).  Built by running the fused HIP
+        kernel on the identity as values, so it is exactly the matrix ``forward`` applies - there
+        is no second, eager implementation of the mask/softmax; ``forward`` never builds it."""
+        plan = ops.MeshPlan(self._metric, mesh_out, mesh_in, float(locality), False)
+        eye = torch.eye(plan.n_in, device=mesh_in.device).unsqueeze(0).repeat(plan.mesh_batch, 1, 1)
+        att = ops.posatt_apply(eye, scale, plan, self.n_head, concat=False)          # (mb, L_out, H*L_in)
+        att = att.reshape(plan.mesh_batch, plan.n_out, self.n_head, plan.n_in).permute(0, 2, 1, 3)
+        return att if self._batched else att[0]
 
     def convolution(self, A, U):
+        """pit.py:54-57 for a caller-provided dense A (a plain tensor contraction; the fused path has
+        no dense A to contract - ``forward`` does not call this)."""
         eq = "bhnj,bjd->bnhd" if self._batched else "hnj,bjd->bnhd"
         return torch.einsum(eq, A, U).reshape(U.shape[0], -1, self.n_head * U.shape[-1])
 

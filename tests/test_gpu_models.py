@@ -289,3 +289,32 @@ def test_bench_prints_exactly_one_json_line():
     for key in ("value", "unit", "cores", "kind", "sample"):
         assert key in rec["cpu_baseline"], key
     assert "workload" in rec["config"] and rec["value"] > 0
+
+
+@pytest.mark.parametrize("kind", ["fixed", "batched", "periodic1d"])
+def test_dist2att_and_convolution_reproduce_forward(kind):
+    """The reference's two-step API (pit.py:46-57): convolution(dist2att(...), inputs) must equal the
+    fused forward, and dist2att must equal the oracle's dense attention weights."""
+    from position_induced_transformer_amd import pit as P
+    g = torch.Generator().manual_seed(3)
+    if kind == "batched":
+        layer = P.posatt_cross(2, 8, 0.1).cuda()
+        mo, mi = torch.rand(2, 40, 2, generator=g), torch.rand(2, 90, 2, generator=g)
+        metric, batched = "euclid", True
+    elif kind == "fixed":
+        layer = P.posatt_cross_fixed(2, 8, 0.1).cuda()
+        mo, mi = torch.rand(40, 2, generator=g), torch.rand(90, 2, generator=g)
+        metric, batched = "euclid", False
+    else:
+        layer = P.posatt_cross_periodic1d(2, 8, 0.1).cuda()
+        mi = torch.linspace(0, 1, 129)[:-1].reshape(-1, 1)
+        mo = torch.rand(40, 1, generator=g)
+        metric, batched = "periodic1d", False
+    x = torch.randn(2, mi.shape[-2], 8, generator=g)
+    fused = layer(mo.cuda(), mi.cuda(), x.cuda())
+    A = layer.dist2att(mo.cuda(), mi.cuda(), layer.lmda, layer.locality)
+    two_step = layer.convolution(A, x.cuda())
+    assert gio.rel_l2(fused.detach().cpu().numpy(), two_step.detach().cpu().numpy()) <= 2e-6
+    c = orc.head_scale(layer.lmda.detach().cpu())
+    ref = orc.attention_weights(orc.sqdist(metric, mo, mi), c, layer.locality, batched)
+    assert gio.rel_l2(ref.numpy(), A.detach().cpu().numpy()) <= 1e-5
