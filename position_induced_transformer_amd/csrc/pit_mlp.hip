@@ -249,15 +249,20 @@ constexpr int LPN = LBN + 4;      // [k][n]
 template <int LBM, bool A_KC, bool B_KC, int EPI, bool BF>
 __global__ __launch_bounds__(256) void gemm_lds_kernel(GemmArgs g) {
     constexpr int LPM = LBM + 4;      // [k][m]
-    constexpr int TN = LBM / 64;      // accumulator tiles per wave
-    constexpr int PA = LBM / 32;      // staging passes for A (4 floats per thread and pass)
+    constexpr int TN = (LBM == 128) ? 2 : 1;      // accumulator tiles per wave
+    constexpr int PA = LBM / 32;                  // staging passes for A (4 floats per thread and pass)
+    // LBM == 32: 32 x 64 tile, the waves pair up on the K axis (each pair member takes two of the four
+    // 8-k sub-steps of a chunk and the partner's partial tile is added through LDS at the end):
+    // twice the workgroups of the 64-row tile for layers that would otherwise not fill the chip
+    constexpr bool KSPLIT = (LBM == 32);
     __shared__ __attribute__((aligned(16))) float As[A_KC ? LBM * LPK : LBK * LPM];
     __shared__ __attribute__((aligned(16))) float Bs[B_KC ? LBN * LPK : LBK * LPN];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, l31 = lane & 31;
     const int m0 = blockIdx.y * LBM, n0 = blockIdx.x * LBN;
-    const int wrow = (LBM == 128) ? wave * 32 : (wave & 1) * 32;    // this wave's rows / first column inside the tile
-    const int wcol = (LBM == 128) ? 0 : (wave >> 1) * 32;
+    const int wrow = (LBM == 128) ? wave * 32 : (LBM == 64 ? (wave & 1) * 32 : 0);   // this wave's rows / first column in the tile
+    const int wcol = (LBM == 128) ? 0 : (LBM == 64 ? (wave >> 1) * 32 : (wave & 1) * 32);
+    const int ksel = KSPLIT ? (wave >> 1) : 0;
     const int kbeg = blockIdx.z * g.k_slab;
     const int kend = min(g.K, kbeg + g.k_slab);
     const __amdgpu_buffer_rsrc_t ra = make_rsrc(g.A, g.a_bytes);
@@ -327,7 +332,8 @@ __global__ __launch_bounds__(256) void gemm_lds_kernel(GemmArgs g) {
         __syncthreads();
         if (kc + LBK < kend) gload(kc + LBK);
 #pragma unroll
-        for (int sub = 0; sub < 4; ++sub) {
+        for (int sub0 = 0; sub0 < (KSPLIT ? 2 : 4); ++sub0) {
+            const int sub = KSPLIT ? 2 * ksel + sub0 : sub0;
             const int ks = sub * 8 + half * 4;          // this half-wave's 4 k of the sub-step
             float av[4], bv[TN][4];
             if (A_KC) {
@@ -363,7 +369,18 @@ __global__ __launch_bounds__(256) void gemm_lds_kernel(GemmArgs g) {
         __syncthreads();
     }
 
-    // epilogue: every wave owns its 32 x 64 block outright
+    if (KSPLIT) {                      // pair reduction: the k-half-1 waves hand their tile to their partners
+        float* red = Bs;               // 2 waves x 16 registers x 64 lanes = 8 KB: fits the (idle) B chunk
+        if (ksel == 1) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[((wave & 1) * 16 + r) * 64 + lane] = acc[0][r];
+        }
+        __syncthreads();
+        if (ksel == 1) return;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][r] += red[((wave & 1) * 16 + r) * 64 + lane];
+    }
+    // epilogue: every (remaining) wave owns its block outright
     if (want_rowsum) {
         rsum += __shfl_xor(rsum, 32);
         const int row = m0 + wrow + l31;
@@ -612,7 +629,10 @@ bool try_launch_gemm_lds(GemmArgs g, hipStream_t s) {
     }
     const int gx = (n_real + LBN - 1) / LBN;
     // 128-row tiles while they still give two workgroups per CU (or when K slabs add parallelism)
-    const int bm = ((long)gx * ((g.M + 127) / 128) >= 512 || g.epi == EPI_ATOMIC) ? 128 : 64;
+    // (and 32-row tiles with an in-workgroup K split while even the 64-row tiling leaves CUs idle)
+    int bm = ((long)gx * ((g.M + 127) / 128) >= 512 || g.epi == EPI_ATOMIC) ? 128 : 64;
+    static const bool no32 = getenv("PIT_LDS_NO_BM32") != nullptr;
+    if (bm == 64 && (long)gx * ((g.M + 63) / 64) < 512 && !no32) bm = 32;
     const int gy = (g.M + bm - 1) / bm;
     int splits = 1;
     g.k_slab = ((g.K + LBK - 1) / LBK) * LBK;
@@ -627,7 +647,8 @@ bool try_launch_gemm_lds(GemmArgs g, hipStream_t s) {
 #define PIT_LDS_BF(A_, B_, EPI_, BF_)                                                                         \
     do {                                                                                                       \
         if (bm == 128) hipLaunchKernelGGL((gemm_lds_kernel<128, A_, B_, EPI_, BF_>), grid, block, 0, s, g);    \
-        else hipLaunchKernelGGL((gemm_lds_kernel<64, A_, B_, EPI_, BF_>), grid, block, 0, s, g);               \
+        else if (bm == 64) hipLaunchKernelGGL((gemm_lds_kernel<64, A_, B_, EPI_, BF_>), grid, block, 0, s, g);  \
+        else hipLaunchKernelGGL((gemm_lds_kernel<32, A_, B_, EPI_, BF_>), grid, block, 0, s, g);               \
     } while (0)
 #define PIT_LDS(A_, B_, EPI_) do { if (g.bf16) PIT_LDS_BF(A_, B_, EPI_, true); else PIT_LDS_BF(A_, B_, EPI_, false); } while (0)
     switch (kind) {
