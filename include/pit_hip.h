@@ -8,7 +8,7 @@
  *     in ELEMENTS; `stream` is a hipStream_t passed as void* (NULL = default stream);
  *   - every function returns 0 on success, a negative PIT_ERR_* for an argument error,
  *     or a positive hipError_t; nothing allocates, frees or synchronises, so every call can
- *     be captured into a hipGraph; the only process-global state is the math mode below;
+ *     be captured into a hipGraph; there is no process-global state;
  *   - outputs and workspaces are caller-owned (the PyTorch host code allocates them).
  *
  * Mesh conventions: `mesh_batch` = 1 for the batch-free (fixed) meshes of
@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define PIT_ABI_VERSION 6
+#define PIT_ABI_VERSION 7
 #define PIT_DSCALE_SLOTS 1024 /* fp64 accumulators per head in pit_posatt_bwd's workspace */
 
 /* distance metric (dist2att variants) */
@@ -42,19 +42,18 @@ int pit_version(void);
 /* human-readable text for a return code of any function below */
 const char* pit_error_string(int code);
 
-/* Math mode of the MFMA contractions (attention forward and d(values), MLP GEMMs), process-wide,
- * read at launch time.  The reference computes in fp32 (pit.py has no autocast), so
- *   PIT_MATH_FP32 (default): v_mfma_f32_32x32x2_f32, exact fp32 products - the parity mode;
- *   PIT_MATH_BF16: operands rounded to bf16 (RNE) in registers, v_mfma_f32_32x32x8_bf16, fp32
- *     accumulation; tensors in memory stay fp32.  Distances, head scale, quantile thresholds,
- *     mask, softmax weights, the d(scale) reduction, loss and optimiser stay fp32 in both modes,
- *     so the kept sets are identical; outputs agree with the fp32 mode to ~1e-2 relative L2
- *     (tests/test_gpu_bf16.py states the tolerance).
- * Returns PIT_ERR_UNSUPPORTED for an unknown mode. */
+/* Math mode of the MFMA contractions (attention forward and d(values), MLP GEMMs): the `math_mode`
+ * ARGUMENT of every call that contracts - the library keeps no process-wide mode (thread-safe; a
+ * captured hipGraph keeps the mode its launches were captured with).  The reference computes in
+ * fp32 (pit.py has no autocast), so
+ *   PIT_MATH_FP32: v_mfma_f32_32x32x2_f32, exact fp32 products - the parity mode;
+ *   PIT_MATH_BF16: operands rounded to bf16 (RNE), bf16 MFMA with fp32 accumulation.  Distances,
+ *     head scale, quantile thresholds, mask, softmax weights, the d(scale) reduction, loss and
+ *     optimiser stay fp32 in both modes, so the kept sets are identical; outputs agree with the
+ *     fp32 mode to ~1e-2 relative L2 (tests/test_gpu_bf16.py states the tolerance).
+ * Any other value returns PIT_ERR_UNSUPPORTED. */
 #define PIT_MATH_FP32 0
 #define PIT_MATH_BF16 1
-int pit_set_math_mode(int mode);
-int pit_get_math_mode(void);
 
 /* pit.py:48 (and :135,:196,:254): c_h = tan(0.25*pi*(1-1e-7)*(1+sin(lmda_h))).
  * Evaluated through fp64 with the reference's fp32 intermediate roundings. */
@@ -111,7 +110,7 @@ int pit_posatt_fwd(const float* mesh_out, const float* mesh_in, int mesh_batch, 
                    const float* stats, float rank_w, int masked, int self_attn,
                    float* out, long ld_out, long out_bstride, int out_col0, int copy_inputs,
                    float* rowstat, float* scale_out,
-                   const int* nbr_idx, const int* nbr_cnt, int nbr_cap, void* stream);
+                   const int* nbr_idx, const int* nbr_cnt, int nbr_cap, int math_mode, void* stream);
 
 /* Backward of pit_posatt_fwd (closed form; the reference uses
  * autograd).  d_out has the layout of `out` (columns out_col0 + h*dim + d).
@@ -144,7 +143,7 @@ int pit_posatt_bwd(const float* mesh_out, const float* mesh_in, int mesh_batch, 
                    float* d_values, long ld_dvalues, long dvalues_bstride, int add_residual,
                    float* d_head, int accumulate_head, double* workspace,
                    const int* nbr_idx, const int* nbr_cnt, int nbr_cap, int nbr_complete,
-                   const int* rev_ptr, const int* rev_row, void* stream);
+                   const int* rev_ptr, const int* rev_row, int math_mode, void* stream);
 
 /* Finishing step of n_layers (<= 32) pit_posatt_bwd calls issued with PIT_HEAD_DEFER, in ONE
  * launch: per layer l drains workspaces[l] (n_heads[l]*PIT_DSCALE_SLOTS doubles, left zero), applies
@@ -163,7 +162,7 @@ int pit_posatt_dhead_finish(int n_layers, double* const* workspaces, float* cons
  *   else may be NULL); y (rows, n2) rows ldy apart. */
 int pit_mlp_fwd(const float* x, long ldx, int rows, int n0, int n1, int n2,
                 const float* w1, const float* b1, const float* w2, const float* b2, int out_gelu,
-                float* z1, float* h, float* z2, float* y, long ldy, void* stream);
+                float* z1, float* h, float* z2, float* y, long ldy, int math_mode, void* stream);
 
 /* Backward of pit_mlp_fwd.  d_y (rows,n2) rows ld_dy apart (ld_dy == n2 when out_gelu).
  * d_x (rows,n0) rows ld_dx apart (NULL = not needed).  d_w1,d_b1,d_w2,d_b2 receive the
@@ -175,7 +174,7 @@ int pit_mlp_bwd(const float* x, long ldx, int rows, int n0, int n1, int n2,
                 const float* w1, const float* w2, const float* z1, const float* h, const float* z2,
                 int out_gelu, const float* d_y, long ld_dy,
                 float* d_x, long ld_dx, float* d_w1, float* d_b1, float* d_w2, float* d_b2,
-                int accumulate, float* scratch, void* stream);
+                int accumulate, float* scratch, int math_mode, void* stream);
 
 /* The two halves of pit_mlp_bwd as separate entry points, so a caller can put the
  * parameter-gradient GEMMs (which nothing downstream in the backward pass depends on) on a
@@ -183,11 +182,11 @@ int pit_mlp_bwd(const float* x, long ldx, int rows, int n0, int n1, int n2,
  * consumes scratch and must be ordered after _data (event / same stream). */
 int pit_mlp_bwd_data(int rows, int n0, int n1, int n2, const float* w1, const float* w2,
                      const float* z1, const float* z2, int out_gelu, const float* d_y, long ld_dy,
-                     float* d_x, long ld_dx, float* scratch, void* stream);
+                     float* d_x, long ld_dx, float* scratch, int math_mode, void* stream);
 int pit_mlp_bwd_params(const float* x, long ldx, int rows, int n0, int n1, int n2, const float* h,
                        int out_gelu, const float* d_y, long ld_dy,
                        float* d_w1, float* d_b1, float* d_w2, float* d_b2,
-                       int accumulate, const float* scratch, void* stream);
+                       int accumulate, const float* scratch, int math_mode, void* stream);
 
 /* RelLpNorm (utils.py:80-98): loss = sum_b mean_c ||true - pred'||_p / ||true||_p with norms
  * over the point axis of (batch, npts, nch) contiguous tensors, pred' = pred*scale + shift when
@@ -214,6 +213,13 @@ int pit_rel_lp_loss_fwd_grad(const float* tru, const float* pred, const float* p
                              const float* pred_shift, int batch, int npts, int nch, int p,
                              float* norms, float* loss, float* workspace, float* d_pred_unit,
                              float* d_true_unit, float* clear_buf, long clear_n, void* stream);
+
+/* RelMaxNorm (utils.py:59-77), the evaluation metric of train_burgers.py:80 / train_sod.py:84 /
+ * train_elasticity.py:118 / train_naca.py:132:  out = sum_b mean_c max_l|true - pred| / max_l|true|
+ * over (batch, npts, nch) contiguous tensors.  Forward only (the scripts never differentiate it).
+ * workspace: 2 doubles (accumulator + arrival counter), zero before the first call, left zero. */
+int pit_rel_max_norm(const float* tru, const float* pred, int batch, int npts, int nch, float* out,
+                     double* workspace, void* stream);
 
 /* nn.InstanceNorm1d over the point axis as train_vorticity.py:43,56,59 applies it
  * (norm(x.permute(0,2,1)).permute(0,2,1); no affine, no running statistics, biased variance),

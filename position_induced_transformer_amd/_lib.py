@@ -22,8 +22,6 @@ _F = ctypes.c_float
 SIGNATURES = {
     "pit_version": [],
     "pit_error_string": [_I],
-    "pit_set_math_mode": [_I],
-    "pit_get_math_mode": [],
     "pit_head_scale": [_P, _I, _P, _P],
     "pit_select_fwd": [_P, _P, _I, _I, _I, _I, _I, _F, _I, _I, _P, _P],
     "pit_plan_fwd": [_P, _P, _I, _I, _I, _I, _I, _F, _I, _P, _I, _P, _P, _P, _P, _P, _P],
@@ -33,23 +31,24 @@ SIGNATURES = {
                        _P, _I, _I,
                        _P, _F, _I, _I,
                        _P, _L, _L, _I, _I,
-                       _P, _P, _P, _P, _I, _P],
+                       _P, _P, _P, _P, _I, _I, _P],
     "pit_posatt_bwd": [_P, _P, _I, _I, _I, _I, _I, _F,
                        _P, _I, _I, _L, _L,
                        _P, _I, _I, _P,
                        _P, _I,
                        _P, _L, _L, _I,
                        _P, _L, _L, _I,
-                       _P, _I, _P, _P, _P, _I, _I, _P, _P, _P],
+                       _P, _I, _P, _P, _P, _I, _I, _P, _P, _I, _P],
     "pit_posatt_dhead_finish": [_I, _P, _P, _P, _P, _P, _P, _P],
-    "pit_mlp_fwd": [_P, _L, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _L, _P],
+    "pit_mlp_fwd": [_P, _L, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _L, _I, _P],
     "pit_mlp_bwd": [_P, _L, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _L,
-                    _P, _L, _P, _P, _P, _P, _I, _P, _P],
-    "pit_mlp_bwd_data": [_I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _L, _P, _L, _P, _P],
-    "pit_mlp_bwd_params": [_P, _L, _I, _I, _I, _I, _P, _I, _P, _L, _P, _P, _P, _P, _I, _P, _P],
+                    _P, _L, _P, _P, _P, _P, _I, _P, _I, _P],
+    "pit_mlp_bwd_data": [_I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _L, _P, _L, _P, _I, _P],
+    "pit_mlp_bwd_params": [_P, _L, _I, _I, _I, _I, _P, _I, _P, _L, _P, _P, _P, _P, _I, _P, _I, _P],
     "pit_rel_lp_loss_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P],
     "pit_rel_lp_loss_fwd_grad": [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _L, _P],
     "pit_rel_lp_loss_bwd": [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P],
+    "pit_rel_max_norm": [_P, _P, _I, _I, _I, _P, _P, _P],
     "pit_instance_norm_fwd": [_P, _L, _L, _I, _I, _I, _F, _P, _P, _P],
     "pit_instance_norm_bwd": [_P, _P, _P, _I, _I, _I, _P, _P],
     "pit_adam_step": [_P, _P, _P, _P, _L, _P, _F, _F, _I, _F, _F, _F, _F, _I, _P, _P],

@@ -15,17 +15,9 @@ __global__ void mfma_probe_kernel(const float* a, const float* b, float* d) {
 }
 }  // namespace
 
-int pit_math_mode_value = PIT_MATH_FP32;
+thread_local int t_call_math = PIT_MATH_FP32;
 
 extern "C" int pit_version(void) { return PIT_ABI_VERSION; }
-
-extern "C" int pit_set_math_mode(int mode) {
-    if (mode != PIT_MATH_FP32 && mode != PIT_MATH_BF16) return PIT_ERR_UNSUPPORTED;
-    pit_math_mode_value = mode;
-    return 0;
-}
-
-extern "C" int pit_get_math_mode(void) { return pit_math_mode_value; }
 
 extern "C" const char* pit_error_string(int code) {
     switch (code) {

@@ -19,14 +19,18 @@ __device__ __forceinline__ f32x16 mfma_32x32x2(float a, float b, f32x16 c) {
 }
 __device__ __forceinline__ int acc_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
 
-// Math mode (pit_set_math_mode): the contractions consume operand groups of 8 along the reduced
+// Math mode (the math_mode argument of the ABI calls): the contractions consume operand groups of 8 along the reduced
 // axis, 4 per half-wave.  PIT_MATH_FP32 issues four exact v_mfma_f32_32x32x2_f32 (lane holds
 // position 2u+half of the group for u = 0..3); PIT_MATH_BF16 rounds both operands to bf16 (RNE)
 // and issues ONE v_mfma_f32_32x32x8_bf16 (lane holds positions 4*half+u, fp32 accumulation).
 // group_pos() is the position a lane must fetch for slot u so that both modes share all the
 // load / weight code.
 typedef short bf16x4 __attribute__((ext_vector_type(4)));
-extern int pit_math_mode_value;          // host side, set through pit_set_math_mode
+// The math mode is an ARGUMENT of every ABI call that contracts (no process-wide state): the entry
+// point parks it in a thread-local for the launch helpers of that call (PIT_ENTER_MATH).
+extern thread_local int t_call_math;
+#define PIT_ENTER_MATH(mode_) do { if ((mode_) != PIT_MATH_FP32 && (mode_) != PIT_MATH_BF16) return PIT_ERR_UNSUPPORTED; \
+                                   t_call_math = (mode_); } while (0)
 __device__ __forceinline__ int group_pos(bool bf16, int u, int half) { return bf16 ? 4 * half + u : 2 * u + half; }
 __device__ __forceinline__ short bf16_bits(float x) { return __builtin_bit_cast(short, (__bf16)x); }
 __device__ __forceinline__ bf16x4 pack_bf16(float a0, float a1, float a2, float a3) {

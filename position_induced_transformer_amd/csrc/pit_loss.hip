@@ -125,7 +125,60 @@ __global__ __launch_bounds__(256) void rel_lp_bwd_kernel(const float* __restrict
     }
 }
 
+// RelMaxNorm (utils.py:59-77): sum_b mean_c max_l |true - pred| / max_l |true|.  One workgroup per
+// (sample, channel); max is exact in any order, so this equals the reference bit for bit up to the
+// final sum over (sample, channel), which is accumulated in fp64 and published by the last arriver.
+__global__ __launch_bounds__(256) void rel_max_fwd_kernel(const float* __restrict__ tru, const float* __restrict__ pred,
+                                                           int npts, int nch, float* __restrict__ out,
+                                                           double* __restrict__ ws) {
+    __shared__ float s_num[4], s_den[4];
+    const int c = blockIdx.x, b = blockIdx.y;
+    const long base = (long)b * npts * nch + c;
+    float num = 0.0f, den = 0.0f;
+    bool bad = false;                                  // torch.max propagates NaN
+    for (int l = threadIdx.x; l < npts; l += blockDim.x) {
+        const long e = base + (long)l * nch;
+        const float t = tru[e], d = fabsf(t - pred[e]);
+        bad |= (d != d) || (t != t);
+        num = fmaxf(num, d);
+        den = fmaxf(den, fabsf(t));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        num = fmaxf(num, __shfl_xor(num, o, 64));
+        den = fmaxf(den, __shfl_xor(den, o, 64));
+    }
+    const int any_bad = __syncthreads_or(bad ? 1 : 0);
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { s_num[wave] = num; s_den[wave] = den; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        num = fmaxf(fmaxf(s_num[0], s_num[1]), fmaxf(s_num[2], s_num[3]));
+        den = fmaxf(fmaxf(s_den[0], s_den[1]), fmaxf(s_den[2], s_den[3]));
+        float ratio = num / den;                       // fp32 division as in the reference (0/0 -> NaN, x/0 -> inf)
+        if (any_bad) ratio = __builtin_nanf("");
+        const double old = atomicAdd(ws, (double)ratio / nch);
+        asm volatile("" ::"v"(old));
+        unsigned long long* counter = reinterpret_cast<unsigned long long*>(ws + 1);
+        const unsigned long long ticket = atomicAdd(counter, 1ull);
+        if (ticket == (unsigned long long)gridDim.x * gridDim.y - 1ull) {
+            *out = (float)__longlong_as_double(atomicExch(reinterpret_cast<unsigned long long*>(ws), 0ull));
+            atomicExch(counter, 0ull);
+        }
+    }
+}
+
 }  // namespace
+
+extern "C" int pit_rel_max_norm(const float* tru, const float* pred, int batch, int npts, int nch, float* out,
+                                double* workspace, void* stream) {
+    if (!tru || !pred || !out || !workspace) return PIT_ERR_NULL;
+    if (batch <= 0 || npts <= 0 || nch <= 0 || batch > 65535) return PIT_ERR_SIZE;
+    hipLaunchKernelGGL(rel_max_fwd_kernel, dim3(nch, batch), dim3(256), 0, (hipStream_t)stream, tru, pred, npts, nch,
+                       out, workspace);
+    PIT_CHECK_LAUNCH();
+    return 0;
+}
 
 extern "C" int pit_rel_lp_loss_fwd(const float* tru, const float* pred, const float* pred_scale,
                                    const float* pred_shift, int batch, int npts, int nch, int p,

@@ -680,7 +680,7 @@ int prepare_gemm(GemmArgs& g, GemmLaunch& L, int force_tn = 0, int force_waves =
     const unsigned long long bb = ((unsigned long long)(g.K - 1) * g.b_rs + (unsigned long long)(std::max(nb_cols, 1) - 1) * g.b_cs + 1) * 4ull;
     if (ab > PIT_MAX_BUFFER_BYTES || bb > PIT_MAX_BUFFER_BYTES) return PIT_ERR_UNSUPPORTED;
     g.a_bytes = (unsigned)ab; g.b_bytes = (unsigned)bb;
-    g.bf16 = (pit_math_mode_value == PIT_MATH_BF16);
+    g.bf16 = (t_call_math == PIT_MATH_BF16);
     g.a_vec = vec_ok(g.A, g.a_rs, g.a_cs) && (!g.a_gz || vec_ok(g.a_gz, g.a_rs, g.a_cs));
     g.b_vec = vec_ok(g.B, g.b_cs, g.b_rs);
     // two column tiles per wave (A fragment reused) only when that still leaves plenty of workgroups
@@ -835,7 +835,8 @@ int launch_dz1(int rows, int n1, int n2, const float* w2, const float* z1, const
 
 extern "C" int pit_mlp_fwd(const float* x, long ldx, int rows, int n0, int n1, int n2,
                            const float* w1, const float* b1, const float* w2, const float* b2, int out_gelu,
-                           float* z1, float* h, float* z2, float* y, long ldy, void* stream) {
+                           float* z1, float* h, float* z2, float* y, long ldy, int math_mode, void* stream) {
+    PIT_ENTER_MATH(math_mode);
     if (!x || !w1 || !b1 || !w2 || !b2 || !z1 || !h || !y) return PIT_ERR_NULL;
     if (out_gelu && !z2) return PIT_ERR_NULL;
     if (rows <= 0 || n0 <= 0 || n1 <= 0 || n2 <= 0 || ldx < n0 || ldy < n2) return PIT_ERR_SIZE;
@@ -860,7 +861,8 @@ extern "C" int pit_mlp_fwd(const float* x, long ldx, int rows, int n0, int n1, i
 
 extern "C" int pit_mlp_bwd_data(int rows, int n0, int n1, int n2, const float* w1, const float* w2,
                                 const float* z1, const float* z2, int out_gelu, const float* d_y, long ld_dy,
-                                float* d_x, long ld_dx, float* scratch, void* stream) {
+                                float* d_x, long ld_dx, float* scratch, int math_mode, void* stream) {
+    PIT_ENTER_MATH(math_mode);
     if (!w1 || !w2 || !z1 || !d_y || !scratch) return PIT_ERR_NULL;
     if (out_gelu && !z2) return PIT_ERR_NULL;
     if (rows <= 0 || n0 <= 0 || n1 <= 0 || n2 <= 0) return PIT_ERR_SIZE;
@@ -879,7 +881,8 @@ extern "C" int pit_mlp_bwd_data(int rows, int n0, int n1, int n2, const float* w
 extern "C" int pit_mlp_bwd_params(const float* x, long ldx, int rows, int n0, int n1, int n2, const float* h,
                                   int out_gelu, const float* d_y, long ld_dy,
                                   float* d_w1, float* d_b1, float* d_w2, float* d_b2,
-                                  int accumulate, const float* scratch, void* stream) {
+                                  int accumulate, const float* scratch, int math_mode, void* stream) {
+    PIT_ENTER_MATH(math_mode);
     if (!x || !h || !d_y || !d_w1 || !d_b1 || !d_w2 || !d_b2 || !scratch) return PIT_ERR_NULL;
     if (rows <= 0 || n0 <= 0 || n1 <= 0 || n2 <= 0) return PIT_ERR_SIZE;
     hipStream_t s = (hipStream_t)stream;
@@ -898,7 +901,8 @@ extern "C" int pit_mlp_bwd(const float* x, long ldx, int rows, int n0, int n1, i
                            const float* w1, const float* w2, const float* z1, const float* h, const float* z2,
                            int out_gelu, const float* d_y, long ld_dy,
                            float* d_x, long ld_dx, float* d_w1, float* d_b1, float* d_w2, float* d_b2,
-                           int accumulate, float* scratch, void* stream) {
+                           int accumulate, float* scratch, int math_mode, void* stream) {
+    PIT_ENTER_MATH(math_mode);
     if (!x || !w1 || !w2 || !z1 || !h || !d_y || !d_w1 || !d_b1 || !d_w2 || !d_b2 || !scratch) return PIT_ERR_NULL;
     if (out_gelu && !z2) return PIT_ERR_NULL;
     if (rows <= 0 || n0 <= 0 || n1 <= 0 || n2 <= 0) return PIT_ERR_SIZE;

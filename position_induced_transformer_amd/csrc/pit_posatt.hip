@@ -1800,7 +1800,7 @@ int fill_common(AttArgs& a, const float* mesh_out, const float* mesh_in, int mes
                                    (unsigned long long)(n_in - 1) * ld_values + dim) * 4ull;
     if (vb > PIT_MAX_BUFFER_BYTES) return PIT_ERR_UNSUPPORTED;
     a.values_bytes = (unsigned)vb;
-    a.bf16 = (pit_math_mode_value == PIT_MATH_BF16);
+    a.bf16 = (t_call_math == PIT_MATH_BF16);
     a.dim_magic = (dim == 1) ? 0xFFFFFFFFu : (unsigned)(0x100000000ull / (unsigned long long)dim);
     a.no_fast_loads = env_int("PIT_NO_FAST_LOADS");
     return 0;
@@ -1815,7 +1815,8 @@ extern "C" int pit_posatt_fwd(const float* mesh_out, const float* mesh_in, int m
                               const float* stats, float rank_w, int masked, int self_attn,
                               float* out, long ld_out, long out_bstride, int out_col0, int copy_inputs,
                               float* rowstat, float* scale_out,
-                              const int* nbr_idx, const int* nbr_cnt, int nbr_cap, void* stream) {
+                              const int* nbr_idx, const int* nbr_cnt, int nbr_cap, int math_mode, void* stream) {
+    PIT_ENTER_MATH(math_mode);
     AttArgs a;
     int rc = fill_common(a, mesh_out, mesh_in, mesh_batch, n_out, n_in, space_dim, metric, period, values, batch,
                          dim, ld_values, values_bstride, head, n_head, head_is_scale);
@@ -1850,7 +1851,8 @@ extern "C" int pit_posatt_bwd(const float* mesh_out, const float* mesh_in, int m
                               float* d_values, long ld_dvalues, long dvalues_bstride, int add_residual,
                               float* d_head, int accumulate_head, double* workspace,
                               const int* nbr_idx, const int* nbr_cnt, int nbr_cap, int nbr_complete,
-                              const int* rev_ptr, const int* rev_row, void* stream) {
+                              const int* rev_ptr, const int* rev_row, int math_mode, void* stream) {
+    PIT_ENTER_MATH(math_mode);
     AttArgs a;
     int rc = fill_common(a, mesh_out, mesh_in, mesh_batch, n_out, n_in, space_dim, metric, period, values, batch,
                          dim, ld_values, values_bstride, head, n_head, head_is_scale);

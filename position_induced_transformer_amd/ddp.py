@@ -37,15 +37,47 @@ class FlatGradients:
             total += (p.numel() + align - 1) // align * align
         self.flat = torch.zeros(total, device=dev, dtype=dt)
         self.flat_params = torch.zeros(total, device=dev, dtype=dt) if flatten_params else None
+        self.offsets = offsets
+        self._views = []
         for p, off in zip(self.params, offsets):
             n = p.numel()
-            p.grad = self.flat[off:off + n].view_as(p)
+            view = self.flat[off:off + n].view_as(p)
+            self._views.append(view)
+            p.grad = view
+            if p.is_cuda:
+                from . import ops
+                ops.mark_inplace_grad(p, view)      # the backward kernels may accumulate into this view in place
             if flatten_params:
                 self.flat_params[off:off + n].copy_(p.data.reshape(-1))
                 p.data = self.flat_params[off:off + n].view_as(p)
 
     def zero_(self) -> None:
+        """Clear the gradients and keep them attached.  Use this (or ``zero_grad(set_to_none=False)``)
+        instead of ``optimizer.zero_grad()``, whose default ``set_to_none=True`` drops the views; if
+        a loop does call it, :meth:`attach` (run by ``all_reduce`` / ``FlatAdam.step``) repairs it."""
+        self.attach(keep_values=False)
         self.flat.zero_()
+
+    def attach(self, keep_values: bool = True) -> int:
+        """Make every parameter's ``.grad`` the registered view into the flat buffer again.
+
+        ``optimizer.zero_grad()`` (train_darcy.py:127; ``set_to_none=True`` by default) sets ``.grad``
+        to None, after which autograd allocates fresh gradient tensors OUTSIDE the flat buffer and a
+        flat all-reduce would sum stale memory.  For each detached parameter the current gradient
+        (if any and ``keep_values``) is copied into its slot - a missing gradient zeroes the slot -
+        and ``.grad`` points at the slot again.  Returns the number of parameters re-attached."""
+        fixed = 0
+        for p, view in zip(self.params, self._views):
+            g = p.grad
+            if g is not None and g.data_ptr() == view.data_ptr() and g.shape == view.shape:
+                continue
+            if g is not None and keep_values:
+                view.copy_(g.detach().reshape(view.shape))
+            else:
+                view.zero_()
+            p.grad = view
+            fixed += 1
+        return fixed
 
     def dense(self) -> torch.Tensor:
         """The gradients concatenated in parameter order WITHOUT the alignment padding (a copy)."""
@@ -53,6 +85,7 @@ class FlatGradients:
 
     def all_reduce(self, average: bool = False, group=None) -> None:
         """Sum (or average) the flat buffer over the ranks; no-op without a process group."""
+        self.attach()                       # .grad tensors that left the flat buffer are copied back first
         if not (dist.is_available() and dist.is_initialized()):
             return
         dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
@@ -99,6 +132,7 @@ class FlatAdam:
     def step(self) -> None:
         from . import _lib
         f = self.flat
+        f.attach()
         rc = _lib.lib().pit_adam_step(f.flat_params.data_ptr(), f.flat.data_ptr(), self.exp_avg.data_ptr(),
                                       self.exp_avg_sq.data_ptr(), f.flat.numel(), self.step_count.data_ptr(),
                                       self.lr, self.eta_min, self.cosine_t_max, self.betas[0], self.betas[1],

@@ -65,7 +65,19 @@ class TrainStep:
     def replay(self) -> None:
         self.graph.replay()
 
-    def set_batch(self, func_in: torch.Tensor, target: torch.Tensor) -> None:
-        """Copy a new batch into the captured static buffers."""
+    def set_batch(self, func_in: torch.Tensor, target: torch.Tensor, mesh_in: Optional[torch.Tensor] = None,
+                  mesh_out: Optional[torch.Tensor] = None) -> None:
+        """Copy a new batch into the captured static buffers.  Tasks with per-sample meshes
+        (train_elasticity.py:46, train_naca.py:62-65) also pass the batch's meshes: the captured step
+        rebuilds its selection plans from the static mesh buffers on every replay, so a replay after
+        ``set_batch`` computes on the new clouds.  (When mesh_in and func_in are one tensor, as in
+        NACA, one copy serves both.)"""
+        if (mesh_in is not None or mesh_out is not None) and not getattr(self.model.down, "_batched", True):
+            raise ValueError("this model's meshes are batch-free (fixed): their selection plans were built once and "
+                             "are part of the captured step; only per-sample meshes can change between replays")
         self.func_in.copy_(func_in)
         self.target.copy_(target)
+        if mesh_in is not None and self.mesh_in.data_ptr() != self.func_in.data_ptr():
+            self.mesh_in.copy_(mesh_in)
+        if mesh_out is not None and self.mesh_out.data_ptr() != self.mesh_in.data_ptr():
+            self.mesh_out.copy_(mesh_out)

@@ -8,7 +8,9 @@ CPU or eager-PyTorch path: tensors must live on the GPU and the shared library m
 from __future__ import annotations
 
 import ctypes
+import math
 import os
+import threading
 from typing import Optional
 
 import numpy as np
@@ -18,10 +20,13 @@ from . import _lib
 
 METRIC_ID = {"euclid": 0, "periodic1d": 1, "periodic2d": 2}
 
-# When a parameter already owns a contiguous fp32 ``.grad`` (e.g. a view into
-# ddp.FlatGradients' buffer, or after ``zero_grad(set_to_none=False)``) the backward kernels
-# accumulate straight into it and autograd receives ``None`` for that input: no memset of a
-# temporary, no separate ``grad += tmp`` launch.  Set to False to always return gradients.
+# In-place gradient accumulation is OPT-IN per parameter: ddp.FlatGradients marks the parameters whose
+# ``.grad`` it owns (``mark_inplace_grad``), and only for those - while the ``.grad`` is still the
+# registered view and the parameter carries no autograd hooks - the backward kernels accumulate
+# straight into ``.grad`` and autograd receives ``None`` for that input (no memset of a temporary,
+# no separate ``grad += tmp`` launch).  Every other parameter gets its gradient RETURNED to autograd,
+# so tensor hooks, post-accumulate hooks, torch DDP's reducer and ``torch.autograd.grad`` behave as
+# with any torch op.  Set to False to disable the in-place path altogether.
 FUSED_GRAD_ACCUMULATION = True
 
 # Backward kernels that nothing later in the backward pass depends on - the d(scale) reduction
@@ -38,15 +43,36 @@ OVERLAP_BACKWARD = os.environ.get("PIT_OVERLAP_BACKWARD", "0") != "0"
 # much shorter than the key axis; False forces the dense MFMA kernels everywhere.
 SPARSE_MASKED = True
 
-_DSCALE_WS = {}
-_LOSS_WS = {}
-_SIDE = {}          # device index -> {"stream", "pending", "keep"}
+_DSCALE_WS = {}     # (device index, stream) -> fp64 accumulators
+_LOSS_WS = {}       # (device index, stream) -> loss accumulator + ticket
+_SIDE = {}          # device index -> {"stream", "task", "keep"}
+# Tensors whose addresses were baked into a hipGraph under capture (mesh plans, accumulators): never
+# released, so a cache eviction cannot hand their memory to someone else while a graph still replays.
+_PINNED = []
+
+
+def _capturing() -> bool:
+    return torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
+
+
+def _pin(*objs) -> None:
+    _PINNED.extend(objs)
+
+
+def _ws_key(device):
+    return (device.index, torch.cuda.current_stream(device).cuda_stream)
+
+
+def _graph_task() -> int:
+    """Id of the backward pass being executed (-1 outside of one): what the end-of-pass callbacks are
+    keyed on, so a pass that died with an exception cannot leave the NEXT pass without its callback."""
+    return torch._C._current_graph_task_id()
 
 
 def _side_state(device):
     st = _SIDE.get(device.index)
     if st is None:
-        st = {"stream": torch.cuda.Stream(device=device), "pending": False, "keep": []}
+        st = {"stream": torch.cuda.Stream(device=device), "task": None, "keep": []}
         _SIDE[device.index] = st
     return st
 
@@ -57,15 +83,19 @@ def _fork_side(device, *keep_alive):
     read by side-stream kernels after autograd would have released them)."""
     st = _side_state(device)
     st["stream"].wait_stream(torch.cuda.current_stream(device))
-    st["keep"].extend(keep_alive)
-    if not st["pending"]:
-        st["pending"] = True
+    task = _graph_task()
+    if st["task"] != task:                   # first fork of THIS pass (a pass that raised never joined)
+        if st["task"] is not None:
+            torch.cuda.current_stream(device).wait_stream(st["stream"])
+            st["keep"].clear()
+        st["task"] = task
 
         def _join():
             torch.cuda.current_stream(device).wait_stream(st["stream"])
             st["keep"].clear()
-            st["pending"] = False
+            st["task"] = None
         torch.autograd.Variable._execution_engine.queue_callback(_join)
+    st["keep"].extend(keep_alive)
     return st["stream"]
 
 
@@ -73,11 +103,13 @@ def _fork_side(device, *keep_alive):
 def _dscale_workspace(device, n_head: int) -> torch.Tensor:
     """fp64 accumulators for d(scale): zero on entry and left zero by pit_posatt_bwd, so one
     zeroed buffer per device serves every layer (launches are stream-ordered)."""
-    key = device.index
+    key = _ws_key(device)                     # per (device, stream): concurrent streams never share accumulators
     ws = _DSCALE_WS.get(key)
     if ws is None or ws.numel() < n_head * 1024 + 8:
         ws = torch.zeros(max(8, n_head) * 1024 + 8, device=device, dtype=torch.float64)   # slots + counter
         _DSCALE_WS[key] = ws
+    if _capturing():
+        _pin(ws)
     return ws
 
 
@@ -86,6 +118,7 @@ def _dscale_workspace(device, n_head: int) -> torch.Tensor:
 # goes in place into lmda.grad (the training path), needs one accumulator buffer per layer.
 DEFER_HEAD_FINISH = os.environ.get("PIT_DEFER_HEAD_FINISH", "1") != "0"
 _PENDING_HEADS = []      # (workspace, d_head, lmda, scale, n_head, flags) of the running backward pass
+_PENDING_TASK = [None]   # graph-task id that _PENDING_HEADS belongs to (None: nothing queued)
 _LAYER_WS = {}
 
 
@@ -93,9 +126,11 @@ def _layer_workspace(slot: torch.Tensor, n_head: int) -> torch.Tensor:
     key = (slot.device.index, slot.data_ptr(), n_head)
     ws = _LAYER_WS.get(key)
     if ws is None:
-        if len(_LAYER_WS) >= 1024:            # gradient buffers were re-created many times: drop stale entries
-            _LAYER_WS.clear()
+        while len(_LAYER_WS) >= 1024:         # gradient buffers were re-created many times: drop the oldest
+            _LAYER_WS.pop(next(iter(_LAYER_WS)))
         ws = _LAYER_WS[key] = torch.zeros(n_head * 1024, device=slot.device, dtype=torch.float64)
+    if _capturing():
+        _pin(ws)
     return ws
 
 
@@ -103,6 +138,7 @@ def _flush_head_finishes() -> None:
     """End-of-backward callback: one launch finishing d(lmda) of all deferred layers."""
     pend = list(_PENDING_HEADS)
     _PENDING_HEADS.clear()
+    _PENDING_TASK[0] = None
     for dev in sorted({p[0].device.index for p in pend}):
         grp = [p for p in pend if p[0].device.index == dev]
         for i in range(0, len(grp), 32):
@@ -120,18 +156,36 @@ def _flush_head_finishes() -> None:
 
 
 def _defer_head_finish(work, d_head, head, scale, n_head: int, flags: int) -> None:
-    if not _PENDING_HEADS:
+    task = _graph_task()
+    if _PENDING_TASK[0] != task:
+        # first deferred layer of THIS backward pass.  Entries left by another pass mean that pass
+        # raised before its end-of-pass callback ran (autograd skips the callbacks then): their
+        # accumulators hold partial sums of an aborted pass - zero them and forget the entries.
+        for stale in _PENDING_HEADS:
+            stale[0].zero_()
+        _PENDING_HEADS.clear()
+        _PENDING_TASK[0] = task
         torch.autograd.Variable._execution_engine.queue_callback(_flush_head_finishes)
     _PENDING_HEADS.append((work, d_head, head, scale, n_head, flags))
+
+
+def mark_inplace_grad(param, grad_view) -> None:
+    """Opt ``param`` in to in-place gradient accumulation into ``grad_view`` (ddp.FlatGradients)."""
+    param._pit_grad_ptr = grad_view.data_ptr()
 
 
 def _grad_slot(param) -> Optional[torch.Tensor]:
     """The parameter's own .grad if the kernels may accumulate into it in place."""
     if not FUSED_GRAD_ACCUMULATION or param is None:
         return None
+    want = getattr(param, "_pit_grad_ptr", None)
     g = getattr(param, "grad", None)
-    if g is None or not g.is_cuda or g.dtype != torch.float32 or not g.is_contiguous():
+    if want is None or g is None or g.data_ptr() != want:
+        return None                      # not opted in, or .grad was dropped / replaced (zero_grad(set_to_none=True))
+    if not g.is_cuda or g.dtype != torch.float32 or not g.is_contiguous():
         return None
+    if param._backward_hooks or getattr(param, "_post_accumulate_grad_hooks", None):
+        return None                      # hooks must see the gradient: return it to autograd
     return g
 
 
@@ -267,6 +321,7 @@ class _PosAtt(torch.autograd.Function):
     def forward(ctx, values, head, plan: MeshPlan, n_head: int, concat: bool, head_is_scale: bool,
                 head_param=None):
         _need_gpu(values, head)
+        ctx.math = _math_code()
         values = _row_view(values)
         b, j, d = values.shape
         if j != plan.n_in:
@@ -288,7 +343,7 @@ class _PosAtt(torch.autograd.Function):
             _lib.ptr(plan.stats), plan.rank_w, 1 if plan.masked else 0, 1 if plan.self_attn else 0,
             out.data_ptr(), out.stride(1), out.stride(0), d if concat else 0, 1 if concat else 0,
             rowstat.data_ptr(), scale.data_ptr(),
-            _lib.ptr(plan.nbr_idx), _lib.ptr(plan.nbr_cnt), plan.nbr_cap, _lib.stream_ptr())
+            _lib.ptr(plan.nbr_idx), _lib.ptr(plan.nbr_cnt), plan.nbr_cap, ctx.math, _lib.stream_ptr())
         _lib.check(rc, "pit_posatt_fwd")
         ctx.plan, ctx.n_head, ctx.concat, ctx.head_is_scale = plan, n_head, concat, head_is_scale
         ctx.head_param = head_param
@@ -326,7 +381,7 @@ class _PosAtt(torch.autograd.Function):
                 1 if concat else 0,
                 _lib.ptr(dh), acc_head, work.data_ptr(),
                 _lib.ptr(plan.nbr_idx), _lib.ptr(plan.nbr_cnt), plan.nbr_cap, plan.lists_complete(),
-                _lib.ptr(plan.rev_ptr), _lib.ptr(plan.rev_row), stream_ptr)
+                _lib.ptr(plan.rev_ptr), _lib.ptr(plan.rev_row), ctx.math, stream_ptr)
             _lib.check(rc, "pit_posatt_bwd")
 
         if OVERLAP_BACKWARD and slot is not None:
@@ -341,11 +396,77 @@ class _PosAtt(torch.autograd.Function):
         return d_values, (None if slot is not None else d_head), None, None, None, None, None
 
 
+# Where the head scale c = tan(0.25*pi*(1-1e-7)*(1+sin(lmda))) (pit.py:48) is evaluated.
+#   "device" (default): inside the kernels, through fp64 with the reference's fp32 roundings - no host
+#       sync, hipGraph-capturable.  ATen-CPU evaluates sin/tan with MKL VML (high-accuracy mode, NOT
+#       correctly rounded, kernels chosen by the host CPU), so this c differs from the reference's by
+#       1 ulp or more for ~2 % of lmda; on regular grids that can move a tie shell across the quantile
+#       threshold (DESIGN.md section 2 quantifies it).
+#   "host": the reference's own op sequence on the HOST CPU (torch.sin / torch.tan on a CPU copy of
+#       lmda, i.e. bit-for-bit what pit.py:48 computes on that machine), injected into the kernels as
+#       the scale; d(lmda) follows by torch-CPU autograd of the same expression.  One device->host
+#       copy per layer and step: for reproducing a reference checkpoint exactly (evaluation, parity
+#       tests), not for captured training steps.
+HEAD_SCALE_ROUTES = ("device", "host")
+_ROUTE = threading.local()
+
+
+def set_head_scale_route(route: str) -> None:
+    if route not in HEAD_SCALE_ROUTES:
+        raise ValueError(f"head-scale route must be one of {HEAD_SCALE_ROUTES}, got {route!r}")
+    _ROUTE.route = route
+
+
+def get_head_scale_route() -> str:
+    return getattr(_ROUTE, "route", "device")
+
+
+class head_scale_route:
+    """`with ops.head_scale_route('host'): ...` - scoped set_head_scale_route."""
+
+    def __init__(self, route: str):
+        self.route, self.prev = route, None
+
+    def __enter__(self):
+        self.prev = get_head_scale_route()
+        set_head_scale_route(self.route)
+        return self
+
+    def __exit__(self, *exc):
+        set_head_scale_route(self.prev)
+        return False
+
+
+class _HostHeadScale(torch.autograd.Function):
+    """c(lmda) by the reference's op sequence on the host CPU (pit.py:48), chain rule by torch-CPU autograd."""
+
+    @staticmethod
+    def forward(ctx, lmda):
+        if _capturing():
+            raise RuntimeError("head-scale route 'host' synchronises with the host and cannot be captured into a "
+                               "hipGraph; use the default 'device' route for captured steps")
+        host = lmda.detach().cpu().requires_grad_(True)
+        with torch.enable_grad():
+            c = torch.tan(0.25 * math.pi * (1 - 1e-7) * (1.0 + torch.sin(host)))
+        ctx.host, ctx.c = host, c
+        return c.detach().to(lmda.device)
+
+    @staticmethod
+    def backward(ctx, d_c):
+        (d_l,) = torch.autograd.grad(ctx.c, ctx.host, d_c.detach().cpu().reshape(ctx.c.shape))
+        return d_l.to(d_c.device)
+
+
+@torch.compiler.disable
 def posatt_apply(values: torch.Tensor, lmda: torch.Tensor, plan: MeshPlan, n_head: int, concat: bool,
                  head_is_scale: bool = False) -> torch.Tensor:
     """out[b,n,h*D+d] = sum_j softmax_j(-c_h m[n,j] | quantile mask)[n,j] * values[b,j,d]
     (pit.py:46-57); with ``concat`` the inputs are prepended (pit.py:44).  ``lmda`` is the
-    (H,1,1) parameter, or the scale c itself when ``head_is_scale`` (tests inject it)."""
+    (H,1,1) parameter, or the scale c itself when ``head_is_scale`` (tests inject it).
+    Opaque to torch.compile (dynamo runs it eagerly: raw pointers cross a ctypes boundary)."""
+    if not head_is_scale and get_head_scale_route() == "host":
+        c = _HostHeadScale.apply(lmda.reshape(-1))
+        return _PosAtt.apply(values, c, plan, n_head, concat, True, None)
     param = lmda if isinstance(lmda, torch.nn.Parameter) else None
     return _PosAtt.apply(values, lmda.reshape(-1), plan, n_head, concat, head_is_scale, param)
 
@@ -371,9 +492,11 @@ class _Mlp(torch.autograd.Function):
         h = torch.empty((rows, n1), device=dev, dtype=torch.float32)
         z2 = torch.empty((rows, n2), device=dev, dtype=torch.float32) if out_gelu else None
         y = torch.empty((rows, n2), device=dev, dtype=torch.float32)
+        ctx.math = _math_code()
         rc = _lib.lib().pit_mlp_fwd(x2.data_ptr(), x2.stride(0), rows, n0, n1, n2, w1c.data_ptr(), b1c.data_ptr(),
                                     w2c.data_ptr(), b2c.data_ptr(), 1 if out_gelu else 0, z1.data_ptr(),
-                                    h.data_ptr(), _lib.ptr(z2), y.data_ptr(), y.stride(0), _lib.stream_ptr())
+                                    h.data_ptr(), _lib.ptr(z2), y.data_ptr(), y.stride(0), ctx.math,
+                                    _lib.stream_ptr())
         _lib.check(rc, "pit_mlp_fwd")
         ctx.out_gelu, ctx.dims, ctx.in_shape = out_gelu, (rows, n0, n1, n2), shape
         ctx.params = (w1, b1, w2, b2)
@@ -406,19 +529,19 @@ class _Mlp(torch.autograd.Function):
         if OVERLAP_BACKWARD and inplace:
             rc = L.pit_mlp_bwd_data(rows, n0, n1, n2, w1.data_ptr(), w2.data_ptr(), z1.data_ptr(), z2p, og,
                                     d_y2.data_ptr(), d_y2.stride(0), _lib.ptr(d_x), n0, scratch.data_ptr(),
-                                    _lib.stream_ptr())
+                                    ctx.math, _lib.stream_ptr())
             _lib.check(rc, "pit_mlp_bwd_data")
             stream_p = _fork_side(dev, x2, h, d_y2, scratch).cuda_stream     # weight grads off the critical path
             rc = L.pit_mlp_bwd_params(x2.data_ptr(), x2.stride(0), rows, n0, n1, n2, h.data_ptr(), og,
                                       d_y2.data_ptr(), d_y2.stride(0), d_w1.data_ptr(), d_b1.data_ptr(),
-                                      d_w2.data_ptr(), d_b2.data_ptr(), 1, scratch.data_ptr(), stream_p)
+                                      d_w2.data_ptr(), d_b2.data_ptr(), 1, scratch.data_ptr(), ctx.math, stream_p)
             _lib.check(rc, "pit_mlp_bwd_params")
         else:
             # one call: dZ1, then dX and both weight-gradient reductions (merged into one launch when small)
             rc = L.pit_mlp_bwd(x2.data_ptr(), x2.stride(0), rows, n0, n1, n2, w1.data_ptr(), w2.data_ptr(),
                                z1.data_ptr(), h.data_ptr(), z2p, og, d_y2.data_ptr(), d_y2.stride(0),
                                _lib.ptr(d_x), n0, d_w1.data_ptr(), d_b1.data_ptr(), d_w2.data_ptr(), d_b2.data_ptr(),
-                               1 if inplace else 0, scratch.data_ptr(), _lib.stream_ptr())
+                               1 if inplace else 0, scratch.data_ptr(), ctx.math, _lib.stream_ptr())
             _lib.check(rc, "pit_mlp_bwd")
         dx = d_x.reshape(ctx.in_shape) if need_x else None
         if inplace:
@@ -426,6 +549,7 @@ class _Mlp(torch.autograd.Function):
         return dx, d_w1, d_b1, d_w2, d_b2, None
 
 
+@torch.compiler.disable
 def mlp_apply(x, w1, b1, w2, b2, out_gelu: bool = False) -> torch.Tensor:
     return _Mlp.apply(x, w1, b1, w2, b2, out_gelu)
 
@@ -452,9 +576,12 @@ class _RelLpLoss(torch.autograd.Function):
         sh = shift.reshape(npts, out_dim).contiguous() if shift is not None else None
         norms = torch.empty((b, out_dim, 2), device=t.device, dtype=torch.float32)
         loss = torch.empty((), device=t.device, dtype=torch.float32)
-        ws = _LOSS_WS.get(t.device.index)
+        wkey = _ws_key(t.device)
+        ws = _LOSS_WS.get(wkey)
         if ws is None:
-            ws = _LOSS_WS[t.device.index] = torch.zeros(2, device=t.device, dtype=torch.float32)
+            ws = _LOSS_WS[wkey] = torch.zeros(2, device=t.device, dtype=torch.float32)
+        if _capturing():
+            _pin(ws)
         unit_p = unit_t = None
         if unit_seed is not None or clear is not None:
             if unit_seed is not None:
@@ -503,11 +630,40 @@ class _RelLpLoss(torch.autograd.Function):
             None, None, None, None, None, None
 
 
+@torch.compiler.disable
 def rel_lp_loss(true, pred, out_dim: int, p: int, pred_scale=None, pred_shift=None, unit_seed=None,
                 clear=None) -> torch.Tensor:
     """sum_b mean_c ||true - pred'||_p / ||true||_p with pred' = pred*pred_scale + pred_shift.
     ``unit_seed`` / ``clear``: see _RelLpLoss (used by engine.TrainStep to save two launches)."""
     return _RelLpLoss.apply(pred, true, out_dim, p, pred_scale, pred_shift, unit_seed, clear)
+
+
+_RELMAX_WS = {}
+
+
+@torch.compiler.disable
+def rel_max_norm(true: torch.Tensor, pred: torch.Tensor, out_dim: int) -> torch.Tensor:
+    """RelMaxNorm (utils.py:59-77) on device: sum_b mean_c max|true-pred| / max|true|.  Forward only -
+    the scripts use it as an evaluation metric under no_grad (train_burgers.py:80, train_naca.py:132)."""
+    _need_gpu(true, pred)
+    if torch.is_grad_enabled() and (true.requires_grad or pred.requires_grad):
+        raise NotImplementedError("RelMaxNorm on device tensors is forward-only (an evaluation metric in the reference "
+                                  "scripts): call it under torch.no_grad() or on detached tensors")
+    b = true.size(0)
+    t = true.detach().reshape(b, -1, out_dim).contiguous()
+    q = pred.detach().reshape(b, -1, out_dim).contiguous()
+    if t.shape != q.shape:
+        raise RuntimeError(f"true {tuple(true.shape)} and pred {tuple(pred.shape)} do not match")
+    wkey = _ws_key(t.device)
+    ws = _RELMAX_WS.get(wkey)
+    if ws is None:
+        ws = _RELMAX_WS[wkey] = torch.zeros(2, device=t.device, dtype=torch.float64)
+    if _capturing():
+        _pin(ws)
+    out = torch.empty((), device=t.device, dtype=torch.float32)
+    _lib.check(_lib.lib().pit_rel_max_norm(t.data_ptr(), q.data_ptr(), b, t.shape[1], out_dim, out.data_ptr(),
+                                           ws.data_ptr(), _lib.stream_ptr()), "pit_rel_max_norm")
+    return out
 
 
 class _InstanceNorm(torch.autograd.Function):
@@ -539,26 +695,32 @@ class _InstanceNorm(torch.autograd.Function):
         return d_x, None
 
 
+@torch.compiler.disable
 def instance_norm_points(x: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
     """(x - mean over points) / sqrt(var over points + eps) per (sample, channel) of a (b, L, C) tensor."""
     return _InstanceNorm.apply(x, eps)
 
 
 MATH_MODES = {"fp32": 0, "bf16": 1}      # PIT_MATH_* of include/pit_hip.h
+_MATH = threading.local()
+
+
+def _math_code() -> int:
+    return MATH_MODES[getattr(_MATH, "mode", "fp32")]
 
 
 def set_math_mode(mode: str) -> None:
     """'fp32' (default, the reference's arithmetic) or 'bf16' (bf16 MFMA operands, fp32 accumulate) for
-    the attention / MLP contractions; process-wide, read when a kernel is launched (so a captured
-    hipGraph keeps the mode it was captured with)."""
+    the attention / MLP contractions.  Host-side, per Python thread: the mode is an ARGUMENT of every
+    C-ABI call (the library keeps no mode of its own), read when an operator's forward runs and reused
+    by its backward; a captured hipGraph keeps the mode its launches were captured with."""
     if mode not in MATH_MODES:
         raise ValueError(f"math mode must be one of {sorted(MATH_MODES)}, got {mode!r}")
-    _lib.check(_lib.lib().pit_set_math_mode(MATH_MODES[mode]), "pit_set_math_mode")
+    _MATH.mode = mode
 
 
 def get_math_mode() -> str:
-    code = _lib.lib().pit_get_math_mode()
-    return next(k for k, v in MATH_MODES.items() if v == code)
+    return getattr(_MATH, "mode", "fp32")
 
 
 class math_mode:

@@ -85,6 +85,58 @@ def test_flat_allreduce_equals_single_rank_gradient(tmp_path, world):
     assert err <= 1e-6, err
 
 
+def _worker_loop(rank, world, port, out_dir):
+    """Three steps of the reference loop shape (train_darcy.py:124-134) under data parallelism:
+    `optimizer.zero_grad()` (set_to_none=True: drops the flat-buffer views), backward (autograd then
+    allocates fresh gradients), `flat.all_reduce()`, `optimizer.step()`.  Rank 0 replays the same
+    three steps single-process on the concatenated batch."""
+    for pth in (ROOT, HERE, os.path.join(ROOT, "oracle")):
+        sys.path.insert(0, pth)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    import golden_io as gio
+    import pit_oracle as orc
+    from position_induced_transformer_amd.ddp import FlatGradients, shard_batch
+
+    shapes = orc.param_shapes(2, 1, 1, 16, 2, 2)
+    mesh, ltt = orc.grid_mesh_2d(12), orc.grid_mesh_2d(5)
+
+    def loss_of(p, x, y):
+        f = orc.with_coords(mesh, x.reshape(x.shape[0], -1, 1))
+        return orc.rel_lp_loss(y, orc.pit_apply(p, "euclid", False, 2, 0.1, 0.1, mesh, f, ltt, mesh), 1, 2)
+
+    def run(params, shard, reduce):
+        flat = FlatGradients(params.values())
+        opt = torch.optim.SGD(list(params.values()), lr=1e-2)
+        for step in range(3):
+            x = torch.from_numpy(gio.synth((4, 144, 1), 200 + step))
+            y = torch.from_numpy(gio.synth((4, 144, 1), 300 + step))
+            opt.zero_grad()                                       # the script's call: .grad -> None
+            loss_of(params, x[shard], y[shard]).backward()
+            if reduce:
+                flat.all_reduce()                                 # re-attaches, then ONE collective
+            else:
+                flat.attach()
+            opt.step()
+        return torch.cat([p.detach().reshape(-1) for p in params.values()])
+
+    mk = lambda: {k: torch.nn.Parameter(torch.from_numpy(v)) for k, v in gio.synth_params(shapes, 10).items()}  # noqa: E731
+    got = run(mk(), shard_batch(4, rank, world), True)
+    if rank == 0:
+        want = run(mk(), slice(0, 4), False)
+        np.save(os.path.join(out_dir, "err_loop.npy"), np.asarray([float((got - want).norm() / want.norm())]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_multi_step_loop_with_optimizer_zero_grad_matches_single_rank(tmp_path):
+    port = _free_port()
+    mp.spawn(_worker_loop, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    (err,) = np.load(os.path.join(tmp_path, "err_loop.npy"))
+    assert err <= 1e-6, err
+
+
 def test_shard_batch_partitions_exactly():
     sys.path.insert(0, ROOT)
     from position_induced_transformer_amd.ddp import shard_batch

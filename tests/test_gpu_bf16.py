@@ -36,7 +36,13 @@ def test_mode_roundtrip_and_rejects_unknown():
     ops.set_math_mode("bf16")
     assert ops.get_math_mode() == "bf16"
     ops.set_math_mode("fp32")
-    assert _lib.lib().pit_set_math_mode(7) == -4          # PIT_ERR_UNSUPPORTED
+    assert not hasattr(_lib.lib(), "pit_set_math_mode")   # no process-wide mode in the ABI: a per-call argument
+    x = torch.zeros(4, 8, device="cuda")
+    w, b_ = torch.zeros(8, 8, device="cuda"), torch.zeros(8, device="cuda")
+    z1, h, y = (torch.empty(4, 8, device="cuda") for _ in range(3))
+    rc = _lib.lib().pit_mlp_fwd(x.data_ptr(), 8, 4, 8, 8, 8, w.data_ptr(), b_.data_ptr(), w.data_ptr(), b_.data_ptr(), 0,
+                                z1.data_ptr(), h.data_ptr(), 0, y.data_ptr(), 8, 7, _lib.stream_ptr())
+    assert rc == -4                                       # PIT_ERR_UNSUPPORTED: unknown math mode
     assert ops.get_math_mode() == "fp32"
     with pytest.raises(ValueError):
         ops.set_math_mode("fp8")

@@ -114,27 +114,82 @@ def test_posatt_forward_backward_injected_scale(ops, name):
     assert np.abs(ref.detach().numpy() - out.detach().cpu().numpy()).max() <= 2e-5 * np.abs(ref.detach().numpy()).max()
 
 
+def _c_host(lmda_np):
+    return orc.head_scale(torch.from_numpy(lmda_np)).numpy()
+
+
+def _ulp(a, b):
+    return int(np.abs(a.reshape(-1).view(np.int32).astype(np.int64) - b.reshape(-1).view(np.int32).astype(np.int64)).max())
+
+
+@pytest.mark.parametrize("draw", ["fixture", "differing"])
 @pytest.mark.parametrize("name", OP_CASES)
-def test_posatt_lmda_path(ops, name):
-    """lmda -> c inside the kernel (fp64 route) and d lmda."""
+def test_posatt_lmda_path(ops, name, draw):
+    """lmda -> c inside the kernel (route 'device': fp64 evaluation) and d lmda, against the ORACLE run
+    live on this host with the same lmda.
+
+    ATen-CPU's sin/tan are MKL VML high-accuracy kernels (not correctly rounded, chosen by the host
+    CPU), so the device c differs from the host's for a few per cent of lmda, by up to ~12 ulp per ulp
+    of sin (tan amplifies).  draw='fixture' uses the golden case's lmda; draw='differing' SEARCHES for
+    an lmda whose device c differs from this host's (the case round 1 never drew).  Asserted either way:
+      (1) the kernel is exact given its c: output == oracle with the DEVICE's c injected, at TOL_FWD;
+      (2) route 'host' reproduces the reference's lmda path: output, d(values), d(lmda) == oracle(lmda);
+      (3) when the two c are bit-equal, route 'device' == oracle(lmda) too, d(lmda) included."""
     fx, cs = load_case(name)
     plan = make_plan(ops, cs)
     n_head = cs["lmda"].shape[0]
-    lm = dev(cs["lmda"]).requires_grad_(True)
-    c_dev = ops.head_scale(lm.detach()).cpu().numpy()
-    ulp = np.abs(c_dev.view(np.int32).astype(np.int64) - cs["c"].view(np.int32).astype(np.int64)).max()
-    assert ulp <= 1, f"lmda->c differs from ATen by {ulp} ulp"
-    values = dev(cs["values"]).requires_grad_(True)
-    out = ops.posatt_apply(values, lm, plan, n_head, concat=cs["self_attn"])
-    d_out = gio.synth(tuple(out.shape), cs["seed"] + 1000)
-    out.backward(dev(d_out))
-    if ulp == 0:
-        e, g, _, _ = gio.expect(fx, "out", out.detach().cpu().numpy())
-        assert gio.rel_l2(e, g) <= TOL_FWD
-        assert gio.rel_l2(fx["d_lmda"], lm.grad.cpu().numpy()) <= TOL_HEAD
-    else:   # a 1-ulp different scale may move a tie shell on regular grids: looser sanity bound only
-        e, g, _, _ = gio.expect(fx, "out", out.detach().cpu().numpy())
-        assert gio.rel_l2(e, g) <= 5e-3
+    lmda = cs["lmda"]
+    if draw == "differing":
+        rng = np.random.default_rng(cs["seed"])
+        for _ in range(4000):
+            cand = rng.random(lmda.shape, dtype=np.float32)
+            if _ulp(_c_host(cand), ops.head_scale(dev(cand)).cpu().numpy()) > 0:
+                lmda = cand
+                break
+        else:
+            pytest.skip("no lmda with a differing c found on this host")
+    c_dev = ops.head_scale(dev(lmda)).cpu().numpy()
+    ulp = _ulp(_c_host(lmda), c_dev)
+    assert (ulp > 0) if draw == "differing" else True
+    assert ulp <= 64, f"lmda->c differs from this host's ATen by {ulp} ulp"
+    d_out = gio.synth((cs["values"].shape[0], plan.n_out, (n_head + (1 if cs["self_attn"] else 0)) * cs["values"].shape[2]),
+                      cs["seed"] + 1000)
+
+    def oracle(**kw):
+        mo, mi = torch.from_numpy(cs["mesh_out"]), torch.from_numpy(cs["mesh_in"])
+        u = torch.from_numpy(cs["values"]).requires_grad_(True)
+        lm = torch.from_numpy(lmda).requires_grad_(True)
+        if cs["self_attn"]:
+            ref = orc.posatt_self(cs["metric"], cs["batched"], mo, u, lm, cs["q"], **kw)
+        else:
+            ref = orc.posatt_cross(cs["metric"], cs["batched"], mo, mi, u, lm, cs["q"], **kw)
+        if not kw:
+            ref.backward(torch.from_numpy(d_out))
+        return ref.detach().numpy(), u.grad, lm.grad
+
+    def device(route):
+        lm = dev(lmda).requires_grad_(True)
+        values = dev(cs["values"]).requires_grad_(True)
+        with ops.head_scale_route(route):
+            out = ops.posatt_apply(values, lm, plan, n_head, concat=cs["self_attn"])
+        out.backward(dev(d_out))
+        return out.detach().cpu().numpy(), values.grad.cpu(), lm.grad.cpu()
+
+    ref, ref_du, ref_dl = oracle()
+    out_d, du_d, dl_d = device("device")
+    out_h, du_h, dl_h = device("host")
+    ref_cdev, _, _ = oracle(c=torch.from_numpy(c_dev.reshape(lmda.shape)))
+    assert gio.rel_l2(ref_cdev, out_d) <= TOL_FWD                                     # (1)
+    assert gio.rel_l2(ref, out_h) <= TOL_FWD                                          # (2)
+    assert gio.rel_l2(ref_du.numpy(), du_h.numpy()) <= TOL_GRAD
+    assert gio.rel_l2(ref_dl.numpy().reshape(-1), dl_h.numpy().reshape(-1)) <= TOL_HEAD
+    if ulp == 0:                                                                      # (3)
+        assert gio.rel_l2(ref, out_d) <= TOL_FWD
+        assert gio.rel_l2(ref_du.numpy(), du_d.numpy()) <= TOL_GRAD
+        assert gio.rel_l2(ref_dl.numpy().reshape(-1), dl_d.numpy().reshape(-1)) <= TOL_HEAD
+        if draw == "fixture":
+            e, g, _, _ = gio.expect(fx, "out", out_d)
+            assert gio.rel_l2(e, g) <= TOL_FWD
 
 
 @pytest.mark.parametrize("name", ["F1_darcy_enc", "F3_darcy_dec", "F5_p1d_enc", "F6_p2d_enc", "E2_duplicates",
@@ -355,7 +410,7 @@ def test_raw_ctypes_binding_as_in_integration_md():
     P, I, F, LG = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_long
     L.pit_select_fwd.argtypes = [P, P, I, I, I, I, I, F, I, I, P, P]
     L.pit_posatt_fwd.argtypes = [P, P, I, I, I, I, I, F, P, I, I, LG, LG, P, I, I, P, F, I, I,
-                                 P, LG, LG, I, I, P, P, P, P, I, P]
+                                 P, LG, LG, I, I, P, P, P, P, I, I, P]
     fx, cs = load_case("F1_darcy_enc")
     mesh_out, mesh_in = dev(cs["mesh_out"]).contiguous(), dev(cs["mesh_in"]).contiguous()   # the ABI takes dense rows
     inputs, lmda = dev(cs["values"]).contiguous(), dev(cs["lmda"]).contiguous()
@@ -375,7 +430,7 @@ def test_raw_ctypes_binding_as_in_integration_md():
                           inputs.data_ptr(), b, d, inputs.stride(1), inputs.stride(0),
                           lmda.data_ptr(), h, 0, stats.data_ptr(), w, 1, 0,
                           out.data_ptr(), out.stride(1), out.stride(0), 0, 0,
-                          rowstat.data_ptr(), scale.data_ptr(), None, None, 0, stream)
+                          rowstat.data_ptr(), scale.data_ptr(), None, None, 0, 0, stream)      # PIT_MATH_FP32
     assert rc == 0
     torch.cuda.synchronize()
     ulp = np.abs(scale.cpu().numpy().view(np.int32).astype(np.int64) - cs["c"].reshape(-1).view(np.int32).astype(np.int64)).max()

@@ -1,0 +1,342 @@
+"""GPU: the boundary items of round 2 - torch.compile survival (train_darcy.py:112,150,152), the
+lmda->c routes on unselected parameter seeds (regular grids: tie shells), RelMaxNorm on device,
+graph replay with NEW per-sample meshes, exception safety of the deferred d(lmda) finish, a
+200-step captured training run against the eager loop."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import golden_io as gio
+import model_cases as mc
+import pit_oracle as orc
+from test_gpu_models import build_model
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# --------------------------------------------------------------------------- torch.compile
+def test_torch_compile_model_matches_eager_and_traces_nothing():
+    """`model = torch.compile(model)` exactly as train_darcy.py:112, forward + backward through the
+    compiled wrapper == eager to 1e-6; dynamo compiles NO graph (nothing of the hot path may go to
+    inductor/Triton); the checkpoint of the wrapper has the `_orig_mod.` keys (train_darcy.py:150)
+    and `torch._dynamo.disable(model)` (train_darcy.py:152) still runs it."""
+    import torch._dynamo as dynamo
+    from position_induced_transformer_amd import pit as P, utils
+
+    class pit_darcy(P.pit_fixed):                 # the script's class, train_darcy.py:25-59
+        def forward(self, mesh_in, func_in, mesh_out):
+            size = mesh_out.shape[:-1]
+            mesh_in = mesh_in.reshape(-1, self.space_dim)
+            func_in = func_in.reshape(func_in.shape[0], -1, self.in_dim)
+            mesh_out = mesh_out.reshape(-1, self.space_dim)
+            func_in = torch.cat((torch.tile(mesh_in.unsqueeze(0), [func_in.shape[0], 1, 1]), func_in), -1)
+            func_ltt = self.encoder(mesh_in, func_in, self.mesh_ltt)
+            func_ltt = self.processor(func_ltt, self.mesh_ltt)
+            func_out = self.decoder(self.mesh_ltt, func_ltt, mesh_out)
+            return func_out.reshape(func_in.shape[0], *size, self.out_dim)
+
+    torch.manual_seed(3)
+    g43, g16 = orc.grid_mesh_2d(43).reshape(43, 43, 2).cuda(), orc.grid_mesh_2d(16).reshape(16, 16, 2).cuda()
+    model = pit_darcy(2, 1, 1, 64, 2, 4, g16, 0.02, 0.02).cuda()
+    x, y = torch.randn(4, 43, 43, 1, device="cuda"), torch.randn(4, 43, 43, 1, device="cuda")
+    loss_fn = utils.RelLpNorm(1, 2)
+
+    out_e = model(g43, x, g43)
+    loss_fn(y, out_e).backward()
+    grads_e = {k: p.grad.clone() for k, p in model.named_parameters()}
+    model.zero_grad()
+
+    dynamo.reset()
+    dynamo.utils.counters.clear()
+    compiled = torch.compile(model)
+    out_c = compiled(g43, x, g43)
+    loss_fn(y, out_c).backward()
+    torch.cuda.synchronize()
+    assert gio.rel_l2(out_e.detach().cpu().numpy(), out_c.detach().cpu().numpy()) <= 1e-6
+    for k, p in model.named_parameters():
+        assert gio.rel_l2(grads_e[k].cpu().numpy(), p.grad.cpu().numpy()) <= (1e-5 if k.endswith("lmda") else 1e-6), k
+    assert dynamo.utils.counters["stats"].get("unique_graphs", 0) == 0, dict(dynamo.utils.counters["stats"])
+    keys = list(compiled.state_dict().keys())
+    assert keys[0] == "_orig_mod.down.lmda" and all(k.startswith("_orig_mod.") for k in keys)
+    with torch.no_grad():
+        out_d = torch._dynamo.disable(compiled)(g43, x, g43)
+    assert gio.rel_l2(out_e.detach().cpu().numpy(), out_d.cpu().numpy()) <= 1e-6
+
+
+# --------------------------------------------------------------------------- lmda -> c routes
+SWEEP_SEEDS = 200
+# measured on MI355X + EPYC 9575F host (profiles/r02_lmda_route_sweep.json); the test fails if the
+# device route gets worse than this
+MAX_FRACTION_ABOVE_1E5 = {"F9_model_darcy": 0.10, "F11_model_burgers": 0.10}
+
+
+@pytest.mark.parametrize("name", ["F9_model_darcy", "F11_model_burgers"])
+def test_unselected_seed_sweep_device_and_host_scale_routes(name):
+    """VERDICT r1 weak #1.  200 parameter seeds taken as they come (nothing selected) on the two
+    regular-grid models, each compared with the oracle on THIS host (whose sin/tan are ATen-CPU's):
+      * route 'host' (c by the reference's own torch-CPU ops, injected): every seed <= 1e-5;
+      * route 'device' (c evaluated in the kernels): <= 1e-5 whenever all c are bit-equal to the
+        host's; otherwise a differing c can move a tie shell of the grid across the quantile
+        threshold - the fraction of seeds above 1e-5 is reported and bounded.
+    The distribution goes to gpurun_out/lmda_route_sweep_<name>.json (summarised in profiles/)."""
+    from position_induced_transformer_amd import ops
+    cs = mc.build_case(name)
+    cfg = cs["cfg"]
+    mi = cs["mesh_in"].reshape(-1, cfg["space_dim"])
+    func = cs["func_in"].reshape(2, -1, cfg["in_dim"])
+    feats = orc.with_coords(mi, func)
+    rows = []
+    model = None
+    for seed in range(1000, 1000 + SWEEP_SEEDS):
+        params = gio.synth_params(cs["shapes"], seed)
+        p = {k: torch.from_numpy(v) for k, v in params.items()}
+        with torch.no_grad():
+            ref = orc.pit_apply(p, cs["metric"], False, cfg["n_blocks"], cfg["en_loc"], cfg["de_loc"], mi, feats,
+                                cs["mesh_ltt"].reshape(-1, cfg["space_dim"]), mi).numpy()
+        if model is None:
+            model = build_model(cs, params)
+        else:
+            model.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
+        ulps = []
+        for k, v in p.items():
+            if k.endswith("lmda"):
+                c_host = orc.head_scale(v).numpy().reshape(-1)
+                c_dev = ops.head_scale(v.cuda()).cpu().numpy().reshape(-1)
+                ulps.append(int(np.abs(c_host.view(np.int32).astype(np.int64) - c_dev.view(np.int32).astype(np.int64)).max()))
+        with torch.no_grad():
+            out_dev = model(cs["mesh_in"].cuda(), cs["func_in"].cuda(), cs["mesh_out"].cuda()).cpu().numpy()
+            with ops.head_scale_route("host"):
+                out_host = model(cs["mesh_in"].cuda(), cs["func_in"].cuda(), cs["mesh_out"].cuda()).cpu().numpy()
+        rows.append(dict(seed=seed, max_ulp=max(ulps), n_layers_differ=int(sum(u > 0 for u in ulps)),
+                         err_device=gio.rel_l2(ref.reshape(-1), out_dev.reshape(-1)),
+                         err_host=gio.rel_l2(ref.reshape(-1), out_host.reshape(-1))))
+    e_dev = np.array([r["err_device"] for r in rows])
+    e_host = np.array([r["err_host"] for r in rows])
+    equal = np.array([r["max_ulp"] == 0 for r in rows])
+    summary = dict(model=name, seeds=len(rows), seeds_with_all_c_bit_equal=int(equal.sum()),
+                   max_ulp_seen=int(max(r["max_ulp"] for r in rows)),
+                   host_route=dict(max=float(e_host.max()), median=float(np.median(e_host)), above_1e5=int((e_host > 1e-5).sum())),
+                   device_route_c_equal=dict(n=int(equal.sum()), max=float(e_dev[equal].max()) if equal.any() else None,
+                                             above_1e5=int((e_dev[equal] > 1e-5).sum())),
+                   device_route_c_differs=dict(n=int((~equal).sum()),
+                                               max=float(e_dev[~equal].max()) if (~equal).any() else None,
+                                               median=float(np.median(e_dev[~equal])) if (~equal).any() else None,
+                                               above_1e5=int((e_dev[~equal] > 1e-5).sum()),
+                                               above_1e4=int((e_dev[~equal] > 1e-4).sum())),
+                   device_route_fraction_above_1e5=float((e_dev > 1e-5).mean()))
+    out_dir = os.path.join(ROOT, "gpurun_out")
+    try:
+        os.makedirs(out_dir, exist_ok=True)
+        with open(os.path.join(out_dir, f"lmda_route_sweep_{name}.json"), "w") as f:
+            json.dump(dict(summary=summary, rows=rows), f, indent=1)
+    except OSError:
+        pass
+    print(json.dumps(summary))
+    assert summary["host_route"]["above_1e5"] == 0, summary
+    assert summary["device_route_c_equal"]["above_1e5"] == 0, summary
+    assert summary["device_route_fraction_above_1e5"] <= MAX_FRACTION_ABOVE_1E5[name], summary
+
+
+def test_host_route_gradients_match_the_oracle_on_a_seed_where_c_differs():
+    """Route 'host' end to end (forward, loss, every gradient incl. d lmda through the torch-CPU chain
+    rule) on the first Darcy seed whose device c differs from the host's: the case the round-1
+    goldens avoided by selecting seeds."""
+    from position_induced_transformer_amd import ops, utils
+    cs = mc.build_case("F9_model_darcy")
+    cfg = cs["cfg"]
+    for seed in range(5000, 5400):
+        params = gio.synth_params(cs["shapes"], seed)
+        differs = [k for k, v in params.items() if k.endswith("lmda") and not np.array_equal(
+            orc.head_scale(torch.from_numpy(v)).numpy(), ops.head_scale(torch.from_numpy(v).cuda()).cpu().numpy())]
+        if differs:
+            break
+    else:
+        pytest.skip("no seed in range with a differing c on this host")
+    model = build_model(cs, params)
+    with ops.head_scale_route("host"):
+        out = model(cs["mesh_in"].cuda(), cs["func_in"].cuda(), cs["mesh_out"].cuda())
+        loss = utils.RelLpNorm(1, 2)(cs["target"].cuda(), out)
+        loss.backward()
+    p = {k: torch.from_numpy(v).requires_grad_(True) for k, v in params.items()}
+    mi = cs["mesh_in"].reshape(-1, 2)
+    ref = orc.pit_apply(p, "euclid", False, cfg["n_blocks"], cfg["en_loc"], cfg["de_loc"], mi,
+                        orc.with_coords(mi, cs["func_in"].reshape(2, -1, 1)), cs["mesh_ltt"].reshape(-1, 2), mi)
+    ref_loss = orc.rel_lp_loss(cs["target"], ref.reshape(2, 43, 43, 1), 1, 2)
+    ref_loss.backward()
+    assert gio.rel_l2(ref.detach().numpy().reshape(-1), out.detach().cpu().numpy().reshape(-1)) <= 1e-5
+    assert abs(float(loss) - float(ref_loss)) <= 1e-5 * abs(float(ref_loss))
+    for k, q in model.named_parameters():
+        tol = 2e-4 if k.endswith("lmda") else 2e-5
+        assert gio.rel_l2(p[k].grad.numpy().reshape(-1), q.grad.cpu().numpy().reshape(-1)) <= tol, (k, differs)
+
+
+def test_host_route_refuses_graph_capture():
+    from position_induced_transformer_amd import ops, tasks
+    model, sample, _ = tasks.make_task("darcy", seed=1)
+    mesh_in, func_in, mesh_out, _ = sample(2)
+    model(mesh_in, func_in, mesh_out)                       # warm the plan caches
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with ops.head_scale_route("host"):
+        with pytest.raises(RuntimeError, match="cannot be captured"):
+            with torch.cuda.graph(g):
+                model(mesh_in, func_in, mesh_out)
+    torch.cuda.synchronize()
+
+
+# --------------------------------------------------------------------------- RelMaxNorm
+@pytest.mark.parametrize("shape,out_dim", [((3, 1024, 1), 1), ((2, 221, 51, 4), 4), ((5, 7, 3), 3)])
+def test_rel_max_norm_on_device(shape, out_dim):
+    """utils.py:59-77 on device tensors runs pit_rel_max_norm; equal to the reference formula."""
+    from position_induced_transformer_amd import utils
+    g = torch.Generator().manual_seed(11)
+    t, q = torch.randn(*shape, generator=g), torch.randn(*shape, generator=g)
+    tr, qr = t.reshape(shape[0], -1, out_dim), q.reshape(shape[0], -1, out_dim)
+    want = torch.sum(torch.mean(torch.max(torch.abs(tr - qr), dim=1)[0] / torch.max(torch.abs(tr), dim=1)[0], dim=-1))
+    with torch.no_grad():
+        got = utils.RelMaxNorm(out_dim)(t.cuda(), q.cuda())
+        again = utils.RelMaxNorm(out_dim)(t.cuda(), q.cuda())          # the accumulator cleans itself
+    assert abs(float(got) - float(want)) <= 1e-6 * abs(float(want))
+    assert float(got) == float(again)
+    with pytest.raises(NotImplementedError):
+        utils.RelMaxNorm(out_dim)(t.cuda(), q.cuda().requires_grad_(True))
+
+
+# --------------------------------------------------------------------------- captured step, new meshes
+@pytest.mark.parametrize("task,batch", [("elasticity", 2), ("naca", 2)])
+@pytest.mark.parametrize("math", ["fp32", "bf16"])
+def test_captured_step_replays_new_per_sample_meshes(task, batch, math):
+    """BASELINE config 5 (NACA: per-sample meshes, hipGraph-captured step) and Elasticity: the captured
+    step rebuilds its selection plans from the static mesh buffers, so after set_batch(...meshes...)
+    a replay must equal an eager step on the NEW clouds (train_naca.py:62-65, train_elasticity.py:46)."""
+    from position_induced_transformer_amd import ops, tasks
+    from position_induced_transformer_amd.engine import TrainStep
+    with ops.math_mode(math):
+        model, sample, meta = tasks.make_task(task, seed=7)
+        first, second = sample(batch), sample(batch)
+        assert not torch.equal(first[2], second[2])
+        static = tuple(t.clone() for t in first)
+        if task == "naca":
+            static = (static[0], static[0], static[2], static[3])          # mesh_in IS func_in (train_naca.py:95)
+        step = TrainStep(model, static, meta["out_dim"], meta["p"])
+        step.capture()
+        step.replay()
+        step.set_batch(second[1], second[3], mesh_in=second[0], mesh_out=second[2])
+        step.replay()
+        torch.cuda.synchronize()
+        got_loss, got = float(step.loss), step.flat.flat.clone()
+        eager = TrainStep(model, second, meta["out_dim"], meta["p"], flat=step.flat)
+        eager.run_eager()
+        torch.cuda.synchronize()
+        tol = 1e-5 if math == "fp32" else 1e-3         # identical kernels either way; atomics reorder sums
+        assert abs(got_loss - float(eager.loss)) <= tol * abs(float(eager.loss))
+        assert gio.rel_l2(eager.flat.flat.cpu().numpy(), got.cpu().numpy()) <= 10 * tol
+        # and the first batch's result differs (the replay really consumed the new clouds)
+        step.set_batch(first[1], first[3], mesh_in=first[0], mesh_out=first[2])
+        step.replay()
+        torch.cuda.synchronize()
+        assert abs(float(step.loss) - got_loss) > 1e-4 * abs(got_loss)
+
+
+def test_set_batch_rejects_meshes_of_fixed_mesh_models():
+    from position_induced_transformer_amd import tasks
+    from position_induced_transformer_amd.engine import TrainStep
+    model, sample, meta = tasks.make_task("darcy", seed=1)
+    b = sample(2)
+    step = TrainStep(model, b, meta["out_dim"], meta["p"])
+    with pytest.raises(ValueError, match="batch-free"):
+        step.set_batch(b[1], b[3], mesh_in=b[0])
+
+
+# --------------------------------------------------------------------------- exception safety on the device
+def test_backward_that_raises_midway_does_not_poison_the_next_step():
+    """ADVICE r1 (ops.py deferred finish): a backward pass that dies after some attention layers have
+    loaded their fp64 d(scale) accumulators must not leak those partial sums - or a missing
+    end-of-pass callback - into the next step's d(lmda)."""
+    from position_induced_transformer_amd import tasks, utils
+    from position_induced_transformer_amd.ddp import FlatGradients
+    from position_induced_transformer_amd import ops
+    for seed in range(9, 60):             # a seed whose device c equals this host's in every layer (see the sweep)
+        model, sample, meta = tasks.make_task("darcy", seed=seed)
+        if all(np.array_equal(orc.head_scale(v.detach().cpu()).numpy(), ops.head_scale(v.detach()).cpu().numpy())
+               for k, v in model.named_parameters() if k.endswith("lmda")):
+            break
+    mesh_in, func_in, mesh_out, target = sample(2)
+    loss_fn = utils.RelLpNorm(meta["out_dim"], meta["p"])
+    flat = FlatGradients(model.parameters())               # in-place accumulation + deferred finishes
+
+    class Boom(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x):
+            return x.clone()
+
+        @staticmethod
+        def backward(ctx, g):
+            raise RuntimeError("boom")
+
+    # die inside the encoder's backward: decoder + processor layers have already deferred
+    orig = model.encoder
+    model.encoder = lambda a, b, c: Boom.apply(orig(a, b, c))
+    with pytest.raises(RuntimeError, match="boom"):
+        loss_fn(target, model(mesh_in, func_in, mesh_out)).backward()
+    model.encoder = orig
+    flat.zero_()
+    loss_fn(target, model(mesh_in, func_in, mesh_out)).backward()
+    torch.cuda.synchronize()
+    p = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in model.state_dict().items()}
+    mi = mesh_in.cpu().reshape(-1, 2)
+    ref = orc.pit_apply(p, "euclid", False, 4, 0.02, 0.02, mi, orc.with_coords(mi, func_in.cpu().reshape(2, -1, 1)),
+                        model.mesh_ltt.cpu(), mi).reshape(2, 43, 43, 1)
+    orc.rel_lp_loss(target.cpu(), ref, 1, 2).backward()
+    for k, q in model.named_parameters():
+        tol = 2e-4 if k.endswith("lmda") else 2e-5
+        assert gio.rel_l2(p[k].grad.numpy().reshape(-1), q.grad.cpu().numpy().reshape(-1)) <= tol, k
+    # a third step equals the second (nothing accumulates across steps)
+    second = flat.flat.clone()
+    flat.zero_()
+    loss_fn(target, model(mesh_in, func_in, mesh_out)).backward()
+    torch.cuda.synchronize()
+    assert gio.rel_l2(second.cpu().numpy(), flat.flat.cpu().numpy()) <= 1e-5
+
+
+# --------------------------------------------------------------------------- 200 captured steps
+def test_200_captured_steps_train_and_equal_the_eager_loop():
+    """engine.TrainStep + ddp.FlatAdam: 200 replays of the captured step (fixed batch) bring the loss
+    down and land on the same parameters as 200 eager steps of the same step function."""
+    from position_induced_transformer_amd import tasks
+    from position_induced_transformer_amd.ddp import FlatAdam, FlatGradients
+    from position_induced_transformer_amd.engine import TrainStep
+
+    def run(graphed):
+        model, sample, meta = tasks.make_task("darcy", seed=21)
+        g = torch.Generator().manual_seed(5)
+        x = torch.randn(4, 43, 43, 1, generator=g).cuda()
+        k = torch.ones(1, 1, 5, 5, device="cuda") / 25.0
+        y = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2), k, padding=2).permute(0, 2, 3, 1).contiguous()
+        mesh = sample(1)[0]
+        flat = FlatGradients(model.parameters(), flatten_params=True)
+        opt = FlatAdam(flat, lr=1e-3, cosine_t_max=203, zero_grads=True)
+        step = TrainStep(model, (mesh, x, mesh, y), meta["out_dim"], meta["p"], optimizer=opt, flat=flat)
+        if graphed:
+            step.capture(warmup=3)                       # three eager steps, then the capture (records, runs nothing)
+        else:
+            for _ in range(3):
+                step.run_eager()
+        first = None
+        for i in range(200):
+            step.replay() if graphed else step.run_eager()
+            if i == 0:
+                first = float(step.loss)
+        torch.cuda.synchronize()
+        return (first, float(step.loss)), flat.flat_params.clone(), int(opt.step_count)
+
+    l_e, p_e, n_e = run(False)
+    l_g, p_g, n_g = run(True)
+    assert n_e == 203 and n_g == 203
+    assert l_e[1] < 0.5 * l_e[0] and l_g[1] < 0.5 * l_g[0], (l_e, l_g)
+    assert abs(l_g[0] - l_e[0]) <= 1e-4 * abs(l_e[0])     # same state after the three warm-up steps
+    assert abs(l_g[1] - l_e[1]) <= 5e-2 * abs(l_e[1])     # fp32 atomics reorder sums; 200 Adam steps amplify

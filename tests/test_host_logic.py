@@ -1,0 +1,179 @@
+"""CPU: host logic around the HIP path that needs no device - the torch.compile boundary, the
+import-time behaviour of pit.py:1-11, exception safety of the deferred d(lmda) finish, the flat
+gradient buffer surviving ``optimizer.zero_grad()``, the per-thread math mode / head-scale route."""
+import os
+import subprocess
+import sys
+import threading
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# --------------------------------------------------------------------------- torch.compile boundary
+def test_task_forward_is_opaque_to_dynamo_and_wrapper_keeps_orig_mod_keys():
+    """train_darcy.py:112 `model = torch.compile(model)` and :150 `model.state_dict()`: the wrapper
+    must carry the `_orig_mod.` keys and calling it must reach OUR operators (which refuse CPU
+    tensors with their own message), not fail inside dynamo."""
+    from position_induced_transformer_amd import pit as P, tasks
+    model, _, _ = tasks.make_task("darcy", device="cpu")
+    assert getattr(type(model).forward, "_pit_eager", False)
+    compiled = torch.compile(model)
+    keys = list(compiled.state_dict().keys())
+    assert keys and all(k.startswith("_orig_mod.") for k in keys)
+    assert [k[len("_orig_mod."):] for k in keys] == list(model.state_dict().keys())
+    with pytest.raises(RuntimeError, match="HIP device only"):
+        compiled(torch.zeros(43, 43, 2), torch.zeros(2, 43, 43, 1), torch.zeros(43, 43, 2))
+    # torch._dynamo.disable(model) of train_darcy.py:152 is accepted on the compiled wrapper as well
+    again = torch._dynamo.disable(compiled)
+    with pytest.raises(RuntimeError, match="HIP device only"):
+        again(torch.zeros(43, 43, 2), torch.zeros(2, 43, 43, 1), torch.zeros(43, 43, 2))
+
+    class script_model(P.pit_fixed):              # a class written the way the scripts write theirs
+        def forward(self, mesh_in, func_in, mesh_out):
+            return self.encoder(mesh_in, func_in, self.mesh_ltt)
+    assert getattr(script_model.forward, "_pit_eager", False)
+
+
+def test_operator_entry_points_are_dynamo_disabled():
+    from position_induced_transformer_amd import ops
+    for fn in (ops.posatt_apply, ops.mlp_apply, ops.rel_lp_loss, ops.instance_norm_points, ops.rel_max_norm):
+        assert getattr(fn, "_torchdynamo_disable", False), fn
+
+
+def test_reference_checkpoint_through_compile_roundtrip(tmp_path):
+    """A checkpoint written as the scripts write it (state_dict of the torch.compile wrapper,
+    train_darcy.py:150) loads back into a fresh model."""
+    from position_induced_transformer_amd import tasks, utils
+    model, _, _ = tasks.make_task("darcy", device="cpu", seed=3)
+    path = tmp_path / "model.pth"
+    torch.save({"model_state": torch.compile(model).state_dict()}, path)
+    fresh, _, _ = tasks.make_task("darcy", device="cpu", seed=4)
+    utils.load_reference_checkpoint(fresh, str(path))
+    for (k, a), (_, b) in zip(model.state_dict().items(), fresh.state_dict().items()):
+        assert torch.equal(a, b), k
+
+
+# --------------------------------------------------------------------------- import-time behaviour
+def _import_probe(env_extra):
+    code = ("import torch, numpy as np; torch.manual_seed(1234); np.random.seed(99); "
+            "import position_induced_transformer_amd.pit as P; "
+            "print(torch.initial_seed(), int(np.random.get_state()[1][0]), torch.get_float32_matmul_precision())")
+    env = dict(os.environ, PYTHONPATH=ROOT, **env_extra)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True).stdout.split()
+    return int(out[0]), int(out[1]), out[2]
+
+
+def test_import_reproduces_the_reference_side_effects_with_opt_out():
+    """pit.py:2-10 seeds torch / numpy with 0 and sets the matmul precision at import; scripts that
+    never seed rely on it.  Reproduced by default, switched off by PIT_IMPORT_SIDE_EFFECTS=0."""
+    seed, np0, prec = _import_probe({})
+    assert seed == 0 and prec == "high"
+    import numpy as np
+    np.random.seed(0)
+    assert np0 == int(np.random.get_state()[1][0])
+    seed, _, _ = _import_probe({"PIT_IMPORT_SIDE_EFFECTS": "0"})
+    assert seed == 1234
+
+
+# --------------------------------------------------------------------------- deferred finish, exception safety
+def test_deferred_head_finish_survives_a_backward_pass_that_raised(monkeypatch):
+    """autograd skips end-of-pass callbacks when a backward raises.  The next pass must
+    still queue its flush, must not drain the aborted pass's entries, and must have zeroed the
+    accumulators those entries point at."""
+    from position_induced_transformer_amd import ops
+    flushed = []
+
+    def fake_flush():
+        flushed.append([p[0] for p in ops._PENDING_HEADS])
+        ops._PENDING_HEADS.clear()
+        ops._PENDING_TASK[0] = None
+    monkeypatch.setattr(ops, "_flush_head_finishes", fake_flush)
+    ops._PENDING_HEADS.clear()
+    ops._PENDING_TASK[0] = None
+
+    class Layer(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x, ws, boom):
+            ctx.ws, ctx.boom = ws, boom
+            return x * 2
+
+        @staticmethod
+        def backward(ctx, g):
+            ctx.ws += 1.0                                 # "partial sums" of this pass
+            ops._defer_head_finish(ctx.ws, None, None, None, 1, 0)
+            if ctx.boom:
+                raise RuntimeError("boom")
+            return g * 2, None, None
+
+    x = torch.ones(3, requires_grad=True)
+    ws_a, ws_b = torch.zeros(4, dtype=torch.float64), torch.zeros(4, dtype=torch.float64)
+    with pytest.raises(RuntimeError, match="boom"):
+        Layer.apply(Layer.apply(x, ws_a, False), ws_a, True).sum().backward()
+    assert flushed == [] and len(ops._PENDING_HEADS) >= 1         # the callback never ran: entries are stale
+    Layer.apply(x, ws_b, False).sum().backward()                    # a healthy pass afterwards
+    assert len(flushed) == 1 and len(flushed[0]) == 1 and flushed[0][0] is ws_b
+    assert float(ws_a.abs().sum()) == 0.0                            # aborted pass's accumulators were cleared
+    assert ops._PENDING_HEADS == [] and ops._PENDING_TASK[0] is None
+    Layer.apply(x, ws_b, False).sum().backward()                    # and the pass after that is normal again
+    assert len(flushed) == 2
+
+
+# --------------------------------------------------------------------------- flat gradients vs zero_grad()
+def test_flat_gradients_reattach_after_optimizer_zero_grad():
+    """`optimizer.zero_grad()` (set_to_none=True) drops the views into the flat buffer;
+    all_reduce()/attach() must copy the fresh gradients back and re-point .grad, every step."""
+    from position_induced_transformer_amd.ddp import FlatGradients
+    torch.manual_seed(0)
+    lin = torch.nn.Linear(5, 3)
+    flat = FlatGradients(lin.parameters())
+    opt = torch.optim.SGD(lin.parameters(), lr=0.1)
+    for step in range(3):
+        opt.zero_grad()                                   # .grad -> None
+        x = torch.randn(4, 5)
+        lin(x).pow(2).sum().backward()                    # autograd allocates fresh grads outside `flat`
+        expect = torch.cat([p.grad.reshape(-1).clone() for p in lin.parameters()])
+        assert flat.attach() == 2
+        assert torch.equal(flat.dense(), expect), step
+        for p, v in zip(flat.params, flat._views):
+            assert p.grad.data_ptr() == v.data_ptr()
+        assert flat.attach() == 0
+        opt.step()
+    flat.zero_()
+    assert float(flat.flat.abs().sum()) == 0.0 and all(p.grad is not None for p in lin.parameters())
+
+
+# --------------------------------------------------------------------------- per-thread modes
+def test_math_mode_and_head_scale_route_are_per_thread_host_state():
+    from position_induced_transformer_amd import ops
+    assert ops.get_math_mode() == "fp32" and ops.get_head_scale_route() == "device"
+    seen = {}
+
+    def worker():
+        seen["before"] = (ops.get_math_mode(), ops.get_head_scale_route())
+        ops.set_math_mode("bf16")
+        ops.set_head_scale_route("host")
+        seen["after"] = (ops.get_math_mode(), ops.get_head_scale_route())
+    with ops.math_mode("bf16"), ops.head_scale_route("host"):
+        t = threading.Thread(target=worker)
+        t.start()
+        t.join()
+        assert (ops.get_math_mode(), ops.get_head_scale_route()) == ("bf16", "host")
+    assert seen["before"] == ("fp32", "device") and seen["after"] == ("bf16", "host")
+    assert (ops.get_math_mode(), ops.get_head_scale_route()) == ("fp32", "device")
+    with pytest.raises(ValueError):
+        ops.set_head_scale_route("gpu")
+
+
+def test_inplace_gradient_slots_are_opt_in():
+    """kernels write into .grad in place only for parameters FlatGradients registered, while
+    the registered view is still attached and no hooks sit on the parameter."""
+    from position_induced_transformer_amd import ops
+    p = torch.nn.Parameter(torch.zeros(4))
+    p.grad = torch.zeros(4)
+    assert ops._grad_slot(p) is None                     # an existing .grad alone is not consent
+    ops.mark_inplace_grad(p, p.grad)
+    # (CPU tensors never qualify: the check is for device fp32 buffers)
+    assert ops._grad_slot(p) is None
