@@ -440,6 +440,17 @@ extern "C" int pit_select_fwd(const float* mesh_out, const float* mesh_in, int m
     return 0;
 }
 
+// plain fill kernel used instead of hipMemsetAsync: a memset NODE of a captured hipGraph is not reliably
+// ordered against the neighbouring kernel nodes on ROCm 7.2 once other work ran between two replays
+// (observed: counts not yet zero when plan_rows_reg adds to them -> cursors past the lists -> wild writes)
+__global__ __launch_bounds__(256) void fill_int_kernel(int* __restrict__ p, long n, int v) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) p[i] = v;
+}
+static void fill_int(int* p, long n, int v, hipStream_t s) {
+    const unsigned blocks = (unsigned)std::min<long>((n + 255) / 256, 1024L);
+    hipLaunchKernelGGL(fill_int_kernel, dim3(std::max(1u, blocks)), dim3(256), 0, s, p, n, v);
+}
+
 // transposed lists from nbr_idx / counts: scan + fill
 static int launch_transpose(const int* nbr_idx, const int* nbr_cnt, int mesh_batch, int n_out, int n_in, int cap,
                      int* rev_ptr, int* rev_row, int* counts, int* cursor, hipStream_t s) {
@@ -479,10 +490,9 @@ extern "C" int pit_plan_fwd(const float* mesh_out, const float* mesh_in, int mes
     const long rows = (long)mesh_batch * n_out;
     int* counts = rev_ptr ? workspace : nullptr;
     int* cursor = rev_ptr ? workspace + (long)mesh_batch * n_in : nullptr;
-    hipError_t e;
     if (rev_ptr) {
-        if ((e = hipMemsetAsync(counts, 0, sizeof(int) * (size_t)mesh_batch * n_in, s)) != hipSuccess) return (int)e;
-        if ((e = hipMemsetAsync(rev_row, 0xFF, sizeof(int) * (size_t)rows * cap, s)) != hipSuccess) return (int)e;
+        fill_int(counts, (long)mesh_batch * n_in, 0, s);
+        fill_int(rev_row, rows * cap, -1, s);
     }
     const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
 #define PIT_PLAN(I_) hipLaunchKernelGGL(plan_rows_reg<I_>, grid, block, 0, s, a, cap, nbr_idx, nbr_cnt, counts)
@@ -519,10 +529,9 @@ extern "C" int pit_neighbors_fwd(const float* mesh_out, const float* mesh_in, in
     const long rows = (long)mesh_batch * n_out;
     int* counts = rev_ptr ? workspace : nullptr;                       // mesh_batch * n_in
     int* cursor = rev_ptr ? workspace + (long)mesh_batch * n_in : nullptr;
-    hipError_t e;
     if (rev_ptr) {
-        if ((e = hipMemsetAsync(counts, 0, sizeof(int) * (size_t)mesh_batch * n_in, s)) != hipSuccess) return (int)e;
-        if ((e = hipMemsetAsync(rev_row, 0xFF, sizeof(int) * (size_t)rows * cap, s)) != hipSuccess) return (int)e;
+        fill_int(counts, (long)mesh_batch * n_in, 0, s);
+        fill_int(rev_row, rows * cap, -1, s);
     }
     hipLaunchKernelGGL(neighbors_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, a, cap, nbr_idx, nbr_cnt,
                        counts);

@@ -60,6 +60,8 @@ def _pin(*objs) -> None:
 
 
 def _ws_key(device):
+    if os.environ.get("PIT_DBG_WS_DEVICE_KEY"):
+        return device.index
     return (device.index, torch.cuda.current_stream(device).cuda_stream)
 
 
