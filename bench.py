@@ -31,6 +31,8 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# before the first HIP call (see position_induced_transformer_amd/__init__.py: ROCm 7.2 graph packet capture)
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402

@@ -157,17 +157,22 @@ def _flush_head_finishes() -> None:
             _lib.check(rc, "pit_posatt_dhead_finish")
 
 
-def _defer_head_finish(work, d_head, head, scale, n_head: int, flags: int) -> None:
+def _defer_head_begin() -> None:
+    """Call BEFORE the backward kernel of a deferred layer loads its accumulators.  On the first
+    deferred layer of a backward pass: entries left by another pass mean that pass raised before its
+    end-of-pass callback ran (autograd skips the callbacks then) - their accumulators hold partial
+    sums of an aborted pass: zero them, forget the entries; then queue this pass's flush."""
     task = _graph_task()
     if _PENDING_TASK[0] != task:
-        # first deferred layer of THIS backward pass.  Entries left by another pass mean that pass
-        # raised before its end-of-pass callback ran (autograd skips the callbacks then): their
-        # accumulators hold partial sums of an aborted pass - zero them and forget the entries.
         for stale in _PENDING_HEADS:
             stale[0].zero_()
         _PENDING_HEADS.clear()
         _PENDING_TASK[0] = task
         torch.autograd.Variable._execution_engine.queue_callback(_flush_head_finishes)
+
+
+def _defer_head_finish(work, d_head, head, scale, n_head: int, flags: int) -> None:
+    _defer_head_begin()
     _PENDING_HEADS.append((work, d_head, head, scale, n_head, flags))
 
 
@@ -370,6 +375,7 @@ class _PosAtt(torch.autograd.Function):
         work = _layer_workspace(slot, n_head) if defer else _dscale_workspace(values.device, n_head)
         if defer:
             acc_head |= 2                               # PIT_HEAD_DEFER: finished by _flush_head_finishes
+            _defer_head_begin()                         # (clears what an aborted pass left, before the kernel adds)
 
         def launch(dv, dh, stream_ptr):
             rc = _lib.lib().pit_posatt_bwd(

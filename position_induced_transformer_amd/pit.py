@@ -148,7 +148,13 @@ class posatt(nn.Module):
         """pit.py:54-57 for a caller-provided dense A (a plain tensor contraction; the fused path has
         no dense A to contract - ``forward`` does not call this)."""
         eq = "bhnj,bjd->bnhd" if self._batched else "hnj,bjd->bnhd"
-        return torch.einsum(eq, A, U).reshape(U.shape[0], -1, self.n_head * U.shape[-1])
+        prev = torch.get_float32_matmul_precision()      # 'high' (pit.py:2) lets ATen use reduced-precision GEMMs:
+        torch.set_float32_matmul_precision("highest")    # this helper stays exact fp32, like the fused forward
+        try:
+            out = torch.einsum(eq, A, U)
+        finally:
+            torch.set_float32_matmul_precision(prev)
+        return out.reshape(U.shape[0], -1, self.n_head * U.shape[-1])
 
 
 class posatt_cross(posatt):

@@ -1,7 +1,11 @@
 import os
 import sys
 
-import pytest
+# must precede the first HIP call of the process (torch.cuda.is_available() below initialises the runtime):
+# see position_induced_transformer_amd/__init__.py for what this works around
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
+
+import pytest  # noqa: E402
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")):
