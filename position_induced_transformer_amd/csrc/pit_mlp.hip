@@ -405,6 +405,195 @@ __global__ __launch_bounds__(256) void gemm_lds_kernel(GemmArgs g) {
     }
 }
 
+// ------------------------------------------------------------------------------------
+// Large-regime GEMM of the bf16 math mode: operands are rounded to bf16 ONCE, while they are staged
+// into LDS, and the contraction runs on v_mfma_f32_32x32x16_bf16 (16 k per instruction, fp32
+// accumulation): 1/16 of the matrix-pipe time of the fp32 form and half the LDS bytes.
+// Both operand images are [i][k] with 8 consecutive k = one 16-B fragment read (the lane map of the
+// instruction: lane (r, h) holds X[r][8h .. 8h+7]); rows are BPK = 40 bf16 = 80 B apart, which makes
+// the 16-lane groups of ds_read_b128 and the 8-lane groups of ds_write_b128 hit 64 / 32 different
+// banks.  A k-contiguous operand (KC) is staged with coalesced 16-B loads and written as 8-B packed
+// quads; an i-contiguous operand (IC) needs the transpose: lane = i, each lane fetches its own 4/8/16
+// consecutive k with coalesced 4-B loads (64 consecutive i per wave instruction) and writes whole
+// 16-B fragments - no cross-lane movement, no 2-byte LDS stores.
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f32x16 mfma_32x32x16_bf16(bf16x8_t a, bf16x8_t b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ unsigned pack2_bf16(float lo, float hi) {
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    const f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+}
+constexpr int BPK = LBK + 8;      // LDS row pitch in bf16 elements
+
+template <int LBM, bool A_KC, bool B_KC, int EPI>
+__global__ __launch_bounds__(256) void gemm_bfl_kernel(GemmArgs g) {
+    constexpr int TN = (LBM == 128) ? 2 : 1;
+    constexpr int PA = LBM / 32;                  // KC staging passes for A (4 floats per thread and pass)
+    constexpr int KPA = LBK / (256 / LBM);        // IC staging: k per thread for A (lane = row)
+    constexpr int KPB = LBK / (256 / LBN);        // ... and for B
+    constexpr bool KSPLIT = (LBM == 32);
+    __shared__ __attribute__((aligned(16))) unsigned short As[LBM * BPK];
+    __shared__ __attribute__((aligned(16))) unsigned short Bs[LBN * BPK];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int m0 = blockIdx.y * LBM, n0 = blockIdx.x * LBN;
+    const int wrow = (LBM == 128) ? wave * 32 : (LBM == 64 ? (wave & 1) * 32 : 0);
+    const int wcol = (LBM == 128) ? 0 : (LBM == 64 ? (wave >> 1) * 32 : (wave & 1) * 32);
+    const int ksel = KSPLIT ? (wave >> 1) : 0;
+    const int kbeg = blockIdx.z * g.k_slab;
+    const int kend = min(g.K, kbeg + g.k_slab);
+    const __amdgpu_buffer_rsrc_t ra = make_rsrc(g.A, g.a_bytes);
+    const __amdgpu_buffer_rsrc_t rb = make_rsrc(g.B, g.b_bytes);
+    const int n_real = (EPI == EPI_ATOMIC && g.ones_col >= 0) ? g.N - 1 : g.N;
+
+    float sa[A_KC ? PA * 4 : KPA], sb[B_KC ? 8 : KPB];
+    // the bias gradient (virtual ones column) = row sums of the A operand, exact fp32 from the staging
+    // registers of the first column block (A is i-contiguous in every row-reducing GEMM)
+    const bool want_rowsum = (EPI == EPI_ATOMIC) && !A_KC && g.ones_col >= 0 && blockIdx.x == 0;
+    float rsum = 0.0f;
+    auto gload = [&](int kc) {
+        if (A_KC) {
+#pragma unroll
+            for (int p = 0; p < PA; ++p) {
+                const int row = m0 + p * 32 + (tid >> 3), k = kc + (tid & 7) * 4;
+                const bool ok = row < g.M && k < kend;
+                float q[4];
+                buf_load4(ra, ok ? ((unsigned)row * (unsigned)g.a_rs + (unsigned)k) * 4u : g.a_bytes, q);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) sa[p * 4 + e] = q[e];
+            }
+        } else {
+            const int m = m0 + tid % LBM, k0 = kc + (tid / LBM) * KPA;
+#pragma unroll
+            for (int e = 0; e < KPA; ++e) {
+                const bool ok = m < g.M && k0 + e < kend;
+                sa[e] = buf_load(ra, ok ? ((unsigned)(k0 + e) * (unsigned)g.a_cs + (unsigned)m) * 4u : g.a_bytes);
+            }
+        }
+        if (B_KC) {
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const int n = n0 + p * 32 + (tid >> 3), k = kc + (tid & 7) * 4;
+                const bool ok = n < n_real && k < kend;
+                float q[4];
+                buf_load4(rb, ok ? ((unsigned)n * (unsigned)g.b_cs + (unsigned)k) * 4u : g.b_bytes, q);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) sb[p * 4 + e] = q[e];
+            }
+        } else {
+            const int n = n0 + tid % LBN, k0 = kc + (tid / LBN) * KPB;
+#pragma unroll
+            for (int e = 0; e < KPB; ++e) {
+                const bool ok = n < n_real && k0 + e < kend;
+                sb[e] = buf_load(rb, ok ? ((unsigned)(k0 + e) * (unsigned)g.b_rs + (unsigned)n) * 4u : g.b_bytes);
+            }
+        }
+    };
+    auto lstore = [&]() {
+        if (A_KC) {
+#pragma unroll
+            for (int p = 0; p < PA; ++p) {
+                uint2 w;
+                w.x = pack2_bf16(sa[p * 4 + 0], sa[p * 4 + 1]);
+                w.y = pack2_bf16(sa[p * 4 + 2], sa[p * 4 + 3]);
+                *reinterpret_cast<uint2*>(As + (p * 32 + (tid >> 3)) * BPK + (tid & 7) * 4) = w;
+            }
+        } else {
+            unsigned short* dst = As + (tid % LBM) * BPK + (tid / LBM) * KPA;
+            if (want_rowsum) {
+#pragma unroll
+                for (int e = 0; e < KPA; ++e) rsum += sa[e];
+            }
+#pragma unroll
+            for (int e = 0; e < KPA; e += 4) {
+                uint2 w;
+                w.x = pack2_bf16(sa[e], sa[e + 1]);
+                w.y = pack2_bf16(sa[e + 2], sa[e + 3]);
+                *reinterpret_cast<uint2*>(dst + e) = w;
+            }
+        }
+        if (B_KC) {
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                uint2 w;
+                w.x = pack2_bf16(sb[p * 4 + 0], sb[p * 4 + 1]);
+                w.y = pack2_bf16(sb[p * 4 + 2], sb[p * 4 + 3]);
+                *reinterpret_cast<uint2*>(Bs + (p * 32 + (tid >> 3)) * BPK + (tid & 7) * 4) = w;
+            }
+        } else {
+            unsigned short* dst = Bs + (tid % LBN) * BPK + (tid / LBN) * KPB;
+#pragma unroll
+            for (int e = 0; e < KPB; e += 4) {
+                uint2 w;
+                w.x = pack2_bf16(sb[e], sb[e + 1]);
+                w.y = pack2_bf16(sb[e + 2], sb[e + 3]);
+                *reinterpret_cast<uint2*>(dst + e) = w;
+            }
+        }
+    };
+
+    f32x16 acc[TN];
+#pragma unroll
+    for (int t = 0; t < TN; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+
+    gload(kbeg);
+    for (int kc = kbeg; kc < kend; kc += LBK) {
+        lstore();
+        __syncthreads();
+        if (kc + LBK < kend) gload(kc + LBK);
+#pragma unroll
+        for (int st0 = 0; st0 < (KSPLIT ? 1 : 2); ++st0) {
+            const int st = KSPLIT ? ksel : st0;
+            const int ks = st * 16 + half * 8;            // lane (r, h): k = 8h .. 8h+7 of the 16-k step
+            const bf16x8_t af = *reinterpret_cast<const bf16x8_t*>(As + (wrow + l31) * BPK + ks);
+#pragma unroll
+            for (int t = 0; t < TN; ++t) {
+                const bf16x8_t bfr = *reinterpret_cast<const bf16x8_t*>(Bs + (wcol + t * 32 + l31) * BPK + ks);
+                acc[t] = mfma_32x32x16_bf16(af, bfr, acc[t]);
+            }
+        }
+        __syncthreads();
+    }
+
+    if (want_rowsum) {
+        const int row = m0 + tid % LBM;
+        if (row < g.M) atomicAdd(g.C2 + row, rsum);
+    }
+    if (KSPLIT) {                      // pair reduction: the k-half-1 waves hand their tile to their partners
+        __shared__ float red[KSPLIT ? 2 * 16 * 64 : 1];    // 2 waves x 16 registers x 64 lanes
+        if (ksel == 1) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[((wave & 1) * 16 + r) * 64 + lane] = acc[0][r];
+        }
+        __syncthreads();
+        if (ksel == 1) return;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][r] += red[((wave & 1) * 16 + r) * 64 + lane];
+    }
+#pragma unroll
+    for (int t = 0; t < TN; ++t) {
+        const int col = n0 + wcol + t * 32 + l31;
+        if (col >= n_real) continue;
+        float bias = 0.0f;
+        if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) bias = g.bias[col];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = m0 + wrow + acc_row(r, half);
+            if (row >= g.M) continue;
+            float v = acc[t][r] + bias;
+            if (EPI == EPI_BIAS_GELU) { g.Z[(long)row * g.ldz + col] = v; v = gelu_erf(v); }
+            if (EPI == EPI_MUL_GELU_GRAD) v *= gelu_erf_grad(g.G[(long)row * g.ldg + col]);
+            if (EPI == EPI_ATOMIC) atomicAdd(g.C + (long)row * g.ldc + col, v);
+            else g.C[(long)row * g.ldc + col] = v;
+        }
+    }
+}
+
 // out[m][k] = a[m][k] * gelu'(z[m][k]) (rows a_rs / out_rs apart, K % 4 == 0, 16-B aligned): the
 // trailing-gelu prologue as its own pass when the GEMM behind it is large - inside the GEMM every
 // column block would redo the erf for the whole A tile
@@ -650,18 +839,27 @@ bool try_launch_gemm_lds(GemmArgs g, hipStream_t s) {
         else if (bm == 64) hipLaunchKernelGGL((gemm_lds_kernel<64, A_, B_, EPI_, BF_>), grid, block, 0, s, g);  \
         else hipLaunchKernelGGL((gemm_lds_kernel<32, A_, B_, EPI_, BF_>), grid, block, 0, s, g);               \
     } while (0)
-#define PIT_LDS(A_, B_, EPI_) do { if (g.bf16) PIT_LDS_BF(A_, B_, EPI_, true); else PIT_LDS_BF(A_, B_, EPI_, false); } while (0)
+#define PIT_BFL(A_, B_, EPI_)                                                                                  \
+    do {                                                                                                       \
+        if (bm == 128) hipLaunchKernelGGL((gemm_bfl_kernel<128, A_, B_, EPI_>), grid, block, 0, s, g);         \
+        else if (bm == 64) hipLaunchKernelGGL((gemm_bfl_kernel<64, A_, B_, EPI_>), grid, block, 0, s, g);      \
+        else hipLaunchKernelGGL((gemm_bfl_kernel<32, A_, B_, EPI_>), grid, block, 0, s, g);                    \
+    } while (0)
+    static const bool legacy_bf = getenv("PIT_BF16_LEGACY") != nullptr;      // the round-1 form: fp32 in LDS, 32x32x8 MFMA
+#define PIT_LDS(A_, B_, EPI_) do { if (g.bf16 && !legacy_bf) PIT_BFL(A_, B_, EPI_); else if (g.bf16) PIT_LDS_BF(A_, B_, EPI_, true); else PIT_LDS_BF(A_, B_, EPI_, false); } while (0)
     switch (kind) {
         case 0: PIT_LDS(true, true, EPI_BIAS); break;
         case 1: PIT_LDS(true, true, EPI_BIAS_GELU); break;
         case 2: PIT_LDS(true, false, EPI_MUL_GELU_GRAD); break;
         case 3: PIT_LDS(true, false, EPI_STORE); break;
         default:
-            if (g.bf16) hipLaunchKernelGGL((gemm_lds_kernel<128, false, false, EPI_ATOMIC, true>), grid, block, 0, s, g);
+            if (g.bf16 && !legacy_bf) hipLaunchKernelGGL((gemm_bfl_kernel<128, false, false, EPI_ATOMIC>), grid, block, 0, s, g);
+            else if (g.bf16) hipLaunchKernelGGL((gemm_lds_kernel<128, false, false, EPI_ATOMIC, true>), grid, block, 0, s, g);
             else hipLaunchKernelGGL((gemm_lds_kernel<128, false, false, EPI_ATOMIC, false>), grid, block, 0, s, g);
             break;
     }
 #undef PIT_LDS
+#undef PIT_BFL
 #undef PIT_LDS_BF
     return true;
 }
