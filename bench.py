@@ -72,6 +72,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip batch sweep / optimizer / roofline probes")
     ap.add_argument("--cpu-iters", type=int, default=100)
+    ap.add_argument("--rollout", type=int, default=0,
+                    help="vorticity only: one step = the N-step autoregressive BPTT optimiser step of train_vorticity.py:118-129")
+    ap.add_argument("--recompute", action="store_true", help="with --rollout: activation recompute (eager only)")
     ap.add_argument("--math", choices=("fp32", "bf16"), default="fp32",
                     help="MFMA math mode of the contractions (pit_set_math_mode); fp32 = the reference's arithmetic")
     return ap.parse_args()
@@ -105,6 +108,12 @@ def build_step(args, device, rank, world, batch, with_optimizer=False, all_reduc
         flat = FlatGradients(model.parameters(), flatten_params=True)
         opt = FlatAdam(flat, lr=1e-3, cosine_t_max=30 * (1024 // 8), zero_grads=True)
     use_ar = (world > 1) if all_reduce is None else all_reduce
+    if args.rollout:
+        from position_induced_transformer_amd.engine import RolloutStep
+        y = torch.randn(*target.shape[:-1], args.rollout, generator=g).to(device)
+        step = RolloutStep(model, (mesh_in, func_in, y), args.rollout, meta["out_dim"], meta["p"], recompute=args.recompute,
+                           all_reduce=use_ar, optimizer=opt, flat=flat)
+        return step, model, meta
     step = TrainStep(model, (mesh_in, func_in, mesh_out, target), meta["out_dim"], meta["p"], affine,
                      all_reduce=use_ar, optimizer=opt, flat=flat)
     return step, model, meta
@@ -208,11 +217,11 @@ def pmc_traffic(kernel_key):
 
 
 def roofline_mlp_probe(model, batch):
-    """The kernel with the LARGEST share of the Darcy b=8 step (profiles/r0x step breakdown: 11 of 39
-    launches, ~19 % of the kernel time) is gemm_rd_kernel<1, EPI_BIAS_GELU>: the forward GEMMs of the
-    pointwise MLP with their bias + erf-GELU epilogue.  Timed here on the processor MLP
-    ((1+H)*hid -> hid -> hid on batch*L_ltt rows, pit.py:103): one kaiming_mlp forward = two launches of
-    that kernel; algorithmic FLOPs 2*rows*(n0*n1 + n1*n2), fp32 MFMA peak."""
+    """The kernel family with the LARGEST share of the Darcy b=8 step (profiles/ step breakdowns) is the forward
+    of the pointwise MLP with its bias + erf-GELU epilogues: since round 2 ONE launch per kaiming_mlp forward
+    in the small regime (mlp_fwd16_kernel: both contractions fused, 16-row slabs on v_mfma_f32_16x16x4_f32),
+    two LDS-tiled GEMM launches in the large regime.  Timed here on the processor MLP ((1+H)*hid -> hid -> hid
+    on batch*L_ltt rows, pit.py:103); algorithmic FLOPs 2*rows*(n0*n1 + n1*n2), fp32 MFMA peak."""
     from position_induced_transformer_amd import ops
     mlp = model.mlp[0]
     rows_per_sample = model.mesh_ltt.shape[0] if model.mesh_ltt is not None else 972
@@ -221,14 +230,17 @@ def roofline_mlp_probe(model, batch):
     with torch.no_grad():
         us = graph_time_us(lambda: ops.mlp_apply(x, mlp.mlp1.weight, mlp.mlp1.bias, mlp.mlp2.weight, mlp.mlp2.bias, True))
     rows = batch * rows_per_sample
-    flops = 2.0 * rows * (n0 * n1 + n1 * n2) / 2.0                 # per launch (two launches per forward)
-    us_launch = us / 2.0
+    # the library's own rule (csrc/pit_mlp.hip: try_launch_mlp_fwd16)
+    fused = n1 in (32, 64, 128) and n2 % 16 == 0 and 16 <= n2 <= n1 and rows >= 256 and rows * n1 * (n0 + n2) <= (1 << 27)
+    launches = 1 if fused else 2
+    flops = 2.0 * rows * (n0 * n1 + n1 * n2) / launches
+    us_launch = us / launches
     achieved = flops / (us_launch * 1e-6) / 1e12
-    alg_bytes = 4.0 * (rows * n0 + 2 * rows * n1 + rows * n1 + 2 * rows * n2 + n0 * n1 + n1 * n2) / 2.0
-    return {"bound": "mfma", "kernel": f"gemm_rd_kernel<1,BIAS_GELU> kaiming_mlp forward {n0}->{n1}->{n2} on {rows} rows "
-                                       f"(2 launches per forward, mean), batch {batch}",
+    alg_bytes = 4.0 * (rows * n0 + 2 * rows * n1 + (0 if fused else rows * n1) + 2 * rows * n2 + n0 * n1 + n1 * n2) / launches
+    name = f"mlp_fwd16_kernel<{n1}> (fused GEMM1+GELU+GEMM2+GELU)" if fused else "gemm_lds/gemm_rd kernel<BIAS_GELU> (mean of the two launches)"
+    return {"bound": "mfma", "kernel": f"{name}: kaiming_mlp forward {n0}->{n1}->{n2} on {rows} rows, batch {batch}",
             "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": pmc_traffic(f"gemm_rd_fwd_b{batch}"),
+            "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": pmc_traffic(f"mlp_fwd_b{batch}"),
             "us_per_launch": round(us_launch, 3), "flops_per_launch": flops, "algorithmic_bytes": alg_bytes}
 
 
@@ -404,10 +416,13 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if args.math == "fp32" else "bf16 MFMA operands, f32 accumulate",
             "data": "synthetic",
-            "config": {"workload": WORKLOADS.get(args.task, args.task) + f", fwd+loss+bwd, per-GPU batch {args.batch}",
+            "config": {"workload": WORKLOADS.get(args.task, args.task) + (f", {args.rollout}-step autoregressive rollout + ONE backward "
+                                                                           f"(train_vorticity.py:118-126){', activation recompute' if args.recompute else ''}"
+                                                                           if args.rollout else ", fwd+loss+bwd") + f", per-GPU batch {args.batch}",
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world,
                        "parallelism": f"dp{world}" if world > 1 else "single", "launch": mode},
             "loss": round(loss_val, 6),
+            "peak_memory_GB": round(torch.cuda.max_memory_allocated() / 1e9, 3),
             "timing": dict(spread, what="value = median over repeated blocks of exactly --steps steps, each bracketed by "
                                         "barrier + synchronize (MAX over ranks)"),
         }

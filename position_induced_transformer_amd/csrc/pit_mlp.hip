@@ -228,6 +228,144 @@ __global__ __launch_bounds__(512) void gemm_rd_triple_kernel(GemmArgs gx, GemmAr
 }
 
 // ------------------------------------------------------------------------------------
+// Small-regime fused MLP forward: Y = W2 gelu(W1 X + b1) + b2 (+ trailing gelu) in ONE launch.
+// A workgroup owns 16 rows and all n1 hidden columns (n1/16 waves, one 16x16 tile of
+// v_mfma_f32_16x16x4_f32 each): 16-row slabs keep rows/16 workgroups in flight (2048 rows -> 128,
+// where the 32-row fused variant of round 1 had 64 and lost to two separate launches), the hidden
+// activations never leave the workgroup (LDS) between the two contractions, and the second weight
+// matrix is prefetched before the first contraction starts.  Z1, H (and Z2) are still written for the
+// backward pass.  Operand fragments go global -> registers, 4 consecutive k per lane and step (the k
+// order inside a 16-k step is permuted identically for A and B).
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4_t mfma_16x16x4(float a, float b, f32x4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+struct FusedMlpArgs {
+    const float* x; long ldx; int rows, n0, n1, n2;
+    const float *w1, *b1, *w2, *b2;
+    int out_gelu;
+    float *z1, *h, *z2, *y; long ldy;
+    unsigned x_bytes, w1_bytes, w2_bytes;
+    int x_vec, w1_vec;                   // 16-B fragment loads legal
+};
+
+template <int N1>
+__global__ __launch_bounds__(N1 * 4) void mlp_fwd16_kernel(FusedMlpArgs g) {
+    constexpr int HP = N1 + 4;                          // LDS pitch of the hidden tile (floats)
+    constexpr int S2 = N1 / 16;                         // 16-k steps of the second contraction
+    __shared__ __attribute__((aligned(16))) float hs[16 * HP];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l15 = lane & 15, kq = lane >> 4;
+    const int m0 = blockIdx.x * 16;
+    const int row = m0 + l15;
+    const bool rvalid = row < g.rows;
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(g.x, g.x_bytes);
+    const __amdgpu_buffer_rsrc_t rw1 = make_rsrc(g.w1, g.w1_bytes);
+    const __amdgpu_buffer_rsrc_t rw2 = make_rsrc(g.w2, g.w2_bytes);
+    const int c1 = wave * 16 + l15;                     // this lane's column of the hidden layer (B operand row of W1)
+    const bool do2 = wave * 16 < g.n2;                  // waves that own an output tile
+    const int c2 = wave * 16 + l15;
+
+    // second weight matrix first: its latency hides behind the whole first contraction
+    float w2v[S2][4];
+#pragma unroll
+    for (int s = 0; s < S2; ++s)
+        buf_load4(rw2, (do2 && c2 < g.n2) ? ((unsigned)c2 * (unsigned)N1 + (unsigned)(16 * s + 4 * kq)) * 4u : g.w2_bytes, w2v[s]);
+
+    f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    const unsigned xbase = (unsigned)row * (unsigned)g.ldx * 4u, wbase = (unsigned)c1 * (unsigned)g.n0 * 4u;
+    const bool fast = g.x_vec && g.w1_vec;
+    for (int k0 = 0; k0 < g.n0; k0 += 64) {             // four 16-k steps per trip: 8 fragment loads in flight
+        float av[4][4], bv[4][4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int kk = k0 + 16 * s + 4 * kq;
+            if (fast && kk + 4 <= g.n0) {
+                buf_load4(rx, rvalid ? xbase + (unsigned)kk * 4u : g.x_bytes, av[s]);
+                buf_load4(rw1, wbase + (unsigned)kk * 4u, bv[s]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const bool ok = kk + e < g.n0;
+                    av[s][e] = buf_load(rx, (ok && rvalid) ? xbase + (unsigned)(kk + e) * 4u : g.x_bytes);
+                    bv[s][e] = buf_load(rw1, ok ? wbase + (unsigned)(kk + e) * 4u : g.w1_bytes);
+                }
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if ((s * 4 + e) & 1) acc1 = mfma_16x16x4(av[s][e], bv[s][e], acc1);
+                else acc0 = mfma_16x16x4(av[s][e], bv[s][e], acc0);
+            }
+    }
+    {   // bias + gelu; Z1 / H to memory (backward) and H to LDS (second contraction)
+        const int col = wave * 16 + l15;
+        const float bias = g.b1[col];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = 4 * kq + i;
+            const float z = acc0[i] + acc1[i] + bias;
+            const float hv = gelu_erf(z);
+            hs[r * HP + col] = hv;
+            if (m0 + r < g.rows) {
+                g.z1[(long)(m0 + r) * N1 + col] = z;
+                g.h[(long)(m0 + r) * N1 + col] = hv;
+            }
+        }
+    }
+    __syncthreads();
+    if (!do2) return;
+    f32x4_t o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < S2; ++s) {
+        const float4 a = *reinterpret_cast<const float4*>(hs + l15 * HP + 16 * s + 4 * kq);
+        o0 = mfma_16x16x4(a.x, w2v[s][0], o0);
+        o1 = mfma_16x16x4(a.y, w2v[s][1], o1);
+        o0 = mfma_16x16x4(a.z, w2v[s][2], o0);
+        o1 = mfma_16x16x4(a.w, w2v[s][3], o1);
+    }
+    if (c2 >= g.n2) return;
+    const float bias2 = g.b2[c2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = m0 + 4 * kq + i;
+        if (r >= g.rows) continue;
+        float v = o0[i] + o1[i] + bias2;
+        if (g.out_gelu) { g.z2[(long)r * g.n2 + c2] = v; v = gelu_erf(v); }
+        g.y[(long)r * g.ldy + c2] = v;
+    }
+}
+
+// eligibility + launch; false = use the two-launch path
+bool try_launch_mlp_fwd16(const float* x, long ldx, int rows, int n0, int n1, int n2, const float* w1, const float* b1,
+                          const float* w2, const float* b2, int out_gelu, float* z1, float* h, float* z2, float* y,
+                          long ldy, hipStream_t s) {
+    static const bool off = getenv("PIT_NO_FUSED_MLP") != nullptr;
+    if (off) return false;
+    if (n1 != 32 && n1 != 64 && n1 != 128) return false;
+    if (n2 % 16 != 0 || n2 > n1 || n2 < 16) return false;
+    if (rows < 256 || (long)rows * n1 * (n0 + n2) > (1L << 27)) return false;    // the LDS-tiled GEMMs take over above
+    const unsigned long long xb = ((unsigned long long)(rows - 1) * ldx + n0) * 4ull;
+    if (xb > PIT_MAX_BUFFER_BYTES) return false;
+    if ((reinterpret_cast<uintptr_t>(w2) & 15) != 0) return false;               // W2 rows are read as 16-B fragments
+    FusedMlpArgs g;
+    g.x = x; g.ldx = ldx; g.rows = rows; g.n0 = n0; g.n1 = n1; g.n2 = n2;
+    g.w1 = w1; g.b1 = b1; g.w2 = w2; g.b2 = b2; g.out_gelu = out_gelu;
+    g.z1 = z1; g.h = h; g.z2 = z2; g.y = y; g.ldy = ldy;
+    g.x_bytes = (unsigned)xb; g.w1_bytes = (unsigned)((size_t)n1 * n0 * 4); g.w2_bytes = (unsigned)((size_t)n2 * n1 * 4);
+    g.x_vec = (reinterpret_cast<uintptr_t>(x) & 15) == 0 && ldx % 4 == 0;
+    g.w1_vec = (reinterpret_cast<uintptr_t>(w1) & 15) == 0 && n0 % 4 == 0;
+    const dim3 grid((rows + 15) / 16);
+    if (n1 == 32) hipLaunchKernelGGL((mlp_fwd16_kernel<32>), grid, dim3(128), 0, s, g);
+    else if (n1 == 64) hipLaunchKernelGGL((mlp_fwd16_kernel<64>), grid, dim3(256), 0, s, g);
+    else hipLaunchKernelGGL((mlp_fwd16_kernel<128>), grid, dim3(512), 0, s, g);
+    return true;
+}
+
+// ------------------------------------------------------------------------------------
 // Large-regime GEMM: operands staged through LDS.
 //
 // The register-direct kernel above has every lane fetch its own fragment: a wave-level 16-B load
@@ -1039,6 +1177,10 @@ extern "C" int pit_mlp_fwd(const float* x, long ldx, int rows, int n0, int n1, i
     if (out_gelu && !z2) return PIT_ERR_NULL;
     if (rows <= 0 || n0 <= 0 || n1 <= 0 || n2 <= 0 || ldx < n0 || ldy < n2) return PIT_ERR_SIZE;
     hipStream_t s = (hipStream_t)stream;
+    if (try_launch_mlp_fwd16(x, ldx, rows, n0, n1, n2, w1, b1, w2, b2, out_gelu, z1, h, z2, y, ldy, s)) {
+        PIT_CHECK_LAUNCH();
+        return 0;
+    }
     GemmArgs g = blank();
     g.A = x; g.a_rs = ldx; g.a_cs = 1;
     g.B = w1; g.b_rs = 1; g.b_cs = n0;            // B(k,n) = w1[n][k]

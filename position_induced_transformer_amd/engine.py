@@ -50,7 +50,9 @@ class TrainStep:
         self._step()
 
     def capture(self, warmup: int = 3) -> None:
-        """Warm up on a side stream (allocator + mesh-plan caches), then capture."""
+        """Warm up (allocator, mesh-plan caches, the per-stream accumulators of ops) and capture ON THE SAME
+        side stream: a workspace first requested during capture would be allocated - and zero-filled by a
+        captured memset on every replay - inside the graph."""
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -59,8 +61,9 @@ class TrainStep:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        with torch.cuda.graph(self.graph, stream=side):
             self._step()
+        self._capture_stream = side
 
     def replay(self) -> None:
         self.graph.replay()
@@ -81,3 +84,29 @@ class TrainStep:
             self.mesh_in.copy_(mesh_in)
         if mesh_out is not None and self.mesh_out.data_ptr() != self.mesh_in.data_ptr():
             self.mesh_out.copy_(mesh_out)
+
+
+class RolloutStep(TrainStep):
+    """The autoregressive optimiser step of train_vorticity.py:118-129 as ONE hipGraph: ``steps`` forward
+    passes (each prediction appended to the input history), the summed RelLp loss with the script's
+    argument order ``myloss(out, y_t)``, one backward through the whole rollout, (all-reduce), (Adam).
+    ``batch`` = (mesh, x, y) with x (b, .., memory) and y (b, .., steps)."""
+
+    def __init__(self, model, batch, steps: int, out_dim: int, p: int, recompute: bool = False, **kw):
+        mesh, x, y = batch
+        super().__init__(model, (mesh, x, mesh, y), out_dim, p, **kw)
+        self.steps, self.recompute = steps, recompute
+
+    def _step(self) -> None:
+        from .tasks import rollout_loss
+        clear = None if getattr(self.optimizer, "zero_grads", False) else self.flat.flat
+        if clear is not None:
+            clear.zero_()
+        loss = rollout_loss(self.model, self.mesh_in, self.func_in, self.target, self.steps,
+                            lambda out, y_t: ops.rel_lp_loss(out, y_t, self.out_dim, self.p), self.recompute)
+        torch.autograd.backward(loss, grad_tensors=self._seed)
+        self.loss = loss.detach()
+        if self.all_reduce:
+            self.flat.all_reduce()
+        if self.optimizer is not None:
+            self.optimizer.step()

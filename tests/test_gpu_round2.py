@@ -358,3 +358,70 @@ def test_200_captured_steps_train_and_equal_the_eager_loop():
     assert l_e[1] < 0.8 * l_e[0] and l_g[1] < 0.8 * l_g[0], (l_e, l_g)
     assert abs(l_g[0] - l_e[0]) <= 1e-4 * abs(l_e[0])     # same state after the three warm-up steps
     assert abs(l_g[1] - l_e[1]) <= 5e-2 * abs(l_e[1])     # fp32 atomics reorder sums; 200 Adam steps amplify
+
+
+# --------------------------------------------------------------------------- row f3: the 20-step rollout
+def _vorticity_full(batch, seed):
+    from position_induced_transformer_amd import tasks
+    model, sample, meta = tasks.make_task("vorticity", seed=seed)
+    g = torch.Generator().manual_seed(seed)
+    mesh = sample(1)[0]
+    x = torch.randn(batch, 64, 64, 10, generator=g).cuda()
+    y = torch.randn(batch, 64, 64, 20, generator=g).cuda()
+    return model, mesh, x, y, meta
+
+
+def test_rollout_20_steps_full_size_matches_oracle_bptt():
+    """train_vorticity.py:118-126 at the script's size (64x64 grid -> 16x16 latent, hid 256, H=2, 4 blocks,
+    InstanceNorm, 20 autoregressive steps, loss(out, y_t) summed, ONE backward through all 20 forwards) on a
+    reduced batch of 1: loss and every parameter gradient against the oracle's BPTT on the CPU.  Head scales
+    through the host route (20 chained forwards on a periodic GRID: one moved tie shell would swamp the
+    comparison - see the sweep).  Tolerances are those of a 20-fold composition of the 1e-5 model."""
+    from position_induced_transformer_amd import ops, tasks, utils
+    model, mesh, x, y, meta = _vorticity_full(1, seed=31)
+    loss_fn = utils.RelLpNorm(1, 2)
+    with ops.head_scale_route("host"):
+        loss = tasks.rollout_loss(model, mesh, x, y, 20, loss_fn)
+        loss.backward()
+    torch.cuda.synchronize()
+    p = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in model.state_dict().items()}
+    mi, ltt = mesh.cpu().reshape(-1, 2), model.mesh_ltt.cpu()
+    xc, yc = x.cpu(), y.cpu()
+    ref_loss = 0.0
+    for t in range(20):
+        f = orc.with_coords(mi, xc.reshape(1, -1, 10))
+        out = orc.pit_apply(p, "periodic2d", False, 4, 0.02, 0.02, mi, f, ltt, mi, norm_after_enc_proc=True).reshape(1, 64, 64, 1)
+        ref_loss = ref_loss + orc.rel_lp_loss(out, yc[..., t:t + 1], 1, 2)
+        xc = torch.cat((xc[..., 1:], out), dim=-1)
+    ref_loss.backward()
+    assert abs(float(loss.detach()) - float(ref_loss)) <= 2e-5 * abs(float(ref_loss)), (float(loss), float(ref_loss))
+    worst = 0.0
+    for k, q in model.named_parameters():
+        e = gio.rel_l2(p[k].grad.numpy().reshape(-1), q.grad.cpu().numpy().reshape(-1))
+        worst = max(worst, e if not k.endswith("lmda") else 0.0)
+        assert e <= (5e-3 if k.endswith("lmda") else 5e-4), (k, e)
+    print("rollout-20 full size: loss", float(loss.detach()), "max weight-grad rel-L2", worst)
+
+
+@pytest.mark.parametrize("recompute", [False, True])
+def test_rollout_step_graph_equals_eager_and_recompute_equals_plain(recompute):
+    """engine.RolloutStep: the captured 20-step optimiser step == the eager one (3 steps here, full size,
+    batch 2), with and without activation recompute; recompute must not change the gradient."""
+    from position_induced_transformer_amd.engine import RolloutStep
+    model, mesh, x, y, meta = _vorticity_full(2, seed=32)
+    eager = RolloutStep(model, (mesh, x, y[..., :3].contiguous()), 3, 1, 2, recompute=False)
+    eager.run_eager()
+    torch.cuda.synchronize()
+    ref_loss, ref = float(eager.loss), eager.flat.flat.clone()
+    step = RolloutStep(model, (mesh, x, y[..., :3].contiguous()), 3, 1, 2, recompute=recompute, flat=eager.flat)
+    step.run_eager()
+    torch.cuda.synchronize()
+    assert abs(float(step.loss) - ref_loss) <= 1e-6 * abs(ref_loss)
+    assert gio.rel_l2(ref.cpu().numpy(), step.flat.flat.cpu().numpy()) <= 2e-5
+    if not recompute:                    # (checkpoint's saved-tensor hooks are not capturable)
+        step.capture()
+        step.replay()
+        step.replay()
+        torch.cuda.synchronize()
+        assert abs(float(step.loss) - ref_loss) <= 1e-6 * abs(ref_loss)
+        assert gio.rel_l2(ref.cpu().numpy(), step.flat.flat.cpu().numpy()) <= 2e-5
