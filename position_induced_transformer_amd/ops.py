@@ -138,7 +138,15 @@ def _layer_workspace(slot: torch.Tensor, n_head: int) -> torch.Tensor:
 
 def _flush_head_finishes() -> None:
     """End-of-backward callback: one launch finishing d(lmda) of all deferred layers."""
-    pend = list(_PENDING_HEADS)
+    # a layer applied several times in one pass (the autoregressive rollout: train_vorticity.py:122-126)
+    # deferred once per application into the SAME accumulators: drain them once - duplicates in one batch
+    # would race on the non-atomic "d_head += ..." of the finishing kernel
+    seen, pend = set(), []
+    for entry in _PENDING_HEADS:
+        key = (entry[0].data_ptr(), entry[1].data_ptr())
+        if key not in seen:
+            seen.add(key)
+            pend.append(entry)
     _PENDING_HEADS.clear()
     _PENDING_TASK[0] = None
     for dev in sorted({p[0].device.index for p in pend}):
