@@ -425,3 +425,59 @@ def test_rollout_step_graph_equals_eager_and_recompute_equals_plain(recompute):
         torch.cuda.synchronize()
         assert abs(float(step.loss) - ref_loss) <= 1e-6 * abs(ref_loss)
         assert gio.rel_l2(ref.cpu().numpy(), step.flat.flat.cpu().numpy()) <= 2e-5
+
+
+# --------------------------------------------------------------------------- row f4: long-J inference, Cylinder
+def test_zssr_421_forward_matches_oracle():
+    """train_darcy.py:152-178: the 43x43-trained Darcy model evaluated at 421x421 (J = 177 241 keys per encoder
+    row, 177 241 decoder rows) under no_grad, batch 1, against the oracle's dense evaluation on the CPU
+    (2 x 256 x 177 241 attention weights per direction).  Streaming selection (rows > 4096 keys) and candidate
+    lists of ~4.4 k keys per latent point are what this exercises."""
+    import time
+    from position_induced_transformer_amd import ops, tasks
+    model, _, _ = tasks.make_task("darcy", seed=41)
+    g = torch.Generator().manual_seed(41)
+    mesh = tasks.grid_mesh_2d(421, True, "cuda")
+    x = torch.randn(1, 421, 421, 1, generator=g).cuda()
+    with torch.no_grad(), ops.head_scale_route("host"):
+        out = model(mesh, x, mesh)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = model(mesh, x, mesh)
+        torch.cuda.synchronize()
+        gpu_ms = (time.perf_counter() - t0) * 1e3
+    p = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    mi = mesh.cpu().reshape(-1, 2)
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        ref = orc.pit_apply(p, "euclid", False, 4, 0.02, 0.02, mi, orc.with_coords(mi, x.cpu().reshape(1, -1, 1)),
+                            model.mesh_ltt.cpu(), mi).reshape(1, 421, 421, 1)
+    cpu_s = time.perf_counter() - t0
+    err = gio.rel_l2(ref.numpy().reshape(-1), out.cpu().numpy().reshape(-1))
+    print(f"ZSSR 421x421 b=1: rel-L2 {err:.3e}; HIP forward {gpu_ms:.2f} ms (plans cached), oracle on this host {cpu_s:.1f} s")
+    assert out.shape == (1, 421, 421, 1) and err <= 1e-5, err
+
+
+def test_cylinder_full_size_matches_oracle():
+    """train_cylinder.py:55-84 at the script's size: 4390 unstructured points -> 896 latent points -> 4390,
+    hid 256, 1 head, 4 blocks, locality 0.01, residual connection (train_cylinder.py:52); batch 2 here
+    (the script's 200 is timed by profiles/r02_tasks): forward, loss (myloss(out, y), :101) and all gradients."""
+    from position_induced_transformer_amd import ops, tasks, utils
+    model, sample, meta = tasks.make_task("cylinder", seed=43)
+    mesh_in, func_in, mesh_out, target = sample(2)
+    with ops.head_scale_route("host"):
+        out = model(mesh_in, func_in, mesh_out)
+        loss = utils.RelLpNorm(3, 2)(out, target)
+        loss.backward()
+    torch.cuda.synchronize()
+    p = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in model.state_dict().items()}
+    mi = mesh_in.cpu()
+    f = orc.with_coords(mi, func_in.cpu())
+    ref = orc.pit_apply(p, "euclid", False, 4, 0.01, 0.01, mi, f, model.mesh_ltt.cpu(), mi) + func_in.cpu()
+    ref_loss = orc.rel_lp_loss(ref, target.cpu(), 3, 2)
+    ref_loss.backward()
+    assert gio.rel_l2(ref.detach().numpy().reshape(-1), out.detach().cpu().numpy().reshape(-1)) <= 1e-5
+    assert abs(float(loss.detach()) - float(ref_loss)) <= 1e-5 * abs(float(ref_loss))
+    for k, q in model.named_parameters():
+        tol = 2e-4 if k.endswith("lmda") else 2e-5
+        assert gio.rel_l2(p[k].grad.numpy().reshape(-1), q.grad.cpu().numpy().reshape(-1)) <= tol, k
