@@ -69,6 +69,9 @@ def parse():
     ap.add_argument("--batch", type=int, default=8, help="per-GPU batch (train_darcy.py:66 uses 8)")
     ap.add_argument("--task", default="darcy")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--eager-allreduce", action="store_true",
+                    help="N > 1: capture the compute only and issue the gradient all-reduce eagerly after each replay")
+    ap.add_argument("--watchdog", type=float, default=120.0, help="N > 1: seconds allowed for capture + first replays")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip batch sweep / optimizer / roofline probes")
     ap.add_argument("--cpu-iters", type=int, default=100)
@@ -117,6 +120,32 @@ def build_step(args, device, rank, world, batch, with_optimizer=False, all_reduc
     step = TrainStep(model, (mesh_in, func_in, mesh_out, target), meta["out_dim"], meta["p"], affine,
                      all_reduce=use_ar, optimizer=opt, flat=flat)
     return step, model, meta
+
+
+class Watchdog:
+    """The all-reduce is captured INSIDE the step graph.  If RCCL and graph replay do not get along on some
+    node the symptom is a hang, not an exception: give the first replays a deadline and leave with a clear
+    message and a non-zero code instead of stalling the driver (never re-exec: this process owns the GPU;
+    rerun with --eager-allreduce, which keeps the collective outside the graph)."""
+
+    def __init__(self, seconds, what):
+        import threading
+        self.t = threading.Timer(seconds, self._fire)
+        self.t.daemon = True
+        self.what, self.seconds = what, seconds
+
+    def _fire(self):
+        print(f"[bench] WATCHDOG: {self.what} did not finish within {self.seconds:.0f} s - the captured RCCL all-reduce "
+              "is not completing on this node; rerun with --eager-allreduce", file=sys.stderr, flush=True)
+        os._exit(3)
+
+    def __enter__(self):
+        self.t.start()
+        return self
+
+    def __exit__(self, *exc):
+        self.t.cancel()
+        return False
 
 
 def prepare(step, use_graph):
@@ -399,7 +428,22 @@ def main():
     from position_induced_transformer_amd import ops
     ops.set_math_mode(args.math)
     step, model, meta = build_step(args, device, rank, world, args.batch, all_reduce=distributed)
-    run, mode = prepare(step, not args.no_graph)
+    if distributed and args.eager_allreduce and not args.no_graph:
+        step.all_reduce = False
+        step.capture()
+        mode = "hipgraph+eager-allreduce"
+
+        def run():
+            step.replay()
+            step.flat.all_reduce()
+    elif distributed:
+        with Watchdog(args.watchdog, "capturing the step and its first replays"):
+            run, mode = prepare(step, not args.no_graph)
+            for _ in range(3):
+                run()
+            torch.cuda.synchronize()
+    else:
+        run, mode = prepare(step, not args.no_graph)
     log(f"step prepared ({mode})")
     dt, spread = timed_blocks(run, args.steps, args.warmup, world)
     log(f"timed region done: {dt / args.steps * 1e3:.4f} ms/step (median of {spread['blocks']} blocks of {args.steps} steps, "

@@ -88,7 +88,14 @@ class FlatGradients:
         self.attach()                       # .grad tensors that left the flat buffer are copied back first
         if not (dist.is_available() and dist.is_initialized()):
             return
-        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
+        if self.flat.is_cuda and dist.get_backend(group) == "gloo":
+            # gloo has no device collectives here: stage through the host (tests that share ONE GPU between
+            # ranks use this; the production backend is "nccl" = RCCL, which reduces the device buffer in place)
+            host = self.flat.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+            self.flat.copy_(host)
+        else:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
         if average:
             self.flat.div_(dist.get_world_size(group))
 

@@ -481,3 +481,54 @@ def test_cylinder_full_size_matches_oracle():
     for k, q in model.named_parameters():
         tol = 2e-4 if k.endswith("lmda") else 2e-5
         assert gio.rel_l2(p[k].grad.numpy().reshape(-1), q.grad.cpu().numpy().reshape(-1)) <= tol, k
+
+
+# --------------------------------------------------------------------------- data parallel with the HIP compute
+def _dp_worker(rank, world, port, out_dir):
+    import os
+    import sys
+    os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
+    for pth in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")):
+        sys.path.insert(0, pth)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from position_induced_transformer_amd import tasks
+    from position_induced_transformer_amd.ddp import FlatGradients, broadcast_parameters, shard_batch
+    from position_induced_transformer_amd.engine import TrainStep
+    torch.cuda.set_device(0)                              # both ranks share the one GPU of the test box
+    model, sample, meta = tasks.make_task("darcy", seed=50 + rank)     # different initialisations ...
+    broadcast_parameters(model)                                         # ... made rank 0's
+    g = torch.Generator().manual_seed(77)
+    mesh = sample(1)[0]
+    x, y = torch.randn(6, 43, 43, 1, generator=g).cuda(), torch.randn(6, 43, 43, 1, generator=g).cuda()
+    sl = shard_batch(6, rank, world)
+    step = TrainStep(model, (mesh, x[sl].contiguous(), mesh, y[sl].contiguous()), meta["out_dim"], meta["p"], all_reduce=True)
+    step.run_eager()                                      # HIP forward/backward on the shard + ONE flat all-reduce
+    torch.cuda.synchronize()
+    if rank == 0:
+        single = TrainStep(model, (mesh, x, mesh, y), meta["out_dim"], meta["p"], all_reduce=False,
+                           flat=FlatGradients(model.parameters()))
+        got = step.flat.flat.clone()                      # (FlatGradients above re-pointed .grad: keep the reduced copy)
+        single.run_eager()
+        torch.cuda.synchronize()
+        want = single.flat.flat
+        err = float((got - want).norm() / want.norm())
+        np.save(os.path.join(out_dir, "dp_err.npy"), np.asarray([err, float(want.abs().sum())]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_on_one_gpu_flat_allreduce_equals_single_rank_hip_gradient(tmp_path):
+    """the data-parallel step with the HIP compute on every rank (two processes sharing
+    this box's one GPU, gloo for the exchange): shard -> forward/backward kernels -> ONE all-reduce of the flat
+    buffer == the single-process gradient of the whole batch (SUM reduction: RelLpNorm sums over the batch)."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_dp_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    err, mass = np.load(os.path.join(tmp_path, "dp_err.npy"))
+    assert mass > 0 and err <= 2e-5, (err, mass)
