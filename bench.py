@@ -260,7 +260,7 @@ def roofline_mlp_probe(model, batch):
         us = graph_time_us(lambda: ops.mlp_apply(x, mlp.mlp1.weight, mlp.mlp1.bias, mlp.mlp2.weight, mlp.mlp2.bias, True))
     rows = batch * rows_per_sample
     # the library's own rule (csrc/pit_mlp.hip: try_launch_mlp_fwd16)
-    fused = n1 in (32, 64, 128) and n2 % 16 == 0 and 16 <= n2 <= n1 and rows >= 256 and rows * n1 * (n0 + n2) <= (1 << 27)
+    fused = n1 in (32, 64, 128) and (n2 <= 4 or (n2 % 16 == 0 and n2 <= n1)) and rows >= 256 and rows * n1 * (n0 + n2) <= (1 << 27)
     launches = 1 if fused else 2
     flops = 2.0 * rows * (n0 * n1 + n1 * n2) / launches
     us_launch = us / launches

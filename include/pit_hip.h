@@ -193,10 +193,12 @@ int pit_mlp_bwd_params(const float* x, long ldx, int rows, int n0, int n1, int n
  * the optional per-pixel (npts, nch) affine of PixelWiseNormalization.denormalize
  * (utils.py:25-34, train_darcy.py:129) is given (both NULL = identity).
  * norms (batch, nch, 2) = {||true-pred'||_p, ||true||_p} is saved for the backward; loss is one
- * float.  workspace: 2 floats (accumulator + arrival counter), zero before the first call and
- * left zero by every call.  grad_loss: device pointer to the upstream scalar (NULL = 1).
+ * float.  workspace: PIT_REL_LP_WS_FLOATS(batch, nch) floats, 16-byte aligned (loss accumulator + arrival
+ * counter, and per (sample, channel) two fp64 partial sums + a counter: a series is split over several
+ * workgroups), zero before the first call and left zero by every call.  grad_loss: device pointer to the upstream scalar (NULL = 1).
  * The backward writes d loss/d pred and/or d loss/d true (either may be NULL): the scripts pass
  * the model output as `pred` (train_darcy.py:130) or as `true` (train_vorticity.py:124). */
+#define PIT_REL_LP_WS_FLOATS(batch, nch) (4 + 5 * (batch) * (nch))
 int pit_rel_lp_loss_fwd(const float* tru, const float* pred, const float* pred_scale,
                         const float* pred_shift, int batch, int npts, int nch, int p,
                         float* norms, float* loss, float* workspace, void* stream);

@@ -15,6 +15,19 @@ __device__ __forceinline__ float pow_abs(float x, int p) {
     return powf(ax, (float)p);
 }
 
+// Workspace layout (floats; ZERO before the first call, left zero by every call):
+//   [0] loss accumulator, [1] arrival counter over the (sample, channel) pairs,
+//   then per pair 4 floats: {num, den} as one fp64 each is too wide for the float view - so per pair
+//   2 doubles (num, den) at double index 1 + 2*pair... see REL_WS_* below - and one arrival counter.
+// One (sample, channel) series is split over gridDim.z workgroups (one dependent-latency round trip each
+// instead of npts/256 in a row); partial sums meet in the pair's fp64 slots and the LAST workgroup to
+// arrive finishes the pair: norms, the pair's term of the loss and - when asked for - the gradients of
+// the whole series for d loss = 1 (it alone knows both norms; 4 points per thread in flight).
+__device__ __forceinline__ double* rel_ws_sums(float* ws, int pair) { return reinterpret_cast<double*>(ws + 4) + 2 * pair; }
+__device__ __forceinline__ unsigned* rel_ws_count(float* ws, int pairs, int pair) {
+    return reinterpret_cast<unsigned*>(ws + 4 + 4 * pairs) + pair;
+}
+
 __global__ __launch_bounds__(256) void rel_lp_fwd_kernel(const float* __restrict__ tru, const float* __restrict__ pred,
                                                           const float* __restrict__ scale, const float* __restrict__ shift,
                                                           int npts, int nch, int p, float* __restrict__ norms,
@@ -23,23 +36,25 @@ __global__ __launch_bounds__(256) void rel_lp_fwd_kernel(const float* __restrict
                                                           float* __restrict__ clear_buf, long clear_n) {
     __shared__ double s_num[4], s_den[4];
     __shared__ float s_norm[2];
+    __shared__ int s_last;
     if (clear_buf) {                                  // fused memset of a caller buffer (gradient accumulators)
-        const long nthreads = (long)gridDim.x * gridDim.y * blockDim.x;
-        for (long i = ((long)blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x; i < clear_n; i += nthreads)
-            clear_buf[i] = 0.0f;
+        const long nthreads = (long)gridDim.x * gridDim.y * gridDim.z * blockDim.x;
+        const long first = (((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x;
+        for (long i = first; i < clear_n; i += nthreads) clear_buf[i] = 0.0f;
     }
-    const int c = blockIdx.x, b = blockIdx.y;
+    const int c = blockIdx.x, b = blockIdx.y, parts = gridDim.z;
+    const int pairs = gridDim.x * gridDim.y, pair = b * nch + c;
     const long base = (long)b * npts * nch + c;
+    const int chunk = (npts + parts - 1) / parts;
+    const int lbeg = blockIdx.z * chunk, lend = min(npts, lbeg + chunk);
     double num = 0.0, den = 0.0;
-    // four points per thread and trip with all loads issued before the first use: the pass is a chain of
-    // dependent-latency round trips otherwise (8 trips x 4 loads at Darcy's 1849 points)
-    for (int l0 = threadIdx.x; l0 < npts; l0 += 4 * blockDim.x) {
+    for (int l0 = lbeg + threadIdx.x; l0 < lend; l0 += 4 * blockDim.x) {      // 4 points per thread in flight
         float qv[4], tv[4], sc[4], sh[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int l = l0 + u * blockDim.x;
-            const bool ok = l < npts;
-            const long e = base + (long)(ok ? l : 0) * nch;
+            const bool ok = l < lend;
+            const long e = base + (long)(ok ? l : lbeg) * nch;
             qv[u] = ok ? pred[e] : 0.0f;
             tv[u] = ok ? tru[e] : 0.0f;
             sc[u] = (scale && ok) ? scale[(long)l * nch + c] : 1.0f;
@@ -60,46 +75,76 @@ __global__ __launch_bounds__(256) void rel_lp_fwd_kernel(const float* __restrict
     if (threadIdx.x == 0) {
         num = s_num[0] + s_num[1] + s_num[2] + s_num[3];
         den = s_den[0] + s_den[1] + s_den[2] + s_den[3];
-        const double nn = (p == 1) ? num : (p == 2 ? sqrt(num) : pow(num, 1.0 / p));
-        const double dn = (p == 1) ? den : (p == 2 ? sqrt(den) : pow(den, 1.0 / p));
-        norms[((long)b * nch + c) * 2 + 0] = (float)nn;
-        norms[((long)b * nch + c) * 2 + 1] = (float)dn;
-        s_norm[0] = (float)nn; s_norm[1] = (float)dn;
-        // sum over (sample, channel) in a persistent accumulator; the last workgroup publishes the
-        // loss and leaves accumulator and arrival counter zero for the next call (no memset launch)
-        const float old = atomicAdd(ws, (float)(nn / dn / nch));
-        asm volatile("" ::"v"(old));              // returning atomic: performed before the ticket below
-        unsigned* counter = reinterpret_cast<unsigned*>(ws + 1);
-        const unsigned ticket = atomicAdd(counter, 1u);
-        if (ticket == gridDim.x * gridDim.y - 1u) {
-            *loss = atomicExch(ws, 0.0f);
-            atomicExch(counter, 0u);
+        double* sums = rel_ws_sums(ws, pair);
+        unsigned* cnt = rel_ws_count(ws, pairs, pair);
+        int last = 1;
+        if (parts > 1) {
+            const double o1 = atomicAdd(sums, num), o2 = atomicAdd(sums + 1, den);
+            asm volatile("" ::"v"(o1), "v"(o2));      // returning atomics: performed before the ticket below
+            last = (atomicAdd(cnt, 1u) == (unsigned)parts - 1u);
+            if (last) {                                // everybody's partial sums are in: take them, leave zeros
+                num = __longlong_as_double(atomicExch(reinterpret_cast<unsigned long long*>(sums), 0ull));
+                den = __longlong_as_double(atomicExch(reinterpret_cast<unsigned long long*>(sums + 1), 0ull));
+                atomicExch(cnt, 0u);
+            }
+        }
+        s_last = last;
+        if (last) {
+            const double nn = (p == 1) ? num : (p == 2 ? sqrt(num) : pow(num, 1.0 / p));
+            const double dn = (p == 1) ? den : (p == 2 ? sqrt(den) : pow(den, 1.0 / p));
+            norms[(long)pair * 2 + 0] = (float)nn;
+            norms[(long)pair * 2 + 1] = (float)dn;
+            s_norm[0] = (float)nn; s_norm[1] = (float)dn;
+            // sum over (sample, channel) in a persistent accumulator; the last pair publishes the loss and
+            // leaves accumulator and arrival counter zero for the next call (no memset launch)
+            const float old = atomicAdd(ws, (float)(nn / dn / nch));
+            asm volatile("" ::"v"(old));
+            unsigned* counter = reinterpret_cast<unsigned*>(ws + 1);
+            const unsigned ticket = atomicAdd(counter, 1u);
+            if (ticket == (unsigned)pairs - 1u) {
+                *loss = atomicExch(ws, 0.0f);
+                atomicExch(counter, 0u);
+            }
         }
     }
     if (!d_pred_unit && !d_true_unit) return;
-    // gradients for an upstream gradient of 1 (this workgroup owns both norms of its (sample, channel)):
-    // the training step then needs no separate backward launch for the loss
+    // gradients for an upstream gradient of 1, by the workgroup that completed the pair (it holds both
+    // norms): the training step then needs no separate backward launch for the loss
     __syncthreads();
+    if (!s_last) return;
     const float nn = s_norm[0], dn = s_norm[1];
-#pragma unroll 4
-    for (int l = threadIdx.x; l < npts; l += blockDim.x) {
-        const long e = base + (long)l * nch;
-        float q = pred[e];
-        float sc = 1.0f;
-        if (scale) { sc = scale[(long)l * nch + c]; q = q * sc + shift[(long)l * nch + c]; }
-        const float t = tru[e];
-        const float d = q - t;
-        float dnorm;
-        if (p == 1) dnorm = (d > 0.0f) ? 1.0f : (d < 0.0f ? -1.0f : 0.0f);
-        else if (p == 2) dnorm = (nn > 0.0f) ? d / nn : 0.0f;
-        else dnorm = (nn > 0.0f) ? copysignf(powf(fabsf(d) / nn, (float)(p - 1)), d) : 0.0f;
-        if (d_pred_unit) d_pred_unit[e] = dnorm * sc / (dn * nch);
-        if (d_true_unit) {
-            float tnorm;
-            if (p == 1) tnorm = (t > 0.0f) ? 1.0f : (t < 0.0f ? -1.0f : 0.0f);
-            else if (p == 2) tnorm = (dn > 0.0f) ? t / dn : 0.0f;
-            else tnorm = (dn > 0.0f) ? copysignf(powf(fabsf(t) / dn, (float)(p - 1)), t) : 0.0f;
-            d_true_unit[e] = (-dnorm / dn - nn / (dn * dn) * tnorm) / nch;
+    for (int l0 = threadIdx.x; l0 < npts; l0 += 4 * blockDim.x) {
+        float qv[4], tv[4], sc[4], sh[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int l = l0 + u * blockDim.x;
+            const bool ok = l < npts;
+            const long e = base + (long)(ok ? l : 0) * nch;
+            qv[u] = ok ? pred[e] : 0.0f;
+            tv[u] = ok ? tru[e] : 0.0f;
+            sc[u] = (scale && ok) ? scale[(long)l * nch + c] : 1.0f;
+            sh[u] = (scale && ok) ? shift[(long)l * nch + c] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int l = l0 + u * blockDim.x;
+            if (l >= npts) continue;
+            const long e = base + (long)l * nch;
+            const float q = scale ? qv[u] * sc[u] + sh[u] : qv[u];
+            const float t = tv[u];
+            const float d = q - t;
+            float dnorm;
+            if (p == 1) dnorm = (d > 0.0f) ? 1.0f : (d < 0.0f ? -1.0f : 0.0f);
+            else if (p == 2) dnorm = (nn > 0.0f) ? d / nn : 0.0f;
+            else dnorm = (nn > 0.0f) ? copysignf(powf(fabsf(d) / nn, (float)(p - 1)), d) : 0.0f;
+            if (d_pred_unit) d_pred_unit[e] = dnorm * sc[u] / (dn * nch);
+            if (d_true_unit) {
+                float tnorm;
+                if (p == 1) tnorm = (t > 0.0f) ? 1.0f : (t < 0.0f ? -1.0f : 0.0f);
+                else if (p == 2) tnorm = (dn > 0.0f) ? t / dn : 0.0f;
+                else tnorm = (dn > 0.0f) ? copysignf(powf(fabsf(t) / dn, (float)(p - 1)), t) : 0.0f;
+                d_true_unit[e] = (-dnorm / dn - nn / (dn * dn) * tnorm) / nch;
+            }
         }
     }
 }
@@ -182,6 +227,13 @@ __global__ __launch_bounds__(256) void rel_max_fwd_kernel(const float* __restric
     }
 }
 
+// workgroups per (sample, channel) series: one 256-point trip each, at most 8, fewer for large batches
+int rel_parts(int batch, int npts, int nch) {
+    int parts = std::max(1, std::min(8, (npts + 255) / 256));
+    while (parts > 1 && (long)parts * batch * nch > 2048) parts >>= 1;
+    return parts;
+}
+
 }  // namespace
 
 extern "C" int pit_rel_max_norm(const float* tru, const float* pred, int batch, int npts, int nch, float* out,
@@ -201,8 +253,9 @@ extern "C" int pit_rel_lp_loss_fwd(const float* tru, const float* pred, const fl
     if ((pred_scale == nullptr) != (pred_shift == nullptr)) return PIT_ERR_NULL;
     if (batch <= 0 || npts <= 0 || nch <= 0 || p < 1 || batch > 65535) return PIT_ERR_SIZE;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(rel_lp_fwd_kernel, dim3(nch, batch), dim3(256), 0, s, tru, pred, pred_scale, pred_shift, npts,
-                       nch, p, norms, loss, workspace, (float*)nullptr, (float*)nullptr, (float*)nullptr, 0L);
+    hipLaunchKernelGGL(rel_lp_fwd_kernel, dim3(nch, batch, rel_parts(batch, npts, nch)), dim3(256), 0, s, tru, pred,
+                       pred_scale, pred_shift, npts, nch, p, norms, loss, workspace, (float*)nullptr, (float*)nullptr,
+                       (float*)nullptr, 0L);
     PIT_CHECK_LAUNCH();
     return 0;
 }
@@ -215,8 +268,8 @@ extern "C" int pit_rel_lp_loss_fwd_grad(const float* tru, const float* pred, con
     if ((pred_scale == nullptr) != (pred_shift == nullptr)) return PIT_ERR_NULL;
     if (batch <= 0 || npts <= 0 || nch <= 0 || p < 1 || batch > 65535 || clear_n < 0) return PIT_ERR_SIZE;
     if (clear_n > 0 && !clear_buf) return PIT_ERR_NULL;
-    hipLaunchKernelGGL(rel_lp_fwd_kernel, dim3(nch, batch), dim3(256), 0, (hipStream_t)stream, tru, pred, pred_scale,
-                       pred_shift, npts, nch, p, norms, loss, workspace, d_pred_unit, d_true_unit,
+    hipLaunchKernelGGL(rel_lp_fwd_kernel, dim3(nch, batch, rel_parts(batch, npts, nch)), dim3(256), 0, (hipStream_t)stream,
+                       tru, pred, pred_scale, pred_shift, npts, nch, p, norms, loss, workspace, d_pred_unit, d_true_unit,
                        clear_n > 0 ? clear_buf : nullptr, clear_n);
     PIT_CHECK_LAUNCH();
     return 0;

@@ -264,7 +264,7 @@ __global__ __launch_bounds__(N1 * 4) void mlp_fwd16_kernel(FusedMlpArgs g) {
     const __amdgpu_buffer_rsrc_t rw1 = make_rsrc(g.w1, g.w1_bytes);
     const __amdgpu_buffer_rsrc_t rw2 = make_rsrc(g.w2, g.w2_bytes);
     const int c1 = wave * 16 + l15;                     // this lane's column of the hidden layer (B operand row of W1)
-    const bool do2 = wave * 16 < g.n2;                  // waves that own an output tile
+    const bool do2 = g.n2 > 4 && wave * 16 < g.n2;      // waves that own an output tile
     const int c2 = wave * 16 + l15;
 
     // second weight matrix first: its latency hides behind the whole first contraction
@@ -317,6 +317,28 @@ __global__ __launch_bounds__(N1 * 4) void mlp_fwd16_kernel(FusedMlpArgs g) {
         }
     }
     __syncthreads();
+    if (g.n2 <= 4) {
+        // thin output layer (out_dim <= 4, pit.py:106 `de`): a row dot per output, one wave, no MFMA tile
+        if (wave != 0) return;
+        const int r = m0 + l15;
+        for (int o = 0; o < g.n2; ++o) {
+            float part = 0.0f;
+#pragma unroll
+            for (int k = 0; k < N1 / 4; k += 4) {
+                const float4 a = *reinterpret_cast<const float4*>(hs + l15 * HP + kq * (N1 / 4) + k);
+                const float* w = g.w2 + (long)o * N1 + kq * (N1 / 4) + k;
+                part += (a.x * w[0] + a.y * w[1]) + (a.z * w[2] + a.w * w[3]);
+            }
+            part += __shfl_xor(part, 16, 64);
+            part += __shfl_xor(part, 32, 64);
+            if (kq == 0 && r < g.rows) {
+                float v = part + g.b2[o];
+                if (g.out_gelu) { g.z2[(long)r * g.n2 + o] = v; v = gelu_erf(v); }
+                g.y[(long)r * g.ldy + o] = v;
+            }
+        }
+        return;
+    }
     if (!do2) return;
     f32x4_t o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -346,7 +368,7 @@ bool try_launch_mlp_fwd16(const float* x, long ldx, int rows, int n0, int n1, in
     static const bool off = getenv("PIT_NO_FUSED_MLP") != nullptr;
     if (off) return false;
     if (n1 != 32 && n1 != 64 && n1 != 128) return false;
-    if (n2 % 16 != 0 || n2 > n1 || n2 < 16) return false;
+    if (n2 > 4 && (n2 % 16 != 0 || n2 > n1)) return false;        // full tiles, or the thin (out_dim <= 4) output layer
     if (rows < 256 || (long)rows * n1 * (n0 + n2) > (1L << 27)) return false;    // the LDS-tiled GEMMs take over above
     const unsigned long long xb = ((unsigned long long)(rows - 1) * ldx + n0) * 4ull;
     if (xb > PIT_MAX_BUFFER_BYTES) return false;

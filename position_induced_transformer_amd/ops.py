@@ -60,8 +60,6 @@ def _pin(*objs) -> None:
 
 
 def _ws_key(device):
-    if os.environ.get("PIT_DBG_WS_DEVICE_KEY"):
-        return device.index
     return (device.index, torch.cuda.current_stream(device).cuda_stream)
 
 
@@ -592,10 +590,10 @@ class _RelLpLoss(torch.autograd.Function):
         sh = shift.reshape(npts, out_dim).contiguous() if shift is not None else None
         norms = torch.empty((b, out_dim, 2), device=t.device, dtype=torch.float32)
         loss = torch.empty((), device=t.device, dtype=torch.float32)
-        wkey = _ws_key(t.device)
+        wkey = _ws_key(t.device) + (b * out_dim,)             # PIT_REL_LP_WS_FLOATS(batch, nch)
         ws = _LOSS_WS.get(wkey)
         if ws is None:
-            ws = _LOSS_WS[wkey] = torch.zeros(2, device=t.device, dtype=torch.float32)
+            ws = _LOSS_WS[wkey] = torch.zeros(4 + 5 * b * out_dim, device=t.device, dtype=torch.float32)
         if _capturing():
             _pin(ws)
         unit_p = unit_t = None
