@@ -260,13 +260,13 @@ def roofline_mlp_probe(model, batch):
         us = graph_time_us(lambda: ops.mlp_apply(x, mlp.mlp1.weight, mlp.mlp1.bias, mlp.mlp2.weight, mlp.mlp2.bias, True))
     rows = batch * rows_per_sample
     # the library's own rule (csrc/pit_mlp.hip: try_launch_mlp_fwd16)
-    fused = n1 in (32, 64, 128) and (n2 <= 4 or (n2 % 16 == 0 and n2 <= n1)) and rows >= 256 and rows * n1 * (n0 + n2) <= (1 << 27)
+    fused = n1 in (32, 64, 128) and (n2 <= 4 or (n2 % 16 == 0 and n2 <= n1)) and rows >= 256 and n0 <= 256 and rows * n1 * (n0 + n2) <= (1 << 27)
     launches = 1 if fused else 2
     flops = 2.0 * rows * (n0 * n1 + n1 * n2) / launches
     us_launch = us / launches
     achieved = flops / (us_launch * 1e-6) / 1e12
     alg_bytes = 4.0 * (rows * n0 + 2 * rows * n1 + (0 if fused else rows * n1) + 2 * rows * n2 + n0 * n1 + n1 * n2) / launches
-    name = f"mlp_fwd16_kernel<{n1}> (fused GEMM1+GELU+GEMM2+GELU)" if fused else "gemm_lds/gemm_rd kernel<BIAS_GELU> (mean of the two launches)"
+    name = f"mlp_fwd16_kernel<{n1},{(n0 + 63) // 64 * 4}> (fused GEMM1+GELU+GEMM2+GELU)" if fused else "gemm_lds/gemm_rd kernel<BIAS_GELU> (mean of the two launches)"
     return {"bound": "mfma", "kernel": f"{name}: kaiming_mlp forward {n0}->{n1}->{n2} on {rows} rows, batch {batch}",
             "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": pmc_traffic(f"mlp_fwd_b{batch}"),

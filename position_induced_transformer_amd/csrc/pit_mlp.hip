@@ -250,7 +250,7 @@ struct FusedMlpArgs {
     int x_vec, w1_vec;                   // 16-B fragment loads legal
 };
 
-template <int N1>
+template <int N1, int KS>
 __global__ __launch_bounds__(N1 * 4) void mlp_fwd16_kernel(FusedMlpArgs g) {
     constexpr int HP = N1 + 4;                          // LDS pitch of the hidden tile (floats)
     constexpr int S2 = N1 / 16;                         // 16-k steps of the second contraction
@@ -267,40 +267,41 @@ __global__ __launch_bounds__(N1 * 4) void mlp_fwd16_kernel(FusedMlpArgs g) {
     const bool do2 = g.n2 > 4 && wave * 16 < g.n2;      // waves that own an output tile
     const int c2 = wave * 16 + l15;
 
-    // second weight matrix first: its latency hides behind the whole first contraction
+    // EVERY operand fragment of the first contraction is requested before the first MFMA (KS 16-k steps,
+    // compile time): one memory round trip for the whole K range instead of one per 64 k
+    float av[KS][4], bv[KS][4];
+    const unsigned xbase = (unsigned)row * (unsigned)g.ldx * 4u, wbase = (unsigned)c1 * (unsigned)g.n0 * 4u;
+    const bool fast = g.x_vec && g.w1_vec;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const int kk = 16 * s + 4 * kq;
+        if (fast) {                                     // n0 % 4 == 0: a quad is in range or out of range as a whole
+            const bool ok = kk < g.n0;
+            buf_load4(rx, (ok && rvalid) ? xbase + (unsigned)kk * 4u : g.x_bytes, av[s]);
+            buf_load4(rw1, ok ? wbase + (unsigned)kk * 4u : g.w1_bytes, bv[s]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const bool ok = kk + e < g.n0;
+                av[s][e] = buf_load(rx, (ok && rvalid) ? xbase + (unsigned)(kk + e) * 4u : g.x_bytes);
+                bv[s][e] = buf_load(rw1, ok ? wbase + (unsigned)(kk + e) * 4u : g.w1_bytes);
+            }
+        }
+    }
+    // second weight matrix: its latency hides behind the first contraction
     float w2v[S2][4];
 #pragma unroll
     for (int s = 0; s < S2; ++s)
         buf_load4(rw2, (do2 && c2 < g.n2) ? ((unsigned)c2 * (unsigned)N1 + (unsigned)(16 * s + 4 * kq)) * 4u : g.w2_bytes, w2v[s]);
 
     f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-    const unsigned xbase = (unsigned)row * (unsigned)g.ldx * 4u, wbase = (unsigned)c1 * (unsigned)g.n0 * 4u;
-    const bool fast = g.x_vec && g.w1_vec;
-    for (int k0 = 0; k0 < g.n0; k0 += 64) {             // four 16-k steps per trip: 8 fragment loads in flight
-        float av[4][4], bv[4][4];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const int kk = k0 + 16 * s + 4 * kq;
-            if (fast && kk + 4 <= g.n0) {
-                buf_load4(rx, rvalid ? xbase + (unsigned)kk * 4u : g.x_bytes, av[s]);
-                buf_load4(rw1, wbase + (unsigned)kk * 4u, bv[s]);
-            } else {
+    for (int s = 0; s < KS; ++s)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const bool ok = kk + e < g.n0;
-                    av[s][e] = buf_load(rx, (ok && rvalid) ? xbase + (unsigned)(kk + e) * 4u : g.x_bytes);
-                    bv[s][e] = buf_load(rw1, ok ? wbase + (unsigned)(kk + e) * 4u : g.w1_bytes);
-                }
-            }
+        for (int e = 0; e < 4; ++e) {
+            if (e & 1) acc1 = mfma_16x16x4(av[s][e], bv[s][e], acc1);
+            else acc0 = mfma_16x16x4(av[s][e], bv[s][e], acc0);
         }
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                if ((s * 4 + e) & 1) acc1 = mfma_16x16x4(av[s][e], bv[s][e], acc1);
-                else acc0 = mfma_16x16x4(av[s][e], bv[s][e], acc0);
-            }
-    }
     {   // bias + gelu; Z1 / H to memory (backward) and H to LDS (second contraction)
         const int col = wave * 16 + l15;
         const float bias = g.b1[col];
@@ -370,6 +371,7 @@ bool try_launch_mlp_fwd16(const float* x, long ldx, int rows, int n0, int n1, in
     if (n1 != 32 && n1 != 64 && n1 != 128) return false;
     if (n2 > 4 && (n2 % 16 != 0 || n2 > n1)) return false;        // full tiles, or the thin (out_dim <= 4) output layer
     if (rows < 256 || (long)rows * n1 * (n0 + n2) > (1L << 27)) return false;    // the LDS-tiled GEMMs take over above
+    if (n0 > 256) return false;                                                  // K range held in registers
     const unsigned long long xb = ((unsigned long long)(rows - 1) * ldx + n0) * 4ull;
     if (xb > PIT_MAX_BUFFER_BYTES) return false;
     if ((reinterpret_cast<uintptr_t>(w2) & 15) != 0) return false;               // W2 rows are read as 16-B fragments
@@ -381,9 +383,15 @@ bool try_launch_mlp_fwd16(const float* x, long ldx, int rows, int n0, int n1, in
     g.x_vec = (reinterpret_cast<uintptr_t>(x) & 15) == 0 && ldx % 4 == 0;
     g.w1_vec = (reinterpret_cast<uintptr_t>(w1) & 15) == 0 && n0 % 4 == 0;
     const dim3 grid((rows + 15) / 16);
-    if (n1 == 32) hipLaunchKernelGGL((mlp_fwd16_kernel<32>), grid, dim3(128), 0, s, g);
-    else if (n1 == 64) hipLaunchKernelGGL((mlp_fwd16_kernel<64>), grid, dim3(256), 0, s, g);
-    else hipLaunchKernelGGL((mlp_fwd16_kernel<128>), grid, dim3(512), 0, s, g);
+    const int ks = (n0 + 63) / 64 * 4;               // 16-k steps, in groups of 4
+#define PIT_F16(N1_) do {                                                                                       \
+        if (ks == 4) hipLaunchKernelGGL((mlp_fwd16_kernel<N1_, 4>), grid, dim3(N1_ * 4), 0, s, g);              \
+        else if (ks == 8) hipLaunchKernelGGL((mlp_fwd16_kernel<N1_, 8>), grid, dim3(N1_ * 4), 0, s, g);         \
+        else if (ks == 12) hipLaunchKernelGGL((mlp_fwd16_kernel<N1_, 12>), grid, dim3(N1_ * 4), 0, s, g);       \
+        else hipLaunchKernelGGL((mlp_fwd16_kernel<N1_, 16>), grid, dim3(N1_ * 4), 0, s, g);                     \
+    } while (0)
+    if (n1 == 32) PIT_F16(32); else if (n1 == 64) PIT_F16(64); else PIT_F16(128);
+#undef PIT_F16
     return true;
 }
 
