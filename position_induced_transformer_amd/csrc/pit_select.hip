@@ -451,15 +451,87 @@ static void fill_int(int* p, long n, int v, hipStream_t s) {
     hipLaunchKernelGGL(fill_int_kernel, dim3(std::max(1u, blocks)), dim3(256), 0, s, p, n, v);
 }
 
-// transposed lists from nbr_idx / counts: scan + fill
+// Transposed lists with workgroup-level aggregation (n_in <= NBR_LDS_KEYS): a key of a small key set is
+// listed by thousands of rows (NACA decoder: 11 271 rows x ~16 listed keys over 728 latent points), so one
+// global atomic per list ENTRY on counts[key] / cursor[key] is thousands of adds per address.  A workgroup
+// takes NBR_ROWS consecutive rows of one mesh sample, histograms their entries in LDS and touches every
+// global counter once: counting (nbr_count_lds) and - after the scan - slot reservation + fill (nbr_fill_lds).
+constexpr int NBR_LDS_KEYS = 4096, NBR_ROWS = 128;
+
+__global__ __launch_bounds__(256) void nbr_count_lds(const int* __restrict__ nbr_idx, const int* __restrict__ nbr_cnt,
+                                                      int n_out, int n_in, int cap, int* __restrict__ counts) {
+    __shared__ int hist[NBR_LDS_KEYS];
+    const int mb = blockIdx.y, r0 = blockIdx.x * NBR_ROWS;
+    for (int k = threadIdx.x; k < n_in; k += 256) hist[k] = 0;
+    __syncthreads();
+    const int nrows = min(NBR_ROWS, n_out - r0);
+    for (int e = threadIdx.x; e < nrows * cap; e += 256) {
+        const int r = e / cap, i = e - r * cap;
+        const long row = (long)mb * n_out + r0 + r;
+        const int cnt = nbr_cnt[row];
+        if (i < min(cnt, cap)) atomicAdd(&hist[nbr_idx[row * cap + i]], 1);      // (overflowed rows count their first cap keys, as before)
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < n_in; k += 256)
+        if (hist[k]) atomicAdd(counts + (long)mb * n_in + k, hist[k]);
+}
+
+__global__ __launch_bounds__(256) void nbr_fill_lds(const int* __restrict__ nbr_idx, const int* __restrict__ nbr_cnt,
+                                                     int n_out, int n_in, int cap, int* __restrict__ cursor,
+                                                     int* __restrict__ rev_row, long rev_stride) {
+    __shared__ int hist[NBR_LDS_KEYS];      // entries of this workgroup per key, then the running slot inside the reservation
+    __shared__ int base[NBR_LDS_KEYS];
+    const int mb = blockIdx.y, r0 = blockIdx.x * NBR_ROWS;
+    for (int k = threadIdx.x; k < n_in; k += 256) hist[k] = 0;
+    __syncthreads();
+    const int nrows = min(NBR_ROWS, n_out - r0);
+    for (int e = threadIdx.x; e < nrows * cap; e += 256) {
+        const int r = e / cap, i = e - r * cap;
+        const long row = (long)mb * n_out + r0 + r;
+        const int cnt = nbr_cnt[row];
+        if (cnt <= cap && i < cnt) atomicAdd(&hist[nbr_idx[row * cap + i]], 1);   // overflowed rows stay out of the transpose
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < n_in; k += 256) {
+        const int c = hist[k];
+        base[k] = c ? atomicAdd(cursor + (long)mb * n_in + k, c) : 0;             // ONE reservation per key and workgroup
+        hist[k] = 0;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < nrows * cap; e += 256) {
+        const int r = e / cap, i = e - r * cap;
+        const long row = (long)mb * n_out + r0 + r;
+        const int cnt = nbr_cnt[row];
+        if (cnt <= cap && i < cnt) {
+            const int key = nbr_idx[row * cap + i];
+            const int pos = base[key] + atomicAdd(&hist[key], 1);
+            rev_row[(long)mb * rev_stride + pos] = r0 + r;
+        }
+    }
+}
+
+// transposed lists from nbr_idx / counts: scan + fill.  counts_done = the counts were already accumulated (by
+// the list-emitting kernel's own atomics); otherwise they are counted here with workgroup aggregation.
 static int launch_transpose(const int* nbr_idx, const int* nbr_cnt, int mesh_batch, int n_out, int n_in, int cap,
-                     int* rev_ptr, int* rev_row, int* counts, int* cursor, hipStream_t s) {
+                     int* rev_ptr, int* rev_row, int* counts, int* cursor, bool counts_done, hipStream_t s) {
     const long rows = (long)mesh_batch * n_out;
+    const bool lds = n_in <= NBR_LDS_KEYS;
+    const dim3 agrid((n_out + NBR_ROWS - 1) / NBR_ROWS, mesh_batch);
+    if (!counts_done) {
+        if (!lds) return PIT_ERR_UNSUPPORTED;
+        hipLaunchKernelGGL(nbr_count_lds, agrid, dim3(256), 0, s, nbr_idx, nbr_cnt, n_out, n_in, cap, counts);
+        PIT_CHECK_LAUNCH();
+    }
     hipLaunchKernelGGL(nbr_scan_kernel, dim3(mesh_batch), dim3(256), 0, s, counts, n_in, rev_ptr, cursor);
     PIT_CHECK_LAUNCH();
-    const unsigned blocks = (unsigned)((rows * cap + 1023) / 1024);         // 4 slots per thread
-    hipLaunchKernelGGL(nbr_fill_kernel, dim3(blocks), dim3(256), 0, s, nbr_idx, nbr_cnt, rows, n_out, n_in, cap, cursor,
-                       rev_row, (long)n_out * cap);
+    if (lds) {
+        hipLaunchKernelGGL(nbr_fill_lds, agrid, dim3(256), 0, s, nbr_idx, nbr_cnt, n_out, n_in, cap, cursor, rev_row,
+                           (long)n_out * cap);
+    } else {
+        const unsigned blocks = (unsigned)((rows * cap + 1023) / 1024);         // 4 slots per thread
+        hipLaunchKernelGGL(nbr_fill_kernel, dim3(blocks), dim3(256), 0, s, nbr_idx, nbr_cnt, rows, n_out, n_in, cap, cursor,
+                           rev_row, (long)n_out * cap);
+    }
     PIT_CHECK_LAUNCH();
     return 0;
 }
@@ -495,7 +567,9 @@ extern "C" int pit_plan_fwd(const float* mesh_out, const float* mesh_in, int mes
         fill_int(rev_row, rows * cap, -1, s);
     }
     const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
-#define PIT_PLAN(I_) hipLaunchKernelGGL(plan_rows_reg<I_>, grid, block, 0, s, a, cap, nbr_idx, nbr_cnt, counts)
+    const bool agg = rev_ptr && n_in <= NBR_LDS_KEYS;             // counts by workgroup aggregation (launch_transpose)
+    int* kcounts = agg ? nullptr : counts;
+#define PIT_PLAN(I_) hipLaunchKernelGGL(plan_rows_reg<I_>, grid, block, 0, s, a, cap, nbr_idx, nbr_cnt, kcounts)
     if (items <= 1) PIT_PLAN(1);
     else if (items <= 2) PIT_PLAN(2);
     else if (items <= 4) PIT_PLAN(4);
@@ -507,7 +581,7 @@ extern "C" int pit_plan_fwd(const float* mesh_out, const float* mesh_in, int mes
     else PIT_PLAN(64);
 #undef PIT_PLAN
     PIT_CHECK_LAUNCH();
-    if (rev_ptr) return launch_transpose(nbr_idx, nbr_cnt, mesh_batch, n_out, n_in, cap, rev_ptr, rev_row, counts, cursor, s);
+    if (rev_ptr) return launch_transpose(nbr_idx, nbr_cnt, mesh_batch, n_out, n_in, cap, rev_ptr, rev_row, counts, cursor, !agg, s);
     return 0;
 }
 
@@ -533,9 +607,10 @@ extern "C" int pit_neighbors_fwd(const float* mesh_out, const float* mesh_in, in
         fill_int(counts, (long)mesh_batch * n_in, 0, s);
         fill_int(rev_row, rows * cap, -1, s);
     }
+    const bool agg = rev_ptr && n_in <= NBR_LDS_KEYS;
     hipLaunchKernelGGL(neighbors_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, a, cap, nbr_idx, nbr_cnt,
-                       counts);
+                       agg ? nullptr : counts);
     PIT_CHECK_LAUNCH();
-    if (rev_ptr) return launch_transpose(nbr_idx, nbr_cnt, mesh_batch, n_out, n_in, cap, rev_ptr, rev_row, counts, cursor, s);
+    if (rev_ptr) return launch_transpose(nbr_idx, nbr_cnt, mesh_batch, n_out, n_in, cap, rev_ptr, rev_row, counts, cursor, !agg, s);
     return 0;
 }
