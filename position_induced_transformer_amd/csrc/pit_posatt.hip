@@ -766,6 +766,15 @@ __global__ __launch_bounds__(512, 4) void posatt_bwd_pair_kernel(AttArgs ar, Att
 // waves, the weights are reused by up to 32 column tiles, value rows are read once per tile.
 constexpr int TK_CHUNK = 256;
 
+#ifdef PIT_STAMPS
+// diagnostic build only (tools/stamp_tiles.py): shader-clock stamps of one wave, never read by the kernels
+__device__ unsigned long long pit_dbg_stamps[64];
+#define PIT_STAMP(i_) do { if (blockIdx.x == 7 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) \
+                               pit_dbg_stamps[i_] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define PIT_STAMP(i_) do { } while (0)
+#endif
+
 // RT = 32-row tiles per workgroup: every value (B) fragment fetched from L2 feeds RT MFMAs, which
 // is what bounds these kernels at scale (16*RT flop per operand byte).
 template <int RT, int TPW, int MODE, bool MASKED, bool BF>
@@ -776,6 +785,7 @@ __global__ __launch_bounds__(512) void posatt_rows_tiles(AttArgs a) {
     __shared__ float4 s_xi[KC];
     __shared__ int s_flag[KC / 8];
     __shared__ float s_rs[2][16][32 * RT];
+    PIT_STAMP(0);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, l31 = lane & 31;
     const int n0 = blockIdx.z * 32 * RT;
@@ -842,7 +852,9 @@ __global__ __launch_bounds__(512) void posatt_rows_tiles(AttArgs a) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) kpos[u] = group_pos(bf, u, half);
 
-    for (int c0 = 0; c0 < a.n_in; c0 += KC) {
+    PIT_STAMP(1);
+    int pass_i = 0;
+    for (int c0 = 0; c0 < a.n_in; c0 += KC, ++pass_i) {
         const int len = min(KC, a.n_in - c0);
         const int ngroups = (len + 7) / 8;
         float bnext[4][TPW];
@@ -859,9 +871,11 @@ __global__ __launch_bounds__(512) void posatt_rows_tiles(AttArgs a) {
         };
         prefetch(0);                                          // value rows in flight during the weight phase
         __syncthreads();                                      // previous chunk fully consumed
+        if (pass_i < 4) PIT_STAMP(2 + 4 * pass_i);
         for (int idx = tid; idx < len; idx += 512)
             s_xi[idx] = load_point4(rmi, mi_bytes, (long)mb * a.n_in + c0 + idx, a.sdim, a.coords_used);
         __syncthreads();
+        if (pass_i < 4) PIT_STAMP(3 + 4 * pass_i);
         // ---- weight phase: this wave fills keys [8*GW*wave, 8*GW*(wave+1)) of the chunk, all RT row tiles
         // (the periodic wrap is a compile-time variant: as a runtime flag it is if-converted into every distance)
         auto fill = [&](auto per_tag) {
@@ -893,7 +907,9 @@ __global__ __launch_bounds__(512) void posatt_rows_tiles(AttArgs a) {
             }
         };
         if (per) fill(std::true_type{}); else fill(std::false_type{});
+        if (pass_i < 4) PIT_STAMP(4 + 4 * pass_i);
         __syncthreads();
+        if (pass_i < 4) PIT_STAMP(5 + 4 * pass_i);
         // ---- contraction phase: every wave walks the whole chunk for its own tiles
         for (int g = 0; g < ngroups; ++g) {
             float bcur[4][TPW];
@@ -931,6 +947,7 @@ __global__ __launch_bounds__(512) void posatt_rows_tiles(AttArgs a) {
         }
     }
 
+    PIT_STAMP(20);
     if (MODE == 1) {
         const __amdgpu_buffer_rsrc_t rdo = make_rsrc(a.d_out, a.dout_bytes);
         double part = 0.0;
@@ -998,6 +1015,7 @@ __global__ __launch_bounds__(512) void posatt_rows_tiles(AttArgs a) {
             *reinterpret_cast<float4*>(a.rowstat + (((long)mb * a.n_head + h) * a.n_out + n0 + rt * 32 + l31) * 4) = st;
         }
     }
+    PIT_STAMP(21);
     if (a.scale_out && tid == 0 && blockIdx.x == 0 && blockIdx.z == 0) a.scale_out[h] = c;
 }
 
@@ -1904,6 +1922,12 @@ extern "C" int pit_posatt_bwd(const float* mesh_out, const float* mesh_in, int m
     }
     return 0;
 }
+
+#ifdef PIT_STAMPS
+extern "C" int pit_debug_read_stamps(unsigned long long* host64) {
+    return (int)hipMemcpyFromSymbol(host64, HIP_SYMBOL(pit_dbg_stamps), 64 * sizeof(unsigned long long));
+}
+#endif
 
 extern "C" int pit_posatt_dhead_finish(int n_layers, double* const* workspaces, float* const* d_heads,
                                        const float* const* heads, const float* const* scales, const int* n_heads,
