@@ -332,9 +332,12 @@ class _PosAtt(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, values, head, plan: MeshPlan, n_head: int, concat: bool, head_is_scale: bool,
-                head_param=None):
+                head_param=None, out_slot=None):
         _need_gpu(values, head)
         ctx.math = _math_code()
+        # (the concat buffer arrives in a one-element list, not as a tensor argument: a tensor that is both an
+        # input and the returned output would be re-materialised by autograd with a full copy)
+        out_buf = out_slot[0].detach() if out_slot else None
         values = _row_view(values)
         b, j, d = values.shape
         if j != plan.n_in:
@@ -345,7 +348,13 @@ class _PosAtt(torch.autograd.Function):
         if head.numel() != n_head:
             raise RuntimeError("lmda must hold one value per head")
         width = (n_head + (1 if concat else 0)) * d
-        out = torch.empty((b, plan.n_out, width), device=values.device, dtype=torch.float32)
+        copy_inputs = 1 if concat else 0
+        if out_buf is not None:
+            # the producer (mlp_apply(..., concat_heads=H)) already wrote `values` into columns [0, d) of this
+            # buffer: the kernel only adds the head columns - no copy of the inputs (torch.cat of pit.py:44)
+            out, copy_inputs = out_buf, 0
+        else:
+            out = torch.empty((b, plan.n_out, width), device=values.device, dtype=torch.float32)
         rowstat = torch.empty((plan.mesh_batch, n_head, plan.n_out, 4), device=values.device, dtype=torch.float32)
         scale = torch.empty((n_head,), device=values.device, dtype=torch.float32)
         rc = _lib.lib().pit_posatt_fwd(
@@ -354,7 +363,7 @@ class _PosAtt(torch.autograd.Function):
             values.data_ptr(), b, d, values.stride(1), values.stride(0),
             head.data_ptr(), n_head, 1 if head_is_scale else 0,
             _lib.ptr(plan.stats), plan.rank_w, 1 if plan.masked else 0, 1 if plan.self_attn else 0,
-            out.data_ptr(), out.stride(1), out.stride(0), d if concat else 0, 1 if concat else 0,
+            out.data_ptr(), out.stride(1), out.stride(0), d if concat else 0, copy_inputs,
             rowstat.data_ptr(), scale.data_ptr(),
             _lib.ptr(plan.nbr_idx), _lib.ptr(plan.nbr_cnt), plan.nbr_cap, ctx.math, _lib.stream_ptr())
         _lib.check(rc, "pit_posatt_fwd")
@@ -407,7 +416,7 @@ class _PosAtt(torch.autograd.Function):
             launch(d_values, d_head, _lib.stream_ptr())
         if defer:
             _defer_head_finish(work, d_head, head, scale, n_head, 1 | (4 if ctx.head_is_scale else 0))
-        return d_values, (None if slot is not None else d_head), None, None, None, None, None
+        return d_values, (None if slot is not None else d_head), None, None, None, None, None, None
 
 
 # Where the head scale c = tan(0.25*pi*(1-1e-7)*(1+sin(lmda))) (pit.py:48) is evaluated.
@@ -471,6 +480,20 @@ class _HostHeadScale(torch.autograd.Function):
         return d_l.to(d_c.device)
 
 
+def _concat_buffer_of(values: torch.Tensor, n_out: int, n_head: int):
+    """The concat buffer a producer attached to ``values`` (mlp_apply(..., concat_heads=H)), if ``values`` really
+    is its first-columns view with the layout this layer needs; consumed once (a second consumer gets a copy)."""
+    buf = getattr(values, "_pit_concat", None)
+    if buf is None:
+        return None
+    values._pit_concat = None
+    b, j, d = values.shape
+    w = (1 + n_head) * d
+    ok = (buf.dim() == 3 and tuple(buf.shape) == (b, n_out, w) and j == n_out and buf.is_contiguous()
+          and values.data_ptr() == buf.data_ptr() and tuple(values.stride()) == (n_out * w, w, 1))
+    return buf if ok else None
+
+
 @torch.compiler.disable
 def posatt_apply(values: torch.Tensor, lmda: torch.Tensor, plan: MeshPlan, n_head: int, concat: bool,
                  head_is_scale: bool = False) -> torch.Tensor:
@@ -478,18 +501,20 @@ def posatt_apply(values: torch.Tensor, lmda: torch.Tensor, plan: MeshPlan, n_hea
     (pit.py:46-57); with ``concat`` the inputs are prepended (pit.py:44).  ``lmda`` is the
     (H,1,1) parameter, or the scale c itself when ``head_is_scale`` (tests inject it).
     Opaque to torch.compile (dynamo runs it eagerly: raw pointers cross a ctypes boundary)."""
+    out_buf = _concat_buffer_of(values, plan.n_out, n_head) if concat else None
     if not head_is_scale and get_head_scale_route() == "host":
         c = _HostHeadScale.apply(lmda.reshape(-1))
-        return _PosAtt.apply(values, c, plan, n_head, concat, True, None)
+        return _PosAtt.apply(values, c, plan, n_head, concat, True, None, [out_buf] if out_buf is not None else None)
     param = lmda if isinstance(lmda, torch.nn.Parameter) else None
-    return _PosAtt.apply(values, lmda.reshape(-1), plan, n_head, concat, head_is_scale, param)
+    return _PosAtt.apply(values, lmda.reshape(-1), plan, n_head, concat, head_is_scale, param,
+                         [out_buf] if out_buf is not None else None)
 
 
 class _Mlp(torch.autograd.Function):
     """kaiming_mlp forward/backward, optionally with the trailing gelu of pit.py:111,121."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, out_gelu: bool):
+    def forward(ctx, x, w1, b1, w2, b2, out_gelu: bool, concat_heads: int = 0):
         _need_gpu(x, w1, b1, w2, b2)
         shape = x.shape
         n0 = shape[-1]
@@ -505,7 +530,12 @@ class _Mlp(torch.autograd.Function):
         z1 = torch.empty((rows, n1), device=dev, dtype=torch.float32)
         h = torch.empty((rows, n1), device=dev, dtype=torch.float32)
         z2 = torch.empty((rows, n2), device=dev, dtype=torch.float32) if out_gelu else None
-        y = torch.empty((rows, n2), device=dev, dtype=torch.float32)
+        buf = None
+        if concat_heads > 0:             # y goes straight into columns [0, n2) of the next self-attention's concat buffer
+            buf = torch.empty((rows, (1 + concat_heads) * n2), device=dev, dtype=torch.float32)
+            y = buf[:, :n2]
+        else:
+            y = torch.empty((rows, n2), device=dev, dtype=torch.float32)
         ctx.math = _math_code()
         rc = _lib.lib().pit_mlp_fwd(x2.data_ptr(), x2.stride(0), rows, n0, n1, n2, w1c.data_ptr(), b1c.data_ptr(),
                                     w2c.data_ptr(), b2c.data_ptr(), 1 if out_gelu else 0, z1.data_ptr(),
@@ -515,12 +545,20 @@ class _Mlp(torch.autograd.Function):
         ctx.out_gelu, ctx.dims, ctx.in_shape = out_gelu, (rows, n0, n1, n2), shape
         ctx.params = (w1, b1, w2, b2)
         ctx.save_for_backward(x2, w1c, w2c, z1, h, z2 if out_gelu else z1)
-        return y.reshape(*shape[:-1], n2)
+        out = y.reshape(*shape[:-1], n2)             # (a view: constant row stride)
+        if buf is None:
+            return out
+        buf = buf.reshape(*shape[:-1], (1 + concat_heads) * n2)
+        ctx.mark_non_differentiable(buf)
+        ctx.set_materialize_grads(False)             # no zero-filled "gradient" tensor for the buffer output
+        return out, buf
 
     @staticmethod
-    def backward(ctx, d_y):
+    def backward(ctx, d_y, _d_buf=None):
         x2, w1, w2, z1, h, z2 = ctx.saved_tensors
         rows, n0, n1, n2 = ctx.dims
+        if d_y is None:                              # (only with set_materialize_grads(False): output unused)
+            d_y = torch.zeros((rows, n2), device=x2.device, dtype=torch.float32)
         dev = x2.device
         d_y2 = d_y.reshape(rows, n2)
         if d_y2.stride(1) != 1 or d_y2.stride(0) < n2:
@@ -559,13 +597,21 @@ class _Mlp(torch.autograd.Function):
             _lib.check(rc, "pit_mlp_bwd")
         dx = d_x.reshape(ctx.in_shape) if need_x else None
         if inplace:
-            return dx, None, None, None, None, None
-        return dx, d_w1, d_b1, d_w2, d_b2, None
+            return dx, None, None, None, None, None, None
+        return dx, d_w1, d_b1, d_w2, d_b2, None, None
 
 
 @torch.compiler.disable
-def mlp_apply(x, w1, b1, w2, b2, out_gelu: bool = False) -> torch.Tensor:
-    return _Mlp.apply(x, w1, b1, w2, b2, out_gelu)
+def mlp_apply(x, w1, b1, w2, b2, out_gelu: bool = False, concat_heads: int = 0) -> torch.Tensor:
+    """kaiming_mlp forward (pit.py:21-26) (+ trailing gelu).  ``concat_heads=H`` (the result feeds a
+    self-attention layer with H heads: pit.py:116-121) makes the kernels write the result directly into the
+    first columns of that layer's (b, L, (1+H)*n2) concat buffer; the returned tensor is that strided view and
+    carries the buffer (``_pit_concat``), so the attention kernel skips copying its inputs (pit.py:44)."""
+    if concat_heads <= 0 or x.dim() != 3:
+        return _Mlp.apply(x, w1, b1, w2, b2, out_gelu, 0)
+    y, buf = _Mlp.apply(x, w1, b1, w2, b2, out_gelu, int(concat_heads))
+    y._pit_concat = buf
+    return y
 
 
 class _RelLpLoss(torch.autograd.Function):

@@ -80,10 +80,12 @@ class kaiming_mlp(nn.Module):
         nn.init.kaiming_normal_(self.mlp1.weight)
         nn.init.kaiming_normal_(self.mlp2.weight)
 
-    def forward(self, x, out_gelu: bool = False):
+    def forward(self, x, out_gelu: bool = False, concat_heads: int = 0):
         """``out_gelu=True`` fuses the gelu that pit.encoder/processor apply to the result
-        (pit.py:111,121) into the second GEMM's epilogue."""
-        return ops.mlp_apply(x, self.mlp1.weight, self.mlp1.bias, self.mlp2.weight, self.mlp2.bias, out_gelu)
+        (pit.py:111,121) into the second GEMM's epilogue; ``concat_heads=H`` writes the result into the
+        concat buffer of the H-head self-attention layer that consumes it (ops.mlp_apply)."""
+        return ops.mlp_apply(x, self.mlp1.weight, self.mlp1.bias, self.mlp2.weight, self.mlp2.bias, out_gelu,
+                             concat_heads)
 
 
 class posatt(nn.Module):
@@ -227,11 +229,18 @@ class pit(nn.Module):
         self.de = kaiming_mlp(self.n_head * self.hid_dim, self.hid_dim, self.out_dim)
 
     @staticmethod
-    def _mlp_gelu(layer, x):
+    def _mlp_gelu(layer, x, concat_heads: int = 0):
         # scripts may replace en_layer / mlp[i] by their own modules (train_elasticity.py:39)
         if isinstance(layer, kaiming_mlp):
-            return layer(x, out_gelu=True)
+            return layer(x, out_gelu=True, concat_heads=concat_heads)
         return gelu(layer(x))
+
+    def _heads_of_block(self, i: int, width: int) -> int:
+        """Heads of processor block i if it is one of OUR self-attention layers consuming ``width`` channels
+        (then the producing MLP writes straight into its concat buffer), else 0."""
+        if 0 <= i < len(self.conv) and isinstance(self.conv[i], posatt) and self.conv[i].in_dim == width:
+            return int(self.conv[i].n_head)
+        return 0
 
     def _swap_attention(self, self_cls, cross_cls):
         """Replace down / conv / up by another geometry's operators AFTER the base layers were
@@ -243,12 +252,12 @@ class pit(nn.Module):
 
     def encoder(self, mesh_in, func_in, mesh_ltt):
         func_ltt = self.down(mesh_ltt, mesh_in, func_in)
-        return self._mlp_gelu(self.en_layer, func_ltt)
+        return self._mlp_gelu(self.en_layer, func_ltt, self._heads_of_block(0, self.hid_dim))
 
     def processor(self, func_ltt, mesh_ltt):
-        for a, w in zip(self.conv, self.mlp):
+        for i, (a, w) in enumerate(zip(self.conv, self.mlp)):
             func_ltt = a(mesh_ltt, func_ltt)
-            func_ltt = self._mlp_gelu(w, func_ltt)
+            func_ltt = self._mlp_gelu(w, func_ltt, self._heads_of_block(i + 1, self.hid_dim))
         return func_ltt
 
     def decoder(self, mesh_ltt, func_ltt, mesh_out):
