@@ -1267,9 +1267,9 @@ void launch_rows(const AttArgs& a0, hipStream_t s) {
     const size_t sm = rows_smem(ct, nwaves, a.n_in);
 #define PIT_ROWS_BF(CT_, BF_)                                                                               \
     do {                                                                                                    \
-        static bool once = (hipFuncSetAttribute((const void*)posatt_rows_kernel<CT_, MODE, true, BF_>,      \
+        static bool once = ((void)hipFuncSetAttribute((const void*)posatt_rows_kernel<CT_, MODE, true, BF_>,      \
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 98304),         \
-                            hipFuncSetAttribute((const void*)posatt_rows_kernel<CT_, MODE, false, BF_>,     \
+                            (void)hipFuncSetAttribute((const void*)posatt_rows_kernel<CT_, MODE, false, BF_>,     \
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 98304), true);  \
         (void)once;                                                                                         \
         if (a.masked) hipLaunchKernelGGL((posatt_rows_kernel<CT_, MODE, true, BF_>), grid, block, sm, s, a); \
@@ -1313,9 +1313,9 @@ void launch_cols(const AttArgs& a0, hipStream_t s) {
     const size_t sm = cols_smem(ct, nwaves, a.n_out);
 #define PIT_COLS_BF(CT_, BF_)                                                                          \
     do {                                                                                               \
-        static bool once = (hipFuncSetAttribute((const void*)posatt_cols_kernel<CT_, true, BF_>,       \
+        static bool once = ((void)hipFuncSetAttribute((const void*)posatt_cols_kernel<CT_, true, BF_>,       \
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 98304),    \
-                            hipFuncSetAttribute((const void*)posatt_cols_kernel<CT_, false, BF_>,      \
+                            (void)hipFuncSetAttribute((const void*)posatt_cols_kernel<CT_, false, BF_>,      \
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 98304), true); \
         (void)once;                                                                                    \
         if (a.masked) hipLaunchKernelGGL((posatt_cols_kernel<CT_, true, BF_>), grid, block, sm, s, a);  \
@@ -1359,7 +1359,7 @@ bool launch_bwd_pair(const AttArgs& a0, hipStream_t s) {
     dim3 grid((unsigned)(rows_wgs + cols_wgs)), block(64 * nwaves);
 #define PIT_PAIR_K(M_, BF_)                                                                                   \
     do {                                                                                                      \
-        static bool once = (hipFuncSetAttribute((const void*)posatt_bwd_pair_kernel<M_, BF_>,                 \
+        static bool once = ((void)hipFuncSetAttribute((const void*)posatt_bwd_pair_kernel<M_, BF_>,                 \
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 98304), true);    \
         (void)once;                                                                                           \
         hipLaunchKernelGGL((posatt_bwd_pair_kernel<M_, BF_>), grid, block, sm, s, ar, ac, (int)cols_wgs,      \
@@ -1367,7 +1367,7 @@ bool launch_bwd_pair(const AttArgs& a0, hipStream_t s) {
     } while (0)
 #define PIT_PAIR_W(CT_, M_, BF_)                                                                              \
     do {                                                                                                      \
-        static bool once = (hipFuncSetAttribute((const void*)posatt_bwd_pair_wide_kernel<CT_, M_, BF_>,       \
+        static bool once = ((void)hipFuncSetAttribute((const void*)posatt_bwd_pair_wide_kernel<CT_, M_, BF_>,       \
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 98304), true);    \
         (void)once;                                                                                           \
         hipLaunchKernelGGL((posatt_bwd_pair_wide_kernel<CT_, M_, BF_>), grid, block, sm, s, ar, ac, (int)cols_wgs, \
