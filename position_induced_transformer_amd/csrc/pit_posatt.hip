@@ -145,6 +145,18 @@ __device__ __forceinline__ float4 load_point4(__amdgpu_buffer_rsrc_t r, unsigned
 // [w*16*CT/nwaves, ...) - so the epilogue (normalise, stores, residual loads) is spread over all
 // waves instead of being serialised on wave 0.  Scalars are summed by every wave (all need them).
 // `part` receives this wave's share (up to 16*CT registers, index q = t*16 + r).
+#ifdef PIT_STAMPS
+// diagnostic build only (tools/stamp_tiles.py): shader-clock stamps of one wave, never read by the kernels
+__device__ unsigned long long pit_dbg_stamps[64];
+#define PIT_STAMP(i_) do { if (blockIdx.x == 7 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) \
+                               pit_dbg_stamps[i_] = __builtin_amdgcn_s_memtime(); } while (0)
+#define PIT_STAMP_B(i_) do { if (bx == 1 && by == 0 && bz == 3 && threadIdx.x == 0) \
+                                 pit_dbg_stamps[i_] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define PIT_STAMP(i_) do { } while (0)
+#define PIT_STAMP_B(i_) do { } while (0)
+#endif
+
 template <int CT, int NX>
 __device__ __forceinline__ void park_tiles(const f32x16 (&acc)[CT], const float (&extra)[NX > 0 ? NX : 1], float* red,
                                            int wave, int lane) {
@@ -182,6 +194,7 @@ __device__ __forceinline__ void posatt_rows_body(const AttArgs& a, const int bx,
     const int mb = bx / a.colgroups, cg = bx % a.colgroups;
     const long rows_total = (long)a.mesh_batch * a.n_out;
 
+    PIT_STAMP_B(32);
     const float c = a.head_is_scale ? a.head[h] : head_scale_from_lmda(a.head[h]);
 
     // ---- per-lane row constants (row = n0 + lane&31, both half-waves hold the same row)
@@ -422,7 +435,9 @@ __device__ __forceinline__ void posatt_rows_body(const AttArgs& a, const int bx,
             }
         }
     };
+    PIT_STAMP_B(33);
     if (per) run(std::true_type{}); else run(std::false_type{});
+    PIT_STAMP_B(34);
 
     if (MODE == 1) {
         // dc_h -= sum acc[n,col] * dO[n,col]   (fp64 accumulation)
@@ -456,36 +471,73 @@ __device__ __forceinline__ void posatt_rows_body(const AttArgs& a, const int bx,
     __syncthreads();                                   // staging region is free
     park_tiles<CT, 2>(acc, extra, red, wave, lane);
     __syncthreads();
+    PIT_STAMP_B(35);
     const float rs_tot = summed<CT, 2>(red, nwaves, CT * 16, lane);       // row = lane & 31
     const float qs_tot = summed<CT, 2>(red, nwaves, CT * 16 + 1, lane);
     const float inv = rs_tot > 0.0f ? 1.0f / rs_tot : 0.0f;
+    PIT_STAMP_B(37);
     const int share = CT * 16 / nwaves;               // nwaves in {1,2,4,8}
     const int q0 = wave * share;
-#pragma unroll 1
-    for (int qq = 0; qq < share; ++qq) {
-        const int q = q0 + qq;
-        const int t = q >> 4, i = q & 15;
-        const int row = acc_row(i, half);
-        const int nr = n0 + row;
-        const float v = summed<CT, 2>(red, nwaves, q, lane) * __shfl(inv, row);
-        // column constants of tile t (t is wave-uniform but dynamic: recompute instead of indexing)
-        const int col = (cg * CT + t) * 32 + l31;
-        const bool cv = col < a.ncols;
-        const int cc = cv ? col : 0;
-        int bb, dd;
-        col_split(a, cc, mb, bb, dd);
-        const bool ok = cv && nr < a.n_out;
-        if (ok) a.out[(long)bb * a.out_bstride + (long)nr * a.ld_out + a.out_col0 + (long)h * a.dim + dd] = v;
-        if (a.copy_inputs && h == 0) {                 // torch.cat((inputs, conv), -1) of pit.py:44
-            const unsigned off = (unsigned)(((long)bb * a.values_bstride + dd) * 4) + (unsigned)nr * ld4;
-            const float iv = buf_load(rvals, ok ? off : a.values_bytes);
-            if (ok) a.out[(long)bb * a.out_bstride + (long)nr * a.ld_out + dd] = iv;
+    // U accumulator registers per trip with ALL their LDS reads (U x nwaves) issued before the first add, and the
+    // input-copy loads of the trip before its stores: one register per trip with a runtime wave loop was a chain
+    // of dependent LDS round trips (measured with in-kernel stamps: 18.8 k of 105 k cycles at D = 256)
+    auto finish = [&](auto u_tag, auto nw_tag, int qfirst) {
+        constexpr int U = decltype(u_tag)::value, NW = decltype(nw_tag)::value;
+        constexpr int SLOT = (CT * 16 + 2) * 64;
+        float part[U][NW];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int w = 0; w < NW; ++w) part[u][w] = red[(long)w * SLOT + (qfirst + u) * 64 + lane];
+        long ooff[U];
+        unsigned ioff[U];
+        bool ok[U];
+        float iv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int q = qfirst + u;
+            const int t = q >> 4, i = q & 15;
+            const int nr = n0 + acc_row(i, half);
+            const int col = (cg * CT + t) * 32 + l31;
+            const bool cv = col < a.ncols;
+            int bb, dd;
+            col_split(a, cv ? col : 0, mb, bb, dd);
+            ok[u] = cv && nr < a.n_out;
+            ooff[u] = (long)bb * a.out_bstride + (long)nr * a.ld_out + dd;
+            ioff[u] = (unsigned)(((long)bb * a.values_bstride + dd) * 4) + (unsigned)nr * ld4;
+            iv[u] = 0.0f;
+            if (a.copy_inputs && h == 0) iv[u] = buf_load(rvals, ok[u] ? ioff[u] : a.values_bytes);   // torch.cat((inputs, conv), -1), pit.py:44
         }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            float v = 0.0f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) v += part[u][w];
+            v *= __shfl(inv, acc_row((qfirst + u) & 15, half));
+            if (ok[u]) a.out[ooff[u] + a.out_col0 + (long)h * a.dim] = v;
+        }
+        if (a.copy_inputs && h == 0) {
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (ok[u]) a.out[ooff[u]] = iv[u];
+        }
+    };
+    auto finish_all = [&](auto nw_tag) {
+        int qq = 0;
+        for (; qq + 4 <= share; qq += 4) { finish(std::integral_constant<int, 4>{}, nw_tag, q0 + qq); PIT_STAMP_B(38 + qq / 4); }
+        for (; qq < share; ++qq) finish(std::integral_constant<int, 1>{}, nw_tag, q0 + qq);
+    };
+    switch (nwaves) {
+        case 1: finish_all(std::integral_constant<int, 1>{}); break;
+        case 2: finish_all(std::integral_constant<int, 2>{}); break;
+        case 4: finish_all(std::integral_constant<int, 4>{}); break;
+        default: finish_all(std::integral_constant<int, 8>{}); break;
     }
     if (wave == 0 && cg == 0 && half == 0 && nvalid) {
         float4 st; st.x = T; st.y = s_min; st.z = inv; st.w = qs_tot * inv;
         *reinterpret_cast<float4*>(a.rowstat + (((long)mb * a.n_head + h) * a.n_out + n) * 4) = st;
     }
+    PIT_STAMP_B(36);
     if (a.scale_out && wave == 0 && bx == 0 && bz == 0 && lane == 0) a.scale_out[h] = c;
 }
 
@@ -712,22 +764,51 @@ __device__ __forceinline__ void posatt_cols_body(const AttArgs& a, const int bx,
     __syncthreads();
     const int share = CT * 16 / nwaves;
     const int q0 = wave * share;
-#pragma unroll 1
-    for (int qq = 0; qq < share; ++qq) {
-        const int q = q0 + qq;
-        const int t = q >> 4, i = q & 15;
-        const int jr = j0 + acc_row(i, half);
-        const int col = (cg * CT + t) * 32 + l31;
-        const bool cv = col < a.ncols;
-        const int cc = cv ? col : 0;
-        int bb, dd;
-        col_split(a, cc, mb, bb, dd);
-        const bool ok = cv && jr < a.n_in;
-        float v = summed<CT, 0>(red, nwaves, q, lane);
-        // residual (self attention): d_out columns [0,dim) of the same row
-        const unsigned roff = (unsigned)(((long)bb * a.dout_bstride + dd) * 4) + (unsigned)jr * ldd4;
-        v += buf_load(rdout, (a.add_residual && ok) ? roff : a.dout_bytes);
-        if (ok) a.d_values[(long)bb * a.dvalues_bstride + (long)jr * a.ld_dvalues + dd] = v;
+    // four registers per trip: their LDS reads (4 x nwaves) and residual loads are all in flight before the first
+    // add (one register per trip with a runtime wave loop was a chain of dependent LDS + memory round trips)
+    auto finish = [&](auto u_tag, auto nw_tag, int qfirst) {
+        constexpr int U = decltype(u_tag)::value, NW = decltype(nw_tag)::value;
+        constexpr int SLOT = (CT * 16) * 64;
+        float part[U][NW], res[U];
+        long ooff[U];
+        bool ok[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int w = 0; w < NW; ++w) part[u][w] = red[(long)w * SLOT + (qfirst + u) * 64 + lane];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int q = qfirst + u;
+            const int t = q >> 4, i = q & 15;
+            const int jr = j0 + acc_row(i, half);
+            const int col = (cg * CT + t) * 32 + l31;
+            const bool cv = col < a.ncols;
+            int bb, dd;
+            col_split(a, cv ? col : 0, mb, bb, dd);
+            ok[u] = cv && jr < a.n_in;
+            // residual (self attention): d_out columns [0,dim) of the same row
+            const unsigned roff = (unsigned)(((long)bb * a.dout_bstride + dd) * 4) + (unsigned)jr * ldd4;
+            res[u] = buf_load(rdout, (a.add_residual && ok[u]) ? roff : a.dout_bytes);
+            ooff[u] = (long)bb * a.dvalues_bstride + (long)jr * a.ld_dvalues + dd;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            float v = 0.0f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) v += part[u][w];
+            if (ok[u]) a.d_values[ooff[u]] = v + res[u];
+        }
+    };
+    auto finish_all = [&](auto nw_tag) {
+        int qq = 0;
+        for (; qq + 4 <= share; qq += 4) finish(std::integral_constant<int, 4>{}, nw_tag, q0 + qq);
+        for (; qq < share; ++qq) finish(std::integral_constant<int, 1>{}, nw_tag, q0 + qq);
+    };
+    switch (nwaves) {
+        case 1: finish_all(std::integral_constant<int, 1>{}); break;
+        case 2: finish_all(std::integral_constant<int, 2>{}); break;
+        case 4: finish_all(std::integral_constant<int, 4>{}); break;
+        default: finish_all(std::integral_constant<int, 8>{}); break;
     }
 }
 
@@ -766,14 +847,6 @@ __global__ __launch_bounds__(512, 4) void posatt_bwd_pair_kernel(AttArgs ar, Att
 // waves, the weights are reused by up to 32 column tiles, value rows are read once per tile.
 constexpr int TK_CHUNK = 256;
 
-#ifdef PIT_STAMPS
-// diagnostic build only (tools/stamp_tiles.py): shader-clock stamps of one wave, never read by the kernels
-__device__ unsigned long long pit_dbg_stamps[64];
-#define PIT_STAMP(i_) do { if (blockIdx.x == 7 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) \
-                               pit_dbg_stamps[i_] = __builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define PIT_STAMP(i_) do { } while (0)
-#endif
 
 // RT = 32-row tiles per workgroup: every value (B) fragment fetched from L2 feeds RT MFMAs, which
 // is what bounds these kernels at scale (16*RT flop per operand byte).
@@ -1262,7 +1335,7 @@ void launch_rows(const AttArgs& a0, hipStream_t s) {
     a.colgroups = (a.ncols + 32 * ct - 1) / (32 * ct);
     const int wmax = (ct == 4) ? 4 : 8;                                  // parked tiles must fit 96 KiB of LDS
     int nwaves = max(1, min(wmax, pow2_floor(a.n_in / 32)));
-    if (int f = env_int("PIT_FORCE_WAVES")) nwaves = min(f, wmax);
+    if (int f = env_int("PIT_FORCE_WAVES")) nwaves = pow2_floor(max(1, min(f, wmax)));     // (the epilogue is specialised for 1/2/4/8)
     dim3 grid(a.mesh_batch * a.colgroups, a.n_head, n_tiles), block(64 * nwaves);
     const size_t sm = rows_smem(ct, nwaves, a.n_in);
 #define PIT_ROWS_BF(CT_, BF_)                                                                               \
@@ -1308,7 +1381,7 @@ void launch_cols(const AttArgs& a0, hipStream_t s) {
     a.colgroups = (a.ncols + 32 * ct - 1) / (32 * ct);
     const int wmax = (ct == 4) ? 4 : 8;
     int nwaves = max(1, min(wmax, pow2_floor(a.n_out * a.n_head / 32)));
-    if (int f = env_int("PIT_FORCE_WAVES")) nwaves = min(f, wmax);
+    if (int f = env_int("PIT_FORCE_WAVES")) nwaves = pow2_floor(max(1, min(f, wmax)));
     dim3 grid(a.colgroups, j_tiles, a.mesh_batch), block(64 * nwaves);
     const size_t sm = cols_smem(ct, nwaves, a.n_out);
 #define PIT_COLS_BF(CT_, BF_)                                                                          \
