@@ -44,6 +44,7 @@ struct GemmArgs {
     int ones_col;                        // >= 0: B(k, ones_col) == 1, that output column goes to C2[m]
     float* C2;
     int bf16;                            // PIT_MATH_BF16: one v_mfma_f32_32x32x8_bf16 per 4 k instead of 4 fp32 MFMAs
+    int seq_epi;                         // experiments (PIT_GEMM_RD_SEQ_EPI): one accumulator register per epilogue trip
 };
 
 // 4 k-values of one operand for this lane: X(i, kk+e), e = 0..3, through a raw buffer
@@ -167,24 +168,58 @@ __device__ __forceinline__ void gemm_rd_body(const GemmArgs& g, int bx, int by, 
         __syncthreads();
     }
     const int q0 = wave * share;
-#pragma unroll 1
-    for (int qq = 0; qq < share; ++qq) {
-        const int q = q0 + qq;
-        const int t = q >> 4, r = q & 15;
-        float v = 0.0f;
-        for (int w = 0; w < nwaves; ++w) v += red[((long)w * NQ + q) * 64 + lane];
-        const int col = n0 + t * 32 + l31;
-        const int row = m0 + acc_row(r, half);
-        if (col >= g.N || row >= g.M) continue;
-        if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) v += g.bias[col];
-        if (EPI == EPI_BIAS_GELU) { g.Z[(long)row * g.ldz + col] = v; v = gelu_erf(v); }
-        if (EPI == EPI_MUL_GELU_GRAD) v *= gelu_erf_grad(g.G[(long)row * g.ldg + col]);
-        if (EPI == EPI_ATOMIC) {
-            if (col == g.ones_col) atomicAdd(g.C2 + row, v);
-            else atomicAdd(g.C + (long)row * g.ldc + col, v);
-        } else {
-            g.C[(long)row * g.ldc + col] = v;
+    // U accumulator registers per trip: their LDS reads (U x nwaves) and the epilogue's global loads (bias, the
+    // gelu' argument) are all requested before the first add - one register per trip with a runtime wave loop
+    // made every trip a chain of dependent LDS and memory round trips
+    auto finish = [&](auto u_tag, auto nw_tag, int qfirst) {
+        constexpr int U = decltype(u_tag)::value, NW = decltype(nw_tag)::value;
+        float part[U][NW], aux[U], bia[U];
+        int col[U], row[U];
+        bool ok[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int w = 0; w < NW; ++w) part[u][w] = red[((long)w * NQ + qfirst + u) * 64 + lane];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int q = qfirst + u;
+            const int t = q >> 4, r = q & 15;
+            col[u] = n0 + t * 32 + l31;
+            row[u] = m0 + acc_row(r, half);
+            ok[u] = col[u] < g.N && row[u] < g.M;
+            bia[u] = 0.0f; aux[u] = 0.0f;
+            if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) bia[u] = ok[u] ? g.bias[col[u]] : 0.0f;
+            if (EPI == EPI_MUL_GELU_GRAD) aux[u] = ok[u] ? g.G[(long)row[u] * g.ldg + col[u]] : 0.0f;
         }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            float v = 0.0f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) v += part[u][w];
+            if (!ok[u]) continue;
+            if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) v += bia[u];
+            if (EPI == EPI_BIAS_GELU) { g.Z[(long)row[u] * g.ldz + col[u]] = v; v = gelu_erf(v); }
+            if (EPI == EPI_MUL_GELU_GRAD) v *= gelu_erf_grad(aux[u]);
+            if (EPI == EPI_ATOMIC) {
+                if (col[u] == g.ones_col) atomicAdd(g.C2 + row[u], v);
+                else atomicAdd(g.C + (long)row[u] * g.ldc + col[u], v);
+            } else {
+                g.C[(long)row[u] * g.ldc + col[u]] = v;
+            }
+        }
+    };
+    auto finish_all = [&](auto nw_tag) {
+        int qq = 0;
+        if (EPI != EPI_ATOMIC && !g.seq_epi) {       // (the row-reducing GEMMs end in atomics, nothing to wait for: batching them measured slower)
+            for (; qq + 4 <= share; qq += 4) finish(std::integral_constant<int, 4>{}, nw_tag, q0 + qq);
+            for (; qq + 2 <= share; qq += 2) finish(std::integral_constant<int, 2>{}, nw_tag, q0 + qq);
+        }
+        for (; qq < share; ++qq) finish(std::integral_constant<int, 1>{}, nw_tag, q0 + qq);
+    };
+    switch (nwaves) {
+        case 2: finish_all(std::integral_constant<int, 2>{}); break;
+        case 4: finish_all(std::integral_constant<int, 4>{}); break;
+        default: finish_all(std::integral_constant<int, 8>{}); break;
     }
 }
 
@@ -1047,6 +1082,8 @@ int prepare_gemm(GemmArgs& g, GemmLaunch& L, int force_tn = 0, int force_waves =
     if (ab > PIT_MAX_BUFFER_BYTES || bb > PIT_MAX_BUFFER_BYTES) return PIT_ERR_UNSUPPORTED;
     g.a_bytes = (unsigned)ab; g.b_bytes = (unsigned)bb;
     g.bf16 = (t_call_math == PIT_MATH_BF16);
+    static const int seq_epi = getenv("PIT_GEMM_RD_SEQ_EPI") != nullptr;
+    g.seq_epi = seq_epi;
     g.a_vec = vec_ok(g.A, g.a_rs, g.a_cs) && (!g.a_gz || vec_ok(g.a_gz, g.a_rs, g.a_cs));
     g.b_vec = vec_ok(g.B, g.b_cs, g.b_rs);
     // two column tiles per wave (A fragment reused) only when that still leaves plenty of workgroups
