@@ -601,3 +601,40 @@ def test_sod_and_elasticity_full_size_match_oracle():
     # hid 256 (K = 768 sums), random-init weights: the oracle's OWN fp32 result is 7.0e-6 from its fp64 evaluation
     # on this case, so two correct fp32 evaluations sit ~1e-5 apart (measured here 1.05e-5): bound = 2 x that distance
     _compare_with_oracle(model, out, loss, ref, ref_loss, p, tol_out=1.4e-5)
+
+
+# --------------------------------------------------------------------------- concat buffer hand-off (MLP -> self-attention)
+def test_mlp_output_in_concat_buffer_equals_the_copy_path_and_is_consumed_once():
+    """ops.mlp_apply(..., concat_heads=H) writes straight into the next self-attention's concat buffer (no input copy
+    in the attention epilogue, pit.py:44).  Same numbers as the plain path, forward and backward; a SECOND consumer of
+    the same MLP output must not reuse (and overwrite) the buffer the first one returned."""
+    from position_induced_transformer_amd import ops, pit as P
+    torch.manual_seed(5)
+    mlp = P.kaiming_mlp(24, 64, 64).cuda()
+    att1, att2 = P.posatt_fixed(2, 64, 1.0).cuda(), P.posatt_fixed(2, 64, 1.0).cuda()
+    mesh = torch.rand(200, 2, device="cuda")
+    x = torch.randn(3, 200, 24, device="cuda")
+
+    def run(concat_heads):
+        for m in (mlp, att1, att2):
+            m.zero_grad()
+        xx = x.clone().requires_grad_(True)
+        y = mlp(xx, out_gelu=True, concat_heads=concat_heads)
+        a = att1(mesh, y)                    # consumes the buffer (if any)
+        b = att2(mesh, y)                    # second consumer: must take the copy path
+        (a.square().sum() + (b * 0.5).sum()).backward()
+        return a.detach().clone(), b.detach().clone(), xx.grad.clone(), [p.grad.clone() for p in mlp.parameters()]
+
+    ref = run(0)
+    got = run(2)
+    assert hasattr(mlp(x, out_gelu=True, concat_heads=2), "_pit_concat")
+    for r, g in zip(ref[:3], got[:3]):
+        assert gio.rel_l2(r.cpu().numpy(), g.cpu().numpy()) <= 1e-6
+    for r, g in zip(ref[3], got[3]):
+        assert gio.rel_l2(r.cpu().numpy(), g.cpu().numpy()) <= 1e-5
+    # the first consumer's output really is the buffer (shares the MLP output's storage), the second's is not
+    y = mlp(x, out_gelu=True, concat_heads=2)
+    a = att1(mesh, y)
+    b = att2(mesh, y)
+    assert a.data_ptr() == y.data_ptr() and b.data_ptr() != y.data_ptr()
+    assert torch.equal(a[..., :64], y) and torch.equal(b[..., :64], y)
