@@ -71,7 +71,7 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--eager-allreduce", action="store_true",
                     help="N > 1: capture the compute only and issue the gradient all-reduce eagerly after each replay")
-    ap.add_argument("--watchdog", type=float, default=120.0, help="N > 1: seconds allowed for capture + first replays")
+    ap.add_argument("--watchdog", type=float, default=300.0, help="N > 1: seconds allowed for capture + first replays")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip batch sweep / optimizer / roofline probes")
     ap.add_argument("--cpu-iters", type=int, default=100)
