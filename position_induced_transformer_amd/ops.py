@@ -432,6 +432,9 @@ class _PosAtt(torch.autograd.Function):
 #       tests), not for captured training steps.
 HEAD_SCALE_ROUTES = ("device", "host")
 _ROUTE = threading.local()
+_DEFAULT_ROUTE = os.environ.get("PIT_HEAD_SCALE_ROUTE", "device")
+if _DEFAULT_ROUTE not in HEAD_SCALE_ROUTES:
+    raise ValueError(f"PIT_HEAD_SCALE_ROUTE must be one of {HEAD_SCALE_ROUTES}, got {_DEFAULT_ROUTE!r}")
 
 
 def set_head_scale_route(route: str) -> None:
@@ -441,7 +444,9 @@ def set_head_scale_route(route: str) -> None:
 
 
 def get_head_scale_route() -> str:
-    return getattr(_ROUTE, "route", "device")
+    """Per-thread route; the process default is 'device' unless PIT_HEAD_SCALE_ROUTE=host is set in the environment
+    (exact reproduction of a reference checkpoint by an unmodified script)."""
+    return getattr(_ROUTE, "route", _DEFAULT_ROUTE)
 
 
 class head_scale_route:
