@@ -55,8 +55,14 @@ def _capturing() -> bool:
     return torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
 
 
+_PINNED_IDS = set()
+
+
 def _pin(*objs) -> None:
-    _PINNED.extend(objs)
+    for o in objs:
+        if id(o) not in _PINNED_IDS:          # (pinned objects are never released, so ids stay unique)
+            _PINNED_IDS.add(id(o))
+            _PINNED.append(o)
 
 
 def _ws_key(device):
