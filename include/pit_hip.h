@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define PIT_ABI_VERSION 7
+#define PIT_ABI_VERSION 8
 #define PIT_DSCALE_SLOTS 1024 /* fp64 accumulators per head in pit_posatt_bwd's workspace */
 
 /* distance metric (dist2att variants) */
@@ -102,7 +102,12 @@ int pit_neighbors_fwd(const float* mesh_out, const float* mesh_in, int mesh_batc
  *   rowstat  (mesh_batch, n_head, n_out, 4) = {T, S_min, 1/rowsum, sum_j P*m} saved for
  *            the backward; scale_out (n_head) receives the c that was used.
  *   nbr_idx/nbr_cnt/nbr_cap: candidate lists from pit_neighbors_fwd (masked layers); NULL = the
- *            dense MFMA kernel.  With lists the layer costs O(n_out * k * columns). */
+ *            dense MFMA kernel.  With lists the layer costs O(n_out * k * columns).
+ *   coord_dims: > 0 fuses the coordinate concat of the task forwards (train_darcy.py:51-55:
+ *            func_in = cat((tile(mesh_in), func_in), -1)): value channels [0, coord_dims) are the key
+ *            coordinates, read from mesh_in; `values` then holds the other dim - coord_dims channels (and
+ *            d_values of pit_posatt_bwd has that many).  Candidate-list kernels only
+ *            (PIT_ERR_UNSUPPORTED otherwise: the caller materialises the concat). */
 int pit_posatt_fwd(const float* mesh_out, const float* mesh_in, int mesh_batch, int n_out, int n_in,
                    int space_dim, int metric, float period,
                    const float* values, int batch, int dim, long ld_values, long values_bstride,
@@ -110,7 +115,7 @@ int pit_posatt_fwd(const float* mesh_out, const float* mesh_in, int mesh_batch, 
                    const float* stats, float rank_w, int masked, int self_attn,
                    float* out, long ld_out, long out_bstride, int out_col0, int copy_inputs,
                    float* rowstat, float* scale_out,
-                   const int* nbr_idx, const int* nbr_cnt, int nbr_cap, int math_mode, void* stream);
+                   const int* nbr_idx, const int* nbr_cnt, int nbr_cap, int coord_dims, int math_mode, void* stream);
 
 /* Backward of pit_posatt_fwd (closed form; the reference uses
  * autograd).  d_out has the layout of `out` (columns out_col0 + h*dim + d).
@@ -143,7 +148,7 @@ int pit_posatt_bwd(const float* mesh_out, const float* mesh_in, int mesh_batch, 
                    float* d_values, long ld_dvalues, long dvalues_bstride, int add_residual,
                    float* d_head, int accumulate_head, double* workspace,
                    const int* nbr_idx, const int* nbr_cnt, int nbr_cap, int nbr_complete,
-                   const int* rev_ptr, const int* rev_row, int math_mode, void* stream);
+                   const int* rev_ptr, const int* rev_row, int coord_dims, int math_mode, void* stream);
 
 /* Finishing step of n_layers (<= 32) pit_posatt_bwd calls issued with PIT_HEAD_DEFER, in ONE
  * launch: per layer l drains workspaces[l] (n_heads[l]*PIT_DSCALE_SLOTS doubles, left zero), applies

@@ -31,14 +31,14 @@ SIGNATURES = {
                        _P, _I, _I,
                        _P, _F, _I, _I,
                        _P, _L, _L, _I, _I,
-                       _P, _P, _P, _P, _I, _I, _P],
+                       _P, _P, _P, _P, _I, _I, _I, _P],
     "pit_posatt_bwd": [_P, _P, _I, _I, _I, _I, _I, _F,
                        _P, _I, _I, _L, _L,
                        _P, _I, _I, _P,
                        _P, _I,
                        _P, _L, _L, _I,
                        _P, _L, _L, _I,
-                       _P, _I, _P, _P, _P, _I, _I, _P, _P, _I, _P],
+                       _P, _I, _P, _P, _P, _I, _I, _P, _P, _I, _I, _P],
     "pit_posatt_dhead_finish": [_I, _P, _P, _P, _P, _P, _P, _P],
     "pit_mlp_fwd": [_P, _L, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _L, _I, _P],
     "pit_mlp_bwd": [_P, _L, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _L,

@@ -44,6 +44,7 @@ struct AttArgs {
     unsigned values_bytes, dout_bytes;    // extents for the raw-buffer descriptors
     unsigned dim_magic;                   // floor(2^32 / dim): column -> (sample, channel) without an integer division
     int no_fast_loads;                    // PIT_NO_FAST_LOADS=1: checked loads everywhere (tests the >= 2 GiB path)
+    int coord_dims;                       // > 0: value channels [0, coord_dims) are the key coordinates themselves (sparse kernels)
 };
 
 // Folded column index -> (sample, channel).  For batch-free meshes the batch is folded into the
@@ -1502,8 +1503,12 @@ __device__ __forceinline__ void sparse_rows_body(const AttArgs& a, const SparseA
             T[h] = rs4.x; smin[h] = rs4.y; invl[h] = rs4.z; mbar[h] = rs4.w;
         }
     }
-    unsigned uoff[CR];
-    bool cvalid[CR];
+    // coordinate channels (coord_dims > 0: the torch.cat((mesh_in, func_in), -1) of the task forwards, e.g.
+    // train_darcy.py:51-55, is never materialised): channel cd < coord_dims of a value row IS coordinate cd of that
+    // key, read from mesh_in; the remaining channels come from `values`, which then holds dim - coord_dims channels
+    const int kd = a.coord_dims;
+    unsigned uoff[CR], coff[CR];
+    bool cvalid[CR], ccoord[CR];
     int cb[CR], cd[CR];
 #pragma unroll
     for (int r = 0; r < CR; ++r) {
@@ -1511,7 +1516,9 @@ __device__ __forceinline__ void sparse_rows_body(const AttArgs& a, const SparseA
         cvalid[r] = col < a.ncols;
         const int cc = cvalid[r] ? col : 0;
         col_split(a, cc, mb, cb[r], cd[r]);
-        uoff[r] = (unsigned)(((long)cb[r] * a.values_bstride + cd[r]) * 4);
+        ccoord[r] = cd[r] < kd;
+        uoff[r] = (unsigned)(((long)cb[r] * a.values_bstride + (cd[r] - kd)) * 4);
+        coff[r] = (unsigned)(((long)mb * a.n_in * a.sdim + cd[r]) * 4);
     }
     float acc[NH][CR];
     float rsum[NH], qsum[NH];
@@ -1566,7 +1573,14 @@ __device__ __forceinline__ void sparse_rows_body(const AttArgs& a, const SparseA
             for (int g = 0; g < G; ++g)
 #pragma unroll
                 for (int r = 0; r < CR; ++r)
-                    v[g][r] = buf_load(rvals, (ji[g] >= 0 && cvalid[r]) ? uoff[r] + (unsigned)ji[g] * ld4 : a.values_bytes);
+                    v[g][r] = buf_load(rvals, (ji[g] >= 0 && cvalid[r] && !ccoord[r]) ? uoff[r] + (unsigned)ji[g] * ld4 : a.values_bytes);
+            if (kd) {                              // wave-uniform: the coordinate channels of these keys (an out-of-range load adds 0)
+#pragma unroll
+                for (int g = 0; g < G; ++g)
+#pragma unroll
+                    for (int r = 0; r < CR; ++r)
+                        v[g][r] += buf_load(rmi, (ji[g] >= 0 && cvalid[r] && ccoord[r]) ? coff[r] + (unsigned)ji[g] * (unsigned)a.sdim * 4u : mi_bytes);
+            }
 #pragma unroll
             for (int g = 0; g < G; ++g)
 #pragma unroll
@@ -1720,7 +1734,9 @@ __device__ __forceinline__ void sparse_cols_body(const AttArgs& a, const SparseA
     for (int r = 0; r < CR; ++r) {
         const unsigned roff = (unsigned)(((long)cb[r] * a.dout_bstride + cd[r]) * 4) + (unsigned)j * ldd4;
         const float res = buf_load(rdout, (a.add_residual && cvalid[r]) ? roff : a.dout_bytes);
-        if (cvalid[r]) a.d_values[(long)cb[r] * a.dvalues_bstride + (long)j * a.ld_dvalues + cd[r]] = acc[r] + res;
+        // (coordinate channels carry no gradient: the meshes are data; d_values holds the dim - coord_dims others)
+        if (cvalid[r] && cd[r] >= a.coord_dims)
+            a.d_values[(long)cb[r] * a.dvalues_bstride + (long)j * a.ld_dvalues + (cd[r] - a.coord_dims)] = acc[r] + res;
     }
 }
 
@@ -1770,8 +1786,9 @@ __device__ __forceinline__ void sparse_overflow_body(const AttArgs& a, const Spa
                 for (int col = lane; col < a.ncols; col += 64) {
                     int bb, dd;
                     col_split(a, col, mb, bb, dd);
+                    if (dd < a.coord_dims) continue;
                     const float g = a.d_out[(long)bb * a.dout_bstride + (long)n * a.ld_dout + a.out_col0 + (long)h * a.dim + dd];
-                    atomicAdd(a.d_values + (long)bb * a.dvalues_bstride + (long)jj * a.ld_dvalues + dd, pv * g);
+                    atomicAdd(a.d_values + (long)bb * a.dvalues_bstride + (long)jj * a.ld_dvalues + (dd - a.coord_dims), pv * g);
                 }
             }
         }
@@ -1872,8 +1889,10 @@ void launch_sparse_cols(const AttArgs& a, const SparseArgs& sp, bool complete, h
 
 int fill_common(AttArgs& a, const float* mesh_out, const float* mesh_in, int mesh_batch, int n_out, int n_in,
                 int space_dim, int metric, float period, const float* values, int batch, int dim,
-                long ld_values, long values_bstride, const float* head, int n_head, int head_is_scale) {
+                long ld_values, long values_bstride, const float* head, int n_head, int head_is_scale,
+                int coord_dims = 0) {
     if (!mesh_out || !mesh_in || !values || !head) return PIT_ERR_NULL;
+    if (coord_dims < 0 || coord_dims >= dim || coord_dims > space_dim) return PIT_ERR_SIZE;
     if (mesh_batch <= 0 || n_out <= 0 || n_in <= 0 || batch <= 0 || dim <= 0 || n_head <= 0) return PIT_ERR_SIZE;
     if (space_dim < 1 || space_dim > 3) return PIT_ERR_SIZE;
     if (metric < PIT_METRIC_EUCLID || metric > PIT_METRIC_PERIODIC2D) return PIT_ERR_METRIC;
@@ -1887,8 +1906,9 @@ int fill_common(AttArgs& a, const float* mesh_out, const float* mesh_in, int mes
     a.values = values; a.batch = batch; a.dim = dim; a.ld_values = ld_values; a.values_bstride = values_bstride;
     a.head = head; a.n_head = n_head; a.head_is_scale = head_is_scale;
     a.ncols = (mesh_batch == 1) ? batch * dim : dim;
+    a.coord_dims = coord_dims;
     const unsigned long long vb = ((unsigned long long)(batch - 1) * values_bstride +
-                                   (unsigned long long)(n_in - 1) * ld_values + dim) * 4ull;
+                                   (unsigned long long)(n_in - 1) * ld_values + (dim - coord_dims)) * 4ull;
     if (vb > PIT_MAX_BUFFER_BYTES) return PIT_ERR_UNSUPPORTED;
     a.values_bytes = (unsigned)vb;
     a.bf16 = (t_call_math == PIT_MATH_BF16);
@@ -1906,13 +1926,15 @@ extern "C" int pit_posatt_fwd(const float* mesh_out, const float* mesh_in, int m
                               const float* stats, float rank_w, int masked, int self_attn,
                               float* out, long ld_out, long out_bstride, int out_col0, int copy_inputs,
                               float* rowstat, float* scale_out,
-                              const int* nbr_idx, const int* nbr_cnt, int nbr_cap, int math_mode, void* stream) {
+                              const int* nbr_idx, const int* nbr_cnt, int nbr_cap, int coord_dims, int math_mode,
+                              void* stream) {
     PIT_ENTER_MATH(math_mode);
     AttArgs a;
     int rc = fill_common(a, mesh_out, mesh_in, mesh_batch, n_out, n_in, space_dim, metric, period, values, batch,
-                         dim, ld_values, values_bstride, head, n_head, head_is_scale);
+                         dim, ld_values, values_bstride, head, n_head, head_is_scale, coord_dims);
     if (rc) return rc;
     if (!out || !rowstat) return PIT_ERR_NULL;
+    if (coord_dims > 0 && (copy_inputs || !(nbr_idx && nbr_cnt && masked))) return PIT_ERR_UNSUPPORTED;   // candidate-list kernels only
     if (!stats && (masked || !self_attn)) return PIT_ERR_NULL;
     if (copy_inputs && n_out != n_in) return PIT_ERR_SIZE;
     a.stats = stats; a.rank_w = rank_w; a.masked = masked;
@@ -1942,12 +1964,14 @@ extern "C" int pit_posatt_bwd(const float* mesh_out, const float* mesh_in, int m
                               float* d_values, long ld_dvalues, long dvalues_bstride, int add_residual,
                               float* d_head, int accumulate_head, double* workspace,
                               const int* nbr_idx, const int* nbr_cnt, int nbr_cap, int nbr_complete,
-                              const int* rev_ptr, const int* rev_row, int math_mode, void* stream) {
+                              const int* rev_ptr, const int* rev_row, int coord_dims, int math_mode, void* stream) {
     PIT_ENTER_MATH(math_mode);
     AttArgs a;
     int rc = fill_common(a, mesh_out, mesh_in, mesh_batch, n_out, n_in, space_dim, metric, period, values, batch,
-                         dim, ld_values, values_bstride, head, n_head, head_is_scale);
+                         dim, ld_values, values_bstride, head, n_head, head_is_scale, coord_dims);
     if (rc) return rc;
+    if (coord_dims > 0 && (add_residual || !(nbr_idx && nbr_cnt && masked) || (d_values && !(rev_ptr && rev_row))))
+        return PIT_ERR_UNSUPPORTED;                             // candidate-list kernels only
     if (!rowstat || !d_out || !workspace) return PIT_ERR_NULL;
     if (add_residual && n_out != n_in) return PIT_ERR_SIZE;
     hipStream_t s = (hipStream_t)stream;

@@ -338,14 +338,16 @@ class _PosAtt(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, values, head, plan: MeshPlan, n_head: int, concat: bool, head_is_scale: bool,
-                head_param=None, out_slot=None):
+                head_param=None, out_slot=None, coord_dims: int = 0):
         _need_gpu(values, head)
         ctx.math = _math_code()
+        ctx.coord_dims = int(coord_dims)
         # (the concat buffer arrives in a one-element list, not as a tensor argument: a tensor that is both an
         # input and the returned output would be re-materialised by autograd with a full copy)
         out_buf = out_slot[0].detach() if out_slot else None
         values = _row_view(values)
         b, j, d = values.shape
+        d += int(coord_dims)                      # coordinate channels come from mesh_in inside the kernel (pit_hip.h)
         if j != plan.n_in:
             raise RuntimeError(f"inputs have {j} points but mesh_in has {plan.n_in}")
         if plan.mesh_batch not in (1, b):
@@ -371,7 +373,7 @@ class _PosAtt(torch.autograd.Function):
             _lib.ptr(plan.stats), plan.rank_w, 1 if plan.masked else 0, 1 if plan.self_attn else 0,
             out.data_ptr(), out.stride(1), out.stride(0), d if concat else 0, copy_inputs,
             rowstat.data_ptr(), scale.data_ptr(),
-            _lib.ptr(plan.nbr_idx), _lib.ptr(plan.nbr_cnt), plan.nbr_cap, ctx.math, _lib.stream_ptr())
+            _lib.ptr(plan.nbr_idx), _lib.ptr(plan.nbr_cnt), plan.nbr_cap, ctx.coord_dims, ctx.math, _lib.stream_ptr())
         _lib.check(rc, "pit_posatt_fwd")
         ctx.plan, ctx.n_head, ctx.concat, ctx.head_is_scale = plan, n_head, concat, head_is_scale
         ctx.head_param = head_param
@@ -382,10 +384,11 @@ class _PosAtt(torch.autograd.Function):
     def backward(ctx, d_out):
         values, head, rowstat, scale = ctx.saved_tensors
         plan, n_head, concat = ctx.plan, ctx.n_head, ctx.concat
-        b, j, d = values.shape
+        b, j, dv = values.shape
+        d = dv + ctx.coord_dims
         d_out = _row_view(d_out)
         need_v, need_h = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
-        d_values = torch.empty((b, j, d), device=values.device, dtype=torch.float32) if need_v else None
+        d_values = torch.empty((b, j, dv), device=values.device, dtype=torch.float32) if need_v else None
         slot = _grad_slot(ctx.head_param) if need_h else None
         if slot is not None:
             d_head, acc_head = slot, 1                  # accumulate into lmda.grad in place
@@ -410,7 +413,7 @@ class _PosAtt(torch.autograd.Function):
                 1 if concat else 0,
                 _lib.ptr(dh), acc_head, work.data_ptr(),
                 _lib.ptr(plan.nbr_idx), _lib.ptr(plan.nbr_cnt), plan.nbr_cap, plan.lists_complete(),
-                _lib.ptr(plan.rev_ptr), _lib.ptr(plan.rev_row), ctx.math, stream_ptr)
+                _lib.ptr(plan.rev_ptr), _lib.ptr(plan.rev_row), ctx.coord_dims, ctx.math, stream_ptr)
             _lib.check(rc, "pit_posatt_bwd")
 
         if OVERLAP_BACKWARD and slot is not None:
@@ -422,7 +425,7 @@ class _PosAtt(torch.autograd.Function):
             launch(d_values, d_head, _lib.stream_ptr())
         if defer:
             _defer_head_finish(work, d_head, head, scale, n_head, 1 | (4 if ctx.head_is_scale else 0))
-        return d_values, (None if slot is not None else d_head), None, None, None, None, None, None
+        return d_values, (None if slot is not None else d_head), None, None, None, None, None, None, None
 
 
 # Where the head scale c = tan(0.25*pi*(1-1e-7)*(1+sin(lmda))) (pit.py:48) is evaluated.
@@ -505,20 +508,40 @@ def _concat_buffer_of(values: torch.Tensor, n_out: int, n_head: int):
     return buf if ok else None
 
 
+def tag_coords(func: torch.Tensor, mesh_in: torch.Tensor) -> torch.Tensor:
+    """``func`` (b, J, C) as the non-coordinate channels of the encoder input ``cat((tile(mesh_in), func), -1)``
+    that the fixed-mesh task forwards build (train_darcy.py:51-55): returns an alias of ``func`` carrying the mesh,
+    so that a cross-attention layer on candidate lists reads the coordinate channels from ``mesh_in`` itself instead
+    of a materialised concat (``materialize_coords`` builds the concat for every other consumer)."""
+    out = func.view_as(func)                     # a fresh tensor object: never tag the caller's own tensor
+    out._pit_coords = mesh_in
+    return out
+
+
+def materialize_coords(func: torch.Tensor) -> torch.Tensor:
+    """The explicit concat for a tensor tagged by ``tag_coords`` (identity for any other tensor)."""
+    mesh = getattr(func, "_pit_coords", None)
+    if mesh is None:
+        return func
+    return torch.cat((mesh.reshape(1, -1, mesh.shape[-1]).expand(func.shape[0], -1, -1), func), -1)
+
+
 @torch.compiler.disable
 def posatt_apply(values: torch.Tensor, lmda: torch.Tensor, plan: MeshPlan, n_head: int, concat: bool,
-                 head_is_scale: bool = False) -> torch.Tensor:
+                 head_is_scale: bool = False, coord_dims: int = 0) -> torch.Tensor:
     """out[b,n,h*D+d] = sum_j softmax_j(-c_h m[n,j] | quantile mask)[n,j] * values[b,j,d]
     (pit.py:46-57); with ``concat`` the inputs are prepended (pit.py:44).  ``lmda`` is the
     (H,1,1) parameter, or the scale c itself when ``head_is_scale`` (tests inject it).
+    ``coord_dims`` > 0: the first coord_dims value channels are the key coordinates (plan.mesh_in), ``values`` holds
+    the others (candidate-list layers only, see pit_hip.h).
     Opaque to torch.compile (dynamo runs it eagerly: raw pointers cross a ctypes boundary)."""
     out_buf = _concat_buffer_of(values, plan.n_out, n_head) if concat else None
+    slot = [out_buf] if out_buf is not None else None
     if not head_is_scale and get_head_scale_route() == "host":
         c = _HostHeadScale.apply(lmda.reshape(-1))
-        return _PosAtt.apply(values, c, plan, n_head, concat, True, None, [out_buf] if out_buf is not None else None)
+        return _PosAtt.apply(values, c, plan, n_head, concat, True, None, slot, coord_dims)
     param = lmda if isinstance(lmda, torch.nn.Parameter) else None
-    return _PosAtt.apply(values, lmda.reshape(-1), plan, n_head, concat, head_is_scale, param,
-                         [out_buf] if out_buf is not None else None)
+    return _PosAtt.apply(values, lmda.reshape(-1), plan, n_head, concat, head_is_scale, param, slot, coord_dims)
 
 
 class _Mlp(torch.autograd.Function):

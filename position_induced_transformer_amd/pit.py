@@ -132,6 +132,14 @@ class posatt(nn.Module):
 
     def _cross(self, mesh_out, mesh_in, inputs):
         plan = self._plan(mesh_out, mesh_in, False)
+        coords = getattr(inputs, "_pit_coords", None)
+        if coords is not None:                   # encoder input tagged by ops.tag_coords: cat((mesh_in, func), -1) not yet built
+            kd = mesh_in.shape[-1]
+            fused = (plan.nbr_idx is not None and plan.mesh_batch == 1 and coords.shape == mesh_in.shape
+                     and coords.data_ptr() == mesh_in.data_ptr())
+            if fused:                            # the candidate-list kernels read the coordinate channels from mesh_in
+                return ops.posatt_apply(inputs, self.lmda, plan, self.n_head, concat=False, coord_dims=kd)
+            inputs = ops.materialize_coords(inputs)
         return ops.posatt_apply(inputs, self.lmda, plan, self.n_head, concat=False)
 
     # -- dense helpers kept for API compatibility with the reference (not used by forward)

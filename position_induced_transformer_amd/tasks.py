@@ -44,7 +44,12 @@ class _FixedMeshForward:
         mesh_in = mesh_in.reshape(-1, self.space_dim)
         mesh_out = mesh_out.reshape(-1, self.space_dim)
         func = func_in.reshape(batch, -1, self.in_dim)
-        feats = torch.cat((mesh_in.unsqueeze(0).expand(batch, -1, -1), func), -1)
+        if isinstance(self.down, P.posatt) and func.is_cuda:
+            # the coordinate concat of train_darcy.py:51-55 is deferred: the encoder's candidate-list kernels read the
+            # coordinate channels from mesh_in (ops.tag_coords); any other consumer materialises the concat
+            feats = ops.tag_coords(func, mesh_in)
+        else:
+            feats = torch.cat((mesh_in.unsqueeze(0).expand(batch, -1, -1), func), -1)
         ltt = self.encoder(mesh_in, feats, self.mesh_ltt)
         ltt = self._between(ltt)
         ltt = self.processor(ltt, self.mesh_ltt)

@@ -410,7 +410,7 @@ def test_raw_ctypes_binding_as_in_integration_md():
     P, I, F, LG = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_long
     L.pit_select_fwd.argtypes = [P, P, I, I, I, I, I, F, I, I, P, P]
     L.pit_posatt_fwd.argtypes = [P, P, I, I, I, I, I, F, P, I, I, LG, LG, P, I, I, P, F, I, I,
-                                 P, LG, LG, I, I, P, P, P, P, I, I, P]
+                                 P, LG, LG, I, I, P, P, P, P, I, I, I, P]
     fx, cs = load_case("F1_darcy_enc")
     mesh_out, mesh_in = dev(cs["mesh_out"]).contiguous(), dev(cs["mesh_in"]).contiguous()   # the ABI takes dense rows
     inputs, lmda = dev(cs["values"]).contiguous(), dev(cs["lmda"]).contiguous()
@@ -430,7 +430,7 @@ def test_raw_ctypes_binding_as_in_integration_md():
                           inputs.data_ptr(), b, d, inputs.stride(1), inputs.stride(0),
                           lmda.data_ptr(), h, 0, stats.data_ptr(), w, 1, 0,
                           out.data_ptr(), out.stride(1), out.stride(0), 0, 0,
-                          rowstat.data_ptr(), scale.data_ptr(), None, None, 0, 0, stream)      # PIT_MATH_FP32
+                          rowstat.data_ptr(), scale.data_ptr(), None, None, 0, 0, 0, stream)   # coord_dims 0, PIT_MATH_FP32
     assert rc == 0
     torch.cuda.synchronize()
     ulp = np.abs(scale.cpu().numpy().view(np.int32).astype(np.int64) - cs["c"].reshape(-1).view(np.int32).astype(np.int64)).max()

@@ -638,3 +638,55 @@ def test_mlp_output_in_concat_buffer_equals_the_copy_path_and_is_consumed_once()
     b = att2(mesh, y)
     assert a.data_ptr() == y.data_ptr() and b.data_ptr() != y.data_ptr()
     assert torch.equal(a[..., :64], y) and torch.equal(b[..., :64], y)
+
+
+# --------------------------------------------------------------------------- coordinate concat fused into the encoder kernel
+@pytest.mark.parametrize("task", ["darcy", "burgers", "sod"])
+def test_fused_coordinate_channels_equal_the_materialised_concat(task):
+    """The task forwards' `func_in = cat((tile(mesh_in), func_in), -1)` (train_darcy.py:51-55, train_burgers.py:44,
+    train_sod.py:49) is not materialised: the encoder's candidate-list kernels take the coordinate channels from
+    mesh_in (pit_posatt_fwd/bwd coord_dims).  Same output, parameter gradients and d(func_in) as the explicit concat
+    through the same modules."""
+    from position_induced_transformer_amd import ops, tasks, utils
+    model, sample, meta = tasks.make_task(task, seed=71)
+    mesh_in, func_in, mesh_out, target = sample(3)
+    loss_fn = utils.RelLpNorm(meta["out_dim"], meta["p"])
+
+    def run(fused):
+        model.zero_grad()
+        x = func_in.clone().requires_grad_(True)
+        if fused:
+            out = model(mesh_in, x, mesh_out)
+        else:
+            mi = mesh_in.reshape(-1, model.space_dim)
+            func = x.reshape(3, -1, model.in_dim)
+            feats = torch.cat((mi.unsqueeze(0).expand(3, -1, -1), func), -1)          # the reference's own line
+            ltt = model.encoder(mi, feats, model.mesh_ltt)
+            ltt = model.processor(ltt, model.mesh_ltt)
+            out = model.decoder(model.mesh_ltt, ltt, mesh_out.reshape(-1, model.space_dim)).reshape(target.shape)
+        loss = loss_fn(target, out)
+        loss.backward()
+        return out.detach().clone(), x.grad.clone(), {k: p.grad.clone() for k, p in model.named_parameters()}
+
+    launched = []
+    orig = ops.posatt_apply
+
+    def spy(*a, **kw):
+        launched.append(kw.get("coord_dims", 0))
+        return orig(*a, **kw)
+    ops.posatt_apply = spy
+    try:
+        got = run(True)
+    finally:
+        ops.posatt_apply = orig
+    assert model.space_dim in launched, "the fused path was not taken"
+    ref = run(False)
+    assert gio.rel_l2(ref[0].cpu().numpy(), got[0].cpu().numpy()) <= 1e-6
+    assert gio.rel_l2(ref[1].cpu().numpy(), got[1].cpu().numpy()) <= 1e-5
+    he, hg = [], []
+    for k in ref[2]:
+        if k.endswith("lmda"):
+            he.append(ref[2][k].cpu().numpy().reshape(-1)); hg.append(got[2][k].cpu().numpy().reshape(-1))
+        else:
+            assert gio.rel_l2(ref[2][k].cpu().numpy(), got[2][k].cpu().numpy()) <= 1e-5, k
+    assert gio.rel_l2(np.concatenate(he), np.concatenate(hg)) <= 1e-4

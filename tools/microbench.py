@@ -82,14 +82,14 @@ def main():
     st = _lib.stream_ptr
     L.pit_posatt_fwd(ltt.data_ptr(), ltt.data_ptr(), 1, 256, 256, 2, 0, 0.0, u.data_ptr(), b, 64, 64, 256 * 64,
                      lm.data_ptr(), 2, 0, _lib.ptr(plan.stats), plan.rank_w, 0, 1, out.data_ptr(), 192, 256 * 192, 64, 1,
-                     rowstat.data_ptr(), scale.data_ptr(), None, None, 0, 0, st())
+                     rowstat.data_ptr(), scale.data_ptr(), None, None, 0, 0, 0, st())
     d_out = torch.randn(b, 256, 192, device="cuda"); d_u = torch.empty_like(u); d_lm = torch.zeros(2, device="cuda")
     work = ops._dscale_workspace(u.device, 2)
     def bwd(dv, dh):
         rc = L.pit_posatt_bwd(ltt.data_ptr(), ltt.data_ptr(), 1, 256, 256, 2, 0, 0.0, u.data_ptr(), b, 64, 64, 256 * 64,
                               lm.data_ptr(), 2, 0, scale.data_ptr(), rowstat.data_ptr(), 0,
                               d_out.data_ptr(), 192, 256 * 192, 64, _lib.ptr(dv), 64, 256 * 64, 1,
-                              _lib.ptr(dh), 0, work.data_ptr(), None, None, 0, 0, None, None, 0, st())
+                              _lib.ptr(dh), 0, work.data_ptr(), None, None, 0, 0, None, None, 0, 0, st())
         assert rc == 0, rc
     res["proc_bwd_dscale_only(+finish)"] = graph_time(lambda: bwd(None, d_lm))
     res["proc_bwd_dvalues_only"] = graph_time(lambda: bwd(d_u, None))
