@@ -690,3 +690,34 @@ def test_fused_coordinate_channels_equal_the_materialised_concat(task):
         else:
             assert gio.rel_l2(ref[2][k].cpu().numpy(), got[2][k].cpu().numpy()) <= 1e-5, k
     assert gio.rel_l2(np.concatenate(he), np.concatenate(hg)) <= 1e-4
+
+
+# --------------------------------------------------------------------------- self-cleaning state after many replays
+@pytest.mark.parametrize("task,batch", [("darcy", 8), ("naca", 2)])
+def test_replays_leave_every_self_cleaning_buffer_clean(task, batch):
+    """The invariants of tools/soak.py after 400 replays of the captured training step (fwd + loss + bwd + fused
+    Adam): the Adam step counter counts exactly, its arrival ticket is back at zero, the gradients it consumed are
+    cleared, the fp64 d(scale) accumulators and the loss workspace (partial sums, per-pair and global tickets) are
+    zero, parameters and loss finite."""
+    from position_induced_transformer_amd import ops, tasks
+    from position_induced_transformer_amd.ddp import FlatAdam, FlatGradients
+    from position_induced_transformer_amd.engine import TrainStep
+    model, sample, meta = tasks.make_task(task, seed=3)
+    flat = FlatGradients(model.parameters(), flatten_params=True)
+    opt = FlatAdam(flat, lr=1e-4, cosine_t_max=500, zero_grads=True)
+    step = TrainStep(model, sample(batch), meta["out_dim"], meta["p"], optimizer=opt, flat=flat)
+    step.capture()
+    torch.cuda.synchronize()
+    base = int(opt.step_count)
+    for _ in range(400):
+        step.replay()
+    torch.cuda.synchronize()
+    assert int(opt.step_count) == base + 400
+    assert int(opt.scalars[3].view(torch.int32)) == 0, "Adam arrival ticket not reset"
+    assert float(flat.flat.abs().max()) == 0.0, "gradients not cleared by the fused Adam"
+    assert any(True for _ in ops._LAYER_WS), "no deferred d(lmda) accumulators were used"
+    for ws in ops._LAYER_WS.values():
+        assert float(ws.abs().max()) == 0.0, "d(scale) accumulators not drained"
+    for ws in ops._LOSS_WS.values():
+        assert float(ws.abs().max()) == 0.0, "loss workspace not reset"
+    assert torch.isfinite(flat.flat_params).all() and torch.isfinite(step.loss)
