@@ -431,6 +431,161 @@ bool try_launch_mlp_fwd16(const float* x, long ldx, int rows, int n0, int n1, in
 }
 
 // ------------------------------------------------------------------------------------
+// Small-regime fused MLP backward, data path: dZ2 = dY * gelu'(Z2) (or dY), dZ1 = (dZ2 W2) * gelu'(Z1),
+// dX = dZ1 W1 in ONE launch on 16-row slabs (the mirror of mlp_fwd16_kernel): the three steps of a slab
+// only depend on that slab, dZ2 / dZ1 stay in LDS between them, and every weight fragment is requested at
+// kernel entry.  dZ2 (when the layer ends in a gelu) and dZ1 are also written to scratch for the
+// weight-gradient reductions, which remain a separate (row-reducing) launch.
+struct FusedMlpBwdArgs {
+    int rows, n0, n1, n2, out_gelu;
+    const float *w1, *w2, *z1, *z2, *d_y; long ld_dy;
+    float *d_x; long ld_dx;
+    float *dz1, *dz2;                    // scratch: (rows, n1) and (rows, n2)
+};
+
+template <int N1, int TPW>                // TPW = dX column tiles (16 wide) per wave
+__global__ __launch_bounds__(N1 * 4) void mlp_bwd16_kernel(FusedMlpBwdArgs g) {
+    constexpr int NW = N1 / 16;
+    constexpr int P1 = N1 + 4;                          // LDS pitch of the dZ1 tile
+    constexpr int S1 = N1 / 16;                         // 16-k steps of the dX contraction (K = n1)
+    __shared__ __attribute__((aligned(16))) float ds1[16 * P1];
+    __shared__ __attribute__((aligned(16))) float ds2[16 * P1];       // dZ2 tile, n2 <= n1 columns
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, kq = lane >> 4;
+    const int m0 = blockIdx.x * 16;
+    const int n0 = g.n0, n2 = g.n2;
+    const bool thin = n2 <= 4;
+    // ---- everything that depends on nothing is requested first: W1 fragments of this wave's dX tiles, the
+    // gelu' argument of this wave's dZ1 tile, and (full tiles) the W2 fragments of the dZ1 contraction
+    float w1v[TPW][S1][4];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+        const int col = (wave + t * NW) * 16 + l15;     // dX column
+#pragma unroll
+        for (int s = 0; s < S1; ++s)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int k = 16 * s + 4 * kq + e;      // B(k, n) = w1[k][n]: the 16 lanes of a k read 64 consecutive bytes
+                w1v[t][s][e] = (col < n0) ? g.w1[(long)k * n0 + col] : 0.0f;
+            }
+    }
+    const int c1 = wave * 16 + l15;                     // this lane's dZ1 column
+    float z1v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = m0 + 4 * kq + i;
+        z1v[i] = (r < g.rows) ? g.z1[(long)r * N1 + c1] : 0.0f;
+    }
+    constexpr int S2MAX = N1 / 16;                      // n2 <= n1
+    float w2v[S2MAX][4];
+#pragma unroll
+    for (int s = 0; s < S2MAX; ++s)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int k = 16 * s + 4 * kq + e;          // B(k, n) = w2[k][n]
+            w2v[s][e] = (!thin && k < n2) ? g.w2[(long)k * N1 + c1] : 0.0f;
+        }
+    // ---- phase A: dZ2 tile (16 x n2) -> LDS (+ scratch when it differs from dY)
+    for (int idx = tid; idx < 16 * n2; idx += NW * 64) {
+        const int r = idx / n2, c = idx - r * n2;
+        const int row = m0 + r;
+        float v = 0.0f;
+        if (row < g.rows) {
+            v = g.d_y[(long)row * g.ld_dy + c];
+            if (g.out_gelu) {
+                v *= gelu_erf_grad(g.z2[(long)row * n2 + c]);
+                g.dz2[(long)row * n2 + c] = v;
+            }
+        }
+        ds2[r * P1 + c] = v;
+    }
+    __syncthreads();
+    // ---- phase B: dZ1 tile of this wave = (dZ2 W2) * gelu'(Z1)
+    f32x4_t a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+    if (thin) {                                         // out_dim <= 4: an outer product per output, no MFMA tile
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float acc = 0.0f;
+            for (int o = 0; o < n2; ++o) acc += ds2[(4 * kq + i) * P1 + o] * g.w2[(long)o * N1 + c1];
+            a0[i] = acc;
+        }
+    } else {
+        const int steps = n2 / 16;
+#pragma unroll
+        for (int s = 0; s < S2MAX; ++s) {
+            if (s < steps) {
+                const float4 a = *reinterpret_cast<const float4*>(ds2 + l15 * P1 + 16 * s + 4 * kq);
+                a0 = mfma_16x16x4(a.x, w2v[s][0], a0);
+                a1 = mfma_16x16x4(a.y, w2v[s][1], a1);
+                a0 = mfma_16x16x4(a.z, w2v[s][2], a0);
+                a1 = mfma_16x16x4(a.w, w2v[s][3], a1);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = 4 * kq + i;
+        const float v = (a0[i] + a1[i]) * gelu_erf_grad(z1v[i]);
+        ds1[r * P1 + c1] = v;
+        if (m0 + r < g.rows) g.dz1[(long)(m0 + r) * N1 + c1] = v;
+    }
+    __syncthreads();
+    if (!g.d_x) return;
+    // ---- phase C: dX tiles of this wave = dZ1 W1
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+        const int tile = wave + t * NW;
+        if (tile * 16 >= n0) break;
+        f32x4_t o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < S1; ++s) {
+            const float4 a = *reinterpret_cast<const float4*>(ds1 + l15 * P1 + 16 * s + 4 * kq);
+            o0 = mfma_16x16x4(a.x, w1v[t][s][0], o0);
+            o1 = mfma_16x16x4(a.y, w1v[t][s][1], o1);
+            o0 = mfma_16x16x4(a.z, w1v[t][s][2], o0);
+            o1 = mfma_16x16x4(a.w, w1v[t][s][3], o1);
+        }
+        const int col = tile * 16 + l15;
+        if (col < n0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = m0 + 4 * kq + i;
+                if (r < g.rows) g.d_x[(long)r * g.ld_dx + col] = o0[i] + o1[i];
+            }
+        }
+    }
+}
+
+// eligibility + launch of the fused data path; false = the separate dZ1 and dX launches
+bool try_launch_mlp_bwd16(int rows, int n0, int n1, int n2, const float* w1, const float* w2, const float* z1,
+                          const float* z2, int out_gelu, const float* d_y, long ld_dy, float* d_x, long ld_dx,
+                          float* dz1, float* dz2, hipStream_t s) {
+    static const bool off = getenv("PIT_NO_FUSED_MLP_BWD") != nullptr;
+    if (off) return false;
+    if (n1 != 32 && n1 != 64 && n1 != 128) return false;
+    if (n2 > 4 && (n2 % 16 != 0 || n2 > n1)) return false;
+    if (rows < 256 || (long)rows * n1 * (n0 + n2) > (1L << 27)) return false;
+    const int nw = n1 / 16;
+    const int tiles = (n0 + 15) / 16;
+    const int tpw = (tiles + nw - 1) / nw;
+    if (tpw > 4) return false;
+    FusedMlpBwdArgs g;
+    g.rows = rows; g.n0 = n0; g.n1 = n1; g.n2 = n2; g.out_gelu = out_gelu;
+    g.w1 = w1; g.w2 = w2; g.z1 = z1; g.z2 = z2; g.d_y = d_y; g.ld_dy = ld_dy;
+    g.d_x = d_x; g.ld_dx = ld_dx; g.dz1 = dz1; g.dz2 = dz2;
+    const dim3 grid((rows + 15) / 16);
+#define PIT_B16(N1_) do {                                                                                     \
+        if (tpw <= 1) hipLaunchKernelGGL((mlp_bwd16_kernel<N1_, 1>), grid, dim3(N1_ * 4), 0, s, g);           \
+        else if (tpw == 2) hipLaunchKernelGGL((mlp_bwd16_kernel<N1_, 2>), grid, dim3(N1_ * 4), 0, s, g);      \
+        else if (tpw == 3) hipLaunchKernelGGL((mlp_bwd16_kernel<N1_, 3>), grid, dim3(N1_ * 4), 0, s, g);      \
+        else hipLaunchKernelGGL((mlp_bwd16_kernel<N1_, 4>), grid, dim3(N1_ * 4), 0, s, g);                    \
+    } while (0)
+    if (n1 == 32) PIT_B16(32); else if (n1 == 64) PIT_B16(64); else PIT_B16(128);
+#undef PIT_B16
+    return true;
+}
+
+// ------------------------------------------------------------------------------------
 // Large-regime GEMM: operands staged through LDS.
 //
 // The register-direct kernel above has every lane fetch its own fragment: a wave-level 16-B load
@@ -1318,12 +1473,19 @@ extern "C" int pit_mlp_bwd(const float* x, long ldx, int rows, int n0, int n1, i
     float* dz2buf = scratch + (long)rows * n1;
     if (!accumulate)
         if (int rc = zero_param_grads(d_w1, d_b1, d_w2, d_b2, n0, n1, n2, s)) return rc;
-    if (int rc = launch_dz1(rows, n1, n2, w2, z1, z2, out_gelu, d_y, ld_dy, dz1, dz2buf, s)) return rc;
-    PIT_CHECK_LAUNCH();
     const float* dz2 = out_gelu ? dz2buf : d_y;
     const long ld_dz2 = out_gelu ? n2 : ld_dy;
     const GemmArgs g2 = make_dw2(dz2, ld_dz2, h, rows, n1, n2, d_w2, d_b2);
     const GemmArgs g1 = make_dw1(dz1, x, ldx, rows, n0, n1, d_w1, d_b1);
+    if ((!out_gelu || ld_dy == n2) &&
+        try_launch_mlp_bwd16(rows, n0, n1, n2, w1, w2, z1, z2, out_gelu, d_y, ld_dy, d_x, ld_dx, dz1, dz2buf, s)) {
+        PIT_CHECK_LAUNCH();                              // dZ2, dZ1 and dX of every 16-row slab in one launch ...
+        if (int rc = launch_gemm_pair_atomic(g2, g1, s)) return rc;      // ... then both weight-gradient reductions
+        PIT_CHECK_LAUNCH();
+        return 0;
+    }
+    if (int rc = launch_dz1(rows, n1, n2, w2, z1, z2, out_gelu, d_y, ld_dy, dz1, dz2buf, s)) return rc;
+    PIT_CHECK_LAUNCH();
     // everything after dZ1 is mutually independent: one launch when small
     if (d_x) { if (int rc = launch_gemm_bwd_tail(make_dx(dz1, w1, rows, n0, n1, d_x, ld_dx), g2, g1, s)) return rc; }
     else if (int rc = launch_gemm_pair_atomic(g2, g1, s)) return rc;
