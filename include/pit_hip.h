@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define PIT_ABI_VERSION 8
+#define PIT_ABI_VERSION 9
 #define PIT_DSCALE_SLOTS 1024 /* fp64 accumulators per head in pit_posatt_bwd's workspace */
 
 /* distance metric (dist2att variants) */
@@ -135,7 +135,17 @@ int pit_posatt_fwd(const float* mesh_out, const float* mesh_in, int mesh_batch, 
  *            everywhere, e.g. checked once for a cached fixed-mesh plan): the pass that adds the
  *            overflowed rows to d_values is not launched.  0 = unknown (always correct).
  * d_values and d_head are computed by independent kernels: a caller may issue two calls (one
- * with d_values == NULL, one with d_head == NULL) on different streams to overlap them. */
+ * with d_values == NULL, one with d_head == NULL) on different streams to overlap them.
+ *   rider    NULL, or the arguments of a pit_mlp_bwd_params call the caller has postponed (the weight-gradient
+ *            reductions of the MLP whose d_x is this call's d_out: pit.py:116-121 runs mlp -> attention, so the
+ *            backward runs them in this order and nothing downstream needs d_w*).  The call performs it: inside
+ *            the attention launch when both are small (latency-bound grids sharing the chip), otherwise as the
+ *            separate launches pit_mlp_bwd_params would have made.  Read during the call only. */
+typedef struct pit_mlp_params_job {          /* = the argument list of pit_mlp_bwd_params */
+    const float* x; long ldx; int rows, n0, n1, n2; const float* h; int out_gelu;
+    const float* d_y; long ld_dy;
+    float *d_w1, *d_b1, *d_w2, *d_b2; int accumulate; const float* scratch; int math_mode;
+} pit_mlp_params_job;
 #define PIT_HEAD_ACCUMULATE 1
 #define PIT_HEAD_DEFER      2
 #define PIT_HEAD_IS_SCALE   4   /* pit_posatt_dhead_finish only: d_head is w.r.t. c, no chain rule */
@@ -148,7 +158,8 @@ int pit_posatt_bwd(const float* mesh_out, const float* mesh_in, int mesh_batch, 
                    float* d_values, long ld_dvalues, long dvalues_bstride, int add_residual,
                    float* d_head, int accumulate_head, double* workspace,
                    const int* nbr_idx, const int* nbr_cnt, int nbr_cap, int nbr_complete,
-                   const int* rev_ptr, const int* rev_row, int coord_dims, int math_mode, void* stream);
+                   const int* rev_ptr, const int* rev_row, const pit_mlp_params_job* rider,
+                   int coord_dims, int math_mode, void* stream);
 
 /* Finishing step of n_layers (<= 32) pit_posatt_bwd calls issued with PIT_HEAD_DEFER, in ONE
  * launch: per layer l drains workspaces[l] (n_heads[l]*PIT_DSCALE_SLOTS doubles, left zero), applies
@@ -192,6 +203,10 @@ int pit_mlp_bwd_params(const float* x, long ldx, int rows, int n0, int n1, int n
                        int out_gelu, const float* d_y, long ld_dy,
                        float* d_w1, float* d_b1, float* d_w2, float* d_b2,
                        int accumulate, const float* scratch, int math_mode, void* stream);
+/* 1 if postponing pit_mlp_bwd_params of this shape and handing it to the next pit_posatt_bwd as `rider` costs
+ * nothing when the attention call cannot merge it (i.e. pit_mlp_bwd would have issued _data and _params as
+ * separate launches anyway), else 0 (pit_mlp_bwd merges d_x with the reductions: keep the single call). */
+int pit_mlp_bwd_params_deferrable(int rows, int n0, int n1, int n2, int out_gelu, long ld_dy);
 
 /* RelLpNorm (utils.py:80-98): loss = sum_b mean_c ||true - pred'||_p / ||true||_p with norms
  * over the point axis of (batch, npts, nch) contiguous tensors, pred' = pred*scale + shift when

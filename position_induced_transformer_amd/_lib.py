@@ -18,6 +18,13 @@ _I = ctypes.c_int
 _L = ctypes.c_long
 _F = ctypes.c_float
 
+class MlpParamsJob(ctypes.Structure):
+    """pit_mlp_params_job of include/pit_hip.h (the argument list of pit_mlp_bwd_params)."""
+    _fields_ = [("x", _P), ("ldx", _L), ("rows", _I), ("n0", _I), ("n1", _I), ("n2", _I), ("h", _P), ("out_gelu", _I),
+                ("d_y", _P), ("ld_dy", _L), ("d_w1", _P), ("d_b1", _P), ("d_w2", _P), ("d_b2", _P),
+                ("accumulate", _I), ("scratch", _P), ("math_mode", _I)]
+
+
 # name -> argtypes, mirrors include/pit_hip.h one to one
 SIGNATURES = {
     "pit_version": [],
@@ -38,13 +45,14 @@ SIGNATURES = {
                        _P, _I,
                        _P, _L, _L, _I,
                        _P, _L, _L, _I,
-                       _P, _I, _P, _P, _P, _I, _I, _P, _P, _I, _I, _P],
+                       _P, _I, _P, _P, _P, _I, _I, _P, _P, _P, _I, _I, _P],
     "pit_posatt_dhead_finish": [_I, _P, _P, _P, _P, _P, _P, _P],
     "pit_mlp_fwd": [_P, _L, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _L, _I, _P],
     "pit_mlp_bwd": [_P, _L, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _L,
                     _P, _L, _P, _P, _P, _P, _I, _P, _I, _P],
     "pit_mlp_bwd_data": [_I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _L, _P, _L, _P, _I, _P],
     "pit_mlp_bwd_params": [_P, _L, _I, _I, _I, _I, _P, _I, _P, _L, _P, _P, _P, _P, _I, _P, _I, _P],
+    "pit_mlp_bwd_params_deferrable": [_I, _I, _I, _I, _I, _L],
     "pit_rel_lp_loss_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P],
     "pit_rel_lp_loss_fwd_grad": [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _L, _P],
     "pit_rel_lp_loss_bwd": [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P],

@@ -1,0 +1,221 @@
+// Register-direct GEMM body (v_mfma_f32_32x32x2_f32, in-workgroup split-K, reduce-scatter epilogue) shared by the
+// MLP kernels (pit_mlp.hip) and by the attention-backward launch that carries an MLP's weight-gradient reductions
+// along (pit_posatt.hip: posatt_bwd_pair_dw_kernel).  See pit_mlp.hip for the design notes.
+#pragma once
+#include "pit_common.h"
+#include <type_traits>
+
+namespace pit_detail {
+
+struct GemmArgs {
+    const float* A; long a_rs, a_cs;     // A(m,k) = A[m*a_rs + k*a_cs]
+    const float* B; long b_rs, b_cs;     // B(k,n) = B[k*b_rs + n*b_cs]
+    int M, N, K;
+    unsigned a_bytes, b_bytes;           // extents for the raw-buffer descriptors
+    int a_vec, b_vec;                    // 16-B fragment loads legal (unit k stride, aligned rows)
+    int k_slab;                          // K range per blockIdx.z
+    const float* a_gz;                   // optional prologue: A(m,k) *= gelu'(a_gz[same index as A])
+    float* a_out; long a_out_rs, a_out_cs;  // optional: write the prologue result (blockIdx.x == 0 only)
+    const float* bias;                   // [N] or null
+    float* C; long ldc;
+    float* Z; long ldz;                  // optional pre-activation copy
+    const float* G; long ldg;            // optional: multiply result by gelu'(G[m,n])
+    int epi;                             // EPI_* epilogue flavour
+    int atomic;                          // 1: row-reducing GEMM, also split over blockIdx.z
+    int ones_col;                        // >= 0: B(k, ones_col) == 1, that output column goes to C2[m]
+    float* C2;
+    int bf16;                            // PIT_MATH_BF16: one v_mfma_f32_32x32x8_bf16 per 4 k instead of 4 fp32 MFMAs
+    int seq_epi;                         // experiments (PIT_GEMM_RD_SEQ_EPI): one accumulator register per epilogue trip
+};
+
+// both weight-gradient reductions of one MLP (dW2|db2 and dW1|db1), prepared for gemm_rd_body<1, EPI_ATOMIC>:
+// workgroups [0, n1) run g1 on a (gx1, gy1, .) grid, [n1, n1 + n2) run g2
+struct DwPair { GemmArgs g1, g2; int n1, n2, gx1, gy1, gx2, gy2; };
+
+// fills `out` and returns true when the job is small enough to ride along in another launch (pit_mlp.hip)
+bool plan_dw_pair(const pit_mlp_params_job& job, DwPair* out);
+
+}  // namespace pit_detail
+
+namespace {
+
+using pit_detail::GemmArgs;
+
+// 4 k-values of one operand for this lane: X(i, kk+e), e = 0..3, through a raw buffer
+// (invalid i / k -> offset out of range -> 0).  VEC: one 16-B load (k is the unit-stride axis
+// and rows are 16-B aligned); FULL: the 4 k are known to be in range.
+template <bool FULL>
+__device__ __forceinline__ void load_frag(__amdgpu_buffer_rsrc_t r, unsigned bytes, unsigned ibase, bool ivalid,
+                                          unsigned kstride4, bool vec, int kk, int kend, float (&v)[4]) {
+    if (FULL && vec) {
+        buf_load4(r, ivalid ? ibase + (unsigned)kk * 4u : bytes, v);
+        return;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const bool ok = ivalid && (FULL || kk + e < kend);
+        v[e] = buf_load(r, ok ? ibase + (unsigned)(kk + e) * kstride4 : bytes);
+    }
+}
+
+// epilogue flavours (compile-time, so the per-element code is branch-free)
+constexpr int EPI_STORE = 0;      // C = acc
+constexpr int EPI_BIAS = 1;       // C = acc + bias
+constexpr int EPI_BIAS_GELU = 2;  // Z = acc + bias; C = gelu(Z)
+constexpr int EPI_MUL_GELU_GRAD = 3;  // C = acc * gelu'(G)
+constexpr int EPI_ATOMIC = 4;     // C += acc (fp32 atomics), ones column -> C2
+
+template <int TN, int EPI>
+__device__ __forceinline__ void gemm_rd_body(const GemmArgs& g, int bx, int by, int bz) {
+    extern __shared__ __attribute__((aligned(16))) float red[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int m0 = by * 32, n0 = bx * 32 * TN;
+    const int kbeg = bz * g.k_slab;
+    const int kend = min(g.K, kbeg + g.k_slab);
+    // this wave's k range: multiples of 8
+    const int span = kend - kbeg;
+    const int per_wave = ((span + nwaves * 8 - 1) / (nwaves * 8)) * 8;
+    const int wk0 = kbeg + wave * per_wave;
+    const int wk1 = min(kend, wk0 + per_wave);
+
+    const __amdgpu_buffer_rsrc_t ra = make_rsrc(g.A, g.a_bytes);
+    const __amdgpu_buffer_rsrc_t rz = make_rsrc(g.a_gz ? g.a_gz : g.A, g.a_bytes);
+    const __amdgpu_buffer_rsrc_t rb = make_rsrc(g.B, g.b_bytes);
+    const int m = m0 + l31;
+    const bool mvalid = m < g.M;
+    const unsigned abase = (unsigned)m * (unsigned)g.a_rs * 4u;
+    const unsigned akstride = (unsigned)g.a_cs * 4u, bkstride = (unsigned)g.b_rs * 4u;
+    int ncol[TN];
+    bool nvalid[TN], nones[TN];
+    unsigned bbase[TN];
+#pragma unroll
+    for (int t = 0; t < TN; ++t) {
+        ncol[t] = n0 + t * 32 + l31;
+        nones[t] = (EPI == EPI_ATOMIC) && ncol[t] == g.ones_col;
+        nvalid[t] = ncol[t] < g.N && !nones[t];
+        bbase[t] = (unsigned)ncol[t] * (unsigned)g.b_cs * 4u;
+    }
+
+    f32x16 acc[TN];
+#pragma unroll
+    for (int t = 0; t < TN; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+
+    auto step = [&](int k0, auto full_tag) {
+        constexpr bool FULL = decltype(full_tag)::value;
+        const int kk = k0 + 4 * half;            // this half-wave's 4 k values
+        float av[4], bv[TN][4];
+        load_frag<FULL>(ra, g.a_bytes, abase, mvalid, akstride, g.a_vec != 0, kk, wk1, av);
+        if (g.a_gz) {
+            float zv[4];
+            load_frag<FULL>(rz, g.a_bytes, abase, mvalid, akstride, g.a_vec != 0, kk, wk1, zv);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) av[e] *= gelu_erf_grad(zv[e]);
+            if (g.a_out && bx == 0 && mvalid) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (FULL || kk + e < wk1) g.a_out[(long)m * g.a_out_rs + (long)(kk + e) * g.a_out_cs] = av[e];
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < TN; ++t) {
+            load_frag<FULL>(rb, g.b_bytes, bbase[t], nvalid[t], bkstride, g.b_vec != 0, kk, wk1, bv[t]);
+            if (EPI == EPI_ATOMIC && nones[t]) {      // virtual all-ones column (bias gradient)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) bv[t][e] = (FULL || kk + e < wk1) ? 1.0f : 0.0f;
+            }
+        }
+        if (g.bf16) {                            // the lane's 4 consecutive k are exactly one bf16 fragment
+            const bf16x4 ap = pack_bf16(av[0], av[1], av[2], av[3]);
+#pragma unroll
+            for (int t = 0; t < TN; ++t)
+                acc[t] = mfma_32x32x8_bf16(ap, pack_bf16(bv[t][0], bv[t][1], bv[t][2], bv[t][3]), acc[t]);
+            return;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int t = 0; t < TN; ++t) acc[t] = mfma_32x32x2(av[e], bv[t][e], acc[t]);
+    };
+
+    int k0 = wk0;
+    for (; k0 + 16 <= wk1; k0 += 16) {           // two steps per trip: 4+ fragment loads in flight
+        step(k0, std::true_type{});
+        step(k0 + 8, std::true_type{});
+    }
+    if (k0 + 8 <= wk1) { step(k0, std::true_type{}); k0 += 8; }
+    if (k0 < wk1) step(k0, std::false_type{});
+
+    // ---- in-workgroup split-K reduction as a reduce-scatter through LDS: every wave parks its
+    // partial tile, then each wave sums and finishes its own share of the 16*TN accumulator
+    // registers, so the (erf-heavy) epilogue is spread over all waves and costs one barrier.
+    constexpr int NQ = TN * 16;
+    const int share = NQ / nwaves;               // nwaves in {1,2,4,8} divides 16
+    {
+        float* dst = red + (long)wave * NQ * 64 + lane;
+#pragma unroll
+        for (int t = 0; t < TN; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dst[(t * 16 + r) * 64] = acc[t][r];
+        __syncthreads();
+    }
+    const int q0 = wave * share;
+    // U accumulator registers per trip: their LDS reads (U x nwaves) and the epilogue's global loads (bias, the
+    // gelu' argument) are all requested before the first add - one register per trip with a runtime wave loop
+    // made every trip a chain of dependent LDS and memory round trips
+    auto finish = [&](auto u_tag, auto nw_tag, int qfirst) {
+        constexpr int U = decltype(u_tag)::value, NW = decltype(nw_tag)::value;
+        float part[U][NW], aux[U], bia[U];
+        int col[U], row[U];
+        bool ok[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int w = 0; w < NW; ++w) part[u][w] = red[((long)w * NQ + qfirst + u) * 64 + lane];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int q = qfirst + u;
+            const int t = q >> 4, r = q & 15;
+            col[u] = n0 + t * 32 + l31;
+            row[u] = m0 + acc_row(r, half);
+            ok[u] = col[u] < g.N && row[u] < g.M;
+            bia[u] = 0.0f; aux[u] = 0.0f;
+            if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) bia[u] = ok[u] ? g.bias[col[u]] : 0.0f;
+            if (EPI == EPI_MUL_GELU_GRAD) aux[u] = ok[u] ? g.G[(long)row[u] * g.ldg + col[u]] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            float v = 0.0f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) v += part[u][w];
+            if (!ok[u]) continue;
+            if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) v += bia[u];
+            if (EPI == EPI_BIAS_GELU) { g.Z[(long)row[u] * g.ldz + col[u]] = v; v = gelu_erf(v); }
+            if (EPI == EPI_MUL_GELU_GRAD) v *= gelu_erf_grad(aux[u]);
+            if (EPI == EPI_ATOMIC) {
+                if (col[u] == g.ones_col) atomicAdd(g.C2 + row[u], v);
+                else atomicAdd(g.C + (long)row[u] * g.ldc + col[u], v);
+            } else {
+                g.C[(long)row[u] * g.ldc + col[u]] = v;
+            }
+        }
+    };
+    auto finish_all = [&](auto nw_tag) {
+        int qq = 0;
+        if (EPI != EPI_ATOMIC && !g.seq_epi) {       // (the row-reducing GEMMs end in atomics, nothing to wait for: batching them measured slower)
+            for (; qq + 4 <= share; qq += 4) finish(std::integral_constant<int, 4>{}, nw_tag, q0 + qq);
+            for (; qq + 2 <= share; qq += 2) finish(std::integral_constant<int, 2>{}, nw_tag, q0 + qq);
+        }
+        for (; qq < share; ++qq) finish(std::integral_constant<int, 1>{}, nw_tag, q0 + qq);
+    };
+    switch (nwaves) {
+        case 2: finish_all(std::integral_constant<int, 2>{}); break;
+        case 4: finish_all(std::integral_constant<int, 4>{}); break;
+        default: finish_all(std::integral_constant<int, 8>{}); break;
+    }
+}
+
+
+}  // namespace

@@ -21,6 +21,7 @@
 // (SURVEY appendix B rearranged so that it is column-separable and centred:
 // mbar_n = sum_j P m is saved by the forward), accumulated in fp64.
 #include "pit_common.h"
+#include "pit_gemm_rd.h"
 #include <cstdlib>
 #include <type_traits>
 
@@ -1406,7 +1407,32 @@ void launch_cols(const AttArgs& a0, hipStream_t s) {
 // d(scale) + d(values) in one launch (posatt_bwd_pair_kernel) when both are in the small regime
 // with the same column-tile count; returns false when the pair does not apply (caller launches
 // the two kernels separately).
-bool launch_bwd_pair(const AttArgs& a0, hipStream_t s) {
+// the pair above plus the two weight-gradient reductions of the MLP that produced d_out (pit_hip.h: `rider`):
+// three small latency-bound grids in one launch; the attention workgroups (the longer ones) come first
+template <bool MASKED, bool BF>
+__global__ __launch_bounds__(512, 4) void posatt_bwd_pair_dw_kernel(AttArgs ar, AttArgs ac, int n_cols_wgs, int cgx, int cgy,
+                                                                     int rgx, int rgy, int n_att, pit_detail::DwPair w) {
+    int id = blockIdx.x;
+    if (id >= n_att) {
+        id -= n_att;
+        if (id < w.n1) {
+            gemm_rd_body<1, EPI_ATOMIC>(w.g1, id % w.gx1, (id / w.gx1) % w.gy1, id / (w.gx1 * w.gy1));
+        } else {
+            id -= w.n1;
+            gemm_rd_body<1, EPI_ATOMIC>(w.g2, id % w.gx2, (id / w.gx2) % w.gy2, id / (w.gx2 * w.gy2));
+        }
+        return;
+    }
+    if (id < n_cols_wgs) {
+        posatt_cols_body<1, MASKED, BF, 4>(ac, id % cgx, (id / cgx) % cgy, id / (cgx * cgy));
+    } else {
+        id -= n_cols_wgs;
+        posatt_rows_body<1, 1, MASKED, false, 4>(ar, id % rgx, (id / rgx) % rgy, id / (rgx * rgy));
+    }
+}
+
+// `rider` (may be null) is carried along when the narrow-tile kernel is the one chosen; *rider_done says so
+bool launch_bwd_pair(const AttArgs& a0, hipStream_t s, const pit_detail::DwPair* rider = nullptr, bool* rider_done = nullptr) {
     if (env_int("PIT_NO_BWD_PAIR") || env_int("PIT_FORCE_CT") || env_int("PIT_FORCE_WAVES")) return false;
     const int n_tiles = (a0.n_out + 31) / 32, j_tiles = (a0.n_in + 31) / 32;
     {   // either part would take the large-regime kernels: keep them separate
@@ -1431,6 +1457,24 @@ bool launch_bwd_pair(const AttArgs& a0, hipStream_t s) {
     if (rows_wgs + cols_wgs > 4096 || rows_wgs + cols_wgs > 0x7fffffffL) return false;
     const size_t sm = std::max(rows_smem(ct, nwaves, a0.n_in), cols_smem(ct, nwaves, a0.n_out));
     dim3 grid((unsigned)(rows_wgs + cols_wgs)), block(64 * nwaves);
+    if (rider && ct == 1 && nwaves >= 2) {
+        const int n_att = (int)(rows_wgs + cols_wgs);
+        const size_t smw = std::max(sm, (size_t)nwaves * 16 * 64 * sizeof(float));
+        dim3 gridw((unsigned)(n_att + rider->n1 + rider->n2));
+#define PIT_PAIR_DW(M_, BF_)                                                                                  \
+    do {                                                                                                      \
+        static bool once = ((void)hipFuncSetAttribute((const void*)posatt_bwd_pair_dw_kernel<M_, BF_>,        \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, 98304), true);    \
+        (void)once;                                                                                           \
+        hipLaunchKernelGGL((posatt_bwd_pair_dw_kernel<M_, BF_>), gridw, block, smw, s, ar, ac, (int)cols_wgs, \
+                           ac.colgroups, j_tiles, a0.mesh_batch * ar.colgroups, a0.n_head, n_att, *rider);    \
+    } while (0)
+        if (a0.masked) { if (a0.bf16) PIT_PAIR_DW(true, true); else PIT_PAIR_DW(true, false); }
+        else { if (a0.bf16) PIT_PAIR_DW(false, true); else PIT_PAIR_DW(false, false); }
+#undef PIT_PAIR_DW
+        *rider_done = true;
+        return true;
+    }
 #define PIT_PAIR_K(M_, BF_)                                                                                   \
     do {                                                                                                      \
         static bool once = ((void)hipFuncSetAttribute((const void*)posatt_bwd_pair_kernel<M_, BF_>,                 \
@@ -1964,12 +2008,27 @@ extern "C" int pit_posatt_bwd(const float* mesh_out, const float* mesh_in, int m
                               float* d_values, long ld_dvalues, long dvalues_bstride, int add_residual,
                               float* d_head, int accumulate_head, double* workspace,
                               const int* nbr_idx, const int* nbr_cnt, int nbr_cap, int nbr_complete,
-                              const int* rev_ptr, const int* rev_row, int coord_dims, int math_mode, void* stream) {
+                              const int* rev_ptr, const int* rev_row, const pit_mlp_params_job* rider,
+                              int coord_dims, int math_mode, void* stream) {
     PIT_ENTER_MATH(math_mode);
     AttArgs a;
     int rc = fill_common(a, mesh_out, mesh_in, mesh_batch, n_out, n_in, space_dim, metric, period, values, batch,
                          dim, ld_values, values_bstride, head, n_head, head_is_scale, coord_dims);
     if (rc) return rc;
+    // the postponed weight-gradient reductions: inside the attention launch when it can carry them, else by
+    // the call the caller postponed (after the attention launches; not at all when this call fails)
+    struct Rider {
+        const pit_mlp_params_job* job; void* stream; bool done;
+        int finish() {
+            if (!job || done) return 0;
+            done = true;
+            return pit_mlp_bwd_params(job->x, job->ldx, job->rows, job->n0, job->n1, job->n2, job->h, job->out_gelu,
+                                      job->d_y, job->ld_dy, job->d_w1, job->d_b1, job->d_w2, job->d_b2,
+                                      job->accumulate, job->scratch, job->math_mode, stream);
+        }
+    } rd{rider, stream, false};
+    pit_detail::DwPair dw;
+    const bool can_ride = rider && pit_detail::plan_dw_pair(*rider, &dw);
     if (coord_dims > 0 && (add_residual || !(nbr_idx && nbr_cnt && masked) || (d_values && !(rev_ptr && rev_row))))
         return PIT_ERR_UNSUPPORTED;                             // candidate-list kernels only
     if (!rowstat || !d_out || !workspace) return PIT_ERR_NULL;
@@ -2002,7 +2061,7 @@ extern "C" int pit_posatt_bwd(const float* mesh_out, const float* mesh_in, int m
         a.nslots = ns;
         bool paired = false;
         if (d_values) {                                                // d(scale) + d(values) in one launch
-            if (!sparse) paired = launch_bwd_pair(a, s);
+            if (!sparse) paired = launch_bwd_pair(a, s, can_ride ? &dw : nullptr, &rd.done);
             else if (rev_ptr && rev_row) paired = launch_sparse_bwd_pair(a, sp, nbr_complete != 0, s);
         }
         if (!paired) { if (sparse) launch_sparse_rows<1>(a, sp, s); else launch_rows<1>(a, s); }
@@ -2011,13 +2070,13 @@ extern "C" int pit_posatt_bwd(const float* mesh_out, const float* mesh_in, int m
             hipLaunchKernelGGL(posatt_dhead_finish, dim3(n_head), dim3(256), 0, s, a);
             PIT_CHECK_LAUNCH();
         }
-        if (paired) return 0;
+        if (paired) return rd.finish();
     }
     if (d_values) {
         if (sparse && rev_ptr && rev_row) launch_sparse_cols(a, sp, nbr_complete != 0, s); else launch_cols(a, s);
         PIT_CHECK_LAUNCH();
     }
-    return 0;
+    return rd.finish();
 }
 
 #ifdef PIT_STAMPS

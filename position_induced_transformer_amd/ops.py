@@ -188,6 +188,77 @@ def _defer_head_finish(work, d_head, head, scale, n_head: int, flags: int) -> No
     _PENDING_HEADS.append((work, d_head, head, scale, n_head, flags))
 
 
+# The weight-gradient reductions of an MLP backward (dW2|db2, dW1|db1: nothing downstream in the pass reads
+# them) are postponed and handed to the NEXT attention backward as its `rider` (pit_hip.h): pit.py:116-121
+# runs mlp -> attention, so in the backward the attention launch that consumes the MLP's d_x can carry the
+# MLP's reductions along - three small latency-bound grids in one launch.  In-place gradient mode only.
+MLP_PARAMS_RIDER = os.environ.get("PIT_DW_RIDER", "1") != "0"
+_PENDING_DW = {"task": None, "job": None}     # job = (MlpParamsJob, keep-alive tensors, stream it was prepared on)
+_DEFERRABLE = {}
+
+
+def _dw_run(job) -> None:
+    """Perform a postponed pit_mlp_bwd_params on the stream its inputs were produced on."""
+    st, keep, stream = job
+    cur = torch.cuda.current_stream(stream.device)
+    with torch.cuda.stream(stream):
+        rc = _lib.lib().pit_mlp_bwd_params(st.x, st.ldx, st.rows, st.n0, st.n1, st.n2, st.h, st.out_gelu, st.d_y,
+                                           st.ld_dy, st.d_w1, st.d_b1, st.d_w2, st.d_b2, st.accumulate, st.scratch,
+                                           st.math_mode, stream.cuda_stream)
+    _lib.check(rc, "pit_mlp_bwd_params")
+    if cur != stream:
+        cur.wait_stream(stream)
+
+
+def _dw_flush() -> None:
+    """End-of-backward callback (and: a second MLP backward with no attention in between)."""
+    job, _PENDING_DW["job"] = _PENDING_DW["job"], None
+    if job is not None:
+        _dw_run(job)
+
+
+def _dw_end_of_pass() -> None:
+    _dw_flush()
+    _PENDING_DW["task"] = None
+
+
+def _dw_defer(st, keep, device) -> None:
+    task = _graph_task()
+    if _PENDING_DW["task"] != task:
+        # a job left by another pass: that pass raised before its end-of-pass callback - its gradients are void
+        _PENDING_DW["job"] = None
+        _PENDING_DW["task"] = task
+        torch.autograd.Variable._execution_engine.queue_callback(_dw_end_of_pass)
+    else:
+        _dw_flush()
+    _PENDING_DW["job"] = (st, keep, torch.cuda.current_stream(device))
+
+
+def _dw_take(device):
+    """The job the current attention backward should carry (None if there is none for this pass / stream)."""
+    job = _PENDING_DW["job"]
+    if job is None:
+        return None
+    if _PENDING_DW["task"] != _graph_task():
+        _PENDING_DW["job"] = None                 # an aborted pass's leftover
+        return None
+    if job[2] != torch.cuda.current_stream(device):
+        _dw_flush()                               # produced on another stream: run it there
+        return None
+    _PENDING_DW["job"] = None
+    return job
+
+
+def _dw_deferrable(rows: int, n0: int, n1: int, n2: int, out_gelu: int, ld_dy: int) -> bool:
+    key = (rows, n0, n1, n2, out_gelu, ld_dy)
+    v = _DEFERRABLE.get(key)
+    if v is None:
+        if len(_DEFERRABLE) > 4096:
+            _DEFERRABLE.clear()
+        v = _DEFERRABLE[key] = bool(_lib.lib().pit_mlp_bwd_params_deferrable(*key))
+    return v
+
+
 def mark_inplace_grad(param, grad_view) -> None:
     """Opt ``param`` in to in-place gradient accumulation into ``grad_view`` (ddp.FlatGradients)."""
     param._pit_grad_ptr = grad_view.data_ptr()
@@ -401,7 +472,9 @@ class _PosAtt(torch.autograd.Function):
             acc_head |= 2                               # PIT_HEAD_DEFER: finished by _flush_head_finishes
             _defer_head_begin()                         # (clears what an aborted pass left, before the kernel adds)
 
-        def launch(dv, dh, stream_ptr):
+        rider = _dw_take(values.device)                 # an MLP's postponed weight-gradient reductions
+
+        def launch(dv, dh, stream_ptr, job=None):
             rc = _lib.lib().pit_posatt_bwd(
                 plan.mesh_out.data_ptr(), plan.mesh_in.data_ptr(), plan.mesh_batch, plan.n_out, plan.n_in,
                 plan.sdim, plan.metric_id, plan.period,
@@ -413,16 +486,20 @@ class _PosAtt(torch.autograd.Function):
                 1 if concat else 0,
                 _lib.ptr(dh), acc_head, work.data_ptr(),
                 _lib.ptr(plan.nbr_idx), _lib.ptr(plan.nbr_cnt), plan.nbr_cap, plan.lists_complete(),
-                _lib.ptr(plan.rev_ptr), _lib.ptr(plan.rev_row), ctx.coord_dims, ctx.math, stream_ptr)
+                _lib.ptr(plan.rev_ptr), _lib.ptr(plan.rev_row),
+                ctypes.cast(ctypes.pointer(job[0]), ctypes.c_void_p) if job is not None else None,
+                ctx.coord_dims, ctx.math, stream_ptr)
             _lib.check(rc, "pit_posatt_bwd")
 
         if OVERLAP_BACKWARD and slot is not None:
+            if rider is not None:
+                _dw_run(rider)
             side = _fork_side(values.device, values, head, rowstat, scale, d_out, plan)
             launch(None, d_head, side.cuda_stream)          # d(scale) -> lmda.grad, off the critical path
             if d_values is not None:
                 launch(d_values, None, _lib.stream_ptr())
         else:
-            launch(d_values, d_head, _lib.stream_ptr())
+            launch(d_values, d_head, _lib.stream_ptr(), rider)
         if defer:
             _defer_head_finish(work, d_head, head, scale, n_head, 1 | (4 if ctx.head_is_scale else 0))
         return d_values, (None if slot is not None else d_head), None, None, None, None, None, None, None
@@ -622,6 +699,16 @@ class _Mlp(torch.autograd.Function):
                                       d_y2.data_ptr(), d_y2.stride(0), d_w1.data_ptr(), d_b1.data_ptr(),
                                       d_w2.data_ptr(), d_b2.data_ptr(), 1, scratch.data_ptr(), ctx.math, stream_p)
             _lib.check(rc, "pit_mlp_bwd_params")
+        elif MLP_PARAMS_RIDER and inplace and _dw_deferrable(rows, n0, n1, n2, og, d_y2.stride(0)):
+            # dZ2, dZ1 and d_x now; the weight-gradient reductions ride along with the next attention backward
+            rc = L.pit_mlp_bwd_data(rows, n0, n1, n2, w1.data_ptr(), w2.data_ptr(), z1.data_ptr(), z2p, og,
+                                    d_y2.data_ptr(), d_y2.stride(0), _lib.ptr(d_x), n0, scratch.data_ptr(),
+                                    ctx.math, _lib.stream_ptr())
+            _lib.check(rc, "pit_mlp_bwd_data")
+            st = _lib.MlpParamsJob(x2.data_ptr(), x2.stride(0), rows, n0, n1, n2, h.data_ptr(), og, d_y2.data_ptr(),
+                                   d_y2.stride(0), d_w1.data_ptr(), d_b1.data_ptr(), d_w2.data_ptr(), d_b2.data_ptr(),
+                                   1, scratch.data_ptr(), ctx.math)
+            _dw_defer(st, (x2, h, d_y2, scratch, d_w1, d_b1, d_w2, d_b2), dev)
         else:
             # one call: dZ1, then dX and both weight-gradient reductions (merged into one launch when small)
             rc = L.pit_mlp_bwd(x2.data_ptr(), x2.stride(0), rows, n0, n1, n2, w1.data_ptr(), w2.data_ptr(),

@@ -721,3 +721,76 @@ def test_replays_leave_every_self_cleaning_buffer_clean(task, batch):
     for ws in ops._LOSS_WS.values():
         assert float(ws.abs().max()) == 0.0, "loss workspace not reset"
     assert torch.isfinite(flat.flat_params).all() and torch.isfinite(step.loss)
+
+
+# --------------------------------------------------------------------------- weight gradients riding with the attention backward
+@pytest.mark.parametrize("task,batch,math", [("darcy", 8, "fp32"), ("darcy", 8, "bf16"), ("burgers", 8, "fp32"),
+                                             ("elasticity", 2, "fp32"), ("vorticity", 2, "fp32")])
+def test_mlp_weight_gradients_carried_by_the_attention_backward_equal_their_own_launch(task, batch, math):
+    """pit_hip.h `rider`: the postponed pit_mlp_bwd_params of a block's MLP performed by the following
+    pit_posatt_bwd (inside its launch when both are small) against the same pass with the MLP backward issuing
+    its own reductions.  Everything but the atomics' summation order is identical."""
+    from position_induced_transformer_amd import ops, tasks, utils
+    from position_induced_transformer_amd.ddp import FlatGradients
+    model, sample, meta = tasks.make_task(task, seed=11)
+    batch_t = sample(batch)
+    loss_fn = utils.RelLpNorm(meta["out_dim"], meta["p"])
+    flat = FlatGradients(model.parameters())
+    got = {}
+    with ops.math_mode(math):
+        for rider in (True, False, True):
+            ops.MLP_PARAMS_RIDER = rider
+            try:
+                flat.zero_()
+                loss_fn(batch_t[-1], model(*batch_t[:-1])).backward()
+                torch.cuda.synchronize()
+            finally:
+                ops.MLP_PARAMS_RIDER = True
+            assert ops._PENDING_DW["job"] is None and ops._PENDING_DW["task"] is None
+            got.setdefault(rider, []).append(flat.flat.clone())
+    assert float(got[True][0].abs().max()) > 0
+    assert gio.rel_l2(got[False][0].cpu().numpy(), got[True][0].cpu().numpy()) <= 2e-6
+    assert gio.rel_l2(got[True][0].cpu().numpy(), got[True][1].cpu().numpy()) <= 2e-6
+    for (k, p), v in zip(model.named_parameters(), flat._views):        # parameter by parameter, not only in norm
+        a = got[False][0][v.storage_offset():v.storage_offset() + v.numel()].cpu().numpy()
+        b = got[True][0][v.storage_offset():v.storage_offset() + v.numel()].cpu().numpy()
+        assert gio.rel_l2(a, b) <= 1e-5, k
+
+
+def test_a_postponed_weight_gradient_job_of_an_aborted_pass_is_dropped():
+    """A pass that raises between an MLP backward (job postponed) and the attention backward that would have
+    carried it leaves the job behind: the next pass must neither run it (its buffers are gone) nor lose its own."""
+    from position_induced_transformer_amd import ops, tasks, utils
+    from position_induced_transformer_amd.ddp import FlatGradients
+    model, sample, meta = tasks.make_task("darcy", seed=4)
+    mesh_in, func_in, mesh_out, target = sample(8)
+    loss_fn = utils.RelLpNorm(meta["out_dim"], meta["p"])
+    flat = FlatGradients(model.parameters())
+    loss_fn(target, model(mesh_in, func_in, mesh_out)).backward()
+    torch.cuda.synchronize()
+    want = flat.flat.clone()
+
+    class Boom(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x):
+            return x.clone()
+
+        @staticmethod
+        def backward(ctx, g):
+            raise RuntimeError("boom")
+
+    # die right after the last block's MLP backward postponed its reductions (before its attention backward)
+    last = model.mlp[-1]
+    orig = last.forward
+    last.forward = lambda x, *a, **k: orig(Boom.apply(x), *a, **k)
+    try:
+        with pytest.raises(RuntimeError, match="boom"):
+            loss_fn(target, model(mesh_in, func_in, mesh_out)).backward()
+    finally:
+        last.forward = orig
+    assert ops._PENDING_DW["job"] is not None, "the scenario did not leave a postponed job"
+    flat.zero_()
+    loss_fn(target, model(mesh_in, func_in, mesh_out)).backward()
+    torch.cuda.synchronize()
+    assert ops._PENDING_DW["job"] is None
+    assert gio.rel_l2(want.cpu().numpy(), flat.flat.cpu().numpy()) <= 2e-6
