@@ -1407,6 +1407,16 @@ void launch_cols(const AttArgs& a0, hipStream_t s) {
 // d(scale) + d(values) in one launch (posatt_bwd_pair_kernel) when both are in the small regime
 // with the same column-tile count; returns false when the pair does not apply (caller launches
 // the two kernels separately).
+// workgroup `id` of a carried pair of weight-gradient reductions (pit_detail::DwPair)
+__device__ __forceinline__ void dw_pair_body(const pit_detail::DwPair& w, int id) {
+    if (id < w.n1) {
+        gemm_rd_body<1, EPI_ATOMIC>(w.g1, id % w.gx1, (id / w.gx1) % w.gy1, id / (w.gx1 * w.gy1));
+    } else {
+        id -= w.n1;
+        gemm_rd_body<1, EPI_ATOMIC>(w.g2, id % w.gx2, (id / w.gx2) % w.gy2, id / (w.gx2 * w.gy2));
+    }
+}
+
 // the pair above plus the two weight-gradient reductions of the MLP that produced d_out (pit_hip.h: `rider`):
 // three small latency-bound grids in one launch; the attention workgroups (the longer ones) come first
 template <bool MASKED, bool BF>
@@ -1414,13 +1424,7 @@ __global__ __launch_bounds__(512, 4) void posatt_bwd_pair_dw_kernel(AttArgs ar, 
                                                                      int rgx, int rgy, int n_att, pit_detail::DwPair w) {
     int id = blockIdx.x;
     if (id >= n_att) {
-        id -= n_att;
-        if (id < w.n1) {
-            gemm_rd_body<1, EPI_ATOMIC>(w.g1, id % w.gx1, (id / w.gx1) % w.gy1, id / (w.gx1 * w.gy1));
-        } else {
-            id -= w.n1;
-            gemm_rd_body<1, EPI_ATOMIC>(w.g2, id % w.gx2, (id / w.gx2) % w.gy2, id / (w.gx2 * w.gy2));
-        }
+        dw_pair_body(w, id - n_att);
         return;
     }
     if (id < n_cols_wgs) {
@@ -1849,8 +1853,12 @@ __global__ __launch_bounds__(256) void posatt_sparse_overflow_cols(AttArgs a, Sp
 // must come after the plain stores of the key-owning waves.
 template <int NH, int CRR, int CRC>
 __global__ __launch_bounds__(256) void posatt_sparse_bwd_kernel(AttArgs a, SparseArgs sp, int n_cols, int cgx,
-                                                                 int rgx, int rgy) {
+                                                                 int rgx, int rgy, int n_att, pit_detail::DwPair w) {
     int id = blockIdx.x;
+    if (id >= n_att) {                                   // a postponed MLP's weight-gradient reductions (pit_hip.h: rider)
+        dw_pair_body(w, id - n_att);
+        return;
+    }
     if (id < n_cols) {
         sparse_cols_body<CRC>(a, sp, id % cgx, id / cgx);
     } else {
@@ -1867,12 +1875,39 @@ int cr_for(int ncols, long units) {
     return cr;
 }
 
+// d(scale) of a candidate-list layer with a postponed MLP's weight-gradient reductions in the same launch
+template <int NH, int CR>
+__global__ __launch_bounds__(256) void posatt_sparse_rows_dw(AttArgs a, SparseArgs sp, int gx, int gy, int n_att,
+                                                              pit_detail::DwPair w) {
+    const int id = blockIdx.x;
+    if (id >= n_att) {
+        dw_pair_body(w, id - n_att);
+        return;
+    }
+    sparse_rows_body<NH, CR, 1>(a, sp, id % gx, (id / gx) % gy, id / (gx * gy));
+}
+
+constexpr size_t DW_SMEM_4WAVES = 4 * 16 * 64 * sizeof(float);   // gemm_rd_body's parking area, 256-thread workgroups
+
 template <int MODE>
-void launch_sparse_rows(const AttArgs& a, const SparseArgs& sp, hipStream_t s) {
+void launch_sparse_rows(const AttArgs& a, const SparseArgs& sp, hipStream_t s, const pit_detail::DwPair* rider = nullptr,
+                        bool* rider_done = nullptr) {
     const int nh = (a.n_head % 2 == 0) ? 2 : 1;
     const long rows = (long)a.mesh_batch * a.n_out;
     const int cr = cr_for(a.ncols, rows * (a.n_head / nh));
     dim3 grid((unsigned)((rows + 3) / 4), (a.ncols + 64 * cr - 1) / (64 * cr), a.n_head / nh), block(256);
+    if (MODE == 1 && rider && (long)grid.x * grid.y * grid.z <= 16384) {       // small launch: carry the reductions
+        const int n_att = (int)(grid.x * grid.y * grid.z);
+        dim3 gridw((unsigned)(n_att + rider->n1 + rider->n2));
+#define PIT_SRW(NH_, CR_) hipLaunchKernelGGL((posatt_sparse_rows_dw<NH_, CR_>), gridw, block, DW_SMEM_4WAVES, s, a, sp, \
+                                             (int)grid.x, (int)grid.y, n_att, *rider)
+#define PIT_SRW_CR(NH_) do { if (cr == 8) PIT_SRW(NH_, 8); else if (cr == 4) PIT_SRW(NH_, 4); else if (cr == 2) PIT_SRW(NH_, 2); else PIT_SRW(NH_, 1); } while (0)
+        if (nh == 2) PIT_SRW_CR(2); else PIT_SRW_CR(1);
+#undef PIT_SRW_CR
+#undef PIT_SRW
+        *rider_done = true;
+        return;
+    }
     const long xtotal = 8L * grid.x * ((grid.y + 7) / 8) * grid.z;
     const bool remap = grid.y >= 16 && xtotal < 0x7fffffffL && !env_int("PIT_NO_XCD_REMAP");   // (few blocks: padding costs more than locality gains)
 #define PIT_SR(NH_, CR_)                                                                                              \
@@ -1890,7 +1925,8 @@ void launch_sparse_rows(const AttArgs& a, const SparseArgs& sp, hipStream_t s) {
 // merged d(values) + d(scale) launch for a sparse layer; false when the launch would be large or
 // the parts' columns-per-lane are a combination that is not instantiated (caller launches the
 // parts separately)
-bool launch_sparse_bwd_pair(const AttArgs& a, const SparseArgs& sp, bool complete, hipStream_t s) {
+bool launch_sparse_bwd_pair(const AttArgs& a, const SparseArgs& sp, bool complete, hipStream_t s,
+                            const pit_detail::DwPair* rider = nullptr, bool* rider_done = nullptr) {
     if (env_int("PIT_NO_BWD_PAIR")) return false;
     const int nh = (a.n_head % 2 == 0) ? 2 : 1;
     const long rows = (long)a.mesh_batch * a.n_out, keys = (long)a.mesh_batch * a.n_in;
@@ -1901,14 +1937,19 @@ bool launch_sparse_bwd_pair(const AttArgs& a, const SparseArgs& sp, bool complet
     const long rgx = (rows + 3) / 4, cgx = (keys + 3) / 4;
     const long n_rows = rgx * rblocks * (a.n_head / nh), n_cols = cgx * cblocks;
     if (n_rows + n_cols > 16384) return false;            // big launches gain nothing from merging
-    dim3 grid((unsigned)(n_rows + n_cols)), block(256);
-#define PIT_SB(NH_, CRR_, CRC_) hipLaunchKernelGGL((posatt_sparse_bwd_kernel<NH_, CRR_, CRC_>), grid, block, 0, s, a, sp, (int)n_cols, (int)cgx, (int)rgx, rblocks)
+    const int n_att = (int)(n_rows + n_cols);
+    static const pit_detail::DwPair no_rider{};
+    dim3 grid((unsigned)(n_att + (rider ? rider->n1 + rider->n2 : 0))), block(256);
+    const size_t sm = rider ? DW_SMEM_4WAVES : 0;
+    const pit_detail::DwPair& w = rider ? *rider : no_rider;
+#define PIT_SB(NH_, CRR_, CRC_) hipLaunchKernelGGL((posatt_sparse_bwd_kernel<NH_, CRR_, CRC_>), grid, block, sm, s, a, sp, (int)n_cols, (int)cgx, (int)rgx, rblocks, n_att, w)
 #define PIT_SB_C(NH_, CRR_) do { if (crc == CRR_) PIT_SB(NH_, CRR_, CRR_); else PIT_SB(NH_, CRR_, 1); } while (0)
 #define PIT_SB_CR(NH_) do { if (crr == 8) PIT_SB_C(NH_, 8); else if (crr == 4) PIT_SB_C(NH_, 4); else if (crr == 2) PIT_SB_C(NH_, 2); else PIT_SB(NH_, 1, 1); } while (0)
     if (nh == 2) PIT_SB_CR(2); else PIT_SB_CR(1);
 #undef PIT_SB_CR
 #undef PIT_SB_C
 #undef PIT_SB
+    if (rider) *rider_done = true;
     if (!complete) hipLaunchKernelGGL(posatt_sparse_overflow_cols, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, a, sp);
     return true;
 }
@@ -2062,9 +2103,13 @@ extern "C" int pit_posatt_bwd(const float* mesh_out, const float* mesh_in, int m
         bool paired = false;
         if (d_values) {                                                // d(scale) + d(values) in one launch
             if (!sparse) paired = launch_bwd_pair(a, s, can_ride ? &dw : nullptr, &rd.done);
-            else if (rev_ptr && rev_row) paired = launch_sparse_bwd_pair(a, sp, nbr_complete != 0, s);
+            else if (rev_ptr && rev_row)
+                paired = launch_sparse_bwd_pair(a, sp, nbr_complete != 0, s, can_ride ? &dw : nullptr, &rd.done);
         }
-        if (!paired) { if (sparse) launch_sparse_rows<1>(a, sp, s); else launch_rows<1>(a, s); }
+        if (!paired) {
+            if (sparse) launch_sparse_rows<1>(a, sp, s, (can_ride && !rd.done) ? &dw : nullptr, &rd.done);
+            else launch_rows<1>(a, s);
+        }
         PIT_CHECK_LAUNCH();
         if (!defer) {
             hipLaunchKernelGGL(posatt_dhead_finish, dim3(n_head), dim3(256), 0, s, a);
