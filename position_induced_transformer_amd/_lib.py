@@ -11,7 +11,7 @@ import os
 import torch  # noqa: F401  (must precede the CDLL load)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libpit_hip.so")
+LIB_PATH = os.environ.get("PIT_LIB_PATH") or os.path.join(_HERE, "csrc", "libpit_hip.so")   # (override: diagnostic builds, tools/)
 
 _P = ctypes.c_void_p
 _I = ctypes.c_int
