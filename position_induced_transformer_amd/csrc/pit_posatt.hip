@@ -46,19 +46,8 @@ struct AttArgs {
     unsigned dim_magic;                   // floor(2^32 / dim): column -> (sample, channel) without an integer division
     int no_fast_loads;                    // PIT_NO_FAST_LOADS=1: checked loads everywhere (tests the >= 2 GiB path)
     int coord_dims;                       // > 0: value channels [0, coord_dims) are the key coordinates themselves (sparse kernels)
-    int stagger, stagger_lo, stagger_hi;  // workgroups with linear id in [lo, hi) sleep `stagger` x 8128 cycles at entry
 };
 
-// Two workgroups that share a CU and start together run their phases in lockstep: prologue, key loop and
-// epilogue of both coincide, and the matrix pipe idles during both prologues / epilogues.  Delaying the
-// second workgroup of every CU in the FIRST round by about half a workgroup life staggers them for the rest
-// of the launch (slots then free up alternately): one's epilogue runs beside the other's key loop.
-__device__ __forceinline__ void stagger_entry(const AttArgs& a) {
-    if (a.stagger <= 0) return;
-    const int id = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-    if (id < a.stagger_lo || id >= a.stagger_hi) return;
-    for (int i = 0; i < a.stagger; ++i) __builtin_amdgcn_s_sleep(127);
-}
 
 // Folded column index -> (sample, channel).  For batch-free meshes the batch is folded into the
 // column axis (col = sample*dim + channel); a runtime integer division costs ~35 VALU
@@ -171,7 +160,9 @@ __device__ unsigned long long pit_dbg_stamps[64];
 #define PIT_STAMP_B(i_) do { } while (0)
 #endif
 
-template <int CT, int NX>
+// IL (interleaved column tiles, see posatt_rows_body): the parked order is register-major (q = i*CT + t), so that
+// four consecutive q are one row's four adjacent columns.
+template <int CT, int NX, bool IL = false>
 __device__ __forceinline__ void park_tiles(const f32x16 (&acc)[CT], const float (&extra)[NX > 0 ? NX : 1], float* red,
                                            int wave, int lane) {
     constexpr int SLOT = (CT * 16 + NX) * 64;
@@ -179,7 +170,7 @@ __device__ __forceinline__ void park_tiles(const f32x16 (&acc)[CT], const float 
 #pragma unroll
     for (int t = 0; t < CT; ++t)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) dst[(t * 16 + i) * 64] = acc[t][i];
+        for (int i = 0; i < 16; ++i) dst[(IL ? i * CT + t : t * 16 + i) * 64] = acc[t][i];
 #pragma unroll
     for (int x = 0; x < NX; ++x) dst[(CT * 16 + x) * 64] = extra[x];
 }
@@ -194,8 +185,14 @@ __device__ __forceinline__ float summed(const float* red, int nwaves, int q, int
 // ------------------------------------------------------------------------------------
 // rows kernel
 // ------------------------------------------------------------------------------------
-template <int CT, int MODE, bool MASKED, bool BF, int NPX = 0>
+// IL ("interleaved", CT == 4 only): column tile t of a workgroup is the columns {4 l + t : l = 0..31} of its 128
+// instead of [32 t, 32 t + 32): a lane's four B operands of a key are then ADJACENT in memory - one 16-B load per
+// key instead of four 4-B loads (bare-loop measurements, tools/micro/mfma_mix.hip: a dword load per fp32 MFMA caps
+// the matrix pipe at ~100 of 154 TF/s whatever the occupancy, a dwordx4 per four MFMAs at ~125) - and its four
+// results of a row are adjacent too (16-B stores).  Needs 16-B aligned rows and dim % 4 == 0 (launch_rows checks).
+template <int CT, int MODE, bool MASKED, bool BF, int NPX = 0, bool IL = false>
 __device__ __forceinline__ void posatt_rows_body(const AttArgs& a, const int bx, const int by, const int bz) {
+    static_assert(!IL || CT == 4, "interleaved tiles are the CT == 4 layout");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float4* s_xi = reinterpret_cast<float4*>(smem);
 
@@ -243,7 +240,7 @@ __device__ __forceinline__ void posatt_rows_body(const AttArgs& a, const int bx,
     int cb[CT], cd[CT];
 #pragma unroll
     for (int t = 0; t < CT; ++t) {
-        const int col = (cg * CT + t) * 32 + l31;
+        const int col = IL ? cg * CT * 32 + l31 * CT + t : (cg * CT + t) * 32 + l31;
         cvalid[t] = col < a.ncols;
         const int cc = cvalid[t] ? col : 0;
         col_split(a, cc, mb, cb[t], cd[t]);
@@ -268,6 +265,18 @@ __device__ __forceinline__ void posatt_rows_body(const AttArgs& a, const int bx,
     float dov[MODE == 1 ? CT : 1][16];
     auto load_dov = [&]() {
         const __amdgpu_buffer_rsrc_t rdo = make_rsrc(a.d_out, a.dout_bytes);
+        if (IL && MODE == 1) {                             // a lane's four columns are adjacent: one 16-B load per row
+            const unsigned cbase = (unsigned)(((long)cb[0] * a.dout_bstride + a.out_col0 + (long)h * a.dim + cd[0]) * 4);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int nr = n0 + acc_row(i, half);
+                float q[4];
+                buf_load4(rdo, (cvalid[0] && nr < a.n_out) ? cbase + (unsigned)nr * (unsigned)a.ld_dout * 4u : a.dout_bytes, q);
+#pragma unroll
+                for (int t = 0; t < (MODE == 1 ? CT : 0); ++t) dov[t][i] = q[t & 3];
+            }
+            return;
+        }
 #pragma unroll
         for (int t = 0; t < (MODE == 1 ? CT : 0); ++t) {
             const unsigned cbase = (unsigned)(((long)cb[t] * a.dout_bstride + a.out_col0 + (long)h * a.dim + cd[t]) * 4);
@@ -321,6 +330,12 @@ __device__ __forceinline__ void posatt_rows_body(const AttArgs& a, const int bx,
                         constexpr int dummy = 0; (void)dummy;
                         const int koff = 8 * (u / 4) + (BF ? (u % 4) : 2 * (u % 4));
                         const int soff = (jc0 + jj + koff) * (int)ld4;  // wave-uniform: scalar offset operand
+                        if (IL) {
+                            const i32x4 q = __builtin_amdgcn_raw_buffer_load_b128(rvals, (int)voff[0], soff, 0);
+                            dst[u][0] = __int_as_float(q.x); dst[u][1 % CT] = __int_as_float(q.y);
+                            dst[u][2 % CT] = __int_as_float(q.z); dst[u][3 % CT] = __int_as_float(q.w);
+                            continue;
+                        }
 #pragma unroll
                         for (int t = 0; t < CT; ++t)
                             dst[u][t] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rvals, (int)voff[t], soff, 0));
@@ -331,6 +346,13 @@ __device__ __forceinline__ void posatt_rows_body(const AttArgs& a, const int bx,
                         const int jl = jj + 8 * (u / 4) + kpos[u % 4];
                         const bool jv = jl < je;
                         const unsigned rowoff = (unsigned)(jc0 + jl) * ld4;
+                        if (IL) {
+                            float q[4];
+                            buf_load4(rvals, (jv && cvalid[0]) ? uoff[0] + rowoff : a.values_bytes, q);
+#pragma unroll
+                            for (int t = 0; t < CT; ++t) dst[u][t] = q[t & 3];
+                            continue;
+                        }
 #pragma unroll
                         for (int t = 0; t < CT; ++t)     // out-of-range offset -> hardware returns 0, no branch
                             dst[u][t] = buf_load(rvals, (jv && cvalid[t]) ? uoff[t] + rowoff : a.values_bytes);
@@ -356,18 +378,11 @@ __device__ __forceinline__ void posatt_rows_body(const AttArgs& a, const int bx,
                         jv = jl < je;
                         xi = s_xi[jv ? jl : jb];
                     }
-#if defined(PIT_ABL) && (PIT_ABL & 1)                            /* diagnostic ablation: no weight formation */
-                    const float m = xi.x;
-                    const float sv = m;
-                    bool keep = jv;
-                    float p = m;
-#else
                     const float m = sq_dist3t<PER>(xo.x, xo.y, xo.z, xi.x, xi.y, xi.z, a.period);
                     const float sv = __fmul_rn(m, c);
                     bool keep = jv;
                     if (MASKED) keep = keep && (sv <= T);
                     float p = __expf(s_min - sv);
-#endif
                     if (MASKED || !FULL) p = keep ? p : 0.0f;
                     if (MODE == 0) {
                         rsum += p;
@@ -403,13 +418,15 @@ __device__ __forceinline__ void posatt_rows_body(const AttArgs& a, const int bx,
                 for (int u = 0; u < NP; ++u) {
                     const int koff = 8 * (u / 4) + (BF ? (u % 4) : 2 * (u % 4));
                     const int soff = (jc0 + jj + koff) * (int)ld4;
+                    if (IL) {
+                        const i32x4 q = __builtin_amdgcn_raw_buffer_load_b128(rvals, (int)voff[0], soff, 0);
+                        dst[u][0] = __int_as_float(q.x); dst[u][1 % CT] = __int_as_float(q.y);
+                        dst[u][2 % CT] = __int_as_float(q.z); dst[u][3 % CT] = __int_as_float(q.w);
+                        continue;
+                    }
 #pragma unroll
                     for (int t = 0; t < CT; ++t)
-#if defined(PIT_ABL) && (PIT_ABL & 2)                            /* diagnostic ablation: no value loads */
-                        dst[u][t] = __int_as_float(soff + (int)voff[t]);
-#else
                         dst[u][t] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rvals, (int)voff[t], soff, 0));
-#endif
                 }
             };
 
@@ -494,7 +511,7 @@ __device__ __forceinline__ void posatt_rows_body(const AttArgs& a, const int bx,
     extra[1] = qsum + __shfl_xor(qsum, 32);
     float* red = reinterpret_cast<float*>(smem);
     __syncthreads();                                   // staging region is free
-    park_tiles<CT, 2>(acc, extra, red, wave, lane);
+    park_tiles<CT, 2, IL>(acc, extra, red, wave, lane);
     __syncthreads();
     PIT_STAMP_B(35);
     const float rs_tot = summed<CT, 2>(red, nwaves, CT * 16, lane);       // row = lane & 31
@@ -514,6 +531,35 @@ __device__ __forceinline__ void posatt_rows_body(const AttArgs& a, const int bx,
         for (int u = 0; u < U; ++u)
 #pragma unroll
             for (int w = 0; w < NW; ++w) part[u][w] = red[(long)w * SLOT + (qfirst + u) * 64 + lane];
+        if constexpr (IL && U == 4) {
+            // q = i*CT + t: the four registers of a trip are row i's four adjacent columns - 16-B accesses
+            const int i = qfirst >> 2;
+            const int nr = n0 + acc_row(i, half);
+            const int col0 = cg * CT * 32 + l31 * CT;
+            const bool cv = col0 < a.ncols;
+            int bb, dd;
+            col_split(a, cv ? col0 : 0, mb, bb, dd);
+            const bool okr = cv && nr < a.n_out;
+            float iv4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (a.copy_inputs && h == 0)                       // torch.cat((inputs, conv), -1), pit.py:44
+                buf_load4(rvals, okr ? (unsigned)(((long)bb * a.values_bstride + dd) * 4) + (unsigned)nr * ld4 : a.values_bytes, iv4);
+            const float rinv = __shfl(inv, acc_row(i, half));
+            float4 v;
+            float* vp = &v.x;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                float sum = 0.0f;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) sum += part[u][w];
+                vp[u] = sum * rinv;
+            }
+            if (okr) {
+                float* orow = a.out + (long)bb * a.out_bstride + (long)nr * a.ld_out + dd;
+                *reinterpret_cast<float4*>(orow + a.out_col0 + (long)h * a.dim) = v;
+                if (a.copy_inputs && h == 0) *reinterpret_cast<float4*>(orow) = make_float4(iv4[0], iv4[1], iv4[2], iv4[3]);
+            }
+            return;
+        }
         long ooff[U];
         unsigned ioff[U];
         bool ok[U];
@@ -521,9 +567,9 @@ __device__ __forceinline__ void posatt_rows_body(const AttArgs& a, const int bx,
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int q = qfirst + u;
-            const int t = q >> 4, i = q & 15;
+            const int t = IL ? q % CT : q >> 4, i = IL ? q / CT : q & 15;
             const int nr = n0 + acc_row(i, half);
-            const int col = (cg * CT + t) * 32 + l31;
+            const int col = IL ? cg * CT * 32 + l31 * CT + t : (cg * CT + t) * 32 + l31;
             const bool cv = col < a.ncols;
             int bb, dd;
             col_split(a, cv ? col : 0, mb, bb, dd);
@@ -538,7 +584,7 @@ __device__ __forceinline__ void posatt_rows_body(const AttArgs& a, const int bx,
             float v = 0.0f;
 #pragma unroll
             for (int w = 0; w < NW; ++w) v += part[u][w];
-            v *= __shfl(inv, acc_row((qfirst + u) & 15, half));
+            v *= __shfl(inv, acc_row(IL ? (qfirst + u) / CT : (qfirst + u) & 15, half));
             if (ok[u]) a.out[ooff[u] + a.out_col0 + (long)h * a.dim] = v;
         }
         if (a.copy_inputs && h == 0) {
@@ -566,317 +612,17 @@ __device__ __forceinline__ void posatt_rows_body(const AttArgs& a, const int bx,
     if (a.scale_out && wave == 0 && bx == 0 && bz == 0 && lane == 0) a.scale_out[h] = c;
 }
 
-// ------------------------------------------------------------------------------------
-// Large-regime dense kernel with the weights SHARED through LDS (no split over the keys, no reduction of
-// accumulator tiles).  posatt_rows_body splits the KEYS of a 32-row tile over its waves: every wave ends with a
-// partial 32 x (32 CT) accumulator that has to be parked in LDS and reduce-scattered (in-kernel stamps on the
-// Elasticity processor layer: 13.6 k of a workgroup's 95 k cycles, beside a key loop at 81 % matrix-pipe
-// occupancy; the 67 KB parking area and 251 registers also cap a CU at two workgroups).  Here the waves of a
-// workgroup split the COLUMNS: wave w owns column tiles [w*CTW, (w+1)*CTW) of the workgroup's 32 x (128 CTW)
-// output for ALL keys, so its accumulators are final.  The weights of a 64-key chunk are formed once per
-// workgroup - wave w forms two of its eight 8-key groups - and handed over through a double-buffered 8 KB LDS
-// tile laid out so that a lane's four weights of a group are one 16-B read; one barrier per chunk.  ~100
-// registers and 34 KB of LDS: four workgroups (16 waves) per CU, whose prologues and epilogues overlap each
-// other's key loops.  MODE 0: forward; MODE 1: the d(scale) contraction of the backward.
-constexpr int SH_WAVES = 4, SH_GROUPS = 8, SH_CHUNK = 64, SH_PASS = 1024;
-#ifndef SH_FENCE
-#define SH_FENCE 0x00E          /* sched_barrier mask: VALU | SALU | MFMA may cross, memory instructions may not */
-#endif
-constexpr size_t SH_SMEM = SH_PASS * sizeof(float4) + 2 * SH_GROUPS * 64 * sizeof(float4) + 2 * SH_GROUPS * sizeof(int) +
-                           SH_WAVES * 2 * 32 * sizeof(double);
-
-template <int CTW, int MODE, bool MASKED, bool BF>
-__device__ __forceinline__ void rows_shared_body(const AttArgs& a, const int bx, const int by, const int bz) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float4* s_xi = reinterpret_cast<float4*>(smem);                                   // [SH_PASS] key coordinates
-    float4* s_p = s_xi + SH_PASS;                                                      // [2][SH_GROUPS][64] weights
-    int* s_any = reinterpret_cast<int*>(s_p + 2 * SH_GROUPS * 64);                     // [2][SH_GROUPS] group has a kept key
-    double* s_red = reinterpret_cast<double*>(s_any + 2 * SH_GROUPS);                  // [SH_WAVES][2][32] (floats or doubles)
-
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int half = lane >> 5, l31 = lane & 31;
-    const int n0 = bz * 32, h = by;
-    const int mb = bx / a.colgroups, cg = bx % a.colgroups;
-    const long rows_total = (long)a.mesh_batch * a.n_out;
-    const float c = a.head_is_scale ? a.head[h] : head_scale_from_lmda(a.head[h]);
-
-    const int n = n0 + l31;
-    const bool nvalid = n < a.n_out;
-    const long rowid = (long)mb * a.n_out + (nvalid ? n : a.n_out - 1);
-    const unsigned mo_bytes = (unsigned)((long)a.mesh_batch * a.n_out * a.sdim * 4);
-    const unsigned mi_bytes = (unsigned)((long)a.mesh_batch * a.n_in * a.sdim * 4);
-    const __amdgpu_buffer_rsrc_t rmo = make_rsrc(a.mesh_out, mo_bytes);
-    const __amdgpu_buffer_rsrc_t rmi = make_rsrc(a.mesh_in, mi_bytes);
-    const float4 xo = load_point4(rmo, mo_bytes, rowid, a.sdim, a.coords_used);
-    float T = __builtin_inff(), s_min = 0.0f, inv_l = 0.0f, mbar = 0.0f;
-    if (MODE == 0) {
-        if (MASKED) T = quantile_lerp(__fmul_rn(c, a.stats[rowid]), __fmul_rn(c, a.stats[rows_total + rowid]), a.rank_w);
-        if (a.stats) s_min = __fmul_rn(c, a.stats[2 * rows_total + rowid]);
-    } else {
-        const float4 rs4 = *reinterpret_cast<const float4*>(
-            a.rowstat + (((long)mb * a.n_head + h) * a.n_out + (nvalid ? n : a.n_out - 1)) * 4);
-        T = rs4.x; s_min = rs4.y; inv_l = rs4.z; mbar = rs4.w;
-    }
-
-    // this wave's columns
-    const __amdgpu_buffer_rsrc_t rvals = make_rsrc(a.values, a.values_bytes);
-    const unsigned ld4 = (unsigned)a.ld_values * 4u;
-    constexpr int HS = BF ? 4 : 1;                       // key distance between the half-waves inside a group of 8
-    const int hk = half * HS;
-    unsigned uoff[CTW], voff[CTW];
-    bool cvalid[CTW];
-    int cb[CTW], cd[CTW];
-#pragma unroll
-    for (int t = 0; t < CTW; ++t) {
-        const int col = ((cg * SH_WAVES + wave) * CTW + t) * 32 + l31;
-        cvalid[t] = col < a.ncols;
-        col_split(a, cvalid[t] ? col : 0, mb, cb[t], cd[t]);
-        uoff[t] = (unsigned)(((long)cb[t] * a.values_bstride + cd[t]) * 4);
-        voff[t] = cvalid[t] ? uoff[t] + (unsigned)hk * ld4 : a.values_bytes;
-    }
-    const bool fast_ok = a.values_bytes < 0x80000000u && !a.no_fast_loads;
-    int kpos[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) kpos[e] = group_pos(BF, e, half);
-
-    f32x16 acc[CTW];
-#pragma unroll
-    for (int t = 0; t < CTW; ++t)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
-    float rsum = 0.0f, qsum = 0.0f;
-
-    auto run = [&](auto per_tag) {
-        constexpr bool PER = decltype(per_tag)::value;
-        for (int jc0 = 0; jc0 < a.n_in; jc0 += SH_PASS) {
-            const int len = min(SH_PASS, a.n_in - jc0);
-            const int nch = (len + SH_CHUNK - 1) / SH_CHUNK;
-            // value rows of half a chunk (4 groups x 4 keys per half-wave), one register per (key, column tile)
-            auto load_half = [&](float (&dst)[16][CTW], int ch, int hf, auto full_tag) {
-                constexpr bool FULL = decltype(full_tag)::value;      // steady state: no range checks, no branches
-                const int k0 = ch * SH_CHUNK + hf * 32;               // first key of the half chunk (inside the pass)
-                if (FULL || (k0 + 32 <= len && fast_ok)) {
-#pragma unroll
-                    for (int u = 0; u < 16; ++u) {
-                        const int koff = 8 * (u / 4) + (BF ? (u % 4) : 2 * (u % 4));
-                        const int soff = (jc0 + k0 + koff) * (int)ld4;       // wave-uniform: scalar offset operand
-#pragma unroll
-                        for (int t = 0; t < CTW; ++t)
-                            dst[u][t] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rvals, (int)voff[t], soff, 0));
-                    }
-                } else if (k0 < len) {
-#pragma unroll
-                    for (int u = 0; u < 16; ++u) {
-                        const int jl = k0 + 8 * (u / 4) + kpos[u % 4];
-                        const unsigned rowoff = (unsigned)(jc0 + jl) * ld4;
-#pragma unroll
-                        for (int t = 0; t < CTW; ++t)         // out-of-range offset -> hardware returns 0, no branch
-                            dst[u][t] = buf_load(rvals, (jl < len && cvalid[t]) ? uoff[t] + rowoff : a.values_bytes);
-                    }
-                }
-            };
-            // weights of group g of chunk ch -> LDS (this wave forms groups 2*wave and 2*wave + 1 of every chunk)
-            auto produce = [&](int ch, int g, auto full_tag) {
-                constexpr bool FULL = decltype(full_tag)::value;
-                const int kb = ch * SH_CHUNK + g * 8;
-                if (!FULL && kb >= len) return;                      // (wave-uniform) nobody reads the group
-                float pw[4];
-                bool any = false;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int jl = kb + kpos[e];
-                    const bool jv = FULL || jl < len;
-                    const float4 xi = s_xi[jv ? jl : kb];
-                    const float m = sq_dist3t<PER>(xo.x, xo.y, xo.z, xi.x, xi.y, xi.z, a.period);
-                    const float sv = __fmul_rn(m, c);
-                    bool keep = jv;
-                    if (MASKED) keep = keep && (sv <= T);
-                    float p = __expf(s_min - sv);
-                    if (MASKED || !FULL) p = keep ? p : 0.0f;
-                    if (MODE == 0) { rsum += p; qsum += p * m; pw[e] = p; }
-                    else pw[e] = p * (m - mbar) * inv_l;
-                    any |= keep;
-                }
-                const int slot = (ch & 1) * SH_GROUPS + g;
-                s_p[slot * 64 + lane] = make_float4(pw[0], pw[1], pw[2], pw[3]);
-                if (MASKED) {
-                    const bool wany = __builtin_amdgcn_ballot_w64(any) != 0ull;
-                    if (lane == 0) s_any[slot] = wany ? 1 : 0;
-                }
-            };
-            auto consume = [&](const float (&src)[16][CTW], int ch, int hf, auto full_tag) {
-                constexpr bool FULL = decltype(full_tag)::value;
-                if (!FULL && ch * SH_CHUNK + hf * 32 >= len) return;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int g = hf * 4 + q;
-                    if (!FULL && ch * SH_CHUNK + g * 8 >= len) break;         // wave-uniform
-                    const int slot = (ch & 1) * SH_GROUPS + g;
-                    if (MASKED && __builtin_amdgcn_readfirstlane(s_any[slot]) == 0) continue;
-                    const float4 pa = s_p[slot * 64 + lane];
-                    if (BF) {
-                        const bf16x4 ap = pack_bf16(pa.x, pa.y, pa.z, pa.w);
-#pragma unroll
-                        for (int t = 0; t < CTW; ++t)
-                            acc[t] = mfma_32x32x8_bf16(ap, pack_bf16(src[4 * q][t], src[4 * q + 1][t], src[4 * q + 2][t], src[4 * q + 3][t]), acc[t]);
-                        continue;
-                    }
-                    const float pe[4] = {pa.x, pa.y, pa.z, pa.w};
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-#pragma unroll
-                        for (int t = 0; t < CTW; ++t) acc[t] = mfma_32x32x2(pe[e], src[4 * q + e][t], acc[t]);
-                }
-            };
-
-            constexpr std::true_type full{};
-            constexpr std::false_type checked{};
-            float b0[16][CTW], b1[16][CTW];
-            load_half(b0, 0, 0, checked);                      // in flight during staging
-            __syncthreads();                                   // the previous pass is consumed
-#pragma unroll 4
-            for (int idx = threadIdx.x; idx < len; idx += blockDim.x)
-                s_xi[idx] = load_point4(rmi, mi_bytes, (long)mb * a.n_in + jc0 + idx, a.sdim, a.coords_used);
-            __syncthreads();
-            produce(0, 2 * wave, checked);
-            produce(0, 2 * wave + 1, checked);
-            __syncthreads();
-            // chunk ch is consumed from buffer ch & 1 while chunk ch + 1 is formed into the other one.  Steady
-            // state (chunks ch and ch + 1 both complete): ONE basic block per chunk - 32 CTW MFMAs, the 8 weights
-            // per lane of the next chunk, 32 CTW value loads - so the scheduler interleaves them freely
-            const int nfc = fast_ok ? len / SH_CHUNK : 0;      // complete chunks
-            int ch = 0;
-#ifdef PIT_STAMPS
-            unsigned long long t_loop0 = __builtin_amdgcn_s_memtime(), t_bar = 0;
-#endif
-            for (; ch + 1 < nfc; ++ch) {
-                // (the fences keep LDS reads and value loads of a later half from being hoisted over an earlier one -
-                // unfenced, the scheduler front-loads them all and the kernel needs 208 registers; vector ALU and
-                // matrix instructions still move across)
-                load_half(b1, ch, 1, full);
-                produce(ch + 1, 2 * wave, full);
-                consume(b0, ch, 0, full);
-                __builtin_amdgcn_sched_barrier(SH_FENCE);
-                load_half(b0, ch + 1, 0, full);
-                produce(ch + 1, 2 * wave + 1, full);
-                consume(b1, ch, 1, full);
-                __builtin_amdgcn_sched_barrier(SH_FENCE);
-#ifdef PIT_STAMPS
-                const unsigned long long tb = __builtin_amdgcn_s_memtime();
-#endif
-                __syncthreads();
-#ifdef PIT_STAMPS
-                t_bar += __builtin_amdgcn_s_memtime() - tb;
-#endif
-            }
-#ifdef PIT_STAMPS
-            if (bx == 1 && by == 0 && bz == 3 && (threadIdx.x & 63) == 0 && wave < 4) {
-                pit_dbg_stamps[48 + wave * 3] = __builtin_amdgcn_s_memtime() - t_loop0;
-                pit_dbg_stamps[49 + wave * 3] = t_bar;
-                pit_dbg_stamps[50 + wave * 3] = (unsigned long long)ch;
-            }
-#endif
-            for (; ch < nch; ++ch) {                           // the last complete chunk and the ragged one
-                load_half(b1, ch, 1, checked);
-                if (ch + 1 < nch) produce(ch + 1, 2 * wave, checked);
-                consume(b0, ch, 0, checked);
-                if (ch + 1 < nch) { load_half(b0, ch + 1, 0, checked); produce(ch + 1, 2 * wave + 1, checked); }
-                consume(b1, ch, 1, checked);
-                __syncthreads();
-            }
-        }
-    };
-    if (a.periodic != 0) run(std::true_type{}); else run(std::false_type{});
-
-    if (MODE == 1) {
-        // dc_h -= sum acc[n,col] * dO[n,col]   (fp64 accumulation; one atomic per workgroup)
-        const __amdgpu_buffer_rsrc_t rdo = make_rsrc(a.d_out, a.dout_bytes);
-        double part = 0.0;
-#pragma unroll
-        for (int t = 0; t < CTW; ++t) {
-            const unsigned cbase = (unsigned)(((long)cb[t] * a.dout_bstride + a.out_col0 + (long)h * a.dim + cd[t]) * 4);
-            float dov[16];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int nr = n0 + acc_row(i, half);
-                dov[i] = buf_load(rdo, (cvalid[t] && nr < a.n_out) ? cbase + (unsigned)nr * (unsigned)a.ld_dout * 4u : a.dout_bytes);
-            }
-#pragma unroll
-            for (int i = 0; i < 16; ++i) part += (double)acc[t][i] * (double)dov[i];
-        }
-        part = wave_sum_d(part);
-        if (lane == 0) s_red[wave] = part;                 // (s_red is not touched by the loop)
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            double tot = 0.0;
-            for (int w = 0; w < SH_WAVES; ++w) tot += s_red[w];
-            const int slot = (int)((bz + 131u * bx) & (a.nslots - 1));
-            dscale_add(a.dscale_acc + h * PIT_DSCALE_SLOTS + slot, -tot, true);
-        }
-        return;
-    }
-
-    // ---- forward epilogue: row sums over the waves (each formed a quarter of the weights), then every wave
-    // normalises and stores its own tiles straight from the accumulators
-    float iv[CTW][16];
-    if (a.copy_inputs && h == 0) {                         // torch.cat((inputs, conv), -1), pit.py:44: in flight during the reduction
-#pragma unroll
-        for (int t = 0; t < CTW; ++t)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int nr = n0 + acc_row(i, half);
-                iv[t][i] = buf_load(rvals, (cvalid[t] && nr < a.n_out) ? uoff[t] + (unsigned)nr * ld4 : a.values_bytes);
-            }
-    }
-    float* fred = reinterpret_cast<float*>(s_red);
-    rsum += __shfl_xor(rsum, 32);
-    qsum += __shfl_xor(qsum, 32);
-    if (half == 0) { fred[(wave * 2 + 0) * 32 + l31] = rsum; fred[(wave * 2 + 1) * 32 + l31] = qsum; }
-    __syncthreads();
-    float rs_tot = 0.0f, qs_tot = 0.0f;
-#pragma unroll
-    for (int w = 0; w < SH_WAVES; ++w) { rs_tot += fred[(w * 2 + 0) * 32 + l31]; qs_tot += fred[(w * 2 + 1) * 32 + l31]; }
-    const float inv = rs_tot > 0.0f ? 1.0f / rs_tot : 0.0f;
-#pragma unroll
-    for (int t = 0; t < CTW; ++t) {
-        const long obase = (long)cb[t] * a.out_bstride + cd[t];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int r = acc_row(i, half);
-            const int nr = n0 + r;
-            const float v = acc[t][i] * __shfl(inv, r);
-            if (cvalid[t] && nr < a.n_out) {
-                a.out[obase + (long)nr * a.ld_out + a.out_col0 + (long)h * a.dim] = v;
-                if (a.copy_inputs && h == 0) a.out[obase + (long)nr * a.ld_out] = iv[t][i];
-            }
-        }
-    }
-    if (wave == 0 && cg == 0 && half == 0 && nvalid) {
-        float4 st; st.x = T; st.y = s_min; st.z = inv; st.w = qs_tot * inv;
-        *reinterpret_cast<float4*>(a.rowstat + (((long)mb * a.n_head + h) * a.n_out + n) * 4) = st;
-    }
-    if (a.scale_out && wave == 0 && bx == 0 && bz == 0 && lane == 0) a.scale_out[h] = c;
-}
-
-#ifndef SH_MINB
-#define SH_MINB 4
-#endif
-template <int CTW, int MODE, bool MASKED, bool BF>
-__global__ __launch_bounds__(256, SH_MINB) void posatt_rows_shared(AttArgs a) {
-    rows_shared_body<CTW, MODE, MASKED, BF>(a, blockIdx.x, blockIdx.y, blockIdx.z);
-}
-
-template <int CT, int MODE, bool MASKED, bool BF>
+template <int CT, int MODE, bool MASKED, bool BF, bool IL = false>
 __global__ __launch_bounds__(512) void posatt_rows_kernel(AttArgs a) {
-    stagger_entry(a);
-    posatt_rows_body<CT, MODE, MASKED, BF>(a, blockIdx.x, blockIdx.y, blockIdx.z);
+    posatt_rows_body<CT, MODE, MASKED, BF, 0, IL>(a, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
 // ------------------------------------------------------------------------------------
 // cols kernel: d values
 // ------------------------------------------------------------------------------------
-template <int CT, bool MASKED, bool BF, int NPX = 0>
+template <int CT, bool MASKED, bool BF, int NPX = 0, bool IL = false>
 __device__ __forceinline__ void posatt_cols_body(const AttArgs& a, const int bx, const int by, const int bz) {
+    static_assert(!IL || CT == 4, "interleaved tiles are the CT == 4 layout (see posatt_rows_body)");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float4* s_rec = reinterpret_cast<float4*>(smem);                   // [ROW_CHUNK] {xo.xyz, T}
     float2* s_nrm = reinterpret_cast<float2*>(smem + ROW_CHUNK * sizeof(float4));   // [ROW_CHUNK] {S_min, 1/L}
@@ -902,7 +648,7 @@ __device__ __forceinline__ void posatt_cols_body(const AttArgs& a, const int bx,
     int cb[CT], cd[CT];
 #pragma unroll
     for (int t = 0; t < CT; ++t) {
-        const int col = (cg * CT + t) * 32 + l31;
+        const int col = IL ? cg * CT * 32 + l31 * CT + t : (cg * CT + t) * 32 + l31;
         cvalid[t] = col < a.ncols;
         const int cc = cvalid[t] ? col : 0;
         col_split(a, cc, mb, cb[t], cd[t]);
@@ -952,6 +698,12 @@ __device__ __forceinline__ void posatt_cols_body(const AttArgs& a, const int bx,
                         for (int u = 0; u < NP; ++u) {
                             const int koff = 8 * (u / 4) + (BF ? (u % 4) : 2 * (u % 4));
                             const int soff = (nc0 + nn + koff) * (int)ldd4 + (int)hoff4;   // wave-uniform
+                            if (IL) {
+                                const i32x4 q = __builtin_amdgcn_raw_buffer_load_b128(rdout, (int)voff[0], soff, 0);
+                                dst[u][0] = __int_as_float(q.x); dst[u][1 % CT] = __int_as_float(q.y);
+                                dst[u][2 % CT] = __int_as_float(q.z); dst[u][3 % CT] = __int_as_float(q.w);
+                                continue;
+                            }
 #pragma unroll
                             for (int t = 0; t < CT; ++t)
                                 dst[u][t] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rdout, (int)voff[t], soff, 0));
@@ -962,6 +714,13 @@ __device__ __forceinline__ void posatt_cols_body(const AttArgs& a, const int bx,
                             const int nl = nn + 8 * (u / 4) + kpos[u % 4];
                             const bool nv = nl < ne;
                             const unsigned rowoff = (unsigned)(nc0 + nl) * ldd4 + hoff4;
+                            if (IL) {
+                                float q[4];
+                                buf_load4(rdout, (nv && cvalid[0]) ? doff[0] + rowoff : a.dout_bytes, q);
+#pragma unroll
+                                for (int t = 0; t < CT; ++t) dst[u][t] = q[t & 3];
+                                continue;
+                            }
 #pragma unroll
                             for (int t = 0; t < CT; ++t)
                                 dst[u][t] = buf_load(rdout, (nv && cvalid[t]) ? doff[t] + rowoff : a.dout_bytes);
@@ -1023,6 +782,12 @@ __device__ __forceinline__ void posatt_cols_body(const AttArgs& a, const int bx,
                     for (int u = 0; u < NP; ++u) {
                         const int koff = 8 * (u / 4) + (BF ? (u % 4) : 2 * (u % 4));
                         const int soff = (nc0 + nn + koff) * (int)ldd4 + (int)hoff4;
+                        if (IL) {
+                            const i32x4 q = __builtin_amdgcn_raw_buffer_load_b128(rdout, (int)voff[0], soff, 0);
+                            dst[u][0] = __int_as_float(q.x); dst[u][1 % CT] = __int_as_float(q.y);
+                            dst[u][2 % CT] = __int_as_float(q.z); dst[u][3 % CT] = __int_as_float(q.w);
+                            continue;
+                        }
 #pragma unroll
                         for (int t = 0; t < CT; ++t)
                             dst[u][t] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rdout, (int)voff[t], soff, 0));
@@ -1086,7 +851,7 @@ __device__ __forceinline__ void posatt_cols_body(const AttArgs& a, const int bx,
     float extra[1] = {0.0f};
     float* red = reinterpret_cast<float*>(smem);
     __syncthreads();
-    park_tiles<CT, 0>(acc, extra, red, wave, lane);
+    park_tiles<CT, 0, IL>(acc, extra, red, wave, lane);
     __syncthreads();
     const int share = CT * 16 / nwaves;
     const int q0 = wave * share;
@@ -1102,12 +867,36 @@ __device__ __forceinline__ void posatt_cols_body(const AttArgs& a, const int bx,
         for (int u = 0; u < U; ++u)
 #pragma unroll
             for (int w = 0; w < NW; ++w) part[u][w] = red[(long)w * SLOT + (qfirst + u) * 64 + lane];
+        if constexpr (IL && U == 4) {
+            // q = i*CT + t: the four registers of a trip are key i's four adjacent columns - 16-B accesses
+            const int i = qfirst >> 2;
+            const int jr = j0 + acc_row(i, half);
+            const int col0 = cg * CT * 32 + l31 * CT;
+            const bool cv = col0 < a.ncols;
+            int bb, dd;
+            col_split(a, cv ? col0 : 0, mb, bb, dd);
+            const bool okr = cv && jr < a.n_in;
+            float r4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (a.add_residual)                                // self attention: d_out columns [0,dim) of the same row
+                buf_load4(rdout, okr ? (unsigned)(((long)bb * a.dout_bstride + dd) * 4) + (unsigned)jr * ldd4 : a.dout_bytes, r4);
+            float4 v;
+            float* vp = &v.x;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                float sum = 0.0f;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) sum += part[u][w];
+                vp[u] = sum + r4[u];
+            }
+            if (okr) *reinterpret_cast<float4*>(a.d_values + (long)bb * a.dvalues_bstride + (long)jr * a.ld_dvalues + dd) = v;
+            return;
+        }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int q = qfirst + u;
-            const int t = q >> 4, i = q & 15;
+            const int t = IL ? q % CT : q >> 4, i = IL ? q / CT : q & 15;
             const int jr = j0 + acc_row(i, half);
-            const int col = (cg * CT + t) * 32 + l31;
+            const int col = IL ? cg * CT * 32 + l31 * CT + t : (cg * CT + t) * 32 + l31;
             const bool cv = col < a.ncols;
             int bb, dd;
             col_split(a, cv ? col : 0, mb, bb, dd);
@@ -1138,9 +927,9 @@ __device__ __forceinline__ void posatt_cols_body(const AttArgs& a, const int bx,
     }
 }
 
-template <int CT, bool MASKED, bool BF>
+template <int CT, bool MASKED, bool BF, bool IL = false>
 __global__ __launch_bounds__(512) void posatt_cols_kernel(AttArgs a) {
-    posatt_cols_body<CT, MASKED, BF>(a, blockIdx.x, blockIdx.y, blockIdx.z);
+    posatt_cols_body<CT, MASKED, BF, 0, IL>(a, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
 // d(scale) and d(values) of one layer in ONE launch: the two are independent (both read d_out,
@@ -1565,15 +1354,15 @@ __global__ __launch_bounds__(512) void posatt_cols_tiles(AttArgs a) {
 
 // the same merge for 2 / 4 column tiles per workgroup (bigger layers: Elasticity, Vorticity), without
 // the register cap - these bodies need their registers, one workgroup per CU
-template <int CT, bool MASKED, bool BF>
+template <int CT, bool MASKED, bool BF, bool IL = false>
 __global__ __launch_bounds__(512) void posatt_bwd_pair_wide_kernel(AttArgs ar, AttArgs ac, int n_cols_wgs, int cgx, int cgy,
                                                                     int rgx, int rgy) {
     int id = blockIdx.x;
     if (id < n_cols_wgs) {
-        posatt_cols_body<CT, MASKED, BF>(ac, id % cgx, (id / cgx) % cgy, id / (cgx * cgy));
+        posatt_cols_body<CT, MASKED, BF, 0, IL>(ac, id % cgx, (id / cgx) % cgy, id / (cgx * cgy));
     } else {
         id -= n_cols_wgs;
-        posatt_rows_body<CT, 1, MASKED, false>(ar, id % rgx, (id / rgx) % rgy, id / (rgx * rgy));
+        posatt_rows_body<CT, 1, MASKED, false, 0, IL>(ar, id % rgx, (id / rgx) % rgy, id / (rgx * rgy));
     }
 }
 
@@ -1626,6 +1415,20 @@ size_t cols_smem(int ct, int nwaves, int n_out) {
     return stage > red ? stage : red;
 }
 
+// interleaved column tiles (16-B operand loads / result stores): every row a lane touches must be 16-B aligned and
+// a lane's four columns must belong to one sample.  mode 0: forward (values, out), 1: d(scale) (values, d_out),
+// 2: d(values) (d_out, d_values)
+bool interleave_ok(const AttArgs& a, int mode) {
+    static const bool off = getenv("PIT_NO_INTERLEAVE") != nullptr;
+    auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    if (off || a.dim % 4 != 0 || a.ncols % 4 != 0) return false;
+    const bool vals = al(a.values) && a.ld_values % 4 == 0 && a.values_bstride % 4 == 0;
+    const bool dout = al(a.d_out) && a.ld_dout % 4 == 0 && a.dout_bstride % 4 == 0 && a.out_col0 % 4 == 0;
+    if (mode == 0) return vals && al(a.out) && a.ld_out % 4 == 0 && a.out_bstride % 4 == 0 && a.out_col0 % 4 == 0;
+    if (mode == 1) return vals && dout;
+    return dout && al(a.d_values) && a.ld_dvalues % 4 == 0 && a.dvalues_bstride % 4 == 0;
+}
+
 template <int MODE>
 void launch_rows(const AttArgs& a0, hipStream_t s) {
     AttArgs a = a0;
@@ -1658,40 +1461,12 @@ void launch_rows(const AttArgs& a0, hipStream_t s) {
     }
     int ct = choose_ct(a.ncols, (long)n_tiles * a.n_head * a.mesh_batch);
     if (int f = env_int("PIT_FORCE_CT")) ct = f;
-    // weights shared through LDS, waves split the columns: whenever a workgroup has four full column tiles
-    // and a key loop long enough to amortise the chunk barriers
-    {
-        const int mode = env_int("PIT_SHARED_ROWS") ? env_int("PIT_SHARED_ROWS") : 1;      // 1 auto, 2 always, -1 never
-        const int per_mesh_cols = a.ncols;
-        const bool fits = (MODE == 0) || true;
-        if (mode == 2 || (mode == 1 && fits && ct == 4 && per_mesh_cols >= 128 && a.n_in >= 256)) {
-            a.colgroups = (a.ncols + 32 * SH_WAVES - 1) / (32 * SH_WAVES);
-            dim3 grid(a.mesh_batch * a.colgroups, a.n_head, n_tiles), block(64 * SH_WAVES);
-            size_t shm = SH_SMEM;
-            if (int f = env_int("PIT_EXP_SMEM")) shm = std::max(shm, (size_t)f);
-#define PIT_SHR(M_, BF_)                                                                                     \
-    do {                                                                                                      \
-        static bool once = ((void)hipFuncSetAttribute((const void*)posatt_rows_shared<1, MODE, M_, BF_>,      \
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, 131072), true);   \
-        (void)once;                                                                                           \
-        hipLaunchKernelGGL((posatt_rows_shared<1, MODE, M_, BF_>), grid, block, shm, s, a);                   \
-    } while (0)
-            if (a.masked) { if (bf) PIT_SHR(true, (MODE == 0)); else PIT_SHR(true, false); }
-            else { if (bf) PIT_SHR(false, (MODE == 0)); else PIT_SHR(false, false); }
-#undef PIT_SHR
-            return;
-        }
-    }
     a.colgroups = (a.ncols + 32 * ct - 1) / (32 * ct);
     const int wmax = (ct == 4) ? 4 : 8;                                  // parked tiles must fit 96 KiB of LDS
     int nwaves = max(1, min(wmax, pow2_floor(a.n_in / 32)));
     if (int f = env_int("PIT_FORCE_WAVES")) nwaves = pow2_floor(max(1, min(f, wmax)));     // (the epilogue is specialised for 1/2/4/8)
     dim3 grid(a.mesh_batch * a.colgroups, a.n_head, n_tiles), block(64 * nwaves);
-    size_t sm = rows_smem(ct, nwaves, a.n_in);
-    if (int f = env_int("PIT_EXP_SMEM")) sm = std::max(sm, (size_t)f);
-    a.stagger = env_int("PIT_EXP_STAGGER");
-    a.stagger_lo = env_int("PIT_EXP_STAGGER_LO") ? env_int("PIT_EXP_STAGGER_LO") : 256;
-    a.stagger_hi = env_int("PIT_EXP_STAGGER_HI") ? env_int("PIT_EXP_STAGGER_HI") : 512;
+    const size_t sm = rows_smem(ct, nwaves, a.n_in);
 #define PIT_ROWS_BF(CT_, BF_)                                                                               \
     do {                                                                                                    \
         static bool once = ((void)hipFuncSetAttribute((const void*)posatt_rows_kernel<CT_, MODE, true, BF_>,      \
@@ -1703,9 +1478,21 @@ void launch_rows(const AttArgs& a0, hipStream_t s) {
         else hipLaunchKernelGGL((posatt_rows_kernel<CT_, MODE, false, BF_>), grid, block, sm, s, a);        \
     } while (0)
 #define PIT_ROWS(CT_) do { if (bf) PIT_ROWS_BF(CT_, (MODE == 0)); else PIT_ROWS_BF(CT_, false); } while (0)
-    if (ct == 4) PIT_ROWS(4);
+#define PIT_ROWS_IL_BF(BF_)                                                                                 \
+    do {                                                                                                    \
+        static bool once = ((void)hipFuncSetAttribute((const void*)posatt_rows_kernel<4, MODE, true, BF_, true>,  \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, 98304),         \
+                            (void)hipFuncSetAttribute((const void*)posatt_rows_kernel<4, MODE, false, BF_, true>, \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, 98304), true);  \
+        (void)once;                                                                                         \
+        if (a.masked) hipLaunchKernelGGL((posatt_rows_kernel<4, MODE, true, BF_, true>), grid, block, sm, s, a); \
+        else hipLaunchKernelGGL((posatt_rows_kernel<4, MODE, false, BF_, true>), grid, block, sm, s, a);    \
+    } while (0)
+    if (ct == 4 && interleave_ok(a, MODE)) { if (bf) PIT_ROWS_IL_BF((MODE == 0)); else PIT_ROWS_IL_BF(false); }
+    else if (ct == 4) PIT_ROWS(4);
     else if (ct == 2) PIT_ROWS(2);
     else PIT_ROWS(1);
+#undef PIT_ROWS_IL_BF
 #undef PIT_ROWS
 #undef PIT_ROWS_BF
 }
@@ -1749,9 +1536,21 @@ void launch_cols(const AttArgs& a0, hipStream_t s) {
         else hipLaunchKernelGGL((posatt_cols_kernel<CT_, false, BF_>), grid, block, sm, s, a);         \
     } while (0)
 #define PIT_COLS(CT_) do { if (bf) PIT_COLS_BF(CT_, true); else PIT_COLS_BF(CT_, false); } while (0)
-    if (ct == 4) PIT_COLS(4);
+#define PIT_COLS_IL_BF(BF_)                                                                            \
+    do {                                                                                               \
+        static bool once = ((void)hipFuncSetAttribute((const void*)posatt_cols_kernel<4, true, BF_, true>,   \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, 98304),    \
+                            (void)hipFuncSetAttribute((const void*)posatt_cols_kernel<4, false, BF_, true>,  \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, 98304), true); \
+        (void)once;                                                                                    \
+        if (a.masked) hipLaunchKernelGGL((posatt_cols_kernel<4, true, BF_, true>), grid, block, sm, s, a); \
+        else hipLaunchKernelGGL((posatt_cols_kernel<4, false, BF_, true>), grid, block, sm, s, a);     \
+    } while (0)
+    if (ct == 4 && interleave_ok(a, 2)) { if (bf) PIT_COLS_IL_BF(true); else PIT_COLS_IL_BF(false); }
+    else if (ct == 4) PIT_COLS(4);
     else if (ct == 2) PIT_COLS(2);
     else PIT_COLS(1);
+#undef PIT_COLS_IL_BF
 #undef PIT_COLS
 #undef PIT_COLS_BF
 }
@@ -1847,10 +1646,20 @@ bool launch_bwd_pair(const AttArgs& a0, hipStream_t s, const pit_detail::DwPair*
         hipLaunchKernelGGL((posatt_bwd_pair_wide_kernel<CT_, M_, BF_>), grid, block, sm, s, ar, ac, (int)cols_wgs, \
                            ac.colgroups, j_tiles, a0.mesh_batch * ar.colgroups, a0.n_head);                   \
     } while (0)
-#define PIT_PAIR_CT(M_, BF_) do { if (ct == 1) PIT_PAIR_K(M_, BF_); else if (ct == 2) PIT_PAIR_W(2, M_, BF_); else PIT_PAIR_W(4, M_, BF_); } while (0)
+#define PIT_PAIR_IL(M_, BF_)                                                                                  \
+    do {                                                                                                      \
+        static bool once = ((void)hipFuncSetAttribute((const void*)posatt_bwd_pair_wide_kernel<4, M_, BF_, true>,   \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, 98304), true);    \
+        (void)once;                                                                                           \
+        hipLaunchKernelGGL((posatt_bwd_pair_wide_kernel<4, M_, BF_, true>), grid, block, sm, s, ar, ac, (int)cols_wgs, \
+                           ac.colgroups, j_tiles, a0.mesh_batch * ar.colgroups, a0.n_head);                   \
+    } while (0)
+    const bool il = ct == 4 && interleave_ok(a0, 1) && interleave_ok(a0, 2);
+#define PIT_PAIR_CT(M_, BF_) do { if (ct == 1) PIT_PAIR_K(M_, BF_); else if (ct == 2) PIT_PAIR_W(2, M_, BF_); else if (il) PIT_PAIR_IL(M_, BF_); else PIT_PAIR_W(4, M_, BF_); } while (0)
     if (a0.masked) { if (a0.bf16) PIT_PAIR_CT(true, true); else PIT_PAIR_CT(true, false); }
     else { if (a0.bf16) PIT_PAIR_CT(false, true); else PIT_PAIR_CT(false, false); }
 #undef PIT_PAIR_CT
+#undef PIT_PAIR_IL
 #undef PIT_PAIR_W
 #undef PIT_PAIR_K
     return true;
@@ -2344,7 +2153,6 @@ int fill_common(AttArgs& a, const float* mesh_out, const float* mesh_in, int mes
     a.head = head; a.n_head = n_head; a.head_is_scale = head_is_scale;
     a.ncols = (mesh_batch == 1) ? batch * dim : dim;
     a.coord_dims = coord_dims;
-    a.stagger = 0; a.stagger_lo = a.stagger_hi = 0;
     const unsigned long long vb = ((unsigned long long)(batch - 1) * values_bstride +
                                    (unsigned long long)(n_in - 1) * ld_values + (dim - coord_dims)) * 4ull;
     if (vb > PIT_MAX_BUFFER_BYTES) return PIT_ERR_UNSUPPORTED;

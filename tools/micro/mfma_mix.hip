@@ -6,7 +6,7 @@
 #include <cstdio>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-template <bool LOADS, int VALU, bool LDS, bool BARRIER>
+template <int LOADS, int VALU, bool LDS, bool BARRIER>
 __global__ __launch_bounds__(256) void k(float* out, const float* vals, int iters, int ld) {
     __shared__ float4 s_p[8 * 64];
     f32x16 acc;
@@ -14,10 +14,13 @@ __global__ __launch_bounds__(256) void k(float* out, const float* vals, int iter
     const int lane = threadIdx.x & 63;
     for (int i = threadIdx.x; i < 8 * 64; i += 256) s_p[i] = make_float4(i * 0.001f, 0.5f, 0.25f, 0.125f);
     __syncthreads();
-    const float* base = vals + (size_t)(blockIdx.x % 61) * 32 + (lane & 31) + (size_t)(lane >> 5) * ld;
+    // LOADS 1: one dword per MFMA (32 adjacent columns per half-wave); 2: one dwordx4 per 4 MFMAs (4 adjacent columns per lane)
+    const float* base = vals + (LOADS == 2 ? (size_t)(blockIdx.x % 15) * 128 + (lane & 31) * 4 : (size_t)(blockIdx.x % 61) * 32 + (lane & 31)) + (size_t)(lane >> 5) * ld;
     float x = lane * 0.01f, y = 0.3f, z = 0.f;
     float b[32];
-    for (int u = 0; u < 32; ++u) b[u] = LOADS ? base[(size_t)(2 * u) * ld] : x + u;
+    for (int u = 0; u < 32; ++u) b[u] = LOADS == 1 ? base[(size_t)(2 * u) * ld] : x + u;
+    if (LOADS == 2)
+        for (int g = 0; g < 8; ++g) { const float4 q = *reinterpret_cast<const float4*>(base + (size_t)(2 * g) * ld); b[4 * g] = q.x; b[4 * g + 1] = q.y; b[4 * g + 2] = q.z; b[4 * g + 3] = q.w; }
     for (int it = 0; it < iters; ++it) {
         float nb[32];
         const float* row = base + (size_t)((it + 1) & 15) * 64 * ld;
@@ -25,10 +28,11 @@ __global__ __launch_bounds__(256) void k(float* out, const float* vals, int iter
         for (int g = 0; g < 8; ++g) {
             float4 pa = LDS ? s_p[g * 64 + lane] : make_float4(x, y, x, y);
             const float pe[4] = {pa.x, pa.y, pa.z, pa.w};
+            if (LOADS == 2) { const float4 q = *reinterpret_cast<const float4*>(row + (size_t)(2 * g) * ld); nb[4 * g] = q.x; nb[4 * g + 1] = q.y; nb[4 * g + 2] = q.z; nb[4 * g + 3] = q.w; }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int u = g * 4 + e;
-                if (LOADS) nb[u] = row[(size_t)(2 * u) * ld];
+                if (LOADS == 1) nb[u] = row[(size_t)(2 * u) * ld];
 #pragma unroll
                 for (int v = 0; v < VALU; ++v) { z = z * 1.0001f + x; x = x * 0.9999f + (v & 1 ? y : z); }
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pe[e] + (VALU ? z : 0.f), b[u], acc, 0, 0, 0);
@@ -45,7 +49,7 @@ __global__ __launch_bounds__(256) void k(float* out, const float* vals, int iter
     if (s == 12345.678f) out[0] = s;
 }
 
-template <bool LOADS, int VALU, bool LDS, bool BARRIER>
+template <int LOADS, int VALU, bool LDS, bool BARRIER>
 void run(const char* name, int wgs_per_cu, const float* vals, int ld) {
     float* out; (void)hipMalloc(&out, 4);
     const int iters = 400, grid = 256 * wgs_per_cu;
@@ -65,18 +69,18 @@ int main() {
     const int ld = 256, rows = 64 * 16 + 64;
     float* vals; (void)hipMalloc(&vals, (size_t)rows * ld * 4 + 4096 * 4); (void)hipMemset(vals, 0, (size_t)rows * ld * 4 + 4096 * 4);
     for (int w : {1, 2, 4}) {
-        if (w == 1) { run<false, 0, false, false>("bare", 1, vals, ld); run<true, 0, false, false>("+ global dword per MFMA (B operand)", 1, vals, ld);
-                      run<false, 6, false, false>("+ 12 VALU per MFMA", 1, vals, ld); run<false, 3, false, false>("+ 6 VALU per MFMA", 1, vals, ld);
-                      run<false, 0, true, false>("+ LDS b128 per 4 MFMAs", 1, vals, ld); run<false, 0, false, true>("+ barrier per 32 MFMAs", 1, vals, ld);
-                      run<true, 3, true, true>("all (6 VALU)", 1, vals, ld); }
-        if (w == 2) { run<false, 0, false, false>("bare", 2, vals, ld); run<true, 0, false, false>("+ global dword per MFMA (B operand)", 2, vals, ld);
-                      run<false, 6, false, false>("+ 12 VALU per MFMA", 2, vals, ld); run<false, 3, false, false>("+ 6 VALU per MFMA", 2, vals, ld);
-                      run<false, 0, true, false>("+ LDS b128 per 4 MFMAs", 2, vals, ld); run<false, 0, false, true>("+ barrier per 32 MFMAs", 2, vals, ld);
-                      run<true, 3, true, true>("all (6 VALU)", 2, vals, ld); }
-        if (w == 4) { run<false, 0, false, false>("bare", 4, vals, ld); run<true, 0, false, false>("+ global dword per MFMA (B operand)", 4, vals, ld);
-                      run<false, 6, false, false>("+ 12 VALU per MFMA", 4, vals, ld); run<false, 3, false, false>("+ 6 VALU per MFMA", 4, vals, ld);
-                      run<false, 0, true, false>("+ LDS b128 per 4 MFMAs", 4, vals, ld); run<false, 0, false, true>("+ barrier per 32 MFMAs", 4, vals, ld);
-                      run<true, 3, true, true>("all (6 VALU)", 4, vals, ld); }
+        if (w == 1) { run<0, 0, false, false>("bare", 1, vals, ld); run<1, 0, false, false>("+ global dword per MFMA (B operand)", 1, vals, ld);
+                      run<0, 6, false, false>("+ 12 VALU per MFMA", 1, vals, ld); run<0, 3, false, false>("+ 6 VALU per MFMA", 1, vals, ld);
+                      run<0, 0, true, false>("+ LDS b128 per 4 MFMAs", 1, vals, ld); run<0, 0, false, true>("+ barrier per 32 MFMAs", 1, vals, ld);
+                      run<1, 3, true, true>("all (6 VALU)", 1, vals, ld); run<2, 0, false, false>("+ global dwordx4 per 4 MFMAs", 1, vals, ld); run<2, 3, true, true>("all, dwordx4 loads (6 VALU)", 1, vals, ld); run<2, 2, true, true>("all, dwordx4 loads (4 VALU)", 1, vals, ld); }
+        if (w == 2) { run<0, 0, false, false>("bare", 2, vals, ld); run<1, 0, false, false>("+ global dword per MFMA (B operand)", 2, vals, ld);
+                      run<0, 6, false, false>("+ 12 VALU per MFMA", 2, vals, ld); run<0, 3, false, false>("+ 6 VALU per MFMA", 2, vals, ld);
+                      run<0, 0, true, false>("+ LDS b128 per 4 MFMAs", 2, vals, ld); run<0, 0, false, true>("+ barrier per 32 MFMAs", 2, vals, ld);
+                      run<1, 3, true, true>("all (6 VALU)", 2, vals, ld); run<2, 0, false, false>("+ global dwordx4 per 4 MFMAs", 2, vals, ld); run<2, 3, true, true>("all, dwordx4 loads (6 VALU)", 2, vals, ld); run<2, 2, true, true>("all, dwordx4 loads (4 VALU)", 2, vals, ld); }
+        if (w == 4) { run<0, 0, false, false>("bare", 4, vals, ld); run<1, 0, false, false>("+ global dword per MFMA (B operand)", 4, vals, ld);
+                      run<0, 6, false, false>("+ 12 VALU per MFMA", 4, vals, ld); run<0, 3, false, false>("+ 6 VALU per MFMA", 4, vals, ld);
+                      run<0, 0, true, false>("+ LDS b128 per 4 MFMAs", 4, vals, ld); run<0, 0, false, true>("+ barrier per 32 MFMAs", 4, vals, ld);
+                      run<1, 3, true, true>("all (6 VALU)", 4, vals, ld); run<2, 0, false, false>("+ global dwordx4 per 4 MFMAs", 4, vals, ld); run<2, 3, true, true>("all, dwordx4 loads (6 VALU)", 4, vals, ld); run<2, 2, true, true>("all, dwordx4 loads (4 VALU)", 4, vals, ld); }
     }
     return 0;
 }
