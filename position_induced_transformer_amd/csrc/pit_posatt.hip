@@ -1716,8 +1716,11 @@ __device__ __forceinline__ void sparse_rows_body(const AttArgs& a, const SparseA
     // train_darcy.py:51-55, is never materialised): channel cd < coord_dims of a value row IS coordinate cd of that
     // key, read from mesh_in; the remaining channels come from `values`, which then holds dim - coord_dims channels
     const int kd = a.coord_dims;
-    unsigned uoff[CR], coff[CR];
-    bool cvalid[CR], ccoord[CR];
+    // (nothing of the coordinate path may stay live across the key loop when kd == 0: two more per-column arrays
+    // took the 8-columns-per-lane instantiation from 4 to 3 waves per SIMD - measured +27 % on the batch-256
+    // up-projection - so the coordinate offsets are re-derived inside the `if (kd)` block)
+    unsigned uoff[CR];
+    bool cvalid[CR], vload[CR];
     int cb[CR], cd[CR];
 #pragma unroll
     for (int r = 0; r < CR; ++r) {
@@ -1725,9 +1728,8 @@ __device__ __forceinline__ void sparse_rows_body(const AttArgs& a, const SparseA
         cvalid[r] = col < a.ncols;
         const int cc = cvalid[r] ? col : 0;
         col_split(a, cc, mb, cb[r], cd[r]);
-        ccoord[r] = cd[r] < kd;
+        vload[r] = cvalid[r] && cd[r] >= kd;                 // this column is read from `values`
         uoff[r] = (unsigned)(((long)cb[r] * a.values_bstride + (cd[r] - kd)) * 4);
-        coff[r] = (unsigned)(((long)mb * a.n_in * a.sdim + cd[r]) * 4);
     }
     float acc[NH][CR];
     float rsum[NH], qsum[NH];
@@ -1782,13 +1784,16 @@ __device__ __forceinline__ void sparse_rows_body(const AttArgs& a, const SparseA
             for (int g = 0; g < G; ++g)
 #pragma unroll
                 for (int r = 0; r < CR; ++r)
-                    v[g][r] = buf_load(rvals, (ji[g] >= 0 && cvalid[r] && !ccoord[r]) ? uoff[r] + (unsigned)ji[g] * ld4 : a.values_bytes);
+                    v[g][r] = buf_load(rvals, (ji[g] >= 0 && vload[r]) ? uoff[r] + (unsigned)ji[g] * ld4 : a.values_bytes);
             if (kd) {                              // wave-uniform: the coordinate channels of these keys (an out-of-range load adds 0)
 #pragma unroll
-                for (int g = 0; g < G; ++g)
+                for (int r = 0; r < CR; ++r) {
+                    const bool cc = cvalid[r] && cd[r] < kd;
+                    const unsigned coff = (unsigned)(((long)mb * a.n_in * a.sdim + cd[r]) * 4);
 #pragma unroll
-                    for (int r = 0; r < CR; ++r)
-                        v[g][r] += buf_load(rmi, (ji[g] >= 0 && cvalid[r] && ccoord[r]) ? coff[r] + (unsigned)ji[g] * (unsigned)a.sdim * 4u : mi_bytes);
+                    for (int g = 0; g < G; ++g)
+                        v[g][r] += buf_load(rmi, (ji[g] >= 0 && cc) ? coff + (unsigned)ji[g] * (unsigned)a.sdim * 4u : mi_bytes);
+                }
             }
 #pragma unroll
             for (int g = 0; g < G; ++g)
@@ -1841,7 +1846,7 @@ __device__ __forceinline__ void sparse_rows_body(const AttArgs& a, const SparseA
 }
 
 template <int NH, int CR, int MODE>
-__global__ __launch_bounds__(256) void posatt_sparse_rows(AttArgs a, SparseArgs sp) {
+__global__ __launch_bounds__(256, 4) void posatt_sparse_rows(AttArgs a, SparseArgs sp) {
     sparse_rows_body<NH, CR, MODE>(a, sp, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
@@ -1859,7 +1864,7 @@ __device__ __forceinline__ bool xcd_remap(int id, int gx, int gy, int& bx, int& 
     return by < gy;
 }
 template <int NH, int CR, int MODE>
-__global__ __launch_bounds__(256) void posatt_sparse_rows_x(AttArgs a, SparseArgs sp, int gx, int gy) {
+__global__ __launch_bounds__(256, 4) void posatt_sparse_rows_x(AttArgs a, SparseArgs sp, int gx, int gy) {
     int bx, by, bz;
     if (!xcd_remap((int)blockIdx.x, gx, gy, bx, by, bz)) return;
     sparse_rows_body<NH, CR, MODE>(a, sp, bx, by, bz);
@@ -2038,7 +2043,7 @@ int cr_for(int ncols, long units) {
 
 // d(scale) of a candidate-list layer with a postponed MLP's weight-gradient reductions in the same launch
 template <int NH, int CR>
-__global__ __launch_bounds__(256) void posatt_sparse_rows_dw(AttArgs a, SparseArgs sp, int gx, int gy, int n_att,
+__global__ __launch_bounds__(256, 4) void posatt_sparse_rows_dw(AttArgs a, SparseArgs sp, int gx, int gy, int n_att,
                                                               pit_detail::DwPair w) {
     const int id = blockIdx.x;
     if (id >= n_att) {

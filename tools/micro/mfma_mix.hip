@@ -6,7 +6,7 @@
 #include <cstdio>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-template <int LOADS, int VALU, bool LDS, bool BARRIER>
+template <int LOADS, int VALU, int LDS, bool BARRIER>
 __global__ __launch_bounds__(256) void k(float* out, const float* vals, int iters, int ld) {
     __shared__ float4 s_p[8 * 64];
     f32x16 acc;
@@ -26,7 +26,9 @@ __global__ __launch_bounds__(256) void k(float* out, const float* vals, int iter
         const float* row = base + (size_t)((it + 1) & 15) * 64 * ld;
 #pragma unroll
         for (int g = 0; g < 8; ++g) {
-            float4 pa = LDS ? s_p[g * 64 + lane] : make_float4(x, y, x, y);
+            float4 pa = LDS == 1 ? s_p[g * 64 + lane] : make_float4(x, y, x, y);
+            const float* sp = reinterpret_cast<const float*>(s_p);
+            if (LDS == 2) { pa.x = sp[(g * 4 + 0) * 64 + lane]; pa.y = sp[(g * 4 + 1) * 64 + lane]; pa.z = sp[(g * 4 + 2) * 64 + lane]; pa.w = sp[(g * 4 + 3) * 64 + lane]; }   // a b32 read per MFMA
             const float pe[4] = {pa.x, pa.y, pa.z, pa.w};
             if (LOADS == 2) { const float4 q = *reinterpret_cast<const float4*>(row + (size_t)(2 * g) * ld); nb[4 * g] = q.x; nb[4 * g + 1] = q.y; nb[4 * g + 2] = q.z; nb[4 * g + 3] = q.w; }
 #pragma unroll
@@ -49,7 +51,7 @@ __global__ __launch_bounds__(256) void k(float* out, const float* vals, int iter
     if (s == 12345.678f) out[0] = s;
 }
 
-template <int LOADS, int VALU, bool LDS, bool BARRIER>
+template <int LOADS, int VALU, int LDS, bool BARRIER>
 void run(const char* name, int wgs_per_cu, const float* vals, int ld) {
     float* out; (void)hipMalloc(&out, 4);
     const int iters = 400, grid = 256 * wgs_per_cu;
@@ -69,18 +71,18 @@ int main() {
     const int ld = 256, rows = 64 * 16 + 64;
     float* vals; (void)hipMalloc(&vals, (size_t)rows * ld * 4 + 4096 * 4); (void)hipMemset(vals, 0, (size_t)rows * ld * 4 + 4096 * 4);
     for (int w : {1, 2, 4}) {
-        if (w == 1) { run<0, 0, false, false>("bare", 1, vals, ld); run<1, 0, false, false>("+ global dword per MFMA (B operand)", 1, vals, ld);
-                      run<0, 6, false, false>("+ 12 VALU per MFMA", 1, vals, ld); run<0, 3, false, false>("+ 6 VALU per MFMA", 1, vals, ld);
-                      run<0, 0, true, false>("+ LDS b128 per 4 MFMAs", 1, vals, ld); run<0, 0, false, true>("+ barrier per 32 MFMAs", 1, vals, ld);
-                      run<1, 3, true, true>("all (6 VALU)", 1, vals, ld); run<2, 0, false, false>("+ global dwordx4 per 4 MFMAs", 1, vals, ld); run<2, 3, true, true>("all, dwordx4 loads (6 VALU)", 1, vals, ld); run<2, 2, true, true>("all, dwordx4 loads (4 VALU)", 1, vals, ld); }
-        if (w == 2) { run<0, 0, false, false>("bare", 2, vals, ld); run<1, 0, false, false>("+ global dword per MFMA (B operand)", 2, vals, ld);
-                      run<0, 6, false, false>("+ 12 VALU per MFMA", 2, vals, ld); run<0, 3, false, false>("+ 6 VALU per MFMA", 2, vals, ld);
-                      run<0, 0, true, false>("+ LDS b128 per 4 MFMAs", 2, vals, ld); run<0, 0, false, true>("+ barrier per 32 MFMAs", 2, vals, ld);
-                      run<1, 3, true, true>("all (6 VALU)", 2, vals, ld); run<2, 0, false, false>("+ global dwordx4 per 4 MFMAs", 2, vals, ld); run<2, 3, true, true>("all, dwordx4 loads (6 VALU)", 2, vals, ld); run<2, 2, true, true>("all, dwordx4 loads (4 VALU)", 2, vals, ld); }
-        if (w == 4) { run<0, 0, false, false>("bare", 4, vals, ld); run<1, 0, false, false>("+ global dword per MFMA (B operand)", 4, vals, ld);
-                      run<0, 6, false, false>("+ 12 VALU per MFMA", 4, vals, ld); run<0, 3, false, false>("+ 6 VALU per MFMA", 4, vals, ld);
-                      run<0, 0, true, false>("+ LDS b128 per 4 MFMAs", 4, vals, ld); run<0, 0, false, true>("+ barrier per 32 MFMAs", 4, vals, ld);
-                      run<1, 3, true, true>("all (6 VALU)", 4, vals, ld); run<2, 0, false, false>("+ global dwordx4 per 4 MFMAs", 4, vals, ld); run<2, 3, true, true>("all, dwordx4 loads (6 VALU)", 4, vals, ld); run<2, 2, true, true>("all, dwordx4 loads (4 VALU)", 4, vals, ld); }
+        if (w == 1) { run<0, 0, 0, false>("bare", 1, vals, ld); run<1, 0, 0, false>("+ global dword per MFMA (B operand)", 1, vals, ld);
+                      run<0, 6, 0, false>("+ 12 VALU per MFMA", 1, vals, ld); run<0, 3, 0, false>("+ 6 VALU per MFMA", 1, vals, ld);
+                      run<0, 0, 1, false>("+ LDS b128 per 4 MFMAs", 1, vals, ld); run<0, 0, 2, false>("+ LDS b32 per MFMA", 1, vals, ld); run<2, 1, 2, true>("dwordx4 loads, 2 VALU, LDS b32 per MFMA", 1, vals, ld); run<2, 1, 1, true>("dwordx4 loads, 2 VALU, LDS b128 per 4", 1, vals, ld); run<0, 0, 0, true>("+ barrier per 32 MFMAs", 1, vals, ld);
+                      run<1, 3, 1, true>("all (6 VALU)", 1, vals, ld); run<2, 0, 0, false>("+ global dwordx4 per 4 MFMAs", 1, vals, ld); run<2, 3, 1, true>("all, dwordx4 loads (6 VALU)", 1, vals, ld); run<2, 2, 1, true>("all, dwordx4 loads (4 VALU)", 1, vals, ld); }
+        if (w == 2) { run<0, 0, 0, false>("bare", 2, vals, ld); run<1, 0, 0, false>("+ global dword per MFMA (B operand)", 2, vals, ld);
+                      run<0, 6, 0, false>("+ 12 VALU per MFMA", 2, vals, ld); run<0, 3, 0, false>("+ 6 VALU per MFMA", 2, vals, ld);
+                      run<0, 0, 1, false>("+ LDS b128 per 4 MFMAs", 2, vals, ld); run<0, 0, 2, false>("+ LDS b32 per MFMA", 2, vals, ld); run<2, 1, 2, true>("dwordx4 loads, 2 VALU, LDS b32 per MFMA", 2, vals, ld); run<2, 1, 1, true>("dwordx4 loads, 2 VALU, LDS b128 per 4", 2, vals, ld); run<0, 0, 0, true>("+ barrier per 32 MFMAs", 2, vals, ld);
+                      run<1, 3, 1, true>("all (6 VALU)", 2, vals, ld); run<2, 0, 0, false>("+ global dwordx4 per 4 MFMAs", 2, vals, ld); run<2, 3, 1, true>("all, dwordx4 loads (6 VALU)", 2, vals, ld); run<2, 2, 1, true>("all, dwordx4 loads (4 VALU)", 2, vals, ld); }
+        if (w == 4) { run<0, 0, 0, false>("bare", 4, vals, ld); run<1, 0, 0, false>("+ global dword per MFMA (B operand)", 4, vals, ld);
+                      run<0, 6, 0, false>("+ 12 VALU per MFMA", 4, vals, ld); run<0, 3, 0, false>("+ 6 VALU per MFMA", 4, vals, ld);
+                      run<0, 0, 1, false>("+ LDS b128 per 4 MFMAs", 4, vals, ld); run<0, 0, 2, false>("+ LDS b32 per MFMA", 4, vals, ld); run<2, 1, 2, true>("dwordx4 loads, 2 VALU, LDS b32 per MFMA", 4, vals, ld); run<2, 1, 1, true>("dwordx4 loads, 2 VALU, LDS b128 per 4", 4, vals, ld); run<0, 0, 0, true>("+ barrier per 32 MFMAs", 4, vals, ld);
+                      run<1, 3, 1, true>("all (6 VALU)", 4, vals, ld); run<2, 0, 0, false>("+ global dwordx4 per 4 MFMAs", 4, vals, ld); run<2, 3, 1, true>("all, dwordx4 loads (6 VALU)", 4, vals, ld); run<2, 2, 1, true>("all, dwordx4 loads (4 VALU)", 4, vals, ld); }
     }
     return 0;
 }
