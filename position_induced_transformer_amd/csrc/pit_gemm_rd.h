@@ -32,8 +32,10 @@ struct GemmArgs {
 // workgroups [0, n1) run g1 on a (gx1, gy1, .) grid, [n1, n1 + n2) run g2
 struct DwPair { GemmArgs g1, g2; int n1, n2, gx1, gy1, gx2, gy2; };
 
-// fills `out` and returns true when the job is small enough to ride along in another launch (pit_mlp.hip)
-bool plan_dw_pair(const pit_mlp_params_job& job, DwPair* out);
+// fills `out` and returns true when the job is small enough to ride along in another launch (pit_mlp.hip);
+// `waves` = waves per workgroup of the carrying launch (the row slabs are sized so that a wave reduces as many rows
+// as in the reductions' own 8-wave launch)
+bool plan_dw_pair(const pit_mlp_params_job& job, int waves, DwPair* out);
 
 }  // namespace pit_detail
 

@@ -1057,9 +1057,12 @@ int prepare_gemm(GemmArgs& g, GemmLaunch& L, int force_tn = 0, int force_waves =
     // (row-reducing) GEMMs, sized so the launch has a few hundred workgroups
     int splits = 1;
     if (g.atomic) {
-        splits = std::max(1, std::min((g.K + 127) / 128, (768 + tiles - 1) / tiles));
+        // (fewer waves per workgroup than the usual 8 - a carrying launch with 256-thread workgroups: proportionally
+        // shorter slabs, so that a wave's share of the rows, the critical path, stays what it is with 8)
+        const int wscale = (force_waves > 0 && force_waves < 8) ? 8 / force_waves : 1;
+        splits = std::max(1, std::min((g.K + 127) / 128, (768 * wscale + tiles - 1) / tiles));
         // every split costs one fp32 atomic per output element: long reductions keep slabs >= 512
-        if (g.K > 4096) splits = std::max(1, std::min(splits, g.K / 512));
+        if (g.K > 4096) splits = std::max(1, std::min(splits, g.K * wscale / 512));
     }
     int slab = (g.K + splits - 1) / splits;
     slab = ((slab + 7) / 8) * 8;
@@ -1201,7 +1204,7 @@ int launch_dz1(int rows, int n1, int n2, const float* w2, const float* z1, const
 
 // the reductions of a postponed pit_mlp_bwd_params, laid out for a launch that carries them along
 // (pit_posatt.hip: posatt_bwd_pair_dw_kernel); same tiling as launch_gemm_pair_atomic
-bool pit_detail::plan_dw_pair(const pit_mlp_params_job& j, DwPair* out) {
+bool pit_detail::plan_dw_pair(const pit_mlp_params_job& j, int waves, DwPair* out) {
     static const bool off = getenv("PIT_NO_DW_RIDER") != nullptr;
     if (off || !j.accumulate) return false;
     if (!j.x || !j.h || !j.d_y || !j.d_w1 || !j.d_b1 || !j.d_w2 || !j.d_b2 || !j.scratch) return false;
@@ -1214,7 +1217,8 @@ bool pit_detail::plan_dw_pair(const pit_mlp_params_job& j, DwPair* out) {
     const int saved = t_call_math;
     t_call_math = j.math_mode;
     GemmLaunch L1, L2;
-    const bool ok = prepare_gemm(out->g1, L1, 1, 8) == 0 && prepare_gemm(out->g2, L2, 1, 8) == 0;
+    const int fw = waves >= 8 ? 8 : (waves >= 4 ? 4 : 2);
+    const bool ok = prepare_gemm(out->g1, L1, 1, fw) == 0 && prepare_gemm(out->g2, L2, 1, fw) == 0;
     t_call_math = saved;
     if (!ok) return false;
     out->n1 = L1.grid.x * L1.grid.y * L1.grid.z; out->n2 = L2.grid.x * L2.grid.y * L2.grid.z;

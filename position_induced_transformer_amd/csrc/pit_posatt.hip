@@ -1587,7 +1587,7 @@ __global__ __launch_bounds__(512, 4) void posatt_bwd_pair_dw_kernel(AttArgs ar, 
 }
 
 // `rider` (may be null) is carried along when the narrow-tile kernel is the one chosen; *rider_done says so
-bool launch_bwd_pair(const AttArgs& a0, hipStream_t s, const pit_detail::DwPair* rider = nullptr, bool* rider_done = nullptr) {
+bool launch_bwd_pair(const AttArgs& a0, hipStream_t s, const pit_mlp_params_job* job = nullptr, bool* rider_done = nullptr) {
     if (env_int("PIT_NO_BWD_PAIR") || env_int("PIT_FORCE_CT") || env_int("PIT_FORCE_WAVES")) return false;
     const int n_tiles = (a0.n_out + 31) / 32, j_tiles = (a0.n_in + 31) / 32;
     {   // either part would take the large-regime kernels: keep them separate
@@ -1612,7 +1612,9 @@ bool launch_bwd_pair(const AttArgs& a0, hipStream_t s, const pit_detail::DwPair*
     if (rows_wgs + cols_wgs > 4096 || rows_wgs + cols_wgs > 0x7fffffffL) return false;
     const size_t sm = std::max(rows_smem(ct, nwaves, a0.n_in), cols_smem(ct, nwaves, a0.n_out));
     dim3 grid((unsigned)(rows_wgs + cols_wgs)), block(64 * nwaves);
-    if (rider && ct == 1 && nwaves >= 2) {
+    pit_detail::DwPair dw;
+    const pit_detail::DwPair* rider = &dw;
+    if (job && ct == 1 && nwaves >= 2 && pit_detail::plan_dw_pair(*job, nwaves, &dw)) {
         const int n_att = (int)(rows_wgs + cols_wgs);
         const size_t smw = std::max(sm, (size_t)nwaves * 16 * 64 * sizeof(float));
         dim3 gridw((unsigned)(n_att + rider->n1 + rider->n2));
@@ -2019,12 +2021,16 @@ __global__ __launch_bounds__(256) void posatt_sparse_overflow_cols(AttArgs a, Sp
 // must come after the plain stores of the key-owning waves.
 template <int NH, int CRR, int CRC>
 __global__ __launch_bounds__(256) void posatt_sparse_bwd_kernel(AttArgs a, SparseArgs sp, int n_cols, int cgx,
-                                                                 int rgx, int rgy, int n_att, pit_detail::DwPair w) {
+                                                                 int rgx, int rgy, int n_dw, pit_detail::DwPair w) {
+    // a postponed MLP's weight-gradient reductions (pit_hip.h: rider) take the FIRST n_dw workgroup ids: this launch
+    // has more workgroups than the chip holds at once, and reductions dispatched after the first wave of attention
+    // workgroups would start when those drain - their ~10 us dependent chain appended instead of overlapped
     int id = blockIdx.x;
-    if (id >= n_att) {                                   // a postponed MLP's weight-gradient reductions (pit_hip.h: rider)
-        dw_pair_body(w, id - n_att);
+    if (id < n_dw) {
+        dw_pair_body(w, id);
         return;
     }
+    id -= n_dw;
     if (id < n_cols) {
         sparse_cols_body<CRC>(a, sp, id % cgx, id / cgx);
     } else {
@@ -2043,30 +2049,33 @@ int cr_for(int ncols, long units) {
 
 // d(scale) of a candidate-list layer with a postponed MLP's weight-gradient reductions in the same launch
 template <int NH, int CR>
-__global__ __launch_bounds__(256, 4) void posatt_sparse_rows_dw(AttArgs a, SparseArgs sp, int gx, int gy, int n_att,
+__global__ __launch_bounds__(256, 4) void posatt_sparse_rows_dw(AttArgs a, SparseArgs sp, int gx, int gy, int n_dw,
                                                               pit_detail::DwPair w) {
-    const int id = blockIdx.x;
-    if (id >= n_att) {
-        dw_pair_body(w, id - n_att);
+    int id = blockIdx.x;
+    if (id < n_dw) {                                     // (first: see posatt_sparse_bwd_kernel)
+        dw_pair_body(w, id);
         return;
     }
+    id -= n_dw;
     sparse_rows_body<NH, CR, 1>(a, sp, id % gx, (id / gx) % gy, id / (gx * gy));
 }
 
 constexpr size_t DW_SMEM_4WAVES = 4 * 16 * 64 * sizeof(float);   // gemm_rd_body's parking area, 256-thread workgroups
 
 template <int MODE>
-void launch_sparse_rows(const AttArgs& a, const SparseArgs& sp, hipStream_t s, const pit_detail::DwPair* rider = nullptr,
+void launch_sparse_rows(const AttArgs& a, const SparseArgs& sp, hipStream_t s, const pit_mlp_params_job* job = nullptr,
                         bool* rider_done = nullptr) {
     const int nh = (a.n_head % 2 == 0) ? 2 : 1;
     const long rows = (long)a.mesh_batch * a.n_out;
     const int cr = cr_for(a.ncols, rows * (a.n_head / nh));
     dim3 grid((unsigned)((rows + 3) / 4), (a.ncols + 64 * cr - 1) / (64 * cr), a.n_head / nh), block(256);
-    if (MODE == 1 && rider && (long)grid.x * grid.y * grid.z <= 16384) {       // small launch: carry the reductions
+    pit_detail::DwPair dw;
+    const pit_detail::DwPair* rider = &dw;
+    if (MODE == 1 && job && (long)grid.x * grid.y * grid.z <= 16384 && pit_detail::plan_dw_pair(*job, 4, &dw)) {   // small launch: carry the reductions
         const int n_att = (int)(grid.x * grid.y * grid.z);
         dim3 gridw((unsigned)(n_att + rider->n1 + rider->n2));
 #define PIT_SRW(NH_, CR_) hipLaunchKernelGGL((posatt_sparse_rows_dw<NH_, CR_>), gridw, block, DW_SMEM_4WAVES, s, a, sp, \
-                                             (int)grid.x, (int)grid.y, n_att, *rider)
+                                             (int)grid.x, (int)grid.y, rider->n1 + rider->n2, *rider)
 #define PIT_SRW_CR(NH_) do { if (cr == 8) PIT_SRW(NH_, 8); else if (cr == 4) PIT_SRW(NH_, 4); else if (cr == 2) PIT_SRW(NH_, 2); else PIT_SRW(NH_, 1); } while (0)
         if (nh == 2) PIT_SRW_CR(2); else PIT_SRW_CR(1);
 #undef PIT_SRW_CR
@@ -2092,7 +2101,7 @@ void launch_sparse_rows(const AttArgs& a, const SparseArgs& sp, hipStream_t s, c
 // the parts' columns-per-lane are a combination that is not instantiated (caller launches the
 // parts separately)
 bool launch_sparse_bwd_pair(const AttArgs& a, const SparseArgs& sp, bool complete, hipStream_t s,
-                            const pit_detail::DwPair* rider = nullptr, bool* rider_done = nullptr) {
+                            const pit_mlp_params_job* job = nullptr, bool* rider_done = nullptr) {
     if (env_int("PIT_NO_BWD_PAIR")) return false;
     const int nh = (a.n_head % 2 == 0) ? 2 : 1;
     const long rows = (long)a.mesh_batch * a.n_out, keys = (long)a.mesh_batch * a.n_in;
@@ -2104,11 +2113,13 @@ bool launch_sparse_bwd_pair(const AttArgs& a, const SparseArgs& sp, bool complet
     const long n_rows = rgx * rblocks * (a.n_head / nh), n_cols = cgx * cblocks;
     if (n_rows + n_cols > 16384) return false;            // big launches gain nothing from merging
     const int n_att = (int)(n_rows + n_cols);
+    pit_detail::DwPair dw;
+    const pit_detail::DwPair* rider = (job && !env_int("PIT_NO_LIST_PAIR_RIDER") && pit_detail::plan_dw_pair(*job, 4, &dw)) ? &dw : nullptr;
     static const pit_detail::DwPair no_rider{};
     dim3 grid((unsigned)(n_att + (rider ? rider->n1 + rider->n2 : 0))), block(256);
     const size_t sm = rider ? DW_SMEM_4WAVES : 0;
     const pit_detail::DwPair& w = rider ? *rider : no_rider;
-#define PIT_SB(NH_, CRR_, CRC_) hipLaunchKernelGGL((posatt_sparse_bwd_kernel<NH_, CRR_, CRC_>), grid, block, sm, s, a, sp, (int)n_cols, (int)cgx, (int)rgx, rblocks, n_att, w)
+#define PIT_SB(NH_, CRR_, CRC_) hipLaunchKernelGGL((posatt_sparse_bwd_kernel<NH_, CRR_, CRC_>), grid, block, sm, s, a, sp, (int)n_cols, (int)cgx, (int)rgx, rblocks, rider ? rider->n1 + rider->n2 : 0, w)
 #define PIT_SB_C(NH_, CRR_) do { if (crc == CRR_) PIT_SB(NH_, CRR_, CRR_); else PIT_SB(NH_, CRR_, 1); } while (0)
 #define PIT_SB_CR(NH_) do { if (crr == 8) PIT_SB_C(NH_, 8); else if (crr == 4) PIT_SB_C(NH_, 4); else if (crr == 2) PIT_SB_C(NH_, 2); else PIT_SB(NH_, 1, 1); } while (0)
     if (nh == 2) PIT_SB_CR(2); else PIT_SB_CR(1);
@@ -2234,8 +2245,6 @@ extern "C" int pit_posatt_bwd(const float* mesh_out, const float* mesh_in, int m
                                       job->accumulate, job->scratch, job->math_mode, stream);
         }
     } rd{rider, stream, false};
-    pit_detail::DwPair dw;
-    const bool can_ride = rider && pit_detail::plan_dw_pair(*rider, &dw);
     if (coord_dims > 0 && (add_residual || !(nbr_idx && nbr_cnt && masked) || (d_values && !(rev_ptr && rev_row))))
         return PIT_ERR_UNSUPPORTED;                             // candidate-list kernels only
     if (!rowstat || !d_out || !workspace) return PIT_ERR_NULL;
@@ -2268,12 +2277,12 @@ extern "C" int pit_posatt_bwd(const float* mesh_out, const float* mesh_in, int m
         a.nslots = ns;
         bool paired = false;
         if (d_values) {                                                // d(scale) + d(values) in one launch
-            if (!sparse) paired = launch_bwd_pair(a, s, can_ride ? &dw : nullptr, &rd.done);
+            if (!sparse) paired = launch_bwd_pair(a, s, rider, &rd.done);
             else if (rev_ptr && rev_row)
-                paired = launch_sparse_bwd_pair(a, sp, nbr_complete != 0, s, can_ride ? &dw : nullptr, &rd.done);
+                paired = launch_sparse_bwd_pair(a, sp, nbr_complete != 0, s, rider, &rd.done);
         }
         if (!paired) {
-            if (sparse) launch_sparse_rows<1>(a, sp, s, (can_ride && !rd.done) ? &dw : nullptr, &rd.done);
+            if (sparse) launch_sparse_rows<1>(a, sp, s, rd.done ? nullptr : rider, &rd.done);
             else launch_rows<1>(a, s);
         }
         PIT_CHECK_LAUNCH();

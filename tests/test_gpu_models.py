@@ -263,7 +263,8 @@ def test_deferred_head_finish_matches_per_layer_finish():
 
     ref, got = grads(False, 1), grads(True, 1)
     for k in ref:
-        assert gio.rel_l2(ref[k], got[k]) <= (1e-6 if k.endswith("lmda") else 0.0) + 1e-7, k
+        # (weight gradients are sums of fp32 atomics over row slabs: run-to-run order differences, ~1 ulp)
+        assert gio.rel_l2(ref[k], got[k]) <= (1e-6 if k.endswith("lmda") else 0.0) + 5e-7, k
     twice = grads(True, 2)
     for k in heads:
         assert gio.rel_l2(2.0 * ref[k], twice[k]) <= 1e-5, k

@@ -1,0 +1,14 @@
+mkdir -p gpurun_out/final
+python bench.py > gpurun_out/final/bench_default.json 2> gpurun_out/final/bench_default.err
+bash tools/task_times.sh > gpurun_out/final/task_times.txt 2>&1
+python bench.py --task cylinder --batch 200 --no-extras --no-cpu-baseline --steps 30 --warmup 5 2>/dev/null | python -c "
+import sys, json
+d = json.loads(sys.stdin.read()); print('cylinder b=200 fp32', d['ms_per_step'], 'ms', d['value'], 'samples/s')" >> gpurun_out/final/task_times.txt
+python bench.py --task vorticity --batch 20 --rollout 20 --no-extras --no-cpu-baseline --steps 10 --warmup 2 2>/dev/null | python -c "
+import sys, json
+d = json.loads(sys.stdin.read()); print('vorticity rollout-20 b=20 fp32', d['ms_per_step'], 'ms/optimiser step', d.get('peak_memory_GB'), 'GB peak')" >> gpurun_out/final/task_times.txt
+python bench.py --task sod --batch 8 --no-extras --no-cpu-baseline --steps 200 --warmup 20 2>/dev/null | python -c "
+import sys, json
+d = json.loads(sys.stdin.read()); print('sod b=8 fp32', d['ms_per_step'], 'ms')" >> gpurun_out/final/task_times.txt
+bash tools/profile_round.sh gpurun_out/r02_prof_f > gpurun_out/final/prof.log 2>&1
+cat gpurun_out/final/task_times.txt; tail -c 1500 gpurun_out/final/bench_default.json
