@@ -298,6 +298,69 @@ def roofline_probe(model, batch):
             "us_per_launch": round(us, 3), "flops_per_launch": flops, "algorithmic_bytes": alg_bytes}
 
 
+def roofline_attention_bwd_probe(model, batch):
+    """The launch with the LARGEST share of the Darcy b=8 step since round 2 (profiles/r02_darcy8.summary.txt:
+    posatt_bwd_pair_dw_kernel, 4 x 13.4 us = 20 %): the backward of a processor attention layer - d(scale) over the
+    rows and d(values) over the keys in one launch - carrying the weight-gradient reductions of the block's MLP
+    (pit_hip.h: rider).  Called through the C ABI exactly as ops._PosAtt.backward does, with a synthetic postponed
+    pit_mlp_bwd_params job of the block MLP's shape.  Algorithmic FLOPs: 2 x the forward's 2*H*N*J*D*b (two
+    contractions) + 2*rows*(n0*n1 + n1*n2) of the two reductions."""
+    import ctypes
+    from position_induced_transformer_amd import _lib, ops
+    layer, mlp = model.conv[0], model.mlp[0]
+    mesh = model.mesh_ltt
+    if mesh is None:
+        return None
+    plan = layer._plan(mesh, mesh, True)
+    d, H = model.hid_dim, layer.n_head
+    u = torch.randn(batch, plan.n_in, d, device="cuda", requires_grad=True)
+    lm = layer.lmda.detach().clone().requires_grad_(True)
+    out = ops.posatt_apply(u, lm, plan, H, True)
+    values, head, rowstat, scale = out.grad_fn.saved_tensors
+    d_out = torch.randn_like(out)
+    d_values = torch.empty_like(u)
+    d_head = torch.zeros(H, device="cuda")
+    work = torch.zeros(H * 1024, device="cuda", dtype=torch.float64)
+    n0, n1, n2 = mlp.mlp1.in_features, mlp.mlp1.out_features, mlp.mlp2.out_features
+    rows = batch * plan.n_out
+    x2, hh = torch.randn(rows, n0, device="cuda"), torch.randn(rows, n1, device="cuda")
+    scratch = torch.randn(rows * (n1 + n2), device="cuda")
+    gw1, gb1 = torch.zeros(n1, n0, device="cuda"), torch.zeros(n1, device="cuda")
+    gw2, gb2 = torch.zeros(n2, n1, device="cuda"), torch.zeros(n2, device="cuda")
+    job = _lib.MlpParamsJob(x2.data_ptr(), n0, rows, n0, n1, n2, hh.data_ptr(), 1, d_out.data_ptr(), d_out.stride(1),
+                            gw1.data_ptr(), gb1.data_ptr(), gw2.data_ptr(), gb2.data_ptr(), 1, scratch.data_ptr(), 0)
+    L = _lib.lib()
+    if not L.pit_mlp_bwd_params_deferrable(rows, n0, n1, n2, 1, n2):
+        return None                                   # large regime: the reductions keep their own launches
+
+    def launch():
+        rc = L.pit_posatt_bwd(
+            plan.mesh_out.data_ptr(), plan.mesh_in.data_ptr(), plan.mesh_batch, plan.n_out, plan.n_in,
+            plan.sdim, plan.metric_id, plan.period,
+            values.data_ptr(), batch, d, values.stride(1), values.stride(0),
+            head.data_ptr(), H, 0, scale.data_ptr(), rowstat.data_ptr(), 1 if plan.masked else 0,
+            d_out.data_ptr(), d_out.stride(1), d_out.stride(0), d,
+            d_values.data_ptr(), d_values.stride(1), d_values.stride(0), 1,
+            d_head.data_ptr(), 1 | 2, work.data_ptr(),            # PIT_HEAD_ACCUMULATE | PIT_HEAD_DEFER: one launch
+            _lib.ptr(plan.nbr_idx), _lib.ptr(plan.nbr_cnt), plan.nbr_cap, plan.lists_complete(),
+            _lib.ptr(plan.rev_ptr), _lib.ptr(plan.rev_row),
+            ctypes.cast(ctypes.pointer(job), ctypes.c_void_p), 0, 0, _lib.stream_ptr())
+        _lib.check(rc, "pit_posatt_bwd")
+
+    us = graph_time_us(launch)
+    work.zero_()
+    att = 2.0 * 2.0 * H * plan.n_out * plan.n_in * d * batch
+    red = 2.0 * rows * (n0 * n1 + n1 * n2)
+    flops = att + red
+    achieved = flops / (us * 1e-6) / 1e12
+    alg_bytes = 4.0 * (batch * plan.n_in * d * 2 + 2 * batch * plan.n_out * (1 + H) * d + rows * (n0 + 2 * n1 + n2))
+    return {"bound": "mfma", "kernel": f"posatt_bwd_pair_dw_kernel: d(scale)+d(values) of a processor layer {plan.n_out}x{plan.n_in}, "
+                                       f"D={d}, H={H}, batch {batch}, + dW/db of its MLP {n0}->{n1}->{n2} ({rows} rows)",
+            "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": pmc_traffic(f"posatt_bwd_pair_dw_b{batch}"),
+            "us_per_launch": round(us, 3), "flops_per_launch": flops, "algorithmic_bytes": alg_bytes}
+
+
 def executed_gflop_per_sample(model, step):
     """FLOPs the kernels actually execute per sample (fwd+bwd = 3 x fwd), next to the dense
     reference-equivalent figure: masked layers run on candidate lists, so their A.V work is
@@ -528,7 +591,13 @@ def main():
         extras["roofline_saturated"] = roofline_probe(model, 256)
         extras["roofline_mlp_saturated"] = roofline_mlp_probe(model, 256)
     if rank == 0:
-        rec["roofline"] = roofline_mlp_probe(model, args.batch)          # the kernel with the largest time share
+        bwd = roofline_attention_bwd_probe(model, args.batch)
+        mlp = roofline_mlp_probe(model, args.batch)
+        if bwd is not None:
+            rec["roofline"] = bwd                                         # the launch with the largest time share
+            rec["roofline_mlp"] = mlp                                     # (round 1-2's dominant family: the MLP forward)
+        else:
+            rec["roofline"] = mlp
         rec["roofline_attention"] = roofline_probe(model, args.batch)    # the fused position-attention forward
         log("roofline probes done")
         rec.update(extras)

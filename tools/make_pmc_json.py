@@ -11,7 +11,8 @@ src, dst = sys.argv[1], sys.argv[2]
 want = {  # bench key -> (config, kernel-name prefix, loads are 16 B per lane)
     "mlp_fwd_b8": ("darcy8", "mlp_fwd16_kernel<64, 12>", True),
     "mlp_fwd_b256": ("darcy256", "gemm_lds_kernel<128, true, true, 2, false>", True),
-    "posatt_rows_fwd_b8": ("darcy8", "posatt_rows_kernel<1, 0, false, false>", False),
+    "posatt_rows_fwd_b8": ("darcy8", "posatt_rows_kernel<1, 0, false, false", False),
+    "posatt_bwd_pair_dw_b8": ("darcy8", "posatt_bwd_pair_dw_kernel<false, false>", False),
     "posatt_rows_fwd_b256": ("darcy256", "posatt_rows_tiles<4, 1, 0, false, false>", False),
 }
 out = {"source": "tools/profile_round.sh: rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (own passes), bench.py "
