@@ -192,6 +192,8 @@ def _defer_head_finish(work, d_head, head, scale, n_head: int, flags: int) -> No
 # them) are postponed and handed to the NEXT attention backward as its `rider` (pit_hip.h): pit.py:116-121
 # runs mlp -> attention, so in the backward the attention launch that consumes the MLP's d_x can carry the
 # MLP's reductions along - three small latency-bound grids in one launch.  In-place gradient mode only.
+# (Like the deferred head finishes above: one backward pass at a time per process - a job found while ANOTHER pass
+# runs is taken for the leftover of a pass that raised, and dropped.)
 MLP_PARAMS_RIDER = os.environ.get("PIT_DW_RIDER", "1") != "0"
 _PENDING_DW = {"task": None, "job": None}     # job = (MlpParamsJob, keep-alive tensors, stream it was prepared on)
 _DEFERRABLE = {}

@@ -1,3 +1,7 @@
+#!/bin/bash
+# Round-end measurement on the GPU box: default bench line, task times (fp32 / bf16 mode), Cylinder, the 20-step rollout,
+# Sod, and the per-configuration rocprofv3 passes (tools/profile_round.sh).  Outputs under gpurun_out/; copy what is to be
+# judged into profiles/ (tools/make_pmc_json.py for the traffic JSON).
 mkdir -p gpurun_out/final
 python bench.py > gpurun_out/final/bench_default.json 2> gpurun_out/final/bench_default.err
 bash tools/task_times.sh > gpurun_out/final/task_times.txt 2>&1
