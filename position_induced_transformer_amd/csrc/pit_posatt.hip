@@ -445,6 +445,17 @@ __device__ __forceinline__ void posatt_rows_body(const AttArgs& a, const int bx,
             int st = 0;
             if (nfull > 0 && fast_ok) {
                 weights(p0, k0, 0, std::true_type{});
+                // two steps per trip with the register buffers swapping roles: as a one-step loop the ping-pong was
+                // 20 register moves per step (a fifth of the loop's vector instructions, each in front of an MFMA
+                // that reads the moved register)
+                for (; st + 2 < nfull; st += 2) {
+                    load_full(b1, st + 1);
+                    weights(p1, k1, st + 1, std::true_type{});
+                    contract(p0, k0, b0);
+                    load_full(b0, st + 2);
+                    weights(p0, k0, st + 2, std::true_type{});
+                    contract(p1, k1, b1);
+                }
                 for (; st + 1 < nfull; ++st) {                 // steady state: steps st and st+1 are both full
                     load_full(b1, st + 1);
                     weights(p1, k1, st + 1, std::true_type{});
@@ -814,6 +825,14 @@ __device__ __forceinline__ void posatt_cols_body(const AttArgs& a, const int bx,
                 if (NPX == 0 && nfull > 0 && fast_ok) {        // software pipeline as in the rows kernel (not in the
                                                                // register-capped merged launch)
                     weights(p0, k0, 0, std::true_type{});
+                    for (; st + 2 < nfull; st += 2) {          // (two steps per trip: see the rows kernel)
+                        load_full(b1, st + 1);
+                        weights(p1, k1, st + 1, std::true_type{});
+                        contract(p0, k0, b0);
+                        load_full(b0, st + 2);
+                        weights(p0, k0, st + 2, std::true_type{});
+                        contract(p1, k1, b1);
+                    }
                     for (; st + 1 < nfull; ++st) {
                         load_full(b1, st + 1);
                         weights(p1, k1, st + 1, std::true_type{});
