@@ -1059,6 +1059,13 @@ __global__ __launch_bounds__(512) void posatt_rows_tiles(AttArgs a) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) kpos[u] = group_pos(bf, u, half);
 
+    // complete chunks: value rows through the instruction's SCALAR offset (row) + a fixed per-lane offset (column, this
+    // half-wave's key inside a group) - no per-load address arithmetic or range select (as posatt_rows_body)
+    const bool fast_ok = a.values_bytes < 0x80000000u && !a.no_fast_loads;
+    unsigned voff[TPW];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) voff[t] = cvalid[t] ? uoff[t] + (unsigned)(half * (BF ? 4 : 1)) * ld4 : a.values_bytes;
+
     PIT_STAMP(1);
     int pass_i = 0;
     for (int c0 = 0; c0 < a.n_in; c0 += KC, ++pass_i) {
@@ -1118,14 +1125,8 @@ __global__ __launch_bounds__(512) void posatt_rows_tiles(AttArgs a) {
         __syncthreads();
         if (pass_i < 4) PIT_STAMP(5 + 4 * pass_i);
         // ---- contraction phase: every wave walks the whole chunk for its own tiles
-        for (int g = 0; g < ngroups; ++g) {
-            float bcur[4][TPW];
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-#pragma unroll
-                for (int t = 0; t < TPW; ++t) bcur[u][t] = bnext[u][t];
-            prefetch(g + 1);
-            if (MASKED && s_flag[g] == 0) continue;
+        auto contract = [&](int g, const float (&bcur)[4][TPW]) {
+            if (MASKED && s_flag[g] == 0) return;
             if (bf) {
                 bf16x4 bp[TPW];
 #pragma unroll
@@ -1139,7 +1140,7 @@ __global__ __launch_bounds__(512) void posatt_rows_tiles(AttArgs a) {
 #pragma unroll
                     for (int t = 0; t < TPW; ++t) acc[rt][t] = mfma_32x32x8_bf16(ap, bp[t], acc[rt][t]);
                 }
-                continue;
+                return;
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -1150,6 +1151,35 @@ __global__ __launch_bounds__(512) void posatt_rows_tiles(AttArgs a) {
                 for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
                     for (int t = 0; t < TPW; ++t) acc[rt][t] = mfma_32x32x2(af[rt], bcur[u][t], acc[rt][t]);
+            }
+        };
+        if (len == KC && fast_ok) {
+            // two groups per trip, the register buffers swapping roles (no copies), unchecked loads
+            auto load_fast = [&](float (&dst)[4][TPW], int g) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int soff = (c0 + g * 8 + (BF ? u : 2 * u)) * (int)ld4;          // wave-uniform
+#pragma unroll
+                    for (int t = 0; t < TPW; ++t)
+                        dst[u][t] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rvals, (int)voff[t], soff, 0));
+                }
+            };
+            for (int g = 0; g < KC / 8; g += 2) {
+                float b1[4][TPW];
+                load_fast(b1, g + 1);
+                contract(g, bnext);
+                if (g + 2 < KC / 8) load_fast(bnext, g + 2);
+                contract(g + 1, b1);
+            }
+        } else {
+            for (int g = 0; g < ngroups; ++g) {
+                float bcur[4][TPW];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int t = 0; t < TPW; ++t) bcur[u][t] = bnext[u][t];
+                prefetch(g + 1);
+                contract(g, bcur);
             }
         }
     }
@@ -1269,6 +1299,12 @@ __global__ __launch_bounds__(512) void posatt_cols_tiles(AttArgs a) {
     int kpos[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) kpos[u] = group_pos(bf, u, half);
+    // complete chunks: d_out rows through the instruction's SCALAR offset (row) + a fixed per-lane offset (column, this
+    // half-wave's row inside a group) - no per-load address arithmetic or range select (as posatt_cols_body)
+    const bool fast_ok = a.dout_bytes < 0x80000000u && !a.no_fast_loads;
+    unsigned voff[TPW];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) voff[t] = cvalid[t] ? doff[t] + (unsigned)(half * (BF ? 4 : 1)) * ldd4 : a.dout_bytes;
 
     for (int h = 0; h < a.n_head; ++h) {
         const float c = a.head_is_scale ? a.head[h] : head_scale_from_lmda(a.head[h]);
@@ -1325,14 +1361,8 @@ __global__ __launch_bounds__(512) void posatt_cols_tiles(AttArgs a) {
             };
             if (per) fill(std::true_type{}); else fill(std::false_type{});
             __syncthreads();
-            for (int g = 0; g < ngroups; ++g) {
-                float bcur[4][TPW];
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-#pragma unroll
-                    for (int t = 0; t < TPW; ++t) bcur[u][t] = bnext[u][t];
-                prefetch(g + 1);
-                if (MASKED && s_flag[g] == 0) continue;
+            auto contract = [&](int g, const float (&bcur)[4][TPW]) {
+                if (MASKED && s_flag[g] == 0) return;
                 if (bf) {
                     float af[4];
 #pragma unroll
@@ -1341,13 +1371,42 @@ __global__ __launch_bounds__(512) void posatt_cols_tiles(AttArgs a) {
 #pragma unroll
                     for (int t = 0; t < TPW; ++t)
                         acc[t] = mfma_32x32x8_bf16(ap, pack_bf16(bcur[0][t], bcur[1][t], bcur[2][t], bcur[3][t]), acc[t]);
-                    continue;
+                    return;
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const float af = Ps[(g * 8 + 2 * u + half) * 32 + l31];
 #pragma unroll
                     for (int t = 0; t < TPW; ++t) acc[t] = mfma_32x32x2(af, bcur[u][t], acc[t]);
+                }
+            };
+            if (len == TK_CHUNK && fast_ok) {
+                // two groups per trip, the register buffers swapping roles (no copies), unchecked loads
+                auto load_fast = [&](float (&dst)[4][TPW], int g) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int soff = (c0 + g * 8 + (BF ? u : 2 * u)) * (int)ldd4 + (int)hoff;   // wave-uniform
+#pragma unroll
+                        for (int t = 0; t < TPW; ++t)
+                            dst[u][t] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rdout, (int)voff[t], soff, 0));
+                    }
+                };
+                for (int g = 0; g < TK_CHUNK / 8; g += 2) {
+                    float b1[4][TPW];
+                    load_fast(b1, g + 1);
+                    contract(g, bnext);
+                    if (g + 2 < TK_CHUNK / 8) load_fast(bnext, g + 2);
+                    contract(g + 1, b1);
+                }
+            } else {
+                for (int g = 0; g < ngroups; ++g) {
+                    float bcur[4][TPW];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+#pragma unroll
+                        for (int t = 0; t < TPW; ++t) bcur[u][t] = bnext[u][t];
+                    prefetch(g + 1);
+                    contract(g, bcur);
                 }
             }
         }

@@ -365,17 +365,20 @@ def test_long_rows_stream_select_and_chunked_keys(ops, n_out, n_in, q):
     assert gio.rel_l2(uc.grad.numpy(), ug.grad.cpu().numpy()) <= TOL_GRAD
 
 
-@pytest.mark.parametrize("batched,q,self_attn,d,b", [(False, 1.0, True, 70, 6), (False, 0.3, False, 70, 6),
-                                                      (True, 1.0, True, 300, 2), (True, 0.4, False, 260, 2),
-                                                      (False, 1.0, False, 64, 20)])
+@pytest.mark.parametrize("batched,q,self_attn,d,b,big", [(False, 1.0, True, 70, 6, False), (False, 0.3, False, 70, 6, False),
+                                                          (True, 1.0, True, 300, 2, False), (True, 0.4, False, 260, 2, False),
+                                                          (False, 1.0, False, 64, 20, False),
+                                                          (False, 1.0, True, 64, 12, True), (False, 0.5, False, 64, 12, True)])
 @pytest.mark.parametrize("force_rt", ["1", "2", "4"])
-def test_wide_column_kernels_vs_oracle(ops, monkeypatch, batched, q, self_attn, d, b, force_rt):
+def test_wide_column_kernels_vs_oracle(ops, monkeypatch, batched, q, self_attn, d, b, big, force_rt):
     """>= 8 column tiles per row tile: the large-regime kernels (weights in LDS, whole tiles per
     wave, 1/2/4 row tiles per workgroup), forward, d(values) and d(scale), against the oracle;
     ragged sizes, 3 heads.  (The work threshold is bypassed so small test shapes take this path.)"""
     monkeypatch.setenv("PIT_FORCE_TILES", "1")
     monkeypatch.setenv("PIT_FORCE_RT", force_rt)
     n_out, n_in = (150, 150) if self_attn else (100, 310)
+    if big:                               # complete 256-row / 256-key chunks: the unchecked two-groups-per-trip loops
+        n_out, n_in = (300, 300) if self_attn else (530, 270)
     shape_o = (b, n_out, 2) if batched else (n_out, 2)
     shape_i = (b, n_in, 2) if batched else (n_in, 2)
     mo = torch.from_numpy(gio.synth(shape_o, 51, 0.0, 1.0))
