@@ -448,7 +448,7 @@ __device__ __forceinline__ void posatt_rows_body(const AttArgs& a, const int bx,
                 // two steps per trip with the register buffers swapping roles: as a one-step loop the ping-pong was
                 // 20 register moves per step (a fifth of the loop's vector instructions, each in front of an MFMA
                 // that reads the moved register)
-                for (; st + 2 < nfull; st += 2) {
+                for (; CT >= 2 && st + 2 < nfull; st += 2) {    // (CT = 1: the latency regime, two or three steps per wave)
                     load_full(b1, st + 1);
                     weights(p1, k1, st + 1, std::true_type{});
                     contract(p0, k0, b0);
@@ -825,7 +825,7 @@ __device__ __forceinline__ void posatt_cols_body(const AttArgs& a, const int bx,
                 if (NPX == 0 && nfull > 0 && fast_ok) {        // software pipeline as in the rows kernel (not in the
                                                                // register-capped merged launch)
                     weights(p0, k0, 0, std::true_type{});
-                    for (; st + 2 < nfull; st += 2) {          // (two steps per trip: see the rows kernel)
+                    for (; CT >= 2 && st + 2 < nfull; st += 2) {   // (two steps per trip: see the rows kernel)
                         load_full(b1, st + 1);
                         weights(p1, k1, st + 1, std::true_type{});
                         contract(p0, k0, b0);
@@ -2099,10 +2099,23 @@ __global__ __launch_bounds__(256) void posatt_sparse_overflow_cols(AttArgs a, Sp
 // must come after the plain stores of the key-owning waves.
 template <int NH, int CRR, int CRC>
 __global__ __launch_bounds__(256) void posatt_sparse_bwd_kernel(AttArgs a, SparseArgs sp, int n_cols, int cgx,
-                                                                 int rgx, int rgy, int n_dw, pit_detail::DwPair w) {
-    // a postponed MLP's weight-gradient reductions (pit_hip.h: rider) take the FIRST n_dw workgroup ids: this launch
-    // has more workgroups than the chip holds at once, and reductions dispatched after the first wave of attention
-    // workgroups would start when those drain - their ~10 us dependent chain appended instead of overlapped
+                                                                 int rgx, int rgy) {
+    int id = blockIdx.x;
+    if (id < n_cols) {
+        sparse_cols_body<CRC>(a, sp, id % cgx, id / cgx);
+    } else {
+        id -= n_cols;
+        sparse_rows_body<NH, CRR, 1>(a, sp, id % rgx, (id / rgx) % rgy, id / (rgx * rgy));
+    }
+}
+
+// The same launch carrying a postponed MLP's weight-gradient reductions (pit_hip.h: rider) - a kernel of its own,
+// instantiated for the small layers only (<= 4 columns per lane): inlined into the kernel above, the reductions'
+// body cost its 8-columns-per-lane instantiation 28 % (Vorticity's up-projection 168 -> 232 us).  The reductions
+// take the FIRST n_dw workgroup ids: the launch has more workgroups than the chip holds at once.
+template <int NH, int CRR, int CRC>
+__global__ __launch_bounds__(256) void posatt_sparse_bwd_dw_kernel(AttArgs a, SparseArgs sp, int n_cols, int cgx,
+                                                                    int rgx, int rgy, int n_dw, pit_detail::DwPair w) {
     int id = blockIdx.x;
     if (id < n_dw) {
         dw_pair_body(w, id);
@@ -2190,21 +2203,29 @@ bool launch_sparse_bwd_pair(const AttArgs& a, const SparseArgs& sp, bool complet
     const long rgx = (rows + 3) / 4, cgx = (keys + 3) / 4;
     const long n_rows = rgx * rblocks * (a.n_head / nh), n_cols = cgx * cblocks;
     if (n_rows + n_cols > 16384) return false;            // big launches gain nothing from merging
-    const int n_att = (int)(n_rows + n_cols);
+    dim3 grid((unsigned)(n_rows + n_cols)), block(256);
     pit_detail::DwPair dw;
-    const pit_detail::DwPair* rider = (job && !env_int("PIT_NO_LIST_PAIR_RIDER") && pit_detail::plan_dw_pair(*job, 4, &dw)) ? &dw : nullptr;
-    static const pit_detail::DwPair no_rider{};
-    dim3 grid((unsigned)(n_att + (rider ? rider->n1 + rider->n2 : 0))), block(256);
-    const size_t sm = rider ? DW_SMEM_4WAVES : 0;
-    const pit_detail::DwPair& w = rider ? *rider : no_rider;
-#define PIT_SB(NH_, CRR_, CRC_) hipLaunchKernelGGL((posatt_sparse_bwd_kernel<NH_, CRR_, CRC_>), grid, block, sm, s, a, sp, (int)n_cols, (int)cgx, (int)rgx, rblocks, rider ? rider->n1 + rider->n2 : 0, w)
+    if (job && crr <= 4 && pit_detail::plan_dw_pair(*job, 4, &dw)) {
+        const int n_dw = dw.n1 + dw.n2;
+        dim3 gridw((unsigned)(n_rows + n_cols + n_dw));
+#define PIT_SBW(NH_, CRR_, CRC_) hipLaunchKernelGGL((posatt_sparse_bwd_dw_kernel<NH_, CRR_, CRC_>), gridw, block, DW_SMEM_4WAVES, s, a, sp, (int)n_cols, (int)cgx, (int)rgx, rblocks, n_dw, dw)
+#define PIT_SBW_C(NH_, CRR_) do { if (crc == CRR_) PIT_SBW(NH_, CRR_, CRR_); else PIT_SBW(NH_, CRR_, 1); } while (0)
+#define PIT_SBW_CR(NH_) do { if (crr == 4) PIT_SBW_C(NH_, 4); else if (crr == 2) PIT_SBW_C(NH_, 2); else PIT_SBW(NH_, 1, 1); } while (0)
+        if (nh == 2) PIT_SBW_CR(2); else PIT_SBW_CR(1);
+#undef PIT_SBW_CR
+#undef PIT_SBW_C
+#undef PIT_SBW
+        *rider_done = true;
+        if (!complete) hipLaunchKernelGGL(posatt_sparse_overflow_cols, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, a, sp);
+        return true;
+    }
+#define PIT_SB(NH_, CRR_, CRC_) hipLaunchKernelGGL((posatt_sparse_bwd_kernel<NH_, CRR_, CRC_>), grid, block, 0, s, a, sp, (int)n_cols, (int)cgx, (int)rgx, rblocks)
 #define PIT_SB_C(NH_, CRR_) do { if (crc == CRR_) PIT_SB(NH_, CRR_, CRR_); else PIT_SB(NH_, CRR_, 1); } while (0)
 #define PIT_SB_CR(NH_) do { if (crr == 8) PIT_SB_C(NH_, 8); else if (crr == 4) PIT_SB_C(NH_, 4); else if (crr == 2) PIT_SB_C(NH_, 2); else PIT_SB(NH_, 1, 1); } while (0)
     if (nh == 2) PIT_SB_CR(2); else PIT_SB_CR(1);
 #undef PIT_SB_CR
 #undef PIT_SB_C
 #undef PIT_SB
-    if (rider) *rider_done = true;
     if (!complete) hipLaunchKernelGGL(posatt_sparse_overflow_cols, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, a, sp);
     return true;
 }

@@ -1,5 +1,5 @@
-python -m pytest tests/test_gpu_ops.py -x -q -m gpu -k "wide_column" 2>&1 | tail -3
-python -m pytest tests/test_gpu_ops.py tests/test_gpu_fuzz.py tests/test_gpu_bf16.py tests/test_gpu_models.py -x -q -m gpu 2>&1 | tail -2
-for b in 256 64; do python bench.py --batch $b --steps 100 --warmup 10 --no-cpu-baseline --no-extras 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('darcy b=$b', d['ms_per_step'])"; done
-python bench.py --batch 256 --math bf16 --steps 100 --warmup 10 --no-cpu-baseline --no-extras 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('darcy b=256 bf16', d['ms_per_step'])"
-cd /tmp; export TMPDIR=/tmp; rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/d256 -o t -- python3 $GRAFT_REPO_ROOT/bench.py --batch 256 --steps 20 --warmup 3 --no-cpu-baseline --no-extras > /dev/null 2>&1; grep "tiles" $GRAFT_REPO_ROOT/gpurun_out/d256/t_kernel_stats.csv | cut -d, -f1-4 | cut -c30-140
+python -m pytest tests/test_gpu_ops.py tests/test_gpu_models.py tests/test_gpu_fuzz.py -x -q -m gpu 2>&1 | tail -2
+python -m pytest tests/test_gpu_round2.py -x -q -m gpu -k "carried_by or postponed or raises_midway or vorticity or rollout_step" 2>&1 | tail -2
+python bench.py --task vorticity --batch 20 --steps 200 --warmup 20 --no-cpu-baseline --no-extras 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('vorticity', d['ms_per_step'])"
+python bench.py --task vorticity --batch 20 --math bf16 --steps 200 --warmup 20 --no-cpu-baseline --no-extras 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('vorticity bf16', d['ms_per_step'])"
+for i in 1 2; do python bench.py --steps 400 --warmup 50 --no-cpu-baseline --no-extras 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('darcy b=8', d['ms_per_step'])"; done
