@@ -794,3 +794,61 @@ def test_a_postponed_weight_gradient_job_of_an_aborted_pass_is_dropped():
     torch.cuda.synchronize()
     assert ops._PENDING_DW["job"] is None
     assert gio.rel_l2(want.cpu().numpy(), flat.flat.cpu().numpy()) <= 2e-6
+
+
+@pytest.mark.parametrize("n,hid,batch,locality", [(256, 64, 8, 1.0), (256, 64, 8, 0.3), (972, 64, 2, 1.0), (300, 128, 1, 1.0)])
+def test_cabi_posatt_bwd_with_a_rider_equals_the_two_separate_calls(n, hid, batch, locality):
+    """include/pit_hip.h, `rider`: one pit_posatt_bwd call carrying a pit_mlp_params_job must leave the same
+    d_values / d_head as the plain call and the same d_w1, d_b1, d_w2, d_b2 as a separate pit_mlp_bwd_params -
+    whether it merges the reductions into its launch (the small cases) or falls back to separate launches."""
+    import ctypes
+    from position_induced_transformer_amd import _lib, ops
+    torch.manual_seed(5)
+    H, d = 2, hid
+    mesh = torch.rand(n, 2, device="cuda")
+    plan = ops.MeshPlan("euclid", mesh, mesh, locality, True)
+    u = torch.randn(batch, n, d, device="cuda", requires_grad=True)
+    lm = torch.rand(H, device="cuda", requires_grad=True)
+    out = ops.posatt_apply(u, lm, plan, H, True)
+    values, head, rowstat, scale = out.grad_fn.saved_tensors
+    d_out = torch.randn_like(out)
+    rows, n0, n1, n2 = batch * n, (1 + H) * d, d, d
+    x2, hh = torch.randn(rows, n0, device="cuda"), torch.randn(rows, n1, device="cuda")
+    scratch = torch.randn(rows * (n1 + n2), device="cuda")
+    L = _lib.lib()
+
+    def run(with_rider):
+        d_values = torch.empty_like(u)
+        d_head = torch.zeros(H, device="cuda")
+        work = torch.zeros(H * 1024, device="cuda", dtype=torch.float64)
+        g = [torch.zeros(n1, n0, device="cuda"), torch.zeros(n1, device="cuda"),
+             torch.zeros(n2, n1, device="cuda"), torch.zeros(n2, device="cuda")]
+        job = _lib.MlpParamsJob(x2.data_ptr(), n0, rows, n0, n1, n2, hh.data_ptr(), 1, d_out.data_ptr(), d_out.stride(1),
+                                g[0].data_ptr(), g[1].data_ptr(), g[2].data_ptr(), g[3].data_ptr(), 1, scratch.data_ptr(), 0)
+        rc = L.pit_posatt_bwd(
+            plan.mesh_out.data_ptr(), plan.mesh_in.data_ptr(), plan.mesh_batch, plan.n_out, plan.n_in,
+            plan.sdim, plan.metric_id, plan.period,
+            values.data_ptr(), batch, d, values.stride(1), values.stride(0),
+            head.data_ptr(), H, 0, scale.data_ptr(), rowstat.data_ptr(), 1 if plan.masked else 0,
+            d_out.data_ptr(), d_out.stride(1), d_out.stride(0), d,
+            d_values.data_ptr(), d_values.stride(1), d_values.stride(0), 1,
+            d_head.data_ptr(), 0, work.data_ptr(),
+            _lib.ptr(plan.nbr_idx), _lib.ptr(plan.nbr_cnt), plan.nbr_cap, plan.lists_complete(),
+            _lib.ptr(plan.rev_ptr), _lib.ptr(plan.rev_row),
+            ctypes.cast(ctypes.pointer(job), ctypes.c_void_p) if with_rider else None, 0, 0, _lib.stream_ptr())
+        _lib.check(rc, "pit_posatt_bwd")
+        if not with_rider:
+            rc = L.pit_mlp_bwd_params(x2.data_ptr(), n0, rows, n0, n1, n2, hh.data_ptr(), 1, d_out.data_ptr(), d_out.stride(1),
+                                      g[0].data_ptr(), g[1].data_ptr(), g[2].data_ptr(), g[3].data_ptr(), 1, scratch.data_ptr(),
+                                      0, _lib.stream_ptr())
+            _lib.check(rc, "pit_mlp_bwd_params")
+        torch.cuda.synchronize()
+        assert float(work.abs().max()) == 0.0, "d(scale) accumulators not drained"
+        return [d_values, d_head] + g
+
+    a, b = run(True), run(False)
+    assert torch.equal(a[0], b[0]), "d_values must not depend on the rider"
+    assert gio.rel_l2(b[1].cpu().numpy(), a[1].cpu().numpy()) <= 1e-6
+    for x, y, name in zip(a[2:], b[2:], ("d_w1", "d_b1", "d_w2", "d_b2")):
+        assert float(y.abs().max()) > 0, name
+        assert gio.rel_l2(y.cpu().numpy(), x.cpu().numpy()) <= 2e-6, name      # (fp32 atomics: summation order)
