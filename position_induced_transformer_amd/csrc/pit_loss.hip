@@ -35,7 +35,7 @@ __global__ __launch_bounds__(256) void rel_lp_fwd_kernel(const float* __restrict
                                                           float* __restrict__ d_pred_unit, float* __restrict__ d_true_unit,
                                                           float* __restrict__ clear_buf, long clear_n) {
     __shared__ double s_num[4], s_den[4];
-    __shared__ float s_norm[2];
+    __shared__ float s_norm[3];                        // {||t - q||, ||t||, this pair's term of the loss}
     __shared__ int s_last;
     if (clear_buf) {                                  // fused memset of a caller buffer (gradient accumulators)
         const long nthreads = (long)gridDim.x * gridDim.y * gridDim.z * blockDim.x;
@@ -94,25 +94,28 @@ __global__ __launch_bounds__(256) void rel_lp_fwd_kernel(const float* __restrict
             const double dn = (p == 1) ? den : (p == 2 ? sqrt(den) : pow(den, 1.0 / p));
             norms[(long)pair * 2 + 0] = (float)nn;
             norms[(long)pair * 2 + 1] = (float)dn;
-            s_norm[0] = (float)nn; s_norm[1] = (float)dn;
-            // sum over (sample, channel) in a persistent accumulator; the last pair publishes the loss and
-            // leaves accumulator and arrival counter zero for the next call (no memset launch)
-            const float old = atomicAdd(ws, (float)(nn / dn / nch));
-            asm volatile("" ::"v"(old));
-            unsigned* counter = reinterpret_cast<unsigned*>(ws + 1);
-            const unsigned ticket = atomicAdd(counter, 1u);
-            if (ticket == (unsigned)pairs - 1u) {
-                *loss = atomicExch(ws, 0.0f);
-                atomicExch(counter, 0u);
-            }
+            s_norm[0] = (float)nn; s_norm[1] = (float)dn; s_norm[2] = (float)(nn / dn / nch);
+        }
+    }
+    __syncthreads();
+    if (!s_last) return;
+    const float nn = s_norm[0], dn = s_norm[1];
+    if (threadIdx.x == 0) {
+        // sum over (sample, channel) in a persistent accumulator; the last pair publishes the loss and
+        // leaves accumulator and arrival counter zero for the next call (no memset launch).  After the barrier:
+        // these two dependent L2 round trips run beside the gradient pass of the other 255 threads
+        const float old = atomicAdd(ws, s_norm[2]);
+        asm volatile("" ::"v"(old));
+        unsigned* counter = reinterpret_cast<unsigned*>(ws + 1);
+        const unsigned ticket = atomicAdd(counter, 1u);
+        if (ticket == (unsigned)pairs - 1u) {
+            *loss = atomicExch(ws, 0.0f);
+            atomicExch(counter, 0u);
         }
     }
     if (!d_pred_unit && !d_true_unit) return;
     // gradients for an upstream gradient of 1, by the workgroup that completed the pair (it holds both
     // norms): the training step then needs no separate backward launch for the loss
-    __syncthreads();
-    if (!s_last) return;
-    const float nn = s_norm[0], dn = s_norm[1];
     for (int l0 = threadIdx.x; l0 < npts; l0 += 4 * blockDim.x) {
         float qv[4], tv[4], sc[4], sh[4];
 #pragma unroll
