@@ -289,19 +289,33 @@ __global__ __launch_bounds__(N1 * 4) void mlp_bwd16_kernel(FusedMlpBwdArgs g) {
             const int k = 16 * s + 4 * kq + e;          // B(k, n) = w2[k][n]
             w2v[s][e] = (!thin && k < n2) ? g.w2[(long)k * N1 + c1] : 0.0f;
         }
-    // ---- phase A: dZ2 tile (16 x n2) -> LDS (+ scratch when it differs from dY)
-    for (int idx = tid; idx < 16 * n2; idx += NW * 64) {
-        const int r = idx / n2, c = idx - r * n2;
-        const int row = m0 + r;
-        float v = 0.0f;
-        if (row < g.rows) {
-            v = g.d_y[(long)row * g.ld_dy + c];
-            if (g.out_gelu) {
-                v *= gelu_erf_grad(g.z2[(long)row * n2 + c]);
-                g.dz2[(long)row * n2 + c] = v;
-            }
+    // ---- phase A: dZ2 tile (16 x n2) -> LDS (+ scratch when it differs from dY).  16 n2 <= 16 N1 = 4 elements per
+    // thread: all of their loads are issued together with the weight fragments above (as a loop with the loads
+    // inside it was up to four dependent memory round trips in front of the first MFMA)
+    {
+        float dyv[4], z2g[4];
+        int rr[4], cc[4];
+        bool in[4], ok[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int idx = tid + u * NW * 64;
+            in[u] = idx < 16 * n2;
+            rr[u] = in[u] ? idx / n2 : 0;
+            cc[u] = in[u] ? idx - rr[u] * n2 : 0;
+            ok[u] = in[u] && m0 + rr[u] < g.rows;
+            const long row = ok[u] ? m0 + rr[u] : 0;
+            dyv[u] = ok[u] ? g.d_y[row * g.ld_dy + cc[u]] : 0.0f;
+            z2g[u] = (ok[u] && g.out_gelu) ? g.z2[row * n2 + cc[u]] : 0.0f;
         }
-        ds2[r * P1 + c] = v;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            float v = dyv[u];
+            if (g.out_gelu) {
+                v *= gelu_erf_grad(z2g[u]);
+                if (ok[u]) g.dz2[(long)(m0 + rr[u]) * n2 + cc[u]] = v;
+            }
+            if (in[u]) ds2[rr[u] * P1 + cc[u]] = ok[u] ? v : 0.0f;
+        }
     }
     __syncthreads();
     // ---- phase B: dZ1 tile of this wave = (dZ2 W2) * gelu'(Z1)
