@@ -127,11 +127,16 @@ __global__ __launch_bounds__(N1 * 4) void mlp_fwd16_kernel(FusedMlpArgs g) {
             }
         }
     }
-    // second weight matrix: its latency hides behind the first contraction
+    // second weight matrix: its latency hides behind the first contraction (full tiles: this lane's B fragments;
+    // thin output layer: the quarter of output 0's weight row this lane's row dot uses)
     float w2v[S2][4];
+    const bool thin_out = g.n2 <= 4;
 #pragma unroll
-    for (int s = 0; s < S2; ++s)
-        buf_load4(rw2, (do2 && c2 < g.n2) ? ((unsigned)c2 * (unsigned)N1 + (unsigned)(16 * s + 4 * kq)) * 4u : g.w2_bytes, w2v[s]);
+    for (int s = 0; s < S2; ++s) {
+        const unsigned off = thin_out ? (unsigned)(kq * (N1 / 4) + 4 * s) * 4u
+                                      : ((unsigned)c2 * (unsigned)N1 + (unsigned)(16 * s + 4 * kq)) * 4u;
+        buf_load4(rw2, (thin_out ? wave == 0 : (do2 && c2 < g.n2)) ? off : g.w2_bytes, w2v[s]);
+    }
 
     f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -166,7 +171,13 @@ __global__ __launch_bounds__(N1 * 4) void mlp_fwd16_kernel(FusedMlpArgs g) {
 #pragma unroll
             for (int k = 0; k < N1 / 4; k += 4) {
                 const float4 a = *reinterpret_cast<const float4*>(hs + l15 * HP + kq * (N1 / 4) + k);
-                const float* w = g.w2 + (long)o * N1 + kq * (N1 / 4) + k;
+                float w[4];
+                if (o == 0) {                              // (prefetched at kernel entry; S2 = N1/16 quads = N1/4 floats)
+                    w[0] = w2v[k / 4][0]; w[1] = w2v[k / 4][1]; w[2] = w2v[k / 4][2]; w[3] = w2v[k / 4][3];
+                } else {
+                    const float* wp = g.w2 + (long)o * N1 + kq * (N1 / 4) + k;
+                    w[0] = wp[0]; w[1] = wp[1]; w[2] = wp[2]; w[3] = wp[3];
+                }
                 part += (a.x * w[0] + a.y * w[1]) + (a.z * w[2] + a.w * w[3]);
             }
             part += __shfl_xor(part, 16, 64);
