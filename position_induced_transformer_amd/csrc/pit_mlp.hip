@@ -298,7 +298,9 @@ __global__ __launch_bounds__(N1 * 4) void mlp_bwd16_kernel(FusedMlpBwdArgs g) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int k = 16 * s + 4 * kq + e;          // B(k, n) = w2[k][n]
-            w2v[s][e] = (!thin && k < n2) ? g.w2[(long)k * N1 + c1] : 0.0f;
+            // (thin output layer: w2[o][c1], o < n2 <= 4, in w2v[0][o] - requested here, used after the barrier)
+            const bool want = thin ? (s == 0 && e < n2) : (k < n2);
+            w2v[s][e] = want ? g.w2[(long)(thin ? e : k) * N1 + c1] : 0.0f;
         }
     // ---- phase A: dZ2 tile (16 x n2) -> LDS (+ scratch when it differs from dY).  16 n2 <= 16 N1 = 4 elements per
     // thread: all of their loads are issued together with the weight fragments above (as a loop with the loads
@@ -335,7 +337,9 @@ __global__ __launch_bounds__(N1 * 4) void mlp_bwd16_kernel(FusedMlpBwdArgs g) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             float acc = 0.0f;
-            for (int o = 0; o < n2; ++o) acc += ds2[(4 * kq + i) * P1 + o] * g.w2[(long)o * N1 + c1];
+#pragma unroll
+            for (int o = 0; o < 4; ++o)
+                if (o < n2) acc += ds2[(4 * kq + i) * P1 + o] * w2v[0][o];
             a0[i] = acc;
         }
     } else {
