@@ -1153,8 +1153,9 @@ __global__ __launch_bounds__(512) void posatt_rows_tiles(AttArgs a) {
                     for (int t = 0; t < TPW; ++t) acc[rt][t] = mfma_32x32x2(af[rt], bcur[u][t], acc[rt][t]);
             }
         };
-        if (len == KC && fast_ok) {
-            // two groups per trip, the register buffers swapping roles (no copies), unchecked loads
+        if (len % 16 == 0 && fast_ok) {
+            // (whole pairs of 8-key groups) two groups per trip, the register buffers swapping roles (no copies),
+            // unchecked loads
             auto load_fast = [&](float (&dst)[4][TPW], int g) {
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
@@ -1164,11 +1165,11 @@ __global__ __launch_bounds__(512) void posatt_rows_tiles(AttArgs a) {
                         dst[u][t] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rvals, (int)voff[t], soff, 0));
                 }
             };
-            for (int g = 0; g < KC / 8; g += 2) {
+            for (int g = 0; g < ngroups; g += 2) {
                 float b1[4][TPW];
                 load_fast(b1, g + 1);
                 contract(g, bnext);
-                if (g + 2 < KC / 8) load_fast(bnext, g + 2);
+                if (g + 2 < ngroups) load_fast(bnext, g + 2);
                 contract(g + 1, b1);
             }
         } else {
@@ -1380,8 +1381,9 @@ __global__ __launch_bounds__(512) void posatt_cols_tiles(AttArgs a) {
                     for (int t = 0; t < TPW; ++t) acc[t] = mfma_32x32x2(af, bcur[u][t], acc[t]);
                 }
             };
-            if (len == TK_CHUNK && fast_ok) {
-                // two groups per trip, the register buffers swapping roles (no copies), unchecked loads
+            if (len % 16 == 0 && fast_ok) {
+                // (whole pairs of 8-row groups) two groups per trip, the register buffers swapping roles (no copies),
+                // unchecked loads
                 auto load_fast = [&](float (&dst)[4][TPW], int g) {
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
@@ -1391,11 +1393,11 @@ __global__ __launch_bounds__(512) void posatt_cols_tiles(AttArgs a) {
                             dst[u][t] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rdout, (int)voff[t], soff, 0));
                     }
                 };
-                for (int g = 0; g < TK_CHUNK / 8; g += 2) {
+                for (int g = 0; g < ngroups; g += 2) {
                     float b1[4][TPW];
                     load_fast(b1, g + 1);
                     contract(g, bnext);
-                    if (g + 2 < TK_CHUNK / 8) load_fast(bnext, g + 2);
+                    if (g + 2 < ngroups) load_fast(bnext, g + 2);
                     contract(g + 1, b1);
                 }
             } else {
