@@ -1764,7 +1764,9 @@ struct SparseArgs {
 
 template <int NH, int CR, int MODE>
 __device__ __forceinline__ void sparse_rows_body(const AttArgs& a, const SparseArgs& sp, const int bx, const int by, const int bz) {
-    constexpr int G = (CR >= 4) ? 4 : 8;
+    // keys gathered per batch: G x CR value registers in flight; at 8 columns per lane two keys keep the rows kernels
+    // at 5 waves per SIMD (93 registers; four keys: 128) - these kernels hide gather latency with occupancy
+    constexpr int G = (CR >= 8) ? 2 : ((CR >= 4) ? 4 : 8);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long rows_total = (long)a.mesh_batch * a.n_out;
     const long row_raw = (long)bx * 4 + wave;
@@ -1954,7 +1956,7 @@ __global__ __launch_bounds__(256, 4) void posatt_sparse_rows_x(AttArgs a, Sparse
 
 template <int CR>
 __device__ __forceinline__ void sparse_cols_body(const AttArgs& a, const SparseArgs& sp, const int bx, const int by) {
-    constexpr int G = (CR >= 4) ? 4 : 8;
+    constexpr int G = (CR >= 8) ? 2 : ((CR >= 4) ? 4 : 8);      // (see sparse_rows_body)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long keys_total = (long)a.mesh_batch * a.n_in;
     const long kid = (long)bx * 4 + wave;
