@@ -47,7 +47,12 @@ __device__ __forceinline__ void group_sum(double (&v)[VW], double* s, int cg, in
     __syncthreads();
 }
 
-template <int VW>
+// RES (npts <= RES_ROWS * RG, the latent meshes of the Vorticity model: 256 points): a thread's rows stay in
+// registers - ONE pass over memory with every load in flight at once instead of three dependent loops of loads;
+// the sums are formed in the same order, so the results are identical bit for bit.
+constexpr int RES_ROWS = 16;
+
+template <int VW, bool RES = false>
 __global__ __launch_bounds__(256) void instance_norm_fwd_kernel(const float* __restrict__ x, long ldx, long x_bstride,
                                                                  int npts, int nch, float eps, float* __restrict__ y,
                                                                  float* __restrict__ rstd_out) {
@@ -60,6 +65,53 @@ __global__ __launch_bounds__(256) void instance_norm_fwd_kernel(const float* __r
     double acc[VW];
 #pragma unroll
     for (int e = 0; e < VW; ++e) acc[e] = 0.0;
+    if (RES) {
+        float xv[RES_ROWS][VW];
+#pragma unroll
+        for (int i = 0; i < RES_ROWS; ++i) {
+            const int l = rg + i * RG;
+            if (l < npts) load_vec<VW>(xb + (long)l * ldx, xv[i]);
+            else {
+#pragma unroll
+                for (int e = 0; e < VW; ++e) xv[i][e] = 0.0f;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < RES_ROWS; ++i)
+#pragma unroll
+            for (int e = 0; e < VW; ++e) acc[e] += (cv && rg + i * RG < npts) ? (double)xv[i][e] : 0.0;
+        group_sum<VW>(acc, s, cg, rg);
+        double mean[VW];
+#pragma unroll
+        for (int e = 0; e < VW; ++e) { mean[e] = acc[e] / npts; acc[e] = 0.0; }
+#pragma unroll
+        for (int i = 0; i < RES_ROWS; ++i)
+#pragma unroll
+            for (int e = 0; e < VW; ++e) {
+                const double d = (cv && rg + i * RG < npts) ? (double)xv[i][e] - mean[e] : 0.0;
+                acc[e] += d * d;
+            }
+        group_sum<VW>(acc, s, cg, rg);
+        float rstd[VW], meanf[VW];
+#pragma unroll
+        for (int e = 0; e < VW; ++e) {
+            rstd[e] = (float)(1.0 / sqrt(acc[e] / npts + (double)eps));
+            meanf[e] = (float)mean[e];
+        }
+        if (!cv) return;
+        float* yb = y + ((long)b * npts) * nch + c;
+#pragma unroll
+        for (int i = 0; i < RES_ROWS; ++i) {
+            const int l = rg + i * RG;
+            if (l >= npts) break;
+            float v[VW];
+#pragma unroll
+            for (int e = 0; e < VW; ++e) v[e] = (xv[i][e] - meanf[e]) * rstd[e];
+            store_vec<VW>(yb + (long)l * nch, v);
+        }
+        if (rg == 0) store_vec<VW>(rstd_out + (long)b * nch + c, rstd);
+        return;
+    }
     for (int l = rg; l < npts; l += RG) {
         float v[VW];
         load_vec<VW>(xb + (long)l * ldx, v);
@@ -96,7 +148,7 @@ __global__ __launch_bounds__(256) void instance_norm_fwd_kernel(const float* __r
 }
 
 // d_x = rstd * (d_y - mean_l(d_y) - y * mean_l(d_y * y)),  y = the normalised output
-template <int VW>
+template <int VW, bool RES = false>
 __global__ __launch_bounds__(256) void instance_norm_bwd_kernel(const float* __restrict__ d_y, const float* __restrict__ y,
                                                                  const float* __restrict__ rstd, int npts, int nch,
                                                                  float* __restrict__ d_x) {
@@ -109,6 +161,45 @@ __global__ __launch_bounds__(256) void instance_norm_bwd_kernel(const float* __r
     double s1[VW], s2[VW];
 #pragma unroll
     for (int e = 0; e < VW; ++e) { s1[e] = 0.0; s2[e] = 0.0; }
+    if (RES) {                                                 // (see instance_norm_fwd_kernel)
+        float gv[RES_ROWS][VW], yv[RES_ROWS][VW];
+#pragma unroll
+        for (int i = 0; i < RES_ROWS; ++i) {
+            const int l = rg + i * RG;
+            if (l < npts) {
+                load_vec<VW>(d_y + base + (long)l * nch, gv[i]);
+                load_vec<VW>(y + base + (long)l * nch, yv[i]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < VW; ++e) { gv[i][e] = 0.0f; yv[i][e] = 0.0f; }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < RES_ROWS; ++i)
+#pragma unroll
+            for (int e = 0; e < VW; ++e) {
+                const double gd = (cv && rg + i * RG < npts) ? (double)gv[i][e] : 0.0;
+                s1[e] += gd;
+                s2[e] += gd * (double)yv[i][e];
+            }
+        group_sum<VW>(s1, s, cg, rg);
+        group_sum<VW>(s2, s, cg, rg);
+        if (!cv) return;
+        float r[VW], m1[VW], m2[VW];
+        load_vec<VW>(rstd + (long)b * nch + c, r);
+#pragma unroll
+        for (int e = 0; e < VW; ++e) { m1[e] = (float)(s1[e] / npts); m2[e] = (float)(s2[e] / npts); }
+#pragma unroll
+        for (int i = 0; i < RES_ROWS; ++i) {
+            const int l = rg + i * RG;
+            if (l >= npts) break;
+            float g[VW];
+#pragma unroll
+            for (int e = 0; e < VW; ++e) g[e] = r[e] * (gv[i][e] - m1[e] - yv[i][e] * m2[e]);
+            store_vec<VW>(d_x + base + (long)l * nch, g);
+        }
+        return;
+    }
     for (int l = rg; l < npts; l += RG) {
         float g[VW], yv[VW];
         load_vec<VW>(d_y + base + (long)l * nch, g);
@@ -148,10 +239,14 @@ extern "C" int pit_instance_norm_fwd(const float* x, long ldx, long x_bstride, i
     if (!x || !y || !rstd) return PIT_ERR_NULL;
     if (batch <= 0 || npts <= 0 || nch <= 0 || ldx < nch || batch > 65535) return PIT_ERR_SIZE;
     const dim3 grid((nch + 63) / 64, batch);
-    if (vec4_ok(x, ldx, x_bstride, nch) && vec4_ok(y, nch, 4, nch) && vec4_ok(rstd, 4, 4, nch))
-        hipLaunchKernelGGL(instance_norm_fwd_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, x, ldx, x_bstride, npts,
-                           nch, eps, y, rstd);
-    else
+    if (vec4_ok(x, ldx, x_bstride, nch) && vec4_ok(y, nch, 4, nch) && vec4_ok(rstd, 4, 4, nch)) {
+        if (npts <= RES_ROWS * NormShape<4>::RG)
+            hipLaunchKernelGGL((instance_norm_fwd_kernel<4, true>), grid, dim3(256), 0, (hipStream_t)stream, x, ldx, x_bstride,
+                               npts, nch, eps, y, rstd);
+        else
+            hipLaunchKernelGGL(instance_norm_fwd_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, x, ldx, x_bstride, npts,
+                               nch, eps, y, rstd);
+    } else
         hipLaunchKernelGGL(instance_norm_fwd_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, x, ldx, x_bstride, npts,
                            nch, eps, y, rstd);
     PIT_CHECK_LAUNCH();
@@ -163,9 +258,13 @@ extern "C" int pit_instance_norm_bwd(const float* d_y, const float* y, const flo
     if (!d_y || !y || !rstd || !d_x) return PIT_ERR_NULL;
     if (batch <= 0 || npts <= 0 || nch <= 0 || batch > 65535) return PIT_ERR_SIZE;
     const dim3 grid((nch + 63) / 64, batch);
-    if (vec4_ok(d_y, nch, 4, nch) && vec4_ok(y, nch, 4, nch) && vec4_ok(d_x, nch, 4, nch) && vec4_ok(rstd, 4, 4, nch))
-        hipLaunchKernelGGL(instance_norm_bwd_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, d_y, y, rstd, npts, nch, d_x);
-    else
+    if (vec4_ok(d_y, nch, 4, nch) && vec4_ok(y, nch, 4, nch) && vec4_ok(d_x, nch, 4, nch) && vec4_ok(rstd, 4, 4, nch)) {
+        if (npts <= RES_ROWS * NormShape<4>::RG)
+            hipLaunchKernelGGL((instance_norm_bwd_kernel<4, true>), grid, dim3(256), 0, (hipStream_t)stream, d_y, y, rstd, npts,
+                               nch, d_x);
+        else
+            hipLaunchKernelGGL(instance_norm_bwd_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, d_y, y, rstd, npts, nch, d_x);
+    } else
         hipLaunchKernelGGL(instance_norm_bwd_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, d_y, y, rstd, npts, nch, d_x);
     PIT_CHECK_LAUNCH();
     return 0;
