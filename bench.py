@@ -71,6 +71,9 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--eager-allreduce", action="store_true",
                     help="N > 1: capture the compute only and issue the gradient all-reduce eagerly after each replay")
+    ap.add_argument("--ar-buckets", type=int, choices=(1, 2), default=1,
+                    help="N > 1: 2 = all-reduce the weights whose gradients are complete half-way through the backward "
+                         "pass (decoder MLP + last processor MLPs) on a second stream while the rest of the backward runs")
     ap.add_argument("--watchdog", type=float, default=300.0, help="N > 1: seconds allowed for capture + first replays")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip batch sweep / optimizer / roofline probes")
@@ -78,6 +81,12 @@ def parse():
     ap.add_argument("--rollout", type=int, default=0,
                     help="vorticity only: one step = the N-step autoregressive BPTT optimiser step of train_vorticity.py:118-129")
     ap.add_argument("--recompute", action="store_true", help="with --rollout: activation recompute (eager only)")
+    ap.add_argument("--head-scale-route", choices=("host", "device"), default="host",
+                    help="where c = tan(K(1+sin lmda)) of pit.py:48 is evaluated for the timed fwd+bwd step: 'host' = the "
+                         "reference's own torch-CPU ops, cached per lmda version (exact, sync-free and capturable while lmda "
+                         "is frozen, as it is in a fwd+bwd step); 'device' = inside the kernels (what a captured TRAINING "
+                         "step with the optimizer in the graph uses; the train_step extra always does)")
+    ap.add_argument("--no-parity", action="store_true", help="skip the parity block (oracle forward+backward on the host)")
     ap.add_argument("--math", choices=("fp32", "bf16"), default="fp32",
                     help="MFMA math mode of the contractions (pit_set_math_mode); fp32 = the reference's arithmetic")
     return ap.parse_args()
@@ -118,7 +127,8 @@ def build_step(args, device, rank, world, batch, with_optimizer=False, all_reduc
                            all_reduce=use_ar, optimizer=opt, flat=flat)
         return step, model, meta
     step = TrainStep(model, (mesh_in, func_in, mesh_out, target), meta["out_dim"], meta["p"], affine,
-                     all_reduce=use_ar, optimizer=opt, flat=flat)
+                     all_reduce=use_ar, optimizer=opt, flat=flat,
+                     all_reduce_buckets=args.ar_buckets if (use_ar and opt is None) else 1)
     return step, model, meta
 
 
@@ -391,6 +401,65 @@ def executed_gflop_per_sample(model, step):
     return 3.0 * (total + mlp) / 1e9
 
 
+def parity_vs_oracle(args, step, model, affine, meta):
+    """rel-L2 of what the TIMED step computed - the prediction, the loss and every gradient left in the flat buffer
+    by the last replay of the timed graph, on the timed model, inputs and head-scale route - against the CPU oracle
+    (oracle/pit_oracle.py: the reference's op sequence, pinned bit-equal to /root/reference/pit.py in the build
+    container) run here on the same parameters and inputs.  BASELINE.json's metric asks for this number next to the
+    throughput.  Tolerances of the parity tests: output 1e-5, weight gradients 2e-5, d(lmda) 2e-4."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pit_oracle as orc
+    torch.cuda.synchronize()
+    b = step.func_in.shape[0]
+    sd, dev_grads = {}, {}
+    for k, q in model.named_parameters():
+        sd[k] = q.detach().cpu().clone().requires_grad_(True)
+        dev_grads[k] = q.grad.detach().cpu().clone()
+    out_dev, loss_dev = step.out.detach().cpu(), float(step.loss)
+    s = model.space_dim
+    metric = model.down._metric
+    norm = hasattr(model, "norm")
+    t0 = time.perf_counter()
+    if model.mesh_ltt is not None:                       # fixed-mesh tasks (train_darcy.py:46-59 and alike)
+        mi = step.mesh_in.cpu().reshape(-1, s)
+        mo = step.mesh_out.cpu().reshape(-1, s)
+        f = orc.with_coords(mi, step.func_in.cpu().reshape(b, -1, model.in_dim))
+        ref = orc.pit_apply(sd, metric, False, model.n_blocks, model.en_local, model.de_local, mi, f,
+                            model.mesh_ltt.cpu(), mo, norm_after_enc_proc=norm)
+        if getattr(model, "residual", False):
+            ref = ref + step.func_in.cpu().reshape(ref.shape)
+    elif args.task == "elasticity":                      # train_elasticity.py:41-54
+        mo = step.mesh_out.cpu()
+        ref = orc.pit_apply(sd, metric, True, model.n_blocks, model.en_local, model.de_local, step.mesh_in.cpu(),
+                            step.func_in.cpu(), mo, mo)
+    elif args.task == "naca":                            # train_naca.py:52-65
+        ltt, flat = model.ltt_mesh(step.mesh_out.cpu())
+        ref = orc.pit_apply(sd, metric, True, model.n_blocks, model.en_local, model.de_local, step.mesh_in.cpu(),
+                            step.func_in.cpu(), ltt, flat)
+    else:
+        return None
+    ref = ref.reshape(out_dev.shape)
+    pred = ref if affine is None else ref * affine[0].cpu() + affine[1].cpu()
+    ref_loss = orc.rel_lp_loss(step.target.cpu(), pred, meta["out_dim"], meta["p"])
+    ref_loss.backward()
+    secs = time.perf_counter() - t0
+
+    def rel(a, r):
+        return float((a.double() - r.double()).norm() / (r.double().norm() + 1e-300))
+    w = {k: rel(dev_grads[k], sd[k].grad) for k in sd if not k.endswith("lmda")}
+    l = {k: rel(dev_grads[k], sd[k].grad) for k in sd if k.endswith("lmda")}
+    kw, kl = max(w, key=w.get), max(l, key=l.get)
+    return {"rel_l2_out": rel(out_dev, ref.detach()), "rel_loss": abs(loss_dev - float(ref_loss)) / abs(float(ref_loss)),
+            "rel_l2_weight_grad_worst": w[kw], "worst_weight_grad": kw,
+            "rel_l2_dlmda_worst": l[kl], "worst_dlmda": kl,
+            "head_scale_route": args.head_scale_route, "math": args.math,
+            "tolerance": {"out": 1e-5, "weight_grad": 2e-5, "dlmda": 2e-4} if args.math == "fp32" else
+                         {"out": 2e-2, "weight_grad": 5e-2, "dlmda": 5e-2},
+            "what": "the timed hipGraph's own results (prediction, loss, flat gradient buffer after its last replay) vs "
+                    "oracle/pit_oracle.py forward+loss+backward on this host, same parameters and inputs",
+            "oracle_seconds": round(secs, 2)}
+
+
 def cpu_baseline(batch, iters):
     """The oracle's Darcy forward+loss+backward on the host cores (PyTorch CPU eager fp32)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -490,6 +559,8 @@ def main():
     log(f"rank {rank}/{world} on {torch.cuda.get_device_name(local)}")
     from position_induced_transformer_amd import ops
     ops.set_math_mode(args.math)
+    # the timed fwd+bwd step never updates lmda: the exact (host-evaluated, cached) head scale is sync-free here
+    ops.set_head_scale_route(args.head_scale_route)
     step, model, meta = build_step(args, device, rank, world, args.batch, all_reduce=distributed)
     if distributed and args.eager_allreduce and not args.no_graph:
         step.all_reduce = False
@@ -527,7 +598,11 @@ def main():
                                                                            f"(train_vorticity.py:118-126){', activation recompute' if args.recompute else ''}"
                                                                            if args.rollout else ", fwd+loss+bwd") + f", per-GPU batch {args.batch}",
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world,
-                       "parallelism": f"dp{world}" if world > 1 else "single", "launch": mode},
+                       "parallelism": f"dp{world}" if world > 1 else "single", "launch": mode,
+                       "head_scale_route": args.head_scale_route,
+                       "allreduce": ({"backend": dist.get_backend(), "captured": mode == "hipgraph",
+                                      "buckets": getattr(step, "buckets", 1), "floats": int(step.flat.flat.numel())}
+                                     if distributed else None)},
             "loss": round(loss_val, 6),
             "peak_memory_GB": round(torch.cuda.max_memory_allocated() / 1e9, 3),
             "timing": dict(spread, what="value = median over repeated blocks of exactly --steps steps, each bracketed by "
@@ -553,15 +628,27 @@ def main():
                     rec["step_tflops"]["executed_frac_of_fp32_mfma_peak"] = round(value * ex / 1e3 / FP32_MFMA_PEAK_TFLOPS / world, 4)
                 except Exception as exc:          # informational only
                     log(f"executed-FLOP count skipped: {type(exc).__name__}: {exc}")
+        if not args.no_parity and not args.rollout and world == 1:
+            try:
+                aff = darcy_affine(device) if args.task == "darcy" else None
+                rec["parity"] = parity_vs_oracle(args, step, model, aff, meta)
+                if rec["parity"] is not None:
+                    log("parity vs oracle: " + json.dumps({k: v for k, v in rec["parity"].items() if k.startswith("rel_")}))
+            except Exception as exc:
+                rec["parity"] = {"error": f"{type(exc).__name__}: {exc}"}
+                log(f"parity block failed: {rec['parity']['error']}")
     extras = {}
     if world == 1 and not args.no_extras:
         # (a) the same step with Adam (capturable) inside the graph
-        st2, _, _ = build_step(args, device, rank, world, args.batch, with_optimizer=True)
-        run2, _ = prepare(st2, not args.no_graph)
-        dt2, _ = timed_blocks(run2, max(args.steps // 2, 10), max(args.warmup // 2, 3), world, min_total=0.1)
+        with ops.head_scale_route("device"):        # lmda changes inside the graph: the in-kernel head scale
+            st2, _, _ = build_step(args, device, rank, world, args.batch, with_optimizer=True)
+            run2, _ = prepare(st2, not args.no_graph)
+            dt2, _ = timed_blocks(run2, max(args.steps // 2, 10), max(args.warmup // 2, 3), world, min_total=0.1)
         log("train_step (with Adam) done")
         extras["train_step"] = {"samples_per_s": round(args.batch * max(args.steps // 2, 10) / dt2, 1),
-                                "what": "fwd+loss+bwd+fused Adam(1e-3)+cosine LR (pit_adam_step) in one hipGraph"}
+                                "head_scale_route": "device",
+                                "what": "fwd+loss+bwd+fused Adam(1e-3)+cosine LR (pit_adam_step) in one hipGraph; lmda is "
+                                        "updated inside the graph, so c is evaluated in the kernels (route 'device')"}
         # (b) saturating batches
         sweep = {}
         for b in (64, 256):

@@ -63,6 +63,8 @@ SIGNATURES = {
     "pit_debug_mfma_tile": [_P, _P, _P, _P],
 }
 
+ABI_VERSION = 9        # PIT_ABI_VERSION of include/pit_hip.h this binding was written against
+
 _lib = None
 
 
@@ -78,6 +80,10 @@ def lib() -> ctypes.CDLL:
             fn = getattr(handle, name)       # AttributeError if the ABI lost a symbol
             fn.argtypes = argtypes
             fn.restype = ctypes.c_char_p if name == "pit_error_string" else _I
+        got = handle.pit_version()           # the default library and a PIT_LIB_PATH override alike
+        if got != ABI_VERSION:
+            raise RuntimeError(f"{LIB_PATH} implements PIT_ABI_VERSION {got}, this package binds version {ABI_VERSION}: "
+                               "rebuild it (python -m position_induced_transformer_amd.build)")
         _lib = handle
     return _lib
 

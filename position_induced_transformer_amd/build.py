@@ -17,8 +17,19 @@ FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared"
 FLAGS += os.environ.get("PIT_EXTRA_FLAGS", "").split()      # diagnostic builds only (e.g. -DPIT_STAMPS, tools/stamp_tiles.py)
 
 
+STAMP = os.path.join(CSRC, "_obj", "flags.stamp")
+
+
 def _stale() -> bool:
+    """Missing, older than a source / header, or built with OTHER flags (a -DPIT_STAMPS diagnostic build left in the
+    tree must not be taken for the production library: the flags of the last build are kept in _obj/flags.stamp)."""
     if not os.path.exists(LIB):
+        return True
+    try:
+        with open(STAMP) as f:
+            if f.read() != " ".join(FLAGS):
+                return True
+    except OSError:
         return True
     t = os.path.getmtime(LIB)
     deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS]
@@ -50,6 +61,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
         if verbose:
             print(" ".join(cmd))
         subprocess.run(cmd, check=True, cwd=CSRC)
+        with open(STAMP, "w") as f:
+            f.write(" ".join(FLAGS))
     return LIB
 
 

@@ -23,10 +23,17 @@ class FlatGradients:
     ``flatten_params=True`` the parameters themselves are also re-homed into one flat buffer
     (``flat_params``; values preserved), which is what the fused optimizer step works on."""
 
-    def __init__(self, params: Iterable[torch.nn.Parameter], flatten_params: bool = False):
+    def __init__(self, params: Iterable[torch.nn.Parameter], flatten_params: bool = False,
+                 tail: Iterable[torch.nn.Parameter] = ()):
+        """``tail``: parameters to lay out LAST, as one contiguous segment ``flat[tail_start:]`` - the bucket a
+        two-bucket step all-reduces early (their gradients are complete before the backward pass ends, see
+        engine.TrainStep(all_reduce_buckets=2))."""
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
         if not self.params:
             raise ValueError("no trainable parameters")
+        tail_ids = {id(p) for p in tail}
+        self.params = [p for p in self.params if id(p) not in tail_ids] + [p for p in self.params if id(p) in tail_ids]
+        n_head_params = sum(1 for p in self.params if id(p) not in tail_ids)
         dev, dt = self.params[0].device, self.params[0].dtype
         # every parameter starts on a 64-byte boundary of the flat buffers (zero padding in between):
         # the GEMM kernels use 16-byte operand loads only on aligned weight matrices
@@ -38,6 +45,7 @@ class FlatGradients:
         self.flat = torch.zeros(total, device=dev, dtype=dt)
         self.flat_params = torch.zeros(total, device=dev, dtype=dt) if flatten_params else None
         self.offsets = offsets
+        self.tail_start = offsets[n_head_params] if n_head_params < len(offsets) else total
         self._views = []
         for p, off in zip(self.params, offsets):
             n = p.numel()
@@ -83,21 +91,28 @@ class FlatGradients:
         """The gradients concatenated in parameter order WITHOUT the alignment padding (a copy)."""
         return torch.cat([p.grad.reshape(-1) for p in self.params])
 
-    def all_reduce(self, average: bool = False, group=None) -> None:
-        """Sum (or average) the flat buffer over the ranks; no-op without a process group."""
-        self.attach()                       # .grad tensors that left the flat buffer are copied back first
+    def all_reduce(self, average: bool = False, group=None, part: str = "all") -> None:
+        """Sum (or average) the flat buffer over the ranks; no-op without a process group.  ``part``: "all", or one
+        of the two buckets of a two-bucket step - "tail" (``flat[tail_start:]``) / "head" (``flat[:tail_start]``)."""
+        if part not in ("all", "head", "tail"):
+            raise ValueError(f"part must be 'all', 'head' or 'tail', got {part!r}")
+        if part != "tail":
+            self.attach()                   # .grad tensors that left the flat buffer are copied back first
         if not (dist.is_available() and dist.is_initialized()):
             return
-        if self.flat.is_cuda and dist.get_backend(group) == "gloo":
+        buf = self.flat if part == "all" else (self.flat[self.tail_start:] if part == "tail" else self.flat[:self.tail_start])
+        if buf.numel() == 0:
+            return
+        if buf.is_cuda and dist.get_backend(group) == "gloo":
             # gloo has no device collectives here: stage through the host (tests that share ONE GPU between
             # ranks use this; the production backend is "nccl" = RCCL, which reduces the device buffer in place)
-            host = self.flat.cpu()
+            host = buf.cpu()
             dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
-            self.flat.copy_(host)
+            buf.copy_(host)
         else:
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
         if average:
-            self.flat.div_(dist.get_world_size(group))
+            buf.div_(dist.get_world_size(group))
 
 
 def broadcast_parameters(module: torch.nn.Module, src: int = 0, group=None) -> None:
@@ -137,9 +152,10 @@ class FlatAdam:
         self.scalars = torch.zeros(4, device=dev, dtype=torch.float32)
 
     def step(self) -> None:
-        from . import _lib
+        from . import _lib, ops
         f = self.flat
         f.attach()
+        ops.parameters_changed()            # raw-pointer update: cached host-evaluated head scales are void
         rc = _lib.lib().pit_adam_step(f.flat_params.data_ptr(), f.flat.data_ptr(), self.exp_avg.data_ptr(),
                                       self.exp_avg_sq.data_ptr(), f.flat.numel(), self.step_count.data_ptr(),
                                       self.lr, self.eta_min, self.cosine_t_max, self.betas[0], self.betas[1],

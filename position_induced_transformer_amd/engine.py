@@ -16,22 +16,81 @@ from . import ops
 from .ddp import FlatGradients
 
 
+def early_gradient_parameters(model: torch.nn.Module):
+    """(parameters, module) for a two-bucket data-parallel step: the weights whose gradients are COMPLETE once the
+    backward pass has gone through processor block ``mid = n_blocks // 2`` (pit.py:116-121 in reverse: de, then
+    mlp[n-1] ... mlp[mid]; an MLP's weight-gradient reductions ride with the attention backward that follows it,
+    ops.MLP_PARAMS_RIDER) and the module whose OUTPUT gradient marks that point (mlp[mid-1]).  The lmda gradients
+    are finished by one launch at the end of the pass and stay in the late bucket."""
+    mlps, de = getattr(model, "mlp", None), getattr(model, "de", None)
+    if mlps is None or de is None or len(mlps) < 2:
+        return [], None
+    mid = len(mlps) // 2
+    params = [p for m in list(mlps[mid:]) + [de] for p in m.parameters() if p.requires_grad]
+    return params, mlps[mid - 1]
+
+
 class TrainStep:
     def __init__(self, model: torch.nn.Module, batch: Sequence[torch.Tensor], out_dim: int, p: int,
                  pred_affine: Optional[Sequence[torch.Tensor]] = None, all_reduce: bool = False,
-                 optimizer: Optional[torch.optim.Optimizer] = None, flat: Optional[FlatGradients] = None):
+                 optimizer: Optional[torch.optim.Optimizer] = None, flat: Optional[FlatGradients] = None,
+                 all_reduce_buckets: int = 1):
+        """``all_reduce_buckets=2``: the gradient exchange is split - the bucket of weights whose gradients are
+        complete half-way through the backward pass (early_gradient_parameters) is all-reduced on a second stream
+        while the rest of the backward runs, the remainder after the pass; needs a ``flat`` built with that
+        bucket as its ``tail`` (done here when ``flat`` is None)."""
         self.model = model
         self.mesh_in, self.func_in, self.mesh_out, self.target = batch
         self.out_dim, self.p = out_dim, p
         self.affine = pred_affine
         self.all_reduce = all_reduce
         self.optimizer = optimizer
+        self.buckets = 1
+        self._early_hook = None
+        if all_reduce_buckets == 2 and not ops.OVERLAP_BACKWARD:    # (side-stream weight gradients join at the end of the pass)
+            tail, marker = early_gradient_parameters(model)
+            if marker is not None:
+                if flat is None:
+                    flat = FlatGradients(model.parameters(), tail=tail)
+                if flat.tail_start < flat.flat.numel() and \
+                        {id(q) for q in flat.params[len(flat.params) - len(tail):]} == {id(q) for q in tail}:
+                    self.buckets = 2
+                    self._side = torch.cuda.Stream(device=self.func_in.device)
+                    self._early_hook = marker.register_forward_hook(self._mark_early_point)
+        elif all_reduce_buckets not in (1, 2):
+            raise ValueError("all_reduce_buckets must be 1 or 2")
         self.flat = flat if flat is not None else FlatGradients(model.parameters())
+        self._early_pending = False
         self.loss = torch.zeros((), device=self.func_in.device)
+        self.out = None
         self._seed = torch.ones((), device=self.func_in.device)      # d loss / d loss, allocated once
         self.graph: Optional[torch.cuda.CUDAGraph] = None
 
+    # two-bucket exchange: when the gradient of the marker module's output arrives, everything after it in the forward
+    # has been back-propagated (launches enqueued) - fork the second stream there and reduce the early bucket on it
+    def _mark_early_point(self, _module, _inputs, output):
+        if self.all_reduce and self.buckets == 2 and torch.is_tensor(output) and output.requires_grad:
+            output.register_hook(self._reduce_early_bucket)
+
+    def _reduce_early_bucket(self, _grad):
+        if not self._early_pending:
+            self._early_pending = True
+            cur = torch.cuda.current_stream()
+            self._side.wait_stream(cur)
+            with torch.cuda.stream(self._side):
+                self.flat.all_reduce(part="tail")
+        return None
+
+    def _exchange_gradients(self) -> None:
+        if self.buckets == 2 and self._early_pending:
+            self.flat.all_reduce(part="head")
+            torch.cuda.current_stream().wait_stream(self._side)
+            self._early_pending = False
+        else:
+            self.flat.all_reduce()
+
     def _step(self) -> None:
+        self._early_pending = False
         out = self.model(self.mesh_in, self.func_in, self.mesh_out)
         sc, sh = self.affine if self.affine is not None else (None, None)
         # the loss launch also writes its own gradient for the seed of ones below and clears the flat
@@ -41,8 +100,9 @@ class TrainStep:
         loss = ops.rel_lp_loss(self.target, out, self.out_dim, self.p, sc, sh, unit_seed=self._seed, clear=clear)
         torch.autograd.backward(loss, grad_tensors=self._seed)        # no ones_like fill per step
         self.loss = loss.detach()            # same storage every replay (graph-private pool): no copy
+        self.out = out.detach()              # (the prediction of the last step / replay: parity checks read it)
         if self.all_reduce:
-            self.flat.all_reduce()
+            self._exchange_gradients()
         if self.optimizer is not None:
             self.optimizer.step()          # torch optimizer (capturable) or ddp.FlatAdam (fused HIP step)
 
@@ -53,6 +113,12 @@ class TrainStep:
         """Warm up (allocator, mesh-plan caches, the per-stream accumulators of ops) and capture ON THE SAME
         side stream: a workspace first requested during capture would be allocated - and zero-filled by a
         captured memset on every replay - inside the graph."""
+        import position_induced_transformer_amd as _pkg
+        if not _pkg.GRAPH_PACKET_CAPTURE_OFF and getattr(getattr(self.model, "down", None), "_batched", False):
+            raise RuntimeError("this step builds per-sample selection plans inside the graph, which faults on replay with "
+                               "ROCm 7.2's hipGraph packet capture; DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 was not in effect "
+                               "when the HIP runtime started (import position_induced_transformer_amd, or export the "
+                               "variable, before the first .cuda() call) - run the step eagerly or restart")
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -60,13 +126,17 @@ class TrainStep:
                 self._step()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph, stream=side):
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
             self._step()
+        ops.assert_frozen_since_capture()     # route 'host': the graph must not update an lmda whose scale it baked in
+        self.graph = graph
         self._capture_stream = side
 
     def replay(self) -> None:
         self.graph.replay()
+        if self.optimizer is not None:
+            ops.parameters_changed()          # the replay rewrote the parameters behind autograd's back
 
     def set_batch(self, func_in: torch.Tensor, target: torch.Tensor, mesh_in: Optional[torch.Tensor] = None,
                   mesh_out: Optional[torch.Tensor] = None) -> None:
@@ -94,6 +164,7 @@ class RolloutStep(TrainStep):
 
     def __init__(self, model, batch, steps: int, out_dim: int, p: int, recompute: bool = False, **kw):
         mesh, x, y = batch
+        kw["all_reduce_buckets"] = 1         # the model is applied `steps` times: its weights' gradients complete at the end
         super().__init__(model, (mesh, x, mesh, y), out_dim, p, **kw)
         self.steps, self.recompute = steps, recompute
 

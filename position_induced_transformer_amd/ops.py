@@ -411,7 +411,7 @@ class _PosAtt(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, values, head, plan: MeshPlan, n_head: int, concat: bool, head_is_scale: bool,
-                head_param=None, out_slot=None, coord_dims: int = 0):
+                head_param=None, out_slot=None, coord_dims: int = 0, scale_in=None):
         _need_gpu(values, head)
         ctx.math = _math_code()
         ctx.coord_dims = int(coord_dims)
@@ -438,11 +438,14 @@ class _PosAtt(torch.autograd.Function):
             out = torch.empty((b, plan.n_out, width), device=values.device, dtype=torch.float32)
         rowstat = torch.empty((plan.mesh_batch, n_head, plan.n_out, 4), device=values.device, dtype=torch.float32)
         scale = torch.empty((n_head,), device=values.device, dtype=torch.float32)
+        # route 'host': `head` is lmda (autograd's input, the chain rule of the backward) but the kernels are
+        # handed the scale c the host evaluated for it (scale_in); the backward gets it back through `scale`
+        k_head, k_is_scale = (scale_in, True) if scale_in is not None else (head, head_is_scale)
         rc = _lib.lib().pit_posatt_fwd(
             plan.mesh_out.data_ptr(), plan.mesh_in.data_ptr(), plan.mesh_batch, plan.n_out, plan.n_in, plan.sdim,
             plan.metric_id, plan.period,
             values.data_ptr(), b, d, values.stride(1), values.stride(0),
-            head.data_ptr(), n_head, 1 if head_is_scale else 0,
+            k_head.data_ptr(), n_head, 1 if k_is_scale else 0,
             _lib.ptr(plan.stats), plan.rank_w, 1 if plan.masked else 0, 1 if plan.self_attn else 0,
             out.data_ptr(), out.stride(1), out.stride(0), d if concat else 0, copy_inputs,
             rowstat.data_ptr(), scale.data_ptr(),
@@ -504,7 +507,7 @@ class _PosAtt(torch.autograd.Function):
             launch(d_values, d_head, _lib.stream_ptr(), rider)
         if defer:
             _defer_head_finish(work, d_head, head, scale, n_head, 1 | (4 if ctx.head_is_scale else 0))
-        return d_values, (None if slot is not None else d_head), None, None, None, None, None, None, None
+        return d_values, (None if slot is not None else d_head), None, None, None, None, None, None, None, None
 
 
 # Where the head scale c = tan(0.25*pi*(1-1e-7)*(1+sin(lmda))) (pit.py:48) is evaluated.
@@ -515,9 +518,11 @@ class _PosAtt(torch.autograd.Function):
 #       threshold (DESIGN.md section 2 quantifies it).
 #   "host": the reference's own op sequence on the HOST CPU (torch.sin / torch.tan on a CPU copy of
 #       lmda, i.e. bit-for-bit what pit.py:48 computes on that machine), injected into the kernels as
-#       the scale; d(lmda) follows by torch-CPU autograd of the same expression.  One device->host
-#       copy per layer and step: for reproducing a reference checkpoint exactly (evaluation, parity
-#       tests), not for captured training steps.
+#       the scale and CACHED per lmda version (host_head_scale): one device->host copy per layer when
+#       lmda changed, none while it is frozen - evaluation of a checkpoint and forward+backward with
+#       frozen lmda are sync-free and hipGraph-capturable after one eager call.  d(lmda) is the kernels'
+#       closed-form chain rule (1+c^2)*K*cos(lmda) in fp64 with that exact c.  A captured step that
+#       UPDATES lmda (optimizer inside the graph) is refused: use 'device' there.
 HEAD_SCALE_ROUTES = ("device", "host")
 _ROUTE = threading.local()
 _DEFAULT_ROUTE = os.environ.get("PIT_HEAD_SCALE_ROUTE", "device")
@@ -553,24 +558,64 @@ class head_scale_route:
         return False
 
 
-class _HostHeadScale(torch.autograd.Function):
-    """c(lmda) by the reference's op sequence on the host CPU (pit.py:48), chain rule by torch-CPU autograd."""
+# Anything that rewrites parameters behind autograd's back (raw-pointer writers: ddp.FlatAdam, a replayed
+# hipGraph that contains an optimizer step) bumps this epoch through ``parameters_changed()``; together with the
+# tensor's own version counter (bumped by every torch in-place op: torch.optim, load_state_dict, copy_) it keys the
+# cached host-evaluated head scales below.
+_PARAM_EPOCH = [0]
+_HOSTC_CAPTURE = {"used": False, "log": []}      # scales consumed under the running stream capture: (lmda, version)
+HOST_SCALE_EVALUATIONS = [0]                     # device->host round trips taken by host_head_scale (tests read it)
 
-    @staticmethod
-    def forward(ctx, lmda):
+
+def parameters_changed() -> None:
+    """Tell the operators that parameter VALUES were rewritten without a torch in-place op (fused optimizer
+    through raw pointers, graph replay of a captured optimizer step): cached head scales are dropped.  Inside a
+    stream capture that already consumed a cached scale this is an error - replays would change lmda while the
+    graph keeps feeding the kernels the scale of the lmda it was captured with."""
+    if _capturing() and _HOSTC_CAPTURE["used"]:
+        raise RuntimeError("head-scale route 'host' is exact for a FROZEN lmda only: this capture consumed a "
+                           "host-evaluated scale and now updates the parameters inside the same graph; capture "
+                           "training steps that include the optimizer with the 'device' route")
+    _PARAM_EPOCH[0] += 1
+
+
+def host_head_scale(lmda: torch.Tensor) -> torch.Tensor:
+    """c(lmda) (n_head floats on lmda's device) by the reference's own op sequence on the HOST CPU - bit-for-bit
+    what pit.py:48 evaluates on this machine - cached on the tensor per (version counter, storage, epoch):
+    one device->host copy when lmda changed, none while it is frozen (evaluation, fwd+bwd benchmarks), so a step
+    with frozen lmda is sync-free and can be captured into a hipGraph after one eager call.  A miss under capture
+    raises: the copy would synchronise."""
+    key = (lmda._version, lmda.data_ptr(), _PARAM_EPOCH[0], lmda.device.index)
+    ent = getattr(lmda, "_pit_host_c", None)
+    if ent is None or ent[0] != key:
         if _capturing():
-            raise RuntimeError("head-scale route 'host' synchronises with the host and cannot be captured into a "
-                               "hipGraph; use the default 'device' route for captured steps")
-        host = lmda.detach().cpu().requires_grad_(True)
-        with torch.enable_grad():
-            c = torch.tan(0.25 * math.pi * (1 - 1e-7) * (1.0 + torch.sin(host)))
-        ctx.host, ctx.c = host, c
-        return c.detach().to(lmda.device)
+            raise RuntimeError("head-scale route 'host' cannot be captured into a hipGraph for an lmda whose scale "
+                               "has not been evaluated yet (that needs a device->host copy): run the step once "
+                               "eagerly with this route first, or use the 'device' route")
+        HOST_SCALE_EVALUATIONS[0] += 1
+        host = lmda.detach().reshape(-1).cpu()
+        c = torch.tan(0.25 * math.pi * (1 - 1e-7) * (1.0 + torch.sin(host)))
+        ent = (key, c.to(lmda.device))
+        lmda._pit_host_c = ent
+    if _capturing():
+        _HOSTC_CAPTURE["used"] = True
+        _HOSTC_CAPTURE["log"].append((lmda, lmda._version))
+        _pin(ent[1])
+    else:
+        _HOSTC_CAPTURE["used"] = False
+        _HOSTC_CAPTURE["log"].clear()
+    return ent[1]
 
-    @staticmethod
-    def backward(ctx, d_c):
-        (d_l,) = torch.autograd.grad(ctx.c, ctx.host, d_c.detach().cpu().reshape(ctx.c.shape))
-        return d_l.to(d_c.device)
+
+def assert_frozen_since_capture() -> None:
+    """After a capture (engine.TrainStep.capture): every lmda whose host-evaluated scale went into the graph must
+    not have been modified by the captured work (a torch optimizer inside the graph bumps its version)."""
+    log, _HOSTC_CAPTURE["log"] = _HOSTC_CAPTURE["log"], []
+    _HOSTC_CAPTURE["used"] = False
+    for lmda, version in log:
+        if lmda._version != version:
+            raise RuntimeError("head-scale route 'host' is exact for a FROZEN lmda only, but the captured step "
+                               "modified lmda (an optimizer inside the graph): capture it with the 'device' route")
 
 
 def _concat_buffer_of(values: torch.Tensor, n_out: int, n_head: int):
@@ -616,11 +661,9 @@ def posatt_apply(values: torch.Tensor, lmda: torch.Tensor, plan: MeshPlan, n_hea
     Opaque to torch.compile (dynamo runs it eagerly: raw pointers cross a ctypes boundary)."""
     out_buf = _concat_buffer_of(values, plan.n_out, n_head) if concat else None
     slot = [out_buf] if out_buf is not None else None
-    if not head_is_scale and get_head_scale_route() == "host":
-        c = _HostHeadScale.apply(lmda.reshape(-1))
-        return _PosAtt.apply(values, c, plan, n_head, concat, True, None, slot, coord_dims)
     param = lmda if isinstance(lmda, torch.nn.Parameter) else None
-    return _PosAtt.apply(values, lmda.reshape(-1), plan, n_head, concat, head_is_scale, param, slot, coord_dims)
+    c = host_head_scale(lmda) if (not head_is_scale and get_head_scale_route() == "host") else None
+    return _PosAtt.apply(values, lmda.reshape(-1), plan, n_head, concat, head_is_scale, param, slot, coord_dims, c)
 
 
 class _Mlp(torch.autograd.Function):

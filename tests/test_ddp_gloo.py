@@ -147,3 +147,55 @@ def test_shard_batch_partitions_exactly():
                 s = shard_batch(n, r, w)
                 idx += list(range(n))[s]
             assert idx == list(range(n))
+
+
+def _worker_buckets(rank, world, port, out_dir):
+    """Two-bucket exchange (engine.TrainStep(all_reduce_buckets=2)): the flat buffer laid out with the early
+    bucket as its tail, reduced as "tail" then "head", equals the single all-reduce of the default layout."""
+    for pth in (ROOT, HERE, os.path.join(ROOT, "oracle")):
+        sys.path.insert(0, pth)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    import golden_io as gio
+    import pit_oracle as orc
+    from position_induced_transformer_amd.ddp import FlatGradients, shard_batch
+
+    shapes = orc.param_shapes(2, 1, 1, 16, 2, 2)
+    x = torch.from_numpy(gio.synth((4, 144, 1), 77))
+    y = torch.from_numpy(gio.synth((4, 144, 1), 78))
+    sl = shard_batch(4, rank, world)
+    res = {}
+    for mode in ("one", "two"):
+        params = {k: torch.nn.Parameter(torch.from_numpy(v)) for k, v in gio.synth_params(shapes, 10).items()}
+        tail = [v for k, v in params.items() if k.startswith(("mlp.1.", "de."))] if mode == "two" else ()
+        flat = FlatGradients(params.values(), tail=tail)
+        if mode == "two":
+            assert 0 < flat.tail_start < flat.flat.numel()
+            assert [id(q) for q in flat.params[-len(tail):]] == [id(q) for q in tail]
+        else:
+            assert flat.tail_start == flat.flat.numel()
+        flat.zero_()
+        g = _oracle_grads({k: v.data for k, v in params.items()}, x[sl], y[sl])
+        for k, p in params.items():
+            p.grad.add_(g[k].grad)
+        if mode == "two":
+            before_head = flat.flat[:flat.tail_start].clone()
+            flat.all_reduce(part="tail")
+            assert torch.equal(flat.flat[:flat.tail_start], before_head)      # the late bucket is untouched
+            flat.all_reduce(part="head")
+        else:
+            flat.all_reduce()
+        res[mode] = {k: p.grad.clone() for k, p in params.items()}
+    if rank == 0:
+        err = max(float((res["two"][k] - res["one"][k]).abs().max()) for k in res["one"])
+        np.save(os.path.join(out_dir, "err_buckets.npy"), np.asarray([err]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_bucket_exchange_equals_one_allreduce(tmp_path):
+    port = _free_port()
+    mp.spawn(_worker_buckets, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    (err,) = np.load(os.path.join(tmp_path, "err_buckets.npy"))
+    assert err == 0.0, err

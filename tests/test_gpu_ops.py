@@ -151,7 +151,10 @@ def test_posatt_lmda_path(ops, name, draw):
     c_dev = ops.head_scale(dev(lmda)).cpu().numpy()
     ulp = _ulp(_c_host(lmda), c_dev)
     assert (ulp > 0) if draw == "differing" else True
-    assert ulp <= 64, f"lmda->c differs from this host's ATen by {ulp} ulp"
+    # analytic bound: a 1-ulp difference in sin(lmda) can move fl(1+s) - and with it u = K(1+s) - by one ulp; near
+    # lmda -> 1 (u = 1.446, c = 7.98) d c = (1+c^2) d u = 64.7 * 2^-23 = 16 ulp of c, plus the host tan's own < 1 ulp
+    # and the device's final rounding: <= 18 (17 was observed on the build container's Xeon); 24 leaves a margin
+    assert ulp <= 24, f"lmda->c differs from this host's ATen by {ulp} ulp"
     d_out = gio.synth((cs["values"].shape[0], plan.n_out, (n_head + (1 if cs["self_attn"] else 0)) * cs["values"].shape[2]),
                       cs["seed"] + 1000)
 
@@ -429,16 +432,30 @@ def test_raw_ctypes_binding_as_in_integration_md():
     out = torch.empty(b, n, h * d, device="cuda")
     rowstat = torch.empty(1, h, n, 4, device="cuda")
     scale = torch.empty(h, device="cuda")
-    rc = L.pit_posatt_fwd(mesh_out.data_ptr(), mesh_in.data_ptr(), 1, n, j, s, 0, 0.0,
-                          inputs.data_ptr(), b, d, inputs.stride(1), inputs.stride(0),
-                          lmda.data_ptr(), h, 0, stats.data_ptr(), w, 1, 0,
-                          out.data_ptr(), out.stride(1), out.stride(0), 0, 0,
-                          rowstat.data_ptr(), scale.data_ptr(), None, None, 0, 0, 0, stream)   # coord_dims 0, PIT_MATH_FP32
-    assert rc == 0
-    torch.cuda.synchronize()
-    ulp = np.abs(scale.cpu().numpy().view(np.int32).astype(np.int64) - cs["c"].reshape(-1).view(np.int32).astype(np.int64)).max()
-    e, g, _, _ = gio.expect(fx, "out", out.cpu().numpy())
-    assert ulp <= 1 and gio.rel_l2(e, g) <= (TOL_FWD if ulp == 0 else 5e-3)
+
+    def forward(head, head_is_scale):
+        rc = L.pit_posatt_fwd(mesh_out.data_ptr(), mesh_in.data_ptr(), 1, n, j, s, 0, 0.0,
+                              inputs.data_ptr(), b, d, inputs.stride(1), inputs.stride(0),
+                              head.data_ptr(), h, head_is_scale, stats.data_ptr(), w, 1, 0,
+                              out.data_ptr(), out.stride(1), out.stride(0), 0, 0,
+                              rowstat.data_ptr(), scale.data_ptr(), None, None, 0, 0, 0, stream)   # coord_dims 0, PIT_MATH_FP32
+        assert rc == 0
+        torch.cuda.synchronize()
+        return out.cpu().numpy(), scale.cpu().numpy()
+
+    # (1) the reference's own c (stored with the fixture) injected: the golden output, no libm in the way
+    got, c_used = forward(dev(cs["c"].reshape(-1)).contiguous(), 1)
+    assert np.array_equal(c_used, cs["c"].reshape(-1))
+    e, g, _, _ = gio.expect(fx, "out", got)
+    assert gio.rel_l2(e, g) <= TOL_FWD
+    # (2) lmda handed over, c evaluated in the kernel (within a few ulp of any host's libm, see test_posatt_lmda_path):
+    #     the output is the oracle's for exactly THAT c - whatever it is, on every host
+    got, c_used = forward(lmda, 0)
+    assert _ulp(c_used, cs["c"].reshape(-1)) <= 24
+    with torch.no_grad():
+        ref = orc.posatt_cross("euclid", False, torch.from_numpy(cs["mesh_out"]), torch.from_numpy(cs["mesh_in"]),
+                               torch.from_numpy(cs["values"]), None, q, c=torch.from_numpy(c_used.reshape(cs["lmda"].shape)))
+    assert gio.rel_l2(ref.numpy(), got) <= TOL_FWD
 
 
 def test_overflowed_candidate_lists_take_the_overflow_pass():

@@ -72,9 +72,10 @@ SWEEP_SEEDS = 200
 # Fraction of unselected seeds whose device-route output is more than 1e-5 from the oracle ON THE SAME
 # HOST.  It is a property of the host's libm as much as of the kernels: measured 0.22 (Darcy) on the
 # MI355X box (EPYC 9575F: MKL's VML kernels for AMD CPUs disagree with the correctly rounded c for ~19 %
-# of lmda, 185 of 200 seeds have at least one differing c) - profiles/r02_lmda_route_sweep.json.  The
-# test fails if the fraction grows beyond this bound.
-MAX_FRACTION_ABOVE_1E5 = {"F9_model_darcy": 0.35, "F11_model_burgers": 0.35}
+# of lmda, 185 of 200 seeds have at least one differing c); 0.005 (Burgers: 1 of 200) -
+# profiles/r02_lmda_route_sweep.json.  The test fails if the fraction grows beyond this bound.
+# Guards set to what was measured plus a margin for host-to-host variation of the libm (round 2 had 0.35 for both).
+MAX_FRACTION_ABOVE_1E5 = {"F9_model_darcy": 0.25, "F11_model_burgers": 0.02}
 
 
 @pytest.mark.parametrize("name", ["F9_model_darcy", "F11_model_burgers"])
@@ -190,20 +191,6 @@ def test_host_route_gradients_match_the_oracle_on_a_seed_where_c_differs():
     for k, q in model.named_parameters():
         tol = 2e-4 if k.endswith("lmda") else 2e-5
         assert gio.rel_l2(p[k].grad.numpy().reshape(-1), q.grad.cpu().numpy().reshape(-1)) <= tol, (k, differs)
-
-
-def test_host_route_refuses_graph_capture():
-    from position_induced_transformer_amd import ops, tasks
-    model, sample, _ = tasks.make_task("darcy", seed=1)
-    mesh_in, func_in, mesh_out, _ = sample(2)
-    model(mesh_in, func_in, mesh_out)                       # warm the plan caches
-    torch.cuda.synchronize()
-    g = torch.cuda.CUDAGraph()
-    with ops.head_scale_route("host"):
-        with pytest.raises(RuntimeError, match="cannot be captured"):
-            with torch.cuda.graph(g):
-                model(mesh_in, func_in, mesh_out)
-    torch.cuda.synchronize()
 
 
 # --------------------------------------------------------------------------- RelMaxNorm

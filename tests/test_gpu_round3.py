@@ -1,0 +1,243 @@
+"""GPU: round 3 - the exact head-scale route made capturable for a frozen lmda (cached host evaluation),
+the RCCL path exercised through a 1-rank torch.distributed.run child, subclass overrides of dist2att /
+convolution, concurrency of the backward bookkeeping."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import golden_io as gio
+import model_cases as mc
+import pit_oracle as orc
+from test_gpu_models import build_model
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _params_whose_device_c_differs(cs, lo=5000, hi=5400):
+    from position_induced_transformer_amd import ops
+    for seed in range(lo, hi):
+        params = gio.synth_params(cs["shapes"], seed)
+        differs = [k for k, v in params.items() if k.endswith("lmda") and not np.array_equal(
+            orc.head_scale(torch.from_numpy(v)).numpy(), ops.head_scale(torch.from_numpy(v).cuda()).cpu().numpy())]
+        if differs:
+            return params, differs
+    pytest.skip("no seed in range with a differing c on this host")
+
+
+def _oracle_step(cs, params):
+    cfg = cs["cfg"]
+    p = {k: torch.from_numpy(v).requires_grad_(True) for k, v in params.items()}
+    mi = cs["mesh_in"].reshape(-1, 2)
+    ref = orc.pit_apply(p, "euclid", False, cfg["n_blocks"], cfg["en_loc"], cfg["de_loc"], mi,
+                        orc.with_coords(mi, cs["func_in"].reshape(2, -1, 1)), cs["mesh_ltt"].reshape(-1, 2), mi)
+    ref_loss = orc.rel_lp_loss(cs["target"], ref.reshape(2, 43, 43, 1), 1, 2)
+    ref_loss.backward()
+    return p, ref.detach().numpy().reshape(-1), float(ref_loss)
+
+
+# --------------------------------------------------------------------------- exact route, cached
+def test_host_route_graph_replay_matches_oracle_on_a_seed_whose_device_c_differs():
+    """VERDICT r2 next-1 'done' criterion.  A Darcy parameter set for which the in-kernel c differs from this
+    host's ATen c in at least one layer: the forward+loss+backward step captured under route 'host' (c evaluated
+    by the reference's torch-CPU ops once, cached while lmda is frozen) replays to the oracle's prediction
+    <= 1e-5, loss, weight gradients <= 2e-5 and d(lmda) <= 2e-4; replays take no device->host copy."""
+    from position_induced_transformer_amd import ops
+    from position_induced_transformer_amd.engine import TrainStep
+    cs = mc.build_case("F9_model_darcy")
+    params, differs = _params_whose_device_c_differs(cs)
+    model = build_model(cs, params)
+    step = TrainStep(model, (cs["mesh_in"].cuda(), cs["func_in"].cuda(), cs["mesh_out"].cuda(), cs["target"].cuda()), 1, 2)
+    with ops.head_scale_route("host"):
+        step.capture()
+        evals = ops.HOST_SCALE_EVALUATIONS[0]
+        for _ in range(3):
+            step.replay()
+        torch.cuda.synchronize()
+        assert ops.HOST_SCALE_EVALUATIONS[0] == evals
+    p, ref, ref_loss = _oracle_step(cs, params)
+    assert gio.rel_l2(ref, step.out.cpu().numpy().reshape(-1)) <= 1e-5, differs
+    assert abs(float(step.loss) - ref_loss) <= 1e-5 * abs(ref_loss)
+    for k, q in model.named_parameters():
+        tol = 2e-4 if k.endswith("lmda") else 2e-5
+        assert gio.rel_l2(p[k].grad.numpy().reshape(-1), q.grad.cpu().numpy().reshape(-1)) <= tol, (k, differs)
+
+
+def test_host_route_is_sync_free_while_lmda_is_frozen_and_re_evaluates_when_it_changes():
+    from position_induced_transformer_amd import ops, tasks, utils
+    model, sample, meta = tasks.make_task("darcy", seed=2)
+    mesh_in, func_in, mesh_out, target = sample(2)
+    loss_fn = utils.RelLpNorm(1, 2)
+    n_layers = sum(1 for k, _ in model.named_parameters() if k.endswith("lmda"))
+    with ops.head_scale_route("host"):
+        e0 = ops.HOST_SCALE_EVALUATIONS[0]
+        out0 = model(mesh_in, func_in, mesh_out)
+        assert ops.HOST_SCALE_EVALUATIONS[0] == e0 + n_layers
+        torch.cuda.synchronize()
+        torch.cuda.set_sync_debug_mode("error")          # any synchronising call raises from here on
+        try:
+            out1 = model(mesh_in, func_in, mesh_out)
+            loss_fn(target, out1).backward()
+        finally:
+            torch.cuda.set_sync_debug_mode("default")
+        assert ops.HOST_SCALE_EVALUATIONS[0] == e0 + n_layers
+        assert torch.equal(out0, out1)
+        with torch.no_grad():                            # a torch in-place update bumps the version counter
+            model.up.lmda.add_(0.25)
+        out2 = model(mesh_in, func_in, mesh_out)
+        assert ops.HOST_SCALE_EVALUATIONS[0] == e0 + n_layers + 1
+        assert not torch.equal(out1, out2)
+        ops.parameters_changed()                         # what raw-pointer writers (ddp.FlatAdam) announce
+        model(mesh_in, func_in, mesh_out)
+        assert ops.HOST_SCALE_EVALUATIONS[0] == e0 + 2 * n_layers + 1
+
+
+def test_host_route_capture_is_refused_for_an_unevaluated_lmda_and_for_an_optimizer_in_the_graph():
+    from position_induced_transformer_amd import ops, tasks
+    from position_induced_transformer_amd.ddp import FlatAdam, FlatGradients
+    from position_induced_transformer_amd.engine import TrainStep
+    model, sample, _ = tasks.make_task("darcy", seed=1)
+    mesh_in, func_in, mesh_out, target = sample(2)
+    model(mesh_in, func_in, mesh_out)                       # warm the plan caches (device route: no c cached)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with ops.head_scale_route("host"):
+        with pytest.raises(RuntimeError, match="cannot be captured"):
+            with torch.cuda.graph(g):
+                model(mesh_in, func_in, mesh_out)
+    torch.cuda.synchronize()
+    # (a) the fused optimizer (raw-pointer update) inside the graph
+    flat = FlatGradients(model.parameters(), flatten_params=True)
+    step = TrainStep(model, (mesh_in, func_in, mesh_out, target), 1, 2, optimizer=FlatAdam(flat, lr=1e-3), flat=flat)
+    with ops.head_scale_route("host"):
+        with pytest.raises(RuntimeError, match="FROZEN lmda"):
+            step.capture()
+    torch.cuda.synchronize()
+    assert step.graph is None
+    # (b) a torch optimizer (capturable) inside the graph: caught by lmda's version counter after the capture
+    model2, _, _ = tasks.make_task("darcy", seed=1)
+    opt = torch.optim.Adam(model2.parameters(), lr=1e-3, capturable=True)
+    step2 = TrainStep(model2, (mesh_in, func_in, mesh_out, target), 1, 2, optimizer=opt)
+    with ops.head_scale_route("host"):
+        with pytest.raises(RuntimeError, match="FROZEN lmda"):
+            step2.capture()
+    torch.cuda.synchronize()
+    assert step2.graph is None
+    # the same steps capture fine on the device route
+    step.capture()
+    step.replay()
+    torch.cuda.synchronize()
+    assert torch.isfinite(step.loss)
+
+
+# --------------------------------------------------------------------------- RCCL path, one rank
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.parametrize("extra", [[], ["--ar-buckets", "2"]], ids=["one-allreduce", "two-buckets"])
+def test_bench_under_torch_distributed_run_one_rank_captures_the_rccl_allreduce(extra):
+    """VERDICT r2 next-4.  `python -m torch.distributed.run --nproc-per-node 1 bench.py ...` exactly as the driver
+    launches N > 1 (a FRESH child: the launcher runs before anything touches the GPU): process group on backend
+    'nccl' (= RCCL), the flat-gradient all-reduce captured INSIDE the step's hipGraph and replayed - rc 0, one JSON
+    line, launch mode 'hipgraph' (not the eager-all-reduce fallback), parity block within tolerance."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "5", "--warmup", "2",
+           "--no-extras", "--no-cpu-baseline"] + extra
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["config"]["launch"] == "hipgraph", rec["config"]
+    assert rec["config"]["allreduce"]["backend"] == "nccl" and rec["config"]["allreduce"]["captured"] is True, rec["config"]
+    assert rec["config"]["allreduce"]["buckets"] == (2 if extra else 1)
+    assert rec["n_gpus"] == 1 and rec["value"] > 0
+    assert rec["parity"]["rel_l2_out"] <= 1e-5 and rec["parity"]["rel_l2_weight_grad_worst"] <= 2e-5, rec["parity"]
+
+
+# --------------------------------------------------------------------------- subclass overrides (pit.py:42-43)
+def test_overridden_convolution_and_dist2att_are_what_forward_runs():
+    from position_induced_transformer_amd import pit as P
+    torch.manual_seed(5)
+    mesh = torch.rand(64, 2, device="cuda")
+    x = torch.randn(3, 64, 8, device="cuda", requires_grad=True)
+
+    class doubled(P.posatt_fixed):
+        def convolution(self, A, U):
+            return 2.0 * super().convolution(A, U)
+
+    class all_keys(P.posatt_cross_fixed):
+        def dist2att(self, mesh_out, mesh_in, scale, locality):
+            return super().dist2att(mesh_out, mesh_in, scale, 1.0)       # ignores the layer's locality
+
+    base, mine = P.posatt_fixed(2, 8, 1.0).cuda(), doubled(2, 8, 1.0).cuda()
+    mine.load_state_dict(base.state_dict())
+    ref, got = base(mesh, x), mine(mesh, x)
+    assert torch.equal(got[..., :8], ref[..., :8])
+    assert gio.rel_l2((2.0 * ref[..., 8:]).detach().cpu().numpy(), got[..., 8:].detach().cpu().numpy()) <= 1e-6
+    got.square().sum().backward()                                         # gradients flow through the composed path
+    assert mine.lmda.grad is not None and torch.isfinite(mine.lmda.grad).all() and x.grad is not None
+    masked, unmasked, override = P.posatt_cross_fixed(2, 8, 0.1).cuda(), P.posatt_cross_fixed(2, 8, 1.0).cuda(), all_keys(2, 8, 0.1).cuda()
+    unmasked.load_state_dict(masked.state_dict())
+    override.load_state_dict(masked.state_dict())
+    out_mesh = torch.rand(16, 2, device="cuda")
+    a, b, c = masked(out_mesh, mesh, x), unmasked(out_mesh, mesh, x), override(out_mesh, mesh, x)
+    assert gio.rel_l2(b.detach().cpu().numpy(), c.detach().cpu().numpy()) <= 1e-6
+    assert gio.rel_l2(b.detach().cpu().numpy(), a.detach().cpu().numpy()) > 1e-3
+
+
+# --------------------------------------------------------------------------- backward bookkeeping under threads
+def test_two_threads_running_backward_concurrently_give_the_single_thread_gradients():
+    """the deferred d(lmda) finishes and the postponed weight-gradient reductions are keyed on
+    autograd's graph-task id in process-global tables.  Two Python threads, each with its own model, flat gradient
+    buffer and stream, run forward+backward at the same time: every gradient must equal the one the same model gives
+    alone (the bookkeeping either isolates the passes or falls back to un-merged launches - never mixes them)."""
+    import threading
+    from position_induced_transformer_amd import tasks, utils
+    from position_induced_transformer_amd.ddp import FlatGradients
+    loss_fn = utils.RelLpNorm(1, 2)
+    jobs = []
+    for seed in (11, 12):
+        model, sample, _ = tasks.make_task("darcy", seed=seed)
+        mesh_in, func_in, mesh_out, target = sample(4)
+        flat = FlatGradients(model.parameters())
+        loss_fn(target, model(mesh_in, func_in, mesh_out)).backward()
+        torch.cuda.synchronize()
+        jobs.append(dict(model=model, batch=(mesh_in, func_in, mesh_out, target), flat=flat, want=flat.flat.clone(),
+                         stream=torch.cuda.Stream(), errors=[]))
+    barrier = threading.Barrier(2)
+
+    def work(job):
+        try:
+            mesh_in, func_in, mesh_out, target = job["batch"]
+            with torch.cuda.stream(job["stream"]):
+                for _ in range(20):
+                    job["flat"].zero_()
+                    barrier.wait()
+                    loss_fn(target, job["model"](mesh_in, func_in, mesh_out)).backward()
+                    job["stream"].synchronize()
+                    err = gio.rel_l2(job["want"].cpu().numpy(), job["flat"].flat.cpu().numpy())
+                    if not err <= 2e-5:
+                        job["errors"].append(err)
+        except Exception as exc:                                        # a clean refusal is acceptable, silence is not
+            job["errors"].append(repr(exc))
+            barrier.abort()
+
+    threads = [threading.Thread(target=work, args=(j,)) for j in jobs]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    torch.cuda.synchronize()
+    for j in jobs:
+        assert not j["errors"], j["errors"][:3]

@@ -177,3 +177,56 @@ def test_inplace_gradient_slots_are_opt_in():
     ops.mark_inplace_grad(p, p.grad)
     # (CPU tensors never qualify: the check is for device fp32 buffers)
     assert ops._grad_slot(p) is None
+
+
+# --------------------------------------------------------------------------- round 3
+def test_importing_ops_or_utils_does_not_fire_the_drop_in_side_effects():
+    """the reference's import-time side effects (pit.py:1-11) belong to the drop-in module `pit` only."""
+    import subprocess
+    code = ("import sys, torch; torch.manual_seed(123); a = torch.rand(1).item();"
+            "torch.manual_seed(123); import position_induced_transformer_amd.ops, position_induced_transformer_amd.utils;"
+            "assert 'position_induced_transformer_amd.pit' not in sys.modules;"
+            "assert torch.rand(1).item() == a;"                    # the global RNG was not reseeded
+            "import position_induced_transformer_amd as P; P.pit;"  # lazy attribute: loads (and seeds, as pit.py:3)
+            "assert 'position_induced_transformer_amd.pit' in sys.modules;"
+            "torch.manual_seed(0); b = torch.rand(1).item(); import importlib;"
+            "importlib.reload(sys.modules['position_induced_transformer_amd.pit']); assert torch.rand(1).item() == b")
+    res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT, timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]
+
+
+def test_subclass_overrides_of_dist2att_or_convolution_are_detected():
+    """pit.py:42-43 calls self.dist2att / self.convolution: a subclass that overrides either must not be bypassed."""
+    from position_induced_transformer_amd import pit as P
+
+    class mine(P.posatt_fixed):
+        def convolution(self, A, U):
+            return 2.0 * super().convolution(A, U)
+
+    class other(P.posatt_cross):
+        def dist2att(self, mesh_out, mesh_in, scale, locality):
+            return super().dist2att(mesh_out, mesh_in, scale, 1.0)
+
+    for cls in (P.posatt, P.posatt_cross, P.posatt_fixed, P.posatt_cross_fixed, P.posatt_periodic1d,
+                P.posatt_cross_periodic1d, P.posatt_periodic2d, P.posatt_cross_periodic2d):
+        assert not cls(2, 4, 0.5)._overridden(), cls
+    assert mine(2, 4, 0.5)._overridden() and other(2, 4, 0.5)._overridden()
+    a, u = torch.rand(2, 5, 7, dtype=torch.float32), torch.rand(3, 7, 4)
+    want = torch.einsum("hnj,bjd->bnhd", a.double(), u.double()).reshape(3, 5, 8).float()
+    assert torch.equal(P.posatt_fixed(2, 4, 1.0).convolution(a, u), want)          # exact fp64 contraction, rounded once
+    assert torch.get_float32_matmul_precision() == "high"                           # (pit.py:2; the helper does not toggle it)
+
+
+def test_build_is_stale_after_a_build_with_other_flags_and_the_binding_checks_the_abi_version(tmp_path, monkeypatch):
+    from position_induced_transformer_amd import _lib, build
+    assert not build._stale()
+    monkeypatch.setattr(build, "FLAGS", build.FLAGS + ["-DPIT_STAMPS"])
+    assert build._stale()                       # a diagnostic build would not be mistaken for this one, nor vice versa
+    monkeypatch.undo()
+    assert _lib.lib().pit_version() == _lib.ABI_VERSION
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "ABI_VERSION", _lib.ABI_VERSION + 1)
+    with pytest.raises(RuntimeError, match="PIT_ABI_VERSION"):
+        _lib.lib()
+    monkeypatch.undo()
+    assert _lib.lib() is not None
