@@ -123,9 +123,14 @@ def _dscale_workspace(device, n_head: int) -> torch.Tensor:
 # pass (pit_posatt_dhead_finish) instead of one small kernel per layer; applies when the gradient
 # goes in place into lmda.grad (the training path), needs one accumulator buffer per layer.
 DEFER_HEAD_FINISH = os.environ.get("PIT_DEFER_HEAD_FINISH", "1") != "0"
-_PENDING_HEADS = []      # (workspace, d_head, lmda, scale, n_head, flags) of the running backward pass
-_PENDING_TASK = [None]   # graph-task id that _PENDING_HEADS belongs to (None: nothing queued)
+# Both this table and the postponed weight-gradient jobs below are keyed on autograd's graph-task id: backward passes
+# of DIFFERENT models may interleave (two Python threads calling backward(): the engine's one device thread runs their
+# nodes alternately) without seeing each other's entries.  An entry whose pass raised before its end-of-pass callback
+# ran is recognised when another pass wants the same accumulators / gradient slots (two live passes accumulating
+# into the same .grad are a race in torch itself): its partial sums are zeroed and it is forgotten.
+_PENDING_HEADS = {}      # graph-task id -> [(workspace, d_head, lmda, scale, n_head, flags), ...]
 _LAYER_WS = {}
+_MAX_PENDING_TASKS = 64
 
 
 def _layer_workspace(slot: torch.Tensor, n_head: int) -> torch.Tensor:
@@ -140,19 +145,17 @@ def _layer_workspace(slot: torch.Tensor, n_head: int) -> torch.Tensor:
     return ws
 
 
-def _flush_head_finishes() -> None:
-    """End-of-backward callback: one launch finishing d(lmda) of all deferred layers."""
+def _flush_head_finishes(task: int) -> None:
+    """End-of-backward callback of graph task ``task``: one launch finishing d(lmda) of all its deferred layers."""
     # a layer applied several times in one pass (the autoregressive rollout: train_vorticity.py:122-126)
     # deferred once per application into the SAME accumulators: drain them once - duplicates in one batch
     # would race on the non-atomic "d_head += ..." of the finishing kernel
     seen, pend = set(), []
-    for entry in _PENDING_HEADS:
+    for entry in _PENDING_HEADS.pop(task, ()):
         key = (entry[0].data_ptr(), entry[1].data_ptr())
         if key not in seen:
             seen.add(key)
             pend.append(entry)
-    _PENDING_HEADS.clear()
-    _PENDING_TASK[0] = None
     for dev in sorted({p[0].device.index for p in pend}):
         grp = [p for p in pend if p[0].device.index == dev]
         for i in range(0, len(grp), 32):
@@ -169,33 +172,39 @@ def _flush_head_finishes() -> None:
             _lib.check(rc, "pit_posatt_dhead_finish")
 
 
-def _defer_head_begin() -> None:
-    """Call BEFORE the backward kernel of a deferred layer loads its accumulators.  On the first
-    deferred layer of a backward pass: entries left by another pass mean that pass raised before its
-    end-of-pass callback ran (autograd skips the callbacks then) - their accumulators hold partial
-    sums of an aborted pass: zero them, forget the entries; then queue this pass's flush."""
+def _defer_head_begin(work: torch.Tensor) -> None:
+    """Call BEFORE the backward kernel of a deferred layer loads its accumulators ``work``.  Entries of ANOTHER pass
+    on the same accumulators mean that pass raised before its end-of-pass callback ran (autograd skips the
+    callbacks then): they hold partial sums of an aborted pass - zero them, forget the entries.  On the first
+    deferred layer of this pass: queue its flush."""
     task = _graph_task()
-    if _PENDING_TASK[0] != task:
-        for stale in _PENDING_HEADS:
-            stale[0].zero_()
-        _PENDING_HEADS.clear()
-        _PENDING_TASK[0] = task
-        torch.autograd.Variable._execution_engine.queue_callback(_flush_head_finishes)
+    ptr = work.data_ptr()
+    for other in [t for t in _PENDING_HEADS if t != task]:
+        stale = [e for e in _PENDING_HEADS[other] if e[0].data_ptr() == ptr]
+        if stale:
+            stale[0][0].zero_()
+            _PENDING_HEADS[other] = [e for e in _PENDING_HEADS[other] if e[0].data_ptr() != ptr]
+            if not _PENDING_HEADS[other]:
+                del _PENDING_HEADS[other]
+    if task not in _PENDING_HEADS:
+        while len(_PENDING_HEADS) >= _MAX_PENDING_TASKS:      # passes that died long ago and whose layers never ran again
+            for e in _PENDING_HEADS.pop(next(iter(_PENDING_HEADS))):
+                e[0].zero_()
+        _PENDING_HEADS[task] = []
+        torch.autograd.Variable._execution_engine.queue_callback(lambda: _flush_head_finishes(task))
 
 
 def _defer_head_finish(work, d_head, head, scale, n_head: int, flags: int) -> None:
-    _defer_head_begin()
-    _PENDING_HEADS.append((work, d_head, head, scale, n_head, flags))
+    _defer_head_begin(work)
+    _PENDING_HEADS[_graph_task()].append((work, d_head, head, scale, n_head, flags))
 
 
 # The weight-gradient reductions of an MLP backward (dW2|db2, dW1|db1: nothing downstream in the pass reads
 # them) are postponed and handed to the NEXT attention backward as its `rider` (pit_hip.h): pit.py:116-121
 # runs mlp -> attention, so in the backward the attention launch that consumes the MLP's d_x can carry the
 # MLP's reductions along - three small latency-bound grids in one launch.  In-place gradient mode only.
-# (Like the deferred head finishes above: one backward pass at a time per process - a job found while ANOTHER pass
-# runs is taken for the leftover of a pass that raised, and dropped.)
 MLP_PARAMS_RIDER = os.environ.get("PIT_DW_RIDER", "1") != "0"
-_PENDING_DW = {"task": None, "job": None}     # job = (MlpParamsJob, keep-alive tensors, stream it was prepared on)
+_PENDING_DW = {}          # graph-task id -> job = (MlpParamsJob, keep-alive tensors, stream it was prepared on) or None
 _DEFERRABLE = {}
 
 
@@ -212,42 +221,44 @@ def _dw_run(job) -> None:
         cur.wait_stream(stream)
 
 
-def _dw_flush() -> None:
-    """End-of-backward callback (and: a second MLP backward with no attention in between)."""
-    job, _PENDING_DW["job"] = _PENDING_DW["job"], None
+def _dw_flush(task: int) -> None:
+    """A second MLP backward of the pass with no attention in between (and the end of the pass)."""
+    job = _PENDING_DW.get(task)
     if job is not None:
+        _PENDING_DW[task] = None
         _dw_run(job)
 
 
-def _dw_end_of_pass() -> None:
-    _dw_flush()
-    _PENDING_DW["task"] = None
+def _dw_end_of_pass(task: int) -> None:
+    _dw_flush(task)
+    _PENDING_DW.pop(task, None)
 
 
 def _dw_defer(st, keep, device) -> None:
     task = _graph_task()
-    if _PENDING_DW["task"] != task:
-        # a job left by another pass: that pass raised before its end-of-pass callback - its gradients are void
-        _PENDING_DW["job"] = None
-        _PENDING_DW["task"] = task
-        torch.autograd.Variable._execution_engine.queue_callback(_dw_end_of_pass)
+    if task not in _PENDING_DW:
+        # a job another pass left for the SAME gradient slots: that pass raised before its end-of-pass callback ran -
+        # its gradients are void (and its table entry would otherwise stay forever)
+        for other in [t for t, j in _PENDING_DW.items() if j is None or j[0].d_w1 == st.d_w1]:
+            if _PENDING_DW[other] is not None or len(_PENDING_DW) >= _MAX_PENDING_TASKS:
+                del _PENDING_DW[other]
+        _PENDING_DW[task] = None
+        torch.autograd.Variable._execution_engine.queue_callback(lambda: _dw_end_of_pass(task))
     else:
-        _dw_flush()
-    _PENDING_DW["job"] = (st, keep, torch.cuda.current_stream(device))
+        _dw_flush(task)
+    _PENDING_DW[task] = (st, keep, torch.cuda.current_stream(device))
 
 
 def _dw_take(device):
     """The job the current attention backward should carry (None if there is none for this pass / stream)."""
-    job = _PENDING_DW["job"]
+    task = _graph_task()
+    job = _PENDING_DW.get(task)
     if job is None:
         return None
-    if _PENDING_DW["task"] != _graph_task():
-        _PENDING_DW["job"] = None                 # an aborted pass's leftover
-        return None
     if job[2] != torch.cuda.current_stream(device):
-        _dw_flush()                               # produced on another stream: run it there
+        _dw_flush(task)                           # produced on another stream: run it there
         return None
-    _PENDING_DW["job"] = None
+    _PENDING_DW[task] = None
     return job
 
 
@@ -475,7 +486,7 @@ class _PosAtt(torch.autograd.Function):
         work = _layer_workspace(slot, n_head) if defer else _dscale_workspace(values.device, n_head)
         if defer:
             acc_head |= 2                               # PIT_HEAD_DEFER: finished by _flush_head_finishes
-            _defer_head_begin()                         # (clears what an aborted pass left, before the kernel adds)
+            _defer_head_begin(work)                     # (clears what an aborted pass left, before the kernel adds)
 
         rider = _dw_take(values.device)                 # an MLP's postponed weight-gradient reductions
 

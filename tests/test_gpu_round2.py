@@ -733,7 +733,7 @@ def test_mlp_weight_gradients_carried_by_the_attention_backward_equal_their_own_
                 torch.cuda.synchronize()
             finally:
                 ops.MLP_PARAMS_RIDER = True
-            assert ops._PENDING_DW["job"] is None and ops._PENDING_DW["task"] is None
+            assert not ops._PENDING_DW
             got.setdefault(rider, []).append(flat.flat.clone())
     assert float(got[True][0].abs().max()) > 0
     assert gio.rel_l2(got[False][0].cpu().numpy(), got[True][0].cpu().numpy()) <= 2e-6
@@ -775,11 +775,11 @@ def test_a_postponed_weight_gradient_job_of_an_aborted_pass_is_dropped():
             loss_fn(target, model(mesh_in, func_in, mesh_out)).backward()
     finally:
         last.forward = orig
-    assert ops._PENDING_DW["job"] is not None, "the scenario did not leave a postponed job"
+    assert any(j is not None for j in ops._PENDING_DW.values()), "the scenario did not leave a postponed job"
     flat.zero_()
     loss_fn(target, model(mesh_in, func_in, mesh_out)).backward()
     torch.cuda.synchronize()
-    assert ops._PENDING_DW["job"] is None
+    assert not ops._PENDING_DW
     assert gio.rel_l2(want.cpu().numpy(), flat.flat.cpu().numpy()) <= 2e-6
 
 

@@ -86,13 +86,10 @@ def test_deferred_head_finish_survives_a_backward_pass_that_raised(monkeypatch):
     from position_induced_transformer_amd import ops
     flushed = []
 
-    def fake_flush():
-        flushed.append([p[0] for p in ops._PENDING_HEADS])
-        ops._PENDING_HEADS.clear()
-        ops._PENDING_TASK[0] = None
+    def fake_flush(task):
+        flushed.append([p[0] for p in ops._PENDING_HEADS.pop(task)])
     monkeypatch.setattr(ops, "_flush_head_finishes", fake_flush)
     ops._PENDING_HEADS.clear()
-    ops._PENDING_TASK[0] = None
 
     class Layer(torch.autograd.Function):
         @staticmethod
@@ -113,12 +110,15 @@ def test_deferred_head_finish_survives_a_backward_pass_that_raised(monkeypatch):
     with pytest.raises(RuntimeError, match="boom"):
         Layer.apply(Layer.apply(x, ws_a, False), ws_a, True).sum().backward()
     assert flushed == [] and len(ops._PENDING_HEADS) >= 1         # the callback never ran: entries are stale
-    Layer.apply(x, ws_b, False).sum().backward()                    # a healthy pass afterwards
+    Layer.apply(x, ws_b, False).sum().backward()                    # a healthy pass on OTHER accumulators (another model)
     assert len(flushed) == 1 and len(flushed[0]) == 1 and flushed[0][0] is ws_b
-    assert float(ws_a.abs().sum()) == 0.0                            # aborted pass's accumulators were cleared
-    assert ops._PENDING_HEADS == [] and ops._PENDING_TASK[0] is None
+    assert float(ws_a.abs().sum()) > 0.0 and len(ops._PENDING_HEADS) == 1   # ... does not touch the aborted pass's entries
+    Layer.apply(x, ws_a, False).sum().backward()                    # the next pass over the SAME accumulators does:
+    assert len(flushed) == 2 and len(flushed[1]) == 1 and flushed[1][0] is ws_a
+    assert float(ws_a.abs().sum()) == 0.0                            # the aborted pass's partial sums were cleared
+    assert ops._PENDING_HEADS == {}
     Layer.apply(x, ws_b, False).sum().backward()                    # and the pass after that is normal again
-    assert len(flushed) == 2
+    assert len(flushed) == 3
 
 
 # --------------------------------------------------------------------------- flat gradients vs zero_grad()
