@@ -236,12 +236,13 @@ def _dw_end_of_pass(task: int) -> None:
 
 def _dw_defer(st, keep, device) -> None:
     task = _graph_task()
+    # a job ANOTHER pass left for the same gradient slots: that pass raised before its end-of-pass callback ran - its
+    # gradients are void (two live passes accumulating into one .grad would be a race in torch itself)
+    for other in [t for t, j in _PENDING_DW.items() if t != task and j is not None and j[0].d_w1 == st.d_w1]:
+        del _PENDING_DW[other]
     if task not in _PENDING_DW:
-        # a job another pass left for the SAME gradient slots: that pass raised before its end-of-pass callback ran -
-        # its gradients are void (and its table entry would otherwise stay forever)
-        for other in [t for t, j in _PENDING_DW.items() if j is None or j[0].d_w1 == st.d_w1]:
-            if _PENDING_DW[other] is not None or len(_PENDING_DW) >= _MAX_PENDING_TASKS:
-                del _PENDING_DW[other]
+        while len(_PENDING_DW) >= _MAX_PENDING_TASKS:         # entries of passes that died long ago
+            del _PENDING_DW[next(iter(_PENDING_DW))]
         _PENDING_DW[task] = None
         torch.autograd.Variable._execution_engine.queue_callback(lambda: _dw_end_of_pass(task))
     else:

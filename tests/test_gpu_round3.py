@@ -77,6 +77,7 @@ def test_host_route_is_sync_free_while_lmda_is_frozen_and_re_evaluates_when_it_c
     with ops.head_scale_route("host"):
         e0 = ops.HOST_SCALE_EVALUATIONS[0]
         out0 = model(mesh_in, func_in, mesh_out)
+        loss_fn(target, out0).backward()                 # (the first backward checks the cached plans' lists once: a sync)
         assert ops.HOST_SCALE_EVALUATIONS[0] == e0 + n_layers
         torch.cuda.synchronize()
         torch.cuda.set_sync_debug_mode("error")          # any synchronising call raises from here on
