@@ -601,9 +601,10 @@ def host_head_scale(lmda: torch.Tensor) -> torch.Tensor:
     ent = getattr(lmda, "_pit_host_c", None)
     if ent is None or ent[0] != key:
         if _capturing():
-            raise RuntimeError("head-scale route 'host' cannot be captured into a hipGraph for an lmda whose scale "
-                               "has not been evaluated yet (that needs a device->host copy): run the step once "
-                               "eagerly with this route first, or use the 'device' route")
+            raise RuntimeError("head-scale route 'host' cannot be captured into a hipGraph for an lmda whose current "
+                               "value has no host-evaluated scale yet (that needs a device->host copy): it is exact "
+                               "for a FROZEN lmda only - run the step once eagerly with this route first; if an "
+                               "optimizer updates lmda every step, capture with the 'device' route")
         HOST_SCALE_EVALUATIONS[0] += 1
         host = lmda.detach().reshape(-1).cpu()
         c = torch.tan(0.25 * math.pi * (1 - 1e-7) * (1.0 + torch.sin(host)))
