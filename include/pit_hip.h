@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define PIT_ABI_VERSION 9
+#define PIT_ABI_VERSION 10
 #define PIT_DSCALE_SLOTS 1024 /* fp64 accumulators per head in pit_posatt_bwd's workspace */
 
 /* distance metric (dist2att variants) */
@@ -169,6 +169,54 @@ int pit_posatt_bwd(const float* mesh_out, const float* mesh_in, int mesh_batch, 
 int pit_posatt_dhead_finish(int n_layers, double* const* workspaces, float* const* d_heads,
                             const float* const* heads, const float* const* scales, const int* n_heads,
                             const int* flags, void* stream);
+
+/* ---- Fused processor blocks (batch-free meshes, small regime; csrc/pit_block.hip) ------------------------------
+ * pit.processor (pit.py:114-122) is n_blocks x [posatt.forward (self attention on the latent mesh, locality 1.0:
+ * pit.py:102) -> kaiming_mlp -> gelu].  For the batch-free operators the softmax weights of every block depend on
+ * (mesh_ltt, lmda_l) only, so ONE launch forms them for all blocks of the step and each block's forward / backward
+ * chain becomes one launch (attention as plain MFMA contractions + the MLP phases on the same 16-row slab).
+ *
+ * pit_block_supported: 1 when this shape takes the fused path (dim = hid_dim = 64, n_head in {1,2}, n_pts a multiple
+ * of 64*8/n_head, 256 <= batch*n_pts <= 8192 rows); callers fall back to pit_posatt_* + pit_mlp_* otherwise. */
+int pit_block_supported(int n_pts, int n_head, int dim, int batch);
+
+/* Weights of n_layers (<= 16) self-attention layers on one batch-free mesh (n_pts, space_dim), nothing masked:
+ *   e   (n_layers, n_head, n_pts, n_pts)  exp(-c_lh m[n,j])  - un-normalised and symmetric (S_min = 0: every row holds
+ *                                          its own point), so e serves the forward (rows) and d(values) (columns)
+ *   q   (same shape)                       e (m - mbar_n) / rowsum_n : the weights of the d(scale) contraction
+ *   inv (n_layers, n_head, n_pts)          1 / rowsum
+ *   rowstat (n_layers, n_head, n_pts, 4)   {T = +inf, S_min = 0, 1/rowsum, mbar} exactly as pit_posatt_fwd saves it, so
+ *                                          pit_posatt_bwd can serve any layer of the stack as well
+ *   scale_out (n_layers, n_head)           the c that was used
+ * heads: HOST array of n_layers device pointers (n_head floats each: lmda, or c itself with head_is_scale = 1). */
+int pit_block_weights(const float* mesh, int n_pts, int space_dim, int metric, float period, int n_layers,
+                      const float* const* heads, int head_is_scale, int n_head, float* e, float* q,
+                      float* inv, float* rowstat, float* scale_out, void* stream);
+
+/* One processor block forward: xcat (batch*n_pts, (1+n_head)*dim) holds the block's input in columns [0, dim); the
+ * attention output of head h is written to columns [(1+h)*dim, (2+h)*dim) (torch.cat((inputs, conv), -1), pit.py:44)
+ * and the block's MLP ((1+n_head)*dim -> dim -> dim, arguments as pit_mlp_fwd) runs on the slab in the same launch.
+ * e / inv: this layer's slices of pit_block_weights' outputs. */
+int pit_block_fwd(const float* e, const float* inv, int n_pts, int n_head, int dim, int batch, float* xcat,
+                  const float* w1, const float* b1, const float* w2, const float* b2, int out_gelu,
+                  float* z1, float* h, float* z2, float* y, long ldy, int math_mode, void* stream);
+
+/* One block of the backward chain.  Given d_xcat (gradient of this block's concat tensor, complete):
+ *   d(values) = d_xcat[:, 0:dim] + sum_h e_h^T (d_xcat[:, head h] / rowsum_h)   per 16-point slab, then
+ *   - with the PREVIOUS block's MLP (w1 (dim, n0_prev), w2 (dim, dim), its saved z1 / z2, out_gelu): the data path of
+ *     that MLP's backward on the slab - dZ2, dZ1 into scratch_prev (rows*(2*dim) floats, the layout of
+ *     pit_mlp_bwd_data) and dX into d_xprev (rows, n0_prev) (NULL = not needed);
+ *   - with w1 == NULL: d(values) is written to d_values (rows, dim).
+ *   dscale != NULL: this layer's d(scale) partial sums are ADDED to these accumulators (n_head*PIT_DSCALE_SLOTS
+ *     doubles, the PIT_HEAD_DEFER convention of pit_posatt_bwd: drain with pit_posatt_dhead_finish); needs qw and
+ *     xcat (the block's concat tensor, whose first dim columns are the attention's values).
+ *   rider: as in pit_posatt_bwd (the weight-gradient reductions of this block's own MLP). */
+int pit_block_bwd(const float* e, const float* inv, const float* qw, int n_pts, int n_head, int dim, int batch,
+                  const float* d_xcat, const float* xcat, double* dscale,
+                  const float* w1, const float* w2, const float* z1, const float* z2, int out_gelu, int n0_prev,
+                  float* d_xprev, long ld_dxprev, float* scratch_prev,
+                  float* d_values, long ld_dvalues,
+                  const struct pit_mlp_params_job* rider, int math_mode, void* stream);
 
 /* kaiming_mlp.forward (pit.py:21-26): y = W2 * gelu_erf(W1 x + b1) + b2, optionally
  * followed by the trailing gelu of pit.py:111,121 (out_gelu=1).

@@ -11,7 +11,7 @@ import subprocess
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libpit_hip.so")
-SOURCES = ("pit_abi.hip", "pit_select.hip", "pit_posatt.hip", "pit_mlp.hip", "pit_loss.hip", "pit_norm.hip", "pit_optim.hip")
+SOURCES = ("pit_abi.hip", "pit_select.hip", "pit_posatt.hip", "pit_block.hip", "pit_mlp.hip", "pit_loss.hip", "pit_norm.hip", "pit_optim.hip")
 HEADERS = ("pit_common.h", "pit_gemm_rd.h", os.path.join("..", "..", "include", "pit_hip.h"))
 FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17"]
 FLAGS += os.environ.get("PIT_EXTRA_FLAGS", "").split()      # diagnostic builds only (e.g. -DPIT_STAMPS, tools/stamp_tiles.py)

@@ -1,0 +1,570 @@
+// Fused processor blocks for batch-free meshes, small (latency-bound) regime.
+//
+// The processor of pit.py:114-122 is n_blocks x [ posatt.forward (self attention on the latent mesh, locality 1:
+// nothing masked, pit.py:102) -> kaiming_mlp -> gelu ].  For the batch-free operators (posatt_fixed / _periodic1d /
+// _periodic2d) the softmax weights of EVERY block depend on the latent mesh and the block's lmda only - not on the
+// activations - so they leave the dependent chain of the step:
+//
+//   block_weights_kernel  (one launch, all blocks)  E[l,h,n,j] = exp(-c_lh m[n,j])      (un-normalised, SYMMETRIC:
+//                                                    m[n,j] = m[j,n] bit for bit, and S_min = 0 on the diagonal)
+//                                                   Q[l,h,n,j] = E (m - mbar_n) / rowsum_n   (the d(scale) weights)
+//                                                   1/rowsum, and rowstat = {T, S_min, 1/rowsum, mbar} as pit_posatt_fwd saves it
+//   block_fwd_kernel      (one launch per block)    16-row slab of one sample: O_h = (E_h X) / rowsum  as plain
+//                                                   v_mfma_f32_16x16x4_f32 contractions (operands straight from memory, no
+//                                                   weight formation), the concat tile [X | O_0 | O_1] stays in LDS and feeds the
+//                                                   block's MLP (mlp_fwd16_kernel's phases) in the same launch
+//   block_bwd_kernel      (one launch per block)    16-key slab: d(values) = residual + sum_h E_h^T (dO_h / rowsum) - E is
+//                                                   symmetric, so this is the same row-major contraction - followed by the data
+//                                                   path of the PREVIOUS block's MLP backward (mlp_bwd16_kernel's phases);
+//                                                   the block's d(scale) (Q X contracted with dO, fp64 partials into the layer's
+//                                                   accumulators) and the weight-gradient reductions of the block's own MLP
+//                                                   (`rider`, gemm_rd_body) ride along as extra workgroups.
+//
+// The forward chain of a block is ONE launch instead of two (attention, MLP), the backward chain ONE instead of two
+// (MLP data path, attention pair), and the weights cost one launch per step instead of being re-formed by all 256
+// workgroups of every attention launch (31-39 VALU instructions per MFMA in posatt_rows_kernel / posatt_bwd_pair).
+// Exact fp32 products (PIT_MATH_FP32 only); per-sample meshes keep the recompute-from-coordinates kernels.
+#include "pit_common.h"
+#include "pit_gemm_rd.h"
+#include <cstdlib>
+
+namespace {
+
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4_t mfma_16x16x4(float a, float b, f32x4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+constexpr int BD = 64;                 // value width (hid_dim) of the fused path: 4 interleaved 16-column tiles per wave
+constexpr int BW = 8;                  // waves per workgroup
+constexpr int MAX_LAYERS = 16;
+
+// ---------------------------------------------------------------------------------------------- weights
+struct WeightsArgs {
+    const float* mesh; int L, sdim, periodic; float period;
+    int n_layers, n_head, head_is_scale;
+    const float* head[MAX_LAYERS];
+    float *e, *q, *inv, *rowstat, *scale_out;
+};
+
+// one wave per (layer, head, row): keys 4*lane + 256*r, 16-B stores
+__global__ __launch_bounds__(256) void block_weights_kernel(WeightsArgs a) {
+    const int lane = threadIdx.x & 63;
+    const long row_id = (long)blockIdx.x * 4 + (threadIdx.x >> 6);          // (layer, head, n)
+    const long rows_total = (long)a.n_layers * a.n_head * a.L;
+    if (row_id >= rows_total) return;
+    const int n = (int)(row_id % a.L);
+    const int lh = (int)(row_id / a.L);
+    const int l = lh / a.n_head, h = lh % a.n_head;
+    const float hv = a.head[l][h];
+    const float c = a.head_is_scale ? hv : head_scale_from_lmda(hv);
+    const float* xo = a.mesh + (long)n * a.sdim;
+    const float ox = xo[0], oy = a.sdim > 1 ? xo[1] : 0.0f, oz = a.sdim > 2 ? xo[2] : 0.0f;
+    const bool per = a.periodic != 0;
+    float rsum = 0.0f, qsum = 0.0f;
+    // (pass 1: row sums; pass 2 re-forms the weights - L is a few hundred, the exp is cheaper than parking them)
+    for (int j0 = 4 * lane; j0 < a.L; j0 += 256) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float* xi = a.mesh + (long)(j0 + u) * a.sdim;
+            const float m = sq_dist3(ox, oy, oz, xi[0], a.sdim > 1 ? xi[1] : 0.0f, a.sdim > 2 ? xi[2] : 0.0f, per, a.period);
+            const float p = __expf(-__fmul_rn(m, c));                       // S_min = 0: the row holds its own point
+            rsum += p;
+            qsum += p * m;
+        }
+    }
+    rsum = wave_sum(rsum);
+    qsum = wave_sum(qsum);
+    const float inv = rsum > 0.0f ? 1.0f / rsum : 0.0f;
+    const float mbar = qsum * inv;
+    float* erow = a.e + row_id * a.L;
+    float* qrow = a.q + row_id * a.L;
+    for (int j0 = 4 * lane; j0 < a.L; j0 += 256) {
+        float4 ev, qv;
+        float* ep = &ev.x;
+        float* qp = &qv.x;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float* xi = a.mesh + (long)(j0 + u) * a.sdim;
+            const float m = sq_dist3(ox, oy, oz, xi[0], a.sdim > 1 ? xi[1] : 0.0f, a.sdim > 2 ? xi[2] : 0.0f, per, a.period);
+            const float p = __expf(-__fmul_rn(m, c));
+            ep[u] = p;
+            qp[u] = p * (m - mbar) * inv;
+        }
+        *reinterpret_cast<float4*>(erow + j0) = ev;
+        *reinterpret_cast<float4*>(qrow + j0) = qv;
+    }
+    if (lane == 0) {
+        a.inv[row_id] = inv;
+        float4 st; st.x = __builtin_inff(); st.y = 0.0f; st.z = inv; st.w = mbar;
+        *reinterpret_cast<float4*>(a.rowstat + row_id * 4) = st;
+        if (n == 0) a.scale_out[lh] = c;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- shared pieces
+// acc[t] (16 rows x 16 columns {4c + t}) += sum over keys [jb, je) of  W[row0 + i][key] * (sc[key]) * V[key][4c + t]
+// W row-major with pitch L (A operand: lane (i = l&15, kq = l>>4) takes 4 consecutive keys with one 16-B load - the key
+// order inside a group of 16 is permuted identically for both operands), V rows ldv floats apart (B operand: one 16-B
+// load = this lane's column of all four tiles).  64 keys per trip: 20 loads in flight, then 64 MFMAs.
+template <bool SCALED>
+__device__ __forceinline__ void slab_contract(const float* __restrict__ wrow, int L, const float* __restrict__ v, long ldv,
+                                              const float* __restrict__ sc, int jb, int je, int l15, int kq,
+                                              f32x4_t (&acc)[4]) {
+    const float* wp = wrow + (long)l15 * L + 4 * kq;
+    const float* vp = v + 4 * l15;
+    for (int j0 = jb; j0 < je; j0 += 64) {
+        float4 av[4], bv[4][4], sv[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            av[s] = *reinterpret_cast<const float4*>(wp + j0 + 16 * s);
+            if (SCALED) sv[s] = *reinterpret_cast<const float4*>(sc + j0 + 16 * s + 4 * kq);
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+                bv[s][m] = *reinterpret_cast<const float4*>(vp + (long)(j0 + 16 * s + 4 * kq + m) * ldv);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const float* ap = &av[s].x;
+            const float* sp = &sv[s].x;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const float aw = SCALED ? ap[m] * sp[m] : ap[m];            // (row scale folded into the A operand)
+                acc[0] = mfma_16x16x4(aw, bv[s][m].x, acc[0]);
+                acc[1] = mfma_16x16x4(aw, bv[s][m].y, acc[1]);
+                acc[2] = mfma_16x16x4(aw, bv[s][m].z, acc[2]);
+                acc[3] = mfma_16x16x4(aw, bv[s][m].w, acc[3]);
+            }
+        }
+    }
+}
+
+// park this wave's 16 x 64 partial tile: slot [(wave*4 + t)*4 + i][lane]
+__device__ __forceinline__ void park(float* pk, int wave, int lane, const f32x4_t (&acc)[4]) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pk[((wave * 4 + t) * 4 + i) * 64 + lane] = acc[t][i];
+}
+// element (row 4*(lane>>4) + i, columns 4*(lane&15) .. +3) summed over waves [w0, w0 + nw)
+__device__ __forceinline__ float4 parked_sum(const float* pk, int w0, int nw, int i, int lane) {
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int w = w0; w < w0 + nw; ++w) {
+        s.x += pk[((w * 4 + 0) * 4 + i) * 64 + lane];
+        s.y += pk[((w * 4 + 1) * 4 + i) * 64 + lane];
+        s.z += pk[((w * 4 + 2) * 4 + i) * 64 + lane];
+        s.w += pk[((w * 4 + 3) * 4 + i) * 64 + lane];
+    }
+    return s;
+}
+
+constexpr int PARK_FLOATS = BW * 16 * 64;              // 32 KiB
+
+// ---------------------------------------------------------------------------------------------- forward
+struct BlockFwdArgs {
+    const float *e, *inv;               // this layer: (H, L, L), (H, L)
+    int L, batch;
+    float* xcat;                        // (batch*L, (1+H)*64): columns [0,64) given, head columns written here
+    const float *w1, *b1, *w2, *b2;     // the block's MLP ((1+H)*64 -> 64 -> 64)
+    int out_gelu;
+    float *z1, *h, *z2, *y; long ldy;
+};
+
+template <int H>
+__global__ __launch_bounds__(512) void block_fwd_kernel(BlockFwdArgs g) {
+    constexpr int NQ = BW / H;                          // key splits per head
+    constexpr int W = (1 + H) * BD;                     // concat width = K of the first contraction
+    constexpr int XP = W + 4, HP = BD + 4;              // LDS pitches
+    constexpr int KS = W / 16;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* pk = smem;                                   // [PARK_FLOATS]
+    float* xs = smem + PARK_FLOATS;                     // [16][XP] concat tile
+    float* hs = xs + 16 * XP;                           // [16][HP] hidden tile
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, kq = lane >> 4;
+    const int slabs = g.L / 16;
+    const int b = blockIdx.x / slabs, n0 = (blockIdx.x % slabs) * 16;
+    const long m0 = (long)blockIdx.x * 16;              // first row of the slab in the (batch*L) row space
+    const int hd = wave / NQ, qt = wave % NQ;
+    const int klen = g.L / NQ;
+
+    // the slab's own X rows (first 64 columns of the concat tile): requested first, parked after the attention loads
+    float4 xown = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (tid < 256) xown = *reinterpret_cast<const float4*>(g.xcat + (m0 + (tid >> 4)) * W + 4 * (tid & 15));
+
+    f32x4_t acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    slab_contract<false>(g.e + ((long)hd * g.L + n0) * g.L, g.L, g.xcat + (long)b * g.L * W, W, nullptr,
+                         qt * klen, (qt + 1) * klen, l15, kq, acc);
+    // MLP operands: requested now, consumed after the reduction (waves 0..3 own the four hidden / output tiles)
+    const bool mlp_wave = wave < 4;
+    const int c1 = (wave & 3) * 16 + l15;
+    float4 bv[KS], w2v[4];
+    if (mlp_wave) {
+#pragma unroll
+        for (int s = 0; s < KS; ++s) bv[s] = *reinterpret_cast<const float4*>(g.w1 + (long)c1 * W + 16 * s + 4 * kq);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) w2v[s] = *reinterpret_cast<const float4*>(g.w2 + (long)c1 * BD + 16 * s + 4 * kq);
+    }
+    park(pk, wave, lane, acc);
+    if (tid < 256) *reinterpret_cast<float4*>(xs + (tid >> 4) * XP + 4 * (tid & 15)) = xown;
+    __syncthreads();
+    // reduce over the key splits, normalise, -> concat tile (LDS) and concat buffer (memory: the backward needs it)
+    for (int item = tid; item < H * 256; item += 512) {
+        const int hh = item >> 8, i = (item >> 6) & 3, ln = item & 63;
+        const int r = 4 * (ln >> 4) + i, col = 4 * (ln & 15);
+        float4 s = parked_sum(pk, hh * NQ, NQ, i, ln);
+        const float rinv = g.inv[(long)hh * g.L + n0 + r];
+        s.x *= rinv; s.y *= rinv; s.z *= rinv; s.w *= rinv;
+        *reinterpret_cast<float4*>(xs + r * XP + BD + hh * BD + col) = s;
+        *reinterpret_cast<float4*>(g.xcat + (m0 + r) * W + BD + hh * BD + col) = s;
+    }
+    __syncthreads();
+    // ---- the block's MLP on the 16 x W tile (the phases of mlp_fwd16_kernel, A operand from LDS)
+    if (mlp_wave) {
+        f32x4_t a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const float4 a = *reinterpret_cast<const float4*>(xs + l15 * XP + 16 * s + 4 * kq);
+            a0 = mfma_16x16x4(a.x, bv[s].x, a0);
+            a1 = mfma_16x16x4(a.y, bv[s].y, a1);
+            a0 = mfma_16x16x4(a.z, bv[s].z, a0);
+            a1 = mfma_16x16x4(a.w, bv[s].w, a1);
+        }
+        const float bias = g.b1[c1];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = 4 * kq + i;
+            const float z = a0[i] + a1[i] + bias;
+            const float hv = gelu_erf(z);
+            hs[r * HP + c1] = hv;
+            g.z1[(m0 + r) * BD + c1] = z;
+            g.h[(m0 + r) * BD + c1] = hv;
+        }
+    }
+    __syncthreads();
+    if (!mlp_wave) return;
+    f32x4_t o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const float4 a = *reinterpret_cast<const float4*>(hs + l15 * HP + 16 * s + 4 * kq);
+        o0 = mfma_16x16x4(a.x, w2v[s].x, o0);
+        o1 = mfma_16x16x4(a.y, w2v[s].y, o1);
+        o0 = mfma_16x16x4(a.z, w2v[s].z, o0);
+        o1 = mfma_16x16x4(a.w, w2v[s].w, o1);
+    }
+    const float bias2 = g.b2[c1];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const long r = m0 + 4 * kq + i;
+        float v = o0[i] + o1[i] + bias2;
+        if (g.out_gelu) { g.z2[r * BD + c1] = v; v = gelu_erf(v); }
+        g.y[r * g.ldy + c1] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- backward
+struct BlockBwdArgs {
+    const float *e, *inv, *qw;          // this layer: (H,L,L), (H,L), (H,L,L)
+    int L, batch;
+    const float* d_xcat;                // (batch*L, (1+H)*64): gradient of this block's concat tensor (complete)
+    const float* xcat;                  // this block's concat tensor (columns [0,64) = the attention's values)
+    double* dscale;                     // this layer's accumulators (n_head * PIT_DSCALE_SLOTS), or null: no d(scale) part
+    // previous block's MLP (null w1 = none: the slab's d(values) is written to d_values)
+    const float *w1, *w2, *z1, *z2; int out_gelu, n0p;      // n0p = input width of that MLP
+    float *d_xprev; long ld_dxprev;     // (rows, n0p)
+    float *dz1, *dz2;                   // scratch of that MLP's backward: (rows, 64) each
+    float* d_values; long ld_dvalues;   // (rows, 64) when there is no previous MLP
+    int n_chain, n_ds;                  // workgroup ranges: [0, n_chain) chain slabs, then n_ds d(scale) slabs, then the rider
+};
+
+template <int H>
+__device__ __forceinline__ void block_bwd_chain(const BlockBwdArgs& g, float* smem, int slab) {
+    constexpr int NQ = BW / H;
+    constexpr int W = (1 + H) * BD;
+    constexpr int P1 = BD + 4;
+    float* pk = smem;
+    float* ds2 = smem + PARK_FLOATS;                    // [16][P1] dZ2 tile (= dY of the previous MLP after its gelu')
+    float* ds1 = ds2 + 16 * P1;                         // [16][P1] dZ1 tile
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, kq = lane >> 4;
+    const int slabs = g.L / 16;
+    const int b = slab / slabs, j0 = (slab % slabs) * 16;
+    const long m0 = (long)slab * 16;
+    const int hd = wave / NQ, qt = wave % NQ;
+    const int klen = g.L / NQ;
+
+    // residual d_out[b, j, 0:64] of torch.cat((inputs, conv), -1) (pit.py:44) and the gelu' argument: requested first
+    const bool own = tid < 256;
+    const int orow = 4 * ((tid & 63) >> 4) + ((tid >> 6) & 3), ocol = 4 * (tid & 15);
+    float4 res = make_float4(0.f, 0.f, 0.f, 0.f), z2v = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool has_mlp = g.w1 != nullptr;
+    if (own) {
+        res = *reinterpret_cast<const float4*>(g.d_xcat + (m0 + orow) * W + ocol);
+        if (has_mlp && g.out_gelu) z2v = *reinterpret_cast<const float4*>(g.z2 + (m0 + orow) * BD + ocol);
+    }
+    // d(values)[j] = sum_h sum_n E_h[j][n] * (inv_h[n] * dO_h[n]):  E is symmetric, row j of E is column j
+    f32x4_t acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    slab_contract<true>(g.e + ((long)hd * g.L + j0) * g.L, g.L, g.d_xcat + (long)b * g.L * W + BD + hd * BD, W,
+                        g.inv + (long)hd * g.L, qt * klen, (qt + 1) * klen, l15, kq, acc);
+    // operands of the MLP phases: requested now (phase B: waves 0..3 own the four dZ1 tiles)
+    const int c1 = (wave & 3) * 16 + l15;
+    float w2v[4][4], z1v[4];
+    if (has_mlp && wave < 4) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int ee = 0; ee < 4; ++ee) w2v[s][ee] = g.w2[(long)(16 * s + 4 * kq + ee) * BD + c1];   // B(k,n) = w2[k][n]
+#pragma unroll
+        for (int i = 0; i < 4; ++i) z1v[i] = g.z1[(m0 + 4 * kq + i) * BD + c1];
+    }
+    park(pk, wave, lane, acc);
+    __syncthreads();
+    if (own) {
+        const int i = (tid >> 6) & 3, ln = tid & 63;
+        float4 s = parked_sum(pk, 0, BW, i, ln);
+        s.x += res.x; s.y += res.y; s.z += res.z; s.w += res.w;
+        if (!has_mlp) {
+            *reinterpret_cast<float4*>(g.d_values + (m0 + orow) * g.ld_dvalues + ocol) = s;
+        } else {
+            if (g.out_gelu) {
+                s.x *= gelu_erf_grad(z2v.x); s.y *= gelu_erf_grad(z2v.y); s.z *= gelu_erf_grad(z2v.z); s.w *= gelu_erf_grad(z2v.w);
+            }
+            *reinterpret_cast<float4*>(g.dz2 + (m0 + orow) * BD + ocol) = s;
+            *reinterpret_cast<float4*>(ds2 + orow * P1 + ocol) = s;
+        }
+    }
+    if (!has_mlp) return;
+    // phase C operands (dX tiles wave, wave + 8: n0p / 16 tiles over 8 waves)
+    float w1v[2][4][4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int col = (wave + t * BW) * 16 + l15;
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int ee = 0; ee < 4; ++ee)
+                w1v[t][s][ee] = (col < g.n0p) ? g.w1[(long)(16 * s + 4 * kq + ee) * g.n0p + col] : 0.0f;
+    }
+    __syncthreads();
+    // ---- phase B: dZ1 = (dZ2 W2) * gelu'(Z1)
+    if (wave < 4) {
+        f32x4_t a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const float4 a = *reinterpret_cast<const float4*>(ds2 + l15 * P1 + 16 * s + 4 * kq);
+            a0 = mfma_16x16x4(a.x, w2v[s][0], a0);
+            a1 = mfma_16x16x4(a.y, w2v[s][1], a1);
+            a0 = mfma_16x16x4(a.z, w2v[s][2], a0);
+            a1 = mfma_16x16x4(a.w, w2v[s][3], a1);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = 4 * kq + i;
+            const float v = (a0[i] + a1[i]) * gelu_erf_grad(z1v[i]);
+            ds1[r * P1 + c1] = v;
+            g.dz1[(m0 + r) * BD + c1] = v;
+        }
+    }
+    __syncthreads();
+    if (!g.d_xprev) return;
+    // ---- phase C: dX tiles = dZ1 W1
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int tile = wave + t * BW;
+        if (tile * 16 >= g.n0p) break;
+        f32x4_t o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const float4 a = *reinterpret_cast<const float4*>(ds1 + l15 * P1 + 16 * s + 4 * kq);
+            o0 = mfma_16x16x4(a.x, w1v[t][s][0], o0);
+            o1 = mfma_16x16x4(a.y, w1v[t][s][1], o1);
+            o0 = mfma_16x16x4(a.z, w1v[t][s][2], o0);
+            o1 = mfma_16x16x4(a.w, w1v[t][s][3], o1);
+        }
+        const int col = tile * 16 + l15;
+        if (col < g.n0p) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) g.d_xprev[(m0 + 4 * kq + i) * g.ld_dxprev + col] = o0[i] + o1[i];
+        }
+    }
+}
+
+// d c_h -= sum_{n, d} dO_h[n, d] * sum_j Q_h[n, j] U[j, d]   (SURVEY appendix B rearranged; Q carries the centring and 1/rowsum)
+template <int H>
+__device__ __forceinline__ void block_bwd_dscale(const BlockBwdArgs& g, float* smem, int slab) {
+    constexpr int NQ = BW / H;
+    constexpr int W = (1 + H) * BD;
+    float* pk = smem;
+    double* wred = reinterpret_cast<double*>(smem + PARK_FLOATS);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, kq = lane >> 4;
+    const int slabs = g.L / 16;
+    const int b = slab / slabs, n0 = (slab % slabs) * 16;
+    const long m0 = (long)slab * 16;
+    const int hd = wave / NQ, qt = wave % NQ;
+    const int klen = g.L / NQ;
+    // this thread's d_out element group (head hh, row, 4 columns): requested before the contraction
+    const bool own = tid < H * 256;
+    const int hh = tid >> 8, i = (tid >> 6) & 3, ln = tid & 63;
+    const int r = 4 * (ln >> 4) + i, col = 4 * (ln & 15);
+    float4 dov = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (own) dov = *reinterpret_cast<const float4*>(g.d_xcat + (m0 + r) * W + BD + hh * BD + col);
+    f32x4_t acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    slab_contract<false>(g.qw + ((long)hd * g.L + n0) * g.L, g.L, g.xcat + (long)b * g.L * W, W, nullptr,
+                         qt * klen, (qt + 1) * klen, l15, kq, acc);
+    park(pk, wave, lane, acc);
+    __syncthreads();
+    double part = 0.0;
+    if (own) {
+        const float4 s = parked_sum(pk, hh * NQ, NQ, i, ln);
+        part = (double)s.x * (double)dov.x + (double)s.y * (double)dov.y + (double)s.z * (double)dov.z + (double)s.w * (double)dov.w;
+    }
+    part = wave_sum_d(part);
+    if (lane == 0) wred[wave] = part;
+    __syncthreads();
+    if (tid < H) {                                      // waves [4h, 4h + 4) hold head h
+        double tot = 0.0;
+        for (int w = 4 * tid; w < 4 * tid + 4; ++w) tot += wred[w];
+        atomicAdd(g.dscale + (long)tid * PIT_DSCALE_SLOTS + (slab & (PIT_DSCALE_SLOTS - 1)), -tot);
+    }
+}
+
+__device__ __forceinline__ void dw_pair_body(const pit_detail::DwPair& w, int id) {
+    if (id < w.n1) {
+        gemm_rd_body<1, EPI_ATOMIC>(w.g1, id % w.gx1, (id / w.gx1) % w.gy1, id / (w.gx1 * w.gy1));
+    } else {
+        id -= w.n1;
+        gemm_rd_body<1, EPI_ATOMIC>(w.g2, id % w.gx2, (id / w.gx2) % w.gy2, id / (w.gx2 * w.gy2));
+    }
+}
+
+template <int H, bool DW>
+__global__ __launch_bounds__(512) void block_bwd_kernel(BlockBwdArgs g, pit_detail::DwPair w) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    int id = blockIdx.x;
+    if (id < g.n_chain) { block_bwd_chain<H>(g, smem, id); return; }
+    id -= g.n_chain;
+    if (id < g.n_ds) { block_bwd_dscale<H>(g, smem, id); return; }
+    if (DW) dw_pair_body(w, id - g.n_ds);
+}
+
+constexpr size_t FWD_SMEM = (PARK_FLOATS + 16 * (3 * BD + 4) + 16 * (BD + 4)) * sizeof(float);
+constexpr size_t BWD_SMEM = (PARK_FLOATS + 2 * 16 * (BD + 4)) * sizeof(float);
+
+bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+// 1 when the fused processor-block path covers this shape (include/pit_hip.h)
+extern "C" int pit_block_supported(int n_pts, int n_head, int dim, int batch) {
+    static const bool off = getenv("PIT_NO_BLOCK_FUSION") != nullptr;
+    if (off) return 0;
+    if (dim != BD || (n_head != 1 && n_head != 2)) return 0;
+    if (n_pts <= 0 || batch <= 0 || n_pts % (64 * (BW / n_head)) != 0) return 0;       // 64-key trips per key split
+    static const long max_rows = getenv("PIT_BLOCK_MAX_ROWS") ? atol(getenv("PIT_BLOCK_MAX_ROWS")) : 8192;
+    const long rows = (long)batch * n_pts;
+    return rows >= 256 && rows <= max_rows;             // the latency regime; above, the tiled kernels of pit_posatt.hip
+}
+
+extern "C" int pit_block_weights(const float* mesh, int n_pts, int space_dim, int metric, float period, int n_layers,
+                                 const float* const* heads, int head_is_scale, int n_head, float* e, float* q,
+                                 float* inv, float* rowstat, float* scale_out, void* stream) {
+    if (!mesh || !heads || !e || !q || !inv || !rowstat || !scale_out) return PIT_ERR_NULL;
+    if (n_pts <= 0 || n_pts % 4 != 0 || space_dim < 1 || space_dim > 3 || n_layers < 1 || n_layers > MAX_LAYERS ||
+        n_head < 1) return PIT_ERR_SIZE;
+    if (metric < PIT_METRIC_EUCLID || metric > PIT_METRIC_PERIODIC2D) return PIT_ERR_METRIC;
+    if (!aligned16(e) || !aligned16(q) || !aligned16(rowstat)) return PIT_ERR_SIZE;
+    WeightsArgs a;
+    a.mesh = mesh; a.L = n_pts; a.sdim = space_dim; a.periodic = metric != PIT_METRIC_EUCLID; a.period = period;
+    a.n_layers = n_layers; a.n_head = n_head; a.head_is_scale = head_is_scale;
+    for (int l = 0; l < n_layers; ++l) {
+        if (!heads[l]) return PIT_ERR_NULL;
+        a.head[l] = heads[l];
+    }
+    a.e = e; a.q = q; a.inv = inv; a.rowstat = rowstat; a.scale_out = scale_out;
+    const long rows = (long)n_layers * n_head * n_pts;
+    hipLaunchKernelGGL(block_weights_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
+    PIT_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pit_block_fwd(const float* e, const float* inv, int n_pts, int n_head, int dim, int batch, float* xcat,
+                             const float* w1, const float* b1, const float* w2, const float* b2, int out_gelu,
+                             float* z1, float* h, float* z2, float* y, long ldy, int math_mode, void* stream) {
+    if (!e || !inv || !xcat || !w1 || !b1 || !w2 || !b2 || !z1 || !h || !y || (out_gelu && !z2)) return PIT_ERR_NULL;
+    if (math_mode != PIT_MATH_FP32 || !pit_block_supported(n_pts, n_head, dim, batch)) return PIT_ERR_UNSUPPORTED;
+    if (ldy < dim || !aligned16(e) || !aligned16(xcat) || !aligned16(w1) || !aligned16(w2)) return PIT_ERR_SIZE;
+    BlockFwdArgs g;
+    g.e = e; g.inv = inv; g.L = n_pts; g.batch = batch; g.xcat = xcat;
+    g.w1 = w1; g.b1 = b1; g.w2 = w2; g.b2 = b2; g.out_gelu = out_gelu;
+    g.z1 = z1; g.h = h; g.z2 = z2; g.y = y; g.ldy = ldy;
+    const dim3 grid((unsigned)((long)batch * n_pts / 16)), block(64 * BW);
+    static bool once = ((void)hipFuncSetAttribute((const void*)block_fwd_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 98304),
+                        (void)hipFuncSetAttribute((const void*)block_fwd_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 98304), true);
+    (void)once;
+    if (n_head == 1) hipLaunchKernelGGL(block_fwd_kernel<1>, grid, block, FWD_SMEM, (hipStream_t)stream, g);
+    else hipLaunchKernelGGL(block_fwd_kernel<2>, grid, block, FWD_SMEM, (hipStream_t)stream, g);
+    PIT_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pit_block_bwd(const float* e, const float* inv, const float* qw, int n_pts, int n_head, int dim, int batch,
+                             const float* d_xcat, const float* xcat, double* dscale,
+                             const float* w1, const float* w2, const float* z1, const float* z2, int out_gelu, int n0_prev,
+                             float* d_xprev, long ld_dxprev, float* scratch_prev,
+                             float* d_values, long ld_dvalues,
+                             const pit_mlp_params_job* rider, int math_mode, void* stream) {
+    if (!e || !inv || !d_xcat) return PIT_ERR_NULL;
+    if (dscale && (!qw || !xcat)) return PIT_ERR_NULL;
+    if (math_mode != PIT_MATH_FP32 || !pit_block_supported(n_pts, n_head, dim, batch)) return PIT_ERR_UNSUPPORTED;
+    const bool has_mlp = w1 != nullptr;
+    if (has_mlp) {
+        if (!w2 || !z1 || !scratch_prev || (out_gelu && !z2)) return PIT_ERR_NULL;
+        if (n0_prev <= 0 || n0_prev > 16 * 16 || (d_xprev && ld_dxprev < n0_prev)) return PIT_ERR_SIZE;   // <= 2 dX tiles per wave
+    } else if (!d_values || ld_dvalues < dim || ld_dvalues % 4 != 0 || !aligned16(d_values)) {
+        return d_values ? PIT_ERR_SIZE : PIT_ERR_NULL;
+    }
+    if (!aligned16(e) || !aligned16(d_xcat) || (qw && !aligned16(qw)) || (xcat && !aligned16(xcat)) ||
+        (has_mlp && (!aligned16(scratch_prev) || (z2 && !aligned16(z2))))) return PIT_ERR_SIZE;
+    hipStream_t s = (hipStream_t)stream;
+    const long rows = (long)batch * n_pts;
+    BlockBwdArgs g;
+    g.e = e; g.inv = inv; g.qw = qw; g.L = n_pts; g.batch = batch; g.d_xcat = d_xcat; g.xcat = xcat; g.dscale = dscale;
+    g.w1 = w1; g.w2 = w2; g.z1 = z1; g.z2 = z2; g.out_gelu = out_gelu; g.n0p = n0_prev;
+    g.d_xprev = d_xprev; g.ld_dxprev = ld_dxprev;
+    g.dz1 = scratch_prev; g.dz2 = has_mlp ? scratch_prev + rows * dim : nullptr;      // the layout pit_mlp_bwd_data uses
+    g.d_values = d_values; g.ld_dvalues = ld_dvalues;
+    g.n_chain = (int)(rows / 16);
+    g.n_ds = dscale ? (int)(rows / 16) : 0;
+    pit_detail::DwPair dw = pit_detail::DwPair();
+    bool carried = false;
+    if (rider) carried = pit_detail::plan_dw_pair(*rider, BW, &dw);
+    const size_t sm = std::max(BWD_SMEM, carried ? (size_t)BW * 16 * 64 * sizeof(float) : (size_t)0);
+    const dim3 grid((unsigned)(g.n_chain + g.n_ds + (carried ? dw.n1 + dw.n2 : 0))), block(64 * BW);
+#define PIT_BLOCK_BWD(H_, DW_)                                                                                             \
+    do {                                                                                                                   \
+        static bool once = ((void)hipFuncSetAttribute((const void*)block_bwd_kernel<H_, DW_>,                             \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, 98304), true);                 \
+        (void)once;                                                                                                        \
+        hipLaunchKernelGGL((block_bwd_kernel<H_, DW_>), grid, block, sm, s, g, dw);                                        \
+    } while (0)
+    if (n_head == 1) { if (carried) PIT_BLOCK_BWD(1, true); else PIT_BLOCK_BWD(1, false); }
+    else { if (carried) PIT_BLOCK_BWD(2, true); else PIT_BLOCK_BWD(2, false); }
+#undef PIT_BLOCK_BWD
+    PIT_CHECK_LAUNCH();
+    if (rider && !carried) {                            // too large to ride: the launches pit_mlp_bwd_params would have made
+        const int rc = pit_mlp_bwd_params(rider->x, rider->ldx, rider->rows, rider->n0, rider->n1, rider->n2, rider->h,
+                                          rider->out_gelu, rider->d_y, rider->ld_dy, rider->d_w1, rider->d_b1, rider->d_w2,
+                                          rider->d_b2, rider->accumulate, rider->scratch, rider->math_mode, stream);
+        if (rc) return rc;
+    }
+    return 0;
+}

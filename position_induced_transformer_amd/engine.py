@@ -55,8 +55,13 @@ class TrainStep:
                 if flat.tail_start < flat.flat.numel() and \
                         {id(q) for q in flat.params[len(flat.params) - len(tail):]} == {id(q) for q in tail}:
                     self.buckets = 2
+                    self._early_block = len(model.mlp) // 2      # after this block's backward its bucket is complete
                     self._side = torch.cuda.Stream(device=self.func_in.device)
-                    self._early_hook = marker.register_forward_hook(self._mark_early_point)
+
+                    def mark(module, inputs, output):      # (a plain function: it carries the marker attribute)
+                        return self._mark_early_point(module, inputs, output)
+                    mark._pit_internal = True              # pit._fused_processor: not a user hook, fusing stays allowed
+                    self._early_hook = marker.register_forward_hook(mark)
         elif all_reduce_buckets not in (1, 2):
             raise ValueError("all_reduce_buckets must be 1 or 2")
         self.flat = flat if flat is not None else FlatGradients(model.parameters())
@@ -89,8 +94,20 @@ class TrainStep:
         else:
             self.flat.all_reduce()
 
+    def _on_processor_block(self, i: int) -> None:
+        # the fused processor (ops._Processor) is one autograd node: it reports each block's backward launch instead
+        if i == self._early_block:
+            self._reduce_early_bucket(None)
+
     def _step(self) -> None:
         self._early_pending = False
+        ops._PROCESSOR_HOOK[0] = self._on_processor_block if (self.buckets == 2 and self.all_reduce) else None
+        try:
+            self._step_body()
+        finally:
+            ops._PROCESSOR_HOOK[0] = None
+
+    def _step_body(self) -> None:
         out = self.model(self.mesh_in, self.func_in, self.mesh_out)
         sc, sh = self.affine if self.affine is not None else (None, None)
         # the loss launch also writes its own gradient for the seed of ones below and clears the flat

@@ -793,6 +793,168 @@ def mlp_apply(x, w1, b1, w2, b2, out_gelu: bool = False, concat_heads: int = 0) 
     return y
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# Fused processor (pit.py:114-122 on batch-free meshes, small regime): csrc/pit_block.hip
+BLOCK_FUSION = os.environ.get("PIT_BLOCK_FUSION", "1") != "0"
+
+
+def block_fusion_supported(n_pts: int, n_head: int, dim: int, batch: int) -> bool:
+    return BLOCK_FUSION and bool(_lib.lib().pit_block_supported(int(n_pts), int(n_head), int(dim), int(batch)))
+
+
+class _Processor(torch.autograd.Function):
+    """n_blocks x [posatt.forward -> kaiming_mlp -> gelu] (pit.py:114-122) on one batch-free latent mesh as ONE
+    autograd node: the softmax weights of all blocks come from one launch (pit_block_weights: they depend on the mesh
+    and the lmda's only), every block's forward is one launch (pit_block_fwd) and its backward chain one launch
+    (pit_block_bwd: d(values) of block i + the data path of block i-1's MLP backward, with block i's d(scale) and its
+    MLP's weight-gradient reductions riding along).  Tensor inputs: x, lmda_0..n-1, then (w1, b1, w2, b2) per block."""
+
+    @staticmethod
+    def forward(ctx, x, plan: MeshPlan, n_head: int, scales, params, *tensors):
+        n = len(tensors) // 5
+        lmdas, mlps = tensors[:n], [tensors[n + 4 * i:n + 4 * i + 4] for i in range(n)]
+        _need_gpu(x, *tensors)
+        b, L, D = x.shape
+        H, W, rows = n_head, (1 + n_head) * D, b * L
+        dev = x.device
+        L_ = _lib.lib()
+        ctx.math = _math_code()
+        heads = [t.detach().reshape(-1).contiguous() for t in lmdas]
+        kheads = list(scales) if scales is not None else heads         # route 'host': the host-evaluated c is what the kernels get
+        E = torch.empty((n, H, L, L), device=dev, dtype=torch.float32)
+        Q = torch.empty((n, H, L, L), device=dev, dtype=torch.float32)
+        inv = torch.empty((n, H, L), device=dev, dtype=torch.float32)
+        rowstat = torch.empty((n, H, L, 4), device=dev, dtype=torch.float32)
+        scale = torch.empty((n, H), device=dev, dtype=torch.float32)
+        hp = (ctypes.c_void_p * n)(*[t.data_ptr() for t in kheads])
+        rc = L_.pit_block_weights(plan.mesh_in.data_ptr(), L, plan.sdim, plan.metric_id, plan.period, n, hp,
+                                  1 if scales is not None else 0, H, E.data_ptr(), Q.data_ptr(), inv.data_ptr(),
+                                  rowstat.data_ptr(), scale.data_ptr(), _lib.stream_ptr())
+        _lib.check(rc, "pit_block_weights")
+        buf0 = _concat_buffer_of(x, L, H)
+        if buf0 is None:                       # the producer did not write into a concat buffer: one copy
+            buf0 = torch.empty((b, L, W), device=dev, dtype=torch.float32)
+            buf0[:, :, :D].copy_(x.detach())
+        else:
+            buf0 = buf0.detach()
+        bufs = [buf0] + [torch.empty((b, L, W), device=dev, dtype=torch.float32) for _ in range(n - 1)]
+        out = torch.empty((b, L, D), device=dev, dtype=torch.float32)
+        z1 = torch.empty((n, rows, D), device=dev, dtype=torch.float32)
+        hh = torch.empty((n, rows, D), device=dev, dtype=torch.float32)
+        z2 = torch.empty((n, rows, D), device=dev, dtype=torch.float32)
+        wts = [tuple(t.detach().contiguous() for t in m) for m in mlps]
+        for i in range(n):
+            y, ldy = (bufs[i + 1], W) if i + 1 < n else (out, D)
+            w1, b1, w2, b2 = wts[i]
+            if tuple(w1.shape) != (D, W) or tuple(w2.shape) != (D, D):
+                raise RuntimeError(f"fused processor: block {i} MLP is {tuple(w1.shape)} / {tuple(w2.shape)}, expected "
+                                   f"({D}, {W}) / ({D}, {D})")
+            rc = L_.pit_block_fwd(E[i].data_ptr(), inv[i].data_ptr(), L, H, D, b, bufs[i].data_ptr(), w1.data_ptr(),
+                                  b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), 1, z1[i].data_ptr(), hh[i].data_ptr(),
+                                  z2[i].data_ptr(), y.data_ptr(), ldy, ctx.math, _lib.stream_ptr())
+            _lib.check(rc, "pit_block_fwd")
+        ctx.n, ctx.H, ctx.dims, ctx.plan = n, H, (b, L, D), plan
+        ctx.params = params                    # (lmda parameters, (w1, b1, w2, b2) parameters) for the in-place gradient slots
+        ctx.keep = (bufs, wts, heads, E, Q, inv, scale, z1, hh, z2)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        n, H = ctx.n, ctx.H
+        b, L, D = ctx.dims
+        W, rows = (1 + H) * D, b * L
+        bufs, wts, heads, E, Q, inv, scale, z1, hh, z2 = ctx.keep
+        lm_params, mlp_params = ctx.params
+        dev = d_out.device
+        L_ = _lib.lib()
+        d_out = d_out.contiguous()
+        dxc = [torch.empty((b, L, W), device=dev, dtype=torch.float32) for _ in range(n)]
+        scratch = [torch.empty((rows * 2 * D,), device=dev, dtype=torch.float32) for _ in range(n)]
+        dx = torch.empty((b, L, D), device=dev, dtype=torch.float32)
+        # gradient destinations: the parameters' own .grad slots (in place, nothing returned) or fresh tensors
+        lm_slots = [_grad_slot(p) if isinstance(p, torch.nn.Parameter) else None for p in lm_params]
+        w_slots, w_grads = [], []
+        for i in range(n):
+            sl = [_grad_slot(p) if isinstance(p, torch.nn.Parameter) else None for p in mlp_params[i]]
+            if all(s is not None for s in sl):
+                w_slots.append(sl)
+                w_grads.append(None)
+            else:
+                g = [torch.zeros_like(t) for t in wts[i]]
+                w_slots.append(g)
+                w_grads.append(g)
+        defer = [DEFER_HEAD_FINISH and s is not None for s in lm_slots]
+        work = []
+        for i in range(n):
+            if defer[i]:
+                ws = _layer_workspace(lm_slots[i], H)
+                _defer_head_begin(ws)
+            else:
+                ws = torch.zeros(H * 1024, device=dev, dtype=torch.float64)
+            work.append(ws)
+        # top of the chain: the last block's MLP backward (data path) from d_out
+        w1, _, w2, _ = wts[n - 1]
+        rc = L_.pit_mlp_bwd_data(rows, W, D, D, w1.data_ptr(), w2.data_ptr(), z1[n - 1].data_ptr(), z2[n - 1].data_ptr(), 1,
+                                 d_out.data_ptr(), D, dxc[n - 1].data_ptr(), W, scratch[n - 1].data_ptr(), ctx.math,
+                                 _lib.stream_ptr())
+        _lib.check(rc, "pit_mlp_bwd_data")
+        for i in range(n - 1, -1, -1):
+            dw1, db1, dw2, db2 = w_slots[i]
+            job = _lib.MlpParamsJob(bufs[i].data_ptr(), W, rows, W, D, D, hh[i].data_ptr(), 1, scratch[i].data_ptr(), D,
+                                    dw1.data_ptr(), db1.data_ptr(), dw2.data_ptr(), db2.data_ptr(), 1,
+                                    scratch[i].data_ptr(), ctx.math)
+            if i > 0:
+                pw1, _, pw2, _ = wts[i - 1]
+                prev = (pw1.data_ptr(), pw2.data_ptr(), z1[i - 1].data_ptr(), z2[i - 1].data_ptr(), 1, W,
+                        dxc[i - 1].data_ptr(), W, scratch[i - 1].data_ptr(), None, 0)
+            else:
+                prev = (None, None, None, None, 0, 0, None, 0, None, dx.data_ptr(), D)
+            rc = L_.pit_block_bwd(E[i].data_ptr(), inv[i].data_ptr(), Q[i].data_ptr(), L, H, D, b, dxc[i].data_ptr(),
+                                  bufs[i].data_ptr(), work[i].data_ptr(), *prev,
+                                  ctypes.cast(ctypes.pointer(job), ctypes.c_void_p), ctx.math, _lib.stream_ptr())
+            _lib.check(rc, "pit_block_bwd")
+            if _PROCESSOR_HOOK[0] is not None:
+                _PROCESSOR_HOOK[0](i)                       # (block i's weight gradients are now enqueued)
+        # d(lmda): deferred layers are finished by the pass's one finishing launch; the others here, in one launch
+        d_heads = [None] * n
+        now = [i for i in range(n) if not defer[i]]
+        for i in range(n):
+            if defer[i]:
+                _defer_head_finish(work[i], lm_slots[i], heads[i], scale[i], H, 1)
+        if now:
+            m = len(now)
+            for i in now:
+                d_heads[i] = lm_slots[i] if lm_slots[i] is not None else torch.empty((H,), device=dev, dtype=torch.float32)
+            ws = (ctypes.c_void_p * m)(*[work[i].data_ptr() for i in now])
+            dh = (ctypes.c_void_p * m)(*[d_heads[i].data_ptr() for i in now])
+            hd = (ctypes.c_void_p * m)(*[heads[i].data_ptr() for i in now])
+            sc = (ctypes.c_void_p * m)(*[scale[i].data_ptr() for i in now])
+            nh = (ctypes.c_int * m)(*[H] * m)
+            fl = (ctypes.c_int * m)(*[1 if lm_slots[i] is not None else 0 for i in now])
+            _lib.check(L_.pit_posatt_dhead_finish(m, ws, dh, hd, sc, nh, fl, _lib.stream_ptr()), "pit_posatt_dhead_finish")
+        grads = [dx, None, None, None, None]
+        for i in range(n):
+            g = None if lm_slots[i] is not None else d_heads[i]
+            grads.append(g)
+        for i in range(n):
+            grads.extend(w_grads[i] if w_grads[i] is not None else [None, None, None, None])
+        return tuple(grads)
+
+
+_PROCESSOR_HOOK = [None]      # engine.TrainStep(all_reduce_buckets=2): called with the block index after its backward launch
+
+
+@torch.compiler.disable
+def processor_apply(x: torch.Tensor, plan: MeshPlan, n_head: int, lmdas, mlps) -> torch.Tensor:
+    """The whole processor (pit.py:114-122) on a batch-free mesh through the fused block kernels.  ``lmdas``: the
+    blocks' lmda parameters; ``mlps``: per block (w1, b1, w2, b2).  The caller checked block_fusion_supported()."""
+    scales = None
+    if get_head_scale_route() == "host":
+        scales = [host_head_scale(p) for p in lmdas]
+    flat = [p.reshape(-1) for p in lmdas] + [t for m in mlps for t in m]
+    return _Processor.apply(x, plan, n_head, scales, (tuple(lmdas), tuple(tuple(m) for m in mlps)), *flat)
+
+
 class _RelLpLoss(torch.autograd.Function):
     """RelLpNorm (utils.py:80-98), optionally fused with the per-pixel affine
     de-normalisation of the prediction (utils.py:25-34).

@@ -279,7 +279,39 @@ class pit(nn.Module):
         func_ltt = self.down(mesh_ltt, mesh_in, func_in)
         return self._mlp_gelu(self.en_layer, func_ltt, self._heads_of_block(0, self.hid_dim))
 
+    def _fused_processor(self, func_ltt, mesh_ltt):
+        """The fused block kernels (ops.processor_apply) when every block is one of OUR batch-free self-attention
+        layers followed by a kaiming_mlp of the standard shape, nothing is hooked or overridden and the shape is in
+        the small regime; None = run the blocks one by one."""
+        n = len(self.conv)
+        if not (ops.BLOCK_FUSION and n and n == len(self.mlp) and torch.is_tensor(mesh_ltt) and mesh_ltt.dim() == 2
+                and func_ltt.is_cuda and func_ltt.dim() == 3 and func_ltt.dtype == torch.float32
+                and ops.get_math_mode() == "fp32"):
+            return None
+        hid, heads = func_ltt.shape[-1], self.conv[0].n_head
+        kinds = (posatt_fixed, posatt_periodic1d, posatt_periodic2d)
+        for a, w in zip(self.conv, self.mlp):
+            if type(a) not in kinds or type(a) is not type(self.conv[0]) or a.locality != 1.0 or a.n_head != heads \
+                    or a.in_dim != hid or type(w) is not kaiming_mlp:
+                return None
+            if tuple(w.mlp1.weight.shape) != (hid, (1 + heads) * hid) or tuple(w.mlp2.weight.shape) != (hid, hid) \
+                    or w.mlp1.bias is None or w.mlp2.bias is None:
+                return None
+            for m in (a, w, w.mlp1, w.mlp2):            # hooks expect the modules to be CALLED
+                if any(not getattr(f, "_pit_internal", False) for f in m._forward_hooks.values()) \
+                        or m._forward_pre_hooks or m._backward_hooks or m._backward_pre_hooks:
+                    return None
+        if mesh_ltt.shape[0] != func_ltt.shape[1] or not ops.block_fusion_supported(mesh_ltt.shape[0], heads, hid,
+                                                                                    func_ltt.shape[0]):
+            return None
+        plan = self.conv[0]._plan(mesh_ltt, mesh_ltt, True)
+        return ops.processor_apply(func_ltt, plan, heads, [a.lmda for a in self.conv],
+                                   [(w.mlp1.weight, w.mlp1.bias, w.mlp2.weight, w.mlp2.bias) for w in self.mlp])
+
     def processor(self, func_ltt, mesh_ltt):
+        fused = self._fused_processor(func_ltt, mesh_ltt)
+        if fused is not None:
+            return fused
         for i, (a, w) in enumerate(zip(self.conv, self.mlp)):
             func_ltt = a(mesh_ltt, func_ltt)
             func_ltt = self._mlp_gelu(w, func_ltt, self._heads_of_block(i + 1, self.hid_dim))

@@ -242,3 +242,124 @@ def test_two_threads_running_backward_concurrently_give_the_single_thread_gradie
     torch.cuda.synchronize()
     for j in jobs:
         assert not j["errors"], j["errors"][:3]
+
+
+# --------------------------------------------------------------------------- fused processor blocks (pit_block.hip)
+def _model_and_batch(task, seed, batch):
+    from position_induced_transformer_amd import tasks
+    model, sample, meta = tasks.make_task(task, seed=seed)
+    return model, sample(batch), meta
+
+
+@pytest.mark.parametrize("metric,sdim", [("euclid", 2), ("periodic1d", 1), ("periodic2d", 2)])
+def test_block_weights_are_the_oracle_attention_matrix(metric, sdim):
+    """pit_block_weights: E * inv == the reference's softmax weights (pit.py:133-139 / 190-200 / 248-258 with locality
+    1.0), E is symmetric bit for bit, Q = P (m - mbar), rowstat as pit_posatt_fwd would save it."""
+    import ctypes
+    from position_induced_transformer_amd import _lib, ops
+    L, H, n = 256, 2, 3
+    if metric == "euclid":
+        mesh = orc.grid_mesh_2d(16)
+    elif metric == "periodic1d":
+        mesh = orc.line_mesh_1d(256)
+    else:
+        mesh = orc.grid_mesh_2d(16, False)
+    lm = [torch.from_numpy(gio.synth((H, 1, 1), 900 + i, 0.0, 1.0)) for i in range(n)]
+    plan = ops.MeshPlan(metric, mesh.cuda(), mesh.cuda(), 1.0, True)
+    heads = [t.reshape(-1).cuda() for t in lm]
+    E = torch.empty(n, H, L, L, device="cuda"); Q = torch.empty_like(E)
+    inv = torch.empty(n, H, L, device="cuda"); rs = torch.empty(n, H, L, 4, device="cuda"); sc = torch.empty(n, H, device="cuda")
+    hp = (ctypes.c_void_p * n)(*[t.data_ptr() for t in heads])
+    rc = _lib.lib().pit_block_weights(plan.mesh_in.data_ptr(), L, sdim, plan.metric_id, plan.period, n, hp, 0, H, E.data_ptr(),
+                                      Q.data_ptr(), inv.data_ptr(), rs.data_ptr(), sc.data_ptr(), _lib.stream_ptr())
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert torch.equal(E, E.transpose(-1, -2))
+    m = orc.sqdist(metric, mesh, mesh)
+    for i in range(n):
+        c = sc[i].cpu().reshape(H, 1, 1)                                    # the c the kernel used (device route)
+        att = orc.attention_weights(m, c, 1.0, False)                       # (H, L, L)
+        got = (E[i] * inv[i].unsqueeze(-1)).cpu()
+        assert gio.rel_l2(att.numpy(), got.numpy()) <= 1e-6
+        mbar = (att * m).sum(-1, keepdim=True)
+        assert gio.rel_l2((att * (m - mbar)).numpy(), Q[i].cpu().numpy()) <= 1e-5
+        assert gio.rel_l2(mbar.reshape(H, L).numpy(), rs[i, :, :, 3].cpu().numpy()) <= 1e-6
+        assert torch.equal(rs[i, :, :, 2], inv[i]) and float(rs[i, :, :, 1].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("task,batch", [("darcy", 8), ("darcy", 3), ("burgers", 4)])
+@pytest.mark.parametrize("inplace", [False, True])
+def test_fused_processor_equals_the_block_by_block_path(task, batch, inplace):
+    """ops.processor_apply (weights in one launch, one launch per block forward / backward) against the same model
+    run block by block through pit_posatt_* and pit_mlp_*: prediction <= 1e-6, every gradient <= 1e-5 (lmda 1e-4),
+    with the gradients returned to autograd and accumulated in place into a flat buffer."""
+    from position_induced_transformer_amd import ops, utils
+    from position_induced_transformer_amd.ddp import FlatGradients
+    model, (mesh_in, func_in, mesh_out, target), meta = _model_and_batch(task, 21, batch)
+    loss_fn = utils.RelLpNorm(meta["out_dim"], meta["p"])
+    if inplace:
+        flat = FlatGradients(model.parameters())
+    res = {}
+    calls = {"n": 0}
+    orig = ops.processor_apply
+
+    def counting(*a, **k):
+        calls["n"] += 1
+        return orig(*a, **k)
+    ops.processor_apply = counting
+    try:
+        for fused in (True, False):
+            ops.BLOCK_FUSION = fused
+            if inplace:
+                flat.zero_()
+            else:
+                model.zero_grad(set_to_none=True)
+            out = model(mesh_in, func_in, mesh_out)
+            loss_fn(target, out).backward()
+            torch.cuda.synchronize()
+            res[fused] = (out.detach().cpu().numpy(), {k: p.grad.detach().cpu().numpy().copy() for k, p in model.named_parameters()})
+    finally:
+        ops.BLOCK_FUSION = True
+        ops.processor_apply = orig
+    assert calls["n"] == 1, "the fused path did not run"
+    assert gio.rel_l2(res[False][0], res[True][0]) <= 1e-6
+    for k in res[False][1]:
+        tol = 1e-4 if k.endswith("lmda") else 1e-5
+        assert gio.rel_l2(res[False][1][k], res[True][1][k]) <= tol, k
+
+
+def test_fused_processor_is_skipped_when_a_block_is_hooked_or_overridden():
+    from position_induced_transformer_amd import ops, pit as P, tasks
+    model, (mesh_in, func_in, mesh_out, _), _ = _model_and_batch("darcy", 22, 4)
+    calls = {"n": 0}
+    orig = ops.processor_apply
+
+    def counting(*a, **k):
+        calls["n"] += 1
+        return orig(*a, **k)
+    ops.processor_apply = counting
+    try:
+        seen = []
+        ref = model(mesh_in, func_in, mesh_out)
+        assert calls["n"] == 1
+        h = model.mlp[1].register_forward_hook(lambda m, i, o: seen.append(tuple(o.shape)))
+        out = model(mesh_in, func_in, mesh_out)
+        h.remove()
+        assert calls["n"] == 1 and seen == [(4, 256, 64)]                  # the user's hook fired: blocks ran one by one
+        assert gio.rel_l2(ref.detach().cpu().numpy(), out.detach().cpu().numpy()) <= 1e-6
+
+        class doubled(P.posatt_fixed):
+            def convolution(self, A, U):
+                return super().convolution(A, U)
+        mine = doubled(2, 64, 1.0).cuda()
+        mine.load_state_dict(model.conv[2].state_dict())
+        model.conv[2] = mine
+        out = model(mesh_in, func_in, mesh_out)
+        assert calls["n"] == 1
+        assert gio.rel_l2(ref.detach().cpu().numpy(), out.detach().cpu().numpy()) <= 1e-5
+        with ops.math_mode("bf16"):
+            model2, _, _ = tasks.make_task("darcy", seed=22)
+            model2(mesh_in, func_in, mesh_out)
+        assert calls["n"] == 1                                              # fp32 contractions only
+    finally:
+        ops.processor_apply = orig
