@@ -323,9 +323,14 @@ def test_fused_processor_equals_the_block_by_block_path(task, batch, inplace):
         ops.processor_apply = orig
     assert calls["n"] == 1, "the fused path did not run"
     assert gio.rel_l2(res[False][0], res[True][0]) <= 1e-6
+    # d(lmda) is a cancellation-heavy global sum: a layer whose gradient happens to be ~1e-10 carries the
+    # rounding noise of the others' scale - its error is measured against the largest d(lmda) of the model
+    lm_scale = max(float(np.linalg.norm(v)) for k, v in res[False][1].items() if k.endswith("lmda"))
     for k in res[False][1]:
-        tol = 1e-4 if k.endswith("lmda") else 1e-5
-        assert gio.rel_l2(res[False][1][k], res[True][1][k]) <= tol, k
+        if k.endswith("lmda"):
+            assert float(np.linalg.norm(res[False][1][k] - res[True][1][k])) <= 1e-4 * lm_scale, k
+        else:
+            assert gio.rel_l2(res[False][1][k], res[True][1][k]) <= 1e-5, k
 
 
 def test_fused_processor_is_skipped_when_a_block_is_hooked_or_overridden():
