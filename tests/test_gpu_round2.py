@@ -724,6 +724,7 @@ def test_mlp_weight_gradients_carried_by_the_attention_backward_equal_their_own_
     loss_fn = utils.RelLpNorm(meta["out_dim"], meta["p"])
     flat = FlatGradients(model.parameters())
     got = {}
+    ops._PENDING_DW.clear()                      # (entries of passes that earlier tests aborted on purpose: other models' slots)
     with ops.math_mode(math):
         for rider in (True, False, True):
             ops.MLP_PARAMS_RIDER = rider
