@@ -10,14 +10,17 @@ import os
 import subprocess
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
-LIB = os.path.join(CSRC, "libpit_hip.so")
+# PIT_LIB_OUT: diagnostic builds (PIT_EXTRA_FLAGS=-DPIT_STAMPS ...) go to their OWN library and object directory, so they
+# can never be mistaken for the production library; load them with PIT_LIB_PATH
+LIB = os.environ.get("PIT_LIB_OUT") or os.path.join(CSRC, "libpit_hip.so")
 SOURCES = ("pit_abi.hip", "pit_select.hip", "pit_posatt.hip", "pit_block.hip", "pit_mlp.hip", "pit_loss.hip", "pit_norm.hip", "pit_optim.hip")
 HEADERS = ("pit_common.h", "pit_gemm_rd.h", os.path.join("..", "..", "include", "pit_hip.h"))
 FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17"]
 FLAGS += os.environ.get("PIT_EXTRA_FLAGS", "").split()      # diagnostic builds only (e.g. -DPIT_STAMPS, tools/stamp_tiles.py)
 
 
-STAMP = os.path.join(CSRC, "_obj", "flags.stamp")
+OBJDIR = (LIB + ".obj") if os.environ.get("PIT_LIB_OUT") else os.path.join(CSRC, "_obj")
+STAMP = os.path.join(OBJDIR, "flags.stamp")
 
 
 def _stale() -> bool:
@@ -43,7 +46,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if force or _stale():
         from concurrent.futures import ThreadPoolExecutor
         hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-        objdir = os.path.join(CSRC, "_obj")
+        objdir = OBJDIR
         os.makedirs(objdir, exist_ok=True)
         cflags = [f for f in FLAGS if f != "-shared"]
 

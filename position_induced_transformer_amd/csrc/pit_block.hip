@@ -35,6 +35,21 @@ __device__ __forceinline__ f32x4_t mfma_16x16x4(float a, float b, f32x4_t c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
+#ifdef PIT_STAMPS
+// diagnostic build only (tools/block_bench.py): shader-clock stamps of wave 0 of one workgroup, never read by the kernels
+__device__ unsigned long long pit_block_stamps[32];
+#define BSTAMP(i_) do { if (blockIdx.x == 5 && threadIdx.x == 0) pit_block_stamps[i_] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define BSTAMP(i_) do { } while (0)
+#endif
+
+#ifdef PIT_STAMPS
+__device__ int pit_block_dbg = 0;      // experiments (tools/block_bench.py): 1 = linear workgroup -> slab map, 2 / 4 = no B / A loads
+#define PIT_BLOCK_DBG pit_block_dbg
+#else
+#define PIT_BLOCK_DBG 0
+#endif
+
 constexpr int BD = 64;                 // value width (hid_dim) of the fused path: 4 interleaved 16-column tiles per wave
 constexpr int BW = 8;                  // waves per workgroup
 constexpr int MAX_LAYERS = 16;
@@ -62,13 +77,55 @@ __global__ __launch_bounds__(256) void block_weights_kernel(WeightsArgs a) {
     const float ox = xo[0], oy = a.sdim > 1 ? xo[1] : 0.0f, oz = a.sdim > 2 ? xo[2] : 0.0f;
     const bool per = a.periodic != 0;
     float rsum = 0.0f, qsum = 0.0f;
-    // (pass 1: row sums; pass 2 re-forms the weights - L is a few hundred, the exp is cheaper than parking them)
+    float* erow = a.e + row_id * a.L;
+    float* qrow = a.q + row_id * a.L;
+    auto weight = [&](int j, float& m) {
+        const float* xi = a.mesh + (long)j * a.sdim;
+        m = sq_dist3(ox, oy, oz, xi[0], a.sdim > 1 ? xi[1] : 0.0f, a.sdim > 2 ? xi[2] : 0.0f, per, a.period);
+        return __expf(-__fmul_rn(m, c));                                    // S_min = 0: the row holds its own point
+    };
+    if (a.L <= 1024) {                                                      // the row stays in registers: one pass
+        float pv[4][4], mv[4][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int j0 = 4 * lane + 256 * r;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                pv[r][u] = 0.0f; mv[r][u] = 0.0f;
+                if (j0 < a.L) {
+                    pv[r][u] = weight(j0 + u, mv[r][u]);
+                    rsum += pv[r][u];
+                    qsum += pv[r][u] * mv[r][u];
+                }
+            }
+        }
+        rsum = wave_sum(rsum);
+        qsum = wave_sum(qsum);
+        const float inv = rsum > 0.0f ? 1.0f / rsum : 0.0f;
+        const float mbar = qsum * inv;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int j0 = 4 * lane + 256 * r;
+            if (j0 < a.L) {
+                *reinterpret_cast<float4*>(erow + j0) = make_float4(pv[r][0], pv[r][1], pv[r][2], pv[r][3]);
+                *reinterpret_cast<float4*>(qrow + j0) = make_float4(pv[r][0] * (mv[r][0] - mbar) * inv, pv[r][1] * (mv[r][1] - mbar) * inv,
+                                                                    pv[r][2] * (mv[r][2] - mbar) * inv, pv[r][3] * (mv[r][3] - mbar) * inv);
+            }
+        }
+        if (lane == 0) {
+            a.inv[row_id] = inv;
+            float4 st; st.x = __builtin_inff(); st.y = 0.0f; st.z = inv; st.w = mbar;
+            *reinterpret_cast<float4*>(a.rowstat + row_id * 4) = st;
+            if (n == 0) a.scale_out[lh] = c;
+        }
+        return;
+    }
+    // longer rows: pass 1 row sums, pass 2 re-forms the weights (an exp is cheaper than parking them)
     for (int j0 = 4 * lane; j0 < a.L; j0 += 256) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const float* xi = a.mesh + (long)(j0 + u) * a.sdim;
-            const float m = sq_dist3(ox, oy, oz, xi[0], a.sdim > 1 ? xi[1] : 0.0f, a.sdim > 2 ? xi[2] : 0.0f, per, a.period);
-            const float p = __expf(-__fmul_rn(m, c));                       // S_min = 0: the row holds its own point
+            float m;
+            const float p = weight(j0 + u, m);
             rsum += p;
             qsum += p * m;
         }
@@ -77,17 +134,14 @@ __global__ __launch_bounds__(256) void block_weights_kernel(WeightsArgs a) {
     qsum = wave_sum(qsum);
     const float inv = rsum > 0.0f ? 1.0f / rsum : 0.0f;
     const float mbar = qsum * inv;
-    float* erow = a.e + row_id * a.L;
-    float* qrow = a.q + row_id * a.L;
     for (int j0 = 4 * lane; j0 < a.L; j0 += 256) {
         float4 ev, qv;
         float* ep = &ev.x;
         float* qp = &qv.x;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const float* xi = a.mesh + (long)(j0 + u) * a.sdim;
-            const float m = sq_dist3(ox, oy, oz, xi[0], a.sdim > 1 ? xi[1] : 0.0f, a.sdim > 2 ? xi[2] : 0.0f, per, a.period);
-            const float p = __expf(-__fmul_rn(m, c));
+            float m;
+            const float p = weight(j0 + u, m);
             ep[u] = p;
             qp[u] = p * (m - mbar) * inv;
         }
@@ -103,55 +157,86 @@ __global__ __launch_bounds__(256) void block_weights_kernel(WeightsArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------- shared pieces
-// acc[t] (16 rows x 16 columns {4c + t}) += sum over keys [jb, je) of  W[row0 + i][key] * (sc[key]) * V[key][4c + t]
-// W row-major with pitch L (A operand: lane (i = l&15, kq = l>>4) takes 4 consecutive keys with one 16-B load - the key
-// order inside a group of 16 is permuted identically for both operands), V rows ldv floats apart (B operand: one 16-B
-// load = this lane's column of all four tiles).  64 keys per trip: 20 loads in flight, then 64 MFMAs.
-template <bool SCALED>
-__device__ __forceinline__ void slab_contract(const float* __restrict__ wrow, int L, const float* __restrict__ v, long ldv,
-                                              const float* __restrict__ sc, int jb, int je, int l15, int kq,
-                                              f32x4_t (&acc)[4]) {
-    const float* wp = wrow + (long)l15 * L + 4 * kq;
+// One wave's share of a slab contraction: keys [jb, je) (32 per trip) for ALL NH heads.
+//   acc[h or 0][t] (16 rows x 16 columns {4c + t}) += sum_key  W_h[row0 + i][key] * (sc_h[key]) * V_h[key][4c + t]
+// W_h = w + h*wstride, row-major with pitch L (A operand: lane (i = l&15, kq = l>>4) takes 4 consecutive keys with one 16-B
+// load - the key order inside a group of 16 is permuted identically for both operands); V rows ldv floats apart (B operand:
+// one 16-B load = this lane's column of all four tiles).
+//   SHARED (forward, d(scale)): every head contracts the SAME value rows - they are fetched once for all heads (the L2 -> CU
+//     path, ~15 B/clk per CU, is what bounds these kernels: a workgroup of the first version pulled 160 KB, two thirds of it
+//     the second head's copy of the value rows) and the heads keep separate accumulators;
+//   !SHARED (d(values)): head h reads its own columns V + h*vhead, rows scaled by sc_h[key] (1/rowsum), one accumulator.
+// All loads of a trip are requested before its first MFMA (sched_barrier: left to itself the scheduler sinks each load to
+// its use and the trip becomes a chain of dependent memory round trips).
+template <int NH, bool SHARED>
+__device__ __forceinline__ void slab_contract(const float* __restrict__ w, long wstride, int L, const float* __restrict__ v,
+                                              long ldv, int vhead, const float* __restrict__ sc, int jb, int je, int l15, int kq,
+                                              f32x4_t (&acc)[SHARED ? NH : 1][4]) {
+    constexpr int NS = SHARED ? 2 : 1;                 // 16-key groups per trip (d(values) fetches per-head rows: half trips
+                                                       // keep the kernel within 128 VGPRs, the path is bandwidth-bound anyway)
+    const float* wp = w + (long)l15 * L + 4 * kq;
     const float* vp = v + 4 * l15;
-    for (int j0 = jb; j0 < je; j0 += 64) {
-        float4 av[4], bv[4][4], sv[4];
+    for (int j0 = jb; j0 < je; j0 += 16 * NS) {
+        float4 av[NH][NS], sv[NH][NS], bv[SHARED ? 1 : NH][NS][4];
+        const int dbg = PIT_BLOCK_DBG;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            av[s] = *reinterpret_cast<const float4*>(wp + j0 + 16 * s);
-            if (SCALED) sv[s] = *reinterpret_cast<const float4*>(sc + j0 + 16 * s + 4 * kq);
-        }
+        for (int h = 0; h < NH; ++h)
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
+            for (int s = 0; s < NS; ++s) {
+                av[h][s] = (dbg & 4) ? make_float4(1.f, 2.f, 3.f, 4.f) : *reinterpret_cast<const float4*>(wp + h * wstride + j0 + 16 * s);
+                if (!SHARED) sv[h][s] = *reinterpret_cast<const float4*>(sc + (long)h * L + j0 + 16 * s + 4 * kq);
+            }
+#pragma unroll
+        for (int h = 0; h < (SHARED ? 1 : NH); ++h)
+#pragma unroll
+            for (int s = 0; s < NS; ++s)
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+                    bv[h][s][m] = (dbg & 2) ? make_float4(1.f, 2.f, 3.f, 4.f)
+                                            : *reinterpret_cast<const float4*>(vp + h * vhead + (long)(j0 + 16 * s + 4 * kq + m) * ldv);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
 #pragma unroll
             for (int m = 0; m < 4; ++m)
-                bv[s][m] = *reinterpret_cast<const float4*>(vp + (long)(j0 + 16 * s + 4 * kq + m) * ldv);
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const float* ap = &av[s].x;
-            const float* sp = &sv[s].x;
-#pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                const float aw = SCALED ? ap[m] * sp[m] : ap[m];            // (row scale folded into the A operand)
-                acc[0] = mfma_16x16x4(aw, bv[s][m].x, acc[0]);
-                acc[1] = mfma_16x16x4(aw, bv[s][m].y, acc[1]);
-                acc[2] = mfma_16x16x4(aw, bv[s][m].z, acc[2]);
-                acc[3] = mfma_16x16x4(aw, bv[s][m].w, acc[3]);
-            }
-        }
+                for (int h = 0; h < NH; ++h) {
+                    const float* ap = &av[h][s].x;
+                    const float* sp = &sv[h][s].x;
+                    const float aw = SHARED ? ap[m] : ap[m] * sp[m];       // (row scale folded into the A operand)
+                    const float4 bb = bv[SHARED ? 0 : h][s][m];
+                    f32x4_t (&ac)[4] = acc[SHARED ? h : 0];
+                    ac[0] = mfma_16x16x4(aw, bb.x, ac[0]);
+                    ac[1] = mfma_16x16x4(aw, bb.y, ac[1]);
+                    ac[2] = mfma_16x16x4(aw, bb.z, ac[2]);
+                    ac[3] = mfma_16x16x4(aw, bb.w, ac[3]);
+                }
     }
 }
 
-// park this wave's 16 x 64 partial tile: slot [(wave*4 + t)*4 + i][lane]
-__device__ __forceinline__ void park(float* pk, int wave, int lane, const f32x4_t (&acc)[4]) {
+// Workgroup id -> (sample, slab) so that all slabs of a sample run on ONE XCD (workgroups are dealt round-robin to the 8
+// XCDs): a sample's activations then live in that XCD's L2 from one block's launch to the next.  The grid has
+// 8 * ceil(batch / 8) * slabs workgroups; ids whose sample is beyond the batch return false.
+__device__ __forceinline__ bool slab_of(int id, int batch, int slabs, int& sample, int& slab) {
+    if (PIT_BLOCK_DBG & 1) { sample = id / slabs; slab = id % slabs; return sample < batch; }
+    const int x = id & 7, k = id >> 3;
+    sample = x + 8 * (k / slabs);
+    slab = k % slabs;
+    return sample < batch;
+}
+__host__ __device__ inline int slab_grid(int batch, int slabs) { return 8 * ((batch + 7) / 8) * slabs; }
+
+// park a 16 x 64 partial tile in slot `slot`: [(slot*4 + t)*4 + i][lane]
+__device__ __forceinline__ void park(float* pk, int slot, int lane, const f32x4_t (&acc)[4]) {
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) pk[((wave * 4 + t) * 4 + i) * 64 + lane] = acc[t][i];
+        for (int i = 0; i < 4; ++i) pk[((slot * 4 + t) * 4 + i) * 64 + lane] = acc[t][i];
 }
-// element (row 4*(lane>>4) + i, columns 4*(lane&15) .. +3) summed over waves [w0, w0 + nw)
-__device__ __forceinline__ float4 parked_sum(const float* pk, int w0, int nw, int i, int lane) {
+// element (row 4*(lane>>4) + i, columns 4*(lane&15) .. +3) summed over slots w0, w0 + step, ... (nw of them)
+__device__ __forceinline__ float4 parked_sum(const float* pk, int w0, int nw, int step, int i, int lane) {
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int w = w0; w < w0 + nw; ++w) {
+    for (int q = 0, w = w0; q < nw; ++q, w += step) {
         s.x += pk[((w * 4 + 0) * 4 + i) * 64 + lane];
         s.y += pk[((w * 4 + 1) * 4 + i) * 64 + lane];
         s.z += pk[((w * 4 + 2) * 4 + i) * 64 + lane];
@@ -160,7 +245,7 @@ __device__ __forceinline__ float4 parked_sum(const float* pk, int w0, int nw, in
     return s;
 }
 
-constexpr int PARK_FLOATS = BW * 16 * 64;              // 32 KiB
+constexpr int PARK_FLOATS = BW * 16 * 64;              // 32 KiB: one 16 x 64 tile per wave
 
 // ---------------------------------------------------------------------------------------------- forward
 struct BlockFwdArgs {
@@ -172,57 +257,72 @@ struct BlockFwdArgs {
     float *z1, *h, *z2, *y; long ldy;
 };
 
-template <int H>
+template <int H, bool EARLYW>
 __global__ __launch_bounds__(512) void block_fwd_kernel(BlockFwdArgs g) {
-    constexpr int NQ = BW / H;                          // key splits per head
     constexpr int W = (1 + H) * BD;                     // concat width = K of the first contraction
     constexpr int XP = W + 4, HP = BD + 4;              // LDS pitches
     constexpr int KS = W / 16;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* pk = smem;                                   // [PARK_FLOATS]
-    float* xs = smem + PARK_FLOATS;                     // [16][XP] concat tile
+    float* pk = smem;                                   // [H * PARK_FLOATS]: slot wave*H + head
+    float* xs = smem + H * PARK_FLOATS;                 // [16][XP] concat tile
     float* hs = xs + 16 * XP;                           // [16][HP] hidden tile
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, kq = lane >> 4;
     const int slabs = g.L / 16;
-    const int b = blockIdx.x / slabs, n0 = (blockIdx.x % slabs) * 16;
-    const long m0 = (long)blockIdx.x * 16;              // first row of the slab in the (batch*L) row space
-    const int hd = wave / NQ, qt = wave % NQ;
-    const int klen = g.L / NQ;
+    int b, slab;
+    if (!slab_of(blockIdx.x, g.batch, slabs, b, slab)) return;
+    const int n0 = slab * 16;
+    const long m0 = ((long)b * slabs + slab) * 16;      // first row of the slab in the (batch*L) row space
+    const int klen = g.L / BW;                          // every wave: its eighth of the keys, all heads
 
     // the slab's own X rows (first 64 columns of the concat tile): requested first, parked after the attention loads
     float4 xown = make_float4(0.f, 0.f, 0.f, 0.f);
     if (tid < 256) xown = *reinterpret_cast<const float4*>(g.xcat + (m0 + (tid >> 4)) * W + 4 * (tid & 15));
 
-    f32x4_t acc[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    slab_contract<false>(g.e + ((long)hd * g.L + n0) * g.L, g.L, g.xcat + (long)b * g.L * W, W, nullptr,
-                         qt * klen, (qt + 1) * klen, l15, kq, acc);
-    // MLP operands: requested now, consumed after the reduction (waves 0..3 own the four hidden / output tiles)
+    BSTAMP(0);
+    // MLP operands (waves 0..3 own the four hidden / output tiles): requested before (EARLYW) or after the attention
+    // contraction, consumed after the reduction
     const bool mlp_wave = wave < 4;
     const int c1 = (wave & 3) * 16 + l15;
     float4 bv[KS], w2v[4];
-    if (mlp_wave) {
+    float bias = 0.0f, bias2 = 0.0f;
+    auto load_weights = [&]() {
+        if (!mlp_wave) return;
 #pragma unroll
         for (int s = 0; s < KS; ++s) bv[s] = *reinterpret_cast<const float4*>(g.w1 + (long)c1 * W + 16 * s + 4 * kq);
 #pragma unroll
         for (int s = 0; s < 4; ++s) w2v[s] = *reinterpret_cast<const float4*>(g.w2 + (long)c1 * BD + 16 * s + 4 * kq);
-    }
-    park(pk, wave, lane, acc);
+        bias = g.b1[c1];
+        bias2 = g.b2[c1];
+    };
+    if (EARLYW) load_weights();
+    f32x4_t acc[H][4];
+#pragma unroll
+    for (int hh = 0; hh < H; ++hh)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[hh][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    slab_contract<H, true>(g.e + (long)n0 * g.L, (long)g.L * g.L, g.L, g.xcat + (long)b * g.L * W, W, 0, nullptr,
+                           wave * klen, (wave + 1) * klen, l15, kq, acc);
+    BSTAMP(1);
+    if (!EARLYW) load_weights();
+#pragma unroll
+    for (int hh = 0; hh < H; ++hh) park(pk, wave * H + hh, lane, acc[hh]);
     if (tid < 256) *reinterpret_cast<float4*>(xs + (tid >> 4) * XP + 4 * (tid & 15)) = xown;
     __syncthreads();
+    BSTAMP(2);
     // reduce over the key splits, normalise, -> concat tile (LDS) and concat buffer (memory: the backward needs it)
     for (int item = tid; item < H * 256; item += 512) {
         const int hh = item >> 8, i = (item >> 6) & 3, ln = item & 63;
         const int r = 4 * (ln >> 4) + i, col = 4 * (ln & 15);
-        float4 s = parked_sum(pk, hh * NQ, NQ, i, ln);
+        float4 s = parked_sum(pk, hh, BW, H, i, ln);
         const float rinv = g.inv[(long)hh * g.L + n0 + r];
         s.x *= rinv; s.y *= rinv; s.z *= rinv; s.w *= rinv;
         *reinterpret_cast<float4*>(xs + r * XP + BD + hh * BD + col) = s;
         *reinterpret_cast<float4*>(g.xcat + (m0 + r) * W + BD + hh * BD + col) = s;
     }
+    BSTAMP(3);
     __syncthreads();
+    BSTAMP(4);
     // ---- the block's MLP on the 16 x W tile (the phases of mlp_fwd16_kernel, A operand from LDS)
     if (mlp_wave) {
         f32x4_t a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
@@ -234,7 +334,7 @@ __global__ __launch_bounds__(512) void block_fwd_kernel(BlockFwdArgs g) {
             a0 = mfma_16x16x4(a.z, bv[s].z, a0);
             a1 = mfma_16x16x4(a.w, bv[s].w, a1);
         }
-        const float bias = g.b1[c1];
+        BSTAMP(5);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int r = 4 * kq + i;
@@ -245,7 +345,9 @@ __global__ __launch_bounds__(512) void block_fwd_kernel(BlockFwdArgs g) {
             g.h[(m0 + r) * BD + c1] = hv;
         }
     }
+    BSTAMP(6);
     __syncthreads();
+    BSTAMP(7);
     if (!mlp_wave) return;
     f32x4_t o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -256,7 +358,7 @@ __global__ __launch_bounds__(512) void block_fwd_kernel(BlockFwdArgs g) {
         o0 = mfma_16x16x4(a.z, w2v[s].z, o0);
         o1 = mfma_16x16x4(a.w, w2v[s].w, o1);
     }
-    const float bias2 = g.b2[c1];
+    BSTAMP(8);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const long r = m0 + 4 * kq + i;
@@ -264,6 +366,7 @@ __global__ __launch_bounds__(512) void block_fwd_kernel(BlockFwdArgs g) {
         if (g.out_gelu) { g.z2[r * BD + c1] = v; v = gelu_erf(v); }
         g.y[r * g.ldy + c1] = v;
     }
+    BSTAMP(9);
 }
 
 // ---------------------------------------------------------------------------------------------- backward
@@ -283,7 +386,6 @@ struct BlockBwdArgs {
 
 template <int H>
 __device__ __forceinline__ void block_bwd_chain(const BlockBwdArgs& g, float* smem, int slab) {
-    constexpr int NQ = BW / H;
     constexpr int W = (1 + H) * BD;
     constexpr int P1 = BD + 4;
     float* pk = smem;
@@ -292,66 +394,74 @@ __device__ __forceinline__ void block_bwd_chain(const BlockBwdArgs& g, float* sm
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, kq = lane >> 4;
     const int slabs = g.L / 16;
-    const int b = slab / slabs, j0 = (slab % slabs) * 16;
-    const long m0 = (long)slab * 16;
-    const int hd = wave / NQ, qt = wave % NQ;
-    const int klen = g.L / NQ;
+    int b, sl;
+    if (!slab_of(slab, g.batch, slabs, b, sl)) return;
+    const int j0 = sl * 16;
+    const long m0 = ((long)b * slabs + sl) * 16;
+    const int klen = g.L / BW;
 
-    // residual d_out[b, j, 0:64] of torch.cat((inputs, conv), -1) (pit.py:44) and the gelu' argument: requested first
-    const bool own = tid < 256;
-    const int orow = 4 * ((tid & 63) >> 4) + ((tid >> 6) & 3), ocol = 4 * (tid & 15);
-    float4 res = make_float4(0.f, 0.f, 0.f, 0.f), z2v = make_float4(0.f, 0.f, 0.f, 0.f);
+    // residual d_out[b, j, 0:64] of torch.cat((inputs, conv), -1) (pit.py:44) and the gelu' argument: requested first.
+    // Every thread owns two adjacent elements of the slab's 16 x 64 d(values) tile.
+    const int oi = (tid >> 6) & 3, oln = tid & 63, oh = tid >> 8;             // register i, parking lane, column pair
+    const int orow = 4 * (oln >> 4) + oi, ocol = 4 * (oln & 15) + 2 * oh;
     const bool has_mlp = g.w1 != nullptr;
-    if (own) {
-        res = *reinterpret_cast<const float4*>(g.d_xcat + (m0 + orow) * W + ocol);
-        if (has_mlp && g.out_gelu) z2v = *reinterpret_cast<const float4*>(g.z2 + (m0 + orow) * BD + ocol);
-    }
-    // d(values)[j] = sum_h sum_n E_h[j][n] * (inv_h[n] * dO_h[n]):  E is symmetric, row j of E is column j
-    f32x4_t acc[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    slab_contract<true>(g.e + ((long)hd * g.L + j0) * g.L, g.L, g.d_xcat + (long)b * g.L * W + BD + hd * BD, W,
-                        g.inv + (long)hd * g.L, qt * klen, (qt + 1) * klen, l15, kq, acc);
-    // operands of the MLP phases: requested now (phase B: waves 0..3 own the four dZ1 tiles)
+    const float2 res = *reinterpret_cast<const float2*>(g.d_xcat + (m0 + orow) * W + ocol);
+    float2 z2v = make_float2(0.f, 0.f);
+    if (has_mlp && g.out_gelu) z2v = *reinterpret_cast<const float2*>(g.z2 + (m0 + orow) * BD + ocol);
     const int c1 = (wave & 3) * 16 + l15;
-    float w2v[4][4], z1v[4];
-    if (has_mlp && wave < 4) {
+    BSTAMP(10);
+    // d(values)[j] = sum_h sum_n E_h[j][n] * (inv_h[n] * dO_h[n]):  E is symmetric, row j of E is column j
+    f32x4_t acc[1][4];
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
+    for (int t = 0; t < 4; ++t) acc[0][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    slab_contract<H, false>(g.e + (long)j0 * g.L, (long)g.L * g.L, g.L, g.d_xcat + (long)b * g.L * W + BD, W, BD, g.inv,
+                            wave * klen, (wave + 1) * klen, l15, kq, acc);
+    BSTAMP(11);
+    // operands of the MLP phases (phase B: waves 0..3 own the four dZ1 tiles; phase C: dX tiles wave, wave + 8): requested
+    // once the contraction's operand registers are free (the kernel must stay within 128 VGPRs: two workgroups per CU, the
+    // d(scale) and rider workgroups run beside the chain), their latency hides behind the reduction
+    float w2v[4][4], z1v[4], w1v[2][4][4];
+    if (has_mlp) {
+        if (wave < 4) {
 #pragma unroll
-            for (int ee = 0; ee < 4; ++ee) w2v[s][ee] = g.w2[(long)(16 * s + 4 * kq + ee) * BD + c1];   // B(k,n) = w2[k][n]
+            for (int s = 0; s < 4; ++s)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) z1v[i] = g.z1[(m0 + 4 * kq + i) * BD + c1];
+                for (int ee = 0; ee < 4; ++ee) w2v[s][ee] = g.w2[(long)(16 * s + 4 * kq + ee) * BD + c1];   // B(k,n) = w2[k][n]
+#pragma unroll
+            for (int i = 0; i < 4; ++i) z1v[i] = g.z1[(m0 + 4 * kq + i) * BD + c1];
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int col = (wave + t * BW) * 16 + l15;
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int ee = 0; ee < 4; ++ee)
+                    w1v[t][s][ee] = (col < g.n0p) ? g.w1[(long)(16 * s + 4 * kq + ee) * g.n0p + col] : 0.0f;
+        }
     }
-    park(pk, wave, lane, acc);
+    park(pk, wave, lane, acc[0]);
     __syncthreads();
-    if (own) {
-        const int i = (tid >> 6) & 3, ln = tid & 63;
-        float4 s = parked_sum(pk, 0, BW, i, ln);
-        s.x += res.x; s.y += res.y; s.z += res.z; s.w += res.w;
+    BSTAMP(12);
+    {
+        float2 s = res;
+#pragma unroll
+        for (int w = 0; w < BW; ++w) {
+            s.x += pk[((w * 4 + 2 * oh) * 4 + oi) * 64 + oln];
+            s.y += pk[((w * 4 + 2 * oh + 1) * 4 + oi) * 64 + oln];
+        }
         if (!has_mlp) {
-            *reinterpret_cast<float4*>(g.d_values + (m0 + orow) * g.ld_dvalues + ocol) = s;
+            *reinterpret_cast<float2*>(g.d_values + (m0 + orow) * g.ld_dvalues + ocol) = s;
         } else {
-            if (g.out_gelu) {
-                s.x *= gelu_erf_grad(z2v.x); s.y *= gelu_erf_grad(z2v.y); s.z *= gelu_erf_grad(z2v.z); s.w *= gelu_erf_grad(z2v.w);
-            }
-            *reinterpret_cast<float4*>(g.dz2 + (m0 + orow) * BD + ocol) = s;
-            *reinterpret_cast<float4*>(ds2 + orow * P1 + ocol) = s;
+            if (g.out_gelu) { s.x *= gelu_erf_grad(z2v.x); s.y *= gelu_erf_grad(z2v.y); }
+            *reinterpret_cast<float2*>(g.dz2 + (m0 + orow) * BD + ocol) = s;
+            *reinterpret_cast<float2*>(ds2 + orow * P1 + ocol) = s;
         }
     }
     if (!has_mlp) return;
-    // phase C operands (dX tiles wave, wave + 8: n0p / 16 tiles over 8 waves)
-    float w1v[2][4][4];
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        const int col = (wave + t * BW) * 16 + l15;
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-#pragma unroll
-            for (int ee = 0; ee < 4; ++ee)
-                w1v[t][s][ee] = (col < g.n0p) ? g.w1[(long)(16 * s + 4 * kq + ee) * g.n0p + col] : 0.0f;
-    }
+    BSTAMP(13);
     __syncthreads();
+    BSTAMP(14);
     // ---- phase B: dZ1 = (dZ2 W2) * gelu'(Z1)
     if (wave < 4) {
         f32x4_t a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
@@ -371,7 +481,9 @@ __device__ __forceinline__ void block_bwd_chain(const BlockBwdArgs& g, float* sm
             g.dz1[(m0 + r) * BD + c1] = v;
         }
     }
+    BSTAMP(15);
     __syncthreads();
+    BSTAMP(16);
     if (!g.d_xprev) return;
     // ---- phase C: dX tiles = dZ1 W1
 #pragma unroll
@@ -393,38 +505,42 @@ __device__ __forceinline__ void block_bwd_chain(const BlockBwdArgs& g, float* sm
             for (int i = 0; i < 4; ++i) g.d_xprev[(m0 + 4 * kq + i) * g.ld_dxprev + col] = o0[i] + o1[i];
         }
     }
+    BSTAMP(17);
 }
 
 // d c_h -= sum_{n, d} dO_h[n, d] * sum_j Q_h[n, j] U[j, d]   (SURVEY appendix B rearranged; Q carries the centring and 1/rowsum)
 template <int H>
 __device__ __forceinline__ void block_bwd_dscale(const BlockBwdArgs& g, float* smem, int slab) {
-    constexpr int NQ = BW / H;
     constexpr int W = (1 + H) * BD;
-    float* pk = smem;
-    double* wred = reinterpret_cast<double*>(smem + PARK_FLOATS);
+    float* pk = smem;                                   // [H * PARK_FLOATS]
+    double* wred = reinterpret_cast<double*>(smem + H * PARK_FLOATS);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, kq = lane >> 4;
     const int slabs = g.L / 16;
-    const int b = slab / slabs, n0 = (slab % slabs) * 16;
-    const long m0 = (long)slab * 16;
-    const int hd = wave / NQ, qt = wave % NQ;
-    const int klen = g.L / NQ;
+    int b, sl;
+    if (!slab_of(slab, g.batch, slabs, b, sl)) return;
+    const int n0 = sl * 16;
+    const long m0 = ((long)b * slabs + sl) * 16;
+    const int klen = g.L / BW;
     // this thread's d_out element group (head hh, row, 4 columns): requested before the contraction
     const bool own = tid < H * 256;
     const int hh = tid >> 8, i = (tid >> 6) & 3, ln = tid & 63;
     const int r = 4 * (ln >> 4) + i, col = 4 * (ln & 15);
     float4 dov = make_float4(0.f, 0.f, 0.f, 0.f);
     if (own) dov = *reinterpret_cast<const float4*>(g.d_xcat + (m0 + r) * W + BD + hh * BD + col);
-    f32x4_t acc[4];
+    f32x4_t acc[H][4];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    slab_contract<false>(g.qw + ((long)hd * g.L + n0) * g.L, g.L, g.xcat + (long)b * g.L * W, W, nullptr,
-                         qt * klen, (qt + 1) * klen, l15, kq, acc);
-    park(pk, wave, lane, acc);
+    for (int h2 = 0; h2 < H; ++h2)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[h2][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    slab_contract<H, true>(g.qw + (long)n0 * g.L, (long)g.L * g.L, g.L, g.xcat + (long)b * g.L * W, W, 0, nullptr,
+                           wave * klen, (wave + 1) * klen, l15, kq, acc);
+#pragma unroll
+    for (int h2 = 0; h2 < H; ++h2) park(pk, wave * H + h2, lane, acc[h2]);
     __syncthreads();
     double part = 0.0;
     if (own) {
-        const float4 s = parked_sum(pk, hh * NQ, NQ, i, ln);
+        const float4 s = parked_sum(pk, hh, BW, H, i, ln);
         part = (double)s.x * (double)dov.x + (double)s.y * (double)dov.y + (double)s.z * (double)dov.z + (double)s.w * (double)dov.w;
     }
     part = wave_sum_d(part);
@@ -433,7 +549,7 @@ __device__ __forceinline__ void block_bwd_dscale(const BlockBwdArgs& g, float* s
     if (tid < H) {                                      // waves [4h, 4h + 4) hold head h
         double tot = 0.0;
         for (int w = 4 * tid; w < 4 * tid + 4; ++w) tot += wred[w];
-        atomicAdd(g.dscale + (long)tid * PIT_DSCALE_SLOTS + (slab & (PIT_DSCALE_SLOTS - 1)), -tot);
+        atomicAdd(g.dscale + (long)tid * PIT_DSCALE_SLOTS + ((int)(m0 >> 4) & (PIT_DSCALE_SLOTS - 1)), -tot);
     }
 }
 
@@ -456,8 +572,11 @@ __global__ __launch_bounds__(512) void block_bwd_kernel(BlockBwdArgs g, pit_deta
     if (DW) dw_pair_body(w, id - g.n_ds);
 }
 
-constexpr size_t FWD_SMEM = (PARK_FLOATS + 16 * (3 * BD + 4) + 16 * (BD + 4)) * sizeof(float);
-constexpr size_t BWD_SMEM = (PARK_FLOATS + 2 * 16 * (BD + 4)) * sizeof(float);
+constexpr size_t fwd_smem(int H) { return ((size_t)H * PARK_FLOATS + 16 * ((1 + H) * BD + 4) + 16 * (BD + 4)) * sizeof(float); }
+constexpr size_t bwd_smem(int H, bool dscale) {
+    return std::max((size_t)(PARK_FLOATS + 2 * 16 * (BD + 4)) * sizeof(float),
+                    dscale ? ((size_t)H * PARK_FLOATS) * sizeof(float) + BW * sizeof(double) : (size_t)0);
+}
 
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
@@ -468,7 +587,7 @@ extern "C" int pit_block_supported(int n_pts, int n_head, int dim, int batch) {
     static const bool off = getenv("PIT_NO_BLOCK_FUSION") != nullptr;
     if (off) return 0;
     if (dim != BD || (n_head != 1 && n_head != 2)) return 0;
-    if (n_pts <= 0 || batch <= 0 || n_pts % (64 * (BW / n_head)) != 0) return 0;       // 64-key trips per key split
+    if (n_pts <= 0 || batch <= 0 || n_pts % (32 * BW) != 0) return 0;                  // 32-key trips, keys split over 8 waves
     static const long max_rows = getenv("PIT_BLOCK_MAX_ROWS") ? atol(getenv("PIT_BLOCK_MAX_ROWS")) : 8192;
     const long rows = (long)batch * n_pts;
     return rows >= 256 && rows <= max_rows;             // the latency regime; above, the tiled kernels of pit_posatt.hip
@@ -506,15 +625,29 @@ extern "C" int pit_block_fwd(const float* e, const float* inv, int n_pts, int n_
     g.e = e; g.inv = inv; g.L = n_pts; g.batch = batch; g.xcat = xcat;
     g.w1 = w1; g.b1 = b1; g.w2 = w2; g.b2 = b2; g.out_gelu = out_gelu;
     g.z1 = z1; g.h = h; g.z2 = z2; g.y = y; g.ldy = ldy;
-    const dim3 grid((unsigned)((long)batch * n_pts / 16)), block(64 * BW);
-    static bool once = ((void)hipFuncSetAttribute((const void*)block_fwd_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 98304),
-                        (void)hipFuncSetAttribute((const void*)block_fwd_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 98304), true);
-    (void)once;
-    if (n_head == 1) hipLaunchKernelGGL(block_fwd_kernel<1>, grid, block, FWD_SMEM, (hipStream_t)stream, g);
-    else hipLaunchKernelGGL(block_fwd_kernel<2>, grid, block, FWD_SMEM, (hipStream_t)stream, g);
+    const dim3 grid((unsigned)slab_grid(batch, n_pts / 16)), block(64 * BW);
+    static const bool earlyw = getenv("PIT_BLOCK_EARLY_W") != nullptr;       // (registers: the late variant fits 128 VGPRs)
+    const size_t FWD_SMEM = fwd_smem(n_head);
+#define PIT_BLOCK_FWD(H_, E_)                                                                                              \
+    do {                                                                                                                   \
+        static bool once = ((void)hipFuncSetAttribute((const void*)block_fwd_kernel<H_, E_>,                              \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, 98304), true);                 \
+        (void)once;                                                                                                        \
+        hipLaunchKernelGGL((block_fwd_kernel<H_, E_>), grid, block, FWD_SMEM, (hipStream_t)stream, g);                     \
+    } while (0)
+    if (n_head == 1) { if (earlyw) PIT_BLOCK_FWD(1, true); else PIT_BLOCK_FWD(1, false); }
+    else { if (earlyw) PIT_BLOCK_FWD(2, true); else PIT_BLOCK_FWD(2, false); }
+#undef PIT_BLOCK_FWD
     PIT_CHECK_LAUNCH();
     return 0;
 }
+
+#ifdef PIT_STAMPS
+extern "C" int pit_block_set_dbg(int v) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(pit_block_dbg), &v, sizeof(int)); }
+extern "C" int pit_block_read_stamps(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pit_block_stamps), sizeof(unsigned long long) * 32);
+}
+#endif
 
 extern "C" int pit_block_bwd(const float* e, const float* inv, const float* qw, int n_pts, int n_head, int dim, int batch,
                              const float* d_xcat, const float* xcat, double* dscale,
@@ -542,12 +675,12 @@ extern "C" int pit_block_bwd(const float* e, const float* inv, const float* qw, 
     g.d_xprev = d_xprev; g.ld_dxprev = ld_dxprev;
     g.dz1 = scratch_prev; g.dz2 = has_mlp ? scratch_prev + rows * dim : nullptr;      // the layout pit_mlp_bwd_data uses
     g.d_values = d_values; g.ld_dvalues = ld_dvalues;
-    g.n_chain = (int)(rows / 16);
-    g.n_ds = dscale ? (int)(rows / 16) : 0;
+    g.n_chain = slab_grid(batch, n_pts / 16);
+    g.n_ds = dscale ? g.n_chain : 0;
     pit_detail::DwPair dw = pit_detail::DwPair();
     bool carried = false;
     if (rider) carried = pit_detail::plan_dw_pair(*rider, BW, &dw);
-    const size_t sm = std::max(BWD_SMEM, carried ? (size_t)BW * 16 * 64 * sizeof(float) : (size_t)0);
+    const size_t sm = std::max(bwd_smem(n_head, dscale != nullptr), carried ? (size_t)BW * 16 * 64 * sizeof(float) : (size_t)0);
     const dim3 grid((unsigned)(g.n_chain + g.n_ds + (carried ? dw.n1 + dw.n2 : 0))), block(64 * BW);
 #define PIT_BLOCK_BWD(H_, DW_)                                                                                             \
     do {                                                                                                                   \

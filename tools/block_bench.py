@@ -1,0 +1,95 @@
+"""Diagnostic (GPU box): the fused processor-block launches in isolation - hipGraph-timed pit_block_weights /
+pit_block_fwd / pit_block_bwd at the Darcy shape - and, with a -DPIT_STAMPS library (PIT_LIB_PATH), the phase timeline
+of one workgroup of the forward and backward chain kernels.
+    python tools/block_bench.py [batch]"""
+import ctypes, os, sys
+ROOT = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
+import torch
+from position_induced_transformer_amd import _lib, ops, tasks
+
+
+def graph_time(fn, reps=20, replays=10):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(reps):
+            fn()
+    g.replay(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(replays):
+        g.replay()
+    e1.record(); e1.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / (reps * replays)
+
+
+b = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+model, sample, meta = tasks.make_task("darcy", seed=0)
+L_, Lp, H, D, n = _lib.lib(), 256, 2, 64, 4
+W, rows = (1 + H) * D, b * 256
+plan = model.conv[0]._plan(model.mesh_ltt, model.mesh_ltt, True)
+heads = [c.lmda.detach().reshape(-1).contiguous() for c in model.conv]
+E = torch.empty(n, H, Lp, Lp, device="cuda"); Q = torch.empty_like(E)
+inv = torch.empty(n, H, Lp, device="cuda"); rs = torch.empty(n, H, Lp, 4, device="cuda"); sc = torch.empty(n, H, device="cuda")
+hp = (ctypes.c_void_p * n)(*[t.data_ptr() for t in heads])
+sp = lambda: torch.cuda.current_stream().cuda_stream
+
+
+def weights():
+    assert L_.pit_block_weights(plan.mesh_in.data_ptr(), Lp, 2, 0, 0.0, n, hp, 0, H, E.data_ptr(), Q.data_ptr(), inv.data_ptr(),
+                                rs.data_ptr(), sc.data_ptr(), sp()) == 0
+
+
+weights()
+xc = torch.randn(b, Lp, W, device="cuda"); y = torch.empty(b, Lp, W, device="cuda")
+z1 = torch.empty(rows, D, device="cuda"); hh = torch.empty_like(z1); z2 = torch.empty_like(z1)
+m = model.mlp[0]
+w1, b1, w2, b2 = (t.detach().contiguous() for t in (m.mlp1.weight, m.mlp1.bias, m.mlp2.weight, m.mlp2.bias))
+
+
+def fwd():
+    assert L_.pit_block_fwd(E[0].data_ptr(), inv[0].data_ptr(), Lp, H, D, b, xc.data_ptr(), w1.data_ptr(), b1.data_ptr(),
+                            w2.data_ptr(), b2.data_ptr(), 1, z1.data_ptr(), hh.data_ptr(), z2.data_ptr(), y.data_ptr(), W, 0, sp()) == 0
+
+
+dxc = torch.randn(b, Lp, W, device="cuda"); dxp = torch.empty(b, Lp, W, device="cuda")
+scr = torch.empty(rows * 2 * D, device="cuda"); scr_own = torch.randn(rows * 2 * D, device="cuda")
+ws = torch.zeros(H * 1024, device="cuda", dtype=torch.float64)
+gw1, gb1, gw2, gb2 = (torch.zeros_like(t) for t in (w1, b1, w2, b2))
+job = _lib.MlpParamsJob(xc.data_ptr(), W, rows, W, D, D, hh.data_ptr(), 1, scr_own.data_ptr(), D, gw1.data_ptr(), gb1.data_ptr(),
+                        gw2.data_ptr(), gb2.data_ptr(), 1, scr_own.data_ptr(), 0)
+jp = ctypes.cast(ctypes.pointer(job), ctypes.c_void_p)
+
+
+def bwd(dscale=True, rider=True):
+    assert L_.pit_block_bwd(E[0].data_ptr(), inv[0].data_ptr(), Q[0].data_ptr(), Lp, H, D, b, dxc.data_ptr(), xc.data_ptr(),
+                            ws.data_ptr() if dscale else None, w1.data_ptr(), w2.data_ptr(), z1.data_ptr(), z2.data_ptr(), 1, W,
+                            dxp.data_ptr(), W, scr.data_ptr(), None, 0, jp if rider else None, 0, sp()) == 0
+
+
+if os.environ.get("BLOCK_DBG"):
+    L_.pit_block_set_dbg.argtypes = [ctypes.c_int]
+    assert L_.pit_block_set_dbg(int(os.environ["BLOCK_DBG"])) == 0
+fwd(); bwd()
+print(f"batch {b}: weights {graph_time(weights):.2f} us | block_fwd {graph_time(fwd):.2f} us | block_bwd {graph_time(bwd):.2f} us "
+      f"(chain only {graph_time(lambda: bwd(False, False)):.2f}, chain+dscale {graph_time(lambda: bwd(True, False)):.2f}, "
+      f"chain+rider {graph_time(lambda: bwd(False, True)):.2f})")
+if hasattr(L_, "pit_block_read_stamps"):
+    fwd(); bwd(False, False); torch.cuda.synchronize()
+    buf = (ctypes.c_ulonglong * 32)()
+    L_.pit_block_read_stamps.argtypes = [ctypes.c_void_p]
+    assert L_.pit_block_read_stamps(buf) == 0
+    t = list(buf)
+    names = {0: "fwd entry", 1: "attention contraction done", 2: "parked + barrier", 3: "reduced, concat tile written",
+             4: "barrier", 5: "GEMM1 done", 6: "bias+gelu, Z1/H stored", 7: "barrier", 8: "GEMM2 done", 9: "stored",
+             10: "bwd entry", 11: "d(values) contraction done", 12: "parked + barrier", 13: "reduced (+gelu'), dZ2 tile",
+             14: "barrier", 15: "phase B (dZ1)", 16: "barrier", 17: "phase C (dX) stored"}
+    for lo, hi in ((0, 9), (10, 17)):
+        prev = t[lo]
+        for i in range(lo, hi + 1):
+            print(f"  {names[i]:36s} +{t[i] - prev:7d}   (t = {t[i] - t[lo]:7d})")
+            prev = t[i]
