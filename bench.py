@@ -244,7 +244,7 @@ def graph_time_us(fn, reps=20, replays=10):
 def pmc_traffic(kernel_key):
     """HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE collected in
     separate runs, corrected as MI355X_MICROARCH.md prescribes): profiles/r02_pmc_traffic.json, else r01."""
-    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 rec = json.load(f)["kernels"].get(kernel_key)
@@ -369,6 +369,71 @@ def roofline_attention_bwd_probe(model, batch):
             "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": pmc_traffic(f"posatt_bwd_pair_dw_b{batch}"),
             "us_per_launch": round(us, 3), "flops_per_launch": flops, "algorithmic_bytes": alg_bytes}
+
+
+def roofline_block_probe(model, batch):
+    """The launches with the LARGEST share of the Darcy b=8 step since round 3 (profiles/r03_darcy8.summary.txt): the fused
+    processor-block kernels of csrc/pit_block.hip, called through the C ABI exactly as ops._Processor does.
+      block_bwd_kernel: d(values) of a block (2*H*L*L*D*b) + its d(scale) (2*H*L*L*D*b) + the data path of the previous
+        block's MLP backward (dZ1 = dZ2 W2, dX = dZ1 W1: 2*rows*(n1*n2 + n1*n0)) + the weight-gradient reductions of
+        the block's own MLP (2*rows*(n0*n1 + n1*n2)) in ONE launch;
+      block_fwd_kernel: the block's attention (2*H*L*L*D*b) + its MLP forward (2*rows*(n0*n1 + n1*n2)).
+    Returns (backward record, forward record) or None when the shape does not take the fused path."""
+    import ctypes
+    from position_induced_transformer_amd import _lib, ops
+    if model.mesh_ltt is None or not hasattr(model, "conv") or len(model.conv) < 2:
+        return None
+    layer, mlp = model.conv[1], model.mlp[1]
+    L, H, D = model.mesh_ltt.shape[0], layer.n_head, model.hid_dim
+    if not ops.block_fusion_supported(L, H, D, batch):
+        return None
+    Lb = _lib.lib()
+    W, rows, n = (1 + H) * D, batch * L, 1
+    plan = layer._plan(model.mesh_ltt, model.mesh_ltt, True)
+    head = layer.lmda.detach().reshape(-1).contiguous()
+    E = torch.empty(n, H, L, L, device="cuda"); Q = torch.empty_like(E)
+    inv = torch.empty(n, H, L, device="cuda"); rs = torch.empty(n, H, L, 4, device="cuda"); sc = torch.empty(n, H, device="cuda")
+    hp = (ctypes.c_void_p * n)(head.data_ptr())
+    _lib.check(Lb.pit_block_weights(plan.mesh_in.data_ptr(), L, plan.sdim, plan.metric_id, plan.period, n, hp, 0, H, E.data_ptr(),
+                                    Q.data_ptr(), inv.data_ptr(), rs.data_ptr(), sc.data_ptr(), _lib.stream_ptr()), "pit_block_weights")
+    xc = torch.randn(batch, L, W, device="cuda"); y = torch.empty(batch, L, W, device="cuda")
+    z1 = torch.randn(rows, D, device="cuda"); hh = torch.randn(rows, D, device="cuda"); z2 = torch.randn(rows, D, device="cuda")
+    w1, b1, w2, b2 = (t.detach().contiguous() for t in (mlp.mlp1.weight, mlp.mlp1.bias, mlp.mlp2.weight, mlp.mlp2.bias))
+    dxc = torch.randn(batch, L, W, device="cuda"); dxp = torch.empty(batch, L, W, device="cuda")
+    scr = torch.empty(rows * 2 * D, device="cuda"); scr_own = torch.randn(rows * 2 * D, device="cuda")
+    ws = torch.zeros(H * 1024, device="cuda", dtype=torch.float64)
+    gw1, gb1, gw2, gb2 = (torch.zeros_like(t) for t in (w1, b1, w2, b2))
+    job = _lib.MlpParamsJob(xc.data_ptr(), W, rows, W, D, D, hh.data_ptr(), 1, scr_own.data_ptr(), D, gw1.data_ptr(),
+                            gb1.data_ptr(), gw2.data_ptr(), gb2.data_ptr(), 1, scr_own.data_ptr(), 0)
+    jp = ctypes.cast(ctypes.pointer(job), ctypes.c_void_p)
+
+    def fwd():
+        _lib.check(Lb.pit_block_fwd(E[0].data_ptr(), inv[0].data_ptr(), L, H, D, batch, xc.data_ptr(), w1.data_ptr(), b1.data_ptr(),
+                                    w2.data_ptr(), b2.data_ptr(), 1, z1.data_ptr(), hh.data_ptr(), z2.data_ptr(), y.data_ptr(), W, 0,
+                                    _lib.stream_ptr()), "pit_block_fwd")
+
+    def bwd():
+        _lib.check(Lb.pit_block_bwd(E[0].data_ptr(), inv[0].data_ptr(), Q[0].data_ptr(), L, H, D, batch, dxc.data_ptr(), xc.data_ptr(),
+                                    ws.data_ptr(), w1.data_ptr(), w2.data_ptr(), z1.data_ptr(), z2.data_ptr(), 1, W, dxp.data_ptr(), W,
+                                    scr.data_ptr(), None, 0, jp, 0, _lib.stream_ptr()), "pit_block_bwd")
+
+    att = 2.0 * H * L * L * D * batch
+    mlp_f = 2.0 * rows * (W * D + D * D)
+    recs = []
+    for name, fn, flops, nbytes, what in (
+            ("block_bwd_kernel", bwd, 2 * att + 2.0 * rows * (D * D + D * W) + mlp_f,
+             4.0 * (2 * rows * W + rows * W + 4 * rows * D + rows * W + 2 * H * L * L + rows * (W + 3 * D)),
+             f"d(values)+d(scale) of a processor block {L}x{L}, D={D}, H={H}, batch {batch}, + data path of the previous block's "
+             f"MLP backward + dW/db of the block's own MLP {W}->{D}->{D} ({rows} rows)"),
+            ("block_fwd_kernel", fwd, att + mlp_f, 4.0 * (2 * rows * W + 4 * rows * D + H * L * L + W * D + D * D),
+             f"attention of a processor block {L}x{L}, D={D}, H={H}, batch {batch}, + its MLP forward {W}->{D}->{D} ({rows} rows)")):
+        us = graph_time_us(fn)
+        ws.zero_()
+        achieved = flops / (us * 1e-6) / 1e12
+        recs.append({"bound": "mfma", "kernel": f"{name}: {what}", "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS,
+                     "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": pmc_traffic(f"{name}_b{batch}"),
+                     "us_per_launch": round(us, 3), "flops_per_launch": flops, "algorithmic_bytes": nbytes})
+    return recs
 
 
 def executed_gflop_per_sample(model, step):
@@ -678,10 +743,15 @@ def main():
         extras["roofline_saturated"] = roofline_probe(model, 256)
         extras["roofline_mlp_saturated"] = roofline_mlp_probe(model, 256)
     if rank == 0:
+        blk = roofline_block_probe(model, args.batch) if args.math == "fp32" else None
         bwd = roofline_attention_bwd_probe(model, args.batch)
         mlp = roofline_mlp_probe(model, args.batch)
-        if bwd is not None:
-            rec["roofline"] = bwd                                         # the launch with the largest time share
+        if blk is not None:
+            rec["roofline"] = blk[0]                                      # the launch with the largest time share (round 3)
+            rec["roofline_block_fwd"] = blk[1]
+            rec["roofline_mlp"] = mlp
+        elif bwd is not None:
+            rec["roofline"] = bwd                                         # (round 2's dominant launch; the path of larger batches)
             rec["roofline_mlp"] = mlp                                     # (round 1-2's dominant family: the MLP forward)
         else:
             rec["roofline"] = mlp

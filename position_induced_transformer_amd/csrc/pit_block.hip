@@ -615,7 +615,7 @@ extern "C" int pit_block_supported(int n_pts, int n_head, int dim, int batch) {
     if (off) return 0;
     if (dim != BD || (n_head != 1 && n_head != 2)) return 0;
     if (n_pts <= 0 || batch <= 0 || n_pts % (32 * BW) != 0) return 0;                  // 32-key trips, keys split over 8 waves
-    static const long max_rows = getenv("PIT_BLOCK_MAX_ROWS") ? atol(getenv("PIT_BLOCK_MAX_ROWS")) : 8192;
+    static const long max_rows = getenv("PIT_BLOCK_MAX_ROWS") ? atol(getenv("PIT_BLOCK_MAX_ROWS")) : 16384;
     const long rows = (long)batch * n_pts;
     return rows >= 256 && rows <= max_rows;             // the latency regime; above, the tiled kernels of pit_posatt.hip
 }
