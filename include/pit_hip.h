@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define PIT_ABI_VERSION 10
+#define PIT_ABI_VERSION 11
 #define PIT_DSCALE_SLOTS 1024 /* fp64 accumulators per head in pit_posatt_bwd's workspace */
 
 /* distance metric (dist2att variants) */
@@ -54,6 +54,26 @@ const char* pit_error_string(int code);
  * Any other value returns PIT_ERR_UNSUPPORTED. */
 #define PIT_MATH_FP32 0
 #define PIT_MATH_BF16 1
+/* bf16 STORAGE of the large decoder-side tensors, OR-ed into the `math_mode` argument (PIT_MATH_BF16 only; ABI 11).
+ * BASELINE configs 3 and 5 (Vorticity, NACA) are bound by the fp32 traffic of the decoder tail - the up-projection's
+ * output (rows x H*hid), the decoder MLP's saved pre-activations and their gradients: 81 920 / 225 420 rows - not by
+ * the matrix pipe; with these flags those tensors live in memory as bf16 (widened exactly on load, RNE on store), every
+ * accumulation stays fp32.  Distances, mask, softmax weights, the d(scale) reduction, parameters and their gradients
+ * are untouched.  A call whose shape does not take the kernels that implement a flag returns PIT_ERR_UNSUPPORTED
+ * (ask pit_mlp_bf16_io_supported first).
+ *   pit_posatt_fwd   PIT_IO_OUT_BF16   `out` is bf16 (candidate-list layers, no input copy)
+ *   pit_posatt_bwd   PIT_IO_DOUT_BF16  `d_out` is bf16 (candidate-list layers)
+ *   pit_mlp_fwd      PIT_IO_X_BF16     `x` is bf16;  PIT_IO_SAVE_BF16: z1, h are written as bf16
+ *   pit_mlp_bwd*     PIT_IO_X_BF16, PIT_IO_SAVE_BF16 (z1, h and the dZ1 scratch - rows*n1 bf16 - are bf16),
+ *                    PIT_IO_DX_BF16    `d_x` is written as bf16 */
+#define PIT_IO_X_BF16    0x100
+#define PIT_IO_SAVE_BF16 0x200
+#define PIT_IO_DX_BF16   0x400
+#define PIT_IO_OUT_BF16  0x800
+#define PIT_IO_DOUT_BF16 0x1000
+/* 1 if pit_mlp_fwd / pit_mlp_bwd* of this shape accept PIT_IO_X_BF16 | PIT_IO_SAVE_BF16 | PIT_IO_DX_BF16 (thin output
+ * layer n2 <= 4 without trailing gelu, large regime, widths multiples of 8) */
+int pit_mlp_bf16_io_supported(int rows, int n0, int n1, int n2, int out_gelu);
 
 /* pit.py:48 (and :135,:196,:254): c_h = tan(0.25*pi*(1-1e-7)*(1+sin(lmda_h))).
  * Evaluated through fp64 with the reference's fp32 intermediate roundings. */

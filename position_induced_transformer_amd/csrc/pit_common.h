@@ -29,8 +29,13 @@ typedef short bf16x4 __attribute__((ext_vector_type(4)));
 // The math mode is an ARGUMENT of every ABI call that contracts (no process-wide state): the entry
 // point parks it in a thread-local for the launch helpers of that call (PIT_ENTER_MATH).
 extern thread_local int t_call_math;
-#define PIT_ENTER_MATH(mode_) do { if ((mode_) != PIT_MATH_FP32 && (mode_) != PIT_MATH_BF16) return PIT_ERR_UNSUPPORTED; \
-                                   t_call_math = (mode_); } while (0)
+// (the low byte of the argument is the math mode, the PIT_IO_* storage flags above it are read by the entry point itself)
+#define PIT_ENTER_MATH(mode_) do { if (((mode_) & 0xff) != PIT_MATH_FP32 && ((mode_) & 0xff) != PIT_MATH_BF16) return PIT_ERR_UNSUPPORTED; \
+                                   if (((mode_) & ~0xff) && ((mode_) & 0xff) != PIT_MATH_BF16) return PIT_ERR_UNSUPPORTED;              \
+                                   t_call_math = ((mode_) & 0xff); } while (0)
+// bf16 storage (PIT_IO_*): a tensor kept as bf16 in memory is widened exactly (bits << 16), narrowed with RNE
+__device__ __forceinline__ float bf16_to_f(unsigned short b) { return __uint_as_float((unsigned)b << 16); }
+__device__ __forceinline__ unsigned short f_to_bf16(float x) { return __builtin_bit_cast(unsigned short, (__bf16)x); }
 __device__ __forceinline__ int group_pos(bool bf16, int u, int half) { return bf16 ? 4 * half + u : 2 * u + half; }
 __device__ __forceinline__ short bf16_bits(float x) { return __builtin_bit_cast(short, (__bf16)x); }
 __device__ __forceinline__ bf16x4 pack_bf16(float a0, float a1, float a2, float a3) {

@@ -26,6 +26,9 @@ struct GemmArgs {
     float* C2;
     int bf16;                            // PIT_MATH_BF16: one v_mfma_f32_32x32x8_bf16 per 4 k instead of 4 fp32 MFMAs
     int seq_epi;                         // experiments (PIT_GEMM_RD_SEQ_EPI): one accumulator register per epilogue trip
+    // bf16 STORAGE (PIT_IO_*; gemm_bfl_kernel and the thin kernels only): the tensor behind A / B / C / Z / G holds bf16
+    // elements; strides stay in elements
+    int a16, b16, c16, z16, g16;
 };
 
 // both weight-gradient reductions of one MLP (dW2|db2 and dW1|db1), prepared for gemm_rd_body<1, EPI_ATOMIC>:

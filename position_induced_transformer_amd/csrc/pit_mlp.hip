@@ -622,6 +622,30 @@ __device__ __forceinline__ unsigned pack2_bf16(float lo, float hi) {
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
 }
 constexpr int BPK = LBK + 8;      // LDS row pitch in bf16 elements
+// four consecutive elements of a tensor stored as fp32 or (PIT_IO_*: is16) bf16; idx in elements, 4-element aligned
+__device__ __forceinline__ float4 ld4e(const float* base, long idx, int is16) {
+    if (is16) {
+        const uint2 q = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(base) + idx);
+        return make_float4(__uint_as_float(q.x << 16), __uint_as_float(q.x & 0xffff0000u),
+                           __uint_as_float(q.y << 16), __uint_as_float(q.y & 0xffff0000u));
+    }
+    return *reinterpret_cast<const float4*>(base + idx);
+}
+__device__ __forceinline__ void st4e(float* base, long idx, float4 v, int is16) {
+    if (is16) {
+        uint2 q;
+        q.x = pack2_bf16(v.x, v.y); q.y = pack2_bf16(v.z, v.w);
+        *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(base) + idx) = q;
+    } else {
+        *reinterpret_cast<float4*>(base + idx) = v;
+    }
+}
+__device__ __forceinline__ float ld1e(const float* base, long idx, int is16) {
+    return is16 ? bf16_to_f(reinterpret_cast<const unsigned short*>(base)[idx]) : base[idx];
+}
+__device__ __forceinline__ void st1e(float* base, long idx, float v, int is16) {
+    if (is16) reinterpret_cast<unsigned short*>(base)[idx] = f_to_bf16(v); else base[idx] = v;
+}
 
 template <int LBM, bool A_KC, bool B_KC, int EPI>
 __global__ __launch_bounds__(256) void gemm_bfl_kernel(GemmArgs g) {
@@ -645,12 +669,34 @@ __global__ __launch_bounds__(256) void gemm_bfl_kernel(GemmArgs g) {
     const int n_real = (EPI == EPI_ATOMIC && g.ones_col >= 0) ? g.N - 1 : g.N;
 
     float sa[A_KC ? PA * 4 : KPA], sb[B_KC ? 8 : KPB];
+    // bf16 STORAGE of an operand (PIT_IO_*, wave-uniform flags): its chunk needs no conversion on the way to LDS.
+    //   k-contiguous A: 4 threads cover the 32 k of a row with one 16-B load each (64 rows per pass);
+    //   i-contiguous A (LBM = 128) / B: a lane owns TWO adjacent rows / columns (one 4-B load = the pair at one k), takes
+    //   8 (A) / 4 (B) consecutive k and writes each row's fragment piece as one 16-B / 8-B LDS store.
+    constexpr int PA16 = (LBM + 63) / 64;
+    uint4 sa16[PA16];
+    unsigned sa2[8], sb2[4];
     // the bias gradient (virtual ones column) = row sums of the A operand, exact fp32 from the staging
     // registers of the first column block (A is i-contiguous in every row-reducing GEMM)
     const bool want_rowsum = (EPI == EPI_ATOMIC) && !A_KC && g.ones_col >= 0 && blockIdx.x == 0;
-    float rsum = 0.0f;
+    float rsum = 0.0f, rsum_hi = 0.0f;
     auto gload = [&](int kc) {
-        if (A_KC) {
+        if (A_KC && g.a16) {
+#pragma unroll
+            for (int p = 0; p < PA16; ++p) {
+                const int rl = p * 64 + (tid >> 2), row = m0 + rl, k = kc + (tid & 3) * 8;
+                const bool ok = rl < LBM && row < g.M && k < kend;
+                const i32x4 q = __builtin_amdgcn_raw_buffer_load_b128(ra, ok ? (int)(((unsigned)row * (unsigned)g.a_rs + (unsigned)k) * 2u) : (int)g.a_bytes, 0, 0);
+                sa16[p] = make_uint4((unsigned)q.x, (unsigned)q.y, (unsigned)q.z, (unsigned)q.w);
+            }
+        } else if (!A_KC && g.a16) {
+            const int m = m0 + 2 * (tid & 63), k0 = kc + (tid >> 6) * 8;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const bool ok = m < g.M && k0 + e < kend;
+                sa2[e] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(ra, ok ? (int)(((unsigned)(k0 + e) * (unsigned)g.a_cs + (unsigned)m) * 2u) : (int)g.a_bytes, 0, 0);
+            }
+        } else if (A_KC) {
 #pragma unroll
             for (int p = 0; p < PA; ++p) {
                 const int row = m0 + p * 32 + (tid >> 3), k = kc + (tid & 7) * 4;
@@ -668,7 +714,14 @@ __global__ __launch_bounds__(256) void gemm_bfl_kernel(GemmArgs g) {
                 sa[e] = buf_load(ra, ok ? ((unsigned)(k0 + e) * (unsigned)g.a_cs + (unsigned)m) * 4u : g.a_bytes);
             }
         }
-        if (B_KC) {
+        if (!B_KC && g.b16) {
+            const int n = n0 + 2 * (tid & 31), k0 = kc + (tid >> 5) * 4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const bool ok = n < n_real && k0 + e < kend;
+                sb2[e] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rb, ok ? (int)(((unsigned)(k0 + e) * (unsigned)g.b_rs + (unsigned)n) * 2u) : (int)g.b_bytes, 0, 0);
+            }
+        } else if (B_KC) {
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
                 const int n = n0 + p * 32 + (tid >> 3), k = kc + (tid & 7) * 4;
@@ -688,7 +741,26 @@ __global__ __launch_bounds__(256) void gemm_bfl_kernel(GemmArgs g) {
         }
     };
     auto lstore = [&]() {
-        if (A_KC) {
+        if (A_KC && g.a16) {
+#pragma unroll
+            for (int p = 0; p < PA16; ++p) {
+                const int rl = p * 64 + (tid >> 2);
+                if (rl < LBM) *reinterpret_cast<uint4*>(As + rl * BPK + (tid & 3) * 8) = sa16[p];
+            }
+        } else if (!A_KC && g.a16) {
+            uint4 lo, hi;
+            lo.x = (sa2[0] & 0xffffu) | (sa2[1] << 16); hi.x = (sa2[0] >> 16) | (sa2[1] & 0xffff0000u);
+            lo.y = (sa2[2] & 0xffffu) | (sa2[3] << 16); hi.y = (sa2[2] >> 16) | (sa2[3] & 0xffff0000u);
+            lo.z = (sa2[4] & 0xffffu) | (sa2[5] << 16); hi.z = (sa2[4] >> 16) | (sa2[5] & 0xffff0000u);
+            lo.w = (sa2[6] & 0xffffu) | (sa2[7] << 16); hi.w = (sa2[6] >> 16) | (sa2[7] & 0xffff0000u);
+            if (want_rowsum) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { rsum += __uint_as_float(sa2[e] << 16); rsum_hi += __uint_as_float(sa2[e] & 0xffff0000u); }
+            }
+            unsigned short* dst = As + (2 * (tid & 63)) * BPK + (tid >> 6) * 8;
+            *reinterpret_cast<uint4*>(dst) = lo;
+            *reinterpret_cast<uint4*>(dst + BPK) = hi;
+        } else if (A_KC) {
 #pragma unroll
             for (int p = 0; p < PA; ++p) {
                 uint2 w;
@@ -710,7 +782,14 @@ __global__ __launch_bounds__(256) void gemm_bfl_kernel(GemmArgs g) {
                 *reinterpret_cast<uint2*>(dst + e) = w;
             }
         }
-        if (B_KC) {
+        if (!B_KC && g.b16) {
+            uint2 lo, hi;
+            lo.x = (sb2[0] & 0xffffu) | (sb2[1] << 16); hi.x = (sb2[0] >> 16) | (sb2[1] & 0xffff0000u);
+            lo.y = (sb2[2] & 0xffffu) | (sb2[3] << 16); hi.y = (sb2[2] >> 16) | (sb2[3] & 0xffff0000u);
+            unsigned short* dst = Bs + (2 * (tid & 31)) * BPK + (tid >> 5) * 4;
+            *reinterpret_cast<uint2*>(dst) = lo;
+            *reinterpret_cast<uint2*>(dst + BPK) = hi;
+        } else if (B_KC) {
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
                 uint2 w;
@@ -756,8 +835,14 @@ __global__ __launch_bounds__(256) void gemm_bfl_kernel(GemmArgs g) {
     }
 
     if (want_rowsum) {
-        const int row = m0 + tid % LBM;
-        if (row < g.M) atomicAdd(g.C2 + row, rsum);
+        if (g.a16) {
+            const int row = m0 + 2 * (tid & 63);
+            if (row < g.M) atomicAdd(g.C2 + row, rsum);
+            if (row + 1 < g.M) atomicAdd(g.C2 + row + 1, rsum_hi);
+        } else {
+            const int row = m0 + tid % LBM;
+            if (row < g.M) atomicAdd(g.C2 + row, rsum);
+        }
     }
     if (KSPLIT) {                      // pair reduction: the k-half-1 waves hand their tile to their partners
         __shared__ float red[KSPLIT ? 2 * 16 * 64 : 1];    // 2 waves x 16 registers x 64 lanes
@@ -781,10 +866,10 @@ __global__ __launch_bounds__(256) void gemm_bfl_kernel(GemmArgs g) {
             const int row = m0 + wrow + acc_row(r, half);
             if (row >= g.M) continue;
             float v = acc[t][r] + bias;
-            if (EPI == EPI_BIAS_GELU) { g.Z[(long)row * g.ldz + col] = v; v = gelu_erf(v); }
-            if (EPI == EPI_MUL_GELU_GRAD) v *= gelu_erf_grad(g.G[(long)row * g.ldg + col]);
+            if (EPI == EPI_BIAS_GELU) { st1e(g.Z, (long)row * g.ldz + col, v, g.z16); v = gelu_erf(v); }
+            if (EPI == EPI_MUL_GELU_GRAD) v *= gelu_erf_grad(ld1e(g.G, (long)row * g.ldg + col, g.g16));
             if (EPI == EPI_ATOMIC) atomicAdd(g.C + (long)row * g.ldc + col, v);
-            else g.C[(long)row * g.ldc + col] = v;
+            else st1e(g.C, (long)row * g.ldc + col, v, g.c16);
         }
     }
 }
@@ -832,11 +917,11 @@ __global__ __launch_bounds__(256) void thin_dz1_kernel(GemmArgs g) {
             const float4 w = *reinterpret_cast<const float4*>(g.B + (long)k * g.b_rs + n);
             acc[0] += a * w.x; acc[1] += a * w.y; acc[2] += a * w.z; acc[3] += a * w.w;
         }
-        const float4 z = *reinterpret_cast<const float4*>(g.G + m * g.ldg + n);
+        const float4 z = ld4e(g.G, m * g.ldg + n, g.g16);
         float4 o;
         o.x = acc[0] * gelu_erf_grad(z.x); o.y = acc[1] * gelu_erf_grad(z.y);
         o.z = acc[2] * gelu_erf_grad(z.z); o.w = acc[3] * gelu_erf_grad(z.w);
-        *reinterpret_cast<float4*>(g.C + m * g.ldc + n) = o;
+        st4e(g.C, m * g.ldc + n, o, g.c16);
     }
 }
 
@@ -851,7 +936,7 @@ __global__ __launch_bounds__(256) void thin_fwd_kernel(GemmArgs g, int tpr) {
         const bool mv = m < g.M;
         float acc[THIN_MAX] = {0.0f, 0.0f, 0.0f, 0.0f};
         for (int k = q * 4; k < g.K; k += tpr * 4) {
-            const float4 h = mv ? *reinterpret_cast<const float4*>(g.A + m * g.a_rs + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 h = mv ? ld4e(g.A, m * g.a_rs + k, g.a16) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
             for (int n = 0; n < THIN_MAX; ++n) {
                 if (n >= g.N) break;
@@ -896,7 +981,7 @@ __global__ __launch_bounds__(256) void thin_dw_kernel(GemmArgs g, int slab) {
                 float d[8][THIN_MAX];
 #pragma unroll
                 for (int r = 0; r < 8; ++r) {
-                    x[r] = *reinterpret_cast<const float4*>(g.B + (k + (long)r * groups) * g.b_rs + n);
+                    x[r] = ld4e(g.B, (k + (long)r * groups) * g.b_rs + n, g.b16);
 #pragma unroll
                     for (int j = 0; j < THIN_MAX; ++j) d[r][j] = (j < g.M) ? g.A[(k + (long)r * groups) * g.a_cs + j] : 0.0f;
                 }
@@ -909,7 +994,7 @@ __global__ __launch_bounds__(256) void thin_dw_kernel(GemmArgs g, int slab) {
                     }
             }
             for (; k < k1; k += groups) {
-                const float4 x = *reinterpret_cast<const float4*>(g.B + k * g.b_rs + n);
+                const float4 x = ld4e(g.B, k * g.b_rs + n, g.b16);
 #pragma unroll
                 for (int j = 0; j < THIN_MAX; ++j) {
                     if (j >= g.M) break;
@@ -954,15 +1039,18 @@ bool try_launch_thin(const GemmArgs& g, hipStream_t s) {
     if (off) return false;
     static const long min_out = getenv("PIT_THIN_MIN") ? atol(getenv("PIT_THIN_MIN")) : (1L << 19);
     static const long min_rows = getenv("PIT_THIN_MIN_ROWS") ? atol(getenv("PIT_THIN_MIN_ROWS")) : 8192;
+    // bf16 storage flags: thin_dz1 reads G / writes C in either format, thin_fwd reads A, thin_dw reads B; anything else
+    // keeps the contraction off these kernels
     if (g.epi == EPI_MUL_GELU_GRAD && g.K <= THIN_MAX && g.a_cs == 1 && g.b_cs == 1 && g.N % 4 == 0 && g.b_rs % 4 == 0 &&
-        g.ldg % 4 == 0 && g.ldc % 4 == 0 && aligned16(g.B) && aligned16(g.G) && aligned16(g.C) &&
-        (long)g.M * g.N >= min_out) {
+        g.ldg % 4 == 0 && g.ldc % 4 == 0 && aligned16(g.B) && aligned16(g.G) && aligned16(g.C) && !g.a16 && !g.b16 && !g.z16 &&
+        (!(g.g16 || g.c16) || !g.a_gz) && (long)g.M * g.N >= min_out) {
         const long quads = (long)g.M * (g.N / 4);
         hipLaunchKernelGGL(thin_dz1_kernel, dim3((unsigned)std::min<long>((quads + 255) / 256, 8192)), dim3(256), 0, s, g);
         return true;
     }
     if ((g.epi == EPI_BIAS || g.epi == EPI_BIAS_GELU) && g.N <= THIN_MAX && g.a_cs == 1 && g.b_rs == 1 && g.K % 4 == 0 &&
-        g.a_rs % 4 == 0 && g.b_cs % 4 == 0 && aligned16(g.A) && aligned16(g.B) && !g.a_gz && (long)g.M * g.K >= min_out) {
+        g.a_rs % 4 == 0 && g.b_cs % 4 == 0 && aligned16(g.A) && aligned16(g.B) && !g.a_gz && !g.b16 && !g.c16 && !g.z16 && !g.g16 &&
+        (long)g.M * g.K >= min_out) {
         int tpr = 4;                                              // lanes per row: >= n2 (one output column each), <= 64
         while (tpr < 64 && tpr * 4 < g.K) tpr <<= 1;
         const long rows_per_wg = 4L * (64 / tpr);
@@ -971,7 +1059,7 @@ bool try_launch_thin(const GemmArgs& g, hipStream_t s) {
         return true;
     }
     if (g.epi == EPI_ATOMIC && g.M <= THIN_MAX && g.ones_col == g.N - 1 && g.a_rs == 1 && g.b_cs == 1 && (g.N - 1) % 4 == 0 &&
-        g.b_rs % 4 == 0 && aligned16(g.B) && !g.a_gz && g.K >= min_rows) {
+        g.b_rs % 4 == 0 && aligned16(g.B) && !g.a_gz && !g.a16 && !g.c16 && !g.z16 && !g.g16 && g.K >= min_rows) {
         // one workgroup per CU: every workgroup ends with one atomic per output element, and atomics on
         // one address serialise in L2 (~40 ns each) - 256 of them cost less than the pass over the rows
         const int slab = std::max(256, ((g.K + 255) / 256 + 15) / 16 * 16);
@@ -995,8 +1083,15 @@ bool try_launch_gemm_lds(GemmArgs g, hipStream_t s) {
     const bool b_kc = g.b_rs == 1 && g.b_cs % 4 == 0 && g.K % 4 == 0;
     const bool b_ic = g.b_cs == 1 && g.b_rs % 4 == 0 && n_real % 4 == 0;
     if (!aligned16(g.A) || !aligned16(g.B) || (g.a_gz && !aligned16(g.a_gz))) return false;
+    const bool io16 = g.a16 || g.b16 || g.c16 || g.z16 || g.g16;
+    if (io16) {                                      // bf16 storage: gemm_bfl_kernel only, and only the layouts it stages
+        if (!g.bf16 || getenv("PIT_BF16_LEGACY") || g.a_gz) return false;
+        if (g.a16 && !((a_kc && g.a_rs % 8 == 0 && g.K % 8 == 0) || (g.epi == EPI_ATOMIC && a_ic && g.a_cs % 2 == 0 && g.M % 2 == 0))) return false;
+        if (g.b16 && !(g.epi == EPI_ATOMIC && b_ic && g.b_rs % 2 == 0 && n_real % 2 == 0)) return false;
+        if ((g.c16 || g.z16 || g.g16) && g.epi == EPI_ATOMIC) return false;
+    }
     const long work = (long)g.M * g.N * g.K;
-    if (mode == 1 && (work < (1L << 27) || g.N < 48)) return false;
+    if (mode == 1 && !io16 && (work < (1L << 27) || g.N < 48)) return false;
     int kind = -1;                                   // which instantiation
     if (g.epi == EPI_ATOMIC) { if (a_ic && b_ic && !g.a_gz) kind = 4; }
     else if (a_kc && b_kc && !g.a_gz && (g.epi == EPI_BIAS || g.epi == EPI_BIAS_GELU)) kind = (g.epi == EPI_BIAS) ? 0 : 1;
@@ -1068,9 +1163,9 @@ bool vec_ok(const float* p, long i_stride, long k_stride) {
 struct GemmLaunch { int tn, nwaves; dim3 grid; };
 
 int prepare_gemm(GemmArgs& g, GemmLaunch& L, int force_tn = 0, int force_waves = 0) {
-    const unsigned long long ab = ((unsigned long long)(g.M - 1) * g.a_rs + (unsigned long long)(g.K - 1) * g.a_cs + 1) * 4ull;
+    const unsigned long long ab = ((unsigned long long)(g.M - 1) * g.a_rs + (unsigned long long)(g.K - 1) * g.a_cs + 1) * (g.a16 ? 2ull : 4ull);
     const int nb_cols = (g.ones_col >= 0) ? g.N - 1 : g.N;       // the ones column is virtual
-    const unsigned long long bb = ((unsigned long long)(g.K - 1) * g.b_rs + (unsigned long long)(std::max(nb_cols, 1) - 1) * g.b_cs + 1) * 4ull;
+    const unsigned long long bb = ((unsigned long long)(g.K - 1) * g.b_rs + (unsigned long long)(std::max(nb_cols, 1) - 1) * g.b_cs + 1) * (g.b16 ? 2ull : 4ull);
     if (ab > PIT_MAX_BUFFER_BYTES || bb > PIT_MAX_BUFFER_BYTES) return PIT_ERR_UNSUPPORTED;
     g.a_bytes = (unsigned)ab; g.b_bytes = (unsigned)bb;
     g.bf16 = (t_call_math == PIT_MATH_BF16);
@@ -1111,6 +1206,7 @@ int launch_gemm(GemmArgs g, hipStream_t s) {
     if (int rc = prepare_gemm(g, L)) return rc;
     if (try_launch_thin(g, s)) return 0;
     if (try_launch_gemm_lds(g, s)) return 0;
+    if (g.a16 || g.b16 || g.c16 || g.z16 || g.g16) return PIT_ERR_UNSUPPORTED;     // the register-direct kernel is fp32-storage only
     const int tn = L.tn;
     dim3 grid = L.grid, block(64 * L.nwaves);
     const size_t sm = (size_t)L.nwaves * tn * 16 * 64 * sizeof(float);
@@ -1131,7 +1227,8 @@ int launch_gemm(GemmArgs g, hipStream_t s) {
 // both weight-gradient reductions of an MLP in one launch (EPI_ATOMIC) when they are small;
 // big reductions keep their own launches (and their own tile shapes)
 int launch_gemm_pair_atomic(GemmArgs g1, GemmArgs g2, hipStream_t s) {
-    if ((long)g1.M * g1.N * g1.K + (long)g2.M * g2.N * g2.K > (1L << 28)) {
+    const bool io16 = g1.a16 || g1.b16 || g2.a16 || g2.b16;
+    if (io16 || (long)g1.M * g1.N * g1.K + (long)g2.M * g2.N * g2.K > (1L << 28)) {
         if (int rc = launch_gemm(g1, s)) return rc;
         return launch_gemm(g2, s);
     }
@@ -1151,7 +1248,8 @@ int launch_gemm_bwd_tail(GemmArgs gx, GemmArgs g1, GemmArgs g2, hipStream_t s) {
     static const bool off = getenv("PIT_NO_BWD_PAIR") != nullptr;
     const long work = (long)gx.M * gx.N * gx.K + (long)g1.M * g1.N * g1.K + (long)g2.M * g2.N * g2.K;
     // the dX GEMM runs with 8 k-splitting waves here: only worth it while it is itself tiny
-    if (off || work > (1L << 28) || (long)gx.M * gx.N * gx.K > (1L << 27)) {
+    const bool io16 = gx.a16 || gx.c16 || g1.a16 || g1.b16 || g2.a16 || g2.b16;
+    if (off || io16 || work > (1L << 28) || (long)gx.M * gx.N * gx.K > (1L << 27)) {
         if (int rc = launch_gemm(gx, s)) return rc;
         return launch_gemm_pair_atomic(g1, g2, s);
     }
@@ -1216,8 +1314,9 @@ int zero_param_grads(float* d_w1, float* d_b1, float* d_w2, float* d_b2, int n0,
 
 // dZ1 = (dZ2 W2) * gelu'(Z1), with dZ2 = dY * gelu'(Z2) formed in the A prologue and kept
 int launch_dz1(int rows, int n1, int n2, const float* w2, const float* z1, const float* z2, int out_gelu,
-               const float* d_y, long ld_dy, float* dz1, float* dz2buf, hipStream_t s) {
+               const float* d_y, long ld_dy, float* dz1, float* dz2buf, hipStream_t s, int save16 = 0) {
     GemmArgs g = blank();
+    g.g16 = g.c16 = save16;
     g.A = d_y; g.a_rs = ld_dy; g.a_cs = 1;
     if (out_gelu) {
         if (ld_dy != n2) return PIT_ERR_SIZE;     // prologue reads z2 with d_y's indexing
@@ -1255,6 +1354,16 @@ bool pit_detail::plan_dw_pair(const pit_mlp_params_job& j, int waves, DwPair* ou
     return true;
 }
 
+// include/pit_hip.h: the shapes whose forward / backward run entirely on the kernels that honour the PIT_IO_* flags (the
+// thin output-layer kernels + gemm_bfl_kernel)
+extern "C" int pit_mlp_bf16_io_supported(int rows, int n0, int n1, int n2, int out_gelu) {
+    static const bool off = getenv("PIT_NO_BF16_IO") != nullptr || getenv("PIT_NO_THIN_GEMM") != nullptr ||
+                            getenv("PIT_BF16_LEGACY") != nullptr || (getenv("PIT_LDS_GEMM") && atoi(getenv("PIT_LDS_GEMM")) == 0);
+    if (off || out_gelu) return 0;
+    if (n2 < 1 || n2 > THIN_MAX || n0 % 8 != 0 || n1 % 8 != 0 || n0 < 48 || n1 < 48) return 0;
+    return (long)rows * n1 >= (1L << 19) && rows >= 8192 && (long)rows * n1 * n0 >= (1L << 27);
+}
+
 extern "C" int pit_mlp_bwd_params_deferrable(int rows, int n0, int n1, int n2, int out_gelu, long ld_dy) {
     static const bool off = getenv("PIT_NO_DW_RIDER") != nullptr;
     return !off && (!out_gelu || ld_dy == n2) && mlp_bwd16_eligible(rows, n0, n1, n2);
@@ -1268,11 +1377,15 @@ extern "C" int pit_mlp_fwd(const float* x, long ldx, int rows, int n0, int n1, i
     if (out_gelu && !z2) return PIT_ERR_NULL;
     if (rows <= 0 || n0 <= 0 || n1 <= 0 || n2 <= 0 || ldx < n0 || ldy < n2) return PIT_ERR_SIZE;
     hipStream_t s = (hipStream_t)stream;
-    if (try_launch_mlp_fwd16(x, ldx, rows, n0, n1, n2, w1, b1, w2, b2, out_gelu, z1, h, z2, y, ldy, s)) {
+    const int x16 = (math_mode & PIT_IO_X_BF16) ? 1 : 0, save16 = (math_mode & PIT_IO_SAVE_BF16) ? 1 : 0;
+    if (math_mode & ~(0xff | PIT_IO_X_BF16 | PIT_IO_SAVE_BF16)) return PIT_ERR_UNSUPPORTED;
+    if ((x16 || save16) && !pit_mlp_bf16_io_supported(rows, n0, n1, n2, out_gelu)) return PIT_ERR_UNSUPPORTED;
+    if (!x16 && !save16 && try_launch_mlp_fwd16(x, ldx, rows, n0, n1, n2, w1, b1, w2, b2, out_gelu, z1, h, z2, y, ldy, s)) {
         PIT_CHECK_LAUNCH();
         return 0;
     }
     GemmArgs g = blank();
+    g.a16 = x16; g.z16 = g.c16 = save16;
     g.A = x; g.a_rs = ldx; g.a_cs = 1;
     g.B = w1; g.b_rs = 1; g.b_cs = n0;            // B(k,n) = w1[n][k]
     g.M = rows; g.N = n1; g.K = n0;
@@ -1280,6 +1393,7 @@ extern "C" int pit_mlp_fwd(const float* x, long ldx, int rows, int n0, int n1, i
     if (int rc = launch_gemm(g, s)) return rc;
     PIT_CHECK_LAUNCH();
     g = blank();
+    g.a16 = save16;
     g.A = h; g.a_rs = n1; g.a_cs = 1;
     g.B = w2; g.b_rs = 1; g.b_cs = n1;
     g.M = rows; g.N = n2; g.K = n1;
@@ -1298,17 +1412,22 @@ extern "C" int pit_mlp_bwd_data(int rows, int n0, int n1, int n2, const float* w
     if (out_gelu && !z2) return PIT_ERR_NULL;
     if (rows <= 0 || n0 <= 0 || n1 <= 0 || n2 <= 0) return PIT_ERR_SIZE;
     hipStream_t s = (hipStream_t)stream;
-    float* dz1 = scratch;                       // rows * n1
+    float* dz1 = scratch;                       // rows * n1 (bf16 elements with PIT_IO_SAVE_BF16)
     float* dz2buf = scratch + (long)rows * n1;  // rows * n2
-    if ((!out_gelu || ld_dy == n2) &&
+    const int save16 = (math_mode & PIT_IO_SAVE_BF16) ? 1 : 0, dx16 = (math_mode & PIT_IO_DX_BF16) ? 1 : 0;
+    if (math_mode & ~(0xff | PIT_IO_X_BF16 | PIT_IO_SAVE_BF16 | PIT_IO_DX_BF16)) return PIT_ERR_UNSUPPORTED;
+    if ((save16 || dx16) && !pit_mlp_bf16_io_supported(rows, n0, n1, n2, out_gelu)) return PIT_ERR_UNSUPPORTED;
+    if (!save16 && !dx16 && (!out_gelu || ld_dy == n2) &&
         try_launch_mlp_bwd16(rows, n0, n1, n2, w1, w2, z1, z2, out_gelu, d_y, ld_dy, d_x, ld_dx, dz1, dz2buf, s)) {
         PIT_CHECK_LAUNCH();
         return 0;
     }
-    if (int rc = launch_dz1(rows, n1, n2, w2, z1, z2, out_gelu, d_y, ld_dy, dz1, dz2buf, s)) return rc;
+    if (int rc = launch_dz1(rows, n1, n2, w2, z1, z2, out_gelu, d_y, ld_dy, dz1, dz2buf, s, save16)) return rc;
     PIT_CHECK_LAUNCH();
     if (d_x) {
-        if (int rc = launch_gemm(make_dx(dz1, w1, rows, n0, n1, d_x, ld_dx), s)) return rc;
+        GemmArgs gx = make_dx(dz1, w1, rows, n0, n1, d_x, ld_dx);
+        gx.a16 = save16; gx.c16 = dx16;
+        if (int rc = launch_gemm(gx, s)) return rc;
         PIT_CHECK_LAUNCH();
     }
     return 0;
@@ -1327,8 +1446,14 @@ extern "C" int pit_mlp_bwd_params(const float* x, long ldx, int rows, int n0, in
     const long ld_dz2 = out_gelu ? n2 : ld_dy;
     if (!accumulate)
         if (int rc = zero_param_grads(d_w1, d_b1, d_w2, d_b2, n0, n1, n2, s)) return rc;
-    if (int rc = launch_gemm_pair_atomic(make_dw2(dz2, ld_dz2, h, rows, n1, n2, d_w2, d_b2),
-                                         make_dw1(dz1, x, ldx, rows, n0, n1, d_w1, d_b1), s)) return rc;
+    const int x16 = (math_mode & PIT_IO_X_BF16) ? 1 : 0, save16 = (math_mode & PIT_IO_SAVE_BF16) ? 1 : 0;
+    if (math_mode & ~(0xff | PIT_IO_X_BF16 | PIT_IO_SAVE_BF16 | PIT_IO_DX_BF16)) return PIT_ERR_UNSUPPORTED;
+    if ((x16 || save16) && !pit_mlp_bf16_io_supported(rows, n0, n1, n2, out_gelu)) return PIT_ERR_UNSUPPORTED;
+    GemmArgs g2 = make_dw2(dz2, ld_dz2, h, rows, n1, n2, d_w2, d_b2);
+    GemmArgs g1 = make_dw1(dz1, x, ldx, rows, n0, n1, d_w1, d_b1);
+    g2.b16 = save16;                          // h
+    g1.a16 = save16; g1.b16 = x16;            // dZ1, x
+    if (int rc = launch_gemm_pair_atomic(g2, g1, s)) return rc;
     PIT_CHECK_LAUNCH();
     return 0;
 }
@@ -1342,6 +1467,11 @@ extern "C" int pit_mlp_bwd(const float* x, long ldx, int rows, int n0, int n1, i
     if (!x || !w1 || !w2 || !z1 || !h || !d_y || !d_w1 || !d_b1 || !d_w2 || !d_b2 || !scratch) return PIT_ERR_NULL;
     if (out_gelu && !z2) return PIT_ERR_NULL;
     if (rows <= 0 || n0 <= 0 || n1 <= 0 || n2 <= 0) return PIT_ERR_SIZE;
+    if (math_mode & ~0xff) {                   // bf16 storage: the two halves, one after the other
+        if (int rc = pit_mlp_bwd_data(rows, n0, n1, n2, w1, w2, z1, z2, out_gelu, d_y, ld_dy, d_x, ld_dx, scratch, math_mode, stream)) return rc;
+        return pit_mlp_bwd_params(x, ldx, rows, n0, n1, n2, h, out_gelu, d_y, ld_dy, d_w1, d_b1, d_w2, d_b2, accumulate, scratch,
+                                  math_mode, stream);
+    }
     hipStream_t s = (hipStream_t)stream;
     float* dz1 = scratch;
     float* dz2buf = scratch + (long)rows * n1;

@@ -46,7 +46,16 @@ struct AttArgs {
     unsigned dim_magic;                   // floor(2^32 / dim): column -> (sample, channel) without an integer division
     int no_fast_loads;                    // PIT_NO_FAST_LOADS=1: checked loads everywhere (tests the >= 2 GiB path)
     int coord_dims;                       // > 0: value channels [0, coord_dims) are the key coordinates themselves (sparse kernels)
+    int out16, dout16;                    // PIT_IO_OUT_BF16 / PIT_IO_DOUT_BF16: `out` / `d_out` hold bf16 elements (candidate-list kernels)
+    unsigned dout_elems;                  // elements of d_out (dout_load's out-of-range offset)
 };
+
+// one element of d_out through its buffer descriptor: fp32, or bf16 widened exactly; offsets in ELEMENTS, `oob` = any
+// element index beyond the tensor (the descriptor's range check then returns 0)
+__device__ __forceinline__ float dout_load(__amdgpu_buffer_rsrc_t r, unsigned elem_off, int is16) {
+    if (is16) return __uint_as_float((unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(r, (int)(elem_off * 2u), 0, 0) << 16);
+    return __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)(elem_off * 4u), 0, 0));
+}
 
 
 // Folded column index -> (sample, channel).  For batch-free meshes the batch is folded into the
@@ -1895,9 +1904,9 @@ __device__ __forceinline__ void sparse_rows_body(const AttArgs& a, const SparseA
             double part = 0.0;
 #pragma unroll
             for (int r = 0; r < CR; ++r) {
-                const unsigned off = (unsigned)(((long)cb[r] * a.dout_bstride + a.out_col0 + (long)(h0 + h) * a.dim + cd[r]) * 4) +
-                                     (unsigned)n * (unsigned)a.ld_dout * 4u;
-                part += (double)acc[h][r] * (double)buf_load(rdo, cvalid[r] ? off : a.dout_bytes);
+                const unsigned off = (unsigned)((long)cb[r] * a.dout_bstride + a.out_col0 + (long)(h0 + h) * a.dim + cd[r]) +
+                                     (unsigned)n * (unsigned)a.ld_dout;
+                part += (double)acc[h][r] * (double)dout_load(rdo, cvalid[r] ? off : a.dout_elems, a.dout16);
             }
             part = wave_sum_d(part);
             const int slot = (int)((bx + 131u * by + 977u * wave) & (a.nslots - 1));
@@ -1912,8 +1921,11 @@ __device__ __forceinline__ void sparse_rows_body(const AttArgs& a, const SparseA
         const float inv = rs > 0.0f ? 1.0f / rs : 0.0f;
 #pragma unroll
         for (int r = 0; r < CR; ++r)
-            if (cvalid[r] && active)
-                a.out[(long)cb[r] * a.out_bstride + (long)n * a.ld_out + a.out_col0 + (long)(h0 + h) * a.dim + cd[r]] = acc[h][r] * inv;
+            if (cvalid[r] && active) {
+                const long o = (long)cb[r] * a.out_bstride + (long)n * a.ld_out + a.out_col0 + (long)(h0 + h) * a.dim + cd[r];
+                if (a.out16) reinterpret_cast<unsigned short*>(a.out)[o] = f_to_bf16(acc[h][r] * inv);
+                else a.out[o] = acc[h][r] * inv;
+            }
         if (cblk == 0 && lane == 0 && active) {
             float4 st; st.x = T[h]; st.y = smin[h]; st.z = inv; st.w = qs * inv;
             *reinterpret_cast<float4*>(a.rowstat + (((long)mb * a.n_head + h0 + h) * a.n_out + n) * 4) = st;
@@ -1968,7 +1980,7 @@ __device__ __forceinline__ void sparse_cols_body(const AttArgs& a, const SparseA
     const __amdgpu_buffer_rsrc_t rmo = make_rsrc(a.mesh_out, mo_bytes);
     const __amdgpu_buffer_rsrc_t rmi = make_rsrc(a.mesh_in, mi_bytes);
     const __amdgpu_buffer_rsrc_t rdout = make_rsrc(a.d_out, a.dout_bytes);
-    const unsigned ldd4 = (unsigned)a.ld_dout * 4u;
+    const unsigned ldd4 = (unsigned)a.ld_dout;                 // (element units: dout_load scales by the element size)
     const float4 xi = load_point4(rmi, mi_bytes, kid, a.sdim, a.coords_used);
     unsigned doff[CR];
     bool cvalid[CR];
@@ -1979,7 +1991,7 @@ __device__ __forceinline__ void sparse_cols_body(const AttArgs& a, const SparseA
         cvalid[r] = col < a.ncols;
         const int cc = cvalid[r] ? col : 0;
         col_split(a, cc, mb, cb[r], cd[r]);
-        doff[r] = (unsigned)(((long)cb[r] * a.dout_bstride + a.out_col0 + cd[r]) * 4);
+        doff[r] = (unsigned)((long)cb[r] * a.dout_bstride + a.out_col0 + cd[r]);
     }
     float acc[CR];
 #pragma unroll
@@ -1990,7 +2002,7 @@ __device__ __forceinline__ void sparse_cols_body(const AttArgs& a, const SparseA
 
     for (int h = 0; h < a.n_head; ++h) {
         const float c = a.head_is_scale ? a.head[h] : head_scale_from_lmda(a.head[h]);
-        const unsigned hoff = (unsigned)h * (unsigned)a.dim * 4u;
+        const unsigned hoff = (unsigned)h * (unsigned)a.dim;
         for (int base = beg; base < end; base += 64) {
             const int e = base + lane;
             int nrow = (e < end) ? rrow[e] : -1;
@@ -2020,7 +2032,7 @@ __device__ __forceinline__ void sparse_cols_body(const AttArgs& a, const SparseA
                 for (int g = 0; g < G; ++g)
 #pragma unroll
                     for (int r = 0; r < CR; ++r)
-                        v[g][r] = buf_load(rdout, (ni[g] >= 0 && cvalid[r]) ? doff[r] + hoff + (unsigned)ni[g] * ldd4 : a.dout_bytes);
+                        v[g][r] = dout_load(rdout, (ni[g] >= 0 && cvalid[r]) ? doff[r] + hoff + (unsigned)ni[g] * ldd4 : a.dout_elems, a.dout16);
 #pragma unroll
                 for (int g = 0; g < G; ++g)
 #pragma unroll
@@ -2030,8 +2042,8 @@ __device__ __forceinline__ void sparse_cols_body(const AttArgs& a, const SparseA
     }
 #pragma unroll
     for (int r = 0; r < CR; ++r) {
-        const unsigned roff = (unsigned)(((long)cb[r] * a.dout_bstride + cd[r]) * 4) + (unsigned)j * ldd4;
-        const float res = buf_load(rdout, (a.add_residual && cvalid[r]) ? roff : a.dout_bytes);
+        const unsigned roff = (unsigned)((long)cb[r] * a.dout_bstride + cd[r]) + (unsigned)j * ldd4;
+        const float res = dout_load(rdout, (a.add_residual && cvalid[r]) ? roff : a.dout_elems, a.dout16);
         // (coordinate channels carry no gradient: the meshes are data; d_values holds the dim - coord_dims others)
         if (cvalid[r] && cd[r] >= a.coord_dims)
             a.d_values[(long)cb[r] * a.dvalues_bstride + (long)j * a.ld_dvalues + (cd[r] - a.coord_dims)] = acc[r] + res;
@@ -2085,7 +2097,8 @@ __device__ __forceinline__ void sparse_overflow_body(const AttArgs& a, const Spa
                     int bb, dd;
                     col_split(a, col, mb, bb, dd);
                     if (dd < a.coord_dims) continue;
-                    const float g = a.d_out[(long)bb * a.dout_bstride + (long)n * a.ld_dout + a.out_col0 + (long)h * a.dim + dd];
+                    const long go = (long)bb * a.dout_bstride + (long)n * a.ld_dout + a.out_col0 + (long)h * a.dim + dd;
+                    const float g = a.dout16 ? bf16_to_f(reinterpret_cast<const unsigned short*>(a.d_out)[go]) : a.d_out[go];
                     atomicAdd(a.d_values + (long)bb * a.dvalues_bstride + (long)jj * a.ld_dvalues + (dd - a.coord_dims), pv * g);
                 }
             }
@@ -2305,6 +2318,9 @@ extern "C" int pit_posatt_fwd(const float* mesh_out, const float* mesh_in, int m
     a.stats = stats; a.rank_w = rank_w; a.masked = masked;
     a.out = out; a.ld_out = ld_out; a.out_bstride = out_bstride; a.out_col0 = out_col0; a.copy_inputs = copy_inputs;
     a.rowstat = rowstat; a.scale_out = scale_out;
+    if (math_mode & ~(0xff | PIT_IO_OUT_BF16)) return PIT_ERR_UNSUPPORTED;
+    a.out16 = (math_mode & PIT_IO_OUT_BF16) ? 1 : 0;
+    if (a.out16 && (copy_inputs || !(nbr_idx && nbr_cnt && masked))) return PIT_ERR_UNSUPPORTED;   // candidate-list kernels only
     if (nbr_idx && nbr_cnt && masked) {
         SparseArgs sp{nbr_idx, nbr_cnt, nbr_cap, nullptr, nullptr, 0};
         if (!head_is_scale && scale_out && (long)mesh_batch * n_out > 8192) {
@@ -2358,14 +2374,18 @@ extern "C" int pit_posatt_bwd(const float* mesh_out, const float* mesh_in, int m
     a.d_out = d_out; a.ld_dout = ld_dout; a.dout_bstride = dout_bstride; a.out_col0 = out_col0;
     a.d_values = d_values; a.ld_dvalues = ld_dvalues; a.dvalues_bstride = dvalues_bstride;
     a.add_residual = add_residual; a.dscale_acc = workspace;
+    if (math_mode & ~(0xff | PIT_IO_DOUT_BF16)) return PIT_ERR_UNSUPPORTED;
+    a.dout16 = (math_mode & PIT_IO_DOUT_BF16) ? 1 : 0;
     {
         const int width = out_col0 + n_head * dim;
-        const unsigned long long db = ((unsigned long long)(batch - 1) * dout_bstride +
-                                       (unsigned long long)(n_out - 1) * ld_dout + width) * 4ull;
+        const unsigned long long de = (unsigned long long)(batch - 1) * dout_bstride + (unsigned long long)(n_out - 1) * ld_dout + width;
+        const unsigned long long db = de * (a.dout16 ? 2ull : 4ull);
         if (db > PIT_MAX_BUFFER_BYTES) return PIT_ERR_UNSUPPORTED;
         a.dout_bytes = (unsigned)db;
+        a.dout_elems = (unsigned)de;
     }
     const bool sparse = masked && nbr_idx && nbr_cnt;
+    if (a.dout16 && (!sparse || add_residual || (d_values && !(rev_ptr && rev_row)))) return PIT_ERR_UNSUPPORTED;   // candidate-list kernels only
     SparseArgs sp{nbr_idx, nbr_cnt, nbr_cap, rev_ptr, rev_row, (long)n_out * nbr_cap};
     if (d_head) {
         a.d_head = d_head; a.dhead_src = head; a.dhead_is_scale = head_is_scale;

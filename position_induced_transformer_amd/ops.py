@@ -293,6 +293,25 @@ def _grad_slot(param) -> Optional[torch.Tensor]:
     return g
 
 
+# bf16 STORAGE flags of the `math_mode` argument (include/pit_hip.h, PIT_IO_*)
+IO_X_BF16, IO_SAVE_BF16, IO_DX_BF16, IO_OUT_BF16, IO_DOUT_BF16 = 0x100, 0x200, 0x400, 0x800, 0x1000
+# bf16 mode: the decoder tail (up-projection output, the decoder MLP's saved activations, their gradients) is kept in
+# memory as bf16 when the shapes take the kernels that implement it (pit.decoder asks); PIT_BF16_STORAGE=0: fp32 tensors
+BF16_STORAGE = os.environ.get("PIT_BF16_STORAGE", "1") != "0"
+
+
+def mlp_bf16_io_supported(rows: int, n0: int, n1: int, n2: int) -> bool:
+    return BF16_STORAGE and get_math_mode() == "bf16" and bool(_lib.lib().pit_mlp_bf16_io_supported(rows, n0, n1, n2, 0))
+
+
+def _need_gpu_bf16_ok(t) -> None:
+    if t is not None and not t.is_cuda:
+        raise RuntimeError("position_induced_transformer_amd: the PiT hot path runs on the HIP device only; "
+                           "got a CPU tensor (move the model and its inputs to 'cuda')")
+    if t is not None and t.dtype not in (torch.float32, torch.bfloat16):
+        raise RuntimeError(f"position_induced_transformer_amd: fp32 (or bf16-stored) tensor expected, got {t.dtype}")
+
+
 def _need_gpu(*tensors) -> None:
     for t in tensors:
         if t is not None and not t.is_cuda:
@@ -423,9 +442,10 @@ class _PosAtt(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, values, head, plan: MeshPlan, n_head: int, concat: bool, head_is_scale: bool,
-                head_param=None, out_slot=None, coord_dims: int = 0, scale_in=None):
+                head_param=None, out_slot=None, coord_dims: int = 0, scale_in=None, out_bf16: bool = False):
         _need_gpu(values, head)
         ctx.math = _math_code()
+        out_bf16 = bool(out_bf16 and not concat and plan.nbr_idx is not None and ctx.math == MATH_MODES["bf16"])
         ctx.coord_dims = int(coord_dims)
         # (the concat buffer arrives in a one-element list, not as a tensor argument: a tensor that is both an
         # input and the returned output would be re-materialised by autograd with a full copy)
@@ -447,7 +467,8 @@ class _PosAtt(torch.autograd.Function):
             # buffer: the kernel only adds the head columns - no copy of the inputs (torch.cat of pit.py:44)
             out, copy_inputs = out_buf, 0
         else:
-            out = torch.empty((b, plan.n_out, width), device=values.device, dtype=torch.float32)
+            out = torch.empty((b, plan.n_out, width), device=values.device,
+                              dtype=torch.bfloat16 if out_bf16 else torch.float32)
         rowstat = torch.empty((plan.mesh_batch, n_head, plan.n_out, 4), device=values.device, dtype=torch.float32)
         scale = torch.empty((n_head,), device=values.device, dtype=torch.float32)
         # route 'host': `head` is lmda (autograd's input, the chain rule of the backward) but the kernels are
@@ -461,7 +482,8 @@ class _PosAtt(torch.autograd.Function):
             _lib.ptr(plan.stats), plan.rank_w, 1 if plan.masked else 0, 1 if plan.self_attn else 0,
             out.data_ptr(), out.stride(1), out.stride(0), d if concat else 0, copy_inputs,
             rowstat.data_ptr(), scale.data_ptr(),
-            _lib.ptr(plan.nbr_idx), _lib.ptr(plan.nbr_cnt), plan.nbr_cap, ctx.coord_dims, ctx.math, _lib.stream_ptr())
+            _lib.ptr(plan.nbr_idx), _lib.ptr(plan.nbr_cnt), plan.nbr_cap, ctx.coord_dims,
+            ctx.math | (IO_OUT_BF16 if out_bf16 else 0), _lib.stream_ptr())
         _lib.check(rc, "pit_posatt_fwd")
         ctx.plan, ctx.n_head, ctx.concat, ctx.head_is_scale = plan, n_head, concat, head_is_scale
         ctx.head_param = head_param
@@ -475,6 +497,8 @@ class _PosAtt(torch.autograd.Function):
         b, j, dv = values.shape
         d = dv + ctx.coord_dims
         d_out = _row_view(d_out)
+        _need_gpu_bf16_ok(d_out)
+        io = IO_DOUT_BF16 if d_out.dtype == torch.bfloat16 else 0
         need_v, need_h = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         d_values = torch.empty((b, j, dv), device=values.device, dtype=torch.float32) if need_v else None
         slot = _grad_slot(ctx.head_param) if need_h else None
@@ -505,7 +529,7 @@ class _PosAtt(torch.autograd.Function):
                 _lib.ptr(plan.nbr_idx), _lib.ptr(plan.nbr_cnt), plan.nbr_cap, plan.lists_complete(),
                 _lib.ptr(plan.rev_ptr), _lib.ptr(plan.rev_row),
                 ctypes.cast(ctypes.pointer(job[0]), ctypes.c_void_p) if job is not None else None,
-                ctx.coord_dims, ctx.math, stream_ptr)
+                ctx.coord_dims, ctx.math | io, stream_ptr)
             _lib.check(rc, "pit_posatt_bwd")
 
         if OVERLAP_BACKWARD and slot is not None:
@@ -519,7 +543,7 @@ class _PosAtt(torch.autograd.Function):
             launch(d_values, d_head, _lib.stream_ptr(), rider)
         if defer:
             _defer_head_finish(work, d_head, head, scale, n_head, 1 | (4 if ctx.head_is_scale else 0))
-        return d_values, (None if slot is not None else d_head), None, None, None, None, None, None, None, None
+        return d_values, (None if slot is not None else d_head), None, None, None, None, None, None, None, None, None
 
 
 # Where the head scale c = tan(0.25*pi*(1-1e-7)*(1+sin(lmda))) (pit.py:48) is evaluated.
@@ -665,7 +689,7 @@ def materialize_coords(func: torch.Tensor) -> torch.Tensor:
 
 @torch.compiler.disable
 def posatt_apply(values: torch.Tensor, lmda: torch.Tensor, plan: MeshPlan, n_head: int, concat: bool,
-                 head_is_scale: bool = False, coord_dims: int = 0) -> torch.Tensor:
+                 head_is_scale: bool = False, coord_dims: int = 0, out_bf16: bool = False) -> torch.Tensor:
     """out[b,n,h*D+d] = sum_j softmax_j(-c_h m[n,j] | quantile mask)[n,j] * values[b,j,d]
     (pit.py:46-57); with ``concat`` the inputs are prepended (pit.py:44).  ``lmda`` is the
     (H,1,1) parameter, or the scale c itself when ``head_is_scale`` (tests inject it).
@@ -676,7 +700,8 @@ def posatt_apply(values: torch.Tensor, lmda: torch.Tensor, plan: MeshPlan, n_hea
     slot = [out_buf] if out_buf is not None else None
     param = lmda if isinstance(lmda, torch.nn.Parameter) else None
     c = host_head_scale(lmda) if (not head_is_scale and get_head_scale_route() == "host") else None
-    return _PosAtt.apply(values, lmda.reshape(-1), plan, n_head, concat, head_is_scale, param, slot, coord_dims, c)
+    return _PosAtt.apply(values, lmda.reshape(-1), plan, n_head, concat, head_is_scale, param, slot, coord_dims, c,
+                         out_bf16)
 
 
 class _Mlp(torch.autograd.Function):
@@ -684,20 +709,25 @@ class _Mlp(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w1, b1, w2, b2, out_gelu: bool, concat_heads: int = 0):
-        _need_gpu(x, w1, b1, w2, b2)
+        _need_gpu(w1, b1, w2, b2)
+        _need_gpu_bf16_ok(x)
         shape = x.shape
         n0 = shape[-1]
+        n1, n2 = w1.shape[0], w2.shape[0]
+        x16 = x.dtype == torch.bfloat16
+        if x16 and (out_gelu or concat_heads > 0 or not mlp_bf16_io_supported(x.numel() // n0, n0, n1, n2)):
+            x, x16 = x.float(), False              # (a bf16-stored input this shape's kernels do not read: widen once)
         x2 = x.reshape(-1, n0)
         if x2.stride(1) != 1 or x2.stride(0) < n0:
             x2 = x2.contiguous()
         rows = x2.shape[0]
-        n1, n2 = w1.shape[0], w2.shape[0]
         if w1.shape[1] != n0 or w2.shape[1] != n1:
             raise RuntimeError(f"mlp shapes do not chain: x[...,{n0}], w1{tuple(w1.shape)}, w2{tuple(w2.shape)}")
         w1c, b1c, w2c, b2c = (t.detach().contiguous() for t in (w1, b1, w2, b2))
         dev = x.device
-        z1 = torch.empty((rows, n1), device=dev, dtype=torch.float32)
-        h = torch.empty((rows, n1), device=dev, dtype=torch.float32)
+        save_dt = torch.bfloat16 if x16 else torch.float32      # decoder tail in bf16 storage: Z1 / H saved as bf16 too
+        z1 = torch.empty((rows, n1), device=dev, dtype=save_dt)
+        h = torch.empty((rows, n1), device=dev, dtype=save_dt)
         z2 = torch.empty((rows, n2), device=dev, dtype=torch.float32) if out_gelu else None
         buf = None
         if concat_heads > 0:             # y goes straight into columns [0, n2) of the next self-attention's concat buffer
@@ -705,10 +735,11 @@ class _Mlp(torch.autograd.Function):
             y = buf[:, :n2]
         else:
             y = torch.empty((rows, n2), device=dev, dtype=torch.float32)
-        ctx.math = _math_code()
+        ctx.math = _math_code() | ((IO_X_BF16 | IO_SAVE_BF16 | IO_DX_BF16) if x16 else 0)
+        ctx.x16 = x16
         rc = _lib.lib().pit_mlp_fwd(x2.data_ptr(), x2.stride(0), rows, n0, n1, n2, w1c.data_ptr(), b1c.data_ptr(),
                                     w2c.data_ptr(), b2c.data_ptr(), 1 if out_gelu else 0, z1.data_ptr(),
-                                    h.data_ptr(), _lib.ptr(z2), y.data_ptr(), y.stride(0), ctx.math,
+                                    h.data_ptr(), _lib.ptr(z2), y.data_ptr(), y.stride(0), ctx.math & ~IO_DX_BF16,
                                     _lib.stream_ptr())
         _lib.check(rc, "pit_mlp_fwd")
         ctx.out_gelu, ctx.dims, ctx.in_shape = out_gelu, (rows, n0, n1, n2), shape
@@ -733,7 +764,7 @@ class _Mlp(torch.autograd.Function):
         if d_y2.stride(1) != 1 or d_y2.stride(0) < n2:
             d_y2 = d_y2.contiguous()
         need_x = ctx.needs_input_grad[0]
-        d_x = torch.empty((rows, n0), device=dev, dtype=torch.float32) if need_x else None
+        d_x = torch.empty((rows, n0), device=dev, dtype=torch.bfloat16 if ctx.x16 else torch.float32) if need_x else None
         slots = [_grad_slot(p) if isinstance(p, torch.nn.Parameter) else None for p in ctx.params]
         inplace = all(s is not None for s in slots) and all(ctx.needs_input_grad[1:5])
         if inplace:

@@ -145,10 +145,12 @@ class posatt(nn.Module):
         plan = self._plan(mesh, mesh, True)
         return ops.posatt_apply(inputs, self.lmda, plan, self.n_head, concat=True)
 
-    def _cross(self, mesh_out, mesh_in, inputs):
+    def _cross(self, mesh_out, mesh_in, inputs, out_bf16: bool = False):
         if self._overridden():
             return self._composed(mesh_out, mesh_in, inputs)
         plan = self._plan(mesh_out, mesh_in, False)
+        if out_bf16:                             # (pit.decoder, bf16 mode: the result feeds a kaiming_mlp that reads bf16)
+            return ops.posatt_apply(ops.materialize_coords(inputs), self.lmda, plan, self.n_head, concat=False, out_bf16=True)
         coords = getattr(inputs, "_pit_coords", None)
         if coords is not None:                   # encoder input tagged by ops.tag_coords: cat((mesh_in, func), -1) not yet built
             kd = mesh_in.shape[-1]
@@ -187,8 +189,8 @@ class posatt(nn.Module):
 class posatt_cross(posatt):
     """Cross attention mesh_in -> mesh_out on per-sample meshes (pit.py:59-71)."""
 
-    def forward(self, mesh_out, mesh_in, inputs):
-        return self._cross(mesh_out, mesh_in, inputs)
+    def forward(self, mesh_out, mesh_in, inputs, out_bf16: bool = False):
+        return self._cross(mesh_out, mesh_in, inputs, out_bf16)
 
 
 class posatt_fixed(posatt):
@@ -197,8 +199,8 @@ class posatt_fixed(posatt):
 
 
 class posatt_cross_fixed(posatt_fixed):
-    def forward(self, mesh_out, mesh_in, inputs):       # pit.py:151-159
-        return self._cross(mesh_out, mesh_in, inputs)
+    def forward(self, mesh_out, mesh_in, inputs, out_bf16: bool = False):       # pit.py:151-159
+        return self._cross(mesh_out, mesh_in, inputs, out_bf16)
 
 
 class posatt_periodic1d(posatt_fixed):
@@ -207,8 +209,8 @@ class posatt_periodic1d(posatt_fixed):
 
 
 class posatt_cross_periodic1d(posatt_periodic1d):
-    def forward(self, mesh_out, mesh_in, inputs):       # pit.py:207-215
-        return self._cross(mesh_out, mesh_in, inputs)
+    def forward(self, mesh_out, mesh_in, inputs, out_bf16: bool = False):       # pit.py:207-215
+        return self._cross(mesh_out, mesh_in, inputs, out_bf16)
 
 
 class posatt_periodic2d(posatt_fixed):
@@ -217,8 +219,11 @@ class posatt_periodic2d(posatt_fixed):
 
 
 class posatt_cross_periodic2d(posatt_periodic2d):
-    def forward(self, mesh_out, mesh_in, inputs):       # pit.py:265-273
-        return self._cross(mesh_out, mesh_in, inputs)
+    def forward(self, mesh_out, mesh_in, inputs, out_bf16: bool = False):       # pit.py:265-273
+        return self._cross(mesh_out, mesh_in, inputs, out_bf16)
+
+
+_OWN_CROSS_FORWARDS = tuple(c.forward for c in (posatt_cross, posatt_cross_fixed, posatt_cross_periodic1d, posatt_cross_periodic2d))
 
 
 class pit(nn.Module):
@@ -318,6 +323,15 @@ class pit(nn.Module):
         return func_ltt
 
     def decoder(self, mesh_ltt, func_ltt, mesh_out):
+        # bf16 mode (BASELINE configs 3 and 5): the up-projection's output - the largest tensor of the model, rows x H*hid -
+        # and with it the decoder MLP's saved activations and their gradients are kept in memory as bf16 when the
+        # decoder MLP's shape runs on the kernels that read them (ops.mlp_bf16_io_supported); fp32 accumulation throughout
+        de, up = self.de, self.up
+        if type(de) is kaiming_mlp and isinstance(up, posatt) and type(up).forward in _OWN_CROSS_FORWARDS and func_ltt.is_cuda \
+                and ops.get_math_mode() == "bf16" and torch.is_tensor(mesh_out) and not up._forward_hooks and not de._forward_hooks:
+            rows = func_ltt.shape[0] * mesh_out.shape[-2]
+            if ops.mlp_bf16_io_supported(rows, de.mlp1.in_features, de.mlp1.out_features, de.mlp2.out_features):
+                return de(up(mesh_out, mesh_ltt, func_ltt, out_bf16=True))
         func_out = self.up(mesh_out, mesh_ltt, func_ltt)
         return self.de(func_out)
 
