@@ -205,7 +205,7 @@ def _count_bf16_outputs(ops):
     return calls, orig, spy
 
 
-@pytest.mark.parametrize("rows,n0,n1,n2", [(8192, 512, 256, 1), (22542, 128, 128, 4), (9001, 64, 96, 3)])
+@pytest.mark.parametrize("rows,n0,n1,n2", [(8192, 512, 256, 1), (22542, 128, 128, 4), (40001, 64, 96, 3)])
 def test_mlp_bf16_storage_matches_fp32_storage(rows, n0, n1, n2, bf16):
     """The decoder MLP with its input, saved Z1 / H, the dZ1 scratch and d_x kept in memory as bf16 (PIT_IO_* flags:
     gemm_bfl_kernel reading / writing bf16, the thin output-layer kernels) against the same bf16-mode contraction on
