@@ -29,6 +29,10 @@ struct GemmArgs {
     // bf16 STORAGE (PIT_IO_*; gemm_bfl_kernel and the thin kernels only): the tensor behind A / B / C / Z / G holds bf16
     // elements; strides stay in elements
     int a16, b16, c16, z16, g16;
+    // XCD-aware tile order of the LDS-staged kernels (non-atomic kinds): a 1-D grid whose workgroup id -> (column block,
+    // row tile) map puts all column blocks of a row tile on ONE XCD (ids are dealt round-robin to the 8 XCDs), so the A
+    // rows are fetched from HBM once per tile instead of once per column block; 0 = the plain (x, y) grid
+    int remap_gx, remap_gy;
 };
 
 // both weight-gradient reductions of one MLP (dW2|db2 and dW1|db1), prepared for gemm_rd_body<1, EPI_ATOMIC>:

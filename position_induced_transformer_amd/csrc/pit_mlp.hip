@@ -454,7 +454,14 @@ __global__ __launch_bounds__(256) void gemm_lds_kernel(GemmArgs g) {
     __shared__ __attribute__((aligned(16))) float Bs[B_KC ? LBN * LPK : LBK * LPN];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, l31 = lane & 31;
-    const int m0 = blockIdx.y * LBM, n0 = blockIdx.x * LBN;
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (g.remap_gx) {                  // XCD-aware order (GemmArgs::remap_gx)
+        const int xcd = blockIdx.x & 7, t = blockIdx.x >> 3;
+        bx = t % g.remap_gx;
+        by = (t / g.remap_gx) * 8 + xcd;
+        if (by >= g.remap_gy) return;
+    }
+    const int m0 = by * LBM, n0 = bx * LBN;
     const int wrow = (LBM == 128) ? wave * 32 : (LBM == 64 ? (wave & 1) * 32 : 0);   // this wave's rows / first column in the tile
     const int wcol = (LBM == 128) ? 0 : (LBM == 64 ? (wave >> 1) * 32 : (wave & 1) * 32);
     const int ksel = KSPLIT ? (wave >> 1) : 0;
@@ -518,7 +525,7 @@ __global__ __launch_bounds__(256) void gemm_lds_kernel(GemmArgs g) {
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
     // the bias gradient (the "ones column" of the register-direct kernel) is the row sum of the A
     // operand: accumulated from the fragments by the first column block, no extra MFMA tile
-    const bool want_rowsum = (EPI == EPI_ATOMIC) && g.ones_col >= 0 && blockIdx.x == 0 && wcol == 0;
+    const bool want_rowsum = (EPI == EPI_ATOMIC) && g.ones_col >= 0 && bx == 0 && wcol == 0;
     float rsum = 0.0f;
 
     gload(kbeg);
@@ -647,8 +654,11 @@ __device__ __forceinline__ void st1e(float* base, long idx, float v, int is16) {
     if (is16) reinterpret_cast<unsigned short*>(base)[idx] = f_to_bf16(v); else base[idx] = v;
 }
 
-template <int LBM, bool A_KC, bool B_KC, int EPI>
+// IO16: the instantiation that honours the bf16-STORAGE flags of GemmArgs (a16 .. g16); the plain one carries none of that
+// code (as runtime-only branches the extra staging registers cost the fp32-storage launches 8-26 %)
+template <int LBM, bool A_KC, bool B_KC, int EPI, bool IO16 = false>
 __global__ __launch_bounds__(256) void gemm_bfl_kernel(GemmArgs g) {
+    const bool a16 = IO16 && g.a16, b16 = IO16 && g.b16, c16 = IO16 && g.c16, z16 = IO16 && g.z16, g16 = IO16 && g.g16;
     constexpr int TN = (LBM == 128) ? 2 : 1;
     constexpr int PA = LBM / 32;                  // KC staging passes for A (4 floats per thread and pass)
     constexpr int KPA = LBK / (256 / LBM);        // IC staging: k per thread for A (lane = row)
@@ -658,7 +668,14 @@ __global__ __launch_bounds__(256) void gemm_bfl_kernel(GemmArgs g) {
     __shared__ __attribute__((aligned(16))) unsigned short Bs[LBN * BPK];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, l31 = lane & 31;
-    const int m0 = blockIdx.y * LBM, n0 = blockIdx.x * LBN;
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (g.remap_gx) {                  // XCD-aware order (GemmArgs::remap_gx)
+        const int xcd = blockIdx.x & 7, t = blockIdx.x >> 3;
+        bx = t % g.remap_gx;
+        by = (t / g.remap_gx) * 8 + xcd;
+        if (by >= g.remap_gy) return;
+    }
+    const int m0 = by * LBM, n0 = bx * LBN;
     const int wrow = (LBM == 128) ? wave * 32 : (LBM == 64 ? (wave & 1) * 32 : 0);
     const int wcol = (LBM == 128) ? 0 : (LBM == 64 ? (wave >> 1) * 32 : (wave & 1) * 32);
     const int ksel = KSPLIT ? (wave >> 1) : 0;
@@ -678,10 +695,10 @@ __global__ __launch_bounds__(256) void gemm_bfl_kernel(GemmArgs g) {
     unsigned sa2[8], sb2[4];
     // the bias gradient (virtual ones column) = row sums of the A operand, exact fp32 from the staging
     // registers of the first column block (A is i-contiguous in every row-reducing GEMM)
-    const bool want_rowsum = (EPI == EPI_ATOMIC) && !A_KC && g.ones_col >= 0 && blockIdx.x == 0;
+    const bool want_rowsum = (EPI == EPI_ATOMIC) && !A_KC && g.ones_col >= 0 && bx == 0;
     float rsum = 0.0f, rsum_hi = 0.0f;
     auto gload = [&](int kc) {
-        if (A_KC && g.a16) {
+        if (A_KC && a16) {
 #pragma unroll
             for (int p = 0; p < PA16; ++p) {
                 const int rl = p * 64 + (tid >> 2), row = m0 + rl, k = kc + (tid & 3) * 8;
@@ -689,7 +706,7 @@ __global__ __launch_bounds__(256) void gemm_bfl_kernel(GemmArgs g) {
                 const i32x4 q = __builtin_amdgcn_raw_buffer_load_b128(ra, ok ? (int)(((unsigned)row * (unsigned)g.a_rs + (unsigned)k) * 2u) : (int)g.a_bytes, 0, 0);
                 sa16[p] = make_uint4((unsigned)q.x, (unsigned)q.y, (unsigned)q.z, (unsigned)q.w);
             }
-        } else if (!A_KC && g.a16) {
+        } else if (!A_KC && a16) {
             const int m = m0 + 2 * (tid & 63), k0 = kc + (tid >> 6) * 8;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -714,7 +731,7 @@ __global__ __launch_bounds__(256) void gemm_bfl_kernel(GemmArgs g) {
                 sa[e] = buf_load(ra, ok ? ((unsigned)(k0 + e) * (unsigned)g.a_cs + (unsigned)m) * 4u : g.a_bytes);
             }
         }
-        if (!B_KC && g.b16) {
+        if (!B_KC && b16) {
             const int n = n0 + 2 * (tid & 31), k0 = kc + (tid >> 5) * 4;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -741,13 +758,13 @@ __global__ __launch_bounds__(256) void gemm_bfl_kernel(GemmArgs g) {
         }
     };
     auto lstore = [&]() {
-        if (A_KC && g.a16) {
+        if (A_KC && a16) {
 #pragma unroll
             for (int p = 0; p < PA16; ++p) {
                 const int rl = p * 64 + (tid >> 2);
                 if (rl < LBM) *reinterpret_cast<uint4*>(As + rl * BPK + (tid & 3) * 8) = sa16[p];
             }
-        } else if (!A_KC && g.a16) {
+        } else if (!A_KC && a16) {
             uint4 lo, hi;
             lo.x = (sa2[0] & 0xffffu) | (sa2[1] << 16); hi.x = (sa2[0] >> 16) | (sa2[1] & 0xffff0000u);
             lo.y = (sa2[2] & 0xffffu) | (sa2[3] << 16); hi.y = (sa2[2] >> 16) | (sa2[3] & 0xffff0000u);
@@ -782,7 +799,7 @@ __global__ __launch_bounds__(256) void gemm_bfl_kernel(GemmArgs g) {
                 *reinterpret_cast<uint2*>(dst + e) = w;
             }
         }
-        if (!B_KC && g.b16) {
+        if (!B_KC && b16) {
             uint2 lo, hi;
             lo.x = (sb2[0] & 0xffffu) | (sb2[1] << 16); hi.x = (sb2[0] >> 16) | (sb2[1] & 0xffff0000u);
             lo.y = (sb2[2] & 0xffffu) | (sb2[3] << 16); hi.y = (sb2[2] >> 16) | (sb2[3] & 0xffff0000u);
@@ -835,7 +852,7 @@ __global__ __launch_bounds__(256) void gemm_bfl_kernel(GemmArgs g) {
     }
 
     if (want_rowsum) {
-        if (g.a16) {
+        if (a16) {
             const int row = m0 + 2 * (tid & 63);
             if (row < g.M) atomicAdd(g.C2 + row, rsum);
             if (row + 1 < g.M) atomicAdd(g.C2 + row + 1, rsum_hi);
@@ -866,10 +883,10 @@ __global__ __launch_bounds__(256) void gemm_bfl_kernel(GemmArgs g) {
             const int row = m0 + wrow + acc_row(r, half);
             if (row >= g.M) continue;
             float v = acc[t][r] + bias;
-            if (EPI == EPI_BIAS_GELU) { st1e(g.Z, (long)row * g.ldz + col, v, g.z16); v = gelu_erf(v); }
-            if (EPI == EPI_MUL_GELU_GRAD) v *= gelu_erf_grad(ld1e(g.G, (long)row * g.ldg + col, g.g16));
+            if (EPI == EPI_BIAS_GELU) { st1e(g.Z, (long)row * g.ldz + col, v, z16); v = gelu_erf(v); }
+            if (EPI == EPI_MUL_GELU_GRAD) v *= gelu_erf_grad(ld1e(g.G, (long)row * g.ldg + col, g16));
             if (EPI == EPI_ATOMIC) atomicAdd(g.C + (long)row * g.ldc + col, v);
-            else st1e(g.C, (long)row * g.ldc + col, v, g.c16);
+            else st1e(g.C, (long)row * g.ldc + col, v, c16);
         }
     }
 }
@@ -1123,6 +1140,11 @@ bool try_launch_gemm_lds(GemmArgs g, hipStream_t s) {
         g.k_slab = slab;
     }
     dim3 grid(gx, gy, splits), block(256);
+    static const bool no_remap = getenv("PIT_NO_GEMM_XCD_REMAP") != nullptr;
+    if (!no_remap && g.epi != EPI_ATOMIC && gx >= 2 && gy >= 64 && 8L * gx * ((gy + 7) / 8) < 0x7fffffffL) {
+        g.remap_gx = gx; g.remap_gy = gy;
+        grid = dim3((unsigned)(8 * gx * ((gy + 7) / 8)), 1, 1);
+    }
 #define PIT_LDS_BF(A_, B_, EPI_, BF_)                                                                         \
     do {                                                                                                       \
         if (bm == 128) hipLaunchKernelGGL((gemm_lds_kernel<128, A_, B_, EPI_, BF_>), grid, block, 0, s, g);    \
@@ -1131,7 +1153,12 @@ bool try_launch_gemm_lds(GemmArgs g, hipStream_t s) {
     } while (0)
 #define PIT_BFL(A_, B_, EPI_)                                                                                  \
     do {                                                                                                       \
-        if (bm == 128) hipLaunchKernelGGL((gemm_bfl_kernel<128, A_, B_, EPI_>), grid, block, 0, s, g);         \
+        if (io16) {                                                                                            \
+            if (bm == 128) hipLaunchKernelGGL((gemm_bfl_kernel<128, A_, B_, EPI_, true>), grid, block, 0, s, g);   \
+            else if (bm == 64) hipLaunchKernelGGL((gemm_bfl_kernel<64, A_, B_, EPI_, true>), grid, block, 0, s, g); \
+            else hipLaunchKernelGGL((gemm_bfl_kernel<32, A_, B_, EPI_, true>), grid, block, 0, s, g);          \
+        }                                                                                                      \
+        else if (bm == 128) hipLaunchKernelGGL((gemm_bfl_kernel<128, A_, B_, EPI_>), grid, block, 0, s, g);    \
         else if (bm == 64) hipLaunchKernelGGL((gemm_bfl_kernel<64, A_, B_, EPI_>), grid, block, 0, s, g);      \
         else hipLaunchKernelGGL((gemm_bfl_kernel<32, A_, B_, EPI_>), grid, block, 0, s, g);                    \
     } while (0)
@@ -1143,7 +1170,8 @@ bool try_launch_gemm_lds(GemmArgs g, hipStream_t s) {
         case 2: PIT_LDS(true, false, EPI_MUL_GELU_GRAD); break;
         case 3: PIT_LDS(true, false, EPI_STORE); break;
         default:
-            if (g.bf16 && !legacy_bf) hipLaunchKernelGGL((gemm_bfl_kernel<128, false, false, EPI_ATOMIC>), grid, block, 0, s, g);
+            if (g.bf16 && !legacy_bf && io16) hipLaunchKernelGGL((gemm_bfl_kernel<128, false, false, EPI_ATOMIC, true>), grid, block, 0, s, g);
+            else if (g.bf16 && !legacy_bf) hipLaunchKernelGGL((gemm_bfl_kernel<128, false, false, EPI_ATOMIC>), grid, block, 0, s, g);
             else if (g.bf16) hipLaunchKernelGGL((gemm_lds_kernel<128, false, false, EPI_ATOMIC, true>), grid, block, 0, s, g);
             else hipLaunchKernelGGL((gemm_lds_kernel<128, false, false, EPI_ATOMIC, false>), grid, block, 0, s, g);
             break;

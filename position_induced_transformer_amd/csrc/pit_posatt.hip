@@ -1966,8 +1966,12 @@ __global__ __launch_bounds__(256, 4) void posatt_sparse_rows_x(AttArgs a, Sparse
     sparse_rows_body<NH, CR, MODE>(a, sp, bx, by, bz);
 }
 
-template <int CR>
+// D16 (PIT_IO_DOUT_BF16): d_out holds bf16 - a lane then owns CR/2 PAIRS of adjacent columns {128 q + 2 lane, +1} and one
+// 4-B load fetches both (2-B loads per lane made the launch 3x slower than the fp32 one: 615 vs 220 us on the Vorticity
+// decoder); needs CR, dim and out_col0 even (the launch helper checks), cross attention only (no residual).
+template <int CR, bool D16 = false>
 __device__ __forceinline__ void sparse_cols_body(const AttArgs& a, const SparseArgs& sp, const int bx, const int by) {
+    static_assert(!D16 || CR % 2 == 0, "bf16 d_out: column pairs");
     constexpr int G = (CR >= 8) ? 2 : ((CR >= 4) ? 4 : 8);      // (see sparse_rows_body)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long keys_total = (long)a.mesh_batch * a.n_in;
@@ -1980,18 +1984,19 @@ __device__ __forceinline__ void sparse_cols_body(const AttArgs& a, const SparseA
     const __amdgpu_buffer_rsrc_t rmo = make_rsrc(a.mesh_out, mo_bytes);
     const __amdgpu_buffer_rsrc_t rmi = make_rsrc(a.mesh_in, mi_bytes);
     const __amdgpu_buffer_rsrc_t rdout = make_rsrc(a.d_out, a.dout_bytes);
-    const unsigned ldd4 = (unsigned)a.ld_dout;                 // (element units: dout_load scales by the element size)
+    constexpr unsigned ES = D16 ? 2u : 4u;                   // bytes per d_out element
+    const unsigned ldd4 = (unsigned)a.ld_dout * ES;
     const float4 xi = load_point4(rmi, mi_bytes, kid, a.sdim, a.coords_used);
     unsigned doff[CR];
     bool cvalid[CR];
     int cb[CR], cd[CR];
 #pragma unroll
     for (int r = 0; r < CR; ++r) {
-        const int col = cblk * 64 * CR + r * 64 + lane;
+        const int col = D16 ? cblk * 64 * CR + (r >> 1) * 128 + 2 * lane + (r & 1) : cblk * 64 * CR + r * 64 + lane;
         cvalid[r] = col < a.ncols;
         const int cc = cvalid[r] ? col : 0;
         col_split(a, cc, mb, cb[r], cd[r]);
-        doff[r] = (unsigned)((long)cb[r] * a.dout_bstride + a.out_col0 + cd[r]);
+        doff[r] = (unsigned)(((long)cb[r] * a.dout_bstride + a.out_col0 + cd[r]) * ES);
     }
     float acc[CR];
 #pragma unroll
@@ -2002,7 +2007,7 @@ __device__ __forceinline__ void sparse_cols_body(const AttArgs& a, const SparseA
 
     for (int h = 0; h < a.n_head; ++h) {
         const float c = a.head_is_scale ? a.head[h] : head_scale_from_lmda(a.head[h]);
-        const unsigned hoff = (unsigned)h * (unsigned)a.dim;
+        const unsigned hoff = (unsigned)h * (unsigned)a.dim * ES;
         for (int base = beg; base < end; base += 64) {
             const int e = base + lane;
             int nrow = (e < end) ? rrow[e] : -1;
@@ -2029,10 +2034,21 @@ __device__ __forceinline__ void sparse_cols_body(const AttArgs& a, const SparseA
                 }
                 float v[G][CR];
 #pragma unroll
-                for (int g = 0; g < G; ++g)
+                for (int g = 0; g < G; ++g) {
+                    if (D16) {
 #pragma unroll
-                    for (int r = 0; r < CR; ++r)
-                        v[g][r] = dout_load(rdout, (ni[g] >= 0 && cvalid[r]) ? doff[r] + hoff + (unsigned)ni[g] * ldd4 : a.dout_elems, a.dout16);
+                        for (int q = 0; q < CR / 2; ++q) {
+                            const unsigned w = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(
+                                rdout, (int)((ni[g] >= 0 && cvalid[2 * q]) ? doff[2 * q] + hoff + (unsigned)ni[g] * ldd4 : a.dout_bytes), 0, 0);
+                            v[g][2 * q] = __uint_as_float(w << 16);
+                            v[g][2 * q + (CR > 1 ? 1 : 0)] = __uint_as_float(w & 0xffff0000u);
+                        }
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < CR; ++r)
+                            v[g][r] = buf_load(rdout, (ni[g] >= 0 && cvalid[r]) ? doff[r] + hoff + (unsigned)ni[g] * ldd4 : a.dout_bytes);
+                    }
+                }
 #pragma unroll
                 for (int g = 0; g < G; ++g)
 #pragma unroll
@@ -2042,23 +2058,26 @@ __device__ __forceinline__ void sparse_cols_body(const AttArgs& a, const SparseA
     }
 #pragma unroll
     for (int r = 0; r < CR; ++r) {
-        const unsigned roff = (unsigned)((long)cb[r] * a.dout_bstride + cd[r]) + (unsigned)j * ldd4;
-        const float res = dout_load(rdout, (a.add_residual && cvalid[r]) ? roff : a.dout_elems, a.dout16);
+        float res = 0.0f;
+        if (!D16) {
+            const unsigned roff = (unsigned)(((long)cb[r] * a.dout_bstride + cd[r]) * 4) + (unsigned)j * ldd4;
+            res = buf_load(rdout, (a.add_residual && cvalid[r]) ? roff : a.dout_bytes);
+        }
         // (coordinate channels carry no gradient: the meshes are data; d_values holds the dim - coord_dims others)
         if (cvalid[r] && cd[r] >= a.coord_dims)
             a.d_values[(long)cb[r] * a.dvalues_bstride + (long)j * a.ld_dvalues + (cd[r] - a.coord_dims)] = acc[r] + res;
     }
 }
 
-template <int CR>
+template <int CR, bool D16 = false>
 __global__ __launch_bounds__(256) void posatt_sparse_cols(AttArgs a, SparseArgs sp) {
-    sparse_cols_body<CR>(a, sp, blockIdx.x, blockIdx.y);
+    sparse_cols_body<CR, D16>(a, sp, blockIdx.x, blockIdx.y);
 }
-template <int CR>
+template <int CR, bool D16 = false>
 __global__ __launch_bounds__(256) void posatt_sparse_cols_x(AttArgs a, SparseArgs sp, int gx, int gy) {
     int bx, by, bz;
     if (!xcd_remap((int)blockIdx.x, gx, gy, bx, by, bz)) return;
-    sparse_cols_body<CR>(a, sp, bx, by);
+    sparse_cols_body<CR, D16>(a, sp, bx, by);
 }
 
 // rows whose candidate list overflowed are not in the transposed lists: add their contribution
@@ -2114,12 +2133,12 @@ __global__ __launch_bounds__(256) void posatt_sparse_overflow_cols(AttArgs a, Sp
 // workgroups [0, n_cols) walk the transposed lists (critical path first), the rest the d(scale)
 // rows.  The overflow pass stays a separate, later launch: it ADDS to d(values) with atomics and
 // must come after the plain stores of the key-owning waves.
-template <int NH, int CRR, int CRC>
+template <int NH, int CRR, int CRC, bool D16 = false>
 __global__ __launch_bounds__(256) void posatt_sparse_bwd_kernel(AttArgs a, SparseArgs sp, int n_cols, int cgx,
                                                                  int rgx, int rgy) {
     int id = blockIdx.x;
     if (id < n_cols) {
-        sparse_cols_body<CRC>(a, sp, id % cgx, id / cgx);
+        sparse_cols_body<CRC, D16>(a, sp, id % cgx, id / cgx);
     } else {
         id -= n_cols;
         sparse_rows_body<NH, CRR, 1>(a, sp, id % rgx, (id / rgx) % rgy, id / (rgx * rgy));
@@ -2216,6 +2235,10 @@ bool launch_sparse_bwd_pair(const AttArgs& a, const SparseArgs& sp, bool complet
     const int crr = cr_for(a.ncols, rows * (a.n_head / nh));
     int crc = cr_for(a.ncols, keys);
     if (crc != crr && crc != 1) crc = (crc > crr) ? crr : 1;     // instantiated: equal, or 1 column per lane for d(values)
+    if (a.dout16) {                                               // bf16 d_out: the column-pair variant of d(values), no rider
+        if (crr < 2 || a.dim % 2 || a.out_col0 % 2 || a.ncols % 2 || a.ld_dout % 2 || a.dout_bstride % 2) return false;
+        crc = crr; job = nullptr;
+    }
     const int rblocks = (a.ncols + 64 * crr - 1) / (64 * crr), cblocks = (a.ncols + 64 * crc - 1) / (64 * crc);
     const long rgx = (rows + 3) / 4, cgx = (keys + 3) / 4;
     const long n_rows = rgx * rblocks * (a.n_head / nh), n_cols = cgx * cblocks;
@@ -2237,11 +2260,13 @@ bool launch_sparse_bwd_pair(const AttArgs& a, const SparseArgs& sp, bool complet
         return true;
     }
 #define PIT_SB(NH_, CRR_, CRC_) hipLaunchKernelGGL((posatt_sparse_bwd_kernel<NH_, CRR_, CRC_>), grid, block, 0, s, a, sp, (int)n_cols, (int)cgx, (int)rgx, rblocks)
-#define PIT_SB_C(NH_, CRR_) do { if (crc == CRR_) PIT_SB(NH_, CRR_, CRR_); else PIT_SB(NH_, CRR_, 1); } while (0)
+#define PIT_SB16(NH_, CRR_) hipLaunchKernelGGL((posatt_sparse_bwd_kernel<NH_, CRR_, CRR_, true>), grid, block, 0, s, a, sp, (int)n_cols, (int)cgx, (int)rgx, rblocks)
+#define PIT_SB_C(NH_, CRR_) do { if (a.dout16) PIT_SB16(NH_, CRR_); else if (crc == CRR_) PIT_SB(NH_, CRR_, CRR_); else PIT_SB(NH_, CRR_, 1); } while (0)
 #define PIT_SB_CR(NH_) do { if (crr == 8) PIT_SB_C(NH_, 8); else if (crr == 4) PIT_SB_C(NH_, 4); else if (crr == 2) PIT_SB_C(NH_, 2); else PIT_SB(NH_, 1, 1); } while (0)
     if (nh == 2) PIT_SB_CR(2); else PIT_SB_CR(1);
 #undef PIT_SB_CR
 #undef PIT_SB_C
+#undef PIT_SB16
 #undef PIT_SB
     if (!complete) hipLaunchKernelGGL(posatt_sparse_overflow_cols, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, a, sp);
     return true;
@@ -2249,7 +2274,7 @@ bool launch_sparse_bwd_pair(const AttArgs& a, const SparseArgs& sp, bool complet
 
 void launch_sparse_cols(const AttArgs& a, const SparseArgs& sp, bool complete, hipStream_t s) {
     const long keys = (long)a.mesh_batch * a.n_in;
-    const int cr = cr_for(a.ncols, keys);
+    const int cr = a.dout16 ? std::max(2, cr_for(a.ncols, keys)) : cr_for(a.ncols, keys);
     dim3 grid((unsigned)((keys + 3) / 4), (a.ncols + 64 * cr - 1) / (64 * cr)), block(256);
     const long xtotal = 8L * grid.x * ((grid.y + 7) / 8);
     const bool remap = grid.y >= 16 && xtotal < 0x7fffffffL && !env_int("PIT_NO_XCD_REMAP");   // (few blocks: padding costs more than locality gains)
@@ -2259,7 +2284,15 @@ void launch_sparse_cols(const AttArgs& a, const SparseArgs& sp, bool complete, h
                                       (int)grid.x, (int)grid.y);                                                      \
         else hipLaunchKernelGGL((posatt_sparse_cols<CR_>), grid, block, 0, s, a, sp);                                 \
     } while (0)
-    if (cr == 8) PIT_SC(8); else if (cr == 4) PIT_SC(4); else if (cr == 2) PIT_SC(2); else PIT_SC(1);
+#define PIT_SC16(CR_)                                                                                                 \
+    do {                                                                                                              \
+        if (remap) hipLaunchKernelGGL((posatt_sparse_cols_x<CR_, true>), dim3((unsigned)xtotal), block, 0, s, a, sp,  \
+                                      (int)grid.x, (int)grid.y);                                                      \
+        else hipLaunchKernelGGL((posatt_sparse_cols<CR_, true>), grid, block, 0, s, a, sp);                           \
+    } while (0)
+    if (a.dout16) { if (cr == 8) PIT_SC16(8); else if (cr == 4) PIT_SC16(4); else PIT_SC16(2); }
+    else if (cr == 8) PIT_SC(8); else if (cr == 4) PIT_SC(4); else if (cr == 2) PIT_SC(2); else PIT_SC(1);
+#undef PIT_SC16
 #undef PIT_SC
     const long rows = (long)a.mesh_batch * a.n_out;
     if (!complete) hipLaunchKernelGGL(posatt_sparse_overflow_cols, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, a, sp);
@@ -2385,7 +2418,9 @@ extern "C" int pit_posatt_bwd(const float* mesh_out, const float* mesh_in, int m
         a.dout_elems = (unsigned)de;
     }
     const bool sparse = masked && nbr_idx && nbr_cnt;
-    if (a.dout16 && (!sparse || add_residual || (d_values && !(rev_ptr && rev_row)))) return PIT_ERR_UNSUPPORTED;   // candidate-list kernels only
+    if (a.dout16 && (!sparse || add_residual || (d_values && !(rev_ptr && rev_row)) || dim % 2 || out_col0 % 2 || ld_dout % 2 ||
+                     dout_bstride % 2 || (reinterpret_cast<uintptr_t>(d_out) & 3)))
+        return PIT_ERR_UNSUPPORTED;                             // candidate-list kernels only, column pairs
     SparseArgs sp{nbr_idx, nbr_cnt, nbr_cap, rev_ptr, rev_row, (long)n_out * nbr_cap};
     if (d_head) {
         a.d_head = d_head; a.dhead_src = head; a.dhead_is_scale = head_is_scale;
