@@ -302,6 +302,8 @@ class pit(nn.Module):
             if tuple(w.mlp1.weight.shape) != (hid, (1 + heads) * hid) or tuple(w.mlp2.weight.shape) != (hid, hid) \
                     or w.mlp1.bias is None or w.mlp2.bias is None:
                 return None
+            if "forward" in a.__dict__ or "forward" in w.__dict__:      # forward patched on the instance: it must be called
+                return None
             for m in (a, w, w.mlp1, w.mlp2):            # hooks expect the modules to be CALLED
                 if any(not getattr(f, "_pit_internal", False) for f in m._forward_hooks.values()) \
                         or m._forward_pre_hooks or m._backward_hooks or m._backward_pre_hooks:
