@@ -6,6 +6,7 @@ is listed raw and x2 - the gfx950 correction of MI355X_MICROARCH.md applies to 1
 import collections, csv, glob, json, os, sys
 
 out, cfg = sys.argv[1], sys.argv[2]
+whole = len(sys.argv) > 3 and sys.argv[3] == "whole"      # shares over the whole run (rollouts, inference probes) instead of one step
 base = os.path.join(out, cfg)
 
 
@@ -31,9 +32,13 @@ try:
     summary["bench"] = json.load(open(os.path.join(out, cfg + ".bench.json")))
 except Exception:
     pass
+if whole and rows:
+    marks = [0, 0, len(rows)]
 if len(marks) >= 3:
     a, b = marks[-3], marks[-2]                      # one steady-state step (loss launch to loss launch)
     step = rows[a:b]
+    if whole:
+        step = rows                                  # every launch of the run (warm-up included: same kernels)
     wall = (int(step[-1]["End_Timestamp"]) - int(step[0]["Start_Timestamp"])) / 1e3
     agg = collections.OrderedDict()
     for r in step:
@@ -59,8 +64,12 @@ json.dump(summary, open(os.path.join(out, cfg + ".summary.json"), "w"), indent=1
 with open(os.path.join(out, cfg + ".summary.txt"), "w") as f:
     b = summary.get("bench", {})
     f.write(f"{cfg}: {b.get('config', {}).get('workload', '')}\n")
-    f.write(f"bench (under the profiler): {b.get('ms_per_step')} ms/step, {b.get('value')} samples/s; one step = "
-            f"{summary.get('launches_per_step')} launches, {summary.get('kernel_time_us')} us of kernels\n")
+    if whole:
+        f.write(f"whole run under the profiler ({b.get('ms_per_step')} ms/step reported): {summary.get('launches_per_step')} launches, "
+                f"{summary.get('kernel_time_us')} us of kernels; shares over all launches (warm-up included)\n")
+    else:
+        f.write(f"bench (under the profiler): {b.get('ms_per_step')} ms/step, {b.get('value')} samples/s; one step = "
+                f"{summary.get('launches_per_step')} launches, {summary.get('kernel_time_us')} us of kernels\n")
     f.write(f"{'share':>6} {'n':>3} {'mean us':>9} {'MFMA busy':>9} {'VALU/MFMA':>9} {'HBM GB/s':>9}  kernel\n")
     for r in summary["kernels"][:24]:
         f.write(f"{r['share']*100:5.1f}% {r['launches']:3d} {r['mean_us']:9.1f} {str(r.get('mfma_busy_frac', '-')):>9} "
