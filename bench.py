@@ -80,7 +80,7 @@ def parse():
     ap.add_argument("--cpu-iters", type=int, default=100)
     ap.add_argument("--rollout", type=int, default=0,
                     help="vorticity only: one step = the N-step autoregressive BPTT optimiser step of train_vorticity.py:118-129")
-    ap.add_argument("--recompute", action="store_true", help="with --rollout: activation recompute (eager only)")
+    ap.add_argument("--recompute", action="store_true", help="with --rollout: activation recompute (each step keeps only its input and is re-run in the backward)")
     ap.add_argument("--head-scale-route", choices=("host", "device"), default="host",
                     help="where c = tan(K(1+sin lmda)) of pit.py:48 is evaluated for the timed fwd+bwd step: 'host' = the "
                          "reference's own torch-CPU ops, cached per lmda version (exact, sync-free and capturable while lmda "

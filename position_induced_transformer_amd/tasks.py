@@ -133,6 +133,31 @@ class pit_naca(P.pit):
         return self.decoder(mesh_ltt, ltt, mesh_flat).reshape(*size, self.out_dim)
 
 
+class _RecomputedStep(torch.autograd.Function):
+    """One rollout step whose forward keeps ONLY its input: the prediction is computed under no_grad, and the backward
+    re-runs the step's forward with autograd on and back-propagates through it (parameter gradients accumulate into
+    ``.grad`` as in any backward pass, the input gradient is returned).  Nothing but kernel launches on the current
+    stream, so - unlike torch.utils.checkpoint with its saved-tensor hooks and RNG bookkeeping - the whole rollout
+    stays capturable into one hipGraph (engine.RolloutStep(recompute=True)).  ``anchor`` is a scalar that requires
+    grad: the first step's input is data, and a node none of whose inputs requires grad would never be visited."""
+
+    @staticmethod
+    def forward(ctx, anchor, model, mesh, x):
+        ctx.model, ctx.mesh = model, mesh
+        ctx.save_for_backward(x)
+        with torch.no_grad():
+            return model(mesh, x, mesh)
+
+    @staticmethod
+    def backward(ctx, d_out):
+        (x,) = ctx.saved_tensors
+        xd = x.detach().requires_grad_(True)
+        with torch.enable_grad():
+            out = ctx.model(ctx.mesh, xd, ctx.mesh)
+        torch.autograd.backward(out, d_out)
+        return None, None, None, xd.grad
+
+
 def rollout_loss(model, mesh, x, y, steps: int, loss_fn, recompute: bool = False):
     """Autoregressive training objective of train_vorticity.py:118-126: ``steps`` successive
     predictions, each appended to the input history (oldest frame dropped), loss summed over the
@@ -143,13 +168,13 @@ def rollout_loss(model, mesh, x, y, steps: int, loss_fn, recompute: bool = False
     backward (decoder attention output and decoder-MLP pre-activations dominate), so the 20-step rollout
     holds ~10 GB - 3.5 % of the MI355X's 288 GB: nothing has to be recomputed, which is the default.
     ``recompute=True`` keeps only each step's input and re-runs that step's forward inside the backward
-    pass (torch.utils.checkpoint, non-reentrant: +1 forward per step, ~25x less activation memory) for
-    rollouts / batches that would not fit."""
+    pass (_RecomputedStep: +1 forward per step, ~25x less activation memory, capturable) for rollouts /
+    batches that would not fit."""
     loss = 0.0
+    anchor = torch.ones((), device=x.device, requires_grad=True) if recompute else None
     for t in range(steps):
         if recompute:
-            from torch.utils.checkpoint import checkpoint
-            out = checkpoint(model, mesh, x, mesh, use_reentrant=False)
+            out = _RecomputedStep.apply(anchor, model, mesh, x)
         else:
             out = model(mesh, x, mesh)
         loss = loss + loss_fn(out, y[..., t:t + 1])

@@ -405,13 +405,14 @@ def test_rollout_step_graph_equals_eager_and_recompute_equals_plain(recompute):
     torch.cuda.synchronize()
     assert abs(float(step.loss) - ref_loss) <= 1e-6 * abs(ref_loss)
     assert gio.rel_l2(ref.cpu().numpy(), step.flat.flat.cpu().numpy()) <= 2e-5
-    if not recompute:                    # (checkpoint's saved-tensor hooks are not capturable)
-        step.capture()
-        step.replay()
-        step.replay()
-        torch.cuda.synchronize()
-        assert abs(float(step.loss) - ref_loss) <= 1e-6 * abs(ref_loss)
-        assert gio.rel_l2(ref.cpu().numpy(), step.flat.flat.cpu().numpy()) <= 2e-5
+    # (round 3: the recomputing rollout is an autograd.Function that re-runs the step - capturable, unlike
+    # torch.utils.checkpoint)
+    step.capture()
+    step.replay()
+    step.replay()
+    torch.cuda.synchronize()
+    assert abs(float(step.loss) - ref_loss) <= 1e-6 * abs(ref_loss)
+    assert gio.rel_l2(ref.cpu().numpy(), step.flat.flat.cpu().numpy()) <= 2e-5
 
 
 # --------------------------------------------------------------------------- row f4: long-J inference, Cylinder
