@@ -2,7 +2,8 @@
 """Summarise one configuration of tools/profile_round.sh into <outdir>/<cfg>.summary.json + .txt:
 per-kernel share of the step, launches per step, mean duration (rocprofv3 --kernel-trace), MFMA busy
 fraction, VALU instructions per MFMA, HBM bytes per launch (FETCH_SIZE / WRITE_SIZE, KiB counters; FETCH_SIZE
-is listed raw and x2 - the gfx950 correction of MI355X_MICROARCH.md applies to 16-B/lane streaming reads)."""
+is listed raw and x2; profiles/r03_fetch_calibration.txt: on this pool the counter is exactly half the bytes for every
+coalesced read shape these kernels use, so 2 x FETCH_SIZE + WRITE_SIZE is the traffic)."""
 import collections, csv, glob, json, os, sys
 
 out, cfg = sys.argv[1], sys.argv[2]
