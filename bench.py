@@ -415,7 +415,7 @@ def roofline_block_probe(model, batch):
     def bwd():
         _lib.check(Lb.pit_block_bwd(E[0].data_ptr(), inv[0].data_ptr(), Q[0].data_ptr(), L, H, D, batch, dxc.data_ptr(), xc.data_ptr(),
                                     ws.data_ptr(), w1.data_ptr(), w2.data_ptr(), z1.data_ptr(), z2.data_ptr(), 1, W, dxp.data_ptr(), W,
-                                    scr.data_ptr(), None, 0, jp, 0, _lib.stream_ptr()), "pit_block_bwd")
+                                    scr.data_ptr(), None, 0, jp, None, 0, _lib.stream_ptr()), "pit_block_bwd")
 
     att = 2.0 * H * L * L * D * batch
     mlp_f = 2.0 * rows * (W * D + D * D)

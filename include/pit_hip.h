@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define PIT_ABI_VERSION 11
+#define PIT_ABI_VERSION 12
 #define PIT_DSCALE_SLOTS 1024 /* fp64 accumulators per head in pit_posatt_bwd's workspace */
 
 /* distance metric (dist2att variants) */
@@ -231,13 +231,17 @@ int pit_block_fwd(const float* e, const float* inv, int n_pts, int n_head, int d
  *   dscale != NULL: this layer's d(scale) partial sums are ADDED to these accumulators (n_head*PIT_DSCALE_SLOTS
  *     doubles, the PIT_HEAD_DEFER convention of pit_posatt_bwd: drain with pit_posatt_dhead_finish); needs qw and
  *     xcat (the block's concat tensor, whose first dim columns are the attention's values).
- *   rider: as in pit_posatt_bwd (the weight-gradient reductions of this block's own MLP). */
+ *   rider: as in pit_posatt_bwd (the weight-gradient reductions of this block's own MLP).
+ *   rider2: a second postponed job carried the same way - typically a SLICE of rows of a larger one (the decoder MLP's
+ *     reductions are row sums: any partition of the rows, each slice with accumulate = 1, gives the same gradient), so
+ *     that a job too big for one launch is spread over the block launches of the backward chain. */
 int pit_block_bwd(const float* e, const float* inv, const float* qw, int n_pts, int n_head, int dim, int batch,
                   const float* d_xcat, const float* xcat, double* dscale,
                   const float* w1, const float* w2, const float* z1, const float* z2, int out_gelu, int n0_prev,
                   float* d_xprev, long ld_dxprev, float* scratch_prev,
                   float* d_values, long ld_dvalues,
-                  const struct pit_mlp_params_job* rider, int math_mode, void* stream);
+                  const struct pit_mlp_params_job* rider, const struct pit_mlp_params_job* rider2,
+                  int math_mode, void* stream);
 
 /* kaiming_mlp.forward (pit.py:21-26): y = W2 * gelu_erf(W1 x + b1) + b2, optionally
  * followed by the trailing gelu of pit.py:111,121 (out_gelu=1).

@@ -589,14 +589,19 @@ __device__ __forceinline__ void dw_pair_body(const pit_detail::DwPair& w, int id
     }
 }
 
-template <int H, bool DW>
-__global__ __launch_bounds__(512) void block_bwd_kernel(BlockBwdArgs g, pit_detail::DwPair w) {
+// NDW riders (0, 1 or 2 pairs of weight-gradient reductions): the block's own MLP, and a slice of a LARGER postponed job
+// (the decoder MLP's: 14 792 rows at Darcy b=8 - inside the decoder attention's own launch it cost more than a launch of
+// its own, spread over the block launches it runs on compute units the chain leaves idle)
+template <int H, int NDW>
+__global__ __launch_bounds__(512) void block_bwd_kernel(BlockBwdArgs g, pit_detail::DwPair w, pit_detail::DwPair w2) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     int id = blockIdx.x;
     if (id < g.n_chain) { block_bwd_chain<H>(g, smem, id); return; }
     id -= g.n_chain;
     if (id < g.n_ds) { block_bwd_dscale<H>(g, smem, id); return; }
-    if (DW) dw_pair_body(w, id - g.n_ds);
+    id -= g.n_ds;
+    if (NDW >= 1 && id < w.n1 + w.n2) { dw_pair_body(w, id); return; }
+    if (NDW >= 2) dw_pair_body(w2, id - (w.n1 + w.n2));
 }
 
 constexpr size_t fwd_smem(int H) { return ((size_t)H * PARK_FLOATS + 16 * ((1 + H) * BD + 4) + 16 * (BD + 4)) * sizeof(float); }
@@ -681,7 +686,7 @@ extern "C" int pit_block_bwd(const float* e, const float* inv, const float* qw, 
                              const float* w1, const float* w2, const float* z1, const float* z2, int out_gelu, int n0_prev,
                              float* d_xprev, long ld_dxprev, float* scratch_prev,
                              float* d_values, long ld_dvalues,
-                             const pit_mlp_params_job* rider, int math_mode, void* stream) {
+                             const pit_mlp_params_job* rider, const pit_mlp_params_job* rider2, int math_mode, void* stream) {
     if (!e || !inv || !d_xcat) return PIT_ERR_NULL;
     if (dscale && (!qw || !xcat)) return PIT_ERR_NULL;
     if (math_mode != PIT_MATH_FP32 || !pit_block_supported(n_pts, n_head, dim, batch)) return PIT_ERR_UNSUPPORTED;
@@ -704,27 +709,34 @@ extern "C" int pit_block_bwd(const float* e, const float* inv, const float* qw, 
     g.d_values = d_values; g.ld_dvalues = ld_dvalues;
     g.n_chain = slab_grid(batch, n_pts / 16);
     g.n_ds = dscale ? g.n_chain : 0;
-    pit_detail::DwPair dw = pit_detail::DwPair();
-    bool carried = false;
-    if (rider) carried = pit_detail::plan_dw_pair(*rider, BW, &dw);
-    const size_t sm = std::max(bwd_smem(n_head, dscale != nullptr), carried ? (size_t)BW * 16 * 64 * sizeof(float) : (size_t)0);
-    const dim3 grid((unsigned)(g.n_chain + g.n_ds + (carried ? dw.n1 + dw.n2 : 0))), block(64 * BW);
+    pit_detail::DwPair dw = pit_detail::DwPair(), dw2 = pit_detail::DwPair();
+    const pit_mlp_params_job* jobs[2] = {rider, rider2};
+    pit_detail::DwPair* plans[2] = {&dw, &dw2};
+    int ndw = 0;                                        // carried riders are packed into dw, dw2 in order
+    bool carried[2] = {false, false};
+    for (int r = 0; r < 2; ++r)
+        if (jobs[r] && pit_detail::plan_dw_pair(*jobs[r], BW, plans[ndw])) { carried[r] = true; ++ndw; }
+    const int n_dw = (ndw >= 1 ? dw.n1 + dw.n2 : 0) + (ndw >= 2 ? dw2.n1 + dw2.n2 : 0);
+    const size_t sm = std::max(bwd_smem(n_head, dscale != nullptr), ndw ? (size_t)BW * 16 * 64 * sizeof(float) : (size_t)0);
+    const dim3 grid((unsigned)(g.n_chain + g.n_ds + n_dw)), block(64 * BW);
 #define PIT_BLOCK_BWD(H_, DW_)                                                                                             \
     do {                                                                                                                   \
         static bool once = ((void)hipFuncSetAttribute((const void*)block_bwd_kernel<H_, DW_>,                             \
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 98304), true);                 \
         (void)once;                                                                                                        \
-        hipLaunchKernelGGL((block_bwd_kernel<H_, DW_>), grid, block, sm, s, g, dw);                                        \
+        hipLaunchKernelGGL((block_bwd_kernel<H_, DW_>), grid, block, sm, s, g, dw, dw2);                                   \
     } while (0)
-    if (n_head == 1) { if (carried) PIT_BLOCK_BWD(1, true); else PIT_BLOCK_BWD(1, false); }
-    else { if (carried) PIT_BLOCK_BWD(2, true); else PIT_BLOCK_BWD(2, false); }
+#define PIT_BLOCK_BWD_H(H_) do { if (ndw == 2) PIT_BLOCK_BWD(H_, 2); else if (ndw == 1) PIT_BLOCK_BWD(H_, 1); else PIT_BLOCK_BWD(H_, 0); } while (0)
+    if (n_head == 1) PIT_BLOCK_BWD_H(1); else PIT_BLOCK_BWD_H(2);
+#undef PIT_BLOCK_BWD_H
 #undef PIT_BLOCK_BWD
     PIT_CHECK_LAUNCH();
-    if (rider && !carried) {                            // too large to ride: the launches pit_mlp_bwd_params would have made
-        const int rc = pit_mlp_bwd_params(rider->x, rider->ldx, rider->rows, rider->n0, rider->n1, rider->n2, rider->h,
-                                          rider->out_gelu, rider->d_y, rider->ld_dy, rider->d_w1, rider->d_b1, rider->d_w2,
-                                          rider->d_b2, rider->accumulate, rider->scratch, rider->math_mode, stream);
-        if (rc) return rc;
-    }
+    for (int r = 0; r < 2; ++r)
+        if (jobs[r] && !carried[r]) {                   // too large to ride: the launches pit_mlp_bwd_params would have made
+            const pit_mlp_params_job* j = jobs[r];
+            const int rc = pit_mlp_bwd_params(j->x, j->ldx, j->rows, j->n0, j->n1, j->n2, j->h, j->out_gelu, j->d_y, j->ld_dy,
+                                              j->d_w1, j->d_b1, j->d_w2, j->d_b2, j->accumulate, j->scratch, j->math_mode, stream);
+            if (rc) return rc;
+        }
     return 0;
 }

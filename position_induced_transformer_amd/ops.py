@@ -263,6 +263,28 @@ def _dw_take(device):
     return job
 
 
+BIG_RIDER_ROWS = 8192
+
+
+def _dw_pending_rows(device) -> int:
+    """Rows of the job the running pass has postponed (0: none)."""
+    job = _PENDING_DW.get(_graph_task())
+    return int(job[0].rows) if job is not None else 0
+
+
+def _dw_slices(job, parts: int):
+    """``job`` (a postponed pit_mlp_bwd_params without trailing gelu: its reductions are plain row sums) cut into
+    ``parts`` row slices, each a job of its own with accumulate = 1."""
+    st = job[0]
+    out, per = [], -(-st.rows // parts // 16) * 16
+    for r0 in range(0, st.rows, per):
+        n = min(per, st.rows - r0)
+        out.append(_lib.MlpParamsJob(st.x + 4 * r0 * st.ldx, st.ldx, n, st.n0, st.n1, st.n2, st.h + 4 * r0 * st.n1, 0,
+                                     st.d_y + 4 * r0 * st.ld_dy, st.ld_dy, st.d_w1, st.d_b1, st.d_w2, st.d_b2, 1,
+                                     st.scratch + 4 * r0 * st.n1, st.math_mode))
+    return out
+
+
 def _dw_deferrable(rows: int, n0: int, n1: int, n2: int, out_gelu: int, ld_dy: int) -> bool:
     key = (rows, n0, n1, n2, out_gelu, ld_dy)
     v = _DEFERRABLE.get(key)
@@ -513,7 +535,12 @@ class _PosAtt(torch.autograd.Function):
             acc_head |= 2                               # PIT_HEAD_DEFER: finished by _flush_head_finishes
             _defer_head_begin(work)                     # (clears what an aborted pass left, before the kernel adds)
 
-        rider = _dw_take(values.device)                 # an MLP's postponed weight-gradient reductions
+        # an MLP's postponed weight-gradient reductions ride along - unless this is a candidate-list layer and the job is
+        # LARGE (the decoder MLP's: inside that launch it costs more than a launch of its own, measured 34.7 vs 16.1 +
+        # 15.7 us at Darcy b=8); left pending, the fused processor spreads it over its block launches (_Processor.backward)
+        # or the next MLP backward / the end of the pass runs it
+        rider = None if (plan.nbr_idx is not None and _dw_pending_rows(values.device) >= BIG_RIDER_ROWS) \
+            else _dw_take(values.device)
 
         def launch(dv, dh, stream_ptr, job=None):
             rc = _lib.lib().pit_posatt_bwd(
@@ -923,6 +950,15 @@ class _Processor(torch.autograd.Function):
             else:
                 ws = torch.zeros(H * 1024, device=dev, dtype=torch.float64)
             work.append(ws)
+        # a large job the pass has postponed (the decoder MLP's weight gradients): one row slice per block launch
+        extra = _dw_take(dev)
+        slices = []
+        if extra is not None:
+            st = extra[0]
+            if not st.out_gelu and st.accumulate and (st.math_mode & 0xff) == 0:
+                slices = _dw_slices(extra, n)
+            else:
+                _dw_run(extra)
         # top of the chain: the last block's MLP backward (data path) from d_out
         w1, _, w2, _ = wts[n - 1]
         rc = L_.pit_mlp_bwd_data(rows, W, D, D, w1.data_ptr(), w2.data_ptr(), z1[n - 1].data_ptr(), z2[n - 1].data_ptr(), 1,
@@ -940,9 +976,11 @@ class _Processor(torch.autograd.Function):
                         dxc[i - 1].data_ptr(), W, scratch[i - 1].data_ptr(), None, 0)
             else:
                 prev = (None, None, None, None, 0, 0, None, 0, None, dx.data_ptr(), D)
+            k = n - 1 - i                              # launch order
+            job2 = ctypes.cast(ctypes.pointer(slices[k]), ctypes.c_void_p) if k < len(slices) else None
             rc = L_.pit_block_bwd(E[i].data_ptr(), inv[i].data_ptr(), Q[i].data_ptr(), L, H, D, b, dxc[i].data_ptr(),
                                   bufs[i].data_ptr(), work[i].data_ptr(), *prev,
-                                  ctypes.cast(ctypes.pointer(job), ctypes.c_void_p), ctx.math, _lib.stream_ptr())
+                                  ctypes.cast(ctypes.pointer(job), ctypes.c_void_p), job2, ctx.math, _lib.stream_ptr())
             _lib.check(rc, "pit_block_bwd")
             if _PROCESSOR_HOOK[0] is not None:
                 _PROCESSOR_HOOK[0](i)                       # (block i's weight gradients are now enqueued)

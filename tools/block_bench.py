@@ -27,7 +27,7 @@ def graph_time(fn, reps=20, replays=10):
     return e0.elapsed_time(e1) * 1e3 / (reps * replays)
 
 
-b = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+b = int(sys.argv[1]) if len(sys.argv) > 1 and __name__ == "__main__" else 8
 model, sample, meta = tasks.make_task("darcy", seed=0)
 L_, Lp, H, D, n = _lib.lib(), 256, 2, 64, 4
 W, rows = (1 + H) * D, b * 256
@@ -68,7 +68,7 @@ jp = ctypes.cast(ctypes.pointer(job), ctypes.c_void_p)
 def bwd(dscale=True, rider=True):
     assert L_.pit_block_bwd(E[0].data_ptr(), inv[0].data_ptr(), Q[0].data_ptr(), Lp, H, D, b, dxc.data_ptr(), xc.data_ptr(),
                             ws.data_ptr() if dscale else None, w1.data_ptr(), w2.data_ptr(), z1.data_ptr(), z2.data_ptr(), 1, W,
-                            dxp.data_ptr(), W, scr.data_ptr(), None, 0, jp if rider else None, 0, sp()) == 0
+                            dxp.data_ptr(), W, scr.data_ptr(), None, 0, jp if rider else None, None, 0, sp()) == 0
 
 
 if os.environ.get("BLOCK_DBG"):
