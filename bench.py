@@ -371,6 +371,12 @@ def roofline_attention_bwd_probe(model, batch):
             "us_per_launch": round(us, 3), "flops_per_launch": flops, "algorithmic_bytes": alg_bytes}
 
 
+def step_rows_out(model):
+    """Output points per sample of the benchmark's task (the decoder MLP's rows): Darcy 43 x 43, else the latent count."""
+    return 43 * 43 if model.mesh_ltt is not None and model.mesh_ltt.shape[0] == 256 and model.space_dim == 2 and model.in_dim == 1 \
+        else model.mesh_ltt.shape[0]
+
+
 def roofline_block_probe(model, batch):
     """The launches with the LARGEST share of the Darcy b=8 step since round 3 (profiles/r03_darcy8.summary.txt): the fused
     processor-block kernels of csrc/pit_block.hip, called through the C ABI exactly as ops._Processor does.
@@ -406,6 +412,25 @@ def roofline_block_probe(model, batch):
     job = _lib.MlpParamsJob(xc.data_ptr(), W, rows, W, D, D, hh.data_ptr(), 1, scr_own.data_ptr(), D, gw1.data_ptr(),
                             gb1.data_ptr(), gw2.data_ptr(), gb2.data_ptr(), 1, scr_own.data_ptr(), 0)
     jp = ctypes.cast(ctypes.pointer(job), ctypes.c_void_p)
+    # rider2: the row slice of the DECODER MLP's weight-gradient job this launch carries in the step (ops._dw_slices: the
+    # job is cut into n_blocks slices, one per block launch) - present when that job is postponed (small regime)
+    jp2, slice_flops, slice_bytes = None, 0.0, 0.0
+    de, n_blocks = getattr(model, "de", None), len(model.mlp)
+    if de is not None and hasattr(de, "mlp1"):
+        rows_de = batch * int(step_rows_out(model))
+        dn0, dn1, dn2 = de.mlp1.in_features, de.mlp1.out_features, de.mlp2.out_features
+        if rows_de >= ops.BIG_RIDER_ROWS and Lb.pit_mlp_bwd_params_deferrable(rows_de, dn0, dn1, dn2, 0, dn2):
+            per = -(-rows_de // n_blocks // 16) * 16
+            xs_, hs_ = torch.randn(per, dn0, device="cuda"), torch.randn(per, dn1, device="cuda")
+            dys, scs = torch.randn(per, dn2, device="cuda"), torch.randn(per * dn1, device="cuda")
+            g1, gb1_, g2, gb2_ = (torch.zeros(dn1, dn0, device="cuda"), torch.zeros(dn1, device="cuda"),
+                                  torch.zeros(dn2, dn1, device="cuda"), torch.zeros(dn2, device="cuda"))
+            job2 = _lib.MlpParamsJob(xs_.data_ptr(), dn0, per, dn0, dn1, dn2, hs_.data_ptr(), 0, dys.data_ptr(), dn2, g1.data_ptr(),
+                                     gb1_.data_ptr(), g2.data_ptr(), gb2_.data_ptr(), 1, scs.data_ptr(), 0)
+            jp2 = ctypes.cast(ctypes.pointer(job2), ctypes.c_void_p)
+            slice_flops = 2.0 * per * (dn0 * dn1 + dn1 * dn2)
+            slice_bytes = 4.0 * per * (dn0 + 2 * dn1 + dn2)
+            keep_alive = (xs_, hs_, dys, scs, g1, gb1_, g2, gb2_, job2)     # noqa: F841
 
     def fwd():
         _lib.check(Lb.pit_block_fwd(E[0].data_ptr(), inv[0].data_ptr(), L, H, D, batch, xc.data_ptr(), w1.data_ptr(), b1.data_ptr(),
@@ -415,16 +440,17 @@ def roofline_block_probe(model, batch):
     def bwd():
         _lib.check(Lb.pit_block_bwd(E[0].data_ptr(), inv[0].data_ptr(), Q[0].data_ptr(), L, H, D, batch, dxc.data_ptr(), xc.data_ptr(),
                                     ws.data_ptr(), w1.data_ptr(), w2.data_ptr(), z1.data_ptr(), z2.data_ptr(), 1, W, dxp.data_ptr(), W,
-                                    scr.data_ptr(), None, 0, jp, None, 0, _lib.stream_ptr()), "pit_block_bwd")
+                                    scr.data_ptr(), None, 0, jp, jp2, 0, _lib.stream_ptr()), "pit_block_bwd")
 
     att = 2.0 * H * L * L * D * batch
     mlp_f = 2.0 * rows * (W * D + D * D)
     recs = []
     for name, fn, flops, nbytes, what in (
-            ("block_bwd_kernel", bwd, 2 * att + 2.0 * rows * (D * D + D * W) + mlp_f,
-             4.0 * (2 * rows * W + rows * W + 4 * rows * D + rows * W + 2 * H * L * L + rows * (W + 3 * D)),
+            ("block_bwd_kernel", bwd, 2 * att + 2.0 * rows * (D * D + D * W) + mlp_f + slice_flops,
+             4.0 * (2 * rows * W + rows * W + 4 * rows * D + rows * W + 2 * H * L * L + rows * (W + 3 * D)) + slice_bytes,
              f"d(values)+d(scale) of a processor block {L}x{L}, D={D}, H={H}, batch {batch}, + data path of the previous block's "
-             f"MLP backward + dW/db of the block's own MLP {W}->{D}->{D} ({rows} rows)"),
+             f"MLP backward + dW/db of the block's own MLP {W}->{D}->{D} ({rows} rows)"
+             + (f" + 1/{n_blocks} of the decoder MLP's dW/db" if jp2 is not None else "")),
             ("block_fwd_kernel", fwd, att + mlp_f, 4.0 * (2 * rows * W + 4 * rows * D + H * L * L + W * D + D * D),
              f"attention of a processor block {L}x{L}, D={D}, H={H}, batch {batch}, + its MLP forward {W}->{D}->{D} ({rows} rows)")):
         us = graph_time_us(fn)
