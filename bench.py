@@ -371,13 +371,7 @@ def roofline_attention_bwd_probe(model, batch):
             "us_per_launch": round(us, 3), "flops_per_launch": flops, "algorithmic_bytes": alg_bytes}
 
 
-def step_rows_out(model):
-    """Output points per sample of the benchmark's task (the decoder MLP's rows): Darcy 43 x 43, else the latent count."""
-    return 43 * 43 if model.mesh_ltt is not None and model.mesh_ltt.shape[0] == 256 and model.space_dim == 2 and model.in_dim == 1 \
-        else model.mesh_ltt.shape[0]
-
-
-def roofline_block_probe(model, batch):
+def roofline_block_probe(model, batch, rows_out):
     """The launches with the LARGEST share of the Darcy b=8 step since round 3 (profiles/r03_darcy8.summary.txt): the fused
     processor-block kernels of csrc/pit_block.hip, called through the C ABI exactly as ops._Processor does.
       block_bwd_kernel: d(values) of a block (2*H*L*L*D*b) + its d(scale) (2*H*L*L*D*b) + the data path of the previous
@@ -417,7 +411,7 @@ def roofline_block_probe(model, batch):
     jp2, slice_flops, slice_bytes = None, 0.0, 0.0
     de, n_blocks = getattr(model, "de", None), len(model.mlp)
     if de is not None and hasattr(de, "mlp1"):
-        rows_de = batch * int(step_rows_out(model))
+        rows_de = batch * int(rows_out)               # the decoder MLP's rows: output points per sample x batch
         dn0, dn1, dn2 = de.mlp1.in_features, de.mlp1.out_features, de.mlp2.out_features
         if rows_de >= ops.BIG_RIDER_ROWS and Lb.pit_mlp_bwd_params_deferrable(rows_de, dn0, dn1, dn2, 0, dn2):
             per = -(-rows_de // n_blocks // 16) * 16
@@ -769,7 +763,8 @@ def main():
         extras["roofline_saturated"] = roofline_probe(model, 256)
         extras["roofline_mlp_saturated"] = roofline_mlp_probe(model, 256)
     if rank == 0:
-        blk = roofline_block_probe(model, args.batch) if args.math == "fp32" else None
+        blk = roofline_block_probe(model, args.batch, step.mesh_out.reshape(-1, model.space_dim).shape[0]) \
+            if (args.math == "fp32" and model.mesh_ltt is not None) else None
         bwd = roofline_attention_bwd_probe(model, args.batch)
         mlp = roofline_mlp_probe(model, args.batch)
         if blk is not None:
