@@ -677,7 +677,8 @@ def main():
             "value": round(value, 1), "unit": "samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if args.math == "fp32" else "bf16 MFMA operands, f32 accumulate",
+            "dtype": "f32" if args.math == "fp32" else "bf16 MFMA operands, f32 accumulate; decoder tail stored as bf16; the small-regime "
+                                                         "fused MLP kernels contract in f32",
             "data": "synthetic",
             "config": {"workload": WORKLOADS.get(args.task, args.task) + (f", {args.rollout}-step autoregressive rollout + ONE backward "
                                                                            f"(train_vorticity.py:118-126){', activation recompute' if args.recompute else ''}"

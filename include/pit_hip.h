@@ -51,6 +51,9 @@ const char* pit_error_string(int code);
  *     head scale, quantile thresholds, mask, softmax weights, the d(scale) reduction, loss and
  *     optimiser stay fp32 in both modes, so the kept sets are identical; outputs agree with the
  *     fp32 mode to ~1e-2 relative L2 (tests/test_gpu_bf16.py states the tolerance).
+ *     Exception (stated, not silent): the small-regime fused kernels - pit_mlp_fwd / pit_mlp_bwd_data on 16-row slabs
+ *     (mlp_fwd16_kernel, mlp_bwd16_kernel) and the fused processor blocks (pit_block_*: PIT_MATH_FP32 only, they
+ *     return PIT_ERR_UNSUPPORTED otherwise) - are latency-bound, not MFMA-bound, and contract in fp32 in BOTH modes.
  * Any other value returns PIT_ERR_UNSUPPORTED. */
 #define PIT_MATH_FP32 0
 #define PIT_MATH_BF16 1

@@ -1181,7 +1181,9 @@ def _math_code() -> int:
 
 def set_math_mode(mode: str) -> None:
     """'fp32' (default, the reference's arithmetic) or 'bf16' (bf16 MFMA operands, fp32 accumulate) for
-    the attention / MLP contractions.  Host-side, per Python thread: the mode is an ARGUMENT of every
+    the attention / MLP contractions (the small-regime fused MLP kernels contract in fp32 in both modes - they
+    are latency-bound - and the fused processor blocks run in fp32 mode only: bf16 mode takes the per-layer path).
+    In bf16 mode the decoder tail is also STORED as bf16 when its shape allows (BF16_STORAGE, pit.decoder).  Host-side, per Python thread: the mode is an ARGUMENT of every
     C-ABI call (the library keeps no mode of its own), read when an operator's forward runs and reused
     by its backward; a captured hipGraph keeps the mode its launches were captured with."""
     if mode not in MATH_MODES:
