@@ -655,17 +655,30 @@ __device__ __forceinline__ void st1e(float* base, long idx, float v, int is16) {
 }
 
 // IO16: the instantiation that honours the bf16-STORAGE flags of GemmArgs (a16 .. g16); the plain one carries none of that
-// code (as runtime-only branches the extra staging registers cost the fp32-storage launches 8-26 %)
-template <int LBM, bool A_KC, bool B_KC, int EPI, bool IO16 = false>
+// code (as runtime-only branches the extra staging registers cost the fp32-storage launches 8-26 %).
+// BK = k per LDS chunk (round 3).  With 32 a chunk is 2 MFMAs per wave and tile (64 cycles of matrix pipe) against one
+// global round trip of ~1.5 k cycles with a single chunk of prefetch: the mid-sized layers (5120 rows, 24 chunks) were 24
+// dependent round trips long - 1-2 % MFMA busy.  128 (tiles up to 64 rows) / 64 (128-row tiles: staging registers) cut the
+// number of dependent iterations 4x / 2x; LDS rows are BK + 8 bf16 apart.
+template <int LBM, bool A_KC, bool B_KC, int EPI, bool IO16 = false, int BK = 32>
 __global__ __launch_bounds__(256) void gemm_bfl_kernel(GemmArgs g) {
-    const bool a16 = IO16 && g.a16, b16 = IO16 && g.b16, c16 = IO16 && g.c16, z16 = IO16 && g.z16, g16 = IO16 && g.g16;
+    // (IO16: the A operand IS bf16-stored, and in the row-reducing kind B as well - compile-time, so that the fp32 staging
+    // registers of the other path do not exist: as runtime flags both sets were live, 196 VGPRs = 2 waves per SIMD)
+    constexpr bool a16 = IO16, b16 = IO16 && (EPI == EPI_ATOMIC);
+    const bool c16 = IO16 && g.c16, z16 = IO16 && g.z16, g16 = IO16 && g.g16;
     constexpr int TN = (LBM == 128) ? 2 : 1;
-    constexpr int PA = LBM / 32;                  // KC staging passes for A (4 floats per thread and pass)
-    constexpr int KPA = LBK / (256 / LBM);        // IC staging: k per thread for A (lane = row)
-    constexpr int KPB = LBK / (256 / LBN);        // ... and for B
+    constexpr int PK = BK + 8;                    // LDS row pitch (bf16 elements)
+    constexpr int TPR = BK / 4;                   // KC fp32 staging: threads per row (4 floats each)
+    constexpr int RPP = 256 / TPR;                // ... rows per pass
+    constexpr int PA = (LBM + RPP - 1) / RPP;     // ... passes for A
+    constexpr int PB = (LBN + RPP - 1) / RPP;     // ... and for B
+    constexpr int KPA = BK / (256 / LBM);         // IC fp32 staging: k per thread for A (lane = row)
+    constexpr int KPB = BK / (256 / LBN);         // ... and for B
     constexpr bool KSPLIT = (LBM == 32);
-    __shared__ __attribute__((aligned(16))) unsigned short As[LBM * BPK];
-    __shared__ __attribute__((aligned(16))) unsigned short Bs[LBN * BPK];
+    constexpr int STEPS = BK / 16;                // 16-k MFMA steps per chunk
+    static_assert(!KSPLIT || STEPS % 2 == 0, "the wave pairs split the steps of a chunk");
+    __shared__ __attribute__((aligned(16))) unsigned short As[LBM * PK];
+    __shared__ __attribute__((aligned(16))) unsigned short Bs[LBN * PK];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, l31 = lane & 31;
     int bx = blockIdx.x, by = blockIdx.y;
@@ -685,39 +698,41 @@ __global__ __launch_bounds__(256) void gemm_bfl_kernel(GemmArgs g) {
     const __amdgpu_buffer_rsrc_t rb = make_rsrc(g.B, g.b_bytes);
     const int n_real = (EPI == EPI_ATOMIC && g.ones_col >= 0) ? g.N - 1 : g.N;
 
-    float sa[A_KC ? PA * 4 : KPA], sb[B_KC ? 8 : KPB];
+    float sa[a16 ? 1 : (A_KC ? PA * 4 : KPA)], sb[b16 ? 1 : (B_KC ? PB * 4 : KPB)];
     // bf16 STORAGE of an operand (PIT_IO_*, wave-uniform flags): its chunk needs no conversion on the way to LDS.
-    //   k-contiguous A: 4 threads cover the 32 k of a row with one 16-B load each (64 rows per pass);
+    //   k-contiguous A: BK/8 threads cover the BK k of a row with one 16-B load each;
     //   i-contiguous A (LBM = 128) / B: a lane owns TWO adjacent rows / columns (one 4-B load = the pair at one k), takes
-    //   8 (A) / 4 (B) consecutive k and writes each row's fragment piece as one 16-B / 8-B LDS store.
-    constexpr int PA16 = (LBM + 63) / 64;
-    uint4 sa16[PA16];
-    unsigned sa2[8], sb2[4];
+    //   BK/4 (A) / BK/8 (B) consecutive k and writes each row's fragment pieces as 16-B / 8-B LDS stores.
+    constexpr int TPR16 = BK / 8, RPP16 = 256 / TPR16;
+    constexpr int PA16 = (LBM + RPP16 - 1) / RPP16;
+    constexpr int KA2 = BK / 4, KB2 = BK / 8;     // 4-B pair loads per thread (A: 64 row pairs x 4 k groups; B: 32 pairs x 8)
+    uint4 sa16[(a16 && A_KC) ? PA16 : 1];
+    unsigned sa2[(a16 && !A_KC) ? KA2 : 1], sb2[b16 ? KB2 : 1];
     // the bias gradient (virtual ones column) = row sums of the A operand, exact fp32 from the staging
     // registers of the first column block (A is i-contiguous in every row-reducing GEMM)
     const bool want_rowsum = (EPI == EPI_ATOMIC) && !A_KC && g.ones_col >= 0 && bx == 0;
     float rsum = 0.0f, rsum_hi = 0.0f;
     auto gload = [&](int kc) {
-        if (A_KC && a16) {
+        if constexpr (a16 && A_KC) {
 #pragma unroll
             for (int p = 0; p < PA16; ++p) {
-                const int rl = p * 64 + (tid >> 2), row = m0 + rl, k = kc + (tid & 3) * 8;
+                const int rl = p * RPP16 + tid / TPR16, row = m0 + rl, k = kc + (tid % TPR16) * 8;
                 const bool ok = rl < LBM && row < g.M && k < kend;
                 const i32x4 q = __builtin_amdgcn_raw_buffer_load_b128(ra, ok ? (int)(((unsigned)row * (unsigned)g.a_rs + (unsigned)k) * 2u) : (int)g.a_bytes, 0, 0);
                 sa16[p] = make_uint4((unsigned)q.x, (unsigned)q.y, (unsigned)q.z, (unsigned)q.w);
             }
-        } else if (!A_KC && a16) {
-            const int m = m0 + 2 * (tid & 63), k0 = kc + (tid >> 6) * 8;
+        } else if constexpr (a16 && !A_KC) {
+            const int m = m0 + 2 * (tid & 63), k0 = kc + (tid >> 6) * KA2;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
+            for (int e = 0; e < KA2; ++e) {
                 const bool ok = m < g.M && k0 + e < kend;
                 sa2[e] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(ra, ok ? (int)(((unsigned)(k0 + e) * (unsigned)g.a_cs + (unsigned)m) * 2u) : (int)g.a_bytes, 0, 0);
             }
-        } else if (A_KC) {
+        } else if constexpr (A_KC) {
 #pragma unroll
             for (int p = 0; p < PA; ++p) {
-                const int row = m0 + p * 32 + (tid >> 3), k = kc + (tid & 7) * 4;
-                const bool ok = row < g.M && k < kend;
+                const int rl = p * RPP + tid / TPR, row = m0 + rl, k = kc + (tid % TPR) * 4;
+                const bool ok = rl < LBM && row < g.M && k < kend;
                 float q[4];
                 buf_load4(ra, ok ? ((unsigned)row * (unsigned)g.a_rs + (unsigned)k) * 4u : g.a_bytes, q);
 #pragma unroll
@@ -731,18 +746,18 @@ __global__ __launch_bounds__(256) void gemm_bfl_kernel(GemmArgs g) {
                 sa[e] = buf_load(ra, ok ? ((unsigned)(k0 + e) * (unsigned)g.a_cs + (unsigned)m) * 4u : g.a_bytes);
             }
         }
-        if (!B_KC && b16) {
-            const int n = n0 + 2 * (tid & 31), k0 = kc + (tid >> 5) * 4;
+        if constexpr (b16 && !B_KC) {
+            const int n = n0 + 2 * (tid & 31), k0 = kc + (tid >> 5) * KB2;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
+            for (int e = 0; e < KB2; ++e) {
                 const bool ok = n < n_real && k0 + e < kend;
                 sb2[e] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rb, ok ? (int)(((unsigned)(k0 + e) * (unsigned)g.b_rs + (unsigned)n) * 2u) : (int)g.b_bytes, 0, 0);
             }
-        } else if (B_KC) {
+        } else if constexpr (B_KC) {
 #pragma unroll
-            for (int p = 0; p < 2; ++p) {
-                const int n = n0 + p * 32 + (tid >> 3), k = kc + (tid & 7) * 4;
-                const bool ok = n < n_real && k < kend;
+            for (int p = 0; p < PB; ++p) {
+                const int nl = p * RPP + tid / TPR, n = n0 + nl, k = kc + (tid % TPR) * 4;
+                const bool ok = nl < LBN && n < n_real && k < kend;
                 float q[4];
                 buf_load4(rb, ok ? ((unsigned)n * (unsigned)g.b_cs + (unsigned)k) * 4u : g.b_bytes, q);
 #pragma unroll
@@ -758,35 +773,39 @@ __global__ __launch_bounds__(256) void gemm_bfl_kernel(GemmArgs g) {
         }
     };
     auto lstore = [&]() {
-        if (A_KC && a16) {
+        if constexpr (a16 && A_KC) {
 #pragma unroll
             for (int p = 0; p < PA16; ++p) {
-                const int rl = p * 64 + (tid >> 2);
-                if (rl < LBM) *reinterpret_cast<uint4*>(As + rl * BPK + (tid & 3) * 8) = sa16[p];
+                const int rl = p * RPP16 + tid / TPR16;
+                if (rl < LBM) *reinterpret_cast<uint4*>(As + rl * PK + (tid % TPR16) * 8) = sa16[p];
             }
-        } else if (!A_KC && a16) {
-            uint4 lo, hi;
-            lo.x = (sa2[0] & 0xffffu) | (sa2[1] << 16); hi.x = (sa2[0] >> 16) | (sa2[1] & 0xffff0000u);
-            lo.y = (sa2[2] & 0xffffu) | (sa2[3] << 16); hi.y = (sa2[2] >> 16) | (sa2[3] & 0xffff0000u);
-            lo.z = (sa2[4] & 0xffffu) | (sa2[5] << 16); hi.z = (sa2[4] >> 16) | (sa2[5] & 0xffff0000u);
-            lo.w = (sa2[6] & 0xffffu) | (sa2[7] << 16); hi.w = (sa2[6] >> 16) | (sa2[7] & 0xffff0000u);
+        } else if constexpr (a16 && !A_KC) {
+            unsigned short* dst = As + (2 * (tid & 63)) * PK + (tid >> 6) * KA2;
+#pragma unroll
+            for (int e = 0; e < KA2; e += 8) {
+                uint4 lo, hi;
+                lo.x = (sa2[e] & 0xffffu) | (sa2[e + 1] << 16);     hi.x = (sa2[e] >> 16) | (sa2[e + 1] & 0xffff0000u);
+                lo.y = (sa2[e + 2] & 0xffffu) | (sa2[e + 3] << 16); hi.y = (sa2[e + 2] >> 16) | (sa2[e + 3] & 0xffff0000u);
+                lo.z = (sa2[e + 4] & 0xffffu) | (sa2[e + 5] << 16); hi.z = (sa2[e + 4] >> 16) | (sa2[e + 5] & 0xffff0000u);
+                lo.w = (sa2[e + 6] & 0xffffu) | (sa2[e + 7] << 16); hi.w = (sa2[e + 6] >> 16) | (sa2[e + 7] & 0xffff0000u);
+                *reinterpret_cast<uint4*>(dst + e) = lo;
+                *reinterpret_cast<uint4*>(dst + PK + e) = hi;
+            }
             if (want_rowsum) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { rsum += __uint_as_float(sa2[e] << 16); rsum_hi += __uint_as_float(sa2[e] & 0xffff0000u); }
+                for (int e = 0; e < KA2; ++e) { rsum += __uint_as_float(sa2[e] << 16); rsum_hi += __uint_as_float(sa2[e] & 0xffff0000u); }
             }
-            unsigned short* dst = As + (2 * (tid & 63)) * BPK + (tid >> 6) * 8;
-            *reinterpret_cast<uint4*>(dst) = lo;
-            *reinterpret_cast<uint4*>(dst + BPK) = hi;
-        } else if (A_KC) {
+        } else if constexpr (A_KC) {
 #pragma unroll
             for (int p = 0; p < PA; ++p) {
+                const int rl = p * RPP + tid / TPR;
                 uint2 w;
                 w.x = pack2_bf16(sa[p * 4 + 0], sa[p * 4 + 1]);
                 w.y = pack2_bf16(sa[p * 4 + 2], sa[p * 4 + 3]);
-                *reinterpret_cast<uint2*>(As + (p * 32 + (tid >> 3)) * BPK + (tid & 7) * 4) = w;
+                if (rl < LBM) *reinterpret_cast<uint2*>(As + rl * PK + (tid % TPR) * 4) = w;
             }
         } else {
-            unsigned short* dst = As + (tid % LBM) * BPK + (tid / LBM) * KPA;
+            unsigned short* dst = As + (tid % LBM) * PK + (tid / LBM) * KPA;
             if (want_rowsum) {
 #pragma unroll
                 for (int e = 0; e < KPA; ++e) rsum += sa[e];
@@ -799,23 +818,27 @@ __global__ __launch_bounds__(256) void gemm_bfl_kernel(GemmArgs g) {
                 *reinterpret_cast<uint2*>(dst + e) = w;
             }
         }
-        if (!B_KC && b16) {
-            uint2 lo, hi;
-            lo.x = (sb2[0] & 0xffffu) | (sb2[1] << 16); hi.x = (sb2[0] >> 16) | (sb2[1] & 0xffff0000u);
-            lo.y = (sb2[2] & 0xffffu) | (sb2[3] << 16); hi.y = (sb2[2] >> 16) | (sb2[3] & 0xffff0000u);
-            unsigned short* dst = Bs + (2 * (tid & 31)) * BPK + (tid >> 5) * 4;
-            *reinterpret_cast<uint2*>(dst) = lo;
-            *reinterpret_cast<uint2*>(dst + BPK) = hi;
-        } else if (B_KC) {
+        if constexpr (b16 && !B_KC) {
+            unsigned short* dst = Bs + (2 * (tid & 31)) * PK + (tid >> 5) * KB2;
 #pragma unroll
-            for (int p = 0; p < 2; ++p) {
+            for (int e = 0; e < KB2; e += 4) {
+                uint2 lo, hi;
+                lo.x = (sb2[e] & 0xffffu) | (sb2[e + 1] << 16);     hi.x = (sb2[e] >> 16) | (sb2[e + 1] & 0xffff0000u);
+                lo.y = (sb2[e + 2] & 0xffffu) | (sb2[e + 3] << 16); hi.y = (sb2[e + 2] >> 16) | (sb2[e + 3] & 0xffff0000u);
+                *reinterpret_cast<uint2*>(dst + e) = lo;
+                *reinterpret_cast<uint2*>(dst + PK + e) = hi;
+            }
+        } else if constexpr (B_KC) {
+#pragma unroll
+            for (int p = 0; p < PB; ++p) {
+                const int nl = p * RPP + tid / TPR;
                 uint2 w;
                 w.x = pack2_bf16(sb[p * 4 + 0], sb[p * 4 + 1]);
                 w.y = pack2_bf16(sb[p * 4 + 2], sb[p * 4 + 3]);
-                *reinterpret_cast<uint2*>(Bs + (p * 32 + (tid >> 3)) * BPK + (tid & 7) * 4) = w;
+                if (nl < LBN) *reinterpret_cast<uint2*>(Bs + nl * PK + (tid % TPR) * 4) = w;
             }
         } else {
-            unsigned short* dst = Bs + (tid % LBN) * BPK + (tid / LBN) * KPB;
+            unsigned short* dst = Bs + (tid % LBN) * PK + (tid / LBN) * KPB;
 #pragma unroll
             for (int e = 0; e < KPB; e += 4) {
                 uint2 w;
@@ -833,18 +856,18 @@ __global__ __launch_bounds__(256) void gemm_bfl_kernel(GemmArgs g) {
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
 
     gload(kbeg);
-    for (int kc = kbeg; kc < kend; kc += LBK) {
+    for (int kc = kbeg; kc < kend; kc += BK) {
         lstore();
         __syncthreads();
-        if (kc + LBK < kend) gload(kc + LBK);
+        if (kc + BK < kend) gload(kc + BK);
 #pragma unroll
-        for (int st0 = 0; st0 < (KSPLIT ? 1 : 2); ++st0) {
-            const int st = KSPLIT ? ksel : st0;
+        for (int st0 = 0; st0 < (KSPLIT ? STEPS / 2 : STEPS); ++st0) {
+            const int st = KSPLIT ? ksel * (STEPS / 2) + st0 : st0;
             const int ks = st * 16 + half * 8;            // lane (r, h): k = 8h .. 8h+7 of the 16-k step
-            const bf16x8_t af = *reinterpret_cast<const bf16x8_t*>(As + (wrow + l31) * BPK + ks);
+            const bf16x8_t af = *reinterpret_cast<const bf16x8_t*>(As + (wrow + l31) * PK + ks);
 #pragma unroll
             for (int t = 0; t < TN; ++t) {
-                const bf16x8_t bfr = *reinterpret_cast<const bf16x8_t*>(Bs + (wcol + t * 32 + l31) * BPK + ks);
+                const bf16x8_t bfr = *reinterpret_cast<const bf16x8_t*>(Bs + (wcol + t * 32 + l31) * PK + ks);
                 acc[t] = mfma_32x32x16_bf16(af, bfr, acc[t]);
             }
         }
@@ -871,6 +894,63 @@ __global__ __launch_bounds__(256) void gemm_bfl_kernel(GemmArgs g) {
         if (ksel == 1) return;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[0][r] += red[((wave & 1) * 16 + r) * 64 + lane];
+    }
+    // bf16-stored outputs: 2-B stores per lane are store-issue bound (MI355X_MICROARCH.md: a `short` store costs ~12x a
+    // dwordx4 per byte; the decoder GEMM1 wrote its two 42 MB outputs at 1.7 TB/s) - the tile goes through LDS (the
+    // operand chunks are dead) and leaves as 16-B row pieces.  Needs whole 8-column groups (n_real, ld % 8 == 0).
+    if constexpr (IO16 && EPI != EPI_ATOMIC) if ((c16 || (EPI == EPI_BIAS_GELU && z16)) && (n_real % 8 == 0)) {
+        constexpr int CP = LBN + 8;                              // tile pitch (bf16)
+        static_assert(LBM * CP <= LBM * PK + LBN * PK, "the output tile reuses the operand chunks");
+        unsigned short* Cs = As;                                 // (As and Bs are adjacent __shared__ arrays: As alone fits for BK >= 64)
+        static_assert(CP <= PK, "output tile rows fit the A chunk rows");
+        float vz[TN][16], vc[TN][16];
+#pragma unroll
+        for (int t = 0; t < TN; ++t) {
+            const int col = n0 + wcol + t * 32 + l31;
+            const bool cok = col < n_real;
+            const float bias = ((EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) && cok) ? g.bias[col] : 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wrow + acc_row(r, half);
+                float v = acc[t][r] + bias;
+                vz[t][r] = v;
+                if (EPI == EPI_BIAS_GELU) v = gelu_erf(v);
+                if (EPI == EPI_MUL_GELU_GRAD) v *= (cok && row < g.M) ? gelu_erf_grad(ld1e(g.G, (long)row * g.ldg + col, g16)) : 0.0f;
+                vc[t][r] = v;
+            }
+        }
+        auto flush = [&](const float (&vals)[TN][16], float* dst, long ld, bool as16) {
+            if (!as16) {                                          // this output stays fp32: plain stores
+#pragma unroll
+                for (int t = 0; t < TN; ++t) {
+                    const int col = n0 + wcol + t * 32 + l31;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = m0 + wrow + acc_row(r, half);
+                        if (col < n_real && row < g.M) dst[(long)row * ld + col] = vals[t][r];
+                    }
+                }
+                return;
+            }
+            __syncthreads();                                      // the tile buffer is free (K loop / previous flush done)
+#pragma unroll
+            for (int t = 0; t < TN; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    Cs[(wrow + acc_row(r, half)) * PK + wcol + t * 32 + l31] = f_to_bf16(vals[t][r]);
+            __syncthreads();
+            unsigned short* out = reinterpret_cast<unsigned short*>(dst);
+#pragma unroll
+            for (int p = 0; p < LBM / 32; ++p) {
+                const int rl = p * 32 + (tid >> 3), c8 = (tid & 7) * 8;
+                const int row = m0 + rl, col = n0 + c8;
+                if (row < g.M && col < n_real)
+                    *reinterpret_cast<uint4*>(out + (long)row * ld + col) = *reinterpret_cast<const uint4*>(Cs + rl * PK + c8);
+            }
+        };
+        if (EPI == EPI_BIAS_GELU) flush(vz, g.Z, g.ldz, z16);
+        flush(vc, g.C, g.ldc, c16);
+        return;
     }
 #pragma unroll
     for (int t = 0; t < TN; ++t) {
@@ -1091,6 +1171,13 @@ bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 
 // 0 = not eligible; otherwise launches the LDS-staged kernel (called after prepare_gemm filled the
 // buffer extents).  Eligibility: layouts that allow 16-B coalesced staging, and enough work that
 // the tile pipeline pays (small layers stay on the latency-optimised register-direct kernel).
+// k per LDS chunk of gemm_bfl_kernel by tile height (see the kernel): 128-row tiles 64 (staging registers), smaller ones 128
+constexpr int BK128 = 64, BK64 = 128;        // bf16-stored operands (IO16)
+#ifndef PIT_BKF128
+#define PIT_BKF128 32
+#define PIT_BKF64 64
+#endif
+constexpr int BKF128 = PIT_BKF128, BKF64 = PIT_BKF64;     // fp32-stored operands: converted in registers on the way to LDS
 bool try_launch_gemm_lds(GemmArgs g, hipStream_t s) {
     static const int mode = getenv("PIT_LDS_GEMM") ? atoi(getenv("PIT_LDS_GEMM")) : 1;   // 0 off, 1 auto, 2 always when legal
     if (mode == 0) return false;
@@ -1106,6 +1193,9 @@ bool try_launch_gemm_lds(GemmArgs g, hipStream_t s) {
         if (g.a16 && !((a_kc && g.a_rs % 8 == 0 && g.K % 8 == 0) || (g.epi == EPI_ATOMIC && a_ic && g.a_cs % 2 == 0 && g.M % 2 == 0))) return false;
         if (g.b16 && !(g.epi == EPI_ATOMIC && b_ic && g.b_rs % 2 == 0 && n_real % 2 == 0)) return false;
         if ((g.c16 || g.z16 || g.g16) && g.epi == EPI_ATOMIC) return false;
+        // the storage-aware instantiation reads a bf16 A operand (and, row-reducing kind, a bf16 B): both are what the
+        // decoder tail hands it (pit_mlp_*: x, Z1/H and dZ1 are bf16 together)
+        if (!g.a16 || (g.epi == EPI_ATOMIC) != (g.b16 != 0)) return false;
     }
     const long work = (long)g.M * g.N * g.K;
     if (mode == 1 && !io16 && (work < (1L << 27) || g.N < 48)) return false;
@@ -1154,13 +1244,13 @@ bool try_launch_gemm_lds(GemmArgs g, hipStream_t s) {
 #define PIT_BFL(A_, B_, EPI_)                                                                                  \
     do {                                                                                                       \
         if (io16) {                                                                                            \
-            if (bm == 128) hipLaunchKernelGGL((gemm_bfl_kernel<128, A_, B_, EPI_, true>), grid, block, 0, s, g);   \
-            else if (bm == 64) hipLaunchKernelGGL((gemm_bfl_kernel<64, A_, B_, EPI_, true>), grid, block, 0, s, g); \
-            else hipLaunchKernelGGL((gemm_bfl_kernel<32, A_, B_, EPI_, true>), grid, block, 0, s, g);          \
+            if (bm == 128) hipLaunchKernelGGL((gemm_bfl_kernel<128, A_, B_, EPI_, true, BK128>), grid, block, 0, s, g);   \
+            else if (bm == 64) hipLaunchKernelGGL((gemm_bfl_kernel<64, A_, B_, EPI_, true, BK64>), grid, block, 0, s, g); \
+            else hipLaunchKernelGGL((gemm_bfl_kernel<32, A_, B_, EPI_, true, BK64>), grid, block, 0, s, g);    \
         }                                                                                                      \
-        else if (bm == 128) hipLaunchKernelGGL((gemm_bfl_kernel<128, A_, B_, EPI_>), grid, block, 0, s, g);    \
-        else if (bm == 64) hipLaunchKernelGGL((gemm_bfl_kernel<64, A_, B_, EPI_>), grid, block, 0, s, g);      \
-        else hipLaunchKernelGGL((gemm_bfl_kernel<32, A_, B_, EPI_>), grid, block, 0, s, g);                    \
+        else if (bm == 128) hipLaunchKernelGGL((gemm_bfl_kernel<128, A_, B_, EPI_, false, BKF128>), grid, block, 0, s, g); \
+        else if (bm == 64) hipLaunchKernelGGL((gemm_bfl_kernel<64, A_, B_, EPI_, false, BKF64>), grid, block, 0, s, g);    \
+        else hipLaunchKernelGGL((gemm_bfl_kernel<32, A_, B_, EPI_, false, BKF64>), grid, block, 0, s, g);      \
     } while (0)
     static const bool legacy_bf = getenv("PIT_BF16_LEGACY") != nullptr;      // the round-1 form: fp32 in LDS, 32x32x8 MFMA
 #define PIT_LDS(A_, B_, EPI_) do { if (g.bf16 && !legacy_bf) PIT_BFL(A_, B_, EPI_); else if (g.bf16) PIT_LDS_BF(A_, B_, EPI_, true); else PIT_LDS_BF(A_, B_, EPI_, false); } while (0)
@@ -1170,8 +1260,8 @@ bool try_launch_gemm_lds(GemmArgs g, hipStream_t s) {
         case 2: PIT_LDS(true, false, EPI_MUL_GELU_GRAD); break;
         case 3: PIT_LDS(true, false, EPI_STORE); break;
         default:
-            if (g.bf16 && !legacy_bf && io16) hipLaunchKernelGGL((gemm_bfl_kernel<128, false, false, EPI_ATOMIC, true>), grid, block, 0, s, g);
-            else if (g.bf16 && !legacy_bf) hipLaunchKernelGGL((gemm_bfl_kernel<128, false, false, EPI_ATOMIC>), grid, block, 0, s, g);
+            if (g.bf16 && !legacy_bf && io16) hipLaunchKernelGGL((gemm_bfl_kernel<128, false, false, EPI_ATOMIC, true, BK128>), grid, block, 0, s, g);
+            else if (g.bf16 && !legacy_bf) hipLaunchKernelGGL((gemm_bfl_kernel<128, false, false, EPI_ATOMIC, false, BKF128>), grid, block, 0, s, g);
             else if (g.bf16) hipLaunchKernelGGL((gemm_lds_kernel<128, false, false, EPI_ATOMIC, true>), grid, block, 0, s, g);
             else hipLaunchKernelGGL((gemm_lds_kernel<128, false, false, EPI_ATOMIC, false>), grid, block, 0, s, g);
             break;
