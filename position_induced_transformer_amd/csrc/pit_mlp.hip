@@ -903,23 +903,24 @@ __global__ __launch_bounds__(256) void gemm_bfl_kernel(GemmArgs g) {
         static_assert(LBM * CP <= LBM * PK + LBN * PK, "the output tile reuses the operand chunks");
         unsigned short* Cs = As;                                 // (As and Bs are adjacent __shared__ arrays: As alone fits for BK >= 64)
         static_assert(CP <= PK, "output tile rows fit the A chunk rows");
-        float vz[TN][16], vc[TN][16];
+        float biasv[TN];
 #pragma unroll
         for (int t = 0; t < TN; ++t) {
             const int col = n0 + wcol + t * 32 + l31;
-            const bool cok = col < n_real;
-            const float bias = ((EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) && cok) ? g.bias[col] : 0.0f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wrow + acc_row(r, half);
-                float v = acc[t][r] + bias;
-                vz[t][r] = v;
-                if (EPI == EPI_BIAS_GELU) v = gelu_erf(v);
-                if (EPI == EPI_MUL_GELU_GRAD) v *= (cok && row < g.M) ? gelu_erf_grad(ld1e(g.G, (long)row * g.ldg + col, g16)) : 0.0f;
-                vc[t][r] = v;
-            }
+            biasv[t] = ((EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) && col < n_real) ? g.bias[col] : 0.0f;
         }
-        auto flush = [&](const float (&vals)[TN][16], float* dst, long ld, bool as16) {
+        // value (t, r) of an output, formed from the accumulators when its tile is flushed (holding both outputs of the
+        // gelu layer in registers next to the accumulators cost an occupancy step: 164 + 32 registers)
+        auto value = [&](int t, int r, bool activated) {
+            float v = acc[t][r] + biasv[t];
+            if (EPI == EPI_BIAS_GELU && activated) v = gelu_erf(v);
+            if (EPI == EPI_MUL_GELU_GRAD) {
+                const int row = m0 + wrow + acc_row(r, half), col = n0 + wcol + t * 32 + l31;
+                v *= (col < n_real && row < g.M) ? gelu_erf_grad(ld1e(g.G, (long)row * g.ldg + col, g16)) : 0.0f;
+            }
+            return v;
+        };
+        auto flush = [&](bool activated, float* dst, long ld, bool as16) {
             if (!as16) {                                          // this output stays fp32: plain stores
 #pragma unroll
                 for (int t = 0; t < TN; ++t) {
@@ -927,7 +928,7 @@ __global__ __launch_bounds__(256) void gemm_bfl_kernel(GemmArgs g) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int row = m0 + wrow + acc_row(r, half);
-                        if (col < n_real && row < g.M) dst[(long)row * ld + col] = vals[t][r];
+                        if (col < n_real && row < g.M) dst[(long)row * ld + col] = value(t, r, activated);
                     }
                 }
                 return;
@@ -937,7 +938,7 @@ __global__ __launch_bounds__(256) void gemm_bfl_kernel(GemmArgs g) {
             for (int t = 0; t < TN; ++t)
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    Cs[(wrow + acc_row(r, half)) * PK + wcol + t * 32 + l31] = f_to_bf16(vals[t][r]);
+                    Cs[(wrow + acc_row(r, half)) * PK + wcol + t * 32 + l31] = f_to_bf16(value(t, r, activated));
             __syncthreads();
             unsigned short* out = reinterpret_cast<unsigned short*>(dst);
 #pragma unroll
@@ -948,8 +949,8 @@ __global__ __launch_bounds__(256) void gemm_bfl_kernel(GemmArgs g) {
                     *reinterpret_cast<uint4*>(out + (long)row * ld + col) = *reinterpret_cast<const uint4*>(Cs + rl * PK + c8);
             }
         };
-        if (EPI == EPI_BIAS_GELU) flush(vz, g.Z, g.ldz, z16);
-        flush(vc, g.C, g.ldc, c16);
+        if (EPI == EPI_BIAS_GELU) flush(false, g.Z, g.ldz, z16);
+        flush(true, g.C, g.ldc, c16);
         return;
     }
 #pragma unroll
