@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define PIT_ABI_VERSION 12
+#define PIT_ABI_VERSION 13
 #define PIT_DSCALE_SLOTS 1024 /* fp64 accumulators per head in pit_posatt_bwd's workspace */
 
 /* distance metric (dist2att variants) */
@@ -279,6 +279,12 @@ int pit_mlp_bwd_params(const float* x, long ldx, int rows, int n0, int n1, int n
                        int out_gelu, const float* d_y, long ld_dy,
                        float* d_w1, float* d_b1, float* d_w2, float* d_b2,
                        int accumulate, const float* scratch, int math_mode, void* stream);
+/* n postponed pit_mlp_bwd_params calls (each with accumulate = 1 when it is to share a launch) performed together: the
+ * small ones as ONE launch whose workgroups are dealt to the jobs (up to 8 per launch), the others by the launches
+ * pit_mlp_bwd_params would have made, in order.  `jobs` is a HOST array, read during the call.  What a backward pass in
+ * the latency regime does with its weight gradients: nothing downstream reads them, so they leave the dependent chain
+ * entirely and run once, chip-wide, when the pass ends (ops.DW_BATCH). */
+int pit_mlp_bwd_params_batch(int n, const struct pit_mlp_params_job* jobs, void* stream);
 /* 1 if postponing pit_mlp_bwd_params of this shape and handing it to the next pit_posatt_bwd as `rider` costs
  * nothing when the attention call cannot merge it (i.e. pit_mlp_bwd would have issued _data and _params as
  * separate launches anyway), else 0 (pit_mlp_bwd merges d_x with the reductions: keep the single call). */

@@ -58,6 +58,7 @@ SIGNATURES = {
     "pit_mlp_bwd_data": [_I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _L, _P, _L, _P, _I, _P],
     "pit_mlp_bwd_params": [_P, _L, _I, _I, _I, _I, _P, _I, _P, _L, _P, _P, _P, _P, _I, _P, _I, _P],
     "pit_mlp_bwd_params_deferrable": [_I, _I, _I, _I, _I, _L],
+    "pit_mlp_bwd_params_batch": [_I, _P, _P],
     "pit_rel_lp_loss_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P],
     "pit_rel_lp_loss_fwd_grad": [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _L, _P],
     "pit_rel_lp_loss_bwd": [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P],
@@ -68,7 +69,7 @@ SIGNATURES = {
     "pit_debug_mfma_tile": [_P, _P, _P, _P],
 }
 
-ABI_VERSION = 12       # PIT_ABI_VERSION of include/pit_hip.h this binding was written against
+ABI_VERSION = 13       # PIT_ABI_VERSION of include/pit_hip.h this binding was written against
 
 _lib = None
 

@@ -42,7 +42,9 @@ struct DwPair { GemmArgs g1, g2; int n1, n2, gx1, gy1, gx2, gy2; };
 // fills `out` and returns true when the job is small enough to ride along in another launch (pit_mlp.hip);
 // `waves` = waves per workgroup of the carrying launch (the row slabs are sized so that a wave reduces as many rows
 // as in the reductions' own 8-wave launch)
-bool plan_dw_pair(const pit_mlp_params_job& job, int waves, DwPair* out);
+// `target_wgs`: workgroups each of the two reductions aims for (its K range is split accordingly; 768 = the reductions' own
+// launch)
+bool plan_dw_pair(const pit_mlp_params_job& job, int waves, DwPair* out, int target_wgs = 768);
 
 }  // namespace pit_detail
 

@@ -46,6 +46,24 @@ __global__ __launch_bounds__(512) void gemm_rd_pair_kernel(GemmArgs g1, GemmArgs
     }
 }
 
+// the weight-gradient reductions of SEVERAL MLPs (up to DW_BATCH_MAX pairs) in ONE launch (pit_mlp_bwd_params_batch): the
+// small-regime backward pass postpones every MLP's reductions - nothing downstream reads them - and runs them together
+// when the pass ends, as one chip-filling grid instead of riders that lengthen every launch of the dependent chain
+constexpr int DW_BATCH_MAX = 8;                     // (8 x 488 B of DwPair + the header stay under the 4 KB kernel-argument limit)
+struct DwBatch { int n; int base[DW_BATCH_MAX + 1]; pit_detail::DwPair p[DW_BATCH_MAX]; };
+__global__ __launch_bounds__(512) void gemm_rd_batch_kernel(DwBatch b) {
+    int i = 0;
+    while (i + 1 < b.n && (int)blockIdx.x >= b.base[i + 1]) ++i;
+    const pit_detail::DwPair& w = b.p[i];
+    int id = (int)blockIdx.x - b.base[i];
+    if (id < w.n1) {
+        gemm_rd_body<1, EPI_ATOMIC>(w.g1, id % w.gx1, (id / w.gx1) % w.gy1, id / (w.gx1 * w.gy1));
+    } else {
+        id -= w.n1;
+        gemm_rd_body<1, EPI_ATOMIC>(w.g2, id % w.gx2, (id / w.gx2) % w.gy2, id / (w.gx2 * w.gy2));
+    }
+}
+
 // the three GEMMs that follow dZ1 in an MLP backward - dX = dZ1 W1 (EPI_STORE, on the critical path:
 // its workgroups come first) and the two weight-gradient reductions - are independent of each
 // other: one launch, so the small latency-bound grids share the chip
@@ -1281,7 +1299,7 @@ bool vec_ok(const float* p, long i_stride, long k_stride) {
 
 struct GemmLaunch { int tn, nwaves; dim3 grid; };
 
-int prepare_gemm(GemmArgs& g, GemmLaunch& L, int force_tn = 0, int force_waves = 0) {
+int prepare_gemm(GemmArgs& g, GemmLaunch& L, int force_tn = 0, int force_waves = 0, int target_wgs = 768) {
     const unsigned long long ab = ((unsigned long long)(g.M - 1) * g.a_rs + (unsigned long long)(g.K - 1) * g.a_cs + 1) * (g.a16 ? 2ull : 4ull);
     const int nb_cols = (g.ones_col >= 0) ? g.N - 1 : g.N;       // the ones column is virtual
     const unsigned long long bb = ((unsigned long long)(g.K - 1) * g.b_rs + (unsigned long long)(std::max(nb_cols, 1) - 1) * g.b_cs + 1) * (g.b16 ? 2ull : 4ull);
@@ -1303,7 +1321,7 @@ int prepare_gemm(GemmArgs& g, GemmLaunch& L, int force_tn = 0, int force_waves =
         // (fewer waves per workgroup than the usual 8 - a carrying launch with 256-thread workgroups: proportionally
         // shorter slabs, so that a wave's share of the rows, the critical path, stays what it is with 8)
         const int wscale = (force_waves > 0 && force_waves < 8) ? 8 / force_waves : 1;
-        splits = std::max(1, std::min((g.K + 127) / 128, (768 * wscale + tiles - 1) / tiles));
+        splits = std::max(1, std::min((g.K + 127) / 128, (target_wgs * wscale + tiles - 1) / tiles));
         // every split costs one fp32 atomic per output element: long reductions keep slabs >= 512
         if (g.K > 4096) splits = std::max(1, std::min(splits, g.K * wscale / 512));
     }
@@ -1451,7 +1469,7 @@ int launch_dz1(int rows, int n1, int n2, const float* w2, const float* z1, const
 
 // the reductions of a postponed pit_mlp_bwd_params, laid out for a launch that carries them along
 // (pit_posatt.hip: posatt_bwd_pair_dw_kernel); same tiling as launch_gemm_pair_atomic
-bool pit_detail::plan_dw_pair(const pit_mlp_params_job& j, int waves, DwPair* out) {
+bool pit_detail::plan_dw_pair(const pit_mlp_params_job& j, int waves, DwPair* out, int target_wgs) {
     static const bool off = getenv("PIT_NO_DW_RIDER") != nullptr;
     if (off || !j.accumulate) return false;
     if (!j.x || !j.h || !j.d_y || !j.d_w1 || !j.d_b1 || !j.d_w2 || !j.d_b2 || !j.scratch) return false;
@@ -1465,12 +1483,42 @@ bool pit_detail::plan_dw_pair(const pit_mlp_params_job& j, int waves, DwPair* ou
     t_call_math = j.math_mode;
     GemmLaunch L1, L2;
     const int fw = waves >= 8 ? 8 : (waves >= 4 ? 4 : 2);
-    const bool ok = prepare_gemm(out->g1, L1, 1, fw) == 0 && prepare_gemm(out->g2, L2, 1, fw) == 0;
+    const bool ok = prepare_gemm(out->g1, L1, 1, fw, target_wgs) == 0 && prepare_gemm(out->g2, L2, 1, fw, target_wgs) == 0;
     t_call_math = saved;
     if (!ok) return false;
     out->n1 = L1.grid.x * L1.grid.y * L1.grid.z; out->n2 = L2.grid.x * L2.grid.y * L2.grid.z;
     out->gx1 = L1.grid.x; out->gy1 = L1.grid.y; out->gx2 = L2.grid.x; out->gy2 = L2.grid.y;
     return true;
+}
+
+// include/pit_hip.h: n postponed pit_mlp_bwd_params calls performed together
+extern "C" int pit_mlp_bwd_params_batch(int n, const pit_mlp_params_job* jobs, void* stream) {
+    if (n <= 0) return 0;
+    if (!jobs) return PIT_ERR_NULL;
+    hipStream_t s = (hipStream_t)stream;
+    int i = 0;
+    while (i < n) {
+        DwBatch b;
+        b.n = 0; b.base[0] = 0;
+        // consecutive jobs small enough to share a launch; a job that is not (or the seventh) ends the group
+        static const int target = getenv("PIT_DW_BATCH_WGS") ? atoi(getenv("PIT_DW_BATCH_WGS")) : 768;
+        while (i < n && b.n < DW_BATCH_MAX && pit_detail::plan_dw_pair(jobs[i], 8, &b.p[b.n], target)) {
+            b.base[b.n + 1] = b.base[b.n] + b.p[b.n].n1 + b.p[b.n].n2;
+            ++b.n; ++i;
+        }
+        if (b.n > 0) {
+            static bool once = ((void)hipFuncSetAttribute((const void*)gemm_rd_batch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 98304), true);
+            (void)once;
+            hipLaunchKernelGGL(gemm_rd_batch_kernel, dim3((unsigned)b.base[b.n]), dim3(512), (size_t)8 * 16 * 64 * sizeof(float), s, b);
+            PIT_CHECK_LAUNCH();
+        }
+        if (i < n && b.n < DW_BATCH_MAX) {               // this one does not ride: its own launches
+            const pit_mlp_params_job& j = jobs[i++];
+            if (int rc = pit_mlp_bwd_params(j.x, j.ldx, j.rows, j.n0, j.n1, j.n2, j.h, j.out_gelu, j.d_y, j.ld_dy, j.d_w1, j.d_b1,
+                                            j.d_w2, j.d_b2, j.accumulate, j.scratch, j.math_mode, stream)) return rc;
+        }
+    }
+    return 0;
 }
 
 // include/pit_hip.h: the shapes whose forward / backward run entirely on the kernels that honour the PIT_IO_* flags (the

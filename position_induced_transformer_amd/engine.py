@@ -101,11 +101,14 @@ class TrainStep:
 
     def _step(self) -> None:
         self._early_pending = False
-        ops._PROCESSOR_HOOK[0] = self._on_processor_block if (self.buckets == 2 and self.all_reduce) else None
+        early = self.buckets == 2 and self.all_reduce
+        ops._PROCESSOR_HOOK[0] = self._on_processor_block if early else None
+        batch, ops.DW_BATCH = ops.DW_BATCH, (ops.DW_BATCH and not early)     # the early bucket needs its gradients before the end
         try:
             self._step_body()
         finally:
             ops._PROCESSOR_HOOK[0] = None
+            ops.DW_BATCH = batch
 
     def _step_body(self) -> None:
         out = self.model(self.mesh_in, self.func_in, self.mesh_out)

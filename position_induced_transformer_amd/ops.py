@@ -204,7 +204,16 @@ def _defer_head_finish(work, d_head, head, scale, n_head: int, flags: int) -> No
 # runs mlp -> attention, so in the backward the attention launch that consumes the MLP's d_x can carry the
 # MLP's reductions along - three small latency-bound grids in one launch.  In-place gradient mode only.
 MLP_PARAMS_RIDER = os.environ.get("PIT_DW_RIDER", "1") != "0"
+# Round 3: DW_BATCH (opt-in, PIT_DW_BATCH=1) - the postponed jobs of a pass are not carried by anybody but COLLECTED and
+# performed together by one launch when the pass ends (pit_mlp_bwd_params_batch).  Riders lengthen every launch of the
+# dependent chain (the fused block backward: 8.7 us alone, 16.2 us with its riders), but the reductions cost the same
+# chip time wherever they run: measured on MI355X, batch vs riders - Darcy b=8 0.2131 vs 0.2169 ms/step, Burgers 0.2097
+# vs 0.2083, Sod 0.1307 vs 0.1286, Darcy b=32 0.4357 vs 0.4362, Darcy + Adam 35.0 k vs 35.0 k samples/s: neutral, so the
+# riders stay the default.  Never used by a two-bucket data-parallel step (engine.TrainStep), which needs the early
+# bucket's gradients before the pass ends.
+DW_BATCH = os.environ.get("PIT_DW_BATCH", "0") != "0"
 _PENDING_DW = {}          # graph-task id -> job = (MlpParamsJob, keep-alive tensors, stream it was prepared on) or None
+_PENDING_BATCH = {}       # graph-task id -> [job, ...]  (DW_BATCH)
 _DEFERRABLE = {}
 
 
@@ -234,7 +243,37 @@ def _dw_end_of_pass(task: int) -> None:
     _PENDING_DW.pop(task, None)
 
 
+def _dw_batch_flush(task: int) -> None:
+    """End-of-backward callback (DW_BATCH): every weight-gradient job the pass postponed, in one call."""
+    jobs = _PENDING_BATCH.pop(task, [])
+    by_stream = {}
+    for job in jobs:
+        by_stream.setdefault(job[2], []).append(job)
+    for stream, grp in by_stream.items():
+        arr = (_lib.MlpParamsJob * len(grp))(*[j[0] for j in grp])
+        cur = torch.cuda.current_stream(stream.device)
+        with torch.cuda.stream(stream):
+            rc = _lib.lib().pit_mlp_bwd_params_batch(len(grp), ctypes.cast(arr, ctypes.c_void_p), stream.cuda_stream)
+        _lib.check(rc, "pit_mlp_bwd_params_batch")
+        if cur != stream:
+            cur.wait_stream(stream)
+
+
+def _dw_batch_add(st, keep, device) -> None:
+    task = _graph_task()
+    lst = _PENDING_BATCH.get(task)
+    if lst is None:
+        while len(_PENDING_BATCH) >= _MAX_PENDING_TASKS:      # lists of passes that died before their callback
+            del _PENDING_BATCH[next(iter(_PENDING_BATCH))]
+        lst = _PENDING_BATCH[task] = []
+        torch.autograd.Variable._execution_engine.queue_callback(lambda: _dw_batch_flush(task))
+    lst.append((st, keep, torch.cuda.current_stream(device)))
+
+
 def _dw_defer(st, keep, device) -> None:
+    if DW_BATCH:
+        _dw_batch_add(st, keep, device)
+        return
     task = _graph_task()
     # a job ANOTHER pass left for the same gradient slots: that pass raised before its end-of-pass callback ran - its
     # gradients are void (two live passes accumulating into one .grad would be a race in torch itself)
@@ -951,6 +990,7 @@ class _Processor(torch.autograd.Function):
                 ws = torch.zeros(H * 1024, device=dev, dtype=torch.float64)
             work.append(ws)
         # a large job the pass has postponed (the decoder MLP's weight gradients): one row slice per block launch
+        # (rider mode; with DW_BATCH nothing rides: every job goes to the end-of-pass batch)
         extra = _dw_take(dev)
         slices = []
         if extra is not None:
@@ -978,9 +1018,13 @@ class _Processor(torch.autograd.Function):
                 prev = (None, None, None, None, 0, 0, None, 0, None, dx.data_ptr(), D)
             k = n - 1 - i                              # launch order
             job2 = ctypes.cast(ctypes.pointer(slices[k]), ctypes.c_void_p) if k < len(slices) else None
+            batched = DW_BATCH and w_grads[i] is None
+            if batched:                                # the block's own reductions join the pass's batch
+                _dw_batch_add(job, (bufs[i], hh, scratch[i], dw1, db1, dw2, db2), dev)
             rc = L_.pit_block_bwd(E[i].data_ptr(), inv[i].data_ptr(), Q[i].data_ptr(), L, H, D, b, dxc[i].data_ptr(),
                                   bufs[i].data_ptr(), work[i].data_ptr(), *prev,
-                                  ctypes.cast(ctypes.pointer(job), ctypes.c_void_p), job2, ctx.math, _lib.stream_ptr())
+                                  None if batched else ctypes.cast(ctypes.pointer(job), ctypes.c_void_p), job2, ctx.math,
+                                  _lib.stream_ptr())
             _lib.check(rc, "pit_block_bwd")
             if _PROCESSOR_HOOK[0] is not None:
                 _PROCESSOR_HOOK[0](i)                       # (block i's weight gradients are now enqueued)
