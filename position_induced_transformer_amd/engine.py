@@ -102,7 +102,7 @@ class TrainStep:
     def _step(self) -> None:
         self._early_pending = False
         early = self.buckets == 2 and self.all_reduce
-        ops._PROCESSOR_HOOK[0] = self._on_processor_block if early else None
+        ops._PROCESSOR_HOOK[0] = (self._on_processor_block, self._early_block) if early else None
         batch, ops.DW_BATCH = ops.DW_BATCH, (ops.DW_BATCH and not early)     # the early bucket needs its gradients before the end
         try:
             self._step_body()
@@ -147,7 +147,23 @@ class TrainStep:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph, stream=side):
+        # A data-parallel step is captured in THREAD-LOCAL error mode, after the process group's watchdog has let go of
+        # the warm-up collectives.  That thread polls the events of every collective issued so far with hipEventQuery
+        # every 100 ms until it has seen them complete.  Under the default global mode HIP refuses the query while ANY
+        # stream captures ("operation not permitted when stream is capturing") and, in every mode, for an event whose
+        # stream has since JOINED a capture - as RCCL's internal stream does when the step's all-reduce is captured
+        # (tools/micro/capture_query_probe.py).  The watchdog rethrows and the process aborts: one capture in eight on
+        # MI355X, when a poll fell inside the capture window.  All work is complete after the synchronize above; a few
+        # poll periods later the watchdog's list is empty.  Launches from autograd's worker thread are still captured:
+        # the mode only decides whose unsafe calls are refused, not what the stream records.
+        mode = "global"
+        if self.all_reduce:
+            mode = "thread_local"
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized() and dist.get_backend() != "gloo":
+                import time
+                time.sleep(0.5)
+        with torch.cuda.graph(graph, stream=side, capture_error_mode=mode):
             self._step()
         ops.assert_frozen_since_capture()     # route 'host': the graph must not update an lmda whose scale it baked in
         self.graph = graph

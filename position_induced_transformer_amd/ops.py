@@ -996,7 +996,9 @@ class _Processor(torch.autograd.Function):
         if extra is not None:
             st = extra[0]
             if not st.out_gelu and st.accumulate and (st.math_mode & 0xff) == 0:
-                slices = _dw_slices(extra, n)
+                # a two-bucket step reduces the postponed job's gradients right after block `complete_by`: every
+                # slice must ride in a launch up to that one
+                slices = _dw_slices(extra, n if _PROCESSOR_HOOK[0] is None else max(1, n - _PROCESSOR_HOOK[0][1]))
             else:
                 _dw_run(extra)
         # top of the chain: the last block's MLP backward (data path) from d_out
@@ -1027,7 +1029,7 @@ class _Processor(torch.autograd.Function):
                                   _lib.stream_ptr())
             _lib.check(rc, "pit_block_bwd")
             if _PROCESSOR_HOOK[0] is not None:
-                _PROCESSOR_HOOK[0](i)                       # (block i's weight gradients are now enqueued)
+                _PROCESSOR_HOOK[0][0](i)                    # (block i's weight gradients are now enqueued)
         # d(lmda): deferred layers are finished by the pass's one finishing launch; the others here, in one launch
         d_heads = [None] * n
         now = [i for i in range(n) if not defer[i]]
@@ -1054,7 +1056,10 @@ class _Processor(torch.autograd.Function):
         return tuple(grads)
 
 
-_PROCESSOR_HOOK = [None]      # engine.TrainStep(all_reduce_buckets=2): called with the block index after its backward launch
+# engine.TrainStep(all_reduce_buckets=2): (callback, complete_by) - the callback is called with the block index after each
+# block's backward launch; everything the pass postponed before the processor (the decoder MLP's weight gradients) must be
+# enqueued by the launch of block `complete_by`, after which the step all-reduces those gradients on its second stream
+_PROCESSOR_HOOK = [None]
 
 
 @torch.compiler.disable

@@ -155,11 +155,12 @@ def test_bench_under_torch_distributed_run_one_rank_captures_the_rccl_allreduce(
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "5", "--warmup", "2",
            "--no-extras", "--no-cpu-baseline"] + extra
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
-    assert res.returncode == 0, res.stderr[-3000:]
+    said = "\n--- child stdout ---\n" + res.stdout[-3000:] + "\n--- child stderr ---\n" + res.stderr[-6000:]
+    assert res.returncode == 0, said
     lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, res.stdout[-2000:]
+    assert len(lines) == 1, said
     rec = json.loads(lines[0])
-    assert rec["config"]["launch"] == "hipgraph", rec["config"]
+    assert rec["config"]["launch"] == "hipgraph", said
     assert rec["config"]["allreduce"]["backend"] == "nccl" and rec["config"]["allreduce"]["captured"] is True, rec["config"]
     assert rec["config"]["allreduce"]["buckets"] == (2 if extra else 1)
     assert rec["n_gpus"] == 1 and rec["value"] > 0
@@ -396,3 +397,108 @@ def test_weight_gradient_batch_launch_equals_the_riders(task, batch):
     assert float(got[True][0].abs().max()) > 0
     assert gio.rel_l2(got[False][0].cpu().numpy(), got[True][0].cpu().numpy()) <= 2e-6
     assert gio.rel_l2(got[False][0].cpu().numpy(), got[False][1].cpu().numpy()) <= 2e-6
+
+
+# --------------------------------------------------------------------------- two-bucket exchange: nothing lands after its reduce
+@pytest.mark.parametrize("task,batch", [("darcy", 8), ("vorticity", 2), ("elasticity", 4)])
+@pytest.mark.parametrize("graph", [False, True], ids=["eager", "hipgraph"])
+def test_two_bucket_step_reduces_only_finished_gradients(task, batch, graph):
+    """A one-process stand-in for the sum over two identical ranks: the collective DOUBLES the bucket it is given, in
+    stream order, exactly where the step issues its all-reduce.  A weight-gradient contribution enqueued AFTER the early
+    bucket's reduce (a rider in a later launch) would be added undoubled - the two-bucket step must give the same
+    2 x gradient as the one-bucket step, eagerly and replayed."""
+    from position_induced_transformer_amd.engine import TrainStep
+    model, b4, meta = _model_and_batch(task, 31, batch)
+    got = {}
+    for buckets in (1, 2):
+        step = TrainStep(model, b4, meta["out_dim"], meta["p"], all_reduce=True, all_reduce_buckets=buckets)
+        assert step.buckets == buckets
+        flat = step.flat
+
+        def doubling(average=False, group=None, part="all", flat=flat):
+            if part != "tail":
+                flat.attach()
+            buf = flat.flat if part == "all" else (flat.flat[flat.tail_start:] if part == "tail" else flat.flat[:flat.tail_start])
+            buf.mul_(2.0)
+        flat.all_reduce = doubling
+        if graph:
+            step.capture()
+            for _ in range(3):
+                step.replay()
+        else:
+            for _ in range(3):
+                step.run_eager()
+        torch.cuda.synchronize()
+        got[buckets] = {k: q.grad.detach().clone() for k, q in model.named_parameters()}
+        if step._early_hook is not None:
+            step._early_hook.remove()
+        for q in model.parameters():
+            q.grad = None
+    plain = TrainStep(model, b4, meta["out_dim"], meta["p"])
+    plain.run_eager()
+    torch.cuda.synchronize()
+    for k, q in model.named_parameters():
+        tol = 2e-4 if k.endswith("lmda") else 2e-5
+        assert float(q.grad.abs().max()) > 0, k
+        assert gio.rel_l2((2.0 * q.grad).cpu().numpy(), got[1][k].cpu().numpy()) <= tol, ("one bucket", k)
+        assert gio.rel_l2((2.0 * q.grad).cpu().numpy(), got[2][k].cpu().numpy()) <= tol, ("two buckets", k)
+
+
+def test_data_parallel_capture_tolerates_another_thread_polling_events():
+    """The intermittent abort of the captured RCCL step (1 run in 8): ProcessGroupNCCL's watchdog thread calls
+    hipEventQuery on the warm-up collectives' events while the step is being captured, which HIP refuses under the
+    default GLOBAL capture error mode (tools/micro/capture_query_probe.py shows the three modes side by side).  A
+    data-parallel TrainStep captures in thread-local mode: a second thread polling an event for the whole capture must
+    not fail and must not invalidate the capture."""
+    import threading
+    from position_induced_transformer_amd.engine import TrainStep
+    model, b4, meta = _model_and_batch("darcy", 41, 4)
+    ev, other = torch.cuda.Event(), torch.cuda.Stream()
+    with torch.cuda.stream(other):
+        torch.zeros(8, device="cuda").add_(1)
+        ev.record(other)
+    torch.cuda.synchronize()
+
+    def capture_while_polling(all_reduce):
+        stop, errors, polls = threading.Event(), [], [0]
+
+        def poll():
+            while not stop.is_set():
+                try:
+                    ev.query()
+                    polls[0] += 1
+                except Exception as exc:
+                    errors.append(repr(exc))
+                    return
+        step = TrainStep(model, b4, meta["out_dim"], meta["p"], all_reduce=all_reduce)
+        step._step()                                    # (allocations and caches before the poller starts)
+        torch.cuda.synchronize()
+        orig = step._step
+
+        def slow_step():                                # hold the capture window open long enough to be polled
+            orig()
+            n = polls[0]
+            import time
+            t0 = time.time()
+            while polls[0] < n + 50 and not errors and time.time() - t0 < 5.0:
+                time.sleep(0.001)
+        t = threading.Thread(target=poll)
+        t.start()
+        failed = None
+        try:
+            step._step = slow_step
+            step.capture(warmup=1)
+        except Exception as exc:                        # (global mode: the refused query may also invalidate the capture)
+            failed = exc
+        finally:
+            stop.set()
+            t.join()
+        torch.cuda.synchronize()
+        if all_reduce:
+            assert failed is None, failed
+            step.replay()
+            torch.cuda.synchronize()
+            assert torch.isfinite(step.loss)
+        return errors
+
+    assert capture_while_polling(True) == []
