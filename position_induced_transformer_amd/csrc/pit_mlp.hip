@@ -626,6 +626,176 @@ __global__ __launch_bounds__(256) void gemm_lds_kernel(GemmArgs g) {
 }
 
 // ------------------------------------------------------------------------------------
+// Row-reducing GEMM of the weight gradients, fp32 (round 3): C[m][n] += sum_k A[k][m] B[k][n] over this workgroup's K
+// slab, both operands i-contiguous in memory (A = dZ, B = the layer input; K = rows of the batch >> M, N).
+// gemm_lds_kernel<128, false, false, EPI_ATOMIC> ran these at 25-45 % MFMA busy: a 128-row tile whatever M is (M = 64:
+// half of the waves multiplied zeros), two barriers and ONE chunk of prefetch per 32 k.  Here
+//  * tiles are 64 RM x 64 RN (2 x 2 waves of (32 RM) x (32 RN)), chosen per shape so that no wave multiplies padding;
+//    row tile t of a wave = rows {RM l + t} (INTERLEAVED: one LDS read of RM consecutive floats is the lane's A operand
+//    for all its row tiles); column tiles stay contiguous - the fp32 atomics of the epilogue run at a fraction of their
+//    rate when a wave's 32 lanes are 8 or 12 B apart (measured: 127 us against 30 for the Darcy b=256 layer);
+//  * both operand images are [k][i], written by the coalesced 16-B global loads as they are (no transpose, no padding);
+//  * LDS is double-buffered: one barrier per chunk, the next chunk's global loads are in flight during the whole
+//    contraction of the current one, whose LDS reads run one k-step ahead of the MFMAs;
+//  * the K chunks are dealt to the slabs as evenly as whole chunks allow (slab s = chunks [s C / S, (s+1) C / S)) and
+//    S x tiles never exceeds the workgroups the chip holds at once - one more and the launch takes two rounds;
+//  * the slabs of one tile set are dealt to ONE XCD (grid id -> (slab, tile) below): the operand rows a slab's tiles
+//    share come from HBM once.
+// Bias gradient = row sums of A, accumulated from the fragments by the first column block (as gemm_lds_kernel).
+#ifdef PIT_STAMPS
+__device__ unsigned long long pit_mlp_stamps[64];
+__device__ unsigned long long pit_mlp_wgrec[4096 * 4];     // per workgroup: entry, exit (100 MHz), HW_ID, XCC_ID
+#define MREC(slot_) do { if (threadIdx.x == 0 && tiles > 1 && blockIdx.x < 4096) {                                        \
+        pit_mlp_wgrec[blockIdx.x * 4 + (slot_)] = __builtin_amdgcn_s_memrealtime();                                       \
+        if ((slot_) == 0) { pit_mlp_wgrec[blockIdx.x * 4 + 2] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)); \
+                            pit_mlp_wgrec[blockIdx.x * 4 + 3] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)); } } } while (0)
+#define MSTAMP(i_) do { if (threadIdx.x == 0 && tiles > 1) {       /* (diagnostic: the multi-tile launch = dW1) */ \
+     const unsigned long long t_ = __builtin_amdgcn_s_memtime();               \
+        if (blockIdx.x == 8) pit_mlp_stamps[i_] = t_;                                                                      \
+        if (blockIdx.x == 8 && (i_) == 0) pit_mlp_stamps[57] = __builtin_amdgcn_s_memrealtime();                            \
+        if (blockIdx.x == 8 && (i_) == 61) pit_mlp_stamps[58] = __builtin_amdgcn_s_memrealtime();                           \
+        if ((i_) == 0) atomicMin(&pit_mlp_stamps[62], __builtin_amdgcn_s_memrealtime());   /* (s_memtime: one per XCD) */  \
+        if ((i_) == 0) atomicMax(&pit_mlp_stamps[59], __builtin_amdgcn_s_memrealtime());                                    \
+        if ((i_) == 61) atomicMin(&pit_mlp_stamps[56], __builtin_amdgcn_s_memrealtime());                                   \
+        if ((i_) == 61) atomicMax(&pit_mlp_stamps[63], __builtin_amdgcn_s_memrealtime()); } } while (0)
+#else
+#define MSTAMP(i_) do { } while (0)
+#define MREC(slot_) do { } while (0)
+#endif
+template <int RM, int RN, int BK>
+__global__ __launch_bounds__(256) void gemm_rr_kernel(GemmArgs g1, GemmArgs g2, int tx1, int T1, int tx2, int T2, int slabs,
+                                                      int nchunks) {
+    constexpr int BM = 64 * RM, BN = 64 * RN;
+    constexpr int PA = BK * BM / 1024, PB = BK * BN / 1024;         // 16-B loads per thread and chunk
+    constexpr int NA = (RM * RN == 1) ? 2 : 1;     // a lone tile alternates between two accumulators: no dependent MFMA chain
+    static_assert(PA >= 1 && PB >= 1 && BK % 4 == 0, "chunk shape");
+    __shared__ __attribute__((aligned(16))) float As[2][BK * BM];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BK * BN];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    // work item w = slab * (T1 + T2) + tile, dealt to the XCDs in CONTIGUOUS ranges (hardware deals workgroup ids round-robin):
+    // every XCD gets the same number of items, and the tiles of a slab - which share operand rows - mostly meet in one L2
+    const int tiles = T1 + T2, P = tiles * slabs, Q = (P + 7) / 8;
+    const int w = (blockIdx.x & 7) * Q + (blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= Q || w >= P) return;
+    const int slab = w / tiles, tile_all = w % tiles;
+    const bool first = tile_all < T1;
+    const GemmArgs& g = first ? g1 : g2;
+    const int tile = first ? tile_all : tile_all - T1, tiles_x = first ? tx1 : tx2;
+    const int bx = tile % tiles_x, by = tile / tiles_x;
+    const int m0 = by * BM, n0 = bx * BN;
+    const int wm = (wave & 1) * 32 * RM, wn = (wave >> 1) * 32 * RN;
+    const int kbeg = (int)((long)slab * nchunks / slabs) * BK;
+    const int kend = min(g.K, (int)((long)(slab + 1) * nchunks / slabs) * BK);
+    const int n_real = g.ones_col >= 0 ? g.N - 1 : g.N;
+    const __amdgpu_buffer_rsrc_t ra = make_rsrc(g.A, g.a_bytes);
+    const __amdgpu_buffer_rsrc_t rb = make_rsrc(g.B, g.b_bytes);
+
+    float sa[PA][4], sb[PB][4];
+    auto gload = [&](int kc) {
+#pragma unroll
+        for (int p = 0; p < PA; ++p) {
+            const int q = p * 256 + tid, k = kc + q / (BM / 4), m = m0 + (q % (BM / 4)) * 4;
+            const bool ok = k < kend && m < g.M;
+            buf_load4(ra, ok ? ((unsigned)k * (unsigned)g.a_cs + (unsigned)m) * 4u : g.a_bytes, sa[p]);
+        }
+#pragma unroll
+        for (int p = 0; p < PB; ++p) {
+            const int q = p * 256 + tid, k = kc + q / (BN / 4), n = n0 + (q % (BN / 4)) * 4;
+            const bool ok = k < kend && n < n_real;
+            buf_load4(rb, ok ? ((unsigned)k * (unsigned)g.b_rs + (unsigned)n) * 4u : g.b_bytes, sb[p]);
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int p = 0; p < PA; ++p)
+            *reinterpret_cast<float4*>(&As[buf][(p * 256 + tid) * 4]) = make_float4(sa[p][0], sa[p][1], sa[p][2], sa[p][3]);
+#pragma unroll
+        for (int p = 0; p < PB; ++p)
+            *reinterpret_cast<float4*>(&Bs[buf][(p * 256 + tid) * 4]) = make_float4(sb[p][0], sb[p][1], sb[p][2], sb[p][3]);
+    };
+
+    f32x16 acc[RM][RN][NA];
+#pragma unroll
+    for (int t = 0; t < RM; ++t)
+#pragma unroll
+        for (int u = 0; u < RN; ++u)
+#pragma unroll
+            for (int x = 0; x < NA; ++x)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][u][x][r] = 0.0f;
+    const bool want_rowsum = g.ones_col >= 0 && bx == 0 && wn == 0;
+    float rsum[RM];
+#pragma unroll
+    for (int t = 0; t < RM; ++t) rsum[t] = 0.0f;
+
+    MSTAMP(0);
+    MREC(0);
+    gload(kbeg);
+    lstore(0);
+    __syncthreads();
+    MSTAMP(1);
+    int cur = 0, chunk_i = 0;
+    for (int kc = kbeg; kc < kend; kc += BK, ++chunk_i) {
+        const bool more = kc + BK < kend;
+        if (more) gload(kc + BK);
+        const float* as = &As[cur][half * BM + wm + RM * l31];          // this half-wave's k of a step: 2 st + half
+        const float* bs = &Bs[cur][half * BN + wn + l31];
+        float av[2][RM], bv[2][RN];
+        auto fetch = [&](int st, float (&a_)[RM], float (&b_)[RN]) {
+#pragma unroll
+            for (int t = 0; t < RM; ++t) a_[t] = as[2 * st * BM + t];
+#pragma unroll
+            for (int u = 0; u < RN; ++u) b_[u] = bs[2 * st * BN + 32 * u];
+        };
+        fetch(0, av[0], bv[0]);
+#pragma unroll
+        for (int st = 0; st < BK / 2; ++st) {
+            if (st + 1 < BK / 2) fetch(st + 1, av[(st + 1) & 1], bv[(st + 1) & 1]);
+            if (want_rowsum) {
+#pragma unroll
+                for (int t = 0; t < RM; ++t) rsum[t] += av[st & 1][t];
+            }
+#pragma unroll
+            for (int t = 0; t < RM; ++t)
+#pragma unroll
+                for (int u = 0; u < RN; ++u)
+                    acc[t][u][st % NA] = mfma_32x32x2(av[st & 1][t], bv[st & 1][u], acc[t][u][st % NA]);
+        }
+        if (chunk_i < 20) MSTAMP(2 + 2 * chunk_i);
+        if (more) lstore(cur ^ 1);
+        __syncthreads();
+        if (chunk_i < 20) MSTAMP(3 + 2 * chunk_i);
+        cur ^= 1;
+    }
+    MSTAMP(60);
+
+    if (want_rowsum) {
+#pragma unroll
+        for (int t = 0; t < RM; ++t) {
+            const float v = rsum[t] + __shfl_xor(rsum[t], 32);
+            const int row = m0 + wm + RM * l31 + t;
+            if (half == 0 && row < g.M) atomicAdd(g.C2 + row, v);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < RM; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = m0 + wm + RM * acc_row(r, half) + t;
+            if (row >= g.M) continue;
+#pragma unroll
+            for (int u = 0; u < RN; ++u) {
+                const int col = n0 + wn + 32 * u + l31;
+                const float v = NA == 2 ? acc[t][u][0][r] + acc[t][u][NA - 1][r] : acc[t][u][0][r];
+                if (col < n_real) atomicAdd(g.C + (long)row * g.ldc + col, v);
+            }
+        }
+    MSTAMP(61);
+    MREC(1);
+}
+
+// ------------------------------------------------------------------------------------
 // Large-regime GEMM of the bf16 math mode: operands are rounded to bf16 ONCE, while they are staged
 // into LDS, and the contraction runs on v_mfma_f32_32x32x16_bf16 (16 k per instruction, fp32
 // accumulation): 1/16 of the matrix-pipe time of the fp32 form and half the LDS bytes.
@@ -1197,6 +1367,44 @@ constexpr int BK128 = 64, BK64 = 128;        // bf16-stored operands (IO16)
 #define PIT_BKF64 64
 #endif
 constexpr int BKF128 = PIT_BKF128, BKF64 = PIT_BKF64;     // fp32-stored operands: converted in registers on the way to LDS
+// the fp32 weight-gradient reductions of the large regime (gemm_rr_kernel): one (g2 == nullptr) or the two reductions of
+// one MLP, which share K (the batch rows), in ONE launch; preconditions checked by the caller (gemm_rr_ok)
+bool gemm_rr_ok(const GemmArgs& g) {
+    const int n_real = (g.ones_col >= 0) ? g.N - 1 : g.N;
+    return g.epi == EPI_ATOMIC && !g.bf16 && !g.a_gz && !(g.a16 || g.b16 || g.c16 || g.z16 || g.g16) &&
+           g.a_rs == 1 && g.a_cs % 4 == 0 && g.M % 4 == 0 && g.b_cs == 1 && g.b_rs % 4 == 0 && n_real % 4 == 0 &&
+           aligned16(g.A) && aligned16(g.B);
+}
+void launch_gemm_rr(const GemmArgs& g1, const GemmArgs* g2, hipStream_t s) {
+    int rm = 1, rn = 1, bk = 64, per_cu = 0, pad_kb = 0;
+    static const char* cfg = getenv("PIT_RR_CFG");                 // experiments: "rm,rn,bk,workgroups per CU,LDS padding KB"
+    if (cfg) sscanf(cfg, "%d,%d,%d,%d,%d", &rm, &rn, &bk, &per_cu, &pad_kb);
+    const int bm = 64 * rm, bn = 64 * rn;
+    auto tiles_of = [&](const GemmArgs& g, int& tx) {
+        const int n_real = (g.ones_col >= 0) ? g.N - 1 : g.N;
+        tx = (n_real + bn - 1) / bn;
+        return tx * ((g.M + bm - 1) / bm);
+    };
+    int tx1 = 1, tx2 = 1;
+    const int T1 = tiles_of(g1, tx1), T2 = g2 ? tiles_of(*g2, tx2) : 0;
+    const int nchunks = (g1.K + bk - 1) / bk;
+    // As many K slabs as keep every CU at exactly 1 (or 2) workgroups.  One workgroup more than the chip holds at once and
+    // the launch takes two rounds; an XCD with 33 of them on its 32 CUs runs 1.6x as long (tools/stamp_dw.py: that, not the
+    // inner loop, was what held gemm_lds_kernel<128, F, F, ATOMIC> at 25-45 % MFMA busy).  Two per CU when a workgroup then
+    // still contracts >= 8 chunks: the second wave per SIMD hides the barriers, but prologue and epilogue are per workgroup.
+    // Measured (us per MLP, both reductions; round-2 kernels -> one per CU / two per CU): Darcy b=256 62.7 -> 31.5 / 31.7,
+    // Vorticity 51.8 -> 36.3 / 34.2, NACA 39.2 -> 22.4 / 22.4, Elasticity 26.7 -> 13.8 / 15.1, Cylinder b=200 307 -> 281 / 244
+    if (per_cu <= 0) per_cu = (nchunks / std::max(1, 512 / (T1 + T2)) >= 8) ? 2 : 1;
+    const int slabs = std::max(1, std::min(std::max(1, nchunks / 2), 256 * per_cu / (T1 + T2)));
+    const int P = (T1 + T2) * slabs;
+    const dim3 grid((unsigned)(8 * ((P + 7) / 8))), block(256);
+    const GemmArgs& gb = g2 ? *g2 : g1;
+#define PIT_RR(RM_, RN_, BK_) hipLaunchKernelGGL((gemm_rr_kernel<RM_, RN_, BK_>), grid, block, (size_t)pad_kb * 1024, s, g1, gb, tx1, T1, tx2, T2, slabs, nchunks)
+    if (rm == 1 && rn == 2) PIT_RR(1, 2, 32);          // (experiments only: 64 x 128 tiles)
+    else PIT_RR(1, 1, 64);
+#undef PIT_RR
+}
+
 bool try_launch_gemm_lds(GemmArgs g, hipStream_t s) {
     static const int mode = getenv("PIT_LDS_GEMM") ? atoi(getenv("PIT_LDS_GEMM")) : 1;   // 0 off, 1 auto, 2 always when legal
     if (mode == 0) return false;
@@ -1272,6 +1480,7 @@ bool try_launch_gemm_lds(GemmArgs g, hipStream_t s) {
         else hipLaunchKernelGGL((gemm_bfl_kernel<32, A_, B_, EPI_, false, BKF64>), grid, block, 0, s, g);      \
     } while (0)
     static const bool legacy_bf = getenv("PIT_BF16_LEGACY") != nullptr;      // the round-1 form: fp32 in LDS, 32x32x8 MFMA
+    static const bool no_rr = getenv("PIT_NO_GEMM_RR") != nullptr;           // the round-2 kernel for the fp32 weight gradients
 #define PIT_LDS(A_, B_, EPI_) do { if (g.bf16 && !legacy_bf) PIT_BFL(A_, B_, EPI_); else if (g.bf16) PIT_LDS_BF(A_, B_, EPI_, true); else PIT_LDS_BF(A_, B_, EPI_, false); } while (0)
     switch (kind) {
         case 0: PIT_LDS(true, true, EPI_BIAS); break;
@@ -1282,6 +1491,7 @@ bool try_launch_gemm_lds(GemmArgs g, hipStream_t s) {
             if (g.bf16 && !legacy_bf && io16) hipLaunchKernelGGL((gemm_bfl_kernel<128, false, false, EPI_ATOMIC, true, BK128>), grid, block, 0, s, g);
             else if (g.bf16 && !legacy_bf) hipLaunchKernelGGL((gemm_bfl_kernel<128, false, false, EPI_ATOMIC, false, BKF128>), grid, block, 0, s, g);
             else if (g.bf16) hipLaunchKernelGGL((gemm_lds_kernel<128, false, false, EPI_ATOMIC, true>), grid, block, 0, s, g);
+            else if (!no_rr && gemm_rr_ok(g)) launch_gemm_rr(g, nullptr, s);
             else hipLaunchKernelGGL((gemm_lds_kernel<128, false, false, EPI_ATOMIC, false>), grid, block, 0, s, g);
             break;
     }
@@ -1366,6 +1576,16 @@ int launch_gemm(GemmArgs g, hipStream_t s) {
 int launch_gemm_pair_atomic(GemmArgs g1, GemmArgs g2, hipStream_t s) {
     const bool io16 = g1.a16 || g1.b16 || g2.a16 || g2.b16;
     if (io16 || (long)g1.M * g1.N * g1.K + (long)g2.M * g2.N * g2.K > (1L << 28)) {
+        static const bool no_rr = getenv("PIT_NO_GEMM_RR") != nullptr || getenv("PIT_NO_GEMM_RR_PAIR") != nullptr;
+        if (!no_rr && !io16 && g1.K == g2.K && std::min(g1.N, g2.N) >= 48 && std::min(g1.M, g2.M) >= 32) {
+            GemmLaunch L;
+            if (int rc = prepare_gemm(g1, L)) return rc;           // (operand extents, math mode)
+            if (int rc = prepare_gemm(g2, L)) return rc;
+            if (gemm_rr_ok(g1) && gemm_rr_ok(g2)) {
+                launch_gemm_rr(g1, &g2, s);           // both reductions share the batch rows: one balanced launch
+                return 0;
+            }
+        }
         if (int rc = launch_gemm(g1, s)) return rc;
         return launch_gemm(g2, s);
     }
@@ -1599,6 +1819,20 @@ extern "C" int pit_mlp_bwd_data(int rows, int n0, int n1, int n2, const float* w
     }
     return 0;
 }
+
+#ifdef PIT_STAMPS
+extern "C" int pit_mlp_debug_read_stamps(unsigned long long* host64) {
+    return (int)hipMemcpyFromSymbol(host64, HIP_SYMBOL(pit_mlp_stamps), 64 * sizeof(unsigned long long));
+}
+extern "C" int pit_mlp_debug_read_wgrec(unsigned long long* host, int n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(pit_mlp_wgrec), (size_t)n * 4 * sizeof(unsigned long long));
+}
+extern "C" int pit_mlp_debug_reset_stamps() {
+    unsigned long long z[64] = {0};
+    z[62] = ~0ull; z[56] = ~0ull;
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(pit_mlp_stamps), z, sizeof(z));
+}
+#endif
 
 extern "C" int pit_mlp_bwd_params(const float* x, long ldx, int rows, int n0, int n1, int n2, const float* h,
                                   int out_gelu, const float* d_y, long ld_dy,

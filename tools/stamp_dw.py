@@ -1,0 +1,74 @@
+"""Diagnostic: phase timeline of gemm_rr_kernel (workgroup 8, thread 0) from in-kernel s_memtime stamps (100 MHz).
+Needs a library built with -DPIT_STAMPS (PIT_LIB_OUT=... PIT_EXTRA_FLAGS=-DPIT_STAMPS python -m ...build) in PIT_LIB_PATH.
+Usage: stamp_dw.py <shape> <which: 1|2>"""
+import ctypes, os, sys
+ROOT = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import torch
+from position_induced_transformer_amd import _lib
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import dw_bench as D  # noqa
+name, which = sys.argv[1], int(sys.argv[2])
+rows, n0, n1, n2, og = D.SHAPES[name]
+L = _lib.lib()
+x, h = torch.randn(rows, n0, device="cuda"), torch.randn(rows, n1, device="cuda")
+scratch = torch.randn(rows * (n1 + n2), device="cuda")
+dy = torch.randn(rows, n2, device="cuda")
+gw1, gb1 = torch.zeros(n1, n0, device="cuda"), torch.zeros(n1, device="cuda")
+gw2, gb2 = torch.zeros(n2, n1, device="cuda"), torch.zeros(n2, device="cuda")
+L.pit_mlp_debug_read_stamps.argtypes = [ctypes.c_void_p]
+if which == 1:      # dW1 only: make the second reduction degenerate by calling with n2 tiny? - simply run both; dW1 is launched LAST
+    pass
+for it in range(5):
+    if it == 4:
+        torch.cuda.synchronize()
+        L.pit_mlp_debug_reset_stamps()
+    rc = L.pit_mlp_bwd_params(x.data_ptr(), n0, rows, n0, n1, n2, h.data_ptr(), og, dy.data_ptr(), n2, gw1.data_ptr(), gb1.data_ptr(),
+                              gw2.data_ptr(), gb2.data_ptr(), 1, scratch.data_ptr(), 0, torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+torch.cuda.synchronize()
+buf = (ctypes.c_ulonglong * 64)()
+assert L.pit_mlp_debug_read_stamps(buf) == 0
+t = list(buf)
+print(f"{name}: the LAST gemm_rr launch (dW1), workgroup 8; s_memtime ticks")
+rt = (t[58] - t[57]) * 10
+print(f"  workgroup 8 lived {t[61] - t[0]} s_memtime ticks = {rt} ns of s_memrealtime (100 MHz) -> {(t[61] - t[0]) / max(rt, 1):.3f} ticks per ns")
+t[57] = t[58] = 0
+print(f"  all workgroups of the call's launches (100 MHz clock): first entry -> last entry {(t[59] - t[62]) * 10} ns, -> first exit "
+      f"{(t[56] - t[62]) * 10} ns, -> last exit {(t[63] - t[62]) * 10} ns")
+t[56] = 0
+prev = t[0]
+for i in range(62):
+    if t[i] and i != 59:
+        what = {0: "entry", 1: "first chunk in LDS", 60: "loop done", 61: "epilogue done"}.get(i, f"chunk {(i - 2) // 2} " + ("contracted" if i % 2 == 0 else "next chunk stored + barrier"))
+        print(f"  {what:40s} +{(t[i] - prev):7d} ticks   (t = {(t[i] - t[0]):7d})")
+        prev = t[i]
+
+# per-workgroup records of the dW1 launch: lifetime against placement
+n = 1024
+rec = (ctypes.c_ulonglong * (4 * n))()
+L.pit_mlp_debug_read_wgrec.argtypes = [ctypes.c_void_p, ctypes.c_int]
+assert L.pit_mlp_debug_read_wgrec(rec, n) == 0
+import collections
+rows_ = [(rec[4 * i], rec[4 * i + 1], rec[4 * i + 2], rec[4 * i + 3], i) for i in range(n) if rec[4 * i + 1] > rec[4 * i] > 0]
+t0 = min(r[0] for r in rows_)
+def place(hw, xcc):
+    return (int(xcc) & 0xf, (int(hw) >> 13) & 0x7, (int(hw) >> 12) & 1, (int(hw) >> 8) & 0xf)      # XCC, SE, SH, CU
+percu = collections.defaultdict(list)
+for a, b, hw, xcc, i in rows_:
+    percu[place(hw, xcc)].append(((a - t0) * 10, (b - t0) * 10, i))
+print(f"{len(rows_)} workgroups on {len(percu)} distinct (XCC, SE, SH, CU); workgroups per CU: "
+      f"{dict(collections.Counter(len(v) for v in percu.values()))}")
+life = sorted((b - a) * 10 for a, b, _, _, _ in rows_)
+print(f"lifetime ns: min {life[0]} median {life[len(life) // 2]} p90 {life[int(len(life) * 0.9)]} max {life[-1]}")
+byx = collections.defaultdict(list)
+for (x, se, sh, cu), v in percu.items():
+    for a, b, i in v:
+        byx[x].append(b - a)
+for x in sorted(byx):
+    v = sorted(byx[x])
+    print(f"  XCC {x}: {len(v):3d} workgroups, lifetime median {v[len(v) // 2]} max {v[-1]} ns")
+alone = [b - a for v in percu.values() if len(v) == 1 for a, b, _ in v]
+shared = [b - a for v in percu.values() if len(v) > 1 for a, b, _ in v]
+if alone: print(f"  alone on their CU: {len(alone)} workgroups, mean lifetime {sum(alone) / len(alone):.0f} ns")
+if shared: print(f"  sharing a CU: {len(shared)} workgroups, mean lifetime {sum(shared) / len(shared):.0f} ns")
