@@ -642,6 +642,16 @@ __global__ __launch_bounds__(256) void gemm_lds_kernel(GemmArgs g) {
 //  * the slabs of one tile set are dealt to ONE XCD (grid id -> (slab, tile) below): the operand rows a slab's tiles
 //    share come from HBM once.
 // Bias gradient = row sums of A, accumulated from the fragments by the first column block (as gemm_lds_kernel).
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f32x16 mfma_32x32x16_bf16(bf16x8_t a, bf16x8_t b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ unsigned pack2_bf16(float lo, float hi) {
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    const f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+}
 #ifdef PIT_STAMPS
 __device__ unsigned long long pit_mlp_stamps[64];
 __device__ unsigned long long pit_mlp_wgrec[4096 * 4];     // per workgroup: entry, exit (100 MHz), HW_ID, XCC_ID
@@ -662,13 +672,15 @@ __device__ unsigned long long pit_mlp_wgrec[4096 * 4];     // per workgroup: ent
 #define MSTAMP(i_) do { } while (0)
 #define MREC(slot_) do { } while (0)
 #endif
-template <int RM, int RN, int BK>
+// BF (PIT_MATH_BF16, fp32-stored operands): the same images, rounded to bf16 (RNE) on the way from LDS to the
+// v_mfma_f32_32x32x16_bf16 operands - 16 k per instruction, this half-wave's 8 k of a step = 8 LDS reads + 4 packs per operand.
+template <int RM, int RN, int BK, bool BF = false>
 __global__ __launch_bounds__(256) void gemm_rr_kernel(GemmArgs g1, GemmArgs g2, int tx1, int T1, int tx2, int T2, int slabs,
                                                       int nchunks) {
     constexpr int BM = 64 * RM, BN = 64 * RN;
     constexpr int PA = BK * BM / 1024, PB = BK * BN / 1024;         // 16-B loads per thread and chunk
     constexpr int NA = (RM * RN == 1) ? 2 : 1;     // a lone tile alternates between two accumulators: no dependent MFMA chain
-    static_assert(PA >= 1 && PB >= 1 && BK % 4 == 0, "chunk shape");
+    static_assert(PA >= 1 && PB >= 1 && BK % (BF ? 32 : 4) == 0, "chunk shape");
     __shared__ __attribute__((aligned(16))) float As[2][BK * BM];
     __shared__ __attribute__((aligned(16))) float Bs[2][BK * BN];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -739,6 +751,35 @@ __global__ __launch_bounds__(256) void gemm_rr_kernel(GemmArgs g1, GemmArgs g2, 
     for (int kc = kbeg; kc < kend; kc += BK, ++chunk_i) {
         const bool more = kc + BK < kend;
         if (more) gload(kc + BK);
+        if constexpr (BF) {
+            const float* as = &As[cur][8 * half * BM + wm + RM * l31];      // this half-wave's k of a step: 16 st + 8 half + e
+            const float* bs = &Bs[cur][8 * half * BN + wn + l31];
+#pragma unroll
+            for (int st = 0; st < BK / 16; ++st) {
+                bf16x8_t a8[RM], b8[RN];
+#pragma unroll
+                for (int t = 0; t < RM; ++t) {
+                    float v[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = as[(16 * st + e) * BM + t];
+                    if (want_rowsum) rsum[t] += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+                    const uint4 q = make_uint4(pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3]), pack2_bf16(v[4], v[5]), pack2_bf16(v[6], v[7]));
+                    a8[t] = __builtin_bit_cast(bf16x8_t, q);
+                }
+#pragma unroll
+                for (int u = 0; u < RN; ++u) {
+                    float v[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = bs[(16 * st + e) * BN + 32 * u];
+                    const uint4 q = make_uint4(pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3]), pack2_bf16(v[4], v[5]), pack2_bf16(v[6], v[7]));
+                    b8[u] = __builtin_bit_cast(bf16x8_t, q);
+                }
+#pragma unroll
+                for (int t = 0; t < RM; ++t)
+#pragma unroll
+                    for (int u = 0; u < RN; ++u) acc[t][u][st % NA] = mfma_32x32x16_bf16(a8[t], b8[u], acc[t][u][st % NA]);
+            }
+        } else {
         const float* as = &As[cur][half * BM + wm + RM * l31];          // this half-wave's k of a step: 2 st + half
         const float* bs = &Bs[cur][half * BN + wn + l31];
         float av[2][RM], bv[2][RN];
@@ -761,6 +802,7 @@ __global__ __launch_bounds__(256) void gemm_rr_kernel(GemmArgs g1, GemmArgs g2, 
 #pragma unroll
                 for (int u = 0; u < RN; ++u)
                     acc[t][u][st % NA] = mfma_32x32x2(av[st & 1][t], bv[st & 1][u], acc[t][u][st % NA]);
+        }
         }
         if (chunk_i < 20) MSTAMP(2 + 2 * chunk_i);
         if (more) lstore(cur ^ 1);
@@ -806,16 +848,6 @@ __global__ __launch_bounds__(256) void gemm_rr_kernel(GemmArgs g1, GemmArgs g2, 
 // quads; an i-contiguous operand (IC) needs the transpose: lane = i, each lane fetches its own 4/8/16
 // consecutive k with coalesced 4-B loads (64 consecutive i per wave instruction) and writes whole
 // 16-B fragments - no cross-lane movement, no 2-byte LDS stores.
-typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
-__device__ __forceinline__ f32x16 mfma_32x32x16_bf16(bf16x8_t a, bf16x8_t b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
-}
-__device__ __forceinline__ unsigned pack2_bf16(float lo, float hi) {
-    typedef float f32x2_t __attribute__((ext_vector_type(2)));
-    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-    const f32x2_t v = {lo, hi};
-    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
-}
 constexpr int BPK = LBK + 8;      // LDS row pitch in bf16 elements
 // four consecutive elements of a tensor stored as fp32 or (PIT_IO_*: is16) bf16; idx in elements, 4-element aligned
 __device__ __forceinline__ float4 ld4e(const float* base, long idx, int is16) {
@@ -1371,7 +1403,9 @@ constexpr int BKF128 = PIT_BKF128, BKF64 = PIT_BKF64;     // fp32-stored operand
 // one MLP, which share K (the batch rows), in ONE launch; preconditions checked by the caller (gemm_rr_ok)
 bool gemm_rr_ok(const GemmArgs& g) {
     const int n_real = (g.ones_col >= 0) ? g.N - 1 : g.N;
-    return g.epi == EPI_ATOMIC && !g.bf16 && !g.a_gz && !(g.a16 || g.b16 || g.c16 || g.z16 || g.g16) &&
+    static const bool no_bf = getenv("PIT_NO_GEMM_RR_BF16") != nullptr;
+    if (g.bf16 && (no_bf || getenv("PIT_BF16_LEGACY"))) return false;
+    return g.epi == EPI_ATOMIC && !g.a_gz && !(g.a16 || g.b16 || g.c16 || g.z16 || g.g16) &&
            g.a_rs == 1 && g.a_cs % 4 == 0 && g.M % 4 == 0 && g.b_cs == 1 && g.b_rs % 4 == 0 && n_real % 4 == 0 &&
            aligned16(g.A) && aligned16(g.B);
 }
@@ -1399,9 +1433,10 @@ void launch_gemm_rr(const GemmArgs& g1, const GemmArgs* g2, hipStream_t s) {
     const int P = (T1 + T2) * slabs;
     const dim3 grid((unsigned)(8 * ((P + 7) / 8))), block(256);
     const GemmArgs& gb = g2 ? *g2 : g1;
-#define PIT_RR(RM_, RN_, BK_) hipLaunchKernelGGL((gemm_rr_kernel<RM_, RN_, BK_>), grid, block, (size_t)pad_kb * 1024, s, g1, gb, tx1, T1, tx2, T2, slabs, nchunks)
-    if (rm == 1 && rn == 2) PIT_RR(1, 2, 32);          // (experiments only: 64 x 128 tiles)
-    else PIT_RR(1, 1, 64);
+#define PIT_RR(RM_, RN_, BK_, BF_) hipLaunchKernelGGL((gemm_rr_kernel<RM_, RN_, BK_, BF_>), grid, block, (size_t)pad_kb * 1024, s, g1, gb, tx1, T1, tx2, T2, slabs, nchunks)
+    if (g1.bf16) PIT_RR(1, 1, 64, true);
+    else if (rm == 1 && rn == 2) PIT_RR(1, 2, 32, false);          // (experiments only: 64 x 128 tiles)
+    else PIT_RR(1, 1, 64, false);
 #undef PIT_RR
 }
 
@@ -1489,9 +1524,9 @@ bool try_launch_gemm_lds(GemmArgs g, hipStream_t s) {
         case 3: PIT_LDS(true, false, EPI_STORE); break;
         default:
             if (g.bf16 && !legacy_bf && io16) hipLaunchKernelGGL((gemm_bfl_kernel<128, false, false, EPI_ATOMIC, true, BK128>), grid, block, 0, s, g);
+            else if (!no_rr && gemm_rr_ok(g)) launch_gemm_rr(g, nullptr, s);
             else if (g.bf16 && !legacy_bf) hipLaunchKernelGGL((gemm_bfl_kernel<128, false, false, EPI_ATOMIC, false, BKF128>), grid, block, 0, s, g);
             else if (g.bf16) hipLaunchKernelGGL((gemm_lds_kernel<128, false, false, EPI_ATOMIC, true>), grid, block, 0, s, g);
-            else if (!no_rr && gemm_rr_ok(g)) launch_gemm_rr(g, nullptr, s);
             else hipLaunchKernelGGL((gemm_lds_kernel<128, false, false, EPI_ATOMIC, false>), grid, block, 0, s, g);
             break;
     }

@@ -8,6 +8,7 @@ os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
 import torch
 from position_induced_transformer_amd import _lib
 
+MATH = int(os.environ.get("DW_MATH", "0"))      # 0 fp32, 1 bf16 math mode
 SHAPES = {   # rows, n0, n1, n2, trailing gelu
     "darcy256": (65536, 192, 64, 64, 1),
     "darcy64": (16384, 192, 64, 64, 1),
@@ -49,7 +50,7 @@ def main():
 
         def call():
             rc = L.pit_mlp_bwd_params(x.data_ptr(), n0, rows, n0, n1, n2, h.data_ptr(), og, dy.data_ptr(), n2, gw1.data_ptr(),
-                                      gb1.data_ptr(), gw2.data_ptr(), gb2.data_ptr(), 1, scratch.data_ptr(), 0,
+                                      gb1.data_ptr(), gw2.data_ptr(), gb2.data_ptr(), 1, scratch.data_ptr(), MATH,
                                       torch.cuda.current_stream().cuda_stream)
             assert rc == 0, rc
         us = graph_time(call)
