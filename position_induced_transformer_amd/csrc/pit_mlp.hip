@@ -455,6 +455,27 @@ bool try_launch_mlp_bwd16(int rows, int n0, int n1, int n2, const float* w1, con
 // i-contiguous (IC: LDS [k][i], fragment = 4 conflict-free 4-B reads).
 // Tile height LBM = 128 (wave = 32 rows x 64 columns) when that still gives >= 2 workgroups per CU,
 // else 64 (wave = 32 rows x 32 columns: twice the workgroups for the mid-sized layers).
+#ifdef PIT_STAMPS
+__device__ unsigned long long pit_mlp_stamps[64];
+__device__ unsigned long long pit_mlp_wgrec[4096 * 4];     // per workgroup: entry, exit (100 MHz), HW_ID, XCC_ID
+__device__ int pit_mlp_rec_k;                               // gemm_lds_kernel records the launches whose K equals this
+#define MREC(slot_, cond_) do { if (threadIdx.x == 0 && (cond_) && blockIdx.x < 4096) {                                        \
+        pit_mlp_wgrec[blockIdx.x * 4 + (slot_)] = __builtin_amdgcn_s_memrealtime();                                       \
+        if ((slot_) == 0) { pit_mlp_wgrec[blockIdx.x * 4 + 2] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)); \
+                            pit_mlp_wgrec[blockIdx.x * 4 + 3] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)); } } } while (0)
+#define MSTAMP(i_) do { if (threadIdx.x == 0 && tiles > 1) {       /* (diagnostic: the multi-tile launch = dW1) */ \
+     const unsigned long long t_ = __builtin_amdgcn_s_memtime();               \
+        if (blockIdx.x == 8) pit_mlp_stamps[i_] = t_;                                                                      \
+        if (blockIdx.x == 8 && (i_) == 0) pit_mlp_stamps[57] = __builtin_amdgcn_s_memrealtime();                            \
+        if (blockIdx.x == 8 && (i_) == 61) pit_mlp_stamps[58] = __builtin_amdgcn_s_memrealtime();                           \
+        if ((i_) == 0) atomicMin(&pit_mlp_stamps[62], __builtin_amdgcn_s_memrealtime());   /* (s_memtime: one per XCD) */  \
+        if ((i_) == 0) atomicMax(&pit_mlp_stamps[59], __builtin_amdgcn_s_memrealtime());                                    \
+        if ((i_) == 61) atomicMin(&pit_mlp_stamps[56], __builtin_amdgcn_s_memrealtime());                                   \
+        if ((i_) == 61) atomicMax(&pit_mlp_stamps[63], __builtin_amdgcn_s_memrealtime()); } } while (0)
+#else
+#define MSTAMP(i_) do { } while (0)
+#define MREC(slot_, cond_) do { } while (0)
+#endif
 constexpr int LBN = 64, LBK = 32;
 constexpr int LPK = LBK + 4;      // row pitch of the [i][k] layouts (floats): 144 B, 16-B aligned, bank-skewed
 constexpr int LPN = LBN + 4;      // [k][n]
@@ -489,6 +510,7 @@ __global__ __launch_bounds__(256) void gemm_lds_kernel(GemmArgs g) {
     const __amdgpu_buffer_rsrc_t rb = make_rsrc(g.B, g.b_bytes);
     const int n_real = (EPI == EPI_ATOMIC && g.ones_col >= 0) ? g.N - 1 : g.N;   // columns that exist in memory
 
+    MREC(0, g.K == pit_mlp_rec_k && blockIdx.y == 0 && blockIdx.z == 0);
     float sa[PA][4], sb[2][4];         // staging registers: next chunk in flight during the MFMAs
     auto gload = [&](int kc) {
 #pragma unroll
@@ -623,6 +645,7 @@ __global__ __launch_bounds__(256) void gemm_lds_kernel(GemmArgs g) {
             else g.C[(long)row * g.ldc + col] = v;
         }
     }
+    MREC(1, g.K == pit_mlp_rec_k && blockIdx.y == 0 && blockIdx.z == 0);
 }
 
 // ------------------------------------------------------------------------------------
@@ -652,26 +675,6 @@ __device__ __forceinline__ unsigned pack2_bf16(float lo, float hi) {
     const f32x2_t v = {lo, hi};
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
 }
-#ifdef PIT_STAMPS
-__device__ unsigned long long pit_mlp_stamps[64];
-__device__ unsigned long long pit_mlp_wgrec[4096 * 4];     // per workgroup: entry, exit (100 MHz), HW_ID, XCC_ID
-#define MREC(slot_) do { if (threadIdx.x == 0 && tiles > 1 && blockIdx.x < 4096) {                                        \
-        pit_mlp_wgrec[blockIdx.x * 4 + (slot_)] = __builtin_amdgcn_s_memrealtime();                                       \
-        if ((slot_) == 0) { pit_mlp_wgrec[blockIdx.x * 4 + 2] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)); \
-                            pit_mlp_wgrec[blockIdx.x * 4 + 3] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)); } } } while (0)
-#define MSTAMP(i_) do { if (threadIdx.x == 0 && tiles > 1) {       /* (diagnostic: the multi-tile launch = dW1) */ \
-     const unsigned long long t_ = __builtin_amdgcn_s_memtime();               \
-        if (blockIdx.x == 8) pit_mlp_stamps[i_] = t_;                                                                      \
-        if (blockIdx.x == 8 && (i_) == 0) pit_mlp_stamps[57] = __builtin_amdgcn_s_memrealtime();                            \
-        if (blockIdx.x == 8 && (i_) == 61) pit_mlp_stamps[58] = __builtin_amdgcn_s_memrealtime();                           \
-        if ((i_) == 0) atomicMin(&pit_mlp_stamps[62], __builtin_amdgcn_s_memrealtime());   /* (s_memtime: one per XCD) */  \
-        if ((i_) == 0) atomicMax(&pit_mlp_stamps[59], __builtin_amdgcn_s_memrealtime());                                    \
-        if ((i_) == 61) atomicMin(&pit_mlp_stamps[56], __builtin_amdgcn_s_memrealtime());                                   \
-        if ((i_) == 61) atomicMax(&pit_mlp_stamps[63], __builtin_amdgcn_s_memrealtime()); } } while (0)
-#else
-#define MSTAMP(i_) do { } while (0)
-#define MREC(slot_) do { } while (0)
-#endif
 // BF (PIT_MATH_BF16, fp32-stored operands): the same images, rounded to bf16 (RNE) on the way from LDS to the
 // v_mfma_f32_32x32x16_bf16 operands - 16 k per instruction, this half-wave's 8 k of a step = 8 LDS reads + 4 packs per operand.
 template <int RM, int RN, int BK, bool BF = false>
@@ -742,7 +745,7 @@ __global__ __launch_bounds__(256) void gemm_rr_kernel(GemmArgs g1, GemmArgs g2, 
     for (int t = 0; t < RM; ++t) rsum[t] = 0.0f;
 
     MSTAMP(0);
-    MREC(0);
+    MREC(0, tiles > 1);
     gload(kbeg);
     lstore(0);
     __syncthreads();
@@ -834,7 +837,7 @@ __global__ __launch_bounds__(256) void gemm_rr_kernel(GemmArgs g1, GemmArgs g2, 
             }
         }
     MSTAMP(61);
-    MREC(1);
+    MREC(1, tiles > 1);
 }
 
 // ------------------------------------------------------------------------------------
@@ -1862,6 +1865,7 @@ extern "C" int pit_mlp_debug_read_stamps(unsigned long long* host64) {
 extern "C" int pit_mlp_debug_read_wgrec(unsigned long long* host, int n) {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(pit_mlp_wgrec), (size_t)n * 4 * sizeof(unsigned long long));
 }
+extern "C" int pit_mlp_debug_set_rec_k(int k) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(pit_mlp_rec_k), &k, sizeof(int)); }
 extern "C" int pit_mlp_debug_reset_stamps() {
     unsigned long long z[64] = {0};
     z[62] = ~0ull; z[56] = ~0ull;
