@@ -502,3 +502,40 @@ def test_data_parallel_capture_tolerates_another_thread_polling_events():
         return errors
 
     assert capture_while_polling(True) == []
+
+
+# --------------------------------------------------------------------------- large-regime weight gradients (gemm_rr_kernel)
+@pytest.mark.parametrize("rows,n0,n1,n2", [(16384, 192, 64, 64), (5120, 768, 256, 256), (14560, 256, 128, 128),
+                                           (9999, 192, 64, 64), (7000, 320, 96, 160), (65536, 192, 64, 64)])
+@pytest.mark.parametrize("math", [0, 1], ids=["fp32", "bf16"])
+@pytest.mark.parametrize("out_gelu", [1, 0])
+def test_weight_gradient_pair_launch_matches_fp64(rows, n0, n1, n2, math, out_gelu):
+    """pit_mlp_bwd_params in the large regime (both reductions of an MLP in ONE gemm_rr_kernel launch, K slabs dealt so that
+    every CU holds the same number of workgroups): dW1 = dZ1^T X, db1 = sum dZ1, dW2 = dZ2^T H, db2 = sum dZ2 against fp64
+    on the same operands - ragged row counts (partial last chunk, uneven slabs), tiles that are not multiples of 64, both
+    accumulate modes.  fp32 mode: exact products, 2e-6; bf16 mode: operands rounded (RNE), 8e-3; bias gradients are sums of
+    the stored values in both modes."""
+    from position_induced_transformer_amd import _lib
+    L = _lib.lib()
+    g = torch.Generator(device="cuda").manual_seed(rows + n0 + 7 * math)
+    x = torch.randn(rows, n0, device="cuda", generator=g)
+    h = torch.randn(rows, n1, device="cuda", generator=g)
+    scratch = torch.randn(rows * (n1 + n2), device="cuda", generator=g)
+    dy = torch.randn(rows, n2, device="cuda", generator=g)
+    dz1 = scratch[:rows * n1].view(rows, n1).double()
+    dz2 = (scratch[rows * n1:].view(rows, n2) if out_gelu else dy).double()
+    want = [dz1.t() @ x.double(), dz1.sum(0), dz2.t() @ h.double(), dz2.sum(0)]
+    for accumulate in (0, 1):
+        base = [torch.randn(n1, n0, device="cuda", generator=g), torch.randn(n1, device="cuda", generator=g),
+                torch.randn(n2, n1, device="cuda", generator=g), torch.randn(n2, device="cuda", generator=g)]
+        got = [b.clone() for b in base]
+        rc = L.pit_mlp_bwd_params(x.data_ptr(), n0, rows, n0, n1, n2, h.data_ptr(), out_gelu, dy.data_ptr(), n2, got[0].data_ptr(),
+                                  got[1].data_ptr(), got[2].data_ptr(), got[3].data_ptr(), accumulate, scratch.data_ptr(), math,
+                                  torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc, "pit_mlp_bwd_params")
+        torch.cuda.synchronize()
+        for k, (a, b, w) in enumerate(zip(got, base, want)):
+            ref = w + b.double() if accumulate else w
+            err = float((a.double() - ref).norm() / ref.norm())
+            tol = 8e-3 if (math == 1 and k in (0, 2)) else 2e-6
+            assert err <= tol, (accumulate, ("dW1", "db1", "dW2", "db2")[k], err)
