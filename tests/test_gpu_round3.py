@@ -513,8 +513,9 @@ def test_weight_gradient_pair_launch_matches_fp64(rows, n0, n1, n2, math, out_ge
     """pit_mlp_bwd_params in the large regime (both reductions of an MLP in ONE gemm_rr_kernel launch, K slabs dealt so that
     every CU holds the same number of workgroups): dW1 = dZ1^T X, db1 = sum dZ1, dW2 = dZ2^T H, db2 = sum dZ2 against fp64
     on the same operands - ragged row counts (partial last chunk, uneven slabs), tiles that are not multiples of 64, both
-    accumulate modes.  fp32 mode: exact products, 2e-6; bf16 mode: operands rounded (RNE), 8e-3; bias gradients are sums of
-    the stored values in both modes."""
+    accumulate modes (9999 rows stay below the large regime: the register-direct pair kernel, same contract).  fp32 mode:
+    exact products, 2e-6; bf16 mode: operands rounded (RNE), 8e-3 (the large-regime kernel sums the bias gradients from the
+    stored values, the small-regime one from the rounded operands: both within the mode's tolerance)."""
     from position_induced_transformer_amd import _lib
     L = _lib.lib()
     g = torch.Generator(device="cuda").manual_seed(rows + n0 + 7 * math)
@@ -537,5 +538,5 @@ def test_weight_gradient_pair_launch_matches_fp64(rows, n0, n1, n2, math, out_ge
         for k, (a, b, w) in enumerate(zip(got, base, want)):
             ref = w + b.double() if accumulate else w
             err = float((a.double() - ref).norm() / ref.norm())
-            tol = 8e-3 if (math == 1 and k in (0, 2)) else 2e-6
+            tol = 8e-3 if math == 1 else 2e-6
             assert err <= tol, (accumulate, ("dW1", "db1", "dW2", "db2")[k], err)
