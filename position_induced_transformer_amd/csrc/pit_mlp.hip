@@ -459,10 +459,11 @@ bool try_launch_mlp_bwd16(int rows, int n0, int n1, int n2, const float* w1, con
 __device__ unsigned long long pit_mlp_stamps[64];
 __device__ unsigned long long pit_mlp_wgrec[4096 * 4];     // per workgroup: entry, exit (100 MHz), HW_ID, XCC_ID
 __device__ int pit_mlp_rec_k;                               // gemm_lds_kernel records the launches whose K equals this
-#define MREC(slot_, cond_) do { if (threadIdx.x == 0 && (cond_) && blockIdx.x < 4096) {                                        \
-        pit_mlp_wgrec[blockIdx.x * 4 + (slot_)] = __builtin_amdgcn_s_memrealtime();                                       \
-        if ((slot_) == 0) { pit_mlp_wgrec[blockIdx.x * 4 + 2] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)); \
-                            pit_mlp_wgrec[blockIdx.x * 4 + 3] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)); } } } while (0)
+#define MREC(slot_, cond_) do { const unsigned lid_ = blockIdx.x + blockIdx.y * gridDim.x;                                 \
+    if (threadIdx.x == 0 && (cond_) && lid_ < 4096) {                                                                      \
+        pit_mlp_wgrec[lid_ * 4 + (slot_)] = __builtin_amdgcn_s_memrealtime();                                              \
+        if ((slot_) == 0) { pit_mlp_wgrec[lid_ * 4 + 2] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));      \
+                            pit_mlp_wgrec[lid_ * 4 + 3] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)); } } } while (0)
 #define MSTAMP(i_) do { if (threadIdx.x == 0 && tiles > 1) {       /* (diagnostic: the multi-tile launch = dW1) */ \
      const unsigned long long t_ = __builtin_amdgcn_s_memtime();               \
         if (blockIdx.x == 8) pit_mlp_stamps[i_] = t_;                                                                      \
@@ -510,7 +511,7 @@ __global__ __launch_bounds__(256) void gemm_lds_kernel(GemmArgs g) {
     const __amdgpu_buffer_rsrc_t rb = make_rsrc(g.B, g.b_bytes);
     const int n_real = (EPI == EPI_ATOMIC && g.ones_col >= 0) ? g.N - 1 : g.N;   // columns that exist in memory
 
-    MREC(0, g.K == pit_mlp_rec_k && blockIdx.y == 0 && blockIdx.z == 0);
+    MREC(0, g.K == pit_mlp_rec_k && blockIdx.z == 0);
     float sa[PA][4], sb[2][4];         // staging registers: next chunk in flight during the MFMAs
     auto gload = [&](int kc) {
 #pragma unroll
@@ -645,7 +646,7 @@ __global__ __launch_bounds__(256) void gemm_lds_kernel(GemmArgs g) {
             else g.C[(long)row * g.ldc + col] = v;
         }
     }
-    MREC(1, g.K == pit_mlp_rec_k && blockIdx.y == 0 && blockIdx.z == 0);
+    MREC(1, g.K == pit_mlp_rec_k && blockIdx.z == 0);
 }
 
 // ------------------------------------------------------------------------------------
@@ -1482,8 +1483,15 @@ bool try_launch_gemm_lds(GemmArgs g, hipStream_t s) {
     // 128-row tiles while they still give two workgroups per CU (or when K slabs add parallelism)
     // (and 32-row tiles with an in-workgroup K split while even the 64-row tiling leaves CUs idle)
     int bm = ((long)gx * ((g.M + 127) / 128) >= 512 || g.epi == EPI_ATOMIC) ? 128 : 64;
+    // short contractions (K <= 256: a workgroup is a load phase, a few chunks and a store phase, and all resident
+    // workgroups go through them in step - tools/stamp_gemm.py: 512 workgroups, every one alive for the whole launch, 4 us of
+    // MFMA in a 15 us life): 64-row tiles double the workgroups and let one's stores overlap another's loads - the hid-64 MLP
+    // at 65 536 rows: forward 49.1 -> 42.5 us, backward data path 59.8 -> 51.9 us, Darcy b=256 step 2.04 -> 1.94 ms
+    if (bm == 128 && g.epi != EPI_ATOMIC && g.K <= 256) bm = 64;
+    static const int force_bm = getenv("PIT_LDS_BM") ? atoi(getenv("PIT_LDS_BM")) : 0;      // experiments
+    if (force_bm && g.epi != EPI_ATOMIC) bm = force_bm;
     static const bool no32 = getenv("PIT_LDS_NO_BM32") != nullptr;
-    if (bm == 64 && (long)gx * ((g.M + 63) / 64) < 512 && !no32) bm = 32;
+    if (!force_bm && bm == 64 && (long)gx * ((g.M + 63) / 64) < 512 && !no32) bm = 32;
     const int gy = (g.M + bm - 1) / bm;
     int splits = 1;
     g.k_slab = ((g.K + LBK - 1) / LBK) * LBK;
