@@ -10,6 +10,8 @@ from position_induced_transformer_amd import _lib
 
 MATH = int(os.environ.get("DW_MATH", "0"))      # 0 fp32, 1 bf16 math mode
 SHAPES = {   # rows, n0, n1, n2, trailing gelu
+    "darcy8": (2048, 192, 64, 64, 1),
+    "darcy32": (8192, 192, 64, 64, 1),
     "darcy256": (65536, 192, 64, 64, 1),
     "darcy64": (16384, 192, 64, 64, 1),
     "vort": (5120, 768, 256, 256, 1),
