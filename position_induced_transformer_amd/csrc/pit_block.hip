@@ -580,12 +580,22 @@ __device__ __forceinline__ void block_bwd_dscale(const BlockBwdArgs& g, float* s
     }
 }
 
-__device__ __forceinline__ void dw_pair_body(const pit_detail::DwPair& w, int id) {
+// one reduction of a rider as a gemm_rr_tile tile (DwPair::rr1 / rr2): the first four waves, 64 KiB of the launch's LDS
+__device__ __forceinline__ void rr_rider(const pit_detail::GemmArgs& g, int id, int tx, int tiles, int slabs, int nchunks, float* smem) {
+    if (threadIdx.x >= 256) return;                       // (ended waves do not take part in the tile's barriers)
+    const int slab = id / tiles, tile = id % tiles;
+    const int kbeg = (int)((long)slab * nchunks / slabs) * pit_detail::RR_BK;
+    const int kend = min(g.K, (int)((long)(slab + 1) * nchunks / slabs) * pit_detail::RR_BK);
+    gemm_rr_tile<1, 1, pit_detail::RR_BK, false>(g, tile % tx, tile / tx, kbeg, kend, smem, smem + 2 * pit_detail::RR_BK * 64);
+}
+__device__ __forceinline__ void dw_pair_body(const pit_detail::DwPair& w, int id, float* smem) {
     if (id < w.n1) {
-        gemm_rd_body<1, EPI_ATOMIC>(w.g1, id % w.gx1, (id / w.gx1) % w.gy1, id / (w.gx1 * w.gy1));
+        if (w.rr1) rr_rider(w.g1, id, w.tx1, w.tiles1, w.slabs1, w.nchunks, smem);
+        else gemm_rd_body<1, EPI_ATOMIC>(w.g1, id % w.gx1, (id / w.gx1) % w.gy1, id / (w.gx1 * w.gy1));
     } else {
         id -= w.n1;
-        gemm_rd_body<1, EPI_ATOMIC>(w.g2, id % w.gx2, (id / w.gx2) % w.gy2, id / (w.gx2 * w.gy2));
+        if (w.rr2) rr_rider(w.g2, id, w.tx2, w.tiles2, w.slabs2, w.nchunks, smem);
+        else gemm_rd_body<1, EPI_ATOMIC>(w.g2, id % w.gx2, (id / w.gx2) % w.gy2, id / (w.gx2 * w.gy2));
     }
 }
 
@@ -600,8 +610,8 @@ __global__ __launch_bounds__(512) void block_bwd_kernel(BlockBwdArgs g, pit_deta
     id -= g.n_chain;
     if (id < g.n_ds) { block_bwd_dscale<H>(g, smem, id); return; }
     id -= g.n_ds;
-    if (NDW >= 1 && id < w.n1 + w.n2) { dw_pair_body(w, id); return; }
-    if (NDW >= 2) dw_pair_body(w2, id - (w.n1 + w.n2));
+    if (NDW >= 1 && id < w.n1 + w.n2) { dw_pair_body(w, id, smem); return; }
+    if (NDW >= 2) dw_pair_body(w2, id - (w.n1 + w.n2), smem);
 }
 
 constexpr size_t fwd_smem(int H) { return ((size_t)H * PARK_FLOATS + 16 * ((1 + H) * BD + 4) + 16 * (BD + 4)) * sizeof(float); }
@@ -715,9 +725,11 @@ extern "C" int pit_block_bwd(const float* e, const float* inv, const float* qw, 
     int ndw = 0;                                        // carried riders are packed into dw, dw2 in order
     bool carried[2] = {false, false};
     for (int r = 0; r < 2; ++r)
-        if (jobs[r] && pit_detail::plan_dw_pair(*jobs[r], BW, plans[ndw])) { carried[r] = true; ++ndw; }
+        if (jobs[r] && pit_detail::plan_dw_pair(*jobs[r], BW, plans[ndw], 768, true)) { carried[r] = true; ++ndw; }
     const int n_dw = (ndw >= 1 ? dw.n1 + dw.n2 : 0) + (ndw >= 2 ? dw2.n1 + dw2.n2 : 0);
-    const size_t sm = std::max(bwd_smem(n_head, dscale != nullptr), ndw ? (size_t)BW * 16 * 64 * sizeof(float) : (size_t)0);
+    const bool any_rr = (ndw >= 1 && (dw.rr1 || dw.rr2)) || (ndw >= 2 && (dw2.rr1 || dw2.rr2));
+    const size_t sm = std::max(std::max(bwd_smem(n_head, dscale != nullptr), ndw ? (size_t)BW * 16 * 64 * sizeof(float) : (size_t)0),
+                               any_rr ? (size_t)4 * pit_detail::RR_BK * 64 * sizeof(float) : (size_t)0);
     const dim3 grid((unsigned)(g.n_chain + g.n_ds + n_dw)), block(64 * BW);
 #define PIT_BLOCK_BWD(H_, DW_)                                                                                             \
     do {                                                                                                                   \

@@ -37,14 +37,18 @@ struct GemmArgs {
 
 // both weight-gradient reductions of one MLP (dW2|db2 and dW1|db1), prepared for gemm_rd_body<1, EPI_ATOMIC>:
 // workgroups [0, n1) run g1 on a (gx1, gy1, .) grid, [n1, n1 + n2) run g2
-struct DwPair { GemmArgs g1, g2; int n1, n2, gx1, gy1, gx2, gy2; };
+// rr1 / rr2 (pit_block.hip's riders): that reduction runs as gemm_rr_tile tiles - workgroup id -> (slab = id / tiles, tile = id % tiles),
+// slab s = chunks [s nchunks / slabs, (s+1) nchunks / slabs) of RR_BK rows
+struct DwPair { GemmArgs g1, g2; int n1, n2, gx1, gy1, gx2, gy2; int rr1, rr2, tx1, tiles1, slabs1, tx2, tiles2, slabs2, nchunks; };
+constexpr int RR_BK = 64;
 
 // fills `out` and returns true when the job is small enough to ride along in another launch (pit_mlp.hip);
 // `waves` = waves per workgroup of the carrying launch (the row slabs are sized so that a wave reduces as many rows
 // as in the reductions' own 8-wave launch)
 // `target_wgs`: workgroups each of the two reductions aims for (its K range is split accordingly; 768 = the reductions' own
 // launch)
-bool plan_dw_pair(const pit_mlp_params_job& job, int waves, DwPair* out, int target_wgs = 768);
+// `allow_rr`: the caller's kernel runs rr1 / rr2 reductions through gemm_rr_tile (>= 64 KiB of LDS, >= 4 waves)
+bool plan_dw_pair(const pit_mlp_params_job& job, int waves, DwPair* out, int target_wgs = 768, bool allow_rr = false);
 
 }  // namespace pit_detail
 
@@ -228,5 +232,161 @@ __device__ __forceinline__ void gemm_rd_body(const GemmArgs& g, int bx, int by, 
     }
 }
 
+
+
+// ------------------------------------------------------------------------------------
+// One tile of the row-reducing GEMM of pit_mlp.hip (gemm_rr_kernel; design notes there): C[m][n] += sum over k in
+// [kbeg, kend) of A[k][m] B[k][n] for the (64 RM) x (64 RN) tile (bx, by), by the FIRST FOUR waves of the calling workgroup
+// (callers with more waves let the others leave before the call: ended waves do not take part in the barriers).
+// As_ / Bs_: 2 x BK x 64 RM and 2 x BK x 64 RN floats of LDS.  Shared with the fused block backward (pit_block.hip), whose
+// riders are these tiles.
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f32x16 mfma_32x32x16_bf16(bf16x8_t a, bf16x8_t b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ unsigned pack2_bf16(float lo, float hi) {
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    const f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+}
+template <int RM, int RN, int BK, bool BF>
+__device__ __forceinline__ void gemm_rr_tile(const GemmArgs& g, int bx, int by, int kbeg, int kend, float* As_, float* Bs_) {
+    constexpr int BM = 64 * RM, BN = 64 * RN;
+    constexpr int PA = BK * BM / 1024, PB = BK * BN / 1024;         // 16-B loads per thread and chunk
+    constexpr int NA = (RM * RN == 1) ? 2 : 1;     // a lone tile alternates between two accumulators: no dependent MFMA chain
+    static_assert(PA >= 1 && PB >= 1 && BK % (BF ? 32 : 4) == 0, "chunk shape");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int m0 = by * BM, n0 = bx * BN;
+    const int wm = (wave & 1) * 32 * RM, wn = (wave >> 1) * 32 * RN;
+    const int n_real = g.ones_col >= 0 ? g.N - 1 : g.N;
+    const __amdgpu_buffer_rsrc_t ra = make_rsrc(g.A, g.a_bytes);
+    const __amdgpu_buffer_rsrc_t rb = make_rsrc(g.B, g.b_bytes);
+
+    float sa[PA][4], sb[PB][4];
+    auto gload = [&](int kc) {
+#pragma unroll
+        for (int p = 0; p < PA; ++p) {
+            const int q = p * 256 + tid, k = kc + q / (BM / 4), m = m0 + (q % (BM / 4)) * 4;
+            const bool ok = k < kend && m < g.M;
+            buf_load4(ra, ok ? ((unsigned)k * (unsigned)g.a_cs + (unsigned)m) * 4u : g.a_bytes, sa[p]);
+        }
+#pragma unroll
+        for (int p = 0; p < PB; ++p) {
+            const int q = p * 256 + tid, k = kc + q / (BN / 4), n = n0 + (q % (BN / 4)) * 4;
+            const bool ok = k < kend && n < n_real;
+            buf_load4(rb, ok ? ((unsigned)k * (unsigned)g.b_rs + (unsigned)n) * 4u : g.b_bytes, sb[p]);
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int p = 0; p < PA; ++p)
+            *reinterpret_cast<float4*>(&As_[buf * BK * BM + (p * 256 + tid) * 4]) = make_float4(sa[p][0], sa[p][1], sa[p][2], sa[p][3]);
+#pragma unroll
+        for (int p = 0; p < PB; ++p)
+            *reinterpret_cast<float4*>(&Bs_[buf * BK * BN + (p * 256 + tid) * 4]) = make_float4(sb[p][0], sb[p][1], sb[p][2], sb[p][3]);
+    };
+
+    f32x16 acc[RM][RN][NA];
+#pragma unroll
+    for (int t = 0; t < RM; ++t)
+#pragma unroll
+        for (int u = 0; u < RN; ++u)
+#pragma unroll
+            for (int x = 0; x < NA; ++x)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][u][x][r] = 0.0f;
+    const bool want_rowsum = g.ones_col >= 0 && bx == 0 && wn == 0;
+    float rsum[RM];
+#pragma unroll
+    for (int t = 0; t < RM; ++t) rsum[t] = 0.0f;
+    gload(kbeg);
+    lstore(0);
+    __syncthreads();
+    int cur = 0;
+    for (int kc = kbeg; kc < kend; kc += BK) {
+        const bool more = kc + BK < kend;
+        if (more) gload(kc + BK);
+        if constexpr (BF) {
+            const float* as = &As_[cur * BK * BM + 8 * half * BM + wm + RM * l31];      // this half-wave's k of a step: 16 st + 8 half + e
+            const float* bs = &Bs_[cur * BK * BN + 8 * half * BN + wn + l31];
+#pragma unroll
+            for (int st = 0; st < BK / 16; ++st) {
+                bf16x8_t a8[RM], b8[RN];
+#pragma unroll
+                for (int t = 0; t < RM; ++t) {
+                    float v[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = as[(16 * st + e) * BM + t];
+                    if (want_rowsum) rsum[t] += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+                    const uint4 q = make_uint4(pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3]), pack2_bf16(v[4], v[5]), pack2_bf16(v[6], v[7]));
+                    a8[t] = __builtin_bit_cast(bf16x8_t, q);
+                }
+#pragma unroll
+                for (int u = 0; u < RN; ++u) {
+                    float v[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = bs[(16 * st + e) * BN + 32 * u];
+                    const uint4 q = make_uint4(pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3]), pack2_bf16(v[4], v[5]), pack2_bf16(v[6], v[7]));
+                    b8[u] = __builtin_bit_cast(bf16x8_t, q);
+                }
+#pragma unroll
+                for (int t = 0; t < RM; ++t)
+#pragma unroll
+                    for (int u = 0; u < RN; ++u) acc[t][u][st % NA] = mfma_32x32x16_bf16(a8[t], b8[u], acc[t][u][st % NA]);
+            }
+        } else {
+        const float* as = &As_[cur * BK * BM + half * BM + wm + RM * l31];          // this half-wave's k of a step: 2 st + half
+        const float* bs = &Bs_[cur * BK * BN + half * BN + wn + l31];
+        float av[2][RM], bv[2][RN];
+        auto fetch = [&](int st, float (&a_)[RM], float (&b_)[RN]) {
+#pragma unroll
+            for (int t = 0; t < RM; ++t) a_[t] = as[2 * st * BM + t];
+#pragma unroll
+            for (int u = 0; u < RN; ++u) b_[u] = bs[2 * st * BN + 32 * u];
+        };
+        fetch(0, av[0], bv[0]);
+#pragma unroll
+        for (int st = 0; st < BK / 2; ++st) {
+            if (st + 1 < BK / 2) fetch(st + 1, av[(st + 1) & 1], bv[(st + 1) & 1]);
+            if (want_rowsum) {
+#pragma unroll
+                for (int t = 0; t < RM; ++t) rsum[t] += av[st & 1][t];
+            }
+#pragma unroll
+            for (int t = 0; t < RM; ++t)
+#pragma unroll
+                for (int u = 0; u < RN; ++u)
+                    acc[t][u][st % NA] = mfma_32x32x2(av[st & 1][t], bv[st & 1][u], acc[t][u][st % NA]);
+        }
+        }
+        if (more) lstore(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    if (want_rowsum) {
+#pragma unroll
+        for (int t = 0; t < RM; ++t) {
+            const float v = rsum[t] + __shfl_xor(rsum[t], 32);
+            const int row = m0 + wm + RM * l31 + t;
+            if (half == 0 && row < g.M) atomicAdd(g.C2 + row, v);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < RM; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = m0 + wm + RM * acc_row(r, half) + t;
+            if (row >= g.M) continue;
+#pragma unroll
+            for (int u = 0; u < RN; ++u) {
+                const int col = n0 + wn + 32 * u + l31;
+                const float v = NA == 2 ? acc[t][u][0][r] + acc[t][u][NA - 1][r] : acc[t][u][0][r];
+                if (col < n_real) atomicAdd(g.C + (long)row * g.ldc + col, v);
+            }
+        }
+}
 
 }  // namespace

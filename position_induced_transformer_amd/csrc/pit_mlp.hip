@@ -49,7 +49,7 @@ __global__ __launch_bounds__(512) void gemm_rd_pair_kernel(GemmArgs g1, GemmArgs
 // the weight-gradient reductions of SEVERAL MLPs (up to DW_BATCH_MAX pairs) in ONE launch (pit_mlp_bwd_params_batch): the
 // small-regime backward pass postpones every MLP's reductions - nothing downstream reads them - and runs them together
 // when the pass ends, as one chip-filling grid instead of riders that lengthen every launch of the dependent chain
-constexpr int DW_BATCH_MAX = 8;                     // (8 x 488 B of DwPair + the header stay under the 4 KB kernel-argument limit)
+constexpr int DW_BATCH_MAX = 7;                     // (7 x 528 B of DwPair + the header stay under the 4 KB kernel-argument limit)
 struct DwBatch { int n; int base[DW_BATCH_MAX + 1]; pit_detail::DwPair p[DW_BATCH_MAX]; };
 __global__ __launch_bounds__(512) void gemm_rd_batch_kernel(DwBatch b) {
     int i = 0;
@@ -464,17 +464,7 @@ __device__ int pit_mlp_rec_k;                               // gemm_lds_kernel r
         pit_mlp_wgrec[lid_ * 4 + (slot_)] = __builtin_amdgcn_s_memrealtime();                                              \
         if ((slot_) == 0) { pit_mlp_wgrec[lid_ * 4 + 2] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));      \
                             pit_mlp_wgrec[lid_ * 4 + 3] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)); } } } while (0)
-#define MSTAMP(i_) do { if (threadIdx.x == 0 && tiles > 1) {       /* (diagnostic: the multi-tile launch = dW1) */ \
-     const unsigned long long t_ = __builtin_amdgcn_s_memtime();               \
-        if (blockIdx.x == 8) pit_mlp_stamps[i_] = t_;                                                                      \
-        if (blockIdx.x == 8 && (i_) == 0) pit_mlp_stamps[57] = __builtin_amdgcn_s_memrealtime();                            \
-        if (blockIdx.x == 8 && (i_) == 61) pit_mlp_stamps[58] = __builtin_amdgcn_s_memrealtime();                           \
-        if ((i_) == 0) atomicMin(&pit_mlp_stamps[62], __builtin_amdgcn_s_memrealtime());   /* (s_memtime: one per XCD) */  \
-        if ((i_) == 0) atomicMax(&pit_mlp_stamps[59], __builtin_amdgcn_s_memrealtime());                                    \
-        if ((i_) == 61) atomicMin(&pit_mlp_stamps[56], __builtin_amdgcn_s_memrealtime());                                   \
-        if ((i_) == 61) atomicMax(&pit_mlp_stamps[63], __builtin_amdgcn_s_memrealtime()); } } while (0)
 #else
-#define MSTAMP(i_) do { } while (0)
 #define MREC(slot_, cond_) do { } while (0)
 #endif
 constexpr int LBN = 64, LBK = 32;
@@ -666,29 +656,15 @@ __global__ __launch_bounds__(256) void gemm_lds_kernel(GemmArgs g) {
 //  * the slabs of one tile set are dealt to ONE XCD (grid id -> (slab, tile) below): the operand rows a slab's tiles
 //    share come from HBM once.
 // Bias gradient = row sums of A, accumulated from the fragments by the first column block (as gemm_lds_kernel).
-typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
-__device__ __forceinline__ f32x16 mfma_32x32x16_bf16(bf16x8_t a, bf16x8_t b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
-}
-__device__ __forceinline__ unsigned pack2_bf16(float lo, float hi) {
-    typedef float f32x2_t __attribute__((ext_vector_type(2)));
-    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-    const f32x2_t v = {lo, hi};
-    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
-}
 // BF (PIT_MATH_BF16, fp32-stored operands): the same images, rounded to bf16 (RNE) on the way from LDS to the
 // v_mfma_f32_32x32x16_bf16 operands - 16 k per instruction, this half-wave's 8 k of a step = 8 LDS reads + 4 packs per operand.
+// (the tile itself: gemm_rr_tile, pit_gemm_rd.h)
 template <int RM, int RN, int BK, bool BF = false>
 __global__ __launch_bounds__(256) void gemm_rr_kernel(GemmArgs g1, GemmArgs g2, int tx1, int T1, int tx2, int T2, int slabs,
                                                       int nchunks) {
     constexpr int BM = 64 * RM, BN = 64 * RN;
-    constexpr int PA = BK * BM / 1024, PB = BK * BN / 1024;         // 16-B loads per thread and chunk
-    constexpr int NA = (RM * RN == 1) ? 2 : 1;     // a lone tile alternates between two accumulators: no dependent MFMA chain
-    static_assert(PA >= 1 && PB >= 1 && BK % (BF ? 32 : 4) == 0, "chunk shape");
-    __shared__ __attribute__((aligned(16))) float As[2][BK * BM];
-    __shared__ __attribute__((aligned(16))) float Bs[2][BK * BN];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int half = lane >> 5, l31 = lane & 31;
+    __shared__ __attribute__((aligned(16))) float As[2 * BK * BM];
+    __shared__ __attribute__((aligned(16))) float Bs[2 * BK * BN];
     // work item w = slab * (T1 + T2) + tile, dealt to the XCDs in CONTIGUOUS ranges (hardware deals workgroup ids round-robin):
     // every XCD gets the same number of items, and the tiles of a slab - which share operand rows - mostly meet in one L2
     const int tiles = T1 + T2, P = tiles * slabs, Q = (P + 7) / 8;
@@ -698,146 +674,10 @@ __global__ __launch_bounds__(256) void gemm_rr_kernel(GemmArgs g1, GemmArgs g2, 
     const bool first = tile_all < T1;
     const GemmArgs& g = first ? g1 : g2;
     const int tile = first ? tile_all : tile_all - T1, tiles_x = first ? tx1 : tx2;
-    const int bx = tile % tiles_x, by = tile / tiles_x;
-    const int m0 = by * BM, n0 = bx * BN;
-    const int wm = (wave & 1) * 32 * RM, wn = (wave >> 1) * 32 * RN;
     const int kbeg = (int)((long)slab * nchunks / slabs) * BK;
     const int kend = min(g.K, (int)((long)(slab + 1) * nchunks / slabs) * BK);
-    const int n_real = g.ones_col >= 0 ? g.N - 1 : g.N;
-    const __amdgpu_buffer_rsrc_t ra = make_rsrc(g.A, g.a_bytes);
-    const __amdgpu_buffer_rsrc_t rb = make_rsrc(g.B, g.b_bytes);
-
-    float sa[PA][4], sb[PB][4];
-    auto gload = [&](int kc) {
-#pragma unroll
-        for (int p = 0; p < PA; ++p) {
-            const int q = p * 256 + tid, k = kc + q / (BM / 4), m = m0 + (q % (BM / 4)) * 4;
-            const bool ok = k < kend && m < g.M;
-            buf_load4(ra, ok ? ((unsigned)k * (unsigned)g.a_cs + (unsigned)m) * 4u : g.a_bytes, sa[p]);
-        }
-#pragma unroll
-        for (int p = 0; p < PB; ++p) {
-            const int q = p * 256 + tid, k = kc + q / (BN / 4), n = n0 + (q % (BN / 4)) * 4;
-            const bool ok = k < kend && n < n_real;
-            buf_load4(rb, ok ? ((unsigned)k * (unsigned)g.b_rs + (unsigned)n) * 4u : g.b_bytes, sb[p]);
-        }
-    };
-    auto lstore = [&](int buf) {
-#pragma unroll
-        for (int p = 0; p < PA; ++p)
-            *reinterpret_cast<float4*>(&As[buf][(p * 256 + tid) * 4]) = make_float4(sa[p][0], sa[p][1], sa[p][2], sa[p][3]);
-#pragma unroll
-        for (int p = 0; p < PB; ++p)
-            *reinterpret_cast<float4*>(&Bs[buf][(p * 256 + tid) * 4]) = make_float4(sb[p][0], sb[p][1], sb[p][2], sb[p][3]);
-    };
-
-    f32x16 acc[RM][RN][NA];
-#pragma unroll
-    for (int t = 0; t < RM; ++t)
-#pragma unroll
-        for (int u = 0; u < RN; ++u)
-#pragma unroll
-            for (int x = 0; x < NA; ++x)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[t][u][x][r] = 0.0f;
-    const bool want_rowsum = g.ones_col >= 0 && bx == 0 && wn == 0;
-    float rsum[RM];
-#pragma unroll
-    for (int t = 0; t < RM; ++t) rsum[t] = 0.0f;
-
-    MSTAMP(0);
     MREC(0, tiles > 1);
-    gload(kbeg);
-    lstore(0);
-    __syncthreads();
-    MSTAMP(1);
-    int cur = 0, chunk_i = 0;
-    for (int kc = kbeg; kc < kend; kc += BK, ++chunk_i) {
-        const bool more = kc + BK < kend;
-        if (more) gload(kc + BK);
-        if constexpr (BF) {
-            const float* as = &As[cur][8 * half * BM + wm + RM * l31];      // this half-wave's k of a step: 16 st + 8 half + e
-            const float* bs = &Bs[cur][8 * half * BN + wn + l31];
-#pragma unroll
-            for (int st = 0; st < BK / 16; ++st) {
-                bf16x8_t a8[RM], b8[RN];
-#pragma unroll
-                for (int t = 0; t < RM; ++t) {
-                    float v[8];
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = as[(16 * st + e) * BM + t];
-                    if (want_rowsum) rsum[t] += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
-                    const uint4 q = make_uint4(pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3]), pack2_bf16(v[4], v[5]), pack2_bf16(v[6], v[7]));
-                    a8[t] = __builtin_bit_cast(bf16x8_t, q);
-                }
-#pragma unroll
-                for (int u = 0; u < RN; ++u) {
-                    float v[8];
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = bs[(16 * st + e) * BN + 32 * u];
-                    const uint4 q = make_uint4(pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3]), pack2_bf16(v[4], v[5]), pack2_bf16(v[6], v[7]));
-                    b8[u] = __builtin_bit_cast(bf16x8_t, q);
-                }
-#pragma unroll
-                for (int t = 0; t < RM; ++t)
-#pragma unroll
-                    for (int u = 0; u < RN; ++u) acc[t][u][st % NA] = mfma_32x32x16_bf16(a8[t], b8[u], acc[t][u][st % NA]);
-            }
-        } else {
-        const float* as = &As[cur][half * BM + wm + RM * l31];          // this half-wave's k of a step: 2 st + half
-        const float* bs = &Bs[cur][half * BN + wn + l31];
-        float av[2][RM], bv[2][RN];
-        auto fetch = [&](int st, float (&a_)[RM], float (&b_)[RN]) {
-#pragma unroll
-            for (int t = 0; t < RM; ++t) a_[t] = as[2 * st * BM + t];
-#pragma unroll
-            for (int u = 0; u < RN; ++u) b_[u] = bs[2 * st * BN + 32 * u];
-        };
-        fetch(0, av[0], bv[0]);
-#pragma unroll
-        for (int st = 0; st < BK / 2; ++st) {
-            if (st + 1 < BK / 2) fetch(st + 1, av[(st + 1) & 1], bv[(st + 1) & 1]);
-            if (want_rowsum) {
-#pragma unroll
-                for (int t = 0; t < RM; ++t) rsum[t] += av[st & 1][t];
-            }
-#pragma unroll
-            for (int t = 0; t < RM; ++t)
-#pragma unroll
-                for (int u = 0; u < RN; ++u)
-                    acc[t][u][st % NA] = mfma_32x32x2(av[st & 1][t], bv[st & 1][u], acc[t][u][st % NA]);
-        }
-        }
-        if (chunk_i < 20) MSTAMP(2 + 2 * chunk_i);
-        if (more) lstore(cur ^ 1);
-        __syncthreads();
-        if (chunk_i < 20) MSTAMP(3 + 2 * chunk_i);
-        cur ^= 1;
-    }
-    MSTAMP(60);
-
-    if (want_rowsum) {
-#pragma unroll
-        for (int t = 0; t < RM; ++t) {
-            const float v = rsum[t] + __shfl_xor(rsum[t], 32);
-            const int row = m0 + wm + RM * l31 + t;
-            if (half == 0 && row < g.M) atomicAdd(g.C2 + row, v);
-        }
-    }
-#pragma unroll
-    for (int t = 0; t < RM; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = m0 + wm + RM * acc_row(r, half) + t;
-            if (row >= g.M) continue;
-#pragma unroll
-            for (int u = 0; u < RN; ++u) {
-                const int col = n0 + wn + 32 * u + l31;
-                const float v = NA == 2 ? acc[t][u][0][r] + acc[t][u][NA - 1][r] : acc[t][u][0][r];
-                if (col < n_real) atomicAdd(g.C + (long)row * g.ldc + col, v);
-            }
-        }
-    MSTAMP(61);
+    gemm_rr_tile<RM, RN, BK, BF>(g, tile % tiles_x, tile / tiles_x, kbeg, kend, As, Bs);
     MREC(1, tiles > 1);
 }
 
@@ -1735,7 +1575,7 @@ int launch_dz1(int rows, int n1, int n2, const float* w2, const float* z1, const
 
 // the reductions of a postponed pit_mlp_bwd_params, laid out for a launch that carries them along
 // (pit_posatt.hip: posatt_bwd_pair_dw_kernel); same tiling as launch_gemm_pair_atomic
-bool pit_detail::plan_dw_pair(const pit_mlp_params_job& j, int waves, DwPair* out, int target_wgs) {
+bool pit_detail::plan_dw_pair(const pit_mlp_params_job& j, int waves, DwPair* out, int target_wgs, bool allow_rr) {
     static const bool off = getenv("PIT_NO_DW_RIDER") != nullptr;
     if (off || !j.accumulate) return false;
     if (!j.x || !j.h || !j.d_y || !j.d_w1 || !j.d_b1 || !j.d_w2 || !j.d_b2 || !j.scratch) return false;
@@ -1754,6 +1594,27 @@ bool pit_detail::plan_dw_pair(const pit_mlp_params_job& j, int waves, DwPair* ou
     if (!ok) return false;
     out->n1 = L1.grid.x * L1.grid.y * L1.grid.z; out->n2 = L2.grid.x * L2.grid.y * L2.grid.z;
     out->gx1 = L1.grid.x; out->gy1 = L1.grid.y; out->gx2 = L2.grid.x; out->gy2 = L2.grid.y;
+    out->rr1 = out->rr2 = 0;
+    out->tx1 = out->tiles1 = out->slabs1 = out->tx2 = out->tiles2 = out->slabs2 = 0;
+    out->nchunks = (j.rows + RR_BK - 1) / RR_BK;
+    // a reduction with full 64-wide tiles rides as gemm_rr_tile tiles when the carrying kernel can run them: LDS-staged,
+    // coalesced, a few chunks per workgroup - the register-direct form of the same reduction keeps 6-12x as many
+    // workgroups busy for the same MACs and lengthens the launch it rides in
+    static const bool no_rr = getenv("PIT_NO_RR_RIDER") != nullptr;
+    static const int per_wg = getenv("PIT_RR_RIDER_CHUNKS") ? std::max(1, atoi(getenv("PIT_RR_RIDER_CHUNKS"))) : 2;
+    if (allow_rr && !no_rr && (j.math_mode & 0xff) == 0) {
+        auto as_rr = [&](const GemmArgs& g, int& rr, int& tx, int& tiles, int& slabs, int& n) {
+            const int n_real = g.ones_col >= 0 ? g.N - 1 : g.N;
+            if (!gemm_rr_ok(g) || g.M < 32 || n_real < 48) return;
+            rr = 1;
+            tx = (n_real + 63) / 64;
+            tiles = tx * ((g.M + 63) / 64);
+            slabs = std::max(1, out->nchunks / per_wg);
+            n = tiles * slabs;
+        };
+        as_rr(out->g1, out->rr1, out->tx1, out->tiles1, out->slabs1, out->n1);
+        as_rr(out->g2, out->rr2, out->tx2, out->tiles2, out->slabs2, out->n2);
+    }
     return true;
 }
 
