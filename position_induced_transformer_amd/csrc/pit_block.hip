@@ -580,25 +580,6 @@ __device__ __forceinline__ void block_bwd_dscale(const BlockBwdArgs& g, float* s
     }
 }
 
-// one reduction of a rider as a gemm_rr_tile tile (DwPair::rr1 / rr2): the first four waves, 64 KiB of the launch's LDS
-__device__ __forceinline__ void rr_rider(const pit_detail::GemmArgs& g, int id, int tx, int tiles, int slabs, int nchunks, float* smem) {
-    if (threadIdx.x >= 256) return;                       // (ended waves do not take part in the tile's barriers)
-    const int slab = id / tiles, tile = id % tiles;
-    const int kbeg = (int)((long)slab * nchunks / slabs) * pit_detail::RR_BK;
-    const int kend = min(g.K, (int)((long)(slab + 1) * nchunks / slabs) * pit_detail::RR_BK);
-    gemm_rr_tile<1, 1, pit_detail::RR_BK, false>(g, tile % tx, tile / tx, kbeg, kend, smem, smem + 2 * pit_detail::RR_BK * 64);
-}
-__device__ __forceinline__ void dw_pair_body(const pit_detail::DwPair& w, int id, float* smem) {
-    if (id < w.n1) {
-        if (w.rr1) rr_rider(w.g1, id, w.tx1, w.tiles1, w.slabs1, w.nchunks, smem);
-        else gemm_rd_body<1, EPI_ATOMIC>(w.g1, id % w.gx1, (id / w.gx1) % w.gy1, id / (w.gx1 * w.gy1));
-    } else {
-        id -= w.n1;
-        if (w.rr2) rr_rider(w.g2, id, w.tx2, w.tiles2, w.slabs2, w.nchunks, smem);
-        else gemm_rd_body<1, EPI_ATOMIC>(w.g2, id % w.gx2, (id / w.gx2) % w.gy2, id / (w.gx2 * w.gy2));
-    }
-}
-
 // NDW riders (0, 1 or 2 pairs of weight-gradient reductions): the block's own MLP, and a slice of a LARGER postponed job
 // (the decoder MLP's: 14 792 rows at Darcy b=8 - inside the decoder attention's own launch it cost more than a launch of
 // its own, spread over the block launches it runs on compute units the chain leaves idle)

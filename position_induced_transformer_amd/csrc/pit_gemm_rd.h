@@ -389,4 +389,31 @@ __device__ __forceinline__ void gemm_rr_tile(const GemmArgs& g, int bx, int by, 
         }
 }
 
+// the launch's dynamic LDS (every `extern __shared__` array of a kernel names the same base)
+__device__ __forceinline__ float* pit_dyn_smem() {
+    extern __shared__ __attribute__((aligned(16))) float pit_dyn_lds[];
+    return pit_dyn_lds;
+}
+// one reduction of a rider as a gemm_rr_tile tile (DwPair::rr1 / rr2): the first four waves, 64 KiB of the launch's LDS
+__device__ __forceinline__ void rr_rider(const pit_detail::GemmArgs& g, int id, int tx, int tiles, int slabs, int nchunks, float* smem) {
+    if (threadIdx.x >= 256) return;                       // (ended waves do not take part in the tile's barriers)
+    const int slab = id / tiles, tile = id % tiles;
+    const int kbeg = (int)((long)slab * nchunks / slabs) * pit_detail::RR_BK;
+    const int kend = min(g.K, (int)((long)(slab + 1) * nchunks / slabs) * pit_detail::RR_BK);
+    gemm_rr_tile<1, 1, pit_detail::RR_BK, false>(g, tile % tx, tile / tx, kbeg, kend, smem, smem + 2 * pit_detail::RR_BK * 64);
+}
+// workgroup `id` of a carried pair of weight-gradient reductions; `smem`: the launch's dynamic LDS (64 KiB when the plan
+// allowed rr reductions, see plan_dw_pair)
+__device__ __forceinline__ void dw_pair_body(const pit_detail::DwPair& w, int id, float* smem) {
+    if (id < w.n1) {
+        if (w.rr1) rr_rider(w.g1, id, w.tx1, w.tiles1, w.slabs1, w.nchunks, smem);
+        else gemm_rd_body<1, EPI_ATOMIC>(w.g1, id % w.gx1, (id / w.gx1) % w.gy1, id / (w.gx1 * w.gy1));
+    } else {
+        id -= w.n1;
+        if (w.rr2) rr_rider(w.g2, id, w.tx2, w.tiles2, w.slabs2, w.nchunks, smem);
+        else gemm_rd_body<1, EPI_ATOMIC>(w.g2, id % w.gx2, (id / w.gx2) % w.gy2, id / (w.gx2 * w.gy2));
+    }
+}
+
+
 }  // namespace
