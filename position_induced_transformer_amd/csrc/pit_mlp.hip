@@ -1327,7 +1327,10 @@ bool try_launch_gemm_lds(GemmArgs g, hipStream_t s) {
     // workgroups go through them in step - tools/stamp_gemm.py: 512 workgroups, every one alive for the whole launch, 4 us of
     // MFMA in a 15 us life): 64-row tiles double the workgroups and let one's stores overlap another's loads - the hid-64 MLP
     // at 65 536 rows: forward 49.1 -> 42.5 us, backward data path 59.8 -> 51.9 us, Darcy b=256 step 2.04 -> 1.94 ms
-    if (bm == 128 && g.epi != EPI_ATOMIC && g.K <= 256) bm = 64;
+    // (N <= 256 only: the decoder's K = 256, N = 768 GEMMs are compute-bound at 70 % MFMA busy and keep the tall tile -
+    // Vorticity bf16 1.249 -> 1.221 ms with the limit)
+    static const int short_n = getenv("PIT_LDS_SHORT_N") ? atoi(getenv("PIT_LDS_SHORT_N")) : 256;
+    if (bm == 128 && g.epi != EPI_ATOMIC && g.K <= 256 && g.N <= short_n) bm = 64;
     static const int force_bm = getenv("PIT_LDS_BM") ? atoi(getenv("PIT_LDS_BM")) : 0;      // experiments
     if (force_bm && g.epi != EPI_ATOMIC) bm = force_bm;
     static const bool no32 = getenv("PIT_LDS_NO_BM32") != nullptr;
