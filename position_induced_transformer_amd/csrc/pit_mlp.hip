@@ -471,8 +471,12 @@ constexpr int LBN = 64, LBK = 32;
 constexpr int LPK = LBK + 4;      // row pitch of the [i][k] layouts (floats): 144 B, 16-B aligned, bank-skewed
 constexpr int LPN = LBN + 4;      // [k][n]
 
-template <int LBM, bool A_KC, bool B_KC, int EPI, bool BF>
+// AGZ (round 3; k-contiguous A only): the trailing-gelu prologue A(m,k) *= gelu'(a_gz[m][k]) applied while the chunk goes from the
+// staging registers to LDS, the product written to a_out by the first column block - was an elementwise pass of its own
+// (mul_gelu_grad_kernel: 10 us per MLP backward at 65 536 rows)
+template <int LBM, bool A_KC, bool B_KC, int EPI, bool BF, bool AGZ = false>
 __global__ __launch_bounds__(256) void gemm_lds_kernel(GemmArgs g) {
+    static_assert(!AGZ || A_KC, "the fused prologue reads a_gz with A's k-contiguous pattern");
     constexpr int LPM = LBM + 4;      // [k][m]
     constexpr int TN = (LBM == 128) ? 2 : 1;      // accumulator tiles per wave
     constexpr int PA = LBM / 32;                  // staging passes for A (4 floats per thread and pass)
@@ -502,7 +506,9 @@ __global__ __launch_bounds__(256) void gemm_lds_kernel(GemmArgs g) {
     const int n_real = (EPI == EPI_ATOMIC && g.ones_col >= 0) ? g.N - 1 : g.N;   // columns that exist in memory
 
     MREC(0, g.K == pit_mlp_rec_k && blockIdx.z == 0);
+    const __amdgpu_buffer_rsrc_t rz = make_rsrc(AGZ ? g.a_gz : g.A, g.a_bytes);
     float sa[PA][4], sb[2][4];         // staging registers: next chunk in flight during the MFMAs
+    float sz[AGZ ? PA : 1][4];
     auto gload = [&](int kc) {
 #pragma unroll
         for (int p = 0; p < PA; ++p) {
@@ -518,7 +524,8 @@ __global__ __launch_bounds__(256) void gemm_lds_kernel(GemmArgs g) {
                 ok = k < kend && m < g.M;
                 off = ((unsigned)k * (unsigned)g.a_cs + (unsigned)m) * 4u;
             }
-            buf_load4(ra, ok ? off : g.a_bytes, sa[p]);     // (a trailing-gelu prologue runs as its own pass before this kernel)
+            buf_load4(ra, ok ? off : g.a_bytes, sa[p]);     // (a trailing-gelu prologue: AGZ, or its own pass before this kernel)
+            if constexpr (AGZ) buf_load4(rz, ok ? off : g.a_bytes, sz[p]);
         }
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
@@ -533,10 +540,17 @@ __global__ __launch_bounds__(256) void gemm_lds_kernel(GemmArgs g) {
             }
         }
     };
-    auto lstore = [&]() {
+    auto lstore = [&](int kc) {
 #pragma unroll
         for (int p = 0; p < PA; ++p) {
             constexpr int TPR = LBM / 4, KPP = 256 / TPR;
+            if constexpr (AGZ) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) sa[p][e] *= gelu_erf_grad(sz[p][e]);
+                const int row = m0 + p * 32 + (tid >> 3), k = kc + (tid & 7) * 4;
+                if (bx == 0 && row < g.M && k < kend)
+                    *reinterpret_cast<float4*>(g.a_out + (long)row * g.a_out_rs + k) = make_float4(sa[p][0], sa[p][1], sa[p][2], sa[p][3]);
+            }
             float* dst = A_KC ? As + (p * 32 + (tid >> 3)) * LPK + (tid & 7) * 4
                               : As + (p * KPP + tid / TPR) * LPM + (tid % TPR) * 4;
             *reinterpret_cast<float4*>(dst) = make_float4(sa[p][0], sa[p][1], sa[p][2], sa[p][3]);
@@ -561,7 +575,7 @@ __global__ __launch_bounds__(256) void gemm_lds_kernel(GemmArgs g) {
 
     gload(kbeg);
     for (int kc = kbeg; kc < kend; kc += LBK) {
-        lstore();
+        lstore(kc);
         __syncthreads();
         if (kc + LBK < kend) gload(kc + LBK);
 #pragma unroll
@@ -1310,14 +1324,20 @@ bool try_launch_gemm_lds(GemmArgs g, hipStream_t s) {
     else if (a_kc && b_kc && !g.a_gz && (g.epi == EPI_BIAS || g.epi == EPI_BIAS_GELU)) kind = (g.epi == EPI_BIAS) ? 0 : 1;
     else if (a_kc && b_ic && (g.epi == EPI_MUL_GELU_GRAD || g.epi == EPI_STORE)) kind = (g.epi == EPI_MUL_GELU_GRAD) ? 2 : 3;
     if (kind < 0) return false;
-    if (g.a_gz) {                                    // trailing-gelu prologue as its own elementwise pass
+    static const bool no_agz = getenv("PIT_NO_FUSED_GELU_PROLOGUE") != nullptr;
+    bool agz = false;
+    if (g.a_gz) {                                    // trailing-gelu prologue
         if (!g.a_out || g.a_out_cs != 1 || g.a_out_rs % 4 != 0 || !aligned16(g.a_out)) return false;
-        const long quads = (long)g.M * (g.K / 4);
-        hipLaunchKernelGGL(mul_gelu_grad_kernel, dim3((unsigned)std::min<long>((quads + 255) / 256, 4096)), dim3(256), 0, s,
-                           g.A, g.a_rs, g.a_gz, g.a_out, g.a_out_rs, g.M, g.K);
-        g.A = g.a_out; g.a_rs = g.a_out_rs;
-        g.a_bytes = (unsigned)((((unsigned long long)(g.M - 1) * g.a_rs) + g.K) * 4ull);
-        g.a_gz = nullptr; g.a_out = nullptr;
+        if (kind == 2 && !g.bf16 && !io16 && !no_agz && g.K <= 128) {    // (K = 256: neutral at Vorticity, +0.6 % at Cylinder)
+            agz = true;                              // fp32 mode: inside the GEMM's staging (gemm_lds_kernel<..., AGZ>)
+        } else {                                     // as its own elementwise pass
+            const long quads = (long)g.M * (g.K / 4);
+            hipLaunchKernelGGL(mul_gelu_grad_kernel, dim3((unsigned)std::min<long>((quads + 255) / 256, 4096)), dim3(256), 0, s,
+                               g.A, g.a_rs, g.a_gz, g.a_out, g.a_out_rs, g.M, g.K);
+            g.A = g.a_out; g.a_rs = g.a_out_rs;
+            g.a_bytes = (unsigned)((((unsigned long long)(g.M - 1) * g.a_rs) + g.K) * 4ull);
+            g.a_gz = nullptr; g.a_out = nullptr;
+        }
     }
     const int gx = (n_real + LBN - 1) / LBN;
     // 128-row tiles while they still give two workgroups per CU (or when K slabs add parallelism)
@@ -1374,7 +1394,13 @@ bool try_launch_gemm_lds(GemmArgs g, hipStream_t s) {
     switch (kind) {
         case 0: PIT_LDS(true, true, EPI_BIAS); break;
         case 1: PIT_LDS(true, true, EPI_BIAS_GELU); break;
-        case 2: PIT_LDS(true, false, EPI_MUL_GELU_GRAD); break;
+        case 2:
+            if (agz) {
+                if (bm == 128) hipLaunchKernelGGL((gemm_lds_kernel<128, true, false, EPI_MUL_GELU_GRAD, false, true>), grid, block, 0, s, g);
+                else if (bm == 64) hipLaunchKernelGGL((gemm_lds_kernel<64, true, false, EPI_MUL_GELU_GRAD, false, true>), grid, block, 0, s, g);
+                else hipLaunchKernelGGL((gemm_lds_kernel<32, true, false, EPI_MUL_GELU_GRAD, false, true>), grid, block, 0, s, g);
+            } else PIT_LDS(true, false, EPI_MUL_GELU_GRAD);
+            break;
         case 3: PIT_LDS(true, false, EPI_STORE); break;
         default:
             if (g.bf16 && !legacy_bf && io16) hipLaunchKernelGGL((gemm_bfl_kernel<128, false, false, EPI_ATOMIC, true, BK128>), grid, block, 0, s, g);
