@@ -12,7 +12,7 @@ want = {  # bench key -> (config, kernel-name prefix)
     "block_bwd_kernel_b8": ("darcy8", "block_bwd_kernel<2, 2>"),
     "block_fwd_kernel_b8": ("darcy8", "block_fwd_kernel<2, false>"),
     "mlp_fwd_b8": ("darcy8", "mlp_fwd16_kernel<64, 8>"),
-    "mlp_fwd_b256": ("darcy256", "gemm_lds_kernel<64, true, true, 2, false>"),
+    "mlp_fwd_b256": ("darcy256", "gemm_lds_kernel<64, true, true, 2, false"),
     "posatt_rows_fwd_b256": ("darcy256", "posatt_rows_tiles<4, 1, 0, false, false>"),
 }
 out = {"source": "tools/profile_round.sh: rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (own passes), bench.py "

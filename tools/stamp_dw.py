@@ -1,4 +1,5 @@
-"""Diagnostic: phase timeline of gemm_rr_kernel (workgroup 8, thread 0) from in-kernel s_memtime stamps (100 MHz).
+"""Diagnostic: per-workgroup records of the gemm_rr_kernel launch inside pit_mlp_bwd_params - entry / exit on the 100 MHz
+s_memrealtime clock, HW_ID and XCC_ID of every workgroup: how many workgroups each CU got, lifetimes alone / sharing a CU, per XCD.
 Needs a library built with -DPIT_STAMPS (PIT_LIB_OUT=... PIT_EXTRA_FLAGS=-DPIT_STAMPS python -m ...build) in PIT_LIB_PATH.
 Usage: stamp_dw.py <shape> <which: 1|2>"""
 import ctypes, os, sys
@@ -27,23 +28,6 @@ for it in range(5):
                               gw2.data_ptr(), gb2.data_ptr(), 1, scratch.data_ptr(), 0, torch.cuda.current_stream().cuda_stream)
     assert rc == 0
 torch.cuda.synchronize()
-buf = (ctypes.c_ulonglong * 64)()
-assert L.pit_mlp_debug_read_stamps(buf) == 0
-t = list(buf)
-print(f"{name}: the LAST gemm_rr launch (dW1), workgroup 8; s_memtime ticks")
-rt = (t[58] - t[57]) * 10
-print(f"  workgroup 8 lived {t[61] - t[0]} s_memtime ticks = {rt} ns of s_memrealtime (100 MHz) -> {(t[61] - t[0]) / max(rt, 1):.3f} ticks per ns")
-t[57] = t[58] = 0
-print(f"  all workgroups of the call's launches (100 MHz clock): first entry -> last entry {(t[59] - t[62]) * 10} ns, -> first exit "
-      f"{(t[56] - t[62]) * 10} ns, -> last exit {(t[63] - t[62]) * 10} ns")
-t[56] = 0
-prev = t[0]
-for i in range(62):
-    if t[i] and i != 59:
-        what = {0: "entry", 1: "first chunk in LDS", 60: "loop done", 61: "epilogue done"}.get(i, f"chunk {(i - 2) // 2} " + ("contracted" if i % 2 == 0 else "next chunk stored + barrier"))
-        print(f"  {what:40s} +{(t[i] - prev):7d} ticks   (t = {(t[i] - t[0]):7d})")
-        prev = t[i]
-
 # per-workgroup records of the dW1 launch: lifetime against placement
 n = 1024
 rec = (ctypes.c_ulonglong * (4 * n))()
