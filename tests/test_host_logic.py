@@ -230,3 +230,27 @@ def test_build_is_stale_after_a_build_with_other_flags_and_the_binding_checks_th
         _lib.lib()
     monkeypatch.undo()
     assert _lib.lib() is not None
+
+
+def test_postponed_job_slices_cover_the_rows_once_and_respect_the_early_bucket():
+    """ops._dw_slices: a postponed weight-gradient job cut into row slices for the fused processor's launches - every row
+    exactly once, slices 16-row aligned, operand pointers advanced by whole rows; and the number of parts a two-bucket step
+    allows (ops._PROCESSOR_HOOK = (callback, complete_by)): only the launches up to the early bucket's reduce."""
+    from position_induced_transformer_amd import _lib, ops
+    rows, n0, n1, n2 = 14792, 128, 64, 1
+    job = _lib.MlpParamsJob(0x10000000, n0, rows, n0, n1, n2, 0x20000000, 0, 0x30000000, n2, 1, 2, 3, 4, 1, 0x40000000, 0)
+    for parts in (1, 2, 3, 4):
+        sl = ops._dw_slices((job,), parts)
+        assert len(sl) <= parts and sum(s.rows for s in sl) == rows
+        r0 = 0
+        for s in sl:
+            assert r0 % 16 == 0 and s.accumulate == 1 and s.out_gelu == 0
+            assert s.x == job.x + 4 * r0 * n0 and s.h == job.h + 4 * r0 * n1
+            assert s.d_y == job.d_y + 4 * r0 * n2 and s.scratch == job.scratch + 4 * r0 * n1
+            assert (s.d_w1, s.d_b1, s.d_w2, s.d_b2) == (1, 2, 3, 4)
+            r0 += s.rows
+    # the number of launches that may carry a slice: all n blocks, or n - complete_by under a two-bucket step
+    n = 4
+    for hook, want in ((None, 4), ((lambda i: None, 2), 2), ((lambda i: None, 3), 1), ((lambda i: None, 0), 4)):
+        parts = n if hook is None else max(1, n - hook[1])
+        assert parts == want
