@@ -283,6 +283,37 @@ def roofline_mlp_probe(model, batch):
             "us_per_launch": round(us_launch, 3), "flops_per_launch": flops, "algorithmic_bytes": alg_bytes}
 
 
+def roofline_dw_probe(model, batch):
+    """The weight-gradient reductions of the processor MLP in the large regime - dW1 = dZ1^T X, dW2 = dZ2^T H and both bias
+    gradients in ONE gemm_rr_kernel launch (pit_mlp_bwd_params): 2*rows*(n0*n1 + n1*n2) FLOPs, algorithmic bytes
+    4*rows*(n0 + 2*n1 + n2) (X, dZ1, H, dZ2 read once; the outputs are a few KB), fp32 MFMA peak; timed live through the
+    C ABI on operands of the step's shapes."""
+    from position_induced_transformer_amd import _lib
+    mlp = model.mlp[0]
+    rows_per_sample = model.mesh_ltt.shape[0] if model.mesh_ltt is not None else 972
+    n0, n1, n2 = mlp.mlp1.in_features, mlp.mlp1.out_features, mlp.mlp2.out_features
+    rows = batch * rows_per_sample
+    x, h = torch.randn(rows, n0, device="cuda"), torch.randn(rows, n1, device="cuda")
+    scratch, dy = torch.randn(rows * (n1 + n2), device="cuda"), torch.randn(rows, n2, device="cuda")
+    gw1, gb1 = torch.zeros(n1, n0, device="cuda"), torch.zeros(n1, device="cuda")
+    gw2, gb2 = torch.zeros(n2, n1, device="cuda"), torch.zeros(n2, device="cuda")
+    L = _lib.lib()
+
+    def call():
+        _lib.check(L.pit_mlp_bwd_params(x.data_ptr(), n0, rows, n0, n1, n2, h.data_ptr(), 1, dy.data_ptr(), n2, gw1.data_ptr(),
+                                        gb1.data_ptr(), gw2.data_ptr(), gb2.data_ptr(), 1, scratch.data_ptr(), 0, _lib.stream_ptr()),
+                   "pit_mlp_bwd_params")
+    us = graph_time_us(call)
+    flops = 2.0 * rows * (n0 * n1 + n1 * n2)
+    achieved = flops / (us * 1e-6) / 1e12
+    return {"bound": "mfma", "kernel": f"gemm_rr_kernel<1,1,64>: dW1|db1 + dW2|db2 of kaiming_mlp {n0}->{n1}->{n2} on {rows} rows, batch {batch} "
+                                       "(one launch)",
+            "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": pmc_traffic(f"mlp_dw_b{batch}"),
+            "us_per_launch": round(us, 3), "flops_per_launch": flops, "algorithmic_bytes": 4.0 * rows * (n0 + 2 * n1 + n2),
+            "algorithmic_GBps": round(4.0 * rows * (n0 + 2 * n1 + n2) / (us * 1e-6) / 1e9, 1)}
+
+
 def roofline_probe(model, batch):
     """The fused position-attention of the processor (posatt_rows_kernel: 4 forward launches + 4 d(scale)
     launches of the same body, plus the transposed posatt_cols_kernel for d(values)): forward launch against
@@ -763,6 +794,7 @@ def main():
             extras["bf16_math_mode_samples_per_s"] = bf
         extras["roofline_saturated"] = roofline_probe(model, 256)
         extras["roofline_mlp_saturated"] = roofline_mlp_probe(model, 256)
+        extras["roofline_dw_saturated"] = roofline_dw_probe(model, 256)
     if rank == 0:
         blk = roofline_block_probe(model, args.batch, step.mesh_out.reshape(-1, model.space_dim).shape[0]) \
             if (args.math == "fp32" and model.mesh_ltt is not None) else None

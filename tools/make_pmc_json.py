@@ -14,6 +14,7 @@ want = {  # bench key -> (config, kernel-name prefix)
     "mlp_fwd_b8": ("darcy8", "mlp_fwd16_kernel<64, 8>"),
     "mlp_fwd_b256": ("darcy256", "gemm_lds_kernel<64, true, true, 2, false"),
     "posatt_rows_fwd_b256": ("darcy256", "posatt_rows_tiles<4, 1, 0, false, false>"),
+    "mlp_dw_b256": ("darcy256", "gemm_rr_kernel<1, 1, 64, false>"),
 }
 out = {"source": "tools/profile_round.sh: rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (own passes), bench.py "
                  "--steps 20 --warmup 3; KiB per launch; traffic_bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 "
