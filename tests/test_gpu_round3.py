@@ -540,3 +540,38 @@ def test_weight_gradient_pair_launch_matches_fp64(rows, n0, n1, n2, math, out_ge
             err = float((a.double() - ref).norm() / ref.norm())
             tol = 8e-3 if math == 1 else 2e-6
             assert err <= tol, (accumulate, ("dW1", "db1", "dW2", "db2")[k], err)
+
+
+# --------------------------------------------------------------------------- large-regime MLP data path (64-row tiles, fused gelu prologue)
+@pytest.mark.parametrize("rows,n0,n1,n2", [(16384, 192, 64, 64), (14560, 256, 128, 128), (5120, 768, 256, 256), (9000, 320, 96, 96)])
+def test_large_mlp_forward_and_backward_data_path_match_fp64(rows, n0, n1, n2):
+    """pit_mlp_fwd / pit_mlp_bwd_data in the LDS-tiled regime, trailing gelu on: the forward (Z1, H, Z2, Y) and the backward
+    data path - dZ2 = dY * gelu'(Z2) formed inside the dZ1 GEMM's staging for K <= 128 (gemm_lds_kernel<..., AGZ>) or by its
+    own pass, dZ1, dX - against fp64 on the same operands; 64-row tiles for K <= 256, 128-/32-row tiles otherwise."""
+    from position_induced_transformer_amd import _lib
+    L = _lib.lib()
+    g = torch.Generator(device="cuda").manual_seed(rows + n0)
+    x = torch.randn(rows, n0, device="cuda", generator=g)
+    w1, b1 = torch.randn(n1, n0, device="cuda", generator=g) * 0.05, torch.randn(n1, device="cuda", generator=g)
+    w2, b2 = torch.randn(n2, n1, device="cuda", generator=g) * 0.05, torch.randn(n2, device="cuda", generator=g)
+    z1, h = torch.empty(rows, n1, device="cuda"), torch.empty(rows, n1, device="cuda")
+    z2, y = torch.empty(rows, n2, device="cuda"), torch.empty(rows, n2, device="cuda")
+    dy, dx = torch.randn(rows, n2, device="cuda", generator=g), torch.empty(rows, n0, device="cuda")
+    scratch = torch.empty(rows * (n1 + n2), device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    _lib.check(L.pit_mlp_fwd(x.data_ptr(), n0, rows, n0, n1, n2, w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), 1,
+                             z1.data_ptr(), h.data_ptr(), z2.data_ptr(), y.data_ptr(), n2, 0, st), "pit_mlp_fwd")
+    _lib.check(L.pit_mlp_bwd_data(rows, n0, n1, n2, w1.data_ptr(), w2.data_ptr(), z1.data_ptr(), z2.data_ptr(), 1, dy.data_ptr(), n2,
+                                  dx.data_ptr(), n0, scratch.data_ptr(), 0, st), "pit_mlp_bwd_data")
+    torch.cuda.synchronize()
+    z1r = x.double() @ w1.double().t() + b1.double()
+    hr = torch.nn.functional.gelu(z1r)
+    z2r = hr @ w2.double().t() + b2.double()
+    gp = lambda z: 0.5 * (1 + torch.erf(z / 2 ** 0.5)) + z * torch.exp(-0.5 * z * z) / (2 * np.pi) ** 0.5
+    dz2 = dy.double() * gp(z2r)
+    dz1 = (dz2 @ w2.double()) * gp(z1r)
+    rel = lambda a, b: float((a.double() - b).norm() / b.norm())
+    assert rel(z1, z1r) <= 1e-6 and rel(h, hr) <= 1e-6 and rel(z2, z2r) <= 1e-6 and rel(y, torch.nn.functional.gelu(z2r)) <= 1e-6
+    assert rel(scratch[rows * n1:].view(rows, n2), dz2) <= 1e-6
+    assert rel(scratch[:rows * n1].view(rows, n1), dz1) <= 2e-6
+    assert rel(dx, dz1 @ w1.double()) <= 2e-6
