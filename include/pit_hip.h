@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define PIT_ABI_VERSION 13
+#define PIT_ABI_VERSION 14
 #define PIT_DSCALE_SLOTS 1024 /* fp64 accumulators per head in pit_posatt_bwd's workspace */
 
 /* distance metric (dist2att variants) */
@@ -245,6 +245,44 @@ int pit_block_bwd(const float* e, const float* inv, const float* qw, int n_pts, 
                   float* d_values, long ld_dvalues,
                   const struct pit_mlp_params_job* rider, const struct pit_mlp_params_job* rider2,
                   int math_mode, void* stream);
+
+/* ---- Persistent latent kernels (round 4; csrc/pit_latent.hip) -----------------------------------------------------
+ * The same processor as ONE launch per direction: a workgroup keeps its (sample, 16-point slab) through all blocks and
+ * the dependency between blocks (block i+1 contracts over every latent point of the same sample, pit.py:116-121) is a
+ * per-sample hand-off inside the launch (write-through stores, one flag word per slab, sc1 loads on the consuming side:
+ * correct for any workgroup placement).  Results are bit-identical to the pit_block_fwd / pit_block_bwd launches.
+ *
+ * pit_latent_supported: pit_block_supported AND all slab workgroups co-resident on the current device (forward: one workgroup
+ *   per slab, backward: two; they wait for each other), n_pts <= 1024, batch <= 64, n_layers <= 16.
+ * sync: PIT_LATENT_SYNC_WORDS 32-bit words, zeroed ONCE by the caller when allocated (the kernels leave them zero);
+ *   one workspace per stream.  sync[0] != 0 after a launch: a wait timed out (2 s) - the results are void.
+ * flags: PIT_LATENT_LINEAR_MAP spreads a sample's slabs over all XCDs (tests: the hand-off must not depend on placement).
+ *
+ * pit_latent_fwd: xcat[l] (batch*n_pts, (1+n_head)*dim) concat buffer of block l (HOST array of device pointers;
+ *   columns [0, dim) of xcat[0] hold the input, everything else is written here and kept for the backward);
+ *   w1 / b1 / w2 / b2: host arrays of the blocks' MLP parameters; e / inv: pit_block_weights' outputs for all layers;
+ *   z1 / h / z2: (n_layers, batch*n_pts, dim) saved activations; out (batch*n_pts, dim) rows ld_out apart.
+ *
+ * pit_latent_bwd: the whole backward chain in one launch.  d_out (batch*n_pts, dim) rows ld_dout apart is the gradient of
+ *   the last block's output; d_in receives the gradient of the processor's input.  Per block l (HOST arrays): xcat[l] the
+ *   forward's concat buffer, d_xcat[l] (batch*n_pts, (1+n_head)*dim) scratch for the gradient of that buffer, w1 / w2 the
+ *   block's MLP weights, scratch[l] (batch*n_pts*2*dim floats: dZ1 | dZ2, the layout of pit_mlp_bwd_data - read by the
+ *   weight-gradient reductions afterwards: pit_mlp_bwd_params / _batch with scratch[l] and d_y = scratch[l]),
+ *   dscale[l] the block's d(scale) accumulators (PIT_HEAD_DEFER convention, drain with pit_posatt_dhead_finish) or NULL.
+ *   z1 / z2 as saved by pit_latent_fwd; e / inv / qw from pit_block_weights.  The launch has 2 x the forward's workgroups
+ *   (chain + d(scale) helpers), all co-resident. */
+#define PIT_LATENT_SYNC_WORDS 4224
+#define PIT_LATENT_LINEAR_MAP 1
+int pit_latent_supported(int n_pts, int n_head, int dim, int batch, int n_layers);
+int pit_latent_fwd(const float* e, const float* inv, int n_pts, int n_head, int dim, int batch, int n_layers,
+                   float* const* xcat, const float* const* w1, const float* const* b1, const float* const* w2,
+                   const float* const* b2, float* z1, float* h, float* z2, float* out, long ld_out,
+                   unsigned* sync, int flags, int math_mode, void* stream);
+int pit_latent_bwd(const float* e, const float* inv, const float* qw, int n_pts, int n_head, int dim, int batch, int n_layers,
+                   const float* const* xcat, float* const* d_xcat, const float* const* w1, const float* const* w2,
+                   const float* z1, const float* z2, float* const* scratch, double* const* dscale,
+                   const float* d_out, long ld_dout, float* d_in, long ld_din,
+                   unsigned* sync, int flags, int math_mode, void* stream);
 
 /* kaiming_mlp.forward (pit.py:21-26): y = W2 * gelu_erf(W1 x + b1) + b2, optionally
  * followed by the trailing gelu of pit.py:111,121 (out_gelu=1).

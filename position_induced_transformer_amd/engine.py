@@ -102,13 +102,11 @@ class TrainStep:
     def _step(self) -> None:
         self._early_pending = False
         early = self.buckets == 2 and self.all_reduce
-        ops._PROCESSOR_HOOK[0] = (self._on_processor_block, self._early_block) if early else None
-        batch, ops.DW_BATCH = ops.DW_BATCH, (ops.DW_BATCH and not early)     # the early bucket needs its gradients before the end
-        try:
+        # per-thread state, read by the autograd nodes in their forward (ops._STEP): the early bucket needs its gradients
+        # before the end of the pass, so nothing of it may wait for the end-of-pass batch launch
+        with ops.step_state(processor_hook=(self._on_processor_block, self._early_block) if early else None,
+                            dw_batch=False if early else None):
             self._step_body()
-        finally:
-            ops._PROCESSOR_HOOK[0] = None
-            ops.DW_BATCH = batch
 
     def _step_body(self) -> None:
         out = self.model(self.mesh_in, self.func_in, self.mesh_out)

@@ -212,6 +212,38 @@ MLP_PARAMS_RIDER = os.environ.get("PIT_DW_RIDER", "1") != "0"
 # riders stay the default.  Never used by a two-bucket data-parallel step (engine.TrainStep), which needs the early
 # bucket's gradients before the pass ends.
 DW_BATCH = os.environ.get("PIT_DW_BATCH", "0") != "0"
+# Per-THREAD step state (round 4; was module-global and toggled per step: two TrainSteps on two threads raced on it).
+# engine.TrainStep sets it around its forward; the autograd nodes read it in their FORWARD (which runs on the calling
+# thread) and keep it on their ctx - the backward runs on autograd's device thread, where a thread-local of the caller
+# is not visible.  `dw_batch`: None = the module default DW_BATCH; `processor_hook`: see _Processor.
+_STEP = threading.local()
+
+
+def _dw_batch_mode() -> bool:
+    v = getattr(_STEP, "dw_batch", None)
+    return DW_BATCH if v is None else bool(v)
+
+
+def _processor_hook():
+    return getattr(_STEP, "processor_hook", None)
+
+
+class step_state:
+    """Context manager: per-thread overrides for the autograd nodes built inside it (engine.TrainStep._step)."""
+
+    def __init__(self, processor_hook=None, dw_batch=None):
+        self.new = (processor_hook, dw_batch)
+
+    def __enter__(self):
+        self.old = (getattr(_STEP, "processor_hook", None), getattr(_STEP, "dw_batch", None))
+        _STEP.processor_hook, _STEP.dw_batch = self.new
+        return self
+
+    def __exit__(self, *exc):
+        _STEP.processor_hook, _STEP.dw_batch = self.old
+        return False
+
+
 _PENDING_DW = {}          # graph-task id -> job = (MlpParamsJob, keep-alive tensors, stream it was prepared on) or None
 _PENDING_BATCH = {}       # graph-task id -> [job, ...]  (DW_BATCH)
 _DEFERRABLE = {}
@@ -270,8 +302,8 @@ def _dw_batch_add(st, keep, device) -> None:
     lst.append((st, keep, torch.cuda.current_stream(device)))
 
 
-def _dw_defer(st, keep, device) -> None:
-    if DW_BATCH:
+def _dw_defer(st, keep, device, batch: bool = False) -> None:
+    if batch:
         _dw_batch_add(st, keep, device)
         return
     task = _graph_task()
@@ -810,6 +842,7 @@ class _Mlp(torch.autograd.Function):
         _lib.check(rc, "pit_mlp_fwd")
         ctx.out_gelu, ctx.dims, ctx.in_shape = out_gelu, (rows, n0, n1, n2), shape
         ctx.params = (w1, b1, w2, b2)
+        ctx.dw_batch = _dw_batch_mode()
         ctx.save_for_backward(x2, w1c, w2c, z1, h, z2 if out_gelu else z1)
         out = y.reshape(*shape[:-1], n2)             # (a view: constant row stride)
         if buf is None:
@@ -863,7 +896,7 @@ class _Mlp(torch.autograd.Function):
             st = _lib.MlpParamsJob(x2.data_ptr(), x2.stride(0), rows, n0, n1, n2, h.data_ptr(), og, d_y2.data_ptr(),
                                    d_y2.stride(0), d_w1.data_ptr(), d_b1.data_ptr(), d_w2.data_ptr(), d_b2.data_ptr(),
                                    1, scratch.data_ptr(), ctx.math)
-            _dw_defer(st, (x2, h, d_y2, scratch, d_w1, d_b1, d_w2, d_b2), dev)
+            _dw_defer(st, (x2, h, d_y2, scratch, d_w1, d_b1, d_w2, d_b2), dev, ctx.dw_batch)
         else:
             # one call: dZ1, then dX and both weight-gradient reductions (merged into one launch when small)
             rc = L.pit_mlp_bwd(x2.data_ptr(), x2.stride(0), rows, n0, n1, n2, w1.data_ptr(), w2.data_ptr(),
@@ -897,6 +930,39 @@ BLOCK_FUSION = os.environ.get("PIT_BLOCK_FUSION", "1") != "0"
 
 def block_fusion_supported(n_pts: int, n_head: int, dim: int, batch: int) -> bool:
     return BLOCK_FUSION and bool(_lib.lib().pit_block_supported(int(n_pts), int(n_head), int(dim), int(batch)))
+
+
+# Round 4: the persistent latent kernels (csrc/pit_latent.hip) - the whole processor as ONE launch per direction when all
+# slab workgroups are co-resident (Darcy / Burgers / Sod at the scripts' batch 8: 128 workgroups); larger batches keep one
+# launch per block.  PIT_LATENT_FUSION=0 forces the per-block launches.
+LATENT_FUSION = os.environ.get("PIT_LATENT_FUSION", "1") != "0"
+LATENT_SYNC_WORDS = 4224           # PIT_LATENT_SYNC_WORDS
+LATENT_FLAGS = 0                   # tests: 1 = PIT_LATENT_LINEAR_MAP (a sample's slabs spread over all XCDs)
+_LATENT_SYNC = {}                  # (device index, stream) -> hand-off flags of the persistent kernels (zero between launches)
+
+
+def _latent_sync(device) -> torch.Tensor:
+    key = _ws_key(device)
+    ws = _LATENT_SYNC.get(key)
+    if ws is None:
+        ws = _LATENT_SYNC[key] = torch.zeros(LATENT_SYNC_WORDS, device=device, dtype=torch.int32)
+    if _capturing():
+        _pin(ws)
+    return ws
+
+
+def latent_status(device=None) -> int:
+    """0, or non-zero when a wait inside a persistent latent kernel timed out since the workspaces were created (the
+    results of that launch are void).  Synchronises; tests / bench.py call it after the step."""
+    bad = 0
+    for (dev, _stream), ws in _LATENT_SYNC.items():
+        if device is None or torch.device(device).index in (None, dev):
+            bad |= int(ws[0].item())
+    return bad
+
+
+def latent_fusion_supported(n_pts: int, n_head: int, dim: int, batch: int, n_layers: int) -> bool:
+    return LATENT_FUSION and bool(_lib.lib().pit_latent_supported(int(n_pts), int(n_head), int(dim), int(batch), int(n_layers)))
 
 
 class _Processor(torch.autograd.Function):
@@ -941,17 +1007,28 @@ class _Processor(torch.autograd.Function):
         z2 = torch.empty((n, rows, D), device=dev, dtype=torch.float32)
         wts = [tuple(t.detach().contiguous() for t in m) for m in mlps]
         for i in range(n):
-            y, ldy = (bufs[i + 1], W) if i + 1 < n else (out, D)
             w1, b1, w2, b2 = wts[i]
             if tuple(w1.shape) != (D, W) or tuple(w2.shape) != (D, D):
                 raise RuntimeError(f"fused processor: block {i} MLP is {tuple(w1.shape)} / {tuple(w2.shape)}, expected "
                                    f"({D}, {W}) / ({D}, {D})")
+        ctx.latent = latent_fusion_supported(L, H, D, b, n)
+        if ctx.latent:                         # ONE persistent launch for all blocks
+            arr = lambda ts: (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])
+            rc = L_.pit_latent_fwd(E.data_ptr(), inv.data_ptr(), L, H, D, b, n, arr(bufs), arr([w[0] for w in wts]),
+                                   arr([w[1] for w in wts]), arr([w[2] for w in wts]), arr([w[3] for w in wts]),
+                                   z1.data_ptr(), hh.data_ptr(), z2.data_ptr(), out.data_ptr(), D,
+                                   _latent_sync(dev).data_ptr(), LATENT_FLAGS, ctx.math, _lib.stream_ptr())
+            _lib.check(rc, "pit_latent_fwd")
+        for i in range(n if not ctx.latent else 0):
+            y, ldy = (bufs[i + 1], W) if i + 1 < n else (out, D)
+            w1, b1, w2, b2 = wts[i]
             rc = L_.pit_block_fwd(E[i].data_ptr(), inv[i].data_ptr(), L, H, D, b, bufs[i].data_ptr(), w1.data_ptr(),
                                   b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), 1, z1[i].data_ptr(), hh[i].data_ptr(),
                                   z2[i].data_ptr(), y.data_ptr(), ldy, ctx.math, _lib.stream_ptr())
             _lib.check(rc, "pit_block_fwd")
         ctx.n, ctx.H, ctx.dims, ctx.plan = n, H, (b, L, D), plan
         ctx.params = params                    # (lmda parameters, (w1, b1, w2, b2) parameters) for the in-place gradient slots
+        ctx.hook, ctx.dw_batch = _processor_hook(), _dw_batch_mode()      # the caller's per-thread step state
         ctx.keep = (bufs, wts, heads, E, Q, inv, scale, z1, hh, z2)
         return out
 
@@ -993,21 +1070,55 @@ class _Processor(torch.autograd.Function):
         # (rider mode; with DW_BATCH nothing rides: every job goes to the end-of-pass batch)
         extra = _dw_take(dev)
         slices = []
+        extra_batched = None
+        if extra is not None and ctx.latent:
+            extra_batched, extra = extra, None         # joins the blocks' reductions in the batch launch
         if extra is not None:
             st = extra[0]
             if not st.out_gelu and st.accumulate and (st.math_mode & 0xff) == 0:
                 # a two-bucket step reduces the postponed job's gradients right after block `complete_by`: every
                 # slice must ride in a launch up to that one
-                slices = _dw_slices(extra, n if _PROCESSOR_HOOK[0] is None else max(1, n - _PROCESSOR_HOOK[0][1]))
+                slices = _dw_slices(extra, n if ctx.hook is None else max(1, n - ctx.hook[1]))
             else:
                 _dw_run(extra)
+        if ctx.latent:
+            # ONE persistent launch: the whole chain + every block's d(scale); the weight-gradient reductions (sums over all
+            # rows) read the scratch afterwards - the blocks' and the job the pass postponed, in ONE launch at the end of the
+            # pass (or right here when a two-bucket step waits for these gradients)
+            arr = lambda ts: (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])
+            rc = L_.pit_latent_bwd(E.data_ptr(), inv.data_ptr(), Q.data_ptr(), L, H, D, b, n, arr(bufs), arr(dxc),
+                                   arr([w[0] for w in wts]), arr([w[2] for w in wts]), z1.data_ptr(), z2.data_ptr(),
+                                   arr(scratch), arr(work), d_out.data_ptr(), D, dx.data_ptr(), D,
+                                   _latent_sync(dev).data_ptr(), LATENT_FLAGS, ctx.math, _lib.stream_ptr())
+            _lib.check(rc, "pit_latent_bwd")
+            jobs = []
+            for i in range(n - 1, -1, -1):
+                dw1, db1, dw2, db2 = w_slots[i]
+                job = _lib.MlpParamsJob(bufs[i].data_ptr(), W, rows, W, D, D, hh[i].data_ptr(), 1, scratch[i].data_ptr(), D,
+                                        dw1.data_ptr(), db1.data_ptr(), dw2.data_ptr(), db2.data_ptr(), 1,
+                                        scratch[i].data_ptr(), ctx.math)
+                jobs.append((job, (bufs[i], hh, scratch[i], dw1, db1, dw2, db2)))
+            if extra_batched is not None:
+                jobs.append((extra_batched[0], extra_batched[1]))
+            if ctx.hook is None and all(g is None for g in w_grads):
+                for job, keep in jobs:                  # (in-place gradients only: nothing autograd waits for)
+                    _dw_batch_add(job, keep, dev)
+            else:                                       # gradients returned to autograd / the early bucket of a two-bucket step:
+                                                        # they must be enqueued before this node returns / the hook fires
+                arrj = (_lib.MlpParamsJob * len(jobs))(*[j[0] for j in jobs])
+                _lib.check(L_.pit_mlp_bwd_params_batch(len(jobs), ctypes.cast(arrj, ctypes.c_void_p), _lib.stream_ptr()),
+                           "pit_mlp_bwd_params_batch")
+                if ctx.hook is not None:
+                    for i in range(n - 1, -1, -1):
+                        ctx.hook[0](i)
         # top of the chain: the last block's MLP backward (data path) from d_out
         w1, _, w2, _ = wts[n - 1]
-        rc = L_.pit_mlp_bwd_data(rows, W, D, D, w1.data_ptr(), w2.data_ptr(), z1[n - 1].data_ptr(), z2[n - 1].data_ptr(), 1,
-                                 d_out.data_ptr(), D, dxc[n - 1].data_ptr(), W, scratch[n - 1].data_ptr(), ctx.math,
-                                 _lib.stream_ptr())
-        _lib.check(rc, "pit_mlp_bwd_data")
-        for i in range(n - 1, -1, -1):
+        if not ctx.latent:
+            rc = L_.pit_mlp_bwd_data(rows, W, D, D, w1.data_ptr(), w2.data_ptr(), z1[n - 1].data_ptr(), z2[n - 1].data_ptr(), 1,
+                                     d_out.data_ptr(), D, dxc[n - 1].data_ptr(), W, scratch[n - 1].data_ptr(), ctx.math,
+                                     _lib.stream_ptr())
+            _lib.check(rc, "pit_mlp_bwd_data")
+        for i in range(n - 1, -1, -1) if not ctx.latent else ():
             dw1, db1, dw2, db2 = w_slots[i]
             job = _lib.MlpParamsJob(bufs[i].data_ptr(), W, rows, W, D, D, hh[i].data_ptr(), 1, scratch[i].data_ptr(), D,
                                     dw1.data_ptr(), db1.data_ptr(), dw2.data_ptr(), db2.data_ptr(), 1,
@@ -1020,7 +1131,7 @@ class _Processor(torch.autograd.Function):
                 prev = (None, None, None, None, 0, 0, None, 0, None, dx.data_ptr(), D)
             k = n - 1 - i                              # launch order
             job2 = ctypes.cast(ctypes.pointer(slices[k]), ctypes.c_void_p) if k < len(slices) else None
-            batched = DW_BATCH and w_grads[i] is None
+            batched = ctx.dw_batch and w_grads[i] is None
             if batched:                                # the block's own reductions join the pass's batch
                 _dw_batch_add(job, (bufs[i], hh, scratch[i], dw1, db1, dw2, db2), dev)
             rc = L_.pit_block_bwd(E[i].data_ptr(), inv[i].data_ptr(), Q[i].data_ptr(), L, H, D, b, dxc[i].data_ptr(),
@@ -1028,8 +1139,8 @@ class _Processor(torch.autograd.Function):
                                   None if batched else ctypes.cast(ctypes.pointer(job), ctypes.c_void_p), job2, ctx.math,
                                   _lib.stream_ptr())
             _lib.check(rc, "pit_block_bwd")
-            if _PROCESSOR_HOOK[0] is not None:
-                _PROCESSOR_HOOK[0][0](i)                    # (block i's weight gradients are now enqueued)
+            if ctx.hook is not None:
+                ctx.hook[0](i)                              # (block i's weight gradients are now enqueued)
         # d(lmda): deferred layers are finished by the pass's one finishing launch; the others here, in one launch
         d_heads = [None] * n
         now = [i for i in range(n) if not defer[i]]
@@ -1056,10 +1167,10 @@ class _Processor(torch.autograd.Function):
         return tuple(grads)
 
 
-# engine.TrainStep(all_reduce_buckets=2): (callback, complete_by) - the callback is called with the block index after each
-# block's backward launch; everything the pass postponed before the processor (the decoder MLP's weight gradients) must be
-# enqueued by the launch of block `complete_by`, after which the step all-reduces those gradients on its second stream
-_PROCESSOR_HOOK = [None]
+# engine.TrainStep(all_reduce_buckets=2) sets step_state(processor_hook=(callback, complete_by)): the callback is called
+# with the block index after each block's backward launch; everything the pass postponed before the processor (the
+# decoder MLP's weight gradients) must be enqueued by the launch of block `complete_by`, after which the step all-reduces
+# those gradients on its second stream.  Per thread, carried by the autograd node (see _STEP).
 
 
 @torch.compiler.disable

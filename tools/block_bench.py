@@ -71,6 +71,86 @@ def bwd(dscale=True, rider=True):
                             dxp.data_ptr(), W, scr.data_ptr(), None, 0, jp if rider else None, None, 0, sp()) == 0
 
 
+# ---- round 4: the persistent launch (all n blocks) against n block launches
+bufs = [torch.randn(b, Lp, W, device="cuda") for _ in range(n)]
+wts = [tuple(t.detach().contiguous() for t in (mm.mlp1.weight, mm.mlp1.bias, mm.mlp2.weight, mm.mlp2.bias)) for mm in model.mlp]
+z1n = torch.empty(n, rows, D, device="cuda"); hn = torch.empty_like(z1n); z2n = torch.empty_like(z1n)
+outn = torch.empty(rows, D, device="cuda")
+sync = torch.zeros(ops.LATENT_SYNC_WORDS, device="cuda", dtype=torch.int32)
+arr = lambda ts: (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])
+A_ = [arr(bufs)] + [arr([w[k] for w in wts]) for k in range(4)]
+
+
+def latent_fwd(flags=0):
+    assert L_.pit_latent_fwd(E.data_ptr(), inv.data_ptr(), Lp, H, D, b, n, A_[0], A_[1], A_[2], A_[3], A_[4], z1n.data_ptr(),
+                             hn.data_ptr(), z2n.data_ptr(), outn.data_ptr(), D, sync.data_ptr(), flags, 0, sp()) == 0
+
+
+def blocks_fwd():
+    for i in range(n):
+        y, ldy = (bufs[i + 1], W) if i + 1 < n else (outn, D)
+        assert L_.pit_block_fwd(E[i].data_ptr(), inv[i].data_ptr(), Lp, H, D, b, bufs[i].data_ptr(), wts[i][0].data_ptr(),
+                                wts[i][1].data_ptr(), wts[i][2].data_ptr(), wts[i][3].data_ptr(), 1, z1n[i].data_ptr(),
+                                hn[i].data_ptr(), z2n[i].data_ptr(), y.data_ptr(), ldy, 0, sp()) == 0
+
+
+if L_.pit_latent_supported(Lp, H, D, b, n):
+    blocks_fwd(); torch.cuda.synchronize(); ref = outn.clone()
+    latent_fwd(); torch.cuda.synchronize()
+    print(f"latent fwd == block launches: {torch.equal(ref, outn)}; sync[0] = {int(sync[0])}")
+    print(f"batch {b}: {n} block_fwd launches {graph_time(blocks_fwd, reps=5):.2f} us | persistent latent fwd {graph_time(latent_fwd, reps=5):.2f} us "
+          f"| spread over XCDs {graph_time(lambda: latent_fwd(1), reps=5):.2f} us")
+
+# ---- the persistent backward (chain + d(scale) of all n blocks, top MLP backward included) against the launches it replaces
+dxcs = [torch.empty(b, Lp, W, device="cuda") for _ in range(n)]
+scrs = [torch.empty(rows * 2 * D, device="cuda") for _ in range(n)]
+wss = [torch.zeros(H * 1024, device="cuda", dtype=torch.float64) for _ in range(n)]
+d_out = torch.randn(rows, D, device="cuda"); d_in = torch.empty(rows, D, device="cuda")
+B_ = [arr(bufs), arr(dxcs), arr([w[0] for w in wts]), arr([w[2] for w in wts]), arr(scrs), arr(wss)]
+
+
+def latent_bwd(flags=0):
+    assert L_.pit_latent_bwd(E.data_ptr(), inv.data_ptr(), Q.data_ptr(), Lp, H, D, b, n, B_[0], B_[1], B_[2], B_[3], z1n.data_ptr(),
+                             z2n.data_ptr(), B_[4], B_[5], d_out.data_ptr(), D, d_in.data_ptr(), D, sync.data_ptr(), flags, 0, sp()) == 0
+
+
+def blocks_bwd(riders=False):
+    assert L_.pit_mlp_bwd_data(rows, W, D, D, wts[n - 1][0].data_ptr(), wts[n - 1][2].data_ptr(), z1n[n - 1].data_ptr(),
+                               z2n[n - 1].data_ptr(), 1, d_out.data_ptr(), D, dxcs[n - 1].data_ptr(), W, scrs[n - 1].data_ptr(), 0, sp()) == 0
+    for i in range(n - 1, -1, -1):
+        if i > 0:
+            prev = (wts[i - 1][0].data_ptr(), wts[i - 1][2].data_ptr(), z1n[i - 1].data_ptr(), z2n[i - 1].data_ptr(), 1, W,
+                    dxcs[i - 1].data_ptr(), W, scrs[i - 1].data_ptr(), None, 0)
+        else:
+            prev = (None, None, None, None, 0, 0, None, 0, None, d_in.data_ptr(), D)
+        assert L_.pit_block_bwd(E[i].data_ptr(), inv[i].data_ptr(), Q[i].data_ptr(), Lp, H, D, b, dxcs[i].data_ptr(), bufs[i].data_ptr(),
+                                wss[i].data_ptr(), *prev, None, None, 0, sp()) == 0
+
+
+if L_.pit_latent_supported(Lp, H, D, b, n):
+    latent_fwd(); torch.cuda.synchronize()
+    blocks_bwd(); torch.cuda.synchronize(); ref_in = d_in.clone(); ref_ws = [w.clone() for w in wss]; [w.zero_() for w in wss]
+    latent_bwd(); torch.cuda.synchronize()
+    print(f"latent bwd d_in == block launches: {torch.equal(ref_in, d_in)}; d(scale) sums rel diff "
+          f"{max(float(abs(a.sum() - r.sum()) / (abs(r.sum()) + 1e-300)) for a, r in zip(wss, ref_ws)):.2e}; sync[0] = {int(sync[0])}")
+    print(f"batch {b}: top MLP bwd + {n} block_bwd launches (no riders) {graph_time(blocks_bwd, reps=5):.2f} us | persistent latent bwd "
+          f"{graph_time(latent_bwd, reps=5):.2f} us | spread over XCDs {graph_time(lambda: latent_bwd(1), reps=5):.2f} us")
+
+if hasattr(L_, "pit_latent_read_stamps") and L_.pit_latent_supported(Lp, H, D, b, n):
+    latent_fwd(); torch.cuda.synchronize()
+    lb = (ctypes.c_ulonglong * 512)()
+    L_.pit_latent_read_stamps.argtypes = [ctypes.c_void_p]
+    assert L_.pit_latent_read_stamps(lb) == 0
+    t = list(lb)
+    pts = ["loop top", "wait done", "contraction issued", "parked", "barrier", "reduced", "barrier", "GEMM1+gelu stored", "barrier",
+           "GEMM2+gelu", "barrier", "hand-off stores issued", "posted"]
+    for wslot, wname in ((0, "wave 0"), (1, "wave 5")):
+        base = t[(wslot * 16 + 0) * 16 + 0]
+        print(f"  latent fwd, {wname} of workgroup 5 (cycles since its loop top of block 0):")
+        for i in range(n):
+            row = [t[(wslot * 16 + i) * 16 + k] - base for k in range(13 if i + 1 < n else 10)]
+            print(f"    block {i}: " + " ".join(f"{pts[k].split()[0]}={row[k]}" for k in range(len(row))))
+
 if os.environ.get("BLOCK_DBG"):
     L_.pit_block_set_dbg.argtypes = [ctypes.c_int]
     assert L_.pit_block_set_dbg(int(os.environ["BLOCK_DBG"])) == 0
