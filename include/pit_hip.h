@@ -256,7 +256,10 @@ int pit_block_bwd(const float* e, const float* inv, const float* qw, int n_pts, 
  *   per slab, backward: two; they wait for each other), n_pts <= 1024, batch <= 64, n_layers <= 16.
  * sync: PIT_LATENT_SYNC_WORDS 32-bit words, zeroed ONCE by the caller when allocated (the kernels leave them zero);
  *   one workspace per stream.  sync[0] != 0 after a launch: a wait timed out (2 s) - the results are void.
- * flags: PIT_LATENT_LINEAR_MAP spreads a sample's slabs over all XCDs (tests: the hand-off must not depend on placement).
+ * flags: PIT_LATENT_LINEAR_MAP spreads a sample's slabs over all XCDs (tests: the hand-off must not depend on placement);
+ *   PIT_LATENT_NO_FAST keeps every hand-off write-through.  By default a producer switches to plain stores + a plain flag
+ *   after its first wait IF every consumer of its sample has published that it runs on the producer's XCD (their sc1 loads
+ *   are then served by the L2 the plain stores land in: 1.9 instead of 3.1 us per hop, tools/micro/handoff_probe.hip).
  *
  * pit_latent_fwd: xcat[l] (batch*n_pts, (1+n_head)*dim) concat buffer of block l (HOST array of device pointers;
  *   columns [0, dim) of xcat[0] hold the input, everything else is written here and kept for the backward);
@@ -270,9 +273,14 @@ int pit_block_bwd(const float* e, const float* inv, const float* qw, int n_pts, 
  *   weight-gradient reductions afterwards: pit_mlp_bwd_params / _batch with scratch[l] and d_y = scratch[l]),
  *   dscale[l] the block's d(scale) accumulators (PIT_HEAD_DEFER convention, drain with pit_posatt_dhead_finish) or NULL.
  *   z1 / z2 as saved by pit_latent_fwd; e / inv / qw from pit_block_weights.  The launch has 2 x the forward's workgroups
- *   (chain + d(scale) helpers), all co-resident. */
-#define PIT_LATENT_SYNC_WORDS 4224
+ *   (chain + helpers), all co-resident.
+ *   h (n_layers, rows, dim) + d_w1 / d_b1 / d_w2 / d_b2 (HOST arrays, entries may be NULL): the helpers also ACCUMULATE the
+ *   weight gradients of block l's MLP into these (each sample's share as soon as its dZ exists: the reductions of
+ *   pit_mlp_bwd_params with accumulate = 1); NULL h or NULL d_w1[l]: the caller runs them afterwards.
+ *   rider: a postponed job as in pit_posatt_bwd (the decoder MLP's reductions) performed by the helpers first. */
+#define PIT_LATENT_SYNC_WORDS 12416
 #define PIT_LATENT_LINEAR_MAP 1
+#define PIT_LATENT_NO_FAST 2
 int pit_latent_supported(int n_pts, int n_head, int dim, int batch, int n_layers);
 int pit_latent_fwd(const float* e, const float* inv, int n_pts, int n_head, int dim, int batch, int n_layers,
                    float* const* xcat, const float* const* w1, const float* const* b1, const float* const* w2,
@@ -281,6 +289,8 @@ int pit_latent_fwd(const float* e, const float* inv, int n_pts, int n_head, int 
 int pit_latent_bwd(const float* e, const float* inv, const float* qw, int n_pts, int n_head, int dim, int batch, int n_layers,
                    const float* const* xcat, float* const* d_xcat, const float* const* w1, const float* const* w2,
                    const float* z1, const float* z2, float* const* scratch, double* const* dscale,
+                   const float* h, float* const* d_w1, float* const* d_b1, float* const* d_w2, float* const* d_b2,
+                   const struct pit_mlp_params_job* rider,
                    const float* d_out, long ld_dout, float* d_in, long ld_din,
                    unsigned* sync, int flags, int math_mode, void* stream);
 

@@ -52,7 +52,7 @@ SIGNATURES = {
     "pit_block_fwd": [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _L, _I, _P],
     "pit_latent_supported": [_I, _I, _I, _I, _I],
     "pit_latent_fwd": [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _I, _I, _P],
-    "pit_latent_bwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _L, _P, _I, _I, _P],
+    "pit_latent_bwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _L, _P, _I, _I, _P],
     "pit_block_bwd": [_P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _L, _P, _P, _L, _P, _P, _I, _P],
     "pit_mlp_bf16_io_supported": [_I, _I, _I, _I, _I],
     "pit_mlp_fwd": [_P, _L, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _L, _I, _P],

@@ -155,6 +155,12 @@ __device__ __forceinline__ void buf_load4(__amdgpu_buffer_rsrc_t r, unsigned byt
     const i32x4 q = __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0);
     v[0] = __int_as_float(q.x); v[1] = __int_as_float(q.y); v[2] = __int_as_float(q.z); v[3] = __int_as_float(q.w);
 }
+// the same with the sc1 cache policy (served by L2 / memory, never by this CU's L1): loads of bytes ANOTHER workgroup of the
+// same launch has stored (csrc/pit_latent.hip)
+__device__ __forceinline__ void buf_load4_sc1(__amdgpu_buffer_rsrc_t r, unsigned byte_off, float (&v)[4]) {
+    const i32x4 q = __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 16);
+    v[0] = __int_as_float(q.x); v[1] = __int_as_float(q.y); v[2] = __int_as_float(q.z); v[3] = __int_as_float(q.w);
+}
 // largest tensor a 32-bit buffer offset can address (with slack for offset arithmetic)
 #define PIT_MAX_BUFFER_BYTES 0xF0000000ull
 

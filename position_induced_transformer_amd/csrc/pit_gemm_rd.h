@@ -250,7 +250,8 @@ __device__ __forceinline__ unsigned pack2_bf16(float lo, float hi) {
     const f32x2_t v = {lo, hi};
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
 }
-template <int RM, int RN, int BK, bool BF>
+// SC1A: the A operand was stored by other workgroups of THIS launch (the persistent latent backward): sc1 loads
+template <int RM, int RN, int BK, bool BF, bool SC1A = false>
 __device__ __forceinline__ void gemm_rr_tile(const GemmArgs& g, int bx, int by, int kbeg, int kend, float* As_, float* Bs_) {
     constexpr int BM = 64 * RM, BN = 64 * RN;
     constexpr int PA = BK * BM / 1024, PB = BK * BN / 1024;         // 16-B loads per thread and chunk
@@ -270,7 +271,8 @@ __device__ __forceinline__ void gemm_rr_tile(const GemmArgs& g, int bx, int by, 
         for (int p = 0; p < PA; ++p) {
             const int q = p * 256 + tid, k = kc + q / (BM / 4), m = m0 + (q % (BM / 4)) * 4;
             const bool ok = k < kend && m < g.M;
-            buf_load4(ra, ok ? ((unsigned)k * (unsigned)g.a_cs + (unsigned)m) * 4u : g.a_bytes, sa[p]);
+            if constexpr (SC1A) buf_load4_sc1(ra, ok ? ((unsigned)k * (unsigned)g.a_cs + (unsigned)m) * 4u : g.a_bytes, sa[p]);
+            else buf_load4(ra, ok ? ((unsigned)k * (unsigned)g.a_cs + (unsigned)m) * 4u : g.a_bytes, sa[p]);
         }
 #pragma unroll
         for (int p = 0; p < PB; ++p) {

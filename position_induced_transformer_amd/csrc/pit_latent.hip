@@ -38,17 +38,58 @@ __device__ unsigned long long pit_latent_stamps[2 * 16 * 16];
 #endif
 
 constexpr int AUX_SC1 = 16;                            // cache-policy bit of the raw-buffer intrinsics on gfx950: sc1
-constexpr int SYNC_ERR = 0, SYNC_DONE = 16, SYNC_FLAGS = 128, SYNC_FLAG_STRIDE = 64, SYNC_MAX_SAMPLES = 64;
+constexpr int SYNC_ERR = 0, SYNC_FAST = 1, SYNC_DONE = 16, SYNC_FLAGS = 128, SYNC_FLAG_STRIDE = 64, SYNC_MAX_SAMPLES = 64;
+constexpr int SYNC_XCC = SYNC_FLAGS + SYNC_MAX_SAMPLES * SYNC_FLAG_STRIDE;        // per sample: 2 x 64 words (slab workgroups, helpers)
+constexpr int SYNC_XCC_STRIDE = 128;
 constexpr unsigned long long WAIT_LIMIT_TICKS = 200000000ull;      // 2 s of the 100 MHz clock per wait
 
 __device__ __forceinline__ float4 ld4_sc1(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
     const i32x4 q = __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, AUX_SC1);
     return make_float4(__int_as_float(q.x), __int_as_float(q.y), __int_as_float(q.z), __int_as_float(q.w));
 }
-__device__ __forceinline__ void st4_sc1(__amdgpu_buffer_rsrc_t r, unsigned byte_off, float4 v) {
+// hand-off payload store: write-through (`sc1`: visible to every XCD), or - `fast`: all consumers of the sample are known to
+// run on the producer's XCD - a plain store, which stays in that XCD's L2 where their sc1 loads are served from
+__device__ __forceinline__ void st4_handoff(__amdgpu_buffer_rsrc_t r, unsigned byte_off, float4 v, bool fast) {
     i32x4 q;
     q.x = __float_as_int(v.x); q.y = __float_as_int(v.y); q.z = __float_as_int(v.z); q.w = __float_as_int(v.w);
-    __builtin_amdgcn_raw_buffer_store_b128(q, r, (int)byte_off, 0, AUX_SC1);
+    if (fast) __builtin_amdgcn_raw_buffer_store_b128(q, r, (int)byte_off, 0, 0);
+    else __builtin_amdgcn_raw_buffer_store_b128(q, r, (int)byte_off, 0, AUX_SC1);
+}
+__device__ __forceinline__ void st2_handoff(float* p, float2 v, bool fast) {
+    typedef int i32x2 __attribute__((ext_vector_type(2)));
+    const __amdgpu_buffer_rsrc_t r = make_rsrc(p, 8u);
+    i32x2 q; q.x = __float_as_int(v.x); q.y = __float_as_int(v.y);
+    if (fast) __builtin_amdgcn_raw_buffer_store_b64(q, r, 0, 0, 0);
+    else __builtin_amdgcn_raw_buffer_store_b64(q, r, 0, 0, AUX_SC1);
+}
+__device__ __forceinline__ void st1_handoff(float* p, float v, bool fast) {
+    if (fast) *p = v;
+    else __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);            // global_store_dword sc1
+}
+__device__ __forceinline__ unsigned my_xcc() { return (__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) & 0xfu) + 1u; }
+// every workgroup that CONSUMES a sample's hand-offs publishes the XCD it runs on (slot = slab, or slabs + slab for a helper)
+__device__ __forceinline__ void publish_xcc(unsigned* xcc_line, int slot) {
+    if (threadIdx.x == 0) __hip_atomic_store(xcc_line + slot, my_xcc(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// producer, once, after its first wait: are ALL `count` consumers of the sample on this XCD?  (a missing word = not yet
+// published = no: the producer then keeps the placement-independent form for the whole launch; the lines are cleared at
+// the end of every launch)  Called by all threads; the answer goes through LDS.
+__device__ __forceinline__ bool all_on_my_xcd(const unsigned* xcc_line, int count, int* s_flag) {
+    if (threadIdx.x < 64) {
+        const __amdgpu_buffer_rsrc_t xr = make_rsrc(xcc_line, (unsigned)count * 4u);
+        const unsigned mine = my_xcc();
+        bool ok = true;
+        for (int c0 = 0; c0 < count; c0 += 64) {
+            const int c = c0 + (int)threadIdx.x;
+            const unsigned v = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(xr, (c < count ? c : 0) * 4, 0, AUX_SC1);
+            ok = ok && v == mine;
+        }
+        const bool all = __builtin_amdgcn_ballot_w64(!ok) == 0;
+        if (threadIdx.x == 0) *s_flag = all ? 1 : 0;
+    }
+    (void)0;
+    __syncthreads();
+    return *s_flag != 0;
 }
 
 // consumer side: wave 0 polls the sample's flag line until every slab has posted `target`, then the workgroup barrier
@@ -70,18 +111,22 @@ __device__ __forceinline__ void wait_sample(unsigned* flags, int slabs, unsigned
     __syncthreads();
 }
 // producer side, after the payload stores: drain, barrier, one lane posts
-__device__ __forceinline__ void post_slab(unsigned* flags, int slab, unsigned value) {
+__device__ __forceinline__ void post_slab(unsigned* flags, int slab, unsigned value, bool fast) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_store(flags + slab, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // global_store_dword sc1
+    if (threadIdx.x == 0) {
+        if (fast) *reinterpret_cast<volatile unsigned*>(flags + slab) = value;                                  // plain: this XCD's L2
+        else __hip_atomic_store(flags + slab, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);                // global_store_dword sc1
+    }
 }
 // after a workgroup's LAST wait of the launch: the sample's last arriver clears its flag line for the next launch
 // (`waiters` workgroups wait on the sample's line: its slab workgroups, and in the backward its helper workgroups too)
-__device__ __forceinline__ void retire_sample(unsigned* flags, unsigned* done, int slabs, int waiters) {
+__device__ __forceinline__ void retire_sample(unsigned* flags, unsigned* xcc_line, unsigned* done, int slabs, int waiters) {
     if (threadIdx.x == 0) {
         const unsigned old = __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (old == (unsigned)waiters - 1u) {
             for (int s = 0; s < slabs; ++s) __hip_atomic_store(flags + s, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int s = 0; s < waiters; ++s) __hip_atomic_store(xcc_line + s, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
@@ -95,7 +140,7 @@ struct LatentLayer {
     float *z1, *h, *z2;                 // saved for the backward: (batch*L, 64) each
 };
 struct LatentFwdArgs {
-    int L, batch, n_layers, linear_map;
+    int L, batch, n_layers, linear_map, no_fast;
     LatentLayer layer[MAX_LAYERS];
     float* out; long ld_out;            // the last block's output (batch*L, 64), rows ld_out apart
     unsigned* sync;
@@ -121,6 +166,10 @@ __global__ __launch_bounds__(512) void latent_fwd_kernel(LatentFwdArgs g) {
     unsigned* err = g.sync + SYNC_ERR;
     unsigned* done = g.sync + SYNC_DONE + b;
     unsigned* flags = g.sync + SYNC_FLAGS + b * SYNC_FLAG_STRIDE;
+    unsigned* xcc_line = g.sync + SYNC_XCC + b * SYNC_XCC_STRIDE;
+    __shared__ int s_same;
+    bool fast = false;                                  // decided after the first wait (the first hand-off is always write-through)
+    publish_xcc(xcc_line, slab);
     const bool mlp_wave = wave < 4;                     // waves 0..3 own the four hidden / output tiles of the MLP
     const int c1 = (wave & 3) * 16 + l15;
     const int n = g.n_layers;
@@ -153,7 +202,11 @@ __global__ __launch_bounds__(512) void latent_fwd_kernel(LatentFwdArgs g) {
         // ---- (2) the sample's rows of the previous block
         if (handed) {
             wait_sample(flags, slabs, (unsigned)i, err);
-            if (i == n - 1) retire_sample(flags, done, slabs, slabs);
+            if (i == 1 && !g.no_fast) {
+                fast = all_on_my_xcd(xcc_line, slabs, &s_same);
+                if (fast && tid == 0) atomicAdd(g.sync + SYNC_FAST, 1u);        // telemetry: producers that switched (cumulative)
+            }
+            if (i == n - 1) retire_sample(flags, xcc_line, done, slabs, slabs);
         }
         LSTAMP(i, 1);
         // ---- (3) O_h = E_h X for all heads against the same value rows (fetched once)
@@ -265,10 +318,10 @@ __global__ __launch_bounds__(512) void latent_fwd_kernel(LatentFwdArgs g) {
                 float* nx = g.layer[i + 1].xcat;
                 const __amdgpu_buffer_rsrc_t rn = make_rsrc(nx + m0 * W, 16u * W * 4u);
                 const float4 v = *reinterpret_cast<const float4*>(xs + (tid >> 4) * XP + 4 * (tid & 15));
-                st4_sc1(rn, (unsigned)(((tid >> 4) * W + 4 * (tid & 15)) * 4), v);
+                st4_handoff(rn, (unsigned)(((tid >> 4) * W + 4 * (tid & 15)) * 4), v, fast);
             }
             LSTAMP(i, 11);
-            post_slab(flags, slab, (unsigned)(i + 1));
+            post_slab(flags, slab, (unsigned)(i + 1), fast);
             LSTAMP(i, 12);
         }
     }
@@ -294,15 +347,73 @@ struct LatentBwdLayer {
     const float *w1, *w2, *z1, *z2;     // the block's MLP: weights and saved pre-activations
     float* scratch;                     // (rows*64) dZ1 | (rows*64) dZ2 of the block's MLP (pit_mlp_bwd_data's layout)
     double* dscale;                     // the block's d(scale) accumulators (n_head * PIT_DSCALE_SLOTS) or null
+    const float* h;                     // the MLP's saved hidden activations (rows, 64)
+    float *d_w1, *d_b1, *d_w2, *d_b2;   // its weight gradients, ACCUMULATED here by the helpers (d_w1 null: not in this launch)
 };
 struct LatentBwdArgs {
-    int L, batch, n_layers, linear_map;
+    int L, batch, n_layers, linear_map, no_fast;
     LatentBwdLayer layer[MAX_LAYERS];
     const float* d_out; long ld_dout;
     float* d_in; long ld_din;
     unsigned* sync;
     int n_chain;
+    int dec_items;                      // > 0: a postponed job (the decoder MLP's weight gradients) the helpers perform first
+    pit_detail::DwPair dec;
 };
+
+// One work item of a carried pair of weight-gradient reductions inside a PERSISTENT workgroup (dw_pair_body is written for
+// launches whose upper waves END before a tile: here every wave stays, so waves 4..7 match the tile's barriers one for one)
+__device__ __forceinline__ void persistent_rider_item(const pit_detail::DwPair& w, int id, float* smem) {
+    const bool second = id >= w.n1;
+    const pit_detail::GemmArgs& ga = second ? w.g2 : w.g1;
+    const int lid = second ? id - w.n1 : id;
+    if (second ? w.rr2 : w.rr1) {
+        const int tx = second ? w.tx2 : w.tx1, tiles = second ? w.tiles2 : w.tiles1, slabs = second ? w.slabs2 : w.slabs1;
+        const int slab = lid / tiles, tile = lid % tiles;
+        const int kbeg = (int)((long)slab * w.nchunks / slabs) * pit_detail::RR_BK;
+        const int kend = min(ga.K, (int)((long)(slab + 1) * w.nchunks / slabs) * pit_detail::RR_BK);
+        if (threadIdx.x < 256) {
+            gemm_rr_tile<1, 1, pit_detail::RR_BK, false>(ga, tile % tx, tile / tx, kbeg, kend, smem, smem + 2 * pit_detail::RR_BK * 64);
+        } else {
+            const int nb = 1 + (kend > kbeg ? (kend - kbeg + pit_detail::RR_BK - 1) / pit_detail::RR_BK : 0);
+            for (int q = 0; q < nb; ++q) __syncthreads();
+        }
+    } else {
+        const int gx = second ? w.gx2 : w.gx1, gy = second ? w.gy2 : w.gy1;
+        gemm_rd_body<1, EPI_ATOMIC>(ga, lid % gx, (lid / gx) % gy, lid / (gx * gy));
+    }
+    __syncthreads();                                    // the next item reuses the LDS
+}
+
+// the weight-gradient reductions of block-MLP `ly` restricted to the rows of ONE sample, as 2 (tx + 1) tile items of half the
+// sample's rows each: dW1 += dZ1^T X (tx = W / 64 tiles, the bias gradient as row sums of tile 0), dW2 += dZ2^T H (one tile).
+// dZ1 / dZ2 were stored by the sample's chain workgroups in this launch: sc1 loads (SC1A).
+template <int W>
+__device__ __forceinline__ void sample_rider_item(const LatentBwdLayer& ly, long rows, int L, int b, int item, float* smem) {
+    constexpr int TX = W / 64;
+    const int tile = item % (TX + 1), khalf = item / (TX + 1);
+    pit_detail::GemmArgs ga = pit_detail::GemmArgs();
+    ga.a_rs = 1; ga.a_cs = BD; ga.b_cs = 1; ga.M = BD; ga.K = (int)rows; ga.atomic = 1; ga.epi = EPI_ATOMIC;
+    ga.a_bytes = (unsigned)(rows * BD * 4);
+    int bx;
+    if (tile < TX) {                                    // dW1
+        ga.A = ly.scratch; ga.B = ly.xcat; ga.b_rs = W; ga.N = W + 1; ga.ones_col = W;
+        ga.b_bytes = (unsigned)(rows * W * 4); ga.C = ly.d_w1; ga.ldc = W; ga.C2 = ly.d_b1;
+        bx = tile;
+    } else {                                            // dW2
+        ga.A = ly.scratch + rows * BD; ga.B = ly.h; ga.b_rs = BD; ga.N = BD + 1; ga.ones_col = BD;
+        ga.b_bytes = (unsigned)(rows * BD * 4); ga.C = ly.d_w2; ga.ldc = BD; ga.C2 = ly.d_b2;
+        bx = 0;
+    }
+    const int kbeg = b * L + khalf * (L / 2), kend = kbeg + L / 2;
+    if (threadIdx.x < 256) {
+        gemm_rr_tile<1, 1, pit_detail::RR_BK, false, true>(ga, bx, 0, kbeg, kend, smem, smem + 2 * pit_detail::RR_BK * 64);
+    } else {
+        const int nb = 1 + (L / 2 + pit_detail::RR_BK - 1) / pit_detail::RR_BK;
+        for (int q = 0; q < nb; ++q) __syncthreads();
+    }
+    __syncthreads();
+}
 
 // operands of one MLP's backward data path on a slab, requested ahead of their use
 struct MlpBackOperands { float w2v[4][4], z1v[4], w1v[2][4][4]; float2 z2v; };
@@ -336,14 +447,11 @@ __device__ __forceinline__ void mlp_back_prefetch(const LatentBwdLayer& ly, long
 // (the phases of mlp_bwd16_kernel / block_bwd_chain; ends with a barrier: dxt is complete for every thread)
 template <int W>
 __device__ __forceinline__ void mlp_back(const LatentBwdLayer& ly, long rows, long m0, float2 s, const MlpBackOperands& op,
-                                         float* ds2, float* ds1, float* dxt, int wave, int l15, int kq, int orow, int ocol) {
+                                         float* ds2, float* ds1, float* dxt, int wave, int l15, int kq, int orow, int ocol, bool fast) {
     constexpr int P1 = BD + 4, WP = W + 4;
     const int c1 = (wave & 3) * 16 + l15;
-    float* dz1 = ly.scratch;
-    float* dz2 = ly.scratch + rows * BD;
     s.x *= gelu_erf_grad(op.z2v.x); s.y *= gelu_erf_grad(op.z2v.y);
-    *reinterpret_cast<float2*>(dz2 + (m0 + orow) * BD + ocol) = s;
-    *reinterpret_cast<float2*>(ds2 + orow * P1 + ocol) = s;
+    *reinterpret_cast<float2*>(ds2 + orow * P1 + ocol) = s;          // (dZ2 / dZ1 go to memory with the hand-off: hand_off_tile)
     __syncthreads();
     if (wave < 4) {                                     // dZ1 tile of this wave
         f32x4_t a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
@@ -360,7 +468,6 @@ __device__ __forceinline__ void mlp_back(const LatentBwdLayer& ly, long rows, lo
             const int r = 4 * kq + i;
             const float v = (a0[i] + a1[i]) * gelu_erf_grad(op.z1v[i]);
             ds1[r * P1 + c1] = v;
-            dz1[(m0 + r) * BD + c1] = v;
         }
     }
     __syncthreads();
@@ -384,16 +491,24 @@ __device__ __forceinline__ void mlp_back(const LatentBwdLayer& ly, long rows, lo
     __syncthreads();
 }
 
-// the slab's dX tile (LDS) -> its 16 rows of d_xcat (contiguous: 16 * W floats), 16 B per lane, write-through; then post
+// the slab's dX tile (LDS) -> its 16 rows of d_xcat (contiguous: 16 * W floats), and the MLP's dZ1 / dZ2 tiles -> scratch (the
+// helpers' weight-gradient tiles read them in this launch): 16 B per lane, whole lines per wave instruction; then post
 template <int W>
-__device__ __forceinline__ void hand_off_tile(const float* dxt, float* dxc_rows, unsigned* flags, int slab, unsigned value) {
-    constexpr int WP = W + 4, Q = 16 * W / 4;
+__device__ __forceinline__ void hand_off_tile(const float* dxt, float* dxc_rows, const float* ds1, float* dz1_rows, const float* ds2,
+                                              float* dz2_rows, unsigned* flags, int slab, unsigned value, bool fast) {
+    constexpr int WP = W + 4, P1 = BD + 4, Q = 16 * W / 4;
     const __amdgpu_buffer_rsrc_t rd = make_rsrc(dxc_rows, 16u * W * 4u);
     for (int q = threadIdx.x; q < Q; q += 512) {
         const int r = q / (W / 4), c4 = q % (W / 4);
-        st4_sc1(rd, (unsigned)q * 16u, *reinterpret_cast<const float4*>(dxt + r * WP + 4 * c4));
+        st4_handoff(rd, (unsigned)q * 16u, *reinterpret_cast<const float4*>(dxt + r * WP + 4 * c4), fast);
     }
-    post_slab(flags, slab, value);
+    {   // 2 x 256 16-B pieces: threads [0, 256) dZ1, [256, 512) dZ2
+        const int t = threadIdx.x & 255, r = t >> 4, c4 = t & 15;
+        const bool second = threadIdx.x >= 256;
+        const __amdgpu_buffer_rsrc_t rz = make_rsrc(second ? dz2_rows : dz1_rows, 16u * BD * 4u);
+        st4_handoff(rz, (unsigned)t * 16u, *reinterpret_cast<const float4*>((second ? ds2 : ds1) + r * P1 + 4 * c4), fast);
+    }
+    post_slab(flags, slab, value, fast);
 }
 
 template <int H>
@@ -414,6 +529,10 @@ __device__ __forceinline__ void latent_bwd_chain(const LatentBwdArgs& g, float* 
     unsigned* err = g.sync + SYNC_ERR;
     unsigned* done = g.sync + SYNC_DONE + b;
     unsigned* flags = g.sync + SYNC_FLAGS + b * SYNC_FLAG_STRIDE;
+    unsigned* xcc_line = g.sync + SYNC_XCC + b * SYNC_XCC_STRIDE;
+    __shared__ int s_same;
+    bool fast = false;
+    publish_xcc(xcc_line, slab);
     // every thread owns two adjacent elements of the slab's 16 x 64 d(values) / dY tile
     const int oi = (tid >> 6) & 3, oln = tid & 63, oh = tid >> 8;
     const int orow = 4 * (oln >> 4) + oi, ocol = 4 * (oln & 15) + 2 * oh;
@@ -423,8 +542,8 @@ __device__ __forceinline__ void latent_bwd_chain(const LatentBwdArgs& g, float* 
         const LatentBwdLayer& top = g.layer[n - 1];
         mlp_back_prefetch<W>(top, m0, wave, l15, kq, orow, ocol, op);
         const float2 dy = *reinterpret_cast<const float2*>(g.d_out + (m0 + orow) * g.ld_dout + ocol);
-        mlp_back<W>(top, rows, m0, dy, op, ds2, ds1, dxt, wave, l15, kq, orow, ocol);
-        hand_off_tile<W>(dxt, top.dxc + m0 * W, flags, slab, 1u);
+        mlp_back<W>(top, rows, m0, dy, op, ds2, ds1, dxt, wave, l15, kq, orow, ocol, false);
+        hand_off_tile<W>(dxt, top.dxc + m0 * W, ds1, top.scratch + m0 * BD, ds2, top.scratch + (rows + m0) * BD, flags, slab, 1u, false);
     }
     for (int i = n - 1; i >= 0; --i) {
         const LatentBwdLayer& ly = g.layer[i];
@@ -440,7 +559,11 @@ __device__ __forceinline__ void latent_bwd_chain(const LatentBwdArgs& g, float* 
         if (i > 0) mlp_back_prefetch<W>(g.layer[i - 1], m0, wave, l15, kq, orow, ocol, op);
         const float2 res = *reinterpret_cast<const float2*>(dxt + orow * WP + ocol);
         wait_sample(flags, slabs, (unsigned)(n - i), err);
-        if (i == 0) retire_sample(flags, done, slabs, 2 * slabs);
+        if (i == n - 1 && !g.no_fast) {
+            fast = all_on_my_xcd(xcc_line, 2 * slabs, &s_same);                                // (slab workgroups and helpers)
+            if (fast && tid == 0) atomicAdd(g.sync + SYNC_FAST, 1u);
+        }
+        if (i == 0) retire_sample(flags, xcc_line, done, slabs, 2 * slabs);
         // ---- d(values)[j] = sum_h sum_n E_h[j][n] (inv_h[n] dO_h[n]): E symmetric, row j of E is column j
         f32x4_t acc[4];
 #pragma unroll
@@ -486,8 +609,9 @@ __device__ __forceinline__ void latent_bwd_chain(const LatentBwdArgs& g, float* 
             return;
         }
         const LatentBwdLayer& prev = g.layer[i - 1];
-        mlp_back<W>(prev, rows, m0, s, op, ds2, ds1, dxt, wave, l15, kq, orow, ocol);
-        hand_off_tile<W>(dxt, prev.dxc + m0 * W, flags, slab, (unsigned)(n - i + 1));
+        mlp_back<W>(prev, rows, m0, s, op, ds2, ds1, dxt, wave, l15, kq, orow, ocol, fast);
+        hand_off_tile<W>(dxt, prev.dxc + m0 * W, ds1, prev.scratch + m0 * BD, ds2, prev.scratch + (rows + m0) * BD, flags, slab,
+                         (unsigned)(n - i + 1), fast);
     }
 }
 
@@ -505,9 +629,14 @@ __device__ __forceinline__ void latent_bwd_helper(const LatentBwdArgs& g, float*
     unsigned* err = g.sync + SYNC_ERR;
     unsigned* done = g.sync + SYNC_DONE + b;
     unsigned* flags = g.sync + SYNC_FLAGS + b * SYNC_FLAG_STRIDE;
+    unsigned* xcc_line = g.sync + SYNC_XCC + b * SYNC_XCC_STRIDE;
+    publish_xcc(xcc_line, slabs + slab);
     const bool own = tid < H * 256;
     const int hh = tid >> 8, ii = (tid >> 6) & 3, ln = tid & 63;
     const int r = 4 * (ln >> 4) + ii, col = 4 * (ln & 15);
+    const long rows = (long)g.batch * g.L;
+    // the postponed job (no dependency on this launch): dealt over the helpers while the chain runs its first phase
+    for (int id = b * slabs + slab; id < g.dec_items; id += g.batch * slabs) persistent_rider_item(g.dec, id, smem);
     for (int i = n - 1; i >= 0; --i) {
         const LatentBwdLayer& ly = g.layer[i];
         const bool active = ly.dscale != nullptr;
@@ -549,7 +678,7 @@ __device__ __forceinline__ void latent_bwd_helper(const LatentBwdArgs& g, float*
             for (int h2 = 0; h2 < H; ++h2) park(pk, wave * H + h2, lane, acc[h2]);
         }
         wait_sample(flags, slabs, (unsigned)(n - i), err);           // (ends with the workgroup barrier: the parks are complete)
-        if (i == 0) retire_sample(flags, done, slabs, 2 * slabs);
+        if (i == 0) retire_sample(flags, xcc_line, done, slabs, 2 * slabs);
         if (active) {
             double part = 0.0;
             if (own) {
@@ -568,6 +697,8 @@ __device__ __forceinline__ void latent_bwd_helper(const LatentBwdArgs& g, float*
             }
             __syncthreads();                            // the next block's parks reuse pk / wred
         }
+        // this block's MLP: its dZ of THIS sample is complete (same hand-off as d_xcat[i]) - the sample's share of dW
+        if (ly.d_w1 != nullptr && slab < 2 * (W / 64 + 1)) sample_rider_item<W>(ly, rows, g.L, b, slab, smem);
     }
 }
 
@@ -585,8 +716,9 @@ __global__ __launch_bounds__(512) void latent_bwd_kernel(LatentBwdArgs g) {
 }
 
 constexpr size_t latent_bwd_smem(int H) {
-    return std::max(((size_t)PARK_FLOATS + 2 * 16 * (BD + 4) + 16 * ((1 + H) * BD + 4)) * sizeof(float),
-                    (size_t)H * PARK_FLOATS * sizeof(float) + BW * sizeof(double));
+    return std::max(std::max(((size_t)PARK_FLOATS + 2 * 16 * (BD + 4) + 16 * ((1 + H) * BD + 4)) * sizeof(float),
+                             (size_t)H * PARK_FLOATS * sizeof(float) + BW * sizeof(double)),
+                    (size_t)4 * pit_detail::RR_BK * 64 * sizeof(float));          // (the riders' tiles: 64 KiB)
 }
 
 constexpr size_t latent_fwd_smem(int H) { return ((size_t)H * PARK_FLOATS + 16 * ((1 + H) * BD + 4) + 16 * (BD + 4)) * sizeof(float); }
@@ -607,13 +739,13 @@ static void latent_capacity(int n_head, long& fwd_slots, long& bwd_slots) {
     if (cus <= 0) return;
     int of = 0, ob = 0;
     if (n_head == 1) {
-        (void)hipFuncSetAttribute((const void*)latent_fwd_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 98304);
-        (void)hipFuncSetAttribute((const void*)latent_bwd_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 98304);
+        (void)hipFuncSetAttribute((const void*)latent_fwd_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+        (void)hipFuncSetAttribute((const void*)latent_bwd_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&of, latent_fwd_kernel<1>, 64 * BW, latent_fwd_smem(1)) != hipSuccess) return;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&ob, latent_bwd_kernel<1>, 64 * BW, latent_bwd_smem(1)) != hipSuccess) return;
     } else {
-        (void)hipFuncSetAttribute((const void*)latent_fwd_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 98304);
-        (void)hipFuncSetAttribute((const void*)latent_bwd_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 98304);
+        (void)hipFuncSetAttribute((const void*)latent_fwd_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+        (void)hipFuncSetAttribute((const void*)latent_bwd_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&of, latent_fwd_kernel<2>, 64 * BW, latent_fwd_smem(2)) != hipSuccess) return;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&ob, latent_bwd_kernel<2>, 64 * BW, latent_bwd_smem(2)) != hipSuccess) return;
     }
@@ -635,6 +767,12 @@ extern "C" int pit_latent_supported(int n_pts, int n_head, int dim, int batch, i
     return grid <= fs && 2 * grid <= bs;
 }
 
+#ifdef PIT_STAMPS
+extern "C" int pit_latent_read_stamps(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pit_latent_stamps), sizeof(unsigned long long) * 2 * 16 * 16);
+}
+#endif
+
 extern "C" int pit_latent_fwd(const float* e, const float* inv, int n_pts, int n_head, int dim, int batch, int n_layers,
                               float* const* xcat, const float* const* w1, const float* const* b1, const float* const* w2,
                               const float* const* b2, float* z1, float* h, float* z2, float* out, long ld_out,
@@ -644,6 +782,7 @@ extern "C" int pit_latent_fwd(const float* e, const float* inv, int n_pts, int n
     if (ld_out < dim || !aligned16(e)) return PIT_ERR_SIZE;
     LatentFwdArgs g;
     g.L = n_pts; g.batch = batch; g.n_layers = n_layers; g.linear_map = (flags & PIT_LATENT_LINEAR_MAP) ? 1 : 0;
+    g.no_fast = (flags & PIT_LATENT_NO_FAST) ? 1 : 0;
     const long rows = (long)batch * n_pts;
     for (int l = 0; l < n_layers; ++l) {
         if (!xcat[l] || !w1[l] || !b1[l] || !w2[l] || !b2[l]) return PIT_ERR_NULL;
@@ -659,7 +798,7 @@ extern "C" int pit_latent_fwd(const float* e, const float* inv, int n_pts, int n
 #define PIT_LATENT_FWD(H_)                                                                                                 \
     do {                                                                                                                   \
         static bool once = ((void)hipFuncSetAttribute((const void*)latent_fwd_kernel<H_>,                                  \
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, 98304), true);                 \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, 131072), true);                 \
         (void)once;                                                                                                        \
         hipLaunchKernelGGL((latent_fwd_kernel<H_>), grid, block, sm, (hipStream_t)stream, g);                              \
     } while (0)
@@ -672,6 +811,8 @@ extern "C" int pit_latent_fwd(const float* e, const float* inv, int n_pts, int n
 extern "C" int pit_latent_bwd(const float* e, const float* inv, const float* qw, int n_pts, int n_head, int dim, int batch, int n_layers,
                               const float* const* xcat, float* const* d_xcat, const float* const* w1, const float* const* w2,
                               const float* z1, const float* z2, float* const* scratch, double* const* dscale,
+                              const float* h, float* const* d_w1, float* const* d_b1, float* const* d_w2, float* const* d_b2,
+                              const pit_mlp_params_job* rider,
                               const float* d_out, long ld_dout, float* d_in, long ld_din,
                               unsigned* sync, int flags, int math_mode, void* stream) {
     if (!e || !inv || !qw || !xcat || !d_xcat || !w1 || !w2 || !z1 || !z2 || !scratch || !dscale || !d_out || !d_in || !sync) return PIT_ERR_NULL;
@@ -680,6 +821,7 @@ extern "C" int pit_latent_bwd(const float* e, const float* inv, const float* qw,
         (reinterpret_cast<uintptr_t>(d_out) & 7) || (reinterpret_cast<uintptr_t>(d_in) & 7)) return PIT_ERR_SIZE;
     LatentBwdArgs g;
     g.L = n_pts; g.batch = batch; g.n_layers = n_layers; g.linear_map = (flags & PIT_LATENT_LINEAR_MAP) ? 1 : 0;
+    g.no_fast = (flags & PIT_LATENT_NO_FAST) ? 1 : 0;
     const long rows = (long)batch * n_pts;
     for (int l = 0; l < n_layers; ++l) {
         if (!xcat[l] || !d_xcat[l] || !w1[l] || !w2[l] || !scratch[l]) return PIT_ERR_NULL;
@@ -688,7 +830,15 @@ extern "C" int pit_latent_bwd(const float* e, const float* inv, const float* qw,
         ly.e = e + (long)l * n_head * n_pts * n_pts; ly.inv = inv + (long)l * n_head * n_pts; ly.qw = qw + (long)l * n_head * n_pts * n_pts;
         ly.xcat = xcat[l]; ly.dxc = d_xcat[l]; ly.w1 = w1[l]; ly.w2 = w2[l];
         ly.z1 = z1 + l * rows * dim; ly.z2 = z2 + l * rows * dim; ly.scratch = scratch[l]; ly.dscale = dscale[l];
+        const bool dw = h && d_w1 && d_w1[l];
+        if (dw && (!d_b1 || !d_w2 || !d_b2 || !d_b1[l] || !d_w2[l] || !d_b2[l])) return PIT_ERR_NULL;
+        ly.h = dw ? h + l * rows * dim : nullptr;
+        ly.d_w1 = dw ? d_w1[l] : nullptr; ly.d_b1 = dw ? d_b1[l] : nullptr;
+        ly.d_w2 = dw ? d_w2[l] : nullptr; ly.d_b2 = dw ? d_b2[l] : nullptr;
     }
+    g.dec_items = 0;
+    bool rider_carried = false;
+    if (rider && pit_detail::plan_dw_pair(*rider, BW, &g.dec, 64, true)) { g.dec_items = g.dec.n1 + g.dec.n2; rider_carried = true; }
     g.d_out = d_out; g.ld_dout = ld_dout; g.d_in = d_in; g.ld_din = ld_din; g.sync = sync;
     g.n_chain = slab_grid(batch, n_pts / 16);
     const dim3 grid((unsigned)(2 * g.n_chain)), block(64 * BW);
@@ -696,12 +846,16 @@ extern "C" int pit_latent_bwd(const float* e, const float* inv, const float* qw,
 #define PIT_LATENT_BWD(H_)                                                                                                 \
     do {                                                                                                                   \
         static bool once = ((void)hipFuncSetAttribute((const void*)latent_bwd_kernel<H_>,                                  \
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, 98304), true);                 \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, 131072), true);                 \
         (void)once;                                                                                                        \
         hipLaunchKernelGGL((latent_bwd_kernel<H_>), grid, block, sm, (hipStream_t)stream, g);                              \
     } while (0)
     if (n_head == 1) PIT_LATENT_BWD(1); else PIT_LATENT_BWD(2);
 #undef PIT_LATENT_BWD
     PIT_CHECK_LAUNCH();
+    if (rider && !rider_carried)                        // too large to ride: the launches pit_mlp_bwd_params would have made
+        return pit_mlp_bwd_params(rider->x, rider->ldx, rider->rows, rider->n0, rider->n1, rider->n2, rider->h, rider->out_gelu,
+                                  rider->d_y, rider->ld_dy, rider->d_w1, rider->d_b1, rider->d_w2, rider->d_b2, rider->accumulate,
+                                  rider->scratch, rider->math_mode, stream);
     return 0;
 }

@@ -933,11 +933,16 @@ def block_fusion_supported(n_pts: int, n_head: int, dim: int, batch: int) -> boo
 
 
 # Round 4: the persistent latent kernels (csrc/pit_latent.hip) - the whole processor as ONE launch per direction when all
-# slab workgroups are co-resident (Darcy / Burgers / Sod at the scripts' batch 8: 128 workgroups); larger batches keep one
-# launch per block.  PIT_LATENT_FUSION=0 forces the per-block launches.
-LATENT_FUSION = os.environ.get("PIT_LATENT_FUSION", "1") != "0"
-LATENT_SYNC_WORDS = 4224           # PIT_LATENT_SYNC_WORDS
-LATENT_FLAGS = 0                   # tests: 1 = PIT_LATENT_LINEAR_MAP (a sample's slabs spread over all XCDs)
+# slab workgroups are co-resident (Darcy / Burgers at the scripts' batch 8: 128 + 128 workgroups).  Bit-identical to the
+# per-block launches and covered by the same tests, but OPT-IN (PIT_LATENT_FUSION=1 / ops.LATENT_FUSION = True): measured on
+# MI355X a hand-off inside the launch costs what a kernel boundary costs (2.6 us including the skew between a sample's 16
+# workgroups; tools/micro/handoff_probe.hip: 1.9-3.1 us against 3.5-3.9), so the forward gains nothing (39.2 vs 38.8 us for
+# the four blocks of Darcy b=8) and the backward (44.7 us with the blocks' weight gradients inside, against 9.1 + 4 x 11.5)
+# loses what it gains once the decoder MLP's postponed reductions, which the per-block launches absorb on idle compute
+# units, need a launch of their own (15.7 us): 0.207-0.224 vs 0.1985 ms/step.  DESIGN.md section 4, "Round 4".
+LATENT_FUSION = os.environ.get("PIT_LATENT_FUSION", "0") != "0"
+LATENT_SYNC_WORDS = 12416          # PIT_LATENT_SYNC_WORDS
+LATENT_FLAGS = 0                   # tests: 1 = PIT_LATENT_LINEAR_MAP (a sample's slabs spread over all XCDs), 2 = PIT_LATENT_NO_FAST
 _LATENT_SYNC = {}                  # (device index, stream) -> hand-off flags of the persistent kernels (zero between launches)
 
 
@@ -1082,35 +1087,21 @@ class _Processor(torch.autograd.Function):
             else:
                 _dw_run(extra)
         if ctx.latent:
-            # ONE persistent launch: the whole chain + every block's d(scale); the weight-gradient reductions (sums over all
-            # rows) read the scratch afterwards - the blocks' and the job the pass postponed, in ONE launch at the end of the
-            # pass (or right here when a two-bucket step waits for these gradients)
+            # ONE persistent launch: the whole chain, every block's d(scale) and - by the helper workgroups, each sample's share
+            # as soon as its dZ exists - the weight gradients of the blocks' MLPs; the job the pass postponed (the decoder
+            # MLP's reductions) is dealt over the helpers first
             arr = lambda ts: (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])
+            job2 = ctypes.cast(ctypes.pointer(extra_batched[0]), ctypes.c_void_p) if extra_batched is not None else None
             rc = L_.pit_latent_bwd(E.data_ptr(), inv.data_ptr(), Q.data_ptr(), L, H, D, b, n, arr(bufs), arr(dxc),
                                    arr([w[0] for w in wts]), arr([w[2] for w in wts]), z1.data_ptr(), z2.data_ptr(),
-                                   arr(scratch), arr(work), d_out.data_ptr(), D, dx.data_ptr(), D,
+                                   arr(scratch), arr(work), hh.data_ptr(), arr([sl[0] for sl in w_slots]),
+                                   arr([sl[1] for sl in w_slots]), arr([sl[2] for sl in w_slots]), arr([sl[3] for sl in w_slots]),
+                                   job2, d_out.data_ptr(), D, dx.data_ptr(), D,
                                    _latent_sync(dev).data_ptr(), LATENT_FLAGS, ctx.math, _lib.stream_ptr())
             _lib.check(rc, "pit_latent_bwd")
-            jobs = []
-            for i in range(n - 1, -1, -1):
-                dw1, db1, dw2, db2 = w_slots[i]
-                job = _lib.MlpParamsJob(bufs[i].data_ptr(), W, rows, W, D, D, hh[i].data_ptr(), 1, scratch[i].data_ptr(), D,
-                                        dw1.data_ptr(), db1.data_ptr(), dw2.data_ptr(), db2.data_ptr(), 1,
-                                        scratch[i].data_ptr(), ctx.math)
-                jobs.append((job, (bufs[i], hh, scratch[i], dw1, db1, dw2, db2)))
-            if extra_batched is not None:
-                jobs.append((extra_batched[0], extra_batched[1]))
-            if ctx.hook is None and all(g is None for g in w_grads):
-                for job, keep in jobs:                  # (in-place gradients only: nothing autograd waits for)
-                    _dw_batch_add(job, keep, dev)
-            else:                                       # gradients returned to autograd / the early bucket of a two-bucket step:
-                                                        # they must be enqueued before this node returns / the hook fires
-                arrj = (_lib.MlpParamsJob * len(jobs))(*[j[0] for j in jobs])
-                _lib.check(L_.pit_mlp_bwd_params_batch(len(jobs), ctypes.cast(arrj, ctypes.c_void_p), _lib.stream_ptr()),
-                           "pit_mlp_bwd_params_batch")
-                if ctx.hook is not None:
-                    for i in range(n - 1, -1, -1):
-                        ctx.hook[0](i)
+            if ctx.hook is not None:                    # (every gradient of the processor and of the postponed job is enqueued)
+                for i in range(n - 1, -1, -1):
+                    ctx.hook[0](i)
         # top of the chain: the last block's MLP backward (data path) from d_out
         w1, _, w2, _ = wts[n - 1]
         if not ctx.latent:

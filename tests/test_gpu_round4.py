@@ -12,6 +12,7 @@ import golden_io as gio
 import pit_oracle as orc
 
 pytestmark = pytest.mark.gpu
+LATENT_DEFAULT = os.environ.get("PIT_LATENT_FUSION", "0") != "0"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 METRIC = {"darcy": "euclid", "burgers": "periodic1d", "sod": "euclid"}
 
@@ -50,8 +51,9 @@ def _run_processor(model, x, lmdas, mlps, d_out):
     return out.detach().cpu(), [g.detach().cpu().clone() for g in grads]
 
 
+@pytest.mark.parametrize("latent", [False, True], ids=["per-block", "persistent"])
 @pytest.mark.parametrize("task,batch", [("darcy", 8), ("darcy", 3), ("burgers", 8), ("darcy", 1)])
-def test_fused_processor_against_the_oracle(task, batch):
+def test_fused_processor_against_the_oracle(task, batch, latent):
     """ops.processor_apply (block weights + the persistent latent launch, or one launch per block where that does not
     apply) against the oracle's processor - posatt_self + mlp + gelu per block, pit.py:114-122 - on the same parameters
     and inputs: output <= 1e-5, d(input) and every weight gradient <= 2e-5, d(lmda) <= 2e-4 of the largest one.  Route
@@ -60,8 +62,12 @@ def test_fused_processor_against_the_oracle(task, batch):
     model, x, lmdas, mlps = _processor_inputs(task, 31, batch)
     g = torch.Generator().manual_seed(77)
     d_out = torch.randn(x.shape, generator=g)
-    with ops.head_scale_route("host"):
-        out, grads = _run_processor(model, x, lmdas, mlps, d_out)
+    try:
+        ops.LATENT_FUSION = latent
+        with ops.head_scale_route("host"):
+            out, grads = _run_processor(model, x, lmdas, mlps, d_out)
+    finally:
+        ops.LATENT_FUSION = LATENT_DEFAULT
     assert ops.latent_status() == 0
     xr = x.clone().requires_grad_(True)
     lm_r = [p.detach().cpu().clone().requires_grad_(True) for p in lmdas]
@@ -88,7 +94,9 @@ def test_latent_launch_is_bit_identical_to_one_launch_per_block(task, batch, lin
     from position_induced_transformer_amd import ops
     model, x, lmdas, mlps = _processor_inputs(task, 32, batch)
     H, D, L = model.conv[0].n_head, model.hid_dim, model.mesh_ltt.shape[0]
+    ops.LATENT_FUSION = True
     if not ops.latent_fusion_supported(L, H, D, batch, len(lmdas)):
+        ops.LATENT_FUSION = LATENT_DEFAULT
         pytest.skip("shape not covered by the persistent kernels on this device")
     d_out = torch.randn(x.shape, generator=torch.Generator().manual_seed(5))
     res = {}
@@ -97,7 +105,7 @@ def test_latent_launch_is_bit_identical_to_one_launch_per_block(task, batch, lin
             ops.LATENT_FUSION, ops.LATENT_FLAGS = latent, linear_map
             res[latent] = _run_processor(model, x, lmdas, mlps, d_out)
     finally:
-        ops.LATENT_FUSION, ops.LATENT_FLAGS = True, 0
+        ops.LATENT_FUSION, ops.LATENT_FLAGS = LATENT_DEFAULT, 0
     assert ops.latent_status() == 0
     assert torch.equal(res[True][0], res[False][0])
     n = len(lmdas)
@@ -122,7 +130,7 @@ def test_latent_launch_replayed_under_load_never_reads_stale_rows(linear_map):
     d_out = torch.randn(x.shape, generator=torch.Generator().manual_seed(6)).cuda()
     xg = x.cuda().requires_grad_(True)
     try:
-        ops.LATENT_FLAGS = linear_map
+        ops.LATENT_FUSION, ops.LATENT_FLAGS = True, linear_map
         side = torch.cuda.Stream()
         with torch.cuda.stream(side):
             for _ in range(3):
@@ -151,4 +159,4 @@ def test_latent_launch_replayed_under_load_never_reads_stale_rows(linear_map):
         assert torch.equal(out, want_out) and torch.equal(xg.grad, want_dx)
         assert ops.latent_status() == 0
     finally:
-        ops.LATENT_FLAGS = 0
+        ops.LATENT_FUSION, ops.LATENT_FLAGS = LATENT_DEFAULT, 0

@@ -98,6 +98,7 @@ if L_.pit_latent_supported(Lp, H, D, b, n):
     blocks_fwd(); torch.cuda.synchronize(); ref = outn.clone()
     latent_fwd(); torch.cuda.synchronize()
     print(f"latent fwd == block launches: {torch.equal(ref, outn)}; sync[0] = {int(sync[0])}")
+    print(f"fast-mode switches after one forward (sync[1]): {int(sync[1])}")
     print(f"batch {b}: {n} block_fwd launches {graph_time(blocks_fwd, reps=5):.2f} us | persistent latent fwd {graph_time(latent_fwd, reps=5):.2f} us "
           f"| spread over XCDs {graph_time(lambda: latent_fwd(1), reps=5):.2f} us")
 
@@ -107,11 +108,29 @@ scrs = [torch.empty(rows * 2 * D, device="cuda") for _ in range(n)]
 wss = [torch.zeros(H * 1024, device="cuda", dtype=torch.float64) for _ in range(n)]
 d_out = torch.randn(rows, D, device="cuda"); d_in = torch.empty(rows, D, device="cuda")
 B_ = [arr(bufs), arr(dxcs), arr([w[0] for w in wts]), arr([w[2] for w in wts]), arr(scrs), arr(wss)]
+gws = [[torch.zeros_like(t) for t in w] for w in wts]
+G_ = [arr([g_[k] for g_ in gws]) for k in range(4)]
 
 
-def latent_bwd(flags=0):
+# a postponed job of the decoder MLP's shape (train_darcy.py: 1849 output points x batch, 128 -> 64 -> 1)
+drows = b * 1849
+dx_ = torch.randn(drows, 128, device="cuda"); dh_ = torch.randn(drows, 64, device="cuda"); ddy_ = torch.randn(drows, 1, device="cuda")
+dscr_ = torch.randn(drows * 65, device="cuda")
+dg_ = [torch.zeros(64, 128, device="cuda"), torch.zeros(64, device="cuda"), torch.zeros(1, 64, device="cuda"), torch.zeros(1, device="cuda")]
+djob = _lib.MlpParamsJob(dx_.data_ptr(), 128, drows, 128, 64, 1, dh_.data_ptr(), 0, ddy_.data_ptr(), 1, dg_[0].data_ptr(), dg_[1].data_ptr(),
+                         dg_[2].data_ptr(), dg_[3].data_ptr(), 1, dscr_.data_ptr(), 0)
+djp = ctypes.cast(ctypes.pointer(djob), ctypes.c_void_p)
+
+
+def dec_job_alone():
+    assert L_.pit_mlp_bwd_params(dx_.data_ptr(), 128, drows, 128, 64, 1, dh_.data_ptr(), 0, ddy_.data_ptr(), 1, dg_[0].data_ptr(), dg_[1].data_ptr(),
+                                 dg_[2].data_ptr(), dg_[3].data_ptr(), 1, dscr_.data_ptr(), 0, sp()) == 0
+
+
+def latent_bwd(flags=0, riders=True, dec=False):
     assert L_.pit_latent_bwd(E.data_ptr(), inv.data_ptr(), Q.data_ptr(), Lp, H, D, b, n, B_[0], B_[1], B_[2], B_[3], z1n.data_ptr(),
-                             z2n.data_ptr(), B_[4], B_[5], d_out.data_ptr(), D, d_in.data_ptr(), D, sync.data_ptr(), flags, 0, sp()) == 0
+                             z2n.data_ptr(), B_[4], B_[5], hn.data_ptr() if riders else None, G_[0], G_[1], G_[2], G_[3], djp if dec else None,
+                             d_out.data_ptr(), D, d_in.data_ptr(), D, sync.data_ptr(), flags, 0, sp()) == 0
 
 
 def blocks_bwd(riders=False):
@@ -131,10 +150,13 @@ if L_.pit_latent_supported(Lp, H, D, b, n):
     latent_fwd(); torch.cuda.synchronize()
     blocks_bwd(); torch.cuda.synchronize(); ref_in = d_in.clone(); ref_ws = [w.clone() for w in wss]; [w.zero_() for w in wss]
     latent_bwd(); torch.cuda.synchronize()
+    print(f"fast-mode switches so far (sync[1]): {int(sync[1])}")
     print(f"latent bwd d_in == block launches: {torch.equal(ref_in, d_in)}; d(scale) sums rel diff "
           f"{max(float(abs(a.sum() - r.sum()) / (abs(r.sum()) + 1e-300)) for a, r in zip(wss, ref_ws)):.2e}; sync[0] = {int(sync[0])}")
     print(f"batch {b}: top MLP bwd + {n} block_bwd launches (no riders) {graph_time(blocks_bwd, reps=5):.2f} us | persistent latent bwd "
-          f"{graph_time(latent_bwd, reps=5):.2f} us | spread over XCDs {graph_time(lambda: latent_bwd(1), reps=5):.2f} us")
+          f"{graph_time(latent_bwd, reps=5):.2f} us (without the weight-gradient tiles {graph_time(lambda: latent_bwd(0, False), reps=5):.2f}) | "
+          f"spread over XCDs {graph_time(lambda: latent_bwd(1), reps=5):.2f} us | with the decoder job riding {graph_time(lambda: latent_bwd(0, True, True), reps=5):.2f} us "
+          f"(the job as its own launch: {graph_time(dec_job_alone, reps=5):.2f} us)")
 
 if hasattr(L_, "pit_latent_read_stamps") and L_.pit_latent_supported(Lp, H, D, b, n):
     latent_fwd(); torch.cuda.synchronize()
