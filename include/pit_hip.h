@@ -8,7 +8,10 @@
  *     in ELEMENTS; `stream` is a hipStream_t passed as void* (NULL = default stream);
  *   - every function returns 0 on success, a negative PIT_ERR_* for an argument error,
  *     or a positive hipError_t; nothing allocates, frees or synchronises, so every call can
- *     be captured into a hipGraph; there is no process-global state;
+ *     be captured into a hipGraph; there is no MUTABLE process-global state (the math mode, the head-scale convention and
+ *     the storage formats are arguments).  What the library does read once per process: diagnostic environment switches
+ *     (PIT_NO_* / PIT_LDS_* / PIT_RR_*: force a slower kernel family for A/B measurements, listed in DESIGN.md section 4;
+ *     never needed for correct results), and per-kernel function attributes (dynamic LDS limits) set on first use;
  *   - outputs and workspaces are caller-owned (the PyTorch host code allocates them).
  *
  * Mesh conventions: `mesh_batch` = 1 for the batch-free (fixed) meshes of
@@ -200,14 +203,14 @@ int pit_posatt_dhead_finish(int n_layers, double* const* workspaces, float* cons
  * chain becomes one launch (attention as plain MFMA contractions + the MLP phases on the same 16-row slab).
  *
  * pit_block_supported: 1 when this shape takes the fused path (dim = hid_dim = 64, n_head in {1,2}, n_pts a multiple
- * of 64*8/n_head, 256 <= batch*n_pts <= 16384 rows (measured on MI355X: +27 % per step at
+ * of 256 and <= 2048 (E and Q are n_layers*n_head*n_pts^2 floats each), 256 <= batch*n_pts <= 16384 rows (measured on MI355X: +27 % per step at
  * Darcy batch 16, +19 % at 32, +2 % at 64 over the unfused kernels)); callers fall back to pit_posatt_* + pit_mlp_* otherwise. */
 int pit_block_supported(int n_pts, int n_head, int dim, int batch);
 
 /* Weights of n_layers (<= 16) self-attention layers on one batch-free mesh (n_pts, space_dim), nothing masked:
  *   e   (n_layers, n_head, n_pts, n_pts)  exp(-c_lh m[n,j])  - un-normalised and symmetric (S_min = 0: every row holds
  *                                          its own point), so e serves the forward (rows) and d(values) (columns)
- *   q   (same shape)                       e (m - mbar_n) / rowsum_n : the weights of the d(scale) contraction
+ *   q   (same shape, or NULL: forward only) e (m - mbar_n) / rowsum_n : the weights of the d(scale) contraction
  *   inv (n_layers, n_head, n_pts)          1 / rowsum
  *   rowstat (n_layers, n_head, n_pts, 4)   {T = +inf, S_min = 0, 1/rowsum, mbar} exactly as pit_posatt_fwd saves it, so
  *                                          pit_posatt_bwd can serve any layer of the stack as well

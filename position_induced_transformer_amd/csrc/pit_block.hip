@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256) void block_weights_kernel(WeightsArgs a) {
     const bool per = a.periodic != 0;
     float rsum = 0.0f, qsum = 0.0f;
     float* erow = a.e + row_id * a.L;
-    float* qrow = a.q + row_id * a.L;
+    float* qrow = a.q ? a.q + row_id * a.L : nullptr;
     auto weight = [&](int j, float& m) {
         const float* xi = a.mesh + (long)j * a.sdim;
         m = sq_dist3(ox, oy, oz, xi[0], a.sdim > 1 ? xi[1] : 0.0f, a.sdim > 2 ? xi[2] : 0.0f, per, a.period);
@@ -127,8 +127,9 @@ __global__ __launch_bounds__(256) void block_weights_kernel(WeightsArgs a) {
             const int j0 = 4 * lane + 256 * r;
             if (j0 < a.L) {
                 *reinterpret_cast<float4*>(erow + j0) = make_float4(pv[r][0], pv[r][1], pv[r][2], pv[r][3]);
-                *reinterpret_cast<float4*>(qrow + j0) = make_float4(pv[r][0] * (mv[r][0] - mbar) * inv, pv[r][1] * (mv[r][1] - mbar) * inv,
-                                                                    pv[r][2] * (mv[r][2] - mbar) * inv, pv[r][3] * (mv[r][3] - mbar) * inv);
+                if (qrow)
+                    *reinterpret_cast<float4*>(qrow + j0) = make_float4(pv[r][0] * (mv[r][0] - mbar) * inv, pv[r][1] * (mv[r][1] - mbar) * inv,
+                                                                        pv[r][2] * (mv[r][2] - mbar) * inv, pv[r][3] * (mv[r][3] - mbar) * inv);
             }
         }
         if (lane == 0) {
@@ -165,7 +166,7 @@ __global__ __launch_bounds__(256) void block_weights_kernel(WeightsArgs a) {
             qp[u] = p * (m - mbar) * inv;
         }
         *reinterpret_cast<float4*>(erow + j0) = ev;
-        *reinterpret_cast<float4*>(qrow + j0) = qv;
+        if (qrow) *reinterpret_cast<float4*>(qrow + j0) = qv;
     }
     if (lane == 0) {
         a.inv[row_id] = inv;
@@ -569,23 +570,23 @@ constexpr size_t bwd_smem(int H, bool dscale) {
 
 // 1 when the fused processor-block path covers this shape (include/pit_hip.h)
 extern "C" int pit_block_supported(int n_pts, int n_head, int dim, int batch) {
-    static const bool off = getenv("PIT_NO_BLOCK_FUSION") != nullptr;
-    if (off) return 0;
     if (dim != BD || (n_head != 1 && n_head != 2)) return 0;
     if (n_pts <= 0 || batch <= 0 || n_pts % (32 * BW) != 0) return 0;                  // 32-key trips, keys split over 8 waves
-    static const long max_rows = getenv("PIT_BLOCK_MAX_ROWS") ? atol(getenv("PIT_BLOCK_MAX_ROWS")) : 16384;
+    // the path materialises E and Q: n_layers * n_head * n_pts^2 floats EACH, kept for the backward (the per-layer kernels keep
+    // nothing of that size) - 2048 points = 32 MiB per layer and head is where it stops paying anyway
+    if (n_pts > 2048) return 0;
     const long rows = (long)batch * n_pts;
-    return rows >= 256 && rows <= max_rows;             // the latency regime; above, the tiled kernels of pit_posatt.hip
+    return rows >= 256 && rows <= 16384;                // the latency regime; above, the tiled kernels of pit_posatt.hip
 }
 
 extern "C" int pit_block_weights(const float* mesh, int n_pts, int space_dim, int metric, float period, int n_layers,
                                  const float* const* heads, int head_is_scale, int n_head, float* e, float* q,
                                  float* inv, float* rowstat, float* scale_out, void* stream) {
-    if (!mesh || !heads || !e || !q || !inv || !rowstat || !scale_out) return PIT_ERR_NULL;
+    if (!mesh || !heads || !e || !inv || !rowstat || !scale_out) return PIT_ERR_NULL;      // (q may be NULL: forward only)
     if (n_pts <= 0 || n_pts % 4 != 0 || space_dim < 1 || space_dim > 3 || n_layers < 1 || n_layers > MAX_LAYERS ||
         n_head < 1) return PIT_ERR_SIZE;
     if (metric < PIT_METRIC_EUCLID || metric > PIT_METRIC_PERIODIC2D) return PIT_ERR_METRIC;
-    if (!aligned16(e) || !aligned16(q) || !aligned16(rowstat)) return PIT_ERR_SIZE;
+    if (!aligned16(e) || (q && !aligned16(q)) || !aligned16(rowstat)) return PIT_ERR_SIZE;
     WeightsArgs a;
     a.mesh = mesh; a.L = n_pts; a.sdim = space_dim; a.periodic = metric != PIT_METRIC_EUCLID; a.period = period;
     a.n_layers = n_layers; a.n_head = n_head; a.head_is_scale = head_is_scale;
@@ -611,7 +612,7 @@ extern "C" int pit_block_fwd(const float* e, const float* inv, int n_pts, int n_
     g.w1 = w1; g.b1 = b1; g.w2 = w2; g.b2 = b2; g.out_gelu = out_gelu;
     g.z1 = z1; g.h = h; g.z2 = z2; g.y = y; g.ldy = ldy;
     const dim3 grid((unsigned)slab_grid(batch, n_pts / 16)), block(64 * BW);
-    static const bool earlyw = getenv("PIT_BLOCK_EARLY_W") != nullptr;       // (registers: the late variant fits 128 VGPRs)
+    const bool earlyw = false;      // (weights requested before the contraction: measured equal, 0.1982 vs 0.1988 ms/step; kept for experiments)
     const size_t FWD_SMEM = fwd_smem(n_head);
 #define PIT_BLOCK_FWD(H_, E_)                                                                                              \
     do {                                                                                                                   \

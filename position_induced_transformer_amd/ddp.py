@@ -59,6 +59,8 @@ class FlatGradients:
                 self.flat_params[off:off + n].copy_(p.data.reshape(-1))
                 p.data = self.flat_params[off:off + n].view_as(p)
 
+    last_work = None          # Work handle of the last eager (not captured) all-reduce on a device backend
+
     def zero_(self) -> None:
         """Clear the gradients and keep them attached.  Use this (or ``zero_grad(set_to_none=False)``)
         instead of ``optimizer.zero_grad()``, whose default ``set_to_none=True`` drops the views; if
@@ -110,7 +112,13 @@ class FlatGradients:
             dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
             buf.copy_(host)
         else:
-            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+            # (async_op + wait(): stream-ordered exactly like the blocking call, but the Work handle survives - TrainStep.capture()
+            # polls the LAST eager collective for completion before it starts capturing)
+            work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group, async_op=True)
+            if work is not None:
+                work.wait()
+                if buf.is_cuda and not torch.cuda.is_current_stream_capturing():
+                    self.last_work = work
         if average:
             buf.div_(dist.get_world_size(group))
 

@@ -55,6 +55,7 @@ class TrainStep:
                 if flat.tail_start < flat.flat.numel() and \
                         {id(q) for q in flat.params[len(flat.params) - len(tail):]} == {id(q) for q in tail}:
                     self.buckets = 2
+                    self._tail_params = list(tail)
                     self._early_block = len(model.mlp) // 2      # after this block's backward its bucket is complete
                     self._side = torch.cuda.Stream(device=self.func_in.device)
 
@@ -66,6 +67,7 @@ class TrainStep:
             raise ValueError("all_reduce_buckets must be 1 or 2")
         self.flat = flat if flat is not None else FlatGradients(model.parameters())
         self._early_pending = False
+        self._early_ok = False
         self.loss = torch.zeros((), device=self.func_in.device)
         self.out = None
         self._seed = torch.ones((), device=self.func_in.device)      # d loss / d loss, allocated once
@@ -73,8 +75,15 @@ class TrainStep:
 
     # two-bucket exchange: when the gradient of the marker module's output arrives, everything after it in the forward
     # has been back-propagated (launches enqueued) - fork the second stream there and reduce the early bucket on it
+    def _tail_in_place(self) -> bool:
+        """The early bucket may only be reduced before the pass ends if every one of its gradients is WRITTEN IN PLACE by
+        the kernels (ops._grad_slot): a parameter with a hook, a dropped / replaced .grad, or FUSED_GRAD_ACCUMULATION off
+        gets its gradient from autograd's AccumulateGrad AFTER the node returns - for the fused processor that is after the
+        early all-reduce was issued, and the ranks would silently diverge."""
+        return all(ops._grad_slot(p) is not None for p in self._tail_params)
+
     def _mark_early_point(self, _module, _inputs, output):
-        if self.all_reduce and self.buckets == 2 and torch.is_tensor(output) and output.requires_grad:
+        if self._early_ok and torch.is_tensor(output) and output.requires_grad:
             output.register_hook(self._reduce_early_bucket)
 
     def _reduce_early_bucket(self, _grad):
@@ -101,7 +110,8 @@ class TrainStep:
 
     def _step(self) -> None:
         self._early_pending = False
-        early = self.buckets == 2 and self.all_reduce
+        early = self.buckets == 2 and self.all_reduce and self._tail_in_place()    # (else: ONE all-reduce after the pass)
+        self._early_ok = early
         # per-thread state, read by the autograd nodes in their forward (ops._STEP): the early bucket needs its gradients
         # before the end of the pass, so nothing of it may wait for the end-of-pass batch launch
         with ops.step_state(processor_hook=(self._on_processor_block, self._early_block) if early else None,
@@ -159,8 +169,13 @@ class TrainStep:
             mode = "thread_local"
             import torch.distributed as dist
             if dist.is_available() and dist.is_initialized() and dist.get_backend() != "gloo":
+                # wait until the watchdog can have nothing left to poll: the last warm-up collective reports completion
+                # (bounded), then 2.5 of the watchdog's 100 ms periods for it to retire the entry
                 import time
-                time.sleep(0.5)
+                work, t0 = getattr(self.flat, "last_work", None), time.monotonic()
+                while work is not None and not work.is_completed() and time.monotonic() - t0 < 5.0:
+                    time.sleep(0.005)
+                time.sleep(0.25)
         with torch.cuda.graph(graph, stream=side, capture_error_mode=mode):
             self._step()
         ops.assert_frozen_since_capture()     # route 'host': the graph must not update an lmda whose scale it baked in

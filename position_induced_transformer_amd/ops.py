@@ -926,6 +926,7 @@ def mlp_apply(x, w1, b1, w2, b2, out_gelu: bool = False, concat_heads: int = 0) 
 # ---------------------------------------------------------------------------------------------------------------
 # Fused processor (pit.py:114-122 on batch-free meshes, small regime): csrc/pit_block.hip
 BLOCK_FUSION = os.environ.get("PIT_BLOCK_FUSION", "1") != "0"
+BLOCK_MAX_LAYERS = 16              # MAX_LAYERS of csrc/pit_block_dev.h: blocks whose weights one pit_block_weights launch forms
 
 
 def block_fusion_supported(n_pts: int, n_head: int, dim: int, batch: int) -> bool:
@@ -990,13 +991,15 @@ class _Processor(torch.autograd.Function):
         heads = [t.detach().reshape(-1).contiguous() for t in lmdas]
         kheads = list(scales) if scales is not None else heads         # route 'host': the host-evaluated c is what the kernels get
         E = torch.empty((n, H, L, L), device=dev, dtype=torch.float32)
-        Q = torch.empty((n, H, L, L), device=dev, dtype=torch.float32)
+        # (Q, the d(scale) weights, is only read by the backward: not formed under no_grad / in eval)
+        need_q = any(ctx.needs_input_grad)
+        Q = torch.empty((n, H, L, L), device=dev, dtype=torch.float32) if need_q else None
         inv = torch.empty((n, H, L), device=dev, dtype=torch.float32)
         rowstat = torch.empty((n, H, L, 4), device=dev, dtype=torch.float32)
         scale = torch.empty((n, H), device=dev, dtype=torch.float32)
         hp = (ctypes.c_void_p * n)(*[t.data_ptr() for t in kheads])
         rc = L_.pit_block_weights(plan.mesh_in.data_ptr(), L, plan.sdim, plan.metric_id, plan.period, n, hp,
-                                  1 if scales is not None else 0, H, E.data_ptr(), Q.data_ptr(), inv.data_ptr(),
+                                  1 if scales is not None else 0, H, E.data_ptr(), _lib.ptr(Q), inv.data_ptr(),
                                   rowstat.data_ptr(), scale.data_ptr(), _lib.stream_ptr())
         _lib.check(rc, "pit_block_weights")
         buf0 = _concat_buffer_of(x, L, H)

@@ -289,7 +289,9 @@ class pit(nn.Module):
         layers followed by a kaiming_mlp of the standard shape, nothing is hooked or overridden and the shape is in
         the small regime; None = run the blocks one by one."""
         n = len(self.conv)
-        if not (ops.BLOCK_FUSION and n and n == len(self.mlp) and torch.is_tensor(mesh_ltt) and mesh_ltt.dim() == 2
+        # (pit_block_weights forms the weights of at most 16 blocks in its one launch: deeper processors - the reference accepts
+        # any n_blocks - run block by block)
+        if not (ops.BLOCK_FUSION and 0 < n <= ops.BLOCK_MAX_LAYERS and n == len(self.mlp) and torch.is_tensor(mesh_ltt) and mesh_ltt.dim() == 2
                 and func_ltt.is_cuda and func_ltt.dim() == 3 and func_ltt.dtype == torch.float32
                 and ops.get_math_mode() == "fp32"):
             return None

@@ -160,3 +160,76 @@ def test_latent_launch_replayed_under_load_never_reads_stale_rows(linear_map):
         assert ops.latent_status() == 0
     finally:
         ops.LATENT_FUSION, ops.LATENT_FLAGS = LATENT_DEFAULT, 0
+
+
+@pytest.mark.parametrize("latent", [False, True], ids=["per-block", "persistent"])
+def test_two_bucket_step_falls_back_to_one_exchange_when_a_tail_gradient_is_not_in_place(latent):
+    """with the fused processor the early bucket is reduced from INSIDE the processor's backward node.  A tail
+    parameter whose gradient is not written in place (here: a tensor hook on de.mlp1.weight, so autograd's AccumulateGrad
+    delivers it after the node returned) would miss the early all-reduce: the step must then exchange everything after
+    the pass.  The collective is the doubling stand-in of test_two_bucket_step_reduces_only_finished_gradients: every
+    gradient must come out exactly doubled."""
+    from position_induced_transformer_amd import ops, tasks
+    from position_induced_transformer_amd.engine import TrainStep
+    model, sample, meta = tasks.make_task("darcy", seed=41)
+    b4 = sample(8)
+    try:
+        ops.LATENT_FUSION = latent
+        step = TrainStep(model, b4, meta["out_dim"], meta["p"], all_reduce=True, all_reduce_buckets=2)
+        assert step.buckets == 2 and step._tail_in_place()
+        seen = []
+        handle = model.de.mlp1.weight.register_hook(lambda g: seen.append(1) or g)
+        assert not step._tail_in_place()
+        flat = step.flat
+        calls = []
+
+        def doubling(average=False, group=None, part="all", flat=flat):
+            calls.append(part)
+            if part != "tail":
+                flat.attach()
+            buf = flat.flat if part == "all" else (flat.flat[flat.tail_start:] if part == "tail" else flat.flat[:flat.tail_start])
+            buf.mul_(2.0)
+        flat.all_reduce = doubling
+        step.run_eager()
+        torch.cuda.synchronize()
+        assert calls == ["all"] and seen, "the step must not reduce the early bucket when a tail gradient arrives late"
+        got = {k: q.grad.detach().clone() for k, q in model.named_parameters()}
+        handle.remove()
+        step._early_hook.remove()
+        for q in model.parameters():
+            q.grad = None
+        plain = TrainStep(model, b4, meta["out_dim"], meta["p"])
+        plain.run_eager()
+        torch.cuda.synchronize()
+        for k, q in model.named_parameters():
+            tol = 2e-4 if k.endswith("lmda") else 2e-5
+            assert gio.rel_l2((2.0 * q.grad).cpu().numpy(), got[k].cpu().numpy()) <= tol, k
+    finally:
+        ops.LATENT_FUSION = LATENT_DEFAULT
+
+
+def test_processor_deeper_than_sixteen_blocks_runs_block_by_block():
+    """pit_block_weights forms at most 16 layers per launch; the reference accepts any n_blocks, so a 17-block
+    model must take the per-layer path instead of raising - and agree with the oracle."""
+    from position_induced_transformer_amd import ops, pit as P
+    torch.manual_seed(3)
+    mesh = orc.grid_mesh_2d(16)
+    model = P.pit_fixed(2, 1, 1, 64, 2, 17, mesh.cuda(), 0.02, 0.02).cuda()
+    x = torch.randn(2, 256, 64, generator=torch.Generator().manual_seed(9))
+    calls = {"n": 0}
+    orig = ops.processor_apply
+
+    def counting(*a, **k):
+        calls["n"] += 1
+        return orig(*a, **k)
+    ops.processor_apply = counting
+    try:
+        with ops.head_scale_route("host"), torch.no_grad():
+            out = model.processor(x.cuda(), model.mesh_ltt)
+    finally:
+        ops.processor_apply = orig
+    assert calls["n"] == 0, "17 blocks must not take the fused path"
+    lm = [a.lmda.detach().cpu() for a in model.conv]
+    ml = [tuple(t.detach().cpu() for t in (w.mlp1.weight, w.mlp1.bias, w.mlp2.weight, w.mlp2.bias)) for w in model.mlp]
+    ref = _oracle_processor("euclid", mesh, x, lm, ml)
+    assert gio.rel_l2(out.cpu().numpy(), ref.numpy()) <= 1e-5

@@ -254,3 +254,21 @@ def test_postponed_job_slices_cover_the_rows_once_and_respect_the_early_bucket()
     for hook, want in ((None, 4), ((lambda i: None, 2), 2), ((lambda i: None, 3), 1), ((lambda i: None, 0), 4)):
         parts = n if hook is None else max(1, n - hook[1])
         assert parts == want
+
+
+def test_fused_processor_gate_refuses_more_blocks_than_one_weights_launch_forms():
+    """pit_block_weights takes at most ops.BLOCK_MAX_LAYERS (16) layers; pit._fused_processor must answer None
+    for a deeper processor (the reference accepts any n_blocks) BEFORE anything touches the device."""
+    import torch
+    from position_induced_transformer_amd import ops, pit as P
+    assert ops.BLOCK_MAX_LAYERS == 16
+    mesh = torch.rand(256, 2)
+    model = P.pit_fixed(2, 1, 1, 64, 2, 17, mesh, 0.02, 0.02)
+    calls = []
+    orig = ops.block_fusion_supported
+    ops.block_fusion_supported = lambda *a: calls.append(a) or True
+    try:
+        assert model._fused_processor(torch.zeros(2, 256, 64), model.mesh_ltt) is None
+    finally:
+        ops.block_fusion_supported = orig
+    assert not calls
