@@ -71,9 +71,11 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--eager-allreduce", action="store_true",
                     help="N > 1: capture the compute only and issue the gradient all-reduce eagerly after each replay")
-    ap.add_argument("--ar-buckets", type=int, choices=(1, 2), default=1,
-                    help="N > 1: 2 = all-reduce the weights whose gradients are complete half-way through the backward "
-                         "pass (decoder MLP + last processor MLPs) on a second stream while the rest of the backward runs")
+    ap.add_argument("--ar-buckets", choices=("auto", "1", "2"), default="auto",
+                    help="gradient exchange of a data-parallel step: one all-reduce after the pass (1), or the early bucket "
+                         "(decoder + last processor MLPs) reduced on a second stream while the rest of the backward runs (2); "
+                         "auto = 1 unless the measured cost of the captured all-reduce exceeds 10 %% of the step, then the faster "
+                         "of the two")
     ap.add_argument("--watchdog", type=float, default=300.0, help="N > 1: seconds allowed for capture + first replays")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip batch sweep / optimizer / roofline probes")
@@ -128,7 +130,7 @@ def build_step(args, device, rank, world, batch, with_optimizer=False, all_reduc
         return step, model, meta
     step = TrainStep(model, (mesh_in, func_in, mesh_out, target), meta["out_dim"], meta["p"], affine,
                      all_reduce=use_ar, optimizer=opt, flat=flat,
-                     all_reduce_buckets=args.ar_buckets if (use_ar and opt is None) else 1)
+                     all_reduce_buckets=int(getattr(args, 'ar_buckets_n', 1)) if (use_ar and opt is None) else 1)
     return step, model, meta
 
 
@@ -680,6 +682,27 @@ def main():
     ops.set_math_mode(args.math)
     # the timed fwd+bwd step never updates lmda: the exact (host-evaluated, cached) head scale is sync-free here
     ops.set_head_scale_route(args.head_scale_route)
+    args.ar_buckets_n = 2 if args.ar_buckets == "2" else 1
+    ar_choice = {"requested": args.ar_buckets}
+    if distributed and args.ar_buckets == "auto" and not args.eager_allreduce and not args.no_graph and not args.rollout:
+        # what the captured exchange costs on THIS node: the step without it, with one all-reduce, and - if that costs more
+        # than 10 % of the step - with the two-bucket overlap; every rank takes the same decision (MAX over ranks)
+        def quick(all_reduce, buckets):
+            args.ar_buckets_n = buckets
+            st, _, _ = build_step(args, device, rank, world, args.batch, all_reduce=all_reduce)
+            with Watchdog(args.watchdog, "capturing a candidate step"):
+                rn, _ = prepare(st, True)
+                dtq, _ = timed_blocks(rn, 20, 5, world, min_total=0.05, min_blocks=3)
+            del st, rn
+            return dtq / 20 * 1e3
+        t_none, t_one = quick(False, 1), quick(True, 1)
+        ar_choice.update(ms_per_step_no_exchange=round(t_none, 4), ms_per_step_one_allreduce=round(t_one, 4))
+        args.ar_buckets_n = 1
+        if t_one > 1.10 * t_none:
+            t_two = quick(True, 2)
+            ar_choice["ms_per_step_two_buckets"] = round(t_two, 4)
+            args.ar_buckets_n = 2 if t_two < t_one else 1
+        log("all-reduce cost on this node: " + json.dumps(ar_choice) + f" -> {args.ar_buckets_n} bucket(s)")
     step, model, meta = build_step(args, device, rank, world, args.batch, all_reduce=distributed)
     if distributed and args.eager_allreduce and not args.no_graph:
         step.all_reduce = False
@@ -721,7 +744,8 @@ def main():
                        "parallelism": f"dp{world}" if world > 1 else "single", "launch": mode,
                        "head_scale_route": args.head_scale_route,
                        "allreduce": ({"backend": dist.get_backend(), "captured": mode == "hipgraph",
-                                      "buckets": getattr(step, "buckets", 1), "floats": int(step.flat.flat.numel())}
+                                      "buckets": getattr(step, "buckets", 1), "floats": int(step.flat.flat.numel()),
+                                      "choice": ar_choice}
                                      if distributed else None)},
             "loss": round(loss_val, 6),
             "peak_memory_GB": round(torch.cuda.max_memory_allocated() / 1e9, 3),

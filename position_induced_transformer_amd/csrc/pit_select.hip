@@ -116,14 +116,11 @@ __device__ __forceinline__ uint32_t wave_kth(const uint32_t (&key)[NI], int k) {
 // one per lane the exact order statistics come from a search over ONE key per lane (31 passes x 1
 // compare instead of x ITEMS).
 template <int ITEMS>
-__global__ __launch_bounds__(256) void plan_rows_reg(SelectArgs a, int cap, int* __restrict__ nbr_idx,
-                                                     int* __restrict__ nbr_cnt, int* __restrict__ counts) {
-    __shared__ uint32_t s_cand[4][64];
+__device__ __forceinline__ void plan_row_wave(const SelectArgs& a, long row, int cap, int* __restrict__ nbr_idx,
+                                              int* __restrict__ nbr_cnt, int* __restrict__ counts, uint32_t (*s_cand)[64]) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const long rows = (long)a.mesh_batch * a.n_out;
-    const long row = (long)blockIdx.x * 4 + wave;
-    if (row >= rows) return;                      // whole wave exits together (no block barrier below)
     const int mb = (int)(row / a.n_out);
     const float* po = a.mesh_out + row * a.sdim;
     const float* pin = a.mesh_in + (long)mb * a.n_in * a.sdim;
@@ -212,6 +209,234 @@ __global__ __launch_bounds__(256) void plan_rows_reg(SelectArgs a, int cap, int*
         total += __popcll(mask);
     }
     if (lane == 0) nbr_cnt[row] = total;
+}
+
+template <int ITEMS>
+__global__ __launch_bounds__(256) void plan_rows_reg(SelectArgs a, int cap, int* __restrict__ nbr_idx,
+                                                     int* __restrict__ nbr_cnt, int* __restrict__ counts) {
+    __shared__ uint32_t s_cand[4][64];
+    const long rows = (long)a.mesh_batch * a.n_out;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;                      // whole wave exits together (no block barrier below)
+    plan_row_wave<ITEMS>(a, row, cap, nbr_idx, nbr_cnt, counts, s_cand);
+}
+
+// rows plan_rows_lane flagged (count = -1: more candidates than a lane's column holds): a wavefront each, the algorithm above
+template <int ITEMS>
+__global__ __launch_bounds__(256) void plan_rows_fix(SelectArgs a, int cap, int* __restrict__ nbr_idx,
+                                                     int* __restrict__ nbr_cnt, int* __restrict__ counts) {
+    __shared__ uint32_t s_cand[4][64];
+    const long rows = (long)a.mesh_batch * a.n_out;
+    const int lane = threadIdx.x & 63;
+    const long wid = (long)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (long)gridDim.x * 4;
+    for (long base = wid * 64; base < rows; base += nw * 64) {         // a wave scans 64 counts at a time
+        const long rr = base + lane;
+        unsigned long long todo = __builtin_amdgcn_ballot_w64(rr < rows && nbr_cnt[rr] < 0);
+        while (todo) {
+            const int l = __builtin_ctzll(todo);
+            todo &= todo - 1;
+            plan_row_wave<ITEMS>(a, base + l, cap, nbr_idx, nbr_cnt, counts, s_cand);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// Round 4: selection AND candidate lists with ONE ROW PER LANE (per-sample meshes: the plan is rebuilt every step -
+// train_naca.py:62-65, train_elasticity.py:46).  plan_rows_reg gives a whole wavefront to each row: ~650 wave
+// instructions per row, 70 % of them the two 31-pass bitwise searches (ballot + scalar popcount per pass), 237 us for the
+// NACA decoder's 225 k rows x 728 keys at 126 GB/s.  Here a lane owns a row and walks ALL keys of its sample (staged once
+// per workgroup in LDS, read as broadcasts), so every wave instruction serves 64 rows and nothing crosses lanes:
+//   pass 1   64 block minima (key j belongs to block j % 64): 6 instructions per key;
+//   bound    the (k+2)-th smallest block minimum U >= m_(k+1) (k + 2 distinct blocks hold a key <= U): a 64-input sorting
+//            network on the lane's own registers; on average only ~2.5 more than k+2 keys are <= U;
+//   pass 2   distances again, the keys with m <= U (1 + 2^-20) appended (in key order) to the lane's LDS column;
+//   exact    those <= LN_CAPB candidates sorted in registers: m_min, m_(k), m_(k+1); the list = candidates with
+//            m <= m_(k+1) (1 + 2^-21), compacted in place, copied out coalesced; per-key counts for the transposed lists
+//            through an LDS histogram (one global atomic per key and workgroup - nbr_count_lds's job).
+// ~210 wave instructions per row instead of ~650, none of them a dependent cross-lane chain.  Distances are formed by the
+// same sq_dist3 as everywhere else, order statistics on their bit patterns: results are bit-identical to plan_rows_reg
+// (tests/test_gpu_ops.py, test_gpu_round4.py).  A lane whose candidates overflow its column (massive ties) flags its row
+// (count = -1); plan_rows_fix then gives such rows a wavefront each with the old algorithm.
+constexpr int LN_NB = 64;               // most blocks a lane keeps (needs rank_k + 2 <= blocks)
+constexpr int LN_CAPB = 40;             // candidates per lane (2-byte key indices: 20 KB per workgroup)
+__host__ __device__ constexpr int ln_capb(int nb) { return nb < LN_CAPB ? nb : LN_CAPB; }
+
+template <int N, int LOGN>
+__device__ __forceinline__ void sort_regs(uint32_t (&v)[N]) {           // bitonic network, every index compile-time
+    static_assert((1 << LOGN) == N, "power of two");
+#pragma unroll
+    for (int lk = 1; lk <= LOGN; ++lk)
+#pragma unroll
+        for (int lj = lk - 1; lj >= 0; --lj)
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                const int k = 1 << lk, j = 1 << lj, l = i ^ j;
+                if (l > i) {
+                    const uint32_t lo = min(v[i], v[l]), hi = max(v[i], v[l]);
+                    const bool up = (i & k) == 0;
+                    v[i] = up ? lo : hi;
+                    v[l] = up ? hi : lo;
+                }
+            }
+}
+// v[idx] and v[idx + 1] for a wave-uniform idx (a chain of selects on registers)
+template <int N>
+__device__ __forceinline__ void pick2_reg(const uint32_t (&v)[N], int idx, uint32_t& a0, uint32_t& a1) {
+    a0 = v[0]; a1 = v[N - 1];
+#pragma unroll
+    for (int i = 1; i < N; ++i) {
+        a0 = (idx == i) ? v[i] : a0;
+        a1 = (idx + 1 == i) ? v[i] : a1;
+    }
+}
+
+// NB blocks (32 when rank_k + 2 <= 16: half the registers and a third of the sorting network; 64 otherwise)
+template <bool SD2, bool PER, int NB, int LOGNB>   // SD2: at most two coordinates enter the distance (keys as float2); PER: periodic wrap
+__global__ __launch_bounds__(256) void plan_rows_lane(SelectArgs a, int cap, int* __restrict__ nbr_idx,
+                                                      int* __restrict__ nbr_cnt, int* __restrict__ counts) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    constexpr int KW = SD2 ? 2 : 4;                                     // floats per staged key
+    constexpr int CAPB = ln_capb(NB);
+    const int npad = (a.n_in + NB - 1) / NB * NB;
+    float* keys = reinterpret_cast<float*>(lds_raw);                    // [npad][KW]
+    unsigned short* cbuf = reinterpret_cast<unsigned short*>(keys + (long)npad * KW);       // [CAPB][256]
+    int* hist = reinterpret_cast<int*>(cbuf + CAPB * 256);              // [n_in] (counts != null)
+    const int tid = threadIdx.x;
+    const int mb = blockIdx.y, r0 = blockIdx.x * 256;
+    const long rows = (long)a.mesh_batch * a.n_out;
+    const float* pin = a.mesh_in + (long)mb * a.n_in * a.sdim;
+    // ---- stage the sample's keys; the padding keys are infinitely far away (m = +inf: never selected)
+    for (int j = tid; j < npad; j += 256) {
+        float x = __builtin_inff(), y = 0.0f, z = 0.0f;
+        if (j < a.n_in) load_point(pin + (long)j * a.sdim, a.sdim, a.coords_used, x, y, z);
+        if (SD2) { keys[2 * j] = x; keys[2 * j + 1] = y; }
+        else *reinterpret_cast<float4*>(keys + 4 * j) = make_float4(x, y, z, 0.0f);
+    }
+    if (counts) for (int j = tid; j < a.n_in; j += 256) hist[j] = 0;
+    const int r = r0 + tid;
+    const bool valid = r < a.n_out;
+    const long row = (long)mb * a.n_out + (valid ? r : a.n_out - 1);
+    float ox, oy, oz;
+    load_point(a.mesh_out + row * a.sdim, a.sdim, a.coords_used, ox, oy, oz);
+    __syncthreads();
+    auto dist_bits = [&](int j) -> uint32_t {
+        float ix, iy, iz = 0.0f;
+        if (SD2) { const float2 q = *reinterpret_cast<const float2*>(keys + 2 * j); ix = q.x; iy = q.y; }
+        else { const float4 q = *reinterpret_cast<const float4*>(keys + 4 * j); ix = q.x; iy = q.y; iz = q.z; }
+        return __float_as_uint(sq_dist3t<PER>(ox, oy, oz, ix, iy, iz, a.period));
+    };
+    const int k = a.rank_k;
+    uint32_t Ub;
+    bool no_bound;
+    {   // ---- pass 1: block minima, eight keys in flight (the scheduler would otherwise request a whole block row at once)
+        uint32_t bmin[NB];
+#pragma unroll
+        for (int u = 0; u < NB; ++u) bmin[u] = 0xFFFFFFFFu;
+        for (int j0 = 0; j0 < npad; j0 += NB) {
+#pragma unroll
+            for (int u = 0; u < NB; ++u) {
+                bmin[u] = min(bmin[u], dist_bits(j0 + u));
+                if ((u & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        sort_regs<NB, LOGNB>(bmin);
+        uint32_t U, unused;
+        pick2_reg<NB>(bmin, k + 1, U, unused);                          // (k+2)-th smallest block minimum >= m_(k+1)
+        no_bound = U >= 0x7F800000u;                                    // (cannot happen with n_in >= k + 2 real keys)
+        Ub = __float_as_uint(__fmul_rn(__uint_as_float(U), 1.00000095367431640625f));     // U (1 + 2^-20)
+    }
+    // ---- pass 2: candidates (key order); eight keys' distances are formed before the (divergent) appends.  (A branch-free
+    // form - every key written to the lane's next slot, the slot advancing only for a qualifying key - measured slower:
+    // 78 vs 70 us, the LDS write traffic outweighs the saved branches.)
+    int cnt = 0;
+    for (int j0 = 0; j0 < npad; j0 += 8) {
+        uint32_t m8[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) m8[u] = dist_bits(j0 + u);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (m8[u] <= Ub) {
+                if (cnt < CAPB) cbuf[cnt * 256 + tid] = (unsigned short)(j0 + u);
+                ++cnt;
+            }
+        }
+    }
+    const bool overflow = cnt > CAPB || no_bound;
+    // ---- exact order statistics among the candidates (all reads of a group of eight requested before they are used: the
+    // slots beyond cnt hold stale indices - clamped - and count as +inf)
+    uint32_t kmin, vk, vk1;
+    {
+        uint32_t cm[NB];
+#pragma unroll
+        for (int g0 = 0; g0 < NB; g0 += 8) {
+            int jj[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int s2 = g0 + u;
+                jj[u] = (s2 < CAPB) ? (int)cbuf[(s2 < CAPB ? s2 : 0) * 256 + tid] : 0;
+                jj[u] = (s2 < cnt && jj[u] < npad) ? jj[u] : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int s2 = g0 + u;
+                const uint32_t m = dist_bits(jj[u]);
+                cm[s2] = (s2 < CAPB && s2 < cnt) ? m : 0xFFFFFFFFu;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        sort_regs<NB, LOGNB>(cm);
+        kmin = cm[0];
+        pick2_reg<NB>(cm, k, vk, vk1);
+        if (k + 1 > a.n_in - 1) vk1 = vk;
+    }
+    // ---- the list: candidates with m <= m_(k+1) (1 + 2^-21), compacted in place (still in key order: a slot is only ever
+    // written at or below the slot being read)
+    const float bound = __uint_as_float(vk1) * 1.00000047683715820312f;
+    int total = 0;
+    if (!overflow) {
+#pragma unroll
+        for (int g0 = 0; g0 < CAPB; g0 += 8) {
+            if (g0 < cnt) {
+                int jj[8];
+                uint32_t mm[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    jj[u] = (int)cbuf[(g0 + u) * 256 + tid];
+                    jj[u] = (g0 + u < cnt && jj[u] < npad) ? jj[u] : 0;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) mm[u] = dist_bits(jj[u]);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    if (g0 + u < cnt && __uint_as_float(mm[u]) <= bound) {
+                        cbuf[total * 256 + tid] = (unsigned short)jj[u];
+                        if (counts && valid && total < cap) atomicAdd(&hist[jj[u]], 1);
+                        ++total;
+                    }
+                }
+            }
+        }
+    }
+    if (valid) {
+        if (!overflow) {
+            a.stats[row] = __uint_as_float(vk);
+            a.stats[rows + row] = __uint_as_float(vk1);
+            a.stats[2 * rows + row] = __uint_as_float(kmin);
+        }
+        nbr_cnt[row] = overflow ? -1 : total;                          // -1: plan_rows_fix redoes this row
+    }
+    // (a list longer than cap keeps its true count and is truncated, as plan_rows_reg does)
+    __syncthreads();
+    const int nrows = min(256, a.n_out - r0);
+    int* out = nbr_idx + ((long)mb * a.n_out + r0) * cap;
+    const int ncopy = min(cap, CAPB);
+    for (int e = tid; e < nrows * ncopy; e += 256) {
+        const int rr = e / ncopy, sl = e - rr * ncopy;
+        out[(long)rr * cap + sl] = (int)cbuf[sl * 256 + rr];
+    }
+    if (counts)
+        for (int j = tid; j < a.n_in; j += 256)
+            if (hist[j]) atomicAdd(counts + (long)mb * a.n_in + j, hist[j]);
 }
 
 // one workgroup per row, distances recomputed per pass
@@ -569,6 +794,39 @@ extern "C" int pit_plan_fwd(const float* mesh_out, const float* mesh_in, int mes
     const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
     const bool agg = rev_ptr && n_in <= NBR_LDS_KEYS;             // counts by workgroup aggregation (launch_transpose)
     int* kcounts = agg ? nullptr : counts;
+    // per-sample meshes (rebuilt every step), short rows: one row per lane (plan_rows_lane); rows it cannot hold in a lane's
+    // column (massive ties) are redone by plan_rows_fix.  Batch-free meshes (one-off, cached plans; regular grids with
+    // large tie shells) keep the wave-per-row kernel.
+    // (a lane per row needs rows: 64 per wave - below ~500 waves the wave-per-row kernel fills the chip better: Elasticity, 9 720 rows,
+    // 2.59 vs 2.45 ms per step)
+    const bool lane_ok = mesh_batch > 1 && rank_k + 2 <= LN_NB && n_in <= NBR_LDS_KEYS && n_in < 65536 && rows >= 32768 &&
+                         (!rev_ptr || agg) && !getenv("PIT_NO_LANE_PLAN");
+    if (lane_ok) {
+        const bool sd2 = a.coords_used <= 2;
+        const int nb = 64;       // (32 blocks: a third of the sorting network, but 144 VGPRs against 95 and a looser bound - 0.2 % of the NACA rows then
+                                 // overflow a 32-slot column and the clustered repairs cost 30 us: 64 blocks measured faster everywhere)
+        const int npad = (n_in + nb - 1) / nb * nb;
+        const size_t sm = (size_t)npad * (sd2 ? 2 : 4) * sizeof(float) + (size_t)ln_capb(nb) * 256 * sizeof(unsigned short) +
+                          (rev_ptr ? (size_t)n_in * sizeof(int) : 0);
+        const dim3 lgrid((unsigned)((n_out + 255) / 256), (unsigned)mesh_batch);
+        int* lcounts = rev_ptr ? counts : nullptr;
+#define PIT_LANE(SD_, PER_, NB_, LG_) hipLaunchKernelGGL((plan_rows_lane<SD_, PER_, NB_, LG_>), lgrid, block, sm, s, a, cap, nbr_idx, nbr_cnt, lcounts)
+#define PIT_LANE_P(SD_, NB_, LG_) do { if (a.periodic) PIT_LANE(SD_, true, NB_, LG_); else PIT_LANE(SD_, false, NB_, LG_); } while (0)
+        if (sd2) { if (nb == 32) PIT_LANE_P(true, 32, 5); else PIT_LANE_P(true, 64, 6); }
+        else { if (nb == 32) PIT_LANE_P(false, 32, 5); else PIT_LANE_P(false, 64, 6); }
+#undef PIT_LANE_P
+#undef PIT_LANE
+        PIT_CHECK_LAUNCH();
+        const dim3 fgrid(256);
+#define PIT_FIX(I_) hipLaunchKernelGGL(plan_rows_fix<I_>, fgrid, block, 0, s, a, cap, nbr_idx, nbr_cnt, rev_ptr ? counts : nullptr)
+        if (items <= 4) PIT_FIX(4);
+        else if (items <= 16) PIT_FIX(16);
+        else PIT_FIX(64);
+#undef PIT_FIX
+        PIT_CHECK_LAUNCH();
+        if (rev_ptr) return launch_transpose(nbr_idx, nbr_cnt, mesh_batch, n_out, n_in, cap, rev_ptr, rev_row, counts, cursor, true, s);
+        return 0;
+    }
 #define PIT_PLAN(I_) hipLaunchKernelGGL(plan_rows_reg<I_>, grid, block, 0, s, a, cap, nbr_idx, nbr_cnt, kcounts)
     if (items <= 1) PIT_PLAN(1);
     else if (items <= 2) PIT_PLAN(2);

@@ -112,13 +112,16 @@ class FlatGradients:
             dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
             buf.copy_(host)
         else:
-            # (async_op + wait(): stream-ordered exactly like the blocking call, but the Work handle survives - TrainStep.capture()
-            # polls the LAST eager collective for completion before it starts capturing)
-            work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group, async_op=True)
-            if work is not None:
-                work.wait()
-                if buf.is_cuda and not torch.cuda.is_current_stream_capturing():
+            # eager calls keep their Work handle (async_op + wait() is stream-ordered exactly like the blocking call):
+            # TrainStep.capture() polls the LAST eager collective for completion before it starts capturing.  Captured
+            # calls stay the plain blocking form.
+            if buf.is_cuda and not torch.cuda.is_current_stream_capturing():
+                work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group, async_op=True)
+                if work is not None:
+                    work.wait()
                     self.last_work = work
+            else:
+                dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
         if average:
             buf.div_(dist.get_world_size(group))
 

@@ -170,12 +170,12 @@ class TrainStep:
             import torch.distributed as dist
             if dist.is_available() and dist.is_initialized() and dist.get_backend() != "gloo":
                 # wait until the watchdog can have nothing left to poll: the last warm-up collective reports completion
-                # (bounded), then 2.5 of the watchdog's 100 ms periods for it to retire the entry
+                # (bounded), then three of the watchdog's 100 ms periods for it to retire the entry
                 import time
                 work, t0 = getattr(self.flat, "last_work", None), time.monotonic()
                 while work is not None and not work.is_completed() and time.monotonic() - t0 < 5.0:
                     time.sleep(0.005)
-                time.sleep(0.25)
+                time.sleep(0.3)
         with torch.cuda.graph(graph, stream=side, capture_error_mode=mode):
             self._step()
         ops.assert_frozen_since_capture()     # route 'host': the graph must not update an lmda whose scale it baked in
