@@ -1687,6 +1687,13 @@ extern "C" int pit_mlp_bf16_io_supported(int rows, int n0, int n1, int n2, int o
     return (long)rows * n1 >= (1L << 19) && rows >= 8192 && (long)rows * n1 * n0 >= (1L << 27);
 }
 
+// pit_mlp_slab.hip
+bool try_launch_mlp_fwd64(const float* x, long ldx, int rows, int n0, int n1, int n2, const float* w1, const float* b1,
+                          const float* w2, const float* b2, int out_gelu, float* z1, float* h, float* z2, float* y, long ldy,
+                          hipStream_t s);
+bool try_launch_mlp_bwd64(int rows, int n0, int n1, int n2, const float* w1, const float* w2, const float* z1, const float* z2,
+                          int out_gelu, const float* d_y, long ld_dy, float* d_x, long ld_dx, float* dz1, float* dz2, hipStream_t s);
+
 extern "C" int pit_mlp_bwd_params_deferrable(int rows, int n0, int n1, int n2, int out_gelu, long ld_dy) {
     static const bool off = getenv("PIT_NO_DW_RIDER") != nullptr;
     return !off && (!out_gelu || ld_dy == n2) && mlp_bwd16_eligible(rows, n0, n1, n2);
@@ -1704,6 +1711,12 @@ extern "C" int pit_mlp_fwd(const float* x, long ldx, int rows, int n0, int n1, i
     if (math_mode & ~(0xff | PIT_IO_X_BF16 | PIT_IO_SAVE_BF16)) return PIT_ERR_UNSUPPORTED;
     if ((x16 || save16) && !pit_mlp_bf16_io_supported(rows, n0, n1, n2, out_gelu)) return PIT_ERR_UNSUPPORTED;
     if (!x16 && !save16 && try_launch_mlp_fwd16(x, ldx, rows, n0, n1, n2, w1, b1, w2, b2, out_gelu, z1, h, z2, y, ldy, s)) {
+        PIT_CHECK_LAUNCH();
+        return 0;
+    }
+    // large regime, hid 64, fp32: ONE fused launch on 64-row slabs staged through LDS (pit_mlp_slab.hip)
+    if (!x16 && !save16 && (math_mode & 0xff) == PIT_MATH_FP32 &&
+        try_launch_mlp_fwd64(x, ldx, rows, n0, n1, n2, w1, b1, w2, b2, out_gelu, z1, h, z2, y, ldy, s)) {
         PIT_CHECK_LAUNCH();
         return 0;
     }
@@ -1742,6 +1755,11 @@ extern "C" int pit_mlp_bwd_data(int rows, int n0, int n1, int n2, const float* w
     if ((save16 || dx16) && !pit_mlp_bf16_io_supported(rows, n0, n1, n2, out_gelu)) return PIT_ERR_UNSUPPORTED;
     if (!save16 && !dx16 && (!out_gelu || ld_dy == n2) &&
         try_launch_mlp_bwd16(rows, n0, n1, n2, w1, w2, z1, z2, out_gelu, d_y, ld_dy, d_x, ld_dx, dz1, dz2buf, s)) {
+        PIT_CHECK_LAUNCH();
+        return 0;
+    }
+    if (!save16 && !dx16 && (math_mode & 0xff) == PIT_MATH_FP32 && (!out_gelu || ld_dy == n2) &&
+        try_launch_mlp_bwd64(rows, n0, n1, n2, w1, w2, z1, z2, out_gelu, d_y, ld_dy, d_x, ld_dx, dz1, dz2buf, s)) {
         PIT_CHECK_LAUNCH();
         return 0;
     }
@@ -1823,6 +1841,13 @@ extern "C" int pit_mlp_bwd(const float* x, long ldx, int rows, int n0, int n1, i
         try_launch_mlp_bwd16(rows, n0, n1, n2, w1, w2, z1, z2, out_gelu, d_y, ld_dy, d_x, ld_dx, dz1, dz2buf, s)) {
         PIT_CHECK_LAUNCH();                              // dZ2, dZ1 and dX of every 16-row slab in one launch ...
         if (int rc = launch_gemm_pair_atomic(g2, g1, s)) return rc;      // ... then both weight-gradient reductions
+        PIT_CHECK_LAUNCH();
+        return 0;
+    }
+    if ((math_mode & 0xff) == PIT_MATH_FP32 && !(math_mode & ~0xff) && (!out_gelu || ld_dy == n2) &&
+        try_launch_mlp_bwd64(rows, n0, n1, n2, w1, w2, z1, z2, out_gelu, d_y, ld_dy, d_x, ld_dx, dz1, dz2buf, s)) {
+        PIT_CHECK_LAUNCH();                              // large regime, hid 64: the data path on 64-row slabs in one launch ...
+        if (int rc = launch_gemm_pair_atomic(g2, g1, s)) return rc;      // ... then both weight-gradient reductions (gemm_rr_kernel)
         PIT_CHECK_LAUNCH();
         return 0;
     }

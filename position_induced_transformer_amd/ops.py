@@ -893,9 +893,12 @@ class _Mlp(torch.autograd.Function):
                                     d_y2.data_ptr(), d_y2.stride(0), _lib.ptr(d_x), n0, scratch.data_ptr(),
                                     ctx.math, _lib.stream_ptr())
             _lib.check(rc, "pit_mlp_bwd_data")
+            # (the postponed reductions of a small-regime MLP contract in fp32 in every math mode, like its fused data-path
+            # kernels: as LDS-staged fp32 tiles they ride in the block launches at a third of the cost of the register-direct
+            # bf16 form - bf16 mode at batch 8 was 5 % slower than fp32 for this alone)
             st = _lib.MlpParamsJob(x2.data_ptr(), x2.stride(0), rows, n0, n1, n2, h.data_ptr(), og, d_y2.data_ptr(),
                                    d_y2.stride(0), d_w1.data_ptr(), d_b1.data_ptr(), d_w2.data_ptr(), d_b2.data_ptr(),
-                                   1, scratch.data_ptr(), ctx.math)
+                                   1, scratch.data_ptr(), 0)
             _dw_defer(st, (x2, h, d_y2, scratch, d_w1, d_b1, d_w2, d_b2), dev, ctx.dw_batch)
         else:
             # one call: dZ1, then dX and both weight-gradient reductions (merged into one launch when small)
@@ -987,7 +990,10 @@ class _Processor(torch.autograd.Function):
         H, W, rows = n_head, (1 + n_head) * D, b * L
         dev = x.device
         L_ = _lib.lib()
-        ctx.math = _math_code()
+        # the fused blocks contract in exact fp32 in EVERY math mode: the small regime is latency-bound (an MFMA form 16x as fast
+        # changes nothing) and fp32 products are inside any bf16 tolerance - so the bf16 mode never loses to fp32 at the scripts'
+        # batch 8 (round 3: 31.8 k vs 40.1 k samples/s because bf16 mode fell back to one launch per layer)
+        ctx.math = 0
         heads = [t.detach().reshape(-1).contiguous() for t in lmdas]
         kheads = list(scales) if scales is not None else heads         # route 'host': the host-evaluated c is what the kernels get
         E = torch.empty((n, H, L, L), device=dev, dtype=torch.float32)

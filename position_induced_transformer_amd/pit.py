@@ -292,8 +292,7 @@ class pit(nn.Module):
         # (pit_block_weights forms the weights of at most 16 blocks in its one launch: deeper processors - the reference accepts
         # any n_blocks - run block by block)
         if not (ops.BLOCK_FUSION and 0 < n <= ops.BLOCK_MAX_LAYERS and n == len(self.mlp) and torch.is_tensor(mesh_ltt) and mesh_ltt.dim() == 2
-                and func_ltt.is_cuda and func_ltt.dim() == 3 and func_ltt.dtype == torch.float32
-                and ops.get_math_mode() == "fp32"):
+                and func_ltt.is_cuda and func_ltt.dim() == 3 and func_ltt.dtype == torch.float32):
             return None
         hid, heads = func_ltt.shape[-1], self.conv[0].n_head
         kinds = (posatt_fixed, posatt_periodic1d, posatt_periodic2d)

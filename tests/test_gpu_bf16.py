@@ -5,7 +5,7 @@ accumulate in fp32, so outputs and gradients are expected within ~1e-2 relative 
 
     TOL_OUT  = 2e-2   forward outputs / loss
     TOL_GRAD = 5e-2   weight, bias and value gradients (two rounded contractions deep)
-    TOL_HEAD = 1e-1   d(lmda): its reduction runs in fp32, but it consumes bf16-mode d_out; at model
+    TOL_HEAD = 5e-2   d(lmda) (round 4: tightened from 1e-1): its reduction runs in fp32, but it consumes bf16-mode d_out; at model
                       level all heads are judged as one vector (see test_model_bf16_close_to_golden)
 
 What must NOT change with the mode: distances, head scale, quantile thresholds and therefore the
@@ -18,7 +18,7 @@ import golden_io as gio
 import model_cases as mc
 
 pytestmark = pytest.mark.gpu
-TOL_OUT, TOL_GRAD, TOL_HEAD = 2e-2, 5e-2, 1e-1
+TOL_OUT, TOL_GRAD, TOL_HEAD = 2e-2, 5e-2, 5e-2
 
 
 @pytest.fixture
@@ -179,7 +179,7 @@ def test_graph_keeps_the_mode_it_was_captured_with(bf16):
     from position_induced_transformer_amd import tasks
     from position_induced_transformer_amd.engine import TrainStep
     model, sample, meta = tasks.make_task("darcy", seed=1)
-    batch = sample(2)
+    batch = sample(32)          # (large enough for the bf16 GEMM kernels: the small regime contracts in fp32 in both modes - round 4)
     step = TrainStep(model, batch, meta["out_dim"], meta["p"])
     step.capture()
     step.replay(); torch.cuda.synchronize()
