@@ -5,6 +5,7 @@
 // One workgroup per (sample, channel) owns both norms, so a single launch produces the
 // loss (one atomicAdd per workgroup) and the two norms the backward needs.
 #include "pit_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -230,6 +231,110 @@ __global__ __launch_bounds__(256) void rel_max_fwd_kernel(const float* __restric
     }
 }
 
+// Round 4: ONE 1024-thread workgroup per (sample, channel) series when the series fits its registers (npts <= 1024 PTS).
+// rel_lp_fwd_kernel's chain for a Darcy-sized series (1849 points split over 8 workgroups) is: loads -> two returning fp64
+// atomics -> a ticket -> three exchanges by the last arriver -> the gradient pass RE-READING the whole series: ~10.6 us of
+// dependent round trips for 15 k values.  Here the series stays in registers: loads (all in flight) -> block reduction ->
+// norms -> the gradients straight from the registers; the loss accumulates through ONE returning 64-bit atomic (arrival count
+// in the top 16 bits, the sum in 2^-32 fixed point below: batch * nch <= 65535 pairs, loss < 65536).
+template <int PTS>
+__global__ __launch_bounds__(1024) void rel_lp_fwd1_kernel(const float* __restrict__ tru, const float* __restrict__ pred,
+                                                           const float* __restrict__ scale, const float* __restrict__ shift,
+                                                           int npts, int nch, int p, float* __restrict__ norms,
+                                                           float* __restrict__ loss, float* __restrict__ ws,
+                                                           float* __restrict__ d_pred_unit, float* __restrict__ d_true_unit,
+                                                           float* __restrict__ clear_buf, long clear_n) {
+    __shared__ double s_num[16], s_den[16];
+    const int tid = threadIdx.x;
+    if (clear_buf) {
+        const long nthreads = (long)gridDim.x * gridDim.y * blockDim.x;
+        const long first = ((long)blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + tid;
+        for (long i = first; i < clear_n; i += nthreads) clear_buf[i] = 0.0f;
+    }
+    const int c = blockIdx.x, b = blockIdx.y;
+    const int pairs = gridDim.x * gridDim.y, pair = b * nch + c;
+    const long base = (long)b * npts * nch + c;
+    float qv[PTS], tv[PTS], sc[PTS], sh[PTS];
+#pragma unroll
+    for (int u = 0; u < PTS; ++u) {
+        const int l = tid + u * 1024;
+        const bool ok = l < npts;
+        const long e = base + (long)(ok ? l : 0) * nch;
+        qv[u] = ok ? pred[e] : 0.0f;
+        tv[u] = ok ? tru[e] : 0.0f;
+        sc[u] = (scale && ok) ? scale[(long)l * nch + c] : 1.0f;
+        sh[u] = (scale && ok) ? shift[(long)l * nch + c] : 0.0f;
+    }
+    double num = 0.0, den = 0.0;
+#pragma unroll
+    for (int u = 0; u < PTS; ++u) {
+        if (scale) qv[u] = qv[u] * sc[u] + sh[u];
+        if (tid + u * 1024 < npts) {
+            num += (double)pow_abs(tv[u] - qv[u], p);
+            den += (double)pow_abs(tv[u], p);
+        }
+    }
+    num = wave_sum_d(num);
+    den = wave_sum_d(den);
+    if ((tid & 63) == 0) { s_num[tid >> 6] = num; s_den[tid >> 6] = den; }
+    __syncthreads();
+    num = 0.0; den = 0.0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) { num += s_num[w]; den += s_den[w]; }          // (every thread: same order, same value)
+    const double nnd = (p == 1) ? num : (p == 2 ? sqrt(num) : pow(num, 1.0 / p));
+    const double dnd = (p == 1) ? den : (p == 2 ? sqrt(den) : pow(den, 1.0 / p));
+    const float nn = (float)nnd, dn = (float)dnd;
+    if (tid == 0) {
+        norms[(long)pair * 2 + 0] = nn;
+        norms[(long)pair * 2 + 1] = dn;
+        const float term = (float)(nnd / dnd / nch);
+        unsigned long long* acc = reinterpret_cast<unsigned long long*>(ws + 2);
+        const unsigned long long add = (1ull << 48) + (unsigned long long)((double)term * 4294967296.0 + 0.5);
+        const unsigned long long old = atomicAdd(acc, add);
+        if ((old >> 48) == (unsigned long long)pairs - 1ull) {
+            const unsigned long long tot = (old + add) & ((1ull << 48) - 1ull);
+            *loss = (float)((double)tot / 4294967296.0);
+            atomicExch(acc, 0ull);
+        }
+    }
+    if (!d_pred_unit && !d_true_unit) return;
+#pragma unroll
+    for (int u = 0; u < PTS; ++u) {
+        const int l = tid + u * 1024;
+        if (l >= npts) continue;
+        const long e = base + (long)l * nch;
+        const float t = tv[u];
+        const float d = qv[u] - t;
+        float dnorm;
+        if (p == 1) dnorm = (d > 0.0f) ? 1.0f : (d < 0.0f ? -1.0f : 0.0f);
+        else if (p == 2) dnorm = (nn > 0.0f) ? d / nn : 0.0f;
+        else dnorm = (nn > 0.0f) ? copysignf(powf(fabsf(d) / nn, (float)(p - 1)), d) : 0.0f;
+        if (d_pred_unit) d_pred_unit[e] = dnorm * sc[u] / (dn * nch);
+        if (d_true_unit) {
+            float tnorm;
+            if (p == 1) tnorm = (t > 0.0f) ? 1.0f : (t < 0.0f ? -1.0f : 0.0f);
+            else if (p == 2) tnorm = (dn > 0.0f) ? t / dn : 0.0f;
+            else tnorm = (dn > 0.0f) ? copysignf(powf(fabsf(t) / dn, (float)(p - 1)), t) : 0.0f;
+            d_true_unit[e] = (-dnorm / dn - nn / (dn * dn) * tnorm) / nch;
+        }
+    }
+}
+
+// the single-workgroup form when the series fits (and the grid is not huge); false = the split form
+bool launch_rel_lp_fwd1(const float* tru, const float* pred, const float* scale, const float* shift, int batch, int npts, int nch,
+                        int p, float* norms, float* loss, float* ws, float* d_pred_unit, float* d_true_unit, float* clear_buf,
+                        long clear_n, hipStream_t s) {
+    static const bool off = getenv("PIT_NO_LOSS1") != nullptr;
+    if (off || npts > 4096 || (long)batch * nch > 4096) return false;
+    const dim3 grid(nch, batch), block(1024);
+    const int pts = (npts + 1023) / 1024;
+#define PIT_L1(P_) hipLaunchKernelGGL(rel_lp_fwd1_kernel<P_>, grid, block, 0, s, tru, pred, scale, shift, npts, nch, p, norms, loss, ws, \
+                                       d_pred_unit, d_true_unit, clear_buf, clear_n)
+    if (pts <= 1) PIT_L1(1); else if (pts <= 2) PIT_L1(2); else PIT_L1(4);
+#undef PIT_L1
+    return true;
+}
+
 // workgroups per (sample, channel) series: one 256-point trip each, at most 8, fewer for large batches
 int rel_parts(int batch, int npts, int nch) {
     int parts = std::max(1, std::min(8, (npts + 255) / 256));
@@ -256,6 +361,10 @@ extern "C" int pit_rel_lp_loss_fwd(const float* tru, const float* pred, const fl
     if ((pred_scale == nullptr) != (pred_shift == nullptr)) return PIT_ERR_NULL;
     if (batch <= 0 || npts <= 0 || nch <= 0 || p < 1 || batch > 65535) return PIT_ERR_SIZE;
     hipStream_t s = (hipStream_t)stream;
+    if (launch_rel_lp_fwd1(tru, pred, pred_scale, pred_shift, batch, npts, nch, p, norms, loss, workspace, nullptr, nullptr, nullptr, 0L, s)) {
+        PIT_CHECK_LAUNCH();
+        return 0;
+    }
     hipLaunchKernelGGL(rel_lp_fwd_kernel, dim3(nch, batch, rel_parts(batch, npts, nch)), dim3(256), 0, s, tru, pred,
                        pred_scale, pred_shift, npts, nch, p, norms, loss, workspace, (float*)nullptr, (float*)nullptr,
                        (float*)nullptr, 0L);
@@ -271,6 +380,11 @@ extern "C" int pit_rel_lp_loss_fwd_grad(const float* tru, const float* pred, con
     if ((pred_scale == nullptr) != (pred_shift == nullptr)) return PIT_ERR_NULL;
     if (batch <= 0 || npts <= 0 || nch <= 0 || p < 1 || batch > 65535 || clear_n < 0) return PIT_ERR_SIZE;
     if (clear_n > 0 && !clear_buf) return PIT_ERR_NULL;
+    if (launch_rel_lp_fwd1(tru, pred, pred_scale, pred_shift, batch, npts, nch, p, norms, loss, workspace, d_pred_unit, d_true_unit,
+                           clear_n > 0 ? clear_buf : nullptr, clear_n, (hipStream_t)stream)) {
+        PIT_CHECK_LAUNCH();
+        return 0;
+    }
     hipLaunchKernelGGL(rel_lp_fwd_kernel, dim3(nch, batch, rel_parts(batch, npts, nch)), dim3(256), 0, (hipStream_t)stream,
                        tru, pred, pred_scale, pred_shift, npts, nch, p, norms, loss, workspace, d_pred_unit, d_true_unit,
                        clear_n > 0 ? clear_buf : nullptr, clear_n);
