@@ -1693,6 +1693,7 @@ bool try_launch_mlp_fwd64(const float* x, long ldx, int rows, int n0, int n1, in
                           hipStream_t s);
 bool try_launch_mlp_bwd64(int rows, int n0, int n1, int n2, const float* w1, const float* w2, const float* z1, const float* z2,
                           int out_gelu, const float* d_y, long ld_dy, float* d_x, long ld_dx, float* dz1, float* dz2, hipStream_t s);
+bool pit_mlp_slab_preferred(int rows, int n0, int n1, int n2);
 
 extern "C" int pit_mlp_bwd_params_deferrable(int rows, int n0, int n1, int n2, int out_gelu, long ld_dy) {
     static const bool off = getenv("PIT_NO_DW_RIDER") != nullptr;
@@ -1710,6 +1711,11 @@ extern "C" int pit_mlp_fwd(const float* x, long ldx, int rows, int n0, int n1, i
     const int x16 = (math_mode & PIT_IO_X_BF16) ? 1 : 0, save16 = (math_mode & PIT_IO_SAVE_BF16) ? 1 : 0;
     if (math_mode & ~(0xff | PIT_IO_X_BF16 | PIT_IO_SAVE_BF16)) return PIT_ERR_UNSUPPORTED;
     if ((x16 || save16) && !pit_mlp_bf16_io_supported(rows, n0, n1, n2, out_gelu)) return PIT_ERR_UNSUPPORTED;
+    const bool slab_first = !x16 && !save16 && pit_mlp_slab_preferred(rows, n0, n1, n2);     // (exact fp32 like mlp_fwd16, in every math mode)
+    if (slab_first && try_launch_mlp_fwd64(x, ldx, rows, n0, n1, n2, w1, b1, w2, b2, out_gelu, z1, h, z2, y, ldy, s)) {
+        PIT_CHECK_LAUNCH();
+        return 0;
+    }
     if (!x16 && !save16 && try_launch_mlp_fwd16(x, ldx, rows, n0, n1, n2, w1, b1, w2, b2, out_gelu, z1, h, z2, y, ldy, s)) {
         PIT_CHECK_LAUNCH();
         return 0;
@@ -1753,6 +1759,11 @@ extern "C" int pit_mlp_bwd_data(int rows, int n0, int n1, int n2, const float* w
     const int save16 = (math_mode & PIT_IO_SAVE_BF16) ? 1 : 0, dx16 = (math_mode & PIT_IO_DX_BF16) ? 1 : 0;
     if (math_mode & ~(0xff | PIT_IO_X_BF16 | PIT_IO_SAVE_BF16 | PIT_IO_DX_BF16)) return PIT_ERR_UNSUPPORTED;
     if ((save16 || dx16) && !pit_mlp_bf16_io_supported(rows, n0, n1, n2, out_gelu)) return PIT_ERR_UNSUPPORTED;
+    if (!save16 && !dx16 && (!out_gelu || ld_dy == n2) && pit_mlp_slab_preferred(rows, n0, n1, n2) &&
+        try_launch_mlp_bwd64(rows, n0, n1, n2, w1, w2, z1, z2, out_gelu, d_y, ld_dy, d_x, ld_dx, dz1, dz2buf, s)) {
+        PIT_CHECK_LAUNCH();
+        return 0;
+    }
     if (!save16 && !dx16 && (!out_gelu || ld_dy == n2) &&
         try_launch_mlp_bwd16(rows, n0, n1, n2, w1, w2, z1, z2, out_gelu, d_y, ld_dy, d_x, ld_dx, dz1, dz2buf, s)) {
         PIT_CHECK_LAUNCH();
@@ -1837,6 +1848,13 @@ extern "C" int pit_mlp_bwd(const float* x, long ldx, int rows, int n0, int n1, i
     const long ld_dz2 = out_gelu ? n2 : ld_dy;
     const GemmArgs g2 = make_dw2(dz2, ld_dz2, h, rows, n1, n2, d_w2, d_b2);
     const GemmArgs g1 = make_dw1(dz1, x, ldx, rows, n0, n1, d_w1, d_b1);
+    if ((!out_gelu || ld_dy == n2) && !(math_mode & ~0xff) && pit_mlp_slab_preferred(rows, n0, n1, n2) &&
+        try_launch_mlp_bwd64(rows, n0, n1, n2, w1, w2, z1, z2, out_gelu, d_y, ld_dy, d_x, ld_dx, dz1, dz2buf, s)) {
+        PIT_CHECK_LAUNCH();                              // (the 64-row slabs also beat the 16-row kernel once most CUs get a slab)
+        if (int rc = launch_gemm_pair_atomic(g2, g1, s)) return rc;
+        PIT_CHECK_LAUNCH();
+        return 0;
+    }
     if ((!out_gelu || ld_dy == n2) &&
         try_launch_mlp_bwd16(rows, n0, n1, n2, w1, w2, z1, z2, out_gelu, d_y, ld_dy, d_x, ld_dx, dz1, dz2buf, s)) {
         PIT_CHECK_LAUNCH();                              // dZ2, dZ1 and dX of every 16-row slab in one launch ...

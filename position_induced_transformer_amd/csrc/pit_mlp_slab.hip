@@ -21,12 +21,12 @@
 namespace {
 
 struct SlabFwdArgs {
-    const float* x; long ldx; int rows, n0;
+    const float* x; long ldx; int rows, n0, n2;
     const float *w1, *b1, *w2, *b2; int out_gelu;
     float *z1, *h, *z2, *y; long ldy;
 };
 
-template <int KS>                                       // n0 = 16 KS
+template <int KS, bool THIN>                            // n0 = 16 KS; THIN: out_dim <= 4 (pit.py:106 `de`): row dots, no output tile
 __global__ __launch_bounds__(256, 2) void mlp_fwd64_kernel(SlabFwdArgs g) {
     constexpr int N0 = 16 * KS, XP = N0 + 4, HP = BD + 4, Q = 64 * N0 / 4 / 256;      // Q: 16-B pieces of a slab per thread
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -41,8 +41,9 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd64_kernel(SlabFwdArgs g) {
 #pragma unroll
     for (int s = 0; s < KS; ++s) bv[s] = *reinterpret_cast<const float4*>(g.w1 + (long)c1 * N0 + 16 * s + 4 * kq);
 #pragma unroll
-    for (int s = 0; s < 4; ++s) w2v[s] = *reinterpret_cast<const float4*>(g.w2 + (long)c1 * BD + 16 * s + 4 * kq);
-    const float bias = g.b1[c1], bias2 = g.b2[c1];
+    for (int s = 0; s < 4; ++s)
+        w2v[s] = THIN ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4*>(g.w2 + (long)c1 * BD + 16 * s + 4 * kq);
+    const float bias = g.b1[c1], bias2 = THIN ? 0.0f : g.b2[c1];
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(g.x, (unsigned)(((long)(g.rows - 1) * g.ldx + N0) * 4));
     const unsigned x_bytes = (unsigned)(((long)(g.rows - 1) * g.ldx + N0) * 4);
     float pre[Q][4];
@@ -93,25 +94,46 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd64_kernel(SlabFwdArgs g) {
             }
         }
         __syncthreads();
+        if (THIN) {
+            // thin output layer: a row dot per output - four lanes per row, 16 hidden values each
+            const int r = tid >> 2, part = tid & 3;
+            for (int o = 0; o < g.n2; ++o) {
+                float acc = 0.0f;
+#pragma unroll
+                for (int k = 0; k < 16; k += 4) {
+                    const float4 a = *reinterpret_cast<const float4*>(hs + r * HP + part * 16 + k);
+                    const float4 w = *reinterpret_cast<const float4*>(g.w2 + (long)o * BD + part * 16 + k);
+                    acc += (a.x * w.x + a.y * w.y) + (a.z * w.z + a.w * w.w);
+                }
+                acc += __shfl_xor(acc, 1, 64);
+                acc += __shfl_xor(acc, 2, 64);
+                if (part == 0 && m0 + r < g.rows) {
+                    float v = acc + g.b2[o];
+                    if (g.out_gelu) { g.z2[(m0 + r) * g.n2 + o] = v; v = gelu_erf(v); }
+                    g.y[(m0 + r) * g.ldy + o] = v;
+                }
+            }
+        } else {
         // ---- GEMM2 + bias (+ gelu)
 #pragma unroll
-        for (int rt = 0; rt < 4; ++rt) {
-            f32x4_t o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
+            for (int rt = 0; rt < 4; ++rt) {
+                f32x4_t o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const float4 a = *reinterpret_cast<const float4*>(hs + (rt * 16 + l15) * HP + 16 * s + 4 * kq);
-                o0 = mfma_16x16x4(a.x, w2v[s].x, o0);
-                o1 = mfma_16x16x4(a.y, w2v[s].y, o1);
-                o0 = mfma_16x16x4(a.z, w2v[s].z, o0);
-                o1 = mfma_16x16x4(a.w, w2v[s].w, o1);
-            }
+                for (int s = 0; s < 4; ++s) {
+                    const float4 a = *reinterpret_cast<const float4*>(hs + (rt * 16 + l15) * HP + 16 * s + 4 * kq);
+                    o0 = mfma_16x16x4(a.x, w2v[s].x, o0);
+                    o1 = mfma_16x16x4(a.y, w2v[s].y, o1);
+                    o0 = mfma_16x16x4(a.z, w2v[s].z, o0);
+                    o1 = mfma_16x16x4(a.w, w2v[s].w, o1);
+                }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const long r = m0 + rt * 16 + 4 * kq + i;
-                if (r >= g.rows) continue;
-                float v = o0[i] + o1[i] + bias2;
-                if (g.out_gelu) { g.z2[r * BD + c1] = v; v = gelu_erf(v); }
-                g.y[r * g.ldy + c1] = v;
+                for (int i = 0; i < 4; ++i) {
+                    const long r = m0 + rt * 16 + 4 * kq + i;
+                    if (r >= g.rows) continue;
+                    float v = o0[i] + o1[i] + bias2;
+                    if (g.out_gelu) { g.z2[r * BD + c1] = v; v = gelu_erf(v); }
+                    g.y[r * g.ldy + c1] = v;
+                }
             }
         }
         __syncthreads();                                // xs / hs are rewritten by the next slab
@@ -119,13 +141,13 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd64_kernel(SlabFwdArgs g) {
 }
 
 struct SlabBwdArgs {
-    int rows, n0, out_gelu;
+    int rows, n0, n2, out_gelu;
     const float *w1, *w2, *z1, *z2, *d_y; long ld_dy;
     float* d_x; long ld_dx;
     float *dz1, *dz2;
 };
 
-template <int TPW>                                      // dX column tiles (16 wide) per wave: n0 <= 64 TPW
+template <int TPW, bool THIN>                           // dX column tiles (16 wide) per wave: n0 <= 64 TPW; THIN: out_dim <= 4
 __global__ __launch_bounds__(256, 2) void mlp_bwd64_kernel(SlabBwdArgs g) {
     constexpr int P1 = BD + 4;
     __shared__ __attribute__((aligned(16))) float ds2[64 * P1];
@@ -139,7 +161,10 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd64_kernel(SlabBwdArgs g) {
 #pragma unroll
     for (int s = 0; s < 4; ++s)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) w2v[s][e] = g.w2[(long)(16 * s + 4 * kq + e) * BD + c1];
+        for (int e = 0; e < 4; ++e) {
+            if (THIN) w2v[s][e] = (s == 0 && e < g.n2) ? g.w2[(long)e * BD + c1] : 0.0f;     // w2[o][c1], o < n2 <= 4, in w2v[0][o]
+            else w2v[s][e] = g.w2[(long)(16 * s + 4 * kq + e) * BD + c1];
+        }
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {
         const int col = (wave + 4 * t) * 16 + l15;
@@ -152,6 +177,18 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd64_kernel(SlabBwdArgs g) {
     const int pr = tid >> 4, pc = 4 * (tid & 15);
     float4 dyv[4], z2v[4];
     auto fetch = [&](int slab) {
+        if (THIN) {                                     // (64 rows x n2 <= 4 values: thread r < 64 takes row r)
+            const long r = (long)slab * 64 + tid;
+            const bool ok = tid < 64 && r < g.rows;
+            float* d = &dyv[0].x;
+            float* z = &z2v[0].x;
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                d[o] = (ok && o < g.n2) ? g.d_y[r * g.ld_dy + o] : 0.0f;
+                z[o] = (ok && o < g.n2 && g.out_gelu) ? g.z2[r * g.n2 + o] : 0.0f;
+            }
+            return;
+        }
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             const long r = (long)slab * 64 + pr + 16 * p;
@@ -165,6 +202,19 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd64_kernel(SlabBwdArgs g) {
     for (; slab < nslabs; slab += gridDim.x) {
         const long m0 = (long)slab * 64;
         // ---- dZ2 = dY * gelu'(Z2) -> LDS (+ scratch)
+        if (THIN) {
+            if (tid < 64) {
+                float4 v = dyv[0];
+                if (g.out_gelu) {
+                    v.x *= gelu_erf_grad(z2v[0].x); v.y *= gelu_erf_grad(z2v[0].y);
+                    v.z *= gelu_erf_grad(z2v[0].z); v.w *= gelu_erf_grad(z2v[0].w);
+                    const float* vv = &v.x;
+                    for (int o = 0; o < g.n2; ++o)
+                        if (m0 + tid < g.rows) g.dz2[(m0 + tid) * g.n2 + o] = vv[o];
+                }
+                *reinterpret_cast<float4*>(ds2 + tid * P1) = v;
+            }
+        } else
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             float4 v = dyv[p];
@@ -191,6 +241,13 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd64_kernel(SlabBwdArgs g) {
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt) {
             f32x4_t a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+            if (THIN) {                                 // an outer product per output, no MFMA tile
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float4 d = *reinterpret_cast<const float4*>(ds2 + (rt * 16 + 4 * kq + i) * P1);
+                    a0[i] = (d.x * w2v[0][0] + d.y * w2v[0][1]) + (d.z * w2v[0][2] + d.w * w2v[0][3]);
+                }
+            } else {
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 const float4 a = *reinterpret_cast<const float4*>(ds2 + (rt * 16 + l15) * P1 + 16 * s + 4 * kq);
@@ -198,6 +255,7 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd64_kernel(SlabBwdArgs g) {
                 a1 = mfma_16x16x4(a.y, w2v[s][1], a1);
                 a0 = mfma_16x16x4(a.z, w2v[s][2], a0);
                 a1 = mfma_16x16x4(a.w, w2v[s][3], a1);
+            }
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -252,27 +310,37 @@ int slab_grid_size(int nslabs) {
 // 16-steps, 16-B-aligned rows.  PIT_NO_SLAB_MLP=1: the two / three GEMM launches (A/B measurements).
 bool pit_mlp_slab_eligible(int rows, int n0, int n1, int n2) {
     static const bool off = getenv("PIT_NO_SLAB_MLP") != nullptr;
-    return !off && n1 == BD && n2 == BD && n0 % 16 == 0 && n0 >= 16 && n0 <= 256 && rows >= 4096;
+    return !off && n1 == BD && (n2 == BD || (n2 >= 1 && n2 <= 4)) && n0 % 16 == 0 && n0 >= 16 && n0 <= 256 && rows >= 4096;
 }
+// Do the slab kernels also replace the SMALL-regime fused kernels (mlp_fwd16 / mlp_bwd16: 16-row slabs, every workgroup
+// re-reading the weights)?  Measured: NO at the Darcy decoder MLP of batch 8 (14 792 rows = 232 slabs, one per compute unit:
+// 0.206 vs 0.195 ms per step - a 64-row slab is a serial ~8 us, the 925 16-row workgroups overlap better).  Only from four
+// slabs per compute unit.
+bool pit_mlp_slab_preferred(int rows, int n0, int n1, int n2) { return pit_mlp_slab_eligible(rows, n0, n1, n2) && rows >= 65536; }
 
 bool try_launch_mlp_fwd64(const float* x, long ldx, int rows, int n0, int n1, int n2, const float* w1, const float* b1,
                           const float* w2, const float* b2, int out_gelu, float* z1, float* h, float* z2, float* y, long ldy,
                           hipStream_t s) {
     if (!pit_mlp_slab_eligible(rows, n0, n1, n2)) return false;
     if ((reinterpret_cast<uintptr_t>(x) & 15) || ldx % 4 || (reinterpret_cast<uintptr_t>(w1) & 15) || (reinterpret_cast<uintptr_t>(w2) & 15)) return false;
+    const bool thin = n2 <= 4;
     if (((unsigned long long)(rows - 1) * ldx + n0) * 4ull > PIT_MAX_BUFFER_BYTES) return false;
     SlabFwdArgs g;
-    g.x = x; g.ldx = ldx; g.rows = rows; g.n0 = n0; g.w1 = w1; g.b1 = b1; g.w2 = w2; g.b2 = b2; g.out_gelu = out_gelu;
+    g.x = x; g.ldx = ldx; g.rows = rows; g.n0 = n0; g.n2 = n2; g.w1 = w1; g.b1 = b1; g.w2 = w2; g.b2 = b2; g.out_gelu = out_gelu;
     g.z1 = z1; g.h = h; g.z2 = z2; g.y = y; g.ldy = ldy;
     const int nslabs = (rows + 63) / 64;
     const dim3 grid((unsigned)slab_grid_size(nslabs)), block(256);
     const int ks = n0 / 16;
     const size_t sm = (size_t)(64 * (n0 + 4) + 64 * (BD + 4)) * sizeof(float);
 #define PIT_SLAB_F(KS_) case KS_: {                                                                                        \
-        static bool once = ((void)hipFuncSetAttribute((const void*)mlp_fwd64_kernel<KS_>,                                  \
+        static bool once = ((void)hipFuncSetAttribute((const void*)mlp_fwd64_kernel<KS_, false>,                           \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, 98304),                        \
+                            (void)hipFuncSetAttribute((const void*)mlp_fwd64_kernel<KS_, true>,                            \
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 98304), true);                 \
         (void)once;                                                                                                        \
-        hipLaunchKernelGGL((mlp_fwd64_kernel<KS_>), grid, block, sm, s, g); break; }
+        if (thin) hipLaunchKernelGGL((mlp_fwd64_kernel<KS_, true>), grid, block, sm, s, g);                                \
+        else hipLaunchKernelGGL((mlp_fwd64_kernel<KS_, false>), grid, block, sm, s, g);                                    \
+        break; }
     switch (ks) {
         PIT_SLAB_F(1) PIT_SLAB_F(2) PIT_SLAB_F(3) PIT_SLAB_F(4) PIT_SLAB_F(5) PIT_SLAB_F(6) PIT_SLAB_F(7) PIT_SLAB_F(8)
         PIT_SLAB_F(9) PIT_SLAB_F(10) PIT_SLAB_F(11) PIT_SLAB_F(12) PIT_SLAB_F(13) PIT_SLAB_F(14) PIT_SLAB_F(15) PIT_SLAB_F(16)
@@ -285,17 +353,18 @@ bool try_launch_mlp_fwd64(const float* x, long ldx, int rows, int n0, int n1, in
 bool try_launch_mlp_bwd64(int rows, int n0, int n1, int n2, const float* w1, const float* w2, const float* z1, const float* z2,
                           int out_gelu, const float* d_y, long ld_dy, float* d_x, long ld_dx, float* dz1, float* dz2, hipStream_t s) {
     if (!pit_mlp_slab_eligible(rows, n0, n1, n2)) return false;
-    if ((reinterpret_cast<uintptr_t>(d_y) & 15) || ld_dy % 4 || (z2 && (reinterpret_cast<uintptr_t>(z2) & 15)) ||
-        (reinterpret_cast<uintptr_t>(dz2) & 15)) return false;
+    const bool thin = n2 <= 4;
+    if (!thin && ((reinterpret_cast<uintptr_t>(d_y) & 15) || ld_dy % 4 || (z2 && (reinterpret_cast<uintptr_t>(z2) & 15)) ||
+                  (reinterpret_cast<uintptr_t>(dz2) & 15))) return false;
     SlabBwdArgs g;
-    g.rows = rows; g.n0 = n0; g.out_gelu = out_gelu; g.w1 = w1; g.w2 = w2; g.z1 = z1; g.z2 = z2; g.d_y = d_y; g.ld_dy = ld_dy;
+    g.rows = rows; g.n0 = n0; g.n2 = n2; g.out_gelu = out_gelu; g.w1 = w1; g.w2 = w2; g.z1 = z1; g.z2 = z2; g.d_y = d_y; g.ld_dy = ld_dy;
     g.d_x = d_x; g.ld_dx = ld_dx; g.dz1 = dz1; g.dz2 = dz2;
     const int nslabs = (rows + 63) / 64;
     const dim3 grid((unsigned)slab_grid_size(nslabs)), block(256);
     const int tpw = (n0 + 63) / 64;
-    if (tpw == 1) hipLaunchKernelGGL((mlp_bwd64_kernel<1>), grid, block, 0, s, g);
-    else if (tpw == 2) hipLaunchKernelGGL((mlp_bwd64_kernel<2>), grid, block, 0, s, g);
-    else if (tpw == 3) hipLaunchKernelGGL((mlp_bwd64_kernel<3>), grid, block, 0, s, g);
-    else hipLaunchKernelGGL((mlp_bwd64_kernel<4>), grid, block, 0, s, g);
+#define PIT_SLAB_B(T_) do { if (thin) hipLaunchKernelGGL((mlp_bwd64_kernel<T_, true>), grid, block, 0, s, g);                  \
+                           else hipLaunchKernelGGL((mlp_bwd64_kernel<T_, false>), grid, block, 0, s, g); } while (0)
+    if (tpw == 1) PIT_SLAB_B(1); else if (tpw == 2) PIT_SLAB_B(2); else if (tpw == 3) PIT_SLAB_B(3); else PIT_SLAB_B(4);
+#undef PIT_SLAB_B
     return true;
 }

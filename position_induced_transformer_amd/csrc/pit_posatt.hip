@@ -1824,15 +1824,18 @@ __device__ __forceinline__ void sparse_rows_body(const AttArgs& a, const SparseA
         for (int r = 0; r < CR; ++r) acc[h][r] = 0.0f;
     }
     const bool per = a.periodic != 0;
+    const int* list = sp.nbr_idx + row * sp.cap;
+    // the first 64 list entries are requested TOGETHER with the count (the list has cap slots whatever the count says): one
+    // dependent round trip less in front of the coordinates (round 4: these launches are chains of ~5 round trips)
+    const int j_first = list[lane < sp.cap ? lane : sp.cap - 1];
     const int cnt = sp.nbr_cnt[row];
     const bool scan_all = cnt > sp.cap;
     const int total = scan_all ? a.n_in : cnt;
-    const int* list = sp.nbr_idx + row * sp.cap;
 
     for (int base = 0; base < total; base += 64) {
         const int i = base + lane;
         const bool valid = i < total;
-        const int j = valid ? (scan_all ? i : list[i]) : 0;
+        const int j = valid ? (scan_all ? i : (base == 0 ? j_first : list[i])) : 0;
         const float4 xi = load_point4(rmi, mi_bytes, (long)mb * a.n_in + j, a.sdim, a.coords_used);
         const float m = sq_dist3(xo.x, xo.y, xo.z, xi.x, xi.y, xi.z, per, a.period);
         float p[NH];

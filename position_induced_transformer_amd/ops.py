@@ -902,10 +902,12 @@ class _Mlp(torch.autograd.Function):
             _dw_defer(st, (x2, h, d_y2, scratch, d_w1, d_b1, d_w2, d_b2), dev, ctx.dw_batch)
         else:
             # one call: dZ1, then dX and both weight-gradient reductions (merged into one launch when small)
+            # (small regime: fp32 in every math mode, like the postponed form above - the two must agree)
+            small = not ctx.x16 and _dw_deferrable(rows, n0, n1, n2, og, d_y2.stride(0))
             rc = L.pit_mlp_bwd(x2.data_ptr(), x2.stride(0), rows, n0, n1, n2, w1.data_ptr(), w2.data_ptr(),
                                z1.data_ptr(), h.data_ptr(), z2p, og, d_y2.data_ptr(), d_y2.stride(0),
                                _lib.ptr(d_x), n0, d_w1.data_ptr(), d_b1.data_ptr(), d_w2.data_ptr(), d_b2.data_ptr(),
-                               1 if inplace else 0, scratch.data_ptr(), ctx.math, _lib.stream_ptr())
+                               1 if inplace else 0, scratch.data_ptr(), 0 if small else ctx.math, _lib.stream_ptr())
             _lib.check(rc, "pit_mlp_bwd")
         dx = d_x.reshape(ctx.in_shape) if need_x else None
         if inplace:
