@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PIT_ABI_VERSION 14
+#define PIT_ABI_VERSION 15
 #define PIT_DSCALE_SLOTS 1024 /* fp64 accumulators per head in pit_posatt_bwd's workspace */
 
 /* distance metric (dist2att variants) */
@@ -248,6 +248,26 @@ int pit_block_bwd(const float* e, const float* inv, const float* qw, int n_pts, 
                   float* d_values, long ld_dvalues,
                   const struct pit_mlp_params_job* rider, const struct pit_mlp_params_job* rider2,
                   int math_mode, void* stream);
+
+/* ---- Batch-free self-attention on PRECOMPUTED weights, large regime (round 4; pit.py:133-144 with locality 1.0) --------
+ * The large-regime attention kernels re-formed exp(-c m) in every workgroup (posatt_rows_tiles / posatt_cols_tiles: the weight
+ * phase and the MFMA phase of a workgroup do not overlap, 47-51 % MFMA busy).  With the weights of pit_block_weights in
+ * memory (n_pts <= 2048) the weight phase is a coalesced copy requested one pass ahead:
+ *   pit_posatt_pre_fwd   out[b, n, out_col0 + h*dim + d] = (1/rowsum_h[n]) sum_j e_h[n][j] values[b, j, d]  (e symmetric)
+ *   pit_posatt_pre_bwd   d_values[b, j, :] = (add_residual ? d_out[b, j, 0:dim] : 0) + sum_h sum_n (e_h[n][j]/rowsum_h[n]) d_out[b, n, head h]
+ *                        and, with workspace != NULL, the layer's d(scale) partial sums ADDED to workspace (PIT_HEAD_DEFER
+ *                        convention: drain with pit_posatt_dhead_finish) from q = e (m - mbar)/rowsum.
+ * e / q: this layer's (n_head, n_pts, n_pts) slices, rowstat its (n_head, n_pts, 4) slice of pit_block_weights' outputs.
+ * pit_posatt_pre_supported: 1 when the shape is in the regime these launches cover (else use pit_posatt_fwd / _bwd). */
+int pit_posatt_pre_supported(int n_pts, int n_head, int dim, int batch);
+int pit_posatt_pre_fwd(const float* e, const float* rowstat, int n_pts, int n_head, int dim, int batch,
+                       const float* values, long ld_values, long values_bstride,
+                       float* out, long ld_out, long out_bstride, int out_col0, int copy_inputs, int math_mode, void* stream);
+int pit_posatt_pre_bwd(const float* e, const float* q, const float* rowstat, int n_pts, int n_head, int dim, int batch,
+                       const float* values, long ld_values, long values_bstride,
+                       const float* d_out, long ld_dout, long dout_bstride, int out_col0,
+                       float* d_values, long ld_dvalues, long dvalues_bstride, int add_residual,
+                       double* workspace, int math_mode, void* stream);
 
 /* ---- Persistent latent kernels (round 4; csrc/pit_latent.hip) -----------------------------------------------------
  * The same processor as ONE launch per direction: a workgroup keeps its (sample, 16-point slab) through all blocks and

@@ -50,6 +50,9 @@ SIGNATURES = {
     "pit_block_supported": [_I, _I, _I, _I],
     "pit_block_weights": [_P, _I, _I, _I, _F, _I, _P, _I, _I, _P, _P, _P, _P, _P, _P],
     "pit_block_fwd": [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _L, _I, _P],
+    "pit_posatt_pre_supported": [_I, _I, _I, _I],
+    "pit_posatt_pre_fwd": [_P, _P, _I, _I, _I, _I, _P, _L, _L, _P, _L, _L, _I, _I, _I, _P],
+    "pit_posatt_pre_bwd": [_P, _P, _P, _I, _I, _I, _I, _P, _L, _L, _P, _L, _L, _I, _P, _L, _L, _I, _P, _I, _P],
     "pit_latent_supported": [_I, _I, _I, _I, _I],
     "pit_latent_fwd": [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _I, _I, _P],
     "pit_latent_bwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _L, _P, _I, _I, _P],
@@ -72,7 +75,7 @@ SIGNATURES = {
     "pit_debug_mfma_tile": [_P, _P, _P, _P],
 }
 
-ABI_VERSION = 14       # PIT_ABI_VERSION of include/pit_hip.h this binding was written against
+ABI_VERSION = 15       # PIT_ABI_VERSION of include/pit_hip.h this binding was written against
 
 _lib = None
 

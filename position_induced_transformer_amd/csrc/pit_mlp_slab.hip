@@ -308,9 +308,12 @@ int slab_grid_size(int nslabs) {
 
 // eligibility of the slab kernels (pit_mlp.hip consults it above the small regime): hid 64, full output tile, K in whole
 // 16-steps, 16-B-aligned rows.  PIT_NO_SLAB_MLP=1: the two / three GEMM launches (A/B measurements).
+// (thin output layers - out_dim <= 4, the decoder MLP - run on the slab variants too: same-box A/B at Darcy b=256, 473 k rows,
+// 1.876 vs 1.890 ms per step against the GEMM + thin_* launches; PIT_NO_SLAB_THIN=1 for that form)
 bool pit_mlp_slab_eligible(int rows, int n0, int n1, int n2) {
     static const bool off = getenv("PIT_NO_SLAB_MLP") != nullptr;
-    return !off && n1 == BD && (n2 == BD || (n2 >= 1 && n2 <= 4)) && n0 % 16 == 0 && n0 >= 16 && n0 <= 256 && rows >= 4096;
+    static const bool thin = getenv("PIT_NO_SLAB_THIN") == nullptr;
+    return !off && n1 == BD && (n2 == BD || (thin && n2 >= 1 && n2 <= 4)) && n0 % 16 == 0 && n0 >= 16 && n0 <= 256 && rows >= 4096;
 }
 // Do the slab kernels also replace the SMALL-regime fused kernels (mlp_fwd16 / mlp_bwd16: 16-row slabs, every workgroup
 // re-reading the weights)?  Measured: NO at the Darcy decoder MLP of batch 8 (14 792 rows = 232 slabs, one per compute unit:

@@ -48,6 +48,10 @@ struct AttArgs {
     int coord_dims;                       // > 0: value channels [0, coord_dims) are the key coordinates themselves (sparse kernels)
     int out16, dout16;                    // PIT_IO_OUT_BF16 / PIT_IO_DOUT_BF16: `out` / `d_out` hold bf16 elements (candidate-list kernels)
     unsigned dout_elems;                  // elements of d_out (dout_load's out-of-range offset)
+    // round 4, large-regime kernels on PRECOMPUTED weights (pit_block_weights; batch-free self-attention, nothing masked):
+    // pre_w (n_head, n_in, n_out) row-major over the CONTRACTED index - forward: E (symmetric), d(values): E, d(scale): Q
+    const float* pre_w;
+    int pre_swap;                         // d(scale) with the operands swapped: B rows = d_out head columns, the dot runs against values
 };
 
 // one element of d_out through its buffer descriptor: fp32, or bf16 widened exactly; offsets in ELEMENTS, `oob` = any
@@ -993,8 +997,9 @@ constexpr int TK_CHUNK = 256;
 
 // RT = 32-row tiles per workgroup: every value (B) fragment fetched from L2 feeds RT MFMAs, which
 // is what bounds these kernels at scale (16*RT flop per operand byte).
-template <int RT, int TPW, int MODE, bool MASKED, bool BF>
+template <int RT, int TPW, int MODE, bool MASKED, bool BF, bool PRE = false>
 __global__ __launch_bounds__(512) void posatt_rows_tiles(AttArgs a) {
+    static_assert(!(PRE && MASKED), "precomputed weights: unmasked layers only");
     constexpr int KC = TK_CHUNK / RT;                     // keys per LDS pass: Ps is always 32 KiB
     constexpr int GW = KC / 64;                           // 8-key groups filled per wave per pass
     __shared__ float Ps[KC * 32 * RT];
@@ -1008,11 +1013,11 @@ __global__ __launch_bounds__(512) void posatt_rows_tiles(AttArgs a) {
     const int h = blockIdx.y;
     const int mb = blockIdx.x / a.colgroups, cs = blockIdx.x % a.colgroups;
     const long rows_total = (long)a.mesh_batch * a.n_out;
-    const float c = a.head_is_scale ? a.head[h] : head_scale_from_lmda(a.head[h]);
+    const float c = PRE ? 0.0f : (a.head_is_scale ? a.head[h] : head_scale_from_lmda(a.head[h]));
     const unsigned mo_bytes = (unsigned)((long)a.mesh_batch * a.n_out * a.sdim * 4);
     const unsigned mi_bytes = (unsigned)((long)a.mesh_batch * a.n_in * a.sdim * 4);
-    const __amdgpu_buffer_rsrc_t rmo = make_rsrc(a.mesh_out, mo_bytes);
-    const __amdgpu_buffer_rsrc_t rmi = make_rsrc(a.mesh_in, mi_bytes);
+    const __amdgpu_buffer_rsrc_t rmo = make_rsrc(a.mesh_out, PRE ? 0u : mo_bytes);
+    const __amdgpu_buffer_rsrc_t rmi = make_rsrc(a.mesh_in, PRE ? 0u : mi_bytes);
 
     // per-lane row constants for each of the RT row tiles (row = n0 + rt*32 + lane&31)
     float4 xo[RT];
@@ -1024,8 +1029,13 @@ __global__ __launch_bounds__(512) void posatt_rows_tiles(AttArgs a) {
         nvalid[rt] = n < a.n_out;
         const int nc = nvalid[rt] ? n : a.n_out - 1;
         const long rowid = (long)mb * a.n_out + nc;
-        xo[rt] = load_point4(rmo, mo_bytes, rowid, a.sdim, a.coords_used);
         T[rt] = __builtin_inff(); s_min[rt] = 0.0f; inv_l[rt] = 0.0f; mbar[rt] = 0.0f;
+        if (PRE) {                                          // (weights come from memory: only 1/rowsum of the forward's rows)
+            xo[rt] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (MODE == 0) inv_l[rt] = a.rowstat[((long)h * a.n_out + nc) * 4 + 2];
+            continue;
+        }
+        xo[rt] = load_point4(rmo, mo_bytes, rowid, a.sdim, a.coords_used);
         if (MODE == 0) {
             if (MASKED) T[rt] = quantile_lerp(__fmul_rn(c, a.stats[rowid]), __fmul_rn(c, a.stats[rows_total + rowid]), a.rank_w);
             if (a.stats) s_min[rt] = __fmul_rn(c, a.stats[2 * rows_total + rowid]);
@@ -1050,7 +1060,7 @@ __global__ __launch_bounds__(512) void posatt_rows_tiles(AttArgs a) {
         cvalid[t] = tile < tile_end && col < a.ncols;
         const int cc = cvalid[t] ? col : 0;
         col_split(a, cc, mb, cb[t], cd[t]);
-        uoff[t] = (unsigned)(((long)cb[t] * a.values_bstride + cd[t]) * 4);
+        uoff[t] = (unsigned)(((long)cb[t] * a.values_bstride + cd[t] + ((PRE && a.pre_swap) ? a.out_col0 + (long)h * a.dim : 0)) * 4);
     }
     f32x16 acc[RT][TPW];
 #pragma unroll
@@ -1076,6 +1086,23 @@ __global__ __launch_bounds__(512) void posatt_rows_tiles(AttArgs a) {
     for (int t = 0; t < TPW; ++t) voff[t] = cvalid[t] ? uoff[t] + (unsigned)(half * (BF ? 4 : 1)) * ld4 : a.values_bytes;
 
     PIT_STAMP(1);
+    // PRE: the weight tile of a pass = KC rows of pre_w (contracted index) x this workgroup's 32 RT columns (its output rows):
+    // coalesced 128-B loads, requested one pass ahead
+    const float* wt = PRE ? a.pre_w + (long)h * a.n_in * a.n_out : nullptr;
+    float wnext[GW][4][RT];
+    auto wload = [&](int c0n) {
+#pragma unroll
+        for (int it = 0; it < GW; ++it)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int jl = (wave * GW + it) * 8 + 2 * u + half;
+                const bool jv = c0n + jl < a.n_in;
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt)
+                    wnext[it][u][rt] = (jv && nvalid[rt]) ? wt[(long)(c0n + jl) * a.n_out + n0 + rt * 32 + l31] : 0.0f;
+            }
+    };
+    if (PRE) wload(0);
     int pass_i = 0;
     for (int c0 = 0; c0 < a.n_in; c0 += KC, ++pass_i) {
         const int len = min(KC, a.n_in - c0);
@@ -1095,9 +1122,11 @@ __global__ __launch_bounds__(512) void posatt_rows_tiles(AttArgs a) {
         prefetch(0);                                          // value rows in flight during the weight phase
         __syncthreads();                                      // previous chunk fully consumed
         if (pass_i < 4) PIT_STAMP(2 + 4 * pass_i);
-        for (int idx = tid; idx < len; idx += 512)
-            s_xi[idx] = load_point4(rmi, mi_bytes, (long)mb * a.n_in + c0 + idx, a.sdim, a.coords_used);
-        __syncthreads();
+        if (!PRE) {
+            for (int idx = tid; idx < len; idx += 512)
+                s_xi[idx] = load_point4(rmi, mi_bytes, (long)mb * a.n_in + c0 + idx, a.sdim, a.coords_used);
+            __syncthreads();
+        }
         if (pass_i < 4) PIT_STAMP(3 + 4 * pass_i);
         // ---- weight phase: this wave fills keys [8*GW*wave, 8*GW*(wave+1)) of the chunk, all RT row tiles
         // (the periodic wrap is a compile-time variant: as a runtime flag it is if-converted into every distance)
@@ -1129,7 +1158,17 @@ __global__ __launch_bounds__(512) void posatt_rows_tiles(AttArgs a) {
                 if (lane == 0) s_flag[g] = flag ? 1 : 0;
             }
         };
-        if (per) fill(std::true_type{}); else fill(std::false_type{});
+        if (PRE) {
+#pragma unroll
+            for (int it = 0; it < GW; ++it)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int jl = (wave * GW + it) * 8 + 2 * u + half;
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) Ps[(jl * RT + rt) * 32 + l31] = wnext[it][u][rt];
+                }
+            if (c0 + KC < a.n_in) wload(c0 + KC);               // the next pass's weights travel during this contraction
+        } else if (per) fill(std::true_type{}); else fill(std::false_type{});
         if (pass_i < 4) PIT_STAMP(4 + 4 * pass_i);
         __syncthreads();
         if (pass_i < 4) PIT_STAMP(5 + 4 * pass_i);
@@ -1202,7 +1241,7 @@ __global__ __launch_bounds__(512) void posatt_rows_tiles(AttArgs a) {
         for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
             for (int t = 0; t < TPW; ++t) {
-                const unsigned cbase = (unsigned)(((long)cb[t] * a.dout_bstride + a.out_col0 + (long)h * a.dim + cd[t]) * 4);
+                const unsigned cbase = (unsigned)(((long)cb[t] * a.dout_bstride + ((PRE && a.pre_swap) ? 0 : a.out_col0 + (long)h * a.dim) + cd[t]) * 4);
                 float dov[16];
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
@@ -1219,18 +1258,22 @@ __global__ __launch_bounds__(512) void posatt_rows_tiles(AttArgs a) {
         return;
     }
     // ---- forward epilogue: row sums over the 16 (wave, half) partials, normalise, store
+    if (!PRE) {
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt) {
-        s_rs[0][wave * 2 + half][rt * 32 + l31] = rsum[rt];
-        s_rs[1][wave * 2 + half][rt * 32 + l31] = qsum[rt];
+        for (int rt = 0; rt < RT; ++rt) {
+            s_rs[0][wave * 2 + half][rt * 32 + l31] = rsum[rt];
+            s_rs[1][wave * 2 + half][rt * 32 + l31] = qsum[rt];
+        }
+        __syncthreads();
     }
-    __syncthreads();
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
         float rs_tot = 0.0f, qs_tot = 0.0f;
+        if (!PRE) {
 #pragma unroll
-        for (int k = 0; k < 16; ++k) { rs_tot += s_rs[0][k][rt * 32 + l31]; qs_tot += s_rs[1][k][rt * 32 + l31]; }
-        const float inv = rs_tot > 0.0f ? 1.0f / rs_tot : 0.0f;
+            for (int k = 0; k < 16; ++k) { rs_tot += s_rs[0][k][rt * 32 + l31]; qs_tot += s_rs[1][k][rt * 32 + l31]; }
+        }
+        const float inv = PRE ? inv_l[rt] : (rs_tot > 0.0f ? 1.0f / rs_tot : 0.0f);
         float inv_row[16];
 #pragma unroll
         for (int i = 0; i < 16; ++i) inv_row[i] = __shfl(inv, acc_row(i, half));
@@ -1257,17 +1300,18 @@ __global__ __launch_bounds__(512) void posatt_rows_tiles(AttArgs a) {
                 }
             }
         }
-        if (wave == 0 && cs == 0 && half == 0 && nvalid[rt]) {
+        if (!PRE && wave == 0 && cs == 0 && half == 0 && nvalid[rt]) {
             float4 st; st.x = T[rt]; st.y = s_min[rt]; st.z = inv; st.w = qs_tot * inv;
             *reinterpret_cast<float4*>(a.rowstat + (((long)mb * a.n_head + h) * a.n_out + n0 + rt * 32 + l31) * 4) = st;
         }
     }
     PIT_STAMP(21);
-    if (a.scale_out && tid == 0 && blockIdx.x == 0 && blockIdx.z == 0) a.scale_out[h] = c;
+    if (!PRE && a.scale_out && tid == 0 && blockIdx.x == 0 && blockIdx.z == 0) a.scale_out[h] = c;
 }
 
-template <int TPW, bool MASKED, bool BF>
+template <int TPW, bool MASKED, bool BF, bool PRE = false>
 __global__ __launch_bounds__(512) void posatt_cols_tiles(AttArgs a) {
+    static_assert(!(PRE && MASKED), "precomputed weights: unmasked layers only");
     __shared__ float Ps[TK_CHUNK * 32];
     __shared__ float4 s_rec[TK_CHUNK * 2];
     __shared__ int s_flag[TK_CHUNK / 8];
@@ -1280,9 +1324,10 @@ __global__ __launch_bounds__(512) void posatt_cols_tiles(AttArgs a) {
     const bool jvalid = j < a.n_in;
     const unsigned mo_bytes = (unsigned)((long)a.mesh_batch * a.n_out * a.sdim * 4);
     const unsigned mi_bytes = (unsigned)((long)a.mesh_batch * a.n_in * a.sdim * 4);
-    const __amdgpu_buffer_rsrc_t rmo = make_rsrc(a.mesh_out, mo_bytes);
-    const __amdgpu_buffer_rsrc_t rmi = make_rsrc(a.mesh_in, mi_bytes);
-    const float4 xi = load_point4(rmi, mi_bytes, (long)mb * a.n_in + (jvalid ? j : a.n_in - 1), a.sdim, a.coords_used);
+    const __amdgpu_buffer_rsrc_t rmo = make_rsrc(a.mesh_out, PRE ? 0u : mo_bytes);
+    const __amdgpu_buffer_rsrc_t rmi = make_rsrc(a.mesh_in, PRE ? 0u : mi_bytes);
+    const float4 xi = PRE ? make_float4(0.f, 0.f, 0.f, 0.f)
+                          : load_point4(rmi, mi_bytes, (long)mb * a.n_in + (jvalid ? j : a.n_in - 1), a.sdim, a.coords_used);
     const __amdgpu_buffer_rsrc_t rdout = make_rsrc(a.d_out, a.dout_bytes);
     const unsigned ldd4 = (unsigned)a.ld_dout * 4u;
     const int ntiles = (a.ncols + 31) / 32;
@@ -1316,8 +1361,21 @@ __global__ __launch_bounds__(512) void posatt_cols_tiles(AttArgs a) {
 #pragma unroll
     for (int t = 0; t < TPW; ++t) voff[t] = cvalid[t] ? doff[t] + (unsigned)(half * (BF ? 4 : 1)) * ldd4 : a.dout_bytes;
 
+    // PRE: pre_w = E (n_head, n_out, n_in) row-major over the contracted row index; P[n][j] = E[n][j] / rowsum[n]
+    float wnext[4][4];
+    auto wload = [&](int h, int c0n) {
+        const float* eh = a.pre_w + (long)h * a.n_out * a.n_in;
+#pragma unroll
+        for (int it = 0; it < 4; ++it)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int nl = (wave * 4 + it) * 8 + 2 * u + half;
+                wnext[it][u] = (c0n + nl < a.n_out && jvalid) ? eh[(long)(c0n + nl) * a.n_in + j] : 0.0f;
+            }
+    };
+    if (PRE) wload(0, 0);
     for (int h = 0; h < a.n_head; ++h) {
-        const float c = a.head_is_scale ? a.head[h] : head_scale_from_lmda(a.head[h]);
+        const float c = PRE ? 0.0f : (a.head_is_scale ? a.head[h] : head_scale_from_lmda(a.head[h]));
         const unsigned hoff = (unsigned)h * (unsigned)a.dim * 4u;
         for (int c0 = 0; c0 < a.n_out; c0 += TK_CHUNK) {
             const int len = min(TK_CHUNK, a.n_out - c0);
@@ -1338,7 +1396,7 @@ __global__ __launch_bounds__(512) void posatt_cols_tiles(AttArgs a) {
             __syncthreads();
             for (int idx = tid; idx < len; idx += 512) {
                 const long rowid = (long)mb * a.n_out + c0 + idx;
-                const float4 xo = load_point4(rmo, mo_bytes, rowid, a.sdim, a.coords_used);
+                const float4 xo = PRE ? make_float4(0.f, 0.f, 0.f, 0.f) : load_point4(rmo, mo_bytes, rowid, a.sdim, a.coords_used);
                 const float4 rs4 = *reinterpret_cast<const float4*>(
                     a.rowstat + (((long)mb * a.n_head + h) * a.n_out + c0 + idx) * 4);
                 float4 r0; r0.x = xo.x; r0.y = xo.y; r0.z = xo.z; r0.w = rs4.x;
@@ -1369,7 +1427,18 @@ __global__ __launch_bounds__(512) void posatt_cols_tiles(AttArgs a) {
                     if (lane == 0) s_flag[g] = flag ? 1 : 0;
                 }
             };
-            if (per) fill(std::true_type{}); else fill(std::false_type{});
+            if (PRE) {
+#pragma unroll
+                for (int it = 0; it < 4; ++it)
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int nl = (wave * 4 + it) * 8 + 2 * u + half;
+                        Ps[nl * 32 + l31] = (nl < len) ? wnext[it][u] * s_rec[2 * nl + 1].y : 0.0f;       // E[n][j] / rowsum[n]
+                    }
+                // the next chunk's (or head's) weights travel during this contraction
+                if (c0 + TK_CHUNK < a.n_out) wload(h, c0 + TK_CHUNK);
+                else if (h + 1 < a.n_head) wload(h + 1, 0);
+            } else if (per) fill(std::true_type{}); else fill(std::false_type{});
             __syncthreads();
             auto contract = [&](int g, const float (&bcur)[4][TPW]) {
                 if (MASKED && s_flag[g] == 0) return;
@@ -2323,7 +2392,134 @@ int fill_common(AttArgs& a, const float* mesh_out, const float* mesh_in, int mes
     return 0;
 }
 
+// ---- large-regime launches on precomputed weights (round 4)
+// one AttArgs for a batch-free self-attention layer whose weights are given: no meshes, no head scale
+int fill_pre(AttArgs& a, int n_pts, int n_head, int dim, int batch, const float* bsrc, long ld_b, long b_bstride) {
+    if (n_pts <= 0 || batch <= 0 || dim <= 0 || n_head <= 0 || n_head > 65535 || (long)batch * dim > 0x7fffffffL) return PIT_ERR_SIZE;
+    a = AttArgs();
+    a.mesh_batch = 1; a.n_out = n_pts; a.n_in = n_pts; a.sdim = 1; a.coords_used = 1;
+    a.values = bsrc; a.batch = batch; a.dim = dim; a.ld_values = ld_b; a.values_bstride = b_bstride;
+    a.n_head = n_head; a.head_is_scale = 1;
+    a.ncols = batch * dim;
+    a.bf16 = (t_call_math == PIT_MATH_BF16);
+    a.dim_magic = (dim == 1) ? 0xFFFFFFFFu : (unsigned)(0x100000000ull / (unsigned long long)dim);
+    a.no_fast_loads = env_int("PIT_NO_FAST_LOADS");
+    return 0;
+}
+// grid of posatt_rows_tiles for this shape (as launch_rows chooses it); false = the shape is not in the tiles regime
+template <int MODE>
+bool launch_rows_pre(AttArgs& a, hipStream_t s) {
+    const bool bf = (MODE == 0) && a.bf16 != 0;
+    const int n_tiles = (a.n_out + 31) / 32;
+    const long work = (long)n_tiles * a.n_head * ((a.ncols + 31) / 32) * ((a.n_in + 1) / 2);
+    int rt = 4;
+    while (rt > 1 && (n_tiles < rt || (long)((n_tiles + rt - 1) / rt) * a.n_head * ((a.ncols + 255) / 256) < 256)) rt >>= 1;
+    const int tpwg0 = tiles_per_wg_for(a.ncols, (long)((n_tiles + rt - 1) / rt) * a.n_head, work, 1);
+    if (!tpwg0) return false;
+    int tpwg = tpwg0;
+    if (rt == 4) tpwg = 8;
+    else if (rt == 2 && tpwg > 16) tpwg = 16;
+    a.tiles_per_wg = tpwg;
+    a.colgroups = ((a.ncols + 31) / 32 + tpwg - 1) / tpwg;
+    dim3 grid(a.colgroups, a.n_head, (n_tiles + rt - 1) / rt), block(512);
+#define PIT_RTP(RT_, TPW_) do { if (bf) hipLaunchKernelGGL((posatt_rows_tiles<RT_, TPW_, MODE, false, (MODE == 0), true>), grid, block, 0, s, a); \
+                                else hipLaunchKernelGGL((posatt_rows_tiles<RT_, TPW_, MODE, false, false, true>), grid, block, 0, s, a); } while (0)
+    if (rt == 4) PIT_RTP(4, 1);
+    else if (rt == 2) { if (tpwg == 16) PIT_RTP(2, 2); else PIT_RTP(2, 1); }
+    else { if (tpwg == 32) PIT_RTP(1, 4); else if (tpwg == 16) PIT_RTP(1, 2); else PIT_RTP(1, 1); }
+#undef PIT_RTP
+    return true;
+}
+bool launch_cols_pre(AttArgs& a, hipStream_t s) {
+    const bool bf = a.bf16 != 0;
+    const int j_tiles = (a.n_in + 31) / 32;
+    const long work = (long)j_tiles * ((a.ncols + 31) / 32) * ((a.n_out + 1) / 2) * a.n_head;
+    const int tpwg = tiles_per_wg_for(a.ncols, (long)j_tiles, work, 1);
+    if (!tpwg) return false;
+    a.tiles_per_wg = tpwg;
+    a.colgroups = ((a.ncols + 31) / 32 + tpwg - 1) / tpwg;
+    dim3 grid(a.colgroups, j_tiles, 1), block(512);
+#define PIT_CTP(TPW_) do { if (bf) hipLaunchKernelGGL((posatt_cols_tiles<TPW_, false, true, true>), grid, block, 0, s, a); \
+                           else hipLaunchKernelGGL((posatt_cols_tiles<TPW_, false, false, true>), grid, block, 0, s, a); } while (0)
+    if (tpwg == 32) PIT_CTP(4); else if (tpwg == 16) PIT_CTP(2); else PIT_CTP(1);
+#undef PIT_CTP
+    return true;
+}
+
 }  // namespace
+
+// include/pit_hip.h: 1 when pit_posatt_pre_fwd / _bwd run this shape (the large regime of a batch-free self-attention layer)
+extern "C" int pit_posatt_pre_supported(int n_pts, int n_head, int dim, int batch) {
+    if (n_pts <= 0 || n_head <= 0 || dim <= 0 || batch <= 0 || getenv("PIT_NO_PRE_WEIGHTS")) return 0;
+    const long ncols = (long)batch * dim;
+    if (ncols > 0x7fffffffL || n_pts % 4 != 0 || n_pts > 2048) return 0;          // (E and Q: n_head * n_pts^2 floats per layer)
+    const int n_tiles = (n_pts + 31) / 32;
+    int rt = 4;
+    while (rt > 1 && (n_tiles < rt || (long)((n_tiles + rt - 1) / rt) * n_head * ((ncols + 255) / 256) < 256)) rt >>= 1;
+    const long work = (long)n_tiles * n_head * ((ncols + 31) / 32) * ((n_pts + 1) / 2);
+    return tiles_per_wg_for((int)ncols, (long)((n_tiles + rt - 1) / rt) * n_head, work, 1) != 0 &&
+           tiles_per_wg_for((int)ncols, (long)n_tiles, work, 1) != 0;
+}
+
+extern "C" int pit_posatt_pre_fwd(const float* e, const float* rowstat, int n_pts, int n_head, int dim, int batch,
+                                  const float* values, long ld_values, long values_bstride,
+                                  float* out, long ld_out, long out_bstride, int out_col0, int copy_inputs,
+                                  int math_mode, void* stream) {
+    PIT_ENTER_MATH(math_mode);
+    if (!e || !rowstat || !values || !out) return PIT_ERR_NULL;
+    if (math_mode & ~0xff) return PIT_ERR_UNSUPPORTED;
+    AttArgs a;
+    if (int rc = fill_pre(a, n_pts, n_head, dim, batch, values, ld_values, values_bstride)) return rc;
+    const unsigned long long vb = ((unsigned long long)(batch - 1) * values_bstride + (unsigned long long)(n_pts - 1) * ld_values + dim) * 4ull;
+    if (vb > PIT_MAX_BUFFER_BYTES) return PIT_ERR_UNSUPPORTED;
+    a.values_bytes = (unsigned)vb;
+    a.out = out; a.ld_out = ld_out; a.out_bstride = out_bstride; a.out_col0 = out_col0; a.copy_inputs = copy_inputs;
+    a.rowstat = const_cast<float*>(rowstat); a.pre_w = e;
+    if (!launch_rows_pre<0>(a, (hipStream_t)stream)) return PIT_ERR_UNSUPPORTED;
+    PIT_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pit_posatt_pre_bwd(const float* e, const float* q, const float* rowstat, int n_pts, int n_head, int dim, int batch,
+                                  const float* values, long ld_values, long values_bstride,
+                                  const float* d_out, long ld_dout, long dout_bstride, int out_col0,
+                                  float* d_values, long ld_dvalues, long dvalues_bstride, int add_residual,
+                                  double* workspace, int math_mode, void* stream) {
+    PIT_ENTER_MATH(math_mode);
+    if (!e || !rowstat || !d_out || !d_values) return PIT_ERR_NULL;
+    if (workspace && (!q || !values)) return PIT_ERR_NULL;
+    if (math_mode & ~0xff) return PIT_ERR_UNSUPPORTED;
+    const unsigned long long db = ((unsigned long long)(batch - 1) * dout_bstride + (unsigned long long)(n_pts - 1) * ld_dout +
+                                   out_col0 + (unsigned long long)n_head * dim) * 4ull;
+    if (db > PIT_MAX_BUFFER_BYTES) return PIT_ERR_UNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    {   // d(values)[j] = residual + sum_h sum_n (E_h[n][j] / rowsum_h[n]) dO_h[n]
+        AttArgs a;
+        if (int rc = fill_pre(a, n_pts, n_head, dim, batch, nullptr, 0, 0)) return rc;
+        a.rowstat = const_cast<float*>(rowstat); a.pre_w = e;
+        a.d_out = d_out; a.ld_dout = ld_dout; a.dout_bstride = dout_bstride; a.out_col0 = out_col0;
+        a.dout_bytes = (unsigned)db; a.dout_elems = (unsigned)(db / 4);
+        a.d_values = d_values; a.ld_dvalues = ld_dvalues; a.dvalues_bstride = dvalues_bstride; a.add_residual = add_residual;
+        if (!launch_cols_pre(a, s)) return PIT_ERR_UNSUPPORTED;
+        PIT_CHECK_LAUNCH();
+    }
+    if (workspace) {
+        // d c_h -= sum_{j,col} U[j,col] * sum_n Q_h[n][j] dO_h[n,col]: the rows kernel with the operands swapped - its B rows are
+        // the head's columns of d_out, the dot runs against the values
+        const unsigned long long vb = ((unsigned long long)(batch - 1) * values_bstride + (unsigned long long)(n_pts - 1) * ld_values + dim) * 4ull;
+        if (vb > PIT_MAX_BUFFER_BYTES) return PIT_ERR_UNSUPPORTED;
+        AttArgs a;
+        if (int rc = fill_pre(a, n_pts, n_head, dim, batch, d_out, ld_dout, dout_bstride)) return rc;
+        a.values_bytes = (unsigned)db;
+        a.out_col0 = out_col0; a.pre_swap = 1; a.pre_w = q; a.rowstat = const_cast<float*>(rowstat);
+        a.d_out = values; a.ld_dout = ld_values; a.dout_bstride = values_bstride;
+        a.dout_bytes = (unsigned)vb; a.dout_elems = (unsigned)(vb / 4);
+        a.dscale_acc = workspace; a.nslots = PIT_DSCALE_SLOTS;
+        if (!launch_rows_pre<1>(a, s)) return PIT_ERR_UNSUPPORTED;
+        PIT_CHECK_LAUNCH();
+    }
+    return 0;
+}
 
 extern "C" int pit_posatt_fwd(const float* mesh_out, const float* mesh_in, int mesh_batch, int n_out, int n_in,
                               int space_dim, int metric, float period,

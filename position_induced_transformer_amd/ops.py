@@ -938,6 +938,118 @@ def block_fusion_supported(n_pts: int, n_head: int, dim: int, batch: int) -> boo
     return BLOCK_FUSION and bool(_lib.lib().pit_block_supported(int(n_pts), int(n_head), int(dim), int(batch)))
 
 
+# Round 4: large-regime self-attention of batch-free models on PRECOMPUTED weights (pit_posatt_pre_fwd / _bwd): the weights
+# of all processor blocks from ONE pit_block_weights launch per step, the attention launches read them instead of re-forming
+# exp(-c m) in every workgroup.  PIT_PRE_WEIGHTS=0: the recompute-from-coordinates kernels.
+PRE_WEIGHTS = os.environ.get("PIT_PRE_WEIGHTS", "1") != "0"
+
+
+def pre_weights_supported(n_pts: int, n_head: int, dim: int, batch: int) -> bool:
+    return PRE_WEIGHTS and bool(_lib.lib().pit_posatt_pre_supported(int(n_pts), int(n_head), int(dim), int(batch)))
+
+
+def block_weights(plan: "MeshPlan", lmdas, n_head: int, need_q: bool = True):
+    """Softmax weights of len(lmdas) unmasked self-attention layers on one batch-free mesh (pit_block_weights, in launches of
+    at most BLOCK_MAX_LAYERS layers): (E, Q or None, inv, rowstat, scale), each with a leading layer axis.  Route 'host':
+    the host-evaluated head scales are what the kernel gets."""
+    n, L, dev = len(lmdas), plan.n_in, plan.mesh_in.device
+    scales = [host_head_scale(p) for p in lmdas] if get_head_scale_route() == "host" else None
+    heads = [t.detach().reshape(-1).contiguous() for t in lmdas]
+    kheads = scales if scales is not None else heads
+    E = torch.empty((n, n_head, L, L), device=dev, dtype=torch.float32)
+    Q = torch.empty((n, n_head, L, L), device=dev, dtype=torch.float32) if need_q else None
+    inv = torch.empty((n, n_head, L), device=dev, dtype=torch.float32)
+    rowstat = torch.empty((n, n_head, L, 4), device=dev, dtype=torch.float32)
+    scale = torch.empty((n, n_head), device=dev, dtype=torch.float32)
+    for l0 in range(0, n, BLOCK_MAX_LAYERS):
+        m = min(BLOCK_MAX_LAYERS, n - l0)
+        hp = (ctypes.c_void_p * m)(*[t.data_ptr() for t in kheads[l0:l0 + m]])
+        rc = _lib.lib().pit_block_weights(plan.mesh_in.data_ptr(), L, plan.sdim, plan.metric_id, plan.period, m, hp,
+                                          1 if scales is not None else 0, n_head, E[l0].data_ptr(),
+                                          Q[l0].data_ptr() if Q is not None else None, inv[l0].data_ptr(),
+                                          rowstat[l0].data_ptr(), scale[l0].data_ptr(), _lib.stream_ptr())
+        _lib.check(rc, "pit_block_weights")
+    return E, Q, inv, rowstat, scale, heads
+
+
+class _PosAttPre(torch.autograd.Function):
+    """posatt.forward (pit.py:37-44) of a batch-free self-attention layer with locality 1.0 on precomputed weights:
+    out = cat((values, conv), -1).  Tensor inputs: values, lmda (flat); e / q / rowstat / scale are this layer's slices of
+    block_weights' outputs (functions of the mesh and lmda: d(lmda) is delivered through the saved q)."""
+
+    @staticmethod
+    def forward(ctx, values, head, e, q, rowstat, scale, n_head: int, head_param, out_slot):
+        _need_gpu(values, head)
+        b, L, D = values.shape
+        W = (1 + n_head) * D
+        if values.stride(2) != 1:
+            values = values.contiguous()
+        given = out_slot[0] if out_slot else None
+        out = given if given is not None else torch.empty((b, L, W), device=values.device, dtype=torch.float32)
+        ctx.math = _math_code()
+        rc = _lib.lib().pit_posatt_pre_fwd(e.data_ptr(), rowstat.data_ptr(), L, n_head, D, b, values.data_ptr(), values.stride(1),
+                                           values.stride(0), out.data_ptr(), W, L * W, D, 0 if given is not None else 1,
+                                           ctx.math, _lib.stream_ptr())
+        _lib.check(rc, "pit_posatt_pre_fwd")
+        ctx.n_head, ctx.head_param = n_head, head_param
+        ctx.save_for_backward(values, head, e, q, rowstat, scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        values, head, e, q, rowstat, scale = ctx.saved_tensors
+        n_head = ctx.n_head
+        b, L, D = values.shape
+        d_out = _row_view(d_out)
+        if d_out.dtype != torch.float32:
+            d_out = d_out.float()
+        need_v, need_h = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        dev = values.device
+        d_values = torch.empty((b, L, D), device=dev, dtype=torch.float32)
+        slot = _grad_slot(ctx.head_param) if need_h else None
+        defer = DEFER_HEAD_FINISH and slot is not None
+        work = None
+        if need_h:
+            if q is None:
+                raise RuntimeError("d(lmda) needs the d(scale) weights: block_weights(..., need_q=True)")
+            if defer:
+                work = _layer_workspace(slot, n_head)
+                _defer_head_begin(work)
+            else:
+                work = torch.zeros(n_head * 1024, device=dev, dtype=torch.float64)
+        rider = _dw_take(dev)                       # (a postponed MLP job: these launches carry nothing - run it now)
+        if rider is not None:
+            _dw_run(rider)
+        rc = _lib.lib().pit_posatt_pre_bwd(e.data_ptr(), _lib.ptr(q), rowstat.data_ptr(), L, n_head, D, b, values.data_ptr(),
+                                           values.stride(1), values.stride(0), d_out.data_ptr(), d_out.stride(1), d_out.stride(0),
+                                           D, d_values.data_ptr(), D, L * D, 1, _lib.ptr(work), ctx.math, _lib.stream_ptr())
+        _lib.check(rc, "pit_posatt_pre_bwd")
+        d_head = None
+        if need_h:
+            if defer:
+                _defer_head_finish(work, slot, head, scale, n_head, 1)
+            else:
+                d_head = slot if slot is not None else torch.empty((n_head,), device=dev, dtype=torch.float32)
+                one = lambda t: (ctypes.c_void_p * 1)(t.data_ptr())
+                _lib.check(_lib.lib().pit_posatt_dhead_finish(1, one(work), one(d_head), one(head), one(scale), (ctypes.c_int * 1)(n_head),
+                                                              (ctypes.c_int * 1)(1 if slot is not None else 0), _lib.stream_ptr()),
+                           "pit_posatt_dhead_finish")
+                if slot is not None:
+                    d_head = None
+        return (d_values if need_v else None), d_head, None, None, None, None, None, None, None
+
+
+@torch.compiler.disable
+def posatt_pre_apply(values: torch.Tensor, lmda: torch.Tensor, weights, layer: int, n_head: int) -> torch.Tensor:
+    """cat((values, conv), -1) of processor block ``layer`` from ``weights`` = block_weights(...)."""
+    E, Q, _inv, rowstat, scale, _heads = weights
+    out_buf = _concat_buffer_of(values, values.shape[1], n_head)
+    slot = [out_buf] if out_buf is not None else None
+    param = lmda if isinstance(lmda, torch.nn.Parameter) else None
+    return _PosAttPre.apply(values, lmda.reshape(-1), E[layer], Q[layer] if Q is not None else None, rowstat[layer], scale[layer],
+                            n_head, param, slot)
+
+
 # Round 4: the persistent latent kernels (csrc/pit_latent.hip) - the whole processor as ONE launch per direction when all
 # slab workgroups are co-resident (Darcy / Burgers at the scripts' batch 8: 128 + 128 workgroups).  Bit-identical to the
 # per-block launches and covered by the same tests, but OPT-IN (PIT_LATENT_FUSION=1 / ops.LATENT_FUSION = True): measured on

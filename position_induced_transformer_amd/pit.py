@@ -316,11 +316,35 @@ class pit(nn.Module):
         return ops.processor_apply(func_ltt, plan, heads, [a.lmda for a in self.conv],
                                    [(w.mlp1.weight, w.mlp1.bias, w.mlp2.weight, w.mlp2.bias) for w in self.mlp])
 
+    def _precomputed_weights(self, func_ltt, mesh_ltt):
+        """Large regime, batch-free meshes (round 4): the softmax weights of every block - functions of (mesh_ltt, lmda) only -
+        from ONE launch, read by the attention launches instead of re-formed in every workgroup.  None = not applicable."""
+        n = len(self.conv)
+        if not (ops.PRE_WEIGHTS and n and torch.is_tensor(mesh_ltt) and mesh_ltt.dim() == 2 and torch.is_tensor(func_ltt)
+                and func_ltt.is_cuda and func_ltt.dim() == 3 and func_ltt.dtype == torch.float32):
+            return None
+        hid, heads = func_ltt.shape[-1], self.conv[0].n_head
+        kinds = (posatt_fixed, posatt_periodic1d, posatt_periodic2d)
+        for a in self.conv:
+            if type(a) not in kinds or type(a) is not type(self.conv[0]) or a.locality != 1.0 or a.n_head != heads or a.in_dim != hid \
+                    or "forward" in a.__dict__ or a._forward_hooks or a._forward_pre_hooks or a._backward_hooks or a._backward_pre_hooks:
+                return None
+        if mesh_ltt.shape[0] != func_ltt.shape[1] or not ops.pre_weights_supported(mesh_ltt.shape[0], heads, hid, func_ltt.shape[0]):
+            return None
+        plan = self.conv[0]._plan(mesh_ltt, mesh_ltt, True)
+        need_q = torch.is_grad_enabled() and any(a.lmda.requires_grad for a in self.conv)
+        return ops.block_weights(plan, [a.lmda for a in self.conv], heads, need_q)
+
     def processor(self, func_ltt, mesh_ltt):
         fused = self._fused_processor(func_ltt, mesh_ltt)
         if fused is not None:
             return fused
+        weights = self._precomputed_weights(func_ltt, mesh_ltt)
         for i, (a, w) in enumerate(zip(self.conv, self.mlp)):
+            if weights is not None:
+                func_ltt = ops.posatt_pre_apply(func_ltt, a.lmda, weights, i, a.n_head)
+                func_ltt = self._mlp_gelu(w, func_ltt, self._heads_of_block(i + 1, self.hid_dim))
+                continue
             func_ltt = a(mesh_ltt, func_ltt)
             func_ltt = self._mlp_gelu(w, func_ltt, self._heads_of_block(i + 1, self.hid_dim))
         return func_ltt
