@@ -308,12 +308,14 @@ int slab_grid_size(int nslabs) {
 
 // eligibility of the slab kernels (pit_mlp.hip consults it above the small regime): hid 64, full output tile, K in whole
 // 16-steps, 16-B-aligned rows.  PIT_NO_SLAB_MLP=1: the two / three GEMM launches (A/B measurements).
-// (thin output layers - out_dim <= 4, the decoder MLP - run on the slab variants too: same-box A/B at Darcy b=256, 473 k rows,
-// 1.876 vs 1.890 ms per step against the GEMM + thin_* launches; PIT_NO_SLAB_THIN=1 for that form)
+// (thin output layers - out_dim <= 4, the decoder MLP - run on the slab variants only at very many rows: same-box A/B per step,
+// Darcy b=256 (473 k rows) 1.876 vs 1.890 ms, but b=64 0.710 vs 0.693, b=32 0.423 vs 0.407, b=16 0.288 vs 0.272 against the GEMM +
+// thin_* launches; PIT_NO_SLAB_THIN=1 for that form everywhere)
 bool pit_mlp_slab_eligible(int rows, int n0, int n1, int n2) {
     static const bool off = getenv("PIT_NO_SLAB_MLP") != nullptr;
     static const bool thin = getenv("PIT_NO_SLAB_THIN") == nullptr;
-    return !off && n1 == BD && (n2 == BD || (thin && n2 >= 1 && n2 <= 4)) && n0 % 16 == 0 && n0 >= 16 && n0 <= 256 && rows >= 4096;
+    const bool thin_ok = thin && n2 >= 1 && n2 <= 4 && rows >= 262144;
+    return !off && n1 == BD && (n2 == BD || thin_ok) && n0 % 16 == 0 && n0 >= 16 && n0 <= 256 && rows >= 4096;
 }
 // Do the slab kernels also replace the SMALL-regime fused kernels (mlp_fwd16 / mlp_bwd16: 16-row slabs, every workgroup
 // re-reading the weights)?  Measured: NO at the Darcy decoder MLP of batch 8 (14 792 rows = 232 slabs, one per compute unit:
