@@ -77,6 +77,13 @@ const char* pit_error_string(int code);
 #define PIT_IO_DX_BF16   0x400
 #define PIT_IO_OUT_BF16  0x800
 #define PIT_IO_DOUT_BF16 0x1000
+/* pit_posatt_fwd / pit_posatt_bwd, masked layers on candidate lists (round 4): OR-ed into math_mode, PIT_ATT_UNION asks for the
+ * UNION-TILE kernels - 64 consecutive rows contract against the union of their candidate keys (every key's value row
+ * fetched once per tile, MFMA contraction) instead of one wavefront per row gathering its own keys.  Exact for any input,
+ * fast when consecutive rows share their keys (grids, body-fitted meshes: a 64-row tile's union <= 128 keys); the caller
+ * decides per mesh plan.  Ignored where it does not apply (coordinate channels, self-attention concat, n_in > 4096).
+ * pit_posatt_bwd with this flag needs a dense d_values (ld_dvalues = dim, dvalues_bstride = n_in*dim); it is zeroed here. */
+#define PIT_ATT_UNION    0x2000
 /* 1 if pit_mlp_fwd / pit_mlp_bwd* of this shape accept PIT_IO_X_BF16 | PIT_IO_SAVE_BF16 | PIT_IO_DX_BF16 (thin output
  * layer n2 <= 4 without trailing gelu, large regime, widths multiples of 8) */
 int pit_mlp_bf16_io_supported(int rows, int n0, int n1, int n2, int out_gelu);

@@ -31,7 +31,7 @@ typedef short bf16x4 __attribute__((ext_vector_type(4)));
 extern thread_local int t_call_math;
 // (the low byte of the argument is the math mode, the PIT_IO_* storage flags above it are read by the entry point itself)
 #define PIT_ENTER_MATH(mode_) do { if (((mode_) & 0xff) != PIT_MATH_FP32 && ((mode_) & 0xff) != PIT_MATH_BF16) return PIT_ERR_UNSUPPORTED; \
-                                   if (((mode_) & ~0xff) && ((mode_) & 0xff) != PIT_MATH_BF16) return PIT_ERR_UNSUPPORTED;              \
+                                   if (((mode_) & ~0xff & ~PIT_ATT_UNION) && ((mode_) & 0xff) != PIT_MATH_BF16) return PIT_ERR_UNSUPPORTED; \
                                    t_call_math = ((mode_) & 0xff); } while (0)
 // bf16 storage (PIT_IO_*): a tensor kept as bf16 in memory is widened exactly (bits << 16), narrowed with RNE
 __device__ __forceinline__ float bf16_to_f(unsigned short b) { return __uint_as_float((unsigned)b << 16); }

@@ -2229,6 +2229,423 @@ __global__ __launch_bounds__(256) void posatt_sparse_bwd_dw_kernel(AttArgs a, Sp
     }
 }
 
+// ------------------------------------------------------------------------------------
+// Round 4: masked layers as UNION-TILE contractions (coherent row orderings: grids, body-fitted meshes).
+//
+// The candidate-list kernels above give a wavefront to every output row and gather the ~k value rows of its kept keys:
+// neighbouring rows of a mesh fetch the same few keys over and over (NACA decoder: 225 k rows x 16 keys x 512 B = 1.85 GB
+// of L2 gathers per launch, three launches per step).  Here ONE WAVEFRONT takes 16 CONSECUTIVE rows (the M of
+// v_mfma_f32_16x16x4_f32), four lanes per row, and works entirely on its own - no workgroup barrier anywhere:
+//   1. lane q of a row holds the row's candidates i = q, q + 4, ... and their squared distances in registers;
+//   2. the union of the 16 lists: an LDS bitmap over the keys, popcount scan, compacted to a sorted list (U keys, typically
+//      25-60 for 16-key rows); a candidate's position in the union = word base + popcount of the lower bits;
+//   3. the exact weights of every (row, candidate) pair - the same distance, threshold test and exp as sparse_rows_body -
+//      scattered into a dense 16 x U tile in LDS (zero where a key is not a row's candidate);
+//   4. MODE 0 / 1: out tile (16 rows x 128 columns per pass) = P (16 x U) V_union (U x 128), every union key's value row
+//      fetched ONCE per tile as 32-byte pieces per lane (column c of MFMA tile t = lane column * 8 + t, so a lane's eight
+//      accumulators are eight consecutive columns: float4 loads and stores);
+//      MODE 2: d(values)[union keys] += P^T (U x 16) dO (16 x 128), added to memory with fp32 atomics (the caller zeroes
+//      d_values; run-to-run the sums differ in the last bits - the host keeps the transposed-list kernel when
+//      torch.use_deterministic_algorithms is on).
+// Unions beyond UW_CH keys (incoherent orderings, overflowed lists) are walked in chunks: correct for any input, fast only
+// when neighbouring rows share their keys - the host decides per kind of mesh plan (ops.MeshPlan.union_tiles).
+// MFMA work = rows x U x columns instead of rows x k x columns of VALU FMAs, U / k ~ 2-3 for coherent meshes (a 64-row
+// tile's union is ~130 keys: the first version of this kernel spent 47 us of a 140 us launch in zero-padding).
+constexpr int UW_ROWS = 16, UW_CH = 64, UW_CB = 128;
+#ifndef UW_OCC
+#define UW_OCC 4      // wavefronts per SIMD the one-head kernels are compiled for (measured: 4 with 2-step fetch groups > 3 with 4)
+#endif
+#ifndef UW_FG
+#define UW_FG 2       // MFMA steps (of 4 keys) per fetch group; two groups in flight
+#endif
+typedef float f32x4u __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4u mfma_16x16x4_u(float a, float b, f32x4u c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+// LDS written by some lanes of a wavefront, read by others: the LDS pipeline is in order per wavefront, the compiler
+// must be told not to move accesses across
+#define PIT_WAVE_LDS_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); \
+                                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+
+// EPL: candidates per lane (four lanes per row): 8 for capacities <= 32, 16 for <= 64
+template <int NH, int MODE, int EPL>
+__global__ __launch_bounds__(256, NH == 1 ? UW_OCC : 1) void posatt_union_kernel(AttArgs a, SparseArgs sp, int cb_per_wave, int wave_lds_bytes) {
+    constexpr int PS = MODE == 2 ? 80 : 68;                           // P row stride (floats): conflict-free operand reads
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    char* mine = reinterpret_cast<char*>(lds) + (size_t)wave * wave_lds_bytes;
+    float* P = reinterpret_cast<float*>(mine);                        // [NH][16][PS]
+    unsigned* bm = reinterpret_cast<unsigned*>(P + NH * UW_ROWS * PS);     // [128] key bitmap, then [128] word bases
+    unsigned short* ulist = reinterpret_cast<unsigned short*>(bm + 256);   // [n_in] union keys (sorted)
+    const int r = lane & 15, q = lane >> 4;
+    const int mb = blockIdx.z, r0 = (blockIdx.y * 4 + wave) * UW_ROWS;
+    if (r0 >= a.n_out) return;                                        // (no workgroup barrier below)
+    const long rows_total = (long)a.mesh_batch * a.n_out;
+    const unsigned mo_bytes = (unsigned)((long)a.mesh_batch * a.n_out * a.sdim * 4);
+    const unsigned mi_bytes = (unsigned)((long)a.mesh_batch * a.n_in * a.sdim * 4);
+    const __amdgpu_buffer_rsrc_t rmo = make_rsrc(a.mesh_out, mo_bytes);
+    const __amdgpu_buffer_rsrc_t rmi = make_rsrc(a.mesh_in, mi_bytes);
+    const bool per = a.periodic != 0;
+    const int nwords = (a.n_in + 31) / 32;
+    float c[NH];
+#pragma unroll
+    for (int h = 0; h < NH; ++h) c[h] = a.head[h];                    // (the host passes the scale itself)
+    // ---- the row's constants, its candidates and their distances: registers for the rest of the kernel
+    const bool rvalid = r0 + r < a.n_out;
+    const long grow = (long)mb * a.n_out + (rvalid ? r0 + r : a.n_out - 1);
+    int jr[EPL];
+    {
+        // (the list slots are read before the count arrives - every slot below the capacity is addressable - and
+        // masked afterwards: one memory round trip instead of two)
+        const int* lst = sp.nbr_idx + grow * sp.cap;
+#pragma unroll
+        for (int t = 0; t < EPL; ++t) {
+            const int i = q + 4 * t;
+            jr[t] = i < sp.cap ? lst[i] : -1;
+        }
+    }
+    const int cnt = rvalid ? sp.nbr_cnt[grow] : 0;
+    const bool ovf = cnt > sp.cap;                                    // (an overflowed row scans every key, below)
+    const float4 xo = load_point4(rmo, mo_bytes, grow, a.sdim, a.coords_used);
+    float rc[NH][4];                                                  // {T, S_min, 1/rowsum, mbar}
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+        if (MODE == 0) {
+            rc[h][0] = quantile_lerp(__fmul_rn(c[h], a.stats[grow]), __fmul_rn(c[h], a.stats[rows_total + grow]), a.rank_w);
+            rc[h][1] = __fmul_rn(c[h], a.stats[2 * rows_total + grow]);
+            rc[h][2] = 0.0f; rc[h][3] = 0.0f;
+        } else {
+            const float4 rs4 = *reinterpret_cast<const float4*>(a.rowstat + (((long)mb * a.n_head + h) * a.n_out + (rvalid ? r0 + r : a.n_out - 1)) * 4);
+            rc[h][0] = rs4.x; rc[h][1] = rs4.y; rc[h][2] = rs4.z; rc[h][3] = rs4.w;
+        }
+    }
+    float mr[EPL];
+#pragma unroll
+    for (int t = 0; t < EPL; ++t) {
+        const unsigned j = (unsigned)jr[t] < (unsigned)a.n_in ? (unsigned)jr[t] : 0u;   // (slots past the count hold anything)
+        const float4 xi = load_point4(rmi, mi_bytes, (long)mb * a.n_in + j, a.sdim, a.coords_used);
+        mr[t] = sq_dist3(xo.x, xo.y, xo.z, xi.x, xi.y, xi.z, per, a.period);
+    }
+#pragma unroll
+    for (int t = 0; t < EPL; ++t)
+        if (ovf || q + 4 * t >= cnt) jr[t] = -1;
+    const bool any_ovf = __builtin_amdgcn_ballot_w64(ovf) != 0ull;
+    // ---- union of the 16 candidate lists
+    bm[lane] = 0u; bm[lane + 64] = 0u;
+    PIT_WAVE_LDS_SYNC();
+    if (any_ovf) {
+#pragma unroll
+        for (int w = lane; w < 128; w += 64) {
+            const int rem = a.n_in - 32 * w;
+            if (rem > 0) bm[w] = rem >= 32 ? 0xFFFFFFFFu : ((1u << rem) - 1u);
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < EPL; ++t)
+            if (jr[t] >= 0) atomicOr(&bm[jr[t] >> 5], 1u << (jr[t] & 31));
+    }
+    PIT_WAVE_LDS_SYNC();
+    int U;
+    {                                                                 // word bases: exclusive scan of the popcounts (<= 128 words)
+        const unsigned w0 = lane < nwords ? bm[lane] : 0u, w1 = lane + 64 < nwords ? bm[lane + 64] : 0u;
+        const int v0 = __popc(w0), v1 = __popc(w1);
+        int s0 = v0, s1 = v1;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t0 = __shfl_up(s0, o, 64), t1 = __shfl_up(s1, o, 64);
+            if (lane >= o) { s0 += t0; s1 += t1; }
+        }
+        const int tot0 = __shfl(s0, 63, 64), tot1 = __shfl(s1, 63, 64);
+        U = tot0 + tot1;
+        int b0 = s0 - v0, b1 = tot0 + s1 - v1;
+        bm[128 + lane] = (unsigned)b0; bm[192 + lane] = (unsigned)b1;
+        unsigned bits = w0;
+        while (bits) { const int t = __builtin_ctz(bits); bits &= bits - 1u; ulist[b0++] = (unsigned short)(32 * lane + t); }
+        bits = w1;
+        while (bits) { const int t = __builtin_ctz(bits); bits &= bits - 1u; ulist[b1++] = (unsigned short)(32 * (lane + 64) + t); }
+    }
+    PIT_WAVE_LDS_SYNC();
+    // a candidate's position in the union (kept in place of its key)
+#pragma unroll
+    for (int t = 0; t < EPL; ++t)
+        if (jr[t] >= 0) jr[t] = (int)bm[128 + (jr[t] >> 5)] + __popc(bm[jr[t] >> 5] & ((1u << (jr[t] & 31)) - 1u));
+    // one (row, key) weight per head from the squared distance m
+    auto weigh = [&](float m, int h) -> float {
+        const float sv = __fmul_rn(m, c[h]);
+        return sv <= rc[h][0] ? __expf(rc[h][1] - sv) : 0.0f;
+    };
+    auto dist_to = [&](int j) -> float {
+        const float4 xi = load_point4(rmi, mi_bytes, (long)mb * a.n_in + j, a.sdim, a.coords_used);
+        return sq_dist3(xo.x, xo.y, xo.z, xi.x, xi.y, xi.z, per, a.period);
+    };
+    float inv[NH];                                                    // MODE 0: 1 / row sum, on all four lanes of the row
+    if (MODE == 0) {
+        // ---- row sums (and sum p m for the backward's mbar): private partial sums of the row's four lanes, combined in a
+        //      fixed order - the same bits on every run
+        float ps[NH], pm[NH];
+#pragma unroll
+        for (int h = 0; h < NH; ++h) { ps[h] = 0.0f; pm[h] = 0.0f; }
+#pragma unroll
+        for (int t = 0; t < EPL; ++t) {
+            if (jr[t] < 0) continue;
+#pragma unroll
+            for (int h = 0; h < NH; ++h) { const float pv = weigh(mr[t], h); ps[h] += pv; pm[h] += pv * mr[t]; }
+        }
+        if (ovf)
+            for (int pos = q; pos < U; pos += 4) {
+                const float m = dist_to((int)ulist[pos]);
+#pragma unroll
+                for (int h = 0; h < NH; ++h) { const float pv = weigh(m, h); ps[h] += pv; pm[h] += pv * m; }
+            }
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+            ps[h] += __shfl_xor(ps[h], 16, 64); ps[h] += __shfl_xor(ps[h], 32, 64);
+            pm[h] += __shfl_xor(pm[h], 16, 64); pm[h] += __shfl_xor(pm[h], 32, 64);
+            inv[h] = ps[h] > 0.0f ? 1.0f / ps[h] : 0.0f;
+            if (q == 0 && blockIdx.x == 0 && rvalid)
+                *reinterpret_cast<float4*>(a.rowstat + (((long)mb * a.n_head + h) * a.n_out + r0 + r) * 4) =
+                    make_float4(rc[h][0], rc[h][1], inv[h], pm[h] * inv[h]);
+        }
+        if (a.scale_out && (blockIdx.x | blockIdx.y | blockIdx.z) == 0 && tid < NH)
+            a.scale_out[tid] = a.head[tid];                           // the backward reads the scale from here
+    }
+    // the weight tile of union positions [c0, c0 + UW_CH)
+    auto build = [&](int c0) {
+        PIT_WAVE_LDS_SYNC();                                          // (the previous chunk's operand reads are done)
+        for (int e = lane; e < NH * UW_ROWS * PS / 4; e += 64) reinterpret_cast<float4*>(P)[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+        PIT_WAVE_LDS_SYNC();
+        auto put = [&](float m, int pos) {
+#pragma unroll
+            for (int h = 0; h < NH; ++h) {
+                float pv = weigh(m, h);
+                if (MODE == 1) pv = pv * (m - rc[h][3]) * rc[h][2];
+                else if (MODE == 2) pv = pv * rc[h][2];
+                P[(h * UW_ROWS + r) * PS + pos] = pv;
+            }
+        };
+#pragma unroll
+        for (int t = 0; t < EPL; ++t) {
+            const int pos = jr[t] - c0;
+            if (jr[t] >= 0 && pos >= 0 && pos < UW_CH) put(mr[t], pos);
+        }
+        if (ovf) {
+            const int uc = min(UW_CH, U - c0);
+            for (int pos = q; pos < uc; pos += 4) put(dist_to((int)ulist[c0 + pos]), pos);
+        }
+        PIT_WAVE_LDS_SYNC();
+    };
+    const bool single = U <= UW_CH;
+    if (single) build(0);
+
+    if (MODE == 2) {
+        // ---- d(values)[key] += sum_h sum_rows P_h[row][key] dO_h[row]: the A operand is P^T (16 union positions x 4 rows per
+        //      MFMA), column c of tile t = 16 t + lane column (64-byte runs per atomic instruction)
+        const __amdgpu_buffer_rsrc_t rdo = make_rsrc(a.d_out, a.dout_bytes);
+        for (int cbi = 0; cbi < cb_per_wave; ++cbi) {
+            const int col0 = (blockIdx.x * cb_per_wave + cbi) * UW_CB;
+            if (col0 >= a.ncols) break;
+            unsigned dvo[8];                                          // d_values element offset of this lane's column in tile t
+            float dv[NH][4][8];                                       // d(out): rows 4 ks + q, this lane's columns
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const int col = col0 + 16 * t + r;
+                const bool cvalid = col < a.ncols;
+                int cb, cd;
+                col_split(a, cvalid ? col : 0, mb, cb, cd);
+                dvo[t] = cvalid ? (unsigned)((long)cb * a.dvalues_bstride + cd) : 0xFFFFFFFFu;
+#pragma unroll
+                for (int h = 0; h < NH; ++h) {
+                    const unsigned dbase = (unsigned)((long)cb * a.dout_bstride + a.out_col0 + (long)h * a.dim + cd);
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) {
+                        const int n = r0 + 4 * ks + q;
+                        dv[h][ks][t] = dout_load(rdo, (cvalid && n < a.n_out) ? dbase + (unsigned)n * (unsigned)a.ld_dout : a.dout_elems, a.dout16);
+                    }
+                }
+            }
+            for (int c0 = 0; c0 < U; c0 += UW_CH) {
+                if (!single) build(c0);
+                const int uc = min(UW_CH, U - c0);
+                for (int kb = 0; kb * 16 < uc; ++kb) {
+                    f32x4u acc[8];
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) acc[t] = f32x4u{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int h = 0; h < NH; ++h)
+#pragma unroll
+                        for (int ks = 0; ks < 4; ++ks) {
+                            const float av = P[(h * UW_ROWS + 4 * ks + q) * PS + kb * 16 + r];
+#pragma unroll
+                            for (int t = 0; t < 8; ++t) acc[t] = mfma_16x16x4_u(av, dv[h][ks][t], acc[t]);
+                        }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int pos = kb * 16 + 4 * q + i;
+                        if (pos >= uc) continue;
+                        float* grow_ = a.d_values + (long)ulist[c0 + pos] * a.ld_dvalues;
+#pragma unroll
+                        for (int t = 0; t < 8; ++t)
+                            if (dvo[t] != 0xFFFFFFFFu) atomicAdd(grow_ + dvo[t], acc[t][i]);
+                    }
+                }
+            }
+        }
+        return;
+    }
+    // ---- MODE 0 / 1: out tile = P V_union, the value rows of the union fetched 16 keys ahead of the MFMAs
+    const __amdgpu_buffer_rsrc_t rvals = make_rsrc(a.values, a.values_bytes);
+    const unsigned ld4 = (unsigned)a.ld_values * 4u;
+    for (int cbi = 0; cbi < cb_per_wave; ++cbi) {
+        const int col0 = (blockIdx.x * cb_per_wave + cbi) * UW_CB;
+        if (col0 >= a.ncols) break;
+        const int col = col0 + 8 * r;                                 // this lane's eight consecutive columns (dim % 8 == 0)
+        const bool cvalid = col < a.ncols;
+        int cb, cd;
+        col_split(a, cvalid ? col : 0, mb, cb, cd);
+        const unsigned uoff = (unsigned)(((long)cb * a.values_bstride + cd) * 4);
+        f32x4u acc[NH][8];
+#pragma unroll
+        for (int h = 0; h < NH; ++h)
+#pragma unroll
+            for (int t = 0; t < 8; ++t) acc[h][t] = f32x4u{0.f, 0.f, 0.f, 0.f};
+        for (int c0 = 0; c0 < U; c0 += UW_CH) {
+            if (!single) build(c0);
+            const int uc = min(UW_CH, U - c0);
+            const int nst = (uc + 3) >> 2;                            // steps of 4 keys
+            auto fetch = [&](int s0, float (&bv)[UW_FG][8]) {
+#pragma unroll
+                for (int g = 0; g < UW_FG; ++g) {
+                    const int k = 4 * (s0 + g) + q;
+                    const unsigned key = (unsigned)ulist[c0 + (k < uc ? k : 0)];
+                    const unsigned off = (cvalid && k < uc) ? uoff + key * ld4 : a.values_bytes;
+                    float lo[4], hi[4];
+                    buf_load4(rvals, off, lo);
+                    buf_load4(rvals, (cvalid && k < uc) ? off + 16u : a.values_bytes, hi);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) { bv[g][t] = lo[t]; bv[g][4 + t] = hi[t]; }
+                }
+            };
+            auto mma = [&](int s0, const float (&bv)[UW_FG][8]) {
+#pragma unroll
+                for (int g = 0; g < UW_FG; ++g) {
+                    if (s0 + g >= nst) break;
+#pragma unroll
+                    for (int h = 0; h < NH; ++h) {
+                        const float av = P[(h * UW_ROWS + r) * PS + 4 * (s0 + g) + q];
+#pragma unroll
+                        for (int t = 0; t < 8; ++t) acc[h][t] = mfma_16x16x4_u(av, bv[g][t], acc[h][t]);
+                    }
+                }
+            };
+            float b0[UW_FG][8], b1[UW_FG][8];
+            fetch(0, b0);
+            for (int s0 = 0; s0 < nst; s0 += 2 * UW_FG) {
+                if (s0 + UW_FG < nst) fetch(s0 + UW_FG, b1);
+                mma(s0, b0);
+                if (s0 + UW_FG < nst) {
+                    if (s0 + 2 * UW_FG < nst) fetch(s0 + 2 * UW_FG, b0);
+                    mma(s0 + UW_FG, b1);
+                }
+            }
+        }
+        // accumulator i of every tile = row 4 q + i, columns cd .. cd + 7 of head h
+        if (MODE == 1) {
+            const __amdgpu_buffer_rsrc_t rdo = make_rsrc(a.d_out, a.dout_bytes);
+#pragma unroll
+            for (int h = 0; h < NH; ++h) {
+                double part = 0.0;
+                const unsigned dbase = (unsigned)((long)cb * a.dout_bstride + a.out_col0 + (long)h * a.dim + cd);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int n = r0 + 4 * q + i;
+                    const bool ok = cvalid && n < a.n_out;
+                    const unsigned e = dbase + (unsigned)n * (unsigned)a.ld_dout;
+                    float dv[8];
+                    if (a.dout16) {
+                        const i32x4 w = __builtin_amdgcn_raw_buffer_load_b128(rdo, ok ? (int)(e * 2u) : (int)a.dout_bytes, 0, 0);
+                        const unsigned ww[4] = {(unsigned)w.x, (unsigned)w.y, (unsigned)w.z, (unsigned)w.w};
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) { dv[2 * t] = __uint_as_float(ww[t] << 16); dv[2 * t + 1] = __uint_as_float(ww[t] & 0xFFFF0000u); }
+                    } else {
+                        float lo[4], hi[4];
+                        buf_load4(rdo, ok ? e * 4u : a.dout_bytes, lo);
+                        buf_load4(rdo, ok ? e * 4u + 16u : a.dout_bytes, hi);
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) { dv[t] = lo[t]; dv[4 + t] = hi[t]; }
+                    }
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) part += (double)acc[h][t][i] * (double)dv[t];
+                }
+                part = wave_sum_d(part);
+                const int slot = (int)((blockIdx.y * 4u + wave + 131u * blockIdx.x + 31u * cbi) & (a.nslots - 1));
+                dscale_add(a.dscale_acc + h * PIT_DSCALE_SLOTS + slot, -part, lane == 0);
+            }
+            continue;
+        }
+#pragma unroll
+        for (int h = 0; h < NH; ++h)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int n = r0 + 4 * q + i;
+                const float rinv = __shfl(inv[h], 4 * q + i, 64);       // (lane `row` is the row's q = 0 lane)
+                if (!cvalid || n >= a.n_out) continue;
+                float v[8];
+#pragma unroll
+                for (int t = 0; t < 8; ++t) v[t] = acc[h][t][i] * rinv;
+                const long o = (long)cb * a.out_bstride + (long)n * a.ld_out + a.out_col0 + (long)h * a.dim + cd;
+                if (a.out16) {
+                    uint4 w;
+                    w.x = (unsigned)f_to_bf16(v[0]) | ((unsigned)f_to_bf16(v[1]) << 16);
+                    w.y = (unsigned)f_to_bf16(v[2]) | ((unsigned)f_to_bf16(v[3]) << 16);
+                    w.z = (unsigned)f_to_bf16(v[4]) | ((unsigned)f_to_bf16(v[5]) << 16);
+                    w.w = (unsigned)f_to_bf16(v[6]) | ((unsigned)f_to_bf16(v[7]) << 16);
+                    *reinterpret_cast<uint4*>(reinterpret_cast<unsigned short*>(a.out) + o) = w;
+                } else {
+                    *reinterpret_cast<float4*>(a.out + o) = make_float4(v[0], v[1], v[2], v[3]);
+                    *reinterpret_cast<float4*>(a.out + o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                }
+            }
+    }
+}
+
+__global__ __launch_bounds__(256) void zero_f32_kernel(float* __restrict__ p, long n) {
+    for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (long)gridDim.x * 1024) {
+        if (i + 4 <= n) *reinterpret_cast<float4*>(p + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+        else for (long k = i; k < n; ++k) p[k] = 0.0f;
+    }
+}
+
+// LDS bytes of one wavefront of posatt_union_kernel
+int union_wave_lds(int nh, int n_in) {
+    return (int)((nh * UW_ROWS * 80 * sizeof(float) + 256 * sizeof(unsigned) + (size_t)n_in * sizeof(unsigned short) + 15) & ~(size_t)15);
+}
+// does the shape qualify?  (the caller made sure a.head holds the scales: head_is_scale)  Eight consecutive columns per lane:
+// 16-byte loads and stores of the value / output rows.
+bool union_ok(const AttArgs& a, const SparseArgs& sp) {
+    return a.masked && sp.nbr_idx && sp.nbr_cnt && a.n_in <= 4096 && a.n_head <= 2 && a.coord_dims == 0 && sp.cap <= 64 &&
+           a.n_out >= 16 && a.dim % 8 == 0 && a.ld_values % 4 == 0 && a.values_bstride % 4 == 0 &&
+           (reinterpret_cast<uintptr_t>(a.values) & 15) == 0 && !env_int("PIT_NO_UNION_TILES");
+}
+bool aligned_rows(const void* p, long ld, long bstride, int col0, int elems16) {   // 16-byte pieces of `elems16` elements
+    return (reinterpret_cast<uintptr_t>(p) & 15) == 0 && ld % elems16 == 0 && bstride % elems16 == 0 && col0 % elems16 == 0;
+}
+template <int MODE>
+void launch_union(const AttArgs& a, const SparseArgs& sp, hipStream_t s) {
+    const int ncb = (a.ncols + UW_CB - 1) / UW_CB;
+    const int rtiles = (a.n_out + UW_ROWS - 1) / UW_ROWS;
+    // column passes per wavefront: the tile's weights are built once per wavefront - as many passes as keep >= 16 wavefronts per CU
+    int per = 1;
+    while (per < ncb && (long)rtiles * a.mesh_batch * ((ncb + 2 * per - 1) / (2 * per)) >= 4096) per *= 2;
+    dim3 grid((unsigned)((ncb + per - 1) / per), (unsigned)((rtiles + 3) / 4), (unsigned)a.mesh_batch), block(256);
+    const int wl = union_wave_lds(a.n_head, a.n_in);
+#define PIT_UN(NH_, EPL_) do {                                                                                             \
+        static bool once = ((void)hipFuncSetAttribute((const void*)posatt_union_kernel<NH_, MODE, EPL_>,                   \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, 98304), true);                 \
+        (void)once;                                                                                                        \
+        hipLaunchKernelGGL((posatt_union_kernel<NH_, MODE, EPL_>), grid, block, (size_t)4 * wl, s, a, sp, per, wl); } while (0)
+    if (a.n_head == 2) { if (sp.cap <= 32) PIT_UN(2, 8); else PIT_UN(2, 16); }
+    else               { if (sp.cap <= 32) PIT_UN(1, 8); else PIT_UN(1, 16); }
+#undef PIT_UN
+}
+
 // columns per lane: as many as the column count allows, fewer when the launch would otherwise
 // have too few wavefronts to hide the gather latency (one wave = one row / key)
 int cr_for(int ncols, long units) {
@@ -2542,9 +2959,22 @@ extern "C" int pit_posatt_fwd(const float* mesh_out, const float* mesh_in, int m
     a.stats = stats; a.rank_w = rank_w; a.masked = masked;
     a.out = out; a.ld_out = ld_out; a.out_bstride = out_bstride; a.out_col0 = out_col0; a.copy_inputs = copy_inputs;
     a.rowstat = rowstat; a.scale_out = scale_out;
-    if (math_mode & ~(0xff | PIT_IO_OUT_BF16)) return PIT_ERR_UNSUPPORTED;
     a.out16 = (math_mode & PIT_IO_OUT_BF16) ? 1 : 0;
     if (a.out16 && (copy_inputs || !(nbr_idx && nbr_cnt && masked))) return PIT_ERR_UNSUPPORTED;   // candidate-list kernels only
+    if (math_mode & ~(0xff | PIT_IO_OUT_BF16 | PIT_ATT_UNION)) return PIT_ERR_UNSUPPORTED;
+    if (nbr_idx && nbr_cnt && masked && (math_mode & PIT_ATT_UNION) && !copy_inputs && (head_is_scale || scale_out)) {
+        SparseArgs spu{nbr_idx, nbr_cnt, nbr_cap, nullptr, nullptr, 0};
+        if (union_ok(a, spu) && aligned_rows(out, ld_out, out_bstride, out_col0, a.out16 ? 8 : 4)) {   // coherent row ordering (the caller's plan says so): union tiles
+            if (!head_is_scale) {
+                if (int rc2 = pit_head_scale(head, n_head, scale_out, stream)) return rc2;
+                a.head = scale_out; a.head_is_scale = 1;
+                a.scale_out = nullptr;
+            }
+            launch_union<0>(a, spu, (hipStream_t)stream);
+            PIT_CHECK_LAUNCH();
+            return 0;
+        }
+    }
     if (nbr_idx && nbr_cnt && masked) {
         SparseArgs sp{nbr_idx, nbr_cnt, nbr_cap, nullptr, nullptr, 0};
         if (!head_is_scale && scale_out && (long)mesh_batch * n_out > 8192) {
@@ -2598,7 +3028,7 @@ extern "C" int pit_posatt_bwd(const float* mesh_out, const float* mesh_in, int m
     a.d_out = d_out; a.ld_dout = ld_dout; a.dout_bstride = dout_bstride; a.out_col0 = out_col0;
     a.d_values = d_values; a.ld_dvalues = ld_dvalues; a.dvalues_bstride = dvalues_bstride;
     a.add_residual = add_residual; a.dscale_acc = workspace;
-    if (math_mode & ~(0xff | PIT_IO_DOUT_BF16)) return PIT_ERR_UNSUPPORTED;
+    if (math_mode & ~(0xff | PIT_IO_DOUT_BF16 | PIT_ATT_UNION)) return PIT_ERR_UNSUPPORTED;
     a.dout16 = (math_mode & PIT_IO_DOUT_BF16) ? 1 : 0;
     {
         const int width = out_col0 + n_head * dim;
@@ -2613,6 +3043,35 @@ extern "C" int pit_posatt_bwd(const float* mesh_out, const float* mesh_in, int m
                      dout_bstride % 2 || (reinterpret_cast<uintptr_t>(d_out) & 3)))
         return PIT_ERR_UNSUPPORTED;                             // candidate-list kernels only, column pairs
     SparseArgs sp{nbr_idx, nbr_cnt, nbr_cap, rev_ptr, rev_row, (long)n_out * nbr_cap};
+    if (sparse && (math_mode & PIT_ATT_UNION) && !add_residual && a.head_is_scale && union_ok(a, sp) &&
+        aligned_rows(d_out, ld_dout, dout_bstride, out_col0, a.dout16 ? 8 : 4) &&
+        (!d_values || (ld_dvalues == dim && dvalues_bstride == (long)n_in * dim))) {
+        // union tiles (coherent row ordering): d(scale) as a dense contraction over each 16-row tile's union of keys
+        if (d_head) {
+            a.d_head = d_head; a.dhead_src = head; a.dhead_is_scale = head_is_scale;
+            a.accumulate_head = (accumulate_head & PIT_HEAD_ACCUMULATE) ? 1 : 0;
+            a.nslots = PIT_DSCALE_SLOTS;
+            launch_union<1>(a, sp, s);
+            PIT_CHECK_LAUNCH();
+            if (!(accumulate_head & PIT_HEAD_DEFER)) {
+                hipLaunchKernelGGL(posatt_dhead_finish, dim3(n_head), dim3(256), 0, s, a);
+                PIT_CHECK_LAUNCH();
+            }
+        }
+        if (d_values && rev_ptr && rev_row) {
+            // d(values) from the transposed lists: measured faster than the tiles' fp32 atomics (191 + 19 vs 303 us on a
+            // NACA-shaped decoder layer - 86 M atomic adds at device scope) and the same bits on every run
+            launch_sparse_cols(a, sp, nbr_complete != 0, s);
+            PIT_CHECK_LAUNCH();
+        } else if (d_values) {
+            const long nv = (long)batch * n_in * dim;
+            hipLaunchKernelGGL(zero_f32_kernel, dim3((unsigned)std::min<long>((nv + 1023) / 1024, 2048L)), dim3(256), 0, s, d_values, nv);
+            PIT_CHECK_LAUNCH();
+            launch_union<2>(a, sp, s);
+            PIT_CHECK_LAUNCH();
+        }
+        return rd.finish();
+    }
     if (d_head) {
         a.d_head = d_head; a.dhead_src = head; a.dhead_is_scale = head_is_scale;
         a.accumulate_head = (accumulate_head & PIT_HEAD_ACCUMULATE) ? 1 : 0;

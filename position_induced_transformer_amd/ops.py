@@ -435,6 +435,11 @@ def mesh_period(metric: str, mesh_in: torch.Tensor) -> float:
     return 0.0
 
 
+UNION_TILES = os.environ.get("PIT_UNION_TILES", "auto")      # "auto" (probe per kind of plan), "0", "1"
+_UNION_DECISIONS = {}
+ATT_UNION = 0x2000                                           # PIT_ATT_UNION
+
+
 class MeshPlan:
     """Everything about a (mesh_out, mesh_in, metric, locality) pair that does not depend on
     lmda: contiguous 3-d meshes, period, quantile rank and the selection statistics
@@ -442,7 +447,7 @@ class MeshPlan:
 
     __slots__ = ("mesh_out", "mesh_in", "mesh_batch", "n_out", "n_in", "sdim", "metric", "metric_id", "period",
                  "rank_k", "rank_w", "masked", "self_attn", "stats", "nbr_idx", "nbr_cnt", "nbr_cap", "rev_ptr",
-                 "rev_row", "_complete")
+                 "rev_row", "_complete", "_union")
 
     def __init__(self, metric: str, mesh_out: torch.Tensor, mesh_in: torch.Tensor, locality: float,
                  self_attn: bool, period: Optional[float] = None):
@@ -474,6 +479,7 @@ class MeshPlan:
         self.nbr_idx = self.nbr_cnt = self.rev_ptr = self.rev_row = None
         self.nbr_cap = 0
         self._complete = None
+        self._union = None
         cap = 0
         if self.masked and SPARSE_MASKED:
             want = self.rank_k + 2
@@ -490,6 +496,44 @@ class MeshPlan:
                                            self.rank_k, 1 if self.masked else 0, self.stats.data_ptr(),
                                            _lib.stream_ptr())
             _lib.check(rc, "pit_select_fwd")
+
+    def union_tiles(self) -> bool:
+        """Round 4: do the masked-layer kernels take the UNION-TILE form (PIT_ATT_UNION) for this plan?  They contract 16
+        consecutive rows against the union of their candidate keys: fast when neighbouring rows share their keys (grids,
+        body-fitted meshes), slow for incoherent orderings (random clouds) - never wrong.  Decided ONCE per kind of plan
+        (metric, sizes, capacity, batched or not) from 32 sampled tiles of the first plan of that kind built outside a
+        stream capture (the probe synchronises); plans built under capture before any probe keep the per-row kernels."""
+        if self._union is not None:
+            return self._union
+        # (meshes shared by the batch: the per-row kernels already stream batch x dim wide rows at the HBM rate - measured)
+        if self.nbr_idx is None or UNION_TILES == "0" or self.n_in > 4096 or self.n_out < 16 or self.nbr_cap > 64 \
+                or (self.mesh_batch == 1 and UNION_TILES != "1"):
+            self._union = False
+            return False
+        if UNION_TILES == "1":
+            self._union = True
+            return True
+        key = (self.metric, self.n_out, self.n_in, self.nbr_cap, self.mesh_batch > 1, self.sdim)
+        hit = _UNION_DECISIONS.get(key)
+        if hit is None:
+            if torch.cuda.is_current_stream_capturing():
+                return False                             # (not cached: a later eager plan of this kind may still probe)
+            # 32 tiles of 16 consecutive rows of the first sample: sizes of the unions of their candidate lists
+            cap, tiles = self.nbr_cap, min(32, self.n_out // 16)
+            first = (torch.linspace(0, self.n_out // 16 - 1, tiles).long() * 16).to(self.nbr_idx.device)
+            rows = (first[:, None] + torch.arange(16, device=first.device)[None, :]).reshape(-1)
+            idx = self.nbr_idx.view(-1, cap)[rows].long()
+            cnt = self.nbr_cnt[rows].long()
+            keys = torch.where(torch.arange(cap, device=first.device)[None, :] < cnt[:, None], idx, -1).view(tiles, 16 * cap)
+            srt = torch.sort(keys, dim=1).values
+            union = (srt[:, 1:] != srt[:, :-1]).sum(1) + 1 - (srt[:, 0] < 0).long()
+            mean_u, mean_k, over = (float(v) for v in torch.stack(
+                [union.float().mean(), cnt.float().mean(), (cnt > cap).float().max()]).tolist())
+            # MFMA work ~ union size, the per-row kernels' ~ list length; one chunk of the kernel holds 64 union keys
+            hit = over == 0.0 and mean_u <= min(64.0, 4.0 * mean_k)
+            _UNION_DECISIONS[key] = hit
+        self._union = hit
+        return hit
 
     def lists_complete(self) -> int:
         """1 if no row's candidate list overflowed its capacity (checked once, for batch-free meshes
@@ -540,6 +584,9 @@ class _PosAtt(torch.autograd.Function):
         ctx.math = _math_code()
         out_bf16 = bool(out_bf16 and not concat and plan.nbr_idx is not None and ctx.math == MATH_MODES["bf16"])
         ctx.coord_dims = int(coord_dims)
+        # masked layer over a coherently ordered mesh: the union-tile kernels (decided per kind of plan, MeshPlan.union_tiles)
+        ctx.union = ATT_UNION if (plan.masked and plan.nbr_idx is not None and not coord_dims and n_head <= 2
+                                  and plan.union_tiles()) else 0
         # (the concat buffer arrives in a one-element list, not as a tensor argument: a tensor that is both an
         # input and the returned output would be re-materialised by autograd with a full copy)
         out_buf = out_slot[0].detach() if out_slot else None
@@ -576,7 +623,7 @@ class _PosAtt(torch.autograd.Function):
             out.data_ptr(), out.stride(1), out.stride(0), d if concat else 0, copy_inputs,
             rowstat.data_ptr(), scale.data_ptr(),
             _lib.ptr(plan.nbr_idx), _lib.ptr(plan.nbr_cnt), plan.nbr_cap, ctx.coord_dims,
-            ctx.math | (IO_OUT_BF16 if out_bf16 else 0), _lib.stream_ptr())
+            ctx.math | (IO_OUT_BF16 if out_bf16 else 0) | ctx.union, _lib.stream_ptr())
         _lib.check(rc, "pit_posatt_fwd")
         ctx.plan, ctx.n_head, ctx.concat, ctx.head_is_scale = plan, n_head, concat, head_is_scale
         ctx.head_param = head_param
@@ -627,7 +674,7 @@ class _PosAtt(torch.autograd.Function):
                 _lib.ptr(plan.nbr_idx), _lib.ptr(plan.nbr_cnt), plan.nbr_cap, plan.lists_complete(),
                 _lib.ptr(plan.rev_ptr), _lib.ptr(plan.rev_row),
                 ctypes.cast(ctypes.pointer(job[0]), ctypes.c_void_p) if job is not None else None,
-                ctx.coord_dims, ctx.math | io, stream_ptr)
+                ctx.coord_dims, ctx.math | io | ctx.union, stream_ptr)
             _lib.check(rc, "pit_posatt_bwd")
 
         if OVERLAP_BACKWARD and slot is not None:

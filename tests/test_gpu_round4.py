@@ -233,3 +233,90 @@ def test_processor_deeper_than_sixteen_blocks_runs_block_by_block():
     ml = [tuple(t.detach().cpu() for t in (w.mlp1.weight, w.mlp1.bias, w.mlp2.weight, w.mlp2.bias)) for w in model.mlp]
     ref = _oracle_processor("euclid", mesh, x, lm, ml)
     assert gio.rel_l2(out.cpu().numpy(), ref.numpy()) <= 1e-5
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# union-tile kernels for masked layers over coherently ordered per-sample meshes (csrc/pit_posatt.hip posatt_union_kernel)
+
+def _grid_meshes(batch, nx, ny, n_in, seed, jitter=0.004):
+    """Per-sample body-fitted-like meshes: a jittered nx x ny grid (row-major: neighbouring rows are neighbours in space)
+    and n_in of its points as the keys."""
+    g = torch.Generator().manual_seed(seed)
+    gx, gy = torch.meshgrid(torch.linspace(0, 1, nx), torch.linspace(0, 1, ny), indexing="ij")
+    base = torch.stack([gx.reshape(-1), gy.reshape(-1)], -1)
+    mo = base[None] + jitter * torch.randn(batch, nx * ny, 2, generator=g)
+    sel = torch.linspace(0, nx * ny - 1, n_in).long()
+    return mo.contiguous(), mo[:, sel].contiguous()
+
+
+@pytest.mark.parametrize("d_values_by", ["transposed-lists", "tile-atomics"])
+@pytest.mark.parametrize("shape", [(3, 37, 19, 150, 32, 1, 0.06), (2, 50, 31, 300, 64, 2, 0.03), (2, 33, 16, 97, 8, 1, 0.12),
+                                   (1, 40, 40, 200, 128, 2, 0.05)],
+                         ids=["h1-dim32", "h2-dim64", "h1-dim8-ragged", "h2-dim128-one-sample"])
+def test_union_tile_kernels_against_the_oracle(shape, d_values_by):
+    """Forward, d(values) and d(lmda) of a masked cross-attention layer on the union-tile kernels vs oracle/pit_oracle.py
+    (fp64-free: the oracle's fp32 torch ops), tolerances of the candidate-list kernels."""
+    from position_induced_transformer_amd import ops
+    b, nx, ny, n_in, dim, nh, loc = shape
+    mo, mi = _grid_meshes(b, nx, ny, n_in, seed=11)
+    g = torch.Generator().manual_seed(12)
+    values = torch.randn(b, n_in, dim, generator=g)
+    lmda = (torch.rand(nh, 1, 1, generator=g) - 0.5) * 2.0
+    d_out = torch.randn(b, nx * ny, nh * dim, generator=g)
+    v0 = values.clone().requires_grad_(True); l0 = lmda.clone().requires_grad_(True)
+    ref = orc.posatt_cross("euclid", True, mo, mi, v0, l0, loc)
+    ref.backward(d_out)
+    old, ops.UNION_TILES = ops.UNION_TILES, "1"
+    try:
+        plan = ops.MeshPlan("euclid", mo.cuda(), mi.cuda(), loc, False)
+        assert plan.nbr_idx is not None and plan.union_tiles()
+        if d_values_by == "tile-atomics":
+            plan.rev_ptr = plan.rev_row = None                 # no transposed lists: d(values) by the tiles' atomic adds
+        v1 = values.cuda().requires_grad_(True); l1 = lmda.cuda().reshape(-1).requires_grad_(True)
+        out = ops.posatt_apply(v1, l1, plan, nh, concat=False, head_is_scale=False)
+        out.backward(d_out.cuda())
+    finally:
+        ops.UNION_TILES = old
+    rel = lambda a, r: float((a.double().cpu() - r.double()).norm() / r.double().norm())
+    assert rel(out.detach(), ref.detach()) <= 1e-6
+    assert rel(v1.grad, v0.grad) <= 1e-5
+    assert rel(l1.grad.reshape(-1), l0.grad.reshape(-1)) <= 1e-4
+
+
+def test_union_tile_forward_is_the_same_bits_on_every_run_and_handles_overflowed_lists():
+    """Deterministic row sums (fixed combination order), and a tile with rows whose candidate list overflowed (duplicated
+    key points: ties beyond the capacity) scans every key - the same results as the candidate-list kernels."""
+    from position_induced_transformer_amd import ops
+    mo, mi = _grid_meshes(2, 40, 20, 160, seed=3)
+    mi[:, 40:120] = mi[:, 40:41]                                # 80 coincident keys: every row near them overflows
+    g = torch.Generator().manual_seed(4)
+    values = torch.randn(2, 160, 32, generator=g).cuda()
+    c = torch.tensor([14.0], device="cuda")
+    outs = {}
+    for mode in ("0", "1"):
+        old, ops.UNION_TILES = ops.UNION_TILES, mode
+        try:
+            plan = ops.MeshPlan("euclid", mo.cuda(), mi.cuda(), 0.1, False)
+            assert bool((plan.nbr_cnt > plan.nbr_cap).any())
+            outs[mode] = [ops.posatt_apply(values, c, plan, 1, concat=False, head_is_scale=True).clone() for _ in range(3)]
+        finally:
+            ops.UNION_TILES = old
+    assert torch.equal(outs["1"][0], outs["1"][1]) and torch.equal(outs["1"][0], outs["1"][2])
+    assert float((outs["1"][0] - outs["0"][0]).norm() / outs["0"][0].norm()) <= 1e-6
+
+
+def test_union_tile_decision_is_made_per_kind_of_plan_and_never_for_shared_meshes():
+    from position_induced_transformer_amd import ops
+    old, ops.UNION_TILES = ops.UNION_TILES, "auto"
+    try:
+        ops._UNION_DECISIONS.clear()
+        mo, mi = _grid_meshes(2, 40, 40, 200, seed=5)
+        assert ops.MeshPlan("euclid", mo.cuda(), mi.cuda(), 0.05, False).union_tiles()           # coherent ordering
+        perm = torch.randperm(1600, generator=torch.Generator().manual_seed(6))
+        ops._UNION_DECISIONS.clear()
+        assert not ops.MeshPlan("euclid", mo[:, perm].contiguous().cuda(), mi.cuda(), 0.05, False).union_tiles()   # shuffled rows
+        ops._UNION_DECISIONS.clear()
+        assert not ops.MeshPlan("euclid", mo[0].cuda(), mi[0].cuda(), 0.05, False).union_tiles()  # one mesh for the batch
+    finally:
+        ops.UNION_TILES = old
+        ops._UNION_DECISIONS.clear()
