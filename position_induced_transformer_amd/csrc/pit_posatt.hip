@@ -2265,162 +2265,139 @@ __device__ __forceinline__ f32x4u mfma_16x16x4_u(float a, float b, f32x4u c) { r
 #define PIT_WAVE_LDS_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); \
                                  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 
+// One wavefront's 16-row tile: the registers and the wave-private LDS of steps 1-3 above.
 // EPL: candidates per lane (four lanes per row): 8 for capacities <= 32, 16 for <= 64
 template <int NH, int MODE, int EPL>
-__global__ __launch_bounds__(256, NH == 1 ? UW_OCC : 1) void posatt_union_kernel(AttArgs a, SparseArgs sp, int cb_per_wave, int wave_lds_bytes) {
-    constexpr int PS = MODE == 2 ? 80 : 68;                           // P row stride (floats): conflict-free operand reads
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    char* mine = reinterpret_cast<char*>(lds) + (size_t)wave * wave_lds_bytes;
-    float* P = reinterpret_cast<float*>(mine);                        // [NH][16][PS]
-    unsigned* bm = reinterpret_cast<unsigned*>(P + NH * UW_ROWS * PS);     // [128] key bitmap, then [128] word bases
-    unsigned short* ulist = reinterpret_cast<unsigned short*>(bm + 256);   // [n_in] union keys (sorted)
-    const int r = lane & 15, q = lane >> 4;
-    const int mb = blockIdx.z, r0 = (blockIdx.y * 4 + wave) * UW_ROWS;
-    if (r0 >= a.n_out) return;                                        // (no workgroup barrier below)
-    const long rows_total = (long)a.mesh_batch * a.n_out;
-    const unsigned mo_bytes = (unsigned)((long)a.mesh_batch * a.n_out * a.sdim * 4);
-    const unsigned mi_bytes = (unsigned)((long)a.mesh_batch * a.n_in * a.sdim * 4);
-    const __amdgpu_buffer_rsrc_t rmo = make_rsrc(a.mesh_out, mo_bytes);
-    const __amdgpu_buffer_rsrc_t rmi = make_rsrc(a.mesh_in, mi_bytes);
-    const bool per = a.periodic != 0;
-    const int nwords = (a.n_in + 31) / 32;
-    float c[NH];
+struct UnionTile {
+    static constexpr int PS = 68;                                     // P row stride (floats): conflict-free operand reads
+    const AttArgs& a; const SparseArgs& sp;
+    float* P;                                                         // [NH][16][PS]
+    unsigned* bm;                                                     // [128] key bitmap, then [128] word bases
+    unsigned short* ulist;                                            // [n_in] union keys (sorted)
+    int lane, r, q, mb, r0, U;
+    bool rvalid, ovf;
+    unsigned mi_bytes;
+    __amdgpu_buffer_rsrc_t rmi;
+    float4 xo;
+    float c[NH], rc[NH][4];                                           // scale; per row {T, S_min, 1/rowsum, mbar}
+    int jr[EPL];                                                      // candidate keys, then their union positions (-1: none)
+    float mr[EPL];                                                    // their squared distances
+
+    __device__ __forceinline__ UnionTile(const AttArgs& a_, const SparseArgs& sp_, char* wave_lds, int lane_, int mb_, int r0_)
+        : a(a_), sp(sp_), lane(lane_), r(lane_ & 15), q(lane_ >> 4), mb(mb_), r0(r0_) {
+        P = reinterpret_cast<float*>(wave_lds);
+        bm = reinterpret_cast<unsigned*>(P + NH * UW_ROWS * PS);
+        ulist = reinterpret_cast<unsigned short*>(bm + 256);
+        mi_bytes = (unsigned)((long)a.mesh_batch * a.n_in * a.sdim * 4);
+        rmi = make_rsrc(a.mesh_in, mi_bytes);
 #pragma unroll
-    for (int h = 0; h < NH; ++h) c[h] = a.head[h];                    // (the host passes the scale itself)
-    // ---- the row's constants, its candidates and their distances: registers for the rest of the kernel
-    const bool rvalid = r0 + r < a.n_out;
-    const long grow = (long)mb * a.n_out + (rvalid ? r0 + r : a.n_out - 1);
-    int jr[EPL];
-    {
-        // (the list slots are read before the count arrives - every slot below the capacity is addressable - and
-        // masked afterwards: one memory round trip instead of two)
-        const int* lst = sp.nbr_idx + grow * sp.cap;
-#pragma unroll
-        for (int t = 0; t < EPL; ++t) {
-            const int i = q + 4 * t;
-            jr[t] = i < sp.cap ? lst[i] : -1;
-        }
+        for (int h = 0; h < NH; ++h) c[h] = a.head[h];                // (the host passes the scale itself)
     }
-    const int cnt = rvalid ? sp.nbr_cnt[grow] : 0;
-    const bool ovf = cnt > sp.cap;                                    // (an overflowed row scans every key, below)
-    const float4 xo = load_point4(rmo, mo_bytes, grow, a.sdim, a.coords_used);
-    float rc[NH][4];                                                  // {T, S_min, 1/rowsum, mbar}
-#pragma unroll
-    for (int h = 0; h < NH; ++h) {
-        if (MODE == 0) {
-            rc[h][0] = quantile_lerp(__fmul_rn(c[h], a.stats[grow]), __fmul_rn(c[h], a.stats[rows_total + grow]), a.rank_w);
-            rc[h][1] = __fmul_rn(c[h], a.stats[2 * rows_total + grow]);
-            rc[h][2] = 0.0f; rc[h][3] = 0.0f;
-        } else {
-            const float4 rs4 = *reinterpret_cast<const float4*>(a.rowstat + (((long)mb * a.n_head + h) * a.n_out + (rvalid ? r0 + r : a.n_out - 1)) * 4);
-            rc[h][0] = rs4.x; rc[h][1] = rs4.y; rc[h][2] = rs4.z; rc[h][3] = rs4.w;
-        }
-    }
-    float mr[EPL];
-#pragma unroll
-    for (int t = 0; t < EPL; ++t) {
-        const unsigned j = (unsigned)jr[t] < (unsigned)a.n_in ? (unsigned)jr[t] : 0u;   // (slots past the count hold anything)
+    __device__ __forceinline__ float dist_to(int j) const {
         const float4 xi = load_point4(rmi, mi_bytes, (long)mb * a.n_in + j, a.sdim, a.coords_used);
-        mr[t] = sq_dist3(xo.x, xo.y, xo.z, xi.x, xi.y, xi.z, per, a.period);
+        return sq_dist3(xo.x, xo.y, xo.z, xi.x, xi.y, xi.z, a.periodic != 0, a.period);
     }
-#pragma unroll
-    for (int t = 0; t < EPL; ++t)
-        if (ovf || q + 4 * t >= cnt) jr[t] = -1;
-    const bool any_ovf = __builtin_amdgcn_ballot_w64(ovf) != 0ull;
-    // ---- union of the 16 candidate lists
-    bm[lane] = 0u; bm[lane + 64] = 0u;
-    PIT_WAVE_LDS_SYNC();
-    if (any_ovf) {
-#pragma unroll
-        for (int w = lane; w < 128; w += 64) {
-            const int rem = a.n_in - 32 * w;
-            if (rem > 0) bm[w] = rem >= 32 ? 0xFFFFFFFFu : ((1u << rem) - 1u);
-        }
-    } else {
-#pragma unroll
-        for (int t = 0; t < EPL; ++t)
-            if (jr[t] >= 0) atomicOr(&bm[jr[t] >> 5], 1u << (jr[t] & 31));
-    }
-    PIT_WAVE_LDS_SYNC();
-    int U;
-    {                                                                 // word bases: exclusive scan of the popcounts (<= 128 words)
-        const unsigned w0 = lane < nwords ? bm[lane] : 0u, w1 = lane + 64 < nwords ? bm[lane + 64] : 0u;
-        const int v0 = __popc(w0), v1 = __popc(w1);
-        int s0 = v0, s1 = v1;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int t0 = __shfl_up(s0, o, 64), t1 = __shfl_up(s1, o, 64);
-            if (lane >= o) { s0 += t0; s1 += t1; }
-        }
-        const int tot0 = __shfl(s0, 63, 64), tot1 = __shfl(s1, 63, 64);
-        U = tot0 + tot1;
-        int b0 = s0 - v0, b1 = tot0 + s1 - v1;
-        bm[128 + lane] = (unsigned)b0; bm[192 + lane] = (unsigned)b1;
-        unsigned bits = w0;
-        while (bits) { const int t = __builtin_ctz(bits); bits &= bits - 1u; ulist[b0++] = (unsigned short)(32 * lane + t); }
-        bits = w1;
-        while (bits) { const int t = __builtin_ctz(bits); bits &= bits - 1u; ulist[b1++] = (unsigned short)(32 * (lane + 64) + t); }
-    }
-    PIT_WAVE_LDS_SYNC();
-    // a candidate's position in the union (kept in place of its key)
-#pragma unroll
-    for (int t = 0; t < EPL; ++t)
-        if (jr[t] >= 0) jr[t] = (int)bm[128 + (jr[t] >> 5)] + __popc(bm[jr[t] >> 5] & ((1u << (jr[t] & 31)) - 1u));
     // one (row, key) weight per head from the squared distance m
-    auto weigh = [&](float m, int h) -> float {
+    __device__ __forceinline__ float weigh(float m, int h) const {
         const float sv = __fmul_rn(m, c[h]);
         return sv <= rc[h][0] ? __expf(rc[h][1] - sv) : 0.0f;
-    };
-    auto dist_to = [&](int j) -> float {
-        const float4 xi = load_point4(rmi, mi_bytes, (long)mb * a.n_in + j, a.sdim, a.coords_used);
-        return sq_dist3(xo.x, xo.y, xo.z, xi.x, xi.y, xi.z, per, a.period);
-    };
-    float inv[NH];                                                    // MODE 0: 1 / row sum, on all four lanes of the row
-    if (MODE == 0) {
-        // ---- row sums (and sum p m for the backward's mbar): private partial sums of the row's four lanes, combined in a
-        //      fixed order - the same bits on every run
-        float ps[NH], pm[NH];
+    }
+    // ---- the row's constants, its candidates and their distances: registers for the rest of the tile
+    __device__ __forceinline__ void load() {
+        const long rows_total = (long)a.mesh_batch * a.n_out;
+        const unsigned mo_bytes = (unsigned)(rows_total * a.sdim * 4);
+        const __amdgpu_buffer_rsrc_t rmo = make_rsrc(a.mesh_out, mo_bytes);
+        rvalid = r0 + r < a.n_out;
+        const long grow = (long)mb * a.n_out + (rvalid ? r0 + r : a.n_out - 1);
+        {
+            // (the list slots are read before the count arrives - every slot below the capacity is addressable - and
+            // masked afterwards: one memory round trip instead of two)
+            const int* lst = sp.nbr_idx + grow * sp.cap;
 #pragma unroll
-        for (int h = 0; h < NH; ++h) { ps[h] = 0.0f; pm[h] = 0.0f; }
-#pragma unroll
-        for (int t = 0; t < EPL; ++t) {
-            if (jr[t] < 0) continue;
-#pragma unroll
-            for (int h = 0; h < NH; ++h) { const float pv = weigh(mr[t], h); ps[h] += pv; pm[h] += pv * mr[t]; }
-        }
-        if (ovf)
-            for (int pos = q; pos < U; pos += 4) {
-                const float m = dist_to((int)ulist[pos]);
-#pragma unroll
-                for (int h = 0; h < NH; ++h) { const float pv = weigh(m, h); ps[h] += pv; pm[h] += pv * m; }
+            for (int t = 0; t < EPL; ++t) {
+                const int i = q + 4 * t;
+                jr[t] = i < sp.cap ? lst[i] : -1;
             }
+        }
+        const int cnt = rvalid ? sp.nbr_cnt[grow] : 0;
+        ovf = cnt > sp.cap;                                           // (an overflowed row scans every key)
+        xo = load_point4(rmo, mo_bytes, grow, a.sdim, a.coords_used);
 #pragma unroll
         for (int h = 0; h < NH; ++h) {
-            ps[h] += __shfl_xor(ps[h], 16, 64); ps[h] += __shfl_xor(ps[h], 32, 64);
-            pm[h] += __shfl_xor(pm[h], 16, 64); pm[h] += __shfl_xor(pm[h], 32, 64);
-            inv[h] = ps[h] > 0.0f ? 1.0f / ps[h] : 0.0f;
-            if (q == 0 && blockIdx.x == 0 && rvalid)
-                *reinterpret_cast<float4*>(a.rowstat + (((long)mb * a.n_head + h) * a.n_out + r0 + r) * 4) =
-                    make_float4(rc[h][0], rc[h][1], inv[h], pm[h] * inv[h]);
+            if (MODE == 0) {
+                rc[h][0] = quantile_lerp(__fmul_rn(c[h], a.stats[grow]), __fmul_rn(c[h], a.stats[rows_total + grow]), a.rank_w);
+                rc[h][1] = __fmul_rn(c[h], a.stats[2 * rows_total + grow]);
+                rc[h][2] = 0.0f; rc[h][3] = 0.0f;
+            } else {
+                const float4 rs4 = *reinterpret_cast<const float4*>(a.rowstat + (((long)mb * a.n_head + h) * a.n_out + (rvalid ? r0 + r : a.n_out - 1)) * 4);
+                rc[h][0] = rs4.x; rc[h][1] = rs4.y; rc[h][2] = rs4.z; rc[h][3] = rs4.w;
+            }
         }
-        if (a.scale_out && (blockIdx.x | blockIdx.y | blockIdx.z) == 0 && tid < NH)
-            a.scale_out[tid] = a.head[tid];                           // the backward reads the scale from here
+#pragma unroll
+        for (int t = 0; t < EPL; ++t) {
+            const unsigned j = (unsigned)jr[t] < (unsigned)a.n_in ? (unsigned)jr[t] : 0u;   // (slots past the count hold anything)
+            mr[t] = dist_to((int)j);
+        }
+#pragma unroll
+        for (int t = 0; t < EPL; ++t)
+            if (ovf || q + 4 * t >= cnt) jr[t] = -1;
     }
-    // the weight tile of union positions [c0, c0 + UW_CH)
-    auto build = [&](int c0) {
+    // ---- union of the 16 candidate lists; the candidates' keys become their positions in it
+    __device__ __forceinline__ void unite() {
+        const int nwords = (a.n_in + 31) / 32;
+        const bool any_ovf = __builtin_amdgcn_ballot_w64(ovf) != 0ull;
+        PIT_WAVE_LDS_SYNC();                                          // (a previous tile's reads of bm / ulist are done)
+        bm[lane] = 0u; bm[lane + 64] = 0u;
+        PIT_WAVE_LDS_SYNC();
+        if (any_ovf) {
+#pragma unroll
+            for (int w = lane; w < 128; w += 64) {
+                const int rem = a.n_in - 32 * w;
+                if (rem > 0) bm[w] = rem >= 32 ? 0xFFFFFFFFu : ((1u << rem) - 1u);
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < EPL; ++t)
+                if (jr[t] >= 0) atomicOr(&bm[jr[t] >> 5], 1u << (jr[t] & 31));
+        }
+        PIT_WAVE_LDS_SYNC();
+        {                                                             // word bases: exclusive scan of the popcounts (<= 128 words)
+            const unsigned w0 = lane < nwords ? bm[lane] : 0u, w1 = lane + 64 < nwords ? bm[lane + 64] : 0u;
+            const int v0 = __popc(w0), v1 = __popc(w1);
+            int s0 = v0, s1 = v1;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int t0 = __shfl_up(s0, o, 64), t1 = __shfl_up(s1, o, 64);
+                if (lane >= o) { s0 += t0; s1 += t1; }
+            }
+            const int tot0 = __shfl(s0, 63, 64), tot1 = __shfl(s1, 63, 64);
+            U = tot0 + tot1;
+            int b0 = s0 - v0, b1 = tot0 + s1 - v1;
+            bm[128 + lane] = (unsigned)b0; bm[192 + lane] = (unsigned)b1;
+            unsigned bits = w0;
+            while (bits) { const int t = __builtin_ctz(bits); bits &= bits - 1u; ulist[b0++] = (unsigned short)(32 * lane + t); }
+            bits = w1;
+            while (bits) { const int t = __builtin_ctz(bits); bits &= bits - 1u; ulist[b1++] = (unsigned short)(32 * (lane + 64) + t); }
+        }
+        PIT_WAVE_LDS_SYNC();
+#pragma unroll
+        for (int t = 0; t < EPL; ++t)
+            if (jr[t] >= 0) jr[t] = (int)bm[128 + (jr[t] >> 5)] + __popc(bm[jr[t] >> 5] & ((1u << (jr[t] & 31)) - 1u));
+    }
+    // ---- the weight tile of union positions [c0, c0 + UW_CH)
+    __device__ __forceinline__ void put(float m, int pos) {
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+            float pv = weigh(m, h);
+            if (MODE == 1) pv = pv * (m - rc[h][3]) * rc[h][2];
+            else if (MODE == 2) pv = pv * rc[h][2];
+            P[(h * UW_ROWS + r) * PS + pos] = pv;
+        }
+    }
+    __device__ __forceinline__ void build(int c0) {
         PIT_WAVE_LDS_SYNC();                                          // (the previous chunk's operand reads are done)
         for (int e = lane; e < NH * UW_ROWS * PS / 4; e += 64) reinterpret_cast<float4*>(P)[e] = make_float4(0.f, 0.f, 0.f, 0.f);
         PIT_WAVE_LDS_SYNC();
-        auto put = [&](float m, int pos) {
-#pragma unroll
-            for (int h = 0; h < NH; ++h) {
-                float pv = weigh(m, h);
-                if (MODE == 1) pv = pv * (m - rc[h][3]) * rc[h][2];
-                else if (MODE == 2) pv = pv * rc[h][2];
-                P[(h * UW_ROWS + r) * PS + pos] = pv;
-            }
-        };
 #pragma unroll
         for (int t = 0; t < EPL; ++t) {
             const int pos = jr[t] - c0;
@@ -2431,66 +2408,59 @@ __global__ __launch_bounds__(256, NH == 1 ? UW_OCC : 1) void posatt_union_kernel
             for (int pos = q; pos < uc; pos += 4) put(dist_to((int)ulist[c0 + pos]), pos);
         }
         PIT_WAVE_LDS_SYNC();
-    };
-    const bool single = U <= UW_CH;
-    if (single) build(0);
-
-    if (MODE == 2) {
-        // ---- d(values)[key] += sum_h sum_rows P_h[row][key] dO_h[row]: the A operand is P^T (16 union positions x 4 rows per
-        //      MFMA), column c of tile t = 16 t + lane column (64-byte runs per atomic instruction)
-        const __amdgpu_buffer_rsrc_t rdo = make_rsrc(a.d_out, a.dout_bytes);
-        for (int cbi = 0; cbi < cb_per_wave; ++cbi) {
-            const int col0 = (blockIdx.x * cb_per_wave + cbi) * UW_CB;
-            if (col0 >= a.ncols) break;
-            unsigned dvo[8];                                          // d_values element offset of this lane's column in tile t
-            float dv[NH][4][8];                                       // d(out): rows 4 ks + q, this lane's columns
-#pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                const int col = col0 + 16 * t + r;
-                const bool cvalid = col < a.ncols;
-                int cb, cd;
-                col_split(a, cvalid ? col : 0, mb, cb, cd);
-                dvo[t] = cvalid ? (unsigned)((long)cb * a.dvalues_bstride + cd) : 0xFFFFFFFFu;
-#pragma unroll
-                for (int h = 0; h < NH; ++h) {
-                    const unsigned dbase = (unsigned)((long)cb * a.dout_bstride + a.out_col0 + (long)h * a.dim + cd);
-#pragma unroll
-                    for (int ks = 0; ks < 4; ++ks) {
-                        const int n = r0 + 4 * ks + q;
-                        dv[h][ks][t] = dout_load(rdo, (cvalid && n < a.n_out) ? dbase + (unsigned)n * (unsigned)a.ld_dout : a.dout_elems, a.dout16);
-                    }
-                }
-            }
-            for (int c0 = 0; c0 < U; c0 += UW_CH) {
-                if (!single) build(c0);
-                const int uc = min(UW_CH, U - c0);
-                for (int kb = 0; kb * 16 < uc; ++kb) {
-                    f32x4u acc[8];
-#pragma unroll
-                    for (int t = 0; t < 8; ++t) acc[t] = f32x4u{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int h = 0; h < NH; ++h)
-#pragma unroll
-                        for (int ks = 0; ks < 4; ++ks) {
-                            const float av = P[(h * UW_ROWS + 4 * ks + q) * PS + kb * 16 + r];
-#pragma unroll
-                            for (int t = 0; t < 8; ++t) acc[t] = mfma_16x16x4_u(av, dv[h][ks][t], acc[t]);
-                        }
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int pos = kb * 16 + 4 * q + i;
-                        if (pos >= uc) continue;
-                        float* grow_ = a.d_values + (long)ulist[c0 + pos] * a.ld_dvalues;
-#pragma unroll
-                        for (int t = 0; t < 8; ++t)
-                            if (dvo[t] != 0xFFFFFFFFu) atomicAdd(grow_ + dvo[t], acc[t][i]);
-                    }
-                }
-            }
-        }
-        return;
     }
-    // ---- MODE 0 / 1: out tile = P V_union, the value rows of the union fetched 16 keys ahead of the MFMAs
+};
+
+// MODE 0: forward; MODE 1: d(scale)
+template <int NH, int MODE, int EPL>
+__global__ __launch_bounds__(256, NH == 1 ? UW_OCC : 1) void posatt_union_kernel(AttArgs a, SparseArgs sp, int cb_per_wave, int wave_lds_bytes) {
+    typedef UnionTile<NH, MODE, EPL> Tile;
+    constexpr int PS = Tile::PS;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int mb = blockIdx.z, r0 = (blockIdx.y * 4 + wave) * UW_ROWS;
+    if (r0 >= a.n_out) return;                                        // (no workgroup barrier below)
+    Tile T(a, sp, reinterpret_cast<char*>(lds) + (size_t)wave * wave_lds_bytes, lane, mb, r0);
+    const int r = T.r, q = T.q;
+    T.load();
+    T.unite();
+    const int U = T.U;
+    float inv[NH];                                                    // MODE 0: 1 / row sum, on all four lanes of the row
+    if (MODE == 0) {
+        // ---- row sums (and sum p m for the backward's mbar): private partial sums of the row's four lanes, combined in a
+        //      fixed order - the same bits on every run
+        float ps[NH], pm[NH];
+#pragma unroll
+        for (int h = 0; h < NH; ++h) { ps[h] = 0.0f; pm[h] = 0.0f; }
+#pragma unroll
+        for (int t = 0; t < EPL; ++t) {
+            if (T.jr[t] < 0) continue;
+#pragma unroll
+            for (int h = 0; h < NH; ++h) { const float pv = T.weigh(T.mr[t], h); ps[h] += pv; pm[h] += pv * T.mr[t]; }
+        }
+        if (T.ovf)
+            for (int pos = q; pos < U; pos += 4) {
+                const float m = T.dist_to((int)T.ulist[pos]);
+#pragma unroll
+                for (int h = 0; h < NH; ++h) { const float pv = T.weigh(m, h); ps[h] += pv; pm[h] += pv * m; }
+            }
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+            ps[h] += __shfl_xor(ps[h], 16, 64); ps[h] += __shfl_xor(ps[h], 32, 64);
+            pm[h] += __shfl_xor(pm[h], 16, 64); pm[h] += __shfl_xor(pm[h], 32, 64);
+            inv[h] = ps[h] > 0.0f ? 1.0f / ps[h] : 0.0f;
+            if (q == 0 && blockIdx.x == 0 && T.rvalid)
+                *reinterpret_cast<float4*>(a.rowstat + (((long)mb * a.n_head + h) * a.n_out + r0 + r) * 4) =
+                    make_float4(T.rc[h][0], T.rc[h][1], inv[h], pm[h] * inv[h]);
+        }
+        if (a.scale_out && (blockIdx.x | blockIdx.y | blockIdx.z) == 0 && tid < NH)
+            a.scale_out[tid] = a.head[tid];                           // the backward reads the scale from here
+    }
+    const bool single = U <= UW_CH;
+    if (single) T.build(0);
+    // ---- out tile = P V_union, the value rows of the union fetched two groups of keys ahead of the MFMAs
+    const float* P = T.P;
+    const unsigned short* ulist = T.ulist;
     const __amdgpu_buffer_rsrc_t rvals = make_rsrc(a.values, a.values_bytes);
     const unsigned ld4 = (unsigned)a.ld_values * 4u;
     for (int cbi = 0; cbi < cb_per_wave; ++cbi) {
@@ -2507,7 +2477,7 @@ __global__ __launch_bounds__(256, NH == 1 ? UW_OCC : 1) void posatt_union_kernel
 #pragma unroll
             for (int t = 0; t < 8; ++t) acc[h][t] = f32x4u{0.f, 0.f, 0.f, 0.f};
         for (int c0 = 0; c0 < U; c0 += UW_CH) {
-            if (!single) build(c0);
+            if (!single) T.build(c0);
             const int uc = min(UW_CH, U - c0);
             const int nst = (uc + 3) >> 2;                            // steps of 4 keys
             auto fetch = [&](int s0, float (&bv)[UW_FG][8]) {
@@ -2606,6 +2576,191 @@ __global__ __launch_bounds__(256, NH == 1 ? UW_OCC : 1) void posatt_union_kernel
     }
 }
 
+// d(values)[key] += sum_h sum_rows P_h[row][key] dO_h[row] WITHOUT transposed lists: a workgroup of 8 wavefronts owns
+// DV_RB = 256 CONSECUTIVE rows.  The keys its rows touch (a bitmap in LDS, compacted: ~100-200 for a coherent ordering) are
+// the M dimension of a transposed contraction  D[slot][column] = sum over the block's rows of  P^T[slot][row] dO[row][column]:
+// P^T is built 64 rows at a time in LDS ([DV_KC slots][64 rows], four lanes per row scatter the row's weights), wavefront w
+// owns columns [16 w, 16 w + 16) and keeps its D tiles (DV_KC / 16 MFMA tiles of 16 slots) in registers over all the rows -
+// the accumulation IS the MFMA's, no adds in LDS (measured: ds_add_f32 sustains one lane per ~3.5 clocks per CU, 490 us for
+// this layer) - skipping the 16-slot x 4-row operand blocks that hold only zeros (most: a row touches ~16 of the slots).
+// One pass at the end adds the block's D to memory with fp32 atomics (the caller zeroes d_values; ~rows / 256 x slots x
+// columns adds instead of rows / 16 x ~45 x columns: 86 M -> ~20 M for a NACA decoder layer).  More than DV_KC keys in a
+// block (incoherent orderings, overflowed lists): the slots are walked in ranges of DV_KC - correct for any input.
+constexpr int DV_WAVES = 8, DV_RB = 256, DV_KC = 192, DV_PS = 68;
+template <int NH, int EPL>
+__global__ __launch_bounds__(512, (NH == 1 && EPL == 8) ? 4 : 2) void posatt_union_dv_kernel(AttArgs a, SparseArgs sp) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* PT = lds;                                                  // [DV_KC][DV_PS]: P^T of 64 rows
+    unsigned* wbm = reinterpret_cast<unsigned*>(PT + DV_KC * DV_PS);  // [128] bitmap of the block's keys, [128] word bases
+    int* wflag = reinterpret_cast<int*>(wbm + 256);                   // [0] = keys in the bitmap, [1] = some list overflowed
+    unsigned short* wkeys = reinterpret_cast<unsigned short*>(wflag + 4);   // [n_in] slot -> key
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, q = lane >> 4;
+    const int mb = blockIdx.z, rb0 = blockIdx.y * DV_RB;
+    const int nwords = (a.n_in + 31) / 32;
+    const long rows_total = (long)a.mesh_batch * a.n_out;
+    const unsigned mo_bytes = (unsigned)(rows_total * a.sdim * 4);
+    const unsigned mi_bytes = (unsigned)((long)a.mesh_batch * a.n_in * a.sdim * 4);
+    const __amdgpu_buffer_rsrc_t rmo = make_rsrc(a.mesh_out, mo_bytes);
+    const __amdgpu_buffer_rsrc_t rmi = make_rsrc(a.mesh_in, mi_bytes);
+    const bool per = a.periodic != 0;
+    float c[NH];
+#pragma unroll
+    for (int h = 0; h < NH; ++h) c[h] = a.head[h];                    // (the host passes the scale itself)
+    // ---- four lanes per row, two rows per thread (rows rb0 + p * 128 + tid / 4): candidates, distances, row constants
+    const int rq = tid & 3;
+    int js[2][EPL];                                                   // candidate keys, then their slots (-1: none)
+    float ms[2][EPL];
+    float rT[2][NH], rS[2][NH], rI[2][NH];                            // threshold, S_min, 1 / row sum
+    float4 xo[2];
+    bool ovf[2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int n = rb0 + p * 128 + (tid >> 2);
+        const bool rvalid = n < a.n_out;
+        const long grow = (long)mb * a.n_out + (rvalid ? n : a.n_out - 1);
+        const int* lst = sp.nbr_idx + grow * sp.cap;
+#pragma unroll
+        for (int t = 0; t < EPL; ++t) {
+            const int i = rq + 4 * t;
+            js[p][t] = i < sp.cap ? lst[i] : -1;                      // (read before the count arrives, masked below)
+        }
+        const int cnt = rvalid ? sp.nbr_cnt[grow] : 0;
+        ovf[p] = cnt > sp.cap;
+        xo[p] = load_point4(rmo, mo_bytes, grow, a.sdim, a.coords_used);
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+            const float4 rs4 = *reinterpret_cast<const float4*>(a.rowstat + (((long)mb * a.n_head + h) * a.n_out + (rvalid ? n : a.n_out - 1)) * 4);
+            rT[p][h] = rs4.x; rS[p][h] = rs4.y; rI[p][h] = rvalid ? rs4.z : 0.0f;
+        }
+#pragma unroll
+        for (int t = 0; t < EPL; ++t) {
+            const unsigned j = (unsigned)js[p][t] < (unsigned)a.n_in ? (unsigned)js[p][t] : 0u;
+            const float4 xi = load_point4(rmi, mi_bytes, (long)mb * a.n_in + j, a.sdim, a.coords_used);
+            ms[p][t] = sq_dist3(xo[p].x, xo[p].y, xo[p].z, xi.x, xi.y, xi.z, per, a.period);
+        }
+#pragma unroll
+        for (int t = 0; t < EPL; ++t)
+            if (ovf[p] || rq + 4 * t >= cnt) js[p][t] = -1;
+    }
+    // ---- the block's key set
+    if (tid < 256) wbm[tid] = 0u;
+    if (tid == 0) wflag[1] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        if (ovf[p]) wflag[1] = 1;
+#pragma unroll
+        for (int t = 0; t < EPL; ++t)
+            if (js[p][t] >= 0) atomicOr(&wbm[js[p][t] >> 5], 1u << (js[p][t] & 31));
+    }
+    __syncthreads();
+    if (wflag[1]) {                                                   // a row whose list overflowed scans ALL keys
+        if (tid < 128) { const int rem = a.n_in - 32 * tid; wbm[tid] = rem <= 0 ? 0u : (rem >= 32 ? 0xFFFFFFFFu : ((1u << rem) - 1u)); }
+        __syncthreads();
+    }
+    if (wave == 0) {
+        const unsigned w0 = lane < nwords ? wbm[lane] : 0u, w1 = lane + 64 < nwords ? wbm[lane + 64] : 0u;
+        const int v0 = __popc(w0), v1 = __popc(w1);
+        int s0 = v0, s1 = v1;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t0 = __shfl_up(s0, o, 64), t1 = __shfl_up(s1, o, 64);
+            if (lane >= o) { s0 += t0; s1 += t1; }
+        }
+        const int tot0 = __shfl(s0, 63, 64), tot1 = __shfl(s1, 63, 64);
+        int b0 = s0 - v0, b1 = tot0 + s1 - v1;
+        wbm[128 + lane] = (unsigned)b0; wbm[192 + lane] = (unsigned)b1;
+        if (lane == 0) wflag[0] = tot0 + tot1;
+        unsigned bits = w0;
+        while (bits) { const int t = __builtin_ctz(bits); bits &= bits - 1u; wkeys[b0++] = (unsigned short)(32 * lane + t); }
+        bits = w1;
+        while (bits) { const int t = __builtin_ctz(bits); bits &= bits - 1u; wkeys[b1++] = (unsigned short)(32 * (lane + 64) + t); }
+    }
+    __syncthreads();
+    const int UW = wflag[0];
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int t = 0; t < EPL; ++t)
+            if (js[p][t] >= 0) js[p][t] = (int)wbm[128 + (js[p][t] >> 5)] + __popc(wbm[js[p][t] >> 5] & ((1u << (js[p][t] & 31)) - 1u));
+    const __amdgpu_buffer_rsrc_t rdo = make_rsrc(a.d_out, a.dout_bytes);
+    const int ncb = (a.ncols + UW_CB - 1) / UW_CB;
+    for (int cbi = blockIdx.x; cbi < ncb; cbi += gridDim.x) {
+        const int col = cbi * UW_CB + 16 * wave + r;                  // this lane's column
+        const bool cvalid = col < a.ncols;
+        int cb, cd;
+        col_split(a, cvalid ? col : 0, mb, cb, cd);
+        const unsigned dob = (unsigned)((long)cb * a.dout_bstride + a.out_col0 + cd);
+        for (int sp0 = 0; sp0 < UW; sp0 += DV_KC) {
+            const int kc = min(DV_KC, UW - sp0);
+            const int nmt = (kc + 15) >> 4;
+            f32x4u acc[DV_KC / 16];
+#pragma unroll
+            for (int mt = 0; mt < DV_KC / 16; ++mt) acc[mt] = f32x4u{0.f, 0.f, 0.f, 0.f};
+            for (int ch = 0; ch < DV_RB / 64; ++ch) {
+                if (rb0 + 64 * ch >= a.n_out) break;
+#pragma unroll
+                for (int h = 0; h < NH; ++h) {
+                    // d(out) of the chunk's rows 4 ks + q, this lane's column: in flight while P^T is built
+                    float bv[16];
+#pragma unroll
+                    for (int ks = 0; ks < 16; ++ks) {
+                        const int n = rb0 + 64 * ch + 4 * ks + q;
+                        bv[ks] = dout_load(rdo, (cvalid && n < a.n_out) ? dob + (unsigned)(h * a.dim) + (unsigned)n * (unsigned)a.ld_dout : a.dout_elems, a.dout16);
+                    }
+                    __syncthreads();                                  // (the previous chunk's operand reads are done)
+                    for (int e = tid; e < nmt * 16 * DV_PS / 4; e += 512) reinterpret_cast<float4*>(PT)[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    __syncthreads();
+                    if ((tid >> 8) == (ch & 1)) {                     // the threads that hold this chunk's rows
+                        const int p = ch >> 1, row = (tid >> 2) & 63;
+                        auto put = [&](float m, int slot) {
+                            const float sv = __fmul_rn(m, c[h]);
+                            if (sv <= (p ? rT[1][h] : rT[0][h]))
+                                PT[slot * DV_PS + row] = __expf((p ? rS[1][h] : rS[0][h]) - sv) * (p ? rI[1][h] : rI[0][h]);
+                        };
+#pragma unroll
+                        for (int t = 0; t < EPL; ++t) {
+                            const int slot = (p ? js[1][t] : js[0][t]) - sp0;
+                            if ((p ? js[1][t] : js[0][t]) >= 0 && slot >= 0 && slot < DV_KC) put(p ? ms[1][t] : ms[0][t], slot);
+                        }
+                        if (p ? ovf[1] : ovf[0]) {
+                            const float4 x = p ? xo[1] : xo[0];
+                            for (int sl = rq; sl < kc; sl += 4) {
+                                const float4 xi = load_point4(rmi, mi_bytes, (long)mb * a.n_in + (int)wkeys[sp0 + sl], a.sdim, a.coords_used);
+                                put(sq_dist3(x.x, x.y, x.z, xi.x, xi.y, xi.z, per, a.period), sl);
+                            }
+                        }
+                    }
+                    __syncthreads();
+#pragma unroll
+                    for (int mt = 0; mt < DV_KC / 16; ++mt) {
+                        if (mt < nmt) {
+                            float av[16];                             // (all 16 operand reads in flight before the first test)
+#pragma unroll
+                            for (int ks = 0; ks < 16; ++ks) av[ks] = PT[(mt * 16 + r) * DV_PS + 4 * ks + q];
+#pragma unroll
+                            for (int ks = 0; ks < 16; ++ks)
+                                if (__builtin_amdgcn_ballot_w64(av[ks] != 0.0f) != 0ull) acc[mt] = mfma_16x16x4_u(av[ks], bv[ks], acc[mt]);
+                        }
+                    }
+                }
+            }
+            // ---- the block's sums to memory: accumulator i of tile mt = slot sp0 + 16 mt + 4 q + i, this lane's column
+            if (cvalid) {
+                float* gcol = a.d_values + (long)cb * a.dvalues_bstride + cd;
+#pragma unroll
+                for (int mt = 0; mt < DV_KC / 16; ++mt)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int sl = 16 * mt + 4 * q + i;
+                        if (sl < kc) atomicAdd(gcol + (long)wkeys[sp0 + sl] * a.ld_dvalues, acc[mt][i]);
+                    }
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void zero_f32_kernel(float* __restrict__ p, long n) {
     for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (long)gridDim.x * 1024) {
         if (i + 4 <= n) *reinterpret_cast<float4*>(p + i) = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -2644,6 +2799,20 @@ void launch_union(const AttArgs& a, const SparseArgs& sp, hipStream_t s) {
     if (a.n_head == 2) { if (sp.cap <= 32) PIT_UN(2, 8); else PIT_UN(2, 16); }
     else               { if (sp.cap <= 32) PIT_UN(1, 8); else PIT_UN(1, 16); }
 #undef PIT_UN
+}
+// d(values) of the union-tile form (posatt_union_dv_kernel); the caller zeroed d_values
+void launch_union_dv(const AttArgs& a, const SparseArgs& sp, hipStream_t s) {
+    const int ncb = (a.ncols + UW_CB - 1) / UW_CB;
+    const size_t sm = (size_t)DV_KC * DV_PS * sizeof(float) + 256 * sizeof(unsigned) + 16 + (size_t)a.n_in * sizeof(unsigned short) + 16;
+    dim3 grid((unsigned)std::min(ncb, 64), (unsigned)((a.n_out + DV_RB - 1) / DV_RB), (unsigned)a.mesh_batch), block(512);
+#define PIT_UNDV(NH_, EPL_) do {                                                                                           \
+        static bool once = ((void)hipFuncSetAttribute((const void*)posatt_union_dv_kernel<NH_, EPL_>,                      \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, 98304), true);                 \
+        (void)once;                                                                                                        \
+        hipLaunchKernelGGL((posatt_union_dv_kernel<NH_, EPL_>), grid, block, sm, s, a, sp); } while (0)
+    if (a.n_head == 2) { if (sp.cap <= 32) PIT_UNDV(2, 8); else PIT_UNDV(2, 16); }
+    else               { if (sp.cap <= 32) PIT_UNDV(1, 8); else PIT_UNDV(1, 16); }
+#undef PIT_UNDV
 }
 
 // columns per lane: as many as the column count allows, fewer when the launch would otherwise
@@ -3039,13 +3208,14 @@ extern "C" int pit_posatt_bwd(const float* mesh_out, const float* mesh_in, int m
         a.dout_elems = (unsigned)de;
     }
     const bool sparse = masked && nbr_idx && nbr_cnt;
-    if (a.dout16 && (!sparse || add_residual || (d_values && !(rev_ptr && rev_row)) || dim % 2 || out_col0 % 2 || ld_dout % 2 ||
+    SparseArgs sp{nbr_idx, nbr_cnt, nbr_cap, rev_ptr, rev_row, (long)n_out * nbr_cap};
+    const bool union_form = sparse && (math_mode & PIT_ATT_UNION) && !add_residual && a.head_is_scale && union_ok(a, sp) &&
+                            aligned_rows(d_out, ld_dout, dout_bstride, out_col0, a.dout16 ? 8 : 4) &&
+                            (!d_values || (ld_dvalues == dim && dvalues_bstride == (long)n_in * dim));
+    if (a.dout16 && (!sparse || add_residual || (d_values && !(rev_ptr && rev_row) && !union_form) || dim % 2 || out_col0 % 2 || ld_dout % 2 ||
                      dout_bstride % 2 || (reinterpret_cast<uintptr_t>(d_out) & 3)))
         return PIT_ERR_UNSUPPORTED;                             // candidate-list kernels only, column pairs
-    SparseArgs sp{nbr_idx, nbr_cnt, nbr_cap, rev_ptr, rev_row, (long)n_out * nbr_cap};
-    if (sparse && (math_mode & PIT_ATT_UNION) && !add_residual && a.head_is_scale && union_ok(a, sp) &&
-        aligned_rows(d_out, ld_dout, dout_bstride, out_col0, a.dout16 ? 8 : 4) &&
-        (!d_values || (ld_dvalues == dim && dvalues_bstride == (long)n_in * dim))) {
+    if (union_form) {
         // union tiles (coherent row ordering): d(scale) as a dense contraction over each 16-row tile's union of keys
         if (d_head) {
             a.d_head = d_head; a.dhead_src = head; a.dhead_is_scale = head_is_scale;
@@ -3059,15 +3229,15 @@ extern "C" int pit_posatt_bwd(const float* mesh_out, const float* mesh_in, int m
             }
         }
         if (d_values && rev_ptr && rev_row) {
-            // d(values) from the transposed lists: measured faster than the tiles' fp32 atomics (191 + 19 vs 303 us on a
-            // NACA-shaped decoder layer - 86 M atomic adds at device scope) and the same bits on every run
+            // d(values) from the transposed lists when the plan carries them (the same bits on every run); the host builds
+            // plans of union-tile kinds without them (ops.MeshPlan._wants_reverse_lists) and the tiles supply d(values)
             launch_sparse_cols(a, sp, nbr_complete != 0, s);
             PIT_CHECK_LAUNCH();
         } else if (d_values) {
             const long nv = (long)batch * n_in * dim;
             hipLaunchKernelGGL(zero_f32_kernel, dim3((unsigned)std::min<long>((nv + 1023) / 1024, 2048L)), dim3(256), 0, s, d_values, nv);
             PIT_CHECK_LAUNCH();
-            launch_union<2>(a, sp, s);
+            launch_union_dv(a, sp, s);
             PIT_CHECK_LAUNCH();
         }
         return rd.finish();

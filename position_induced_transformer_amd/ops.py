@@ -436,6 +436,7 @@ def mesh_period(metric: str, mesh_in: torch.Tensor) -> float:
 
 
 UNION_TILES = os.environ.get("PIT_UNION_TILES", "auto")      # "auto" (probe per kind of plan), "0", "1"
+UNION_DV = os.environ.get("PIT_UNION_DV", "auto")            # d(values) of union-tile layers: "auto", "lists" (transposed lists)
 _UNION_DECISIONS = {}
 ATT_UNION = 0x2000                                           # PIT_ATT_UNION
 
@@ -489,13 +490,32 @@ class MeshPlan:
         if self.masked or not self.self_attn:
             self.stats = torch.empty((3, self.mesh_batch, self.n_out), device=mesh_out.device, dtype=torch.float32)
         if cap:
-            self._build_lists(cap)                                      # selection + lists in one pass
+            self._build_lists(cap, self._wants_reverse_lists(cap))      # selection + lists in one pass
         elif self.stats is not None:
             rc = _lib.lib().pit_select_fwd(self.mesh_out.data_ptr(), self.mesh_in.data_ptr(), self.mesh_batch,
                                            self.n_out, self.n_in, self.sdim, self.metric_id, self.period,
                                            self.rank_k, 1 if self.masked else 0, self.stats.data_ptr(),
                                            _lib.stream_ptr())
             _lib.check(rc, "pit_select_fwd")
+
+    def _union_key(self, cap):
+        return (self.metric, self.n_out, self.n_in, cap, self.mesh_batch > 1, self.sdim)
+
+    def _wants_reverse_lists(self, cap: int) -> bool:
+        """The transposed lists (key -> rows) serve d(values) of the candidate-list kernels.  A plan of a kind already
+        decided for the union-tile kernels skips them (~90 us of a NACA step): its d(values) comes from the tiles
+        (posatt_union_dv_kernel: LDS accumulators, then fp32 atomic adds to memory - sums that differ in the last bits from
+        run to run, so not under torch.use_deterministic_algorithms, nor with PIT_UNION_DV=lists).  A backward that cannot
+        take the union form after all builds them on demand (ensure_reverse_lists)."""
+        if UNION_DV == "lists" or UNION_TILES == "0" or self.self_attn or self.mesh_batch == 1:
+            return True
+        if torch.are_deterministic_algorithms_enabled() or self.n_in > 4096 or self.n_out < 16 or cap > 64:
+            return True
+        return not (UNION_TILES == "1" or _UNION_DECISIONS.get(self._union_key(cap)) is True)
+
+    def ensure_reverse_lists(self) -> None:
+        if self.nbr_idx is not None and self.rev_ptr is None:
+            self._build_lists(self.nbr_cap, True)
 
     def union_tiles(self) -> bool:
         """Round 4: do the masked-layer kernels take the UNION-TILE form (PIT_ATT_UNION) for this plan?  They contract 16
@@ -513,7 +533,7 @@ class MeshPlan:
         if UNION_TILES == "1":
             self._union = True
             return True
-        key = (self.metric, self.n_out, self.n_in, self.nbr_cap, self.mesh_batch > 1, self.sdim)
+        key = self._union_key(self.nbr_cap)
         hit = _UNION_DECISIONS.get(key)
         if hit is None:
             if torch.cuda.is_current_stream_capturing():
@@ -546,8 +566,8 @@ class MeshPlan:
             self._complete = int(bool((self.nbr_cnt <= self.nbr_cap).all().item()))
         return self._complete
 
-    def _build_lists(self, cap: int) -> None:
-        """Order statistics, candidate lists (row -> keys) and their transpose (key -> rows) for the
+    def _build_lists(self, cap: int, reverse: bool = True) -> None:
+        """Order statistics, candidate lists (row -> keys) and - with `reverse` - their transpose (key -> rows) for the
         sparse kernels, one pass over the rows (pit_plan_fwd)."""
         dev = self.mesh_out.device
         rows = self.mesh_batch * self.n_out
@@ -555,13 +575,15 @@ class MeshPlan:
         self.nbr_cap = cap
         self.nbr_idx = torch.empty((rows, cap), device=dev, dtype=torch.int32)
         self.nbr_cnt = torch.empty((rows,), device=dev, dtype=torch.int32)
-        self.rev_ptr = torch.empty((self.mesh_batch, self.n_in + 1), device=dev, dtype=torch.int32)
-        self.rev_row = torch.empty((self.mesh_batch, self.n_out * cap), device=dev, dtype=torch.int32)
-        work = torch.empty((2 * self.mesh_batch * self.n_in,), device=dev, dtype=torch.int32)
+        work = None
+        if reverse:
+            self.rev_ptr = torch.empty((self.mesh_batch, self.n_in + 1), device=dev, dtype=torch.int32)
+            self.rev_row = torch.empty((self.mesh_batch, self.n_out * cap), device=dev, dtype=torch.int32)
+            work = torch.empty((2 * self.mesh_batch * self.n_in,), device=dev, dtype=torch.int32)
         rc = L.pit_plan_fwd(self.mesh_out.data_ptr(), self.mesh_in.data_ptr(), self.mesh_batch, self.n_out,
                             self.n_in, self.sdim, self.metric_id, self.period, self.rank_k, self.stats.data_ptr(), cap,
-                            self.nbr_idx.data_ptr(), self.nbr_cnt.data_ptr(), self.rev_ptr.data_ptr(),
-                            self.rev_row.data_ptr(), work.data_ptr(), _lib.stream_ptr())
+                            self.nbr_idx.data_ptr(), self.nbr_cnt.data_ptr(), _lib.ptr(self.rev_ptr),
+                            _lib.ptr(self.rev_row), _lib.ptr(work), _lib.stream_ptr())
         _lib.check(rc, "pit_plan_fwd")
 
 
@@ -586,7 +608,7 @@ class _PosAtt(torch.autograd.Function):
         ctx.coord_dims = int(coord_dims)
         # masked layer over a coherently ordered mesh: the union-tile kernels (decided per kind of plan, MeshPlan.union_tiles)
         ctx.union = ATT_UNION if (plan.masked and plan.nbr_idx is not None and not coord_dims and n_head <= 2
-                                  and plan.union_tiles()) else 0
+                                  and values.shape[-1] % 8 == 0 and plan.union_tiles()) else 0
         # (the concat buffer arrives in a one-element list, not as a tensor argument: a tensor that is both an
         # input and the returned output would be re-materialised by autograd with a full copy)
         out_buf = out_slot[0].detach() if out_slot else None
@@ -640,6 +662,14 @@ class _PosAtt(torch.autograd.Function):
         _need_gpu_bf16_ok(d_out)
         io = IO_DOUT_BF16 if d_out.dtype == torch.bfloat16 else 0
         need_v, need_h = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        union = ctx.union
+        if union:                                       # (the kernels' 16-byte row pieces: csrc/pit_posatt.hip union_ok / aligned_rows)
+            k = 8 if io else 4
+            if (values.data_ptr() | d_out.data_ptr()) % 16 or values.stride(1) % 4 or values.stride(0) % 4 \
+                    or d_out.stride(1) % k or d_out.stride(0) % k:
+                union = 0
+        if need_v and not union:
+            plan.ensure_reverse_lists()                 # (a plan built for the union-tile form has none)
         d_values = torch.empty((b, j, dv), device=values.device, dtype=torch.float32) if need_v else None
         slot = _grad_slot(ctx.head_param) if need_h else None
         if slot is not None:
@@ -674,7 +704,7 @@ class _PosAtt(torch.autograd.Function):
                 _lib.ptr(plan.nbr_idx), _lib.ptr(plan.nbr_cnt), plan.nbr_cap, plan.lists_complete(),
                 _lib.ptr(plan.rev_ptr), _lib.ptr(plan.rev_row),
                 ctypes.cast(ctypes.pointer(job[0]), ctypes.c_void_p) if job is not None else None,
-                ctx.coord_dims, ctx.math | io | ctx.union, stream_ptr)
+                ctx.coord_dims, ctx.math | io | union, stream_ptr)
             _lib.check(rc, "pit_posatt_bwd")
 
         if OVERLAP_BACKWARD and slot is not None:

@@ -320,3 +320,38 @@ def test_union_tile_decision_is_made_per_kind_of_plan_and_never_for_shared_meshe
     finally:
         ops.UNION_TILES = old
         ops._UNION_DECISIONS.clear()
+
+
+def test_union_tile_plans_carry_transposed_lists_only_when_a_backward_needs_them():
+    """A plan of a kind decided for the union tiles is built without the transposed lists (d(values) comes from the tiles);
+    deterministic mode keeps them; a layer the union kernels cannot take (width not a multiple of 8) builds them on demand."""
+    from position_induced_transformer_amd import ops
+    old, ops.UNION_TILES = ops.UNION_TILES, "auto"
+    try:
+        ops._UNION_DECISIONS.clear()
+        mo, mi = _grid_meshes(2, 40, 40, 200, seed=7)
+        first = ops.MeshPlan("euclid", mo.cuda(), mi.cuda(), 0.05, False)
+        assert first.rev_ptr is not None and first.union_tiles()          # (the probing plan has them)
+        plan = ops.MeshPlan("euclid", mo.cuda(), mi.cuda(), 0.05, False)
+        assert plan.rev_ptr is None and plan.union_tiles()
+        torch.use_deterministic_algorithms(True)
+        try:
+            assert ops.MeshPlan("euclid", mo.cuda(), mi.cuda(), 0.05, False).rev_ptr is not None
+        finally:
+            torch.use_deterministic_algorithms(False)
+        g = torch.Generator().manual_seed(8)
+        for dim in (12, 16):
+            values = torch.randn(2, 200, dim, generator=g)
+            lmda = torch.tensor([0.3]).reshape(1, 1, 1)
+            d_out = torch.randn(2, 1600, dim, generator=g)
+            v0 = values.clone().requires_grad_(True); l0 = lmda.clone().requires_grad_(True)
+            orc.posatt_cross("euclid", True, mo, mi, v0, l0, 0.05).backward(d_out)
+            plan = ops.MeshPlan("euclid", mo.cuda(), mi.cuda(), 0.05, False)
+            v1 = values.cuda().requires_grad_(True); l1 = lmda.cuda().reshape(-1).requires_grad_(True)
+            ops.posatt_apply(v1, l1, plan, 1, concat=False, head_is_scale=False).backward(d_out.cuda())
+            assert (plan.rev_ptr is None) == (dim == 16)
+            assert float((v1.grad.cpu() - v0.grad).norm() / v0.grad.norm()) <= 1e-5
+            assert float((l1.grad.cpu().reshape(-1) - l0.grad.reshape(-1)).norm() / l0.grad.norm()) <= 1e-4
+    finally:
+        ops.UNION_TILES = old
+        ops._UNION_DECISIONS.clear()
