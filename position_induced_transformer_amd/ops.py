@@ -1165,6 +1165,64 @@ def latent_fusion_supported(n_pts: int, n_head: int, dim: int, batch: int, n_lay
     return LATENT_FUSION and bool(_lib.lib().pit_latent_supported(int(n_pts), int(n_head), int(dim), int(batch), int(n_layers)))
 
 
+# The fused processor's softmax weights depend on the latent mesh and the lmda's only - not on the data: with
+# PIT_EARLY_WEIGHTS=1 pit.encoder starts their launch on a side stream BEFORE the down-projection and joins after it (inside
+# a captured step: a parallel branch of the hipGraph), taking the ~7 us launch out of the step's chain.  MEASURED SLOWER and
+# therefore off by default: a second branch makes the replayed graph pay cross-queue signalling on every edge into and out of
+# it - Darcy b=8 0.194 -> 0.222 ms/step, Burgers b=8 0.198 -> 0.230, Darcy b=16 0.270 -> 0.301 (same box, 300 steps; the
+# same finding as PIT_OVERLAP_BACKWARD above).  A straight chain of kernels is the fastest graph this runtime replays.
+EARLY_WEIGHTS = os.environ.get("PIT_EARLY_WEIGHTS", "0") != "0"
+
+
+class EarlyWeights:
+    """Weights of all blocks (pit_block_weights) in flight on the side stream; join() before anything reads them."""
+    __slots__ = ("key", "E", "Q", "inv", "rowstat", "scale", "event")
+
+    def join(self) -> None:
+        torch.cuda.current_stream(self.E.device).wait_event(self.event)
+
+
+def _weights_key(plan: MeshPlan, lmdas, scales, n_head: int):
+    return (id(plan), n_head, _PARAM_EPOCH[0], scales is not None,
+            tuple((p._version, p.data_ptr()) for p in lmdas), tuple(t.data_ptr() for t in scales) if scales is not None else None)
+
+
+def _launch_block_weights(plan: MeshPlan, kheads, is_scale: bool, n_head: int, need_q: bool, stream_ptr):
+    n, L, dev = len(kheads), plan.n_in, plan.mesh_in.device
+    E = torch.empty((n, n_head, L, L), device=dev, dtype=torch.float32)
+    # (Q, the d(scale) weights, is only read by the backward: not formed under no_grad / in eval)
+    Q = torch.empty((n, n_head, L, L), device=dev, dtype=torch.float32) if need_q else None
+    inv = torch.empty((n, n_head, L), device=dev, dtype=torch.float32)
+    rowstat = torch.empty((n, n_head, L, 4), device=dev, dtype=torch.float32)
+    scale = torch.empty((n, n_head), device=dev, dtype=torch.float32)
+    hp = (ctypes.c_void_p * n)(*[t.data_ptr() for t in kheads])
+    rc = _lib.lib().pit_block_weights(plan.mesh_in.data_ptr(), L, plan.sdim, plan.metric_id, plan.period, n, hp,
+                                      1 if is_scale else 0, n_head, E.data_ptr(), _lib.ptr(Q), inv.data_ptr(),
+                                      rowstat.data_ptr(), scale.data_ptr(), stream_ptr)
+    _lib.check(rc, "pit_block_weights")
+    return E, Q, inv, rowstat, scale
+
+
+def early_block_weights(plan: MeshPlan, lmdas, n_head: int, need_q: bool):
+    """Start pit_block_weights for processor_apply(x, plan, n_head, lmdas, ...) on the side stream.  The caller join()s the
+    returned handle on the same stream before its function ends (no work is left unjoined - a stream capture would refuse to
+    end) and hands it to processor_apply, which uses it when lmdas / scales are still the ones it was formed from."""
+    if not EARLY_WEIGHTS or not plan.mesh_in.is_cuda:
+        return None
+    scales = [host_head_scale(p) for p in lmdas] if get_head_scale_route() == "host" else None
+    heads = [t.detach().reshape(-1).contiguous() for t in lmdas]
+    dev = plan.mesh_in.device
+    side = _side_state(dev)["stream"]
+    side.wait_stream(torch.cuda.current_stream(dev))
+    ew = EarlyWeights()
+    ew.key = _weights_key(plan, lmdas, scales, n_head)
+    ew.E, ew.Q, ew.inv, ew.rowstat, ew.scale = _launch_block_weights(plan, scales if scales is not None else heads,
+                                                                     scales is not None, n_head, need_q, side.cuda_stream)
+    ew.event = torch.cuda.Event()
+    ew.event.record(side)
+    return ew
+
+
 class _Processor(torch.autograd.Function):
     """n_blocks x [posatt.forward -> kaiming_mlp -> gelu] (pit.py:114-122) on one batch-free latent mesh as ONE
     autograd node: the softmax weights of all blocks come from one launch (pit_block_weights: they depend on the mesh
@@ -1173,7 +1231,7 @@ class _Processor(torch.autograd.Function):
     MLP's weight-gradient reductions riding along).  Tensor inputs: x, lmda_0..n-1, then (w1, b1, w2, b2) per block."""
 
     @staticmethod
-    def forward(ctx, x, plan: MeshPlan, n_head: int, scales, params, *tensors):
+    def forward(ctx, x, plan: MeshPlan, n_head: int, scales, params, early, *tensors):
         n = len(tensors) // 5
         lmdas, mlps = tensors[:n], [tensors[n + 4 * i:n + 4 * i + 4] for i in range(n)]
         _need_gpu(x, *tensors)
@@ -1187,18 +1245,11 @@ class _Processor(torch.autograd.Function):
         ctx.math = 0
         heads = [t.detach().reshape(-1).contiguous() for t in lmdas]
         kheads = list(scales) if scales is not None else heads         # route 'host': the host-evaluated c is what the kernels get
-        E = torch.empty((n, H, L, L), device=dev, dtype=torch.float32)
-        # (Q, the d(scale) weights, is only read by the backward: not formed under no_grad / in eval)
         need_q = any(ctx.needs_input_grad)
-        Q = torch.empty((n, H, L, L), device=dev, dtype=torch.float32) if need_q else None
-        inv = torch.empty((n, H, L), device=dev, dtype=torch.float32)
-        rowstat = torch.empty((n, H, L, 4), device=dev, dtype=torch.float32)
-        scale = torch.empty((n, H), device=dev, dtype=torch.float32)
-        hp = (ctypes.c_void_p * n)(*[t.data_ptr() for t in kheads])
-        rc = L_.pit_block_weights(plan.mesh_in.data_ptr(), L, plan.sdim, plan.metric_id, plan.period, n, hp,
-                                  1 if scales is not None else 0, H, E.data_ptr(), _lib.ptr(Q), inv.data_ptr(),
-                                  rowstat.data_ptr(), scale.data_ptr(), _lib.stream_ptr())
-        _lib.check(rc, "pit_block_weights")
+        if early is not None and early.key == _weights_key(plan, params[0], scales, H) and (early.Q is not None or not need_q):
+            E, Q, inv, rowstat, scale = early.E, early.Q, early.inv, early.rowstat, early.scale   # (formed under the encoder)
+        else:
+            E, Q, inv, rowstat, scale = _launch_block_weights(plan, kheads, scales is not None, H, need_q, _lib.stream_ptr())
         buf0 = _concat_buffer_of(x, L, H)
         if buf0 is None:                       # the producer did not write into a concat buffer: one copy
             buf0 = torch.empty((b, L, W), device=dev, dtype=torch.float32)
@@ -1349,7 +1400,7 @@ class _Processor(torch.autograd.Function):
             nh = (ctypes.c_int * m)(*[H] * m)
             fl = (ctypes.c_int * m)(*[1 if lm_slots[i] is not None else 0 for i in now])
             _lib.check(L_.pit_posatt_dhead_finish(m, ws, dh, hd, sc, nh, fl, _lib.stream_ptr()), "pit_posatt_dhead_finish")
-        grads = [dx, None, None, None, None]
+        grads = [dx, None, None, None, None, None]
         for i in range(n):
             g = None if lm_slots[i] is not None else d_heads[i]
             grads.append(g)
@@ -1365,14 +1416,15 @@ class _Processor(torch.autograd.Function):
 
 
 @torch.compiler.disable
-def processor_apply(x: torch.Tensor, plan: MeshPlan, n_head: int, lmdas, mlps) -> torch.Tensor:
+def processor_apply(x: torch.Tensor, plan: MeshPlan, n_head: int, lmdas, mlps, early=None) -> torch.Tensor:
     """The whole processor (pit.py:114-122) on a batch-free mesh through the fused block kernels.  ``lmdas``: the
-    blocks' lmda parameters; ``mlps``: per block (w1, b1, w2, b2).  The caller checked block_fusion_supported()."""
+    blocks' lmda parameters; ``mlps``: per block (w1, b1, w2, b2); ``early``: early_block_weights(...) of the same plan and
+    lmdas, already joined.  The caller checked block_fusion_supported()."""
     scales = None
     if get_head_scale_route() == "host":
         scales = [host_head_scale(p) for p in lmdas]
     flat = [p.reshape(-1) for p in lmdas] + [t for m in mlps for t in m]
-    return _Processor.apply(x, plan, n_head, scales, (tuple(lmdas), tuple(tuple(m) for m in mlps)), *flat)
+    return _Processor.apply(x, plan, n_head, scales, (tuple(lmdas), tuple(tuple(m) for m in mlps)), early, *flat)
 
 
 class _RelLpLoss(torch.autograd.Function):

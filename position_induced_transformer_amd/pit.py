@@ -281,20 +281,43 @@ class pit(nn.Module):
         self.up = cross_cls(self.n_head, self.hid_dim, self.de_local)
 
     def encoder(self, mesh_in, func_in, mesh_ltt):
+        # the fused processor's weights depend on (mesh_ltt, lmda) only: their launch runs on a side stream under the
+        # down-projection and is joined before this function returns (ops.early_block_weights); processor() picks them up
+        early = None
+        if ops.EARLY_WEIGHTS and torch.is_tensor(func_in) and func_in.is_cuda and func_in.dim() >= 2:
+            plan = self._fused_plan(mesh_ltt, func_in.shape[0], self.hid_dim, func_in.device)
+            if plan is not None:
+                need_q = torch.is_grad_enabled() and (func_in.requires_grad or any(q.requires_grad for q in self.parameters()))
+                early = ops.early_block_weights(plan, [a.lmda for a in self.conv], self.conv[0].n_head, need_q)
         func_ltt = self.down(mesh_ltt, mesh_in, func_in)
+        self.__dict__["_early_weights"] = early
+        if early is not None:
+            early.join()
         return self._mlp_gelu(self.en_layer, func_ltt, self._heads_of_block(0, self.hid_dim))
 
     def _fused_processor(self, func_ltt, mesh_ltt):
         """The fused block kernels (ops.processor_apply) when every block is one of OUR batch-free self-attention
         layers followed by a kaiming_mlp of the standard shape, nothing is hooked or overridden and the shape is in
         the small regime; None = run the blocks one by one."""
+        early = self.__dict__.pop("_early_weights", None)
+        if not (func_ltt.is_cuda and func_ltt.dim() == 3 and func_ltt.dtype == torch.float32):
+            return None
+        plan = self._fused_plan(mesh_ltt, func_ltt.shape[0], func_ltt.shape[-1], func_ltt.device, func_ltt.shape[1])
+        if plan is None:
+            return None
+        return ops.processor_apply(func_ltt, plan, self.conv[0].n_head, [a.lmda for a in self.conv],
+                                   [(w.mlp1.weight, w.mlp1.bias, w.mlp2.weight, w.mlp2.bias) for w in self.mlp], early=early)
+
+    def _fused_plan(self, mesh_ltt, batch, hid, device, n_pts=None):
+        """The latent mesh plan of the fused processor for activations (batch, n_pts, hid) on `device`, or None when the
+        blocks have to run one by one."""
         n = len(self.conv)
         # (pit_block_weights forms the weights of at most 16 blocks in its one launch: deeper processors - the reference accepts
         # any n_blocks - run block by block)
         if not (ops.BLOCK_FUSION and 0 < n <= ops.BLOCK_MAX_LAYERS and n == len(self.mlp) and torch.is_tensor(mesh_ltt) and mesh_ltt.dim() == 2
-                and func_ltt.is_cuda and func_ltt.dim() == 3 and func_ltt.dtype == torch.float32):
+                and device.type == "cuda" and mesh_ltt.device == device):
             return None
-        hid, heads = func_ltt.shape[-1], self.conv[0].n_head
+        heads = self.conv[0].n_head
         kinds = (posatt_fixed, posatt_periodic1d, posatt_periodic2d)
         for a, w in zip(self.conv, self.mlp):
             if type(a) not in kinds or type(a) is not type(self.conv[0]) or a.locality != 1.0 or a.n_head != heads \
@@ -309,12 +332,9 @@ class pit(nn.Module):
                 if any(not getattr(f, "_pit_internal", False) for f in m._forward_hooks.values()) \
                         or m._forward_pre_hooks or m._backward_hooks or m._backward_pre_hooks:
                     return None
-        if mesh_ltt.shape[0] != func_ltt.shape[1] or not ops.block_fusion_supported(mesh_ltt.shape[0], heads, hid,
-                                                                                    func_ltt.shape[0]):
+        if (n_pts is not None and mesh_ltt.shape[0] != n_pts) or not ops.block_fusion_supported(mesh_ltt.shape[0], heads, hid, batch):
             return None
-        plan = self.conv[0]._plan(mesh_ltt, mesh_ltt, True)
-        return ops.processor_apply(func_ltt, plan, heads, [a.lmda for a in self.conv],
-                                   [(w.mlp1.weight, w.mlp1.bias, w.mlp2.weight, w.mlp2.bias) for w in self.mlp])
+        return self.conv[0]._plan(mesh_ltt, mesh_ltt, True)
 
     def _precomputed_weights(self, func_ltt, mesh_ltt):
         """Large regime, batch-free meshes (round 4): the softmax weights of every block - functions of (mesh_ltt, lmda) only -

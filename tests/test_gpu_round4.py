@@ -355,3 +355,34 @@ def test_union_tile_plans_carry_transposed_lists_only_when_a_backward_needs_them
     finally:
         ops.UNION_TILES = old
         ops._UNION_DECISIONS.clear()
+
+
+def test_processor_weights_formed_early_on_the_side_stream_are_the_same_weights():
+    """ops.EARLY_WEIGHTS (opt-in: measured slower inside a replayed graph): pit.encoder forms the fused processor's softmax
+    weights on a side stream under the down-projection; the forward is bit-identical to the default order, also when it is
+    captured and replayed, the gradients equal up to the summation order of the weight-gradient atomics."""
+    from position_induced_transformer_amd import ops, tasks, utils
+    model, sample, meta = tasks.make_task("darcy", seed=31)
+    mesh_in, func_in, mesh_out, target = sample(4)
+    loss_fn = utils.RelLpNorm(1, 2)
+
+    def run():
+        model.zero_grad(set_to_none=True)
+        out = model(mesh_in, func_in, mesh_out)
+        loss_fn(target, out).backward()
+        return out.detach().clone(), [p.grad.clone() for p in model.parameters()]
+    ref_out, ref_grads = run()
+    old, ops.EARLY_WEIGHTS = ops.EARLY_WEIGHTS, True
+    try:
+        out, grads = run()
+        assert torch.equal(out, ref_out)
+        for a, b in zip(grads, ref_grads):                 # (weight-gradient reductions add with atomics: order-dependent last bits)
+            assert float((a - b).norm()) <= 1e-5 * float(b.norm()) + 1e-12
+        g = torch.cuda.CUDAGraph()
+        run(); torch.cuda.synchronize()
+        with torch.no_grad(), torch.cuda.graph(g):
+            o2 = model(mesh_in, func_in, mesh_out)
+        g.replay(); torch.cuda.synchronize()
+        assert torch.equal(o2, ref_out)
+    finally:
+        ops.EARLY_WEIGHTS = old
