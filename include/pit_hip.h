@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PIT_ABI_VERSION 15
+#define PIT_ABI_VERSION 16
 #define PIT_DSCALE_SLOTS 1024 /* fp64 accumulators per head in pit_posatt_bwd's workspace */
 
 /* distance metric (dist2att variants) */
@@ -149,6 +149,25 @@ int pit_posatt_fwd(const float* mesh_out, const float* mesh_in, int mesh_batch, 
                    float* out, long ld_out, long out_bstride, int out_col0, int copy_inputs,
                    float* rowstat, float* scale_out,
                    const int* nbr_idx, const int* nbr_cnt, int nbr_cap, int coord_dims, int math_mode, void* stream);
+
+/* pit_posatt_fwd with a RIDER (round 4): the processor's block weights (pit_block_weights, declared below - they depend on
+ * the latent mesh and the lmda's only, not on this layer's data) formed by extra workgroups of the SAME launch when this
+ * layer runs on the small candidate-list kernel (the down-projection of the small regime), by a launch of their own
+ * right after it otherwise.  job == NULL: exactly pit_posatt_fwd.  The job's fields are pit_block_weights' arguments. */
+struct pit_block_weights_job {
+    const float* mesh; int n_pts, space_dim, metric; float period;
+    int n_layers; const float* const* heads; int head_is_scale, n_head;
+    float *e, *q, *inv, *rowstat, *scale_out;
+};
+int pit_posatt_fwd_job(const float* mesh_out, const float* mesh_in, int mesh_batch, int n_out, int n_in,
+                       int space_dim, int metric, float period,
+                       const float* values, int batch, int dim, long ld_values, long values_bstride,
+                       const float* head, int n_head, int head_is_scale,
+                       const float* stats, float rank_w, int masked, int self_attn,
+                       float* out, long ld_out, long out_bstride, int out_col0, int copy_inputs,
+                       float* rowstat, float* scale_out,
+                       const int* nbr_idx, const int* nbr_cnt, int nbr_cap, int coord_dims, int math_mode, void* stream,
+                       const struct pit_block_weights_job* job);
 
 /* Backward of pit_posatt_fwd (closed form; the reference uses
  * autograd).  d_out has the layout of `out` (columns out_col0 + h*dim + d).

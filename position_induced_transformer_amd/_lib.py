@@ -25,6 +25,13 @@ class MlpParamsJob(ctypes.Structure):
                 ("accumulate", _I), ("scratch", _P), ("math_mode", _I)]
 
 
+class BlockWeightsJob(ctypes.Structure):
+    """pit_block_weights_job of include/pit_hip.h (the argument list of pit_block_weights)."""
+    _fields_ = [("mesh", _P), ("n_pts", _I), ("space_dim", _I), ("metric", _I), ("period", _F),
+                ("n_layers", _I), ("heads", _P), ("head_is_scale", _I), ("n_head", _I),
+                ("e", _P), ("q", _P), ("inv", _P), ("rowstat", _P), ("scale_out", _P)]
+
+
 # name -> argtypes, mirrors include/pit_hip.h one to one
 SIGNATURES = {
     "pit_version": [],
@@ -39,6 +46,12 @@ SIGNATURES = {
                        _P, _F, _I, _I,
                        _P, _L, _L, _I, _I,
                        _P, _P, _P, _P, _I, _I, _I, _P],
+    "pit_posatt_fwd_job": [_P, _P, _I, _I, _I, _I, _I, _F,
+                           _P, _I, _I, _L, _L,
+                           _P, _I, _I,
+                           _P, _F, _I, _I,
+                           _P, _L, _L, _I, _I,
+                           _P, _P, _P, _P, _I, _I, _I, _P, _P],
     "pit_posatt_bwd": [_P, _P, _I, _I, _I, _I, _I, _F,
                        _P, _I, _I, _L, _L,
                        _P, _I, _I, _P,
@@ -75,7 +88,7 @@ SIGNATURES = {
     "pit_debug_mfma_tile": [_P, _P, _P, _P],
 }
 
-ABI_VERSION = 15       # PIT_ABI_VERSION of include/pit_hip.h this binding was written against
+ABI_VERSION = 16       # PIT_ABI_VERSION of include/pit_hip.h this binding was written against
 
 _lib = None
 

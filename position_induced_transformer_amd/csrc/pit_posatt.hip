@@ -21,6 +21,7 @@
 // (SURVEY appendix B rearranged so that it is column-separable and centred:
 // mbar_n = sum_j P m is saved by the forward), accumulated in fp64.
 #include "pit_common.h"
+#include "pit_block_dev.h"      // block_weights_body: the processor's weights as a rider of the down-projection launch
 #include "pit_gemm_rd.h"
 #include <cstdlib>
 #include <type_traits>
@@ -2838,13 +2839,36 @@ __global__ __launch_bounds__(256, 4) void posatt_sparse_rows_dw(AttArgs a, Spars
 
 constexpr size_t DW_SMEM_4WAVES = 4 * 16 * 64 * sizeof(float);   // gemm_rd_body's parking area, 256-thread workgroups
 
+// forward of a (small) candidate-list layer with the processor's block weights formed by extra workgroups of the launch
+// (pit_posatt_fwd_job: they depend on the latent mesh and the lmda's only - one launch less in the step's chain)
+template <int NH, int CR>
+__global__ __launch_bounds__(256, 4) void posatt_sparse_rows_w(AttArgs a, SparseArgs sp, int gx, int gy, int n_att, WeightsArgs w) {
+    const int id = blockIdx.x;
+    if (id >= n_att) {                                   // (last: the attention rows are the longer chains)
+        block_weights_body(w, id - n_att);
+        return;
+    }
+    sparse_rows_body<NH, CR, 0>(a, sp, id % gx, (id / gx) % gy, id / (gx * gy));
+}
+
 template <int MODE>
 void launch_sparse_rows(const AttArgs& a, const SparseArgs& sp, hipStream_t s, const pit_mlp_params_job* job = nullptr,
-                        bool* rider_done = nullptr) {
+                        bool* rider_done = nullptr, const WeightsArgs* wjob = nullptr) {
     const int nh = (a.n_head % 2 == 0) ? 2 : 1;
     const long rows = (long)a.mesh_batch * a.n_out;
     const int cr = cr_for(a.ncols, rows * (a.n_head / nh));
     dim3 grid((unsigned)((rows + 3) / 4), (a.ncols + 64 * cr - 1) / (64 * cr), a.n_head / nh), block(256);
+    if (MODE == 0 && wjob && (long)grid.x * grid.y * grid.z <= 4096) {       // small launch: carry the processor's weights
+        const int n_att = (int)(grid.x * grid.y * grid.z);
+        dim3 gridw((unsigned)(n_att + block_weights_wgs(wjob->n_layers, wjob->n_head, wjob->L)));
+#define PIT_SRW(NH_, CR_) hipLaunchKernelGGL((posatt_sparse_rows_w<NH_, CR_>), gridw, block, 0, s, a, sp, (int)grid.x, (int)grid.y, n_att, *wjob)
+#define PIT_SRW_CR(NH_) do { if (cr == 8) PIT_SRW(NH_, 8); else if (cr == 4) PIT_SRW(NH_, 4); else if (cr == 2) PIT_SRW(NH_, 2); else PIT_SRW(NH_, 1); } while (0)
+        if (nh == 2) PIT_SRW_CR(2); else PIT_SRW_CR(1);
+#undef PIT_SRW_CR
+#undef PIT_SRW
+        *rider_done = true;
+        return;
+    }
     pit_detail::DwPair dw;
     const pit_detail::DwPair* rider = &dw;
     if (MODE == 1 && job && (long)grid.x * grid.y * grid.z <= 16384 && pit_detail::plan_dw_pair(*job, 4, &dw)) {   // small launch: carry the reductions
@@ -3116,7 +3140,37 @@ extern "C" int pit_posatt_fwd(const float* mesh_out, const float* mesh_in, int m
                               float* rowstat, float* scale_out,
                               const int* nbr_idx, const int* nbr_cnt, int nbr_cap, int coord_dims, int math_mode,
                               void* stream) {
+    return pit_posatt_fwd_job(mesh_out, mesh_in, mesh_batch, n_out, n_in, space_dim, metric, period, values, batch, dim, ld_values,
+                              values_bstride, head, n_head, head_is_scale, stats, rank_w, masked, self_attn, out, ld_out,
+                              out_bstride, out_col0, copy_inputs, rowstat, scale_out, nbr_idx, nbr_cnt, nbr_cap, coord_dims,
+                              math_mode, stream, nullptr);
+}
+
+extern "C" int pit_posatt_fwd_job(const float* mesh_out, const float* mesh_in, int mesh_batch, int n_out, int n_in,
+                                  int space_dim, int metric, float period,
+                                  const float* values, int batch, int dim, long ld_values, long values_bstride,
+                                  const float* head, int n_head, int head_is_scale,
+                                  const float* stats, float rank_w, int masked, int self_attn,
+                                  float* out, long ld_out, long out_bstride, int out_col0, int copy_inputs,
+                                  float* rowstat, float* scale_out,
+                                  const int* nbr_idx, const int* nbr_cnt, int nbr_cap, int coord_dims, int math_mode,
+                                  void* stream, const pit_block_weights_job* job) {
     PIT_ENTER_MATH(math_mode);
+    // the rider: inside the attention launch when that is the small candidate-list kernel, else a launch of its own after the
+    // attention's (not at all when this call fails)
+    WeightsArgs wargs;
+    bool wdone = job == nullptr;
+    if (job) {
+        if (int rcw = fill_weights_args(wargs, job->mesh, job->n_pts, job->space_dim, job->metric, job->period, job->n_layers,
+                                        job->heads, job->head_is_scale, job->n_head, job->e, job->q, job->inv, job->rowstat,
+                                        job->scale_out)) return rcw;
+    }
+    auto finish = [&]() -> int {
+        if (wdone) return 0;
+        wdone = true;
+        return pit_block_weights(job->mesh, job->n_pts, job->space_dim, job->metric, job->period, job->n_layers, job->heads,
+                                 job->head_is_scale, job->n_head, job->e, job->q, job->inv, job->rowstat, job->scale_out, stream);
+    };
     AttArgs a;
     int rc = fill_common(a, mesh_out, mesh_in, mesh_batch, n_out, n_in, space_dim, metric, period, values, batch,
                          dim, ld_values, values_bstride, head, n_head, head_is_scale, coord_dims);
@@ -3141,7 +3195,7 @@ extern "C" int pit_posatt_fwd(const float* mesh_out, const float* mesh_in, int m
             }
             launch_union<0>(a, spu, (hipStream_t)stream);
             PIT_CHECK_LAUNCH();
-            return 0;
+            return finish();
         }
     }
     if (nbr_idx && nbr_cnt && masked) {
@@ -3151,12 +3205,12 @@ extern "C" int pit_posatt_fwd(const float* mesh_out, const float* mesh_in, int m
             if (int rc2 = pit_head_scale(head, n_head, scale_out, stream)) return rc2;
             a.head = scale_out; a.head_is_scale = 1;
         }
-        launch_sparse_rows<0>(a, sp, (hipStream_t)stream);
+        launch_sparse_rows<0>(a, sp, (hipStream_t)stream, nullptr, &wdone, job ? &wargs : nullptr);
     } else {
         launch_rows<0>(a, (hipStream_t)stream);
     }
     PIT_CHECK_LAUNCH();
-    return 0;
+    return finish();
 }
 
 extern "C" int pit_posatt_bwd(const float* mesh_out, const float* mesh_in, int mesh_batch, int n_out, int n_in,

@@ -636,7 +636,10 @@ class _PosAtt(torch.autograd.Function):
         # route 'host': `head` is lmda (autograd's input, the chain rule of the backward) but the kernels are
         # handed the scale c the host evaluated for it (scale_in); the backward gets it back through `scale`
         k_head, k_is_scale = (scale_in, True) if scale_in is not None else (head, head_is_scale)
-        rc = _lib.lib().pit_posatt_fwd(
+        wjob = getattr(_STEP, "fwd_job", None)             # the processor's weights riding in this launch (early_block_weights)
+        if wjob is not None:
+            _STEP.fwd_job = None
+        rc = _lib.lib().pit_posatt_fwd_job(
             plan.mesh_out.data_ptr(), plan.mesh_in.data_ptr(), plan.mesh_batch, plan.n_out, plan.n_in, plan.sdim,
             plan.metric_id, plan.period,
             values.data_ptr(), b, d, values.stride(1), values.stride(0),
@@ -645,7 +648,8 @@ class _PosAtt(torch.autograd.Function):
             out.data_ptr(), out.stride(1), out.stride(0), d if concat else 0, copy_inputs,
             rowstat.data_ptr(), scale.data_ptr(),
             _lib.ptr(plan.nbr_idx), _lib.ptr(plan.nbr_cnt), plan.nbr_cap, ctx.coord_dims,
-            ctx.math | (IO_OUT_BF16 if out_bf16 else 0) | ctx.union, _lib.stream_ptr())
+            ctx.math | (IO_OUT_BF16 if out_bf16 else 0) | ctx.union, _lib.stream_ptr(),
+            ctypes.cast(ctypes.pointer(wjob.job), ctypes.c_void_p) if wjob is not None else None)
         _lib.check(rc, "pit_posatt_fwd")
         ctx.plan, ctx.n_head, ctx.concat, ctx.head_is_scale = plan, n_head, concat, head_is_scale
         ctx.head_param = head_param
@@ -1165,21 +1169,34 @@ def latent_fusion_supported(n_pts: int, n_head: int, dim: int, batch: int, n_lay
     return LATENT_FUSION and bool(_lib.lib().pit_latent_supported(int(n_pts), int(n_head), int(dim), int(batch), int(n_layers)))
 
 
-# The fused processor's softmax weights depend on the latent mesh and the lmda's only - not on the data: with
-# PIT_EARLY_WEIGHTS=1 pit.encoder starts their launch on a side stream BEFORE the down-projection and joins after it (inside
-# a captured step: a parallel branch of the hipGraph), taking the ~7 us launch out of the step's chain.  MEASURED SLOWER and
-# therefore off by default: a second branch makes the replayed graph pay cross-queue signalling on every edge into and out of
-# it - Darcy b=8 0.194 -> 0.222 ms/step, Burgers b=8 0.198 -> 0.230, Darcy b=16 0.270 -> 0.301 (same box, 300 steps; the
-# same finding as PIT_OVERLAP_BACKWARD above).  A straight chain of kernels is the fastest graph this runtime replays.
-EARLY_WEIGHTS = os.environ.get("PIT_EARLY_WEIGHTS", "0") != "0"
+# The fused processor's softmax weights (pit_block_weights) depend on the latent mesh and the lmda's only - not on the data -
+# so their launch need not sit in the step's chain between the encoder and the first block.  PIT_EARLY_WEIGHTS:
+#   "rider" (default)  extra workgroups of the down-projection's launch form them (pit_posatt_fwd_job: one launch less in the
+#                      chain); a down-projection that is not one of the small candidate-list launches gets them as a launch
+#                      of their own right after it - the order of round 3, one call earlier.
+#   "stream"           a side stream under the down-projection, joined before the encoder returns (inside a captured step: a
+#                      parallel branch of the hipGraph).  MEASURED SLOWER: a second branch makes the replayed graph pay
+#                      cross-queue signalling on the edges into and out of it - Darcy b=8 0.194 -> 0.222 ms/step, Burgers
+#                      b=8 0.198 -> 0.230, Darcy b=16 0.270 -> 0.301 (same box, 300 steps; the same finding as
+#                      PIT_OVERLAP_BACKWARD above).  A straight chain of kernels is the fastest graph this runtime replays.
+#   "0"                formed by _Processor.forward itself (round 3).
+EARLY_WEIGHTS = os.environ.get("PIT_EARLY_WEIGHTS", "rider")
 
 
 class EarlyWeights:
-    """Weights of all blocks (pit_block_weights) in flight on the side stream; join() before anything reads them."""
-    __slots__ = ("key", "E", "Q", "inv", "rowstat", "scale", "event")
+    """Weights of all blocks (pit_block_weights) requested before the processor runs; join() before anything reads them."""
+    __slots__ = ("key", "E", "Q", "inv", "rowstat", "scale", "event", "job", "keep")
 
     def join(self) -> None:
-        torch.cuda.current_stream(self.E.device).wait_event(self.event)
+        if self.event is not None:
+            torch.cuda.current_stream(self.E.device).wait_event(self.event)
+        elif getattr(_STEP, "fwd_job", None) is self:        # no attention launch took the job: a launch of its own, now
+            _STEP.fwd_job = None
+            j = self.job
+            rc = _lib.lib().pit_block_weights(j.mesh, j.n_pts, j.space_dim, j.metric, j.period, j.n_layers, j.heads,
+                                              j.head_is_scale, j.n_head, j.e, j.q, j.inv, j.rowstat, j.scale_out,
+                                              _lib.stream_ptr())
+            _lib.check(rc, "pit_block_weights")
 
 
 def _weights_key(plan: MeshPlan, lmdas, scales, n_head: int):
@@ -1187,16 +1204,22 @@ def _weights_key(plan: MeshPlan, lmdas, scales, n_head: int):
             tuple((p._version, p.data_ptr()) for p in lmdas), tuple(t.data_ptr() for t in scales) if scales is not None else None)
 
 
-def _launch_block_weights(plan: MeshPlan, kheads, is_scale: bool, n_head: int, need_q: bool, stream_ptr):
-    n, L, dev = len(kheads), plan.n_in, plan.mesh_in.device
+def _weights_buffers(plan: MeshPlan, n: int, n_head: int, need_q: bool):
+    L, dev = plan.n_in, plan.mesh_in.device
     E = torch.empty((n, n_head, L, L), device=dev, dtype=torch.float32)
     # (Q, the d(scale) weights, is only read by the backward: not formed under no_grad / in eval)
     Q = torch.empty((n, n_head, L, L), device=dev, dtype=torch.float32) if need_q else None
     inv = torch.empty((n, n_head, L), device=dev, dtype=torch.float32)
     rowstat = torch.empty((n, n_head, L, 4), device=dev, dtype=torch.float32)
     scale = torch.empty((n, n_head), device=dev, dtype=torch.float32)
+    return E, Q, inv, rowstat, scale
+
+
+def _launch_block_weights(plan: MeshPlan, kheads, is_scale: bool, n_head: int, need_q: bool, stream_ptr):
+    n = len(kheads)
+    E, Q, inv, rowstat, scale = _weights_buffers(plan, n, n_head, need_q)
     hp = (ctypes.c_void_p * n)(*[t.data_ptr() for t in kheads])
-    rc = _lib.lib().pit_block_weights(plan.mesh_in.data_ptr(), L, plan.sdim, plan.metric_id, plan.period, n, hp,
+    rc = _lib.lib().pit_block_weights(plan.mesh_in.data_ptr(), plan.n_in, plan.sdim, plan.metric_id, plan.period, n, hp,
                                       1 if is_scale else 0, n_head, E.data_ptr(), _lib.ptr(Q), inv.data_ptr(),
                                       rowstat.data_ptr(), scale.data_ptr(), stream_ptr)
     _lib.check(rc, "pit_block_weights")
@@ -1204,22 +1227,35 @@ def _launch_block_weights(plan: MeshPlan, kheads, is_scale: bool, n_head: int, n
 
 
 def early_block_weights(plan: MeshPlan, lmdas, n_head: int, need_q: bool):
-    """Start pit_block_weights for processor_apply(x, plan, n_head, lmdas, ...) on the side stream.  The caller join()s the
-    returned handle on the same stream before its function ends (no work is left unjoined - a stream capture would refuse to
-    end) and hands it to processor_apply, which uses it when lmdas / scales are still the ones it was formed from."""
-    if not EARLY_WEIGHTS or not plan.mesh_in.is_cuda:
+    """Request pit_block_weights for processor_apply(x, plan, n_head, lmdas, ...) BEFORE the layer in front of the processor
+    runs (modes: EARLY_WEIGHTS above).  The caller join()s the returned handle on the same stream before its function ends
+    (nothing is left pending or unjoined) and hands it to processor_apply, which uses it when lmdas / scales are still the ones
+    it was formed from."""
+    if EARLY_WEIGHTS not in ("rider", "stream") or not plan.mesh_in.is_cuda:
         return None
     scales = [host_head_scale(p) for p in lmdas] if get_head_scale_route() == "host" else None
     heads = [t.detach().reshape(-1).contiguous() for t in lmdas]
+    kheads = scales if scales is not None else heads
     dev = plan.mesh_in.device
-    side = _side_state(dev)["stream"]
-    side.wait_stream(torch.cuda.current_stream(dev))
     ew = EarlyWeights()
     ew.key = _weights_key(plan, lmdas, scales, n_head)
-    ew.E, ew.Q, ew.inv, ew.rowstat, ew.scale = _launch_block_weights(plan, scales if scales is not None else heads,
-                                                                     scales is not None, n_head, need_q, side.cuda_stream)
-    ew.event = torch.cuda.Event()
-    ew.event.record(side)
+    ew.event = ew.job = ew.keep = None
+    if EARLY_WEIGHTS == "stream":
+        side = _side_state(dev)["stream"]
+        side.wait_stream(torch.cuda.current_stream(dev))
+        ew.E, ew.Q, ew.inv, ew.rowstat, ew.scale = _launch_block_weights(plan, kheads, scales is not None, n_head, need_q,
+                                                                         side.cuda_stream)
+        ew.event = torch.cuda.Event()
+        ew.event.record(side)
+        return ew
+    n = len(kheads)
+    ew.E, ew.Q, ew.inv, ew.rowstat, ew.scale = _weights_buffers(plan, n, n_head, need_q)
+    hp = (ctypes.c_void_p * n)(*[t.data_ptr() for t in kheads])
+    ew.keep = (hp, kheads, plan)
+    ew.job = _lib.BlockWeightsJob(plan.mesh_in.data_ptr(), plan.n_in, plan.sdim, plan.metric_id, plan.period, n,
+                                  ctypes.cast(hp, ctypes.c_void_p), 1 if scales is not None else 0, n_head,
+                                  ew.E.data_ptr(), _lib.ptr(ew.Q), ew.inv.data_ptr(), ew.rowstat.data_ptr(), ew.scale.data_ptr())
+    _STEP.fwd_job = ew                       # the next attention forward of this thread carries it (_PosAtt.forward)
     return ew
 
 

@@ -281,10 +281,10 @@ class pit(nn.Module):
         self.up = cross_cls(self.n_head, self.hid_dim, self.de_local)
 
     def encoder(self, mesh_in, func_in, mesh_ltt):
-        # the fused processor's weights depend on (mesh_ltt, lmda) only: their launch runs on a side stream under the
-        # down-projection and is joined before this function returns (ops.early_block_weights); processor() picks them up
+        # the fused processor's weights depend on (mesh_ltt, lmda) only: they are formed by extra workgroups of the
+        # down-projection's launch (ops.early_block_weights) instead of a launch of their own; processor() picks them up
         early = None
-        if ops.EARLY_WEIGHTS and torch.is_tensor(func_in) and func_in.is_cuda and func_in.dim() >= 2:
+        if ops.EARLY_WEIGHTS != "0" and torch.is_tensor(func_in) and func_in.is_cuda and func_in.dim() >= 2:
             plan = self._fused_plan(mesh_ltt, func_in.shape[0], self.hid_dim, func_in.device)
             if plan is not None:
                 need_q = torch.is_grad_enabled() and (func_in.requires_grad or any(q.requires_grad for q in self.parameters()))

@@ -357,10 +357,12 @@ def test_union_tile_plans_carry_transposed_lists_only_when_a_backward_needs_them
         ops._UNION_DECISIONS.clear()
 
 
-def test_processor_weights_formed_early_on_the_side_stream_are_the_same_weights():
-    """ops.EARLY_WEIGHTS (opt-in: measured slower inside a replayed graph): pit.encoder forms the fused processor's softmax
-    weights on a side stream under the down-projection; the forward is bit-identical to the default order, also when it is
-    captured and replayed, the gradients equal up to the summation order of the weight-gradient atomics."""
+@pytest.mark.parametrize("mode", ["rider", "stream"])
+def test_processor_weights_requested_before_the_down_projection_are_the_same_weights(mode):
+    """ops.EARLY_WEIGHTS: pit.encoder has the fused processor's softmax weights formed by extra workgroups of the
+    down-projection's launch ("rider", the default) or on a side stream under it ("stream": measured slower inside a
+    replayed graph); the forward is bit-identical to forming them in front of the first block ("0"), also when it is captured
+    and replayed, the gradients equal up to the summation order of the weight-gradient atomics."""
     from position_induced_transformer_amd import ops, tasks, utils
     model, sample, meta = tasks.make_task("darcy", seed=31)
     mesh_in, func_in, mesh_out, target = sample(4)
@@ -371,9 +373,10 @@ def test_processor_weights_formed_early_on_the_side_stream_are_the_same_weights(
         out = model(mesh_in, func_in, mesh_out)
         loss_fn(target, out).backward()
         return out.detach().clone(), [p.grad.clone() for p in model.parameters()]
-    ref_out, ref_grads = run()
-    old, ops.EARLY_WEIGHTS = ops.EARLY_WEIGHTS, True
+    old, ops.EARLY_WEIGHTS = ops.EARLY_WEIGHTS, "0"
     try:
+        ref_out, ref_grads = run()
+        ops.EARLY_WEIGHTS = mode
         out, grads = run()
         assert torch.equal(out, ref_out)
         for a, b in zip(grads, ref_grads):                 # (weight-gradient reductions add with atomics: order-dependent last bits)
