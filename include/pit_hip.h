@@ -150,6 +150,30 @@ int pit_posatt_fwd(const float* mesh_out, const float* mesh_in, int mesh_batch, 
                    float* rowstat, float* scale_out,
                    const int* nbr_idx, const int* nbr_cnt, int nbr_cap, int coord_dims, int math_mode, void* stream);
 
+/* pit_posatt_bwd with the END-OF-PASS FINISH inside (round 4).  `fin` lists every layer whose d(scale) accumulators are loaded and
+ * waiting (pit_posatt_dhead_finish's arguments) INCLUDING this call's own layer at index `self` (its workspace / d_head / head /
+ * scale / flags: the values this call was given; this call must use PIT_HEAD_DEFER).  When this call is a d(scale)-only
+ * candidate-list launch of the small regime, extra workgroups of the launch drain the other layers' accumulators while the rows
+ * run and the LAST workgroup to arrive (device-side counter `counter`: one int, zero on entry, left zero) drains this layer's:
+ * *taken = 1 and no pit_posatt_dhead_finish launch is needed for the listed layers.  Otherwise *taken = 0 and the call behaves
+ * exactly like pit_posatt_bwd (the caller finishes later, as before).  fin == NULL: exactly pit_posatt_bwd. */
+struct pit_head_finish_job {
+    int n_layers; double* const* workspaces; float* const* d_heads; const float* const* heads; const float* const* scales;
+    const int* n_heads; const int* flags; int self; int* counter; int* taken;
+};
+struct pit_mlp_params_job;
+int pit_posatt_bwd_job(const float* mesh_out, const float* mesh_in, int mesh_batch, int n_out, int n_in,
+                       int space_dim, int metric, float period,
+                       const float* values, int batch, int dim, long ld_values, long values_bstride,
+                       const float* head, int n_head, int head_is_scale, const float* scale,
+                       const float* rowstat, int masked,
+                       const float* d_out, long ld_dout, long dout_bstride, int out_col0,
+                       float* d_values, long ld_dvalues, long dvalues_bstride, int add_residual,
+                       float* d_head, int accumulate_head, double* workspace,
+                       const int* nbr_idx, const int* nbr_cnt, int nbr_cap, int nbr_complete,
+                       const int* rev_ptr, const int* rev_row, const struct pit_mlp_params_job* rider,
+                       int coord_dims, int math_mode, void* stream, const struct pit_head_finish_job* fin);
+
 /* pit_posatt_fwd with a RIDER (round 4): the processor's block weights (pit_block_weights, declared below - they depend on
  * the latent mesh and the lmda's only, not on this layer's data) formed by extra workgroups of the SAME launch when this
  * layer runs on the small candidate-list kernel (the down-projection of the small regime), by a launch of their own

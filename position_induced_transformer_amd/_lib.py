@@ -25,6 +25,12 @@ class MlpParamsJob(ctypes.Structure):
                 ("accumulate", _I), ("scratch", _P), ("math_mode", _I)]
 
 
+class HeadFinishJob(ctypes.Structure):
+    """pit_head_finish_job of include/pit_hip.h (pit_posatt_dhead_finish's arguments + this layer's index, counter, result)."""
+    _fields_ = [("n_layers", _I), ("workspaces", _P), ("d_heads", _P), ("heads", _P), ("scales", _P), ("n_heads", _P),
+                ("flags", _P), ("self", _I), ("counter", _P), ("taken", _P)]
+
+
 class BlockWeightsJob(ctypes.Structure):
     """pit_block_weights_job of include/pit_hip.h (the argument list of pit_block_weights)."""
     _fields_ = [("mesh", _P), ("n_pts", _I), ("space_dim", _I), ("metric", _I), ("period", _F),
@@ -59,6 +65,13 @@ SIGNATURES = {
                        _P, _L, _L, _I,
                        _P, _L, _L, _I,
                        _P, _I, _P, _P, _P, _I, _I, _P, _P, _P, _I, _I, _P],
+    "pit_posatt_bwd_job": [_P, _P, _I, _I, _I, _I, _I, _F,
+                           _P, _I, _I, _L, _L,
+                           _P, _I, _I, _P,
+                           _P, _I,
+                           _P, _L, _L, _I,
+                           _P, _L, _L, _I,
+                           _P, _I, _P, _P, _P, _I, _I, _P, _P, _P, _I, _I, _P, _P],
     "pit_posatt_dhead_finish": [_I, _P, _P, _P, _P, _P, _P, _P],
     "pit_block_supported": [_I, _I, _I, _I],
     "pit_block_weights": [_P, _I, _I, _I, _F, _I, _P, _I, _I, _P, _P, _P, _P, _P, _P],

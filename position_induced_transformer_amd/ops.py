@@ -194,6 +194,51 @@ def _defer_head_begin(work: torch.Tensor) -> None:
         torch.autograd.Variable._execution_engine.queue_callback(lambda: _flush_head_finishes(task))
 
 
+# (opt-in: MEASURED SLOWER - the arrival counter, the fences and the last workgroup's fp64 drain of this layer's heads cost more
+# than the 4.6 us launch they replace: Darcy b=8 0.1885 -> 0.1908 ms/step, Burgers 0.1922 -> 0.1952, Sod 0.1268 -> 0.1263)
+FINISH_IN_LAUNCH = os.environ.get("PIT_FINISH_IN_LAUNCH", "0") != "0"
+_FINISH_COUNTERS = {}
+
+
+def _finish_job(device, work, d_head, head, scale, n_head: int, flags: int):
+    """pit_head_finish_job for the layers of this pass whose accumulators are loaded (deduplicated as _flush_head_finishes
+    does) plus the calling layer (`work`, ...); None when it cannot be formed.  Returns (struct, taken flag, keep-alive)."""
+    seen, ent = set(), []
+    for e in _PENDING_HEADS.get(_graph_task(), ()):
+        key = (e[0].data_ptr(), e[1].data_ptr())
+        if key not in seen:
+            seen.add(key)
+            ent.append(e)
+    mine = (work.data_ptr(), d_head.data_ptr())
+    if mine in seen:                                  # (this layer already ran in the pass: its entry stands for both)
+        me = [i for i, e in enumerate(ent) if (e[0].data_ptr(), e[1].data_ptr()) == mine][0]
+    else:
+        me = len(ent)
+        ent.append((work, d_head, head, scale, n_head, flags))
+    if len(ent) > 32 or any(e[0].device != device for e in ent):
+        return None
+    n = len(ent)
+    ws = (ctypes.c_void_p * n)(*[e[0].data_ptr() for e in ent])
+    dh = (ctypes.c_void_p * n)(*[e[1].data_ptr() for e in ent])
+    hd = (ctypes.c_void_p * n)(*[e[2].data_ptr() for e in ent])
+    sc = (ctypes.c_void_p * n)(*[e[3].data_ptr() for e in ent])
+    nh = (ctypes.c_int * n)(*[e[4] for e in ent])
+    fl = (ctypes.c_int * n)(*[e[5] for e in ent])
+    key = _ws_key(device)
+    counter = _FINISH_COUNTERS.get(key)
+    if counter is None:
+        if _capturing():
+            return None                               # (allocating and zeroing it needs a launch outside the graph's chain: first eager pass)
+        counter = _FINISH_COUNTERS[key] = torch.zeros(1, device=device, dtype=torch.int32)
+    if _capturing():
+        _pin(counter)
+    taken = ctypes.c_int(0)
+    c = lambda a: ctypes.cast(a, ctypes.c_void_p)
+    job = _lib.HeadFinishJob(n, c(ws), c(dh), c(hd), c(sc), c(nh), c(fl), me, counter.data_ptr(),
+                             ctypes.cast(ctypes.pointer(taken), ctypes.c_void_p))
+    return job, taken, (ws, dh, hd, sc, nh, fl, ent)
+
+
 def _defer_head_finish(work, d_head, head, scale, n_head: int, flags: int) -> None:
     _defer_head_begin(work)
     _PENDING_HEADS[_graph_task()].append((work, d_head, head, scale, n_head, flags))
@@ -639,6 +684,9 @@ class _PosAtt(torch.autograd.Function):
         wjob = getattr(_STEP, "fwd_job", None)             # the processor's weights riding in this launch (early_block_weights)
         if wjob is not None:
             _STEP.fwd_job = None
+        # (the layer in front of the processor is the model's first attention layer: its backward is the pass's LAST attention
+        # launch and may carry the end-of-pass d(lmda) finish - see backward)
+        ctx.before_processor = wjob is not None
         rc = _lib.lib().pit_posatt_fwd_job(
             plan.mesh_out.data_ptr(), plan.mesh_in.data_ptr(), plan.mesh_batch, plan.n_out, plan.n_in, plan.sdim,
             plan.metric_id, plan.period,
@@ -694,8 +742,15 @@ class _PosAtt(torch.autograd.Function):
         rider = None if (plan.nbr_idx is not None and _dw_pending_rows(values.device) >= BIG_RIDER_ROWS) \
             else _dw_take(values.device)
 
+        # FINISH_IN_LAUNCH: the d(lmda) finish of the whole pass inside this launch (pit_posatt_bwd_job) when this is the layer in
+        # front of the processor (its backward runs after every other layer's), d(scale)-only and deferred.  Layers finishing
+        # after it anyway (another order of independent branches) are drained by the end-of-pass flush as before.
+        fin = None
+        if FINISH_IN_LAUNCH and defer and getattr(ctx, "before_processor", False) and not need_v and plan.nbr_idx is not None:
+            fin = _finish_job(values.device, work, d_head, head, scale, n_head, 1 | (4 if ctx.head_is_scale else 0))
+
         def launch(dv, dh, stream_ptr, job=None):
-            rc = _lib.lib().pit_posatt_bwd(
+            rc = _lib.lib().pit_posatt_bwd_job(
                 plan.mesh_out.data_ptr(), plan.mesh_in.data_ptr(), plan.mesh_batch, plan.n_out, plan.n_in,
                 plan.sdim, plan.metric_id, plan.period,
                 values.data_ptr(), b, d, values.stride(1), values.stride(0),
@@ -708,7 +763,8 @@ class _PosAtt(torch.autograd.Function):
                 _lib.ptr(plan.nbr_idx), _lib.ptr(plan.nbr_cnt), plan.nbr_cap, plan.lists_complete(),
                 _lib.ptr(plan.rev_ptr), _lib.ptr(plan.rev_row),
                 ctypes.cast(ctypes.pointer(job[0]), ctypes.c_void_p) if job is not None else None,
-                ctx.coord_dims, ctx.math | io | union, stream_ptr)
+                ctx.coord_dims, ctx.math | io | union, stream_ptr,
+                ctypes.cast(ctypes.pointer(fin[0]), ctypes.c_void_p) if fin is not None else None)
             _lib.check(rc, "pit_posatt_bwd")
 
         if OVERLAP_BACKWARD and slot is not None:
@@ -720,7 +776,9 @@ class _PosAtt(torch.autograd.Function):
                 launch(d_values, None, _lib.stream_ptr())
         else:
             launch(d_values, d_head, _lib.stream_ptr(), rider)
-        if defer:
+        if fin is not None and fin[1].value:
+            _PENDING_HEADS[_graph_task()] = []          # every layer deferred so far (and this one) was finished by the launch
+        elif defer:
             _defer_head_finish(work, d_head, head, scale, n_head, 1 | (4 if ctx.head_is_scale else 0))
         return d_values, (None if slot is not None else d_head), None, None, None, None, None, None, None, None, None
 
