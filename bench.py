@@ -570,12 +570,16 @@ def parity_vs_oracle(args, step, model, affine, meta):
     w = {k: rel(dev_grads[k], sd[k].grad) for k in sd if not k.endswith("lmda")}
     l = {k: rel(dev_grads[k], sd[k].grad) for k in sd if k.endswith("lmda")}
     kw, kl = max(w, key=w.get), max(l, key=l.get)
+    # all layers' d(lmda) as one vector (what tests/test_gpu_bf16.py bounds: a single layer's scalar is a cancellation-heavy sum
+    # and its own relative error is noisier than the vector's)
+    lk = [k for k in sd if k.endswith("lmda")]
+    l_all = rel(torch.cat([dev_grads[k].reshape(-1) for k in lk]), torch.cat([sd[k].grad.reshape(-1) for k in lk]))
     return {"rel_l2_out": rel(out_dev, ref.detach()), "rel_loss": abs(loss_dev - float(ref_loss)) / abs(float(ref_loss)),
             "rel_l2_weight_grad_worst": w[kw], "worst_weight_grad": kw,
-            "rel_l2_dlmda_worst": l[kl], "worst_dlmda": kl,
+            "rel_l2_dlmda_all_layers": l_all, "rel_l2_dlmda_worst": l[kl], "worst_dlmda": kl,
             "head_scale_route": args.head_scale_route, "math": args.math,
-            "tolerance": {"out": 1e-5, "weight_grad": 2e-5, "dlmda": 2e-4} if args.math == "fp32" else
-                         {"out": 2e-2, "weight_grad": 5e-2, "dlmda": 5e-2},
+            "tolerance": {"out": 1e-5, "weight_grad": 2e-5, "dlmda_worst_layer": 2e-4} if args.math == "fp32" else
+                         {"out": 2e-2, "weight_grad": 5e-2, "dlmda_all_layers": 5e-2},
             "what": "the timed hipGraph's own results (prediction, loss, flat gradient buffer after its last replay) vs "
                     "oracle/pit_oracle.py forward+loss+backward on this host, same parameters and inputs",
             "oracle_seconds": round(secs, 2)}

@@ -102,6 +102,14 @@ int pit_select_fwd(const float* mesh_out, const float* mesh_in, int mesh_batch, 
                    int space_dim, int metric, float period, int rank_k, int need_kth,
                    float* stats, void* stream);
 
+/* The transposed lists (key -> listing rows) of candidate lists that were built WITHOUT them (rev_ptr = NULL in pit_plan_fwd /
+ * pit_neighbors_fwd): round 4 - per-sample plans are rebuilt every step and only a backward that walks the lists by key
+ * (d(values) of the candidate-list kernels) needs the transpose; the forward and d(scale) do not.  rev_ptr (mesh_batch, n_in+1),
+ * rev_row (mesh_batch, n_out*cap), workspace 2*mesh_batch*n_in ints - as in pit_neighbors_fwd.  n_in <= 4096
+ * (PIT_ERR_UNSUPPORTED otherwise: rebuild the plan with rev_ptr). */
+int pit_lists_transpose(const int* nbr_idx, const int* nbr_cnt, int mesh_batch, int n_out, int n_in, int cap,
+                        int* rev_ptr, int* rev_row, int* workspace, void* stream);
+
 /* pit_select_fwd (need_kth = 1) and pit_neighbors_fwd in ONE pass over the rows: the distances of
  * a row stay in registers, the order statistics are searched on a narrowed candidate set and the
  * lists are emitted from the same registers (rows longer than 4096 keys fall back to the two

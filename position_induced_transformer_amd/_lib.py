@@ -45,6 +45,7 @@ SIGNATURES = {
     "pit_head_scale": [_P, _I, _P, _P],
     "pit_select_fwd": [_P, _P, _I, _I, _I, _I, _I, _F, _I, _I, _P, _P],
     "pit_plan_fwd": [_P, _P, _I, _I, _I, _I, _I, _F, _I, _P, _I, _P, _P, _P, _P, _P, _P],
+    "pit_lists_transpose": [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P],
     "pit_neighbors_fwd": [_P, _P, _I, _I, _I, _I, _I, _F, _P, _I, _P, _P, _P, _P, _P, _P],
     "pit_posatt_fwd": [_P, _P, _I, _I, _I, _I, _I, _F,
                        _P, _I, _I, _L, _L,

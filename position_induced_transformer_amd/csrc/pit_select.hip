@@ -761,6 +761,19 @@ static int launch_transpose(const int* nbr_idx, const int* nbr_cnt, int mesh_bat
     return 0;
 }
 
+extern "C" int pit_lists_transpose(const int* nbr_idx, const int* nbr_cnt, int mesh_batch, int n_out, int n_in, int cap,
+                                   int* rev_ptr, int* rev_row, int* workspace, void* stream) {
+    if (!nbr_idx || !nbr_cnt || !rev_ptr || !rev_row || !workspace) return PIT_ERR_NULL;
+    if (mesh_batch <= 0 || n_out <= 0 || n_in <= 0 || cap <= 0) return PIT_ERR_SIZE;
+    if (n_in > NBR_LDS_KEYS) return PIT_ERR_UNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    int* counts = workspace;
+    int* cursor = workspace + (long)mesh_batch * n_in;
+    fill_int(counts, (long)mesh_batch * n_in, 0, s);
+    fill_int(rev_row, (long)mesh_batch * n_out * cap, -1, s);
+    return launch_transpose(nbr_idx, nbr_cnt, mesh_batch, n_out, n_in, cap, rev_ptr, rev_row, counts, cursor, false, s);
+}
+
 extern "C" int pit_plan_fwd(const float* mesh_out, const float* mesh_in, int mesh_batch, int n_out, int n_in,
                             int space_dim, int metric, float period, int rank_k, float* stats, int cap,
                             int* nbr_idx, int* nbr_cnt, int* rev_ptr, int* rev_row, int* workspace, void* stream) {

@@ -547,20 +547,28 @@ class MeshPlan:
         return (self.metric, self.n_out, self.n_in, cap, self.mesh_batch > 1, self.sdim)
 
     def _wants_reverse_lists(self, cap: int) -> bool:
-        """The transposed lists (key -> rows) serve d(values) of the candidate-list kernels.  A plan of a kind already
-        decided for the union-tile kernels skips them (~90 us of a NACA step): its d(values) comes from the tiles
-        (posatt_union_dv_kernel: LDS accumulators, then fp32 atomic adds to memory - sums that differ in the last bits from
-        run to run, so not under torch.use_deterministic_algorithms, nor with PIT_UNION_DV=lists).  A backward that cannot
-        take the union form after all builds them on demand (ensure_reverse_lists)."""
-        if UNION_DV == "lists" or UNION_TILES == "0" or self.self_attn or self.mesh_batch == 1:
-            return True
-        if torch.are_deterministic_algorithms_enabled() or self.n_in > 4096 or self.n_out < 16 or cap > 64:
-            return True
-        return not (UNION_TILES == "1" or _UNION_DECISIONS.get(self._union_key(cap)) is True)
+        """The transposed lists (key -> rows) serve d(values) of the candidate-list kernels only.  Plans of meshes shared by the
+        batch are cached: built once, with them.  Per-sample plans are rebuilt EVERY step (train_naca.py:62-65): built without,
+        and the backward that needs them (d(values) requested and not supplied by the union tiles) builds them on demand
+        (ensure_reverse_lists) - an encoder whose inputs need no gradient never pays for them (NACA: 33 us, Elasticity 45 us per
+        step), nor does a union-tile layer (NACA decoder: 93 us)."""
+        return self.mesh_batch == 1
 
     def ensure_reverse_lists(self) -> None:
-        if self.nbr_idx is not None and self.rev_ptr is None:
+        if self.nbr_idx is None or self.rev_ptr is not None:
+            return
+        dev = self.mesh_out.device
+        rev_ptr = torch.empty((self.mesh_batch, self.n_in + 1), device=dev, dtype=torch.int32)
+        rev_row = torch.empty((self.mesh_batch, self.n_out * self.nbr_cap), device=dev, dtype=torch.int32)
+        work = torch.empty((2 * self.mesh_batch * self.n_in,), device=dev, dtype=torch.int32)
+        rc = _lib.lib().pit_lists_transpose(self.nbr_idx.data_ptr(), self.nbr_cnt.data_ptr(), self.mesh_batch, self.n_out,
+                                            self.n_in, self.nbr_cap, rev_ptr.data_ptr(), rev_row.data_ptr(), work.data_ptr(),
+                                            _lib.stream_ptr())
+        if rc == -4:                                    # PIT_ERR_UNSUPPORTED (rows longer than 4096 keys): the whole plan again
             self._build_lists(self.nbr_cap, True)
+            return
+        _lib.check(rc, "pit_lists_transpose")
+        self.rev_ptr, self.rev_row = rev_ptr, rev_row
 
     def union_tiles(self) -> bool:
         """Round 4: do the masked-layer kernels take the UNION-TILE form (PIT_ATT_UNION) for this plan?  They contract 16
@@ -720,8 +728,10 @@ class _PosAtt(torch.autograd.Function):
             if (values.data_ptr() | d_out.data_ptr()) % 16 or values.stride(1) % 4 or values.stride(0) % 4 \
                     or d_out.stride(1) % k or d_out.stride(0) % k:
                 union = 0
-        if need_v and not union:
-            plan.ensure_reverse_lists()                 # (a plan built for the union-tile form has none)
+        # d(values): from the union tiles (fp32 atomic adds: sums that differ in the last bits from run to run - not under
+        # torch.use_deterministic_algorithms, nor with PIT_UNION_DV=lists), else from the transposed lists, built on demand
+        if need_v and not (union and UNION_DV != "lists" and not torch.are_deterministic_algorithms_enabled()):
+            plan.ensure_reverse_lists()
         d_values = torch.empty((b, j, dv), device=values.device, dtype=torch.float32) if need_v else None
         slot = _grad_slot(ctx.head_param) if need_h else None
         if slot is not None:

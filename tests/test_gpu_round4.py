@@ -270,8 +270,10 @@ def test_union_tile_kernels_against_the_oracle(shape, d_values_by):
     try:
         plan = ops.MeshPlan("euclid", mo.cuda(), mi.cuda(), loc, False)
         assert plan.nbr_idx is not None and plan.union_tiles()
-        if d_values_by == "tile-atomics":
-            plan.rev_ptr = plan.rev_row = None                 # no transposed lists: d(values) by the tiles' atomic adds
+        if d_values_by == "transposed-lists":
+            plan.ensure_reverse_lists()                        # (present: d(values) walks them; absent: the tiles supply it)
+        else:
+            plan.rev_ptr = plan.rev_row = None
         v1 = values.cuda().requires_grad_(True); l1 = lmda.cuda().reshape(-1).requires_grad_(True)
         out = ops.posatt_apply(v1, l1, plan, nh, concat=False, head_is_scale=False)
         out.backward(d_out.cuda())
@@ -322,36 +324,46 @@ def test_union_tile_decision_is_made_per_kind_of_plan_and_never_for_shared_meshe
         ops._UNION_DECISIONS.clear()
 
 
-def test_union_tile_plans_carry_transposed_lists_only_when_a_backward_needs_them():
-    """A plan of a kind decided for the union tiles is built without the transposed lists (d(values) comes from the tiles);
-    deterministic mode keeps them; a layer the union kernels cannot take (width not a multiple of 8) builds them on demand."""
+def test_per_sample_plans_build_transposed_lists_only_when_a_backward_needs_them():
+    """Per-sample plans (rebuilt every step) come without the transposed lists; the backward builds them (pit_lists_transpose)
+    when d(values) is needed and the union tiles do not supply it: a layer the union kernels cannot take (width not a multiple
+    of 8), deterministic mode, incoherent orderings.  Plans of shared meshes (cached) carry them from the start."""
     from position_induced_transformer_amd import ops
     old, ops.UNION_TILES = ops.UNION_TILES, "auto"
     try:
         ops._UNION_DECISIONS.clear()
         mo, mi = _grid_meshes(2, 40, 40, 200, seed=7)
-        first = ops.MeshPlan("euclid", mo.cuda(), mi.cuda(), 0.05, False)
-        assert first.rev_ptr is not None and first.union_tiles()          # (the probing plan has them)
-        plan = ops.MeshPlan("euclid", mo.cuda(), mi.cuda(), 0.05, False)
-        assert plan.rev_ptr is None and plan.union_tiles()
-        torch.use_deterministic_algorithms(True)
-        try:
-            assert ops.MeshPlan("euclid", mo.cuda(), mi.cuda(), 0.05, False).rev_ptr is not None
-        finally:
-            torch.use_deterministic_algorithms(False)
+        assert ops.MeshPlan("euclid", mo[0].cuda(), mi[0].cuda(), 0.05, False).rev_ptr is not None     # shared mesh
         g = torch.Generator().manual_seed(8)
-        for dim in (12, 16):
+        perm = torch.randperm(1600, generator=g)
+        for dim, det, shuffled, want_lists in ((16, False, False, False), (12, False, False, True), (16, True, False, True),
+                                               (16, False, True, True)):
+            m_out = mo[:, perm].contiguous() if shuffled else mo
             values = torch.randn(2, 200, dim, generator=g)
             lmda = torch.tensor([0.3]).reshape(1, 1, 1)
             d_out = torch.randn(2, 1600, dim, generator=g)
             v0 = values.clone().requires_grad_(True); l0 = lmda.clone().requires_grad_(True)
-            orc.posatt_cross("euclid", True, mo, mi, v0, l0, 0.05).backward(d_out)
-            plan = ops.MeshPlan("euclid", mo.cuda(), mi.cuda(), 0.05, False)
+            orc.posatt_cross("euclid", True, m_out, mi, v0, l0, 0.05).backward(d_out)
+            ops._UNION_DECISIONS.clear()
+            plan = ops.MeshPlan("euclid", m_out.cuda(), mi.cuda(), 0.05, False)
+            assert plan.rev_ptr is None and plan.union_tiles() == (not shuffled)
             v1 = values.cuda().requires_grad_(True); l1 = lmda.cuda().reshape(-1).requires_grad_(True)
-            ops.posatt_apply(v1, l1, plan, 1, concat=False, head_is_scale=False).backward(d_out.cuda())
-            assert (plan.rev_ptr is None) == (dim == 16)
+            out = ops.posatt_apply(v1, l1, plan, 1, concat=False, head_is_scale=False)
+            assert plan.rev_ptr is None                                    # (the forward never needs them)
+            torch.use_deterministic_algorithms(det)
+            try:
+                out.backward(d_out.cuda())
+            finally:
+                torch.use_deterministic_algorithms(False)
+            assert (plan.rev_ptr is not None) == want_lists, (dim, det, shuffled)
             assert float((v1.grad.cpu() - v0.grad).norm() / v0.grad.norm()) <= 1e-5
             assert float((l1.grad.cpu().reshape(-1) - l0.grad.reshape(-1)).norm() / l0.grad.norm()) <= 1e-4
+            # values that need no gradient: no lists either way
+            plan2 = ops.MeshPlan("euclid", m_out.cuda(), mi.cuda(), 0.05, False)
+            l2 = lmda.cuda().reshape(-1).requires_grad_(True)
+            ops.posatt_apply(values.cuda(), l2, plan2, 1, concat=False, head_is_scale=False).backward(d_out.cuda())
+            assert plan2.rev_ptr is None
+            assert float((l2.grad.cpu().reshape(-1) - l0.grad.reshape(-1)).norm() / l0.grad.norm()) <= 1e-4
     finally:
         ops.UNION_TILES = old
         ops._UNION_DECISIONS.clear()
