@@ -276,12 +276,17 @@ def roofline_mlp_probe(model, batch):
     rows = batch * rows_per_sample
     # the library's own rule (csrc/pit_mlp.hip: try_launch_mlp_fwd16)
     fused = n1 in (32, 64, 128) and (n2 <= 4 or (n2 % 16 == 0 and n2 <= n1)) and rows >= 256 and n0 <= 256 and rows * n1 * (n0 + n2) <= (1 << 27)
-    launches = 1 if fused else 2
+    # (csrc/pit_mlp_slab.hip: pit_mlp_slab_eligible + _preferred - the large regime at hid 64 is ONE launch too since round 4)
+    slab = (not fused) and n1 == 64 and n2 == 64 and n0 % 16 == 0 and n0 <= 256 and rows >= 65536 \
+        and ops.get_math_mode() == "fp32" and not os.environ.get("PIT_NO_SLAB_MLP")
+    launches = 1 if (fused or slab) else 2
     flops = 2.0 * rows * (n0 * n1 + n1 * n2) / launches
     us_launch = us / launches
     achieved = flops / (us_launch * 1e-6) / 1e12
-    alg_bytes = 4.0 * (rows * n0 + 2 * rows * n1 + (0 if fused else rows * n1) + 2 * rows * n2 + n0 * n1 + n1 * n2) / launches
-    name = f"mlp_fwd16_kernel<{n1},{(n0 + 63) // 64 * 4}> (fused GEMM1+GELU+GEMM2+GELU)" if fused else "gemm_lds/gemm_rd kernel<BIAS_GELU> (mean of the two launches)"
+    alg_bytes = 4.0 * (rows * n0 + 2 * rows * n1 + (0 if (fused or slab) else rows * n1) + 2 * rows * n2 + n0 * n1 + n1 * n2) / launches
+    name = f"mlp_fwd16_kernel<{n1},{(n0 + 63) // 64 * 4}> (fused GEMM1+GELU+GEMM2+GELU)" if fused else \
+        (f"mlp_fwd64_kernel<{n0 // 16}> (64-row slabs, fused GEMM1+GELU+GEMM2+GELU)" if slab else
+         "gemm_lds/gemm_rd kernel<BIAS_GELU> (mean of the two launches)")
     return {"bound": "mfma", "kernel": f"{name}: kaiming_mlp forward {n0}->{n1}->{n2} on {rows} rows, batch {batch}",
             "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": pmc_traffic(f"mlp_fwd_b{batch}", f"rows{rows}_{n0}_{n1}_{n2}"),
@@ -331,12 +336,21 @@ def roofline_probe(model, batch):
     plan = layer._plan(mesh, mesh, True)
     d = model.hid_dim
     u = torch.randn(batch, plan.n_in, d, device="cuda")
+    # what the step runs for this shape (pit.processor): in the large regime of a batch-free mesh the launch reads the weights
+    # pit_block_weights formed once per step for ALL blocks (round 4); that launch is outside this probe's timed region
+    pre = model.mesh_ltt is not None and ops.pre_weights_supported(plan.n_in, layer.n_head, d, batch)
     with torch.no_grad():
-        us = graph_time_us(lambda: ops.posatt_apply(u, layer.lmda, plan, layer.n_head, True))
+        if pre:
+            weights = ops.block_weights(plan, [a.lmda for a in model.conv], layer.n_head, False)
+            us = graph_time_us(lambda: ops.posatt_pre_apply(u, layer.lmda, weights, 0, layer.n_head))
+        else:
+            us = graph_time_us(lambda: ops.posatt_apply(u, layer.lmda, plan, layer.n_head, True))
     flops = 2.0 * layer.n_head * plan.n_out * plan.n_in * d * batch
     achieved = flops / (us * 1e-6) / 1e12
-    alg_bytes = 4.0 * batch * plan.n_in * d + 4.0 * batch * plan.n_out * (1 + layer.n_head) * d
-    return {"bound": "mfma", "kernel": f"posatt_rows_kernel<fwd> processor {plan.n_out}x{plan.n_in}, D={d}, "
+    alg_bytes = 4.0 * batch * plan.n_in * d + 4.0 * batch * plan.n_out * (1 + layer.n_head) * d \
+        + (4.0 * layer.n_head * plan.n_out * plan.n_in if pre else 0.0)
+    kname = "posatt_rows_tiles<PRE> (weights of pit_block_weights)" if pre else "posatt_rows_kernel<fwd>"
+    return {"bound": "mfma", "kernel": f"{kname} processor {plan.n_out}x{plan.n_in}, D={d}, "
                                        f"H={layer.n_head}, batch {batch}",
             "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),

@@ -78,11 +78,15 @@ const char* pit_error_string(int code);
 #define PIT_IO_OUT_BF16  0x800
 #define PIT_IO_DOUT_BF16 0x1000
 /* pit_posatt_fwd / pit_posatt_bwd, masked layers on candidate lists (round 4): OR-ed into math_mode, PIT_ATT_UNION asks for the
- * UNION-TILE kernels - 64 consecutive rows contract against the union of their candidate keys (every key's value row
- * fetched once per tile, MFMA contraction) instead of one wavefront per row gathering its own keys.  Exact for any input,
- * fast when consecutive rows share their keys (grids, body-fitted meshes: a 64-row tile's union <= 128 keys); the caller
- * decides per mesh plan.  Ignored where it does not apply (coordinate channels, self-attention concat, n_in > 4096).
- * pit_posatt_bwd with this flag needs a dense d_values (ld_dvalues = dim, dvalues_bstride = n_in*dim); it is zeroed here. */
+ * UNION-TILE kernels - 16 consecutive rows (one wavefront) contract against the union of their candidate keys (every key's value
+ * row fetched once per tile, v_mfma_f32_16x16x4_f32) instead of one wavefront per row gathering its own keys.  Exact for any
+ * input, fast when consecutive rows share their keys (grids, body-fitted meshes: a 16-row tile's union is 25-60 keys); the
+ * caller decides per mesh plan.  Ignored where it does not apply: coordinate channels, self-attention concat, n_in > 4096,
+ * n_head > 2, list capacity > 64, dim not a multiple of 8 or rows not 16-byte aligned (the per-row kernels run instead).
+ * pit_posatt_bwd with this flag: d(scale) from the tiles; d(values) from the transposed lists when rev_ptr / rev_row are
+ * given, else from the tiles (256-row blocks contracted on MFMA, their sums ADDED to memory with fp32 atomics - the call
+ * zeroes d_values first; needs a dense d_values: ld_dvalues = dim, dvalues_bstride = n_in*dim; sums differ in the last
+ * bits from run to run). */
 #define PIT_ATT_UNION    0x2000
 /* 1 if pit_mlp_fwd / pit_mlp_bwd* of this shape accept PIT_IO_X_BF16 | PIT_IO_SAVE_BF16 | PIT_IO_DX_BF16 (thin output
  * layer n2 <= 4 without trailing gelu, large regime, widths multiples of 8) */

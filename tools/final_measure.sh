@@ -14,5 +14,5 @@ d = json.loads(sys.stdin.read()); print('vorticity rollout-20 b=20 fp32', d['ms_
 python bench.py --task sod --batch 8 --no-extras --no-cpu-baseline --steps 200 --warmup 20 2>/dev/null | python -c "
 import sys, json
 d = json.loads(sys.stdin.read()); print('sod b=8 fp32', d['ms_per_step'], 'ms')" >> gpurun_out/final/task_times.txt
-bash tools/profile_round.sh gpurun_out/r03_prof_f > gpurun_out/final/prof.log 2>&1
+# (per-configuration rocprofv3 passes: run tools/profile_round.sh <outdir> separately)
 cat gpurun_out/final/task_times.txt; tail -c 1500 gpurun_out/final/bench_default.json

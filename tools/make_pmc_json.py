@@ -14,8 +14,8 @@ want = {  # bench key -> (config, kernel-name prefix, shape of the launch(es) th
     "block_bwd_kernel_b8": ("darcy8", "block_bwd_kernel<2, 2>", "L256_H2_D64_b8"),
     "block_fwd_kernel_b8": ("darcy8", "block_fwd_kernel<2, false>", "L256_H2_D64_b8"),
     "mlp_fwd_b8": ("darcy8", "mlp_fwd16_kernel<64, 8>", "rows14792_128_64_1"),          # the decoder MLP (not the probe's 192->64->64)
-    "mlp_fwd_b256": ("darcy256", "gemm_lds_kernel<64, true, true, 2, false", "family"),
-    "posatt_rows_fwd_b256": ("darcy256", "posatt_rows_tiles<4, 1, 0, false, false>", "256x256_D64_H2_b256"),
+    "mlp_fwd_b256": ("darcy256", "mlp_fwd64_kernel<12, false>", "rows65536_192_64_64"),          # the four processor MLPs (one shape)
+    "posatt_rows_fwd_b256": ("darcy256", "posatt_rows_tiles<4, 1, 0, false, false, true>", "256x256_D64_H2_b256"),
     "mlp_dw_b256": ("darcy256", "gemm_rr_kernel<1, 1, 64, false>", "family"),
 }
 out = {"source": "tools/profile_round.sh: rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (own passes), bench.py "
