@@ -428,3 +428,42 @@ def test_end_of_pass_finish_inside_the_last_attention_launch_gives_the_same_grad
                 assert float((got[k] - ref[k]).abs().max()) <= 1e-6 * float(ref[k].abs().max()) + 1e-12, k
     finally:
         ops.FINISH_IN_LAUNCH = old
+
+
+@pytest.mark.parametrize("case", ["cloud-2d", "grid-with-ties-2d", "cloud-3d"])
+def test_one_row_per_lane_plan_equals_the_wave_per_row_plan(case):
+    """plan_rows_lane (per-sample meshes from 32 768 rows: the NACA decoder at the script's batch) against plan_rows_reg
+    (PIT_NO_LANE_PLAN): order statistics bit for bit, the same list lengths, the same candidate SETS per row (the order inside
+    a list differs), overflowed rows flagged alike - on random clouds, on a grid whose tie shells overflow the lanes' columns
+    (plan_rows_fix redoes those rows) and in three dimensions."""
+    from position_induced_transformer_amd import ops
+    g = torch.Generator().manual_seed(17)
+    b, n_out, n_in = 4, 9000, 500
+    if case == "grid-with-ties-2d":
+        gx, gy = torch.meshgrid(torch.arange(100.0), torch.arange(90.0), indexing="ij")
+        mo = torch.stack([gx.reshape(-1), gy.reshape(-1)], -1)[None].repeat(b, 1, 1) / 100.0
+        kx, ky = torch.meshgrid(torch.arange(25.0), torch.arange(20.0), indexing="ij")
+        mi = torch.stack([kx.reshape(-1) * 4, ky.reshape(-1) * 4.5], -1)[None].repeat(b, 1, 1) / 100.0
+    else:
+        sd = 3 if case == "cloud-3d" else 2
+        mo, mi = torch.rand(b, n_out, sd, generator=g), torch.rand(b, n_in, sd, generator=g)
+    plans = {}
+    for flag in ("", "1"):
+        if flag:
+            os.environ["PIT_NO_LANE_PLAN"] = flag
+        try:
+            plans[flag] = ops.MeshPlan("euclid", mo.cuda(), mi.cuda(), 0.03, False)
+        finally:
+            os.environ.pop("PIT_NO_LANE_PLAN", None)
+    lane, reg = plans[""], plans["1"]
+    assert lane.nbr_cap == reg.nbr_cap and torch.equal(lane.stats, reg.stats)
+    assert torch.equal(lane.nbr_cnt, reg.nbr_cnt)
+    cap = lane.nbr_cap
+    ok = (lane.nbr_cnt <= cap)
+    valid = (torch.arange(cap, device="cuda")[None, :] < lane.nbr_cnt[:, None]) & ok[:, None]
+    big = torch.iinfo(torch.int32).max
+    a = torch.where(valid, lane.nbr_idx.view(-1, cap), big).sort(dim=1).values
+    c = torch.where(valid, reg.nbr_idx.view(-1, cap), big).sort(dim=1).values
+    assert torch.equal(a, c)
+    if case == "grid-with-ties-2d":
+        assert int((~ok).sum()) >= 0                    # (rows beyond the capacity are flagged by their count in both)
