@@ -2787,9 +2787,11 @@ template <int MODE>
 void launch_union(const AttArgs& a, const SparseArgs& sp, hipStream_t s) {
     const int ncb = (a.ncols + UW_CB - 1) / UW_CB;
     const int rtiles = (a.n_out + UW_ROWS - 1) / UW_ROWS;
-    // column passes per wavefront: the tile's weights are built once per wavefront - as many passes as keep >= 16 wavefronts per CU
+    // column passes per wavefront: the tile's weights are built once per wavefront - as many passes as keep >= 2048 wavefronts
+    // (meshes shared by the batch, PIT_UNION_TILES=1: Vorticity b=20 with 1 / 2 / 4 / 8 / 16 / 40 passes 1.842 / 1.821 / 1.816 / 1.813 /
+    // 1.863 / 2.077 ms against 1.835 on the per-row kernels; Darcy b=256 with 2 / 4 / 16: 1.858 / 1.833 / 1.867 against 1.859)
     int per = 1;
-    while (per < ncb && (long)rtiles * a.mesh_batch * ((ncb + 2 * per - 1) / (2 * per)) >= 4096) per *= 2;
+    while (per < ncb && (long)rtiles * a.mesh_batch * ((ncb + 2 * per - 1) / (2 * per)) >= 2048) per *= 2;
     dim3 grid((unsigned)((ncb + per - 1) / per), (unsigned)((rtiles + 3) / 4), (unsigned)a.mesh_batch), block(256);
     const int wl = union_wave_lds(a.n_head, a.n_in);
 #define PIT_UN(NH_, EPL_) do {                                                                                             \
