@@ -473,3 +473,46 @@ def test_one_row_per_lane_plan_equals_the_wave_per_row_plan(case):
     assert torch.equal(a, c)
     if case == "grid-with-ties-2d":
         assert int((~ok).sum()) >= 0                    # (rows beyond the capacity are flagged by their count in both)
+
+
+def test_union_tile_kernels_fuzz_against_the_candidate_list_kernels():
+    """Random shapes, both heads counts, Euclidean and periodic metrics, coherent and shuffled row orders, with and without
+    the transposed lists: the union-tile kernels against the candidate-list kernels on the same plan inputs."""
+    from position_induced_transformer_amd import ops
+    rng = np.random.RandomState(123)
+    old = ops.UNION_TILES
+    try:
+        for trial in range(24):
+            b = int(rng.randint(1, 4)); nx = int(rng.randint(9, 50)); ny = int(rng.randint(9, 40))
+            n_in = int(rng.randint(48, min(600, nx * ny))); dim = int(rng.choice([8, 16, 40, 64, 136])); nh = int(rng.randint(1, 3))
+            loc = float(rng.uniform(0.01, 0.15)); metric = str(rng.choice(["euclid", "periodic2d"]))
+            mo, mi = _grid_meshes(b, nx, ny, n_in, seed=100 + trial, jitter=0.003)
+            if metric == "periodic2d":                         # (periodic metrics: one mesh for the batch, pit.py:186-258)
+                mo, mi = (mo % 1.0)[0], (mi % 1.0)[0]
+            g = torch.Generator().manual_seed(200 + trial)
+            if trial % 3 == 2:
+                mo = mo[..., torch.randperm(nx * ny, generator=g), :].contiguous()
+            values = torch.randn(b, n_in, dim, generator=g).cuda()
+            lmda = ((torch.rand(nh, generator=g) - 0.5) * 2.0).cuda()
+            d_out = torch.randn(b, nx * ny, nh * dim, generator=g).cuda()
+            res = {}
+            for mode in ("0", "1"):
+                ops.UNION_TILES = mode
+                plan = ops.MeshPlan(metric, mo.cuda(), mi.cuda(), loc, False)
+                if plan.nbr_idx is None:
+                    break                                      # (lists not shorter than the rows: dense kernels either way)
+                if mode == "1" and trial % 2 == 0:
+                    plan.ensure_reverse_lists()                # d(values) from the lists in half of the trials
+                v = values.clone().requires_grad_(True); lm = lmda.clone().requires_grad_(True)
+                out = ops.posatt_apply(v, lm, plan, nh, concat=False, head_is_scale=False)
+                out.backward(d_out)
+                res[mode] = (out.detach(), v.grad.clone(), lm.grad.clone())
+            if len(res) < 2:
+                continue
+            rel = lambda a, r: float((a.double() - r.double()).norm() / (r.double().norm() + 1e-30))
+            tag = (trial, b, nx, ny, n_in, dim, nh, round(loc, 3), metric)
+            assert rel(res["1"][0], res["0"][0]) <= 1e-6, tag
+            assert rel(res["1"][1], res["0"][1]) <= 1e-5, tag
+            assert rel(res["1"][2], res["0"][2]) <= 1e-4, tag
+    finally:
+        ops.UNION_TILES = old
