@@ -290,6 +290,9 @@ __device__ __forceinline__ void pick2_reg(const uint32_t (&v)[N], int idx, uint3
     }
 }
 
+#ifndef PL_G
+#define PL_G 6          // keys of a block whose distances are formed together in pass 2 (NACA plan: 8 / 6 / 4 -> 102.8 / 97.5 / 98.5 us)
+#endif
 // NB blocks (32 when rank_k + 2 <= 16: half the registers and a third of the sorting network; 64 otherwise)
 template <bool SD2, bool PER, int NB, int LOGNB>   // SD2: at most two coordinates enter the distance (keys as float2); PER: periodic wrap
 __global__ __launch_bounds__(256) void plan_rows_lane(SelectArgs a, int cap, int* __restrict__ nbr_idx,
@@ -370,12 +373,12 @@ __global__ __launch_bounds__(256) void plan_rows_lane(SelectArgs a, int cap, int
         const int u = live ? (int)__builtin_ctzll(bmask) : 0;
         bmask &= bmask - 1ull;
 #pragma unroll 1
-        for (int j0 = u; j0 < npad; j0 += 8 * NB) {
-            uint32_t m8[8];
+        for (int j0 = u; j0 < npad; j0 += PL_G * NB) {
+            uint32_t m8[PL_G];
 #pragma unroll
-            for (int t = 0; t < 8; ++t) m8[t] = dist_bits(min(j0 + t * NB, npad - 1));
+            for (int t = 0; t < PL_G; ++t) m8[t] = dist_bits(min(j0 + t * NB, npad - 1));
 #pragma unroll
-            for (int t = 0; t < 8; ++t) {
+            for (int t = 0; t < PL_G; ++t) {
                 if (live && j0 + t * NB < npad && m8[t] <= Ub) {
                     if (cnt < CAPB) cbuf[cnt * 256 + tid] = (unsigned short)(j0 + t * NB);
                     ++cnt;
