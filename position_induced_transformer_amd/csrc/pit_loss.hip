@@ -231,7 +231,8 @@ __global__ __launch_bounds__(256) void rel_max_fwd_kernel(const float* __restric
     }
 }
 
-// Round 4: ONE 1024-thread workgroup per (sample, channel) series when the series fits its registers (npts <= 1024 PTS).
+// Round 4: ONE 1024-thread workgroup per (sample, channel) series when the series fits its registers (npts <= 1024 PTS, PTS <= 16:
+// the NACA field of 11 271 points takes 12 - 31 -> 9 us against the split form, whose last arriver writes a series' gradients alone).
 // rel_lp_fwd_kernel's chain for a Darcy-sized series (1849 points split over 8 workgroups) is: loads -> two returning fp64
 // atomics -> a ticket -> three exchanges by the last arriver -> the gradient pass RE-READING the whole series: ~10.6 us of
 // dependent round trips for 15 k values.  Here the series stays in registers: loads (all in flight) -> block reduction ->
@@ -325,12 +326,13 @@ bool launch_rel_lp_fwd1(const float* tru, const float* pred, const float* scale,
                         int p, float* norms, float* loss, float* ws, float* d_pred_unit, float* d_true_unit, float* clear_buf,
                         long clear_n, hipStream_t s) {
     static const bool off = getenv("PIT_NO_LOSS1") != nullptr;
-    if (off || npts > 4096 || (long)batch * nch > 4096) return false;
+    if (off || npts > 16384 || (long)batch * nch > 4096) return false;          // (series of up to 16 values per thread: 64 registers)
     const dim3 grid(nch, batch), block(1024);
     const int pts = (npts + 1023) / 1024;
 #define PIT_L1(P_) hipLaunchKernelGGL(rel_lp_fwd1_kernel<P_>, grid, block, 0, s, tru, pred, scale, shift, npts, nch, p, norms, loss, ws, \
                                        d_pred_unit, d_true_unit, clear_buf, clear_n)
-    if (pts <= 1) PIT_L1(1); else if (pts <= 2) PIT_L1(2); else PIT_L1(4);
+    if (pts <= 1) PIT_L1(1); else if (pts <= 2) PIT_L1(2); else if (pts <= 4) PIT_L1(4); else if (pts <= 8) PIT_L1(8);
+    else if (pts <= 12) PIT_L1(12); else PIT_L1(16);
 #undef PIT_L1
     return true;
 }

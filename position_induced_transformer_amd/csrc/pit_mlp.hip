@@ -1103,10 +1103,69 @@ __global__ __launch_bounds__(256) void thin_dz1_kernel(GemmArgs g) {
 
 // Y[m,n] = sum_k H[m,k] * W2[n,k] + b[n] (optionally gelu, Z kept),  N = n2 <= 4: tpr = K/4 (<= 64)
 // lanes share a row (one 16-B load each per 4*tpr columns), 64/tpr rows per wavefront and pass
-__global__ __launch_bounds__(256) void thin_fwd_kernel(GemmArgs g, int tpr) {
+__global__ __launch_bounds__(256) void thin_fwd_kernel(GemmArgs g, int tpr, int streamed) {
     const int lane = threadIdx.x & 63;
     const int q = lane % tpr, sub = lane / tpr, rpw = 64 / tpr;
     const long wave0 = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((long)gridDim.x * blockDim.x) >> 6;
+    auto finish = [&](long m, bool mv, float (&acc)[THIN_MAX]) {
+        if (g.N >= 2) {
+            // four partial sums per lane, tpr lanes per row: the first two exchanges HALVE the sums a lane carries (lane bit 0
+            // picks the output pair, bit 1 the output of the pair), the rest add one value - 6 cross-lane moves for tpr = 32
+            // instead of 20 (the reduction bounded this kernel more than its loads: NACA decoder 63 -> 50 us, 36 us with the streamed loads)
+            const bool odd = q & 1, hi = (q >> 1) & 1;
+            const float r0 = (odd ? acc[2] : acc[0]) + __shfl_xor(odd ? acc[0] : acc[2], 1);
+            const float r1 = (odd ? acc[3] : acc[1]) + __shfl_xor(odd ? acc[1] : acc[3], 1);
+            float r = (hi ? r1 : r0) + __shfl_xor(hi ? r0 : r1, 2);
+            for (int o = tpr >> 1; o >= 4; o >>= 1) r += __shfl_xor(r, o);
+            const int n = 2 * (q & 1) + ((q >> 1) & 1);            // the output lane q < 4 holds
+            if (mv && q < 4 && n < g.N) {
+                float v = r + g.bias[n];
+                if (g.epi == EPI_BIAS_GELU) { g.Z[m * g.ldz + n] = v; v = gelu_erf(v); }
+                g.C[m * g.ldc + n] = v;
+            }
+            return;
+        }
+        for (int o = tpr >> 1; o > 0; o >>= 1) acc[0] += __shfl_xor(acc[0], o);
+        if (mv && q == 0) {
+            float v = acc[0] + g.bias[0];
+            if (g.epi == EPI_BIAS_GELU) { g.Z[m * g.ldz] = v; v = gelu_erf(v); }
+            g.C[m * g.ldc] = v;
+        }
+    };
+    if (streamed) {
+        // the whole fp32 row in one pass (K <= 256): the lane's weight quads live in registers for the launch and EIGHT row groups
+        // are requested per wavefront before the first is used - raw buffer loads, predicated on the OFFSET (a predicated global
+        // load is sunk into an exec-masked block with its own s_waitcnt: one load in flight per lane, 1.9 TB/s on the NACA
+        // decoder's 225 k x 128 activations)
+        constexpr int U = 8;
+        const int k = q * 4;
+        const bool kv = k < g.K;
+        const unsigned a_bytes = (unsigned)((((long)g.M - 1) * g.a_rs + g.K) * 4);
+        const __amdgpu_buffer_rsrc_t ra = make_rsrc(g.A, a_bytes);
+        float4 w[THIN_MAX];
+#pragma unroll
+        for (int n = 0; n < THIN_MAX; ++n)
+            w[n] = (kv && n < g.N) ? *reinterpret_cast<const float4*>(g.B + (long)n * g.b_cs + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const long stride = nwaves * rpw;
+        for (long mbase = wave0 * rpw; mbase < g.M; mbase += U * stride) {
+            float h[U][4];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const long m = mbase + u * stride + sub;
+                buf_load4(ra, (m < g.M && kv) ? (unsigned)((m * g.a_rs + k) * 4) : a_bytes, h[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const long m = mbase + u * stride + sub;
+                if (mbase + u * stride >= g.M) break;             // wave-uniform
+                float acc[THIN_MAX];
+#pragma unroll
+                for (int n = 0; n < THIN_MAX; ++n) acc[n] = (h[u][0] * w[n].x + h[u][1] * w[n].y) + (h[u][2] * w[n].z + h[u][3] * w[n].w);
+                finish(m, m < g.M, acc);
+            }
+        }
+        return;
+    }
     for (long mbase = wave0 * rpw; mbase < g.M; mbase += nwaves * rpw) {
         const long m = mbase + sub;
         const bool mv = m < g.M;
@@ -1120,15 +1179,7 @@ __global__ __launch_bounds__(256) void thin_fwd_kernel(GemmArgs g, int tpr) {
                 acc[n] += (h.x * w.x + h.y * w.y) + (h.z * w.z + h.w * w.w);
             }
         }
-#pragma unroll
-        for (int n = 0; n < THIN_MAX; ++n)
-            if (n < g.N)                                          // wave-uniform
-                for (int o = tpr >> 1; o > 0; o >>= 1) acc[n] += __shfl_xor(acc[n], o);
-        if (mv && q < g.N) {
-            float v = (q == 0 ? acc[0] : q == 1 ? acc[1] : q == 2 ? acc[2] : acc[3]) + g.bias[q];
-            if (g.epi == EPI_BIAS_GELU) { g.Z[m * g.ldz + q] = v; v = gelu_erf(v); }
-            g.C[m * g.ldc + q] = v;
-        }
+        finish(m, mv, acc);
     }
 }
 
@@ -1230,8 +1281,11 @@ bool try_launch_thin(const GemmArgs& g, hipStream_t s) {
         int tpr = 4;                                              // lanes per row: >= n2 (one output column each), <= 64
         while (tpr < 64 && tpr * 4 < g.K) tpr <<= 1;
         const long rows_per_wg = 4L * (64 / tpr);
-        hipLaunchKernelGGL(thin_fwd_kernel, dim3((unsigned)std::min<long>((g.M + rows_per_wg - 1) / rows_per_wg, 16384)),
-                           dim3(256), 0, s, g, tpr);
+        // single-pass fp32 rows of many-row launches: 2048 workgroups walk the rows with eight row groups in flight each
+        const unsigned long long a_bytes = (unsigned long long)(((long)g.M - 1) * g.a_rs + g.K) * 4ull;
+        const int streamed = (g.K <= tpr * 4 && !g.a16 && a_bytes < PIT_MAX_BUFFER_BYTES && g.M >= 65536 && !getenv("PIT_NO_THIN_STREAM")) ? 1 : 0;
+        hipLaunchKernelGGL(thin_fwd_kernel, dim3((unsigned)std::min<long>((g.M + rows_per_wg - 1) / rows_per_wg, streamed ? 2048 : 16384)),
+                           dim3(256), 0, s, g, tpr, streamed);
         return true;
     }
     if (g.epi == EPI_ATOMIC && g.M <= THIN_MAX && g.ones_col == g.N - 1 && g.a_rs == 1 && g.b_cs == 1 && (g.N - 1) % 4 == 0 &&
