@@ -232,7 +232,7 @@ __global__ __launch_bounds__(256) void rel_max_fwd_kernel(const float* __restric
 }
 
 // Round 4: ONE 1024-thread workgroup per (sample, channel) series when the series fits its registers (npts <= 1024 PTS, PTS <= 16:
-// the NACA field of 11 271 points takes 12 - 31 -> 9 us against the split form, whose last arriver writes a series' gradients alone).
+// the NACA field of 11 271 points takes 12 - 31 -> 27 us against the split form, whose last arriver writes a series' gradients alone).
 // rel_lp_fwd_kernel's chain for a Darcy-sized series (1849 points split over 8 workgroups) is: loads -> two returning fp64
 // atomics -> a ticket -> three exchanges by the last arriver -> the gradient pass RE-READING the whole series: ~10.6 us of
 // dependent round trips for 15 k values.  Here the series stays in registers: loads (all in flight) -> block reduction ->
