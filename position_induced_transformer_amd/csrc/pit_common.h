@@ -120,6 +120,42 @@ __device__ __forceinline__ double head_scale_grad(float lmda, float c) {
     return (1.0 + (double)c * (double)c) * PIT_SCALE_K * cos((double)lmda);
 }
 
+// Wave-wide sums on the VALU's DPP lanes instead of six ds_bpermute round trips through the LDS pipe (round 4: the cross-lane
+// reduction, not the loads, bounded thin_fwd_kernel): quad swaps, row rotations by 4 and 8 (every lane of a 16-lane row then holds
+// the row's sum), row_bcast:15 / :31 into the following rows, the total read from lane 63.  Returned to EVERY lane.
+#ifndef PIT_NO_DPP_SUM
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, true));
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_d(double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)b, CTRL, ROW_MASK, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, ROW_MASK, 0xf, true);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ float wave_sum(float v) {
+    v += dpp_f<0xB1, 0xf>(v);                            // quad_perm(1,0,3,2)
+    v += dpp_f<0x4E, 0xf>(v);                            // quad_perm(2,3,0,1)
+    v += dpp_f<0x124, 0xf>(v);                           // row_ror:4
+    v += dpp_f<0x128, 0xf>(v);                           // row_ror:8
+    v += dpp_f<0x142, 0xa>(v);                           // row_bcast:15 -> rows 1 and 3
+    v += dpp_f<0x143, 0xc>(v);                           // row_bcast:31 -> rows 2 and 3
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+    v += dpp_d<0xB1, 0xf>(v);
+    v += dpp_d<0x4E, 0xf>(v);
+    v += dpp_d<0x124, 0xf>(v);
+    v += dpp_d<0x128, 0xf>(v);
+    v += dpp_d<0x142, 0xa>(v);
+    v += dpp_d<0x143, 0xc>(v);
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)b, 63), hi = __builtin_amdgcn_readlane((int)(b >> 32), 63);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+#else
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -130,6 +166,7 @@ __device__ __forceinline__ double wave_sum_d(double v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
     return v;
 }
+#endif
 
 __device__ __forceinline__ float gelu_erf(float x) {
     return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
