@@ -595,7 +595,8 @@ def parity_vs_oracle(args, step, model, affine, meta):
             # weight gradients are fp32 sums over batch x points rows on BOTH sides (the oracle's torch-CPU reductions too): the
             # 2e-5 of the tests (batch 2, tests/test_gpu_round2.py) grows with the square root of the rows beyond Darcy b=8's 14 792
             "tolerance": {"out": 1e-5, "weight_grad": round(2e-5 * max(1.0, (out_dev.numel() / meta["out_dim"] / 16384.0) ** 0.5), 7),
-                          "dlmda_worst_layer": 2e-4} if args.math == "fp32" else
+                          "dlmda_all_layers": 2e-4} if args.math == "fp32" else     # (one vector, as the tests judge it: a single layer's
+                                                                                     # d(lmda) can be 1e-9 of the others - its own ratio is noise)
                          {"out": 2e-2, "weight_grad": 5e-2, "dlmda_all_layers": 5e-2},
             "what": "the timed hipGraph's own results (prediction, loss, flat gradient buffer after its last replay) vs "
                     "oracle/pit_oracle.py forward+loss+backward on this host, same parameters and inputs",

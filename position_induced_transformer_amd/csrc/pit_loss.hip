@@ -238,14 +238,17 @@ __global__ __launch_bounds__(256) void rel_max_fwd_kernel(const float* __restric
 // dependent round trips for 15 k values.  Here the series stays in registers: loads (all in flight) -> block reduction ->
 // norms -> the gradients straight from the registers; the loss accumulates through ONE returning 64-bit atomic (arrival count
 // in the top 16 bits, the sum in 2^-32 fixed point below: batch * nch <= 65535 pairs, loss < 65536).
-template <int PTS>
+// PK: the exponent at compile time (1, 2; 0 = the run-time p): with a run-time p the generic powf path is inlined for every value of the
+// series in both passes - 12.7 k instructions at PTS = 12, more than the instruction cache holds: the NACA loss took 26.7 us
+template <int PTS, int PK>
 __global__ __launch_bounds__(1024) void rel_lp_fwd1_kernel(const float* __restrict__ tru, const float* __restrict__ pred,
                                                            const float* __restrict__ scale, const float* __restrict__ shift,
-                                                           int npts, int nch, int p, float* __restrict__ norms,
+                                                           int npts, int nch, int p_arg, float* __restrict__ norms,
                                                            float* __restrict__ loss, float* __restrict__ ws,
                                                            float* __restrict__ d_pred_unit, float* __restrict__ d_true_unit,
                                                            float* __restrict__ clear_buf, long clear_n) {
     __shared__ double s_num[16], s_den[16];
+    const int p = PK ? PK : p_arg;
     const int tid = threadIdx.x;
     if (clear_buf) {
         const long nthreads = (long)gridDim.x * gridDim.y * blockDim.x;
@@ -329,11 +332,13 @@ bool launch_rel_lp_fwd1(const float* tru, const float* pred, const float* scale,
     if (off || npts > 16384 || (long)batch * nch > 4096) return false;          // (series of up to 16 values per thread: 64 registers)
     const dim3 grid(nch, batch), block(1024);
     const int pts = (npts + 1023) / 1024;
-#define PIT_L1(P_) hipLaunchKernelGGL(rel_lp_fwd1_kernel<P_>, grid, block, 0, s, tru, pred, scale, shift, npts, nch, p, norms, loss, ws, \
-                                       d_pred_unit, d_true_unit, clear_buf, clear_n)
+#define PIT_L1K(P_, K_) hipLaunchKernelGGL((rel_lp_fwd1_kernel<P_, K_>), grid, block, 0, s, tru, pred, scale, shift, npts, nch, p, norms, loss, ws, \
+                                           d_pred_unit, d_true_unit, clear_buf, clear_n)
+#define PIT_L1(P_) do { if (p == 2) PIT_L1K(P_, 2); else if (p == 1) PIT_L1K(P_, 1); else PIT_L1K(P_, 0); } while (0)
     if (pts <= 1) PIT_L1(1); else if (pts <= 2) PIT_L1(2); else if (pts <= 4) PIT_L1(4); else if (pts <= 8) PIT_L1(8);
     else if (pts <= 12) PIT_L1(12); else PIT_L1(16);
 #undef PIT_L1
+#undef PIT_L1K
     return true;
 }
 
