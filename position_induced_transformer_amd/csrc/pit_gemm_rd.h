@@ -406,15 +406,16 @@ __device__ __forceinline__ void rr_rider(const pit_detail::GemmArgs& g, int id, 
 }
 // workgroup `id` of a carried pair of weight-gradient reductions; `smem`: the launch's dynamic LDS (64 KiB when the plan
 // allowed rr reductions, see plan_dw_pair)
+// (ONE instance of each reduction body per call site: the job's arguments are selected first.  With a body per reduction -
+// and block_bwd_kernel calling this for two pairs - that kernel carried eight inlined reduction bodies, 14.8 k instructions)
 __device__ __forceinline__ void dw_pair_body(const pit_detail::DwPair& w, int id, float* smem) {
-    if (id < w.n1) {
-        if (w.rr1) rr_rider(w.g1, id, w.tx1, w.tiles1, w.slabs1, w.nchunks, smem);
-        else gemm_rd_body<1, EPI_ATOMIC>(w.g1, id % w.gx1, (id / w.gx1) % w.gy1, id / (w.gx1 * w.gy1));
-    } else {
-        id -= w.n1;
-        if (w.rr2) rr_rider(w.g2, id, w.tx2, w.tiles2, w.slabs2, w.nchunks, smem);
-        else gemm_rd_body<1, EPI_ATOMIC>(w.g2, id % w.gx2, (id / w.gx2) % w.gy2, id / (w.gx2 * w.gy2));
-    }
+    const bool second = id >= w.n1;
+    if (second) id -= w.n1;
+    const GemmArgs& g = second ? w.g2 : w.g1;
+    const int rr = second ? w.rr2 : w.rr1, tx = second ? w.tx2 : w.tx1, tiles = second ? w.tiles2 : w.tiles1;
+    const int slabs = second ? w.slabs2 : w.slabs1, gx = second ? w.gx2 : w.gx1, gy = second ? w.gy2 : w.gy1;
+    if (rr) rr_rider(g, id, tx, tiles, slabs, w.nchunks, smem);
+    else gemm_rd_body<1, EPI_ATOMIC>(g, id % gx, (id / gx) % gy, id / (gx * gy));
 }
 
 
