@@ -535,13 +535,16 @@ def _compare_with_oracle(model, out, loss, ref, ref_loss, p, tol_out=1e-5):
     assert gio.rel_l2(np.concatenate(he), np.concatenate(hg)) <= 2e-4
 
 
-def test_naca_full_size_matches_oracle():
+@pytest.mark.parametrize("batch", [2, 3])
+def test_naca_full_size_matches_oracle(batch):
     """train_naca.py:17-89 at the script's size (120-point outline -> 728 latent points cut out of the
-    221x51 body-fitted grid -> 11 271 output points, hid 128, 1 head, 4 blocks, per-sample meshes), batch 2:
-    forward, RelL2 loss and every gradient against the oracle (was a finite-and-shape check)."""
+    221x51 body-fitted grid -> 11 271 output points, hid 128, 1 head, 4 blocks, per-sample meshes):
+    forward, RelL2 loss and every gradient against the oracle (was a finite-and-shape check).
+    Batch 2 = 22 542 decoder rows builds its plan with plan_rows_reg (a wave per row); batch 3 = 33 813 rows is past the
+    32 768-row switch and runs plan_rows_lane (a row per lane) - the kernel the batch-20 bench runs."""
     from position_induced_transformer_amd import ops, tasks, utils
     model, sample, meta = tasks.make_task("naca", seed=61)
-    mesh_in, func_in, mesh_out, target = sample(2)
+    mesh_in, func_in, mesh_out, target = sample(batch)
     with ops.head_scale_route("host"):
         out = model(mesh_in, func_in, mesh_out)
         loss = utils.RelLpNorm(4, 2)(target, out)
@@ -549,8 +552,9 @@ def test_naca_full_size_matches_oracle():
     torch.cuda.synchronize()
     p = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in model.state_dict().items()}
     mo = mesh_out.cpu()
-    ltt = mo[:, ::4, ::4, :][:, :56, :13, :].reshape(2, -1, 2)                  # train_naca.py:62-65
-    ref = orc.pit_apply(p, "euclid", True, 4, 0.02, 0.02, mesh_in.cpu(), func_in.cpu(), ltt, mo.reshape(2, -1, 2)).reshape(2, 221, 51, 4)
+    ltt = mo[:, ::4, ::4, :][:, :56, :13, :].reshape(batch, -1, 2)              # train_naca.py:62-65
+    ref = orc.pit_apply(p, "euclid", True, 4, 0.02, 0.02, mesh_in.cpu(), func_in.cpu(), ltt,
+                        mo.reshape(batch, -1, 2)).reshape(batch, 221, 51, 4)
     ref_loss = orc.rel_lp_loss(target.cpu(), ref, 4, 2)
     ref_loss.backward()
     _compare_with_oracle(model, out, loss, ref, ref_loss, p)
