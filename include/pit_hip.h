@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PIT_ABI_VERSION 16
+#define PIT_ABI_VERSION 17
 #define PIT_DSCALE_SLOTS 1024 /* fp64 accumulators per head in pit_posatt_bwd's workspace */
 
 /* distance metric (dist2att variants) */
@@ -117,10 +117,15 @@ int pit_lists_transpose(const int* nbr_idx, const int* nbr_cnt, int mesh_batch, 
 /* pit_select_fwd (need_kth = 1) and pit_neighbors_fwd in ONE pass over the rows: the distances of
  * a row stay in registers, the order statistics are searched on a narrowed candidate set and the
  * lists are emitted from the same registers (rows longer than 4096 keys fall back to the two
- * streaming passes).  Arguments as in those two functions; stats is written, then used. */
+ * streaming passes).  Arguments as in those two functions; stats is written, then used.
+ * flags (0 = let the library choose; ABI 17 - these were environment reads per call): PIT_PLAN_WAVE_PER_ROW keeps the
+ * wave-per-row kernel where the one-row-per-lane kernel (per-sample meshes from 32 768 rows) would run, PIT_PLAN_TWO_PASSES
+ * forces the two streaming passes.  Same results either way (tests compare them). */
+#define PIT_PLAN_WAVE_PER_ROW 1
+#define PIT_PLAN_TWO_PASSES   2
 int pit_plan_fwd(const float* mesh_out, const float* mesh_in, int mesh_batch, int n_out, int n_in,
                  int space_dim, int metric, float period, int rank_k, float* stats, int cap,
-                 int* nbr_idx, int* nbr_cnt, int* rev_ptr, int* rev_row, int* workspace, void* stream);
+                 int* nbr_idx, int* nbr_cnt, int* rev_ptr, int* rev_row, int* workspace, int flags, void* stream);
 
 /* Candidate lists for the masked layers (sparse path).  For every row: the keys with
  * m <= m_(k+1)*(1+2^-21) - a superset of the kept set of pit.py:50 for ANY head scale (k+2 keys
@@ -162,29 +167,7 @@ int pit_posatt_fwd(const float* mesh_out, const float* mesh_in, int mesh_batch, 
                    float* rowstat, float* scale_out,
                    const int* nbr_idx, const int* nbr_cnt, int nbr_cap, int coord_dims, int math_mode, void* stream);
 
-/* pit_posatt_bwd with the END-OF-PASS FINISH inside (round 4).  `fin` lists every layer whose d(scale) accumulators are loaded and
- * waiting (pit_posatt_dhead_finish's arguments) INCLUDING this call's own layer at index `self` (its workspace / d_head / head /
- * scale / flags: the values this call was given; this call must use PIT_HEAD_DEFER).  When this call is a d(scale)-only
- * candidate-list launch of the small regime, extra workgroups of the launch drain the other layers' accumulators while the rows
- * run and the LAST workgroup to arrive (device-side counter `counter`: one int, zero on entry, left zero) drains this layer's:
- * *taken = 1 and no pit_posatt_dhead_finish launch is needed for the listed layers.  Otherwise *taken = 0 and the call behaves
- * exactly like pit_posatt_bwd (the caller finishes later, as before).  fin == NULL: exactly pit_posatt_bwd. */
-struct pit_head_finish_job {
-    int n_layers; double* const* workspaces; float* const* d_heads; const float* const* heads; const float* const* scales;
-    const int* n_heads; const int* flags; int self; int* counter; int* taken;
-};
 struct pit_mlp_params_job;
-int pit_posatt_bwd_job(const float* mesh_out, const float* mesh_in, int mesh_batch, int n_out, int n_in,
-                       int space_dim, int metric, float period,
-                       const float* values, int batch, int dim, long ld_values, long values_bstride,
-                       const float* head, int n_head, int head_is_scale, const float* scale,
-                       const float* rowstat, int masked,
-                       const float* d_out, long ld_dout, long dout_bstride, int out_col0,
-                       float* d_values, long ld_dvalues, long dvalues_bstride, int add_residual,
-                       float* d_head, int accumulate_head, double* workspace,
-                       const int* nbr_idx, const int* nbr_cnt, int nbr_cap, int nbr_complete,
-                       const int* rev_ptr, const int* rev_row, const struct pit_mlp_params_job* rider,
-                       int coord_dims, int math_mode, void* stream, const struct pit_head_finish_job* fin);
 
 /* pit_posatt_fwd with a RIDER (round 4): the processor's block weights (pit_block_weights, declared below - they depend on
  * the latent mesh and the lmda's only, not on this layer's data) formed by extra workgroups of the SAME launch when this
@@ -331,54 +314,6 @@ int pit_posatt_pre_bwd(const float* e, const float* q, const float* rowstat, int
                        float* d_values, long ld_dvalues, long dvalues_bstride, int add_residual,
                        double* workspace, int math_mode, void* stream);
 
-/* ---- Persistent latent kernels (round 4; csrc/pit_latent.hip) -----------------------------------------------------
- * The same processor as ONE launch per direction: a workgroup keeps its (sample, 16-point slab) through all blocks and
- * the dependency between blocks (block i+1 contracts over every latent point of the same sample, pit.py:116-121) is a
- * per-sample hand-off inside the launch (write-through stores, one flag word per slab, sc1 loads on the consuming side:
- * correct for any workgroup placement).  Results are bit-identical to the pit_block_fwd / pit_block_bwd launches.
- *
- * pit_latent_supported: pit_block_supported AND all slab workgroups co-resident on the current device (forward: one workgroup
- *   per slab, backward: two; they wait for each other), n_pts <= 1024, batch <= 64, n_layers <= 16.
- * sync: PIT_LATENT_SYNC_WORDS 32-bit words, zeroed ONCE by the caller when allocated (the kernels leave them zero);
- *   one workspace per stream.  sync[0] != 0 after a launch: a wait timed out (2 s) - the results are void.
- * flags: PIT_LATENT_LINEAR_MAP spreads a sample's slabs over all XCDs (tests: the hand-off must not depend on placement);
- *   PIT_LATENT_NO_FAST keeps every hand-off write-through.  By default a producer switches to plain stores + a plain flag
- *   after its first wait IF every consumer of its sample has published that it runs on the producer's XCD (their sc1 loads
- *   are then served by the L2 the plain stores land in: 1.9 instead of 3.1 us per hop, tools/micro/handoff_probe.hip).
- *
- * pit_latent_fwd: xcat[l] (batch*n_pts, (1+n_head)*dim) concat buffer of block l (HOST array of device pointers;
- *   columns [0, dim) of xcat[0] hold the input, everything else is written here and kept for the backward);
- *   w1 / b1 / w2 / b2: host arrays of the blocks' MLP parameters; e / inv: pit_block_weights' outputs for all layers;
- *   z1 / h / z2: (n_layers, batch*n_pts, dim) saved activations; out (batch*n_pts, dim) rows ld_out apart.
- *
- * pit_latent_bwd: the whole backward chain in one launch.  d_out (batch*n_pts, dim) rows ld_dout apart is the gradient of
- *   the last block's output; d_in receives the gradient of the processor's input.  Per block l (HOST arrays): xcat[l] the
- *   forward's concat buffer, d_xcat[l] (batch*n_pts, (1+n_head)*dim) scratch for the gradient of that buffer, w1 / w2 the
- *   block's MLP weights, scratch[l] (batch*n_pts*2*dim floats: dZ1 | dZ2, the layout of pit_mlp_bwd_data - read by the
- *   weight-gradient reductions afterwards: pit_mlp_bwd_params / _batch with scratch[l] and d_y = scratch[l]),
- *   dscale[l] the block's d(scale) accumulators (PIT_HEAD_DEFER convention, drain with pit_posatt_dhead_finish) or NULL.
- *   z1 / z2 as saved by pit_latent_fwd; e / inv / qw from pit_block_weights.  The launch has 2 x the forward's workgroups
- *   (chain + helpers), all co-resident.
- *   h (n_layers, rows, dim) + d_w1 / d_b1 / d_w2 / d_b2 (HOST arrays, entries may be NULL): the helpers also ACCUMULATE the
- *   weight gradients of block l's MLP into these (each sample's share as soon as its dZ exists: the reductions of
- *   pit_mlp_bwd_params with accumulate = 1); NULL h or NULL d_w1[l]: the caller runs them afterwards.
- *   rider: a postponed job as in pit_posatt_bwd (the decoder MLP's reductions) performed by the helpers first. */
-#define PIT_LATENT_SYNC_WORDS 12416
-#define PIT_LATENT_LINEAR_MAP 1
-#define PIT_LATENT_NO_FAST 2
-int pit_latent_supported(int n_pts, int n_head, int dim, int batch, int n_layers);
-int pit_latent_fwd(const float* e, const float* inv, int n_pts, int n_head, int dim, int batch, int n_layers,
-                   float* const* xcat, const float* const* w1, const float* const* b1, const float* const* w2,
-                   const float* const* b2, float* z1, float* h, float* z2, float* out, long ld_out,
-                   unsigned* sync, int flags, int math_mode, void* stream);
-int pit_latent_bwd(const float* e, const float* inv, const float* qw, int n_pts, int n_head, int dim, int batch, int n_layers,
-                   const float* const* xcat, float* const* d_xcat, const float* const* w1, const float* const* w2,
-                   const float* z1, const float* z2, float* const* scratch, double* const* dscale,
-                   const float* h, float* const* d_w1, float* const* d_b1, float* const* d_w2, float* const* d_b2,
-                   const struct pit_mlp_params_job* rider,
-                   const float* d_out, long ld_dout, float* d_in, long ld_din,
-                   unsigned* sync, int flags, int math_mode, void* stream);
-
 /* kaiming_mlp.forward (pit.py:21-26): y = W2 * gelu_erf(W1 x + b1) + b2, optionally
  * followed by the trailing gelu of pit.py:111,121 (out_gelu=1).
  *   x (rows, n0) rows ldx apart; w1 (n1,n0), b1 (n1), w2 (n2,n1), b2 (n2) contiguous;
@@ -412,12 +347,6 @@ int pit_mlp_bwd_params(const float* x, long ldx, int rows, int n0, int n1, int n
                        int out_gelu, const float* d_y, long ld_dy,
                        float* d_w1, float* d_b1, float* d_w2, float* d_b2,
                        int accumulate, const float* scratch, int math_mode, void* stream);
-/* n postponed pit_mlp_bwd_params calls (each with accumulate = 1 when it is to share a launch) performed together: the
- * small ones as ONE launch whose workgroups are dealt to the jobs (up to 8 per launch), the others by the launches
- * pit_mlp_bwd_params would have made, in order.  `jobs` is a HOST array, read during the call.  What a backward pass in
- * the latency regime does with its weight gradients: nothing downstream reads them, so they leave the dependent chain
- * entirely and run once, chip-wide, when the pass ends (ops.DW_BATCH). */
-int pit_mlp_bwd_params_batch(int n, const struct pit_mlp_params_job* jobs, void* stream);
 /* 1 if postponing pit_mlp_bwd_params of this shape and handing it to the next pit_posatt_bwd as `rider` costs
  * nothing when the attention call cannot merge it (i.e. pit_mlp_bwd would have issued _data and _params as
  * separate launches anyway), else 0 (pit_mlp_bwd merges d_x with the reductions: keep the single call). */

@@ -25,12 +25,6 @@ class MlpParamsJob(ctypes.Structure):
                 ("accumulate", _I), ("scratch", _P), ("math_mode", _I)]
 
 
-class HeadFinishJob(ctypes.Structure):
-    """pit_head_finish_job of include/pit_hip.h (pit_posatt_dhead_finish's arguments + this layer's index, counter, result)."""
-    _fields_ = [("n_layers", _I), ("workspaces", _P), ("d_heads", _P), ("heads", _P), ("scales", _P), ("n_heads", _P),
-                ("flags", _P), ("self", _I), ("counter", _P), ("taken", _P)]
-
-
 class BlockWeightsJob(ctypes.Structure):
     """pit_block_weights_job of include/pit_hip.h (the argument list of pit_block_weights)."""
     _fields_ = [("mesh", _P), ("n_pts", _I), ("space_dim", _I), ("metric", _I), ("period", _F),
@@ -44,7 +38,7 @@ SIGNATURES = {
     "pit_error_string": [_I],
     "pit_head_scale": [_P, _I, _P, _P],
     "pit_select_fwd": [_P, _P, _I, _I, _I, _I, _I, _F, _I, _I, _P, _P],
-    "pit_plan_fwd": [_P, _P, _I, _I, _I, _I, _I, _F, _I, _P, _I, _P, _P, _P, _P, _P, _P],
+    "pit_plan_fwd": [_P, _P, _I, _I, _I, _I, _I, _F, _I, _P, _I, _P, _P, _P, _P, _P, _I, _P],
     "pit_lists_transpose": [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P],
     "pit_neighbors_fwd": [_P, _P, _I, _I, _I, _I, _I, _F, _P, _I, _P, _P, _P, _P, _P, _P],
     "pit_posatt_fwd": [_P, _P, _I, _I, _I, _I, _I, _F,
@@ -66,13 +60,6 @@ SIGNATURES = {
                        _P, _L, _L, _I,
                        _P, _L, _L, _I,
                        _P, _I, _P, _P, _P, _I, _I, _P, _P, _P, _I, _I, _P],
-    "pit_posatt_bwd_job": [_P, _P, _I, _I, _I, _I, _I, _F,
-                           _P, _I, _I, _L, _L,
-                           _P, _I, _I, _P,
-                           _P, _I,
-                           _P, _L, _L, _I,
-                           _P, _L, _L, _I,
-                           _P, _I, _P, _P, _P, _I, _I, _P, _P, _P, _I, _I, _P, _P],
     "pit_posatt_dhead_finish": [_I, _P, _P, _P, _P, _P, _P, _P],
     "pit_block_supported": [_I, _I, _I, _I],
     "pit_block_weights": [_P, _I, _I, _I, _F, _I, _P, _I, _I, _P, _P, _P, _P, _P, _P],
@@ -80,9 +67,6 @@ SIGNATURES = {
     "pit_posatt_pre_supported": [_I, _I, _I, _I],
     "pit_posatt_pre_fwd": [_P, _P, _I, _I, _I, _I, _P, _L, _L, _P, _L, _L, _I, _I, _I, _P],
     "pit_posatt_pre_bwd": [_P, _P, _P, _I, _I, _I, _I, _P, _L, _L, _P, _L, _L, _I, _P, _L, _L, _I, _P, _I, _P],
-    "pit_latent_supported": [_I, _I, _I, _I, _I],
-    "pit_latent_fwd": [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _I, _I, _P],
-    "pit_latent_bwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _L, _P, _I, _I, _P],
     "pit_block_bwd": [_P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _L, _P, _P, _L, _P, _P, _I, _P],
     "pit_mlp_bf16_io_supported": [_I, _I, _I, _I, _I],
     "pit_mlp_fwd": [_P, _L, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _L, _I, _P],
@@ -91,7 +75,6 @@ SIGNATURES = {
     "pit_mlp_bwd_data": [_I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _L, _P, _L, _P, _I, _P],
     "pit_mlp_bwd_params": [_P, _L, _I, _I, _I, _I, _P, _I, _P, _L, _P, _P, _P, _P, _I, _P, _I, _P],
     "pit_mlp_bwd_params_deferrable": [_I, _I, _I, _I, _I, _L],
-    "pit_mlp_bwd_params_batch": [_I, _P, _P],
     "pit_rel_lp_loss_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P],
     "pit_rel_lp_loss_fwd_grad": [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _L, _P],
     "pit_rel_lp_loss_bwd": [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P],
@@ -102,7 +85,7 @@ SIGNATURES = {
     "pit_debug_mfma_tile": [_P, _P, _P, _P],
 }
 
-ABI_VERSION = 16       # PIT_ABI_VERSION of include/pit_hip.h this binding was written against
+ABI_VERSION = 17       # PIT_ABI_VERSION of include/pit_hip.h this binding was written against
 
 _lib = None
 

@@ -13,7 +13,7 @@ CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 # PIT_LIB_OUT: diagnostic builds (PIT_EXTRA_FLAGS=-DPIT_STAMPS ...) go to their OWN library and object directory, so they
 # can never be mistaken for the production library; load them with PIT_LIB_PATH
 LIB = os.environ.get("PIT_LIB_OUT") or os.path.join(CSRC, "libpit_hip.so")
-SOURCES = ("pit_abi.hip", "pit_select.hip", "pit_posatt.hip", "pit_block.hip", "pit_latent.hip", "pit_mlp.hip", "pit_mlp_slab.hip", "pit_loss.hip", "pit_norm.hip", "pit_optim.hip")
+SOURCES = ("pit_abi.hip", "pit_select.hip", "pit_posatt.hip", "pit_block.hip", "pit_mlp.hip", "pit_mlp_slab.hip", "pit_loss.hip", "pit_norm.hip", "pit_optim.hip")
 HEADERS = ("pit_common.h", "pit_gemm_rd.h", "pit_block_dev.h", os.path.join("..", "..", "include", "pit_hip.h"))
 FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17"]
 FLAGS += os.environ.get("PIT_EXTRA_FLAGS", "").split()      # diagnostic builds only (e.g. -DPIT_STAMPS, tools/stamp_tiles.py)
@@ -50,8 +50,20 @@ def build(force: bool = False, verbose: bool = False) -> str:
         os.makedirs(objdir, exist_ok=True)
         cflags = [f for f in FLAGS if f != "-shared"]
 
+        try:
+            with open(STAMP) as f:
+                same_flags = f.read() == " ".join(FLAGS)
+        except OSError:
+            same_flags = False
+        hdr_time = max(os.path.getmtime(os.path.join(CSRC, h)) for h in HEADERS if os.path.exists(os.path.join(CSRC, h)))
+
         def compile_one(src: str) -> str:
             obj = os.path.join(objdir, src.replace(".hip", ".o"))
+            # an object newer than its source and every header, built with these flags, is reused (a change to one
+            # translation unit recompiles that unit only)
+            if not force and same_flags and os.path.exists(obj) and \
+                    os.path.getmtime(obj) > max(hdr_time, os.path.getmtime(os.path.join(CSRC, src))):
+                return obj
             cmd = [hipcc] + cflags + ["-c", os.path.join(CSRC, src), "-o", obj]
             if verbose:
                 print(" ".join(cmd))

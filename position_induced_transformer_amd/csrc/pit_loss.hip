@@ -236,8 +236,8 @@ __global__ __launch_bounds__(256) void rel_max_fwd_kernel(const float* __restric
 // rel_lp_fwd_kernel's chain for a Darcy-sized series (1849 points split over 8 workgroups) is: loads -> two returning fp64
 // atomics -> a ticket -> three exchanges by the last arriver -> the gradient pass RE-READING the whole series: ~10.6 us of
 // dependent round trips for 15 k values.  Here the series stays in registers: loads (all in flight) -> block reduction ->
-// norms -> the gradients straight from the registers; the loss accumulates through ONE returning 64-bit atomic (arrival count
-// in the top 16 bits, the sum in 2^-32 fixed point below: batch * nch <= 65535 pairs, loss < 65536).
+// norms -> the gradients straight from the registers; the loss accumulates in an fp64 word, the arrivals in a ticket word of
+// their own (round 5; non-finite terms propagate to *loss and the workspace is always left zero).
 // PK: the exponent at compile time (1, 2; 0 = the run-time p): with a run-time p the generic powf path is inlined for every value of the
 // series in both passes - 12.7 k instructions at PTS = 12, more than the instruction cache holds: the NACA loss took 26.7 us
 template <int PTS, int PK>
@@ -291,14 +291,18 @@ __global__ __launch_bounds__(1024) void rel_lp_fwd1_kernel(const float* __restri
     if (tid == 0) {
         norms[(long)pair * 2 + 0] = nn;
         norms[(long)pair * 2 + 1] = dn;
+        // the pair's term joins an fp64 accumulator, THEN the arrival ticket (its own word): a non-finite term (0/0 from an all-zero
+        // target series, a diverged prediction) reaches *loss as nan / inf exactly as the reference's LpLoss reports it, and can
+        // never disturb the count - a packed count|fixed-point word (round 4) turned inf into a finite wrong loss and, once the
+        // borrow hit the count, left the accumulator armed for every later call
         const float term = (float)(nnd / dnd / nch);
-        unsigned long long* acc = reinterpret_cast<unsigned long long*>(ws + 2);
-        const unsigned long long add = (1ull << 48) + (unsigned long long)((double)term * 4294967296.0 + 0.5);
-        const unsigned long long old = atomicAdd(acc, add);
-        if ((old >> 48) == (unsigned long long)pairs - 1ull) {
-            const unsigned long long tot = (old + add) & ((1ull << 48) - 1ull);
-            *loss = (float)((double)tot / 4294967296.0);
-            atomicExch(acc, 0ull);
+        double* acc = reinterpret_cast<double*>(ws + 2);
+        const double old = atomicAdd(acc, (double)term);
+        asm volatile("" ::"v"(old));                   // returning atomic: performed before the ticket below
+        unsigned* counter = reinterpret_cast<unsigned*>(ws + 1);
+        if (atomicAdd(counter, 1u) == (unsigned)pairs - 1u) {
+            *loss = (float)__longlong_as_double(atomicExch(reinterpret_cast<unsigned long long*>(acc), 0ull));
+            atomicExch(counter, 0u);
         }
     }
     if (!d_pred_unit && !d_true_unit) return;

@@ -46,24 +46,6 @@ __global__ __launch_bounds__(512) void gemm_rd_pair_kernel(GemmArgs g1, GemmArgs
     }
 }
 
-// the weight-gradient reductions of SEVERAL MLPs (up to DW_BATCH_MAX pairs) in ONE launch (pit_mlp_bwd_params_batch): the
-// small-regime backward pass postpones every MLP's reductions - nothing downstream reads them - and runs them together
-// when the pass ends, as one chip-filling grid instead of riders that lengthen every launch of the dependent chain
-constexpr int DW_BATCH_MAX = 7;                     // (7 x 528 B of DwPair + the header stay under the 4 KB kernel-argument limit)
-struct DwBatch { int n; int base[DW_BATCH_MAX + 1]; pit_detail::DwPair p[DW_BATCH_MAX]; };
-__global__ __launch_bounds__(512) void gemm_rd_batch_kernel(DwBatch b) {
-    int i = 0;
-    while (i + 1 < b.n && (int)blockIdx.x >= b.base[i + 1]) ++i;
-    const pit_detail::DwPair& w = b.p[i];
-    int id = (int)blockIdx.x - b.base[i];
-    if (id < w.n1) {
-        gemm_rd_body<1, EPI_ATOMIC>(w.g1, id % w.gx1, (id / w.gx1) % w.gy1, id / (w.gx1 * w.gy1));
-    } else {
-        id -= w.n1;
-        gemm_rd_body<1, EPI_ATOMIC>(w.g2, id % w.gx2, (id / w.gx2) % w.gy2, id / (w.gx2 * w.gy2));
-    }
-}
-
 // the three GEMMs that follow dZ1 in an MLP backward - dX = dZ1 W1 (EPI_STORE, on the critical path:
 // its workgroups come first) and the two weight-gradient reductions - are independent of each
 // other: one launch, so the small latency-bound grids share the chip
@@ -1283,7 +1265,8 @@ bool try_launch_thin(const GemmArgs& g, hipStream_t s) {
         const long rows_per_wg = 4L * (64 / tpr);
         // single-pass fp32 rows of many-row launches: 2048 workgroups walk the rows with eight row groups in flight each
         const unsigned long long a_bytes = (unsigned long long)(((long)g.M - 1) * g.a_rs + g.K) * 4ull;
-        const int streamed = (g.K <= tpr * 4 && !g.a16 && a_bytes < PIT_MAX_BUFFER_BYTES && g.M >= 65536 && !getenv("PIT_NO_THIN_STREAM")) ? 1 : 0;
+        static const bool no_stream = getenv("PIT_NO_THIN_STREAM") != nullptr;      // (diagnostic switch, read once)
+        const int streamed = (g.K <= tpr * 4 && !g.a16 && a_bytes < PIT_MAX_BUFFER_BYTES && g.M >= 65536 && !no_stream) ? 1 : 0;
         hipLaunchKernelGGL(thin_fwd_kernel, dim3((unsigned)std::min<long>((g.M + rows_per_wg - 1) / rows_per_wg, streamed ? 2048 : 16384)),
                            dim3(256), 0, s, g, tpr, streamed);
         return true;
@@ -1699,36 +1682,6 @@ bool pit_detail::plan_dw_pair(const pit_mlp_params_job& j, int waves, DwPair* ou
         as_rr(out->g2, out->rr2, out->tx2, out->tiles2, out->slabs2, out->n2);
     }
     return true;
-}
-
-// include/pit_hip.h: n postponed pit_mlp_bwd_params calls performed together
-extern "C" int pit_mlp_bwd_params_batch(int n, const pit_mlp_params_job* jobs, void* stream) {
-    if (n <= 0) return 0;
-    if (!jobs) return PIT_ERR_NULL;
-    hipStream_t s = (hipStream_t)stream;
-    int i = 0;
-    while (i < n) {
-        DwBatch b;
-        b.n = 0; b.base[0] = 0;
-        // consecutive jobs small enough to share a launch; a job that is not (or the seventh) ends the group
-        static const int target = getenv("PIT_DW_BATCH_WGS") ? atoi(getenv("PIT_DW_BATCH_WGS")) : 768;
-        while (i < n && b.n < DW_BATCH_MAX && pit_detail::plan_dw_pair(jobs[i], 8, &b.p[b.n], target)) {
-            b.base[b.n + 1] = b.base[b.n] + b.p[b.n].n1 + b.p[b.n].n2;
-            ++b.n; ++i;
-        }
-        if (b.n > 0) {
-            static bool once = ((void)hipFuncSetAttribute((const void*)gemm_rd_batch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 98304), true);
-            (void)once;
-            hipLaunchKernelGGL(gemm_rd_batch_kernel, dim3((unsigned)b.base[b.n]), dim3(512), (size_t)8 * 16 * 64 * sizeof(float), s, b);
-            PIT_CHECK_LAUNCH();
-        }
-        if (i < n && b.n < DW_BATCH_MAX) {               // this one does not ride: its own launches
-            const pit_mlp_params_job& j = jobs[i++];
-            if (int rc = pit_mlp_bwd_params(j.x, j.ldx, j.rows, j.n0, j.n1, j.n2, j.h, j.out_gelu, j.d_y, j.ld_dy, j.d_w1, j.d_b1,
-                                            j.d_w2, j.d_b2, j.accumulate, j.scratch, j.math_mode, stream)) return rc;
-        }
-    }
-    return 0;
 }
 
 // include/pit_hip.h: the shapes whose forward / backward run entirely on the kernels that honour the PIT_IO_* flags (the

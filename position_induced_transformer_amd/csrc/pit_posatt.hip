@@ -2839,58 +2839,6 @@ __global__ __launch_bounds__(256, 4) void posatt_sparse_rows_dw(AttArgs a, Spars
     sparse_rows_body<NH, CR, 1>(a, sp, id % gx, (id / gx) % gy, id / (gx * gy));
 }
 
-// The same launch as the LAST attention launch of a backward pass (pit_posatt_bwd_job): `n_fin` more workgroups drain the d(scale)
-// accumulators of the pass's OTHER layers (complete when this launch starts), and the last row workgroup to arrive drains this
-// layer's own - no finishing launch at the end of the pass.
-__device__ __forceinline__ void finish_entry(const FinishBatch& fb, int g, double* s_red) {
-    int l = 0;
-    while (l + 1 < fb.n && g >= fb.wg_base[l + 1]) ++l;
-    AttArgs a = AttArgs();
-    a.dscale_acc = fb.ws[l];
-    a.nslots = PIT_DSCALE_SLOTS;
-    a.d_head = fb.d_head[l];
-    a.dhead_src = fb.head[l];
-    a.dhead_is_scale = (fb.flags[l] & PIT_HEAD_IS_SCALE) ? 1 : 0;
-    a.accumulate_head = (fb.flags[l] & PIT_HEAD_ACCUMULATE) ? 1 : 0;
-    a.head = fb.scale[l] ? fb.scale[l] : fb.head[l];
-    a.head_is_scale = (fb.scale[l] || a.dhead_is_scale) ? 1 : 0;
-    dscale_drain_head(a, g - fb.wg_base[l], s_red);
-}
-template <int NH, int CR>
-__global__ __launch_bounds__(256, 4) void posatt_sparse_rows_dwf(AttArgs a, SparseArgs sp, int gx, int gy, int n_dw,
-                                                               pit_detail::DwPair w, FinishBatch fb, int self, int n_fin,
-                                                               int n_att, int* counter) {
-    __shared__ double s_red[10];
-    __shared__ int s_last;
-    int id = blockIdx.x;
-    if (id < n_dw) {                                     // (first: see posatt_sparse_bwd_kernel)
-        dw_pair_body(w, id, pit_dyn_smem());
-        return;
-    }
-    id -= n_dw;
-    if (id < n_fin) {                                    // another layer's (layer, head): skip this layer's own range
-        const int g = id < fb.wg_base[self] ? id : id + (fb.wg_base[self + 1] - fb.wg_base[self]);
-        finish_entry(fb, g, s_red);
-        return;
-    }
-    id -= n_fin;
-    sparse_rows_body<NH, CR, 1>(a, sp, id % gx, (id / gx) % gy, id / (gx * gy));
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __threadfence();                                 // this workgroup's accumulator adds before its arrival
-        s_last = atomicAdd(counter, 1) == n_att - 1;
-    }
-    __syncthreads();
-    if (s_last) {
-        __threadfence();
-        for (int g = fb.wg_base[self]; g < fb.wg_base[self + 1]; ++g) {
-            finish_entry(fb, g, s_red);
-            __syncthreads();
-        }
-        if (threadIdx.x == 0) *counter = 0;              // (left zero for the next pass)
-    }
-}
-
 constexpr size_t DW_SMEM_4WAVES = 4 * 16 * 64 * sizeof(float);   // gemm_rd_body's parking area, 256-thread workgroups
 
 // forward of a (small) candidate-list layer with the processor's block weights formed by extra workgroups of the launch
@@ -2907,8 +2855,7 @@ __global__ __launch_bounds__(256, 4) void posatt_sparse_rows_w(AttArgs a, Sparse
 
 template <int MODE>
 void launch_sparse_rows(const AttArgs& a, const SparseArgs& sp, hipStream_t s, const pit_mlp_params_job* job = nullptr,
-                        bool* rider_done = nullptr, const WeightsArgs* wjob = nullptr, const FinishBatch* fin = nullptr,
-                        int fin_self = 0, int* fin_counter = nullptr, bool* fin_done = nullptr) {
+                        bool* rider_done = nullptr, const WeightsArgs* wjob = nullptr) {
     const int nh = (a.n_head % 2 == 0) ? 2 : 1;
     const long rows = (long)a.mesh_batch * a.n_out;
     const int cr = cr_for(a.ncols, rows * (a.n_head / nh));
@@ -2926,22 +2873,6 @@ void launch_sparse_rows(const AttArgs& a, const SparseArgs& sp, hipStream_t s, c
     }
     pit_detail::DwPair dw;
     const pit_detail::DwPair* rider = &dw;
-    if (MODE == 1 && fin && (long)grid.x * grid.y * grid.z <= 4096) {       // the pass's last attention launch: finish inside
-        const bool with_dw = job && pit_detail::plan_dw_pair(*job, 4, &dw);
-        if (!with_dw) { dw = pit_detail::DwPair(); dw.n1 = 0; dw.n2 = 0; }
-        const int n_att = (int)(grid.x * grid.y * grid.z), n_dw = with_dw ? dw.n1 + dw.n2 : 0;
-        const int n_fin = fin->wg_base[fin->n] - (fin->wg_base[fin_self + 1] - fin->wg_base[fin_self]);
-        dim3 gridw((unsigned)(n_dw + n_fin + n_att));
-#define PIT_SRF(NH_, CR_) hipLaunchKernelGGL((posatt_sparse_rows_dwf<NH_, CR_>), gridw, block, DW_SMEM_4WAVES, s, a, sp, (int)grid.x, \
-                                             (int)grid.y, n_dw, dw, *fin, fin_self, n_fin, n_att, fin_counter)
-#define PIT_SRF_CR(NH_) do { if (cr == 8) PIT_SRF(NH_, 8); else if (cr == 4) PIT_SRF(NH_, 4); else if (cr == 2) PIT_SRF(NH_, 2); else PIT_SRF(NH_, 1); } while (0)
-        if (nh == 2) PIT_SRF_CR(2); else PIT_SRF_CR(1);
-#undef PIT_SRF_CR
-#undef PIT_SRF
-        if (with_dw) *rider_done = true;
-        *fin_done = true;
-        return;
-    }
     if (MODE == 1 && job && (long)grid.x * grid.y * grid.z <= 16384 && pit_detail::plan_dw_pair(*job, 4, &dw)) {   // small launch: carry the reductions
         const int n_att = (int)(grid.x * grid.y * grid.z);
         dim3 gridw((unsigned)(n_att + rider->n1 + rider->n2));
@@ -3131,7 +3062,8 @@ bool launch_cols_pre(AttArgs& a, hipStream_t s) {
 
 // include/pit_hip.h: 1 when pit_posatt_pre_fwd / _bwd run this shape (the large regime of a batch-free self-attention layer)
 extern "C" int pit_posatt_pre_supported(int n_pts, int n_head, int dim, int batch) {
-    if (n_pts <= 0 || n_head <= 0 || dim <= 0 || batch <= 0 || getenv("PIT_NO_PRE_WEIGHTS")) return 0;
+    static const bool off = getenv("PIT_NO_PRE_WEIGHTS") != nullptr;        // (diagnostic switch, read once)
+    if (n_pts <= 0 || n_head <= 0 || dim <= 0 || batch <= 0 || off) return 0;
     const long ncols = (long)batch * dim;
     if (ncols > 0x7fffffffL || n_pts % 4 != 0 || n_pts > 2048) return 0;          // (E and Q: n_head * n_pts^2 floats per layer)
     const int n_tiles = (n_pts + 31) / 32;
@@ -3295,48 +3227,7 @@ extern "C" int pit_posatt_bwd(const float* mesh_out, const float* mesh_in, int m
                               const int* nbr_idx, const int* nbr_cnt, int nbr_cap, int nbr_complete,
                               const int* rev_ptr, const int* rev_row, const pit_mlp_params_job* rider,
                               int coord_dims, int math_mode, void* stream) {
-    return pit_posatt_bwd_job(mesh_out, mesh_in, mesh_batch, n_out, n_in, space_dim, metric, period, values, batch, dim, ld_values,
-                              values_bstride, head, n_head, head_is_scale, scale, rowstat, masked, d_out, ld_dout, dout_bstride,
-                              out_col0, d_values, ld_dvalues, dvalues_bstride, add_residual, d_head, accumulate_head, workspace,
-                              nbr_idx, nbr_cnt, nbr_cap, nbr_complete, rev_ptr, rev_row, rider, coord_dims, math_mode, stream,
-                              nullptr);
-}
-
-extern "C" int pit_posatt_bwd_job(const float* mesh_out, const float* mesh_in, int mesh_batch, int n_out, int n_in,
-                                  int space_dim, int metric, float period,
-                                  const float* values, int batch, int dim, long ld_values, long values_bstride,
-                                  const float* head, int n_head, int head_is_scale, const float* scale,
-                                  const float* rowstat, int masked,
-                                  const float* d_out, long ld_dout, long dout_bstride, int out_col0,
-                                  float* d_values, long ld_dvalues, long dvalues_bstride, int add_residual,
-                                  float* d_head, int accumulate_head, double* workspace,
-                                  const int* nbr_idx, const int* nbr_cnt, int nbr_cap, int nbr_complete,
-                                  const int* rev_ptr, const int* rev_row, const pit_mlp_params_job* rider,
-                                  int coord_dims, int math_mode, void* stream, const pit_head_finish_job* fin) {
     PIT_ENTER_MATH(math_mode);
-    // the end-of-pass finish inside this launch (validated here, taken only by the small d(scale)-only candidate-list launch)
-    FinishBatch fbatch;
-    bool fin_ok = false, fin_done = false;
-    if (fin) {
-        if (!fin->taken || !fin->counter) return PIT_ERR_NULL;
-        *fin->taken = 0;
-        fin_ok = fin->n_layers >= 1 && fin->n_layers <= FINISH_MAX_LAYERS && fin->self >= 0 && fin->self < fin->n_layers &&
-                 fin->workspaces && fin->d_heads && fin->heads && fin->scales && fin->n_heads && fin->flags &&
-                 (accumulate_head & PIT_HEAD_DEFER) && d_head && !d_values && fin->workspaces[fin->self] == workspace;
-        if (fin_ok) {
-            fbatch.n = fin->n_layers;
-            int total = 0;
-            for (int l = 0; l < fin->n_layers && fin_ok; ++l) {
-                fin_ok = fin->workspaces[l] && fin->d_heads[l] && fin->heads[l] && fin->n_heads[l] > 0;
-                fbatch.ws[l] = fin->workspaces[l]; fbatch.d_head[l] = fin->d_heads[l]; fbatch.head[l] = fin->heads[l];
-                fbatch.scale[l] = fin->scales[l]; fbatch.n_head[l] = fin->n_heads[l]; fbatch.flags[l] = fin->flags[l];
-                fbatch.wg_base[l] = total;
-                total += fin->n_heads[l];
-            }
-            fbatch.wg_base[fin->n_layers] = total;
-            fin_ok = fin_ok && fin->n_heads[fin->self] == n_head;
-        }
-    }
     AttArgs a;
     int rc = fill_common(a, mesh_out, mesh_in, mesh_batch, n_out, n_in, space_dim, metric, period, values, batch,
                          dim, ld_values, values_bstride, head, n_head, head_is_scale, coord_dims);
@@ -3426,12 +3317,10 @@ extern "C" int pit_posatt_bwd_job(const float* mesh_out, const float* mesh_in, i
                 paired = launch_sparse_bwd_pair(a, sp, nbr_complete != 0, s, rider, &rd.done);
         }
         if (!paired) {
-            if (sparse) launch_sparse_rows<1>(a, sp, s, rd.done ? nullptr : rider, &rd.done, nullptr, fin_ok ? &fbatch : nullptr,
-                                              fin_ok ? fin->self : 0, fin_ok ? fin->counter : nullptr, &fin_done);
+            if (sparse) launch_sparse_rows<1>(a, sp, s, rd.done ? nullptr : rider, &rd.done);
             else launch_rows<1>(a, s);
         }
         PIT_CHECK_LAUNCH();
-        if (fin_done) *fin->taken = 1;
         if (!defer) {
             hipLaunchKernelGGL(posatt_dhead_finish, dim3(n_head), dim3(256), 0, s, a);
             PIT_CHECK_LAUNCH();

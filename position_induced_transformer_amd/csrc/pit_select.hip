@@ -801,14 +801,14 @@ extern "C" int pit_lists_transpose(const int* nbr_idx, const int* nbr_cnt, int m
 
 extern "C" int pit_plan_fwd(const float* mesh_out, const float* mesh_in, int mesh_batch, int n_out, int n_in,
                             int space_dim, int metric, float period, int rank_k, float* stats, int cap,
-                            int* nbr_idx, int* nbr_cnt, int* rev_ptr, int* rev_row, int* workspace, void* stream) {
+                            int* nbr_idx, int* nbr_cnt, int* rev_ptr, int* rev_row, int* workspace, int flags, void* stream) {
     if (!mesh_out || !mesh_in || !stats || !nbr_idx || !nbr_cnt) return PIT_ERR_NULL;
     if (rev_ptr && (!rev_row || !workspace)) return PIT_ERR_NULL;
     if (mesh_batch <= 0 || n_out <= 0 || n_in <= 0 || space_dim < 1 || space_dim > 3 || cap <= 0) return PIT_ERR_SIZE;
     if (metric < PIT_METRIC_EUCLID || metric > PIT_METRIC_PERIODIC2D) return PIT_ERR_METRIC;
     if (rank_k < 0 || rank_k > n_in - 1) return PIT_ERR_SIZE;
     const int items = (n_in + 63) / 64;
-    if (items > 64 || getenv("PIT_NO_FUSED_PLAN")) {          // long rows: the two streaming passes
+    if (items > 64 || (flags & PIT_PLAN_TWO_PASSES)) {        // long rows: the two streaming passes
         int rc = pit_select_fwd(mesh_out, mesh_in, mesh_batch, n_out, n_in, space_dim, metric, period, rank_k, 1, stats,
                                 stream);
         if (rc) return rc;
@@ -838,9 +838,13 @@ extern "C" int pit_plan_fwd(const float* mesh_out, const float* mesh_in, int mes
     // (a lane per row needs rows: 64 per wave - below ~500 waves the wave-per-row kernel fills the chip better: Elasticity, 9 720 rows,
     // 2.59 vs 2.45 ms per step)
     const bool lane_ok = mesh_batch > 1 && rank_k + 2 <= LN_NB && n_in <= NBR_LDS_KEYS && n_in < 65536 && rows >= 32768 &&
-                         (!rev_ptr || agg) && !getenv("PIT_NO_LANE_PLAN");
-    if (lane_ok) {
-        const bool sd2 = a.coords_used <= 2;
+                         (!rev_ptr || agg) && !(flags & PIT_PLAN_WAVE_PER_ROW);
+    const bool sd2 = a.coords_used <= 2;
+    // (dynamic LDS of the lane kernel: the sample's keys + the lanes' columns (+ the per-key histogram): 3-d meshes of 2 816 ..
+    // 4 096 keys would need 66-102 KB - beyond the 64 KB a launch gets without raising the kernel's limit: those keep the wave-per-row kernel)
+    const size_t lane_sm = (size_t)((n_in + 63) / 64 * 64) * (sd2 ? 2 : 4) * sizeof(float) + (size_t)ln_capb(64) * 256 * sizeof(unsigned short) +
+                           (rev_ptr ? (size_t)n_in * sizeof(int) : 0);
+    if (lane_ok && lane_sm <= 65536) {
         const int nb = 64;       // (32 blocks: a third of the sorting network, but 144 VGPRs against 95 and a looser bound - 0.2 % of the NACA rows then
                                  // overflow a 32-slot column and the clustered repairs cost 30 us: 64 blocks measured faster everywhere)
         const int npad = (n_in + nb - 1) / nb * nb;

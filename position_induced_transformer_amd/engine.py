@@ -47,7 +47,7 @@ class TrainStep:
         self.optimizer = optimizer
         self.buckets = 1
         self._early_hook = None
-        if all_reduce_buckets == 2 and not ops.OVERLAP_BACKWARD:    # (side-stream weight gradients join at the end of the pass)
+        if all_reduce_buckets == 2:
             tail, marker = early_gradient_parameters(model)
             if marker is not None:
                 if flat is None:
@@ -112,10 +112,8 @@ class TrainStep:
         self._early_pending = False
         early = self.buckets == 2 and self.all_reduce and self._tail_in_place()    # (else: ONE all-reduce after the pass)
         self._early_ok = early
-        # per-thread state, read by the autograd nodes in their forward (ops._STEP): the early bucket needs its gradients
-        # before the end of the pass, so nothing of it may wait for the end-of-pass batch launch
-        with ops.step_state(processor_hook=(self._on_processor_block, self._early_block) if early else None,
-                            dw_batch=False if early else None):
+        # per-thread state, read by the autograd nodes in their forward (ops._STEP)
+        with ops.step_state(processor_hook=(self._on_processor_block, self._early_block) if early else None):
             self._step_body()
 
     def _step_body(self) -> None:

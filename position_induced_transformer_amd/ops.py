@@ -29,23 +29,12 @@ METRIC_ID = {"euclid": 0, "periodic1d": 1, "periodic2d": 2}
 # with any torch op.  Set to False to disable the in-place path altogether.
 FUSED_GRAD_ACCUMULATION = True
 
-# Backward kernels that nothing later in the backward pass depends on - the d(scale) reduction
-# of an attention layer and the weight/bias-gradient GEMMs of an MLP - are issued on a second
-# HIP stream (fork after their inputs exist, one join when the backward pass ends), so they
-# overlap the critical d-values / d-x chain.  Only used together with in-place accumulation
-# (their results then go nowhere but the .grad buffers).  Captured into hipGraphs as parallel
-# branches.  OFF by default: measured on MI355X (Darcy b=8) a graph with cross-stream edges replays
-# slower than the linear one once the kernels are ~5 us (0.524 vs 0.485 ms/step); it pays only for
-# long kernels.  Enable with PIT_OVERLAP_BACKWARD=1.
-OVERLAP_BACKWARD = os.environ.get("PIT_OVERLAP_BACKWARD", "0") != "0"
-
 # Masked (locality < 1) layers run on per-row candidate lists (O(N*k) work) when the lists are
 # much shorter than the key axis; False forces the dense MFMA kernels everywhere.
 SPARSE_MASKED = True
 
 _DSCALE_WS = {}     # (device index, stream) -> fp64 accumulators
 _LOSS_WS = {}       # (device index, stream) -> loss accumulator + ticket
-_SIDE = {}          # device index -> {"stream", "task", "keep"}
 # Tensors whose addresses were baked into a hipGraph under capture (mesh plans, accumulators): never
 # released, so a cache eviction cannot hand their memory to someone else while a graph still replays.
 _PINNED = []
@@ -73,37 +62,6 @@ def _graph_task() -> int:
     """Id of the backward pass being executed (-1 outside of one): what the end-of-pass callbacks are
     keyed on, so a pass that died with an exception cannot leave the NEXT pass without its callback."""
     return torch._C._current_graph_task_id()
-
-
-def _side_state(device):
-    st = _SIDE.get(device.index)
-    if st is None:
-        st = {"stream": torch.cuda.Stream(device=device), "task": None, "keep": []}
-        _SIDE[device.index] = st
-    return st
-
-
-def _fork_side(device, *keep_alive):
-    """Make the side stream wait for everything enqueued so far on the current stream, register
-    the end-of-backward join once, keep ``keep_alive`` tensors referenced until then (they are
-    read by side-stream kernels after autograd would have released them)."""
-    st = _side_state(device)
-    st["stream"].wait_stream(torch.cuda.current_stream(device))
-    task = _graph_task()
-    if st["task"] != task:                   # first fork of THIS pass (a pass that raised never joined)
-        if st["task"] is not None:
-            torch.cuda.current_stream(device).wait_stream(st["stream"])
-            st["keep"].clear()
-        st["task"] = task
-
-        def _join():
-            torch.cuda.current_stream(device).wait_stream(st["stream"])
-            st["keep"].clear()
-            st["task"] = None
-        torch.autograd.Variable._execution_engine.queue_callback(_join)
-    st["keep"].extend(keep_alive)
-    return st["stream"]
-
 
 
 def _dscale_workspace(device, n_head: int) -> torch.Tensor:
@@ -194,51 +152,6 @@ def _defer_head_begin(work: torch.Tensor) -> None:
         torch.autograd.Variable._execution_engine.queue_callback(lambda: _flush_head_finishes(task))
 
 
-# (opt-in: MEASURED SLOWER - the arrival counter, the fences and the last workgroup's fp64 drain of this layer's heads cost more
-# than the 4.6 us launch they replace: Darcy b=8 0.1885 -> 0.1908 ms/step, Burgers 0.1922 -> 0.1952, Sod 0.1268 -> 0.1263)
-FINISH_IN_LAUNCH = os.environ.get("PIT_FINISH_IN_LAUNCH", "0") != "0"
-_FINISH_COUNTERS = {}
-
-
-def _finish_job(device, work, d_head, head, scale, n_head: int, flags: int):
-    """pit_head_finish_job for the layers of this pass whose accumulators are loaded (deduplicated as _flush_head_finishes
-    does) plus the calling layer (`work`, ...); None when it cannot be formed.  Returns (struct, taken flag, keep-alive)."""
-    seen, ent = set(), []
-    for e in _PENDING_HEADS.get(_graph_task(), ()):
-        key = (e[0].data_ptr(), e[1].data_ptr())
-        if key not in seen:
-            seen.add(key)
-            ent.append(e)
-    mine = (work.data_ptr(), d_head.data_ptr())
-    if mine in seen:                                  # (this layer already ran in the pass: its entry stands for both)
-        me = [i for i, e in enumerate(ent) if (e[0].data_ptr(), e[1].data_ptr()) == mine][0]
-    else:
-        me = len(ent)
-        ent.append((work, d_head, head, scale, n_head, flags))
-    if len(ent) > 32 or any(e[0].device != device for e in ent):
-        return None
-    n = len(ent)
-    ws = (ctypes.c_void_p * n)(*[e[0].data_ptr() for e in ent])
-    dh = (ctypes.c_void_p * n)(*[e[1].data_ptr() for e in ent])
-    hd = (ctypes.c_void_p * n)(*[e[2].data_ptr() for e in ent])
-    sc = (ctypes.c_void_p * n)(*[e[3].data_ptr() for e in ent])
-    nh = (ctypes.c_int * n)(*[e[4] for e in ent])
-    fl = (ctypes.c_int * n)(*[e[5] for e in ent])
-    key = _ws_key(device)
-    counter = _FINISH_COUNTERS.get(key)
-    if counter is None:
-        if _capturing():
-            return None                               # (allocating and zeroing it needs a launch outside the graph's chain: first eager pass)
-        counter = _FINISH_COUNTERS[key] = torch.zeros(1, device=device, dtype=torch.int32)
-    if _capturing():
-        _pin(counter)
-    taken = ctypes.c_int(0)
-    c = lambda a: ctypes.cast(a, ctypes.c_void_p)
-    job = _lib.HeadFinishJob(n, c(ws), c(dh), c(hd), c(sc), c(nh), c(fl), me, counter.data_ptr(),
-                             ctypes.cast(ctypes.pointer(taken), ctypes.c_void_p))
-    return job, taken, (ws, dh, hd, sc, nh, fl, ent)
-
-
 def _defer_head_finish(work, d_head, head, scale, n_head: int, flags: int) -> None:
     _defer_head_begin(work)
     _PENDING_HEADS[_graph_task()].append((work, d_head, head, scale, n_head, flags))
@@ -249,24 +162,11 @@ def _defer_head_finish(work, d_head, head, scale, n_head: int, flags: int) -> No
 # runs mlp -> attention, so in the backward the attention launch that consumes the MLP's d_x can carry the
 # MLP's reductions along - three small latency-bound grids in one launch.  In-place gradient mode only.
 MLP_PARAMS_RIDER = os.environ.get("PIT_DW_RIDER", "1") != "0"
-# Round 3: DW_BATCH (opt-in, PIT_DW_BATCH=1) - the postponed jobs of a pass are not carried by anybody but COLLECTED and
-# performed together by one launch when the pass ends (pit_mlp_bwd_params_batch).  Riders lengthen every launch of the
-# dependent chain (the fused block backward: 8.7 us alone, 16.2 us with its riders), but the reductions cost the same
-# chip time wherever they run: measured on MI355X, batch vs riders - Darcy b=8 0.2131 vs 0.2169 ms/step, Burgers 0.2097
-# vs 0.2083, Sod 0.1307 vs 0.1286, Darcy b=32 0.4357 vs 0.4362, Darcy + Adam 35.0 k vs 35.0 k samples/s: neutral, so the
-# riders stay the default.  Never used by a two-bucket data-parallel step (engine.TrainStep), which needs the early
-# bucket's gradients before the pass ends.
-DW_BATCH = os.environ.get("PIT_DW_BATCH", "0") != "0"
 # Per-THREAD step state (round 4; was module-global and toggled per step: two TrainSteps on two threads raced on it).
 # engine.TrainStep sets it around its forward; the autograd nodes read it in their FORWARD (which runs on the calling
 # thread) and keep it on their ctx - the backward runs on autograd's device thread, where a thread-local of the caller
-# is not visible.  `dw_batch`: None = the module default DW_BATCH; `processor_hook`: see _Processor.
+# is not visible.  `processor_hook`: see _Processor.
 _STEP = threading.local()
-
-
-def _dw_batch_mode() -> bool:
-    v = getattr(_STEP, "dw_batch", None)
-    return DW_BATCH if v is None else bool(v)
 
 
 def _processor_hook():
@@ -276,21 +176,20 @@ def _processor_hook():
 class step_state:
     """Context manager: per-thread overrides for the autograd nodes built inside it (engine.TrainStep._step)."""
 
-    def __init__(self, processor_hook=None, dw_batch=None):
-        self.new = (processor_hook, dw_batch)
+    def __init__(self, processor_hook=None):
+        self.new = processor_hook
 
     def __enter__(self):
-        self.old = (getattr(_STEP, "processor_hook", None), getattr(_STEP, "dw_batch", None))
-        _STEP.processor_hook, _STEP.dw_batch = self.new
+        self.old = getattr(_STEP, "processor_hook", None)
+        _STEP.processor_hook = self.new
         return self
 
     def __exit__(self, *exc):
-        _STEP.processor_hook, _STEP.dw_batch = self.old
+        _STEP.processor_hook = self.old
         return False
 
 
 _PENDING_DW = {}          # graph-task id -> job = (MlpParamsJob, keep-alive tensors, stream it was prepared on) or None
-_PENDING_BATCH = {}       # graph-task id -> [job, ...]  (DW_BATCH)
 _DEFERRABLE = {}
 
 
@@ -320,37 +219,7 @@ def _dw_end_of_pass(task: int) -> None:
     _PENDING_DW.pop(task, None)
 
 
-def _dw_batch_flush(task: int) -> None:
-    """End-of-backward callback (DW_BATCH): every weight-gradient job the pass postponed, in one call."""
-    jobs = _PENDING_BATCH.pop(task, [])
-    by_stream = {}
-    for job in jobs:
-        by_stream.setdefault(job[2], []).append(job)
-    for stream, grp in by_stream.items():
-        arr = (_lib.MlpParamsJob * len(grp))(*[j[0] for j in grp])
-        cur = torch.cuda.current_stream(stream.device)
-        with torch.cuda.stream(stream):
-            rc = _lib.lib().pit_mlp_bwd_params_batch(len(grp), ctypes.cast(arr, ctypes.c_void_p), stream.cuda_stream)
-        _lib.check(rc, "pit_mlp_bwd_params_batch")
-        if cur != stream:
-            cur.wait_stream(stream)
-
-
-def _dw_batch_add(st, keep, device) -> None:
-    task = _graph_task()
-    lst = _PENDING_BATCH.get(task)
-    if lst is None:
-        while len(_PENDING_BATCH) >= _MAX_PENDING_TASKS:      # lists of passes that died before their callback
-            del _PENDING_BATCH[next(iter(_PENDING_BATCH))]
-        lst = _PENDING_BATCH[task] = []
-        torch.autograd.Variable._execution_engine.queue_callback(lambda: _dw_batch_flush(task))
-    lst.append((st, keep, torch.cuda.current_stream(device)))
-
-
-def _dw_defer(st, keep, device, batch: bool = False) -> None:
-    if batch:
-        _dw_batch_add(st, keep, device)
-        return
+def _dw_defer(st, keep, device) -> None:
     task = _graph_task()
     # a job ANOTHER pass left for the same gradient slots: that pass raised before its end-of-pass callback ran - its
     # gradients are void (two live passes accumulating into one .grad would be a race in torch itself)
@@ -480,6 +349,7 @@ def mesh_period(metric: str, mesh_in: torch.Tensor) -> float:
     return 0.0
 
 
+PLAN_FLAGS = 0                                               # pit_plan_fwd's `flags` (tests: 1 = PIT_PLAN_WAVE_PER_ROW, 2 = PIT_PLAN_TWO_PASSES)
 UNION_TILES = os.environ.get("PIT_UNION_TILES", "auto")      # "auto" (probe per kind of plan), "0", "1"
 UNION_DV = os.environ.get("PIT_UNION_DV", "auto")            # d(values) of union-tile layers: "auto", "lists" (transposed lists)
 _UNION_DECISIONS = {}
@@ -636,7 +506,7 @@ class MeshPlan:
         rc = L.pit_plan_fwd(self.mesh_out.data_ptr(), self.mesh_in.data_ptr(), self.mesh_batch, self.n_out,
                             self.n_in, self.sdim, self.metric_id, self.period, self.rank_k, self.stats.data_ptr(), cap,
                             self.nbr_idx.data_ptr(), self.nbr_cnt.data_ptr(), _lib.ptr(self.rev_ptr),
-                            _lib.ptr(self.rev_row), _lib.ptr(work), _lib.stream_ptr())
+                            _lib.ptr(self.rev_row), _lib.ptr(work), int(PLAN_FLAGS), _lib.stream_ptr())
         _lib.check(rc, "pit_plan_fwd")
 
 
@@ -692,9 +562,6 @@ class _PosAtt(torch.autograd.Function):
         wjob = getattr(_STEP, "fwd_job", None)             # the processor's weights riding in this launch (early_block_weights)
         if wjob is not None:
             _STEP.fwd_job = None
-        # (the layer in front of the processor is the model's first attention layer: its backward is the pass's LAST attention
-        # launch and may carry the end-of-pass d(lmda) finish - see backward)
-        ctx.before_processor = wjob is not None
         rc = _lib.lib().pit_posatt_fwd_job(
             plan.mesh_out.data_ptr(), plan.mesh_in.data_ptr(), plan.mesh_batch, plan.n_out, plan.n_in, plan.sdim,
             plan.metric_id, plan.period,
@@ -739,7 +606,7 @@ class _PosAtt(torch.autograd.Function):
         else:
             d_head = torch.empty((n_head,), device=values.device, dtype=torch.float32) if need_h else None
             acc_head = 0
-        defer = DEFER_HEAD_FINISH and slot is not None and not OVERLAP_BACKWARD
+        defer = DEFER_HEAD_FINISH and slot is not None
         work = _layer_workspace(slot, n_head) if defer else _dscale_workspace(values.device, n_head)
         if defer:
             acc_head |= 2                               # PIT_HEAD_DEFER: finished by _flush_head_finishes
@@ -752,15 +619,8 @@ class _PosAtt(torch.autograd.Function):
         rider = None if (plan.nbr_idx is not None and _dw_pending_rows(values.device) >= BIG_RIDER_ROWS) \
             else _dw_take(values.device)
 
-        # FINISH_IN_LAUNCH: the d(lmda) finish of the whole pass inside this launch (pit_posatt_bwd_job) when this is the layer in
-        # front of the processor (its backward runs after every other layer's), d(scale)-only and deferred.  Layers finishing
-        # after it anyway (another order of independent branches) are drained by the end-of-pass flush as before.
-        fin = None
-        if FINISH_IN_LAUNCH and defer and getattr(ctx, "before_processor", False) and not need_v and plan.nbr_idx is not None:
-            fin = _finish_job(values.device, work, d_head, head, scale, n_head, 1 | (4 if ctx.head_is_scale else 0))
-
         def launch(dv, dh, stream_ptr, job=None):
-            rc = _lib.lib().pit_posatt_bwd_job(
+            rc = _lib.lib().pit_posatt_bwd(
                 plan.mesh_out.data_ptr(), plan.mesh_in.data_ptr(), plan.mesh_batch, plan.n_out, plan.n_in,
                 plan.sdim, plan.metric_id, plan.period,
                 values.data_ptr(), b, d, values.stride(1), values.stride(0),
@@ -773,22 +633,11 @@ class _PosAtt(torch.autograd.Function):
                 _lib.ptr(plan.nbr_idx), _lib.ptr(plan.nbr_cnt), plan.nbr_cap, plan.lists_complete(),
                 _lib.ptr(plan.rev_ptr), _lib.ptr(plan.rev_row),
                 ctypes.cast(ctypes.pointer(job[0]), ctypes.c_void_p) if job is not None else None,
-                ctx.coord_dims, ctx.math | io | union, stream_ptr,
-                ctypes.cast(ctypes.pointer(fin[0]), ctypes.c_void_p) if fin is not None else None)
+                ctx.coord_dims, ctx.math | io | union, stream_ptr)
             _lib.check(rc, "pit_posatt_bwd")
 
-        if OVERLAP_BACKWARD and slot is not None:
-            if rider is not None:
-                _dw_run(rider)
-            side = _fork_side(values.device, values, head, rowstat, scale, d_out, plan)
-            launch(None, d_head, side.cuda_stream)          # d(scale) -> lmda.grad, off the critical path
-            if d_values is not None:
-                launch(d_values, None, _lib.stream_ptr())
-        else:
-            launch(d_values, d_head, _lib.stream_ptr(), rider)
-        if fin is not None and fin[1].value:
-            _PENDING_HEADS[_graph_task()] = []          # every layer deferred so far (and this one) was finished by the launch
-        elif defer:
+        launch(d_values, d_head, _lib.stream_ptr(), rider)
+        if defer:
             _defer_head_finish(work, d_head, head, scale, n_head, 1 | (4 if ctx.head_is_scale else 0))
         return d_values, (None if slot is not None else d_head), None, None, None, None, None, None, None, None, None
 
@@ -991,7 +840,6 @@ class _Mlp(torch.autograd.Function):
         _lib.check(rc, "pit_mlp_fwd")
         ctx.out_gelu, ctx.dims, ctx.in_shape = out_gelu, (rows, n0, n1, n2), shape
         ctx.params = (w1, b1, w2, b2)
-        ctx.dw_batch = _dw_batch_mode()
         ctx.save_for_backward(x2, w1c, w2c, z1, h, z2 if out_gelu else z1)
         out = y.reshape(*shape[:-1], n2)             # (a view: constant row stride)
         if buf is None:
@@ -1026,17 +874,7 @@ class _Mlp(torch.autograd.Function):
         L = _lib.lib()
         z2p = z2.data_ptr() if ctx.out_gelu else 0
         og = 1 if ctx.out_gelu else 0
-        if OVERLAP_BACKWARD and inplace:
-            rc = L.pit_mlp_bwd_data(rows, n0, n1, n2, w1.data_ptr(), w2.data_ptr(), z1.data_ptr(), z2p, og,
-                                    d_y2.data_ptr(), d_y2.stride(0), _lib.ptr(d_x), n0, scratch.data_ptr(),
-                                    ctx.math, _lib.stream_ptr())
-            _lib.check(rc, "pit_mlp_bwd_data")
-            stream_p = _fork_side(dev, x2, h, d_y2, scratch).cuda_stream     # weight grads off the critical path
-            rc = L.pit_mlp_bwd_params(x2.data_ptr(), x2.stride(0), rows, n0, n1, n2, h.data_ptr(), og,
-                                      d_y2.data_ptr(), d_y2.stride(0), d_w1.data_ptr(), d_b1.data_ptr(),
-                                      d_w2.data_ptr(), d_b2.data_ptr(), 1, scratch.data_ptr(), ctx.math, stream_p)
-            _lib.check(rc, "pit_mlp_bwd_params")
-        elif MLP_PARAMS_RIDER and inplace and _dw_deferrable(rows, n0, n1, n2, og, d_y2.stride(0)):
+        if MLP_PARAMS_RIDER and inplace and _dw_deferrable(rows, n0, n1, n2, og, d_y2.stride(0)):
             # dZ2, dZ1 and d_x now; the weight-gradient reductions ride along with the next attention backward
             rc = L.pit_mlp_bwd_data(rows, n0, n1, n2, w1.data_ptr(), w2.data_ptr(), z1.data_ptr(), z2p, og,
                                     d_y2.data_ptr(), d_y2.stride(0), _lib.ptr(d_x), n0, scratch.data_ptr(),
@@ -1048,7 +886,7 @@ class _Mlp(torch.autograd.Function):
             st = _lib.MlpParamsJob(x2.data_ptr(), x2.stride(0), rows, n0, n1, n2, h.data_ptr(), og, d_y2.data_ptr(),
                                    d_y2.stride(0), d_w1.data_ptr(), d_b1.data_ptr(), d_w2.data_ptr(), d_b2.data_ptr(),
                                    1, scratch.data_ptr(), 0)
-            _dw_defer(st, (x2, h, d_y2, scratch, d_w1, d_b1, d_w2, d_b2), dev, ctx.dw_batch)
+            _dw_defer(st, (x2, h, d_y2, scratch, d_w1, d_b1, d_w2, d_b2), dev)
         else:
             # one call: dZ1, then dX and both weight-gradient reductions (merged into one launch when small)
             # (small regime: fp32 in every math mode, like the postponed form above - the two must agree)
@@ -1199,66 +1037,23 @@ def posatt_pre_apply(values: torch.Tensor, lmda: torch.Tensor, weights, layer: i
                             n_head, param, slot)
 
 
-# Round 4: the persistent latent kernels (csrc/pit_latent.hip) - the whole processor as ONE launch per direction when all
-# slab workgroups are co-resident (Darcy / Burgers at the scripts' batch 8: 128 + 128 workgroups).  Bit-identical to the
-# per-block launches and covered by the same tests, but OPT-IN (PIT_LATENT_FUSION=1 / ops.LATENT_FUSION = True): measured on
-# MI355X a hand-off inside the launch costs what a kernel boundary costs (2.6 us including the skew between a sample's 16
-# workgroups; tools/micro/handoff_probe.hip: 1.9-3.1 us against 3.5-3.9), so the forward gains nothing (39.2 vs 38.8 us for
-# the four blocks of Darcy b=8) and the backward (44.7 us with the blocks' weight gradients inside, against 9.1 + 4 x 11.5)
-# loses what it gains once the decoder MLP's postponed reductions, which the per-block launches absorb on idle compute
-# units, need a launch of their own (15.7 us): 0.207-0.224 vs 0.1985 ms/step.  DESIGN.md section 4, "Round 4".
-LATENT_FUSION = os.environ.get("PIT_LATENT_FUSION", "0") != "0"
-LATENT_SYNC_WORDS = 12416          # PIT_LATENT_SYNC_WORDS
-LATENT_FLAGS = 0                   # tests: 1 = PIT_LATENT_LINEAR_MAP (a sample's slabs spread over all XCDs), 2 = PIT_LATENT_NO_FAST
-_LATENT_SYNC = {}                  # (device index, stream) -> hand-off flags of the persistent kernels (zero between launches)
-
-
-def _latent_sync(device) -> torch.Tensor:
-    key = _ws_key(device)
-    ws = _LATENT_SYNC.get(key)
-    if ws is None:
-        ws = _LATENT_SYNC[key] = torch.zeros(LATENT_SYNC_WORDS, device=device, dtype=torch.int32)
-    if _capturing():
-        _pin(ws)
-    return ws
-
-
-def latent_status(device=None) -> int:
-    """0, or non-zero when a wait inside a persistent latent kernel timed out since the workspaces were created (the
-    results of that launch are void).  Synchronises; tests / bench.py call it after the step."""
-    bad = 0
-    for (dev, _stream), ws in _LATENT_SYNC.items():
-        if device is None or torch.device(device).index in (None, dev):
-            bad |= int(ws[0].item())
-    return bad
-
-
-def latent_fusion_supported(n_pts: int, n_head: int, dim: int, batch: int, n_layers: int) -> bool:
-    return LATENT_FUSION and bool(_lib.lib().pit_latent_supported(int(n_pts), int(n_head), int(dim), int(batch), int(n_layers)))
-
-
 # The fused processor's softmax weights (pit_block_weights) depend on the latent mesh and the lmda's only - not on the data -
 # so their launch need not sit in the step's chain between the encoder and the first block.  PIT_EARLY_WEIGHTS:
 #   "rider" (default)  extra workgroups of the down-projection's launch form them (pit_posatt_fwd_job: one launch less in the
 #                      chain); a down-projection that is not one of the small candidate-list launches gets them as a launch
 #                      of their own right after it - the order of round 3, one call earlier.
-#   "stream"           a side stream under the down-projection, joined before the encoder returns (inside a captured step: a
-#                      parallel branch of the hipGraph).  MEASURED SLOWER: a second branch makes the replayed graph pay
-#                      cross-queue signalling on the edges into and out of it - Darcy b=8 0.194 -> 0.222 ms/step, Burgers
-#                      b=8 0.198 -> 0.230, Darcy b=16 0.270 -> 0.301 (same box, 300 steps; the same finding as
-#                      PIT_OVERLAP_BACKWARD above).  A straight chain of kernels is the fastest graph this runtime replays.
+#   (a side stream under the down-projection - a parallel branch of the step graph - was measured slower twice, rounds 3 and 4:
+#   Darcy b=8 0.194 -> 0.222 ms/step; a straight chain of kernels is the fastest graph this runtime replays; removed in round 5)
 #   "0"                formed by _Processor.forward itself (round 3).
 EARLY_WEIGHTS = os.environ.get("PIT_EARLY_WEIGHTS", "rider")
 
 
 class EarlyWeights:
     """Weights of all blocks (pit_block_weights) requested before the processor runs; join() before anything reads them."""
-    __slots__ = ("key", "E", "Q", "inv", "rowstat", "scale", "event", "job", "keep")
+    __slots__ = ("key", "E", "Q", "inv", "rowstat", "scale", "job", "keep")
 
     def join(self) -> None:
-        if self.event is not None:
-            torch.cuda.current_stream(self.E.device).wait_event(self.event)
-        elif getattr(_STEP, "fwd_job", None) is self:        # no attention launch took the job: a launch of its own, now
+        if getattr(_STEP, "fwd_job", None) is self:        # no attention launch took the job: a launch of its own, now
             _STEP.fwd_job = None
             j = self.job
             rc = _lib.lib().pit_block_weights(j.mesh, j.n_pts, j.space_dim, j.metric, j.period, j.n_layers, j.heads,
@@ -1299,23 +1094,14 @@ def early_block_weights(plan: MeshPlan, lmdas, n_head: int, need_q: bool):
     runs (modes: EARLY_WEIGHTS above).  The caller join()s the returned handle on the same stream before its function ends
     (nothing is left pending or unjoined) and hands it to processor_apply, which uses it when lmdas / scales are still the ones
     it was formed from."""
-    if EARLY_WEIGHTS not in ("rider", "stream") or not plan.mesh_in.is_cuda:
+    if EARLY_WEIGHTS != "rider" or not plan.mesh_in.is_cuda:
         return None
     scales = [host_head_scale(p) for p in lmdas] if get_head_scale_route() == "host" else None
     heads = [t.detach().reshape(-1).contiguous() for t in lmdas]
     kheads = scales if scales is not None else heads
-    dev = plan.mesh_in.device
     ew = EarlyWeights()
     ew.key = _weights_key(plan, lmdas, scales, n_head)
-    ew.event = ew.job = ew.keep = None
-    if EARLY_WEIGHTS == "stream":
-        side = _side_state(dev)["stream"]
-        side.wait_stream(torch.cuda.current_stream(dev))
-        ew.E, ew.Q, ew.inv, ew.rowstat, ew.scale = _launch_block_weights(plan, kheads, scales is not None, n_head, need_q,
-                                                                         side.cuda_stream)
-        ew.event = torch.cuda.Event()
-        ew.event.record(side)
-        return ew
+    ew.job = ew.keep = None
     n = len(kheads)
     ew.E, ew.Q, ew.inv, ew.rowstat, ew.scale = _weights_buffers(plan, n, n_head, need_q)
     hp = (ctypes.c_void_p * n)(*[t.data_ptr() for t in kheads])
@@ -1371,15 +1157,7 @@ class _Processor(torch.autograd.Function):
             if tuple(w1.shape) != (D, W) or tuple(w2.shape) != (D, D):
                 raise RuntimeError(f"fused processor: block {i} MLP is {tuple(w1.shape)} / {tuple(w2.shape)}, expected "
                                    f"({D}, {W}) / ({D}, {D})")
-        ctx.latent = latent_fusion_supported(L, H, D, b, n)
-        if ctx.latent:                         # ONE persistent launch for all blocks
-            arr = lambda ts: (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])
-            rc = L_.pit_latent_fwd(E.data_ptr(), inv.data_ptr(), L, H, D, b, n, arr(bufs), arr([w[0] for w in wts]),
-                                   arr([w[1] for w in wts]), arr([w[2] for w in wts]), arr([w[3] for w in wts]),
-                                   z1.data_ptr(), hh.data_ptr(), z2.data_ptr(), out.data_ptr(), D,
-                                   _latent_sync(dev).data_ptr(), LATENT_FLAGS, ctx.math, _lib.stream_ptr())
-            _lib.check(rc, "pit_latent_fwd")
-        for i in range(n if not ctx.latent else 0):
+        for i in range(n):
             y, ldy = (bufs[i + 1], W) if i + 1 < n else (out, D)
             w1, b1, w2, b2 = wts[i]
             rc = L_.pit_block_fwd(E[i].data_ptr(), inv[i].data_ptr(), L, H, D, b, bufs[i].data_ptr(), w1.data_ptr(),
@@ -1388,7 +1166,7 @@ class _Processor(torch.autograd.Function):
             _lib.check(rc, "pit_block_fwd")
         ctx.n, ctx.H, ctx.dims, ctx.plan = n, H, (b, L, D), plan
         ctx.params = params                    # (lmda parameters, (w1, b1, w2, b2) parameters) for the in-place gradient slots
-        ctx.hook, ctx.dw_batch = _processor_hook(), _dw_batch_mode()      # the caller's per-thread step state
+        ctx.hook = _processor_hook()           # the caller's per-thread step state
         ctx.keep = (bufs, wts, heads, E, Q, inv, scale, z1, hh, z2)
         return out
 
@@ -1427,12 +1205,8 @@ class _Processor(torch.autograd.Function):
                 ws = torch.zeros(H * 1024, device=dev, dtype=torch.float64)
             work.append(ws)
         # a large job the pass has postponed (the decoder MLP's weight gradients): one row slice per block launch
-        # (rider mode; with DW_BATCH nothing rides: every job goes to the end-of-pass batch)
         extra = _dw_take(dev)
         slices = []
-        extra_batched = None
-        if extra is not None and ctx.latent:
-            extra_batched, extra = extra, None         # joins the blocks' reductions in the batch launch
         if extra is not None:
             st = extra[0]
             if not st.out_gelu and st.accumulate and (st.math_mode & 0xff) == 0:
@@ -1441,30 +1215,13 @@ class _Processor(torch.autograd.Function):
                 slices = _dw_slices(extra, n if ctx.hook is None else max(1, n - ctx.hook[1]))
             else:
                 _dw_run(extra)
-        if ctx.latent:
-            # ONE persistent launch: the whole chain, every block's d(scale) and - by the helper workgroups, each sample's share
-            # as soon as its dZ exists - the weight gradients of the blocks' MLPs; the job the pass postponed (the decoder
-            # MLP's reductions) is dealt over the helpers first
-            arr = lambda ts: (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])
-            job2 = ctypes.cast(ctypes.pointer(extra_batched[0]), ctypes.c_void_p) if extra_batched is not None else None
-            rc = L_.pit_latent_bwd(E.data_ptr(), inv.data_ptr(), Q.data_ptr(), L, H, D, b, n, arr(bufs), arr(dxc),
-                                   arr([w[0] for w in wts]), arr([w[2] for w in wts]), z1.data_ptr(), z2.data_ptr(),
-                                   arr(scratch), arr(work), hh.data_ptr(), arr([sl[0] for sl in w_slots]),
-                                   arr([sl[1] for sl in w_slots]), arr([sl[2] for sl in w_slots]), arr([sl[3] for sl in w_slots]),
-                                   job2, d_out.data_ptr(), D, dx.data_ptr(), D,
-                                   _latent_sync(dev).data_ptr(), LATENT_FLAGS, ctx.math, _lib.stream_ptr())
-            _lib.check(rc, "pit_latent_bwd")
-            if ctx.hook is not None:                    # (every gradient of the processor and of the postponed job is enqueued)
-                for i in range(n - 1, -1, -1):
-                    ctx.hook[0](i)
         # top of the chain: the last block's MLP backward (data path) from d_out
         w1, _, w2, _ = wts[n - 1]
-        if not ctx.latent:
-            rc = L_.pit_mlp_bwd_data(rows, W, D, D, w1.data_ptr(), w2.data_ptr(), z1[n - 1].data_ptr(), z2[n - 1].data_ptr(), 1,
-                                     d_out.data_ptr(), D, dxc[n - 1].data_ptr(), W, scratch[n - 1].data_ptr(), ctx.math,
-                                     _lib.stream_ptr())
-            _lib.check(rc, "pit_mlp_bwd_data")
-        for i in range(n - 1, -1, -1) if not ctx.latent else ():
+        rc = L_.pit_mlp_bwd_data(rows, W, D, D, w1.data_ptr(), w2.data_ptr(), z1[n - 1].data_ptr(), z2[n - 1].data_ptr(), 1,
+                                 d_out.data_ptr(), D, dxc[n - 1].data_ptr(), W, scratch[n - 1].data_ptr(), ctx.math,
+                                 _lib.stream_ptr())
+        _lib.check(rc, "pit_mlp_bwd_data")
+        for i in range(n - 1, -1, -1):
             dw1, db1, dw2, db2 = w_slots[i]
             job = _lib.MlpParamsJob(bufs[i].data_ptr(), W, rows, W, D, D, hh[i].data_ptr(), 1, scratch[i].data_ptr(), D,
                                     dw1.data_ptr(), db1.data_ptr(), dw2.data_ptr(), db2.data_ptr(), 1,
@@ -1477,12 +1234,9 @@ class _Processor(torch.autograd.Function):
                 prev = (None, None, None, None, 0, 0, None, 0, None, dx.data_ptr(), D)
             k = n - 1 - i                              # launch order
             job2 = ctypes.cast(ctypes.pointer(slices[k]), ctypes.c_void_p) if k < len(slices) else None
-            batched = ctx.dw_batch and w_grads[i] is None
-            if batched:                                # the block's own reductions join the pass's batch
-                _dw_batch_add(job, (bufs[i], hh, scratch[i], dw1, db1, dw2, db2), dev)
             rc = L_.pit_block_bwd(E[i].data_ptr(), inv[i].data_ptr(), Q[i].data_ptr(), L, H, D, b, dxc[i].data_ptr(),
                                   bufs[i].data_ptr(), work[i].data_ptr(), *prev,
-                                  None if batched else ctypes.cast(ctypes.pointer(job), ctypes.c_void_p), job2, ctx.math,
+                                  ctypes.cast(ctypes.pointer(job), ctypes.c_void_p), job2, ctx.math,
                                   _lib.stream_ptr())
             _lib.check(rc, "pit_block_bwd")
             if ctx.hook is not None:

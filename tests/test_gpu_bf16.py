@@ -174,7 +174,7 @@ def test_model_bf16_close_to_golden(name, bf16):
         else:
             assert gio.rel_l2(e, g) <= TOL_GRAD, (k, gio.rel_l2(e, g))
     # d(lmda) is a heavily cancelled sum: the decoder's is 1e-3 of the processor's in these cases and
-    # carries the same ABSOLUTE bf16 noise (measured 0.1-0.3 relative on it, tools/bf16_errors.py),
+    # carries the same ABSOLUTE bf16 noise (measured 0.1-0.3 relative on it),
     # so the head gradients are judged together, as the optimiser sees them
     heads_e, heads_g = np.concatenate(heads_e), np.concatenate(heads_g)
     assert gio.rel_l2(heads_e, heads_g) <= TOL_HEAD, gio.rel_l2(heads_e, heads_g)

@@ -687,7 +687,7 @@ def test_fused_coordinate_channels_equal_the_materialised_concat(task):
 # --------------------------------------------------------------------------- self-cleaning state after many replays
 @pytest.mark.parametrize("task,batch", [("darcy", 8), ("naca", 2)])
 def test_replays_leave_every_self_cleaning_buffer_clean(task, batch):
-    """The invariants of tools/soak.py after 400 replays of the captured training step (fwd + loss + bwd + fused
+    """The soak invariants after 400 replays of the captured training step (fwd + loss + bwd + fused
     Adam): the Adam step counter counts exactly, its arrival ticket is back at zero, the gradients it consumed are
     cleared, the fp64 d(scale) accumulators and the loss workspace (partial sums, per-pair and global tickets) are
     zero, parameters and loss finite."""

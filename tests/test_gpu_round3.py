@@ -380,34 +380,6 @@ def test_fused_processor_is_skipped_when_a_block_is_hooked_or_overridden():
         ops.processor_apply = orig
 
 
-# --------------------------------------------------------------------------- weight gradients: riders vs one batch launch
-@pytest.mark.parametrize("task,batch", [("darcy", 8), ("burgers", 4), ("vorticity", 2)])
-def test_weight_gradient_batch_launch_equals_the_riders(task, batch):
-    """ops.DW_BATCH (pit_mlp_bwd_params_batch: every postponed weight-gradient job of the pass in ONE launch at its end)
-    against the default, where the jobs ride in the attention / block launches: same gradients up to the atomics'
-    summation order; nothing left pending."""
-    from position_induced_transformer_amd import ops, utils
-    from position_induced_transformer_amd.ddp import FlatGradients
-    model, (mesh_in, func_in, mesh_out, target), meta = _model_and_batch(task, 23, batch)
-    loss_fn = utils.RelLpNorm(meta["out_dim"], meta["p"])
-    flat = FlatGradients(model.parameters())
-    got = {}
-    prev = ops.DW_BATCH
-    try:
-        for mode in (False, True, False):
-            ops.DW_BATCH = mode
-            flat.zero_()
-            loss_fn(target, model(mesh_in, func_in, mesh_out)).backward()
-            torch.cuda.synchronize()
-            assert not ops._PENDING_BATCH and not any(j is not None for j in ops._PENDING_DW.values())
-            got.setdefault(mode, []).append(flat.flat.clone())
-    finally:
-        ops.DW_BATCH = prev
-    assert float(got[True][0].abs().max()) > 0
-    assert gio.rel_l2(got[False][0].cpu().numpy(), got[True][0].cpu().numpy()) <= 2e-6
-    assert gio.rel_l2(got[False][0].cpu().numpy(), got[False][1].cpu().numpy()) <= 2e-6
-
-
 # --------------------------------------------------------------------------- two-bucket exchange: nothing lands after its reduce
 @pytest.mark.parametrize("task,batch", [("darcy", 8), ("vorticity", 2), ("elasticity", 4)])
 @pytest.mark.parametrize("graph", [False, True], ids=["eager", "hipgraph"])
