@@ -294,6 +294,75 @@ int pit_block_bwd(const float* e, const float* inv, const float* qw, int n_pts, 
                   const struct pit_mlp_params_job* rider, const struct pit_mlp_params_job* rider2,
                   int math_mode, void* stream);
 
+/* ---- Fused encoder-side and decoder-side launches (batch-free meshes, small regime; round 5; csrc/pit_edge.hip) ------------
+ * pit.encoder (pit.py:108-112) = cross attention mesh_in -> mesh_ltt + kaiming_mlp + gelu, pit.decoder (pit.py:124-127) =
+ * cross attention mesh_ltt -> mesh_out + kaiming_mlp, each as ONE launch per direction on 16-row slabs of one sample: the
+ * attention output of a slab stays in LDS as the A operand of the MLP, and in the backward the gradient of that tensor
+ * ((batch, n_out, n_head*dim): 7.6 MB at Darcy b=8) never exists in memory.
+ *
+ * pit_slab_plan: the lmda-independent part of a masked cross-attention layer on a FIXED mesh pair, per 16-row slab - built once
+ * (pit_slab_plan_build) from the candidate lists of pit_plan_fwd, which must be complete (no row's count above cap; report[1]
+ * says so) and, for the decoder, have unions of at most PIT_SLAB_UNION_MAX keys (report[0] = the largest union):
+ *   m     (n_slabs*16, cap) squared distance of every candidate (rows beyond n_out: unused), the fp32 expression of pit.py:47 /
+ *         :192-194 / :251-253; slot (n_slabs*16, cap) the candidate's position in the sorted union of its slab's keys;
+ *   keys  (n_slabs, PIT_SLAB_UNION_MAX) that union, nkeys (n_slabs) its size.  stats / rank_w / idx / cnt / cap as pit_posatt_fwd.
+ * All pointers are device memory owned by the caller; the struct is passed by pointer and read during the call. */
+#define PIT_SLAB_UNION_MAX 64
+typedef struct pit_slab_plan {
+    int n_out, n_in, cap, n_slabs, umax;
+    const float* stats; float rank_w;
+    const int* idx; const int* cnt;
+    const float* m; const unsigned short* slot; const int* keys; const int* nkeys;
+} pit_slab_plan;
+/* report: 2 ints, ZERO on entry (max union size, 1 if a list overflowed).  n_in <= 16384. */
+int pit_slab_plan_build(const float* mesh_out, const float* mesh_in, int n_out, int n_in, int space_dim, int metric, float period,
+                        const int* nbr_idx, const int* nbr_cnt, int cap, float* m, unsigned short* slot, int* keys, int* nkeys,
+                        int* report, void* stream);
+/* 1 when the fused launches cover this shape: n_head 1 or 2, dim (= the MLP's hidden width) 32 or 64, 256 <= batch*rows <= 32768 */
+int pit_edge_supported(int n_head, int dim, int batch, int rows_per_sample);
+/* pit.decoder forward.  values (batch, n_in, dim) rows ld_values apart; the MLP is (n_head*dim -> dim -> n2), n2 <= 4, no trailing
+ * gelu; y (batch*n_out, n2).  Saved for the backward when given (all or none): x (batch*n_out, n_head*dim) the attention's output,
+ * z1 / h (batch*n_out, dim), rowstat (n_head, n_out, 4), scale_out (n_head).  zero_buf: zero_n floats cleared on the way (the
+ * d_values buffer pit_decoder_bwd adds to).  loss_part != NULL: the slab's partial sums of RelLpNorm(true, y*scale + shift)
+ * (utils.py:86-98, p = 1 or 2) as (batch, n2, n_slabs, 2) doubles - plain stores, nothing to zero, the same bits on every run. */
+int pit_decoder_fwd(const pit_slab_plan* plan, const float* values, long ld_values, long values_bstride, int batch,
+                    int n_head, int dim, const float* head, int head_is_scale,
+                    const float* w1, const float* b1, const float* w2, const float* b2, int n2,
+                    float* x, float* z1, float* h, float* y, float* rowstat, float* scale_out, float* zero_buf, long zero_n,
+                    const float* loss_true, const float* loss_scale, const float* loss_shift, int loss_p, double* loss_part,
+                    void* stream);
+/* pit.decoder backward: d_y (batch*n_out, n2) -> dz1 (batch*n_out, dim: the scratch of the MLP's weight-gradient reductions,
+ * pit_mlp_bwd_params with d_y and this scratch), d_values (batch, n_in, dim) ADDED to (fp32 atomics; zero on entry), the layer's
+ * d(scale) accumulators (PIT_HEAD_DEFER convention).  d_y == NULL: the loss inside - d(pred) is formed from loss_part (the
+ * forward's partial sums), multiplied by *loss_seed when given, written to d_pred (batch*n_out, n2); *loss_out receives
+ * sum_b mean_c ||true - pred'|| / ||true||, norms_out (batch, n2, 2) the two norms per series (may be NULL). */
+int pit_decoder_bwd(const pit_slab_plan* plan, const float* values, long ld_values, long values_bstride, int batch,
+                    int n_head, int dim, const float* scale, const float* rowstat,
+                    const float* w1, const float* w2, int n2, const float* z1,
+                    const float* d_y, long ld_dy, float* dz1, float* d_values, long dvalues_bstride, double* dscale,
+                    const float* loss_pred, const float* loss_true, const float* loss_scale, const float* loss_shift,
+                    const float* loss_seed, int loss_p, const double* loss_part, float* d_pred, float* loss_out,
+                    float* norms_out, void* stream);
+/* pit.encoder forward.  Value channels [0, coord_dims) are the key coordinates (mesh_in; train_darcy.py:51-55), the other
+ * value_dim channels come from values (batch, n_in, value_dim); n_head*(coord_dims + value_dim) <= 16.  The MLP is
+ * (n_head*(coord_dims+value_dim) -> dim -> dim) followed by gelu; y rows ldy apart (the first columns of the processor's concat
+ * buffer).  clear_buf: clear_n floats zeroed on the way (the step's flat gradient buffer).  weights: pit_block_weights' arguments,
+ * performed by extra workgroups of this launch (dim 64) or a launch of its own right after. */
+struct pit_block_weights_job;
+int pit_encoder_fwd(const pit_slab_plan* plan, const float* mesh_in, int space_dim, int coord_dims,
+                    const float* values, long ld_values, long values_bstride, int value_dim, int batch,
+                    int n_head, int dim, const float* head, int head_is_scale,
+                    const float* w1, const float* b1, const float* w2, const float* b2,
+                    float* x, float* z1, float* h, float* z2, float* y, long ldy, float* rowstat, float* scale_out,
+                    float* clear_buf, long clear_n, const struct pit_block_weights_job* weights, void* stream);
+/* pit.encoder backward: d_y (batch*n_out, dim) rows ld_dy apart -> scratch (dZ1 | dZ2: the layout of pit_mlp_bwd_data) and the
+ * down-projection's d(scale) accumulators (dscale == NULL: the MLP's data path only).  The inputs get no gradient (data). */
+int pit_encoder_bwd(const pit_slab_plan* plan, const float* mesh_in, int space_dim, int coord_dims,
+                    const float* values, long ld_values, long values_bstride, int value_dim, int batch,
+                    int n_head, int dim, const float* scale, const float* rowstat,
+                    const float* w1, const float* w2, const float* z1, const float* z2,
+                    const float* d_y, long ld_dy, float* scratch, double* dscale, void* stream);
+
 /* ---- Batch-free self-attention on PRECOMPUTED weights, large regime (round 4; pit.py:133-144 with locality 1.0) --------
  * The large-regime attention kernels re-formed exp(-c m) in every workgroup (posatt_rows_tiles / posatt_cols_tiles: the weight
  * phase and the MFMA phase of a workgroup do not overlap, 47-51 % MFMA busy).  With the weights of pit_block_weights in

@@ -32,6 +32,12 @@ class BlockWeightsJob(ctypes.Structure):
                 ("e", _P), ("q", _P), ("inv", _P), ("rowstat", _P), ("scale_out", _P)]
 
 
+class SlabPlan(ctypes.Structure):
+    """pit_slab_plan of include/pit_hip.h (the static per-slab plan of a masked cross-attention layer on a fixed mesh pair)."""
+    _fields_ = [("n_out", _I), ("n_in", _I), ("cap", _I), ("n_slabs", _I), ("umax", _I), ("stats", _P), ("rank_w", _F),
+                ("idx", _P), ("cnt", _P), ("m", _P), ("slot", _P), ("keys", _P), ("nkeys", _P)]
+
+
 # name -> argtypes, mirrors include/pit_hip.h one to one
 SIGNATURES = {
     "pit_version": [],
@@ -64,6 +70,15 @@ SIGNATURES = {
     "pit_block_supported": [_I, _I, _I, _I],
     "pit_block_weights": [_P, _I, _I, _I, _F, _I, _P, _I, _I, _P, _P, _P, _P, _P, _P],
     "pit_block_fwd": [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _L, _I, _P],
+    "pit_slab_plan_build": [_P, _P, _I, _I, _I, _I, _F, _P, _P, _I, _P, _P, _P, _P, _P, _P],
+    "pit_edge_supported": [_I, _I, _I, _I],
+    "pit_decoder_fwd": [_P, _P, _L, _L, _I, _I, _I, _P, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _L,
+                        _P, _P, _P, _I, _P, _P],
+    "pit_decoder_bwd": [_P, _P, _L, _L, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _L, _P, _P, _L, _P,
+                        _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P],
+    "pit_encoder_fwd": [_P, _P, _I, _I, _P, _L, _L, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P,
+                        _P, _P, _P, _P, _P, _L, _P, _P, _P, _L, _P, _P],
+    "pit_encoder_bwd": [_P, _P, _I, _I, _P, _L, _L, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _L, _P, _P, _P],
     "pit_posatt_pre_supported": [_I, _I, _I, _I],
     "pit_posatt_pre_fwd": [_P, _P, _I, _I, _I, _I, _P, _L, _L, _P, _L, _L, _I, _I, _I, _P],
     "pit_posatt_pre_bwd": [_P, _P, _P, _I, _I, _I, _I, _P, _L, _L, _P, _L, _L, _I, _P, _L, _L, _I, _P, _I, _P],

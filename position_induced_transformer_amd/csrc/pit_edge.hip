@@ -1,0 +1,1025 @@
+// Fused encoder-side and decoder-side launches of the small (latency-bound) regime on batch-free meshes.
+//
+// Around the fused processor (pit_block.hip) a Darcy-sized step still ran eleven launches: the down-projection (pit.py:109,
+// posatt_cross_fixed on candidate lists), the encoder MLP + gelu (pit.py:110-111), the up-projection (pit.py:125), the
+// decoder MLP (pit.py:126), the loss (utils.py:86-98) and their backward counterparts - each 5-17 us of dependent round trips at
+// <= 9 % MFMA busy, with the (batch, n_out, H*hid) up-projection output and its gradient making a full trip through memory between
+// two launches in both directions.  Here each side is ONE launch per direction, a workgroup owning 16 consecutive mesh rows of one
+// sample from the attention to the end of the MLP:
+//
+//   slab_plan_kernel     once per (mesh_out, mesh_in) pair - the meshes are batch-free and fixed, so everything about a 16-row
+//                        slab that does not depend on lmda is static: the candidates' squared distances (sq_dist3, the same
+//                        function every other kernel uses), the sorted UNION of the slab's candidate keys and each candidate's
+//                        slot in it.  No coordinate is read on the step's path any more.
+//   decoder_fwd_kernel   up-projection as a union-tile contraction (P: 16 x U weights scattered into LDS, the U <= 64 value rows
+//                        of the union fetched ONCE per slab, v_mfma_f32_16x16x4_f32) -> the 16 x H*hid tile stays in LDS as the A
+//                        operand of the decoder MLP (GEMM1 + bias + gelu, thin out_dim <= 4 output as row dots) -> optionally the
+//                        slab's partial sums of the RelLp loss (fp64, one slot per slab: deterministic, nothing to zero).
+//   decoder_bwd_kernel   d(pred) (given, or formed from the loss's partial sums) -> dZ1 -> dX = dZ1 W1 (16 x H*hid, LDS only: the
+//                        7.6 MB gradient of the up-projection's output never exists) -> d(scale) as (Q U) . dX and d(values) as
+//                        P^T dX on MFMA against the same union tile, added to memory with one pass of fp32 atomics per slab.
+//   encoder_fwd_kernel   down-projection (a wave per row, lane = candidate: 40 keys x 3 channels is no contraction worth an MFMA)
+//                        -> encoder MLP + gelu on the slab -> the processor's first concat buffer; the processor's block weights
+//                        (block_weights_body) ride as extra workgroups, the step's gradient accumulators are cleared on the way.
+//   encoder_bwd_kernel   encoder MLP backward (data path) -> dX (16 x H*(s+in_dim), LDS only) -> the down-projection's d(scale).
+//
+// Exactness: mask decisions use the same fp32 expression tree as every other kernel (S = fl(c m), T = lerp(fl(c m_k), fl(c m_k1), w),
+// keep = S <= T) on distances computed by the same sq_dist3; tests/test_gpu_round5.py compares each launch with the oracle.
+#include "pit_common.h"
+#include "pit_gemm_rd.h"
+#include "pit_block_dev.h"
+
+namespace {
+
+constexpr int ER = 16;                  // rows per slab
+constexpr int EU = PIT_SLAB_UNION_MAX;  // union keys a slab tile holds (64)
+constexpr int EUP = EU + 4;             // LDS pitch of a [..][slot] tile
+constexpr int PTP = 2 * ER + 4;         // LDS pitch of the transposed weights tile [slot][h*16 + row]
+
+// sum over the LPR-lane segment a lane belongs to (16, 32 or 64 lanes), returned to every lane of the segment
+template <int LPR>
+__device__ __forceinline__ float seg_sum(float v) {
+    v += dpp_f<0xB1, 0xf>(v);
+    v += dpp_f<0x4E, 0xf>(v);
+    v += dpp_f<0x124, 0xf>(v);
+    v += dpp_f<0x128, 0xf>(v);
+    if (LPR >= 32) v += __shfl_xor(v, 16, 64);
+    if (LPR >= 64) v += __shfl_xor(v, 32, 64);
+    return v;
+}
+
+__device__ __forceinline__ float pow_abs_p(float x, int p) {
+    const float ax = fabsf(x);
+    return p == 1 ? ax : ax * ax;
+}
+
+// ------------------------------------------------------------------------------------------------ static slab plan
+struct SlabBuildArgs {
+    const float *mesh_out, *mesh_in;
+    int n_out, n_in, sdim, used, periodic; float period;
+    const int *idx, *cnt; int cap, umax;
+    float* m; unsigned short* slot; int* keys; int* nkeys; int* report;      // report[0] = max union, report[1] = 1 if a list overflowed
+};
+
+__global__ __launch_bounds__(256) void slab_plan_kernel(SlabBuildArgs a) {
+    __shared__ unsigned bm[512];          // n_in <= 16384 keys
+    __shared__ int pref[513];
+    const int tid = threadIdx.x, slab = blockIdx.x;
+    const int nwords = (a.n_in + 31) >> 5;
+    for (int w = tid; w < nwords; w += 256) bm[w] = 0u;
+    __syncthreads();
+    const int total = ER * a.cap;
+    for (int e = tid; e < total; e += 256) {
+        const int r = e / a.cap, i = e - r * a.cap;
+        const int row = slab * ER + r;
+        float mv = 0.0f;
+        if (row < a.n_out) {
+            const int c = a.cnt[row];
+            if (c > a.cap && i == 0) atomicMax(a.report + 1, 1);
+            if (i < min(c, a.cap)) {
+                const int j = a.idx[(long)row * a.cap + i];
+                const float* xo = a.mesh_out + (long)row * a.sdim;
+                const float* xi = a.mesh_in + (long)j * a.sdim;
+                mv = sq_dist3(xo[0], a.used > 1 ? xo[1] : 0.0f, a.used > 2 ? xo[2] : 0.0f,
+                              xi[0], a.used > 1 ? xi[1] : 0.0f, a.used > 2 ? xi[2] : 0.0f, a.periodic != 0, a.period);
+                atomicOr(&bm[j >> 5], 1u << (j & 31));
+            }
+        }
+        a.m[(long)(slab * ER + r) * a.cap + i] = mv;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0;
+        for (int w = 0; w < nwords; ++w) { pref[w] = run; run += __popc(bm[w]); }
+        pref[nwords] = run;
+        a.nkeys[slab] = run;
+        atomicMax(a.report, run);
+    }
+    __syncthreads();
+    const int nk = pref[nwords];
+    for (int w = tid; w < nwords; w += 256) {
+        unsigned bits = bm[w];
+        int s = pref[w];
+        while (bits) {
+            const int bpos = __ffs(bits) - 1;
+            bits &= bits - 1u;
+            if (s < a.umax) a.keys[(long)slab * a.umax + s] = w * 32 + bpos;
+            ++s;
+        }
+    }
+    for (int s = nk + tid; s < a.umax; s += 256) a.keys[(long)slab * a.umax + s] = 0;      // padding: a valid key, weight 0
+    for (int e = tid; e < total; e += 256) {
+        const int r = e / a.cap, i = e - r * a.cap;
+        const int row = slab * ER + r;
+        int s = 0;
+        if (row < a.n_out && i < min(a.cnt[row], a.cap)) {
+            const int j = a.idx[(long)row * a.cap + i];
+            s = pref[j >> 5] + __popc(bm[j >> 5] & ((1u << (j & 31)) - 1u));
+        }
+        a.slot[(long)(slab * ER + r) * a.cap + i] = (unsigned short)min(s, 65535);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ shared pieces
+// The head scales of the launch: c_h as the caller gives it, or from lmda (pit_common.h).
+template <int H>
+__device__ __forceinline__ void head_scales(const float* head, int is_scale, float (&c)[H]) {
+#pragma unroll
+    for (int h = 0; h < H; ++h) c[h] = is_scale ? head[h] : head_scale_from_lmda(head[h]);
+}
+
+// One pass of weight formation: this lane is candidate `i` of slab row `row_l` (mesh row n).  FWD: thresholds from the order
+// statistics, un-normalised weights, the row's sums by segment reductions -> P = p / rowsum and the saved rowstat;
+// !FWD: everything from the saved rowstat -> P and Q = P (m - mbar).
+struct Cand { float m; int slot; bool valid; };
+
+template <int LPR>
+__device__ __forceinline__ Cand load_cand(const pit_slab_plan& p, int slab, int row_l, int i) {
+    Cand c;
+    const int n = slab * ER + row_l;
+    const int cnt = n < p.n_out ? min(p.cnt[n], p.cap) : 0;
+    c.valid = i < cnt;
+    const long off = (long)(slab * ER + row_l) * p.cap + (c.valid ? i : 0);
+    c.m = p.m[off];
+    c.slot = p.slot[off];
+    return c;
+}
+
+// ------------------------------------------------------------------------------------------------ decoder forward
+struct DecFwdArgs {
+    pit_slab_plan p;
+    const float* values; long ld_values, values_bstride; int batch;
+    const float* head; int head_is_scale;
+    const float *w1, *b1, *w2, *b2; int n2;
+    float *x, *z1, *h, *y;
+    float* rowstat; float* scale_out;
+    float* zero_buf; long zero_n;
+    const float *tru, *lscale, *lshift; int loss_p; double* lpart;
+};
+
+// gather the slab's union value rows: 16 rows per pass (NT / (D/4) threads per row), up to EU / 16 passes, all in flight
+template <int D>
+__device__ __forceinline__ void gather_union(const float* __restrict__ vb, long ldv, const int* keys_s, int nk, int nkup, int tid,
+                                             float4 (&uv)[EU / 16]) {
+    const int r0 = tid / (D / 4), q = tid % (D / 4);
+#pragma unroll
+    for (int u = 0; u < EU / 16; ++u) {
+        uv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int r = r0 + 16 * u;
+        if (16 * u < nkup && r < nk) uv[u] = *reinterpret_cast<const float4*>(vb + (long)keys_s[r] * ldv + 4 * q);
+    }
+}
+template <int D>
+__device__ __forceinline__ void park_union(float* ut, int nkup, int tid, const float4 (&uv)[EU / 16]) {
+    const int r0 = tid / (D / 4), q = tid % (D / 4);
+#pragma unroll
+    for (int u = 0; u < EU / 16; ++u)
+        if (16 * u < nkup) *reinterpret_cast<float4*>(ut + (r0 + 16 * u) * (D + 4) + 4 * q) = uv[u];
+}
+
+// acc (16 rows x columns [16 wave, 16 wave + 16)) = W[16 x nkup] (row-major in LDS, pitch EUP) @ ut[nkup x D]
+template <int D>
+__device__ __forceinline__ f32x4_t tile_times_union(const float* wrow, const float* ut, int nkup, int wave, int l15, int kq) {
+    f32x4_t a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < nkup / 16; ++s) {
+        const float4 a = *reinterpret_cast<const float4*>(wrow + l15 * EUP + 16 * s + 4 * kq);
+        const float* bp = ut + (16 * s + 4 * kq) * (D + 4) + 16 * wave + l15;
+        a0 = mfma_16x16x4(a.x, bp[0], a0);
+        a1 = mfma_16x16x4(a.y, bp[D + 4], a1);
+        a0 = mfma_16x16x4(a.z, bp[2 * (D + 4)], a0);
+        a1 = mfma_16x16x4(a.w, bp[3 * (D + 4)], a1);
+    }
+    f32x4_t r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r[i] = a0[i] + a1[i];
+    return r;
+}
+
+template <int H, int D, int LPR>
+__global__ __launch_bounds__(4 * D) void decoder_fwd_kernel(DecFwdArgs g) {
+    constexpr int NT = 4 * D, NW = D / 16, K0 = H * D, KS = K0 / 16, XP = K0 + 4, HP = D + 4;
+    constexpr int RPW = 64 / LPR, NP = ER / (NW * RPW);           // rows per wave and pass, passes
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* pt = smem;                          // [H][16][EUP] normalised weights
+    float* ut = pt + H * ER * EUP;             // [EU][D + 4] union value rows
+    float* xs = ut + EU * (D + 4);             // [16][XP]
+    float* hs = xs + ER * XP;                  // [16][HP]
+    float* w2s = hs + ER * HP;                 // [4][D], then b2[4]
+    int* keys_s = reinterpret_cast<int*>(w2s + 4 * D + 4);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, kq = lane >> 4;
+    const pit_slab_plan& p = g.p;
+    int b, slab;
+    if (!slab_of_xcd(blockIdx.x, g.batch, p.n_slabs, b, slab)) return;
+    const int nk = min(p.nkeys[slab], EU), nkup = (nk + 15) & ~15;
+    const long row0 = (long)b * p.n_out + slab * ER;             // first row of the slab in the (batch * n_out) row space
+
+    // ---- everything that depends on nothing: MLP operands, the plan's records, the union keys
+    const int c1 = wave * 16 + l15;
+    float4 bv[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) bv[s] = *reinterpret_cast<const float4*>(g.w1 + (long)c1 * K0 + 16 * s + 4 * kq);
+    const float bias1 = g.b1[c1];
+    if (tid < EU) keys_s[tid] = p.keys[(long)slab * p.umax + tid];
+    for (int e = tid; e < g.n2 * D; e += NT) w2s[e] = g.w2[e];
+    if (tid < g.n2) w2s[4 * D + tid] = g.b2[tid];
+    Cand cd[NP];
+    float st_k[NP], st_k1[NP], st_min[NP];
+#pragma unroll
+    for (int ps = 0; ps < NP; ++ps) {
+        const int row_l = ps * NW * RPW + wave * RPW + lane / LPR, n = slab * ER + row_l;
+        cd[ps] = load_cand<LPR>(p, slab, row_l, lane % LPR);
+        const int nn = n < p.n_out ? n : p.n_out - 1;
+        st_k[ps] = p.stats[nn]; st_k1[ps] = p.stats[p.n_out + nn]; st_min[ps] = p.stats[2 * (long)p.n_out + nn];
+    }
+    for (int e = tid; e < H * ER * EUP; e += NT) pt[e] = 0.0f;
+    if (g.zero_buf) {                                            // this workgroup's share of a buffer the backward adds to
+        const long wgs = (long)g.batch * p.n_slabs, me = (long)b * p.n_slabs + slab;
+        const long per = ((g.zero_n + wgs - 1) / wgs + 3) & ~3L;
+        const long beg = me * per, end = min(g.zero_n, beg + per);
+        for (long e = beg + 4 * tid; e < end; e += 4 * NT) {
+            if (e + 4 <= end) *reinterpret_cast<float4*>(g.zero_buf + e) = make_float4(0.f, 0.f, 0.f, 0.f);
+            else for (long q = e; q < end; ++q) g.zero_buf[q] = 0.0f;
+        }
+    }
+    float c[H];
+    head_scales<H>(g.head, g.head_is_scale, c);
+    __syncthreads();
+    // ---- union value rows requested, weights formed while they fly
+    float4 uv[EU / 16];
+    gather_union<D>(g.values + (long)b * g.values_bstride, g.ld_values, keys_s, nk, nkup, tid, uv);
+#pragma unroll
+    for (int ps = 0; ps < NP; ++ps) {
+        const int row_l = ps * NW * RPW + wave * RPW + lane / LPR, n = slab * ER + row_l;
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+            const float T = quantile_lerp(__fmul_rn(c[h], st_k[ps]), __fmul_rn(c[h], st_k1[ps]), p.rank_w);
+            const float smin = __fmul_rn(c[h], st_min[ps]);
+            const float sv = __fmul_rn(cd[ps].m, c[h]);
+            const bool keep = cd[ps].valid && sv <= T;
+            const float pv = keep ? __expf(smin - sv) : 0.0f;
+            const float rs = seg_sum<LPR>(pv), qs = seg_sum<LPR>(pv * cd[ps].m);
+            const float inv = rs > 0.0f ? 1.0f / rs : 0.0f;
+            if (cd[ps].valid) pt[(h * ER + row_l) * EUP + cd[ps].slot] = pv * inv;
+            if (lane % LPR == 0 && n < p.n_out && b == 0 && g.rowstat) {
+                float4 st; st.x = T; st.y = smin; st.z = inv; st.w = qs * inv;
+                *reinterpret_cast<float4*>(g.rowstat + ((long)h * p.n_out + n) * 4) = st;
+                if (n == 0 && g.scale_out) g.scale_out[h] = c[h];
+            }
+        }
+    }
+    park_union<D>(ut, nkup, tid, uv);
+    __syncthreads();
+    // ---- attention output tile: X[:, h*D + 16 wave ..] = P_h @ U
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+        const f32x4_t o = tile_times_union<D>(pt + h * ER * EUP, ut, nkup, wave, l15, kq);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = 4 * kq + i;
+            xs[r * XP + h * D + c1] = o[i];
+            if (g.x && slab * ER + r < p.n_out) g.x[(row0 + r) * K0 + h * D + c1] = o[i];
+        }
+    }
+    __syncthreads();
+    // ---- decoder MLP, first layer: Z1 = X W1^T + b1, H = gelu(Z1)
+    {
+        f32x4_t a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const float4 a = *reinterpret_cast<const float4*>(xs + l15 * XP + 16 * s + 4 * kq);
+            a0 = mfma_16x16x4(a.x, bv[s].x, a0);
+            a1 = mfma_16x16x4(a.y, bv[s].y, a1);
+            a0 = mfma_16x16x4(a.z, bv[s].z, a0);
+            a1 = mfma_16x16x4(a.w, bv[s].w, a1);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = 4 * kq + i;
+            const float z = a0[i] + a1[i] + bias1;
+            const float hv = gelu_erf(z);
+            hs[r * HP + c1] = hv;
+            if (g.z1 && slab * ER + r < p.n_out) {
+                g.z1[(row0 + r) * D + c1] = z;
+                g.h[(row0 + r) * D + c1] = hv;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- thin output layer (out_dim <= 4, pit.py:106): a row dot per output; the slab's share of the loss
+    if (wave != 0) return;
+    const int n = slab * ER + l15;
+    const bool rv = n < p.n_out;
+    for (int o = 0; o < g.n2; ++o) {
+        float part = 0.0f;
+#pragma unroll
+        for (int k = 0; k < D / 4; k += 4) {
+            const float4 a = *reinterpret_cast<const float4*>(hs + l15 * HP + kq * (D / 4) + k);
+            const float4 w = *reinterpret_cast<const float4*>(w2s + o * D + kq * (D / 4) + k);
+            part += (a.x * w.x + a.y * w.y) + (a.z * w.z + a.w * w.w);
+        }
+        part += __shfl_xor(part, 16, 64);
+        part += __shfl_xor(part, 32, 64);
+        const float pred = part + w2s[4 * D + o];
+        if (kq == 0 && rv) g.y[(row0 + l15) * g.n2 + o] = pred;
+        if (g.lpart) {
+            double num = 0.0, den = 0.0;
+            if (kq == 0 && rv) {
+                const float t = g.tru[(row0 + l15) * g.n2 + o];
+                const float q = g.lscale ? pred * g.lscale[(long)n * g.n2 + o] + g.lshift[(long)n * g.n2 + o] : pred;
+                num = (double)pow_abs_p(t - q, g.loss_p);
+                den = (double)pow_abs_p(t, g.loss_p);
+            }
+            num = wave_sum_d(num);
+            den = wave_sum_d(den);
+            if (lane == 0) {
+                double* dst = g.lpart + (((long)b * g.n2 + o) * p.n_slabs + slab) * 2;
+                dst[0] = num; dst[1] = den;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ decoder backward
+struct DecBwdArgs {
+    pit_slab_plan p;
+    const float* values; long ld_values, values_bstride; int batch;
+    const float* scale; const float* rowstat;
+    const float *w1, *w2; int n2;
+    const float* z1;
+    const float* d_y; long ld_dy;
+    float* dz1;
+    float* d_values; long dvalues_bstride;
+    double* dscale;
+    // the loss inside (d_y == NULL): d(pred) from the forward's partial sums, written to d_pred for the weight-gradient reductions
+    const float *pred, *tru, *lscale, *lshift, *gseed; int loss_p; const double* lpart; float* d_pred; float* loss_out; float* norms_out;
+};
+
+// ||t - q||_p and ||t||_p of series (b, o) from the slabs' partial sums (every lane gets both)
+__device__ __forceinline__ void series_norms(const double* lpart, int b, int o, int n2, int slabs, int p, int lane, double& nn, double& dn) {
+    double num = 0.0, den = 0.0;
+    const double* src = lpart + ((long)b * n2 + o) * slabs * 2;
+    for (int s = lane; s < slabs; s += 64) { num += src[2 * s]; den += src[2 * s + 1]; }
+    num = wave_sum_d(num);
+    den = wave_sum_d(den);
+    nn = p == 1 ? num : sqrt(num);
+    dn = p == 1 ? den : sqrt(den);
+}
+
+template <int H, int D, int LPR>
+__global__ __launch_bounds__(4 * D) void decoder_bwd_kernel(DecBwdArgs g) {
+    constexpr int NT = 4 * D, NW = D / 16, K0 = H * D, S1 = D / 16, XP = K0 + 4, P1 = D + 4;
+    constexpr int RPW = 64 / LPR, NP = ER / (NW * RPW);
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* pts = smem;                         // [EU][PTP]      P^T: [slot][h*16 + row]
+    float* qs = pts + EU * PTP;                // [H][16][EUP]   Q = P (m - mbar)
+    float* ut = qs + H * ER * EUP;             // [EU][D + 4]
+    float* ds1 = ut + EU * (D + 4);            // [16][P1]       dZ1
+    float* dxs = ds1 + ER * P1;                // [16][XP]       dX
+    float* w2s = dxs + ER * XP;                // [4][D]
+    float* ds2 = w2s + 4 * D;                  // [16][4]        dZ2 = d(pred)
+    double* wred = reinterpret_cast<double*>(ds2 + ER * 4);      // [NW][H]
+    float* nrm = reinterpret_cast<float*>(wred + NW * H);        // [4][2] norms of the sample's series
+    int* keys_s = reinterpret_cast<int*>(nrm + 8);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, kq = lane >> 4;
+    const pit_slab_plan& p = g.p;
+    int b, slab;
+    if (!slab_of_xcd(blockIdx.x, g.batch, p.n_slabs, b, slab)) return;
+    const int nk = min(p.nkeys[slab], EU), nkup = (nk + 15) & ~15;
+    const long row0 = (long)b * p.n_out + slab * ER;
+    const int c1 = wave * 16 + l15;
+
+    // ---- requested first: W1 as the B operand of dX (B(k, n) = w1[k][n]), the gelu' arguments, the plan's records
+    float w1v[H][S1][4];
+#pragma unroll
+    for (int hh = 0; hh < H; ++hh)
+#pragma unroll
+        for (int s = 0; s < S1; ++s)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) w1v[hh][s][e] = g.w1[(long)(16 * s + 4 * kq + e) * K0 + hh * D + c1];
+    float z1v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int e = tid + u * NT, r = e / D, cc = e % D;
+        z1v[u] = slab * ER + r < p.n_out ? g.z1[(row0 + r) * D + cc] : 0.0f;
+    }
+    if (tid < EU) keys_s[tid] = p.keys[(long)slab * p.umax + tid];
+    for (int e = tid; e < g.n2 * D; e += NT) w2s[e] = g.w2[e];
+    Cand cd[NP];
+    float4 rs4[NP][H];
+#pragma unroll
+    for (int ps = 0; ps < NP; ++ps) {
+        const int row_l = ps * NW * RPW + wave * RPW + lane / LPR, n = slab * ER + row_l;
+        cd[ps] = load_cand<LPR>(p, slab, row_l, lane % LPR);
+        const int nn = n < p.n_out ? n : p.n_out - 1;
+#pragma unroll
+        for (int h = 0; h < H; ++h) rs4[ps][h] = *reinterpret_cast<const float4*>(g.rowstat + ((long)h * p.n_out + nn) * 4);
+    }
+    float dyv = 0.0f, predv = 0.0f, truv = 0.0f, lsc = 1.0f, lsh = 0.0f;
+    const int dr = tid / g.n2, dcol = tid % g.n2;                // this thread's d(pred) element (tid < 16 n2)
+    const bool downer = tid < ER * g.n2 && slab * ER + dr < p.n_out;
+    if (downer) {
+        if (g.d_y) dyv = g.d_y[(row0 + dr) * g.ld_dy + dcol];
+        else {
+            predv = g.pred[(row0 + dr) * g.n2 + dcol];
+            truv = g.tru[(row0 + dr) * g.n2 + dcol];
+            if (g.lscale) {
+                lsc = g.lscale[(long)(slab * ER + dr) * g.n2 + dcol];
+                lsh = g.lshift[(long)(slab * ER + dr) * g.n2 + dcol];
+            }
+        }
+    }
+    for (int e = tid; e < EU * PTP; e += NT) pts[e] = 0.0f;
+    for (int e = tid; e < H * ER * EUP; e += NT) qs[e] = 0.0f;
+    float c[H];
+#pragma unroll
+    for (int h = 0; h < H; ++h) c[h] = g.scale[h];
+    if (!g.d_y) {
+        // the loss of the step (utils.py:86-98) finished here: this sample's norms by wave 0, the scalar by the first workgroup
+        if (wave == 0)
+            for (int o = 0; o < g.n2; ++o) {
+                double nn, dn;
+                series_norms(g.lpart, b, o, g.n2, p.n_slabs, g.loss_p, lane, nn, dn);
+                if (lane == 0) { nrm[2 * o] = (float)nn; nrm[2 * o + 1] = (float)dn; }
+            }
+        if (blockIdx.x == 0 && wave == NW - 1) {
+            double tot = 0.0;
+            for (int bb = 0; bb < g.batch; ++bb)
+                for (int o = 0; o < g.n2; ++o) {
+                    double nn, dn;
+                    series_norms(g.lpart, bb, o, g.n2, p.n_slabs, g.loss_p, lane, nn, dn);
+                    tot += (double)((float)(nn / dn / g.n2));
+                    if (lane == 0 && g.norms_out) {
+                        g.norms_out[((long)bb * g.n2 + o) * 2] = (float)nn;
+                        g.norms_out[((long)bb * g.n2 + o) * 2 + 1] = (float)dn;
+                    }
+                }
+            if (lane == 0) *g.loss_out = (float)tot;
+        }
+    }
+    __syncthreads();
+    float4 uv[EU / 16];
+    gather_union<D>(g.values + (long)b * g.values_bstride, g.ld_values, keys_s, nk, nkup, tid, uv);
+    // ---- d(pred) -> LDS (and, with the loss inside, to memory for the weight-gradient reductions)
+    if (tid < ER * g.n2) {
+        float v = dyv;
+        if (!g.d_y && downer) {
+            const float nn = nrm[2 * dcol], dn = nrm[2 * dcol + 1];
+            const float d = predv * lsc + lsh - truv;
+            float dnorm;
+            if (g.loss_p == 1) dnorm = (d > 0.0f) ? 1.0f : (d < 0.0f ? -1.0f : 0.0f);
+            else dnorm = (nn > 0.0f) ? d / nn : 0.0f;
+            v = dnorm * lsc / (dn * g.n2);
+            if (g.gseed) v *= g.gseed[0];
+            g.d_pred[(row0 + dr) * g.n2 + dcol] = v;
+        }
+        ds2[dr * 4 + dcol] = downer ? v : 0.0f;
+    }
+    // ---- weights from the saved row statistics: P^T and Q tiles
+#pragma unroll
+    for (int ps = 0; ps < NP; ++ps) {
+        const int row_l = ps * NW * RPW + wave * RPW + lane / LPR;
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+            const float sv = __fmul_rn(cd[ps].m, c[h]);
+            const bool keep = cd[ps].valid && sv <= rs4[ps][h].x;
+            const float pv = keep ? __expf(rs4[ps][h].y - sv) * rs4[ps][h].z : 0.0f;
+            if (cd[ps].valid) {
+                pts[cd[ps].slot * PTP + h * ER + row_l] = pv;
+                qs[(h * ER + row_l) * EUP + cd[ps].slot] = pv * (cd[ps].m - rs4[ps][h].w);
+            }
+        }
+    }
+    __syncthreads();
+    // ---- dZ1 = (dZ2 W2) * gelu'(Z1): elementwise for the thin output layer
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int e = tid + u * NT, r = e / D, cc = e % D;
+        float acc = 0.0f;
+        for (int o = 0; o < g.n2; ++o) acc += ds2[r * 4 + o] * w2s[o * D + cc];
+        const float v = acc * gelu_erf_grad(z1v[u]);
+        ds1[r * P1 + cc] = v;
+        if (slab * ER + r < p.n_out) g.dz1[(row0 + r) * D + cc] = v;
+    }
+    park_union<D>(ut, nkup, tid, uv);
+    __syncthreads();
+    // ---- dX = dZ1 W1 (16 x H*D), LDS only
+#pragma unroll
+    for (int hh = 0; hh < H; ++hh) {
+        f32x4_t o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < S1; ++s) {
+            const float4 a = *reinterpret_cast<const float4*>(ds1 + l15 * P1 + 16 * s + 4 * kq);
+            o0 = mfma_16x16x4(a.x, w1v[hh][s][0], o0);
+            o1 = mfma_16x16x4(a.y, w1v[hh][s][1], o1);
+            o0 = mfma_16x16x4(a.z, w1v[hh][s][2], o0);
+            o1 = mfma_16x16x4(a.w, w1v[hh][s][3], o1);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dxs[(4 * kq + i) * XP + hh * D + c1] = o0[i] + o1[i];
+    }
+    __syncthreads();
+    // ---- d(scale): dc_h -= sum_{row, d} dX[row, h*D + d] * (Q_h U)[row, d]
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+        const f32x4_t qu = tile_times_union<D>(qs + h * ER * EUP, ut, nkup, wave, l15, kq);
+        double part = 0.0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) part += (double)qu[i] * (double)dxs[(4 * kq + i) * XP + h * D + c1];
+        part = wave_sum_d(part);
+        if (lane == 0) wred[wave * H + h] = part;
+    }
+    // ---- d(values)[key(slot), 16 wave ..] += sum_{h, row} P_h[row][slot] dX[row, h*D + ..]
+    for (int mt = 0; mt < nkup / 16; ++mt) {
+        f32x4_t a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+            const float4 a = *reinterpret_cast<const float4*>(pts + (16 * mt + l15) * PTP + h * ER + 4 * kq);
+            const float* bp = dxs + (4 * kq) * XP + h * D + c1;
+            a0 = mfma_16x16x4(a.x, bp[0], a0);
+            a1 = mfma_16x16x4(a.y, bp[XP], a1);
+            a0 = mfma_16x16x4(a.z, bp[2 * XP], a0);
+            a1 = mfma_16x16x4(a.w, bp[3 * XP], a1);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int s = 16 * mt + 4 * kq + i;
+            if (s < nk) atomicAdd(g.d_values + (long)b * g.dvalues_bstride + (long)keys_s[s] * D + c1, a0[i] + a1[i]);
+        }
+    }
+    __syncthreads();
+    if (tid < H && g.dscale) {
+        double tot = 0.0;
+        for (int w = 0; w < NW; ++w) tot += wred[w * H + tid];
+        atomicAdd(g.dscale + (long)tid * PIT_DSCALE_SLOTS + ((int)blockIdx.x & (PIT_DSCALE_SLOTS - 1)), -tot);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ encoder forward
+constexpr int EC = 8;                   // value channels of the down-projection (coordinates + in_dim) at most
+struct EncArgs {
+    pit_slab_plan p;
+    const float* mesh_in; int sdim, kd;                  // value channels [0, kd) are the key coordinates (train_darcy.py:51-55)
+    const float* values; long ld_values, values_bstride; int dv, batch;
+    const float* head; int head_is_scale;                // forward: lmda or c; backward: the saved c
+    const float *w1, *b1, *w2, *b2;
+    float* x;                                            // (batch * n_out, H * (kd + dv)): the attention's output, saved
+    float *z1, *h, *z2, *y; long ldy;
+    float* rowstat; float* scale_out;
+    float* clear_buf; long clear_n;
+    int n_att;
+    // backward
+    const float* d_y; long ld_dy; float* scratch; double* dscale;
+};
+
+// the candidate records and value channels of this wave's rows: a wave per row, lane = candidate (LPR = 64)
+struct EncCand { float m; bool valid; float v[EC]; };
+
+template <int NW>
+__device__ __forceinline__ void enc_gather(const EncArgs& g, int b, int slab, int wave, int lane, EncCand (&cd)[ER / NW]) {
+    const pit_slab_plan& p = g.p;
+    int jj[ER / NW];
+#pragma unroll
+    for (int ps = 0; ps < ER / NW; ++ps) {
+        const int row_l = ps * NW + wave, n = slab * ER + row_l;
+        const int cnt = n < p.n_out ? min(p.cnt[n], p.cap) : 0;
+        cd[ps].valid = lane < cnt;
+        const long off = (long)(slab * ER + row_l) * p.cap + (cd[ps].valid ? lane : 0);
+        cd[ps].m = p.m[off];
+        jj[ps] = cd[ps].valid ? p.idx[(long)(n < p.n_out ? n : 0) * p.cap + lane] : 0;
+    }
+    const int dc = g.kd + g.dv;
+#pragma unroll
+    for (int ps = 0; ps < ER / NW; ++ps)
+#pragma unroll
+        for (int cc = 0; cc < EC; ++cc) {
+            float v = 0.0f;
+            if (cc < dc && cd[ps].valid)
+                v = cc < g.kd ? g.mesh_in[(long)jj[ps] * g.sdim + cc]
+                              : g.values[(long)b * g.values_bstride + (long)jj[ps] * g.ld_values + (cc - g.kd)];
+            cd[ps].v[cc] = v;
+        }
+}
+
+template <int H, int D>
+__global__ __launch_bounds__(4 * D) void encoder_fwd_kernel(EncArgs g, WeightsArgs wj) {
+    constexpr int NT = 4 * D, NW = D / 16, S2 = D / 16, HP = D + 4, XP = 20;
+    __shared__ __attribute__((aligned(16))) float xs[ER * XP];
+    __shared__ __attribute__((aligned(16))) float hs[ER * HP];
+    if ((int)blockIdx.x >= g.n_att) {                           // the processor's block weights ride here (256-thread workgroups)
+        if (D == 64) block_weights_body(wj, (long)blockIdx.x - g.n_att);
+        return;
+    }
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, kq = lane >> 4;
+    const pit_slab_plan& p = g.p;
+    if (g.clear_buf) {                                          // the step's gradient accumulators (engine.TrainStep): zero before any backward launch
+        const long nthreads = (long)g.n_att * NT;
+        for (long i = (long)blockIdx.x * NT + tid; i < g.clear_n; i += nthreads) g.clear_buf[i] = 0.0f;
+    }
+    int b, slab;
+    if (!slab_of_xcd(blockIdx.x, g.batch, p.n_slabs, b, slab)) return;
+    const long row0 = (long)b * p.n_out + slab * ER;
+    const int dc = g.kd + g.dv, K0 = H * dc;
+    const int c1 = wave * 16 + l15;
+    // ---- requested first: MLP operands; candidate records and their value channels
+    float bv1[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) bv1[e] = (4 * kq + e < K0) ? g.w1[(long)c1 * K0 + 4 * kq + e] : 0.0f;
+    float4 w2v[S2];
+#pragma unroll
+    for (int s = 0; s < S2; ++s) w2v[s] = *reinterpret_cast<const float4*>(g.w2 + (long)c1 * D + 16 * s + 4 * kq);
+    const float bias1 = g.b1[c1], bias2 = g.b2[c1];
+    EncCand cd[ER / NW];
+    enc_gather<NW>(g, b, slab, wave, lane, cd);
+    float st_k[ER / NW], st_k1[ER / NW], st_min[ER / NW];
+#pragma unroll
+    for (int ps = 0; ps < ER / NW; ++ps) {
+        const int n = slab * ER + ps * NW + wave, nn = n < p.n_out ? n : p.n_out - 1;
+        st_k[ps] = p.stats[nn]; st_k1[ps] = p.stats[p.n_out + nn]; st_min[ps] = p.stats[2 * (long)p.n_out + nn];
+    }
+    for (int e = tid; e < ER * XP; e += NT) xs[e] = 0.0f;
+    float c[H];
+    head_scales<H>(g.head, g.head_is_scale, c);
+    __syncthreads();
+    // ---- down-projection: one row per wave and pass
+#pragma unroll
+    for (int ps = 0; ps < ER / NW; ++ps) {
+        const int row_l = ps * NW + wave, n = slab * ER + row_l;
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+            const float T = quantile_lerp(__fmul_rn(c[h], st_k[ps]), __fmul_rn(c[h], st_k1[ps]), p.rank_w);
+            const float smin = __fmul_rn(c[h], st_min[ps]);
+            const float sv = __fmul_rn(cd[ps].m, c[h]);
+            const bool keep = cd[ps].valid && sv <= T;
+            const float pv = keep ? __expf(smin - sv) : 0.0f;
+            const float rs = wave_sum(pv), qsum = wave_sum(pv * cd[ps].m);
+            const float inv = rs > 0.0f ? 1.0f / rs : 0.0f;
+#pragma unroll
+            for (int cc = 0; cc < EC; ++cc) {
+                if (cc >= dc) break;
+                const float o = wave_sum(pv * cd[ps].v[cc]) * inv;
+                if (lane == 0) {
+                    xs[row_l * XP + h * dc + cc] = o;
+                    if (g.x && n < p.n_out) g.x[(row0 + row_l) * K0 + h * dc + cc] = o;
+                }
+            }
+            if (lane == 0 && n < p.n_out && b == 0 && g.rowstat) {
+                float4 st; st.x = T; st.y = smin; st.z = inv; st.w = qsum * inv;
+                *reinterpret_cast<float4*>(g.rowstat + ((long)h * p.n_out + n) * 4) = st;
+                if (n == 0 && g.scale_out) g.scale_out[h] = c[h];
+            }
+        }
+    }
+    __syncthreads();
+    // ---- encoder MLP (pit.py:110-111): one 16-k step for the first layer (K0 <= 16)
+    {
+        const float4 a = *reinterpret_cast<const float4*>(xs + l15 * XP + 4 * kq);
+        f32x4_t a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+        a0 = mfma_16x16x4(a.x, bv1[0], a0);
+        a1 = mfma_16x16x4(a.y, bv1[1], a1);
+        a0 = mfma_16x16x4(a.z, bv1[2], a0);
+        a1 = mfma_16x16x4(a.w, bv1[3], a1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = 4 * kq + i;
+            const float z = a0[i] + a1[i] + bias1;
+            const float hv = gelu_erf(z);
+            hs[r * HP + c1] = hv;
+            if (g.z1 && slab * ER + r < p.n_out) {
+                g.z1[(row0 + r) * D + c1] = z;
+                g.h[(row0 + r) * D + c1] = hv;
+            }
+        }
+    }
+    __syncthreads();
+    f32x4_t o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < S2; ++s) {
+        const float4 a = *reinterpret_cast<const float4*>(hs + l15 * HP + 16 * s + 4 * kq);
+        o0 = mfma_16x16x4(a.x, w2v[s].x, o0);
+        o1 = mfma_16x16x4(a.y, w2v[s].y, o1);
+        o0 = mfma_16x16x4(a.z, w2v[s].z, o0);
+        o1 = mfma_16x16x4(a.w, w2v[s].w, o1);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = 4 * kq + i;
+        if (slab * ER + r >= p.n_out) continue;
+        const float v = o0[i] + o1[i] + bias2;
+        if (g.z2) g.z2[(row0 + r) * D + c1] = v;
+        g.y[(row0 + r) * g.ldy + c1] = gelu_erf(v);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ encoder backward
+template <int H, int D>
+__global__ __launch_bounds__(4 * D) void encoder_bwd_kernel(EncArgs g) {
+    constexpr int NT = 4 * D, NW = D / 16, S = D / 16, P1 = D + 4, XP = 20;
+    __shared__ __attribute__((aligned(16))) float ds2[ER * P1];
+    __shared__ __attribute__((aligned(16))) float ds1[ER * P1];
+    __shared__ __attribute__((aligned(16))) float dxs[ER * XP];
+    __shared__ double wred[NW * H];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, kq = lane >> 4;
+    const pit_slab_plan& p = g.p;
+    int b, slab;
+    if (!slab_of_xcd(blockIdx.x, g.batch, p.n_slabs, b, slab)) return;
+    const long row0 = (long)b * p.n_out + slab * ER;
+    const long rows = (long)g.batch * p.n_out;
+    const int dc = g.kd + g.dv, K0 = H * dc;
+    const int c1 = wave * 16 + l15;
+    // ---- requested first: W2 (B(k, n) = w2[k][n]) and W1 (B(k, n) = w1[k][n], n < K0: wave 0) fragments, gelu' arguments, d_y
+    float w2v[S][4], w1x[S][4];
+#pragma unroll
+    for (int s = 0; s < S; ++s)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int k = 16 * s + 4 * kq + e;
+            w2v[s][e] = g.w2[(long)k * D + c1];
+            w1x[s][e] = (wave == 0 && l15 < K0) ? g.w1[(long)k * K0 + l15] : 0.0f;
+        }
+    float z1v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) z1v[i] = slab * ER + 4 * kq + i < p.n_out ? g.z1[(row0 + 4 * kq + i) * D + c1] : 0.0f;
+    float dyv[4], z2v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int e = tid + u * NT, r = e / D, cc = e % D;
+        const bool ok = slab * ER + r < p.n_out;
+        dyv[u] = ok ? g.d_y[(row0 + r) * g.ld_dy + cc] : 0.0f;
+        z2v[u] = ok ? g.z2[(row0 + r) * D + cc] : 0.0f;
+    }
+    EncCand cd[ER / NW];
+    float4 rs4[ER / NW][H];
+    if (g.dscale) {
+        enc_gather<NW>(g, b, slab, wave, lane, cd);
+#pragma unroll
+        for (int ps = 0; ps < ER / NW; ++ps) {
+            const int n = slab * ER + ps * NW + wave, nn = n < p.n_out ? n : p.n_out - 1;
+#pragma unroll
+            for (int h = 0; h < H; ++h) rs4[ps][h] = *reinterpret_cast<const float4*>(g.rowstat + ((long)h * p.n_out + nn) * 4);
+        }
+    }
+    // ---- dZ2 = dY * gelu'(Z2)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int e = tid + u * NT, r = e / D, cc = e % D;
+        const float v = dyv[u] * gelu_erf_grad(z2v[u]);
+        ds2[r * P1 + cc] = v;
+        if (slab * ER + r < p.n_out) g.scratch[rows * D + (row0 + r) * D + cc] = v;
+    }
+    for (int e = tid; e < ER * XP; e += NT) dxs[e] = 0.0f;
+    __syncthreads();
+    // ---- dZ1 = (dZ2 W2) * gelu'(Z1)
+    {
+        f32x4_t a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const float4 a = *reinterpret_cast<const float4*>(ds2 + l15 * P1 + 16 * s + 4 * kq);
+            a0 = mfma_16x16x4(a.x, w2v[s][0], a0);
+            a1 = mfma_16x16x4(a.y, w2v[s][1], a1);
+            a0 = mfma_16x16x4(a.z, w2v[s][2], a0);
+            a1 = mfma_16x16x4(a.w, w2v[s][3], a1);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = 4 * kq + i;
+            const float v = (a0[i] + a1[i]) * gelu_erf_grad(z1v[i]);
+            ds1[r * P1 + c1] = v;
+            if (slab * ER + r < p.n_out) g.scratch[(row0 + r) * D + c1] = v;
+        }
+    }
+    __syncthreads();
+    if (!g.dscale) return;
+    // ---- dX = dZ1 W1 (16 x K0 <= 16 columns): one tile, wave 0
+    if (wave == 0) {
+        f32x4_t o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const float4 a = *reinterpret_cast<const float4*>(ds1 + l15 * P1 + 16 * s + 4 * kq);
+            o0 = mfma_16x16x4(a.x, w1x[s][0], o0);
+            o1 = mfma_16x16x4(a.y, w1x[s][1], o1);
+            o0 = mfma_16x16x4(a.z, w1x[s][2], o0);
+            o1 = mfma_16x16x4(a.w, w1x[s][3], o1);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dxs[(4 * kq + i) * XP + l15] = o0[i] + o1[i];
+    }
+    __syncthreads();
+    // ---- d(scale) of the down-projection: dc_h -= sum_{row, cc} dX[row, h*dc + cc] * sum_j Q_h[row, j] V[j, cc]
+    double part[H];
+#pragma unroll
+    for (int h = 0; h < H; ++h) part[h] = 0.0;
+#pragma unroll
+    for (int ps = 0; ps < ER / NW; ++ps) {
+        const int row_l = ps * NW + wave;
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+            const float sv = __fmul_rn(cd[ps].m, g.head[h]);
+            const bool keep = cd[ps].valid && sv <= rs4[ps][h].x;
+            const float qv = keep ? __expf(rs4[ps][h].y - sv) * rs4[ps][h].z * (cd[ps].m - rs4[ps][h].w) : 0.0f;
+            float dot = 0.0f;
+#pragma unroll
+            for (int cc = 0; cc < EC; ++cc) {
+                if (cc >= dc) break;
+                dot += cd[ps].v[cc] * dxs[row_l * XP + h * dc + cc];
+            }
+            part[h] += (double)qv * (double)dot;
+        }
+    }
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+        const double s = wave_sum_d(part[h]);
+        if (lane == 0) wred[wave * H + h] = s;
+    }
+    __syncthreads();
+    if (tid < H) {
+        double tot = 0.0;
+        for (int w = 0; w < NW; ++w) tot += wred[w * H + tid];
+        atomicAdd(g.dscale + (long)tid * PIT_DSCALE_SLOTS + ((int)blockIdx.x & (PIT_DSCALE_SLOTS - 1)), -tot);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+bool plan_ok(const pit_slab_plan* p, bool needs_union) {
+    if (!p || !p->stats || !p->idx || !p->cnt || !p->m) return false;
+    if (p->n_out <= 0 || p->n_in <= 0 || p->cap <= 0 || p->cap > 64 || p->n_slabs != (p->n_out + ER - 1) / ER) return false;
+    if (needs_union && (!p->slot || !p->keys || !p->nkeys || p->umax != EU)) return false;
+    return true;
+}
+bool hid_ok(int n_head, int dim) { return (n_head == 1 || n_head == 2) && (dim == 32 || dim == 64); }
+
+template <int H, int D>
+constexpr size_t dec_fwd_smem() { return (size_t)(H * ER * EUP + EU * (D + 4) + ER * (H * D + 4) + ER * (D + 4) + 4 * D + 4 + EU) * 4; }
+template <int H, int D>
+constexpr size_t dec_bwd_smem() {
+    return (size_t)(EU * PTP + H * ER * EUP + EU * (D + 4) + ER * (D + 4) + ER * (H * D + 4) + 4 * D + ER * 4) * 4 + (size_t)(D / 16) * H * 8 +
+           8 * 4 + EU * 4;
+}
+
+}  // namespace
+
+extern "C" int pit_edge_supported(int n_head, int dim, int batch, int rows_per_sample) {
+    if (!hid_ok(n_head, dim) || batch <= 0 || rows_per_sample <= 0) return 0;
+    const long rows = (long)batch * rows_per_sample;
+    return rows >= 256 && rows <= 32768;                // the latency regime; above it the per-layer kernels stream at the HBM rate
+}
+
+extern "C" int pit_slab_plan_build(const float* mesh_out, const float* mesh_in, int n_out, int n_in, int space_dim, int metric,
+                                   float period, const int* nbr_idx, const int* nbr_cnt, int cap, float* m, unsigned short* slot,
+                                   int* keys, int* nkeys, int* report, void* stream) {
+    if (!mesh_out || !mesh_in || !nbr_idx || !nbr_cnt || !m || !slot || !keys || !nkeys || !report) return PIT_ERR_NULL;
+    if (n_out <= 0 || n_in <= 0 || n_in > 16384 || space_dim < 1 || space_dim > 3 || cap <= 0) return PIT_ERR_SIZE;
+    if (metric < PIT_METRIC_EUCLID || metric > PIT_METRIC_PERIODIC2D) return PIT_ERR_METRIC;
+    SlabBuildArgs a;
+    a.mesh_out = mesh_out; a.mesh_in = mesh_in; a.n_out = n_out; a.n_in = n_in; a.sdim = space_dim;
+    a.used = (metric == PIT_METRIC_PERIODIC1D) ? 1 : space_dim;
+    a.periodic = metric != PIT_METRIC_EUCLID; a.period = period;
+    a.idx = nbr_idx; a.cnt = nbr_cnt; a.cap = cap; a.umax = EU;
+    a.m = m; a.slot = slot; a.keys = keys; a.nkeys = nkeys; a.report = report;
+    hipLaunchKernelGGL(slab_plan_kernel, dim3((unsigned)((n_out + ER - 1) / ER)), dim3(256), 0, (hipStream_t)stream, a);
+    PIT_CHECK_LAUNCH();
+    return 0;
+}
+
+#define PIT_EDGE_DISPATCH(H_, D_, CALL_)                                         \
+    do {                                                                         \
+        if ((H_) == 1 && (D_) == 32) { CALL_(1, 32); }                           \
+        else if ((H_) == 1) { CALL_(1, 64); }                                    \
+        else if ((D_) == 32) { CALL_(2, 32); }                                   \
+        else { CALL_(2, 64); }                                                   \
+    } while (0)
+
+extern "C" int pit_decoder_fwd(const pit_slab_plan* plan, const float* values, long ld_values, long values_bstride, int batch,
+                               int n_head, int dim, const float* head, int head_is_scale,
+                               const float* w1, const float* b1, const float* w2, const float* b2, int n2,
+                               float* x, float* z1, float* h, float* y, float* rowstat, float* scale_out,
+                               float* zero_buf, long zero_n,
+                               const float* loss_true, const float* loss_scale, const float* loss_shift, int loss_p, double* loss_part,
+                               void* stream) {
+    if (!plan_ok(plan, true) || !values || !head || !w1 || !b1 || !w2 || !b2 || !y) return PIT_ERR_NULL;
+    if (!hid_ok(n_head, dim) || n2 < 1 || n2 > 4 || batch <= 0) return PIT_ERR_UNSUPPORTED;
+    if ((z1 == nullptr) != (h == nullptr)) return PIT_ERR_NULL;
+    if (ld_values % 4 || values_bstride % 4 || !aligned16(values) || !aligned16(w1) || (zero_buf && !aligned16(zero_buf))) return PIT_ERR_SIZE;
+    if (loss_part && (!loss_true || (loss_p != 1 && loss_p != 2) || (loss_scale == nullptr) != (loss_shift == nullptr))) return PIT_ERR_UNSUPPORTED;
+    DecFwdArgs g;
+    g.p = *plan; g.values = values; g.ld_values = ld_values; g.values_bstride = values_bstride; g.batch = batch;
+    g.head = head; g.head_is_scale = head_is_scale; g.w1 = w1; g.b1 = b1; g.w2 = w2; g.b2 = b2; g.n2 = n2;
+    g.x = x; g.z1 = z1; g.h = h; g.y = y; g.rowstat = rowstat; g.scale_out = scale_out; g.zero_buf = zero_buf; g.zero_n = zero_buf ? zero_n : 0;
+    g.tru = loss_true; g.lscale = loss_scale; g.lshift = loss_shift; g.loss_p = loss_p; g.lpart = loss_part;
+    const dim3 grid((unsigned)slab_grid(batch, plan->n_slabs));
+    hipStream_t s = (hipStream_t)stream;
+#define PIT_DF(H_, D_)                                                                                                    \
+    do {                                                                                                                  \
+        if (plan->cap <= 32) hipLaunchKernelGGL((decoder_fwd_kernel<H_, D_, 32>), grid, dim3(4 * D_), (dec_fwd_smem<H_, D_>()), s, g); \
+        else hipLaunchKernelGGL((decoder_fwd_kernel<H_, D_, 64>), grid, dim3(4 * D_), (dec_fwd_smem<H_, D_>()), s, g);       \
+    } while (0)
+    PIT_EDGE_DISPATCH(n_head, dim, PIT_DF);
+#undef PIT_DF
+    PIT_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pit_decoder_bwd(const pit_slab_plan* plan, const float* values, long ld_values, long values_bstride, int batch,
+                               int n_head, int dim, const float* scale, const float* rowstat,
+                               const float* w1, const float* w2, int n2, const float* z1,
+                               const float* d_y, long ld_dy, float* dz1, float* d_values, long dvalues_bstride, double* dscale,
+                               const float* loss_pred, const float* loss_true, const float* loss_scale, const float* loss_shift,
+                               const float* loss_seed, int loss_p, const double* loss_part, float* d_pred, float* loss_out,
+                               float* norms_out, void* stream) {
+    if (!plan_ok(plan, true) || !values || !scale || !rowstat || !w1 || !w2 || !z1 || !dz1 || !d_values) return PIT_ERR_NULL;
+    if (!hid_ok(n_head, dim) || n2 < 1 || n2 > 4 || batch <= 0) return PIT_ERR_UNSUPPORTED;
+    if (!d_y && (!loss_pred || !loss_true || !loss_part || !d_pred || !loss_out || (loss_p != 1 && loss_p != 2) ||
+                 (loss_scale == nullptr) != (loss_shift == nullptr))) return PIT_ERR_NULL;
+    if (d_y && ld_dy < n2) return PIT_ERR_SIZE;
+    if (ld_values % 4 || values_bstride % 4 || !aligned16(values) || !aligned16(rowstat)) return PIT_ERR_SIZE;
+    DecBwdArgs g;
+    g.p = *plan; g.values = values; g.ld_values = ld_values; g.values_bstride = values_bstride; g.batch = batch;
+    g.scale = scale; g.rowstat = rowstat; g.w1 = w1; g.w2 = w2; g.n2 = n2; g.z1 = z1; g.d_y = d_y; g.ld_dy = ld_dy;
+    g.dz1 = dz1; g.d_values = d_values; g.dvalues_bstride = dvalues_bstride; g.dscale = dscale;
+    g.pred = loss_pred; g.tru = loss_true; g.lscale = loss_scale; g.lshift = loss_shift; g.gseed = loss_seed; g.loss_p = loss_p;
+    g.lpart = loss_part; g.d_pred = d_pred; g.loss_out = loss_out; g.norms_out = norms_out;
+    const dim3 grid((unsigned)slab_grid(batch, plan->n_slabs));
+    hipStream_t s = (hipStream_t)stream;
+#define PIT_DB(H_, D_)                                                                                                    \
+    do {                                                                                                                  \
+        if (plan->cap <= 32) hipLaunchKernelGGL((decoder_bwd_kernel<H_, D_, 32>), grid, dim3(4 * D_), (dec_bwd_smem<H_, D_>()), s, g); \
+        else hipLaunchKernelGGL((decoder_bwd_kernel<H_, D_, 64>), grid, dim3(4 * D_), (dec_bwd_smem<H_, D_>()), s, g);       \
+    } while (0)
+    PIT_EDGE_DISPATCH(n_head, dim, PIT_DB);
+#undef PIT_DB
+    PIT_CHECK_LAUNCH();
+    return 0;
+}
+
+namespace {
+int fill_enc(EncArgs& g, const pit_slab_plan* plan, const float* mesh_in, int space_dim, int coord_dims, const float* values,
+             long ld_values, long values_bstride, int dv, int batch, int n_head, int dim) {
+    if (!plan_ok(plan, false) || !mesh_in || !values) return PIT_ERR_NULL;
+    if (!hid_ok(n_head, dim) || batch <= 0 || space_dim < 1 || space_dim > 3 || coord_dims < 0 || coord_dims > space_dim || dv < 0 ||
+        coord_dims + dv < 1 || coord_dims + dv > EC || n_head * (coord_dims + dv) > 16) return PIT_ERR_UNSUPPORTED;
+    g = EncArgs();
+    g.p = *plan; g.mesh_in = mesh_in; g.sdim = space_dim; g.kd = coord_dims; g.values = values; g.ld_values = ld_values;
+    g.values_bstride = values_bstride; g.dv = dv; g.batch = batch;
+    return 0;
+}
+}  // namespace
+
+extern "C" int pit_encoder_fwd(const pit_slab_plan* plan, const float* mesh_in, int space_dim, int coord_dims,
+                               const float* values, long ld_values, long values_bstride, int value_dim, int batch,
+                               int n_head, int dim, const float* head, int head_is_scale,
+                               const float* w1, const float* b1, const float* w2, const float* b2,
+                               float* x, float* z1, float* h, float* z2, float* y, long ldy, float* rowstat, float* scale_out,
+                               float* clear_buf, long clear_n, const pit_block_weights_job* weights, void* stream) {
+    EncArgs g;
+    if (int rc = fill_enc(g, plan, mesh_in, space_dim, coord_dims, values, ld_values, values_bstride, value_dim, batch, n_head, dim)) return rc;
+    if (!head || !w1 || !b1 || !w2 || !b2 || !y) return PIT_ERR_NULL;
+    if ((z1 == nullptr) != (h == nullptr) || ldy < dim || !aligned16(w2)) return PIT_ERR_SIZE;
+    g.head = head; g.head_is_scale = head_is_scale; g.w1 = w1; g.b1 = b1; g.w2 = w2; g.b2 = b2;
+    g.x = x; g.z1 = z1; g.h = h; g.z2 = z2; g.y = y; g.ldy = ldy; g.rowstat = rowstat; g.scale_out = scale_out;
+    g.clear_buf = clear_n > 0 ? clear_buf : nullptr; g.clear_n = clear_n;
+    g.n_att = slab_grid(batch, plan->n_slabs);
+    WeightsArgs wa = WeightsArgs();
+    int n_w = 0;
+    bool own_launch = false;
+    if (weights) {
+        if (int rc = fill_weights_args(wa, weights->mesh, weights->n_pts, weights->space_dim, weights->metric, weights->period,
+                                       weights->n_layers, weights->heads, weights->head_is_scale, weights->n_head, weights->e, weights->q,
+                                       weights->inv, weights->rowstat, weights->scale_out)) return rc;
+        if (dim == 64) n_w = block_weights_wgs(wa.n_layers, wa.n_head, wa.L); else own_launch = true;
+    }
+    const dim3 grid((unsigned)(g.n_att + n_w));
+    hipStream_t s = (hipStream_t)stream;
+#define PIT_EF(H_, D_) hipLaunchKernelGGL((encoder_fwd_kernel<H_, D_>), grid, dim3(4 * D_), 0, s, g, wa)
+    PIT_EDGE_DISPATCH(n_head, dim, PIT_EF);
+#undef PIT_EF
+    PIT_CHECK_LAUNCH();
+    if (own_launch)
+        return pit_block_weights(weights->mesh, weights->n_pts, weights->space_dim, weights->metric, weights->period, weights->n_layers,
+                                 weights->heads, weights->head_is_scale, weights->n_head, weights->e, weights->q, weights->inv,
+                                 weights->rowstat, weights->scale_out, stream);
+    return 0;
+}
+
+extern "C" int pit_encoder_bwd(const pit_slab_plan* plan, const float* mesh_in, int space_dim, int coord_dims,
+                               const float* values, long ld_values, long values_bstride, int value_dim, int batch,
+                               int n_head, int dim, const float* scale, const float* rowstat,
+                               const float* w1, const float* w2, const float* z1, const float* z2,
+                               const float* d_y, long ld_dy, float* scratch, double* dscale, void* stream) {
+    EncArgs g;
+    if (int rc = fill_enc(g, plan, mesh_in, space_dim, coord_dims, values, ld_values, values_bstride, value_dim, batch, n_head, dim)) return rc;
+    if (!w1 || !w2 || !z1 || !z2 || !d_y || !scratch) return PIT_ERR_NULL;
+    if (dscale && (!scale || !rowstat || !aligned16(rowstat))) return PIT_ERR_NULL;
+    if (ld_dy < dim) return PIT_ERR_SIZE;
+    g.head = scale; g.head_is_scale = 1; g.rowstat = const_cast<float*>(rowstat); g.w1 = w1; g.w2 = w2;
+    g.z1 = const_cast<float*>(z1); g.z2 = const_cast<float*>(z2); g.d_y = d_y; g.ld_dy = ld_dy; g.scratch = scratch; g.dscale = dscale;
+    const dim3 grid((unsigned)slab_grid(batch, plan->n_slabs));
+    hipStream_t s = (hipStream_t)stream;
+#define PIT_EB(H_, D_) hipLaunchKernelGGL((encoder_bwd_kernel<H_, D_>), grid, dim3(4 * D_), 0, s, g)
+    PIT_EDGE_DISPATCH(n_head, dim, PIT_EB);
+#undef PIT_EB
+    PIT_CHECK_LAUNCH();
+    return 0;
+}

@@ -112,17 +112,21 @@ class TrainStep:
         self._early_pending = False
         early = self.buckets == 2 and self.all_reduce and self._tail_in_place()    # (else: ONE all-reduce after the pass)
         self._early_ok = early
-        # per-thread state, read by the autograd nodes in their forward (ops._STEP)
-        with ops.step_state(processor_hook=(self._on_processor_block, self._early_block) if early else None):
-            self._step_body()
-
-    def _step_body(self) -> None:
-        out = self.model(self.mesh_in, self.func_in, self.mesh_out)
         sc, sh = self.affine if self.affine is not None else (None, None)
-        # the loss launch also writes its own gradient for the seed of ones below and clears the flat
-        # gradient accumulators (unless FlatAdam(zero_grads=True) already did): no loss-backward launch,
-        # no memset launch
+        # the flat gradient accumulators are cleared on the way by the step's first fused launch (ops.encoder_apply) or by
+        # the loss launch (unless FlatAdam(zero_grads=True) already did): no memset launch
         clear = None if getattr(self.optimizer, "zero_grads", False) else self.flat.flat
+        # the loss the step applies to the prediction: a fused decoder accumulates its partial sums in the forward launch and
+        # forms d(pred) in the backward launch - no loss launch (ops.LossSpec; any other model runs the loss kernel below)
+        spec = ops.LossSpec(self.target, sc, sh, self.out_dim, self.p) if self.p in (1, 2) and ops.EDGE_FUSION else None
+        # per-thread state, read by the autograd nodes in their forward (ops._STEP)
+        with ops.step_state(processor_hook=(self._on_processor_block, self._early_block) if early else None, loss=spec, clear=clear):
+            self._step_body(sc, sh)
+
+    def _step_body(self, sc, sh) -> None:
+        out = self.model(self.mesh_in, self.func_in, self.mesh_out)
+        clear = ops.take_pending_clear()         # None when a launch of the forward already zeroed the buffer
+        # the loss launch also writes its own gradient for the seed of ones below: no loss-backward launch
         loss = ops.rel_lp_loss(self.target, out, self.out_dim, self.p, sc, sh, unit_seed=self._seed, clear=clear)
         torch.autograd.backward(loss, grad_tensors=self._seed)        # no ones_like fill per step
         self.loss = loss.detach()            # same storage every replay (graph-private pool): no copy

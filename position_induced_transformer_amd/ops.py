@@ -176,17 +176,29 @@ def _processor_hook():
 class step_state:
     """Context manager: per-thread overrides for the autograd nodes built inside it (engine.TrainStep._step)."""
 
-    def __init__(self, processor_hook=None):
-        self.new = processor_hook
+    def __init__(self, processor_hook=None, loss=None, clear=None):
+        """``loss``: a LossSpec the step will apply to the model's prediction (the fused decoder takes it); ``clear``: a contiguous
+        fp32 tensor the step wants zeroed before its backward (the flat gradient buffer: the fused encoder launch clears it on
+        the way).  Whoever takes either resets it to None; what is left when the forward returns is the caller's to do."""
+        self.new = (processor_hook, loss, clear)
 
     def __enter__(self):
-        self.old = getattr(_STEP, "processor_hook", None)
-        _STEP.processor_hook = self.new
+        self.old = (getattr(_STEP, "processor_hook", None), getattr(_STEP, "loss", None), getattr(_STEP, "clear", None),
+                    getattr(_STEP, "loss_issued", None))
+        _STEP.processor_hook, _STEP.loss, _STEP.clear = self.new
+        _STEP.loss_issued = None
         return self
 
     def __exit__(self, *exc):
-        _STEP.processor_hook = self.old
+        _STEP.processor_hook, _STEP.loss, _STEP.clear, _STEP.loss_issued = self.old
         return False
+
+
+def take_pending_clear():
+    """The buffer step_state(clear=...) asked to have zeroed, if no launch of the forward took it (then the caller zeroes it)."""
+    t = getattr(_STEP, "clear", None)
+    _STEP.clear = None
+    return t
 
 
 _PENDING_DW = {}          # graph-task id -> job = (MlpParamsJob, keep-alive tensors, stream it was prepared on) or None
@@ -349,6 +361,7 @@ def mesh_period(metric: str, mesh_in: torch.Tensor) -> float:
     return 0.0
 
 
+SLAB_UNION_MAX = 64                                          # PIT_SLAB_UNION_MAX
 PLAN_FLAGS = 0                                               # pit_plan_fwd's `flags` (tests: 1 = PIT_PLAN_WAVE_PER_ROW, 2 = PIT_PLAN_TWO_PASSES)
 UNION_TILES = os.environ.get("PIT_UNION_TILES", "auto")      # "auto" (probe per kind of plan), "0", "1"
 UNION_DV = os.environ.get("PIT_UNION_DV", "auto")            # d(values) of union-tile layers: "auto", "lists" (transposed lists)
@@ -363,7 +376,7 @@ class MeshPlan:
 
     __slots__ = ("mesh_out", "mesh_in", "mesh_batch", "n_out", "n_in", "sdim", "metric", "metric_id", "period",
                  "rank_k", "rank_w", "masked", "self_attn", "stats", "nbr_idx", "nbr_cnt", "nbr_cap", "rev_ptr",
-                 "rev_row", "_complete", "_union")
+                 "rev_row", "_complete", "_union", "_slab")
 
     def __init__(self, metric: str, mesh_out: torch.Tensor, mesh_in: torch.Tensor, locality: float,
                  self_attn: bool, period: Optional[float] = None):
@@ -396,6 +409,7 @@ class MeshPlan:
         self.nbr_cap = 0
         self._complete = None
         self._union = None
+        self._slab = None
         cap = 0
         if self.masked and SPARSE_MASKED:
             want = self.rank_k + 2
@@ -477,6 +491,41 @@ class MeshPlan:
             _UNION_DECISIONS[key] = hit
         self._union = hit
         return hit
+
+    def slab_plan(self):
+        """Round 5: the static per-slab plan of this (fixed) mesh pair for the fused encoder- / decoder-side launches
+        (csrc/pit_edge.hip; include/pit_hip.h: pit_slab_plan) as (struct, largest union of a 16-row slab's candidate keys), or
+        None: per-sample meshes, no candidate lists, a list that overflowed its capacity.  Built once per plan - the meshes are
+        batch-free and cached - with one host read of two ints; never under stream capture (a plan first seen there keeps the
+        per-layer kernels)."""
+        if self._slab is not None:
+            return self._slab or None
+        if self.nbr_idx is None or self.mesh_batch != 1 or not self.masked or self.n_in > 16384 or self.nbr_cap > 64:
+            self._slab = False
+            return None
+        if torch.cuda.is_current_stream_capturing():
+            return None
+        dev = self.mesh_out.device
+        n_slabs = (self.n_out + 15) // 16
+        m = torch.empty((n_slabs * 16, self.nbr_cap), device=dev, dtype=torch.float32)
+        slot = torch.empty((n_slabs * 16, self.nbr_cap), device=dev, dtype=torch.int16)
+        keys = torch.empty((n_slabs, SLAB_UNION_MAX), device=dev, dtype=torch.int32)
+        nkeys = torch.empty((n_slabs,), device=dev, dtype=torch.int32)
+        report = torch.zeros((2,), device=dev, dtype=torch.int32)
+        rc = _lib.lib().pit_slab_plan_build(self.mesh_out.data_ptr(), self.mesh_in.data_ptr(), self.n_out, self.n_in, self.sdim,
+                                            self.metric_id, self.period, self.nbr_idx.data_ptr(), self.nbr_cnt.data_ptr(),
+                                            self.nbr_cap, m.data_ptr(), slot.data_ptr(), keys.data_ptr(), nkeys.data_ptr(),
+                                            report.data_ptr(), _lib.stream_ptr())
+        _lib.check(rc, "pit_slab_plan_build")
+        max_union, overflowed = report.tolist()
+        if overflowed:
+            self._slab = False
+            return None
+        sp = _lib.SlabPlan(self.n_out, self.n_in, self.nbr_cap, n_slabs, SLAB_UNION_MAX, self.stats.data_ptr(), self.rank_w,
+                           self.nbr_idx.data_ptr(), self.nbr_cnt.data_ptr(), m.data_ptr(), slot.data_ptr(), keys.data_ptr(),
+                           nkeys.data_ptr())
+        self._slab = (sp, int(max_union), (m, slot, keys, nkeys))
+        return self._slab
 
     def lists_complete(self) -> int:
         """1 if no row's candidate list overflowed its capacity (checked once, for batch-free meshes
@@ -1062,6 +1111,12 @@ class EarlyWeights:
             _lib.check(rc, "pit_block_weights")
 
 
+def drop_forward_job(early) -> None:
+    """Disarm ``early`` if no launch took it (pit.encoder's finally: a forward that raised leaves nothing pending on the thread)."""
+    if early is not None and getattr(_STEP, "fwd_job", None) is early:
+        _STEP.fwd_job = None
+
+
 def _weights_key(plan: MeshPlan, lmdas, scales, n_head: int):
     return (id(plan), n_head, _PARAM_EPOCH[0], scales is not None,
             tuple((p._version, p.data_ptr()) for p in lmdas), tuple(t.data_ptr() for t in scales) if scales is not None else None)
@@ -1285,6 +1340,321 @@ def processor_apply(x: torch.Tensor, plan: MeshPlan, n_head: int, lmdas, mlps, e
     return _Processor.apply(x, plan, n_head, scales, (tuple(lmdas), tuple(tuple(m) for m in mlps)), early, *flat)
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# Round 5: the encoder side (pit.py:108-112) and the decoder side (pit.py:124-127) of a small-regime model on batch-free
+# meshes as ONE launch per direction each (csrc/pit_edge.hip), on the static slab plan of the mesh pair.
+EDGE_FUSION = os.environ.get("PIT_EDGE_FUSION", "1") != "0"
+
+
+def edge_fusion_supported(plan: MeshPlan, n_head: int, dim: int, batch: int, needs_union: bool) -> bool:
+    """The fused encoder- / decoder-side launch covers this layer: a masked cross-attention on a batch-free mesh pair with
+    complete candidate lists (and, for the decoder, unions of at most 64 keys per 16-row slab), 1-2 heads, hidden width 32 / 64,
+    in the latency regime."""
+    if not EDGE_FUSION or plan.mesh_batch != 1 or plan.self_attn or not plan.masked or plan.nbr_idx is None:
+        return False
+    if not _lib.lib().pit_edge_supported(int(n_head), int(dim), int(batch), int(plan.n_out)):
+        return False
+    sp = plan.slab_plan()
+    return sp is not None and (not needs_union or sp[1] <= SLAB_UNION_MAX)
+
+
+def _finish_heads_now(work, d_head, head, scale, n_head: int, flags: int) -> None:
+    """d(lmda) of ONE layer from freshly loaded accumulators, now (the gradient is returned to autograd, not accumulated in place)."""
+    one = lambda t: (ctypes.c_void_p * 1)(_lib.ptr(t))
+    rc = _lib.lib().pit_posatt_dhead_finish(1, one(work), one(d_head), one(head), one(scale), (ctypes.c_int * 1)(n_head),
+                                            (ctypes.c_int * 1)(flags), _lib.stream_ptr())
+    _lib.check(rc, "pit_posatt_dhead_finish")
+
+
+def _mlp_grad_slots(params, shapes, needs, device):
+    """([d_w1, d_b1, d_w2, d_b2], in place?) for an MLP's weight gradients: the parameters' own .grad (the kernels accumulate) when
+    every one of them opted in, else fresh ZEROED tensors returned to autograd."""
+    slots = [_grad_slot(p) if isinstance(p, torch.nn.Parameter) else None for p in params]
+    if all(s is not None for s in slots) and all(needs):
+        return slots, True
+    return [torch.zeros(tuple(sh), device=device, dtype=torch.float32) for sh in shapes], False
+
+
+class LossSpec:
+    """The RelLp loss a training step will apply to the model's prediction (engine.TrainStep sets it in step_state): the fused
+    decoder forward accumulates the loss's partial sums in its epilogue, the decoder backward forms d(pred) from them - the step
+    then has no loss launch.  ``true`` (b, npts, out_dim) contiguous, ``scale`` / ``shift`` (npts, out_dim) or None, p in {1, 2}."""
+    __slots__ = ("true", "scale", "shift", "p", "out_dim", "seed", "partials", "pred", "token", "value")
+
+    def __init__(self, true, scale, shift, out_dim: int, p: int, seed=None):
+        b = true.size(0)
+        self.true = true.reshape(b, -1, out_dim).contiguous()
+        npts = self.true.shape[1]
+        self.scale = scale.reshape(npts, out_dim).contiguous() if scale is not None else None
+        self.shift = shift.reshape(npts, out_dim).contiguous() if shift is not None else None
+        self.p, self.out_dim, self.seed = int(p), int(out_dim), seed
+        self.partials = self.pred = self.token = self.value = None
+
+    def fits(self, batch: int, npts: int, n2: int) -> bool:
+        return self.p in (1, 2) and n2 == self.out_dim and tuple(self.true.shape) == (batch, npts, n2) and not self.true.requires_grad
+
+
+class _Decoder(torch.autograd.Function):
+    """pit.decoder (pit.py:124-127): posatt_cross_* (mesh_ltt -> mesh_out) followed by the thin-output kaiming_mlp `de`."""
+
+    @staticmethod
+    def forward(ctx, values, head, plan: MeshPlan, n_head: int, head_is_scale: bool, head_param, scale_in, params, loss, w1, b1, w2, b2):
+        _need_gpu(values, head, w1, b1, w2, b2)
+        values = _row_view(values)
+        if values.stride(1) % 4 or values.stride(0) % 4 or values.data_ptr() % 16:
+            values = values.contiguous()
+        b, j, d = values.shape
+        n2 = w2.shape[0]
+        dev = values.device
+        sp = plan.slab_plan()[0]
+        head = head.detach().reshape(-1).contiguous()
+        k_head, k_is_scale = (scale_in, True) if scale_in is not None else (head, head_is_scale)
+        w1c, b1c, w2c, b2c = (t.detach().contiguous() for t in (w1, b1, w2, b2))
+        rows = b * plan.n_out
+        need = any(ctx.needs_input_grad)
+        y = torch.empty((b, plan.n_out, n2), device=dev, dtype=torch.float32)
+        x = z1 = h = rowstat = scale = dvals = None
+        if need:
+            x = torch.empty((rows, n_head * d), device=dev, dtype=torch.float32)
+            z1 = torch.empty((rows, d), device=dev, dtype=torch.float32)
+            h = torch.empty((rows, d), device=dev, dtype=torch.float32)
+            rowstat = torch.empty((n_head, plan.n_out, 4), device=dev, dtype=torch.float32)
+            scale = torch.empty((n_head,), device=dev, dtype=torch.float32)
+            dvals = torch.empty((b, j, d), device=dev, dtype=torch.float32)       # zeroed by the launch, added to by the backward
+        lt = ls = lh = lpart = None
+        lp = 0
+        if loss is not None and need:
+            lt, ls, lh, lp = loss.true, loss.scale, loss.shift, loss.p
+            lpart = loss.partials = torch.empty((b, n2, sp.n_slabs, 2), device=dev, dtype=torch.float64)
+            loss.value = torch.empty((), device=dev, dtype=torch.float32)
+        rc = _lib.lib().pit_decoder_fwd(ctypes.byref(sp), values.data_ptr(), values.stride(1), values.stride(0), b, n_head, d,
+                                        k_head.data_ptr(), 1 if k_is_scale else 0, w1c.data_ptr(), b1c.data_ptr(), w2c.data_ptr(),
+                                        b2c.data_ptr(), n2, _lib.ptr(x), _lib.ptr(z1), _lib.ptr(h), y.data_ptr(), _lib.ptr(rowstat),
+                                        _lib.ptr(scale), _lib.ptr(dvals), dvals.numel() if dvals is not None else 0,
+                                        _lib.ptr(lt), _lib.ptr(ls), _lib.ptr(lh), lp, _lib.ptr(lpart), _lib.stream_ptr())
+        _lib.check(rc, "pit_decoder_fwd")
+        ctx.plan, ctx.n_head, ctx.head_is_scale, ctx.head_param, ctx.params = plan, n_head, head_is_scale, head_param, params
+        ctx.loss = loss if lpart is not None else None
+        if ctx.loss is not None:
+            loss.pred = y
+        ctx.dvals_clean = True
+        ctx.keep = (values, head, w1c, w2c, x, z1, h, rowstat, scale, dvals)
+        return y
+
+    @staticmethod
+    def backward(ctx, d_y):
+        values, head, w1, w2, x, z1, h, rowstat, scale, dvals = ctx.keep
+        plan, n_head = ctx.plan, ctx.n_head
+        b, j, d = values.shape
+        n2, rows = w2.shape[0], b * plan.n_out
+        dev = values.device
+        sp = plan.slab_plan()[0]
+        loss = ctx.loss
+        inside = loss is not None and loss.token is not None and d_y.data_ptr() == loss.token.data_ptr()
+        if loss is not None and loss.token is not None and not inside:
+            raise RuntimeError("the fused loss's gradient token reached pit.decoder's backward as a copy: the prediction must reach "
+                               "the loss through views only (engine.TrainStep)")
+        if not ctx.dvals_clean:                         # a second backward through the same node (retain_graph)
+            dvals.zero_()
+        ctx.dvals_clean = False
+        dz1 = torch.empty((rows, d), device=dev, dtype=torch.float32)
+        if inside:
+            d_pred = torch.empty((rows, n2), device=dev, dtype=torch.float32)
+            dyp, ld = None, n2
+        else:
+            d_pred = d_y.reshape(rows, n2)
+            if d_pred.stride(1) != 1 or d_pred.stride(0) < n2:
+                d_pred = d_pred.contiguous()
+            dyp, ld = d_pred, d_pred.stride(0)
+        need_h = ctx.needs_input_grad[1]
+        slot = _grad_slot(ctx.head_param) if need_h else None
+        defer = DEFER_HEAD_FINISH and slot is not None
+        work = None
+        if need_h:
+            work = _layer_workspace(slot, n_head) if defer else torch.zeros(n_head * 1024, device=dev, dtype=torch.float64)
+            if defer:
+                _defer_head_begin(work)
+        L = _lib.lib()
+        rc = L.pit_decoder_bwd(ctypes.byref(sp), values.data_ptr(), values.stride(1), values.stride(0), b, n_head, d,
+                               scale.data_ptr(), rowstat.data_ptr(), w1.data_ptr(), w2.data_ptr(), n2, z1.data_ptr(),
+                               _lib.ptr(dyp), ld, dz1.data_ptr(), dvals.data_ptr(), dvals.stride(0), _lib.ptr(work),
+                               loss.pred.data_ptr() if inside else None, _lib.ptr(loss.true) if inside else None,
+                               _lib.ptr(loss.scale) if inside else None, _lib.ptr(loss.shift) if inside else None,
+                               _lib.ptr(loss.seed) if inside else None, loss.p if inside else 0,
+                               _lib.ptr(loss.partials) if inside else None, d_pred.data_ptr() if inside else None,
+                               loss.value.data_ptr() if inside else None, None, _lib.stream_ptr())
+        _lib.check(rc, "pit_decoder_bwd")
+        d_head = None
+        if need_h:
+            flags = 1 | (4 if ctx.head_is_scale else 0)
+            if defer:
+                _defer_head_finish(work, slot, head, scale, n_head, flags)
+            else:
+                d_head = slot if slot is not None else torch.empty((n_head,), device=dev, dtype=torch.float32)
+                _finish_heads_now(work, d_head, head, scale, n_head, flags if slot is not None else flags & ~1)
+                if slot is not None:
+                    d_head = None
+        # weight gradients: the reductions over all rows are postponed and carried by a later launch of the pass (_dw_defer) in the
+        # in-place mode, performed now otherwise
+        grads, inplace = _mlp_grad_slots(ctx.params, (w1.shape, (d,), w2.shape, (n2,)), ctx.needs_input_grad[9:13], dev)
+        d_w1, d_b1, d_w2, d_b2 = grads
+        st = _lib.MlpParamsJob(x.data_ptr(), x.stride(0), rows, n_head * d, d, n2, h.data_ptr(), 0, d_pred.data_ptr(),
+                               d_pred.stride(0), d_w1.data_ptr(), d_b1.data_ptr(), d_w2.data_ptr(), d_b2.data_ptr(), 1,
+                               dz1.data_ptr(), 0)
+        keep = (x, h, d_pred, dz1, d_w1, d_b1, d_w2, d_b2)
+        if inplace and MLP_PARAMS_RIDER and _dw_deferrable(rows, n_head * d, d, n2, 0, d_pred.stride(0)):
+            _dw_defer(st, keep, dev)
+        else:
+            _dw_run((st, keep, torch.cuda.current_stream(dev)))
+        dv = dvals if ctx.needs_input_grad[0] else None
+        w = (None, None, None, None) if inplace else (d_w1, d_b1, d_w2, d_b2)
+        return (dv, d_head, None, None, None, None, None, None, None) + w
+
+
+@torch.compiler.disable
+def decoder_apply(values: torch.Tensor, lmda: torch.Tensor, plan: MeshPlan, n_head: int, mlp, head_is_scale: bool = False) -> torch.Tensor:
+    """pit.decoder (pit.py:124-127) as one launch per direction: de(posatt_cross(mesh_out, mesh_ltt, values)) with
+    ``mlp`` = de's (w1, b1, w2, b2).  The caller checked edge_fusion_supported(plan, ..., needs_union=True)."""
+    param = lmda if isinstance(lmda, torch.nn.Parameter) else None
+    c = host_head_scale(lmda) if (not head_is_scale and get_head_scale_route() == "host") else None
+    loss = getattr(_STEP, "loss", None)
+    if loss is not None:
+        _STEP.loss = None                        # (one decoder per step takes it)
+        if not loss.fits(values.shape[0], plan.n_out, mlp[2].shape[0]):
+            loss = None
+        else:
+            _STEP.loss_issued = loss
+    return _Decoder.apply(values, lmda.reshape(-1), plan, n_head, head_is_scale, param, c, tuple(mlp), loss, *mlp)
+
+
+class _Encoder(torch.autograd.Function):
+    """pit.encoder (pit.py:108-112): posatt_cross_* (mesh_in -> mesh_ltt) + kaiming_mlp `en_layer` + gelu."""
+
+    @staticmethod
+    def forward(ctx, values, head, plan: MeshPlan, n_head: int, head_is_scale: bool, head_param, scale_in, params, coord_dims: int,
+                concat_heads: int, wjob, clear, w1, b1, w2, b2):
+        _need_gpu(values, head, w1, b1, w2, b2)
+        values = _row_view(values)
+        b, j, dv = values.shape
+        d = w1.shape[0]
+        kd = int(coord_dims)
+        k0 = n_head * (kd + dv)
+        dev = values.device
+        sp = plan.slab_plan()[0]
+        head = head.detach().reshape(-1).contiguous()
+        k_head, k_is_scale = (scale_in, True) if scale_in is not None else (head, head_is_scale)
+        w1c, b1c, w2c, b2c = (t.detach().contiguous() for t in (w1, b1, w2, b2))
+        rows = b * plan.n_out
+        need = any(ctx.needs_input_grad)
+        buf = None
+        if concat_heads > 0:
+            buf = torch.empty((rows, (1 + concat_heads) * d), device=dev, dtype=torch.float32)
+            y = buf[:, :d]
+        else:
+            y = torch.empty((rows, d), device=dev, dtype=torch.float32)
+        x = z1 = h = z2 = rowstat = scale = None
+        if need:
+            x = torch.empty((rows, k0), device=dev, dtype=torch.float32)
+            z1 = torch.empty((rows, d), device=dev, dtype=torch.float32)
+            h = torch.empty((rows, d), device=dev, dtype=torch.float32)
+            z2 = torch.empty((rows, d), device=dev, dtype=torch.float32)
+            rowstat = torch.empty((n_head, plan.n_out, 4), device=dev, dtype=torch.float32)
+            scale = torch.empty((n_head,), device=dev, dtype=torch.float32)
+        rc = _lib.lib().pit_encoder_fwd(ctypes.byref(sp), plan.mesh_in.data_ptr(), plan.sdim, kd, values.data_ptr(), values.stride(1),
+                                        values.stride(0), dv, b, n_head, d, k_head.data_ptr(), 1 if k_is_scale else 0,
+                                        w1c.data_ptr(), b1c.data_ptr(), w2c.data_ptr(), b2c.data_ptr(), _lib.ptr(x), _lib.ptr(z1),
+                                        _lib.ptr(h), _lib.ptr(z2), y.data_ptr(), y.stride(0), _lib.ptr(rowstat), _lib.ptr(scale),
+                                        _lib.ptr(clear), clear.numel() if clear is not None else 0,
+                                        ctypes.cast(ctypes.pointer(wjob.job), ctypes.c_void_p) if wjob is not None else None,
+                                        _lib.stream_ptr())
+        _lib.check(rc, "pit_encoder_fwd")
+        ctx.plan, ctx.n_head, ctx.head_is_scale, ctx.head_param, ctx.params, ctx.kd = plan, n_head, head_is_scale, head_param, params, kd
+        ctx.keep = (values, head, w1c, w2c, x, z1, h, z2, rowstat, scale)
+        out = y.reshape(b, plan.n_out, d)
+        if buf is None:
+            return out
+        buf = buf.reshape(b, plan.n_out, (1 + concat_heads) * d)
+        ctx.mark_non_differentiable(buf)
+        ctx.set_materialize_grads(False)
+        return out, buf
+
+    @staticmethod
+    def backward(ctx, d_y, _d_buf=None):
+        values, head, w1, w2, x, z1, h, z2, rowstat, scale = ctx.keep
+        plan, n_head, kd = ctx.plan, ctx.n_head, ctx.kd
+        b, j, dv = values.shape
+        d, rows = w1.shape[0], b * plan.n_out
+        dev = values.device
+        sp = plan.slab_plan()[0]
+        if d_y is None:
+            d_y = torch.zeros((rows, d), device=dev, dtype=torch.float32)
+        d_y2 = d_y.reshape(rows, d)
+        if d_y2.stride(1) != 1 or d_y2.stride(0) < d:
+            d_y2 = d_y2.contiguous()
+        scratch = torch.empty((rows * 2 * d,), device=dev, dtype=torch.float32)
+        need_h = ctx.needs_input_grad[1]
+        slot = _grad_slot(ctx.head_param) if need_h else None
+        defer = DEFER_HEAD_FINISH and slot is not None
+        work = None
+        if need_h:
+            work = _layer_workspace(slot, n_head) if defer else torch.zeros(n_head * 1024, device=dev, dtype=torch.float64)
+            if defer:
+                _defer_head_begin(work)
+        rc = _lib.lib().pit_encoder_bwd(ctypes.byref(sp), plan.mesh_in.data_ptr(), plan.sdim, kd, values.data_ptr(), values.stride(1),
+                                        values.stride(0), dv, b, n_head, d, scale.data_ptr(), rowstat.data_ptr(), w1.data_ptr(),
+                                        w2.data_ptr(), z1.data_ptr(), z2.data_ptr(), d_y2.data_ptr(), d_y2.stride(0),
+                                        scratch.data_ptr(), _lib.ptr(work), _lib.stream_ptr())
+        _lib.check(rc, "pit_encoder_bwd")
+        d_head = None
+        if need_h:
+            flags = 1 | (4 if ctx.head_is_scale else 0)
+            if defer:
+                _defer_head_finish(work, slot, head, scale, n_head, flags)
+            else:
+                d_head = slot if slot is not None else torch.empty((n_head,), device=dev, dtype=torch.float32)
+                _finish_heads_now(work, d_head, head, scale, n_head, flags if slot is not None else flags & ~1)
+                if slot is not None:
+                    d_head = None
+        grads, inplace = _mlp_grad_slots(ctx.params, (w1.shape, (d,), w2.shape, (d,)), ctx.needs_input_grad[12:16], dev)
+        d_w1, d_b1, d_w2, d_b2 = grads
+        k0 = n_head * (kd + dv)
+        st = _lib.MlpParamsJob(x.data_ptr(), x.stride(0), rows, k0, d, d, h.data_ptr(), 1, d_y2.data_ptr(), d_y2.stride(0),
+                               d_w1.data_ptr(), d_b1.data_ptr(), d_w2.data_ptr(), d_b2.data_ptr(), 1, scratch.data_ptr(), 0)
+        keep = (x, h, d_y2, scratch, d_w1, d_b1, d_w2, d_b2)
+        if inplace and MLP_PARAMS_RIDER and _dw_deferrable(rows, k0, d, d, 1, d_y2.stride(0)):
+            _dw_defer(st, keep, dev)
+        else:
+            _dw_run((st, keep, torch.cuda.current_stream(dev)))
+        w = (None, None, None, None) if inplace else (d_w1, d_b1, d_w2, d_b2)
+        return (None, d_head, None, None, None, None, None, None, None, None, None, None) + w
+
+
+@torch.compiler.disable
+def encoder_apply(values: torch.Tensor, lmda: torch.Tensor, plan: MeshPlan, n_head: int, mlp, concat_heads: int = 0,
+                  head_is_scale: bool = False, early=None) -> torch.Tensor:
+    """pit.encoder (pit.py:108-112) as one launch per direction: gelu(en_layer(posatt_cross(mesh_ltt, mesh_in, values))); ``values``
+    may be tagged by tag_coords (the coordinate channels then come from the mesh).  ``early``: early_block_weights(...) whose job
+    this launch carries.  The inputs get no gradient (the caller checked that they need none)."""
+    param = lmda if isinstance(lmda, torch.nn.Parameter) else None
+    c = host_head_scale(lmda) if (not head_is_scale and get_head_scale_route() == "host") else None
+    coords = getattr(values, "_pit_coords", None)
+    kd = plan.sdim if coords is not None else 0
+    wjob = None
+    if early is not None and getattr(_STEP, "fwd_job", None) is early:
+        _STEP.fwd_job = None
+        wjob = early
+    clear = getattr(_STEP, "clear", None)
+    if clear is not None:
+        _STEP.clear = None                       # (zeroed by this launch: the step's loss launch need not)
+    res = _Encoder.apply(values.detach(), lmda.reshape(-1), plan, n_head, head_is_scale, param, c, tuple(mlp), kd, int(concat_heads),
+                         wjob, clear, *mlp)
+    if concat_heads <= 0:
+        return res
+    y, buf = res
+    y._pit_concat = buf
+    return y
+
+
 class _RelLpLoss(torch.autograd.Function):
     """RelLpNorm (utils.py:80-98), optionally fused with the per-pixel affine
     de-normalisation of the prediction (utils.py:25-34).
@@ -1361,11 +1731,53 @@ class _RelLpLoss(torch.autograd.Function):
             None, None, None, None, None, None
 
 
+class _FusedLoss(torch.autograd.Function):
+    """The loss node of a step whose decoder launches carry the loss (LossSpec): no launch in either direction.  The forward
+    returns the scalar the decoder BACKWARD launch will write (a training step reads its loss after the pass); the backward hands
+    a token tensor down the graph that pit.decoder's backward recognises by its address - it reaches it through views only."""
+
+    @staticmethod
+    def forward(ctx, pred, spec: LossSpec):
+        ctx.spec, ctx.pred_shape = spec, pred.shape
+        return spec.value
+
+    @staticmethod
+    def backward(ctx, g):
+        spec = ctx.spec
+        spec.seed = g.contiguous()
+        spec.token = torch.empty_like(spec.pred)           # never written, never read: its address is the message
+        return spec.token.view(ctx.pred_shape), None
+
+
+def _take_fused_loss(true, pred, out_dim: int, p: int, scale, shift):
+    """The LossSpec the running step's decoder accumulated for exactly this loss call, or None."""
+    spec = getattr(_STEP, "loss_issued", None)
+    if spec is None or spec.pred is None:
+        return None
+    _STEP.loss_issued = None
+    same = lambda a, b_: (a is None and b_ is None) or (a is not None and b_ is not None and a.data_ptr() == b_.data_ptr())
+    npts = spec.true.shape[1]
+    sc = scale.reshape(npts, out_dim) if scale is not None and scale.numel() == npts * out_dim else scale
+    sh = shift.reshape(npts, out_dim) if shift is not None and shift.numel() == npts * out_dim else shift
+    ok = (int(p) == spec.p and int(out_dim) == spec.out_dim and pred.requires_grad and pred.is_contiguous()
+          and pred.data_ptr() == spec.pred.data_ptr() and pred.numel() == spec.pred.numel()
+          and true.numel() == spec.true.numel() and true.is_contiguous() and true.data_ptr() == spec.true.data_ptr()
+          and (sc is None or sc.is_contiguous()) and (sh is None or sh.is_contiguous())
+          and same(sc, spec.scale) and same(sh, spec.shift))
+    return spec if ok else None
+
+
 @torch.compiler.disable
 def rel_lp_loss(true, pred, out_dim: int, p: int, pred_scale=None, pred_shift=None, unit_seed=None,
                 clear=None) -> torch.Tensor:
     """sum_b mean_c ||true - pred'||_p / ||true||_p with pred' = pred*pred_scale + pred_shift.
-    ``unit_seed`` / ``clear``: see _RelLpLoss (used by engine.TrainStep to save two launches)."""
+    ``unit_seed`` / ``clear``: see _RelLpLoss (used by engine.TrainStep to save two launches).  Inside a step whose fused decoder
+    already accumulated this very loss (step_state(loss=...)), no launch at all: see _FusedLoss."""
+    spec = _take_fused_loss(true, pred, out_dim, p, pred_scale, pred_shift)
+    if spec is not None:
+        if clear is not None:
+            clear.zero_()
+        return _FusedLoss.apply(pred, spec)
     return _RelLpLoss.apply(pred, true, out_dim, p, pred_scale, pred_shift, unit_seed, clear)
 
 

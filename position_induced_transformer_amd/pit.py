@@ -280,19 +280,73 @@ class pit(nn.Module):
         self.conv = nn.ModuleList([self_cls(self.n_head, self.hid_dim, 1.0) for _ in range(self.n_blocks)])
         self.up = cross_cls(self.n_head, self.hid_dim, self.de_local)
 
+    @staticmethod
+    def _plain(*modules) -> bool:
+        """None of the modules is hooked or has its forward patched on the instance (those expect to be CALLED: no fusing)."""
+        for m in modules:
+            if "forward" in m.__dict__ or m._forward_pre_hooks or m._backward_hooks or m._backward_pre_hooks \
+                    or any(not getattr(f, "_pit_internal", False) for f in m._forward_hooks.values()):
+                return False
+        return True
+
+    def _edge_layer(self, att, mlp, mesh_out, mesh_in, batch, device, needs_union):
+        """The mesh plan when cross-attention ``att`` followed by kaiming_mlp ``mlp`` can run as one fused launch per direction
+        (ops.encoder_apply / ops.decoder_apply: batch-free meshes, small regime), else None."""
+        if not (ops.EDGE_FUSION and isinstance(att, posatt) and not att._batched and type(att).forward in _OWN_CROSS_FORWARDS
+                and not att._overridden() and type(mlp) is kaiming_mlp and mlp.mlp1.bias is not None and mlp.mlp2.bias is not None
+                and self._plain(att, mlp, mlp.mlp1, mlp.mlp2)):
+            return None
+        if not (torch.is_tensor(mesh_out) and torch.is_tensor(mesh_in) and mesh_out.dim() == 2 and mesh_in.dim() == 2
+                and mesh_out.is_cuda and mesh_in.is_cuda and mesh_out.device == device and mesh_in.device == device):
+            return None
+        if mlp.mlp1.out_features not in (32, 64) or att.n_head not in (1, 2):
+            return None
+        plan = att._plan(mesh_out, mesh_in, False)
+        return plan if ops.edge_fusion_supported(plan, att.n_head, mlp.mlp1.out_features, batch, needs_union) else None
+
+    def _fused_encoder(self, mesh_in, func_in, mesh_ltt, early):
+        """gelu(en_layer(down(...))) as ONE launch per direction (ops.encoder_apply), or None: run the two modules."""
+        if not (torch.is_tensor(func_in) and func_in.is_cuda and func_in.dim() == 3 and func_in.dtype == torch.float32):
+            return None
+        if torch.is_grad_enabled() and func_in.requires_grad:         # (the fused backward gives the input data no gradient)
+            return None
+        en, down = self.en_layer, self.down
+        if type(en) is not kaiming_mlp or en.mlp1.out_features != en.mlp2.out_features:
+            return None
+        coords = getattr(func_in, "_pit_coords", None)
+        kd = 0
+        if coords is not None:
+            if not (torch.is_tensor(mesh_in) and coords.shape == mesh_in.shape and coords.data_ptr() == mesh_in.data_ptr()):
+                return None
+            kd = mesh_in.shape[-1]
+        chans = kd + func_in.shape[-1]
+        if chans > 8 or down.n_head * chans > 16 or en.mlp1.in_features != down.n_head * chans:
+            return None
+        plan = self._edge_layer(down, en, mesh_ltt, mesh_in, func_in.shape[0], func_in.device, False)
+        if plan is None or plan.n_in != func_in.shape[1]:
+            return None
+        return ops.encoder_apply(func_in, down.lmda, plan, down.n_head, (en.mlp1.weight, en.mlp1.bias, en.mlp2.weight, en.mlp2.bias),
+                                 concat_heads=self._heads_of_block(0, self.hid_dim), early=early)
+
     def encoder(self, mesh_in, func_in, mesh_ltt):
         # the fused processor's weights depend on (mesh_ltt, lmda) only: they are formed by extra workgroups of the
-        # down-projection's launch (ops.early_block_weights) instead of a launch of their own; processor() picks them up
+        # encoder-side launch (ops.early_block_weights) instead of a launch of their own; processor() picks them up
         early = None
-        if ops.EARLY_WEIGHTS != "0" and torch.is_tensor(func_in) and func_in.is_cuda and func_in.dim() >= 2:
-            plan = self._fused_plan(mesh_ltt, func_in.shape[0], self.hid_dim, func_in.device)
-            if plan is not None:
-                need_q = torch.is_grad_enabled() and (func_in.requires_grad or any(q.requires_grad for q in self.parameters()))
-                early = ops.early_block_weights(plan, [a.lmda for a in self.conv], self.conv[0].n_head, need_q)
-        func_ltt = self.down(mesh_ltt, mesh_in, func_in)
+        try:
+            if ops.EARLY_WEIGHTS != "0" and torch.is_tensor(func_in) and func_in.is_cuda and func_in.dim() >= 2:
+                plan = self._fused_plan(mesh_ltt, func_in.shape[0], self.hid_dim, func_in.device)
+                if plan is not None:
+                    need_q = torch.is_grad_enabled() and (func_in.requires_grad or any(q.requires_grad for q in self.parameters()))
+                    early = ops.early_block_weights(plan, [a.lmda for a in self.conv], self.conv[0].n_head, need_q)
+            fused = self._fused_encoder(mesh_in, func_in, mesh_ltt, early)
+            func_ltt = self.down(mesh_ltt, mesh_in, func_in) if fused is None else None
+            if early is not None:
+                early.join()
+        finally:
+            ops.drop_forward_job(early)          # (a call that raised must not leave its job armed for the thread's next layer)
         self.__dict__["_early_weights"] = early
-        if early is not None:
-            early.join()
+        if fused is not None:
+            return fused
         return self._mlp_gelu(self.en_layer, func_ltt, self._heads_of_block(0, self.hid_dim))
 
     def _fused_processor(self, func_ltt, mesh_ltt):
@@ -374,6 +428,15 @@ class pit(nn.Module):
         # and with it the decoder MLP's saved activations and their gradients are kept in memory as bf16 when the
         # decoder MLP's shape runs on the kernels that read them (ops.mlp_bf16_io_supported); fp32 accumulation throughout
         de, up = self.de, self.up
+        # small regime on batch-free meshes: up-projection + decoder MLP as ONE launch per direction (every math mode: the
+        # launch is latency-bound and contracts in fp32, like the fused processor blocks)
+        if torch.is_tensor(func_ltt) and func_ltt.is_cuda and func_ltt.dim() == 3 and func_ltt.dtype == torch.float32 \
+                and type(de) is kaiming_mlp and isinstance(up, posatt) and de.mlp2.out_features <= 4 \
+                and de.mlp1.out_features == func_ltt.shape[-1] and de.mlp1.in_features == up.n_head * func_ltt.shape[-1]:
+            plan = self._edge_layer(up, de, mesh_out, mesh_ltt, func_ltt.shape[0], func_ltt.device, True)
+            if plan is not None and plan.n_in == func_ltt.shape[1]:
+                return ops.decoder_apply(func_ltt, up.lmda, plan, up.n_head,
+                                         (de.mlp1.weight, de.mlp1.bias, de.mlp2.weight, de.mlp2.bias))
         if type(de) is kaiming_mlp and isinstance(up, posatt) and type(up).forward in _OWN_CROSS_FORWARDS and func_ltt.is_cuda \
                 and ops.get_math_mode() == "bf16" and torch.is_tensor(mesh_out) and not up._forward_hooks and not de._forward_hooks:
             rows = func_ltt.shape[0] * mesh_out.shape[-2]

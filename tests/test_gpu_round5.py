@@ -43,3 +43,207 @@ def test_rel_lp_loss_reports_non_finite_terms_and_recovers(npts, out_dim):
     ref_big, got_big = float(orc.rel_lp_loss(t, big, out_dim, 2)), float(loss(t.cuda(), big.cuda()))
     assert (np.isinf(ref_big) and np.isinf(got_big)) or abs(got_big - ref_big) <= 1e-5 * abs(ref_big)
     assert abs(float(loss(t.cuda(), q.cuda())) - want) <= 1e-6 * abs(want)
+
+
+# --------------------------------------------------------------------------- fused encoder- / decoder-side launches
+METRIC = {"darcy": "euclid", "burgers": "periodic1d", "sod": "euclid"}
+EDGE_CASES = [("darcy", 8), ("darcy", 3), ("darcy", 1), ("burgers", 8), ("sod", 8)]
+
+
+class _Count:
+    """Counts calls of ops.<name> (the tests must exercise the fused launches, not a fallback)."""
+
+    def __init__(self, name):
+        from position_induced_transformer_amd import ops
+        self.ops, self.name, self.n = ops, name, 0
+
+    def __enter__(self):
+        self.orig = getattr(self.ops, self.name)
+
+        def counting(*a, **k):
+            self.n += 1
+            return self.orig(*a, **k)
+        setattr(self.ops, self.name, counting)
+        return self
+
+    def __exit__(self, *exc):
+        setattr(self.ops, self.name, self.orig)
+        return False
+
+
+def _cpu_params(*tensors):
+    return [t.detach().cpu().clone().requires_grad_(True) for t in tensors]
+
+
+def test_slab_plan_records_distances_unions_and_slots():
+    """pit_slab_plan_build on the Darcy decoder pair (43 x 43 output grid <- 16 x 16 latent) and a random cloud: the candidates'
+    distances are the reference's fp32 expression bit for bit (pit.py:134), a slab's keys are the sorted union of its rows' lists,
+    every candidate's slot points at its key, the reported maximum is the largest union."""
+    from position_induced_transformer_amd import ops
+    g = torch.Generator().manual_seed(3)
+    pairs = [(orc.grid_mesh_2d(43), orc.grid_mesh_2d(16), 0.02), (torch.rand(700, 2, generator=g), torch.rand(300, 2, generator=g), 0.05)]
+    for mo, mi, loc in pairs:
+        plan = ops.MeshPlan("euclid", mo.cuda(), mi.cuda(), loc, False)
+        sp, max_union, (m, slot, keys, nkeys) = plan.slab_plan()
+        cap, n_out = plan.nbr_cap, plan.n_out
+        idx, cnt = plan.nbr_idx.view(n_out, cap).cpu().long(), plan.nbr_cnt.cpu().long()
+        ref_m = ((mo[:, None, :] - mi[None, :, :]) ** 2).sum(-1)
+        m, slot, keys, nkeys = m.cpu(), slot.cpu().long() & 0xffff, keys.cpu().long(), nkeys.cpu().long()
+        assert int(nkeys.max()) == max_union
+        for s in range(sp.n_slabs):
+            rows = range(16 * s, min(16 * s + 16, n_out))
+            union = sorted({int(idx[r, i]) for r in rows for i in range(int(cnt[r]))})
+            assert int(nkeys[s]) == len(union)
+            if len(union) <= 64:
+                assert keys[s, :len(union)].tolist() == union
+            for r in rows:
+                c = int(cnt[r])
+                assert torch.equal(m[r, :c], ref_m[r, idx[r, :c]])
+                if len(union) <= 64:
+                    assert keys[s, slot[r, :c]].tolist() == idx[r, :c].tolist()
+
+
+@pytest.mark.parametrize("task,batch", EDGE_CASES)
+def test_fused_decoder_against_the_oracle(task, batch):
+    """pit.decoder (pit.py:124-127) through ops.decoder_apply - ONE launch forward, ONE backward - against the oracle's
+    posatt_cross + mlp on the same parameters and inputs: prediction <= 1e-5, d(values) and weight gradients <= 2e-5, d(lmda) <= 2e-4.
+    Route 'host': the head scale is the reference's own torch-CPU value, so the check holds for any seed."""
+    from position_induced_transformer_amd import ops, tasks
+    model, sample, meta = tasks.make_task(task, seed=51)
+    mesh_in, func_in, mesh_out, target = sample(batch)
+    mo = mesh_out.reshape(-1, model.space_dim)
+    L, hid = model.mesh_ltt.shape[0], model.hid_dim
+    g = torch.Generator().manual_seed(52)
+    x = torch.randn(batch, L, hid, generator=g)
+    d_out = torch.randn(batch, mo.shape[0], model.out_dim, generator=g)
+    xg = x.cuda().requires_grad_(True)
+    with _Count("decoder_apply") as cnt, ops.head_scale_route("host"):
+        out = model.decoder(model.mesh_ltt, xg, mo)
+        out.backward(d_out.cuda())
+    torch.cuda.synchronize()
+    assert cnt.n == 1, "the fused decoder launch did not run"
+    de = model.de
+    xr, lm, w1, b1, w2, b2 = _cpu_params(x, model.up.lmda, de.mlp1.weight, de.mlp1.bias, de.mlp2.weight, de.mlp2.bias)
+    ref = orc.mlp(orc.posatt_cross(METRIC[task], False, mo.cpu(), model.mesh_ltt.cpu(), xr, lm, 0.02), w1, b1, w2, b2)
+    ref.backward(d_out)
+    assert gio.rel_l2(out.detach().cpu().numpy(), ref.detach().numpy()) <= 1e-5
+    assert gio.rel_l2(xg.grad.cpu().numpy(), xr.grad.numpy()) <= 2e-5
+    for name, a, r in (("w1", de.mlp1.weight, w1), ("b1", de.mlp1.bias, b1), ("w2", de.mlp2.weight, w2), ("b2", de.mlp2.bias, b2)):
+        assert gio.rel_l2(a.grad.cpu().numpy(), r.grad.numpy()) <= 2e-5, name
+    assert float((model.up.lmda.grad.cpu().reshape(-1) - lm.grad.reshape(-1)).norm()) <= 2e-4 * float(lm.grad.norm()), "d(lmda)"
+    # forward only (no_grad: nothing is saved) gives the same prediction
+    with torch.no_grad(), ops.head_scale_route("host"):
+        again = model.decoder(model.mesh_ltt, x.cuda(), mo)
+    assert torch.equal(again, out.detach())
+
+
+@pytest.mark.parametrize("tagged", [True, False], ids=["coordinates-from-the-mesh", "materialised-concat"])
+@pytest.mark.parametrize("task,batch", EDGE_CASES)
+def test_fused_encoder_against_the_oracle(task, batch, tagged):
+    """pit.encoder (pit.py:108-112) through ops.encoder_apply against the oracle's gelu(mlp(posatt_cross(...))), with the
+    coordinate channels read from the mesh (ops.tag_coords, train_darcy.py:51-55) and with the concat materialised."""
+    from position_induced_transformer_amd import ops, tasks
+    model, sample, meta = tasks.make_task(task, seed=53)
+    mesh_in, func_in, mesh_out, target = sample(batch)
+    mi = mesh_in.reshape(-1, model.space_dim)
+    func = func_in.reshape(batch, -1, model.in_dim)
+    L, hid = model.mesh_ltt.shape[0], model.hid_dim
+    d_out = torch.randn(batch, L, hid, generator=torch.Generator().manual_seed(54))
+    feats = ops.tag_coords(func, mi) if tagged else torch.cat((mi.unsqueeze(0).expand(batch, -1, -1), func), -1)
+    with _Count("encoder_apply") as cnt, ops.head_scale_route("host"):
+        out = model.encoder(mi, feats, model.mesh_ltt)
+        torch.autograd.backward(out, d_out.cuda())
+    torch.cuda.synchronize()
+    assert cnt.n == 1, "the fused encoder launch did not run"
+    en = model.en_layer
+    lm, w1, b1, w2, b2 = _cpu_params(model.down.lmda, en.mlp1.weight, en.mlp1.bias, en.mlp2.weight, en.mlp2.bias)
+    f = orc.posatt_cross(METRIC[task], False, model.mesh_ltt.cpu(), mi.cpu(), orc.with_coords(mi.cpu(), func.cpu()), lm, 0.02)
+    ref = F.gelu(orc.mlp(f, w1, b1, w2, b2))
+    ref.backward(d_out)
+    assert gio.rel_l2(out.detach().cpu().numpy(), ref.detach().numpy()) <= 1e-5
+    for name, a, r in (("w1", en.mlp1.weight, w1), ("b1", en.mlp1.bias, b1), ("w2", en.mlp2.weight, w2), ("b2", en.mlp2.bias, b2)):
+        assert gio.rel_l2(a.grad.cpu().numpy(), r.grad.numpy()) <= 2e-5, name
+    assert float((model.down.lmda.grad.cpu().reshape(-1) - lm.grad.reshape(-1)).norm()) <= 2e-4 * float(lm.grad.norm()), "d(lmda)"
+
+
+def _oracle_step(task, model, batch, affine, meta):
+    """Forward + RelLp loss + backward of the whole model with the oracle; returns (prediction, loss, gradients by name)."""
+    mesh_in, func_in, mesh_out, target = batch
+    b = func_in.shape[0]
+    sd = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in model.state_dict().items()}
+    mi, mo = mesh_in.cpu().reshape(-1, model.space_dim), mesh_out.cpu().reshape(-1, model.space_dim)
+    f = orc.with_coords(mi, func_in.cpu().reshape(b, -1, model.in_dim))
+    ref = orc.pit_apply(sd, METRIC[task], False, model.n_blocks, model.en_local, model.de_local, mi, f, model.mesh_ltt.cpu(), mo)
+    ref = ref.reshape(target.shape)
+    pred = ref if affine is None else ref * affine[0].cpu() + affine[1].cpu()
+    loss = orc.rel_lp_loss(target.cpu(), pred, meta["out_dim"], meta["p"])
+    loss.backward()
+    return ref.detach(), float(loss), {k: v.grad for k, v in sd.items()}
+
+
+@pytest.mark.parametrize("graph", [False, True], ids=["eager", "hipgraph"])
+@pytest.mark.parametrize("task,batch,affine", [("darcy", 8, True), ("darcy", 3, False), ("burgers", 8, False), ("sod", 8, False)])
+def test_train_step_with_the_loss_inside_the_decoder_launches_matches_the_oracle(task, batch, affine, graph):
+    """engine.TrainStep on a model whose encoder and decoder sides are fused launches: the RelLp loss (p = 2 with the Darcy loop's
+    affine de-normalisation, train_darcy.py:129-130; p = 1: Burgers, Sod with three channels) is accumulated by the decoder's
+    forward launch and differentiated by its backward launch - no loss launch - and prediction, loss and every gradient of the
+    flat buffer equal the oracle's forward + loss + backward."""
+    from position_induced_transformer_amd import ops, tasks
+    from position_induced_transformer_amd.engine import TrainStep
+    model, sample, meta = tasks.make_task(task, seed=55)
+    b4 = sample(batch)
+    aff = None
+    if affine:
+        g = torch.Generator().manual_seed(56)
+        aff = (torch.rand(b4[3].shape[1:], generator=g).cuda() + 0.5, torch.randn(b4[3].shape[1:], generator=g).cuda())
+    with ops.head_scale_route("host"), _Count("decoder_apply") as cd, _Count("encoder_apply") as ce:
+        step = TrainStep(model, b4, meta["out_dim"], meta["p"], pred_affine=aff)
+        fused = {"n": 0}
+        orig = ops._FusedLoss.apply
+
+        def counting(*a, **k):
+            fused["n"] += 1
+            return orig(*a, **k)
+        ops._FusedLoss.apply = counting
+        try:
+            if graph:
+                step.capture()
+                for _ in range(3):
+                    step.replay()
+            else:
+                step.run_eager()
+                step.run_eager()
+        finally:
+            ops._FusedLoss.apply = orig
+    torch.cuda.synchronize()
+    assert cd.n >= 1 and ce.n >= 1 and fused["n"] >= 1, "the fused launches / the loss inside them did not run"
+    ref, ref_loss, ref_grads = _oracle_step(task, model, b4, aff, meta)
+    assert gio.rel_l2(step.out.cpu().numpy(), ref.numpy()) <= 1e-5
+    assert abs(float(step.loss) - ref_loss) <= 1e-5 * abs(ref_loss)
+    lk = [k for k in ref_grads if k.endswith("lmda")]
+    for k, q in model.named_parameters():
+        if not k.endswith("lmda"):
+            assert gio.rel_l2(q.grad.cpu().numpy(), ref_grads[k].numpy()) <= 2e-5, k
+    got = torch.cat([dict(model.named_parameters())[k].grad.cpu().reshape(-1) for k in lk])
+    want = torch.cat([ref_grads[k].reshape(-1) for k in lk])
+    assert float((got - want).norm()) <= 2e-4 * float(want.norm()), "d(lmda)"
+
+
+def test_prediction_that_is_post_processed_keeps_the_loss_launch():
+    """The loss rides in the decoder launches only when the model's prediction reaches it through views; Cylinder adds its input
+    back onto the prediction (train_cylinder.py:52): the step must fall back to the loss kernel - and still be right."""
+    from position_induced_transformer_amd import ops, tasks
+    from position_induced_transformer_amd.engine import TrainStep
+    model, sample, meta = tasks.make_task("darcy", seed=57)
+    model.residual = True
+    b4 = sample(4)
+    step = TrainStep(model, b4, meta["out_dim"], meta["p"])
+    with ops.head_scale_route("host"):
+        step.run_eager()
+        step.run_eager()
+    torch.cuda.synchronize()
+    model.residual = False
+    t, o = b4[3].cpu().reshape(4, -1), step.out.cpu().reshape(4, -1)
+    want = float(((t - o).norm(dim=1) / t.norm(dim=1)).sum())
+    assert abs(float(step.loss) - want) <= 1e-5 * abs(want)
+    assert all(torch.isfinite(q.grad).all() and float(q.grad.abs().max()) > 0 for q in model.parameters())
