@@ -324,13 +324,14 @@ int pit_edge_supported(int n_head, int dim, int batch, int rows_per_sample);
  * gelu; y (batch*n_out, n2).  Saved for the backward when given (all or none): x (batch*n_out, n_head*dim) the attention's output,
  * z1 / h (batch*n_out, dim), rowstat (n_head, n_out, 4), scale_out (n_head).  zero_buf: zero_n floats cleared on the way (the
  * d_values buffer pit_decoder_bwd adds to).  loss_part != NULL: the slab's partial sums of RelLpNorm(true, y*scale + shift)
- * (utils.py:86-98, p = 1 or 2) as (batch, n2, n_slabs, 2) doubles - plain stores, nothing to zero, the same bits on every run. */
+ * (utils.py:86-98, p = 1 or 2) as (batch, n2, n_slabs, 2) doubles - plain stores, nothing to zero, the same bits on every run.
+ * max_union: report[0] of pit_slab_plan_build (<= PIT_SLAB_UNION_MAX): sizes the launch's LDS tiles (32, 48 or 64 slots). */
 int pit_decoder_fwd(const pit_slab_plan* plan, const float* values, long ld_values, long values_bstride, int batch,
                     int n_head, int dim, const float* head, int head_is_scale,
                     const float* w1, const float* b1, const float* w2, const float* b2, int n2,
                     float* x, float* z1, float* h, float* y, float* rowstat, float* scale_out, float* zero_buf, long zero_n,
                     const float* loss_true, const float* loss_scale, const float* loss_shift, int loss_p, double* loss_part,
-                    void* stream);
+                    int max_union, void* stream);
 /* pit.decoder backward: d_y (batch*n_out, n2) -> dz1 (batch*n_out, dim: the scratch of the MLP's weight-gradient reductions,
  * pit_mlp_bwd_params with d_y and this scratch), d_values (batch, n_in, dim) ADDED to (fp32 atomics; zero on entry), the layer's
  * d(scale) accumulators (PIT_HEAD_DEFER convention).  d_y == NULL: the loss inside - d(pred) is formed from loss_part (the
@@ -342,7 +343,7 @@ int pit_decoder_bwd(const pit_slab_plan* plan, const float* values, long ld_valu
                     const float* d_y, long ld_dy, float* dz1, float* d_values, long dvalues_bstride, double* dscale,
                     const float* loss_pred, const float* loss_true, const float* loss_scale, const float* loss_shift,
                     const float* loss_seed, int loss_p, const double* loss_part, float* d_pred, float* loss_out,
-                    float* norms_out, void* stream);
+                    float* norms_out, int max_union, void* stream);
 /* pit.encoder forward.  Value channels [0, coord_dims) are the key coordinates (mesh_in; train_darcy.py:51-55), the other
  * value_dim channels come from values (batch, n_in, value_dim); n_head*(coord_dims + value_dim) <= 16.  The MLP is
  * (n_head*(coord_dims+value_dim) -> dim -> dim) followed by gelu; y rows ldy apart (the first columns of the processor's concat
@@ -356,7 +357,7 @@ int pit_encoder_fwd(const pit_slab_plan* plan, const float* mesh_in, int space_d
                     float* x, float* z1, float* h, float* z2, float* y, long ldy, float* rowstat, float* scale_out,
                     float* clear_buf, long clear_n, const struct pit_block_weights_job* weights, void* stream);
 /* pit.encoder backward: d_y (batch*n_out, dim) rows ld_dy apart -> scratch (dZ1 | dZ2: the layout of pit_mlp_bwd_data) and the
- * down-projection's d(scale) accumulators (dscale == NULL: the MLP's data path only).  The inputs get no gradient (data). */
+ * down-projection's d(scale) accumulators (required).  The inputs get no gradient (data). */
 int pit_encoder_bwd(const pit_slab_plan* plan, const float* mesh_in, int space_dim, int coord_dims,
                     const float* values, long ld_values, long values_bstride, int value_dim, int batch,
                     int n_head, int dim, const float* scale, const float* rowstat,

@@ -29,12 +29,22 @@
 #include "pit_gemm_rd.h"
 #include "pit_block_dev.h"
 
+#ifndef PIT_EDGE_DBG
+#define PIT_EDGE_DBG 0      // diagnostic builds (tools/edge_variants.sh): bits switch parts of the launches off to time them
+#endif
+
 namespace {
+
+#if PIT_EDGE_DBG & 0x100
+// diagnostic build (tools/edge_variants.sh 256): REFCLK stamps (100 MHz) of wave 0 of one workgroup per kernel, never read by the kernels
+__device__ unsigned long long pit_edge_stamps[4][16];
+#define ESTAMP(k_, i_) do { if (blockIdx.x == 300 && threadIdx.x == 0) pit_edge_stamps[k_][i_] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define ESTAMP(k_, i_) do { } while (0)
+#endif
 
 constexpr int ER = 16;                  // rows per slab
 constexpr int EU = PIT_SLAB_UNION_MAX;  // union keys a slab tile holds (64)
-constexpr int EUP = EU + 4;             // LDS pitch of a [..][slot] tile
-constexpr int PTP = 2 * ER + 4;         // LDS pitch of the transposed weights tile [slot][h*16 + row]
 
 // sum over the LPR-lane segment a lane belongs to (16, 32 or 64 lanes), returned to every lane of the segment
 template <int LPR>
@@ -46,6 +56,25 @@ __device__ __forceinline__ float seg_sum(float v) {
     if (LPR >= 32) v += __shfl_xor(v, 16, 64);
     if (LPR >= 64) v += __shfl_xor(v, 32, 64);
     return v;
+}
+
+// Predicated loads WITHOUT a branch: hipcc turns `ok ? p[i] : 0` - and, by sinking the load to its only use, even
+// `v = p[ok ? i : 0]; ok ? v : 0` - into an exec-masked block that ends in s_waitcnt vmcnt(0): every such load a serial memory
+// round trip (eleven of them in the first version of decoder_fwd_kernel).  As in pit_common.h the load goes through a raw buffer
+// descriptor whose range check returns 0: an unconditional instruction whose result is used unconditionally.  The descriptor
+// spans 2 GiB from the (wave-uniform) base pointer - the tensors of this regime are a few MB.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t wide_rsrc(const void* p) { return make_rsrc(p, 0x7ffffff0u); }
+constexpr unsigned OOB = 0x7ffffff8u;
+__device__ __forceinline__ float ldg_if(const float* p, long i, bool ok) {
+    return buf_load(wide_rsrc(p), ok ? (unsigned)(i * 4) : OOB);
+}
+__device__ __forceinline__ int ldi_if(const int* p, long i, bool ok) {
+    return __builtin_amdgcn_raw_buffer_load_b32(wide_rsrc(p), (int)(ok ? (unsigned)(i * 4) : OOB), 0, 0);
+}
+__device__ __forceinline__ float4 ldg4_if(const float* p, long i, bool ok) {
+    float v[4];
+    buf_load4(wide_rsrc(p), ok ? (unsigned)(i * 4) : OOB, v);
+    return make_float4(v[0], v[1], v[2], v[3]);
 }
 
 __device__ __forceinline__ float pow_abs_p(float x, int p) {
@@ -123,9 +152,9 @@ __global__ __launch_bounds__(256) void slab_plan_kernel(SlabBuildArgs a) {
 // ------------------------------------------------------------------------------------------------ shared pieces
 // The head scales of the launch: c_h as the caller gives it, or from lmda (pit_common.h).
 template <int H>
-__device__ __forceinline__ void head_scales(const float* head, int is_scale, float (&c)[H]) {
+__device__ __forceinline__ void head_scales(const float (&raw)[H], int is_scale, float (&c)[H]) {
 #pragma unroll
-    for (int h = 0; h < H; ++h) c[h] = is_scale ? head[h] : head_scale_from_lmda(head[h]);
+    for (int h = 0; h < H; ++h) c[h] = is_scale ? raw[h] : head_scale_from_lmda(raw[h]);
 }
 
 // One pass of weight formation: this lane is candidate `i` of slab row `row_l` (mesh row n).  FWD: thresholds from the order
@@ -135,13 +164,14 @@ struct Cand { float m; int slot; bool valid; };
 
 template <int LPR>
 __device__ __forceinline__ Cand load_cand(const pit_slab_plan& p, int slab, int row_l, int i) {
+    // (three independent loads: the records of all cap slots exist - pit_slab_plan_build writes zeros beyond a row's count)
     Cand c;
     const int n = slab * ER + row_l;
-    const int cnt = n < p.n_out ? min(p.cnt[n], p.cap) : 0;
-    c.valid = i < cnt;
-    const long off = (long)(slab * ER + row_l) * p.cap + (c.valid ? i : 0);
+    const int craw = ldi_if(p.cnt, n, n < p.n_out);                // (rows beyond the mesh: count 0)
+    const long off = (long)(slab * ER + row_l) * p.cap + (i < p.cap ? i : 0);
     c.m = p.m[off];
     c.slot = p.slot[off];
+    c.valid = i < min(craw, p.cap);
     return c;
 }
 
@@ -155,18 +185,31 @@ struct DecFwdArgs {
     float* rowstat; float* scale_out;
     float* zero_buf; long zero_n;
     const float *tru, *lscale, *lshift; int loss_p; double* lpart;
+    int um;                                   // slots of the union tiles in LDS: 32, 48 or 64 >= the plan's largest union
 };
 
-// gather the slab's union value rows: 16 rows per pass (NT / (D/4) threads per row), up to EU / 16 passes, all in flight
+// The slab's union value rows: thread (r0 = tid / (D/4), q = tid % (D/4)) owns the 16-byte piece q of slots r0, r0 + 16, ... .
+// The keys come straight from the plan (padded with key 0 - a valid row - beyond the union; the select zeroes those): two dependent
+// round trips, no LDS hand-off in front of the second.  The upper half of the tile only for unions above 32 keys (wave-uniform).
 template <int D>
-__device__ __forceinline__ void gather_union(const float* __restrict__ vb, long ldv, const int* keys_s, int nk, int nkup, int tid,
+__device__ __forceinline__ void union_keys(const pit_slab_plan& p, int slab, int tid, int nkup, int (&key)[EU / 16]) {
+    const int r0 = tid / (D / 4);
+    const int* kp = p.keys + (long)slab * p.umax + r0;
+#pragma unroll
+    for (int u = 0; u < EU / 16; ++u) key[u] = kp[16 * u];         // (all four: no branch on the union's size in front of them)
+}
+template <int D>
+__device__ __forceinline__ void gather_union(const float* __restrict__ vb, long ldv, const int (&key)[EU / 16], int nk, int nkup, int tid,
                                              float4 (&uv)[EU / 16]) {
     const int r0 = tid / (D / 4), q = tid % (D / 4);
 #pragma unroll
-    for (int u = 0; u < EU / 16; ++u) {
-        uv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-        const int r = r0 + 16 * u;
-        if (16 * u < nkup && r < nk) uv[u] = *reinterpret_cast<const float4*>(vb + (long)keys_s[r] * ldv + 4 * q);
+    for (int u = 0; u < EU / 16; ++u) uv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (PIT_EDGE_DBG & 2) return;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) uv[u] = ldg4_if(vb, (long)key[u] * ldv + 4 * q, r0 + 16 * u < nk);
+    if (nkup > 32) {
+#pragma unroll
+        for (int u = 2; u < EU / 16; ++u) uv[u] = ldg4_if(vb, (long)key[u] * ldv + 4 * q, r0 + 16 * u < nk);
     }
 }
 template <int D>
@@ -177,12 +220,12 @@ __device__ __forceinline__ void park_union(float* ut, int nkup, int tid, const f
         if (16 * u < nkup) *reinterpret_cast<float4*>(ut + (r0 + 16 * u) * (D + 4) + 4 * q) = uv[u];
 }
 
-// acc (16 rows x columns [16 wave, 16 wave + 16)) = W[16 x nkup] (row-major in LDS, pitch EUP) @ ut[nkup x D]
+// acc (16 rows x columns [16 wave, 16 wave + 16)) = W[16 x nkup] (row-major in LDS, pitch `up`) @ ut[nkup x D]
 template <int D>
-__device__ __forceinline__ f32x4_t tile_times_union(const float* wrow, const float* ut, int nkup, int wave, int l15, int kq) {
+__device__ __forceinline__ f32x4_t tile_times_union(const float* wrow, int up, const float* ut, int nkup, int wave, int l15, int kq) {
     f32x4_t a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
     for (int s = 0; s < nkup / 16; ++s) {
-        const float4 a = *reinterpret_cast<const float4*>(wrow + l15 * EUP + 16 * s + 4 * kq);
+        const float4 a = *reinterpret_cast<const float4*>(wrow + l15 * up + 16 * s + 4 * kq);
         const float* bp = ut + (16 * s + 4 * kq) * (D + 4) + 16 * wave + l15;
         a0 = mfma_16x16x4(a.x, bp[0], a0);
         a1 = mfma_16x16x4(a.y, bp[D + 4], a1);
@@ -195,17 +238,30 @@ __device__ __forceinline__ f32x4_t tile_times_union(const float* wrow, const flo
     return r;
 }
 
-template <int H, int D, int LPR>
+// a wave clears the weight-tile rows it is about to scatter into: LDS operations of ONE wave execute in order, so no barrier sits
+// between the clearing and the scatter (rows of pass ps: ps*NW*RPW + wave*RPW + [0, RPW), every head)
+template <int H, int NW, int RPW, int NP>
+__device__ __forceinline__ void clear_own_rows(float* tile, int up, int wave, int lane) {
+#pragma unroll
+    for (int ps = 0; ps < NP; ++ps)
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+            float* base = tile + (h * ER + ps * NW * RPW + wave * RPW) * up;
+            for (int e = lane; e < RPW * up; e += 64) base[e] = 0.0f;
+        }
+}
+
+template <int H, int D, int LPR, bool LOSS>
 __global__ __launch_bounds__(4 * D) void decoder_fwd_kernel(DecFwdArgs g) {
     constexpr int NT = 4 * D, NW = D / 16, K0 = H * D, KS = K0 / 16, XP = K0 + 4, HP = D + 4;
     constexpr int RPW = 64 / LPR, NP = ER / (NW * RPW);           // rows per wave and pass, passes
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* pt = smem;                          // [H][16][EUP] normalised weights
-    float* ut = pt + H * ER * EUP;             // [EU][D + 4] union value rows
-    float* xs = ut + EU * (D + 4);             // [16][XP]
+    const int UP = g.um + 4;                   // pitch of the weight tiles (the plan's largest union decides the LDS a launch takes)
+    float* pt = smem;                          // [H][16][UP] normalised weights
+    float* ut = pt + H * ER * UP;              // [um][D + 4] union value rows
+    float* xs = ut + g.um * (D + 4);           // [16][XP]
     float* hs = xs + ER * XP;                  // [16][HP]
     float* w2s = hs + ER * HP;                 // [4][D], then b2[4]
-    int* keys_s = reinterpret_cast<int*>(w2s + 4 * D + 4);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, kq = lane >> 4;
     const pit_slab_plan& p = g.p;
@@ -213,16 +269,16 @@ __global__ __launch_bounds__(4 * D) void decoder_fwd_kernel(DecFwdArgs g) {
     if (!slab_of_xcd(blockIdx.x, g.batch, p.n_slabs, b, slab)) return;
     const int nk = min(p.nkeys[slab], EU), nkup = (nk + 15) & ~15;
     const long row0 = (long)b * p.n_out + slab * ER;             // first row of the slab in the (batch * n_out) row space
-
-    // ---- everything that depends on nothing: MLP operands, the plan's records, the union keys
     const int c1 = wave * 16 + l15;
-    float4 bv[KS];
+
+    ESTAMP(0, 0);
+    // ---- ONE block of loads, nothing consumed inside it: the union keys first (the gather waits for them alone), then the
+    // plan's candidate records, the row statistics, the MLP operands, the loss's operands
+    int key[EU / 16];
+    union_keys<D>(p, slab, tid, nkup, key);
+    float hraw[H];
 #pragma unroll
-    for (int s = 0; s < KS; ++s) bv[s] = *reinterpret_cast<const float4*>(g.w1 + (long)c1 * K0 + 16 * s + 4 * kq);
-    const float bias1 = g.b1[c1];
-    if (tid < EU) keys_s[tid] = p.keys[(long)slab * p.umax + tid];
-    for (int e = tid; e < g.n2 * D; e += NT) w2s[e] = g.w2[e];
-    if (tid < g.n2) w2s[4 * D + tid] = g.b2[tid];
+    for (int h = 0; h < H; ++h) hraw[h] = g.head[h];
     Cand cd[NP];
     float st_k[NP], st_k1[NP], st_min[NP];
 #pragma unroll
@@ -232,22 +288,32 @@ __global__ __launch_bounds__(4 * D) void decoder_fwd_kernel(DecFwdArgs g) {
         const int nn = n < p.n_out ? n : p.n_out - 1;
         st_k[ps] = p.stats[nn]; st_k1[ps] = p.stats[p.n_out + nn]; st_min[ps] = p.stats[2 * (long)p.n_out + nn];
     }
-    for (int e = tid; e < H * ER * EUP; e += NT) pt[e] = 0.0f;
-    if (g.zero_buf) {                                            // this workgroup's share of a buffer the backward adds to
-        const long wgs = (long)g.batch * p.n_slabs, me = (long)b * p.n_slabs + slab;
-        const long per = ((g.zero_n + wgs - 1) / wgs + 3) & ~3L;
-        const long beg = me * per, end = min(g.zero_n, beg + per);
-        for (long e = beg + 4 * tid; e < end; e += 4 * NT) {
-            if (e + 4 <= end) *reinterpret_cast<float4*>(g.zero_buf + e) = make_float4(0.f, 0.f, 0.f, 0.f);
-            else for (long q = e; q < end; ++q) g.zero_buf[q] = 0.0f;
-        }
+    float4 bv[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+        bv[s] = (PIT_EDGE_DBG & 1) ? make_float4(1.f, 2.f, 3.f, 4.f) : *reinterpret_cast<const float4*>(g.w1 + (long)c1 * K0 + 16 * s + 4 * kq);
+    const float bias1 = g.b1[c1];
+    const float w2r = ldg_if(g.w2, tid, tid < g.n2 * D);          // (n2 * D <= 4 * D = NT: one element per thread)
+    const float b2r = ldg_if(g.b2, tid, tid < g.n2);
+    // the loss's operands of this lane's row, output channel 0 (wave 0 finishes the slab; every wave requests them: no branch)
+    float l_t0 = 0.0f, l_sc0 = 1.0f, l_sh0 = 0.0f;
+    if (LOSS) {
+        const int n = slab * ER + l15;
+        const bool rv = n < p.n_out;
+        l_t0 = ldg_if(g.tru, (row0 + l15) * g.n2, rv);
+        const bool aff = rv && g.lscale != nullptr;              // (no affine map: out-of-range loads, the values are not used)
+        l_sc0 = ldg_if(g.lscale, (long)n * g.n2, aff);
+        l_sh0 = ldg_if(g.lshift, (long)n * g.n2, aff);
     }
-    float c[H];
-    head_scales<H>(g.head, g.head_is_scale, c);
-    __syncthreads();
-    // ---- union value rows requested, weights formed while they fly
+    // ---- the union's value rows (second round trip), weights formed while they fly
     float4 uv[EU / 16];
-    gather_union<D>(g.values + (long)b * g.values_bstride, g.ld_values, keys_s, nk, nkup, tid, uv);
+    gather_union<D>(g.values + (long)b * g.values_bstride, g.ld_values, key, nk, nkup, tid, uv);
+    ESTAMP(0, 1);
+    clear_own_rows<H, NW, RPW, NP>(pt, UP, wave, lane);
+    float c[H];
+    head_scales<H>(hraw, g.head_is_scale, c);
+    w2s[tid] = w2r;
+    if (tid < 4) w2s[4 * D + tid] = b2r;
 #pragma unroll
     for (int ps = 0; ps < NP; ++ps) {
         const int row_l = ps * NW * RPW + wave * RPW + lane / LPR, n = slab * ER + row_l;
@@ -260,7 +326,7 @@ __global__ __launch_bounds__(4 * D) void decoder_fwd_kernel(DecFwdArgs g) {
             const float pv = keep ? __expf(smin - sv) : 0.0f;
             const float rs = seg_sum<LPR>(pv), qs = seg_sum<LPR>(pv * cd[ps].m);
             const float inv = rs > 0.0f ? 1.0f / rs : 0.0f;
-            if (cd[ps].valid) pt[(h * ER + row_l) * EUP + cd[ps].slot] = pv * inv;
+            if (cd[ps].valid) pt[(h * ER + row_l) * UP + cd[ps].slot] = pv * inv;
             if (lane % LPR == 0 && n < p.n_out && b == 0 && g.rowstat) {
                 float4 st; st.x = T; st.y = smin; st.z = inv; st.w = qs * inv;
                 *reinterpret_cast<float4*>(g.rowstat + ((long)h * p.n_out + n) * 4) = st;
@@ -268,20 +334,30 @@ __global__ __launch_bounds__(4 * D) void decoder_fwd_kernel(DecFwdArgs g) {
             }
         }
     }
+    ESTAMP(0, 2);
     park_union<D>(ut, nkup, tid, uv);
+    ESTAMP(0, 3);
     __syncthreads();
+    ESTAMP(0, 4);
     // ---- attention output tile: X[:, h*D + 16 wave ..] = P_h @ U
 #pragma unroll
     for (int h = 0; h < H; ++h) {
-        const f32x4_t o = tile_times_union<D>(pt + h * ER * EUP, ut, nkup, wave, l15, kq);
+        const f32x4_t o = tile_times_union<D>(pt + h * ER * UP, UP, ut, nkup, wave, l15, kq);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int r = 4 * kq + i;
-            xs[r * XP + h * D + c1] = o[i];
-            if (g.x && slab * ER + r < p.n_out) g.x[(row0 + r) * K0 + h * D + c1] = o[i];
+        for (int i = 0; i < 4; ++i) xs[(4 * kq + i) * XP + h * D + c1] = o[i];
+    }
+    ESTAMP(0, 5);
+    __syncthreads();
+    ESTAMP(0, 6);
+    // the tile goes to memory as 16-byte pieces (the backward's weight-gradient reductions read it)
+    if (g.x && !(PIT_EDGE_DBG & 4)) {
+#pragma unroll
+        for (int u = 0; u < (ER * K0 / 4 + NT - 1) / NT; ++u) {
+            const int e = tid + u * NT, r = e / (K0 / 4), q = e % (K0 / 4);
+            if (e < ER * K0 / 4 && slab * ER + r < p.n_out)
+                *reinterpret_cast<float4*>(g.x + (row0 + r) * K0 + 4 * q) = *reinterpret_cast<const float4*>(xs + r * XP + 4 * q);
         }
     }
-    __syncthreads();
     // ---- decoder MLP, first layer: Z1 = X W1^T + b1, H = gelu(Z1)
     {
         f32x4_t a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
@@ -297,20 +373,37 @@ __global__ __launch_bounds__(4 * D) void decoder_fwd_kernel(DecFwdArgs g) {
         for (int i = 0; i < 4; ++i) {
             const int r = 4 * kq + i;
             const float z = a0[i] + a1[i] + bias1;
-            const float hv = gelu_erf(z);
-            hs[r * HP + c1] = hv;
-            if (g.z1 && slab * ER + r < p.n_out) {
-                g.z1[(row0 + r) * D + c1] = z;
-                g.h[(row0 + r) * D + c1] = hv;
-            }
+            hs[r * HP + c1] = gelu_erf(z);
+            if (g.z1 && slab * ER + r < p.n_out && !(PIT_EDGE_DBG & 4)) g.z1[(row0 + r) * D + c1] = z;
         }
     }
+    ESTAMP(0, 7);
     __syncthreads();
+    ESTAMP(0, 8);
+    if (g.h && !(PIT_EDGE_DBG & 4)) {
+        const int r = tid / (D / 4), q = tid % (D / 4);             // NT = 16 * D / 4: one 16-byte piece per thread
+        if (slab * ER + r < p.n_out)
+            *reinterpret_cast<float4*>(g.h + (row0 + r) * D + 4 * q) = *reinterpret_cast<const float4*>(hs + r * HP + 4 * q);
+    }
+    if (wave != 0) {
+        // the other waves clear this workgroup's share of the buffer the backward adds to (fire and forget, off wave 0's path)
+        if (g.zero_buf) {
+            const long wgs = (long)g.batch * p.n_slabs, me = (long)b * p.n_slabs + slab;
+            const long per = ((g.zero_n + wgs - 1) / wgs + 3) & ~3L;
+            const long beg = me * per, end = min(g.zero_n, beg + per);
+            for (long e = beg + 4 * (tid - 64); e < end; e += 4 * (NT - 64)) {
+                if (e + 4 <= end) *reinterpret_cast<float4*>(g.zero_buf + e) = make_float4(0.f, 0.f, 0.f, 0.f);
+                else for (long q = e; q < end; ++q) g.zero_buf[q] = 0.0f;
+            }
+        }
+        return;
+    }
     // ---- thin output layer (out_dim <= 4, pit.py:106): a row dot per output; the slab's share of the loss
-    if (wave != 0) return;
     const int n = slab * ER + l15;
     const bool rv = n < p.n_out;
-    for (int o = 0; o < g.n2; ++o) {
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+        if (o >= g.n2) break;
         float part = 0.0f;
 #pragma unroll
         for (int k = 0; k < D / 4; k += 4) {
@@ -322,11 +415,16 @@ __global__ __launch_bounds__(4 * D) void decoder_fwd_kernel(DecFwdArgs g) {
         part += __shfl_xor(part, 32, 64);
         const float pred = part + w2s[4 * D + o];
         if (kq == 0 && rv) g.y[(row0 + l15) * g.n2 + o] = pred;
-        if (g.lpart) {
+        if (LOSS) {
             double num = 0.0, den = 0.0;
+            float t = l_t0, sc = l_sc0, sh = l_sh0;
+            if (o > 0) {                                          // (further channels: their operands now - a round trip each)
+                t = ldg_if(g.tru, (row0 + l15) * g.n2 + o, rv);
+                sc = ldg_if(g.lscale, (long)n * g.n2 + o, rv && g.lscale != nullptr);
+                sh = ldg_if(g.lshift, (long)n * g.n2 + o, rv && g.lscale != nullptr);
+            }
             if (kq == 0 && rv) {
-                const float t = g.tru[(row0 + l15) * g.n2 + o];
-                const float q = g.lscale ? pred * g.lscale[(long)n * g.n2 + o] + g.lshift[(long)n * g.n2 + o] : pred;
+                const float q = g.lscale ? pred * sc + sh : pred;
                 num = (double)pow_abs_p(t - q, g.loss_p);
                 den = (double)pow_abs_p(t, g.loss_p);
             }
@@ -338,6 +436,7 @@ __global__ __launch_bounds__(4 * D) void decoder_fwd_kernel(DecFwdArgs g) {
             }
         }
     }
+    ESTAMP(0, 9);
 }
 
 // ------------------------------------------------------------------------------------------------ decoder backward
@@ -353,6 +452,7 @@ struct DecBwdArgs {
     double* dscale;
     // the loss inside (d_y == NULL): d(pred) from the forward's partial sums, written to d_pred for the weight-gradient reductions
     const float *pred, *tru, *lscale, *lshift, *gseed; int loss_p; const double* lpart; float* d_pred; float* loss_out; float* norms_out;
+    int um;
 };
 
 // ||t - q||_p and ||t||_p of series (b, o) from the slabs' partial sums (every lane gets both)
@@ -366,21 +466,19 @@ __device__ __forceinline__ void series_norms(const double* lpart, int b, int o, 
     dn = p == 1 ? den : sqrt(den);
 }
 
-template <int H, int D, int LPR>
+template <int H, int D, int LPR, bool LOSS>
 __global__ __launch_bounds__(4 * D) void decoder_bwd_kernel(DecBwdArgs g) {
     constexpr int NT = 4 * D, NW = D / 16, K0 = H * D, S1 = D / 16, XP = K0 + 4, P1 = D + 4;
     constexpr int RPW = 64 / LPR, NP = ER / (NW * RPW);
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* pts = smem;                         // [EU][PTP]      P^T: [slot][h*16 + row]
-    float* qs = pts + EU * PTP;                // [H][16][EUP]   Q = P (m - mbar)
-    float* ut = qs + H * ER * EUP;             // [EU][D + 4]
-    float* ds1 = ut + EU * (D + 4);            // [16][P1]       dZ1
+    const int UP = g.um + 4;
+    float* ps_ = smem;                         // [H][16][UP]    P (normalised weights)
+    float* qs = ps_ + H * ER * UP;             // [H][16][UP]    Q = P (m - mbar)
+    float* ut = qs + H * ER * UP;              // [um][D + 4]
+    float* ds1 = ut + g.um * (D + 4);          // [16][P1]       dZ1
     float* dxs = ds1 + ER * P1;                // [16][XP]       dX
-    float* w2s = dxs + ER * XP;                // [4][D]
-    float* ds2 = w2s + 4 * D;                  // [16][4]        dZ2 = d(pred)
-    double* wred = reinterpret_cast<double*>(ds2 + ER * 4);      // [NW][H]
-    float* nrm = reinterpret_cast<float*>(wred + NW * H);        // [4][2] norms of the sample's series
-    int* keys_s = reinterpret_cast<int*>(nrm + 8);
+    double* wred = reinterpret_cast<double*>(dxs + ER * XP);     // [NW][H]
+    int* keys_s = reinterpret_cast<int*>(wred + NW * H);         // [EU]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, kq = lane >> 4;
     const pit_slab_plan& p = g.p;
@@ -390,22 +488,15 @@ __global__ __launch_bounds__(4 * D) void decoder_bwd_kernel(DecBwdArgs g) {
     const long row0 = (long)b * p.n_out + slab * ER;
     const int c1 = wave * 16 + l15;
 
-    // ---- requested first: W1 as the B operand of dX (B(k, n) = w1[k][n]), the gelu' arguments, the plan's records
-    float w1v[H][S1][4];
+    ESTAMP(1, 0);
+    // ---- ONE block of loads: union keys, candidate records + saved row statistics, d(pred) or the loss's operands, gelu'
+    // arguments, W2, W1 as the B operand of dX (B(k, n) = w1[k][n])
+    int key[EU / 16];
+    union_keys<D>(p, slab, tid, nkup, key);
+    const int akey = p.keys[(long)slab * p.umax + (tid & (EU - 1))];   // slot -> key for the d(values) adds, through LDS
+    float c[H];
 #pragma unroll
-    for (int hh = 0; hh < H; ++hh)
-#pragma unroll
-        for (int s = 0; s < S1; ++s)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) w1v[hh][s][e] = g.w1[(long)(16 * s + 4 * kq + e) * K0 + hh * D + c1];
-    float z1v[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const int e = tid + u * NT, r = e / D, cc = e % D;
-        z1v[u] = slab * ER + r < p.n_out ? g.z1[(row0 + r) * D + cc] : 0.0f;
-    }
-    if (tid < EU) keys_s[tid] = p.keys[(long)slab * p.umax + tid];
-    for (int e = tid; e < g.n2 * D; e += NT) w2s[e] = g.w2[e];
+    for (int h = 0; h < H; ++h) c[h] = g.scale[h];
     Cand cd[NP];
     float4 rs4[NP][H];
 #pragma unroll
@@ -416,33 +507,45 @@ __global__ __launch_bounds__(4 * D) void decoder_bwd_kernel(DecBwdArgs g) {
 #pragma unroll
         for (int h = 0; h < H; ++h) rs4[ps][h] = *reinterpret_cast<const float4*>(g.rowstat + ((long)h * p.n_out + nn) * 4);
     }
-    float dyv = 0.0f, predv = 0.0f, truv = 0.0f, lsc = 1.0f, lsh = 0.0f;
-    const int dr = tid / g.n2, dcol = tid % g.n2;                // this thread's d(pred) element (tid < 16 n2)
-    const bool downer = tid < ER * g.n2 && slab * ER + dr < p.n_out;
-    if (downer) {
-        if (g.d_y) dyv = g.d_y[(row0 + dr) * g.ld_dy + dcol];
-        else {
-            predv = g.pred[(row0 + dr) * g.n2 + dcol];
-            truv = g.tru[(row0 + dr) * g.n2 + dcol];
-            if (g.lscale) {
-                lsc = g.lscale[(long)(slab * ER + dr) * g.n2 + dcol];
-                lsh = g.lshift[(long)(slab * ER + dr) * g.n2 + dcol];
-            }
+    // this thread's four dZ1 elements: rows er[u] (element e = tid + u * NT of the 16 x D tile), column ec
+    const int ec = tid % D;
+    // (output channel 0 - the only one of most models - is requested here with everything else; further channels, out_dim <= 4,
+    // by the loop below: holding all of them would cost 60 more registers and a wave per SIMD)
+    float z1v[4], dyv[4], prv[4], trv[4], lsc[4], lsh[4];
+    const float w2c0 = g.w2[ec];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int r = (tid + u * NT) / D;
+        const bool ok = slab * ER + r < p.n_out;
+        z1v[u] = ldg_if(g.z1, (row0 + r) * D + ec, ok);
+        dyv[u] = 0.0f; prv[u] = 0.0f; trv[u] = 0.0f; lsc[u] = 1.0f; lsh[u] = 0.0f;
+        if (!LOSS) {
+            dyv[u] = ldg_if(g.d_y, (row0 + r) * g.ld_dy, ok);
+        } else {
+            prv[u] = ldg_if(g.pred, (row0 + r) * g.n2, ok);
+            trv[u] = ldg_if(g.tru, (row0 + r) * g.n2, ok);
+            const bool aff = ok && g.lscale != nullptr;           // (no affine map: out-of-range loads give 0; scale 1 below)
+            const float a = ldg_if(g.lscale, (long)(slab * ER + r) * g.n2, aff), bq = ldg_if(g.lshift, (long)(slab * ER + r) * g.n2, aff);
+            lsc[u] = g.lscale ? a : 1.0f;
+            lsh[u] = bq;
         }
     }
-    for (int e = tid; e < EU * PTP; e += NT) pts[e] = 0.0f;
-    for (int e = tid; e < H * ER * EUP; e += NT) qs[e] = 0.0f;
-    float c[H];
-#pragma unroll
-    for (int h = 0; h < H; ++h) c[h] = g.scale[h];
-    if (!g.d_y) {
-        // the loss of the step (utils.py:86-98) finished here: this sample's norms by wave 0, the scalar by the first workgroup
-        if (wave == 0)
-            for (int o = 0; o < g.n2; ++o) {
-                double nn, dn;
-                series_norms(g.lpart, b, o, g.n2, p.n_slabs, g.loss_p, lane, nn, dn);
-                if (lane == 0) { nrm[2 * o] = (float)nn; nrm[2 * o + 1] = (float)dn; }
-            }
+    // ---- the union's value rows (second round trip)
+    float4 uv[EU / 16];
+    gather_union<D>(g.values + (long)b * g.values_bstride, g.ld_values, key, nk, nkup, tid, uv);
+    ESTAMP(1, 1);
+    clear_own_rows<H, NW, RPW, NP>(ps_, UP, wave, lane);
+    clear_own_rows<H, NW, RPW, NP>(qs, UP, wave, lane);
+    if (tid < EU) keys_s[tid] = akey;
+    // ---- the loss of the step (utils.py:86-98) finished here: every wave sums this sample's norms itself (no hand-off), the
+    // scalar is the first workgroup's last wave's
+    float nrm0 = 0.0f, nrm1 = 1.0f;
+    if (LOSS) {
+        {
+            double nn, dn;
+            series_norms(g.lpart, b, 0, g.n2, p.n_slabs, g.loss_p, lane, nn, dn);
+            nrm0 = (float)nn; nrm1 = (float)dn;
+        }
         if (blockIdx.x == 0 && wave == NW - 1) {
             double tot = 0.0;
             for (int bb = 0; bb < g.batch; ++bb)
@@ -458,25 +561,8 @@ __global__ __launch_bounds__(4 * D) void decoder_bwd_kernel(DecBwdArgs g) {
             if (lane == 0) *g.loss_out = (float)tot;
         }
     }
-    __syncthreads();
-    float4 uv[EU / 16];
-    gather_union<D>(g.values + (long)b * g.values_bstride, g.ld_values, keys_s, nk, nkup, tid, uv);
-    // ---- d(pred) -> LDS (and, with the loss inside, to memory for the weight-gradient reductions)
-    if (tid < ER * g.n2) {
-        float v = dyv;
-        if (!g.d_y && downer) {
-            const float nn = nrm[2 * dcol], dn = nrm[2 * dcol + 1];
-            const float d = predv * lsc + lsh - truv;
-            float dnorm;
-            if (g.loss_p == 1) dnorm = (d > 0.0f) ? 1.0f : (d < 0.0f ? -1.0f : 0.0f);
-            else dnorm = (nn > 0.0f) ? d / nn : 0.0f;
-            v = dnorm * lsc / (dn * g.n2);
-            if (g.gseed) v *= g.gseed[0];
-            g.d_pred[(row0 + dr) * g.n2 + dcol] = v;
-        }
-        ds2[dr * 4 + dcol] = downer ? v : 0.0f;
-    }
-    // ---- weights from the saved row statistics: P^T and Q tiles
+    ESTAMP(1, 2);
+    // ---- weights from the saved row statistics: P and Q tiles (each wave its own rows)
 #pragma unroll
     for (int ps = 0; ps < NP; ++ps) {
         const int row_l = ps * NW * RPW + wave * RPW + lane / LPR;
@@ -486,24 +572,81 @@ __global__ __launch_bounds__(4 * D) void decoder_bwd_kernel(DecBwdArgs g) {
             const bool keep = cd[ps].valid && sv <= rs4[ps][h].x;
             const float pv = keep ? __expf(rs4[ps][h].y - sv) * rs4[ps][h].z : 0.0f;
             if (cd[ps].valid) {
-                pts[cd[ps].slot * PTP + h * ER + row_l] = pv;
-                qs[(h * ER + row_l) * EUP + cd[ps].slot] = pv * (cd[ps].m - rs4[ps][h].w);
+                ps_[(h * ER + row_l) * UP + cd[ps].slot] = pv;
+                qs[(h * ER + row_l) * UP + cd[ps].slot] = pv * (cd[ps].m - rs4[ps][h].w);
             }
         }
     }
-    __syncthreads();
-    // ---- dZ1 = (dZ2 W2) * gelu'(Z1): elementwise for the thin output layer
+    ESTAMP(1, 3);
+    // ---- dZ1 = (dZ2 W2) * gelu'(Z1), dZ2 = d(pred): elementwise for the thin output layer
+    const float gs = (LOSS && g.gseed) ? g.gseed[0] : 1.0f;
+    auto dpred = [&](float pr, float tr, float sc, float sh, float nn, float dn) {
+        const float d = pr * sc + sh - tr;
+        float dnorm;
+        if (g.loss_p == 1) dnorm = (d > 0.0f) ? 1.0f : (d < 0.0f ? -1.0f : 0.0f);
+        else dnorm = (nn > 0.0f) ? d / nn : 0.0f;
+        return gs * dnorm * sc / (dn * g.n2);
+    };
+    float acc[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-        const int e = tid + u * NT, r = e / D, cc = e % D;
-        float acc = 0.0f;
-        for (int o = 0; o < g.n2; ++o) acc += ds2[r * 4 + o] * w2s[o * D + cc];
-        const float v = acc * gelu_erf_grad(z1v[u]);
-        ds1[r * P1 + cc] = v;
-        if (slab * ER + r < p.n_out) g.dz1[(row0 + r) * D + cc] = v;
+        const int r = (tid + u * NT) / D;
+        const bool ok = slab * ER + r < p.n_out;
+        float v = dyv[u];
+        if (LOSS) {
+            v = dpred(prv[u], trv[u], lsc[u], lsh[u], nrm0, nrm1);
+            if (ec == 0 && ok) g.d_pred[(row0 + r) * g.n2] = v;
+        }
+        acc[u] = v * w2c0;
     }
+    for (int o = 1; o < g.n2; ++o) {                                 // further output channels (Sod: 3): a round trip each
+        const float w2o = g.w2[(long)o * D + ec];
+        float nn = 0.0f, dn = 1.0f;
+        if (LOSS) {
+            double a, bq;
+            series_norms(g.lpart, b, o, g.n2, p.n_slabs, g.loss_p, lane, a, bq);
+            nn = (float)a; dn = (float)bq;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int r = (tid + u * NT) / D;
+            const bool ok = slab * ER + r < p.n_out;
+            float v;
+            if (!LOSS) {
+                v = ldg_if(g.d_y, (row0 + r) * g.ld_dy + o, ok);
+            } else {
+                const long e = (long)(slab * ER + r) * g.n2 + o;
+                const bool aff = ok && g.lscale != nullptr;
+                const float a = ldg_if(g.lscale, e, aff), bq = ldg_if(g.lshift, e, aff);
+                v = dpred(ldg_if(g.pred, (row0 + r) * g.n2 + o, ok), ldg_if(g.tru, (row0 + r) * g.n2 + o, ok),
+                          g.lscale ? a : 1.0f, bq, nn, dn);
+                if (ec == o && ok) g.d_pred[(row0 + r) * g.n2 + o] = v;
+            }
+            acc[u] += v * w2o;
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int r = (tid + u * NT) / D;
+        const bool ok = slab * ER + r < p.n_out;
+        const float v = ok ? acc[u] * gelu_erf_grad(z1v[u]) : 0.0f;
+        ds1[r * P1 + ec] = v;
+        if (ok) g.dz1[(row0 + r) * D + ec] = v;
+    }
+    ESTAMP(1, 4);
     park_union<D>(ut, nkup, tid, uv);
+    ESTAMP(1, 5);
+    // W1 as the B operand of dX (B(k, n) = w1[k][n]): requested only now - 32 registers that would otherwise be live across the
+    // whole first half and cost the kernel a wave per SIMD; the barrier overlaps most of their (L2) latency
+    float w1v[H][S1][4];
+#pragma unroll
+    for (int hh = 0; hh < H; ++hh)
+#pragma unroll
+        for (int s = 0; s < S1; ++s)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) w1v[hh][s][e] = (PIT_EDGE_DBG & 8) ? 0.5f : g.w1[(long)(16 * s + 4 * kq + e) * K0 + hh * D + c1];
     __syncthreads();
+    ESTAMP(1, 6);
     // ---- dX = dZ1 W1 (16 x H*D), LDS only
 #pragma unroll
     for (int hh = 0; hh < H; ++hh) {
@@ -519,45 +662,50 @@ __global__ __launch_bounds__(4 * D) void decoder_bwd_kernel(DecBwdArgs g) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) dxs[(4 * kq + i) * XP + hh * D + c1] = o0[i] + o1[i];
     }
+    ESTAMP(1, 7);
     __syncthreads();
-    // ---- d(scale): dc_h -= sum_{row, d} dX[row, h*D + d] * (Q_h U)[row, d]
-#pragma unroll
-    for (int h = 0; h < H; ++h) {
-        const f32x4_t qu = tile_times_union<D>(qs + h * ER * EUP, ut, nkup, wave, l15, kq);
-        double part = 0.0;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) part += (double)qu[i] * (double)dxs[(4 * kq + i) * XP + h * D + c1];
-        part = wave_sum_d(part);
-        if (lane == 0) wred[wave * H + h] = part;
-    }
-    // ---- d(values)[key(slot), 16 wave ..] += sum_{h, row} P_h[row][slot] dX[row, h*D + ..]
+    ESTAMP(1, 8);
+    // ---- d(values)[key(slot), 16 wave ..] += sum_{h, row} P_h[row][slot] dX[row, h*D + ..]   (first: its atomics are the long tail)
     for (int mt = 0; mt < nkup / 16; ++mt) {
         f32x4_t a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int h = 0; h < H; ++h) {
-            const float4 a = *reinterpret_cast<const float4*>(pts + (16 * mt + l15) * PTP + h * ER + 4 * kq);
+            const float* ap = ps_ + (h * ER + 4 * kq) * UP + 16 * mt + l15;        // A(i = slot, k = row): the tile read transposed
             const float* bp = dxs + (4 * kq) * XP + h * D + c1;
-            a0 = mfma_16x16x4(a.x, bp[0], a0);
-            a1 = mfma_16x16x4(a.y, bp[XP], a1);
-            a0 = mfma_16x16x4(a.z, bp[2 * XP], a0);
-            a1 = mfma_16x16x4(a.w, bp[3 * XP], a1);
+            a0 = mfma_16x16x4(ap[0], bp[0], a0);
+            a1 = mfma_16x16x4(ap[UP], bp[XP], a1);
+            a0 = mfma_16x16x4(ap[2 * UP], bp[2 * XP], a0);
+            a1 = mfma_16x16x4(ap[3 * UP], bp[3 * XP], a1);
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int s = 16 * mt + 4 * kq + i;
-            if (s < nk) atomicAdd(g.d_values + (long)b * g.dvalues_bstride + (long)keys_s[s] * D + c1, a0[i] + a1[i]);
+            if (s < nk && !(PIT_EDGE_DBG & 16)) atomicAdd(g.d_values + (long)b * g.dvalues_bstride + (long)keys_s[s] * D + c1, a0[i] + a1[i]);
         }
     }
-    __syncthreads();
-    if (tid < H && g.dscale) {
-        double tot = 0.0;
-        for (int w = 0; w < NW; ++w) tot += wred[w * H + tid];
-        atomicAdd(g.dscale + (long)tid * PIT_DSCALE_SLOTS + ((int)blockIdx.x & (PIT_DSCALE_SLOTS - 1)), -tot);
+    ESTAMP(1, 9);
+    // ---- d(scale): dc_h -= sum_{row, d} dX[row, h*D + d] * (Q_h U)[row, d]
+    if (g.dscale) {
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+            const f32x4_t qu = tile_times_union<D>(qs + h * ER * UP, UP, ut, nkup, wave, l15, kq);
+            double part = 0.0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) part += (double)qu[i] * (double)dxs[(4 * kq + i) * XP + h * D + c1];
+            part = wave_sum_d(part);
+            if (lane == 0) wred[wave * H + h] = part;
+        }
+        __syncthreads();
+        if (tid < H) {
+            double tot = 0.0;
+            for (int w = 0; w < NW; ++w) tot += wred[w * H + tid];
+            atomicAdd(g.dscale + (long)tid * PIT_DSCALE_SLOTS + ((int)blockIdx.x & (PIT_DSCALE_SLOTS - 1)), -tot);
+        }
     }
+    ESTAMP(1, 10);
 }
 
 // ------------------------------------------------------------------------------------------------ encoder forward
-constexpr int EC = 8;                   // value channels of the down-projection (coordinates + in_dim) at most
 struct EncArgs {
     pit_slab_plan p;
     const float* mesh_in; int sdim, kd;                  // value channels [0, kd) are the key coordinates (train_darcy.py:51-55)
@@ -573,38 +721,41 @@ struct EncArgs {
     const float* d_y; long ld_dy; float* scratch; double* dscale;
 };
 
-// the candidate records and value channels of this wave's rows: a wave per row, lane = candidate (LPR = 64)
-struct EncCand { float m; bool valid; float v[EC]; };
-
+// the candidate records of this wave's rows (a wave per row and pass, lane = candidate): first round trip
 template <int NW>
-__device__ __forceinline__ void enc_gather(const EncArgs& g, int b, int slab, int wave, int lane, EncCand (&cd)[ER / NW]) {
-    const pit_slab_plan& p = g.p;
-    int jj[ER / NW];
+struct EncRows { float m[ER / NW]; int cnt[ER / NW], j[ER / NW]; };
+template <int NW>
+__device__ __forceinline__ void enc_records(const pit_slab_plan& p, int slab, int wave, int lane, EncRows<NW>& r) {
 #pragma unroll
     for (int ps = 0; ps < ER / NW; ++ps) {
         const int row_l = ps * NW + wave, n = slab * ER + row_l;
-        const int cnt = n < p.n_out ? min(p.cnt[n], p.cap) : 0;
-        cd[ps].valid = lane < cnt;
-        const long off = (long)(slab * ER + row_l) * p.cap + (cd[ps].valid ? lane : 0);
-        cd[ps].m = p.m[off];
-        jj[ps] = cd[ps].valid ? p.idx[(long)(n < p.n_out ? n : 0) * p.cap + lane] : 0;
+        r.cnt[ps] = ldi_if(p.cnt, n, n < p.n_out);
+        r.m[ps] = p.m[(long)(slab * ER + row_l) * p.cap + (lane < p.cap ? lane : 0)];
+        r.j[ps] = ldi_if(p.idx, (long)n * p.cap + lane, n < p.n_out && lane < p.cap);    // (slots beyond the count: never dereferenced)
     }
+}
+// ... and their value channels (second round trip): channel cc < kd is coordinate cc of the key, the others come from `values`;
+// channels beyond kd + dv and lanes without a candidate load out of range (0).  EC = 4 or 8 channels at compile time: no branch.
+template <int NW, int EC>
+__device__ __forceinline__ void enc_values(const EncArgs& g, int b, int lane, const EncRows<NW>& r, float (&v)[ER / NW][EC]) {
     const int dc = g.kd + g.dv;
+    const float* vb = g.values + (long)b * g.values_bstride;
 #pragma unroll
-    for (int ps = 0; ps < ER / NW; ++ps)
+    for (int ps = 0; ps < ER / NW; ++ps) {
+        const bool valid = lane < min(r.cnt[ps], g.p.cap);
 #pragma unroll
         for (int cc = 0; cc < EC; ++cc) {
-            float v = 0.0f;
-            if (cc < dc && cd[ps].valid)
-                v = cc < g.kd ? g.mesh_in[(long)jj[ps] * g.sdim + cc]
-                              : g.values[(long)b * g.values_bstride + (long)jj[ps] * g.ld_values + (cc - g.kd)];
-            cd[ps].v[cc] = v;
+            const bool coord = cc < g.kd;                        // (wave-uniform: selects the descriptor's base)
+            const float* base = coord ? g.mesh_in : vb;
+            const long off = coord ? (long)r.j[ps] * g.sdim + cc : (long)r.j[ps] * g.ld_values + (cc - g.kd);
+            v[ps][cc] = ldg_if(base, off, valid && cc < dc && !(PIT_EDGE_DBG & 64));
         }
+    }
 }
 
-template <int H, int D>
+template <int H, int D, int EC>
 __global__ __launch_bounds__(4 * D) void encoder_fwd_kernel(EncArgs g, WeightsArgs wj) {
-    constexpr int NT = 4 * D, NW = D / 16, S2 = D / 16, HP = D + 4, XP = 20;
+    constexpr int NT = 4 * D, NW = D / 16, S2 = D / 16, HP = D + 4, XP = 20, NP = ER / NW;
     __shared__ __attribute__((aligned(16))) float xs[ER * XP];
     __shared__ __attribute__((aligned(16))) float hs[ER * HP];
     if ((int)blockIdx.x >= g.n_att) {                           // the processor's block weights ride here (256-thread workgroups)
@@ -614,109 +765,119 @@ __global__ __launch_bounds__(4 * D) void encoder_fwd_kernel(EncArgs g, WeightsAr
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, kq = lane >> 4;
     const pit_slab_plan& p = g.p;
-    if (g.clear_buf) {                                          // the step's gradient accumulators (engine.TrainStep): zero before any backward launch
-        const long nthreads = (long)g.n_att * NT;
-        for (long i = (long)blockIdx.x * NT + tid; i < g.clear_n; i += nthreads) g.clear_buf[i] = 0.0f;
-    }
     int b, slab;
-    if (!slab_of_xcd(blockIdx.x, g.batch, p.n_slabs, b, slab)) return;
-    const long row0 = (long)b * p.n_out + slab * ER;
-    const int dc = g.kd + g.dv, K0 = H * dc;
-    const int c1 = wave * 16 + l15;
-    // ---- requested first: MLP operands; candidate records and their value channels
-    float bv1[4];
+    const bool mine = slab_of_xcd(blockIdx.x, g.batch, p.n_slabs, b, slab);
+    if (mine) {
+        const long row0 = (long)b * p.n_out + slab * ER;
+        const int dc = g.kd + g.dv, K0 = H * dc;
+        const int c1 = wave * 16 + l15;
+        // ---- ONE block of loads: candidate records, row statistics, MLP operands
+        EncRows<NW> rec;
+        enc_records<NW>(p, slab, wave, lane, rec);
+        float hraw[H];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) bv1[e] = (4 * kq + e < K0) ? g.w1[(long)c1 * K0 + 4 * kq + e] : 0.0f;
-    float4 w2v[S2];
+        for (int h = 0; h < H; ++h) hraw[h] = g.head[h];
+        float st_k[NP], st_k1[NP], st_min[NP];
 #pragma unroll
-    for (int s = 0; s < S2; ++s) w2v[s] = *reinterpret_cast<const float4*>(g.w2 + (long)c1 * D + 16 * s + 4 * kq);
-    const float bias1 = g.b1[c1], bias2 = g.b2[c1];
-    EncCand cd[ER / NW];
-    enc_gather<NW>(g, b, slab, wave, lane, cd);
-    float st_k[ER / NW], st_k1[ER / NW], st_min[ER / NW];
+        for (int ps = 0; ps < NP; ++ps) {
+            const int n = slab * ER + ps * NW + wave, nn = n < p.n_out ? n : p.n_out - 1;
+            st_k[ps] = p.stats[nn]; st_k1[ps] = p.stats[p.n_out + nn]; st_min[ps] = p.stats[2 * (long)p.n_out + nn];
+        }
+        float bv1[4];
 #pragma unroll
-    for (int ps = 0; ps < ER / NW; ++ps) {
-        const int n = slab * ER + ps * NW + wave, nn = n < p.n_out ? n : p.n_out - 1;
-        st_k[ps] = p.stats[nn]; st_k1[ps] = p.stats[p.n_out + nn]; st_min[ps] = p.stats[2 * (long)p.n_out + nn];
-    }
-    for (int e = tid; e < ER * XP; e += NT) xs[e] = 0.0f;
-    float c[H];
-    head_scales<H>(g.head, g.head_is_scale, c);
-    __syncthreads();
-    // ---- down-projection: one row per wave and pass
+        for (int e = 0; e < 4; ++e) bv1[e] = ldg_if(g.w1, (long)c1 * K0 + 4 * kq + e, 4 * kq + e < K0);
+        float4 w2v[S2];
 #pragma unroll
-    for (int ps = 0; ps < ER / NW; ++ps) {
-        const int row_l = ps * NW + wave, n = slab * ER + row_l;
+        for (int s = 0; s < S2; ++s) w2v[s] = *reinterpret_cast<const float4*>(g.w2 + (long)c1 * D + 16 * s + 4 * kq);
+        const float bias1 = g.b1[c1], bias2 = g.b2[c1];
+        // ---- second round trip: the candidates' value channels
+        float v[NP][EC];
+        enc_values<NW, EC>(g, b, lane, rec, v);
+        // (this wave's rows of the tile: cleared by the wave itself, in order with its own writes below)
+        for (int e = lane; e < NP * XP; e += 64) xs[((e / XP) * NW + wave) * XP + e % XP] = 0.0f;
+        float c[H];
+        head_scales<H>(hraw, g.head_is_scale, c);
+        // ---- down-projection: one row per wave and pass
 #pragma unroll
-        for (int h = 0; h < H; ++h) {
-            const float T = quantile_lerp(__fmul_rn(c[h], st_k[ps]), __fmul_rn(c[h], st_k1[ps]), p.rank_w);
-            const float smin = __fmul_rn(c[h], st_min[ps]);
-            const float sv = __fmul_rn(cd[ps].m, c[h]);
-            const bool keep = cd[ps].valid && sv <= T;
-            const float pv = keep ? __expf(smin - sv) : 0.0f;
-            const float rs = wave_sum(pv), qsum = wave_sum(pv * cd[ps].m);
-            const float inv = rs > 0.0f ? 1.0f / rs : 0.0f;
+        for (int ps = 0; ps < NP; ++ps) {
+            const int row_l = ps * NW + wave, n = slab * ER + row_l;
+            const bool valid = lane < min(rec.cnt[ps], p.cap);
 #pragma unroll
-            for (int cc = 0; cc < EC; ++cc) {
-                if (cc >= dc) break;
-                const float o = wave_sum(pv * cd[ps].v[cc]) * inv;
-                if (lane == 0) {
-                    xs[row_l * XP + h * dc + cc] = o;
-                    if (g.x && n < p.n_out) g.x[(row0 + row_l) * K0 + h * dc + cc] = o;
+            for (int h = 0; h < H; ++h) {
+                const float T = quantile_lerp(__fmul_rn(c[h], st_k[ps]), __fmul_rn(c[h], st_k1[ps]), p.rank_w);
+                const float smin = __fmul_rn(c[h], st_min[ps]);
+                const float sv = __fmul_rn(rec.m[ps], c[h]);
+                const bool keep = valid && sv <= T;
+                const float pv = keep ? __expf(smin - sv) : 0.0f;
+                const float rs = wave_sum(pv), qsum = wave_sum(pv * rec.m[ps]);
+                const float inv = rs > 0.0f ? 1.0f / rs : 0.0f;
+                float o[EC];
+#pragma unroll
+                for (int cc = 0; cc < EC; ++cc) o[cc] = wave_sum(pv * v[ps][cc]) * inv;
+                if (lane < dc) {                                 // lane cc keeps channel cc
+                    float mine_o = o[0];
+#pragma unroll
+                    for (int cc = 1; cc < EC; ++cc) mine_o = lane == cc ? o[cc] : mine_o;
+                    xs[row_l * XP + h * dc + lane] = mine_o;
+                    if (g.x && n < p.n_out) g.x[(row0 + row_l) * K0 + h * dc + lane] = mine_o;
+                }
+                if (lane == 0 && n < p.n_out && b == 0 && g.rowstat) {
+                    float4 st; st.x = T; st.y = smin; st.z = inv; st.w = qsum * inv;
+                    *reinterpret_cast<float4*>(g.rowstat + ((long)h * p.n_out + n) * 4) = st;
+                    if (n == 0 && g.scale_out) g.scale_out[h] = c[h];
                 }
             }
-            if (lane == 0 && n < p.n_out && b == 0 && g.rowstat) {
-                float4 st; st.x = T; st.y = smin; st.z = inv; st.w = qsum * inv;
-                *reinterpret_cast<float4*>(g.rowstat + ((long)h * p.n_out + n) * 4) = st;
-                if (n == 0 && g.scale_out) g.scale_out[h] = c[h];
+        }
+        __syncthreads();
+        // ---- encoder MLP (pit.py:110-111): one 16-k step for the first layer (K0 <= 16)
+        {
+            const float4 a = *reinterpret_cast<const float4*>(xs + l15 * XP + 4 * kq);
+            f32x4_t a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+            a0 = mfma_16x16x4(a.x, bv1[0], a0);
+            a1 = mfma_16x16x4(a.y, bv1[1], a1);
+            a0 = mfma_16x16x4(a.z, bv1[2], a0);
+            a1 = mfma_16x16x4(a.w, bv1[3], a1);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = 4 * kq + i;
+                const float z = a0[i] + a1[i] + bias1;
+                const float hv = gelu_erf(z);
+                hs[r * HP + c1] = hv;
+                if (g.z1 && slab * ER + r < p.n_out) {
+                    g.z1[(row0 + r) * D + c1] = z;
+                    g.h[(row0 + r) * D + c1] = hv;
+                }
             }
         }
-    }
-    __syncthreads();
-    // ---- encoder MLP (pit.py:110-111): one 16-k step for the first layer (K0 <= 16)
-    {
-        const float4 a = *reinterpret_cast<const float4*>(xs + l15 * XP + 4 * kq);
-        f32x4_t a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
-        a0 = mfma_16x16x4(a.x, bv1[0], a0);
-        a1 = mfma_16x16x4(a.y, bv1[1], a1);
-        a0 = mfma_16x16x4(a.z, bv1[2], a0);
-        a1 = mfma_16x16x4(a.w, bv1[3], a1);
+        __syncthreads();
+        f32x4_t o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < S2; ++s) {
+            const float4 a = *reinterpret_cast<const float4*>(hs + l15 * HP + 16 * s + 4 * kq);
+            o0 = mfma_16x16x4(a.x, w2v[s].x, o0);
+            o1 = mfma_16x16x4(a.y, w2v[s].y, o1);
+            o0 = mfma_16x16x4(a.z, w2v[s].z, o0);
+            o1 = mfma_16x16x4(a.w, w2v[s].w, o1);
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int r = 4 * kq + i;
-            const float z = a0[i] + a1[i] + bias1;
-            const float hv = gelu_erf(z);
-            hs[r * HP + c1] = hv;
-            if (g.z1 && slab * ER + r < p.n_out) {
-                g.z1[(row0 + r) * D + c1] = z;
-                g.h[(row0 + r) * D + c1] = hv;
-            }
+            if (slab * ER + r >= p.n_out) continue;
+            const float vv = o0[i] + o1[i] + bias2;
+            if (g.z2) g.z2[(row0 + r) * D + c1] = vv;
+            g.y[(row0 + r) * g.ldy + c1] = gelu_erf(vv);
         }
     }
-    __syncthreads();
-    f32x4_t o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int s = 0; s < S2; ++s) {
-        const float4 a = *reinterpret_cast<const float4*>(hs + l15 * HP + 16 * s + 4 * kq);
-        o0 = mfma_16x16x4(a.x, w2v[s].x, o0);
-        o1 = mfma_16x16x4(a.y, w2v[s].y, o1);
-        o0 = mfma_16x16x4(a.z, w2v[s].z, o0);
-        o1 = mfma_16x16x4(a.w, w2v[s].w, o1);
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int r = 4 * kq + i;
-        if (slab * ER + r >= p.n_out) continue;
-        const float v = o0[i] + o1[i] + bias2;
-        if (g.z2) g.z2[(row0 + r) * D + c1] = v;
-        g.y[(row0 + r) * g.ldy + c1] = gelu_erf(v);
+    if (g.clear_buf) {                                          // the step's gradient accumulators (engine.TrainStep): zeroed on the way out,
+        const long nthreads = (long)g.n_att * NT;               // long before the first backward launch adds to them
+        for (long i = (long)blockIdx.x * NT + tid; i < g.clear_n; i += nthreads) g.clear_buf[i] = 0.0f;
     }
 }
 
 // ------------------------------------------------------------------------------------------------ encoder backward
-template <int H, int D>
+template <int H, int D, int EC>
 __global__ __launch_bounds__(4 * D) void encoder_bwd_kernel(EncArgs g) {
-    constexpr int NT = 4 * D, NW = D / 16, S = D / 16, P1 = D + 4, XP = 20;
+    constexpr int NT = 4 * D, NW = D / 16, S = D / 16, P1 = D + 4, XP = 20, NP = ER / NW;
     __shared__ __attribute__((aligned(16))) float ds2[ER * P1];
     __shared__ __attribute__((aligned(16))) float ds1[ER * P1];
     __shared__ __attribute__((aligned(16))) float dxs[ER * XP];
@@ -730,47 +891,48 @@ __global__ __launch_bounds__(4 * D) void encoder_bwd_kernel(EncArgs g) {
     const long rows = (long)g.batch * p.n_out;
     const int dc = g.kd + g.dv, K0 = H * dc;
     const int c1 = wave * 16 + l15;
-    // ---- requested first: W2 (B(k, n) = w2[k][n]) and W1 (B(k, n) = w1[k][n], n < K0: wave 0) fragments, gelu' arguments, d_y
-    float w2v[S][4], w1x[S][4];
+    // ---- ONE block of loads: candidate records + saved row statistics, d_y and the gelu' arguments, W2 (B(k, n) = w2[k][n])
+    EncRows<NW> rec;
+    enc_records<NW>(p, slab, wave, lane, rec);
+    float4 rs4[NP][H];
 #pragma unroll
-    for (int s = 0; s < S; ++s)
+    for (int ps = 0; ps < NP; ++ps) {
+        const int n = slab * ER + ps * NW + wave, nn = n < p.n_out ? n : p.n_out - 1;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int k = 16 * s + 4 * kq + e;
-            w2v[s][e] = g.w2[(long)k * D + c1];
-            w1x[s][e] = (wave == 0 && l15 < K0) ? g.w1[(long)k * K0 + l15] : 0.0f;
-        }
-    float z1v[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) z1v[i] = slab * ER + 4 * kq + i < p.n_out ? g.z1[(row0 + 4 * kq + i) * D + c1] : 0.0f;
-    float dyv[4], z2v[4];
+        for (int h = 0; h < H; ++h) rs4[ps][h] = *reinterpret_cast<const float4*>(g.rowstat + ((long)h * p.n_out + nn) * 4);
+    }
+    float dyv[4], z2v[4], z1v[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         const int e = tid + u * NT, r = e / D, cc = e % D;
         const bool ok = slab * ER + r < p.n_out;
-        dyv[u] = ok ? g.d_y[(row0 + r) * g.ld_dy + cc] : 0.0f;
-        z2v[u] = ok ? g.z2[(row0 + r) * D + cc] : 0.0f;
+        dyv[u] = ldg_if(g.d_y, (row0 + r) * g.ld_dy + cc, ok);
+        z2v[u] = ldg_if(g.z2, (row0 + r) * D + cc, ok);
     }
-    EncCand cd[ER / NW];
-    float4 rs4[ER / NW][H];
-    if (g.dscale) {
-        enc_gather<NW>(g, b, slab, wave, lane, cd);
 #pragma unroll
-        for (int ps = 0; ps < ER / NW; ++ps) {
-            const int n = slab * ER + ps * NW + wave, nn = n < p.n_out ? n : p.n_out - 1;
+    for (int i = 0; i < 4; ++i) z1v[i] = ldg_if(g.z1, (row0 + 4 * kq + i) * D + c1, slab * ER + 4 * kq + i < p.n_out);
+    float w2v[S][4];
 #pragma unroll
-            for (int h = 0; h < H; ++h) rs4[ps][h] = *reinterpret_cast<const float4*>(g.rowstat + ((long)h * p.n_out + nn) * 4);
-        }
-    }
+    for (int s = 0; s < S; ++s)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w2v[s][e] = g.w2[(long)(16 * s + 4 * kq + e) * D + c1];
+    // ---- second round trip: the candidates' value channels
+    float v[NP][EC];
+    enc_values<NW, EC>(g, b, lane, rec, v);
     // ---- dZ2 = dY * gelu'(Z2)
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         const int e = tid + u * NT, r = e / D, cc = e % D;
-        const float v = dyv[u] * gelu_erf_grad(z2v[u]);
-        ds2[r * P1 + cc] = v;
-        if (slab * ER + r < p.n_out) g.scratch[rows * D + (row0 + r) * D + cc] = v;
+        const float vv = dyv[u] * gelu_erf_grad(z2v[u]);
+        ds2[r * P1 + cc] = vv;
+        if (slab * ER + r < p.n_out) g.scratch[rows * D + (row0 + r) * D + cc] = vv;
     }
-    for (int e = tid; e < ER * XP; e += NT) dxs[e] = 0.0f;
+    // W1 (B(k, n) = w1[k][n], n < K0) for the one dX tile, wave 0: requested now, used after two barriers
+    float w1x[S][4];
+#pragma unroll
+    for (int s = 0; s < S; ++s)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w1x[s][e] = ldg_if(g.w1, (long)(16 * s + 4 * kq + e) * K0 + l15, wave == 0 && l15 < K0);
     __syncthreads();
     // ---- dZ1 = (dZ2 W2) * gelu'(Z1)
     {
@@ -786,13 +948,12 @@ __global__ __launch_bounds__(4 * D) void encoder_bwd_kernel(EncArgs g) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int r = 4 * kq + i;
-            const float v = (a0[i] + a1[i]) * gelu_erf_grad(z1v[i]);
-            ds1[r * P1 + c1] = v;
-            if (slab * ER + r < p.n_out) g.scratch[(row0 + r) * D + c1] = v;
+            const float vv = (a0[i] + a1[i]) * gelu_erf_grad(z1v[i]);
+            ds1[r * P1 + c1] = vv;
+            if (slab * ER + r < p.n_out) g.scratch[(row0 + r) * D + c1] = vv;
         }
     }
     __syncthreads();
-    if (!g.dscale) return;
     // ---- dX = dZ1 W1 (16 x K0 <= 16 columns): one tile, wave 0
     if (wave == 0) {
         f32x4_t o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
@@ -813,26 +974,24 @@ __global__ __launch_bounds__(4 * D) void encoder_bwd_kernel(EncArgs g) {
 #pragma unroll
     for (int h = 0; h < H; ++h) part[h] = 0.0;
 #pragma unroll
-    for (int ps = 0; ps < ER / NW; ++ps) {
+    for (int ps = 0; ps < NP; ++ps) {
         const int row_l = ps * NW + wave;
+        const bool valid = lane < min(rec.cnt[ps], p.cap);
 #pragma unroll
         for (int h = 0; h < H; ++h) {
-            const float sv = __fmul_rn(cd[ps].m, g.head[h]);
-            const bool keep = cd[ps].valid && sv <= rs4[ps][h].x;
-            const float qv = keep ? __expf(rs4[ps][h].y - sv) * rs4[ps][h].z * (cd[ps].m - rs4[ps][h].w) : 0.0f;
+            const float sv = __fmul_rn(rec.m[ps], g.head[h]);
+            const bool keep = valid && sv <= rs4[ps][h].x;
+            const float qv = keep ? __expf(rs4[ps][h].y - sv) * rs4[ps][h].z * (rec.m[ps] - rs4[ps][h].w) : 0.0f;
             float dot = 0.0f;
 #pragma unroll
-            for (int cc = 0; cc < EC; ++cc) {
-                if (cc >= dc) break;
-                dot += cd[ps].v[cc] * dxs[row_l * XP + h * dc + cc];
-            }
+            for (int cc = 0; cc < EC; ++cc) dot += v[ps][cc] * dxs[row_l * XP + min(h * dc + cc, XP - 1)];      // (v is 0 beyond dc)
             part[h] += (double)qv * (double)dot;
         }
     }
 #pragma unroll
     for (int h = 0; h < H; ++h) {
-        const double s = wave_sum_d(part[h]);
-        if (lane == 0) wred[wave * H + h] = s;
+        const double sum = wave_sum_d(part[h]);
+        if (lane == 0) wred[wave * H + h] = sum;
     }
     __syncthreads();
     if (tid < H) {
@@ -851,12 +1010,14 @@ bool plan_ok(const pit_slab_plan* p, bool needs_union) {
 }
 bool hid_ok(int n_head, int dim) { return (n_head == 1 || n_head == 2) && (dim == 32 || dim == 64); }
 
+// slots of the union tiles a launch reserves in LDS (what decides how many workgroups a CU holds: Darcy's decoder backward takes
+// 30 KB at 32 slots, 39 KB at 48 - four or more workgroups per CU, all 928 resident at once - and 47 KB at 64: three, a second round)
+int union_slots(int max_union) { return max_union <= 32 ? 32 : (max_union <= 48 ? 48 : 64); }
 template <int H, int D>
-constexpr size_t dec_fwd_smem() { return (size_t)(H * ER * EUP + EU * (D + 4) + ER * (H * D + 4) + ER * (D + 4) + 4 * D + 4 + EU) * 4; }
+size_t dec_fwd_smem(int um) { return (size_t)(H * ER * (um + 4) + um * (D + 4) + ER * (H * D + 4) + ER * (D + 4) + 4 * D + 4) * 4; }
 template <int H, int D>
-constexpr size_t dec_bwd_smem() {
-    return (size_t)(EU * PTP + H * ER * EUP + EU * (D + 4) + ER * (D + 4) + ER * (H * D + 4) + 4 * D + ER * 4) * 4 + (size_t)(D / 16) * H * 8 +
-           8 * 4 + EU * 4;
+size_t dec_bwd_smem(int um) {
+    return (size_t)(2 * H * ER * (um + 4) + um * (D + 4) + ER * (D + 4) + ER * (H * D + 4)) * 4 + (size_t)(D / 16) * H * 8 + EU * 4;
 }
 
 }  // namespace
@@ -898,7 +1059,8 @@ extern "C" int pit_decoder_fwd(const pit_slab_plan* plan, const float* values, l
                                float* x, float* z1, float* h, float* y, float* rowstat, float* scale_out,
                                float* zero_buf, long zero_n,
                                const float* loss_true, const float* loss_scale, const float* loss_shift, int loss_p, double* loss_part,
-                               void* stream) {
+                               int max_union, void* stream) {
+    if (max_union < 1 || max_union > EU) return PIT_ERR_UNSUPPORTED;
     if (!plan_ok(plan, true) || !values || !head || !w1 || !b1 || !w2 || !b2 || !y) return PIT_ERR_NULL;
     if (!hid_ok(n_head, dim) || n2 < 1 || n2 > 4 || batch <= 0) return PIT_ERR_UNSUPPORTED;
     if ((z1 == nullptr) != (h == nullptr)) return PIT_ERR_NULL;
@@ -909,12 +1071,15 @@ extern "C" int pit_decoder_fwd(const pit_slab_plan* plan, const float* values, l
     g.head = head; g.head_is_scale = head_is_scale; g.w1 = w1; g.b1 = b1; g.w2 = w2; g.b2 = b2; g.n2 = n2;
     g.x = x; g.z1 = z1; g.h = h; g.y = y; g.rowstat = rowstat; g.scale_out = scale_out; g.zero_buf = zero_buf; g.zero_n = zero_buf ? zero_n : 0;
     g.tru = loss_true; g.lscale = loss_scale; g.lshift = loss_shift; g.loss_p = loss_p; g.lpart = loss_part;
+    g.um = union_slots(max_union);
     const dim3 grid((unsigned)slab_grid(batch, plan->n_slabs));
     hipStream_t s = (hipStream_t)stream;
 #define PIT_DF(H_, D_)                                                                                                    \
     do {                                                                                                                  \
-        if (plan->cap <= 32) hipLaunchKernelGGL((decoder_fwd_kernel<H_, D_, 32>), grid, dim3(4 * D_), (dec_fwd_smem<H_, D_>()), s, g); \
-        else hipLaunchKernelGGL((decoder_fwd_kernel<H_, D_, 64>), grid, dim3(4 * D_), (dec_fwd_smem<H_, D_>()), s, g);       \
+        if (plan->cap <= 32) { if (loss_part) hipLaunchKernelGGL((decoder_fwd_kernel<H_, D_, 32, true>), grid, dim3(4 * D_), (dec_fwd_smem<H_, D_>(g.um)), s, g); \
+                               else hipLaunchKernelGGL((decoder_fwd_kernel<H_, D_, 32, false>), grid, dim3(4 * D_), (dec_fwd_smem<H_, D_>(g.um)), s, g); } \
+        else { if (loss_part) hipLaunchKernelGGL((decoder_fwd_kernel<H_, D_, 64, true>), grid, dim3(4 * D_), (dec_fwd_smem<H_, D_>(g.um)), s, g); \
+               else hipLaunchKernelGGL((decoder_fwd_kernel<H_, D_, 64, false>), grid, dim3(4 * D_), (dec_fwd_smem<H_, D_>(g.um)), s, g); } \
     } while (0)
     PIT_EDGE_DISPATCH(n_head, dim, PIT_DF);
 #undef PIT_DF
@@ -928,7 +1093,8 @@ extern "C" int pit_decoder_bwd(const pit_slab_plan* plan, const float* values, l
                                const float* d_y, long ld_dy, float* dz1, float* d_values, long dvalues_bstride, double* dscale,
                                const float* loss_pred, const float* loss_true, const float* loss_scale, const float* loss_shift,
                                const float* loss_seed, int loss_p, const double* loss_part, float* d_pred, float* loss_out,
-                               float* norms_out, void* stream) {
+                               float* norms_out, int max_union, void* stream) {
+    if (max_union < 1 || max_union > EU) return PIT_ERR_UNSUPPORTED;
     if (!plan_ok(plan, true) || !values || !scale || !rowstat || !w1 || !w2 || !z1 || !dz1 || !d_values) return PIT_ERR_NULL;
     if (!hid_ok(n_head, dim) || n2 < 1 || n2 > 4 || batch <= 0) return PIT_ERR_UNSUPPORTED;
     if (!d_y && (!loss_pred || !loss_true || !loss_part || !d_pred || !loss_out || (loss_p != 1 && loss_p != 2) ||
@@ -941,12 +1107,15 @@ extern "C" int pit_decoder_bwd(const pit_slab_plan* plan, const float* values, l
     g.dz1 = dz1; g.d_values = d_values; g.dvalues_bstride = dvalues_bstride; g.dscale = dscale;
     g.pred = loss_pred; g.tru = loss_true; g.lscale = loss_scale; g.lshift = loss_shift; g.gseed = loss_seed; g.loss_p = loss_p;
     g.lpart = loss_part; g.d_pred = d_pred; g.loss_out = loss_out; g.norms_out = norms_out;
+    g.um = union_slots(max_union);
     const dim3 grid((unsigned)slab_grid(batch, plan->n_slabs));
     hipStream_t s = (hipStream_t)stream;
 #define PIT_DB(H_, D_)                                                                                                    \
     do {                                                                                                                  \
-        if (plan->cap <= 32) hipLaunchKernelGGL((decoder_bwd_kernel<H_, D_, 32>), grid, dim3(4 * D_), (dec_bwd_smem<H_, D_>()), s, g); \
-        else hipLaunchKernelGGL((decoder_bwd_kernel<H_, D_, 64>), grid, dim3(4 * D_), (dec_bwd_smem<H_, D_>()), s, g);       \
+        if (plan->cap <= 32) { if (!d_y) hipLaunchKernelGGL((decoder_bwd_kernel<H_, D_, 32, true>), grid, dim3(4 * D_), (dec_bwd_smem<H_, D_>(g.um)), s, g); \
+                               else hipLaunchKernelGGL((decoder_bwd_kernel<H_, D_, 32, false>), grid, dim3(4 * D_), (dec_bwd_smem<H_, D_>(g.um)), s, g); } \
+        else { if (!d_y) hipLaunchKernelGGL((decoder_bwd_kernel<H_, D_, 64, true>), grid, dim3(4 * D_), (dec_bwd_smem<H_, D_>(g.um)), s, g); \
+               else hipLaunchKernelGGL((decoder_bwd_kernel<H_, D_, 64, false>), grid, dim3(4 * D_), (dec_bwd_smem<H_, D_>(g.um)), s, g); } \
     } while (0)
     PIT_EDGE_DISPATCH(n_head, dim, PIT_DB);
 #undef PIT_DB
@@ -959,7 +1128,7 @@ int fill_enc(EncArgs& g, const pit_slab_plan* plan, const float* mesh_in, int sp
              long ld_values, long values_bstride, int dv, int batch, int n_head, int dim) {
     if (!plan_ok(plan, false) || !mesh_in || !values) return PIT_ERR_NULL;
     if (!hid_ok(n_head, dim) || batch <= 0 || space_dim < 1 || space_dim > 3 || coord_dims < 0 || coord_dims > space_dim || dv < 0 ||
-        coord_dims + dv < 1 || coord_dims + dv > EC || n_head * (coord_dims + dv) > 16) return PIT_ERR_UNSUPPORTED;
+        coord_dims + dv < 1 || coord_dims + dv > 8 || n_head * (coord_dims + dv) > 16) return PIT_ERR_UNSUPPORTED;
     g = EncArgs();
     g.p = *plan; g.mesh_in = mesh_in; g.sdim = space_dim; g.kd = coord_dims; g.values = values; g.ld_values = ld_values;
     g.values_bstride = values_bstride; g.dv = dv; g.batch = batch;
@@ -992,7 +1161,8 @@ extern "C" int pit_encoder_fwd(const pit_slab_plan* plan, const float* mesh_in, 
     }
     const dim3 grid((unsigned)(g.n_att + n_w));
     hipStream_t s = (hipStream_t)stream;
-#define PIT_EF(H_, D_) hipLaunchKernelGGL((encoder_fwd_kernel<H_, D_>), grid, dim3(4 * D_), 0, s, g, wa)
+#define PIT_EF(H_, D_) do { if (coord_dims + value_dim <= 4) hipLaunchKernelGGL((encoder_fwd_kernel<H_, D_, 4>), grid, dim3(4 * D_), 0, s, g, wa); \
+                            else hipLaunchKernelGGL((encoder_fwd_kernel<H_, D_, 8>), grid, dim3(4 * D_), 0, s, g, wa); } while (0)
     PIT_EDGE_DISPATCH(n_head, dim, PIT_EF);
 #undef PIT_EF
     PIT_CHECK_LAUNCH();
@@ -1011,15 +1181,22 @@ extern "C" int pit_encoder_bwd(const pit_slab_plan* plan, const float* mesh_in, 
     EncArgs g;
     if (int rc = fill_enc(g, plan, mesh_in, space_dim, coord_dims, values, ld_values, values_bstride, value_dim, batch, n_head, dim)) return rc;
     if (!w1 || !w2 || !z1 || !z2 || !d_y || !scratch) return PIT_ERR_NULL;
-    if (dscale && (!scale || !rowstat || !aligned16(rowstat))) return PIT_ERR_NULL;
+    if (!dscale || !scale || !rowstat || !aligned16(rowstat)) return PIT_ERR_NULL;
     if (ld_dy < dim) return PIT_ERR_SIZE;
     g.head = scale; g.head_is_scale = 1; g.rowstat = const_cast<float*>(rowstat); g.w1 = w1; g.w2 = w2;
     g.z1 = const_cast<float*>(z1); g.z2 = const_cast<float*>(z2); g.d_y = d_y; g.ld_dy = ld_dy; g.scratch = scratch; g.dscale = dscale;
     const dim3 grid((unsigned)slab_grid(batch, plan->n_slabs));
     hipStream_t s = (hipStream_t)stream;
-#define PIT_EB(H_, D_) hipLaunchKernelGGL((encoder_bwd_kernel<H_, D_>), grid, dim3(4 * D_), 0, s, g)
+#define PIT_EB(H_, D_) do { if (coord_dims + value_dim <= 4) hipLaunchKernelGGL((encoder_bwd_kernel<H_, D_, 4>), grid, dim3(4 * D_), 0, s, g); \
+                            else hipLaunchKernelGGL((encoder_bwd_kernel<H_, D_, 8>), grid, dim3(4 * D_), 0, s, g); } while (0)
     PIT_EDGE_DISPATCH(n_head, dim, PIT_EB);
 #undef PIT_EB
     PIT_CHECK_LAUNCH();
     return 0;
 }
+
+#if PIT_EDGE_DBG & 0x100
+extern "C" int pit_edge_read_stamps(unsigned long long* host) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(pit_edge_stamps), sizeof(unsigned long long) * 64);
+}
+#endif

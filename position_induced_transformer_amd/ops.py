@@ -1431,7 +1431,8 @@ class _Decoder(torch.autograd.Function):
                                         k_head.data_ptr(), 1 if k_is_scale else 0, w1c.data_ptr(), b1c.data_ptr(), w2c.data_ptr(),
                                         b2c.data_ptr(), n2, _lib.ptr(x), _lib.ptr(z1), _lib.ptr(h), y.data_ptr(), _lib.ptr(rowstat),
                                         _lib.ptr(scale), _lib.ptr(dvals), dvals.numel() if dvals is not None else 0,
-                                        _lib.ptr(lt), _lib.ptr(ls), _lib.ptr(lh), lp, _lib.ptr(lpart), _lib.stream_ptr())
+                                        _lib.ptr(lt), _lib.ptr(ls), _lib.ptr(lh), lp, _lib.ptr(lpart), plan.slab_plan()[1],
+                                        _lib.stream_ptr())
         _lib.check(rc, "pit_decoder_fwd")
         ctx.plan, ctx.n_head, ctx.head_is_scale, ctx.head_param, ctx.params = plan, n_head, head_is_scale, head_param, params
         ctx.loss = loss if lpart is not None else None
@@ -1482,7 +1483,7 @@ class _Decoder(torch.autograd.Function):
                                _lib.ptr(loss.scale) if inside else None, _lib.ptr(loss.shift) if inside else None,
                                _lib.ptr(loss.seed) if inside else None, loss.p if inside else 0,
                                _lib.ptr(loss.partials) if inside else None, d_pred.data_ptr() if inside else None,
-                               loss.value.data_ptr() if inside else None, None, _lib.stream_ptr())
+                               loss.value.data_ptr() if inside else None, None, plan.slab_plan()[1], _lib.stream_ptr())
         _lib.check(rc, "pit_decoder_bwd")
         d_head = None
         if need_h:
@@ -1595,11 +1596,10 @@ class _Encoder(torch.autograd.Function):
         need_h = ctx.needs_input_grad[1]
         slot = _grad_slot(ctx.head_param) if need_h else None
         defer = DEFER_HEAD_FINISH and slot is not None
-        work = None
-        if need_h:
-            work = _layer_workspace(slot, n_head) if defer else torch.zeros(n_head * 1024, device=dev, dtype=torch.float64)
-            if defer:
-                _defer_head_begin(work)
+        # (the launch always reduces d(scale): accumulators of its own when lmda needs no gradient)
+        work = _layer_workspace(slot, n_head) if defer else torch.zeros(n_head * 1024, device=dev, dtype=torch.float64)
+        if defer:
+            _defer_head_begin(work)
         rc = _lib.lib().pit_encoder_bwd(ctypes.byref(sp), plan.mesh_in.data_ptr(), plan.sdim, kd, values.data_ptr(), values.stride(1),
                                         values.stride(0), dv, b, n_head, d, scale.data_ptr(), rowstat.data_ptr(), w1.data_ptr(),
                                         w2.data_ptr(), z1.data_ptr(), z2.data_ptr(), d_y2.data_ptr(), d_y2.stride(0),
