@@ -236,10 +236,12 @@ int pit_posatt_bwd(const float* mesh_out, const float* mesh_in, int mesh_batch, 
  * launch: per layer l drains workspaces[l] (n_heads[l]*PIT_DSCALE_SLOTS doubles, left zero), applies
  * d c / d lmda (heads[l] = lmda, scales[l] = the forward's c or NULL to recompute; with
  * PIT_HEAD_IS_SCALE in flags[l] the result is d c itself) and writes or (PIT_HEAD_ACCUMULATE) adds to
- * d_heads[l].  The arrays are HOST arrays of device pointers / ints, read during the call. */
+ * d_heads[l].  The arrays are HOST arrays of device pointers / ints, read during the call.
+ * rider (ABI 17): NULL, or a postponed pit_mlp_bwd_params the pass has no later launch for (the encoder MLP's, when its fused
+ * backward is the pass's last launch): performed by extra workgroups of this launch when small, else by its own launches. */
 int pit_posatt_dhead_finish(int n_layers, double* const* workspaces, float* const* d_heads,
                             const float* const* heads, const float* const* scales, const int* n_heads,
-                            const int* flags, void* stream);
+                            const int* flags, const pit_mlp_params_job* rider, void* stream);
 
 /* ---- Fused processor blocks (batch-free meshes, small regime; csrc/pit_block.hip) ------------------------------
  * pit.processor (pit.py:114-122) is n_blocks x [posatt.forward (self attention on the latent mesh, locality 1.0:

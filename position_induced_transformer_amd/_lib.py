@@ -66,7 +66,7 @@ SIGNATURES = {
                        _P, _L, _L, _I,
                        _P, _L, _L, _I,
                        _P, _I, _P, _P, _P, _I, _I, _P, _P, _P, _I, _I, _P],
-    "pit_posatt_dhead_finish": [_I, _P, _P, _P, _P, _P, _P, _P],
+    "pit_posatt_dhead_finish": [_I, _P, _P, _P, _P, _P, _P, _P, _P],
     "pit_block_supported": [_I, _I, _I, _I],
     "pit_block_weights": [_P, _I, _I, _I, _F, _I, _P, _I, _I, _P, _P, _P, _P, _P, _P],
     "pit_block_fwd": [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _L, _I, _P],

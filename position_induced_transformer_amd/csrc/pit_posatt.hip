@@ -126,8 +126,7 @@ struct FinishBatch {
     int flags[FINISH_MAX_LAYERS];            // PIT_HEAD_ACCUMULATE | PIT_HEAD_IS_SCALE
     int wg_base[FINISH_MAX_LAYERS + 1];
 };
-__global__ __launch_bounds__(256) void posatt_dhead_finish_batch(FinishBatch fb) {
-    __shared__ double s_red[10];
+__device__ __forceinline__ void finish_batch_body(const FinishBatch& fb, double* s_red) {
     int l = 0;
     while (l + 1 < fb.n && (int)blockIdx.x >= fb.wg_base[l + 1]) ++l;
     AttArgs a = AttArgs();
@@ -140,6 +139,17 @@ __global__ __launch_bounds__(256) void posatt_dhead_finish_batch(FinishBatch fb)
     a.head = fb.scale[l] ? fb.scale[l] : fb.head[l];
     a.head_is_scale = (fb.scale[l] || a.dhead_is_scale) ? 1 : 0;
     dscale_drain_head(a, (int)blockIdx.x - fb.wg_base[l], s_red);
+}
+__global__ __launch_bounds__(256) void posatt_dhead_finish_batch(FinishBatch fb) {
+    __shared__ double s_red[10];
+    finish_batch_body(fb, s_red);
+}
+// the same launch carrying a postponed MLP's weight-gradient reductions (round 5: the encoder MLP's, whose fused backward launch
+// is the pass's last one - nothing else is left to carry them): workgroups [0, n_fin) drain, the rest reduce
+__global__ __launch_bounds__(256) void posatt_dhead_finish_dw(FinishBatch fb, int n_fin, pit_detail::DwPair w) {
+    __shared__ double s_red[10];
+    if ((int)blockIdx.x < n_fin) { finish_batch_body(fb, s_red); return; }
+    dw_pair_body(w, (int)blockIdx.x - n_fin, pit_dyn_smem());
 }
 
 constexpr int KEY_CHUNK = 2048;   // keys staged in LDS per pass (float4 each = 32 KiB)
@@ -3342,8 +3352,14 @@ extern "C" int pit_debug_read_stamps(unsigned long long* host64) {
 
 extern "C" int pit_posatt_dhead_finish(int n_layers, double* const* workspaces, float* const* d_heads,
                                        const float* const* heads, const float* const* scales, const int* n_heads,
-                                       const int* flags, void* stream) {
-    if (n_layers <= 0) return 0;
+                                       const int* flags, const pit_mlp_params_job* rider, void* stream) {
+    auto run_rider = [&]() -> int {
+        if (!rider) return 0;
+        return pit_mlp_bwd_params(rider->x, rider->ldx, rider->rows, rider->n0, rider->n1, rider->n2, rider->h, rider->out_gelu,
+                                  rider->d_y, rider->ld_dy, rider->d_w1, rider->d_b1, rider->d_w2, rider->d_b2, rider->accumulate,
+                                  rider->scratch, rider->math_mode, stream);
+    };
+    if (n_layers <= 0) return run_rider();
     if (n_layers > FINISH_MAX_LAYERS) return PIT_ERR_SIZE;
     if (!workspaces || !d_heads || !heads || !scales || !n_heads || !flags) return PIT_ERR_NULL;
     FinishBatch fb;
@@ -3358,7 +3374,14 @@ extern "C" int pit_posatt_dhead_finish(int n_layers, double* const* workspaces, 
         total += n_heads[l];
     }
     fb.wg_base[n_layers] = total;
+    pit_detail::DwPair dw;
+    if (rider && pit_detail::plan_dw_pair(*rider, 4, &dw)) {           // small enough to share the launch
+        hipLaunchKernelGGL(posatt_dhead_finish_dw, dim3((unsigned)(total + dw.n1 + dw.n2)), dim3(256), DW_SMEM_4WAVES,
+                           (hipStream_t)stream, fb, total, dw);
+        PIT_CHECK_LAUNCH();
+        return 0;
+    }
     hipLaunchKernelGGL(posatt_dhead_finish_batch, dim3(total), dim3(256), 0, (hipStream_t)stream, fb);
     PIT_CHECK_LAUNCH();
-    return 0;
+    return run_rider();
 }

@@ -114,11 +114,18 @@ def _flush_head_finishes(task: int) -> None:
         if key not in seen:
             seen.add(key)
             pend.append(entry)
+    # a weight-gradient job the pass still holds (the encoder MLP's: its fused backward is the pass's last launch, nobody is left
+    # to carry it) rides in the finishing launch when it sits on the same device and stream
+    job = _PENDING_DW.get(task)
     for dev in sorted({p[0].device.index for p in pend}):
         grp = [p for p in pend if p[0].device.index == dev]
         for i in range(0, len(grp), 32):
             part = grp[i:i + 32]
             n = len(part)
+            rider = None
+            if job is not None and job[2].device.index == dev and job[2] == torch.cuda.current_stream(job[2].device):
+                rider, job = job, None
+                _PENDING_DW[task] = None
             ws = (ctypes.c_void_p * n)(*[p[0].data_ptr() for p in part])
             dh = (ctypes.c_void_p * n)(*[p[1].data_ptr() for p in part])
             hd = (ctypes.c_void_p * n)(*[p[2].data_ptr() for p in part])
@@ -126,7 +133,9 @@ def _flush_head_finishes(task: int) -> None:
             nh = (ctypes.c_int * n)(*[p[4] for p in part])
             fl = (ctypes.c_int * n)(*[p[5] for p in part])
             with torch.cuda.device(dev):
-                rc = _lib.lib().pit_posatt_dhead_finish(n, ws, dh, hd, sc, nh, fl, _lib.stream_ptr())
+                rc = _lib.lib().pit_posatt_dhead_finish(n, ws, dh, hd, sc, nh, fl,
+                                                        ctypes.cast(ctypes.pointer(rider[0]), ctypes.c_void_p) if rider is not None else None,
+                                                        _lib.stream_ptr())
             _lib.check(rc, "pit_posatt_dhead_finish")
 
 
@@ -1068,7 +1077,7 @@ class _PosAttPre(torch.autograd.Function):
                 d_head = slot if slot is not None else torch.empty((n_head,), device=dev, dtype=torch.float32)
                 one = lambda t: (ctypes.c_void_p * 1)(t.data_ptr())
                 _lib.check(_lib.lib().pit_posatt_dhead_finish(1, one(work), one(d_head), one(head), one(scale), (ctypes.c_int * 1)(n_head),
-                                                              (ctypes.c_int * 1)(1 if slot is not None else 0), _lib.stream_ptr()),
+                                                              (ctypes.c_int * 1)(1 if slot is not None else 0), None, _lib.stream_ptr()),
                            "pit_posatt_dhead_finish")
                 if slot is not None:
                     d_head = None
@@ -1312,7 +1321,7 @@ class _Processor(torch.autograd.Function):
             sc = (ctypes.c_void_p * m)(*[scale[i].data_ptr() for i in now])
             nh = (ctypes.c_int * m)(*[H] * m)
             fl = (ctypes.c_int * m)(*[1 if lm_slots[i] is not None else 0 for i in now])
-            _lib.check(L_.pit_posatt_dhead_finish(m, ws, dh, hd, sc, nh, fl, _lib.stream_ptr()), "pit_posatt_dhead_finish")
+            _lib.check(L_.pit_posatt_dhead_finish(m, ws, dh, hd, sc, nh, fl, None, _lib.stream_ptr()), "pit_posatt_dhead_finish")
         grads = [dx, None, None, None, None, None]
         for i in range(n):
             g = None if lm_slots[i] is not None else d_heads[i]
@@ -1362,7 +1371,7 @@ def _finish_heads_now(work, d_head, head, scale, n_head: int, flags: int) -> Non
     """d(lmda) of ONE layer from freshly loaded accumulators, now (the gradient is returned to autograd, not accumulated in place)."""
     one = lambda t: (ctypes.c_void_p * 1)(_lib.ptr(t))
     rc = _lib.lib().pit_posatt_dhead_finish(1, one(work), one(d_head), one(head), one(scale), (ctypes.c_int * 1)(n_head),
-                                            (ctypes.c_int * 1)(flags), _lib.stream_ptr())
+                                            (ctypes.c_int * 1)(flags), None, _lib.stream_ptr())
     _lib.check(rc, "pit_posatt_dhead_finish")
 
 
