@@ -316,24 +316,25 @@ typedef struct pit_slab_plan {
     const int* idx; const int* cnt;
     const float* m; const unsigned short* slot; const int* keys; const int* nkeys;
 } pit_slab_plan;
-/* report: 2 ints, ZERO on entry (max union size, 1 if a list overflowed).  n_in <= 16384. */
+/* report: 3 ints, ZERO on entry (largest union, 1 if a list overflowed, longest list).  n_in <= 16384. */
 int pit_slab_plan_build(const float* mesh_out, const float* mesh_in, int n_out, int n_in, int space_dim, int metric, float period,
                         const int* nbr_idx, const int* nbr_cnt, int cap, float* m, unsigned short* slot, int* keys, int* nkeys,
                         int* report, void* stream);
-/* 1 when the fused launches cover this shape: n_head 1 or 2, dim (= the MLP's hidden width) 32 or 64, 256 <= batch*rows <= 32768 */
+/* 1 when the fused launches cover this shape: n_head 1 or 2, dim (= the MLP's hidden width) 32 or 64, 256 <= batch*rows <= 2^20 */
 int pit_edge_supported(int n_head, int dim, int batch, int rows_per_sample);
 /* pit.decoder forward.  values (batch, n_in, dim) rows ld_values apart; the MLP is (n_head*dim -> dim -> n2), n2 <= 4, no trailing
  * gelu; y (batch*n_out, n2).  Saved for the backward when given (all or none): x (batch*n_out, n_head*dim) the attention's output,
  * z1 / h (batch*n_out, dim), rowstat (n_head, n_out, 4), scale_out (n_head).  zero_buf: zero_n floats cleared on the way (the
  * d_values buffer pit_decoder_bwd adds to).  loss_part != NULL: the slab's partial sums of RelLpNorm(true, y*scale + shift)
  * (utils.py:86-98, p = 1 or 2) as (batch, n2, n_slabs, 2) doubles - plain stores, nothing to zero, the same bits on every run.
- * max_union: report[0] of pit_slab_plan_build (<= PIT_SLAB_UNION_MAX): sizes the launch's LDS tiles (32, 48 or 64 slots). */
+ * max_union / max_count: report[0] / report[2] of pit_slab_plan_build: size the launch's LDS tiles (32, 48 or 64 slots) and the
+ * lanes a row's candidates occupy while the weights are formed (16, 32 or 64). */
 int pit_decoder_fwd(const pit_slab_plan* plan, const float* values, long ld_values, long values_bstride, int batch,
                     int n_head, int dim, const float* head, int head_is_scale,
                     const float* w1, const float* b1, const float* w2, const float* b2, int n2,
                     float* x, float* z1, float* h, float* y, float* rowstat, float* scale_out, float* zero_buf, long zero_n,
                     const float* loss_true, const float* loss_scale, const float* loss_shift, int loss_p, double* loss_part,
-                    int max_union, void* stream);
+                    int max_union, int max_count, void* stream);
 /* pit.decoder backward: d_y (batch*n_out, n2) -> dz1 (batch*n_out, dim: the scratch of the MLP's weight-gradient reductions,
  * pit_mlp_bwd_params with d_y and this scratch), d_values (batch, n_in, dim) ADDED to (fp32 atomics; zero on entry), the layer's
  * d(scale) accumulators (PIT_HEAD_DEFER convention).  d_y == NULL: the loss inside - d(pred) is formed from loss_part (the
@@ -345,7 +346,7 @@ int pit_decoder_bwd(const pit_slab_plan* plan, const float* values, long ld_valu
                     const float* d_y, long ld_dy, float* dz1, float* d_values, long dvalues_bstride, double* dscale,
                     const float* loss_pred, const float* loss_true, const float* loss_scale, const float* loss_shift,
                     const float* loss_seed, int loss_p, const double* loss_part, float* d_pred, float* loss_out,
-                    float* norms_out, int max_union, void* stream);
+                    float* norms_out, int max_union, int max_count, void* stream);
 /* pit.encoder forward.  Value channels [0, coord_dims) are the key coordinates (mesh_in; train_darcy.py:51-55), the other
  * value_dim channels come from values (batch, n_in, value_dim); n_head*(coord_dims + value_dim) <= 16.  The MLP is
  * (n_head*(coord_dims+value_dim) -> dim -> dim) followed by gelu; y rows ldy apart (the first columns of the processor's concat

@@ -73,9 +73,9 @@ SIGNATURES = {
     "pit_slab_plan_build": [_P, _P, _I, _I, _I, _I, _F, _P, _P, _I, _P, _P, _P, _P, _P, _P],
     "pit_edge_supported": [_I, _I, _I, _I],
     "pit_decoder_fwd": [_P, _P, _L, _L, _I, _I, _I, _P, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _L,
-                        _P, _P, _P, _I, _P, _I, _P],
+                        _P, _P, _P, _I, _P, _I, _I, _P],
     "pit_decoder_bwd": [_P, _P, _L, _L, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _L, _P, _P, _L, _P,
-                        _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _P],
+                        _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _P],
     "pit_encoder_fwd": [_P, _P, _I, _I, _P, _L, _L, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P,
                         _P, _P, _P, _P, _P, _L, _P, _P, _P, _L, _P, _P],
     "pit_encoder_bwd": [_P, _P, _I, _I, _P, _L, _L, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _L, _P, _P, _P],

@@ -29,6 +29,10 @@
 #include "pit_gemm_rd.h"
 #include "pit_block_dev.h"
 
+#ifndef PIT_EDGE_MAX_ROWS
+#define PIT_EDGE_MAX_ROWS (1 << 20) // rows (batch x mesh points) up to which a layer takes the fused launch: measured faster than the per-layer
+                                   // kernels at every Darcy batch from 8 to 256 (473 k decoder rows); 32-bit buffer offsets hold to 8 M rows
+#endif
 #ifndef PIT_EDGE_DBG
 #define PIT_EDGE_DBG 0      // diagnostic builds (tools/edge_variants.sh): bits switch parts of the launches off to time them
 #endif
@@ -87,7 +91,7 @@ struct SlabBuildArgs {
     const float *mesh_out, *mesh_in;
     int n_out, n_in, sdim, used, periodic; float period;
     const int *idx, *cnt; int cap, umax;
-    float* m; unsigned short* slot; int* keys; int* nkeys; int* report;      // report[0] = max union, report[1] = 1 if a list overflowed
+    float* m; unsigned short* slot; int* keys; int* nkeys; int* report;      // report[0] = max union, [1] = 1 if a list overflowed, [2] = max count
 };
 
 __global__ __launch_bounds__(256) void slab_plan_kernel(SlabBuildArgs a) {
@@ -105,6 +109,7 @@ __global__ __launch_bounds__(256) void slab_plan_kernel(SlabBuildArgs a) {
         if (row < a.n_out) {
             const int c = a.cnt[row];
             if (c > a.cap && i == 0) atomicMax(a.report + 1, 1);
+            if (i == 0) atomicMax(a.report + 2, min(c, a.cap));
             if (i < min(c, a.cap)) {
                 const int j = a.idx[(long)row * a.cap + i];
                 const float* xo = a.mesh_out + (long)row * a.sdim;
@@ -1025,7 +1030,7 @@ size_t dec_bwd_smem(int um) {
 extern "C" int pit_edge_supported(int n_head, int dim, int batch, int rows_per_sample) {
     if (!hid_ok(n_head, dim) || batch <= 0 || rows_per_sample <= 0) return 0;
     const long rows = (long)batch * rows_per_sample;
-    return rows >= 256 && rows <= 32768;                // the latency regime; above it the per-layer kernels stream at the HBM rate
+    return rows >= 256 && rows <= PIT_EDGE_MAX_ROWS;
 }
 
 extern "C" int pit_slab_plan_build(const float* mesh_out, const float* mesh_in, int n_out, int n_in, int space_dim, int metric,
@@ -1059,8 +1064,9 @@ extern "C" int pit_decoder_fwd(const pit_slab_plan* plan, const float* values, l
                                float* x, float* z1, float* h, float* y, float* rowstat, float* scale_out,
                                float* zero_buf, long zero_n,
                                const float* loss_true, const float* loss_scale, const float* loss_shift, int loss_p, double* loss_part,
-                               int max_union, void* stream) {
-    if (max_union < 1 || max_union > EU) return PIT_ERR_UNSUPPORTED;
+                               int max_union, int max_count, void* stream) {
+    if (max_union < 1 || max_union > EU || max_count < 1 || max_count > 64) return PIT_ERR_UNSUPPORTED;
+    const int lpr = max_count <= 16 ? 16 : (max_count <= 32 ? 32 : 64);       // lanes per row of the weight formation
     if (!plan_ok(plan, true) || !values || !head || !w1 || !b1 || !w2 || !b2 || !y) return PIT_ERR_NULL;
     if (!hid_ok(n_head, dim) || n2 < 1 || n2 > 4 || batch <= 0) return PIT_ERR_UNSUPPORTED;
     if ((z1 == nullptr) != (h == nullptr)) return PIT_ERR_NULL;
@@ -1076,7 +1082,9 @@ extern "C" int pit_decoder_fwd(const pit_slab_plan* plan, const float* values, l
     hipStream_t s = (hipStream_t)stream;
 #define PIT_DF(H_, D_)                                                                                                    \
     do {                                                                                                                  \
-        if (plan->cap <= 32) { if (loss_part) hipLaunchKernelGGL((decoder_fwd_kernel<H_, D_, 32, true>), grid, dim3(4 * D_), (dec_fwd_smem<H_, D_>(g.um)), s, g); \
+        if (lpr == 16) { if (loss_part) hipLaunchKernelGGL((decoder_fwd_kernel<H_, D_, 16, true>), grid, dim3(4 * D_), (dec_fwd_smem<H_, D_>(g.um)), s, g); \
+                         else hipLaunchKernelGGL((decoder_fwd_kernel<H_, D_, 16, false>), grid, dim3(4 * D_), (dec_fwd_smem<H_, D_>(g.um)), s, g); } \
+        else if (lpr == 32) { if (loss_part) hipLaunchKernelGGL((decoder_fwd_kernel<H_, D_, 32, true>), grid, dim3(4 * D_), (dec_fwd_smem<H_, D_>(g.um)), s, g); \
                                else hipLaunchKernelGGL((decoder_fwd_kernel<H_, D_, 32, false>), grid, dim3(4 * D_), (dec_fwd_smem<H_, D_>(g.um)), s, g); } \
         else { if (loss_part) hipLaunchKernelGGL((decoder_fwd_kernel<H_, D_, 64, true>), grid, dim3(4 * D_), (dec_fwd_smem<H_, D_>(g.um)), s, g); \
                else hipLaunchKernelGGL((decoder_fwd_kernel<H_, D_, 64, false>), grid, dim3(4 * D_), (dec_fwd_smem<H_, D_>(g.um)), s, g); } \
@@ -1093,8 +1101,9 @@ extern "C" int pit_decoder_bwd(const pit_slab_plan* plan, const float* values, l
                                const float* d_y, long ld_dy, float* dz1, float* d_values, long dvalues_bstride, double* dscale,
                                const float* loss_pred, const float* loss_true, const float* loss_scale, const float* loss_shift,
                                const float* loss_seed, int loss_p, const double* loss_part, float* d_pred, float* loss_out,
-                               float* norms_out, int max_union, void* stream) {
-    if (max_union < 1 || max_union > EU) return PIT_ERR_UNSUPPORTED;
+                               float* norms_out, int max_union, int max_count, void* stream) {
+    if (max_union < 1 || max_union > EU || max_count < 1 || max_count > 64) return PIT_ERR_UNSUPPORTED;
+    const int lpr = max_count <= 16 ? 16 : (max_count <= 32 ? 32 : 64);
     if (!plan_ok(plan, true) || !values || !scale || !rowstat || !w1 || !w2 || !z1 || !dz1 || !d_values) return PIT_ERR_NULL;
     if (!hid_ok(n_head, dim) || n2 < 1 || n2 > 4 || batch <= 0) return PIT_ERR_UNSUPPORTED;
     if (!d_y && (!loss_pred || !loss_true || !loss_part || !d_pred || !loss_out || (loss_p != 1 && loss_p != 2) ||
@@ -1112,7 +1121,9 @@ extern "C" int pit_decoder_bwd(const pit_slab_plan* plan, const float* values, l
     hipStream_t s = (hipStream_t)stream;
 #define PIT_DB(H_, D_)                                                                                                    \
     do {                                                                                                                  \
-        if (plan->cap <= 32) { if (!d_y) hipLaunchKernelGGL((decoder_bwd_kernel<H_, D_, 32, true>), grid, dim3(4 * D_), (dec_bwd_smem<H_, D_>(g.um)), s, g); \
+        if (lpr == 16) { if (!d_y) hipLaunchKernelGGL((decoder_bwd_kernel<H_, D_, 16, true>), grid, dim3(4 * D_), (dec_bwd_smem<H_, D_>(g.um)), s, g); \
+                         else hipLaunchKernelGGL((decoder_bwd_kernel<H_, D_, 16, false>), grid, dim3(4 * D_), (dec_bwd_smem<H_, D_>(g.um)), s, g); } \
+        else if (lpr == 32) { if (!d_y) hipLaunchKernelGGL((decoder_bwd_kernel<H_, D_, 32, true>), grid, dim3(4 * D_), (dec_bwd_smem<H_, D_>(g.um)), s, g); \
                                else hipLaunchKernelGGL((decoder_bwd_kernel<H_, D_, 32, false>), grid, dim3(4 * D_), (dec_bwd_smem<H_, D_>(g.um)), s, g); } \
         else { if (!d_y) hipLaunchKernelGGL((decoder_bwd_kernel<H_, D_, 64, true>), grid, dim3(4 * D_), (dec_bwd_smem<H_, D_>(g.um)), s, g); \
                else hipLaunchKernelGGL((decoder_bwd_kernel<H_, D_, 64, false>), grid, dim3(4 * D_), (dec_bwd_smem<H_, D_>(g.um)), s, g); } \

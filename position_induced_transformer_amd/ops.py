@@ -520,20 +520,20 @@ class MeshPlan:
         slot = torch.empty((n_slabs * 16, self.nbr_cap), device=dev, dtype=torch.int16)
         keys = torch.empty((n_slabs, SLAB_UNION_MAX), device=dev, dtype=torch.int32)
         nkeys = torch.empty((n_slabs,), device=dev, dtype=torch.int32)
-        report = torch.zeros((2,), device=dev, dtype=torch.int32)
+        report = torch.zeros((3,), device=dev, dtype=torch.int32)
         rc = _lib.lib().pit_slab_plan_build(self.mesh_out.data_ptr(), self.mesh_in.data_ptr(), self.n_out, self.n_in, self.sdim,
                                             self.metric_id, self.period, self.nbr_idx.data_ptr(), self.nbr_cnt.data_ptr(),
                                             self.nbr_cap, m.data_ptr(), slot.data_ptr(), keys.data_ptr(), nkeys.data_ptr(),
                                             report.data_ptr(), _lib.stream_ptr())
         _lib.check(rc, "pit_slab_plan_build")
-        max_union, overflowed = report.tolist()
+        max_union, overflowed, max_count = report.tolist()
         if overflowed:
             self._slab = False
             return None
         sp = _lib.SlabPlan(self.n_out, self.n_in, self.nbr_cap, n_slabs, SLAB_UNION_MAX, self.stats.data_ptr(), self.rank_w,
                            self.nbr_idx.data_ptr(), self.nbr_cnt.data_ptr(), m.data_ptr(), slot.data_ptr(), keys.data_ptr(),
                            nkeys.data_ptr())
-        self._slab = (sp, int(max_union), (m, slot, keys, nkeys))
+        self._slab = (sp, int(max_union), (m, slot, keys, nkeys), max(1, int(max_count)))
         return self._slab
 
     def lists_complete(self) -> int:
@@ -1441,7 +1441,7 @@ class _Decoder(torch.autograd.Function):
                                         b2c.data_ptr(), n2, _lib.ptr(x), _lib.ptr(z1), _lib.ptr(h), y.data_ptr(), _lib.ptr(rowstat),
                                         _lib.ptr(scale), _lib.ptr(dvals), dvals.numel() if dvals is not None else 0,
                                         _lib.ptr(lt), _lib.ptr(ls), _lib.ptr(lh), lp, _lib.ptr(lpart), plan.slab_plan()[1],
-                                        _lib.stream_ptr())
+                                        plan.slab_plan()[3], _lib.stream_ptr())
         _lib.check(rc, "pit_decoder_fwd")
         ctx.plan, ctx.n_head, ctx.head_is_scale, ctx.head_param, ctx.params = plan, n_head, head_is_scale, head_param, params
         ctx.loss = loss if lpart is not None else None
@@ -1492,7 +1492,7 @@ class _Decoder(torch.autograd.Function):
                                _lib.ptr(loss.scale) if inside else None, _lib.ptr(loss.shift) if inside else None,
                                _lib.ptr(loss.seed) if inside else None, loss.p if inside else 0,
                                _lib.ptr(loss.partials) if inside else None, d_pred.data_ptr() if inside else None,
-                               loss.value.data_ptr() if inside else None, None, plan.slab_plan()[1], _lib.stream_ptr())
+                               loss.value.data_ptr() if inside else None, None, plan.slab_plan()[1], plan.slab_plan()[3], _lib.stream_ptr())
         _lib.check(rc, "pit_decoder_bwd")
         d_head = None
         if need_h:

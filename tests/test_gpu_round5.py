@@ -84,7 +84,8 @@ def test_slab_plan_records_distances_unions_and_slots():
     pairs = [(orc.grid_mesh_2d(43), orc.grid_mesh_2d(16), 0.02), (torch.rand(700, 2, generator=g), torch.rand(300, 2, generator=g), 0.05)]
     for mo, mi, loc in pairs:
         plan = ops.MeshPlan("euclid", mo.cuda(), mi.cuda(), loc, False)
-        sp, max_union, (m, slot, keys, nkeys) = plan.slab_plan()
+        sp, max_union, (m, slot, keys, nkeys), max_count = plan.slab_plan()
+        assert max_count == int(plan.nbr_cnt.clamp(max=plan.nbr_cap).max())
         cap, n_out = plan.nbr_cap, plan.n_out
         idx, cnt = plan.nbr_idx.view(n_out, cap).cpu().long(), plan.nbr_cnt.cpu().long()
         ref_m = ((mo[:, None, :] - mi[None, :, :]) ** 2).sum(-1)
