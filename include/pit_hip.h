@@ -322,43 +322,54 @@ int pit_slab_plan_build(const float* mesh_out, const float* mesh_in, int n_out, 
                         int* report, void* stream);
 /* 1 when the fused launches cover this shape: n_head 1 or 2, dim (= the MLP's hidden width) 32 or 64, 256 <= batch*rows <= 2^20 */
 int pit_edge_supported(int n_head, int dim, int batch, int rows_per_sample);
-/* pit.decoder forward.  values (batch, n_in, dim) rows ld_values apart; the MLP is (n_head*dim -> dim -> n2), n2 <= 4, no trailing
- * gelu; y (batch*n_out, n2).  Saved for the backward when given (all or none): x (batch*n_out, n_head*dim) the attention's output,
- * z1 / h (batch*n_out, dim), rowstat (n_head, n_out, 4), scale_out (n_head).  zero_buf: zero_n floats cleared on the way (the
+/* The up-projection's softmax weights for one step: they depend on (mesh pair, lmda) only, so they are formed ONCE (one workgroup
+ * per slab) and every (sample, slab) workgroup of pit_decoder_fwd / _bwd reads its tile as an MFMA operand:
+ *   pw (n_slabs, n_head, 16, um) = P (normalised), qw (same shape; NULL: forward only) = P (m - mbar), zeros where a row does not
+ *   list a slot; um = 32, 48 or 64 >= max_union (report[0] of pit_slab_plan_build), max_count = report[2]; scale_out (n_head) = c.
+ * As a launch of its own, or - the job struct - as extra workgroups of pit_encoder_fwd's launch. */
+int pit_decoder_weights(const pit_slab_plan* plan, const float* head, int head_is_scale, int n_head, int max_union, int max_count,
+                        float* pw, float* qw, float* scale_out, void* stream);
+typedef struct pit_decoder_weights_job {
+    const pit_slab_plan* plan; const float* head; int head_is_scale, n_head, max_union, max_count;
+    float *pw, *qw, *scale_out;
+} pit_decoder_weights_job;
+/* pit.decoder forward.  values (batch, n_in, dim) rows ld_values apart; pw from pit_decoder_weights; the MLP is
+ * (n_head*dim -> dim -> n2), n2 <= 4, no trailing gelu; y (batch*n_out, n2).  Saved for the backward when given (all or none):
+ * x (batch*n_out, n_head*dim) the attention's output, z1 / h (batch*n_out, dim).  zero_buf: zero_n floats cleared on the way (the
  * d_values buffer pit_decoder_bwd adds to).  loss_part != NULL: the slab's partial sums of RelLpNorm(true, y*scale + shift)
  * (utils.py:86-98, p = 1 or 2) as (batch, n2, n_slabs, 2) doubles - plain stores, nothing to zero, the same bits on every run.
- * max_union / max_count: report[0] / report[2] of pit_slab_plan_build: size the launch's LDS tiles (32, 48 or 64 slots) and the
- * lanes a row's candidates occupy while the weights are formed (16, 32 or 64). */
+ * max_union: report[0] of pit_slab_plan_build: sizes the launch's LDS tiles (as in pit_decoder_weights). */
 int pit_decoder_fwd(const pit_slab_plan* plan, const float* values, long ld_values, long values_bstride, int batch,
-                    int n_head, int dim, const float* head, int head_is_scale,
+                    int n_head, int dim, const float* pw,
                     const float* w1, const float* b1, const float* w2, const float* b2, int n2,
-                    float* x, float* z1, float* h, float* y, float* rowstat, float* scale_out, float* zero_buf, long zero_n,
+                    float* x, float* z1, float* h, float* y, float* zero_buf, long zero_n,
                     const float* loss_true, const float* loss_scale, const float* loss_shift, int loss_p, double* loss_part,
-                    int max_union, int max_count, void* stream);
+                    int max_union, void* stream);
 /* pit.decoder backward: d_y (batch*n_out, n2) -> dz1 (batch*n_out, dim: the scratch of the MLP's weight-gradient reductions,
  * pit_mlp_bwd_params with d_y and this scratch), d_values (batch, n_in, dim) ADDED to (fp32 atomics; zero on entry), the layer's
- * d(scale) accumulators (PIT_HEAD_DEFER convention).  d_y == NULL: the loss inside - d(pred) is formed from loss_part (the
- * forward's partial sums), multiplied by *loss_seed when given, written to d_pred (batch*n_out, n2); *loss_out receives
- * sum_b mean_c ||true - pred'|| / ||true||, norms_out (batch, n2, 2) the two norms per series (may be NULL). */
+ * d(scale) accumulators (PIT_HEAD_DEFER convention; finish with the scale_out of pit_decoder_weights).  d_y == NULL: the loss
+ * inside - d(pred) is formed from loss_part (the forward's partial sums), multiplied by *loss_seed when given, written to d_pred
+ * (batch*n_out, n2); *loss_out receives sum_b mean_c ||true - pred'|| / ||true||, norms_out (batch, n2, 2) the norms (may be NULL). */
 int pit_decoder_bwd(const pit_slab_plan* plan, const float* values, long ld_values, long values_bstride, int batch,
-                    int n_head, int dim, const float* scale, const float* rowstat,
+                    int n_head, int dim, const float* pw, const float* qw,
                     const float* w1, const float* w2, int n2, const float* z1,
                     const float* d_y, long ld_dy, float* dz1, float* d_values, long dvalues_bstride, double* dscale,
                     const float* loss_pred, const float* loss_true, const float* loss_scale, const float* loss_shift,
                     const float* loss_seed, int loss_p, const double* loss_part, float* d_pred, float* loss_out,
-                    float* norms_out, int max_union, int max_count, void* stream);
+                    float* norms_out, int max_union, void* stream);
 /* pit.encoder forward.  Value channels [0, coord_dims) are the key coordinates (mesh_in; train_darcy.py:51-55), the other
  * value_dim channels come from values (batch, n_in, value_dim); n_head*(coord_dims + value_dim) <= 16.  The MLP is
  * (n_head*(coord_dims+value_dim) -> dim -> dim) followed by gelu; y rows ldy apart (the first columns of the processor's concat
  * buffer).  clear_buf: clear_n floats zeroed on the way (the step's flat gradient buffer).  weights: pit_block_weights' arguments,
- * performed by extra workgroups of this launch (dim 64) or a launch of its own right after. */
+ * dec_weights: pit_decoder_weights' - each performed by extra workgroups of this launch (dim 64) or a launch of its own right after. */
 struct pit_block_weights_job;
 int pit_encoder_fwd(const pit_slab_plan* plan, const float* mesh_in, int space_dim, int coord_dims,
                     const float* values, long ld_values, long values_bstride, int value_dim, int batch,
                     int n_head, int dim, const float* head, int head_is_scale,
                     const float* w1, const float* b1, const float* w2, const float* b2,
                     float* x, float* z1, float* h, float* z2, float* y, long ldy, float* rowstat, float* scale_out,
-                    float* clear_buf, long clear_n, const struct pit_block_weights_job* weights, void* stream);
+                    float* clear_buf, long clear_n, const struct pit_block_weights_job* weights,
+                    const pit_decoder_weights_job* dec_weights, void* stream);
 /* pit.encoder backward: d_y (batch*n_out, dim) rows ld_dy apart -> scratch (dZ1 | dZ2: the layout of pit_mlp_bwd_data) and the
  * down-projection's d(scale) accumulators (required).  The inputs get no gradient (data). */
 int pit_encoder_bwd(const pit_slab_plan* plan, const float* mesh_in, int space_dim, int coord_dims,

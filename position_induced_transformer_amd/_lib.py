@@ -38,6 +38,12 @@ class SlabPlan(ctypes.Structure):
                 ("idx", _P), ("cnt", _P), ("m", _P), ("slot", _P), ("keys", _P), ("nkeys", _P)]
 
 
+class DecoderWeightsJob(ctypes.Structure):
+    """pit_decoder_weights_job of include/pit_hip.h (the argument list of pit_decoder_weights)."""
+    _fields_ = [("plan", _P), ("head", _P), ("head_is_scale", _I), ("n_head", _I), ("max_union", _I), ("max_count", _I),
+                ("pw", _P), ("qw", _P), ("scale_out", _P)]
+
+
 # name -> argtypes, mirrors include/pit_hip.h one to one
 SIGNATURES = {
     "pit_version": [],
@@ -72,12 +78,13 @@ SIGNATURES = {
     "pit_block_fwd": [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _L, _I, _P],
     "pit_slab_plan_build": [_P, _P, _I, _I, _I, _I, _F, _P, _P, _I, _P, _P, _P, _P, _P, _P],
     "pit_edge_supported": [_I, _I, _I, _I],
-    "pit_decoder_fwd": [_P, _P, _L, _L, _I, _I, _I, _P, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _L,
-                        _P, _P, _P, _I, _P, _I, _I, _P],
+    "pit_decoder_weights": [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P],
+    "pit_decoder_fwd": [_P, _P, _L, _L, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _L,
+                        _P, _P, _P, _I, _P, _I, _P],
     "pit_decoder_bwd": [_P, _P, _L, _L, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _L, _P, _P, _L, _P,
-                        _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _P],
+                        _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _P],
     "pit_encoder_fwd": [_P, _P, _I, _I, _P, _L, _L, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P,
-                        _P, _P, _P, _P, _P, _L, _P, _P, _P, _L, _P, _P],
+                        _P, _P, _P, _P, _P, _L, _P, _P, _P, _L, _P, _P, _P],
     "pit_encoder_bwd": [_P, _P, _I, _I, _P, _L, _L, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _L, _P, _P, _P],
     "pit_posatt_pre_supported": [_I, _I, _I, _I],
     "pit_posatt_pre_fwd": [_P, _P, _I, _I, _I, _I, _P, _L, _L, _P, _L, _L, _I, _I, _I, _P],

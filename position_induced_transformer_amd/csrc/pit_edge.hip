@@ -50,18 +50,6 @@ __device__ unsigned long long pit_edge_stamps[4][16];
 constexpr int ER = 16;                  // rows per slab
 constexpr int EU = PIT_SLAB_UNION_MAX;  // union keys a slab tile holds (64)
 
-// sum over the LPR-lane segment a lane belongs to (16, 32 or 64 lanes), returned to every lane of the segment
-template <int LPR>
-__device__ __forceinline__ float seg_sum(float v) {
-    v += dpp_f<0xB1, 0xf>(v);
-    v += dpp_f<0x4E, 0xf>(v);
-    v += dpp_f<0x124, 0xf>(v);
-    v += dpp_f<0x128, 0xf>(v);
-    if (LPR >= 32) v += __shfl_xor(v, 16, 64);
-    if (LPR >= 64) v += __shfl_xor(v, 32, 64);
-    return v;
-}
-
 // Predicated loads WITHOUT a branch: hipcc turns `ok ? p[i] : 0` - and, by sinking the load to its only use, even
 // `v = p[ok ? i : 0]; ok ? v : 0` - into an exec-masked block that ends in s_waitcnt vmcnt(0): every such load a serial memory
 // round trip (eleven of them in the first version of decoder_fwd_kernel).  As in pit_common.h the load goes through a raw buffer
@@ -162,32 +150,84 @@ __device__ __forceinline__ void head_scales(const float (&raw)[H], int is_scale,
     for (int h = 0; h < H; ++h) c[h] = is_scale ? raw[h] : head_scale_from_lmda(raw[h]);
 }
 
-// One pass of weight formation: this lane is candidate `i` of slab row `row_l` (mesh row n).  FWD: thresholds from the order
-// statistics, un-normalised weights, the row's sums by segment reductions -> P = p / rowsum and the saved rowstat;
-// !FWD: everything from the saved rowstat -> P and Q = P (m - mbar).
-struct Cand { float m; int slot; bool valid; };
-
-template <int LPR>
-__device__ __forceinline__ Cand load_cand(const pit_slab_plan& p, int slab, int row_l, int i) {
-    // (three independent loads: the records of all cap slots exist - pit_slab_plan_build writes zeros beyond a row's count)
-    Cand c;
-    const int n = slab * ER + row_l;
-    const int craw = ldi_if(p.cnt, n, n < p.n_out);                // (rows beyond the mesh: count 0)
-    const long off = (long)(slab * ER + row_l) * p.cap + (i < p.cap ? i : 0);
-    c.m = p.m[off];
-    c.slot = p.slot[off];
-    c.valid = i < min(craw, p.cap);
-    return c;
+// ------------------------------------------------------------------------------------------------ decoder weights
+// The up-projection's softmax weights depend on (mesh pair, lmda) only - not on the sample, not on the activations: ONE workgroup
+// per slab forms them once per step (as extra workgroups of the encoder-side launch, or a launch of its own), every
+// (sample, slab) workgroup of the decoder launches then reads its 16 x U tile as an MFMA operand straight from memory.
+//   pw[slab][h][row][slot] = P (normalised), qw[...] = Q = P (m - mbar) (the d(scale) weights; NULL: not needed), zeros elsewhere.
+struct DecWArgs {
+    pit_slab_plan p;
+    const float* head; int head_is_scale, n_head, um, lpr;
+    float *pw, *qw, *scale_out;
+};
+__device__ __forceinline__ float seg_sum_rt(float v, int lpr) {
+    v += dpp_f<0xB1, 0xf>(v);
+    v += dpp_f<0x4E, 0xf>(v);
+    v += dpp_f<0x124, 0xf>(v);
+    v += dpp_f<0x128, 0xf>(v);
+    if (lpr >= 32) v += __shfl_xor(v, 16, 64);
+    if (lpr >= 64) v += __shfl_xor(v, 32, 64);
+    return v;
+}
+// 256 threads; `tile`: 2 * 2 * 16 * PIT_SLAB_UNION_MAX floats of LDS
+__device__ __forceinline__ void dec_weights_body(const DecWArgs& g, int slab, float* tile) {
+    const pit_slab_plan& p = g.p;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int H = g.n_head, um = g.um, lpr = g.lpr;
+    const int per = H * ER * um;                            // floats of one tile (P; Q follows)
+    for (int e = tid; e < 2 * per; e += 256) tile[e] = 0.0f;
+    float c[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const float raw = g.head[h < H ? h : 0];
+        c[h] = g.head_is_scale ? raw : head_scale_from_lmda(raw);
+    }
+    __syncthreads();
+    const int rpw = 64 / lpr;
+    for (int r0 = 0; r0 < ER; r0 += 4 * rpw) {
+        const int row_l = r0 + wave * rpw + lane / lpr, i = lane % lpr, n = slab * ER + row_l;
+        const int craw = ldi_if(p.cnt, n, n < p.n_out);
+        const long off = (long)(slab * ER + row_l) * p.cap + (i < p.cap ? i : 0);
+        const float m = p.m[off];
+        const int slot = p.slot[off];
+        const bool valid = i < min(craw, p.cap);
+        const int nn = n < p.n_out ? n : p.n_out - 1;
+        const float mk = p.stats[nn], mk1 = p.stats[p.n_out + nn], mmin = p.stats[2 * (long)p.n_out + nn];
+        for (int h = 0; h < H; ++h) {
+            const float T = quantile_lerp(__fmul_rn(c[h], mk), __fmul_rn(c[h], mk1), p.rank_w);
+            const float smin = __fmul_rn(c[h], mmin);
+            const float sv = __fmul_rn(m, c[h]);
+            const bool keep = valid && sv <= T;
+            const float pv = keep ? __expf(smin - sv) : 0.0f;
+            const float rs = seg_sum_rt(pv, lpr), qsum = seg_sum_rt(pv * m, lpr);
+            const float inv = rs > 0.0f ? 1.0f / rs : 0.0f;
+            if (valid && slot < um) {
+                tile[(h * ER + row_l) * um + slot] = pv * inv;
+                tile[per + (h * ER + row_l) * um + slot] = pv * inv * (m - qsum * inv);
+            }
+        }
+    }
+    __syncthreads();
+    float* pdst = g.pw + (long)slab * per;
+    for (int e = 4 * tid; e < per; e += 4 * 256) *reinterpret_cast<float4*>(pdst + e) = *reinterpret_cast<const float4*>(tile + e);
+    if (g.qw) {
+        float* qdst = g.qw + (long)slab * per;
+        for (int e = 4 * tid; e < per; e += 4 * 256) *reinterpret_cast<float4*>(qdst + e) = *reinterpret_cast<const float4*>(tile + per + e);
+    }
+    if (slab == 0 && tid < H && g.scale_out) g.scale_out[tid] = c[tid];
+}
+__global__ __launch_bounds__(256) void decoder_weights_kernel(DecWArgs g) {
+    __shared__ __attribute__((aligned(16))) float tile[2 * 2 * ER * EU];
+    dec_weights_body(g, blockIdx.x, tile);
 }
 
 // ------------------------------------------------------------------------------------------------ decoder forward
 struct DecFwdArgs {
     pit_slab_plan p;
     const float* values; long ld_values, values_bstride; int batch;
-    const float* head; int head_is_scale;
+    const float* pw;                          // (n_slabs, H, 16, um): the step's normalised weights (dec_weights_body)
     const float *w1, *b1, *w2, *b2; int n2;
     float *x, *z1, *h, *y;
-    float* rowstat; float* scale_out;
     float* zero_buf; long zero_n;
     const float *tru, *lscale, *lshift; int loss_p; double* lpart;
     int um;                                   // slots of the union tiles in LDS: 32, 48 or 64 >= the plan's largest union
@@ -207,15 +247,10 @@ template <int D>
 __device__ __forceinline__ void gather_union(const float* __restrict__ vb, long ldv, const int (&key)[EU / 16], int nk, int nkup, int tid,
                                              float4 (&uv)[EU / 16]) {
     const int r0 = tid / (D / 4), q = tid % (D / 4);
+    // (slots beyond the union load out of range through the buffer descriptor: four unconditional loads, no branch)
 #pragma unroll
-    for (int u = 0; u < EU / 16; ++u) uv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (PIT_EDGE_DBG & 2) return;
-#pragma unroll
-    for (int u = 0; u < 2; ++u) uv[u] = ldg4_if(vb, (long)key[u] * ldv + 4 * q, r0 + 16 * u < nk);
-    if (nkup > 32) {
-#pragma unroll
-        for (int u = 2; u < EU / 16; ++u) uv[u] = ldg4_if(vb, (long)key[u] * ldv + 4 * q, r0 + 16 * u < nk);
-    }
+    for (int u = 0; u < EU / 16; ++u)
+        uv[u] = (PIT_EDGE_DBG & 2) ? make_float4(0.f, 0.f, 0.f, 0.f) : ldg4_if(vb, (long)key[u] * ldv + 4 * q, r0 + 16 * u < nk);
 }
 template <int D>
 __device__ __forceinline__ void park_union(float* ut, int nkup, int tid, const float4 (&uv)[EU / 16]) {
@@ -225,6 +260,24 @@ __device__ __forceinline__ void park_union(float* ut, int nkup, int tid, const f
         if (16 * u < nkup) *reinterpret_cast<float4*>(ut + (r0 + 16 * u) * (D + 4) + 4 * q) = uv[u];
 }
 
+// A 16-row weight tile (H * 16 rows x um slots, contiguous in memory) goes through LDS: requested ONCE per workgroup as 16-byte
+// pieces with the other loads, parked row-major with pitch um + 4, read by every wave as its MFMA A operand.  (Each wave loading
+// its own fragments from memory was measured slower - decoder_fwd 13.1 -> 14.9 us: the L1 / address path, already carrying 32 KB
+// of W1 per workgroup, is what bounds these launches.)
+constexpr int WCP = (2 * ER * EU / 4 + 255) / 256;          // 16-byte pieces per thread at 256 threads, H = 2, um = 64
+template <int NT>
+__device__ __forceinline__ void wtile_request(const float* tile, int npc, int tid, float4 (&cp)[WCP * 256 / NT]) {
+#pragma unroll
+    for (int u = 0; u < WCP * 256 / NT; ++u) cp[u] = ldg4_if(tile, 4L * (tid + u * NT), tid + u * NT < npc);
+}
+template <int NT>
+__device__ __forceinline__ void wtile_park(float* lds, int um, int npc, int tid, const float4 (&cp)[WCP * 256 / NT]) {
+#pragma unroll
+    for (int u = 0; u < WCP * 256 / NT; ++u) {
+        const int e = tid + u * NT;
+        if (e < npc) *reinterpret_cast<float4*>(lds + ((4 * e) / um) * (um + 4) + (4 * e) % um) = cp[u];
+    }
+}
 // acc (16 rows x columns [16 wave, 16 wave + 16)) = W[16 x nkup] (row-major in LDS, pitch `up`) @ ut[nkup x D]
 template <int D>
 __device__ __forceinline__ f32x4_t tile_times_union(const float* wrow, int up, const float* ut, int nkup, int wave, int l15, int kq) {
@@ -243,26 +296,12 @@ __device__ __forceinline__ f32x4_t tile_times_union(const float* wrow, int up, c
     return r;
 }
 
-// a wave clears the weight-tile rows it is about to scatter into: LDS operations of ONE wave execute in order, so no barrier sits
-// between the clearing and the scatter (rows of pass ps: ps*NW*RPW + wave*RPW + [0, RPW), every head)
-template <int H, int NW, int RPW, int NP>
-__device__ __forceinline__ void clear_own_rows(float* tile, int up, int wave, int lane) {
-#pragma unroll
-    for (int ps = 0; ps < NP; ++ps)
-#pragma unroll
-        for (int h = 0; h < H; ++h) {
-            float* base = tile + (h * ER + ps * NW * RPW + wave * RPW) * up;
-            for (int e = lane; e < RPW * up; e += 64) base[e] = 0.0f;
-        }
-}
-
-template <int H, int D, int LPR, bool LOSS>
+template <int H, int D, bool LOSS>
 __global__ __launch_bounds__(4 * D) void decoder_fwd_kernel(DecFwdArgs g) {
     constexpr int NT = 4 * D, NW = D / 16, K0 = H * D, KS = K0 / 16, XP = K0 + 4, HP = D + 4;
-    constexpr int RPW = 64 / LPR, NP = ER / (NW * RPW);           // rows per wave and pass, passes
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int UP = g.um + 4;                   // pitch of the weight tiles (the plan's largest union decides the LDS a launch takes)
-    float* pt = smem;                          // [H][16][UP] normalised weights
+    const int UP = g.um + 4;                   // pitch of the weight tile (the plan's largest union decides the LDS a launch takes)
+    float* pt = smem;                          // [H][16][UP] the step's normalised weights of this slab
     float* ut = pt + H * ER * UP;              // [um][D + 4] union value rows
     float* xs = ut + g.um * (D + 4);           // [16][XP]
     float* hs = xs + ER * XP;                  // [16][HP]
@@ -281,18 +320,9 @@ __global__ __launch_bounds__(4 * D) void decoder_fwd_kernel(DecFwdArgs g) {
     // plan's candidate records, the row statistics, the MLP operands, the loss's operands
     int key[EU / 16];
     union_keys<D>(p, slab, tid, nkup, key);
-    float hraw[H];
-#pragma unroll
-    for (int h = 0; h < H; ++h) hraw[h] = g.head[h];
-    Cand cd[NP];
-    float st_k[NP], st_k1[NP], st_min[NP];
-#pragma unroll
-    for (int ps = 0; ps < NP; ++ps) {
-        const int row_l = ps * NW * RPW + wave * RPW + lane / LPR, n = slab * ER + row_l;
-        cd[ps] = load_cand<LPR>(p, slab, row_l, lane % LPR);
-        const int nn = n < p.n_out ? n : p.n_out - 1;
-        st_k[ps] = p.stats[nn]; st_k1[ps] = p.stats[p.n_out + nn]; st_min[ps] = p.stats[2 * (long)p.n_out + nn];
-    }
+    const int npc = H * ER * g.um / 4;
+    float4 pcp[WCP * 256 / NT];
+    wtile_request<NT>(g.pw + (long)slab * H * ER * g.um, npc, tid, pcp);
     float4 bv[KS];
 #pragma unroll
     for (int s = 0; s < KS; ++s)
@@ -313,32 +343,11 @@ __global__ __launch_bounds__(4 * D) void decoder_fwd_kernel(DecFwdArgs g) {
     // ---- the union's value rows (second round trip), weights formed while they fly
     float4 uv[EU / 16];
     gather_union<D>(g.values + (long)b * g.values_bstride, g.ld_values, key, nk, nkup, tid, uv);
+    __builtin_amdgcn_sched_barrier(0);       // (left to itself the scheduler sinks each load to its use: dependent round trips again)
     ESTAMP(0, 1);
-    clear_own_rows<H, NW, RPW, NP>(pt, UP, wave, lane);
-    float c[H];
-    head_scales<H>(hraw, g.head_is_scale, c);
     w2s[tid] = w2r;
     if (tid < 4) w2s[4 * D + tid] = b2r;
-#pragma unroll
-    for (int ps = 0; ps < NP; ++ps) {
-        const int row_l = ps * NW * RPW + wave * RPW + lane / LPR, n = slab * ER + row_l;
-#pragma unroll
-        for (int h = 0; h < H; ++h) {
-            const float T = quantile_lerp(__fmul_rn(c[h], st_k[ps]), __fmul_rn(c[h], st_k1[ps]), p.rank_w);
-            const float smin = __fmul_rn(c[h], st_min[ps]);
-            const float sv = __fmul_rn(cd[ps].m, c[h]);
-            const bool keep = cd[ps].valid && sv <= T;
-            const float pv = keep ? __expf(smin - sv) : 0.0f;
-            const float rs = seg_sum<LPR>(pv), qs = seg_sum<LPR>(pv * cd[ps].m);
-            const float inv = rs > 0.0f ? 1.0f / rs : 0.0f;
-            if (cd[ps].valid) pt[(h * ER + row_l) * UP + cd[ps].slot] = pv * inv;
-            if (lane % LPR == 0 && n < p.n_out && b == 0 && g.rowstat) {
-                float4 st; st.x = T; st.y = smin; st.z = inv; st.w = qs * inv;
-                *reinterpret_cast<float4*>(g.rowstat + ((long)h * p.n_out + n) * 4) = st;
-                if (n == 0 && g.scale_out) g.scale_out[h] = c[h];
-            }
-        }
-    }
+    wtile_park<NT>(pt, g.um, npc, tid, pcp);
     ESTAMP(0, 2);
     park_union<D>(ut, nkup, tid, uv);
     ESTAMP(0, 3);
@@ -448,7 +457,7 @@ __global__ __launch_bounds__(4 * D) void decoder_fwd_kernel(DecFwdArgs g) {
 struct DecBwdArgs {
     pit_slab_plan p;
     const float* values; long ld_values, values_bstride; int batch;
-    const float* scale; const float* rowstat;
+    const float *pw, *qw;                     // the step's weights (dec_weights_body): P and Q = P (m - mbar)
     const float *w1, *w2; int n2;
     const float* z1;
     const float* d_y; long ld_dy;
@@ -471,13 +480,12 @@ __device__ __forceinline__ void series_norms(const double* lpart, int b, int o, 
     dn = p == 1 ? den : sqrt(den);
 }
 
-template <int H, int D, int LPR, bool LOSS>
+template <int H, int D, bool LOSS>
 __global__ __launch_bounds__(4 * D) void decoder_bwd_kernel(DecBwdArgs g) {
     constexpr int NT = 4 * D, NW = D / 16, K0 = H * D, S1 = D / 16, XP = K0 + 4, P1 = D + 4;
-    constexpr int RPW = 64 / LPR, NP = ER / (NW * RPW);
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int UP = g.um + 4;
-    float* ps_ = smem;                         // [H][16][UP]    P (normalised weights)
+    float* ps_ = smem;                         // [H][16][UP]    P (normalised weights), read transposed by the d(values) contraction
     float* qs = ps_ + H * ER * UP;             // [H][16][UP]    Q = P (m - mbar)
     float* ut = qs + H * ER * UP;              // [um][D + 4]
     float* ds1 = ut + g.um * (D + 4);          // [16][P1]       dZ1
@@ -499,19 +507,10 @@ __global__ __launch_bounds__(4 * D) void decoder_bwd_kernel(DecBwdArgs g) {
     int key[EU / 16];
     union_keys<D>(p, slab, tid, nkup, key);
     const int akey = p.keys[(long)slab * p.umax + (tid & (EU - 1))];   // slot -> key for the d(values) adds, through LDS
-    float c[H];
-#pragma unroll
-    for (int h = 0; h < H; ++h) c[h] = g.scale[h];
-    Cand cd[NP];
-    float4 rs4[NP][H];
-#pragma unroll
-    for (int ps = 0; ps < NP; ++ps) {
-        const int row_l = ps * NW * RPW + wave * RPW + lane / LPR, n = slab * ER + row_l;
-        cd[ps] = load_cand<LPR>(p, slab, row_l, lane % LPR);
-        const int nn = n < p.n_out ? n : p.n_out - 1;
-#pragma unroll
-        for (int h = 0; h < H; ++h) rs4[ps][h] = *reinterpret_cast<const float4*>(g.rowstat + ((long)h * p.n_out + nn) * 4);
-    }
+    const int npc = H * ER * g.um / 4;
+    float4 pcp[WCP * 256 / NT], qcp[WCP * 256 / NT];
+    wtile_request<NT>(g.pw + (long)slab * H * ER * g.um, npc, tid, pcp);
+    wtile_request<NT>(g.qw + (long)slab * H * ER * g.um, npc, tid, qcp);
     // this thread's four dZ1 elements: rows er[u] (element e = tid + u * NT of the 16 x D tile), column ec
     const int ec = tid % D;
     // (output channel 0 - the only one of most models - is requested here with everything else; further channels, out_dim <= 4,
@@ -536,20 +535,34 @@ __global__ __launch_bounds__(4 * D) void decoder_bwd_kernel(DecBwdArgs g) {
         }
     }
     // ---- the union's value rows (second round trip)
+    // (the loss's partial sums of this sample's series, channel 0: the first 256 slabs' pairs with the other loads)
+    float4 np4[4];
+#pragma unroll
+    for (int cq = 0; cq < 4; ++cq)
+        np4[cq] = ldg4_if(reinterpret_cast<const float*>(g.lpart) + (long)b * g.n2 * p.n_slabs * 4, 4L * (lane + 64 * cq),
+                          LOSS && lane + 64 * cq < p.n_slabs);
     float4 uv[EU / 16];
     gather_union<D>(g.values + (long)b * g.values_bstride, g.ld_values, key, nk, nkup, tid, uv);
+    __builtin_amdgcn_sched_barrier(0);
     ESTAMP(1, 1);
-    clear_own_rows<H, NW, RPW, NP>(ps_, UP, wave, lane);
-    clear_own_rows<H, NW, RPW, NP>(qs, UP, wave, lane);
     if (tid < EU) keys_s[tid] = akey;
     // ---- the loss of the step (utils.py:86-98) finished here: every wave sums this sample's norms itself (no hand-off), the
     // scalar is the first workgroup's last wave's
     float nrm0 = 0.0f, nrm1 = 1.0f;
     if (LOSS) {
         {
-            double nn, dn;
-            series_norms(g.lpart, b, 0, g.n2, p.n_slabs, g.loss_p, lane, nn, dn);
-            nrm0 = (float)nn; nrm1 = (float)dn;
+            double num = 0.0, den = 0.0;
+#pragma unroll
+            for (int cq = 0; cq < 4; ++cq) {
+                num += __hiloint2double(__float_as_int(np4[cq].y), __float_as_int(np4[cq].x));
+                den += __hiloint2double(__float_as_int(np4[cq].w), __float_as_int(np4[cq].z));
+            }
+            const double* src = g.lpart + (long)b * g.n2 * p.n_slabs * 2;
+            for (int sl = lane + 256; sl < p.n_slabs; sl += 64) { num += src[2 * sl]; den += src[2 * sl + 1]; }
+            num = wave_sum_d(num);
+            den = wave_sum_d(den);
+            nrm0 = (float)(g.loss_p == 1 ? num : sqrt(num));
+            nrm1 = (float)(g.loss_p == 1 ? den : sqrt(den));
         }
         if (blockIdx.x == 0 && wave == NW - 1) {
             double tot = 0.0;
@@ -567,21 +580,9 @@ __global__ __launch_bounds__(4 * D) void decoder_bwd_kernel(DecBwdArgs g) {
         }
     }
     ESTAMP(1, 2);
-    // ---- weights from the saved row statistics: P and Q tiles (each wave its own rows)
-#pragma unroll
-    for (int ps = 0; ps < NP; ++ps) {
-        const int row_l = ps * NW * RPW + wave * RPW + lane / LPR;
-#pragma unroll
-        for (int h = 0; h < H; ++h) {
-            const float sv = __fmul_rn(cd[ps].m, c[h]);
-            const bool keep = cd[ps].valid && sv <= rs4[ps][h].x;
-            const float pv = keep ? __expf(rs4[ps][h].y - sv) * rs4[ps][h].z : 0.0f;
-            if (cd[ps].valid) {
-                ps_[(h * ER + row_l) * UP + cd[ps].slot] = pv;
-                qs[(h * ER + row_l) * UP + cd[ps].slot] = pv * (cd[ps].m - rs4[ps][h].w);
-            }
-        }
-    }
+    // ---- the weight tiles into LDS (row-major, pitch UP)
+    wtile_park<NT>(ps_, g.um, npc, tid, pcp);
+    wtile_park<NT>(qs, g.um, npc, tid, qcp);
     ESTAMP(1, 3);
     // ---- dZ1 = (dZ2 W2) * gelu'(Z1), dZ2 = d(pred): elementwise for the thin output layer
     const float gs = (LOSS && g.gseed) ? g.gseed[0] : 1.0f;
@@ -759,12 +760,16 @@ __device__ __forceinline__ void enc_values(const EncArgs& g, int b, int lane, co
 }
 
 template <int H, int D, int EC>
-__global__ __launch_bounds__(4 * D) void encoder_fwd_kernel(EncArgs g, WeightsArgs wj) {
+__global__ __launch_bounds__(4 * D) void encoder_fwd_kernel(EncArgs g, WeightsArgs wj, DecWArgs dj, int n_w) {
     constexpr int NT = 4 * D, NW = D / 16, S2 = D / 16, HP = D + 4, XP = 20, NP = ER / NW;
     __shared__ __attribute__((aligned(16))) float xs[ER * XP];
     __shared__ __attribute__((aligned(16))) float hs[ER * HP];
-    if ((int)blockIdx.x >= g.n_att) {                           // the processor's block weights ride here (256-thread workgroups)
-        if (D == 64) block_weights_body(wj, (long)blockIdx.x - g.n_att);
+    if ((int)blockIdx.x >= g.n_att) {       // riders (256-thread workgroups): the processor's block weights, the decoder's weight tiles
+        if (D == 64) {
+            __shared__ __attribute__((aligned(16))) float tile[2 * 2 * ER * EU];
+            const int id = (int)blockIdx.x - g.n_att;
+            if (id < n_w) block_weights_body(wj, id); else dec_weights_body(dj, id - n_w, tile);
+        }
         return;
     }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -798,6 +803,7 @@ __global__ __launch_bounds__(4 * D) void encoder_fwd_kernel(EncArgs g, WeightsAr
         // ---- second round trip: the candidates' value channels
         float v[NP][EC];
         enc_values<NW, EC>(g, b, lane, rec, v);
+        __builtin_amdgcn_sched_barrier(0);
         // (this wave's rows of the tile: cleared by the wave itself, in order with its own writes below)
         for (int e = lane; e < NP * XP; e += 64) xs[((e / XP) * NW + wave) * XP + e % XP] = 0.0f;
         float c[H];
@@ -924,6 +930,7 @@ __global__ __launch_bounds__(4 * D) void encoder_bwd_kernel(EncArgs g) {
     // ---- second round trip: the candidates' value channels
     float v[NP][EC];
     enc_values<NW, EC>(g, b, lane, rec, v);
+    __builtin_amdgcn_sched_barrier(0);
     // ---- dZ2 = dY * gelu'(Z2)
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -1058,36 +1065,54 @@ extern "C" int pit_slab_plan_build(const float* mesh_out, const float* mesh_in, 
         else { CALL_(2, 64); }                                                   \
     } while (0)
 
+namespace {
+// pit_decoder_weights' argument checks -> kernel arguments
+int fill_dec_weights(DecWArgs& g, const pit_slab_plan* plan, const float* head, int head_is_scale, int n_head, int max_union,
+                     int max_count, float* pw, float* qw, float* scale_out) {
+    if (!plan_ok(plan, true) || !head || !pw) return PIT_ERR_NULL;
+    if ((n_head != 1 && n_head != 2) || max_union < 1 || max_union > EU || max_count < 1 || max_count > 64) return PIT_ERR_UNSUPPORTED;
+    if (!aligned16(pw) || (qw && !aligned16(qw))) return PIT_ERR_SIZE;
+    g.p = *plan; g.head = head; g.head_is_scale = head_is_scale; g.n_head = n_head; g.um = union_slots(max_union);
+    g.lpr = max_count <= 16 ? 16 : (max_count <= 32 ? 32 : 64);
+    g.pw = pw; g.qw = qw; g.scale_out = scale_out;
+    return 0;
+}
+}  // namespace
+
+extern "C" int pit_decoder_weights(const pit_slab_plan* plan, const float* head, int head_is_scale, int n_head, int max_union,
+                                   int max_count, float* pw, float* qw, float* scale_out, void* stream) {
+    DecWArgs g;
+    if (int rc = fill_dec_weights(g, plan, head, head_is_scale, n_head, max_union, max_count, pw, qw, scale_out)) return rc;
+    hipLaunchKernelGGL(decoder_weights_kernel, dim3((unsigned)plan->n_slabs), dim3(256), 0, (hipStream_t)stream, g);
+    PIT_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int pit_decoder_fwd(const pit_slab_plan* plan, const float* values, long ld_values, long values_bstride, int batch,
-                               int n_head, int dim, const float* head, int head_is_scale,
+                               int n_head, int dim, const float* pw,
                                const float* w1, const float* b1, const float* w2, const float* b2, int n2,
-                               float* x, float* z1, float* h, float* y, float* rowstat, float* scale_out,
-                               float* zero_buf, long zero_n,
+                               float* x, float* z1, float* h, float* y, float* zero_buf, long zero_n,
                                const float* loss_true, const float* loss_scale, const float* loss_shift, int loss_p, double* loss_part,
-                               int max_union, int max_count, void* stream) {
-    if (max_union < 1 || max_union > EU || max_count < 1 || max_count > 64) return PIT_ERR_UNSUPPORTED;
-    const int lpr = max_count <= 16 ? 16 : (max_count <= 32 ? 32 : 64);       // lanes per row of the weight formation
-    if (!plan_ok(plan, true) || !values || !head || !w1 || !b1 || !w2 || !b2 || !y) return PIT_ERR_NULL;
+                               int max_union, void* stream) {
+    if (max_union < 1 || max_union > EU) return PIT_ERR_UNSUPPORTED;
+    if (!plan_ok(plan, true) || !values || !pw || !w1 || !b1 || !w2 || !b2 || !y) return PIT_ERR_NULL;
     if (!hid_ok(n_head, dim) || n2 < 1 || n2 > 4 || batch <= 0) return PIT_ERR_UNSUPPORTED;
     if ((z1 == nullptr) != (h == nullptr)) return PIT_ERR_NULL;
-    if (ld_values % 4 || values_bstride % 4 || !aligned16(values) || !aligned16(w1) || (zero_buf && !aligned16(zero_buf))) return PIT_ERR_SIZE;
+    if (ld_values % 4 || values_bstride % 4 || !aligned16(values) || !aligned16(w1) || !aligned16(pw) || (zero_buf && !aligned16(zero_buf)))
+        return PIT_ERR_SIZE;
     if (loss_part && (!loss_true || (loss_p != 1 && loss_p != 2) || (loss_scale == nullptr) != (loss_shift == nullptr))) return PIT_ERR_UNSUPPORTED;
     DecFwdArgs g;
     g.p = *plan; g.values = values; g.ld_values = ld_values; g.values_bstride = values_bstride; g.batch = batch;
-    g.head = head; g.head_is_scale = head_is_scale; g.w1 = w1; g.b1 = b1; g.w2 = w2; g.b2 = b2; g.n2 = n2;
-    g.x = x; g.z1 = z1; g.h = h; g.y = y; g.rowstat = rowstat; g.scale_out = scale_out; g.zero_buf = zero_buf; g.zero_n = zero_buf ? zero_n : 0;
+    g.pw = pw; g.w1 = w1; g.b1 = b1; g.w2 = w2; g.b2 = b2; g.n2 = n2;
+    g.x = x; g.z1 = z1; g.h = h; g.y = y; g.zero_buf = zero_buf; g.zero_n = zero_buf ? zero_n : 0;
     g.tru = loss_true; g.lscale = loss_scale; g.lshift = loss_shift; g.loss_p = loss_p; g.lpart = loss_part;
     g.um = union_slots(max_union);
     const dim3 grid((unsigned)slab_grid(batch, plan->n_slabs));
     hipStream_t s = (hipStream_t)stream;
-#define PIT_DF(H_, D_)                                                                                                    \
-    do {                                                                                                                  \
-        if (lpr == 16) { if (loss_part) hipLaunchKernelGGL((decoder_fwd_kernel<H_, D_, 16, true>), grid, dim3(4 * D_), (dec_fwd_smem<H_, D_>(g.um)), s, g); \
-                         else hipLaunchKernelGGL((decoder_fwd_kernel<H_, D_, 16, false>), grid, dim3(4 * D_), (dec_fwd_smem<H_, D_>(g.um)), s, g); } \
-        else if (lpr == 32) { if (loss_part) hipLaunchKernelGGL((decoder_fwd_kernel<H_, D_, 32, true>), grid, dim3(4 * D_), (dec_fwd_smem<H_, D_>(g.um)), s, g); \
-                               else hipLaunchKernelGGL((decoder_fwd_kernel<H_, D_, 32, false>), grid, dim3(4 * D_), (dec_fwd_smem<H_, D_>(g.um)), s, g); } \
-        else { if (loss_part) hipLaunchKernelGGL((decoder_fwd_kernel<H_, D_, 64, true>), grid, dim3(4 * D_), (dec_fwd_smem<H_, D_>(g.um)), s, g); \
-               else hipLaunchKernelGGL((decoder_fwd_kernel<H_, D_, 64, false>), grid, dim3(4 * D_), (dec_fwd_smem<H_, D_>(g.um)), s, g); } \
+#define PIT_DF(H_, D_)                                                                                                                \
+    do {                                                                                                                              \
+        if (loss_part) hipLaunchKernelGGL((decoder_fwd_kernel<H_, D_, true>), grid, dim3(4 * D_), (dec_fwd_smem<H_, D_>(g.um)), s, g); \
+        else hipLaunchKernelGGL((decoder_fwd_kernel<H_, D_, false>), grid, dim3(4 * D_), (dec_fwd_smem<H_, D_>(g.um)), s, g);          \
     } while (0)
     PIT_EDGE_DISPATCH(n_head, dim, PIT_DF);
 #undef PIT_DF
@@ -1096,37 +1121,32 @@ extern "C" int pit_decoder_fwd(const pit_slab_plan* plan, const float* values, l
 }
 
 extern "C" int pit_decoder_bwd(const pit_slab_plan* plan, const float* values, long ld_values, long values_bstride, int batch,
-                               int n_head, int dim, const float* scale, const float* rowstat,
+                               int n_head, int dim, const float* pw, const float* qw,
                                const float* w1, const float* w2, int n2, const float* z1,
                                const float* d_y, long ld_dy, float* dz1, float* d_values, long dvalues_bstride, double* dscale,
                                const float* loss_pred, const float* loss_true, const float* loss_scale, const float* loss_shift,
                                const float* loss_seed, int loss_p, const double* loss_part, float* d_pred, float* loss_out,
-                               float* norms_out, int max_union, int max_count, void* stream) {
-    if (max_union < 1 || max_union > EU || max_count < 1 || max_count > 64) return PIT_ERR_UNSUPPORTED;
-    const int lpr = max_count <= 16 ? 16 : (max_count <= 32 ? 32 : 64);
-    if (!plan_ok(plan, true) || !values || !scale || !rowstat || !w1 || !w2 || !z1 || !dz1 || !d_values) return PIT_ERR_NULL;
+                               float* norms_out, int max_union, void* stream) {
+    if (max_union < 1 || max_union > EU) return PIT_ERR_UNSUPPORTED;
+    if (!plan_ok(plan, true) || !values || !pw || !qw || !w1 || !w2 || !z1 || !dz1 || !d_values) return PIT_ERR_NULL;
     if (!hid_ok(n_head, dim) || n2 < 1 || n2 > 4 || batch <= 0) return PIT_ERR_UNSUPPORTED;
     if (!d_y && (!loss_pred || !loss_true || !loss_part || !d_pred || !loss_out || (loss_p != 1 && loss_p != 2) ||
                  (loss_scale == nullptr) != (loss_shift == nullptr))) return PIT_ERR_NULL;
     if (d_y && ld_dy < n2) return PIT_ERR_SIZE;
-    if (ld_values % 4 || values_bstride % 4 || !aligned16(values) || !aligned16(rowstat)) return PIT_ERR_SIZE;
+    if (ld_values % 4 || values_bstride % 4 || !aligned16(values) || !aligned16(pw) || !aligned16(qw)) return PIT_ERR_SIZE;
     DecBwdArgs g;
     g.p = *plan; g.values = values; g.ld_values = ld_values; g.values_bstride = values_bstride; g.batch = batch;
-    g.scale = scale; g.rowstat = rowstat; g.w1 = w1; g.w2 = w2; g.n2 = n2; g.z1 = z1; g.d_y = d_y; g.ld_dy = ld_dy;
+    g.pw = pw; g.qw = qw; g.w1 = w1; g.w2 = w2; g.n2 = n2; g.z1 = z1; g.d_y = d_y; g.ld_dy = ld_dy;
     g.dz1 = dz1; g.d_values = d_values; g.dvalues_bstride = dvalues_bstride; g.dscale = dscale;
     g.pred = loss_pred; g.tru = loss_true; g.lscale = loss_scale; g.lshift = loss_shift; g.gseed = loss_seed; g.loss_p = loss_p;
     g.lpart = loss_part; g.d_pred = d_pred; g.loss_out = loss_out; g.norms_out = norms_out;
     g.um = union_slots(max_union);
     const dim3 grid((unsigned)slab_grid(batch, plan->n_slabs));
     hipStream_t s = (hipStream_t)stream;
-#define PIT_DB(H_, D_)                                                                                                    \
-    do {                                                                                                                  \
-        if (lpr == 16) { if (!d_y) hipLaunchKernelGGL((decoder_bwd_kernel<H_, D_, 16, true>), grid, dim3(4 * D_), (dec_bwd_smem<H_, D_>(g.um)), s, g); \
-                         else hipLaunchKernelGGL((decoder_bwd_kernel<H_, D_, 16, false>), grid, dim3(4 * D_), (dec_bwd_smem<H_, D_>(g.um)), s, g); } \
-        else if (lpr == 32) { if (!d_y) hipLaunchKernelGGL((decoder_bwd_kernel<H_, D_, 32, true>), grid, dim3(4 * D_), (dec_bwd_smem<H_, D_>(g.um)), s, g); \
-                               else hipLaunchKernelGGL((decoder_bwd_kernel<H_, D_, 32, false>), grid, dim3(4 * D_), (dec_bwd_smem<H_, D_>(g.um)), s, g); } \
-        else { if (!d_y) hipLaunchKernelGGL((decoder_bwd_kernel<H_, D_, 64, true>), grid, dim3(4 * D_), (dec_bwd_smem<H_, D_>(g.um)), s, g); \
-               else hipLaunchKernelGGL((decoder_bwd_kernel<H_, D_, 64, false>), grid, dim3(4 * D_), (dec_bwd_smem<H_, D_>(g.um)), s, g); } \
+#define PIT_DB(H_, D_)                                                                                                            \
+    do {                                                                                                                          \
+        if (!d_y) hipLaunchKernelGGL((decoder_bwd_kernel<H_, D_, true>), grid, dim3(4 * D_), (dec_bwd_smem<H_, D_>(g.um)), s, g);  \
+        else hipLaunchKernelGGL((decoder_bwd_kernel<H_, D_, false>), grid, dim3(4 * D_), (dec_bwd_smem<H_, D_>(g.um)), s, g);      \
     } while (0)
     PIT_EDGE_DISPATCH(n_head, dim, PIT_DB);
 #undef PIT_DB
@@ -1152,7 +1172,8 @@ extern "C" int pit_encoder_fwd(const pit_slab_plan* plan, const float* mesh_in, 
                                int n_head, int dim, const float* head, int head_is_scale,
                                const float* w1, const float* b1, const float* w2, const float* b2,
                                float* x, float* z1, float* h, float* z2, float* y, long ldy, float* rowstat, float* scale_out,
-                               float* clear_buf, long clear_n, const pit_block_weights_job* weights, void* stream) {
+                               float* clear_buf, long clear_n, const pit_block_weights_job* weights,
+                               const pit_decoder_weights_job* dec_weights, void* stream) {
     EncArgs g;
     if (int rc = fill_enc(g, plan, mesh_in, space_dim, coord_dims, values, ld_values, values_bstride, value_dim, batch, n_head, dim)) return rc;
     if (!head || !w1 || !b1 || !w2 || !b2 || !y) return PIT_ERR_NULL;
@@ -1170,13 +1191,25 @@ extern "C" int pit_encoder_fwd(const pit_slab_plan* plan, const float* mesh_in, 
                                        weights->inv, weights->rowstat, weights->scale_out)) return rc;
         if (dim == 64) n_w = block_weights_wgs(wa.n_layers, wa.n_head, wa.L); else own_launch = true;
     }
-    const dim3 grid((unsigned)(g.n_att + n_w));
+    DecWArgs da = DecWArgs();
+    int n_dw = 0;
+    if (dec_weights) {
+        if (int rc = fill_dec_weights(da, dec_weights->plan, dec_weights->head, dec_weights->head_is_scale, dec_weights->n_head,
+                                      dec_weights->max_union, dec_weights->max_count, dec_weights->pw, dec_weights->qw,
+                                      dec_weights->scale_out)) return rc;
+        if (dim == 64) n_dw = da.p.n_slabs;
+    }
+    const dim3 grid((unsigned)(g.n_att + n_w + n_dw));
     hipStream_t s = (hipStream_t)stream;
-#define PIT_EF(H_, D_) do { if (coord_dims + value_dim <= 4) hipLaunchKernelGGL((encoder_fwd_kernel<H_, D_, 4>), grid, dim3(4 * D_), 0, s, g, wa); \
-                            else hipLaunchKernelGGL((encoder_fwd_kernel<H_, D_, 8>), grid, dim3(4 * D_), 0, s, g, wa); } while (0)
+#define PIT_EF(H_, D_) do { if (coord_dims + value_dim <= 4) hipLaunchKernelGGL((encoder_fwd_kernel<H_, D_, 4>), grid, dim3(4 * D_), 0, s, g, wa, da, n_w); \
+                            else hipLaunchKernelGGL((encoder_fwd_kernel<H_, D_, 8>), grid, dim3(4 * D_), 0, s, g, wa, da, n_w); } while (0)
     PIT_EDGE_DISPATCH(n_head, dim, PIT_EF);
 #undef PIT_EF
     PIT_CHECK_LAUNCH();
+    if (dec_weights && dim != 64)
+        if (int rc = pit_decoder_weights(dec_weights->plan, dec_weights->head, dec_weights->head_is_scale, dec_weights->n_head,
+                                         dec_weights->max_union, dec_weights->max_count, dec_weights->pw, dec_weights->qw,
+                                         dec_weights->scale_out, stream)) return rc;
     if (own_launch)
         return pit_block_weights(weights->mesh, weights->n_pts, weights->space_dim, weights->metric, weights->period, weights->n_layers,
                                  weights->heads, weights->head_is_scale, weights->n_head, weights->e, weights->q, weights->inv,

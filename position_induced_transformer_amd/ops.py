@@ -1124,6 +1124,7 @@ def drop_forward_job(early) -> None:
     """Disarm ``early`` if no launch took it (pit.encoder's finally: a forward that raised leaves nothing pending on the thread)."""
     if early is not None and getattr(_STEP, "fwd_job", None) is early:
         _STEP.fwd_job = None
+    _STEP.dec_job = None                         # (a decoder-weights request nobody carried: the decoder forms them itself)
 
 
 def _weights_key(plan: MeshPlan, lmdas, scales, n_head: int):
@@ -1403,11 +1404,56 @@ class LossSpec:
         return self.p in (1, 2) and n2 == self.out_dim and tuple(self.true.shape) == (batch, npts, n2) and not self.true.requires_grad
 
 
+class DecoderWeights:
+    """The up-projection's softmax weights of one step (pit_decoder_weights): P / Q tiles per 16-row slab and the head scales c.
+    They depend on (mesh pair, lmda) only: formed once per step - by extra workgroups of the encoder-side launch when pit.encoder
+    could request them (early_decoder_weights), else by a launch of their own in front of the decoder launch."""
+    __slots__ = ("key", "pw", "qw", "scale", "job", "keep")
+
+
+def _dec_weights_key(plan: MeshPlan, lmda, scale_in, n_head: int, head_is_scale: bool):
+    return (id(plan), n_head, _PARAM_EPOCH[0], lmda._version, lmda.data_ptr(), bool(head_is_scale),
+            scale_in.data_ptr() if scale_in is not None else None)
+
+
+def _new_decoder_weights(plan: MeshPlan, lmda, scale_in, n_head: int, head_is_scale: bool, need_q: bool) -> DecoderWeights:
+    sp, max_union, _t, max_count = plan.slab_plan()
+    um = 32 if max_union <= 32 else (48 if max_union <= 48 else 64)
+    dev = plan.mesh_out.device
+    w = DecoderWeights()
+    w.key = _dec_weights_key(plan, lmda, scale_in, n_head, head_is_scale)
+    w.pw = torch.empty((sp.n_slabs, n_head, 16, um), device=dev, dtype=torch.float32)
+    w.qw = torch.empty((sp.n_slabs, n_head, 16, um), device=dev, dtype=torch.float32) if need_q else None
+    w.scale = torch.empty((n_head,), device=dev, dtype=torch.float32)
+    head = scale_in if scale_in is not None else lmda.detach().reshape(-1).contiguous()
+    w.keep = (head, plan, sp)
+    w.job = _lib.DecoderWeightsJob(ctypes.cast(ctypes.pointer(sp), ctypes.c_void_p), head.data_ptr(),
+                                   1 if (scale_in is not None or head_is_scale) else 0, n_head, max_union, max_count,
+                                   w.pw.data_ptr(), _lib.ptr(w.qw), w.scale.data_ptr())
+    return w
+
+
+def _launch_decoder_weights(w: DecoderWeights) -> None:
+    j = w.job
+    rc = _lib.lib().pit_decoder_weights(j.plan, j.head, j.head_is_scale, j.n_head, j.max_union, j.max_count, j.pw, j.qw,
+                                        j.scale_out, _lib.stream_ptr())
+    _lib.check(rc, "pit_decoder_weights")
+
+
+def early_decoder_weights(plan: MeshPlan, lmda, n_head: int, need_q: bool) -> None:
+    """Request the decoder's weights BEFORE the encoder-side launch of the same forward (pit.encoder): encoder_apply carries the job
+    in its launch; decoder_apply uses the result when plan / lmda / route are still the ones it was formed from.  A job no launch
+    took is dropped (drop_forward_job) - the decoder then forms its weights itself."""
+    scale_in = host_head_scale(lmda) if get_head_scale_route() == "host" else None
+    _STEP.dec_job = _new_decoder_weights(plan, lmda, scale_in, n_head, False, need_q)
+    _STEP.dec_ready = None
+
+
 class _Decoder(torch.autograd.Function):
     """pit.decoder (pit.py:124-127): posatt_cross_* (mesh_ltt -> mesh_out) followed by the thin-output kaiming_mlp `de`."""
 
     @staticmethod
-    def forward(ctx, values, head, plan: MeshPlan, n_head: int, head_is_scale: bool, head_param, scale_in, params, loss, w1, b1, w2, b2):
+    def forward(ctx, values, head, plan: MeshPlan, n_head: int, head_is_scale: bool, head_param, weights, params, loss, w1, b1, w2, b2):
         _need_gpu(values, head, w1, b1, w2, b2)
         values = _row_view(values)
         if values.stride(1) % 4 or values.stride(0) % 4 or values.data_ptr() % 16:
@@ -1417,18 +1463,15 @@ class _Decoder(torch.autograd.Function):
         dev = values.device
         sp = plan.slab_plan()[0]
         head = head.detach().reshape(-1).contiguous()
-        k_head, k_is_scale = (scale_in, True) if scale_in is not None else (head, head_is_scale)
         w1c, b1c, w2c, b2c = (t.detach().contiguous() for t in (w1, b1, w2, b2))
         rows = b * plan.n_out
-        need = any(ctx.needs_input_grad)
+        need = weights.qw is not None          # (decoder_apply asked for the d(scale) tiles exactly when a backward can follow)
         y = torch.empty((b, plan.n_out, n2), device=dev, dtype=torch.float32)
-        x = z1 = h = rowstat = scale = dvals = None
+        x = z1 = h = dvals = None
         if need:
             x = torch.empty((rows, n_head * d), device=dev, dtype=torch.float32)
             z1 = torch.empty((rows, d), device=dev, dtype=torch.float32)
             h = torch.empty((rows, d), device=dev, dtype=torch.float32)
-            rowstat = torch.empty((n_head, plan.n_out, 4), device=dev, dtype=torch.float32)
-            scale = torch.empty((n_head,), device=dev, dtype=torch.float32)
             dvals = torch.empty((b, j, d), device=dev, dtype=torch.float32)       # zeroed by the launch, added to by the backward
         lt = ls = lh = lpart = None
         lp = 0
@@ -1437,23 +1480,24 @@ class _Decoder(torch.autograd.Function):
             lpart = loss.partials = torch.empty((b, n2, sp.n_slabs, 2), device=dev, dtype=torch.float64)
             loss.value = torch.empty((), device=dev, dtype=torch.float32)
         rc = _lib.lib().pit_decoder_fwd(ctypes.byref(sp), values.data_ptr(), values.stride(1), values.stride(0), b, n_head, d,
-                                        k_head.data_ptr(), 1 if k_is_scale else 0, w1c.data_ptr(), b1c.data_ptr(), w2c.data_ptr(),
-                                        b2c.data_ptr(), n2, _lib.ptr(x), _lib.ptr(z1), _lib.ptr(h), y.data_ptr(), _lib.ptr(rowstat),
-                                        _lib.ptr(scale), _lib.ptr(dvals), dvals.numel() if dvals is not None else 0,
+                                        weights.pw.data_ptr(), w1c.data_ptr(), b1c.data_ptr(), w2c.data_ptr(),
+                                        b2c.data_ptr(), n2, _lib.ptr(x), _lib.ptr(z1), _lib.ptr(h), y.data_ptr(),
+                                        _lib.ptr(dvals), dvals.numel() if dvals is not None else 0,
                                         _lib.ptr(lt), _lib.ptr(ls), _lib.ptr(lh), lp, _lib.ptr(lpart), plan.slab_plan()[1],
-                                        plan.slab_plan()[3], _lib.stream_ptr())
+                                        _lib.stream_ptr())
         _lib.check(rc, "pit_decoder_fwd")
         ctx.plan, ctx.n_head, ctx.head_is_scale, ctx.head_param, ctx.params = plan, n_head, head_is_scale, head_param, params
         ctx.loss = loss if lpart is not None else None
         if ctx.loss is not None:
             loss.pred = y
         ctx.dvals_clean = True
-        ctx.keep = (values, head, w1c, w2c, x, z1, h, rowstat, scale, dvals)
+        ctx.keep = (values, head, w1c, w2c, x, z1, h, weights, dvals)
         return y
 
     @staticmethod
     def backward(ctx, d_y):
-        values, head, w1, w2, x, z1, h, rowstat, scale, dvals = ctx.keep
+        values, head, w1, w2, x, z1, h, weights, dvals = ctx.keep
+        scale = weights.scale
         plan, n_head = ctx.plan, ctx.n_head
         b, j, d = values.shape
         n2, rows = w2.shape[0], b * plan.n_out
@@ -1486,13 +1530,13 @@ class _Decoder(torch.autograd.Function):
                 _defer_head_begin(work)
         L = _lib.lib()
         rc = L.pit_decoder_bwd(ctypes.byref(sp), values.data_ptr(), values.stride(1), values.stride(0), b, n_head, d,
-                               scale.data_ptr(), rowstat.data_ptr(), w1.data_ptr(), w2.data_ptr(), n2, z1.data_ptr(),
+                               weights.pw.data_ptr(), weights.qw.data_ptr(), w1.data_ptr(), w2.data_ptr(), n2, z1.data_ptr(),
                                _lib.ptr(dyp), ld, dz1.data_ptr(), dvals.data_ptr(), dvals.stride(0), _lib.ptr(work),
                                loss.pred.data_ptr() if inside else None, _lib.ptr(loss.true) if inside else None,
                                _lib.ptr(loss.scale) if inside else None, _lib.ptr(loss.shift) if inside else None,
                                _lib.ptr(loss.seed) if inside else None, loss.p if inside else 0,
                                _lib.ptr(loss.partials) if inside else None, d_pred.data_ptr() if inside else None,
-                               loss.value.data_ptr() if inside else None, None, plan.slab_plan()[1], plan.slab_plan()[3], _lib.stream_ptr())
+                               loss.value.data_ptr() if inside else None, None, plan.slab_plan()[1], _lib.stream_ptr())
         _lib.check(rc, "pit_decoder_bwd")
         d_head = None
         if need_h:
@@ -1527,6 +1571,13 @@ def decoder_apply(values: torch.Tensor, lmda: torch.Tensor, plan: MeshPlan, n_he
     ``mlp`` = de's (w1, b1, w2, b2).  The caller checked edge_fusion_supported(plan, ..., needs_union=True)."""
     param = lmda if isinstance(lmda, torch.nn.Parameter) else None
     c = host_head_scale(lmda) if (not head_is_scale and get_head_scale_route() == "host") else None
+    need_q = torch.is_grad_enabled() and (values.requires_grad or lmda.requires_grad or any(t.requires_grad for t in mlp))
+    # the step's weights: formed under the encoder-side launch when pit.encoder requested them for exactly this plan / lmda / route
+    weights = getattr(_STEP, "dec_ready", None)
+    _STEP.dec_ready = None
+    if weights is None or weights.key != _dec_weights_key(plan, lmda, c, n_head, head_is_scale) or (need_q and weights.qw is None):
+        weights = _new_decoder_weights(plan, lmda, c, n_head, head_is_scale, need_q)
+        _launch_decoder_weights(weights)
     loss = getattr(_STEP, "loss", None)
     if loss is not None:
         _STEP.loss = None                        # (one decoder per step takes it)
@@ -1534,7 +1585,7 @@ def decoder_apply(values: torch.Tensor, lmda: torch.Tensor, plan: MeshPlan, n_he
             loss = None
         else:
             _STEP.loss_issued = loss
-    return _Decoder.apply(values, lmda.reshape(-1), plan, n_head, head_is_scale, param, c, tuple(mlp), loss, *mlp)
+    return _Decoder.apply(values, lmda.reshape(-1), plan, n_head, head_is_scale, param, weights, tuple(mlp), loss, *mlp)
 
 
 class _Encoder(torch.autograd.Function):
@@ -1542,7 +1593,7 @@ class _Encoder(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, values, head, plan: MeshPlan, n_head: int, head_is_scale: bool, head_param, scale_in, params, coord_dims: int,
-                concat_heads: int, wjob, clear, w1, b1, w2, b2):
+                concat_heads: int, wjob, clear, w1, b1, w2, b2, djob=None, need=True):
         _need_gpu(values, head, w1, b1, w2, b2)
         values = _row_view(values)
         b, j, dv = values.shape
@@ -1555,7 +1606,6 @@ class _Encoder(torch.autograd.Function):
         k_head, k_is_scale = (scale_in, True) if scale_in is not None else (head, head_is_scale)
         w1c, b1c, w2c, b2c = (t.detach().contiguous() for t in (w1, b1, w2, b2))
         rows = b * plan.n_out
-        need = any(ctx.needs_input_grad)
         buf = None
         if concat_heads > 0:
             buf = torch.empty((rows, (1 + concat_heads) * d), device=dev, dtype=torch.float32)
@@ -1576,6 +1626,7 @@ class _Encoder(torch.autograd.Function):
                                         _lib.ptr(h), _lib.ptr(z2), y.data_ptr(), y.stride(0), _lib.ptr(rowstat), _lib.ptr(scale),
                                         _lib.ptr(clear), clear.numel() if clear is not None else 0,
                                         ctypes.cast(ctypes.pointer(wjob.job), ctypes.c_void_p) if wjob is not None else None,
+                                        ctypes.cast(ctypes.pointer(djob.job), ctypes.c_void_p) if djob is not None else None,
                                         _lib.stream_ptr())
         _lib.check(rc, "pit_encoder_fwd")
         ctx.plan, ctx.n_head, ctx.head_is_scale, ctx.head_param, ctx.params, ctx.kd = plan, n_head, head_is_scale, head_param, params, kd
@@ -1635,7 +1686,7 @@ class _Encoder(torch.autograd.Function):
         else:
             _dw_run((st, keep, torch.cuda.current_stream(dev)))
         w = (None, None, None, None) if inplace else (d_w1, d_b1, d_w2, d_b2)
-        return (None, d_head, None, None, None, None, None, None, None, None, None, None) + w
+        return (None, d_head, None, None, None, None, None, None, None, None, None, None) + w + (None, None)
 
 
 @torch.compiler.disable
@@ -1655,8 +1706,12 @@ def encoder_apply(values: torch.Tensor, lmda: torch.Tensor, plan: MeshPlan, n_he
     clear = getattr(_STEP, "clear", None)
     if clear is not None:
         _STEP.clear = None                       # (zeroed by this launch: the step's loss launch need not)
+    djob = getattr(_STEP, "dec_job", None)       # the decoder's weights of this forward ride in this launch (early_decoder_weights)
+    _STEP.dec_job = None
     res = _Encoder.apply(values.detach(), lmda.reshape(-1), plan, n_head, head_is_scale, param, c, tuple(mlp), kd, int(concat_heads),
-                         wjob, clear, *mlp)
+                         wjob, clear, *mlp, djob,
+                         torch.is_grad_enabled() and (lmda.requires_grad or any(t.requires_grad for t in mlp)))
+    _STEP.dec_ready = djob
     if concat_heads <= 0:
         return res
     y, buf = res

@@ -328,6 +328,21 @@ class pit(nn.Module):
         return ops.encoder_apply(func_in, down.lmda, plan, down.n_head, (en.mlp1.weight, en.mlp1.bias, en.mlp2.weight, en.mlp2.bias),
                                  concat_heads=self._heads_of_block(0, self.hid_dim), early=early)
 
+    def _cached_decoder_plan(self, mesh_ltt, batch, device):
+        """The plan the fused decoder ran on last time, if this forward's decoder will - as far as the encoder can tell: same
+        latent mesh - run on it again; its weights are then formed under the encoder-side launch (ops.early_decoder_weights).
+        A wrong guess costs nothing but the unused tiles: ops.decoder_apply checks plan and lmda before it uses them."""
+        up, de = self.up, self.de
+        if not (isinstance(up, posatt) and up._plans and torch.is_tensor(mesh_ltt) and mesh_ltt.dim() == 2 and type(de) is kaiming_mlp):
+            return None
+        plan = next(reversed(up._plans.values()))
+        if plan.mesh_in.data_ptr() != mesh_ltt.data_ptr() or plan.n_in != mesh_ltt.shape[0] or plan.mesh_in.device != device:
+            return None
+        hid = self.hid_dim
+        if de.mlp2.out_features > 4 or de.mlp1.out_features != hid or de.mlp1.in_features != up.n_head * hid:
+            return None
+        return self._edge_layer(up, de, plan.mesh_out, plan.mesh_in, batch, device, True)
+
     def encoder(self, mesh_in, func_in, mesh_ltt):
         # the fused processor's weights depend on (mesh_ltt, lmda) only: they are formed by extra workgroups of the
         # encoder-side launch (ops.early_block_weights) instead of a launch of their own; processor() picks them up
@@ -338,6 +353,11 @@ class pit(nn.Module):
                 if plan is not None:
                     need_q = torch.is_grad_enabled() and (func_in.requires_grad or any(q.requires_grad for q in self.parameters()))
                     early = ops.early_block_weights(plan, [a.lmda for a in self.conv], self.conv[0].n_head, need_q)
+            if ops.EDGE_FUSION and torch.is_tensor(func_in) and func_in.is_cuda and func_in.dim() == 3:
+                dplan = self._cached_decoder_plan(mesh_ltt, func_in.shape[0], func_in.device)
+                if dplan is not None:
+                    need_q = torch.is_grad_enabled() and any(q.requires_grad for q in self.parameters())
+                    ops.early_decoder_weights(dplan, self.up.lmda, self.up.n_head, need_q)
             fused = self._fused_encoder(mesh_in, func_in, mesh_ltt, early)
             func_ltt = self.down(mesh_ltt, mesh_in, func_in) if fused is None else None
             if early is not None:
