@@ -187,7 +187,9 @@ def test_graph_keeps_the_mode_it_was_captured_with(bf16):
     from position_induced_transformer_amd import tasks
     from position_induced_transformer_amd.engine import TrainStep
     model, sample, meta = tasks.make_task("darcy", seed=1)
-    batch = sample(32)          # (large enough for the bf16 GEMM kernels: the small regime contracts in fp32 in both modes - round 4)
+    # (large enough for the bf16 GEMM kernels of the processor: the fused small-regime kernels - processor blocks up to 16 384
+    # rows, the encoder- / decoder-side launches at every size - contract in fp32 in both modes, rounds 4 / 5)
+    batch = sample(128)
     step = TrainStep(model, batch, meta["out_dim"], meta["p"])
     step.capture()
     step.replay(); torch.cuda.synchronize()
