@@ -143,6 +143,9 @@ __global__ __launch_bounds__(512) void block_fwd_kernel(BlockFwdArgs g) {
     // the slab's own X rows (first 64 columns of the concat tile): requested first, parked after the attention loads
     float4 xown = make_float4(0.f, 0.f, 0.f, 0.f);
     if (tid < 256) xown = *reinterpret_cast<const float4*>(g.xcat + (m0 + (tid >> 4)) * W + 4 * (tid & 15));
+    // 1 / rowsum of the row this thread normalises after the reduction (item = tid when H = 2: one per thread): requested here -
+    // round 5: loaded inside the reduction it was a dependent memory round trip in the middle of the chain
+    const float rinv0 = g.inv[(long)((tid >> 8) % H) * g.L + n0 + 4 * ((tid & 63) >> 4) + ((tid >> 6) & 3)];
 
     BSTAMP(0);
     // MLP operands (waves 0..3 own the four hidden / output tiles): requested before (EARLYW) or after the attention
@@ -180,7 +183,7 @@ __global__ __launch_bounds__(512) void block_fwd_kernel(BlockFwdArgs g) {
         const int hh = item >> 8, i = (item >> 6) & 3, ln = item & 63;
         const int r = 4 * (ln >> 4) + i, col = 4 * (ln & 15);
         float4 s = parked_sum(pk, hh, BW, H, i, ln);
-        const float rinv = g.inv[(long)hh * g.L + n0 + r];
+        const float rinv = item == tid ? rinv0 : g.inv[(long)hh * g.L + n0 + r];
         s.x *= rinv; s.y *= rinv; s.z *= rinv; s.w *= rinv;
         *reinterpret_cast<float4*>(xs + r * XP + BD + hh * BD + col) = s;
         *reinterpret_cast<float4*>(g.xcat + (m0 + r) * W + BD + hh * BD + col) = s;

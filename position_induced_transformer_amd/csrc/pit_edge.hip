@@ -231,7 +231,6 @@ struct DecFwdArgs {
     float* zero_buf; long zero_n;
     const float *tru, *lscale, *lshift; int loss_p; double* lpart;
     int um;                                   // slots of the union tiles in LDS: 32, 48 or 64 >= the plan's largest union
-    int spw;                                  // slabs per workgroup
 };
 
 // The slab's union value rows: thread (r0 = tid / (D/4), q = tid % (D/4)) owns the 16-byte piece q of slots r0, r0 + 16, ... .
@@ -310,13 +309,23 @@ __global__ __launch_bounds__(4 * D) void decoder_fwd_kernel(DecFwdArgs g) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, kq = lane >> 4;
     const pit_slab_plan& p = g.p;
-    // a workgroup owns g.spw consecutive slabs of one sample (1 in the latency regime; more when the launch has thousands of
-    // slabs: the MLP operands - 32 KB of W1 per workgroup, what loads the L1 / address path most - are then fetched once for all)
-    const int groups = (p.n_slabs + g.spw - 1) / g.spw;
-    int b, sg;
-    if (!slab_of_xcd(blockIdx.x, g.batch, groups, b, sg)) return;
+    // (ONE slab per workgroup.  A loop over 2-4 slabs with the MLP operands - 32 KB of W1, what loads the L1 / address path most -
+    // fetched once was measured SLOWER: at Darcy b=256, 29 696 slabs, decoder_fwd 182 -> 202 us with four slabs per workgroup - they
+    // run one after the other and wave 0's output phase stalls the rest; and the loop alone, with one slab, cost 3 us at b=8: the
+    // loads of its body no longer overlap the operands requested in front of it.)
+    int b, slab;
+    if (!slab_of_xcd(blockIdx.x, g.batch, p.n_slabs, b, slab)) return;
+    const int nk = min(p.nkeys[slab], EU), nkup = (nk + 15) & ~15;
+    const long row0 = (long)b * p.n_out + slab * ER;             // first row of the slab in the (batch * n_out) row space
     const int c1 = wave * 16 + l15;
     ESTAMP(0, 0);
+    // ---- ONE block of loads, nothing consumed inside it: the union keys first (the gather waits for them alone), then the
+    // slab's weight tile, the MLP operands, the loss's operands
+    int key[EU / 16];
+    union_keys<D>(p, slab, tid, nkup, key);
+    const int npc = H * ER * g.um / 4;
+    float4 pcp[WCP * 256 / NT];
+    wtile_request<NT>(g.pw + (long)slab * H * ER * g.um, npc, tid, pcp);
     float4 bv[KS];
 #pragma unroll
     for (int s = 0; s < KS; ++s)
@@ -324,18 +333,6 @@ __global__ __launch_bounds__(4 * D) void decoder_fwd_kernel(DecFwdArgs g) {
     const float bias1 = g.b1[c1];
     const float w2r = ldg_if(g.w2, tid, tid < g.n2 * D);          // (n2 * D <= 4 * D = NT: one element per thread)
     const float b2r = ldg_if(g.b2, tid, tid < g.n2);
-  for (int it = 0; it < g.spw; ++it) {
-    const int slab = sg * g.spw + it;
-    if (slab >= p.n_slabs) break;
-    const int nk = min(p.nkeys[slab], EU), nkup = (nk + 15) & ~15;
-    const long row0 = (long)b * p.n_out + slab * ER;             // first row of the slab in the (batch * n_out) row space
-    // ---- ONE block of loads, nothing consumed inside it: the union keys first (the gather waits for them alone), then the
-    // slab's weight tile and the loss's operands (the MLP operands above, once per workgroup)
-    int key[EU / 16];
-    union_keys<D>(p, slab, tid, nkup, key);
-    const int npc = H * ER * g.um / 4;
-    float4 pcp[WCP * 256 / NT];
-    wtile_request<NT>(g.pw + (long)slab * H * ER * g.um, npc, tid, pcp);
     // the loss's operands of this lane's row, output channel 0 (wave 0 finishes the slab; every wave requests them: no branch)
     float l_t0 = 0.0f, l_sc0 = 1.0f, l_sh0 = 0.0f;
     if (LOSS) {
@@ -351,10 +348,8 @@ __global__ __launch_bounds__(4 * D) void decoder_fwd_kernel(DecFwdArgs g) {
     gather_union<D>(g.values + (long)b * g.values_bstride, g.ld_values, key, nk, nkup, tid, uv);
     __builtin_amdgcn_sched_barrier(0);       // (left to itself the scheduler sinks each load to its use: dependent round trips again)
     ESTAMP(0, 1);
-    if (it == 0) {
-        w2s[tid] = w2r;
-        if (tid < 4) w2s[4 * D + tid] = b2r;
-    }
+    w2s[tid] = w2r;
+    if (tid < 4) w2s[4 * D + tid] = b2r;
     wtile_park<NT>(pt, g.um, npc, tid, pcp);
     ESTAMP(0, 2);
     park_union<D>(ut, nkup, tid, uv);
@@ -407,8 +402,20 @@ __global__ __launch_bounds__(4 * D) void decoder_fwd_kernel(DecFwdArgs g) {
         if (slab * ER + r < p.n_out)
             *reinterpret_cast<float4*>(g.h + (row0 + r) * D + 4 * q) = *reinterpret_cast<const float4*>(hs + r * HP + 4 * q);
     }
-    // ---- thin output layer (out_dim <= 4, pit.py:106): a row dot per output; the slab's share of the loss - wave 0
-   if (wave == 0) {
+    if (wave != 0) {
+        // the other waves clear this workgroup's share of the buffer the backward adds to (fire and forget, off wave 0's path)
+        if (g.zero_buf) {
+            const long wgs = (long)g.batch * p.n_slabs, me = (long)b * p.n_slabs + slab;
+            const long per = ((g.zero_n + wgs - 1) / wgs + 3) & ~3L;
+            const long beg = me * per, end = min(g.zero_n, beg + per);
+            for (long e = beg + 4 * (tid - 64); e < end; e += 4 * (NT - 64)) {
+                if (e + 4 <= end) *reinterpret_cast<float4*>(g.zero_buf + e) = make_float4(0.f, 0.f, 0.f, 0.f);
+                else for (long q = e; q < end; ++q) g.zero_buf[q] = 0.0f;
+            }
+        }
+        return;
+    }
+    // ---- thin output layer (out_dim <= 4, pit.py:106): a row dot per output; the slab's share of the loss
     const int n = slab * ER + l15;
     const bool rv = n < p.n_out;
 #pragma unroll
@@ -446,20 +453,7 @@ __global__ __launch_bounds__(4 * D) void decoder_fwd_kernel(DecFwdArgs g) {
             }
         }
     }
-   }
-    if (it + 1 < g.spw) __syncthreads();       // (the next slab's tiles overwrite what wave 0 has just read)
-  }
     ESTAMP(0, 9);
-    if (wave != 0 && g.zero_buf) {
-        // the other waves clear this workgroup's share of the buffer the backward adds to (fire and forget, off wave 0's path)
-        const long wgs = (long)g.batch * groups, me = (long)b * groups + sg;
-        const long per = ((g.zero_n + wgs - 1) / wgs + 3) & ~3L;
-        const long beg = me * per, end = min(g.zero_n, beg + per);
-        for (long e = beg + 4 * (tid - 64); e < end; e += 4 * (NT - 64)) {
-            if (e + 4 <= end) *reinterpret_cast<float4*>(g.zero_buf + e) = make_float4(0.f, 0.f, 0.f, 0.f);
-            else for (long q = e; q < end; ++q) g.zero_buf[q] = 0.0f;
-        }
-    }
 }
 
 // ------------------------------------------------------------------------------------------------ decoder backward
@@ -1116,11 +1110,7 @@ extern "C" int pit_decoder_fwd(const pit_slab_plan* plan, const float* values, l
     g.x = x; g.z1 = z1; g.h = h; g.y = y; g.zero_buf = zero_buf; g.zero_n = zero_buf ? zero_n : 0;
     g.tru = loss_true; g.lscale = loss_scale; g.lshift = loss_shift; g.loss_p = loss_p; g.lpart = loss_part;
     g.um = union_slots(max_union);
-    // slabs per workgroup: ONE.  (Fetching W1 once for 4 slabs of a workgroup was measured slower at Darcy b=256 - 29 696 slabs:
-    // decoder_fwd 182 -> 202 us; the slabs of a workgroup run one after the other and wave 0's output phase stalls the rest -
-    // co-resident workgroups overlap better than a loop does.)
-    g.spw = 1;
-    const dim3 grid((unsigned)slab_grid(batch, (plan->n_slabs + g.spw - 1) / g.spw));
+    const dim3 grid((unsigned)slab_grid(batch, plan->n_slabs));
     hipStream_t s = (hipStream_t)stream;
 #define PIT_DF(H_, D_)                                                                                                                \
     do {                                                                                                                              \

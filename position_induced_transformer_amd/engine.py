@@ -68,6 +68,7 @@ class TrainStep:
         self.flat = flat if flat is not None else FlatGradients(model.parameters())
         self._early_pending = False
         self._early_ok = False
+        self._early_decision = None          # two buckets or one exchange: decided ONCE, by all ranks together (_decide_early)
         self.loss = torch.zeros((), device=self.func_in.device)
         self.out = None
         self._seed = torch.ones((), device=self.func_in.device)      # d loss / d loss, allocated once
@@ -81,6 +82,30 @@ class TrainStep:
         gets its gradient from autograd's AccumulateGrad AFTER the node returns - for the fused processor that is after the
         early all-reduce was issued, and the ranks would silently diverge."""
         return all(ops._grad_slot(p) is not None for p in self._tail_params)
+
+    def _decide_early(self) -> bool:
+        """Two-bucket exchange or one all-reduce after the pass: the SHAPE of the collective sequence.  Decided once per step
+        object - at its first step, before any capture - and by all ranks together (MIN over the group of "every tail gradient
+        is written in place here"): a rank with a hook on a tail parameter, a dropped .grad or another
+        FUSED_GRAD_ACCUMULATION setting would otherwise issue collectives of other counts and sizes than its peers - a hang the
+        watchdog is the only witness of.  If the local condition changes afterwards the step raises instead of
+        silently switching shape (a captured graph has the shape it was captured with baked in)."""
+        local = bool(self.buckets == 2 and self.all_reduce and self._tail_in_place())
+        if self._early_decision is None:
+            agreed = local
+            if self.buckets == 2 and self.all_reduce:
+                import torch.distributed as dist
+                if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+                    flag = torch.tensor([1 if local else 0], device=self.func_in.device if dist.get_backend() != "gloo" else "cpu",
+                                        dtype=torch.int32)
+                    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                    agreed = bool(int(flag.item()))
+            self._early_decision = agreed
+        elif self._early_decision and not local:
+            raise RuntimeError("two-bucket data-parallel step: a gradient of the early bucket is no longer written in place (a hook "
+                               "on the parameter, a dropped / replaced .grad, in-place accumulation switched off) - the ranks "
+                               "agreed on the two-bucket exchange when the step was built; rebuild the TrainStep")
+        return self._early_decision
 
     def _mark_early_point(self, _module, _inputs, output):
         if self._early_ok and torch.is_tensor(output) and output.requires_grad:
@@ -110,7 +135,7 @@ class TrainStep:
 
     def _step(self) -> None:
         self._early_pending = False
-        early = self.buckets == 2 and self.all_reduce and self._tail_in_place()    # (else: ONE all-reduce after the pass)
+        early = self._decide_early()             # (False: ONE all-reduce after the pass)
         self._early_ok = early
         sc, sh = self.affine if self.affine is not None else (None, None)
         # the flat gradient accumulators are cleared on the way by the step's first fused launch (ops.encoder_apply) or by

@@ -248,3 +248,62 @@ def test_prediction_that_is_post_processed_keeps_the_loss_launch():
     want = float(((t - o).norm(dim=1) / t.norm(dim=1)).sum())
     assert abs(float(step.loss) - want) <= 1e-5 * abs(want)
     assert all(torch.isfinite(q.grad).all() and float(q.grad.abs().max()) > 0 for q in model.parameters())
+
+
+def test_large_batch_step_on_the_large_regime_kernels_matches_the_oracle():
+    """Darcy at batch 256 (the large-regime paths had no direct test): 65 536 latent rows take the precomputed-weights
+    self-attention (pit_posatt_pre_fwd / _bwd) and the 64-row-slab MLP kernels (pit_mlp_slab.hip), 473 344 decoder rows the fused
+    decoder launches with the loss inside - forward, loss and every gradient of the flat buffer against the oracle.  (The
+    weight-gradient tolerance grows with the square root of the rows summed, as in bench.parity_vs_oracle.)"""
+    from position_induced_transformer_amd import ops, tasks
+    from position_induced_transformer_amd.engine import TrainStep
+    model, sample, meta = tasks.make_task("darcy", seed=58)
+    b4 = sample(256)
+    calls = {"pre": 0}
+    orig = ops.posatt_pre_apply
+
+    def counting(*a, **k):
+        calls["pre"] += 1
+        return orig(*a, **k)
+    ops.posatt_pre_apply = counting
+    try:
+        with ops.head_scale_route("host"), _Count("decoder_apply") as cd:
+            step = TrainStep(model, b4, meta["out_dim"], meta["p"])
+            step.run_eager()
+            step.run_eager()
+    finally:
+        ops.posatt_pre_apply = orig
+    torch.cuda.synchronize()
+    assert calls["pre"] >= len(model.conv) and cd.n >= 1
+    ref, ref_loss, ref_grads = _oracle_step("darcy", model, b4, None, meta)
+    assert gio.rel_l2(step.out.cpu().numpy(), ref.numpy()) <= 1e-5
+    assert abs(float(step.loss) - ref_loss) <= 1e-5 * abs(ref_loss)
+    wtol = 2e-5 * (256 * 1849 / 16384.0) ** 0.5
+    lk = [k for k in ref_grads if k.endswith("lmda")]
+    for k, q in model.named_parameters():
+        if not k.endswith("lmda"):
+            assert gio.rel_l2(q.grad.cpu().numpy(), ref_grads[k].numpy()) <= wtol, k
+    got = torch.cat([dict(model.named_parameters())[k].grad.cpu().reshape(-1) for k in lk])
+    want = torch.cat([ref_grads[k].reshape(-1) for k in lk])
+    assert float((got - want).norm()) <= 5e-4 * float(want.norm()), "d(lmda)"
+
+
+def test_two_bucket_decision_is_made_once_and_a_later_change_raises():
+    """whether a data-parallel step reduces an early bucket is the SHAPE of its collective sequence - decided at the
+    first step (by all ranks together: MIN over the group) and never silently switched: a tail gradient that stops being written
+    in place afterwards raises."""
+    from position_induced_transformer_amd import tasks
+    from position_induced_transformer_amd.engine import TrainStep
+    model, sample, meta = tasks.make_task("darcy", seed=59)
+    step = TrainStep(model, sample(4), meta["out_dim"], meta["p"], all_reduce=True, all_reduce_buckets=2)
+    step.flat.all_reduce = lambda average=False, group=None, part="all": None          # (one process: the sum over one rank)
+    step.run_eager()
+    assert step._early_decision is True
+    handle = model.de.mlp1.weight.register_hook(lambda g: g)
+    try:
+        with pytest.raises(RuntimeError, match="no longer written in place"):
+            step.run_eager()
+    finally:
+        handle.remove()
+        step._early_hook.remove()
+    torch.cuda.synchronize()
