@@ -247,9 +247,9 @@ def pmc_traffic(kernel_key, shape):
     """HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE collected in separate
     runs - counters cannot be read inside this process -, corrected as MI355X_MICROARCH.md prescribes and calibrated in
     profiles/r03_fetch_calibration.txt).  The committed record is keyed by kernel AND by the shape of the launch it was
-    measured on (profiles/r04_pmc_traffic.json: ``shape``): a probe that times another launch of the family gets None,
+    measured on (profiles/r05_pmc_traffic.json: ``shape``): a probe that times another launch of the family gets None,
     never another launch's bytes."""
-    for name in ("r04_pmc_traffic.json",):
+    for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 rec = json.load(f)["kernels"].get(kernel_key)

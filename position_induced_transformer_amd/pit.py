@@ -289,12 +289,16 @@ class pit(nn.Module):
                 return False
         return True
 
+    def _edge_modules(self, att, mlp) -> bool:
+        """Cross-attention ``att`` and kaiming_mlp ``mlp`` are OUR unmodified modules of a shape the fused launches cover."""
+        return bool(ops.EDGE_FUSION and isinstance(att, posatt) and not att._batched and type(att).forward in _OWN_CROSS_FORWARDS
+                    and not att._overridden() and type(mlp) is kaiming_mlp and mlp.mlp1.bias is not None and mlp.mlp2.bias is not None
+                    and self._plain(att, mlp, mlp.mlp1, mlp.mlp2) and mlp.mlp1.out_features in (32, 64) and att.n_head in (1, 2))
+
     def _edge_layer(self, att, mlp, mesh_out, mesh_in, batch, device, needs_union):
         """The mesh plan when cross-attention ``att`` followed by kaiming_mlp ``mlp`` can run as one fused launch per direction
         (ops.encoder_apply / ops.decoder_apply: batch-free meshes, small regime), else None."""
-        if not (ops.EDGE_FUSION and isinstance(att, posatt) and not att._batched and type(att).forward in _OWN_CROSS_FORWARDS
-                and not att._overridden() and type(mlp) is kaiming_mlp and mlp.mlp1.bias is not None and mlp.mlp2.bias is not None
-                and self._plain(att, mlp, mlp.mlp1, mlp.mlp2)):
+        if not self._edge_modules(att, mlp):
             return None
         if not (torch.is_tensor(mesh_out) and torch.is_tensor(mesh_in) and mesh_out.dim() == 2 and mesh_in.dim() == 2
                 and mesh_out.is_cuda and mesh_in.is_cuda and mesh_out.device == device and mesh_in.device == device):
@@ -333,15 +337,16 @@ class pit(nn.Module):
         latent mesh - run on it again; its weights are then formed under the encoder-side launch (ops.early_decoder_weights).
         A wrong guess costs nothing but the unused tiles: ops.decoder_apply checks plan and lmda before it uses them."""
         up, de = self.up, self.de
-        if not (isinstance(up, posatt) and up._plans and torch.is_tensor(mesh_ltt) and mesh_ltt.dim() == 2 and type(de) is kaiming_mlp):
-            return None
-        plan = next(reversed(up._plans.values()))
-        if plan.mesh_in.data_ptr() != mesh_ltt.data_ptr() or plan.n_in != mesh_ltt.shape[0] or plan.mesh_in.device != device:
+        if not (isinstance(up, posatt) and up._plans and torch.is_tensor(mesh_ltt) and mesh_ltt.dim() == 2 and self._edge_modules(up, de)):
             return None
         hid = self.hid_dim
         if de.mlp2.out_features > 4 or de.mlp1.out_features != hid or de.mlp1.in_features != up.n_head * hid:
             return None
-        return self._edge_layer(up, de, plan.mesh_out, plan.mesh_in, batch, device, True)
+        # (the cache is keyed on the CALLER's mesh tensors - posatt._plan: address, shape, version - the plan may hold copies)
+        key, plan = next(reversed(up._plans.items()))
+        if key[1] != mesh_ltt.data_ptr() or key[3] != tuple(mesh_ltt.shape) or key[5] != mesh_ltt._version or key[8] != device.index:
+            return None
+        return plan if ops.edge_fusion_supported(plan, up.n_head, hid, batch, True) else None
 
     def encoder(self, mesh_in, func_in, mesh_ltt):
         # the fused processor's weights depend on (mesh_ltt, lmda) only: they are formed by extra workgroups of the

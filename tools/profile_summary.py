@@ -27,7 +27,11 @@ trace = glob.glob(os.path.join(base, "trace", "**", "*kernel_trace.csv"), recurs
 rows = list(csv.DictReader(open(trace[0]))) if trace else []
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 names = [clean(r["Kernel_Name"]) for r in rows]
-marks = [i for i, n in enumerate(names) if "rel_lp_fwd" in n]
+# one step = from a launch that occurs once per step to its next occurrence: the loss launch, or - round 5: the loss of the
+# small-regime models rides in the decoder launches - the fused encoder-side launch that opens their step
+marks = [i for i, n in enumerate(names) if "encoder_fwd_kernel" in n]
+if len(marks) < 3:
+    marks = [i for i, n in enumerate(names) if "rel_lp_fwd" in n]
 summary = {"config": cfg, "kernels": []}
 try:
     summary["bench"] = json.load(open(os.path.join(out, cfg + ".bench.json")))
