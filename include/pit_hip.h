@@ -357,6 +357,19 @@ int pit_decoder_bwd(const pit_slab_plan* plan, const float* values, long ld_valu
                     const float* loss_pred, const float* loss_true, const float* loss_scale, const float* loss_shift,
                     const float* loss_seed, int loss_p, const double* loss_part, float* d_pred, float* loss_out,
                     float* norms_out, int max_union, void* stream);
+/* The same union-tile contraction WITHOUT the MLP, for any value width that is a multiple of 64 (masked cross attention on a
+ * batch-free mesh pair with a slab plan: the up-projections of Vorticity / Cylinder at hid 256): a workgroup per (sample, slab,
+ * 64-column chunk).  out[b, n, h*dim + d] (no input copy, column offset 0) fp32 or - out_bf16 - bf16; the backward reads d_out of the
+ * same layout ONCE, ADDS d(values) (fp32 atomics; zero on entry; NULL: not needed) and / or the d(scale) accumulators (PIT_HEAD_DEFER
+ * convention; NULL: not needed).  pw / qw from pit_decoder_weights. */
+int pit_union_att_supported(int n_head, int dim, int batch, int rows_per_sample);
+int pit_union_att_fwd(const pit_slab_plan* plan, const float* values, long ld_values, long values_bstride, int batch,
+                      int n_head, int dim, const float* pw, void* out, long ld_out, long out_bstride, int out_bf16,
+                      int max_union, void* stream);
+int pit_union_att_bwd(const pit_slab_plan* plan, const float* values, long ld_values, long values_bstride, int batch,
+                      int n_head, int dim, const float* pw, const float* qw,
+                      const void* d_out, long ld_dout, long dout_bstride, int dout_bf16,
+                      float* d_values, long ld_dvalues, long dvalues_bstride, double* dscale, int max_union, void* stream);
 /* pit.encoder forward.  Value channels [0, coord_dims) are the key coordinates (mesh_in; train_darcy.py:51-55), the other
  * value_dim channels come from values (batch, n_in, value_dim); n_head*(coord_dims + value_dim) <= 16.  The MLP is
  * (n_head*(coord_dims+value_dim) -> dim -> dim) followed by gelu; y rows ldy apart (the first columns of the processor's concat

@@ -83,6 +83,9 @@ SIGNATURES = {
                         _P, _P, _P, _I, _P, _I, _P],
     "pit_decoder_bwd": [_P, _P, _L, _L, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _L, _P, _P, _L, _P,
                         _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _P],
+    "pit_union_att_supported": [_I, _I, _I, _I],
+    "pit_union_att_fwd": [_P, _P, _L, _L, _I, _I, _I, _P, _P, _L, _L, _I, _I, _P],
+    "pit_union_att_bwd": [_P, _P, _L, _L, _I, _I, _I, _P, _P, _P, _L, _L, _I, _P, _L, _L, _P, _I, _P],
     "pit_encoder_fwd": [_P, _P, _I, _I, _P, _L, _L, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P,
                         _P, _P, _P, _P, _P, _L, _P, _P, _P, _L, _P, _P, _P],
     "pit_encoder_bwd": [_P, _P, _I, _I, _P, _L, _L, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _L, _P, _P, _P],

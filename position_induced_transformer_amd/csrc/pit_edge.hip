@@ -1016,6 +1016,171 @@ __global__ __launch_bounds__(4 * D) void encoder_bwd_kernel(EncArgs g) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------ union attention, any width
+// The same union-tile contraction as the decoder's, WITHOUT the MLP, for value widths that are multiples of 64 (Vorticity / Cylinder:
+// hid 256): a workgroup owns (sample, 16-row slab, 64-column chunk).  Forward `out = P U`; backward d(values) `+= P^T dO` (fp32
+// atomics) and d(scale) `-= (Q U) . dO` from the same tiles, `d_out` read ONCE (the candidate-list backward gathers every row of it
+// once per listing key, ~9x: posatt_sparse_bwd_kernel 170-187 us at Vorticity b=20).  `out` / `d_out` fp32 or bf16 (PIT_IO_*).
+struct UAttArgs {
+    pit_slab_plan p; int um, batch, dim;
+    const float* values; long ld_values, values_bstride;
+    const float *pw, *qw;
+    void* out; long ld_out, out_bstride; int out16;
+    const void* d_out; long ld_dout, dout_bstride; int dout16;
+    float* d_values; long ld_dvalues, dvalues_bstride; double* dscale;
+};
+
+template <int H>
+__global__ __launch_bounds__(256) void union_att_fwd_kernel(UAttArgs g) {
+    constexpr int D = 64, NT = 256, XP = H * D + 4;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int UP = g.um + 4;
+    float* pt = smem;                          // [H][16][UP]
+    float* ut = pt + H * ER * UP;              // [um][D + 4]
+    float* xs = ut + g.um * (D + 4);           // [16][XP]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, kq = lane >> 4;
+    const pit_slab_plan& p = g.p;
+    const int chunks = g.dim / D;
+    const int chunk = (int)blockIdx.x % chunks;
+    int b, slab;
+    if (!slab_of_xcd((int)blockIdx.x / chunks, g.batch, p.n_slabs, b, slab)) return;
+    const int nk = min(p.nkeys[slab], EU), nkup = (nk + 15) & ~15;
+    const int c1 = wave * 16 + l15;
+    int key[EU / 16];
+    union_keys<D>(p, slab, tid, nkup, key);
+    const int npc = H * ER * g.um / 4;
+    float4 pcp[WCP];
+    wtile_request<NT>(g.pw + (long)slab * H * ER * g.um, npc, tid, pcp);
+    float4 uv[EU / 16];
+    gather_union<D>(g.values + (long)b * g.values_bstride + chunk * D, g.ld_values, key, nk, nkup, tid, uv);
+    __builtin_amdgcn_sched_barrier(0);
+    wtile_park<NT>(pt, g.um, npc, tid, pcp);
+    park_union<D>(ut, nkup, tid, uv);
+    __syncthreads();
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+        const f32x4_t o = tile_times_union<D>(pt + h * ER * UP, UP, ut, nkup, wave, l15, kq);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xs[(4 * kq + i) * XP + h * D + c1] = o[i];
+    }
+    __syncthreads();
+    // the tile to memory as 4-column pieces (16 B of fp32, 8 B of bf16): column h*64 + 4q of the tile is h*dim + chunk*64 + 4q of out
+#pragma unroll
+    for (int u = 0; u < H * ER * D / 4 / NT; ++u) {
+        const int e = tid + u * NT, r = e / (H * D / 4), q4 = e % (H * D / 4), h = q4 / (D / 4), q = q4 % (D / 4);
+        const int n = slab * ER + r;
+        if (n >= p.n_out) continue;
+        const float4 v = *reinterpret_cast<const float4*>(xs + r * XP + h * D + 4 * q);
+        const long o = (long)b * g.out_bstride + (long)n * g.ld_out + (long)h * g.dim + chunk * D + 4 * q;
+        if (g.out16) {
+            uint2 pk;
+            pk.x = (unsigned)f_to_bf16(v.x) | ((unsigned)f_to_bf16(v.y) << 16);
+            pk.y = (unsigned)f_to_bf16(v.z) | ((unsigned)f_to_bf16(v.w) << 16);
+            *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(g.out) + o) = pk;
+        } else {
+            *reinterpret_cast<float4*>(reinterpret_cast<float*>(g.out) + o) = v;
+        }
+    }
+}
+
+template <int H>
+__global__ __launch_bounds__(256) void union_att_bwd_kernel(UAttArgs g) {
+    constexpr int D = 64, NT = 256, XP = H * D + 4, NW = 4;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int UP = g.um + 4;
+    float* ps_ = smem;                         // [H][16][UP]
+    float* qs = ps_ + H * ER * UP;             // [H][16][UP]
+    float* ut = qs + H * ER * UP;              // [um][D + 4]
+    float* dxs = ut + g.um * (D + 4);          // [16][XP]   this chunk's columns of d_out, both heads
+    double* wred = reinterpret_cast<double*>(dxs + ER * XP);     // [NW][H]
+    int* keys_s = reinterpret_cast<int*>(wred + NW * H);         // [EU]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, kq = lane >> 4;
+    const pit_slab_plan& p = g.p;
+    const int chunks = g.dim / D;
+    const int chunk = (int)blockIdx.x % chunks;
+    int b, slab;
+    if (!slab_of_xcd((int)blockIdx.x / chunks, g.batch, p.n_slabs, b, slab)) return;
+    const int nk = min(p.nkeys[slab], EU), nkup = (nk + 15) & ~15;
+    const int c1 = wave * 16 + l15;
+    int key[EU / 16];
+    union_keys<D>(p, slab, tid, nkup, key);
+    const int akey = p.keys[(long)slab * p.umax + (tid & (EU - 1))];
+    const int npc = H * ER * g.um / 4;
+    float4 pcp[WCP], qcp[WCP];
+    wtile_request<NT>(g.pw + (long)slab * H * ER * g.um, npc, tid, pcp);
+    wtile_request<NT>(g.qw + (long)slab * H * ER * g.um, npc, tid, qcp);
+    // this chunk of d_out: 4-column pieces (rows beyond the mesh and nothing else load out of range)
+    float4 dv[H * ER * D / 4 / NT];
+#pragma unroll
+    for (int u = 0; u < H * ER * D / 4 / NT; ++u) {
+        const int e = tid + u * NT, r = e / (H * D / 4), q4 = e % (H * D / 4), h = q4 / (D / 4), q = q4 % (D / 4);
+        const int n = slab * ER + r;
+        const long o = (long)b * g.dout_bstride + (long)n * g.ld_dout + (long)h * g.dim + chunk * D + 4 * q;
+        if (g.dout16) {
+            const __amdgpu_buffer_rsrc_t r16 = wide_rsrc(g.d_out);
+            const unsigned off = n < p.n_out ? (unsigned)(o * 2) : OOB;
+            const unsigned lo = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(r16, (int)off, 0, 0);
+            const unsigned hi = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(r16, (int)(n < p.n_out ? off + 4u : OOB), 0, 0);
+            dv[u] = make_float4(__uint_as_float(lo << 16), __uint_as_float(lo & 0xffff0000u), __uint_as_float(hi << 16),
+                                __uint_as_float(hi & 0xffff0000u));
+        } else {
+            dv[u] = ldg4_if(reinterpret_cast<const float*>(g.d_out), o, n < p.n_out);
+        }
+    }
+    float4 uv[EU / 16];
+    gather_union<D>(g.values + (long)b * g.values_bstride + chunk * D, g.ld_values, key, nk, nkup, tid, uv);
+    __builtin_amdgcn_sched_barrier(0);
+    if (tid < EU) keys_s[tid] = akey;
+    wtile_park<NT>(ps_, g.um, npc, tid, pcp);
+    wtile_park<NT>(qs, g.um, npc, tid, qcp);
+#pragma unroll
+    for (int u = 0; u < H * ER * D / 4 / NT; ++u) {
+        const int e = tid + u * NT, r = e / (H * D / 4), q4 = e % (H * D / 4);
+        *reinterpret_cast<float4*>(dxs + r * XP + 4 * q4) = dv[u];
+    }
+    park_union<D>(ut, nkup, tid, uv);
+    __syncthreads();
+    // d(values)[key(slot), chunk*64 + 16 wave ..] += sum_{h, row} P_h[row][slot] dO[row, h*dim + chunk*64 + ..]
+    if (g.d_values) {
+        for (int mt = 0; mt < nkup / 16; ++mt) {
+            f32x4_t a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int h = 0; h < H; ++h) {
+                const float* ap = ps_ + (h * ER + 4 * kq) * UP + 16 * mt + l15;
+                const float* bp = dxs + (4 * kq) * XP + h * D + c1;
+                a0 = mfma_16x16x4(ap[0], bp[0], a0);
+                a1 = mfma_16x16x4(ap[UP], bp[XP], a1);
+                a0 = mfma_16x16x4(ap[2 * UP], bp[2 * XP], a0);
+                a1 = mfma_16x16x4(ap[3 * UP], bp[3 * XP], a1);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int sl = 16 * mt + 4 * kq + i;
+                if (sl < nk) atomicAdd(g.d_values + (long)b * g.dvalues_bstride + (long)keys_s[sl] * g.ld_dvalues + chunk * D + c1, a0[i] + a1[i]);
+            }
+        }
+    }
+    if (g.dscale) {
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+            const f32x4_t qu = tile_times_union<D>(qs + h * ER * UP, UP, ut, nkup, wave, l15, kq);
+            double part = 0.0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) part += (double)qu[i] * (double)dxs[(4 * kq + i) * XP + h * D + c1];
+            part = wave_sum_d(part);
+            if (lane == 0) wred[wave * H + h] = part;
+        }
+        __syncthreads();
+        if (tid < H) {
+            double tot = 0.0;
+            for (int w = 0; w < NW; ++w) tot += wred[w * H + tid];
+            atomicAdd(g.dscale + (long)tid * PIT_DSCALE_SLOTS + ((int)blockIdx.x & (PIT_DSCALE_SLOTS - 1)), -tot);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ host side
 bool plan_ok(const pit_slab_plan* p, bool needs_union) {
     if (!p || !p->stats || !p->idx || !p->cnt || !p->m) return false;
@@ -1238,6 +1403,53 @@ extern "C" int pit_encoder_bwd(const pit_slab_plan* plan, const float* mesh_in, 
                             else hipLaunchKernelGGL((encoder_bwd_kernel<H_, D_, 8>), grid, dim3(4 * D_), 0, s, g); } while (0)
     PIT_EDGE_DISPATCH(n_head, dim, PIT_EB);
 #undef PIT_EB
+    PIT_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pit_union_att_supported(int n_head, int dim, int batch, int rows_per_sample) {
+    if ((n_head != 1 && n_head != 2) || dim < 64 || dim % 64 != 0 || batch <= 0 || rows_per_sample <= 0) return 0;
+    return (long)batch * rows_per_sample * dim <= (1L << 28);      // 32-bit buffer offsets of the bf16 / fp32 tensors
+}
+
+extern "C" int pit_union_att_fwd(const pit_slab_plan* plan, const float* values, long ld_values, long values_bstride, int batch,
+                                 int n_head, int dim, const float* pw, void* out, long ld_out, long out_bstride, int out_bf16,
+                                 int max_union, void* stream) {
+    if (!plan_ok(plan, true) || !values || !pw || !out) return PIT_ERR_NULL;
+    if (!pit_union_att_supported(n_head, dim, batch, plan->n_out) || max_union < 1 || max_union > EU) return PIT_ERR_UNSUPPORTED;
+    if (ld_values % 4 || values_bstride % 4 || !aligned16(values) || !aligned16(pw) || ld_out % 4 || out_bstride % 4 ||
+        (reinterpret_cast<uintptr_t>(out) & (out_bf16 ? 7 : 15))) return PIT_ERR_SIZE;
+    UAttArgs g = UAttArgs();
+    g.p = *plan; g.um = union_slots(max_union); g.batch = batch; g.dim = dim;
+    g.values = values; g.ld_values = ld_values; g.values_bstride = values_bstride; g.pw = pw;
+    g.out = out; g.ld_out = ld_out; g.out_bstride = out_bstride; g.out16 = out_bf16;
+    const dim3 grid((unsigned)(slab_grid(batch, plan->n_slabs) * (dim / 64)));
+    const size_t sm1 = (size_t)(1 * ER * (g.um + 4) + g.um * 68 + ER * (1 * 64 + 4)) * 4;
+    const size_t sm2 = (size_t)(2 * ER * (g.um + 4) + g.um * 68 + ER * (2 * 64 + 4)) * 4;
+    if (n_head == 1) hipLaunchKernelGGL(union_att_fwd_kernel<1>, grid, dim3(256), sm1, (hipStream_t)stream, g);
+    else hipLaunchKernelGGL(union_att_fwd_kernel<2>, grid, dim3(256), sm2, (hipStream_t)stream, g);
+    PIT_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pit_union_att_bwd(const pit_slab_plan* plan, const float* values, long ld_values, long values_bstride, int batch,
+                                 int n_head, int dim, const float* pw, const float* qw,
+                                 const void* d_out, long ld_dout, long dout_bstride, int dout_bf16,
+                                 float* d_values, long ld_dvalues, long dvalues_bstride, double* dscale, int max_union, void* stream) {
+    if (!plan_ok(plan, true) || !values || !pw || !qw || !d_out || (!d_values && !dscale)) return PIT_ERR_NULL;
+    if (!pit_union_att_supported(n_head, dim, batch, plan->n_out) || max_union < 1 || max_union > EU) return PIT_ERR_UNSUPPORTED;
+    if (ld_values % 4 || values_bstride % 4 || !aligned16(values) || !aligned16(pw) || !aligned16(qw) || ld_dout % 4 || dout_bstride % 4 ||
+        (reinterpret_cast<uintptr_t>(d_out) & (dout_bf16 ? 7 : 15))) return PIT_ERR_SIZE;
+    UAttArgs g = UAttArgs();
+    g.p = *plan; g.um = union_slots(max_union); g.batch = batch; g.dim = dim;
+    g.values = values; g.ld_values = ld_values; g.values_bstride = values_bstride; g.pw = pw; g.qw = qw;
+    g.d_out = d_out; g.ld_dout = ld_dout; g.dout_bstride = dout_bstride; g.dout16 = dout_bf16;
+    g.d_values = d_values; g.ld_dvalues = ld_dvalues; g.dvalues_bstride = dvalues_bstride; g.dscale = dscale;
+    const dim3 grid((unsigned)(slab_grid(batch, plan->n_slabs) * (dim / 64)));
+    const size_t sm1 = (size_t)(2 * 1 * ER * (g.um + 4) + g.um * 68 + ER * (1 * 64 + 4)) * 4 + 4 * 1 * 8 + EU * 4;
+    const size_t sm2 = (size_t)(2 * 2 * ER * (g.um + 4) + g.um * 68 + ER * (2 * 64 + 4)) * 4 + 4 * 2 * 8 + EU * 4;
+    if (n_head == 1) hipLaunchKernelGGL(union_att_bwd_kernel<1>, grid, dim3(256), sm1, (hipStream_t)stream, g);
+    else hipLaunchKernelGGL(union_att_bwd_kernel<2>, grid, dim3(256), sm2, (hipStream_t)stream, g);
     PIT_CHECK_LAUNCH();
     return 0;
 }

@@ -577,6 +577,24 @@ def _row_view(t: torch.Tensor) -> torch.Tensor:
     return t
 
 
+UNION_ATT = os.environ.get("PIT_UNION_ATT", "1") != "0"
+
+
+def _union_att_ok(plan: "MeshPlan", n_head: int, d: int, b: int, values: torch.Tensor) -> bool:
+    if not (plan.mesh_batch == 1 and plan.masked and plan.nbr_idx is not None and not plan.self_attn and n_head in (1, 2)
+            and d % 64 == 0 and d >= UNION_ATT_MIN_DIM):
+        return False
+    if values.stride(1) % 4 or values.stride(0) % 4 or values.data_ptr() % 16:
+        return False
+    if not _lib.lib().pit_union_att_supported(int(n_head), int(d), int(b), int(plan.n_out)):
+        return False
+    sp = plan.slab_plan()
+    return sp is not None and sp[1] <= SLAB_UNION_MAX
+
+
+UNION_ATT_MIN_DIM = 128            # (width 64 models take the fused decoder launch; a layer that cannot keeps the candidate-list kernels)
+
+
 class _PosAtt(torch.autograd.Function):
     """dist2att + convolution (+ the self-attention concat) as one op."""
 
@@ -603,6 +621,24 @@ class _PosAtt(torch.autograd.Function):
         head = head.detach().reshape(-1).contiguous()
         if head.numel() != n_head:
             raise RuntimeError("lmda must hold one value per head")
+        # round 5: masked cross attention on a batch-free mesh pair with a slab plan and a width that is a multiple of 64 - the
+        # union-tile contraction of csrc/pit_edge.hip (weights once per call, d_out read once in the backward): Vorticity / Cylinder
+        ctx.uatt = None
+        if UNION_ATT and not concat and not coord_dims and out_buf is None and _union_att_ok(plan, n_head, d, b, values):
+            w = _new_decoder_weights(plan, head, scale_in, n_head, head_is_scale, True)      # (Q too: 2 KB per slab)
+            _launch_decoder_weights(w)
+            out = torch.empty((b, plan.n_out, n_head * d), device=values.device, dtype=torch.bfloat16 if out_bf16 else torch.float32)
+            sp, max_union = plan.slab_plan()[0], plan.slab_plan()[1]
+            rc = _lib.lib().pit_union_att_fwd(ctypes.byref(sp), values.data_ptr(), values.stride(1), values.stride(0), b, n_head, d,
+                                              w.pw.data_ptr(), out.data_ptr(), out.stride(1), out.stride(0), 1 if out_bf16 else 0,
+                                              max_union, _lib.stream_ptr())
+            _lib.check(rc, "pit_union_att_fwd")
+            ctx.uatt = w
+            ctx.plan, ctx.n_head, ctx.concat, ctx.head_is_scale = plan, n_head, concat, head_is_scale
+            ctx.head_param = head_param
+            ctx.union = 0
+            ctx.save_for_backward(values, head, w.scale, w.scale)
+            return out
         width = (n_head + (1 if concat else 0)) * d
         copy_inputs = 1 if concat else 0
         if out_buf is not None:
@@ -676,6 +712,26 @@ class _PosAtt(torch.autograd.Function):
         # or the next MLP backward / the end of the pass runs it
         rider = None if (plan.nbr_idx is not None and _dw_pending_rows(values.device) >= BIG_RIDER_ROWS) \
             else _dw_take(values.device)
+        if ctx.uatt is not None:                         # the union-tile backward: d_out read once, d(values) added from the tiles
+            if rider is not None:
+                _dw_run(rider)
+            w = ctx.uatt
+            if d_values is not None:
+                d_values.zero_()
+            sp, max_union = plan.slab_plan()[0], plan.slab_plan()[1]
+            rc = _lib.lib().pit_union_att_bwd(ctypes.byref(sp), values.data_ptr(), values.stride(1), values.stride(0), b, n_head, dv,
+                                              w.pw.data_ptr(), w.qw.data_ptr(), d_out.data_ptr(), d_out.stride(1), d_out.stride(0),
+                                              1 if io else 0, _lib.ptr(d_values), d_values.stride(1) if d_values is not None else 0,
+                                              d_values.stride(0) if d_values is not None else 0, work.data_ptr() if need_h else None,
+                                              max_union, _lib.stream_ptr())
+            _lib.check(rc, "pit_union_att_bwd")
+            flags = (1 if slot is not None else 0) | (4 if ctx.head_is_scale else 0)
+            if need_h:
+                if defer:
+                    _defer_head_finish(work, d_head, head, w.scale, n_head, 1 | (4 if ctx.head_is_scale else 0))
+                else:
+                    _finish_heads_now(work, d_head, head, w.scale, n_head, flags)
+            return d_values, (None if slot is not None else d_head), None, None, None, None, None, None, None, None, None
 
         def launch(dv, dh, stream_ptr, job=None):
             rc = _lib.lib().pit_posatt_bwd(

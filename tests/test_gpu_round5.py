@@ -307,3 +307,54 @@ def test_two_bucket_decision_is_made_once_and_a_later_change_raises():
         handle.remove()
         step._early_hook.remove()
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("metric,n_out_side,n_in_side,dim,heads,batch,loc", [
+    ("periodic2d", 64, 16, 256, 2, 2, 0.02),          # Vorticity's up-projection (train_vorticity.py:98-106)
+    ("euclid", 43, 16, 128, 1, 3, 0.02),
+    ("euclid", 30, 12, 192, 2, 2, 0.05),
+])
+def test_union_attention_of_any_width_against_the_oracle(metric, n_out_side, n_in_side, dim, heads, batch, loc):
+    """Masked cross attention on a batch-free mesh pair at widths 128 / 192 / 256 (pit_union_att_fwd / _bwd: the decoder's
+    union-tile contraction without the MLP, a workgroup per 64-column chunk) against the oracle's posatt_cross: output <= 1e-6,
+    d(values) <= 1e-5, d(lmda) <= 1e-4; and with bf16-stored out / d_out (PIT_IO_*) within the bf16 tolerances."""
+    from position_induced_transformer_amd import ops
+    per = metric != "euclid"
+    mo, mi = orc.grid_mesh_2d(n_out_side, not per).reshape(-1, 2), orc.grid_mesh_2d(n_in_side, not per).reshape(-1, 2)
+    g = torch.Generator().manual_seed(61)
+    values = torch.randn(batch, mi.shape[0], dim, generator=g)
+    lmda = torch.rand(heads, 1, 1, generator=g)
+    d_out = torch.randn(batch, mo.shape[0], heads * dim, generator=g)
+    v0, l0 = values.clone().requires_grad_(True), lmda.clone().requires_grad_(True)
+    ref = orc.posatt_cross(metric, False, mo, mi, v0, l0, loc)
+    ref.backward(d_out)
+    plan = ops.MeshPlan(metric, mo.cuda(), mi.cuda(), loc, False)
+    calls = {"n": 0}
+    orig = ops._launch_decoder_weights
+
+    def counting(w):
+        calls["n"] += 1
+        return orig(w)
+    ops._launch_decoder_weights = counting
+    try:
+        with ops.head_scale_route("host"):
+            v1, l1 = values.cuda().requires_grad_(True), lmda.cuda().requires_grad_(True)
+            out = ops.posatt_apply(v1, l1, plan, heads, concat=False)
+            out.backward(d_out.cuda())
+    finally:
+        ops._launch_decoder_weights = orig
+    torch.cuda.synchronize()
+    assert calls["n"] == 1, "the union-tile attention did not run"
+    assert gio.rel_l2(out.detach().cpu().numpy(), ref.detach().numpy()) <= 1e-6
+    assert gio.rel_l2(v1.grad.cpu().numpy(), v0.grad.numpy()) <= 1e-5
+    assert float((l1.grad.cpu().reshape(-1) - l0.grad.reshape(-1)).norm()) <= 1e-4 * float(l0.grad.norm())
+    # bf16-stored output and gradient (bf16 math mode): storage rounding only
+    with ops.math_mode("bf16"), ops.head_scale_route("host"):
+        v2, l2 = values.cuda().requires_grad_(True), lmda.cuda().requires_grad_(True)
+        out16 = ops.posatt_apply(v2, l2, plan, heads, concat=False, out_bf16=True)
+        assert out16.dtype == torch.bfloat16
+        out16.backward(d_out.cuda().to(torch.bfloat16))
+    torch.cuda.synchronize()
+    assert gio.rel_l2(out16.detach().float().cpu().numpy(), ref.detach().numpy()) <= 1e-2
+    assert gio.rel_l2(v2.grad.cpu().numpy(), v0.grad.numpy()) <= 1e-2
+    assert float((l2.grad.cpu().reshape(-1) - l0.grad.reshape(-1)).norm()) <= 5e-2 * float(l0.grad.norm())
