@@ -638,9 +638,9 @@ __global__ __launch_bounds__(4 * D) void decoder_bwd_kernel(DecBwdArgs g) {
     for (int u = 0; u < 4; ++u) {
         const int r = (tid + u * NT) / D;
         const bool ok = slab * ER + r < p.n_out;
-        const float v = ok ? acc[u] * gelu_erf_grad(z1v[u]) : 0.0f;
+        const float v = ok ? acc[u] * ((PIT_EDGE_DBG & 32) ? 1.0f : gelu_erf_grad(z1v[u])) : 0.0f;
         ds1[r * P1 + ec] = v;
-        if (ok) g.dz1[(row0 + r) * D + ec] = v;
+        if (ok && !(PIT_EDGE_DBG & 512)) g.dz1[(row0 + r) * D + ec] = v;
     }
     ESTAMP(1, 4);
     park_union<D>(ut, nkup, tid, uv);
@@ -694,7 +694,7 @@ __global__ __launch_bounds__(4 * D) void decoder_bwd_kernel(DecBwdArgs g) {
     }
     ESTAMP(1, 9);
     // ---- d(scale): dc_h -= sum_{row, d} dX[row, h*D + d] * (Q_h U)[row, d]
-    if (g.dscale) {
+    if (g.dscale && !(PIT_EDGE_DBG & 128)) {
 #pragma unroll
         for (int h = 0; h < H; ++h) {
             const f32x4_t qu = tile_times_union<D>(qs + h * ER * UP, UP, ut, nkup, wave, l15, kq);

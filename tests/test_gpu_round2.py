@@ -747,7 +747,12 @@ def test_mlp_weight_gradients_carried_by_the_attention_backward_equal_their_own_
     for (k, p), v in zip(model.named_parameters(), flat._views):        # parameter by parameter, not only in norm
         a = got[False][0][v.storage_offset():v.storage_offset() + v.numel()].cpu().numpy()
         b = got[True][0][v.storage_offset():v.storage_offset() + v.numel()].cpu().numpy()
-        assert gio.rel_l2(a, b) <= 1e-5, k
+        c = got[True][1][v.storage_offset():v.storage_offset() + v.numel()].cpu().numpy()
+        # (the union-tile attention backward sums d(values) with atomics: two identical passes differ by `noise`,
+        #  largest on the bias sums, which cancel heavily)
+        noise = gio.rel_l2(c, b)
+        assert gio.rel_l2(a, b) <= max(1e-5, 4 * noise), (k, noise)
+        assert noise <= 1e-4, (k, noise)
 
 
 def test_a_postponed_weight_gradient_job_of_an_aborted_pass_is_dropped():
