@@ -342,13 +342,25 @@ def roofline_probe(model, batch):
     with torch.no_grad():
         if pre:
             weights = ops.block_weights(plan, [a.lmda for a in model.conv], layer.n_head, False)
-            us = graph_time_us(lambda: ops.posatt_pre_apply(u, layer.lmda, weights, 0, layer.n_head))
+            # the launch exactly as the step makes it: the values ARE the first columns of the block's concat buffer (written there
+            # by the producing MLP, pit.processor), the launch adds the head columns - no copy of the values (until round 5 this
+            # probe handed over a detached tensor and timed the copying form: 51 us against the step's 40.5 us, profiles/r05_darcy256)
+            xcat = torch.randn(batch, plan.n_in, (1 + layer.n_head) * d, device="cuda")
+
+            def launch():
+                v = xcat[:, :, :d]
+                v._pit_concat = xcat
+                return ops.posatt_pre_apply(v, layer.lmda, weights, 0, layer.n_head)
+            assert launch().data_ptr() == xcat.data_ptr()
+            us = graph_time_us(launch)
         else:
             us = graph_time_us(lambda: ops.posatt_apply(u, layer.lmda, plan, layer.n_head, True))
     flops = 2.0 * layer.n_head * plan.n_out * plan.n_in * d * batch
     achieved = flops / (us * 1e-6) / 1e12
-    alg_bytes = 4.0 * batch * plan.n_in * d + 4.0 * batch * plan.n_out * (1 + layer.n_head) * d \
-        + (4.0 * layer.n_head * plan.n_out * plan.n_in if pre else 0.0)
+    if pre:      # values read, head columns written, E of every head once
+        alg_bytes = 4.0 * batch * plan.n_in * d + 4.0 * batch * plan.n_out * layer.n_head * d + 4.0 * layer.n_head * plan.n_out * plan.n_in
+    else:
+        alg_bytes = 4.0 * batch * plan.n_in * d + 4.0 * batch * plan.n_out * (1 + layer.n_head) * d
     kname = "posatt_rows_tiles<PRE> (weights of pit_block_weights)" if pre else "posatt_rows_kernel<fwd>"
     return {"bound": "mfma", "kernel": f"{kname} processor {plan.n_out}x{plan.n_in}, D={d}, "
                                        f"H={layer.n_head}, batch {batch}",

@@ -45,6 +45,11 @@ __device__ int pit_block_dbg = 0;      // experiments (tools/block_bench.py): 1 
 #else
 #define PIT_BLOCK_DBG 0
 #endif
+// timing experiments (tools/block_variants.sh; results void): 1 = forward contraction issues half its MFMAs (all loads kept),
+// 2 = forward GEMM1 half its k-steps, 4 = backward contraction half its MFMAs, 8 = backward phase C one tile per wave
+#ifndef PIT_BLOCK_EXP
+#define PIT_BLOCK_EXP 0
+#endif
 
 // ---------------------------------------------------------------------------------------------- weights (body: pit_block_dev.h)
 __global__ __launch_bounds__(256) void block_weights_kernel(WeightsArgs a) { block_weights_body(a, blockIdx.x); }
@@ -94,6 +99,12 @@ __device__ __forceinline__ void slab_contract(const float* __restrict__ w, long 
             for (int m = 0; m < 4; ++m)
 #pragma unroll
                 for (int h = 0; h < NH; ++h) {
+                    if ((PIT_BLOCK_EXP & (SHARED ? 1 : 4)) && (SHARED ? s == 1 : h == 1)) {
+                        asm volatile("" :: "v"(av[h][s].x), "v"(av[h][s].y), "v"(av[h][s].z), "v"(av[h][s].w));
+                        asm volatile("" :: "v"(bv[SHARED ? 0 : h][s][m].x), "v"(bv[SHARED ? 0 : h][s][m].y), "v"(bv[SHARED ? 0 : h][s][m].z), "v"(bv[SHARED ? 0 : h][s][m].w));
+                        if (!SHARED) asm volatile("" :: "v"(sv[h][s].x), "v"(sv[h][s].y), "v"(sv[h][s].z), "v"(sv[h][s].w));
+                        continue;
+                    }
                     const float* ap = &av[h][s].x;
                     const float* sp = &sv[h][s].x;
                     const float aw = SHARED ? ap[m] : ap[m] * sp[m];       // (row scale folded into the A operand)
@@ -196,6 +207,7 @@ __global__ __launch_bounds__(512) void block_fwd_kernel(BlockFwdArgs g) {
         f32x4_t a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
+            if ((PIT_BLOCK_EXP & 2) && (s & 1)) { asm volatile("" :: "v"(bv[s].x), "v"(bv[s].y), "v"(bv[s].z), "v"(bv[s].w)); continue; }
             const float4 a = *reinterpret_cast<const float4*>(xs + l15 * XP + 16 * s + 4 * kq);
             a0 = mfma_16x16x4(a.x, bv[s].x, a0);
             a1 = mfma_16x16x4(a.y, bv[s].y, a1);
@@ -358,6 +370,11 @@ __device__ __forceinline__ void block_bwd_chain(const BlockBwdArgs& g, float* sm
     for (int t = 0; t < 2; ++t) {
         const int tile = wave + t * BW;
         if (tile * 16 >= g.n0p) break;
+        if ((PIT_BLOCK_EXP & 8) && t == 1) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) asm volatile("" :: "v"(w1v[t][s][0]), "v"(w1v[t][s][1]), "v"(w1v[t][s][2]), "v"(w1v[t][s][3]));
+            break;
+        }
         f32x4_t o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int s = 0; s < 4; ++s) {

@@ -397,7 +397,7 @@ __global__ __launch_bounds__(4 * D) void decoder_fwd_kernel(DecFwdArgs g) {
     ESTAMP(0, 7);
     __syncthreads();
     ESTAMP(0, 8);
-    if (g.h && !(PIT_EDGE_DBG & 4)) {
+    if (g.h && !(PIT_EDGE_DBG & (4 | 1024))) {
         const int r = tid / (D / 4), q = tid % (D / 4);             // NT = 16 * D / 4: one 16-byte piece per thread
         if (slab * ER + r < p.n_out)
             *reinterpret_cast<float4*>(g.h + (row0 + r) * D + 4 * q) = *reinterpret_cast<const float4*>(hs + r * HP + 4 * q);

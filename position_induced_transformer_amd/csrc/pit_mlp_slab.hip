@@ -89,7 +89,9 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd64_kernel(SlabFwdArgs g) {
                 hs[r * HP + c1] = hv;
                 if (m0 + r < g.rows) {
                     g.z1[(m0 + r) * BD + c1] = z;
+#ifndef PIT_SLAB_NO_H      // (timing experiment: the hidden activation not stored)
                     g.h[(m0 + r) * BD + c1] = hv;
+#endif
                 }
             }
         }
