@@ -581,6 +581,8 @@ UNION_ATT = os.environ.get("PIT_UNION_ATT", "1") != "0"
 
 
 def _union_att_ok(plan: "MeshPlan", n_head: int, d: int, b: int, values: torch.Tensor) -> bool:
+    if torch.are_deterministic_algorithms_enabled():       # (d(values) leaves these kernels as fp32 atomic adds)
+        return False
     if not (plan.mesh_batch == 1 and plan.masked and plan.nbr_idx is not None and not plan.self_attn and n_head in (1, 2)
             and d % 64 == 0 and d >= UNION_ATT_MIN_DIM):
         return False
@@ -1417,6 +1419,8 @@ def edge_fusion_supported(plan: MeshPlan, n_head: int, dim: int, batch: int, nee
     complete candidate lists (and, for the decoder, unions of at most 64 keys per 16-row slab), 1-2 heads, hidden width 32 / 64,
     in the latency regime."""
     if not EDGE_FUSION or plan.mesh_batch != 1 or plan.self_attn or not plan.masked or plan.nbr_idx is None:
+        return False
+    if needs_union and torch.are_deterministic_algorithms_enabled():     # (the decoder's d(values): fp32 atomic adds)
         return False
     if not _lib.lib().pit_edge_supported(int(n_head), int(dim), int(batch), int(plan.n_out)):
         return False

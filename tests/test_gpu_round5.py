@@ -358,3 +358,32 @@ def test_union_attention_of_any_width_against_the_oracle(metric, n_out_side, n_i
     assert gio.rel_l2(out16.detach().float().cpu().numpy(), ref.detach().numpy()) <= 1e-2
     assert gio.rel_l2(v2.grad.cpu().numpy(), v0.grad.numpy()) <= 1e-2
     assert float((l2.grad.cpu().reshape(-1) - l0.grad.reshape(-1)).norm()) <= 5e-2 * float(l0.grad.norm())
+
+
+# --------------------------------------------------------------------------- determinism flag
+@pytest.mark.gpu
+def test_deterministic_algorithms_flag_keeps_the_atomic_free_data_path():
+    """d(values) of the fused decoder launch and of the union attention leave as fp32 atomic adds; under
+    torch.use_deterministic_algorithms both layers keep the candidate-list kernels (transposed lists, fixed summation order):
+    the gradient of the input function is bit-identical from pass to pass."""
+    import torch
+    from position_induced_transformer_amd import ops, tasks, utils
+    model, sample, meta = tasks.make_task("darcy", seed=5)
+    mesh_in, func_in, mesh_out, target = sample(4)
+    loss_fn = utils.RelLpNorm(meta["out_dim"], meta["p"])
+    plan = model.up._plan(mesh_out.reshape(-1, 2), model.mesh_ltt, False)
+    assert ops.edge_fusion_supported(plan, model.up.n_head, model.hid_dim, 4, True)
+    torch.use_deterministic_algorithms(True, warn_only=True)
+    try:
+        assert not ops.edge_fusion_supported(plan, model.up.n_head, model.hid_dim, 4, True)
+        assert not ops._union_att_ok(plan, 2, 256, 4, torch.empty(4, plan.n_in, 256, device="cuda"))
+        grads = []
+        for _ in range(3):
+            f = func_in.clone().requires_grad_(True)
+            model.zero_grad(set_to_none=True)
+            loss_fn(target, model(mesh_in, f, mesh_out)).backward()
+            grads.append(f.grad.clone())
+        assert torch.equal(grads[0], grads[1]) and torch.equal(grads[0], grads[2])
+        assert float(grads[0].abs().max()) > 0
+    finally:
+        torch.use_deterministic_algorithms(False)
