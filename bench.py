@@ -344,7 +344,7 @@ def roofline_probe(model, batch):
             weights = ops.block_weights(plan, [a.lmda for a in model.conv], layer.n_head, False)
             # the launch exactly as the step makes it: the values ARE the first columns of the block's concat buffer (written there
             # by the producing MLP, pit.processor), the launch adds the head columns - no copy of the values (until round 5 this
-            # probe handed over a detached tensor and timed the copying form: 51 us against the step's 40.5 us, profiles/r05_darcy256)
+            # probe handed over a detached tensor and timed the copying form: 51 us against the step's 44.5 us, profiles/r05_darcy256)
             xcat = torch.randn(batch, plan.n_in, (1 + layer.n_head) * d, device="cuda")
 
             def launch():
