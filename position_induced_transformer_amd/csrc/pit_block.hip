@@ -39,14 +39,25 @@ __device__ unsigned long long pit_block_stamps[32];
 #define BSTAMP(i_) do { } while (0)
 #endif
 
-#ifdef PIT_STAMPS
+#ifdef PIT_WGREC
+// per workgroup of the LAST block_bwd launch: entry, exit (100 MHz), HW_ID, XCC_ID (tools/stamp_block.py; -DPIT_WGREC build)
+__device__ unsigned long long pit_block_wgrec[1024 * 4];
+#define BREC(slot_) do { if (threadIdx.x == 0 && blockIdx.x < 1024) {                                                       \
+        pit_block_wgrec[blockIdx.x * 4 + (slot_)] = __builtin_amdgcn_s_memrealtime();                                       \
+        if ((slot_) == 0) { pit_block_wgrec[blockIdx.x * 4 + 2] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   \
+                            pit_block_wgrec[blockIdx.x * 4 + 3] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)); } } } while (0)
+#else
+#define BREC(slot_) do { } while (0)
+#endif
+#ifdef PIT_STAMPS_DBG
 __device__ int pit_block_dbg = 0;      // experiments (tools/block_bench.py): 1 = linear workgroup -> slab map, 2 / 4 = no B / A loads
 #define PIT_BLOCK_DBG pit_block_dbg
 #else
 #define PIT_BLOCK_DBG 0
 #endif
 // timing experiments (tools/block_variants.sh; results void): 1 = forward contraction issues half its MFMAs (all loads kept),
-// 2 = forward GEMM1 half its k-steps, 4 = backward contraction half its MFMAs, 8 = backward phase C one tile per wave
+// 2 = forward GEMM1 half its k-steps, 4 = backward contraction half its MFMAs, 8 = backward phase C one tile per wave,
+// 32 = backward: the rider workgroups leave at once
 #ifndef PIT_BLOCK_EXP
 #define PIT_BLOCK_EXP 0
 #endif
@@ -445,12 +456,19 @@ template <int H, int NDW>
 __global__ __launch_bounds__(512) void block_bwd_kernel(BlockBwdArgs g, pit_detail::DwPair w, pit_detail::DwPair w2) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     int id = blockIdx.x;
-    if (id < g.n_chain) { block_bwd_chain<H>(g, smem, id); return; }
+    BREC(0);
+    // (placement, tools/stamp_block.py: the dispatcher deals workgroup ids to the CUs of an XCD in turn and starts over after one
+    //  each, so the riders - dealt third - share the compute units of the FIRST range.  d(scale) slabs first, i.e. riders beside
+    //  the 5 us d(scale) workgroups instead of the 7 us chain workgroups, was measured: 11.4 against 11.1 us in the step - a rider
+    //  beside a d(scale) slab lives 8 us, 4.8 alone)
+    if (id < g.n_chain) { block_bwd_chain<H>(g, smem, id); BREC(1); return; }
     id -= g.n_chain;
-    if (id < g.n_ds) { block_bwd_dscale<H>(g, smem, id); return; }
+    if (id < g.n_ds) { block_bwd_dscale<H>(g, smem, id); BREC(1); return; }
     id -= g.n_ds;
-    if (NDW >= 1 && id < w.n1 + w.n2) { dw_pair_body(w, id, smem); return; }
+    if (PIT_BLOCK_EXP & 32) return;                     // (experiment: riders leave at once - the launch without their work)
+    if (NDW >= 1 && id < w.n1 + w.n2) { dw_pair_body(w, id, smem); BREC(1); return; }
     if (NDW >= 2) dw_pair_body(w2, id - (w.n1 + w.n2), smem);
+    BREC(1);
 }
 
 constexpr size_t fwd_smem(int H) { return ((size_t)H * PARK_FLOATS + 16 * ((1 + H) * BD + 4) + 16 * (BD + 4)) * sizeof(float); }
@@ -511,8 +529,15 @@ extern "C" int pit_block_fwd(const float* e, const float* inv, int n_pts, int n_
     return 0;
 }
 
-#ifdef PIT_STAMPS
+#ifdef PIT_WGREC
+extern "C" int pit_block_read_wgrec(unsigned long long* out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pit_block_wgrec), (size_t)n * 4 * sizeof(unsigned long long));
+}
+#endif
+#ifdef PIT_STAMPS_DBG
 extern "C" int pit_block_set_dbg(int v) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(pit_block_dbg), &v, sizeof(int)); }
+#endif
+#ifdef PIT_STAMPS
 extern "C" int pit_block_read_stamps(unsigned long long* out) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pit_block_stamps), sizeof(unsigned long long) * 32);
 }

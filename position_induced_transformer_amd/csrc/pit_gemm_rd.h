@@ -5,6 +5,13 @@
 #include "pit_common.h"
 #include <type_traits>
 
+// (timing experiment -DPIT_RR_NO_ATOMICS: the split-K partial tiles leave as plain stores - results void)
+#ifdef PIT_RR_NO_ATOMICS
+#define PIT_RR_ADD(p_, v_) (*(p_) = (v_))
+#else
+#define PIT_RR_ADD(p_, v_) atomicAdd((p_), (v_))
+#endif
+
 namespace pit_detail {
 
 struct GemmArgs {
@@ -210,8 +217,8 @@ __device__ __forceinline__ void gemm_rd_body(const GemmArgs& g, int bx, int by, 
             if (EPI == EPI_BIAS_GELU) { g.Z[(long)row[u] * g.ldz + col[u]] = v; v = gelu_erf(v); }
             if (EPI == EPI_MUL_GELU_GRAD) v *= gelu_erf_grad(aux[u]);
             if (EPI == EPI_ATOMIC) {
-                if (col[u] == g.ones_col) atomicAdd(g.C2 + row[u], v);
-                else atomicAdd(g.C + (long)row[u] * g.ldc + col[u], v);
+                if (col[u] == g.ones_col) PIT_RR_ADD(g.C2 + row[u], v);
+                else PIT_RR_ADD(g.C + (long)row[u] * g.ldc + col[u], v);
             } else {
                 g.C[(long)row[u] * g.ldc + col[u]] = v;
             }
@@ -373,7 +380,7 @@ __device__ __forceinline__ void gemm_rr_tile(const GemmArgs& g, int bx, int by, 
         for (int t = 0; t < RM; ++t) {
             const float v = rsum[t] + __shfl_xor(rsum[t], 32);
             const int row = m0 + wm + RM * l31 + t;
-            if (half == 0 && row < g.M) atomicAdd(g.C2 + row, v);
+            if (half == 0 && row < g.M) PIT_RR_ADD(g.C2 + row, v);
         }
     }
 #pragma unroll
@@ -386,7 +393,7 @@ __device__ __forceinline__ void gemm_rr_tile(const GemmArgs& g, int bx, int by, 
             for (int u = 0; u < RN; ++u) {
                 const int col = n0 + wn + 32 * u + l31;
                 const float v = NA == 2 ? acc[t][u][0][r] + acc[t][u][NA - 1][r] : acc[t][u][0][r];
-                if (col < n_real) atomicAdd(g.C + (long)row * g.ldc + col, v);
+                if (col < n_real) PIT_RR_ADD(g.C + (long)row * g.ldc + col, v);
             }
         }
 }
