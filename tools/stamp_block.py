@@ -10,9 +10,20 @@ import bench  # noqa: E402
 from position_induced_transformer_amd import _lib, tasks  # noqa: E402
 
 batch = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+in_step = len(sys.argv) > 2 and sys.argv[2] == "step"     # the records of the step's LAST block_bwd launch (block 0: no previous MLP)
 model, sample, meta = tasks.make_task("darcy", seed=0)
-recs = bench.roofline_block_probe(model, batch, 43 * 43)
-print("block_bwd", recs[0]["us_per_launch"], "us   block_fwd", recs[1]["us_per_launch"], "us (graph replay)")
+if in_step:
+    from position_induced_transformer_amd import utils
+    from position_induced_transformer_amd.ddp import FlatGradients
+    mesh_in, func_in, mesh_out, target = sample(batch)
+    loss_fn = utils.RelLpNorm(meta["out_dim"], meta["p"])
+    flat = FlatGradients(model.parameters())
+    for _ in range(3):
+        flat.zero_()
+        loss_fn(target, model(mesh_in, func_in, mesh_out)).backward()
+else:
+    recs = bench.roofline_block_probe(model, batch, 43 * 43)
+    print("block_bwd", recs[0]["us_per_launch"], "us   block_fwd", recs[1]["us_per_launch"], "us (graph replay)")
 torch.cuda.synchronize()
 n = 1024
 rec = (ctypes.c_ulonglong * (4 * n))()
@@ -30,7 +41,7 @@ def place(hw, xcc):
 
 percu = collections.defaultdict(list)
 for a, b, hw, xcc, i in rows:
-    percu[place(hw, xcc)].append(("chain" if i < n_chain else ("dscale" if i < 2 * n_chain else "rider"), (a - t0) * 10, (b - t0) * 10, i))
+    percu[place(hw, xcc)].append(("chain" if i < n_chain else "rider", (a - t0) * 10, (b - t0) * 10, i))
 print(f"{len(rows)} workgroups on {len(percu)} distinct CUs; per CU: {dict(collections.Counter(len(v) for v in percu.values()))}")
 mix = collections.Counter(tuple(sorted(k for k, _, _, _ in v)) for v in percu.values())
 print("CU contents:", dict(mix))
@@ -63,3 +74,10 @@ if hasattr(L, "pit_block_read_stamps"):        # -DPIT_STAMPS as well: shader-cl
             if i in names and st[i]:
                 print(f"  {names[i]:28s} +{st[i] - prev:6d} ticks of s_memtime  (at {st[i] - st[base]})")
                 prev = st[i]
+
+# lifetimes by workgroup-id range (PIT_BLOCK_PRINT=1 prints the ranges of every launch)
+ids = sorted((i, (b - a) * 10, (b - t0) * 10) for a, b, hw, xcc, i in rows if i >= n_chain)
+step = 16
+for k in range(0, len(ids), step):
+    seg = ids[k:k + step]
+    print(f"  riders {seg[0][0] - n_chain:4d}..{seg[-1][0] - n_chain:4d}: lifetime mean {sum(x[1] for x in seg) / len(seg):6.0f} max {max(x[1] for x in seg):6d} ns, last exit {max(x[2] for x in seg)} ns")
