@@ -144,15 +144,23 @@ struct BlockFwdArgs {
     float *z1, *h, *z2, *y; long ldy;
 };
 
-template <int H, bool EARLYW>
-__global__ __launch_bounds__(512) void block_fwd_kernel(BlockFwdArgs g) {
+// WLDS (round 5): the MLP's weights reach the MFMAs through LDS.  As B-operand fragments straight from memory (lane = weight row,
+// 16 B of it per instruction) every wave instruction touches 16 different cache lines for 64 useful bytes each - 4 096 line
+// look-ups per workgroup for W1 | W2 against 512 when all eight waves copy the 64 KB with unit-stride 16-byte loads; the copy lands
+// in LDS before the barrier in front of GEMM1 and the fragments are ds_read_b128s.  Needs 64 KB more LDS (one workgroup per CU):
+// taken when the launch has no more workgroups than the chip has CUs.
+template <int H, bool WLDS>
+__global__ __launch_bounds__(512, WLDS ? 1 : 2) void block_fwd_kernel(BlockFwdArgs g) {      // (WLDS: one workgroup per CU, 256 registers)
     constexpr int W = (1 + H) * BD;                     // concat width = K of the first contraction
     constexpr int XP = W + 4, HP = BD + 4;              // LDS pitches
     constexpr int KS = W / 16;
+    constexpr int NW1 = BD * W / 4 / 512, NW2 = BD * BD / 4 / 512;      // 16-byte pieces of W1 / W2 per thread (6 / 2 at H = 2)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* pk = smem;                                   // [H * PARK_FLOATS]: slot wave*H + head
     float* xs = smem + H * PARK_FLOATS;                 // [16][XP] concat tile
     float* hs = xs + 16 * XP;                           // [16][HP] hidden tile
+    float* w1s = hs + 16 * HP;                          // WLDS: [64][XP] image of W1, then [64][HP] image of W2
+    float* w2s = w1s + BD * XP;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, kq = lane >> 4;
     const int slabs = g.L / 16;
@@ -178,14 +186,25 @@ __global__ __launch_bounds__(512) void block_fwd_kernel(BlockFwdArgs g) {
     float bias = 0.0f, bias2 = 0.0f;
     auto load_weights = [&]() {
         if (!mlp_wave) return;
+        if (!WLDS) {
 #pragma unroll
-        for (int s = 0; s < KS; ++s) bv[s] = *reinterpret_cast<const float4*>(g.w1 + (long)c1 * W + 16 * s + 4 * kq);
+            for (int s = 0; s < KS; ++s) bv[s] = *reinterpret_cast<const float4*>(g.w1 + (long)c1 * W + 16 * s + 4 * kq);
 #pragma unroll
-        for (int s = 0; s < 4; ++s) w2v[s] = *reinterpret_cast<const float4*>(g.w2 + (long)c1 * BD + 16 * s + 4 * kq);
+            for (int s = 0; s < 4; ++s) w2v[s] = *reinterpret_cast<const float4*>(g.w2 + (long)c1 * BD + 16 * s + 4 * kq);
+        }
         bias = g.b1[c1];
         bias2 = g.b2[c1];
     };
-    if (EARLYW) load_weights();
+    // WLDS: every thread's unit-stride pieces of W1 | W2, requested in front of the contraction's operands (the copy must be in LDS
+    // one barrier before GEMM1); plain locals, not lambda captures (those went to scratch)
+    f32x4_t wq1[WLDS ? NW1 : 1], wq2[WLDS ? NW2 : 1];
+    if (WLDS) {
+#pragma unroll
+        for (int p = 0; p < NW1; ++p) wq1[p] = reinterpret_cast<const f32x4_t*>(g.w1)[p * 512 + tid];
+#pragma unroll
+        for (int p = 0; p < NW2; ++p) wq2[p] = reinterpret_cast<const f32x4_t*>(g.w2)[p * 512 + tid];
+        load_weights();
+    }
     f32x4_t acc[H][4];
 #pragma unroll
     for (int hh = 0; hh < H; ++hh)
@@ -194,7 +213,7 @@ __global__ __launch_bounds__(512) void block_fwd_kernel(BlockFwdArgs g) {
     slab_contract<H, true>(g.e + (long)n0 * g.L, (long)g.L * g.L, g.L, g.xcat + (long)b * g.L * W, W, 0, nullptr,
                            wave * klen, (wave + 1) * klen, l15, kq, acc);
     BSTAMP(1);
-    if (!EARLYW) load_weights();
+    if (!WLDS) load_weights();
 #pragma unroll
     for (int hh = 0; hh < H; ++hh) park(pk, wave * H + hh, lane, acc[hh]);
     if (tid < 256) *reinterpret_cast<float4*>(xs + (tid >> 4) * XP + 4 * (tid & 15)) = xown;
@@ -210,6 +229,18 @@ __global__ __launch_bounds__(512) void block_fwd_kernel(BlockFwdArgs g) {
         *reinterpret_cast<float4*>(xs + r * XP + BD + hh * BD + col) = s;
         *reinterpret_cast<float4*>(g.xcat + (m0 + r) * W + BD + hh * BD + col) = s;
     }
+    if (WLDS) {
+#pragma unroll
+        for (int p = 0; p < NW1; ++p) {
+            const int q = p * 512 + tid, row = q / (W / 4), c4 = q % (W / 4);
+            *reinterpret_cast<f32x4_t*>(w1s + row * XP + 4 * c4) = wq1[p];
+        }
+#pragma unroll
+        for (int p = 0; p < NW2; ++p) {
+            const int q = p * 512 + tid, row = q / (BD / 4), c4 = q % (BD / 4);
+            *reinterpret_cast<f32x4_t*>(w2s + row * HP + 4 * c4) = wq2[p];
+        }
+    }
     BSTAMP(3);
     __syncthreads();
     BSTAMP(4);
@@ -218,12 +249,13 @@ __global__ __launch_bounds__(512) void block_fwd_kernel(BlockFwdArgs g) {
         f32x4_t a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-            if ((PIT_BLOCK_EXP & 2) && (s & 1)) { asm volatile("" :: "v"(bv[s].x), "v"(bv[s].y), "v"(bv[s].z), "v"(bv[s].w)); continue; }
+            if ((PIT_BLOCK_EXP & 2) && (s & 1)) { if (!WLDS) asm volatile("" :: "v"(bv[s].x), "v"(bv[s].y), "v"(bv[s].z), "v"(bv[s].w)); continue; }
             const float4 a = *reinterpret_cast<const float4*>(xs + l15 * XP + 16 * s + 4 * kq);
-            a0 = mfma_16x16x4(a.x, bv[s].x, a0);
-            a1 = mfma_16x16x4(a.y, bv[s].y, a1);
-            a0 = mfma_16x16x4(a.z, bv[s].z, a0);
-            a1 = mfma_16x16x4(a.w, bv[s].w, a1);
+            const float4 bw = WLDS ? *reinterpret_cast<const float4*>(w1s + c1 * XP + 16 * s + 4 * kq) : bv[s];
+            a0 = mfma_16x16x4(a.x, bw.x, a0);
+            a1 = mfma_16x16x4(a.y, bw.y, a1);
+            a0 = mfma_16x16x4(a.z, bw.z, a0);
+            a1 = mfma_16x16x4(a.w, bw.w, a1);
         }
         BSTAMP(5);
 #pragma unroll
@@ -244,10 +276,11 @@ __global__ __launch_bounds__(512) void block_fwd_kernel(BlockFwdArgs g) {
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
         const float4 a = *reinterpret_cast<const float4*>(hs + l15 * HP + 16 * s + 4 * kq);
-        o0 = mfma_16x16x4(a.x, w2v[s].x, o0);
-        o1 = mfma_16x16x4(a.y, w2v[s].y, o1);
-        o0 = mfma_16x16x4(a.z, w2v[s].z, o0);
-        o1 = mfma_16x16x4(a.w, w2v[s].w, o1);
+        const float4 bw = WLDS ? *reinterpret_cast<const float4*>(w2s + c1 * HP + 16 * s + 4 * kq) : w2v[s];
+        o0 = mfma_16x16x4(a.x, bw.x, o0);
+        o1 = mfma_16x16x4(a.y, bw.y, o1);
+        o0 = mfma_16x16x4(a.z, bw.z, o0);
+        o1 = mfma_16x16x4(a.w, bw.w, o1);
     }
     BSTAMP(8);
 #pragma unroll
@@ -471,7 +504,9 @@ __global__ __launch_bounds__(512) void block_bwd_kernel(BlockBwdArgs g, pit_deta
     BREC(1);
 }
 
-constexpr size_t fwd_smem(int H) { return ((size_t)H * PARK_FLOATS + 16 * ((1 + H) * BD + 4) + 16 * (BD + 4)) * sizeof(float); }
+constexpr size_t fwd_smem(int H, bool wlds) {
+    return ((size_t)H * PARK_FLOATS + 16 * ((1 + H) * BD + 4) + 16 * (BD + 4) + (wlds ? BD * ((1 + H) * BD + 4) + BD * (BD + 4) : 0)) * sizeof(float);
+}
 constexpr size_t bwd_smem(int H, bool dscale) {
     return std::max((size_t)(PARK_FLOATS + 2 * 16 * (BD + 4)) * sizeof(float),
                     dscale ? ((size_t)H * PARK_FLOATS) * sizeof(float) + BW * sizeof(double) : (size_t)0);
@@ -513,12 +548,13 @@ extern "C" int pit_block_fwd(const float* e, const float* inv, int n_pts, int n_
     g.w1 = w1; g.b1 = b1; g.w2 = w2; g.b2 = b2; g.out_gelu = out_gelu;
     g.z1 = z1; g.h = h; g.z2 = z2; g.y = y; g.ldy = ldy;
     const dim3 grid((unsigned)slab_grid(batch, n_pts / 16)), block(64 * BW);
-    const bool earlyw = false;      // (weights requested before the contraction: measured equal, 0.1982 vs 0.1988 ms/step; kept for experiments)
-    const size_t FWD_SMEM = fwd_smem(n_head);
+    static const bool no_wlds = getenv("PIT_NO_BLOCK_WLDS") != nullptr;                  // (A/B switch, read once)
+    const bool earlyw = !no_wlds && grid.x <= 256;      // WLDS: the weights through LDS (one workgroup per CU: 64 KB more LDS)
+    const size_t FWD_SMEM = fwd_smem(n_head, earlyw);
 #define PIT_BLOCK_FWD(H_, E_)                                                                                              \
     do {                                                                                                                   \
         static bool once = ((void)hipFuncSetAttribute((const void*)block_fwd_kernel<H_, E_>,                              \
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, 98304), true);                 \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);            \
         (void)once;                                                                                                        \
         hipLaunchKernelGGL((block_fwd_kernel<H_, E_>), grid, block, FWD_SMEM, (hipStream_t)stream, g);                     \
     } while (0)
