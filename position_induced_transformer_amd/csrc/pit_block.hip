@@ -210,8 +210,52 @@ __global__ __launch_bounds__(512, WLDS ? 1 : 2) void block_fwd_kernel(BlockFwdAr
     for (int hh = 0; hh < H; ++hh)
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc[hh][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    slab_contract<H, true>(g.e + (long)n0 * g.L, (long)g.L * g.L, g.L, g.xcat + (long)b * g.L * W, W, 0, nullptr,
-                           wave * klen, (wave + 1) * klen, l15, kq, acc);
+    // ELDS: the slab's E rows (A operand) through LDS as well, when they fit the region the weights take later (L <= 256: one
+    // 32-key trip per wave).  As fragments, lane = row: 16 cache lines per wave instruction (2 048 look-ups per workgroup); as
+    // unit-stride copies 256.  The value rows (B operand: lanes along the row) are requested first, in the same round trip.
+    constexpr int EP = 256 + 4;
+    const bool elds = WLDS && g.L == 256 && !(PIT_BLOCK_EXP & 64);
+    if (elds) {
+        float* es = w1s;                                // [H][16][EP], overwritten by the weights after the next barrier but one
+        const float* vp = g.xcat + (long)b * g.L * W + 4 * l15;
+        const int j0 = wave * 32;
+        f32x4_t eq[H * 2];
+#pragma unroll
+        for (int p = 0; p < H * 2; ++p) {               // piece q: head q >> 10, row (q >> 6) & 15, keys 4 (q & 63) ..
+            const int q = p * 512 + tid;
+            eq[p] = *reinterpret_cast<const f32x4_t*>(g.e + (long)(q >> 10) * g.L * g.L + (long)(n0 + ((q >> 6) & 15)) * g.L + 4 * (q & 63));
+        }
+        f32x4_t bvv[2][4];
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) bvv[s][m] = *reinterpret_cast<const f32x4_t*>(vp + (long)(j0 + 16 * s + 4 * kq + m) * W);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int p = 0; p < H * 2; ++p) {
+            const int q = p * 512 + tid;
+            *reinterpret_cast<f32x4_t*>(es + ((q >> 10) * 16 + ((q >> 6) & 15)) * EP + 4 * (q & 63)) = eq[p];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            f32x4_t av[H];
+#pragma unroll
+            for (int hh = 0; hh < H; ++hh) av[hh] = *reinterpret_cast<const f32x4_t*>(es + (hh * 16 + l15) * EP + j0 + 16 * s + 4 * kq);
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int hh = 0; hh < H; ++hh) {
+                    acc[hh][0] = mfma_16x16x4(av[hh][m], bvv[s][m][0], acc[hh][0]);
+                    acc[hh][1] = mfma_16x16x4(av[hh][m], bvv[s][m][1], acc[hh][1]);
+                    acc[hh][2] = mfma_16x16x4(av[hh][m], bvv[s][m][2], acc[hh][2]);
+                    acc[hh][3] = mfma_16x16x4(av[hh][m], bvv[s][m][3], acc[hh][3]);
+                }
+        }
+    } else {
+        slab_contract<H, true>(g.e + (long)n0 * g.L, (long)g.L * g.L, g.L, g.xcat + (long)b * g.L * W, W, 0, nullptr,
+                               wave * klen, (wave + 1) * klen, l15, kq, acc);
+    }
     BSTAMP(1);
     if (!WLDS) load_weights();
 #pragma unroll
