@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PIT_ABI_VERSION 17
+#define PIT_ABI_VERSION 18
 #define PIT_DSCALE_SLOTS 1024 /* fp64 accumulators per head in pit_posatt_bwd's workspace */
 
 /* distance metric (dist2att variants) */
@@ -328,20 +328,24 @@ int pit_edge_supported(int n_head, int dim, int batch, int rows_per_sample);
  *   list a slot; um = 32, 48 or 64 >= max_union (report[0] of pit_slab_plan_build), max_count = report[2]; scale_out (n_head) = c.
  * As a launch of its own, or - the job struct - as extra workgroups of pit_encoder_fwd's launch. */
 int pit_decoder_weights(const pit_slab_plan* plan, const float* head, int head_is_scale, int n_head, int max_union, int max_count,
-                        float* pw, float* qw, float* scale_out, void* stream);
+                        float* pw, float* qw, float* scale_out, const float* w1, float* w1f, int dim, void* stream);
+/* w1 / w1f (both or neither; ABI 18): the decoder MLP's first weight w1 (dim, n_head*dim), copied to w1f in the order the lanes of
+ * pit_decoder_fwd consume it as MFMA operand fragments (the copy is part of the step because w1 changes once per step). */
 typedef struct pit_decoder_weights_job {
     const pit_slab_plan* plan; const float* head; int head_is_scale, n_head, max_union, max_count;
     float *pw, *qw, *scale_out;
+    const float* w1; float* w1f; int dim;
 } pit_decoder_weights_job;
 /* pit.decoder forward.  values (batch, n_in, dim) rows ld_values apart; pw from pit_decoder_weights; the MLP is
  * (n_head*dim -> dim -> n2), n2 <= 4, no trailing gelu; y (batch*n_out, n2).  Saved for the backward when given (all or none):
  * x (batch*n_out, n_head*dim) the attention's output, z1 / h (batch*n_out, dim).  zero_buf: zero_n floats cleared on the way (the
  * d_values buffer pit_decoder_bwd adds to).  loss_part != NULL: the slab's partial sums of RelLpNorm(true, y*scale + shift)
  * (utils.py:86-98, p = 1 or 2) as (batch, n2, n_slabs, 2) doubles - plain stores, nothing to zero, the same bits on every run.
- * max_union: report[0] of pit_slab_plan_build: sizes the launch's LDS tiles (as in pit_decoder_weights). */
+ * max_union: report[0] of pit_slab_plan_build: sizes the launch's LDS tiles (as in pit_decoder_weights).
+ * w1f: the fragment-order copy of w1 formed by pit_decoder_weights for THIS w1, or NULL (the launch then reads w1's rows). */
 int pit_decoder_fwd(const pit_slab_plan* plan, const float* values, long ld_values, long values_bstride, int batch,
                     int n_head, int dim, const float* pw,
-                    const float* w1, const float* b1, const float* w2, const float* b2, int n2,
+                    const float* w1, const float* w1f, const float* b1, const float* w2, const float* b2, int n2,
                     float* x, float* z1, float* h, float* y, float* zero_buf, long zero_n,
                     const float* loss_true, const float* loss_scale, const float* loss_shift, int loss_p, double* loss_part,
                     int max_union, void* stream);

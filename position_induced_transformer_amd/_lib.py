@@ -41,7 +41,7 @@ class SlabPlan(ctypes.Structure):
 class DecoderWeightsJob(ctypes.Structure):
     """pit_decoder_weights_job of include/pit_hip.h (the argument list of pit_decoder_weights)."""
     _fields_ = [("plan", _P), ("head", _P), ("head_is_scale", _I), ("n_head", _I), ("max_union", _I), ("max_count", _I),
-                ("pw", _P), ("qw", _P), ("scale_out", _P)]
+                ("pw", _P), ("qw", _P), ("scale_out", _P), ("w1", _P), ("w1f", _P), ("dim", _I)]
 
 
 # name -> argtypes, mirrors include/pit_hip.h one to one
@@ -78,8 +78,8 @@ SIGNATURES = {
     "pit_block_fwd": [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _L, _I, _P],
     "pit_slab_plan_build": [_P, _P, _I, _I, _I, _I, _F, _P, _P, _I, _P, _P, _P, _P, _P, _P],
     "pit_edge_supported": [_I, _I, _I, _I],
-    "pit_decoder_weights": [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P],
-    "pit_decoder_fwd": [_P, _P, _L, _L, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _L,
+    "pit_decoder_weights": [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P],
+    "pit_decoder_fwd": [_P, _P, _L, _L, _I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _L,
                         _P, _P, _P, _I, _P, _I, _P],
     "pit_decoder_bwd": [_P, _P, _L, _L, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _L, _P, _P, _L, _P,
                         _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _P],
@@ -110,7 +110,7 @@ SIGNATURES = {
     "pit_debug_mfma_tile": [_P, _P, _P, _P],
 }
 
-ABI_VERSION = 17       # PIT_ABI_VERSION of include/pit_hip.h this binding was written against
+ABI_VERSION = 18       # PIT_ABI_VERSION of include/pit_hip.h this binding was written against
 
 _lib = None
 

@@ -159,6 +159,7 @@ struct DecWArgs {
     pit_slab_plan p;
     const float* head; int head_is_scale, n_head, um, lpr;
     float *pw, *qw, *scale_out;
+    const float* w1; float* w1f; int dim;     // optional: the decoder MLP's W1 (dim, n_head*dim) copied in MFMA-fragment order
 };
 __device__ __forceinline__ float seg_sum_rt(float v, int lpr) {
     v += dpp_f<0xB1, 0xf>(v);
@@ -215,6 +216,18 @@ __device__ __forceinline__ void dec_weights_body(const DecWArgs& g, int slab, fl
         for (int e = 4 * tid; e < per; e += 4 * 256) *reinterpret_cast<float4*>(qdst + e) = *reinterpret_cast<const float4*>(tile + per + e);
     }
     if (slab == 0 && tid < H && g.scale_out) g.scale_out[tid] = c[tid];
+    // W1 of the decoder MLP in the order decoder_fwd_kernel's lanes consume it: 16-byte piece o = (wave * KS + s) * 64 + lane holds
+    // w1[16 wave + (lane & 15)][16 s + 4 (lane >> 4) ..].  As fragments of the row-major matrix (lane = weight row) a wave instruction
+    // touches 16 cache lines for 64 useful bytes each - 2 048 line look-ups per workgroup, in 928 workgroups; from this copy 256:
+    // decoder_fwd 13.5 -> 11.5 us at Darcy b=8, 188 -> 170 us at b=256.  Once per step, here, because W1 changes once per step.
+    if (g.w1f) {
+        const int K0 = H * g.dim, KS = K0 / 16, n4 = g.dim * K0 / 4;
+        for (int o = slab * 256 + tid; o < n4; o += p.n_slabs * 256) {
+            const int ln = o & 63, s_ = (o >> 6) % KS, w = (o >> 6) / KS;
+            reinterpret_cast<float4*>(g.w1f)[o] =
+                *reinterpret_cast<const float4*>(g.w1 + (long)(16 * w + (ln & 15)) * K0 + 16 * s_ + 4 * (ln >> 4));
+        }
+    }
 }
 __global__ __launch_bounds__(256) void decoder_weights_kernel(DecWArgs g) {
     __shared__ __attribute__((aligned(16))) float tile[2 * 2 * ER * EU];
@@ -227,6 +240,7 @@ struct DecFwdArgs {
     const float* values; long ld_values, values_bstride; int batch;
     const float* pw;                          // (n_slabs, H, 16, um): the step's normalised weights (dec_weights_body)
     const float *w1, *b1, *w2, *b2; int n2;
+    const float* w1f;                         // W1 in fragment order (dec_weights_body), or null: fragments of the row-major w1
     float *x, *z1, *h, *y;
     float* zero_buf; long zero_n;
     const float *tru, *lscale, *lshift; int loss_p; double* lpart;
@@ -327,9 +341,11 @@ __global__ __launch_bounds__(4 * D) void decoder_fwd_kernel(DecFwdArgs g) {
     float4 pcp[WCP * 256 / NT];
     wtile_request<NT>(g.pw + (long)slab * H * ER * g.um, npc, tid, pcp);
     float4 bv[KS];
+    const float* w1base = g.w1f ? g.w1f : g.w1;          // (a select on the address, not a branch around the loads)
 #pragma unroll
     for (int s = 0; s < KS; ++s)
-        bv[s] = (PIT_EDGE_DBG & 1) ? make_float4(1.f, 2.f, 3.f, 4.f) : *reinterpret_cast<const float4*>(g.w1 + (long)c1 * K0 + 16 * s + 4 * kq);
+        bv[s] = (PIT_EDGE_DBG & 1) ? make_float4(1.f, 2.f, 3.f, 4.f)
+              : *reinterpret_cast<const float4*>(w1base + (g.w1f ? ((wave * KS + s) * 64 + lane) * 4 : c1 * K0 + 16 * s + 4 * kq));
     const float bias1 = g.b1[c1];
     const float w2r = ldg_if(g.w2, tid, tid < g.n2 * D);          // (n2 * D <= 4 * D = NT: one element per thread)
     const float b2r = ldg_if(g.b2, tid, tid < g.n2);
@@ -653,7 +669,8 @@ __global__ __launch_bounds__(4 * D) void decoder_bwd_kernel(DecBwdArgs g) {
 #pragma unroll
         for (int s = 0; s < S1; ++s)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) w1v[hh][s][e] = (PIT_EDGE_DBG & 8) ? 0.5f : g.w1[(long)(16 * s + 4 * kq + e) * K0 + hh * D + c1];
+            for (int e = 0; e < 4; ++e) w1v[hh][s][e] = (PIT_EDGE_DBG & 8) ? 0.5f
+                : g.w1[(long)(16 * s + 4 * kq + e) * K0 + hh * D + c1];
     __syncthreads();
     ESTAMP(1, 6);
     // ---- dX = dZ1 W1 (16 x H*D), LDS only
@@ -1236,8 +1253,11 @@ extern "C" int pit_slab_plan_build(const float* mesh_out, const float* mesh_in, 
 namespace {
 // pit_decoder_weights' argument checks -> kernel arguments
 int fill_dec_weights(DecWArgs& g, const pit_slab_plan* plan, const float* head, int head_is_scale, int n_head, int max_union,
-                     int max_count, float* pw, float* qw, float* scale_out) {
+                     int max_count, float* pw, float* qw, float* scale_out, const float* w1, float* w1f, int dim) {
     if (!plan_ok(plan, true) || !head || !pw) return PIT_ERR_NULL;
+    if ((w1 == nullptr) != (w1f == nullptr)) return PIT_ERR_NULL;
+    if (w1f && (dim < 16 || dim % 16 != 0 || !aligned16(w1) || !aligned16(w1f))) return PIT_ERR_SIZE;
+    g.w1 = w1; g.w1f = w1f; g.dim = dim;
     if ((n_head != 1 && n_head != 2) || max_union < 1 || max_union > EU || max_count < 1 || max_count > 64) return PIT_ERR_UNSUPPORTED;
     if (!aligned16(pw) || (qw && !aligned16(qw))) return PIT_ERR_SIZE;
     g.p = *plan; g.head = head; g.head_is_scale = head_is_scale; g.n_head = n_head; g.um = union_slots(max_union);
@@ -1248,9 +1268,10 @@ int fill_dec_weights(DecWArgs& g, const pit_slab_plan* plan, const float* head, 
 }  // namespace
 
 extern "C" int pit_decoder_weights(const pit_slab_plan* plan, const float* head, int head_is_scale, int n_head, int max_union,
-                                   int max_count, float* pw, float* qw, float* scale_out, void* stream) {
+                                   int max_count, float* pw, float* qw, float* scale_out, const float* w1, float* w1f, int dim,
+                                   void* stream) {
     DecWArgs g;
-    if (int rc = fill_dec_weights(g, plan, head, head_is_scale, n_head, max_union, max_count, pw, qw, scale_out)) return rc;
+    if (int rc = fill_dec_weights(g, plan, head, head_is_scale, n_head, max_union, max_count, pw, qw, scale_out, w1, w1f, dim)) return rc;
     hipLaunchKernelGGL(decoder_weights_kernel, dim3((unsigned)plan->n_slabs), dim3(256), 0, (hipStream_t)stream, g);
     PIT_CHECK_LAUNCH();
     return 0;
@@ -1258,11 +1279,12 @@ extern "C" int pit_decoder_weights(const pit_slab_plan* plan, const float* head,
 
 extern "C" int pit_decoder_fwd(const pit_slab_plan* plan, const float* values, long ld_values, long values_bstride, int batch,
                                int n_head, int dim, const float* pw,
-                               const float* w1, const float* b1, const float* w2, const float* b2, int n2,
+                               const float* w1, const float* w1f, const float* b1, const float* w2, const float* b2, int n2,
                                float* x, float* z1, float* h, float* y, float* zero_buf, long zero_n,
                                const float* loss_true, const float* loss_scale, const float* loss_shift, int loss_p, double* loss_part,
                                int max_union, void* stream) {
     if (max_union < 1 || max_union > EU) return PIT_ERR_UNSUPPORTED;
+    if (w1f && !aligned16(w1f)) return PIT_ERR_SIZE;
     if (!plan_ok(plan, true) || !values || !pw || !w1 || !b1 || !w2 || !b2 || !y) return PIT_ERR_NULL;
     if (!hid_ok(n_head, dim) || n2 < 1 || n2 > 4 || batch <= 0) return PIT_ERR_UNSUPPORTED;
     if ((z1 == nullptr) != (h == nullptr)) return PIT_ERR_NULL;
@@ -1271,7 +1293,7 @@ extern "C" int pit_decoder_fwd(const pit_slab_plan* plan, const float* values, l
     if (loss_part && (!loss_true || (loss_p != 1 && loss_p != 2) || (loss_scale == nullptr) != (loss_shift == nullptr))) return PIT_ERR_UNSUPPORTED;
     DecFwdArgs g;
     g.p = *plan; g.values = values; g.ld_values = ld_values; g.values_bstride = values_bstride; g.batch = batch;
-    g.pw = pw; g.w1 = w1; g.b1 = b1; g.w2 = w2; g.b2 = b2; g.n2 = n2;
+    g.pw = pw; g.w1 = w1; g.w1f = w1f; g.b1 = b1; g.w2 = w2; g.b2 = b2; g.n2 = n2;
     g.x = x; g.z1 = z1; g.h = h; g.y = y; g.zero_buf = zero_buf; g.zero_n = zero_buf ? zero_n : 0;
     g.tru = loss_true; g.lscale = loss_scale; g.lshift = loss_shift; g.loss_p = loss_p; g.lpart = loss_part;
     g.um = union_slots(max_union);
@@ -1364,7 +1386,7 @@ extern "C" int pit_encoder_fwd(const pit_slab_plan* plan, const float* mesh_in, 
     if (dec_weights) {
         if (int rc = fill_dec_weights(da, dec_weights->plan, dec_weights->head, dec_weights->head_is_scale, dec_weights->n_head,
                                       dec_weights->max_union, dec_weights->max_count, dec_weights->pw, dec_weights->qw,
-                                      dec_weights->scale_out)) return rc;
+                                      dec_weights->scale_out, dec_weights->w1, dec_weights->w1f, dec_weights->dim)) return rc;
         if (dim == 64) n_dw = da.p.n_slabs;
     }
     const dim3 grid((unsigned)(g.n_att + n_w + n_dw));
@@ -1377,7 +1399,7 @@ extern "C" int pit_encoder_fwd(const pit_slab_plan* plan, const float* mesh_in, 
     if (dec_weights && dim != 64)
         if (int rc = pit_decoder_weights(dec_weights->plan, dec_weights->head, dec_weights->head_is_scale, dec_weights->n_head,
                                          dec_weights->max_union, dec_weights->max_count, dec_weights->pw, dec_weights->qw,
-                                         dec_weights->scale_out, stream)) return rc;
+                                         dec_weights->scale_out, dec_weights->w1, dec_weights->w1f, dec_weights->dim, stream)) return rc;
     if (own_launch)
         return pit_block_weights(weights->mesh, weights->n_pts, weights->space_dim, weights->metric, weights->period, weights->n_layers,
                                  weights->heads, weights->head_is_scale, weights->n_head, weights->e, weights->q, weights->inv,

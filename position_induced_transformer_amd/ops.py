@@ -1468,44 +1468,50 @@ class DecoderWeights:
     """The up-projection's softmax weights of one step (pit_decoder_weights): P / Q tiles per 16-row slab and the head scales c.
     They depend on (mesh pair, lmda) only: formed once per step - by extra workgroups of the encoder-side launch when pit.encoder
     could request them (early_decoder_weights), else by a launch of their own in front of the decoder launch."""
-    __slots__ = ("key", "pw", "qw", "scale", "job", "keep")
+    __slots__ = ("key", "pw", "qw", "scale", "job", "keep", "w1f")
 
 
-def _dec_weights_key(plan: MeshPlan, lmda, scale_in, n_head: int, head_is_scale: bool):
+def _dec_weights_key(plan: MeshPlan, lmda, scale_in, n_head: int, head_is_scale: bool, w1=None):
     return (id(plan), n_head, _PARAM_EPOCH[0], lmda._version, lmda.data_ptr(), bool(head_is_scale),
-            scale_in.data_ptr() if scale_in is not None else None)
+            scale_in.data_ptr() if scale_in is not None else None,
+            (w1.data_ptr(), w1._version, tuple(w1.shape)) if w1 is not None else None)
 
 
-def _new_decoder_weights(plan: MeshPlan, lmda, scale_in, n_head: int, head_is_scale: bool, need_q: bool) -> DecoderWeights:
+def _new_decoder_weights(plan: MeshPlan, lmda, scale_in, n_head: int, head_is_scale: bool, need_q: bool, w1=None) -> DecoderWeights:
     sp, max_union, _t, max_count = plan.slab_plan()
     um = 32 if max_union <= 32 else (48 if max_union <= 48 else 64)
     dev = plan.mesh_out.device
     w = DecoderWeights()
-    w.key = _dec_weights_key(plan, lmda, scale_in, n_head, head_is_scale)
+    w.key = _dec_weights_key(plan, lmda, scale_in, n_head, head_is_scale, w1)
+    # the decoder MLP's W1 in MFMA-fragment order (pit_hip.h: w1f): formed with the tiles, once per step
+    w1c = w1.detach() if (w1 is not None and w1.is_contiguous() and w1.dtype == torch.float32 and w1.dim() == 2
+                          and w1.shape[0] % 16 == 0 and w1.shape[1] == n_head * w1.shape[0] and w1.data_ptr() % 16 == 0) else None
+    w.w1f = torch.empty_like(w1c) if w1c is not None else None
     w.pw = torch.empty((sp.n_slabs, n_head, 16, um), device=dev, dtype=torch.float32)
     w.qw = torch.empty((sp.n_slabs, n_head, 16, um), device=dev, dtype=torch.float32) if need_q else None
     w.scale = torch.empty((n_head,), device=dev, dtype=torch.float32)
     head = scale_in if scale_in is not None else lmda.detach().reshape(-1).contiguous()
-    w.keep = (head, plan, sp)
+    w.keep = (head, plan, sp, w1c)
     w.job = _lib.DecoderWeightsJob(ctypes.cast(ctypes.pointer(sp), ctypes.c_void_p), head.data_ptr(),
                                    1 if (scale_in is not None or head_is_scale) else 0, n_head, max_union, max_count,
-                                   w.pw.data_ptr(), _lib.ptr(w.qw), w.scale.data_ptr())
+                                   w.pw.data_ptr(), _lib.ptr(w.qw), w.scale.data_ptr(),
+                                   _lib.ptr(w1c), _lib.ptr(w.w1f), w1c.shape[0] if w1c is not None else 0)
     return w
 
 
 def _launch_decoder_weights(w: DecoderWeights) -> None:
     j = w.job
     rc = _lib.lib().pit_decoder_weights(j.plan, j.head, j.head_is_scale, j.n_head, j.max_union, j.max_count, j.pw, j.qw,
-                                        j.scale_out, _lib.stream_ptr())
+                                        j.scale_out, j.w1, j.w1f, j.dim, _lib.stream_ptr())
     _lib.check(rc, "pit_decoder_weights")
 
 
-def early_decoder_weights(plan: MeshPlan, lmda, n_head: int, need_q: bool) -> None:
+def early_decoder_weights(plan: MeshPlan, lmda, n_head: int, need_q: bool, w1=None) -> None:
     """Request the decoder's weights BEFORE the encoder-side launch of the same forward (pit.encoder): encoder_apply carries the job
     in its launch; decoder_apply uses the result when plan / lmda / route are still the ones it was formed from.  A job no launch
     took is dropped (drop_forward_job) - the decoder then forms its weights itself."""
     scale_in = host_head_scale(lmda) if get_head_scale_route() == "host" else None
-    _STEP.dec_job = _new_decoder_weights(plan, lmda, scale_in, n_head, False, need_q)
+    _STEP.dec_job = _new_decoder_weights(plan, lmda, scale_in, n_head, False, need_q, w1)
     _STEP.dec_ready = None
 
 
@@ -1539,8 +1545,10 @@ class _Decoder(torch.autograd.Function):
             lt, ls, lh, lp = loss.true, loss.scale, loss.shift, loss.p
             lpart = loss.partials = torch.empty((b, n2, sp.n_slabs, 2), device=dev, dtype=torch.float64)
             loss.value = torch.empty((), device=dev, dtype=torch.float32)
+        # (the fragment-order copy of W1 belongs to the tensor the weights were formed from)
+        w1f = weights.w1f if (weights.w1f is not None and weights.keep[3].data_ptr() == w1c.data_ptr()) else None
         rc = _lib.lib().pit_decoder_fwd(ctypes.byref(sp), values.data_ptr(), values.stride(1), values.stride(0), b, n_head, d,
-                                        weights.pw.data_ptr(), w1c.data_ptr(), b1c.data_ptr(), w2c.data_ptr(),
+                                        weights.pw.data_ptr(), w1c.data_ptr(), _lib.ptr(w1f), b1c.data_ptr(), w2c.data_ptr(),
                                         b2c.data_ptr(), n2, _lib.ptr(x), _lib.ptr(z1), _lib.ptr(h), y.data_ptr(),
                                         _lib.ptr(dvals), dvals.numel() if dvals is not None else 0,
                                         _lib.ptr(lt), _lib.ptr(ls), _lib.ptr(lh), lp, _lib.ptr(lpart), plan.slab_plan()[1],
@@ -1635,8 +1643,8 @@ def decoder_apply(values: torch.Tensor, lmda: torch.Tensor, plan: MeshPlan, n_he
     # the step's weights: formed under the encoder-side launch when pit.encoder requested them for exactly this plan / lmda / route
     weights = getattr(_STEP, "dec_ready", None)
     _STEP.dec_ready = None
-    if weights is None or weights.key != _dec_weights_key(plan, lmda, c, n_head, head_is_scale) or (need_q and weights.qw is None):
-        weights = _new_decoder_weights(plan, lmda, c, n_head, head_is_scale, need_q)
+    if weights is None or weights.key != _dec_weights_key(plan, lmda, c, n_head, head_is_scale, mlp[0]) or (need_q and weights.qw is None):
+        weights = _new_decoder_weights(plan, lmda, c, n_head, head_is_scale, need_q, mlp[0])
         _launch_decoder_weights(weights)
     loss = getattr(_STEP, "loss", None)
     if loss is not None:

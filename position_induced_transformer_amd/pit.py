@@ -362,7 +362,7 @@ class pit(nn.Module):
                 dplan = self._cached_decoder_plan(mesh_ltt, func_in.shape[0], func_in.device)
                 if dplan is not None:
                     need_q = torch.is_grad_enabled() and any(q.requires_grad for q in self.parameters())
-                    ops.early_decoder_weights(dplan, self.up.lmda, self.up.n_head, need_q)
+                    ops.early_decoder_weights(dplan, self.up.lmda, self.up.n_head, need_q, self.de.mlp1.weight)
             fused = self._fused_encoder(mesh_in, func_in, mesh_ltt, early)
             func_ltt = self.down(mesh_ltt, mesh_in, func_in) if fused is None else None
             if early is not None:
