@@ -14,7 +14,7 @@ f = glob.glob(d + "/**/*kernel_stats.csv", recursive=True)
 rows = list(csv.DictReader(open(f[0]))) if f else []
 pick = {}
 for r in rows:
-    for k in ("decoder_fwd", "decoder_bwd", "encoder_fwd", "encoder_bwd", "block_fwd", "block_bwd", "mlp_bwd16", "dhead_finish", "gemm_rd_pair", "mlp_fwd64", "mlp_bwd64", "gemm_rr", "thin_dw"):
+    for k in ("decoder_fwd", "decoder_bwd", "encoder_fwd", "encoder_bwd", "block_fwd", "block_bwd", "mlp_bwd16", "dhead_finish", "gemm_rd_pair", "mlp_fwd64", "mlp_bwd64", "gemm_rr", "thin_dw", "posatt_cols_tiles", "posatt_rows_tiles"):
         if k in r["Name"] and int(r["Calls"]) > 100:
             pick[k] = float(r["AverageNs"]) / 1e3
 try:
