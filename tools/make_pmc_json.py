@@ -12,7 +12,7 @@ want = {  # bench key -> (config, kernel-name prefix, shape of the launch(es) th
          # quotes the bytes for a probe of exactly this shape; "family": the kernel runs on several shapes in the step and the
          # figure is their mean, which no single-shape probe may quote)
     "block_bwd_kernel_b8": ("darcy8", "block_bwd_kernel<2, 2>", "L256_H2_D64_b8"),
-    "block_fwd_kernel_b8": ("darcy8", "block_fwd_kernel<2, false>", "L256_H2_D64_b8"),
+    "block_fwd_kernel_b8": ("darcy8", "block_fwd_kernel<2, true>", "L256_H2_D64_b8"),      # (<H, WLDS>: weights and E rows through LDS)
     # round 5: the fused encoder- / decoder-side launches of the small regime (csrc/pit_edge.hip)
     "decoder_fwd_kernel_b8": ("darcy8", "decoder_fwd_kernel<2, 64, true>", "N1849_J256_H2_D64_b8"),
     "decoder_bwd_kernel_b8": ("darcy8", "decoder_bwd_kernel<2, 64, true>", "N1849_J256_H2_D64_b8"),
