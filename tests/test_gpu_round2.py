@@ -68,7 +68,9 @@ def test_torch_compile_model_matches_eager_and_traces_nothing():
 
 
 # --------------------------------------------------------------------------- lmda -> c routes
-SWEEP_SEEDS = 200
+# seeds of the route sweep: 200 produced profiles/r02_lmda_route_sweep.json (PIT_SWEEP_SEEDS=200 re-runs it); the suite's default
+# keeps the same seeds' first 100 - the oracle on the host is what the sweep's time goes to (79 of the suite's 201 s with 200)
+SWEEP_SEEDS = int(os.environ.get("PIT_SWEEP_SEEDS", "100"))
 # Fraction of unselected seeds whose device-route output is more than 1e-5 from the oracle ON THE SAME
 # HOST.  It is a property of the host's libm as much as of the kernels: measured 0.22 (Darcy) on the
 # MI355X box (EPYC 9575F: MKL's VML kernels for AMD CPUs disagree with the correctly rounded c for ~19 %
@@ -80,7 +82,7 @@ MAX_FRACTION_ABOVE_1E5 = {"F9_model_darcy": 0.25, "F11_model_burgers": 0.02}
 
 @pytest.mark.parametrize("name", ["F9_model_darcy", "F11_model_burgers"])
 def test_unselected_seed_sweep_device_and_host_scale_routes(name):
-    """VERDICT r1 weak #1.  200 parameter seeds taken as they come (nothing selected) on the two
+    """VERDICT r1 weak #1.  SWEEP_SEEDS (100; 200 for the committed record) parameter seeds taken as they come (nothing selected) on the two
     regular-grid models, each compared with the oracle on THIS host (whose sin/tan are ATen-CPU's):
       * route 'host' (c by the reference's own torch-CPU ops, injected): every seed <= 1e-5;
       * route 'device' (c evaluated in the kernels): <= 1e-5 whenever all c are bit-equal to the
@@ -157,7 +159,9 @@ def test_unselected_seed_sweep_device_and_host_scale_routes(name):
             r["oracle_fp32_vs_fp64"] = own
     assert summary["host_route"]["above_1e5"] <= 2, summary
     assert summary["device_route_c_equal"]["above_1e5"] == 0, summary
-    assert summary["device_route_fraction_above_1e5"] <= MAX_FRACTION_ABOVE_1E5[name], summary
+    # (the bound is the 200-seed figure; a shorter sweep gets the sampling slack of its size: 0.24 on the first 100 Darcy seeds)
+    slack = 0.0 if SWEEP_SEEDS >= 200 else 0.05
+    assert summary["device_route_fraction_above_1e5"] <= MAX_FRACTION_ABOVE_1E5[name] + slack, summary
 
 
 def test_host_route_gradients_match_the_oracle_on_a_seed_where_c_differs():
