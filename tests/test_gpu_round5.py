@@ -387,3 +387,31 @@ def test_deterministic_algorithms_flag_keeps_the_atomic_free_data_path():
         assert float(grads[0].abs().max()) > 0
     finally:
         torch.use_deterministic_algorithms(False)
+
+
+# --------------------------------------------------------------------------- operands as unit-stride copies
+@pytest.mark.gpu
+def test_weights_and_e_rows_through_lds_give_the_bits_of_the_fragment_loads():
+    """block_fwd_kernel<H, WLDS> (the MLP's weights and the slab's E rows reach the MFMAs through LDS when the launch has at most 256
+    workgroups) against the same kernel with per-lane fragment loads (PIT_NO_BLOCK_WLDS, read once per process: a child each),
+    and the decoder forward on the step's fragment-order copy of W1 against the row-major W1: the same operands in the same
+    order - the prediction is bit-identical."""
+    import hashlib, os, subprocess, sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    code = (
+        "import sys, hashlib; sys.path.insert(0, %r); import torch\n"
+        "from position_induced_transformer_amd import ops, tasks\n"
+        "if 'NOW1F' in sys.argv:\n"
+        "    real = ops._new_decoder_weights\n"
+        "    ops._new_decoder_weights = lambda *a, **k: real(*a[:6])\n"
+        "model, sample, meta = tasks.make_task('darcy', seed=21)\n"
+        "mesh_in, func_in, mesh_out, target = sample(8)\n"
+        "with torch.no_grad():\n"
+        "    out = model(mesh_in, func_in, mesh_out)\n"
+        "print('DIGEST', hashlib.sha256(out.cpu().numpy().tobytes()).hexdigest())\n" % os.path.dirname(here))
+    digests = {}
+    for name, env, args in (("lds", {}, []), ("fragments", {"PIT_NO_BLOCK_WLDS": "1"}, []), ("row-major-w1", {}, ["NOW1F"])):
+        r = subprocess.run([sys.executable, "-c", code] + args, env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+        digests[name] = [ln.split()[1] for ln in r.stdout.splitlines() if ln.startswith("DIGEST")][0]
+    assert digests["lds"] == digests["fragments"] == digests["row-major-w1"], digests
