@@ -593,7 +593,12 @@ extern "C" int pit_block_fwd(const float* e, const float* inv, int n_pts, int n_
     g.z1 = z1; g.h = h; g.z2 = z2; g.y = y; g.ldy = ldy;
     const dim3 grid((unsigned)slab_grid(batch, n_pts / 16)), block(64 * BW);
     static const bool no_wlds = getenv("PIT_NO_BLOCK_WLDS") != nullptr;                  // (A/B switch, read once)
-    const bool earlyw = !no_wlds && grid.x <= 256;      // WLDS: the weights through LDS (one workgroup per CU: 64 KB more LDS)
+    static const int n_cus = [] {                       // (one device per process: read once)
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 0;
+        return cus;
+    }();
+    const bool earlyw = !no_wlds && (int)grid.x <= n_cus;      // WLDS: the weights through LDS (one workgroup per CU: 64 KB more LDS)
     const size_t FWD_SMEM = fwd_smem(n_head, earlyw);
 #define PIT_BLOCK_FWD(H_, E_)                                                                                              \
     do {                                                                                                                   \
