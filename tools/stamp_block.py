@@ -41,7 +41,8 @@ def place(hw, xcc):
 
 percu = collections.defaultdict(list)
 for a, b, hw, xcc, i in rows:
-    percu[place(hw, xcc)].append(("chain" if i < n_chain else "rider", (a - t0) * 10, (b - t0) * 10, i))
+    kind = "chain" if i < n_chain else ("dscale" if i < 2 * n_chain else "rider")      # (block_bwd's ranges: chain, d(scale) slabs, riders)
+    percu[place(hw, xcc)].append((kind, (a - t0) * 10, (b - t0) * 10, i))
 print(f"{len(rows)} workgroups on {len(percu)} distinct CUs; per CU: {dict(collections.Counter(len(v) for v in percu.values()))}")
 mix = collections.Counter(tuple(sorted(k for k, _, _, _ in v)) for v in percu.values())
 print("CU contents:", dict(mix))
@@ -76,8 +77,8 @@ if hasattr(L, "pit_block_read_stamps"):        # -DPIT_STAMPS as well: shader-cl
                 prev = st[i]
 
 # lifetimes by workgroup-id range (PIT_BLOCK_PRINT=1 prints the ranges of every launch)
-ids = sorted((i, (b - a) * 10, (b - t0) * 10) for a, b, hw, xcc, i in rows if i >= n_chain)
+ids = sorted((i, (b - a) * 10, (b - t0) * 10) for a, b, hw, xcc, i in rows if i >= 2 * n_chain)
 step = 16
 for k in range(0, len(ids), step):
     seg = ids[k:k + step]
-    print(f"  riders {seg[0][0] - n_chain:4d}..{seg[-1][0] - n_chain:4d}: lifetime mean {sum(x[1] for x in seg) / len(seg):6.0f} max {max(x[1] for x in seg):6d} ns, last exit {max(x[2] for x in seg)} ns")
+    print(f"  riders {seg[0][0] - 2 * n_chain:4d}..{seg[-1][0] - 2 * n_chain:4d}: lifetime mean {sum(x[1] for x in seg) / len(seg):6.0f} max {max(x[1] for x in seg):6d} ns, last exit {max(x[2] for x in seg)} ns")
