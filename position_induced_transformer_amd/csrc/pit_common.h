@@ -168,6 +168,22 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 }
 #endif
 
+#ifdef PIT_GELU_FAST       // (timing experiment, DESIGN section 4 Round 5: A&S 7.1.26 refitted, 16 / 18 straight-line instructions; NOT the default)
+__device__ __forceinline__ float normal_cdf(float x, float& e) {
+    const float t = __builtin_amdgcn_rcpf(fmaf(fabsf(x), 0.28284271247f, 1.0f));
+    e = __builtin_amdgcn_exp2f(x * x * -0.72134752044f);
+    float p = -0.100061134f;
+    p = fmaf(p, t, 0.354291141f);
+    p = fmaf(p, t, -0.184991121f);
+    p = fmaf(p, t, 0.233760774f);
+    p = fmaf(p, t, 0.0810635462f);
+    p = fmaf(p, t, 0.115936771f);
+    const float q = p * t * e;
+    return x > 0.0f ? 1.0f - q : q;
+}
+__device__ __forceinline__ float gelu_erf(float x) { float e; return x * normal_cdf(x, e); }
+__device__ __forceinline__ float gelu_erf_grad(float x) { float e; const float c = normal_cdf(x, e); return fmaf(x * 0.39894228040143267794f, e, c); }
+#else
 __device__ __forceinline__ float gelu_erf(float x) {
     return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
 }
@@ -176,6 +192,7 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
     const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
     return cdf + x * pdf;
 }
+#endif
 
 // Raw buffer loads (T8): out-of-range offsets return 0 in hardware, so row / column / tail
 // predication costs an integer select on the OFFSET instead of a branch around the load
