@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PIT_ABI_VERSION 18
+#define PIT_ABI_VERSION 19
 #define PIT_DSCALE_SLOTS 1024 /* fp64 accumulators per head in pit_posatt_bwd's workspace */
 
 /* distance metric (dist2att variants) */
@@ -315,11 +315,13 @@ typedef struct pit_slab_plan {
     const float* stats; float rank_w;
     const int* idx; const int* cnt;
     const float* m; const unsigned short* slot; const int* keys; const int* nkeys;
+    int rows;       /* rows per slab (ABI 19): 16 for the fused launches and pit_union_att_*, 64 / 128 / 256 for pit_fold_* */
 } pit_slab_plan;
-/* report: 3 ints, ZERO on entry (largest union, 1 if a list overflowed, longest list).  n_in <= 16384. */
+/* report: 3 ints, ZERO on entry (largest union, 1 if a list overflowed, longest list).  n_in <= 16384.  rows_per_slab: 16, 64, 128
+ * or 256; m / slot hold n_slabs*rows_per_slab rows, n_slabs = ceil(n_out / rows_per_slab). */
 int pit_slab_plan_build(const float* mesh_out, const float* mesh_in, int n_out, int n_in, int space_dim, int metric, float period,
-                        const int* nbr_idx, const int* nbr_cnt, int cap, float* m, unsigned short* slot, int* keys, int* nkeys,
-                        int* report, void* stream);
+                        const int* nbr_idx, const int* nbr_cnt, int cap, int rows_per_slab, float* m, unsigned short* slot,
+                        int* keys, int* nkeys, int* report, void* stream);
 /* 1 when the fused launches cover this shape: n_head 1 or 2, dim (= the MLP's hidden width) 32 or 64, 256 <= batch*rows <= 2^20 */
 int pit_edge_supported(int n_head, int dim, int batch, int rows_per_sample);
 /* The up-projection's softmax weights for one step: they depend on (mesh pair, lmda) only, so they are formed ONCE (one workgroup
@@ -374,6 +376,44 @@ int pit_union_att_bwd(const pit_slab_plan* plan, const float* values, long ld_va
                       int n_head, int dim, const float* pw, const float* qw,
                       const void* d_out, long ld_dout, long dout_bstride, int dout_bf16,
                       float* d_values, long ld_dvalues, long dvalues_bstride, double* dscale, int max_union, void* stream);
+/* ---- The decoder side with the decoder MLP's first layer folded into the values (round 6; csrc/pit_fold.hip) -------------------
+ * pit.decoder (pit.py:124-127) = de(up(values)) with nothing non-linear between the up-projection and de.mlp1, so
+ *     Z1 = sum_h P_h (V W1_h^T) + b1,   W1_h = W1[:, h*dim : (h+1)*dim]
+ * - the first Linear runs on the n_in LATENT points instead of the n_out output points, and the (batch, n_out, n_head*dim) tensor of
+ * pit.py:125 never exists.  vw (batch, n_in, dim*n_head) is HEAD-INTERLEAVED: vw[b, j, n*n_head + h] = sum_d values[b, j, d] W1[n][h*dim + d]
+ * = pit_linear_fwd(values, w = W1's memory read as an (n_head*dim, dim) row-major matrix) - no permuted copy of W1, and the weight
+ * gradient of that Linear has W1.grad's layout.  For batch-free mesh pairs:
+ *   pit_slab_plan_build(..., rows_per_slab = 64 | 128 | 256)  the plan (tall slabs: their unions must fit PIT_SLAB_UNION_MAX)
+ *   pit_fold_weights   pw / qw (n_slabs*n_head, rows, um) for one step, as pit_decoder_weights
+ *   pit_fold_att_fwd   z[b, n, c] = sum_h sum_j P_h[n][j] vw[b, j, c*n_head + h]        (fp32, or bf16 with PIT_IO_OUT_BF16)
+ *   pit_fold_att_bwd   d_vw[b, j, c*n_head + h] += sum_n P_h[n][j] dz[b, n, c] (fp32 atomics, ZERO on entry; NULL: not needed),
+ *                      d(scale) accumulators (PIT_HEAD_DEFER convention; NULL: not needed); dz bf16 with PIT_IO_DOUT_BF16
+ * math_mode PIT_MATH_FP32: v_mfma_f32_16x16x4_f32; PIT_MATH_BF16: tiles rounded to bf16 in LDS, v_mfma_f32_16x16x32_bf16.
+ * dim a multiple of 64, n_head 1 or 2, every tensor below 2 GiB (pit_fold_supported). */
+int pit_fold_supported(int n_head, int dim, int batch, int rows_per_sample, int n_in);
+int pit_fold_weights(const pit_slab_plan* plan, const float* head, int head_is_scale, int n_head, int max_union, int max_count,
+                     float* pw, float* qw, float* scale_out, void* stream);
+int pit_fold_att_fwd(const pit_slab_plan* plan, const float* vw, long ld_vw, long vw_bstride, int batch, int n_head, int dim,
+                     const float* pw, void* z, long ld_z, long z_bstride, int max_union, int math_mode, void* stream);
+int pit_fold_att_bwd(const pit_slab_plan* plan, const float* vw, long ld_vw, long vw_bstride, int batch, int n_head, int dim,
+                     const float* pw, const float* qw, const void* dz, long ld_dz, long dz_bstride,
+                     float* d_vw, long ld_dvw, long dvw_bstride, double* dscale, int max_union, int math_mode, void* stream);
+/* The rest of `de` (pit.py:21-26 after the first Linear) for out_dim = n2 <= 4 and n1 in {64, 128, 256}:
+ *   pit_thin_tail_fwd   y[m][o] = sum_n gelu_erf(z[m][n] + b1[n]) w2[o][n] + b2[o]           (z fp32 or bf16; nothing is saved)
+ *   pit_thin_tail_bwd   dz[m][n] = (sum_o d_y[m][o] w2[o][n]) gelu'(z[m][n] + b1[n]) (fp32 or bf16), and ADDS (fp32 atomics) d_b1[n] =
+ *                       sum_m dz[m][n], d_w2[o][n] = sum_m d_y[m][o] gelu(z[m][n] + b1[n]), d_b2[o] = sum_m d_y[m][o]. */
+int pit_thin_tail_fwd(const void* z, long ldz, int rows, int n1, int n2, const float* b1, const float* w2, const float* b2,
+                      float* y, long ldy, int z_bf16, void* stream);
+int pit_thin_tail_bwd(const void* z, long ldz, int rows, int n1, int n2, const float* b1, const float* w2,
+                      const float* d_y, long ld_dy, void* dz, long ld_dz, float* d_b1, float* d_w2, float* d_b2,
+                      int z_bf16, int dz_bf16, void* stream);
+/* y = x w^T without bias (w (n_out, n_in) contiguous; zero_bias: n_out zeros) and its backward d_x = d_y w (NULL: not needed),
+ * d_w (+)= d_y^T x (NULL: not needed; accumulate = 0 zeroes it first) - the GEMM launchers of pit_mlp_fwd / _bwd. */
+int pit_linear_fwd(const float* x, long ldx, int rows, int n_in, int n_out, const float* w, const float* zero_bias,
+                   float* y, long ldy, int math_mode, void* stream);
+int pit_linear_bwd(const float* x, long ldx, int rows, int n_in, int n_out, const float* w, const float* d_y, long ld_dy,
+                   float* d_x, long ld_dx, float* d_w, int accumulate, int math_mode, void* stream);
+
 /* pit.encoder forward.  Value channels [0, coord_dims) are the key coordinates (mesh_in; train_darcy.py:51-55), the other
  * value_dim channels come from values (batch, n_in, value_dim); n_head*(coord_dims + value_dim) <= 16.  The MLP is
  * (n_head*(coord_dims+value_dim) -> dim -> dim) followed by gelu; y rows ldy apart (the first columns of the processor's concat

@@ -35,7 +35,7 @@ class BlockWeightsJob(ctypes.Structure):
 class SlabPlan(ctypes.Structure):
     """pit_slab_plan of include/pit_hip.h (the static per-slab plan of a masked cross-attention layer on a fixed mesh pair)."""
     _fields_ = [("n_out", _I), ("n_in", _I), ("cap", _I), ("n_slabs", _I), ("umax", _I), ("stats", _P), ("rank_w", _F),
-                ("idx", _P), ("cnt", _P), ("m", _P), ("slot", _P), ("keys", _P), ("nkeys", _P)]
+                ("idx", _P), ("cnt", _P), ("m", _P), ("slot", _P), ("keys", _P), ("nkeys", _P), ("rows", _I)]
 
 
 class DecoderWeightsJob(ctypes.Structure):
@@ -76,7 +76,15 @@ SIGNATURES = {
     "pit_block_supported": [_I, _I, _I, _I],
     "pit_block_weights": [_P, _I, _I, _I, _F, _I, _P, _I, _I, _P, _P, _P, _P, _P, _P],
     "pit_block_fwd": [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _L, _I, _P],
-    "pit_slab_plan_build": [_P, _P, _I, _I, _I, _I, _F, _P, _P, _I, _P, _P, _P, _P, _P, _P],
+    "pit_slab_plan_build": [_P, _P, _I, _I, _I, _I, _F, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P],
+    "pit_fold_supported": [_I, _I, _I, _I, _I],
+    "pit_fold_weights": [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P],
+    "pit_fold_att_fwd": [_P, _P, _L, _L, _I, _I, _I, _P, _P, _L, _L, _I, _I, _P],
+    "pit_fold_att_bwd": [_P, _P, _L, _L, _I, _I, _I, _P, _P, _P, _L, _L, _P, _L, _L, _P, _I, _I, _P],
+    "pit_thin_tail_fwd": [_P, _L, _I, _I, _I, _P, _P, _P, _P, _L, _I, _P],
+    "pit_thin_tail_bwd": [_P, _L, _I, _I, _I, _P, _P, _P, _L, _P, _L, _P, _P, _P, _I, _I, _P],
+    "pit_linear_fwd": [_P, _L, _I, _I, _I, _P, _P, _P, _L, _I, _P],
+    "pit_linear_bwd": [_P, _L, _I, _I, _I, _P, _P, _L, _P, _L, _P, _I, _I, _P],
     "pit_edge_supported": [_I, _I, _I, _I],
     "pit_decoder_weights": [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P],
     "pit_decoder_fwd": [_P, _P, _L, _L, _I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _L,
@@ -110,7 +118,7 @@ SIGNATURES = {
     "pit_debug_mfma_tile": [_P, _P, _P, _P],
 }
 
-ABI_VERSION = 18       # PIT_ABI_VERSION of include/pit_hip.h this binding was written against
+ABI_VERSION = 19       # PIT_ABI_VERSION of include/pit_hip.h this binding was written against
 
 _lib = None
 

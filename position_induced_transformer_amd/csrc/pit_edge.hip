@@ -80,6 +80,7 @@ struct SlabBuildArgs {
     int n_out, n_in, sdim, used, periodic; float period;
     const int *idx, *cnt; int cap, umax;
     float* m; unsigned short* slot; int* keys; int* nkeys; int* report;      // report[0] = max union, [1] = 1 if a list overflowed, [2] = max count
+    int er;                                                                  // rows per slab: 16 (the fused launches), 64 / 128 / 256 (pit_fold.hip)
 };
 
 __global__ __launch_bounds__(256) void slab_plan_kernel(SlabBuildArgs a) {
@@ -89,10 +90,11 @@ __global__ __launch_bounds__(256) void slab_plan_kernel(SlabBuildArgs a) {
     const int nwords = (a.n_in + 31) >> 5;
     for (int w = tid; w < nwords; w += 256) bm[w] = 0u;
     __syncthreads();
-    const int total = ER * a.cap;
+    const int er = a.er;
+    const int total = er * a.cap;
     for (int e = tid; e < total; e += 256) {
         const int r = e / a.cap, i = e - r * a.cap;
-        const int row = slab * ER + r;
+        const int row = slab * er + r;
         float mv = 0.0f;
         if (row < a.n_out) {
             const int c = a.cnt[row];
@@ -107,7 +109,7 @@ __global__ __launch_bounds__(256) void slab_plan_kernel(SlabBuildArgs a) {
                 atomicOr(&bm[j >> 5], 1u << (j & 31));
             }
         }
-        a.m[(long)(slab * ER + r) * a.cap + i] = mv;
+        a.m[(long)(slab * er + r) * a.cap + i] = mv;
     }
     __syncthreads();
     if (tid == 0) {
@@ -132,13 +134,13 @@ __global__ __launch_bounds__(256) void slab_plan_kernel(SlabBuildArgs a) {
     for (int s = nk + tid; s < a.umax; s += 256) a.keys[(long)slab * a.umax + s] = 0;      // padding: a valid key, weight 0
     for (int e = tid; e < total; e += 256) {
         const int r = e / a.cap, i = e - r * a.cap;
-        const int row = slab * ER + r;
+        const int row = slab * er + r;
         int s = 0;
         if (row < a.n_out && i < min(a.cnt[row], a.cap)) {
             const int j = a.idx[(long)row * a.cap + i];
             s = pref[j >> 5] + __popc(bm[j >> 5] & ((1u << (j & 31)) - 1u));
         }
-        a.slot[(long)(slab * ER + r) * a.cap + i] = (unsigned short)min(s, 65535);
+        a.slot[(long)(slab * er + r) * a.cap + i] = (unsigned short)min(s, 65535);
     }
 }
 
@@ -160,6 +162,7 @@ struct DecWArgs {
     const float* head; int head_is_scale, n_head, um, lpr;
     float *pw, *qw, *scale_out;
     const float* w1; float* w1f; int dim;     // optional: the decoder MLP's W1 (dim, n_head*dim) copied in MFMA-fragment order
+    int rb;                                   // rows per slab of the plan (16; pit_fold.hip: 64 / 128 / 256): a workgroup still forms 16 rows
 };
 __device__ __forceinline__ float seg_sum_rt(float v, int lpr) {
     v += dpp_f<0xB1, 0xf>(v);
@@ -170,7 +173,8 @@ __device__ __forceinline__ float seg_sum_rt(float v, int lpr) {
     if (lpr >= 64) v += __shfl_xor(v, 32, 64);
     return v;
 }
-// 256 threads; `tile`: 2 * 2 * 16 * PIT_SLAB_UNION_MAX floats of LDS
+// 256 threads; `tile`: 2 * 2 * 16 * PIT_SLAB_UNION_MAX floats of LDS.  `slab` counts 16-row groups: group c of the plan's slab
+// blk = slab / (rb / 16) (rb = 16: the slab itself); head h's rows of it go to pw + ((blk * H + h) * rb + 16 c) * um.
 __device__ __forceinline__ void dec_weights_body(const DecWArgs& g, int slab, float* tile) {
     const pit_slab_plan& p = g.p;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -209,11 +213,14 @@ __device__ __forceinline__ void dec_weights_body(const DecWArgs& g, int slab, fl
         }
     }
     __syncthreads();
-    float* pdst = g.pw + (long)slab * per;
-    for (int e = 4 * tid; e < per; e += 4 * 256) *reinterpret_cast<float4*>(pdst + e) = *reinterpret_cast<const float4*>(tile + e);
-    if (g.qw) {
-        float* qdst = g.qw + (long)slab * per;
-        for (int e = 4 * tid; e < per; e += 4 * 256) *reinterpret_cast<float4*>(qdst + e) = *reinterpret_cast<const float4*>(tile + per + e);
+    {
+        const int gpb = g.rb / ER, blk = slab / gpb, cg = slab - blk * gpb, perh = ER * um;
+        for (int e = 4 * tid; e < per; e += 4 * 256) {
+            const int h = e / perh, r = e - h * perh;
+            const long o = ((long)(blk * H + h) * g.rb + cg * ER) * um + r;
+            *reinterpret_cast<float4*>(g.pw + o) = *reinterpret_cast<const float4*>(tile + e);
+            if (g.qw) *reinterpret_cast<float4*>(g.qw + o) = *reinterpret_cast<const float4*>(tile + per + e);
+        }
     }
     if (slab == 0 && tid < H && g.scale_out) g.scale_out[tid] = c[tid];
     // W1 of the decoder MLP in the order decoder_fwd_kernel's lanes consume it: 16-byte piece o = (wave * KS + s) * 64 + lane holds
@@ -222,7 +229,7 @@ __device__ __forceinline__ void dec_weights_body(const DecWArgs& g, int slab, fl
     // decoder_fwd 13.5 -> 11.5 us at Darcy b=8, 188 -> 170 us at b=256.  Once per step, here, because W1 changes once per step.
     if (g.w1f) {
         const int K0 = H * g.dim, KS = K0 / 16, n4 = g.dim * K0 / 4;
-        for (int o = slab * 256 + tid; o < n4; o += p.n_slabs * 256) {
+        for (int o = slab * 256 + tid; o < n4; o += p.n_slabs * (g.rb / ER) * 256) {
             const int ln = o & 63, s_ = (o >> 6) % KS, w = (o >> 6) / KS;
             reinterpret_cast<float4*>(g.w1f)[o] =
                 *reinterpret_cast<const float4*>(g.w1 + (long)(16 * w + (ln & 15)) * K0 + 16 * s_ + 4 * (ln >> 4));
@@ -1201,6 +1208,7 @@ __global__ __launch_bounds__(256) void union_att_bwd_kernel(UAttArgs g) {
 // ------------------------------------------------------------------------------------------------ host side
 bool plan_ok(const pit_slab_plan* p, bool needs_union) {
     if (!p || !p->stats || !p->idx || !p->cnt || !p->m) return false;
+    if (p->rows != ER) return false;                 // (plans of taller slabs belong to pit_fold.hip)
     if (p->n_out <= 0 || p->n_in <= 0 || p->cap <= 0 || p->cap > 64 || p->n_slabs != (p->n_out + ER - 1) / ER) return false;
     if (needs_union && (!p->slot || !p->keys || !p->nkeys || p->umax != EU)) return false;
     return true;
@@ -1226,18 +1234,19 @@ extern "C" int pit_edge_supported(int n_head, int dim, int batch, int rows_per_s
 }
 
 extern "C" int pit_slab_plan_build(const float* mesh_out, const float* mesh_in, int n_out, int n_in, int space_dim, int metric,
-                                   float period, const int* nbr_idx, const int* nbr_cnt, int cap, float* m, unsigned short* slot,
-                                   int* keys, int* nkeys, int* report, void* stream) {
+                                   float period, const int* nbr_idx, const int* nbr_cnt, int cap, int rows_per_slab, float* m,
+                                   unsigned short* slot, int* keys, int* nkeys, int* report, void* stream) {
     if (!mesh_out || !mesh_in || !nbr_idx || !nbr_cnt || !m || !slot || !keys || !nkeys || !report) return PIT_ERR_NULL;
     if (n_out <= 0 || n_in <= 0 || n_in > 16384 || space_dim < 1 || space_dim > 3 || cap <= 0) return PIT_ERR_SIZE;
+    if (rows_per_slab != 16 && rows_per_slab != 64 && rows_per_slab != 128 && rows_per_slab != 256) return PIT_ERR_SIZE;
     if (metric < PIT_METRIC_EUCLID || metric > PIT_METRIC_PERIODIC2D) return PIT_ERR_METRIC;
     SlabBuildArgs a;
     a.mesh_out = mesh_out; a.mesh_in = mesh_in; a.n_out = n_out; a.n_in = n_in; a.sdim = space_dim;
     a.used = (metric == PIT_METRIC_PERIODIC1D) ? 1 : space_dim;
     a.periodic = metric != PIT_METRIC_EUCLID; a.period = period;
     a.idx = nbr_idx; a.cnt = nbr_cnt; a.cap = cap; a.umax = EU;
-    a.m = m; a.slot = slot; a.keys = keys; a.nkeys = nkeys; a.report = report;
-    hipLaunchKernelGGL(slab_plan_kernel, dim3((unsigned)((n_out + ER - 1) / ER)), dim3(256), 0, (hipStream_t)stream, a);
+    a.m = m; a.slot = slot; a.keys = keys; a.nkeys = nkeys; a.report = report; a.er = rows_per_slab;
+    hipLaunchKernelGGL(slab_plan_kernel, dim3((unsigned)((n_out + rows_per_slab - 1) / rows_per_slab)), dim3(256), 0, (hipStream_t)stream, a);
     PIT_CHECK_LAUNCH();
     return 0;
 }
@@ -1257,7 +1266,7 @@ int fill_dec_weights(DecWArgs& g, const pit_slab_plan* plan, const float* head, 
     if (!plan_ok(plan, true) || !head || !pw) return PIT_ERR_NULL;
     if ((w1 == nullptr) != (w1f == nullptr)) return PIT_ERR_NULL;
     if (w1f && (dim < 16 || dim % 16 != 0 || !aligned16(w1) || !aligned16(w1f))) return PIT_ERR_SIZE;
-    g.w1 = w1; g.w1f = w1f; g.dim = dim;
+    g.w1 = w1; g.w1f = w1f; g.dim = dim; g.rb = ER;
     if ((n_head != 1 && n_head != 2) || max_union < 1 || max_union > EU || max_count < 1 || max_count > 64) return PIT_ERR_UNSUPPORTED;
     if (!aligned16(pw) || (qw && !aligned16(qw))) return PIT_ERR_SIZE;
     g.p = *plan; g.head = head; g.head_is_scale = head_is_scale; g.n_head = n_head; g.um = union_slots(max_union);
@@ -1273,6 +1282,25 @@ extern "C" int pit_decoder_weights(const pit_slab_plan* plan, const float* head,
     DecWArgs g;
     if (int rc = fill_dec_weights(g, plan, head, head_is_scale, n_head, max_union, max_count, pw, qw, scale_out, w1, w1f, dim)) return rc;
     hipLaunchKernelGGL(decoder_weights_kernel, dim3((unsigned)plan->n_slabs), dim3(256), 0, (hipStream_t)stream, g);
+    PIT_CHECK_LAUNCH();
+    return 0;
+}
+
+// The same weights for a plan whose slabs are 64 / 128 / 256 rows tall (pit_fold.hip): a workgroup still forms 16 rows; head h's
+// rows of slab s are the `rows` x um block at pw + (s * n_head + h) * rows * um.
+extern "C" int pit_fold_weights(const pit_slab_plan* plan, const float* head, int head_is_scale, int n_head, int max_union,
+                                int max_count, float* pw, float* qw, float* scale_out, void* stream) {
+    if (!plan || !plan->stats || !plan->idx || !plan->cnt || !plan->m || !plan->slot || !plan->keys || !plan->nkeys || !head || !pw)
+        return PIT_ERR_NULL;
+    if ((plan->rows != 64 && plan->rows != 128 && plan->rows != 256) || plan->umax != EU || plan->cap <= 0 || plan->cap > 64 ||
+        plan->n_slabs != (plan->n_out + plan->rows - 1) / plan->rows) return PIT_ERR_SIZE;
+    if ((n_head != 1 && n_head != 2) || max_union < 1 || max_union > EU || max_count < 1 || max_count > 64) return PIT_ERR_UNSUPPORTED;
+    if (!aligned16(pw) || (qw && !aligned16(qw))) return PIT_ERR_SIZE;
+    DecWArgs g = DecWArgs();
+    g.p = *plan; g.head = head; g.head_is_scale = head_is_scale; g.n_head = n_head; g.um = union_slots(max_union);
+    g.lpr = max_count <= 16 ? 16 : (max_count <= 32 ? 32 : 64);
+    g.pw = pw; g.qw = qw; g.scale_out = scale_out; g.rb = plan->rows;
+    hipLaunchKernelGGL(decoder_weights_kernel, dim3((unsigned)(plan->n_slabs * (plan->rows / ER))), dim3(256), 0, (hipStream_t)stream, g);
     PIT_CHECK_LAUNCH();
     return 0;
 }

@@ -1792,6 +1792,56 @@ extern "C" int pit_mlp_bwd_data(int rows, int n0, int n1, int n2, const float* w
     return 0;
 }
 
+// y = x W^T (no bias): the fold of the decoder MLP's first layer into the up-projection's values (pit_fold.hip), and its
+// backward d_x = d_y W, d_w (+)= d_y^T x - the GEMMs of pit_mlp_fwd / _bwd without an activation between them.
+extern "C" int pit_linear_fwd(const float* x, long ldx, int rows, int n_in, int n_out, const float* w, const float* zero_bias,
+                              float* y, long ldy, int math_mode, void* stream) {
+    PIT_ENTER_MATH(math_mode);
+    if (math_mode & ~0xff) return PIT_ERR_UNSUPPORTED;
+    if (!x || !w || !zero_bias || !y) return PIT_ERR_NULL;
+    if (rows <= 0 || n_in <= 0 || n_out <= 0 || ldx < n_in || ldy < n_out) return PIT_ERR_SIZE;
+    GemmArgs g = blank();
+    g.A = x; g.a_rs = ldx; g.a_cs = 1;
+    g.B = w; g.b_rs = 1; g.b_cs = n_in;            // B(k,n) = w[n][k]
+    g.M = rows; g.N = n_out; g.K = n_in;
+    g.bias = zero_bias; g.C = y; g.ldc = ldy; g.epi = EPI_BIAS;
+    if (int rc = launch_gemm(g, (hipStream_t)stream)) return rc;
+    PIT_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pit_linear_bwd(const float* x, long ldx, int rows, int n_in, int n_out, const float* w, const float* d_y, long ld_dy,
+                              float* d_x, long ld_dx, float* d_w, int accumulate, int math_mode, void* stream) {
+    PIT_ENTER_MATH(math_mode);
+    if (math_mode & ~0xff) return PIT_ERR_UNSUPPORTED;
+    if (!w || !d_y || (!d_x && !d_w) || (d_w && !x)) return PIT_ERR_NULL;
+    if (rows <= 0 || n_in <= 0 || n_out <= 0 || ld_dy < n_out || (d_x && ld_dx < n_in) || (d_w && ldx < n_in)) return PIT_ERR_SIZE;
+    hipStream_t s = (hipStream_t)stream;
+    if (d_x) {
+        GemmArgs g = blank();
+        g.A = d_y; g.a_rs = ld_dy; g.a_cs = 1;
+        g.B = w; g.b_rs = n_in; g.b_cs = 1;        // B(k,n) = w[k][n]
+        g.M = rows; g.N = n_in; g.K = n_out;
+        g.C = d_x; g.ldc = ld_dx; g.epi = EPI_STORE;
+        if (int rc = launch_gemm(g, s)) return rc;
+        PIT_CHECK_LAUNCH();
+    }
+    if (d_w) {
+        if (!accumulate) {
+            hipError_t e = hipMemsetAsync(d_w, 0, sizeof(float) * (size_t)n_out * n_in, s);
+            if (e != hipSuccess) return (int)e;
+        }
+        GemmArgs g = blank();
+        g.A = d_y; g.a_rs = 1; g.a_cs = ld_dy;     // A(m,k) = d_y[k][m]
+        g.B = x; g.b_rs = ldx; g.b_cs = 1;
+        g.M = n_out; g.N = n_in; g.K = rows;
+        g.C = d_w; g.ldc = n_in; g.atomic = 1; g.epi = EPI_ATOMIC;
+        if (int rc = launch_gemm(g, s)) return rc;
+        PIT_CHECK_LAUNCH();
+    }
+    return 0;
+}
+
 #ifdef PIT_STAMPS
 extern "C" int pit_mlp_debug_read_stamps(unsigned long long* host64) {
     return (int)hipMemcpyFromSymbol(host64, HIP_SYMBOL(pit_mlp_stamps), 64 * sizeof(unsigned long long));

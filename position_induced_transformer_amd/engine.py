@@ -57,7 +57,7 @@ class TrainStep:
                     self.buckets = 2
                     self._tail_params = list(tail)
                     self._early_block = len(model.mlp) // 2      # after this block's backward its bucket is complete
-                    self._side = torch.cuda.Stream(device=self.func_in.device)
+                    self._side = None                            # second stream of the early exchange: created at its first use
 
                     def mark(module, inputs, output):      # (a plain function: it carries the marker attribute)
                         return self._mark_early_point(module, inputs, output)
@@ -68,11 +68,12 @@ class TrainStep:
         self.flat = flat if flat is not None else FlatGradients(model.parameters())
         self._early_pending = False
         self._early_ok = False
-        self._early_decision = None          # two buckets or one exchange: decided ONCE, by all ranks together (_decide_early)
+        self._early_decision = None          # two buckets or one exchange: decided ONCE, by all ranks together (_agree_early)
         self.loss = torch.zeros((), device=self.func_in.device)
         self.out = None
         self._seed = torch.ones((), device=self.func_in.device)      # d loss / d loss, allocated once
         self.graph: Optional[torch.cuda.CUDAGraph] = None
+        self._agree_early()                  # (a collective when the process group has more than one rank: every rank builds its step)
 
     # two-bucket exchange: when the gradient of the marker module's output arrives, everything after it in the forward
     # has been back-propagated (launches enqueued) - fork the second stream there and reduce the early bucket on it
@@ -83,25 +84,36 @@ class TrainStep:
         early all-reduce was issued, and the ranks would silently diverge."""
         return all(ops._grad_slot(p) is not None for p in self._tail_params)
 
+    def _agree_early(self) -> None:
+        """Two-bucket exchange or one all-reduce after the pass: the SHAPE of the collective sequence.  Decided ONCE, when the
+        step object is built, by all ranks together: EVERY rank of a data-parallel step enters the MIN all-reduce below,
+        whatever its own bucket count - a rank that ended with one bucket (no marker module, a caller-supplied ``flat`` without
+        the tail layout, a hook on a tail parameter, a dropped .grad, another FUSED_GRAD_ACCUMULATION setting) contributes 0
+        and every rank then issues ONE all-reduce per step.  (Round 5 ran the agreement lazily in the first ``_step`` and only
+        on ranks with two buckets: a rank with one skipped the collective its peers blocked in, and ``capture(warmup=0)`` put
+        a collective and a host sync inside the stream capture - ADVICE r5.)"""
+        local = bool(self.buckets == 2 and self._tail_in_place())
+        agreed = local
+        if self.all_reduce:
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+                flag = torch.tensor([1 if local else 0], device=self.func_in.device if dist.get_backend() != "gloo" else "cpu",
+                                    dtype=torch.int32)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                agreed = bool(int(flag.item()))
+        else:
+            agreed = False                   # (no exchange at all: nothing to split)
+        self._early_decision = agreed
+
     def _decide_early(self) -> bool:
-        """Two-bucket exchange or one all-reduce after the pass: the SHAPE of the collective sequence.  Decided once per step
-        object - at its first step, before any capture - and by all ranks together (MIN over the group of "every tail gradient
-        is written in place here"): a rank with a hook on a tail parameter, a dropped .grad or another
-        FUSED_GRAD_ACCUMULATION setting would otherwise issue collectives of other counts and sizes than its peers - a hang the
-        watchdog is the only witness of.  If the local condition changes afterwards the step raises instead of
-        silently switching shape (a captured graph has the shape it was captured with baked in)."""
-        local = bool(self.buckets == 2 and self.all_reduce and self._tail_in_place())
+        """The agreed shape (``_agree_early``); raises if the local condition it rested on stopped holding - a captured graph has
+        the shape it was captured with baked in, and the other ranks keep theirs."""
         if self._early_decision is None:
-            agreed = local
-            if self.buckets == 2 and self.all_reduce:
-                import torch.distributed as dist
-                if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-                    flag = torch.tensor([1 if local else 0], device=self.func_in.device if dist.get_backend() != "gloo" else "cpu",
-                                        dtype=torch.int32)
-                    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-                    agreed = bool(int(flag.item()))
-            self._early_decision = agreed
-        elif self._early_decision and not local:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("TrainStep: the collective sequence was never agreed on (the step object was not built by "
+                                   "__init__?) - refusing to run a collective and a host sync inside a stream capture")
+            self._agree_early()
+        if self._early_decision and not (self.buckets == 2 and self.all_reduce and self._tail_in_place()):
             raise RuntimeError("two-bucket data-parallel step: a gradient of the early bucket is no longer written in place (a hook "
                                "on the parameter, a dropped / replaced .grad, in-place accumulation switched off) - the ranks "
                                "agreed on the two-bucket exchange when the step was built; rebuild the TrainStep")
@@ -115,6 +127,8 @@ class TrainStep:
         if not self._early_pending:
             self._early_pending = True
             cur = torch.cuda.current_stream()
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=self.func_in.device)
             self._side.wait_stream(cur)
             with torch.cuda.stream(self._side):
                 self.flat.all_reduce(part="tail")

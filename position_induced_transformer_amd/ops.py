@@ -371,6 +371,7 @@ def mesh_period(metric: str, mesh_in: torch.Tensor) -> float:
 
 
 SLAB_UNION_MAX = 64                                          # PIT_SLAB_UNION_MAX
+FOLD_SLAB_ROWS = (256, 128, 64)                              # slab heights MeshPlan.fold_plan tries, tallest first
 PLAN_FLAGS = 0                                               # pit_plan_fwd's `flags` (tests: 1 = PIT_PLAN_WAVE_PER_ROW, 2 = PIT_PLAN_TWO_PASSES)
 UNION_TILES = os.environ.get("PIT_UNION_TILES", "auto")      # "auto" (probe per kind of plan), "0", "1"
 UNION_DV = os.environ.get("PIT_UNION_DV", "auto")            # d(values) of union-tile layers: "auto", "lists" (transposed lists)
@@ -385,7 +386,7 @@ class MeshPlan:
 
     __slots__ = ("mesh_out", "mesh_in", "mesh_batch", "n_out", "n_in", "sdim", "metric", "metric_id", "period",
                  "rank_k", "rank_w", "masked", "self_attn", "stats", "nbr_idx", "nbr_cnt", "nbr_cap", "rev_ptr",
-                 "rev_row", "_complete", "_union", "_slab")
+                 "rev_row", "_complete", "_union", "_slab", "_fold")
 
     def __init__(self, metric: str, mesh_out: torch.Tensor, mesh_in: torch.Tensor, locality: float,
                  self_attn: bool, period: Optional[float] = None):
@@ -419,6 +420,7 @@ class MeshPlan:
         self._complete = None
         self._union = None
         self._slab = None
+        self._fold = None
         cap = 0
         if self.masked and SPARSE_MASKED:
             want = self.rank_k + 2
@@ -515,26 +517,58 @@ class MeshPlan:
         if torch.cuda.is_current_stream_capturing():
             return None
         dev = self.mesh_out.device
-        n_slabs = (self.n_out + 15) // 16
-        m = torch.empty((n_slabs * 16, self.nbr_cap), device=dev, dtype=torch.float32)
-        slot = torch.empty((n_slabs * 16, self.nbr_cap), device=dev, dtype=torch.int16)
+        built = self._build_slab_plan(16)
+        if built is None:
+            self._slab = False
+            return None
+        self._slab = built
+        return self._slab
+
+    def _build_slab_plan(self, rows: int):
+        """pit_slab_plan_build for slabs of `rows` rows: (struct, largest union, keep-alive tensors, longest list) or None when a
+        candidate list overflowed its capacity (one host read of three ints)."""
+        dev = self.mesh_out.device
+        n_slabs = (self.n_out + rows - 1) // rows
+        m = torch.empty((n_slabs * rows, self.nbr_cap), device=dev, dtype=torch.float32)
+        slot = torch.empty((n_slabs * rows, self.nbr_cap), device=dev, dtype=torch.int16)
         keys = torch.empty((n_slabs, SLAB_UNION_MAX), device=dev, dtype=torch.int32)
         nkeys = torch.empty((n_slabs,), device=dev, dtype=torch.int32)
         report = torch.zeros((3,), device=dev, dtype=torch.int32)
         rc = _lib.lib().pit_slab_plan_build(self.mesh_out.data_ptr(), self.mesh_in.data_ptr(), self.n_out, self.n_in, self.sdim,
                                             self.metric_id, self.period, self.nbr_idx.data_ptr(), self.nbr_cnt.data_ptr(),
-                                            self.nbr_cap, m.data_ptr(), slot.data_ptr(), keys.data_ptr(), nkeys.data_ptr(),
+                                            self.nbr_cap, rows, m.data_ptr(), slot.data_ptr(), keys.data_ptr(), nkeys.data_ptr(),
                                             report.data_ptr(), _lib.stream_ptr())
         _lib.check(rc, "pit_slab_plan_build")
         max_union, overflowed, max_count = report.tolist()
         if overflowed:
-            self._slab = False
             return None
         sp = _lib.SlabPlan(self.n_out, self.n_in, self.nbr_cap, n_slabs, SLAB_UNION_MAX, self.stats.data_ptr(), self.rank_w,
                            self.nbr_idx.data_ptr(), self.nbr_cnt.data_ptr(), m.data_ptr(), slot.data_ptr(), keys.data_ptr(),
-                           nkeys.data_ptr())
-        self._slab = (sp, int(max_union), (m, slot, keys, nkeys), max(1, int(max_count)))
-        return self._slab
+                           nkeys.data_ptr(), rows)
+        return (sp, int(max_union), (m, slot, keys, nkeys), max(1, int(max_count)))
+
+    def fold_plan(self):
+        """Round 6: the slab plan of the folded decoder (csrc/pit_fold.hip) - the TALLEST slabs (256, 128, 64 rows) whose candidate
+        keys' union still fits a tile (64 keys): the taller, the fewer adds d(values) costs.  None: per-sample meshes, no lists,
+        an overflowed list, or unions beyond 64 keys even at 64 rows (incoherently ordered meshes).  Built once, never under
+        stream capture."""
+        if self._fold is not None:
+            return self._fold or None
+        if self.nbr_idx is None or self.mesh_batch != 1 or not self.masked or self.n_in > 16384 or self.nbr_cap > 64 \
+                or self.n_out < 64:
+            self._fold = False
+            return None
+        if torch.cuda.is_current_stream_capturing():
+            return None
+        for rows in FOLD_SLAB_ROWS:
+            built = self._build_slab_plan(rows)
+            if built is None:
+                break
+            if built[1] <= SLAB_UNION_MAX:
+                self._fold = built
+                return built
+        self._fold = False
+        return None
 
     def lists_complete(self) -> int:
         """1 if no row's candidate list overflowed its capacity (checked once, for batch-free meshes
@@ -1654,6 +1688,240 @@ def decoder_apply(values: torch.Tensor, lmda: torch.Tensor, plan: MeshPlan, n_he
         else:
             _STEP.loss_issued = loss
     return _Decoder.apply(values, lmda.reshape(-1), plan, n_head, head_is_scale, param, weights, tuple(mlp), loss, *mlp)
+
+
+# ------------------------------------------------------------------------------------------------ folded decoder (round 6)
+# pit.decoder = de(up(values)) with de.mlp1 folded into the values (csrc/pit_fold.hip):
+#     vw = values @ W'^T  (W' = W1's memory as an (H*hid, hid) matrix: head-interleaved columns)      _Linear, n_in rows
+#     z  = sum_h P_h vw_h                                                                              _FoldAtt (batch-free meshes)
+#          or posatt_cross on vw for one head (any mesh kind: the candidate-list / union-tile kernels)  _PosAtt
+#     y  = gelu(z + b1) @ W2^T + b2                                                                     _ThinTail
+# The (batch, n_out, H*hid) tensor of pit.py:125 and the three GEMMs on its rows are gone; nothing of size n_out x hid is saved
+# except z itself.  PIT_FOLD_DECODER=0: the round-5 path (attention output materialised, kaiming_mlp kernels).
+FOLD_DECODER = os.environ.get("PIT_FOLD_DECODER", "1") != "0"
+_ZERO_BIAS = {}
+
+
+def _zero_bias(n: int, device) -> torch.Tensor:
+    key = (device.index, n)
+    z = _ZERO_BIAS.get(key)
+    if z is None:
+        z = _ZERO_BIAS[key] = torch.zeros((n,), device=device, dtype=torch.float32)
+        _pin(z)
+    return z
+
+
+def _rows2d(t: torch.Tensor) -> torch.Tensor:
+    """(b, L, D) tensor whose (b*L) rows are uniformly strided with unit channel stride (copy only if they are not)."""
+    t = _row_view(t)
+    if t.stride(0) != t.shape[1] * t.stride(1) or t.stride(1) % 4 or t.data_ptr() % 16:
+        t = t.contiguous()
+    return t
+
+
+class _Linear(torch.autograd.Function):
+    """y = x @ W'^T without bias, W' = ``w``'s memory read as a (w.numel() / d, d) row-major matrix (d = x's width): for the fold,
+    ``w`` is de.mlp1.weight (hid, H*hid) and W' its (H*hid, hid) view - row n*H + h of W' is W1[n, h*hid:(h+1)*hid]."""
+
+    @staticmethod
+    def forward(ctx, x, w, w_param):
+        _need_gpu(x, w)
+        x = _rows2d(x)
+        b, j, d = x.shape
+        wc = w.detach()
+        if not wc.is_contiguous() or wc.data_ptr() % 16:
+            wc = wc.contiguous()
+        n_out = wc.numel() // d
+        y = torch.empty((b, j, n_out), device=x.device, dtype=torch.float32)
+        ctx.math = _math_code()
+        rc = _lib.lib().pit_linear_fwd(x.data_ptr(), x.stride(1), b * j, d, n_out, wc.data_ptr(), _zero_bias(n_out, x.device).data_ptr(),
+                                       y.data_ptr(), n_out, ctx.math, _lib.stream_ptr())
+        _lib.check(rc, "pit_linear_fwd")
+        ctx.w_param = w_param
+        ctx.save_for_backward(x, wc)
+        return y
+
+    @staticmethod
+    def backward(ctx, d_y):
+        x, wc = ctx.saved_tensors
+        b, j, d = x.shape
+        n_out = wc.numel() // d
+        d_y = d_y.contiguous()
+        need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        d_x = torch.empty((b, j, d), device=x.device, dtype=torch.float32) if need_x else None
+        slot = _grad_slot(ctx.w_param) if (need_w and ctx.w_param is not None and ctx.w_param.data_ptr() == wc.data_ptr()) else None
+        d_w = slot if slot is not None else (torch.empty_like(wc) if need_w else None)
+        rc = _lib.lib().pit_linear_bwd(x.data_ptr(), x.stride(1), b * j, d, n_out, wc.data_ptr(), d_y.data_ptr(), n_out,
+                                       _lib.ptr(d_x), d, _lib.ptr(d_w), 1 if slot is not None else 0, ctx.math, _lib.stream_ptr())
+        _lib.check(rc, "pit_linear_bwd")
+        return d_x, (None if slot is not None else d_w), None
+
+
+class FoldWeights:
+    """The softmax weights of one step on a fold plan (pit_fold_weights): pw / qw (n_slabs*H, rows, um), the head scales c."""
+    __slots__ = ("pw", "qw", "scale", "keep")
+
+
+def _new_fold_weights(plan: MeshPlan, head, scale_in, n_head: int, head_is_scale: bool, need_q: bool) -> FoldWeights:
+    sp, max_union, _t, max_count = plan.fold_plan()
+    um = 32 if max_union <= 32 else (48 if max_union <= 48 else 64)
+    dev = plan.mesh_out.device
+    w = FoldWeights()
+    w.pw = torch.empty((sp.n_slabs * n_head, sp.rows, um), device=dev, dtype=torch.float32)
+    w.qw = torch.empty((sp.n_slabs * n_head, sp.rows, um), device=dev, dtype=torch.float32) if need_q else None
+    w.scale = torch.empty((n_head,), device=dev, dtype=torch.float32)
+    k_head = scale_in if scale_in is not None else head
+    w.keep = (k_head, plan, sp)
+    rc = _lib.lib().pit_fold_weights(ctypes.byref(sp), k_head.data_ptr(), 1 if (scale_in is not None or head_is_scale) else 0, n_head,
+                                     max_union, max_count, w.pw.data_ptr(), _lib.ptr(w.qw), w.scale.data_ptr(), _lib.stream_ptr())
+    _lib.check(rc, "pit_fold_weights")
+    return w
+
+
+def fold_att_supported(plan: MeshPlan, n_head: int, dim: int, batch: int) -> bool:
+    """The fold attention launches cover this layer: a masked cross attention on a batch-free mesh pair with complete candidate
+    lists whose unions fit a tile for slabs of at least 64 rows, 1-2 heads, a width that is a multiple of 64."""
+    if plan.mesh_batch != 1 or plan.self_attn or not plan.masked or plan.nbr_idx is None:
+        return False
+    if torch.are_deterministic_algorithms_enabled():         # (d(values): fp32 atomic adds)
+        return False
+    if not _lib.lib().pit_fold_supported(int(n_head), int(dim), int(batch), int(plan.n_out), int(plan.n_in)):
+        return False
+    return plan.fold_plan() is not None
+
+
+class _FoldAtt(torch.autograd.Function):
+    """z[b, n, c] = sum_h sum_j P_h[n, j] vw[b, j, c*H + h] on a batch-free mesh pair (pit_fold_att_fwd / _bwd)."""
+
+    @staticmethod
+    def forward(ctx, vw, head, plan: MeshPlan, n_head: int, head_is_scale: bool, head_param, scale_in, out_bf16: bool,
+                need_q: bool = True):
+        _need_gpu(vw, head)
+        vw = _rows2d(vw)
+        b, j, hd = vw.shape
+        d = hd // n_head
+        if j != plan.n_in:
+            raise RuntimeError(f"inputs have {j} points but mesh_in has {plan.n_in}")
+        head = head.detach().reshape(-1).contiguous()
+        ctx.math = _math_code()
+        out_bf16 = bool(out_bf16 and ctx.math == MATH_MODES["bf16"])
+        w = _new_fold_weights(plan, head, scale_in, n_head, head_is_scale, need_q)
+        sp, max_union = plan.fold_plan()[0], plan.fold_plan()[1]
+        z = torch.empty((b, plan.n_out, d), device=vw.device, dtype=torch.bfloat16 if out_bf16 else torch.float32)
+        rc = _lib.lib().pit_fold_att_fwd(ctypes.byref(sp), vw.data_ptr(), vw.stride(1), vw.stride(0), b, n_head, d, w.pw.data_ptr(),
+                                         z.data_ptr(), z.stride(1), z.stride(0), max_union,
+                                         ctx.math | (IO_OUT_BF16 if out_bf16 else 0), _lib.stream_ptr())
+        _lib.check(rc, "pit_fold_att_fwd")
+        ctx.plan, ctx.n_head, ctx.head_is_scale, ctx.head_param, ctx.w = plan, n_head, head_is_scale, head_param, w
+        ctx.save_for_backward(vw, head)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        vw, head = ctx.saved_tensors
+        plan, n_head, w = ctx.plan, ctx.n_head, ctx.w
+        b, j, hd = vw.shape
+        d = hd // n_head
+        dz = _row_view(dz)
+        _need_gpu_bf16_ok(dz)
+        io = IO_DOUT_BF16 if dz.dtype == torch.bfloat16 else 0
+        if dz.stride(1) % 4 or dz.stride(0) % 4 or dz.data_ptr() % 16:
+            dz = dz.contiguous()
+        need_v, need_h = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        if need_h and w.qw is None:
+            raise RuntimeError("fold attention: d(lmda) requested but the forward ran without grad mode")
+        d_vw = torch.zeros((b, j, hd), device=vw.device, dtype=torch.float32) if need_v else None
+        slot = _grad_slot(ctx.head_param) if need_h else None
+        defer = DEFER_HEAD_FINISH and slot is not None
+        work = None
+        if need_h:
+            work = _layer_workspace(slot, n_head) if defer else torch.zeros(n_head * 1024, device=vw.device, dtype=torch.float64)
+            if defer:
+                _defer_head_begin(work)
+        rider = _dw_take(vw.device)                  # (a postponed weight-gradient job: nothing here carries it - run it now)
+        if rider is not None:
+            _dw_run(rider)
+        sp, max_union = plan.fold_plan()[0], plan.fold_plan()[1]
+        qw = w.qw if w.qw is not None else w.pw       # (read only for d(scale))
+        rc = _lib.lib().pit_fold_att_bwd(ctypes.byref(sp), vw.data_ptr(), vw.stride(1), vw.stride(0), b, n_head, d, w.pw.data_ptr(),
+                                         qw.data_ptr(), dz.data_ptr(), dz.stride(1), dz.stride(0),
+                                         _lib.ptr(d_vw), hd, j * hd, _lib.ptr(work), max_union, ctx.math | io, _lib.stream_ptr())
+        _lib.check(rc, "pit_fold_att_bwd")
+        d_head = None
+        if need_h:
+            flags = 1 | (4 if ctx.head_is_scale else 0)
+            if defer:
+                _defer_head_finish(work, slot, head, w.scale, n_head, flags)
+            else:
+                d_head = slot if slot is not None else torch.empty((n_head,), device=vw.device, dtype=torch.float32)
+                _finish_heads_now(work, d_head, head, w.scale, n_head, flags if slot is not None else flags & ~1)
+                if slot is not None:
+                    d_head = None
+        return d_vw, d_head, None, None, None, None, None, None, None
+
+
+class _ThinTail(torch.autograd.Function):
+    """y = gelu(z + b1) @ W2^T + b2 for out_dim <= 4 (pit_thin_tail_fwd / _bwd): z fp32 or bf16, nothing but z is saved."""
+
+    @staticmethod
+    def forward(ctx, z, b1, w2, b2, params):
+        _need_gpu_bf16_ok(z)
+        _need_gpu(b1, w2, b2)
+        z = _row_view(z)
+        if z.stride(0) != z.shape[1] * z.stride(1) or z.stride(1) % 4 or z.data_ptr() % 16:
+            z = z.contiguous()
+        b, n, d = z.shape
+        n2 = w2.shape[0]
+        b1c, w2c, b2c = (t.detach().contiguous() for t in (b1, w2, b2))
+        y = torch.empty((b, n, n2), device=z.device, dtype=torch.float32)
+        rc = _lib.lib().pit_thin_tail_fwd(z.data_ptr(), z.stride(1), b * n, d, n2, b1c.data_ptr(), w2c.data_ptr(), b2c.data_ptr(),
+                                          y.data_ptr(), n2, 1 if z.dtype == torch.bfloat16 else 0, _lib.stream_ptr())
+        _lib.check(rc, "pit_thin_tail_fwd")
+        ctx.params = params
+        ctx.save_for_backward(z, b1c, w2c)
+        return y
+
+    @staticmethod
+    def backward(ctx, d_y):
+        z, b1c, w2c = ctx.saved_tensors
+        b, n, d = z.shape
+        n2 = w2c.shape[0]
+        d_y = d_y.reshape(b * n, n2)
+        if d_y.stride(1) != 1 or d_y.stride(0) < n2:
+            d_y = d_y.contiguous()
+        dz = torch.empty((b, n, d), device=z.device, dtype=z.dtype)
+        slots = [_grad_slot(q) if isinstance(q, torch.nn.Parameter) else None for q in ctx.params]
+        inplace = all(t is not None for t in slots) and all(ctx.needs_input_grad[1:4])
+        if inplace:
+            d_b1, d_w2, d_b2 = slots
+        else:
+            d_b1, d_w2, d_b2 = (torch.zeros_like(t) for t in (b1c, w2c, b1c[:n2]))
+        rc = _lib.lib().pit_thin_tail_bwd(z.data_ptr(), z.stride(1), b * n, d, n2, b1c.data_ptr(), w2c.data_ptr(), d_y.data_ptr(),
+                                          d_y.stride(0), dz.data_ptr(), d, d_b1.data_ptr(), d_w2.data_ptr(), d_b2.data_ptr(),
+                                          1 if z.dtype == torch.bfloat16 else 0, 1 if dz.dtype == torch.bfloat16 else 0,
+                                          _lib.stream_ptr())
+        _lib.check(rc, "pit_thin_tail_bwd")
+        if inplace:
+            return dz, None, None, None, None
+        return dz, d_b1, d_w2, d_b2, None
+
+
+@torch.compiler.disable
+def fold_decoder_apply(values: torch.Tensor, lmda: torch.Tensor, plan: MeshPlan, n_head: int, mlp, use_fold_att: bool) -> torch.Tensor:
+    """pit.decoder (pit.py:124-127) with de.mlp1 folded into the values (see the section comment); ``mlp`` = de's
+    (w1, b1, w2, b2).  ``use_fold_att``: the fold attention launches (batch-free meshes, fold_att_supported) - else one head on
+    the candidate-list / union-tile kernels of posatt_apply."""
+    w1, b1, w2, b2 = mlp
+    vw = _Linear.apply(values, w1, w1 if isinstance(w1, torch.nn.Parameter) else None)
+    bf16 = get_math_mode() == "bf16" and BF16_STORAGE
+    if use_fold_att:
+        param = lmda if isinstance(lmda, torch.nn.Parameter) else None
+        c = host_head_scale(lmda) if get_head_scale_route() == "host" else None
+        need_q = torch.is_grad_enabled() and lmda.requires_grad        # (Q = P (m - mbar): read by d(scale) only)
+        z = _FoldAtt.apply(vw, lmda.reshape(-1), plan, n_head, False, param, c, bf16, need_q)
+    else:
+        z = posatt_apply(vw, lmda, plan, n_head, concat=False, out_bf16=bf16)
+    return _ThinTail.apply(z, b1, w2, b2, (b1, w2, b2))
 
 
 class _Encoder(torch.autograd.Function):

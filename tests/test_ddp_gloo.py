@@ -199,3 +199,47 @@ def test_two_bucket_exchange_equals_one_allreduce(tmp_path):
     mp.spawn(_worker_buckets, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     (err,) = np.load(os.path.join(tmp_path, "err_buckets.npy"))
     assert err == 0.0, err
+
+
+def _worker_agree(rank, world, port, out_dir):
+    """engine.TrainStep agrees on the SHAPE of its collective sequence when it is built, and every rank of a data-parallel
+    step takes part whatever its own bucket count (a rank that ended with one bucket used to skip the MIN
+    all-reduce its peers blocked in)."""
+    for pth in (ROOT, HERE, os.path.join(ROOT, "oracle")):
+        sys.path.insert(0, pth)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ["PIT_IMPORT_SIDE_EFFECTS"] = "0"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    from position_induced_transformer_amd import ops
+    from position_induced_transformer_amd import pit as P
+    from position_induced_transformer_amd.engine import TrainStep
+    # (CPU stand-in for "the kernels write this gradient in place": the real predicate wants a device gradient view)
+    ops._grad_slot = lambda p: None if (p is None or p._backward_hooks) else p.grad
+
+    def build(buckets, hook_tail=False):
+        ltt = torch.rand(16, 2)
+        model = P.pit_fixed(2, 1, 1, 16, 2, 4, ltt, 0.1, 0.1)
+        if hook_tail:                                         # its gradient then comes from AccumulateGrad, not in place
+            model.de.mlp1.weight.register_hook(lambda g: g)
+        x = torch.zeros(2, 36, 1)
+        return TrainStep(model, (torch.rand(36, 2), x, torch.rand(36, 2), x.clone()), 1, 2, all_reduce=True, all_reduce_buckets=buckets)
+
+    got = []
+    got.append(build(2)._early_decision)                      # every rank: two buckets, all in place -> two buckets
+    got.append(build(2 if rank == 0 else 1)._early_decision)  # rank 1 has ONE bucket: both must fall back (and nobody hangs)
+    got.append(build(2, hook_tail=(rank == 1))._early_decision)   # rank 1's tail gradient is not written in place
+    st = build(1)
+    got.append(st._early_decision)
+    np.save(os.path.join(out_dir, f"agree_{rank}.npy"), np.asarray(got, dtype=np.int64))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_bucket_agreement_includes_every_rank(tmp_path):
+    port = _free_port()
+    mp.spawn(_worker_agree, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    for rank in (0, 1):
+        got = np.load(os.path.join(tmp_path, f"agree_{rank}.npy")).tolist()
+        assert got == [1, 0, 0, 0], (rank, got)

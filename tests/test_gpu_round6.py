@@ -1,0 +1,206 @@
+"""GPU: round 6 - the decoder side with de.mlp1 folded into the values (csrc/pit_fold.hip): the bias-free Linear on the latent
+points, the fold attention launches on tall slabs (fp32 and bf16 MFMA flavours), the thin tail, each against the oracle
+(pit.py:124-127: de(up(values)))."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import golden_io as gio
+import pit_oracle as orc
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).norm() / b.norm())
+
+
+# --------------------------------------------------------------------------- the pieces
+@pytest.mark.parametrize("rows_b,rows_j,d,heads", [(3, 256, 256, 2), (2, 100, 128, 1), (5, 64, 64, 2)])
+def test_linear_on_the_weights_own_memory_equals_the_per_head_products(rows_b, rows_j, d, heads):
+    """ops._Linear reads de.mlp1.weight (hid, H*hid) as an (H*hid, hid) matrix: column n*H + h of the result is
+    (V W1_h^T)[:, n] (pit.py:126 restricted to head h's columns); d_x and d_w against fp64."""
+    from position_induced_transformer_amd import ops
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(rows_b, rows_j, d, generator=g)
+    w1 = torch.randn(d, heads * d, generator=g) / d ** 0.5
+    dy = torch.randn(rows_b, rows_j, heads * d, generator=g)
+    x0, w0 = x.double().requires_grad_(True), w1.double().requires_grad_(True)
+    ref = torch.stack([x0 @ w0[:, h * d:(h + 1) * d].T for h in range(heads)], dim=-1).reshape(rows_b, rows_j, d * heads)
+    ref.backward(dy.double())
+    x1, w_ = x.cuda().requires_grad_(True), w1.cuda().requires_grad_(True)
+    y = ops._Linear.apply(x1, w_, None)
+    y.backward(dy.cuda())
+    torch.cuda.synchronize()
+    assert _rel(y, ref) <= 1e-6
+    assert _rel(x1.grad, x0.grad) <= 1e-6
+    assert _rel(w_.grad, w0.grad) <= 2e-6
+
+
+@pytest.mark.parametrize("rows,n1,n2,bf16", [(4096, 256, 1, False), (1234, 128, 4, False), (777, 64, 3, False), (4096, 256, 1, True)])
+def test_thin_tail_against_torch(rows, n1, n2, bf16):
+    """y = gelu(z + b1) W2^T + b2 (pit.py:21-26 after the first Linear) and its backward - dz, d_b1, d_w2, d_b2 - against fp64."""
+    from position_induced_transformer_amd import ops
+    g = torch.Generator().manual_seed(11)
+    z = torch.randn(2, rows // 2, n1, generator=g)
+    b1, w2, b2 = torch.randn(n1, generator=g), torch.randn(n2, n1, generator=g) / n1 ** 0.5, torch.randn(n2, generator=g)
+    dy = torch.randn(2, rows // 2, n2, generator=g)
+    zin = z.to(torch.bfloat16).float() if bf16 else z
+    t0 = [t.double().requires_grad_(True) for t in (zin, b1, w2, b2)]
+    ref = F.linear(F.gelu(t0[0] + t0[1]), t0[2], t0[3])
+    ref.backward(dy.double())
+    t1 = [t.cuda().requires_grad_(True) for t in (zin, b1, w2, b2)]
+    zz = t1[0].to(torch.bfloat16) if bf16 else t1[0]
+    y = ops._ThinTail.apply(zz, t1[1], t1[2], t1[3], (None, None, None))
+    y.backward(dy.cuda())
+    torch.cuda.synchronize()
+    assert _rel(y, ref) <= 1e-6
+    tol = 6e-3 if bf16 else 1e-5                  # (bf16: dz leaves as bf16)
+    assert _rel(t1[0].grad, t0[0].grad) <= tol
+    for got, want in zip(t1[1:], t0[1:]):
+        assert _rel(got.grad, want.grad) <= 1e-5, (got.shape, _rel(got.grad, want.grad))
+
+
+# --------------------------------------------------------------------------- the folded decoder against the oracle
+CASES = [
+    ("periodic2d", 64, 16, 256, 2, 2, 0.02, 1),          # Vorticity's decoder (train_vorticity.py:98-106): 256-row slabs, unions of 64
+    ("euclid", 43, 16, 128, 1, 3, 0.02, 3),              # 1849 rows: the mesh ends inside the last slab
+    ("euclid", 30, 12, 64, 2, 2, 0.05, 4),
+    ("euclid", 50, 10, 192, 2, 1, 0.03, 2),
+]
+
+
+def _decoder_case(metric, n_out_side, n_in_side, dim, heads, batch, loc, n2, seed=61):
+    per = metric != "euclid"
+    mo, mi = orc.grid_mesh_2d(n_out_side, not per).reshape(-1, 2), orc.grid_mesh_2d(n_in_side, not per).reshape(-1, 2)
+    g = torch.Generator().manual_seed(seed)
+    t = dict(values=torch.randn(batch, mi.shape[0], dim, generator=g), lmda=torch.rand(heads, 1, 1, generator=g),
+             w1=torch.randn(dim, heads * dim, generator=g) * (2.0 / (heads * dim)) ** 0.5, b1=0.1 * torch.randn(dim, generator=g),
+             w2=torch.randn(n2, dim, generator=g) * (2.0 / dim) ** 0.5, b2=0.1 * torch.randn(n2, generator=g))
+    d_y = torch.randn(batch, mo.shape[0], n2, generator=g)
+    return mo, mi, t, d_y
+
+
+def _oracle_decoder(metric, batched, mo, mi, t, loc, d_y):
+    p = {k: v.clone().requires_grad_(True) for k, v in t.items()}
+    ref = orc.mlp(orc.posatt_cross(metric, batched, mo, mi, p["values"], p["lmda"], loc), p["w1"], p["b1"], p["w2"], p["b2"])
+    ref.backward(d_y)
+    return ref, p
+
+
+@pytest.mark.parametrize("metric,n_out_side,n_in_side,dim,heads,batch,loc,n2", CASES)
+def test_folded_decoder_against_the_oracle(metric, n_out_side, n_in_side, dim, heads, batch, loc, n2):
+    """de(up(values)) (pit.py:124-127) with de.mlp1 folded into the values - pit_linear_fwd on the latent points, pit_fold_att_fwd /
+    _bwd on the tallest slabs whose unions fit, pit_thin_tail_* - against the oracle's posatt_cross + kaiming_mlp: prediction
+    <= 1e-6, d(values) and every weight gradient <= 1e-5, d(lmda) <= 1e-4 (fp32 math mode, exact head scales)."""
+    from position_induced_transformer_amd import ops
+    mo, mi, t, d_y = _decoder_case(metric, n_out_side, n_in_side, dim, heads, batch, loc, n2)
+    ref, p0 = _oracle_decoder(metric, False, mo, mi, t, loc, d_y)
+    plan = ops.MeshPlan(metric, mo.cuda(), mi.cuda(), loc, False)
+    assert ops.fold_att_supported(plan, heads, dim, batch), "no fold plan for this mesh pair"
+    fp = plan.fold_plan()
+    assert fp[0].rows in (64, 128, 256) and fp[1] <= 64
+    with ops.head_scale_route("host"):
+        p1 = {k: v.cuda().requires_grad_(True) for k, v in t.items()}
+        y = ops.fold_decoder_apply(p1["values"], p1["lmda"], plan, heads, (p1["w1"], p1["b1"], p1["w2"], p1["b2"]), True)
+        y.backward(d_y.cuda())
+    torch.cuda.synchronize()
+    assert _rel(y, ref) <= 1e-6
+    for k in ("values", "w1", "b1", "w2", "b2"):
+        assert _rel(p1[k].grad, p0[k].grad) <= 1e-5, (k, _rel(p1[k].grad, p0[k].grad))
+    assert float((p1["lmda"].grad.cpu().reshape(-1) - p0["lmda"].grad.reshape(-1)).norm()) <= 1e-4 * float(p0["lmda"].grad.norm())
+
+
+@pytest.mark.parametrize("metric,n_out_side,n_in_side,dim,heads,batch,loc,n2", CASES[:3])
+def test_folded_decoder_in_bf16_mode(metric, n_out_side, n_in_side, dim, heads, batch, loc, n2):
+    """The same in the bf16 math mode: tiles rounded to bf16 in LDS, v_mfma_f32_16x16x32_bf16 (the [k][n] images through
+    ds_read_b64_tr_b16), z / dz stored as bf16 - within the mode's tolerances against the fp32 oracle (tests/test_gpu_bf16.py)."""
+    from position_induced_transformer_amd import ops
+    mo, mi, t, d_y = _decoder_case(metric, n_out_side, n_in_side, dim, heads, batch, loc, n2)
+    ref, p0 = _oracle_decoder(metric, False, mo, mi, t, loc, d_y)
+    plan = ops.MeshPlan(metric, mo.cuda(), mi.cuda(), loc, False)
+    with ops.math_mode("bf16"), ops.head_scale_route("host"):
+        p1 = {k: v.cuda().requires_grad_(True) for k, v in t.items()}
+        y = ops.fold_decoder_apply(p1["values"], p1["lmda"], plan, heads, (p1["w1"], p1["b1"], p1["w2"], p1["b2"]), True)
+        y.backward(d_y.cuda())
+    torch.cuda.synchronize()
+    assert _rel(y, ref) <= 2e-2
+    for k in ("values", "w1", "b1", "w2", "b2"):
+        assert _rel(p1[k].grad, p0[k].grad) <= 5e-2, (k, _rel(p1[k].grad, p0[k].grad))
+    assert float((p1["lmda"].grad.cpu().reshape(-1) - p0["lmda"].grad.reshape(-1)).norm()) <= 5e-2 * float(p0["lmda"].grad.norm())
+
+
+@pytest.mark.parametrize("bf16", [False, True])
+def test_folded_decoder_on_per_sample_meshes_one_head(bf16):
+    """NACA's kind of decoder (train_naca.py:79-89: per-sample meshes, one head, hid 128, four output channels): the fold with the
+    attention on the candidate-list / union-tile kernels of posatt_apply."""
+    from position_induced_transformer_amd import ops
+    g = torch.Generator().manual_seed(3)
+    b, n_in, n_out, dim, n2, loc = 2, 160, 1500, 128, 4, 0.05
+    mi = torch.rand(b, n_in, 2, generator=g)
+    mo = torch.rand(b, n_out, 2, generator=g)
+    t = dict(values=torch.randn(b, n_in, dim, generator=g), lmda=torch.rand(1, 1, 1, generator=g),
+             w1=torch.randn(dim, dim, generator=g) * (2.0 / dim) ** 0.5, b1=0.1 * torch.randn(dim, generator=g),
+             w2=torch.randn(n2, dim, generator=g) * (2.0 / dim) ** 0.5, b2=0.1 * torch.randn(n2, generator=g))
+    d_y = torch.randn(b, n_out, n2, generator=g)
+    ref, p0 = _oracle_decoder("euclid", True, mo, mi, t, loc, d_y)
+    plan = ops.MeshPlan("euclid", mo.cuda(), mi.cuda(), loc, False)
+    ctxs = (ops.math_mode("bf16"), ops.head_scale_route("host")) if bf16 else (ops.head_scale_route("host"),)
+    from contextlib import ExitStack
+    with ExitStack() as st:
+        for c in ctxs:
+            st.enter_context(c)
+        p1 = {k: v.cuda().requires_grad_(True) for k, v in t.items()}
+        y = ops.fold_decoder_apply(p1["values"], p1["lmda"], plan, 1, (p1["w1"], p1["b1"], p1["w2"], p1["b2"]), False)
+        y.backward(d_y.cuda())
+    torch.cuda.synchronize()
+    to, tg, tl = (2e-2, 5e-2, 5e-2) if bf16 else (1e-6, 1e-5, 1e-4)
+    assert _rel(y, ref) <= to
+    for k in ("values", "w1", "b1", "w2", "b2"):
+        assert _rel(p1[k].grad, p0[k].grad) <= tg, (k, _rel(p1[k].grad, p0[k].grad))
+    assert float((p1["lmda"].grad.cpu().reshape(-1) - p0["lmda"].grad.reshape(-1)).norm()) <= tl * float(p0["lmda"].grad.norm())
+
+
+def test_fold_plan_picks_the_tallest_slabs_and_refuses_incoherent_meshes():
+    """MeshPlan.fold_plan: Vorticity's 64^2 <- 16^2 periodic pair takes 256-row slabs (unions of exactly 64 keys); a randomly
+    ordered cloud has unions beyond a tile even at 64 rows and keeps the per-layer path."""
+    from position_induced_transformer_amd import ops
+    mo, mi = orc.grid_mesh_2d(64, False).reshape(-1, 2), orc.grid_mesh_2d(16, False).reshape(-1, 2)
+    plan = ops.MeshPlan("periodic2d", mo.cuda(), mi.cuda(), 0.02, False)
+    sp, max_union, _keep, _mc = plan.fold_plan()
+    assert (sp.rows, sp.n_slabs, max_union) == (256, 16, 64)
+    g = torch.Generator().manual_seed(0)
+    cloud_o, cloud_i = torch.rand(4390, 2, generator=g), torch.rand(896, 2, generator=g)
+    plan2 = ops.MeshPlan("euclid", cloud_o.cuda(), cloud_i.cuda(), 0.01, False)
+    assert plan2.fold_plan() is None
+    assert not ops.fold_att_supported(plan2, 1, 256, 4)
+
+
+def test_models_take_the_folded_decoder_where_it_pays():
+    """pit.decoder dispatch: Vorticity (hid 256, two heads, shared meshes) and NACA (hid 128, one head, per-sample meshes) run the
+    folded decoder; Elasticity (as many output as latent points) and Darcy b=8 (the fused edge launches) do not."""
+    from position_induced_transformer_amd import ops, tasks
+    calls = []
+    orig = ops.fold_decoder_apply
+
+    def spy(*a, **k):
+        calls.append(a[5])
+        return orig(*a, **k)
+    ops.fold_decoder_apply = spy
+    try:
+        want = {"vorticity": [True], "naca": [False], "elasticity": [], "darcy": []}
+        for name, expect in want.items():
+            calls.clear()
+            model, sample, meta = tasks.make_task(name, seed=1)
+            batch = sample(2)
+            with torch.no_grad():
+                model(*batch[:3])
+            assert calls == expect, (name, calls)
+    finally:
+        ops.fold_decoder_apply = orig
+    torch.cuda.synchronize()

@@ -7,7 +7,7 @@ set -e
 R=$(cd "$(dirname "$0")/.." && pwd)
 C=$R/position_induced_transformer_amd/csrc
 mkdir -p $R/_diag
-OBJS=$(ls $C/_obj/*.o | grep -v pit_block.o)
+OBJS=$(python $R/tools/prod_objects.py pit_block)
 for v in "$@"; do
   /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -fPIC -std=c++17 -DPIT_BLOCK_EXP=$v -c $C/pit_block.hip -o $R/_diag/block_v$v.o
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -fPIC -shared -o $R/_diag/libpit_vb$v.so $OBJS $R/_diag/block_v$v.o

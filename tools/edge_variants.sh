@@ -8,7 +8,7 @@ set -e
 R=$(cd "$(dirname "$0")/.." && pwd)
 C=$R/position_induced_transformer_amd/csrc
 mkdir -p $R/_diag
-OBJS=$(ls $C/_obj/*.o | grep -v pit_edge.o | grep -v pit_latent.o)
+OBJS=$(python $R/tools/prod_objects.py pit_edge)
 for v in "$@"; do
   /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -fPIC -std=c++17 -DPIT_EDGE_DBG=$v -c $C/pit_edge.hip -o $R/_diag/edge_v$v.o
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -fPIC -shared -o $R/_diag/libpit_v$v.so $OBJS $R/_diag/edge_v$v.o
