@@ -399,14 +399,19 @@ int pit_fold_att_bwd(const pit_slab_plan* plan, const float* vw, long ld_vw, lon
                      const float* pw, const float* qw, const void* dz, long ld_dz, long dz_bstride,
                      float* d_vw, long ld_dvw, long dvw_bstride, double* dscale, int max_union, int math_mode, void* stream);
 /* The rest of `de` (pit.py:21-26 after the first Linear) for out_dim = n2 <= 4 and n1 in {64, 128, 256}:
- *   pit_thin_tail_fwd   y[m][o] = sum_n gelu_erf(z[m][n] + b1[n]) w2[o][n] + b2[o]           (z fp32 or bf16; nothing is saved)
- *   pit_thin_tail_bwd   dz[m][n] = (sum_o d_y[m][o] w2[o][n]) gelu'(z[m][n] + b1[n]) (fp32 or bf16), and ADDS (fp32 atomics) d_b1[n] =
- *                       sum_m dz[m][n], d_w2[o][n] = sum_m d_y[m][o] gelu(z[m][n] + b1[n]), d_b2[o] = sum_m d_y[m][o]. */
+ *   pit_thin_tail_fwd   y[m][o] = sum_n gelu_erf(z[m][n] + b1[n]) w2[o][n] + b2[o]                      (nothing is saved)
+ *   pit_thin_tail_bwd   dz[m][n] = (sum_o d_y[m][o] w2[o][n]) gelu'(z[m][n] + b1[n]), and ADDS d_b1[n] = sum_m dz[m][n],
+ *                       d_w2[o][n] = sum_m d_y[m][o] gelu(z[m][n] + b1[n]), d_b2[o] = sum_m d_y[m][o] to the gradients (partial sums meet
+ *                       in `scratch` - pit_thin_tail_scratch_floats() floats, ZERO on first use, left zero - and a finishing launch adds
+ *                       them: the gradients are complete when the call's launches are).
+ * math_mode: PIT_MATH_FP32 - libm's erff; PIT_MATH_BF16 - the polynomial normal CDF of pit_common.h (|error| 1.4e-8); PIT_IO_X_BF16:
+ * z (and dz) are bf16 in memory. */
+int pit_thin_tail_scratch_floats(void);
 int pit_thin_tail_fwd(const void* z, long ldz, int rows, int n1, int n2, const float* b1, const float* w2, const float* b2,
-                      float* y, long ldy, int z_bf16, void* stream);
+                      float* y, long ldy, int math_mode, void* stream);
 int pit_thin_tail_bwd(const void* z, long ldz, int rows, int n1, int n2, const float* b1, const float* w2,
                       const float* d_y, long ld_dy, void* dz, long ld_dz, float* d_b1, float* d_w2, float* d_b2,
-                      int z_bf16, int dz_bf16, void* stream);
+                      float* scratch, int math_mode, void* stream);
 /* y = x w^T without bias (w (n_out, n_in) contiguous; zero_bias: n_out zeros) and its backward d_x = d_y w (NULL: not needed),
  * d_w (+)= d_y^T x (NULL: not needed; accumulate = 0 zeroes it first) - the GEMM launchers of pit_mlp_fwd / _bwd. */
 int pit_linear_fwd(const float* x, long ldx, int rows, int n_in, int n_out, const float* w, const float* zero_bias,

@@ -168,6 +168,22 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 }
 #endif
 
+// The normal CDF as exp(-x^2/2) t (c1 + ... + c6 t^5), t = 1 / (1 + 0.4 |x| / sqrt 2) (Abramowitz & Stegun 7.1.26 refitted for
+// absolute error: 1.4e-8; relative L2 error of gelu / gelu' over N(0,1) arguments 4e-8 / 6e-8, libm's erff: 4e-8 / 4e-8): 16 / 18
+// straight-line instructions against erff's ~60 behind a branch.  Used where the result is rounded to bf16 anyway (the bf16 math
+// mode's thin tail, pit_fold.hip); the fp32 parity path keeps erff.
+__device__ __forceinline__ float normal_cdf_fast(float x, float& e) {
+    const float t = __builtin_amdgcn_rcpf(fmaf(fabsf(x), 0.28284271247f, 1.0f));
+    e = __builtin_amdgcn_exp2f(x * x * -0.72134752044f);
+    float p = -0.100061134f;
+    p = fmaf(p, t, 0.354291141f);
+    p = fmaf(p, t, -0.184991121f);
+    p = fmaf(p, t, 0.233760774f);
+    p = fmaf(p, t, 0.0810635462f);
+    p = fmaf(p, t, 0.115936771f);
+    const float q = p * t * e;
+    return x > 0.0f ? 1.0f - q : q;
+}
 #ifdef PIT_GELU_FAST       // (timing experiment, DESIGN section 4 Round 5: A&S 7.1.26 refitted, 16 / 18 straight-line instructions; NOT the default)
 __device__ __forceinline__ float normal_cdf(float x, float& e) {
     const float t = __builtin_amdgcn_rcpf(fmaf(fabsf(x), 0.28284271247f, 1.0f));

@@ -436,16 +436,19 @@ int union_slots(int max_union) { return max_union <= 32 ? 32 : (max_union <= 48 
 
 // ------------------------------------------------------------------------------------------------ thin tail
 // y[m][o] = sum_n gelu(z[m][n] + b1[n]) w2[o][n] + b2[o], o < n2 <= 4.  tpr = n1 / 4 lanes share a row (16 / 32 / 64), each
-// owning four adjacent columns; eight row groups per wavefront in flight.
+// owning four adjacent columns; four row groups per wavefront in flight, at most 128 registers (four waves per SIMD: the kernels
+// are an erf per element beside a stream - first version, 135-148 registers and 512 workgroups: 42 / 68 us for the 21 M elements
+// of Vorticity's decoder at 1.0 / 1.3 TB/s).  FAST: the polynomial normal CDF (pit_common.h) - the bf16 math mode only.
 struct TailArgs {
-    const void* z; long ldz; int z16; int rows, n1, n2;
+    const void* z; long ldz; int rows, n1, n2;
     const float *b1, *w2, *b2;
     float* y; long ldy;
     const float* d_y; long ld_dy;
-    void* dz; long ld_dz; int dz16;
-    float *d_b1, *d_w2, *d_b2;
+    void* dz; long ld_dz;
+    float* acc;                       // backward: TAIL_SLOTS x ((1 + TMAX) n1 + TMAX) partial sums (zero on entry)
+    float *d_b1, *d_w2, *d_b2;        // finishing launch
 };
-constexpr int TMAX = 4;
+constexpr int TMAX = 4, TAIL_SLOTS = 16;
 
 __device__ __forceinline__ float seg_sum(float v, int tpr) {
     v += dpp_f<0xB1, 0xf>(v);
@@ -456,126 +459,173 @@ __device__ __forceinline__ float seg_sum(float v, int tpr) {
     if (tpr >= 64) v += __shfl_xor(v, 32, 64);
     return v;
 }
-__device__ __forceinline__ float4 tail_load(const TailArgs& g, long m, int k, bool ok) {
-    return g.z16 ? ldh4_if(g.z, m * g.ldz + k, ok) : ldg4_if(reinterpret_cast<const float*>(g.z), m * g.ldz + k, ok);
+template <bool Z16>
+__device__ __forceinline__ float4 tail_load(const void* z, long i, bool ok) {
+    return Z16 ? ldh4_if(z, i, ok) : ldg4_if(reinterpret_cast<const float*>(z), i, ok);
+}
+template <bool FAST>
+__device__ __forceinline__ void gelu_pair(float t, float& a, float& gp) {
+    if (FAST) {
+        float e;
+        const float cdf = normal_cdf_fast(t, e);
+        a = t * cdf;
+        gp = fmaf(t * 0.39894228040143267794f, e, cdf);
+    } else {
+        const float cdf = 0.5f * (1.0f + erff(t * 0.70710678118654752440f));
+        const float pdf = 0.39894228040143267794f * __expf(-0.5f * t * t);
+        a = t * cdf;
+        gp = cdf + t * pdf;
+    }
+}
+template <bool FAST>
+__device__ __forceinline__ float gelu_one(float t) {
+    if (FAST) { float e; return t * normal_cdf_fast(t, e); }
+    return gelu_erf(t);
 }
 
-__global__ __launch_bounds__(256) void thin_tail_fwd_kernel(TailArgs g) {
-    constexpr int U = 8;
+template <int N2, bool FAST, bool Z16>
+__global__ __launch_bounds__(256, 4) void thin_tail_fwd_kernel(TailArgs g) {
+    constexpr int U = 4;
     const int tpr = g.n1 / 4, rpw = 64 / tpr;
     const int lane = threadIdx.x & 63, q = lane % tpr, sub = lane / tpr, k = 4 * q;
     const long wave0 = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((long)gridDim.x * blockDim.x) >> 6;
     const float4 bq = *reinterpret_cast<const float4*>(g.b1 + k);
-    float4 w[TMAX];
+    float4 w[N2];
+    float b2v[N2];
 #pragma unroll
-    for (int o = 0; o < TMAX; ++o) w[o] = o < g.n2 ? *reinterpret_cast<const float4*>(g.w2 + (long)o * g.n1 + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int o = 0; o < N2; ++o) {
+        w[o] = o < g.n2 ? *reinterpret_cast<const float4*>(g.w2 + (long)o * g.n1 + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+        b2v[o] = o < g.n2 ? g.b2[o] : 0.0f;
+    }
     const long stride = nwaves * rpw;
     for (long mbase = wave0 * rpw; mbase < g.rows; mbase += U * stride) {
         float4 zv[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const long m = mbase + u * stride + sub;
-            zv[u] = tail_load(g, m, k, m < g.rows);
+            zv[u] = tail_load<Z16>(g.z, m * g.ldz + k, m < g.rows);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             if (mbase + u * stride >= g.rows) break;             // wave-uniform
             const long m = mbase + u * stride + sub;
-            const float a0 = gelu_erf(zv[u].x + bq.x), a1 = gelu_erf(zv[u].y + bq.y), a2 = gelu_erf(zv[u].z + bq.z), a3 = gelu_erf(zv[u].w + bq.w);
+            const float a0 = gelu_one<FAST>(zv[u].x + bq.x), a1 = gelu_one<FAST>(zv[u].y + bq.y);
+            const float a2 = gelu_one<FAST>(zv[u].z + bq.z), a3 = gelu_one<FAST>(zv[u].w + bq.w);
 #pragma unroll
-            for (int o = 0; o < TMAX; ++o) {
-                if (o >= g.n2) break;
+            for (int o = 0; o < N2; ++o) {
                 float s = (a0 * w[o].x + a1 * w[o].y) + (a2 * w[o].z + a3 * w[o].w);
                 s = seg_sum(s, tpr);
-                if (q == 0 && m < g.rows) g.y[m * g.ldy + o] = s + g.b2[o];
+                if (q == 0 && m < g.rows && o < g.n2) g.y[m * g.ldy + o] = s + b2v[o];
             }
         }
     }
 }
 
-// dz[m][n] = (sum_o d_y[m][o] w2[o][n]) gelu'(z[m][n] + b1[n]);  d_b1 += column sums of dz, d_w2[o] += sum_m d_y[m][o] gelu(..)[m],
-// d_b2[o] += sum_m d_y[m][o]: per-lane partial sums over the rows the lane visits, reduced through LDS, one atomic per output
-// element and workgroup (the grid is kept at 512 workgroups for that reason)
-__global__ __launch_bounds__(256) void thin_tail_bwd_kernel(TailArgs g) {
+// dz[m][n] = (sum_o d_y[m][o] w2[o][n]) gelu'(z[m][n] + b1[n]);  d_b1 = column sums of dz, d_w2[o] = sum_m d_y[m][o] gelu(..)[m],
+// d_b2[o] = sum_m d_y[m][o]: per-lane partial sums over the rows the lane visits, reduced through LDS, then ONE atomic per
+// output element and workgroup into one of 16 slots of a scratch (adds to one address serialise at ~40 ns each: straight into
+// the 512 gradient words, 512 workgroups were a 20 us tail), which thin_tail_finish_kernel drains into the gradients and clears.
+template <int N2, bool FAST, bool Z16>
+__global__ __launch_bounds__(256, N2 == 1 ? 4 : 3) void thin_tail_bwd_kernel(TailArgs g) {
     constexpr int U = 4;
-    __shared__ float red[16 * 64 * (1 + TMAX)];           // [row group of the workgroup][(1 + n2) x 4 x tpr] ; 16 groups x 64 lanes x 5 x ... see below
+    __shared__ float red[16 * 64 * (1 + N2)];
     const int tpr = g.n1 / 4, rpw = 64 / tpr;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane % tpr, sub = lane / tpr, k = 4 * q;
     const long wave0 = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((long)gridDim.x * blockDim.x) >> 6;
     const float4 bq = *reinterpret_cast<const float4*>(g.b1 + k);
-    float4 w[TMAX];
+    float4 w[N2];
 #pragma unroll
-    for (int o = 0; o < TMAX; ++o) w[o] = o < g.n2 ? *reinterpret_cast<const float4*>(g.w2 + (long)o * g.n1 + k) : make_float4(0.f, 0.f, 0.f, 0.f);
-    float sb1[4] = {0.f, 0.f, 0.f, 0.f}, sw2[TMAX][4], sb2[TMAX];
+    for (int o = 0; o < N2; ++o) w[o] = o < g.n2 ? *reinterpret_cast<const float4*>(g.w2 + (long)o * g.n1 + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float sb1[4] = {0.f, 0.f, 0.f, 0.f}, sw2[N2][4], sb2[N2];
 #pragma unroll
-    for (int o = 0; o < TMAX; ++o) { sb2[o] = 0.f; sw2[o][0] = sw2[o][1] = sw2[o][2] = sw2[o][3] = 0.f; }
+    for (int o = 0; o < N2; ++o) { sb2[o] = 0.f; sw2[o][0] = sw2[o][1] = sw2[o][2] = sw2[o][3] = 0.f; }
     const long stride = nwaves * rpw;
+    const __amdgpu_buffer_rsrc_t rdy = wide_rsrc(g.d_y);
     for (long mbase = wave0 * rpw; mbase < g.rows; mbase += U * stride) {
         float4 zv[U];
-        float dy[U][TMAX];
+        float dy[U][N2];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const long m = mbase + u * stride + sub;
             const bool ok = m < g.rows;
-            zv[u] = tail_load(g, m, k, ok);
+            zv[u] = tail_load<Z16>(g.z, m * g.ldz + k, ok);
 #pragma unroll
-            for (int o = 0; o < TMAX; ++o)
-                dy[u][o] = buf_load(wide_rsrc(g.d_y), (ok && o < g.n2) ? (unsigned)((m * g.ld_dy + o) * 4) : OOB);
+            for (int o = 0; o < N2; ++o) dy[u][o] = buf_load(rdy, (ok && o < g.n2) ? (unsigned)((m * g.ld_dy + o) * 4) : OOB);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             if (mbase + u * stride >= g.rows) break;
             const long m = mbase + u * stride + sub;
-            const bool ok = m < g.rows;
             const float t[4] = {zv[u].x + bq.x, zv[u].y + bq.y, zv[u].z + bq.z, zv[u].w + bq.w};
             float s[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int o = 0; o < TMAX; ++o) {
+            for (int o = 0; o < N2; ++o) {
                 s[0] += dy[u][o] * w[o].x; s[1] += dy[u][o] * w[o].y; s[2] += dy[u][o] * w[o].z; s[3] += dy[u][o] * w[o].w;
             }
             float dzv[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                const float cdf = 0.5f * (1.0f + erff(t[c] * 0.70710678118654752440f));
-                const float pdf = 0.39894228040143267794f * __expf(-0.5f * t[c] * t[c]);
-                const float a = t[c] * cdf;                 // gelu (rows beyond the end: dy = 0, nothing accumulates)
-                dzv[c] = s[c] * (cdf + t[c] * pdf);
+                float a, gp;
+                gelu_pair<FAST>(t[c], a, gp);          // (rows beyond the end: dy = 0, nothing accumulates)
+                dzv[c] = s[c] * gp;
                 sb1[c] += dzv[c];
 #pragma unroll
-                for (int o = 0; o < TMAX; ++o) sw2[o][c] += dy[u][o] * a;
+                for (int o = 0; o < N2; ++o) sw2[o][c] += dy[u][o] * a;
             }
 #pragma unroll
-            for (int o = 0; o < TMAX; ++o) sb2[o] += dy[u][o];
-            if (ok) {
+            for (int o = 0; o < N2; ++o) sb2[o] += dy[u][o];
+            if (m < g.rows) {
                 const float4 v = make_float4(dzv[0], dzv[1], dzv[2], dzv[3]);
-                if (g.dz16) *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(g.dz) + m * g.ld_dz + k) = pack4_bf16(v);
+                if (Z16) *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(g.dz) + m * g.ld_dz + k) = pack4_bf16(v);
                 else *reinterpret_cast<float4*>(reinterpret_cast<float*>(g.dz) + m * g.ld_dz + k) = v;
             }
         }
     }
     // reduce over the workgroup's 4 * rpw row groups: quantity j (0 = b1, 1 + o = w2[o]) of column 4 q + c at
-    // red[(grp * 5 + j) * n1 + 4 q + c]; then thread t sums column t of each quantity over the groups and adds it to memory
+    // red[(grp * (1 + N2) + j) * n1 + 4 q + c]; thread t then sums a column of a quantity over the groups
     const int grp = wave * rpw + sub, ngrp = 4 * rpw;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-        red[(grp * (1 + TMAX) + 0) * g.n1 + k + c] = sb1[c];
+        red[(grp * (1 + N2) + 0) * g.n1 + k + c] = sb1[c];
 #pragma unroll
-        for (int o = 0; o < TMAX; ++o) red[(grp * (1 + TMAX) + 1 + o) * g.n1 + k + c] = sw2[o][c];
+        for (int o = 0; o < N2; ++o) red[(grp * (1 + N2) + 1 + o) * g.n1 + k + c] = sw2[o][c];
     }
     __syncthreads();
+    float* acc = g.acc + (long)((int)blockIdx.x & (TAIL_SLOTS - 1)) * ((1 + TMAX) * g.n1 + TMAX);
     for (int e = threadIdx.x; e < (1 + g.n2) * g.n1; e += 256) {
         const int j = e / g.n1, col = e - j * g.n1;
         float v = 0.0f;
-        for (int gq = 0; gq < ngrp; ++gq) v += red[(gq * (1 + TMAX) + j) * g.n1 + col];
-        atomicAdd(j == 0 ? g.d_b1 + col : g.d_w2 + (long)(j - 1) * g.n1 + col, v);
+        for (int gq = 0; gq < ngrp; ++gq) v += red[(gq * (1 + N2) + j) * g.n1 + col];
+        atomicAdd(acc + j * g.n1 + col, v);
     }
-    // d_b2: every lane with q == 0 holds its rows' sums (the other lanes of a row saw the same d_y: count one of them)
+    // d_b2: the lanes with q == 0 hold their rows' sums (the other lanes of a row saw the same d_y)
 #pragma unroll
-    for (int o = 0; o < TMAX; ++o) {
-        if (o >= g.n2) break;
+    for (int o = 0; o < N2; ++o) {
         const float v = wave_sum(q == 0 ? sb2[o] : 0.0f);
-        if (lane == 0) atomicAdd(g.d_b2 + o, v);
+        if (lane == 0 && o < g.n2) atomicAdd(acc + (1 + TMAX) * g.n1 + o, v);
     }
+}
+
+// slots -> gradients (ADDED), scratch left zero for the next call
+__global__ __launch_bounds__(256) void thin_tail_finish_kernel(TailArgs g) {
+    const int per = (1 + TMAX) * g.n1 + TMAX;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    const int nw = (1 + g.n2) * g.n1;
+    int src = -1;
+    float* dst = nullptr;
+    if (e < nw) {
+        const int j = e / g.n1, col = e - j * g.n1;
+        src = e;
+        dst = j == 0 ? g.d_b1 + col : g.d_w2 + (long)(j - 1) * g.n1 + col;
+    } else if (e < nw + g.n2) {
+        src = (1 + TMAX) * g.n1 + (e - nw);
+        dst = g.d_b2 + (e - nw);
+    }
+    if (src < 0) return;
+    float v = 0.0f;
+#pragma unroll
+    for (int sl = 0; sl < TAIL_SLOTS; ++sl) { v += g.acc[(long)sl * per + src]; g.acc[(long)sl * per + src] = 0.0f; }
+    *dst += v;
 }
 
 bool aligned16p(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -650,37 +700,59 @@ int tail_fill(TailArgs& g, const void* z, long ldz, int rows, int n1, int n2, co
     if ((reinterpret_cast<uintptr_t>(z) & (z_bf16 ? 7 : 15)) || !aligned16p(b1) || !aligned16p(w2)) return PIT_ERR_SIZE;
     if ((long)rows * ldz * 4 >= (1L << 31) - 65536) return PIT_ERR_UNSUPPORTED;
     g = TailArgs();
-    g.z = z; g.ldz = ldz; g.z16 = z_bf16; g.rows = rows; g.n1 = n1; g.n2 = n2; g.b1 = b1; g.w2 = w2;
+    g.z = z; g.ldz = ldz; g.rows = rows; g.n1 = n1; g.n2 = n2; g.b1 = b1; g.w2 = w2;
     return 0;
 }
+// N2 (1 or 4 at compile time) x the polynomial CDF (bf16 math mode) x bf16-stored z
+#define PIT_TAIL_DISPATCH(KERNEL_, n2_, fast_, z16_, ...)                                                        \
+    do {                                                                                                          \
+        if ((n2_) == 1) {                                                                                         \
+            if (fast_) { if (z16_) hipLaunchKernelGGL((KERNEL_<1, true, true>), __VA_ARGS__); else hipLaunchKernelGGL((KERNEL_<1, true, false>), __VA_ARGS__); }    \
+            else { if (z16_) hipLaunchKernelGGL((KERNEL_<1, false, true>), __VA_ARGS__); else hipLaunchKernelGGL((KERNEL_<1, false, false>), __VA_ARGS__); }         \
+        } else {                                                                                                  \
+            if (fast_) { if (z16_) hipLaunchKernelGGL((KERNEL_<4, true, true>), __VA_ARGS__); else hipLaunchKernelGGL((KERNEL_<4, true, false>), __VA_ARGS__); }    \
+            else { if (z16_) hipLaunchKernelGGL((KERNEL_<4, false, true>), __VA_ARGS__); else hipLaunchKernelGGL((KERNEL_<4, false, false>), __VA_ARGS__); }         \
+        }                                                                                                         \
+    } while (0)
 }  // namespace
 
+extern "C" int pit_thin_tail_scratch_floats(void) { return TAIL_SLOTS * ((1 + TMAX) * 256 + TMAX); }
+
 extern "C" int pit_thin_tail_fwd(const void* z, long ldz, int rows, int n1, int n2, const float* b1, const float* w2, const float* b2,
-                                 float* y, long ldy, int z_bf16, void* stream) {
+                                 float* y, long ldy, int math_mode, void* stream) {
+    const int mode = math_mode & 0xff, z16 = (math_mode & PIT_IO_X_BF16) ? 1 : 0;
+    if ((mode != PIT_MATH_FP32 && mode != PIT_MATH_BF16) || (math_mode & ~(0xff | PIT_IO_X_BF16))) return PIT_ERR_UNSUPPORTED;
     TailArgs g;
-    if (int rc = tail_fill(g, z, ldz, rows, n1, n2, b1, w2, z_bf16)) return rc;
+    if (int rc = tail_fill(g, z, ldz, rows, n1, n2, b1, w2, z16)) return rc;
     if (!b2 || !y) return PIT_ERR_NULL;
     if (ldy < n2) return PIT_ERR_SIZE;
     g.b2 = b2; g.y = y; g.ldy = ldy;
     const int rpw = 64 / (n1 / 4);
-    const long need = ((long)rows + 4L * rpw * 8 - 1) / (4L * rpw * 8);
-    hipLaunchKernelGGL(thin_tail_fwd_kernel, dim3((unsigned)std::max<long>(1, std::min<long>(need, 2048))), dim3(256), 0, (hipStream_t)stream, g);
+    const long need = ((long)rows + 4L * rpw * 4 - 1) / (4L * rpw * 4);
+    const dim3 grid((unsigned)std::max<long>(1, std::min<long>(need, 4096)));
+    PIT_TAIL_DISPATCH(thin_tail_fwd_kernel, n2, mode == PIT_MATH_BF16, z16, grid, dim3(256), 0, (hipStream_t)stream, g);
     PIT_CHECK_LAUNCH();
     return 0;
 }
 
 extern "C" int pit_thin_tail_bwd(const void* z, long ldz, int rows, int n1, int n2, const float* b1, const float* w2,
                                  const float* d_y, long ld_dy, void* dz, long ld_dz, float* d_b1, float* d_w2, float* d_b2,
-                                 int z_bf16, int dz_bf16, void* stream) {
+                                 float* scratch, int math_mode, void* stream) {
+    const int mode = math_mode & 0xff, z16 = (math_mode & PIT_IO_X_BF16) ? 1 : 0;
+    if ((mode != PIT_MATH_FP32 && mode != PIT_MATH_BF16) || (math_mode & ~(0xff | PIT_IO_X_BF16))) return PIT_ERR_UNSUPPORTED;
     TailArgs g;
-    if (int rc = tail_fill(g, z, ldz, rows, n1, n2, b1, w2, z_bf16)) return rc;
-    if (!d_y || !dz || !d_b1 || !d_w2 || !d_b2) return PIT_ERR_NULL;
-    if (ld_dy < n2 || ld_dz < n1 || ld_dz % 4 || (reinterpret_cast<uintptr_t>(dz) & (dz_bf16 ? 7 : 15))) return PIT_ERR_SIZE;
+    if (int rc = tail_fill(g, z, ldz, rows, n1, n2, b1, w2, z16)) return rc;
+    if (!d_y || !dz || !d_b1 || !d_w2 || !d_b2 || !scratch) return PIT_ERR_NULL;
+    if (ld_dy < n2 || ld_dz < n1 || ld_dz % 4 || (reinterpret_cast<uintptr_t>(dz) & (z16 ? 7 : 15))) return PIT_ERR_SIZE;
     if ((long)rows * ld_dy * 4 >= (1L << 31) - 65536) return PIT_ERR_UNSUPPORTED;
-    g.d_y = d_y; g.ld_dy = ld_dy; g.dz = dz; g.ld_dz = ld_dz; g.dz16 = dz_bf16; g.d_b1 = d_b1; g.d_w2 = d_w2; g.d_b2 = d_b2;
+    g.d_y = d_y; g.ld_dy = ld_dy; g.dz = dz; g.ld_dz = ld_dz; g.acc = scratch; g.d_b1 = d_b1; g.d_w2 = d_w2; g.d_b2 = d_b2;
     const int rpw = 64 / (n1 / 4);
-    const long need = ((long)rows + 4L * rpw * 4 - 1) / (4L * rpw * 4);
-    hipLaunchKernelGGL(thin_tail_bwd_kernel, dim3((unsigned)std::max<long>(1, std::min<long>(need, 512))), dim3(256), 0, (hipStream_t)stream, g);
+    const long need = ((long)rows + 4L * rpw * 4 * 2 - 1) / (4L * rpw * 4 * 2);     // two batches of four row groups per wavefront
+    const dim3 grid((unsigned)std::max<long>(1, std::min<long>(need, 2048)));
+    hipStream_t s = (hipStream_t)stream;
+    PIT_TAIL_DISPATCH(thin_tail_bwd_kernel, n2, mode == PIT_MATH_BF16, z16, grid, dim3(256), 0, s, g);
+    PIT_CHECK_LAUNCH();
+    hipLaunchKernelGGL(thin_tail_finish_kernel, dim3((unsigned)(((1 + n2) * n1 + n2 + 255) / 256)), dim3(256), 0, s, g);
     PIT_CHECK_LAUNCH();
     return 0;
 }

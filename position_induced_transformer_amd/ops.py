@@ -1860,6 +1860,18 @@ class _FoldAtt(torch.autograd.Function):
         return d_vw, d_head, None, None, None, None, None, None, None
 
 
+_TAIL_WS = {}       # (device index, stream) -> the thin tail's slotted partial sums (self-cleaning)
+
+
+def _tail_scratch(device) -> torch.Tensor:
+    key = _ws_key(device)
+    ws = _TAIL_WS.get(key)
+    if ws is None:
+        ws = _TAIL_WS[key] = torch.zeros((_lib.lib().pit_thin_tail_scratch_floats(),), device=device, dtype=torch.float32)
+        _pin(ws)
+    return ws
+
+
 class _ThinTail(torch.autograd.Function):
     """y = gelu(z + b1) @ W2^T + b2 for out_dim <= 4 (pit_thin_tail_fwd / _bwd): z fp32 or bf16, nothing but z is saved."""
 
@@ -1874,8 +1886,9 @@ class _ThinTail(torch.autograd.Function):
         n2 = w2.shape[0]
         b1c, w2c, b2c = (t.detach().contiguous() for t in (b1, w2, b2))
         y = torch.empty((b, n, n2), device=z.device, dtype=torch.float32)
+        ctx.math = _math_code() | (IO_X_BF16 if z.dtype == torch.bfloat16 else 0)
         rc = _lib.lib().pit_thin_tail_fwd(z.data_ptr(), z.stride(1), b * n, d, n2, b1c.data_ptr(), w2c.data_ptr(), b2c.data_ptr(),
-                                          y.data_ptr(), n2, 1 if z.dtype == torch.bfloat16 else 0, _lib.stream_ptr())
+                                          y.data_ptr(), n2, ctx.math, _lib.stream_ptr())
         _lib.check(rc, "pit_thin_tail_fwd")
         ctx.params = params
         ctx.save_for_backward(z, b1c, w2c)
@@ -1898,8 +1911,7 @@ class _ThinTail(torch.autograd.Function):
             d_b1, d_w2, d_b2 = (torch.zeros_like(t) for t in (b1c, w2c, b1c[:n2]))
         rc = _lib.lib().pit_thin_tail_bwd(z.data_ptr(), z.stride(1), b * n, d, n2, b1c.data_ptr(), w2c.data_ptr(), d_y.data_ptr(),
                                           d_y.stride(0), dz.data_ptr(), d, d_b1.data_ptr(), d_w2.data_ptr(), d_b2.data_ptr(),
-                                          1 if z.dtype == torch.bfloat16 else 0, 1 if dz.dtype == torch.bfloat16 else 0,
-                                          _lib.stream_ptr())
+                                          _tail_scratch(z.device).data_ptr(), ctx.math, _lib.stream_ptr())
         _lib.check(rc, "pit_thin_tail_bwd")
         if inplace:
             return dz, None, None, None, None
