@@ -77,6 +77,12 @@ def parse():
                          "auto = 1 unless the measured cost of the captured all-reduce exceeds 10 %% of the step, then the faster "
                          "of the two")
     ap.add_argument("--watchdog", type=float, default=300.0, help="N > 1: seconds allowed for capture + first replays")
+    ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
+                    help="process-group backend; gloo (tests: several ranks on ONE GPU) stages the exchange through the host and "
+                         "implies --eager-allreduce")
+    ap.add_argument("--device-index", type=int, default=None, help="GPU of this process (default: LOCAL_RANK)")
+    ap.add_argument("--sweep-batch", type=int, default=256, help="per-GPU batch of the saturated-regime scaling point (N > 1)")
+    ap.add_argument("--ddp-sweep", action="store_true", help="time the saturated-regime scaling point even with --no-extras")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip batch sweep / optimizer / roofline probes")
     ap.add_argument("--cpu-iters", type=int, default=100)
@@ -200,7 +206,7 @@ def timed(run, steps, warmup, world):
         dist.barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        t = torch.tensor([dt], device="cpu" if dist.get_backend() == "gloo" else "cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     return dt
@@ -548,71 +554,118 @@ def executed_gflop_per_sample(model, step):
     return 3.0 * (total + mlp) / 1e9
 
 
+def _oracle_step(args, model, meta, affine, mesh_in, func_in, mesh_out, target):
+    """oracle/pit_oracle.py forward + loss + backward on the host for the model's current parameters and the given (CPU) batch:
+    (prediction before the affine map, loss, {name: gradient}, seconds)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pit_oracle as orc
+    b = func_in.shape[0]
+    sd = {k: q.detach().cpu().clone().requires_grad_(True) for k, q in model.named_parameters()}
+    s = model.space_dim
+    metric = model.down._metric
+    norm = hasattr(model, "norm")
+    t0 = time.perf_counter()
+    if model.mesh_ltt is not None:                       # fixed-mesh tasks (train_darcy.py:46-59 and alike)
+        mi = mesh_in.reshape(-1, s)
+        mo = mesh_out.reshape(-1, s)
+        f = orc.with_coords(mi, func_in.reshape(b, -1, model.in_dim))
+        ref = orc.pit_apply(sd, metric, False, model.n_blocks, model.en_local, model.de_local, mi, f,
+                            model.mesh_ltt.cpu(), mo, norm_after_enc_proc=norm)
+        if getattr(model, "residual", False):
+            ref = ref + func_in.reshape(ref.shape)
+    elif args.task == "elasticity":                      # train_elasticity.py:41-54
+        ref = orc.pit_apply(sd, metric, True, model.n_blocks, model.en_local, model.de_local, mesh_in, func_in, mesh_out, mesh_out)
+    elif args.task == "naca":                            # train_naca.py:52-65
+        ltt, flat = model.ltt_mesh(mesh_out)
+        ref = orc.pit_apply(sd, metric, True, model.n_blocks, model.en_local, model.de_local, mesh_in, func_in, ltt, flat)
+    else:
+        return None
+    ref = ref.reshape(target.shape)
+    pred = ref if affine is None else ref * affine[0].cpu() + affine[1].cpu()
+    ref_loss = orc.rel_lp_loss(target, pred, meta["out_dim"], meta["p"])
+    ref_loss.backward()
+    return ref.detach(), float(ref_loss), {k: v.grad for k, v in sd.items()}, time.perf_counter() - t0
+
+
+def _rel(a, r):
+    return float((a.double() - r.double()).norm() / (r.double().norm() + 1e-300))
+
+
+def _parity_record(args, meta, out_dev, loss_dev, dev_grads, ref_out, ref_loss, ref_grads, secs, rows):
+    w = {k: _rel(dev_grads[k], ref_grads[k]) for k in ref_grads if not k.endswith("lmda")}
+    l = {k: _rel(dev_grads[k], ref_grads[k]) for k in ref_grads if k.endswith("lmda")}
+    kw, kl = max(w, key=w.get), max(l, key=l.get)
+    # all layers' d(lmda) as one vector (what tests/test_gpu_bf16.py bounds: a single layer's scalar is a cancellation-heavy sum
+    # and its own relative error is noisier than the vector's)
+    lk = [k for k in ref_grads if k.endswith("lmda")]
+    l_all = _rel(torch.cat([dev_grads[k].reshape(-1) for k in lk]), torch.cat([ref_grads[k].reshape(-1) for k in lk]))
+    return {"rel_l2_out": _rel(out_dev, ref_out), "rel_loss": abs(loss_dev - ref_loss) / abs(ref_loss),
+            "rel_l2_weight_grad_worst": w[kw], "worst_weight_grad": kw,
+            "rel_l2_dlmda_all_layers": l_all, "rel_l2_dlmda_worst": l[kl], "worst_dlmda": kl,
+            "head_scale_route": args.head_scale_route, "math": args.math,
+            # weight gradients are fp32 sums over batch x points rows on BOTH sides (the oracle's torch-CPU reductions too): the
+            # 2e-5 of the tests (batch 2, tests/test_gpu_round2.py) grows with the square root of the rows beyond Darcy b=8's 14 792
+            "tolerance": {"out": 1e-5, "weight_grad": round(2e-5 * max(1.0, (rows / 16384.0) ** 0.5), 7),
+                          "dlmda_all_layers": 2e-4} if args.math == "fp32" else     # (one vector, as the tests judge it: a single layer's
+                                                                                     # d(lmda) can be 1e-9 of the others - its own ratio is noise)
+                         {"out": 2e-2, "weight_grad": 5e-2, "dlmda_all_layers": 5e-2},
+            "oracle_seconds": round(secs, 2)}
+
+
 def parity_vs_oracle(args, step, model, affine, meta):
     """rel-L2 of what the TIMED step computed - the prediction, the loss and every gradient left in the flat buffer
     by the last replay of the timed graph, on the timed model, inputs and head-scale route - against the CPU oracle
     (oracle/pit_oracle.py: the reference's op sequence, pinned bit-equal to /root/reference/pit.py in the build
     container) run here on the same parameters and inputs.  BASELINE.json's metric asks for this number next to the
     throughput.  Tolerances of the parity tests: output 1e-5, weight gradients 2e-5, d(lmda) 2e-4."""
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import pit_oracle as orc
     torch.cuda.synchronize()
-    b = step.func_in.shape[0]
-    sd, dev_grads = {}, {}
-    for k, q in model.named_parameters():
-        sd[k] = q.detach().cpu().clone().requires_grad_(True)
-        dev_grads[k] = q.grad.detach().cpu().clone()
+    dev_grads = {k: q.grad.detach().cpu().clone() for k, q in model.named_parameters()}
     out_dev, loss_dev = step.out.detach().cpu(), float(step.loss)
-    s = model.space_dim
-    metric = model.down._metric
-    norm = hasattr(model, "norm")
-    t0 = time.perf_counter()
-    if model.mesh_ltt is not None:                       # fixed-mesh tasks (train_darcy.py:46-59 and alike)
-        mi = step.mesh_in.cpu().reshape(-1, s)
-        mo = step.mesh_out.cpu().reshape(-1, s)
-        f = orc.with_coords(mi, step.func_in.cpu().reshape(b, -1, model.in_dim))
-        ref = orc.pit_apply(sd, metric, False, model.n_blocks, model.en_local, model.de_local, mi, f,
-                            model.mesh_ltt.cpu(), mo, norm_after_enc_proc=norm)
-        if getattr(model, "residual", False):
-            ref = ref + step.func_in.cpu().reshape(ref.shape)
-    elif args.task == "elasticity":                      # train_elasticity.py:41-54
-        mo = step.mesh_out.cpu()
-        ref = orc.pit_apply(sd, metric, True, model.n_blocks, model.en_local, model.de_local, step.mesh_in.cpu(),
-                            step.func_in.cpu(), mo, mo)
-    elif args.task == "naca":                            # train_naca.py:52-65
-        ltt, flat = model.ltt_mesh(step.mesh_out.cpu())
-        ref = orc.pit_apply(sd, metric, True, model.n_blocks, model.en_local, model.de_local, step.mesh_in.cpu(),
-                            step.func_in.cpu(), ltt, flat)
-    else:
+    got = _oracle_step(args, model, meta, affine, step.mesh_in.cpu(), step.func_in.cpu(), step.mesh_out.cpu(), step.target.cpu())
+    if got is None:
         return None
-    ref = ref.reshape(out_dev.shape)
-    pred = ref if affine is None else ref * affine[0].cpu() + affine[1].cpu()
-    ref_loss = orc.rel_lp_loss(step.target.cpu(), pred, meta["out_dim"], meta["p"])
-    ref_loss.backward()
-    secs = time.perf_counter() - t0
+    ref_out, ref_loss, ref_grads, secs = got
+    rec = _parity_record(args, meta, out_dev, loss_dev, dev_grads, ref_out.reshape(out_dev.shape), ref_loss, ref_grads, secs,
+                         out_dev.numel() / meta["out_dim"])
+    rec["what"] = ("the timed hipGraph's own results (prediction, loss, flat gradient buffer after its last replay) vs "
+                   "oracle/pit_oracle.py forward+loss+backward on this host, same parameters and inputs")
+    return rec
 
-    def rel(a, r):
-        return float((a.double() - r.double()).norm() / (r.double().norm() + 1e-300))
-    w = {k: rel(dev_grads[k], sd[k].grad) for k in sd if not k.endswith("lmda")}
-    l = {k: rel(dev_grads[k], sd[k].grad) for k in sd if k.endswith("lmda")}
-    kw, kl = max(w, key=w.get), max(l, key=l.get)
-    # all layers' d(lmda) as one vector (what tests/test_gpu_bf16.py bounds: a single layer's scalar is a cancellation-heavy sum
-    # and its own relative error is noisier than the vector's)
-    lk = [k for k in sd if k.endswith("lmda")]
-    l_all = rel(torch.cat([dev_grads[k].reshape(-1) for k in lk]), torch.cat([sd[k].grad.reshape(-1) for k in lk]))
-    return {"rel_l2_out": rel(out_dev, ref.detach()), "rel_loss": abs(loss_dev - float(ref_loss)) / abs(float(ref_loss)),
-            "rel_l2_weight_grad_worst": w[kw], "worst_weight_grad": kw,
-            "rel_l2_dlmda_all_layers": l_all, "rel_l2_dlmda_worst": l[kl], "worst_dlmda": kl,
-            "head_scale_route": args.head_scale_route, "math": args.math,
-            # weight gradients are fp32 sums over batch x points rows on BOTH sides (the oracle's torch-CPU reductions too): the
-            # 2e-5 of the tests (batch 2, tests/test_gpu_round2.py) grows with the square root of the rows beyond Darcy b=8's 14 792
-            "tolerance": {"out": 1e-5, "weight_grad": round(2e-5 * max(1.0, (out_dev.numel() / meta["out_dim"] / 16384.0) ** 0.5), 7),
-                          "dlmda_all_layers": 2e-4} if args.math == "fp32" else     # (one vector, as the tests judge it: a single layer's
-                                                                                     # d(lmda) can be 1e-9 of the others - its own ratio is noise)
-                         {"out": 2e-2, "weight_grad": 5e-2, "dlmda_all_layers": 5e-2},
-            "what": "the timed hipGraph's own results (prediction, loss, flat gradient buffer after its last replay) vs "
-                    "oracle/pit_oracle.py forward+loss+backward on this host, same parameters and inputs",
-            "oracle_seconds": round(secs, 2)}
+
+def parity_ddp(args, step, model, affine, meta, world, rank):
+    """SURVEY 8(e)'s parity row for the step that was TIMED on `world` ranks: rank 0 rebuilds the GLOBAL batch (every rank's
+    shard comes from the generator seeded 100 + rank, build_step) and runs the oracle on it; the all-reduced flat gradient must be
+    the global batch's gradient (RelLpNorm sums over the batch, utils.py:98: the reduction is SUM), the losses summed over the
+    ranks its loss, rank 0's prediction its first shard's.  Collective: every rank calls it."""
+    torch.cuda.synchronize()
+    loss_all = step.loss.detach().reshape(1).clone()
+    if dist.get_backend() == "gloo":
+        loss_all = loss_all.cpu()
+    dist.all_reduce(loss_all)
+    if rank != 0:
+        return None
+    dev_grads = {k: q.grad.detach().cpu().clone() for k, q in model.named_parameters()}
+    b = step.func_in.shape[0]
+    funcs, targets = [], []
+    for r in range(world):
+        g = torch.Generator().manual_seed(100 + r)
+        funcs.append(torch.randn(step.func_in.shape, generator=g))
+        targets.append(torch.randn(step.target.shape, generator=g))
+    if not torch.equal(funcs[0], step.func_in.cpu()):
+        return {"error": "rank 0's shard is not what the seed rebuilds"}
+    rep = lambda m: m.cpu() if model.mesh_ltt is not None else torch.cat([m.cpu()] * world, 0)     # per-sample meshes: same on every rank
+    got = _oracle_step(args, model, meta, affine, rep(step.mesh_in), torch.cat(funcs, 0), rep(step.mesh_out), torch.cat(targets, 0))
+    if got is None:
+        return None
+    ref_out, ref_loss, ref_grads, secs = got
+    out_dev = step.out.detach().cpu()
+    rec = _parity_record(args, meta, out_dev, float(loss_all), dev_grads, ref_out[:b].reshape(out_dev.shape), ref_loss, ref_grads, secs,
+                         world * out_dev.numel() / meta["out_dim"])
+    rec["world"] = world
+    rec["what"] = (f"{world} rank(s): the all-reduced flat gradient buffer vs the oracle's gradient of the GLOBAL batch ({world * b} "
+                   "samples, rebuilt on rank 0 from the ranks' seeds), the losses summed over the ranks vs its loss, rank 0's "
+                   "prediction vs its first shard's (SURVEY 8(e): W-rank gradient == 1-rank gradient on the concatenated batch)")
+    return rec
 
 
 def cpu_baseline(batch, iters):
@@ -701,6 +754,10 @@ def main():
         print(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE", file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP hot path has no CPU fallback)")
+    if args.device_index is not None:
+        local = args.device_index
+    if args.backend == "gloo":
+        args.eager_allreduce = True
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     distributed = world > 1 or "RANK" in os.environ           # under torch.distributed.run even with 1 rank
@@ -709,7 +766,10 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=device)
+        if args.backend == "gloo":
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
 
     log(f"rank {rank}/{world} on {torch.cuda.get_device_name(local)}")
     from position_induced_transformer_amd import ops
@@ -762,6 +822,44 @@ def main():
     value = args.batch * world * args.steps / dt
     loss_val = float(step.loss)
 
+    # N > 1 (and a 1-rank torch.distributed.run): SURVEY 8(e)'s parity row for the timed step - collective, every rank
+    ddp_parity = None
+    if distributed and not args.no_parity and not args.rollout:
+        try:
+            ddp_parity = parity_ddp(args, step, model, darcy_affine(device) if args.task == "darcy" else None, meta, world, rank)
+        except Exception as exc:
+            ddp_parity = {"error": f"{type(exc).__name__}: {exc}"}
+        if rank == 0:
+            log("parity_ddp: " + json.dumps({k: v for k, v in (ddp_parity or {}).items() if k.startswith("rel_") or k == "error"}))
+    # ... and a saturated-regime scaling point next to the latency-regime headline (collective too)
+    ddp_sweep = None
+    if distributed and (not args.no_extras or args.ddp_sweep) and not args.rollout and args.sweep_batch != args.batch:
+        try:
+            st6, _, _ = build_step(args, device, rank, world, args.sweep_batch, all_reduce=True)
+            with Watchdog(args.watchdog, "capturing the saturated-batch step"):
+                if args.eager_allreduce and not args.no_graph:
+                    st6.all_reduce = False
+                    st6.capture()
+
+                    def run6():
+                        st6.replay()
+                        st6.flat.all_reduce()
+                else:
+                    run6, _ = prepare(st6, not args.no_graph)
+                for _ in range(2):
+                    run6()
+                torch.cuda.synchronize()
+            n6 = max(args.steps // 4, 10)
+            dt6, _ = timed_blocks(run6, n6, 5, world, min_total=0.1)
+            ddp_sweep = {str(args.sweep_batch): round(args.sweep_batch * world * n6 / dt6, 1),
+                         "ms_per_step": round(dt6 / n6 * 1e3, 4),
+                         "what": f"whole-job samples/s at per-GPU batch {args.sweep_batch} on {world} rank(s), gradient exchange included"}
+            del st6, run6
+            torch.cuda.empty_cache()
+        except Exception as exc:
+            ddp_sweep = {"error": f"{type(exc).__name__}: {exc}"}
+        if rank == 0:
+            log("saturated-batch scaling point: " + json.dumps(ddp_sweep))
     if rank == 0:
         rec = {
             "metric": "PiT fwd+bwd samples/sec on Darcy2D" if args.task == "darcy" else f"PiT fwd+bwd samples/sec on {args.task}",
@@ -806,6 +904,10 @@ def main():
                     rec["step_tflops"]["executed_frac_of_fp32_mfma_peak"] = round(value * ex / 1e3 / FP32_MFMA_PEAK_TFLOPS / world, 4)
                 except Exception as exc:          # informational only
                     log(f"executed-FLOP count skipped: {type(exc).__name__}: {exc}")
+        if ddp_parity is not None:
+            rec["parity_ddp"] = ddp_parity
+        if ddp_sweep is not None:
+            rec["batch_sweep_ddp_samples_per_s"] = ddp_sweep
         if not args.no_parity and not args.rollout and world == 1:
             try:
                 aff = darcy_affine(device) if args.task == "darcy" else None

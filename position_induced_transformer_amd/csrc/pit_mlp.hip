@@ -25,6 +25,15 @@
 #include <cstdlib>
 #include <type_traits>
 
+// Diagnostic switches (PIT_NO_* / PIT_LDS_* / PIT_RR_* / PIT_THIN_*: force another kernel family or tile shape for an A/B
+// measurement) are compiled in only with -DPIT_EXPERIMENTS (tools/variant_build.sh): the production library reads no environment
+// variable on this path, and nobody has to re-measure configurations nobody runs.
+#ifdef PIT_EXPERIMENTS
+static inline const char* exp_env(const char* name) { return getenv(name); }
+#else
+static inline const char* exp_env(const char*) { return nullptr; }
+#endif
+
 namespace {
 
 template <int TN, int EPI>
@@ -216,7 +225,7 @@ __global__ __launch_bounds__(N1 * 4) void mlp_fwd16_kernel(FusedMlpArgs g) {
 bool try_launch_mlp_fwd16(const float* x, long ldx, int rows, int n0, int n1, int n2, const float* w1, const float* b1,
                           const float* w2, const float* b2, int out_gelu, float* z1, float* h, float* z2, float* y,
                           long ldy, hipStream_t s) {
-    static const bool off = getenv("PIT_NO_FUSED_MLP") != nullptr;
+    static const bool off = exp_env("PIT_NO_FUSED_MLP") != nullptr;
     if (off) return false;
     if (n1 != 32 && n1 != 64 && n1 != 128) return false;
     if (n2 > 4 && (n2 % 16 != 0 || n2 > n1)) return false;        // full tiles, or the thin (out_dim <= 4) output layer
@@ -390,7 +399,7 @@ __global__ __launch_bounds__(N1 * 4) void mlp_bwd16_kernel(FusedMlpBwdArgs g) {
 }
 
 bool mlp_bwd16_eligible(int rows, int n0, int n1, int n2) {
-    static const bool off = getenv("PIT_NO_FUSED_MLP_BWD") != nullptr;
+    static const bool off = exp_env("PIT_NO_FUSED_MLP_BWD") != nullptr;
     if (off) return false;
     if (n1 != 32 && n1 != 64 && n1 != 128) return false;
     if (n2 > 4 && (n2 % 16 != 0 || n2 > n1)) return false;
@@ -1244,10 +1253,10 @@ bool aligned16(const void* p);
 
 // true if one of the thin kernels took the contraction
 bool try_launch_thin(const GemmArgs& g, hipStream_t s) {
-    static const bool off = getenv("PIT_NO_THIN_GEMM") != nullptr;
+    static const bool off = exp_env("PIT_NO_THIN_GEMM") != nullptr;
     if (off) return false;
-    static const long min_out = getenv("PIT_THIN_MIN") ? atol(getenv("PIT_THIN_MIN")) : (1L << 19);
-    static const long min_rows = getenv("PIT_THIN_MIN_ROWS") ? atol(getenv("PIT_THIN_MIN_ROWS")) : 8192;
+    static const long min_out = exp_env("PIT_THIN_MIN") ? atol(exp_env("PIT_THIN_MIN")) : (1L << 19);
+    static const long min_rows = exp_env("PIT_THIN_MIN_ROWS") ? atol(exp_env("PIT_THIN_MIN_ROWS")) : 8192;
     // bf16 storage flags: thin_dz1 reads G / writes C in either format, thin_fwd reads A, thin_dw reads B; anything else
     // keeps the contraction off these kernels
     if (g.epi == EPI_MUL_GELU_GRAD && g.K <= THIN_MAX && g.a_cs == 1 && g.b_cs == 1 && g.N % 4 == 0 && g.b_rs % 4 == 0 &&
@@ -1265,7 +1274,7 @@ bool try_launch_thin(const GemmArgs& g, hipStream_t s) {
         const long rows_per_wg = 4L * (64 / tpr);
         // single-pass fp32 rows of many-row launches: 2048 workgroups walk the rows with eight row groups in flight each
         const unsigned long long a_bytes = (unsigned long long)(((long)g.M - 1) * g.a_rs + g.K) * 4ull;
-        static const bool no_stream = getenv("PIT_NO_THIN_STREAM") != nullptr;      // (diagnostic switch, read once)
+        static const bool no_stream = exp_env("PIT_NO_THIN_STREAM") != nullptr;      // (diagnostic switch, read once)
         const int streamed = (g.K <= tpr * 4 && !g.a16 && a_bytes < PIT_MAX_BUFFER_BYTES && g.M >= 65536 && !no_stream) ? 1 : 0;
         hipLaunchKernelGGL(thin_fwd_kernel, dim3((unsigned)std::min<long>((g.M + rows_per_wg - 1) / rows_per_wg, streamed ? 2048 : 16384)),
                            dim3(256), 0, s, g, tpr, streamed);
@@ -1298,15 +1307,15 @@ constexpr int BKF128 = PIT_BKF128, BKF64 = PIT_BKF64;     // fp32-stored operand
 // one MLP, which share K (the batch rows), in ONE launch; preconditions checked by the caller (gemm_rr_ok)
 bool gemm_rr_ok(const GemmArgs& g) {
     const int n_real = (g.ones_col >= 0) ? g.N - 1 : g.N;
-    static const bool no_bf = getenv("PIT_NO_GEMM_RR_BF16") != nullptr;
-    if (g.bf16 && (no_bf || getenv("PIT_BF16_LEGACY"))) return false;
+    static const bool no_bf = exp_env("PIT_NO_GEMM_RR_BF16") != nullptr;
+    if (g.bf16 && (no_bf || exp_env("PIT_BF16_LEGACY"))) return false;
     return g.epi == EPI_ATOMIC && !g.a_gz && !(g.a16 || g.b16 || g.c16 || g.z16 || g.g16) &&
            g.a_rs == 1 && g.a_cs % 4 == 0 && g.M % 4 == 0 && g.b_cs == 1 && g.b_rs % 4 == 0 && n_real % 4 == 0 &&
            aligned16(g.A) && aligned16(g.B);
 }
 void launch_gemm_rr(const GemmArgs& g1, const GemmArgs* g2, hipStream_t s) {
     int rm = 1, rn = 1, bk = 64, per_cu = 0, pad_kb = 0;
-    static const char* cfg = getenv("PIT_RR_CFG");                 // experiments: "rm,rn,bk,workgroups per CU,LDS padding KB"
+    static const char* cfg = exp_env("PIT_RR_CFG");                 // experiments: "rm,rn,bk,workgroups per CU,LDS padding KB"
     if (cfg) sscanf(cfg, "%d,%d,%d,%d,%d", &rm, &rn, &bk, &per_cu, &pad_kb);
     const int bm = 64 * rm, bn = 64 * rn;
     auto tiles_of = [&](const GemmArgs& g, int& tx) {
@@ -1336,7 +1345,7 @@ void launch_gemm_rr(const GemmArgs& g1, const GemmArgs* g2, hipStream_t s) {
 }
 
 bool try_launch_gemm_lds(GemmArgs g, hipStream_t s) {
-    static const int mode = getenv("PIT_LDS_GEMM") ? atoi(getenv("PIT_LDS_GEMM")) : 1;   // 0 off, 1 auto, 2 always when legal
+    static const int mode = exp_env("PIT_LDS_GEMM") ? atoi(exp_env("PIT_LDS_GEMM")) : 1;   // 0 off, 1 auto, 2 always when legal
     if (mode == 0) return false;
     const int n_real = (g.ones_col >= 0) ? g.N - 1 : g.N;
     const bool a_kc = g.a_cs == 1 && g.a_rs % 4 == 0 && g.K % 4 == 0;
@@ -1346,7 +1355,7 @@ bool try_launch_gemm_lds(GemmArgs g, hipStream_t s) {
     if (!aligned16(g.A) || !aligned16(g.B) || (g.a_gz && !aligned16(g.a_gz))) return false;
     const bool io16 = g.a16 || g.b16 || g.c16 || g.z16 || g.g16;
     if (io16) {                                      // bf16 storage: gemm_bfl_kernel only, and only the layouts it stages
-        if (!g.bf16 || getenv("PIT_BF16_LEGACY") || g.a_gz) return false;
+        if (!g.bf16 || exp_env("PIT_BF16_LEGACY") || g.a_gz) return false;
         if (g.a16 && !((a_kc && g.a_rs % 8 == 0 && g.K % 8 == 0) || (g.epi == EPI_ATOMIC && a_ic && g.a_cs % 2 == 0 && g.M % 2 == 0))) return false;
         if (g.b16 && !(g.epi == EPI_ATOMIC && b_ic && g.b_rs % 2 == 0 && n_real % 2 == 0)) return false;
         if ((g.c16 || g.z16 || g.g16) && g.epi == EPI_ATOMIC) return false;
@@ -1361,7 +1370,7 @@ bool try_launch_gemm_lds(GemmArgs g, hipStream_t s) {
     else if (a_kc && b_kc && !g.a_gz && (g.epi == EPI_BIAS || g.epi == EPI_BIAS_GELU)) kind = (g.epi == EPI_BIAS) ? 0 : 1;
     else if (a_kc && b_ic && (g.epi == EPI_MUL_GELU_GRAD || g.epi == EPI_STORE)) kind = (g.epi == EPI_MUL_GELU_GRAD) ? 2 : 3;
     if (kind < 0) return false;
-    static const bool no_agz = getenv("PIT_NO_FUSED_GELU_PROLOGUE") != nullptr;
+    static const bool no_agz = exp_env("PIT_NO_FUSED_GELU_PROLOGUE") != nullptr;
     bool agz = false;
     if (g.a_gz) {                                    // trailing-gelu prologue
         if (!g.a_out || g.a_out_cs != 1 || g.a_out_rs % 4 != 0 || !aligned16(g.a_out)) return false;
@@ -1386,11 +1395,11 @@ bool try_launch_gemm_lds(GemmArgs g, hipStream_t s) {
     // at 65 536 rows: forward 49.1 -> 42.5 us, backward data path 59.8 -> 51.9 us, Darcy b=256 step 2.04 -> 1.94 ms
     // (N <= 256 only: the decoder's K = 256, N = 768 GEMMs are compute-bound at 70 % MFMA busy and keep the tall tile -
     // Vorticity bf16 1.249 -> 1.221 ms with the limit)
-    static const int short_n = getenv("PIT_LDS_SHORT_N") ? atoi(getenv("PIT_LDS_SHORT_N")) : 256;
+    static const int short_n = exp_env("PIT_LDS_SHORT_N") ? atoi(exp_env("PIT_LDS_SHORT_N")) : 256;
     if (bm == 128 && g.epi != EPI_ATOMIC && g.K <= 256 && g.N <= short_n) bm = 64;
-    static const int force_bm = getenv("PIT_LDS_BM") ? atoi(getenv("PIT_LDS_BM")) : 0;      // experiments
+    static const int force_bm = exp_env("PIT_LDS_BM") ? atoi(exp_env("PIT_LDS_BM")) : 0;      // experiments
     if (force_bm && g.epi != EPI_ATOMIC) bm = force_bm;
-    static const bool no32 = getenv("PIT_LDS_NO_BM32") != nullptr;
+    static const bool no32 = exp_env("PIT_LDS_NO_BM32") != nullptr;
     if (!force_bm && bm == 64 && (long)gx * ((g.M + 63) / 64) < 512 && !no32) bm = 32;
     const int gy = (g.M + bm - 1) / bm;
     int splits = 1;
@@ -1403,7 +1412,7 @@ bool try_launch_gemm_lds(GemmArgs g, hipStream_t s) {
         g.k_slab = slab;
     }
     dim3 grid(gx, gy, splits), block(256);
-    static const bool no_remap = getenv("PIT_NO_GEMM_XCD_REMAP") != nullptr;
+    static const bool no_remap = exp_env("PIT_NO_GEMM_XCD_REMAP") != nullptr;
     if (!no_remap && g.epi != EPI_ATOMIC && gx >= 2 && gy >= 64 && 8L * gx * ((gy + 7) / 8) < 0x7fffffffL) {
         g.remap_gx = gx; g.remap_gy = gy;
         grid = dim3((unsigned)(8 * gx * ((gy + 7) / 8)), 1, 1);
@@ -1425,9 +1434,13 @@ bool try_launch_gemm_lds(GemmArgs g, hipStream_t s) {
         else if (bm == 64) hipLaunchKernelGGL((gemm_bfl_kernel<64, A_, B_, EPI_, false, BKF64>), grid, block, 0, s, g);    \
         else hipLaunchKernelGGL((gemm_bfl_kernel<32, A_, B_, EPI_, false, BKF64>), grid, block, 0, s, g);      \
     } while (0)
-    static const bool legacy_bf = getenv("PIT_BF16_LEGACY") != nullptr;      // the round-1 form: fp32 in LDS, 32x32x8 MFMA
-    static const bool no_rr = getenv("PIT_NO_GEMM_RR") != nullptr;           // the round-2 kernel for the fp32 weight gradients
+    static const bool legacy_bf = exp_env("PIT_BF16_LEGACY") != nullptr;      // the round-1 form: fp32 in LDS, 32x32x8 MFMA
+    static const bool no_rr = exp_env("PIT_NO_GEMM_RR") != nullptr;           // the round-2 kernel for the fp32 weight gradients
+#ifdef PIT_EXPERIMENTS
 #define PIT_LDS(A_, B_, EPI_) do { if (g.bf16 && !legacy_bf) PIT_BFL(A_, B_, EPI_); else if (g.bf16) PIT_LDS_BF(A_, B_, EPI_, true); else PIT_LDS_BF(A_, B_, EPI_, false); } while (0)
+#else
+#define PIT_LDS(A_, B_, EPI_) do { (void)legacy_bf; if (g.bf16) PIT_BFL(A_, B_, EPI_); else PIT_LDS_BF(A_, B_, EPI_, false); } while (0)
+#endif
     switch (kind) {
         case 0: PIT_LDS(true, true, EPI_BIAS); break;
         case 1: PIT_LDS(true, true, EPI_BIAS_GELU); break;
@@ -1443,7 +1456,9 @@ bool try_launch_gemm_lds(GemmArgs g, hipStream_t s) {
             if (g.bf16 && !legacy_bf && io16) hipLaunchKernelGGL((gemm_bfl_kernel<128, false, false, EPI_ATOMIC, true, BK128>), grid, block, 0, s, g);
             else if (!no_rr && gemm_rr_ok(g)) launch_gemm_rr(g, nullptr, s);
             else if (g.bf16 && !legacy_bf) hipLaunchKernelGGL((gemm_bfl_kernel<128, false, false, EPI_ATOMIC, false, BKF128>), grid, block, 0, s, g);
+#ifdef PIT_EXPERIMENTS
             else if (g.bf16) hipLaunchKernelGGL((gemm_lds_kernel<128, false, false, EPI_ATOMIC, true>), grid, block, 0, s, g);
+#endif
             else hipLaunchKernelGGL((gemm_lds_kernel<128, false, false, EPI_ATOMIC, false>), grid, block, 0, s, g);
             break;
     }
@@ -1468,7 +1483,7 @@ int prepare_gemm(GemmArgs& g, GemmLaunch& L, int force_tn = 0, int force_waves =
     if (ab > PIT_MAX_BUFFER_BYTES || bb > PIT_MAX_BUFFER_BYTES) return PIT_ERR_UNSUPPORTED;
     g.a_bytes = (unsigned)ab; g.b_bytes = (unsigned)bb;
     g.bf16 = (t_call_math == PIT_MATH_BF16);
-    static const int seq_epi = getenv("PIT_GEMM_RD_SEQ_EPI") != nullptr;
+    static const int seq_epi = exp_env("PIT_GEMM_RD_SEQ_EPI") != nullptr;
     g.seq_epi = seq_epi;
     g.a_vec = vec_ok(g.A, g.a_rs, g.a_cs) && (!g.a_gz || vec_ok(g.a_gz, g.a_rs, g.a_cs));
     g.b_vec = vec_ok(g.B, g.b_cs, g.b_rs);
@@ -1528,7 +1543,7 @@ int launch_gemm(GemmArgs g, hipStream_t s) {
 int launch_gemm_pair_atomic(GemmArgs g1, GemmArgs g2, hipStream_t s) {
     const bool io16 = g1.a16 || g1.b16 || g2.a16 || g2.b16;
     if (io16 || (long)g1.M * g1.N * g1.K + (long)g2.M * g2.N * g2.K > (1L << 28)) {
-        static const bool no_rr = getenv("PIT_NO_GEMM_RR") != nullptr || getenv("PIT_NO_GEMM_RR_PAIR") != nullptr;
+        static const bool no_rr = exp_env("PIT_NO_GEMM_RR") != nullptr || exp_env("PIT_NO_GEMM_RR_PAIR") != nullptr;
         if (!no_rr && !io16 && g1.K == g2.K && std::min(g1.N, g2.N) >= 48 && std::min(g1.M, g2.M) >= 32) {
             GemmLaunch L;
             if (int rc = prepare_gemm(g1, L)) return rc;           // (operand extents, math mode)
@@ -1554,7 +1569,7 @@ int launch_gemm_pair_atomic(GemmArgs g1, GemmArgs g2, hipStream_t s) {
 // dX GEMM + both weight-gradient reductions in one launch when everything is small; otherwise the
 // dX GEMM alone followed by launch_gemm_pair_atomic
 int launch_gemm_bwd_tail(GemmArgs gx, GemmArgs g1, GemmArgs g2, hipStream_t s) {
-    static const bool off = getenv("PIT_NO_BWD_PAIR") != nullptr;
+    static const bool off = exp_env("PIT_NO_BWD_PAIR") != nullptr;
     const long work = (long)gx.M * gx.N * gx.K + (long)g1.M * g1.N * g1.K + (long)g2.M * g2.N * g2.K;
     // the dX GEMM runs with 8 k-splitting waves here: only worth it while it is itself tiny
     const bool io16 = gx.a16 || gx.c16 || g1.a16 || g1.b16 || g2.a16 || g2.b16;
@@ -1642,7 +1657,7 @@ int launch_dz1(int rows, int n1, int n2, const float* w2, const float* z1, const
 // the reductions of a postponed pit_mlp_bwd_params, laid out for a launch that carries them along
 // (pit_posatt.hip: posatt_bwd_pair_dw_kernel); same tiling as launch_gemm_pair_atomic
 bool pit_detail::plan_dw_pair(const pit_mlp_params_job& j, int waves, DwPair* out, int target_wgs, bool allow_rr) {
-    static const bool off = getenv("PIT_NO_DW_RIDER") != nullptr;
+    static const bool off = exp_env("PIT_NO_DW_RIDER") != nullptr;
     if (off || !j.accumulate) return false;
     if (!j.x || !j.h || !j.d_y || !j.d_w1 || !j.d_b1 || !j.d_w2 || !j.d_b2 || !j.scratch) return false;
     if (j.rows <= 0 || j.n0 <= 0 || j.n1 <= 0 || j.n2 <= 0) return false;
@@ -1666,8 +1681,8 @@ bool pit_detail::plan_dw_pair(const pit_mlp_params_job& j, int waves, DwPair* ou
     // a reduction with full 64-wide tiles rides as gemm_rr_tile tiles when the carrying kernel can run them: LDS-staged,
     // coalesced, a few chunks per workgroup - the register-direct form of the same reduction keeps 6-12x as many
     // workgroups busy for the same MACs and lengthens the launch it rides in
-    static const bool no_rr = getenv("PIT_NO_RR_RIDER") != nullptr;
-    static const int per_wg = getenv("PIT_RR_RIDER_CHUNKS") ? std::max(1, atoi(getenv("PIT_RR_RIDER_CHUNKS"))) : 2;
+    static const bool no_rr = exp_env("PIT_NO_RR_RIDER") != nullptr;
+    static const int per_wg = exp_env("PIT_RR_RIDER_CHUNKS") ? std::max(1, atoi(exp_env("PIT_RR_RIDER_CHUNKS"))) : 2;
     if (allow_rr && !no_rr && (j.math_mode & 0xff) == 0) {
         auto as_rr = [&](const GemmArgs& g, int& rr, int& tx, int& tiles, int& slabs, int& n) {
             const int n_real = g.ones_col >= 0 ? g.N - 1 : g.N;
@@ -1687,8 +1702,8 @@ bool pit_detail::plan_dw_pair(const pit_mlp_params_job& j, int waves, DwPair* ou
 // include/pit_hip.h: the shapes whose forward / backward run entirely on the kernels that honour the PIT_IO_* flags (the
 // thin output-layer kernels + gemm_bfl_kernel)
 extern "C" int pit_mlp_bf16_io_supported(int rows, int n0, int n1, int n2, int out_gelu) {
-    static const bool off = getenv("PIT_NO_BF16_IO") != nullptr || getenv("PIT_NO_THIN_GEMM") != nullptr ||
-                            getenv("PIT_BF16_LEGACY") != nullptr || (getenv("PIT_LDS_GEMM") && atoi(getenv("PIT_LDS_GEMM")) == 0);
+    static const bool off = exp_env("PIT_NO_BF16_IO") != nullptr || exp_env("PIT_NO_THIN_GEMM") != nullptr ||
+                            exp_env("PIT_BF16_LEGACY") != nullptr || (exp_env("PIT_LDS_GEMM") && atoi(exp_env("PIT_LDS_GEMM")) == 0);
     if (off || out_gelu) return 0;
     if (n2 < 1 || n2 > THIN_MAX || n0 % 8 != 0 || n1 % 8 != 0 || n0 < 48 || n1 < 48) return 0;
     return (long)rows * n1 >= (1L << 19) && rows >= 8192 && (long)rows * n1 * n0 >= (1L << 27);
@@ -1703,7 +1718,7 @@ bool try_launch_mlp_bwd64(int rows, int n0, int n1, int n2, const float* w1, con
 bool pit_mlp_slab_preferred(int rows, int n0, int n1, int n2);
 
 extern "C" int pit_mlp_bwd_params_deferrable(int rows, int n0, int n1, int n2, int out_gelu, long ld_dy) {
-    static const bool off = getenv("PIT_NO_DW_RIDER") != nullptr;
+    static const bool off = exp_env("PIT_NO_DW_RIDER") != nullptr;
     return !off && (!out_gelu || ld_dy == n2) && mlp_bwd16_eligible(rows, n0, n1, n2);
 }
 

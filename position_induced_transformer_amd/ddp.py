@@ -131,7 +131,12 @@ def broadcast_parameters(module: torch.nn.Module, src: int = 0, group=None) -> N
     if not (dist.is_available() and dist.is_initialized()):
         return
     for t in list(module.parameters()) + list(module.buffers()):
-        dist.broadcast(t.data, src=src, group=group)
+        if t.is_cuda and dist.get_backend(group) == "gloo":       # (tests that share one GPU between ranks: through the host)
+            host = t.data.cpu()
+            dist.broadcast(host, src=src, group=group)
+            t.data.copy_(host)
+        else:
+            dist.broadcast(t.data, src=src, group=group)
 
 
 def shard_batch(n_items: int, rank: int, world: int) -> slice:

@@ -1699,6 +1699,10 @@ def decoder_apply(values: torch.Tensor, lmda: torch.Tensor, plan: MeshPlan, n_he
 # The (batch, n_out, H*hid) tensor of pit.py:125 and the three GEMMs on its rows are gone; nothing of size n_out x hid is saved
 # except z itself.  PIT_FOLD_DECODER=0: the round-5 path (attention output materialised, kaiming_mlp kernels).
 FOLD_DECODER = os.environ.get("PIT_FOLD_DECODER", "1") != "0"
+# hid 32 / 64 models on batch-free meshes: rows (batch x output points) from which pit.decoder prefers the folded decoder to the
+# fused one-launch-per-direction decoder of csrc/pit_edge.hip (which recomputes nothing but pays 16-row slabs: one gather of the
+# union's value rows and one pass of atomic adds per 16 rows)
+FOLD_EDGE_ROWS = int(os.environ.get("PIT_FOLD_EDGE_ROWS", "300000"))      # Darcy: batch 128 0.974 vs 0.979 ms, batch 256 1.789 vs 1.711
 _ZERO_BIAS = {}
 
 

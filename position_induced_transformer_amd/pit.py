@@ -489,6 +489,11 @@ class pit(nn.Module):
                 and type(de) is kaiming_mlp and isinstance(up, posatt) and de.mlp2.out_features <= 4 \
                 and de.mlp1.out_features == func_ltt.shape[-1] and de.mlp1.in_features == up.n_head * func_ltt.shape[-1]:
             plan = self._edge_layer(up, de, mesh_out, mesh_ltt, func_ltt.shape[0], func_ltt.device, True)
+            if plan is not None and func_ltt.shape[0] * plan.n_out >= ops.FOLD_EDGE_ROWS:
+                # many rows: the folded decoder (below) moves de.mlp1 to the latent points and adds d(values) once per TALL slab
+                folded = self._folded_decoder(mesh_ltt, func_ltt, mesh_out)
+                if folded is not None:
+                    return folded
             if plan is not None and plan.n_in == func_ltt.shape[1]:
                 return ops.decoder_apply(func_ltt, up.lmda, plan, up.n_head,
                                          (de.mlp1.weight, de.mlp1.bias, de.mlp2.weight, de.mlp2.bias))

@@ -1,7 +1,10 @@
 """GPU: round 6 - the decoder side with de.mlp1 folded into the values (csrc/pit_fold.hip): the bias-free Linear on the latent
 points, the fold attention launches on tall slabs (fp32 and bf16 MFMA flavours), the thin tail, each against the oracle
 (pit.py:124-127: de(up(values)))."""
+import json
 import os
+import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -206,3 +209,57 @@ def test_models_take_the_folded_decoder_where_it_pays():
     finally:
         ops.fold_decoder_apply = orig
     torch.cuda.synchronize()
+
+
+# --------------------------------------------------------------------------- the N > 1 bench line proves itself
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _bench_child(nproc, extra):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(nproc), "--steps", "5", "--warmup", "2",
+           "--no-extras", "--no-cpu-baseline", "--ddp-sweep"] + extra
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    said = "\n--- child stdout ---\n" + res.stdout[-3000:] + "\n--- child stderr ---\n" + res.stderr[-6000:]
+    assert res.returncode == 0, said
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, said
+    return json.loads(lines[0]), said
+
+
+def _check_parity_block(p, said):
+    assert "error" not in p, said
+    tol = p["tolerance"]
+    assert p["rel_l2_out"] <= tol["out"] and p["rel_loss"] <= 1e-5, p
+    assert p["rel_l2_weight_grad_worst"] <= tol["weight_grad"], p
+    assert p["rel_l2_dlmda_all_layers"] <= tol["dlmda_all_layers"], p
+
+
+def test_one_rank_bench_line_carries_the_ddp_parity_block_and_the_saturated_point():
+    """`torch.distributed.run --nproc-per-node 1 bench.py` (the driver's N > 1 launch with one rank): the record carries
+    `parity_ddp` - the all-reduced (RCCL, captured in the hipGraph) flat gradient against the oracle on the global batch rebuilt
+    from the ranks' seeds - and the collective saturated-batch scaling point."""
+    rec, said = _bench_child(1, ["--sweep-batch", "32"])
+    assert rec["config"]["allreduce"]["backend"] == "nccl" and rec["config"]["allreduce"]["captured"] is True
+    assert rec["parity_ddp"]["world"] == 1
+    _check_parity_block(rec["parity_ddp"], said)
+    sweep = rec["batch_sweep_ddp_samples_per_s"]
+    assert "error" not in sweep and sweep["32"] > rec["value"], (sweep, rec["value"])
+
+
+def test_two_ranks_on_one_gpu_bench_line_proves_the_summed_gradient():
+    """Two ranks of bench.py sharing this box's one MI355X (backend gloo: the flat gradient is exchanged through the host, outside
+    the graph): each runs the HIP step on its own shard (seeds 100 + rank); `parity_ddp` holds the exchanged gradient to the
+    oracle's gradient of the 16-sample GLOBAL batch, the summed loss to its loss, rank 0's prediction to its shard's - the
+    W-rank == 1-rank check of SURVEY 8(e) on the product path, with W = 2."""
+    rec, said = _bench_child(2, ["--backend", "gloo", "--device-index", "0", "--sweep-batch", "16"])
+    assert rec["n_gpus"] == 2 and rec["config"]["global_batch"] == 16
+    assert rec["config"]["allreduce"]["backend"] == "gloo" and rec["config"]["allreduce"]["captured"] is False
+    assert rec["parity_ddp"]["world"] == 2
+    _check_parity_block(rec["parity_ddp"], said)
+    assert "error" not in rec["batch_sweep_ddp_samples_per_s"], said
