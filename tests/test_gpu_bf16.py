@@ -205,13 +205,23 @@ def test_graph_keeps_the_mode_it_was_captured_with(bf16):
 
 # --------------------------------------------------------------------------- bf16 STORAGE of the decoder tail (round 3)
 def _count_bf16_outputs(ops):
+    """Counts the attention forwards whose output is bf16-stored: the candidate-list / union-tile kernels (_PosAtt) and, since
+    round 6, the fold attention of the folded decoder (_FoldAtt: Vorticity's decoder)."""
     calls = {"bf16_out": 0}
     orig = ops._PosAtt.forward
+    orig_fold = ops._FoldAtt.forward
 
     def spy(ctx, *a, **k):
         out = orig(ctx, *a, **k)
         calls["bf16_out"] += int(out.dtype == torch.bfloat16)
         return out
+
+    def spy_fold(ctx, *a, **k):
+        out = orig_fold(ctx, *a, **k)
+        calls["bf16_out"] += int(out.dtype == torch.bfloat16)
+        return out
+    ops._FoldAtt.forward = staticmethod(spy_fold)
+    calls["_restore_fold"] = lambda: setattr(ops._FoldAtt, "forward", staticmethod(orig_fold))
     return calls, orig, spy
 
 
@@ -269,6 +279,7 @@ def test_bf16_mode_full_size_vs_oracle(task, batch, bf16):
             loss.backward()
     finally:
         ops._PosAtt.forward = staticmethod(orig)
+        calls["_restore_fold"]()
     torch.cuda.synchronize()
     assert calls["bf16_out"] == 1, "the decoder tail did not take the bf16-storage kernels"
     p = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in model.state_dict().items()}

@@ -250,11 +250,13 @@ def test_prediction_that_is_post_processed_keeps_the_loss_launch():
     assert all(torch.isfinite(q.grad).all() and float(q.grad.abs().max()) > 0 for q in model.parameters())
 
 
-def test_large_batch_step_on_the_large_regime_kernels_matches_the_oracle():
+@pytest.mark.parametrize("decoder", ["folded", "fused"])
+def test_large_batch_step_on_the_large_regime_kernels_matches_the_oracle(decoder):
     """Darcy at batch 256 (the large-regime paths had no direct test): 65 536 latent rows take the precomputed-weights
-    self-attention (pit_posatt_pre_fwd / _bwd) and the 64-row-slab MLP kernels (pit_mlp_slab.hip), 473 344 decoder rows the fused
-    decoder launches with the loss inside - forward, loss and every gradient of the flat buffer against the oracle.  (The
-    weight-gradient tolerance grows with the square root of the rows summed, as in bench.parity_vs_oracle.)"""
+    self-attention (pit_posatt_pre_fwd / _bwd) and the 64-row-slab MLP kernels (pit_mlp_slab.hip); the 473 344 decoder rows the
+    folded decoder (round 6: from ops.FOLD_EDGE_ROWS rows) or - the threshold moved away - the fused decoder launches with the
+    loss inside: forward, loss and every gradient of the flat buffer against the oracle.  (The weight-gradient tolerance grows
+    with the square root of the rows summed, as in bench.parity_vs_oracle.)"""
     from position_induced_transformer_amd import ops, tasks
     from position_induced_transformer_amd.engine import TrainStep
     model, sample, meta = tasks.make_task("darcy", seed=58)
@@ -266,15 +268,20 @@ def test_large_batch_step_on_the_large_regime_kernels_matches_the_oracle():
         calls["pre"] += 1
         return orig(*a, **k)
     ops.posatt_pre_apply = counting
+    saved = ops.FOLD_EDGE_ROWS
+    if decoder == "fused":
+        ops.FOLD_EDGE_ROWS = 1 << 62
     try:
-        with ops.head_scale_route("host"), _Count("decoder_apply") as cd:
+        with ops.head_scale_route("host"), _Count("decoder_apply") as cd, _Count("fold_decoder_apply") as cf:
             step = TrainStep(model, b4, meta["out_dim"], meta["p"])
             step.run_eager()
             step.run_eager()
     finally:
         ops.posatt_pre_apply = orig
+        ops.FOLD_EDGE_ROWS = saved
     torch.cuda.synchronize()
-    assert calls["pre"] >= len(model.conv) and cd.n >= 1
+    assert calls["pre"] >= len(model.conv)
+    assert (cf.n >= 1 and cd.n == 0) if decoder == "folded" else (cd.n >= 1 and cf.n == 0), (cd.n, cf.n)
     ref, ref_loss, ref_grads = _oracle_step("darcy", model, b4, None, meta)
     assert gio.rel_l2(step.out.cpu().numpy(), ref.numpy()) <= 1e-5
     assert abs(float(step.loss) - ref_loss) <= 1e-5 * abs(ref_loss)
