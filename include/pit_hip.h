@@ -470,6 +470,20 @@ int pit_mlp_fwd(const float* x, long ldx, int rows, int n0, int n1, int n2,
                 const float* w1, const float* b1, const float* w2, const float* b2, int out_gelu,
                 float* z1, float* h, float* z2, float* y, long ldy, int math_mode, void* stream);
 
+/* One-launch kaiming_mlp + gelu chains of the bf16 math mode for hid 128 / 256 on a few thousand rows (round 6; csrc/pit_chain.hip):
+ * pit_mlp_fwd(..., out_gelu = 1) / pit_mlp_bwd_data as ONE launch each on 32-row slabs, the weights streamed through LDS as bf16
+ * panels.  w1_bf16 (n1, n0) / w2_bf16 (n1, n1): row-major bf16 copies of the weights (pit_cast_bf16_multi); n2 == n1 in {128, 256},
+ * n0 a multiple of n1 (the processor's (1 + H) hid), <= 1024.  z1 / h / z2 (rows, n1) fp32 as pit_mlp_fwd saves them; y rows ldy apart.
+ * Backward: scratch = dZ1 | dZ2 (rows*n1 floats each: what pit_mlp_bwd_params reads), d_x (rows, n0) rows ld_dx apart or NULL.
+ * gelu / gelu' are the polynomial CDF of the bf16 mode (pit_thin_tail_*). */
+int pit_mlp_chain_supported(int rows, int n0, int n1, int n2);
+int pit_mlp_chain_fwd(const float* x, long ldx, int rows, int n0, int n1, const unsigned short* w1_bf16, const float* b1,
+                      const unsigned short* w2_bf16, const float* b2, float* z1, float* h, float* z2, float* y, long ldy, void* stream);
+int pit_mlp_chain_bwd(int rows, int n0, int n1, const unsigned short* w1_bf16, const unsigned short* w2_bf16,
+                      const float* z1, const float* z2, const float* d_y, long ld_dy, float* d_x, long ld_dx, float* scratch, void* stream);
+/* dst[i] = bf16(src[i]) (RNE) for n <= 32 tensors of count[i] floats (multiples of 4; 16-byte aligned sources): one launch. */
+int pit_cast_bf16_multi(int n, const float* const* src, unsigned short* const* dst, const long* count, void* stream);
+
 /* Backward of pit_mlp_fwd.  d_y (rows,n2) rows ld_dy apart (ld_dy == n2 when out_gelu).
  * d_x (rows,n0) rows ld_dx apart (NULL = not needed).  d_w1,d_b1,d_w2,d_b2 receive the
  * parameter gradients through fp32 atomics over row slabs: accumulate=0 zeroes them first

@@ -84,6 +84,10 @@ SIGNATURES = {
     "pit_thin_tail_scratch_floats": [],
     "pit_thin_tail_fwd": [_P, _L, _I, _I, _I, _P, _P, _P, _P, _L, _I, _P],
     "pit_thin_tail_bwd": [_P, _L, _I, _I, _I, _P, _P, _P, _L, _P, _L, _P, _P, _P, _P, _I, _P],
+    "pit_mlp_chain_supported": [_I, _I, _I, _I],
+    "pit_mlp_chain_fwd": [_P, _L, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P],
+    "pit_mlp_chain_bwd": [_I, _I, _I, _P, _P, _P, _P, _P, _L, _P, _L, _P, _P],
+    "pit_cast_bf16_multi": [_I, _P, _P, _P, _P],
     "pit_linear_fwd": [_P, _L, _I, _I, _I, _P, _P, _P, _L, _I, _P],
     "pit_linear_bwd": [_P, _L, _I, _I, _I, _P, _P, _L, _P, _L, _P, _I, _I, _P],
     "pit_edge_supported": [_I, _I, _I, _I],

@@ -1,0 +1,427 @@
+// One-launch kaiming_mlp chains for the mid-sized processors in the bf16 math mode (round 6; pit.py:21-26 + the gelu of
+// pit.py:111,121): hid 128 / 256 on a few thousand rows (Vorticity 5 120 x 768 -> 256 -> 256, Elasticity 9 720, NACA 14 560 x
+// 256 -> 128 -> 128).
+//
+// Such an MLP ran as two GEMM launches forward (12.7 us each at Vorticity: 2.5 % MFMA busy, 45 vector instructions per MFMA - the
+// fp32 activations are rounded in-kernel, one round trip per 64-k chunk, 160-320 workgroups that each pull their weights through
+// the L1) and three launches for the backward data path (gelu' pass 5.4 + dZ1 15.4 + dX 12.0 us): 58 of a block's 122 us.  Here
+// each direction is ONE launch on 32-row slabs:
+//   mlp_chain_fwd_kernel   X slab -> LDS (bf16) once; W1 | W2 - bf16 copies formed once per weight version by the host side -
+//                          stream through LDS as 64-k panels, double-buffered, one barrier per panel, the next panel's loads in
+//                          flight under the current panel's v_mfma_f32_16x16x32_bf16; Z1 / H / Z2 / Y leave from the accumulators
+//                          (H also stays in LDS as GEMM2's A operand).
+//   mlp_chain_bwd_kernel   dZ2 = dY gelu'(Z2) -> LDS; dZ1 = (dZ2 W2) gelu'(Z1) -> LDS; dX = dZ1 W1 in n0 / n1 column chunks.  The
+//                          weights are the SAME row-major bf16 copies read as [k][n] images through ds_read_b64_tr_b16.
+// A workgroup's 512 KB of weights (hid 256) at the ~70 GB/s a CU pulls from L2 is the launch: ~8 us, whatever the slab height.
+// gelu / gelu' are the polynomial CDF of pit_common.h (the mode's operands are bf16: 8 bits): the fp32 mode never comes here.
+#include "pit_common.h"
+
+namespace {
+
+typedef short v4s_t __attribute__((ext_vector_type(4)));
+typedef short v8s_t __attribute__((ext_vector_type(8)));
+typedef __bf16 v8bf_t __attribute__((ext_vector_type(8)));
+
+constexpr int CR = 32;       // rows per workgroup
+constexpr int KP = 64;       // k per weight panel
+constexpr int PADE = 8;      // pad (bf16 elements) of every LDS row: 16 bytes
+
+struct ChainArgs {
+    int rows, n0, n1;
+    const float* x; long ldx;
+    const unsigned short *w1b, *w2b;          // bf16 copies: (n1, n0) and (n1, n1), row-major
+    const float *b1, *b2;
+    float *z1, *h, *z2, *y; long ldy;
+    const float* d_y; long ld_dy;
+    const float *z1r, *z2r;
+    float* d_x; long ld_dx;
+    float *dz1, *dz2;
+};
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t wide_rsrc(const void* p) { return make_rsrc(p, 0x7ffffff0u); }
+constexpr unsigned OOB = 0x7ffffff8u;
+__device__ __forceinline__ float4 ldg4_if(const float* p, long i, bool ok) {
+    float v[4];
+    buf_load4(wide_rsrc(p), ok ? (unsigned)(i * 4) : OOB, v);
+    return make_float4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ uint2 pack4(float4 v) {
+    uint2 pk;
+    pk.x = (unsigned)f_to_bf16(v.x) | ((unsigned)f_to_bf16(v.y) << 16);
+    pk.y = (unsigned)f_to_bf16(v.z) | ((unsigned)f_to_bf16(v.w) << 16);
+    return pk;
+}
+// eight bf16 of row `row` starting at k0 of a [row][k] image (one ds_read_b128)
+__device__ __forceinline__ v8s_t frag_row(const unsigned short* t, int pitch, int row, int k0) {
+    return *reinterpret_cast<const v8s_t*>(t + row * pitch + k0);
+}
+// the lane's eight k's (k0 + 8 kq ..) of column n0 + l15 of a [k][n] image: two ds_read_b64_tr_b16 (cdna guide T10; EXEC all ones)
+__device__ __forceinline__ v8s_t frag_tr(const unsigned short* t, int pitch, int k0, int n0, int l15, int kq) {
+    const unsigned short* a0 = t + (k0 + 8 * kq + (l15 >> 2)) * pitch + n0 + 4 * (l15 & 3);
+    typedef v4s_t __attribute__((address_space(3))) * lds_v4;
+    const v4s_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(a0));
+    const v4s_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(a0 + 4 * pitch));
+    v8s_t f = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return f;
+}
+__device__ __forceinline__ f32x4 mma(v8s_t a, v8s_t b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf_t, a), __builtin_bit_cast(v8bf_t, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ float gelu_f(float t) { float e; return t * normal_cdf_fast(t, e); }
+__device__ __forceinline__ float gelu_grad_f(float t) { float e; const float c = normal_cdf_fast(t, e); return fmaf(t * 0.39894228040143267794f, e, c); }
+
+// A weight panel as 16-byte pieces (8 bf16) in registers: NPC pieces per thread.  (ext_vector_type, not HIP's uint4 struct: an
+// array of the struct type that is filled from memory and consumed behind a barrier is kept in scratch by hipcc - DESIGN section 4.)
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+template <int NPC> struct Panel { u32x4_t v[NPC]; };
+
+// forward panels: N1 rows (output neurons) x KP k's of w (row stride ldw elements, k offset k0): image [n][KP + 8]
+template <int N1>
+__device__ __forceinline__ void fwd_panel_load(const unsigned short* w, int ldw, int k0, int tid, Panel<N1 * KP / 8 / 256>& p) {
+#pragma unroll
+    for (int u = 0; u < N1 * KP / 8 / 256; ++u) {
+        const int e = tid + 256 * u, n = e / (KP / 8), kc = e % (KP / 8);
+        p.v[u] = *reinterpret_cast<const u32x4_t*>(w + (long)n * ldw + k0 + 8 * kc);
+    }
+}
+template <int N1>
+__device__ __forceinline__ void fwd_panel_park(unsigned short* dst, int tid, const Panel<N1 * KP / 8 / 256>& p) {
+#pragma unroll
+    for (int u = 0; u < N1 * KP / 8 / 256; ++u) {
+        const int e = tid + 256 * u, n = e / (KP / 8), kc = e % (KP / 8);
+        *reinterpret_cast<u32x4_t*>(dst + n * (KP + PADE) + 8 * kc) = p.v[u];
+    }
+}
+// backward panels: KP rows (k) x N1 columns of w (row stride ldw, row offset k0, column offset c0): image [k][N1 + 8]
+template <int N1>
+__device__ __forceinline__ void bwd_panel_load(const unsigned short* w, int ldw, int k0, int c0, int tid, Panel<N1 * KP / 8 / 256>& p) {
+#pragma unroll
+    for (int u = 0; u < N1 * KP / 8 / 256; ++u) {
+        const int e = tid + 256 * u, k = e / (N1 / 8), nc = e % (N1 / 8);
+        p.v[u] = *reinterpret_cast<const u32x4_t*>(w + (long)(k0 + k) * ldw + c0 + 8 * nc);
+    }
+}
+template <int N1>
+__device__ __forceinline__ void bwd_panel_park(unsigned short* dst, int tid, const Panel<N1 * KP / 8 / 256>& p) {
+#pragma unroll
+    for (int u = 0; u < N1 * KP / 8 / 256; ++u) {
+        const int e = tid + 256 * u, k = e / (N1 / 8), nc = e % (N1 / 8);
+        *reinterpret_cast<u32x4_t*>(dst + k * (N1 + PADE) + 8 * nc) = p.v[u];
+    }
+}
+
+template <int N1>
+__global__ __launch_bounds__(256) void mlp_chain_fwd_kernel(ChainArgs g) {
+    constexpr int NC = N1 / 4, CT = NC / 16, RT = CR / 16, WP = KP + PADE, HP = N1 + PADE;
+    extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
+    const int XP = g.n0 + PADE;
+    unsigned short* xs = smem;                                   // [CR][XP]   X slab; later [CR][HP] H
+    unsigned short* wp = smem + CR * (XP > HP ? XP : HP);        // [2][N1][WP]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, kq = lane >> 4;
+    const int row0 = (int)blockIdx.x * CR;
+    const int p1 = g.n0 / KP, np = p1 + N1 / KP;                 // panels of W1, then of W2
+    // (panel p: a select on the ADDRESS, not a branch around the loads; no lambda - a panel whose address escapes lives in scratch)
+#define PIT_CHAIN_LOAD(p_) fwd_panel_load<N1>((p_) < p1 ? g.w1b : g.w2b, (p_) < p1 ? g.n0 : N1, ((p_) < p1 ? (p_) : (p_) - p1) * KP, tid, reg)
+    Panel<N1 * KP / 8 / 256> reg;
+    PIT_CHAIN_LOAD(0);
+    // the X slab: fp32 rows -> bf16 image, eight 16-byte pieces per thread and round
+    {
+        const int q4 = g.n0 / 4, total = CR * q4;
+        for (int base = 0; base < total; base += 8 * 256) {
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = base + tid + 256 * u, r = e / q4, c = e - r * q4;
+                v[u] = ldg4_if(g.x, (long)(row0 + r) * g.ldx + 4 * c, e < total && row0 + r < g.rows);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = base + tid + 256 * u, r = e / q4, c = e - r * q4;
+                if (e < total) *reinterpret_cast<uint2*>(xs + r * XP + 4 * c) = pack4(v[u]);
+            }
+        }
+    }
+    fwd_panel_park<N1>(wp, tid, reg);
+    PIT_CHAIN_LOAD(1);
+    f32x4 acc[RT][CT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int p = 0; p < np; ++p) {
+        __syncthreads();                                         // panel p parked (and, p == p1, H written) by every wave
+        if (p + 1 < np) {
+            fwd_panel_park<N1>(wp + ((p + 1) & 1) * N1 * WP, tid, reg);      // (that buffer's readers passed the barrier above)
+            if (p + 2 < np) PIT_CHAIN_LOAD(p + 2);
+        }
+        const unsigned short* a_img = p < p1 ? xs : xs;          // X before, H after (same region)
+        const int apitch = p < p1 ? XP : HP, ak0 = (p < p1 ? p : p - p1) * KP;
+        const unsigned short* wb = wp + (p & 1) * N1 * WP;
+#pragma unroll
+        for (int ks = 0; ks < KP / 32; ++ks) {
+            v8s_t a[RT];
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) a[rt] = frag_row(a_img, apitch, 16 * rt + l15, ak0 + 32 * ks + 8 * kq);
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                const v8s_t b = frag_row(wb, WP, wave * NC + 16 * ct + l15, 32 * ks + 8 * kq);
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) acc[rt][ct] = mma(a[rt], b, acc[rt][ct]);
+            }
+        }
+        if (p == p1 - 1) {
+            // GEMM1 done: Z1 = acc + b1, H = gelu(Z1) -> memory (the backward reads them) and, as bf16, the A operand of GEMM2
+            __syncthreads();                                     // every wave is through with the X image
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                const int col = wave * NC + 16 * ct + l15;
+                const float bias = g.b1[col];
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int r = 16 * rt + 4 * kq + i;
+                        const float z = acc[rt][ct][i] + bias, hv = gelu_f(z);
+                        xs[r * HP + col] = f_to_bf16(hv);
+                        if (row0 + r < g.rows) {
+                            g.z1[(long)(row0 + r) * N1 + col] = z;
+                            g.h[(long)(row0 + r) * N1 + col] = hv;
+                        }
+                        acc[rt][ct][i] = 0.0f;
+                    }
+            }
+        }
+    }
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+        const int col = wave * NC + 16 * ct + l15;
+        const float bias = g.b2[col];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = 16 * rt + 4 * kq + i;
+                if (row0 + r < g.rows) {
+                    const float z = acc[rt][ct][i] + bias;
+                    g.z2[(long)(row0 + r) * N1 + col] = z;
+                    g.y[(long)(row0 + r) * g.ldy + col] = gelu_f(z);
+                }
+            }
+    }
+}
+
+#undef PIT_CHAIN_LOAD
+
+template <int N1>
+__global__ __launch_bounds__(256) void mlp_chain_bwd_kernel(ChainArgs g) {
+    constexpr int NC = N1 / 4, CT = NC / 16, RT = CR / 16, AP = N1 + PADE, WP = N1 + PADE;
+    extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
+    unsigned short* a2s = smem;                       // [CR][AP]  dZ2
+    unsigned short* a1s = a2s + CR * AP;              // [CR][AP]  dZ1
+    unsigned short* wp = a1s + CR * AP;               // [2][KP][WP]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, kq = lane >> 4;
+    const int row0 = (int)blockIdx.x * CR;
+    constexpr int PW = N1 / KP;                       // panels per [N1 x N1] product
+    const int chunks = g.n0 / N1, np = PW * (1 + chunks);
+#define PIT_CHAIN_LOAD(p_) bwd_panel_load<N1>((p_) < PW ? g.w2b : g.w1b, (p_) < PW ? N1 : g.n0, ((p_) % PW) * KP, \
+                                             (p_) < PW ? 0 : (((p_) - PW) / PW) * N1, tid, reg)
+    Panel<N1 * KP / 8 / 256> reg;
+    PIT_CHAIN_LOAD(0);
+    // dZ2 = dY gelu'(Z2): memory (the weight-gradient reductions read it) and the bf16 A image
+    {
+        constexpr int Q4 = N1 / 4, TOTAL = CR * Q4;
+        float4 dy[TOTAL / 256], zz[TOTAL / 256];
+#pragma unroll
+        for (int u = 0; u < TOTAL / 256; ++u) {
+            const int e = tid + 256 * u, r = e / Q4, c = e % Q4;
+            const bool ok = row0 + r < g.rows;
+            dy[u] = ldg4_if(g.d_y, (long)(row0 + r) * g.ld_dy + 4 * c, ok);
+            zz[u] = ldg4_if(g.z2r, (long)(row0 + r) * N1 + 4 * c, ok);
+        }
+#pragma unroll
+        for (int u = 0; u < TOTAL / 256; ++u) {
+            const int e = tid + 256 * u, r = e / Q4, c = e % Q4;
+            const float4 v = make_float4(dy[u].x * gelu_grad_f(zz[u].x), dy[u].y * gelu_grad_f(zz[u].y),
+                                         dy[u].z * gelu_grad_f(zz[u].z), dy[u].w * gelu_grad_f(zz[u].w));
+            *reinterpret_cast<uint2*>(a2s + r * AP + 4 * c) = pack4(v);
+            if (row0 + r < g.rows) *reinterpret_cast<float4*>(g.dz2 + (long)(row0 + r) * N1 + 4 * c) = v;
+        }
+    }
+    bwd_panel_park<N1>(wp, tid, reg);
+    PIT_CHAIN_LOAD(1);
+    f32x4 acc[RT][CT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // Z1 at the accumulator positions of GEMM A's epilogue: requested now, used PW panels later
+    float z1v[RT][CT][4];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = 16 * rt + 4 * kq + i;
+                z1v[rt][ct][i] = buf_load(wide_rsrc(g.z1r), row0 + r < g.rows ? (unsigned)(((long)(row0 + r) * N1 + wave * NC + 16 * ct + l15) * 4) : OOB);
+            }
+    for (int p = 0; p < np; ++p) {
+        __syncthreads();
+        if (p + 1 < np) {
+            bwd_panel_park<N1>(wp + ((p + 1) & 1) * KP * WP, tid, reg);
+            if (p + 2 < np) PIT_CHAIN_LOAD(p + 2);
+        }
+        const unsigned short* a_img = p < PW ? a2s : a1s;
+        const int ak0 = (p < PW ? p : (p - PW) % PW) * KP;
+        const unsigned short* wb = wp + (p & 1) * KP * WP;
+#pragma unroll
+        for (int ks = 0; ks < KP / 32; ++ks) {
+            v8s_t a[RT];
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) a[rt] = frag_row(a_img, AP, 16 * rt + l15, ak0 + 32 * ks + 8 * kq);
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                const v8s_t b = frag_tr(wb, WP, 32 * ks, wave * NC + 16 * ct, l15, kq);
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) acc[rt][ct] = mma(a[rt], b, acc[rt][ct]);
+            }
+        }
+        if (p == PW - 1) {
+            // dZ1 = (dZ2 W2) gelu'(Z1) -> memory and the bf16 A image of the dX products (nobody reads a1s before the next barrier)
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                const int col = wave * NC + 16 * ct + l15;
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int r = 16 * rt + 4 * kq + i;
+                        const float v = acc[rt][ct][i] * gelu_grad_f(z1v[rt][ct][i]);
+                        a1s[r * AP + col] = f_to_bf16(v);
+                        if (row0 + r < g.rows) g.dz1[(long)(row0 + r) * N1 + col] = v;
+                        acc[rt][ct][i] = 0.0f;
+                    }
+            }
+        } else if (p >= PW && (p - PW) % PW == PW - 1) {
+            const int c = (p - PW) / PW;                       // a column chunk of dX is complete
+            if (g.d_x) {
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) {
+                    const int col = c * N1 + wave * NC + 16 * ct + l15;
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const int r = 16 * rt + 4 * kq + i;
+                            if (row0 + r < g.rows) g.d_x[(long)(row0 + r) * g.ld_dx + col] = acc[rt][ct][i];
+                        }
+                }
+            }
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+}
+
+// bf16 copies of up to 32 weight matrices in ONE launch (the chains read their weights as bf16; the copies are formed once per
+// weight version - inside a captured step once per replay - by the host side, ops.prepare_chain_weights)
+constexpr int CAST_MAX = 32;
+struct CastArgs { const float* src[CAST_MAX]; unsigned short* dst[CAST_MAX]; long n4[CAST_MAX]; int n; };
+__global__ __launch_bounds__(256) void cast_bf16_multi_kernel(CastArgs g) {
+    const int t = blockIdx.y;
+    const long n4 = g.n4[t];
+    const float4* s = reinterpret_cast<const float4*>(g.src[t]);
+    uint2* d = reinterpret_cast<uint2*>(g.dst[t]);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) d[i] = pack4(s[i]);
+}
+
+#undef PIT_CHAIN_LOAD
+
+bool chain_shape_ok(int rows, int n0, int n1, int n2) {
+    return rows > 0 && n1 == n2 && (n1 == 128 || n1 == 256) && n0 >= n1 && n0 % n1 == 0 && n0 % KP == 0 && n0 <= 1024 &&
+           (long)rows * n0 * 4 < (1L << 31) - 65536;
+}
+size_t chain_fwd_smem(int n0, int n1) { return (size_t)(CR * (std::max(n0, n1) + PADE) + 2 * n1 * (KP + PADE)) * 2; }
+size_t chain_bwd_smem(int n1) { return (size_t)(2 * CR * (n1 + PADE) + 2 * KP * (n1 + PADE)) * 2; }
+bool a16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+// 1 when pit_mlp_chain_fwd / _bwd cover kaiming_mlp (n0 -> n1 -> n2) followed by gelu on `rows` rows: hid 128 / 256, n0 a multiple
+// of the hidden width (the processor's (1 + H) hid), a few thousand rows (below: the fused small-regime kernels; far above: the
+// tiled GEMMs, whose workgroups then amortise their weights)
+extern "C" int pit_mlp_chain_supported(int rows, int n0, int n1, int n2) {
+    return chain_shape_ok(rows, n0, n1, n2) && rows >= 1024 && rows <= 65536;
+}
+
+extern "C" int pit_mlp_chain_fwd(const float* x, long ldx, int rows, int n0, int n1, const unsigned short* w1_bf16, const float* b1,
+                                 const unsigned short* w2_bf16, const float* b2, float* z1, float* h, float* z2, float* y, long ldy,
+                                 void* stream) {
+    if (!x || !w1_bf16 || !b1 || !w2_bf16 || !b2 || !z1 || !h || !z2 || !y) return PIT_ERR_NULL;
+    if (!chain_shape_ok(rows, n0, n1, n1) || ldx < n0 || ldy < n1) return PIT_ERR_UNSUPPORTED;
+    if (ldx % 4 || !a16(x) || !a16(w1_bf16) || !a16(w2_bf16)) return PIT_ERR_SIZE;
+    ChainArgs g = ChainArgs();
+    g.rows = rows; g.n0 = n0; g.n1 = n1; g.x = x; g.ldx = ldx; g.w1b = w1_bf16; g.w2b = w2_bf16; g.b1 = b1; g.b2 = b2;
+    g.z1 = z1; g.h = h; g.z2 = z2; g.y = y; g.ldy = ldy;
+    const dim3 grid((unsigned)((rows + CR - 1) / CR));
+    const size_t sm = chain_fwd_smem(n0, n1);
+    hipStream_t s = (hipStream_t)stream;
+    if (n1 == 256) {
+        static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_chain_fwd_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
+        (void)once;
+        hipLaunchKernelGGL((mlp_chain_fwd_kernel<256>), grid, dim3(256), sm, s, g);
+    } else {
+        static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_chain_fwd_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
+        (void)once;
+        hipLaunchKernelGGL((mlp_chain_fwd_kernel<128>), grid, dim3(256), sm, s, g);
+    }
+    PIT_CHECK_LAUNCH();
+    return 0;
+}
+
+// The data path of the backward: scratch = dZ1 (rows*n1) | dZ2 (rows*n1) fp32 - the layout pit_mlp_bwd_params reads - and d_x (NULL:
+// not needed).  d_y rows ld_dy apart.
+extern "C" int pit_mlp_chain_bwd(int rows, int n0, int n1, const unsigned short* w1_bf16, const unsigned short* w2_bf16,
+                                 const float* z1, const float* z2, const float* d_y, long ld_dy, float* d_x, long ld_dx,
+                                 float* scratch, void* stream) {
+    if (!w1_bf16 || !w2_bf16 || !z1 || !z2 || !d_y || !scratch) return PIT_ERR_NULL;
+    if (!chain_shape_ok(rows, n0, n1, n1) || ld_dy < n1 || (d_x && ld_dx < n0)) return PIT_ERR_UNSUPPORTED;
+    if (ld_dy % 4 || !a16(d_y) || !a16(z2) || !a16(w1_bf16) || !a16(w2_bf16) || !a16(scratch)) return PIT_ERR_SIZE;
+    ChainArgs g = ChainArgs();
+    g.rows = rows; g.n0 = n0; g.n1 = n1; g.w1b = w1_bf16; g.w2b = w2_bf16; g.z1r = z1; g.z2r = z2; g.d_y = d_y; g.ld_dy = ld_dy;
+    g.d_x = d_x; g.ld_dx = ld_dx; g.dz1 = scratch; g.dz2 = scratch + (long)rows * n1;
+    const dim3 grid((unsigned)((rows + CR - 1) / CR));
+    const size_t sm = chain_bwd_smem(n1);
+    hipStream_t s = (hipStream_t)stream;
+    if (n1 == 256) {
+        static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_chain_bwd_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
+        (void)once;
+        hipLaunchKernelGGL((mlp_chain_bwd_kernel<256>), grid, dim3(256), sm, s, g);
+    } else {
+        static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_chain_bwd_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
+        (void)once;
+        hipLaunchKernelGGL((mlp_chain_bwd_kernel<128>), grid, dim3(256), sm, s, g);
+    }
+    PIT_CHECK_LAUNCH();
+    return 0;
+}
+
+// dst[i] = bf16(src[i]) (round to nearest even) for n tensors of count[i] floats each (multiples of 4, 16-byte aligned): one launch
+extern "C" int pit_cast_bf16_multi(int n, const float* const* src, unsigned short* const* dst, const long* count, void* stream) {
+    if (n <= 0 || n > CAST_MAX || !src || !dst || !count) return PIT_ERR_SIZE;
+    CastArgs g = CastArgs();
+    long most = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!src[i] || !dst[i]) return PIT_ERR_NULL;
+        if (count[i] <= 0 || count[i] % 4 || !a16(src[i]) || (reinterpret_cast<uintptr_t>(dst[i]) & 7)) return PIT_ERR_SIZE;
+        g.src[i] = src[i]; g.dst[i] = dst[i]; g.n4[i] = count[i] / 4;
+        most = std::max(most, g.n4[i]);
+    }
+    g.n = n;
+    const unsigned gx = (unsigned)std::max<long>(1, std::min<long>((most + 255) / 256, 64));
+    hipLaunchKernelGGL(cast_bf16_multi_kernel, dim3(gx, (unsigned)n), dim3(256), 0, (hipStream_t)stream, g);
+    PIT_CHECK_LAUNCH();
+    return 0;
+}

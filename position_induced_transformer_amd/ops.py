@@ -11,6 +11,7 @@ import ctypes
 import math
 import os
 import threading
+from collections import OrderedDict
 from typing import Optional
 
 import numpy as np
@@ -950,6 +951,75 @@ def posatt_apply(values: torch.Tensor, lmda: torch.Tensor, plan: MeshPlan, n_hea
                          out_bf16)
 
 
+# ---- one-launch MLP chains of the bf16 math mode (csrc/pit_chain.hip): hid 128 / 256 on a few thousand rows ----------------------
+# The chains read their weights as bf16: copies are kept per weight tensor and re-formed when the weight changed (version counter /
+# parameters_changed() epoch) - all requested copies in ONE launch.  Inside a stream capture nothing can be known about the
+# weights at replay time (an optimizer between replays, or inside the graph): the cast is then always part of the graph, once per
+# forward pass (pit.processor requests every block's weights at its entry: prepare_chain_weights).
+CHAIN_MLP = os.environ.get("PIT_CHAIN_MLP", "1") != "0"
+_BF16_W = OrderedDict()          # (data_ptr, numel) -> [bf16 tensor, version, epoch]
+_BF16_W_MAX = 128
+
+
+def chain_mlp_supported(rows: int, n0: int, n1: int, n2: int, out_gelu: bool) -> bool:
+    return bool(CHAIN_MLP and out_gelu and get_math_mode() == "bf16"
+                and _lib.lib().pit_mlp_chain_supported(int(rows), int(n0), int(n1), int(n2)))
+
+
+def bf16_weights(tensors, new_pass: bool = False):
+    """bf16 copies (RNE) of contiguous fp32 weight tensors, cached; see the section comment."""
+    cap = _capturing()
+    if new_pass:
+        _STEP.cap_fresh = set()
+    fresh = getattr(_STEP, "cap_fresh", None) if cap else None
+    out, need = [], []
+    for t in tensors:
+        key = (t.data_ptr(), t.numel())
+        ent = _BF16_W.get(key)
+        if ent is None:
+            while len(_BF16_W) >= _BF16_W_MAX:
+                _BF16_W.popitem(last=False)
+            ent = _BF16_W[key] = [torch.empty(t.shape, device=t.device, dtype=torch.bfloat16), -1, -1]
+        else:
+            _BF16_W.move_to_end(key)
+        if cap:
+            _pin(ent[0])
+            stale = fresh is None or key not in fresh
+        else:
+            stale = ent[1] != t._version or ent[2] != _PARAM_EPOCH[0]
+        if stale:
+            need.append((t, ent, key))
+        out.append(ent[0])
+    if need:
+        n = len(need)
+        src = (ctypes.c_void_p * n)(*[t.data_ptr() for t, _e, _k in need])
+        dst = (ctypes.c_void_p * n)(*[e[0].data_ptr() for _t, e, _k in need])
+        cnt = (ctypes.c_long * n)(*[t.numel() for t, _e, _k in need])
+        rc = _lib.lib().pit_cast_bf16_multi(n, src, dst, cnt, _lib.stream_ptr())
+        _lib.check(rc, "pit_cast_bf16_multi")
+        for t, ent, key in need:
+            if cap:                       # recorded, not executed: the copy in memory is NOT this version
+                ent[1] = ent[2] = -1
+                if fresh is None:
+                    fresh = _STEP.cap_fresh = set()
+                fresh.add(key)
+            else:
+                ent[1], ent[2] = t._version, _PARAM_EPOCH[0]
+    return out
+
+
+def prepare_chain_weights(mlps, rows: int) -> None:
+    """pit.processor's entry: the bf16 copies of every block MLP's weights that will take the chain launches, in one launch."""
+    ws = []
+    for w1, w2 in mlps:
+        n1, n0 = w1.shape
+        if w2.shape == (n1, n1) and chain_mlp_supported(rows, n0, n1, n1, True) and w1.is_cuda and w1.is_contiguous() \
+                and w2.is_contiguous() and w1.dtype == torch.float32:
+            ws += [w1.detach(), w2.detach()]
+    if ws:
+        bf16_weights(ws[:32], new_pass=True)
+
+
 class _Mlp(torch.autograd.Function):
     """kaiming_mlp forward/backward, optionally with the trailing gelu of pit.py:111,121."""
 
@@ -983,11 +1053,21 @@ class _Mlp(torch.autograd.Function):
             y = torch.empty((rows, n2), device=dev, dtype=torch.float32)
         ctx.math = _math_code() | ((IO_X_BF16 | IO_SAVE_BF16 | IO_DX_BF16) if x16 else 0)
         ctx.x16 = x16
-        rc = _lib.lib().pit_mlp_fwd(x2.data_ptr(), x2.stride(0), rows, n0, n1, n2, w1c.data_ptr(), b1c.data_ptr(),
-                                    w2c.data_ptr(), b2c.data_ptr(), 1 if out_gelu else 0, z1.data_ptr(),
-                                    h.data_ptr(), _lib.ptr(z2), y.data_ptr(), y.stride(0), ctx.math & ~IO_DX_BF16,
-                                    _lib.stream_ptr())
-        _lib.check(rc, "pit_mlp_fwd")
+        ctx.chain = None
+        if not x16 and chain_mlp_supported(rows, n0, n1, n2, out_gelu) and x2.stride(0) % 4 == 0 and x2.data_ptr() % 16 == 0:
+            # bf16 mode, hid 128 / 256, a few thousand rows: GEMM1 + gelu + GEMM2 + gelu in ONE launch (csrc/pit_chain.hip)
+            w1b, w2b = bf16_weights([w1c, w2c])
+            rc = _lib.lib().pit_mlp_chain_fwd(x2.data_ptr(), x2.stride(0), rows, n0, n1, w1b.data_ptr(), b1c.data_ptr(),
+                                              w2b.data_ptr(), b2c.data_ptr(), z1.data_ptr(), h.data_ptr(), z2.data_ptr(),
+                                              y.data_ptr(), y.stride(0), _lib.stream_ptr())
+            _lib.check(rc, "pit_mlp_chain_fwd")
+            ctx.chain = (w1b, w2b)
+        else:
+            rc = _lib.lib().pit_mlp_fwd(x2.data_ptr(), x2.stride(0), rows, n0, n1, n2, w1c.data_ptr(), b1c.data_ptr(),
+                                        w2c.data_ptr(), b2c.data_ptr(), 1 if out_gelu else 0, z1.data_ptr(),
+                                        h.data_ptr(), _lib.ptr(z2), y.data_ptr(), y.stride(0), ctx.math & ~IO_DX_BF16,
+                                        _lib.stream_ptr())
+            _lib.check(rc, "pit_mlp_fwd")
         ctx.out_gelu, ctx.dims, ctx.in_shape = out_gelu, (rows, n0, n1, n2), shape
         ctx.params = (w1, b1, w2, b2)
         ctx.save_for_backward(x2, w1c, w2c, z1, h, z2 if out_gelu else z1)
@@ -1024,7 +1104,17 @@ class _Mlp(torch.autograd.Function):
         L = _lib.lib()
         z2p = z2.data_ptr() if ctx.out_gelu else 0
         og = 1 if ctx.out_gelu else 0
-        if MLP_PARAMS_RIDER and inplace and _dw_deferrable(rows, n0, n1, n2, og, d_y2.stride(0)):
+        if ctx.chain is not None and d_y2.stride(0) % 4 == 0 and d_y2.data_ptr() % 16 == 0:
+            # the data path (dZ2, dZ1, d_x) in ONE launch on the forward's bf16 weight copies, then both weight-gradient reductions
+            w1b, w2b = ctx.chain
+            rc = L.pit_mlp_chain_bwd(rows, n0, n1, w1b.data_ptr(), w2b.data_ptr(), z1.data_ptr(), z2p, d_y2.data_ptr(),
+                                     d_y2.stride(0), _lib.ptr(d_x), n0, scratch.data_ptr(), _lib.stream_ptr())
+            _lib.check(rc, "pit_mlp_chain_bwd")
+            rc = L.pit_mlp_bwd_params(x2.data_ptr(), x2.stride(0), rows, n0, n1, n2, h.data_ptr(), og, d_y2.data_ptr(),
+                                      d_y2.stride(0), d_w1.data_ptr(), d_b1.data_ptr(), d_w2.data_ptr(), d_b2.data_ptr(),
+                                      1 if inplace else 0, scratch.data_ptr(), ctx.math, _lib.stream_ptr())
+            _lib.check(rc, "pit_mlp_bwd_params")
+        elif MLP_PARAMS_RIDER and inplace and _dw_deferrable(rows, n0, n1, n2, og, d_y2.stride(0)):
             # dZ2, dZ1 and d_x now; the weight-gradient reductions ride along with the next attention backward
             rc = L.pit_mlp_bwd_data(rows, n0, n1, n2, w1.data_ptr(), w2.data_ptr(), z1.data_ptr(), z2p, og,
                                     d_y2.data_ptr(), d_y2.stride(0), _lib.ptr(d_x), n0, scratch.data_ptr(),

@@ -442,6 +442,10 @@ class pit(nn.Module):
         if fused is not None:
             return fused
         weights = self._precomputed_weights(func_ltt, mesh_ltt)
+        if torch.is_tensor(func_ltt) and func_ltt.is_cuda and func_ltt.dim() == 3 and ops.get_math_mode() == "bf16":
+            # bf16 mode: the one-launch MLP chains read bf16 copies of the weights - all blocks' in one launch, here
+            ops.prepare_chain_weights([(w.mlp1.weight, w.mlp2.weight) for w in self.mlp if type(w) is kaiming_mlp],
+                                      func_ltt.shape[0] * func_ltt.shape[1])
         for i, (a, w) in enumerate(zip(self.conv, self.mlp)):
             if weights is not None:
                 func_ltt = ops.posatt_pre_apply(func_ltt, a.lmda, weights, i, a.n_head)

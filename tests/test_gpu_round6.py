@@ -263,3 +263,65 @@ def test_two_ranks_on_one_gpu_bench_line_proves_the_summed_gradient():
     assert rec["parity_ddp"]["world"] == 2
     _check_parity_block(rec["parity_ddp"], said)
     assert "error" not in rec["batch_sweep_ddp_samples_per_s"], said
+
+
+# --------------------------------------------------------------------------- one-launch MLP chains of the bf16 mode (csrc/pit_chain.hip)
+@pytest.mark.parametrize("rows,n0,n1", [(5120, 768, 256), (2 * 728, 256, 128), (9720, 768, 256), (1030, 512, 256)])
+def test_mlp_chain_against_the_fp64_formula(rows, n0, n1):
+    """gelu(kaiming_mlp(x)) (pit.py:21-26 + :121) for hid 128 / 256 on a few thousand rows in the bf16 math mode: pit_mlp_chain_fwd /
+    _bwd (one launch per direction, bf16 weight panels through LDS, ds_read_b64_tr_b16 in the backward) against the fp64 formula at
+    the mode's tolerances - and against the SAME mode's two-GEMM path, which rounds the same operands (<= 1e-2)."""
+    from position_induced_transformer_amd import ops
+    g = torch.Generator().manual_seed(rows + n0)
+    x = torch.randn(rows, n0, generator=g)
+    w1 = torch.randn(n1, n0, generator=g) * (2.0 / n0) ** 0.5
+    b1 = 0.1 * torch.randn(n1, generator=g)
+    w2 = torch.randn(n1, n1, generator=g) * (2.0 / n1) ** 0.5
+    b2 = 0.1 * torch.randn(n1, generator=g)
+    dy = torch.randn(rows, n1, generator=g)
+    t0 = [t.double().requires_grad_(True) for t in (x, w1, b1, w2, b2)]
+    ref = F.gelu(F.linear(F.gelu(F.linear(t0[0], t0[1], t0[2])), t0[3], t0[4]))
+    ref.backward(dy.double())
+    res = {}
+    for chain in (True, False):
+        saved = ops.CHAIN_MLP
+        ops.CHAIN_MLP = chain
+        try:
+            with ops.math_mode("bf16"):
+                assert ops.chain_mlp_supported(rows, n0, n1, n1, True) == chain
+                t1 = [t.cuda().requires_grad_(True) for t in (x, w1, b1, w2, b2)]
+                y = ops.mlp_apply(t1[0], t1[1], t1[2], t1[3], t1[4], out_gelu=True)
+                y.backward(dy.cuda())
+        finally:
+            ops.CHAIN_MLP = saved
+        torch.cuda.synchronize()
+        res[chain] = [y.detach()] + [t.grad for t in t1]
+    want = [ref.detach()] + [t.grad for t in t0]
+    for i, name in enumerate(("y", "d_x", "d_w1", "d_b1", "d_w2", "d_b2")):
+        assert _rel(res[True][i], want[i]) <= (2e-2 if i == 0 else 5e-2), (name, _rel(res[True][i], want[i]))
+        assert _rel(res[True][i], res[False][i]) <= 1.5e-2, (name, _rel(res[True][i], res[False][i]))
+
+
+def test_chain_weights_follow_the_parameters():
+    """The chains read cached bf16 copies of the weights: an in-place update of a weight (version counter) and a raw-pointer update
+    announced by ops.parameters_changed() (ddp.FlatAdam, a replayed graph) must both reach the next forward."""
+    from position_induced_transformer_amd import ops
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2048, 256, generator=g).cuda()
+    w1 = (torch.randn(128, 256, generator=g) * 0.1).cuda()
+    w2 = (torch.randn(128, 128, generator=g) * 0.1).cuda()
+    b = torch.zeros(128).cuda()
+    with ops.math_mode("bf16"):
+        y0 = ops.mlp_apply(x, w1, b, w2, b, out_gelu=True).clone()
+        w1.mul_(2.0)                                   # version counter moves
+        y1 = ops.mlp_apply(x, w1, b, w2, b, out_gelu=True).clone()
+        w2.view(-1).data_ptr()                         # (raw-pointer writers do not touch the counter)
+        torch.cuda.synchronize()
+        w2.data.copy_(2.0 * w2.data)                   # .data: no version bump
+        ops.parameters_changed()
+        y2 = ops.mlp_apply(x, w1, b, w2, b, out_gelu=True).clone()
+        ref1 = F.gelu(F.linear(F.gelu(F.linear(x, w1, b)), w2 / 2.0, b))
+        ref2 = F.gelu(F.linear(F.gelu(F.linear(x, w1, b)), w2, b))
+    torch.cuda.synchronize()
+    assert _rel(y1, ref1) <= 2e-2 and _rel(y2, ref2) <= 2e-2
+    assert _rel(y0, y1) > 0.1 and _rel(y1, y2) > 0.1
