@@ -23,8 +23,10 @@ typedef short v8s_t __attribute__((ext_vector_type(8)));
 typedef __bf16 v8bf_t __attribute__((ext_vector_type(8)));
 
 constexpr int CR = 32;       // rows per workgroup
-constexpr int KP = 64;       // k per weight panel
 constexpr int PADE = 8;      // pad (bf16 elements) of every LDS row: 16 bytes
+constexpr int NT = 512;      // threads: eight waves, wave w owns rows x columns [w N1 / 8, (w + 1) N1 / 8)
+constexpr int NSETS = 4;     // weight panels in flight in registers (first version: one, 256 threads - every panel waited a full L2
+                             // round trip behind 16 MFMAs: 27.7 / 23.6 us per launch where the two-GEMM path took 25.4 / 32.8)
 
 struct ChainArgs {
     int rows, n0, n1;
@@ -74,124 +76,132 @@ __device__ __forceinline__ float gelu_grad_f(float t) { float e; const float c =
 // array of the struct type that is filled from memory and consumed behind a barrier is kept in scratch by hipcc - DESIGN section 4.)
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 template <int NPC> struct Panel { u32x4_t v[NPC]; };
+template <int N1> struct Kp { static constexpr int v = N1 / 4; };     // k per weight panel: 64 (hid 256), 32 (hid 128)
 
 // forward panels: N1 rows (output neurons) x KP k's of w (row stride ldw elements, k offset k0): image [n][KP + 8]
 template <int N1>
-__device__ __forceinline__ void fwd_panel_load(const unsigned short* w, int ldw, int k0, int tid, Panel<N1 * KP / 8 / 256>& p) {
+__device__ __forceinline__ void fwd_panel_load(const unsigned short* w, int ldw, int k0, int tid, Panel<N1 * Kp<N1>::v / 8 / NT>& p) {
+    constexpr int KP = Kp<N1>::v;
 #pragma unroll
-    for (int u = 0; u < N1 * KP / 8 / 256; ++u) {
-        const int e = tid + 256 * u, n = e / (KP / 8), kc = e % (KP / 8);
+    for (int u = 0; u < N1 * KP / 8 / NT; ++u) {
+        const int e = tid + NT * u, n = e / (KP / 8), kc = e % (KP / 8);
         p.v[u] = *reinterpret_cast<const u32x4_t*>(w + (long)n * ldw + k0 + 8 * kc);
     }
 }
 template <int N1>
-__device__ __forceinline__ void fwd_panel_park(unsigned short* dst, int tid, const Panel<N1 * KP / 8 / 256>& p) {
+__device__ __forceinline__ void fwd_panel_park(unsigned short* dst, int tid, const Panel<N1 * Kp<N1>::v / 8 / NT>& p) {
+    constexpr int KP = Kp<N1>::v;
 #pragma unroll
-    for (int u = 0; u < N1 * KP / 8 / 256; ++u) {
-        const int e = tid + 256 * u, n = e / (KP / 8), kc = e % (KP / 8);
+    for (int u = 0; u < N1 * KP / 8 / NT; ++u) {
+        const int e = tid + NT * u, n = e / (KP / 8), kc = e % (KP / 8);
         *reinterpret_cast<u32x4_t*>(dst + n * (KP + PADE) + 8 * kc) = p.v[u];
     }
 }
 // backward panels: KP rows (k) x N1 columns of w (row stride ldw, row offset k0, column offset c0): image [k][N1 + 8]
 template <int N1>
-__device__ __forceinline__ void bwd_panel_load(const unsigned short* w, int ldw, int k0, int c0, int tid, Panel<N1 * KP / 8 / 256>& p) {
+__device__ __forceinline__ void bwd_panel_load(const unsigned short* w, int ldw, int k0, int c0, int tid, Panel<N1 * Kp<N1>::v / 8 / NT>& p) {
+    constexpr int KP = Kp<N1>::v;
 #pragma unroll
-    for (int u = 0; u < N1 * KP / 8 / 256; ++u) {
-        const int e = tid + 256 * u, k = e / (N1 / 8), nc = e % (N1 / 8);
+    for (int u = 0; u < N1 * KP / 8 / NT; ++u) {
+        const int e = tid + NT * u, k = e / (N1 / 8), nc = e % (N1 / 8);
         p.v[u] = *reinterpret_cast<const u32x4_t*>(w + (long)(k0 + k) * ldw + c0 + 8 * nc);
     }
 }
 template <int N1>
-__device__ __forceinline__ void bwd_panel_park(unsigned short* dst, int tid, const Panel<N1 * KP / 8 / 256>& p) {
+__device__ __forceinline__ void bwd_panel_park(unsigned short* dst, int tid, const Panel<N1 * Kp<N1>::v / 8 / NT>& p) {
+    constexpr int KP = Kp<N1>::v;
 #pragma unroll
-    for (int u = 0; u < N1 * KP / 8 / 256; ++u) {
-        const int e = tid + 256 * u, k = e / (N1 / 8), nc = e % (N1 / 8);
+    for (int u = 0; u < N1 * KP / 8 / NT; ++u) {
+        const int e = tid + NT * u, k = e / (N1 / 8), nc = e % (N1 / 8);
         *reinterpret_cast<u32x4_t*>(dst + k * (N1 + PADE) + 8 * nc) = p.v[u];
     }
 }
 
 template <int N1>
-__global__ __launch_bounds__(256) void mlp_chain_fwd_kernel(ChainArgs g) {
-    constexpr int NC = N1 / 4, CT = NC / 16, RT = CR / 16, WP = KP + PADE, HP = N1 + PADE;
+__global__ __launch_bounds__(NT) void mlp_chain_fwd_kernel(ChainArgs g) {
+    constexpr int KP = Kp<N1>::v, NC = N1 / 8, CT = NC / 16, RT = CR / 16, WP = KP + PADE, HP = N1 + PADE;
     extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
     const int XP = g.n0 + PADE;
     unsigned short* xs = smem;                                   // [CR][XP]   X slab; later [CR][HP] H
     unsigned short* wp = smem + CR * (XP > HP ? XP : HP);        // [2][N1][WP]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, kq = lane >> 4;
     const int row0 = (int)blockIdx.x * CR;
-    const int p1 = g.n0 / KP, np = p1 + N1 / KP;                 // panels of W1, then of W2
-    // (panel p: a select on the ADDRESS, not a branch around the loads; no lambda - a panel whose address escapes lives in scratch)
-#define PIT_CHAIN_LOAD(p_) fwd_panel_load<N1>((p_) < p1 ? g.w1b : g.w2b, (p_) < p1 ? g.n0 : N1, ((p_) < p1 ? (p_) : (p_) - p1) * KP, tid, reg)
-    Panel<N1 * KP / 8 / 256> reg;
-    PIT_CHAIN_LOAD(0);
-    // the X slab: fp32 rows -> bf16 image, eight 16-byte pieces per thread and round
+    const int p1 = g.n0 / KP, np = p1 + N1 / KP;                 // panels of W1 (a multiple of NSETS), then NSETS of W2
+    // (panel p: a select on the ADDRESS, never a branch around the loads: the loops below carry NO conditional load or store, so
+    // that the compiler's counted s_waitcnt leaves the younger panels in flight - with a conditional park in the loop it waited for
+    // everything: 20.8 us; panels beyond the last re-read panel 0 and are parked into a buffer nobody reads)
+#define PIT_CHAIN_LOAD(p_, set_) do { const int pp_ = (p_) < np ? (p_) : 0; \
+        fwd_panel_load<N1>(pp_ < p1 ? g.w1b : g.w2b, pp_ < p1 ? g.n0 : N1, (pp_ < p1 ? pp_ : pp_ - p1) * KP, tid, reg[set_]); } while (0)
+#define PIT_CHAIN_STEP(p_, j_, A_PITCH_, A_K0_)                                                                       \
+    do {                                                                                                              \
+        __syncthreads();                                                                                              \
+        fwd_panel_park<N1>(wp + (((p_) + 1) & 1) * N1 * WP, tid, reg[((j_) + 1) % NSETS]);                            \
+        PIT_CHAIN_LOAD((p_) + 1 + NSETS, ((j_) + 1) % NSETS);                                                          \
+        const unsigned short* wb_ = wp + ((p_) & 1) * N1 * WP;                                                        \
+        _Pragma("unroll") for (int ks = 0; ks < KP / 32; ++ks) {                                                      \
+            v8s_t a_[RT];                                                                                             \
+            _Pragma("unroll") for (int rt = 0; rt < RT; ++rt) a_[rt] = frag_row(xs, A_PITCH_, 16 * rt + l15, (A_K0_) + 32 * ks + 8 * kq); \
+            _Pragma("unroll") for (int ct = 0; ct < CT; ++ct) {                                                       \
+                const v8s_t b_ = frag_row(wb_, WP, wave * NC + 16 * ct + l15, 32 * ks + 8 * kq);                      \
+                _Pragma("unroll") for (int rt = 0; rt < RT; ++rt) acc[rt][ct] = mma(a_[rt], b_, acc[rt][ct]);         \
+            }                                                                                                         \
+        }                                                                                                             \
+    } while (0)
+    Panel<N1 * KP / 8 / NT> reg[NSETS];
+#pragma unroll
+    for (int j = 0; j < NSETS; ++j) PIT_CHAIN_LOAD(j, j);
+    // the X slab: fp32 rows -> bf16 image, all pieces of a thread requested at once
     {
         const int q4 = g.n0 / 4, total = CR * q4;
-        for (int base = 0; base < total; base += 8 * 256) {
-            float4 v[8];
+        for (int base = 0; base < total; base += 12 * NT) {
+            float4 v[12];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int e = base + tid + 256 * u, r = e / q4, c = e - r * q4;
+            for (int u = 0; u < 12; ++u) {
+                const int e = base + tid + NT * u, r = e / q4, c = e - r * q4;
                 v[u] = ldg4_if(g.x, (long)(row0 + r) * g.ldx + 4 * c, e < total && row0 + r < g.rows);
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int e = base + tid + 256 * u, r = e / q4, c = e - r * q4;
+            for (int u = 0; u < 12; ++u) {
+                const int e = base + tid + NT * u, r = e / q4, c = e - r * q4;
                 if (e < total) *reinterpret_cast<uint2*>(xs + r * XP + 4 * c) = pack4(v[u]);
             }
         }
     }
-    fwd_panel_park<N1>(wp, tid, reg);
-    PIT_CHAIN_LOAD(1);
+    fwd_panel_park<N1>(wp, tid, reg[0]);
+    PIT_CHAIN_LOAD(NSETS, 0);
     f32x4 acc[RT][CT];
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int p = 0; p < np; ++p) {
-        __syncthreads();                                         // panel p parked (and, p == p1, H written) by every wave
-        if (p + 1 < np) {
-            fwd_panel_park<N1>(wp + ((p + 1) & 1) * N1 * WP, tid, reg);      // (that buffer's readers passed the barrier above)
-            if (p + 2 < np) PIT_CHAIN_LOAD(p + 2);
-        }
-        const unsigned short* a_img = p < p1 ? xs : xs;          // X before, H after (same region)
-        const int apitch = p < p1 ? XP : HP, ak0 = (p < p1 ? p : p - p1) * KP;
-        const unsigned short* wb = wp + (p & 1) * N1 * WP;
+    // At the top of step p the sets hold panels p + 1 .. p + NSETS (set (p + j) % NSETS holds panel p + j): the oldest is parked into the
+    // LDS buffer panel p - 1 just left and its set re-used for panel p + 1 + NSETS.  Rounds of NSETS steps: set indices are compile-time.
+    for (int pb = 0; pb < p1; pb += NSETS) {
 #pragma unroll
-        for (int ks = 0; ks < KP / 32; ++ks) {
-            v8s_t a[RT];
-#pragma unroll
-            for (int rt = 0; rt < RT; ++rt) a[rt] = frag_row(a_img, apitch, 16 * rt + l15, ak0 + 32 * ks + 8 * kq);
-#pragma unroll
-            for (int ct = 0; ct < CT; ++ct) {
-                const v8s_t b = frag_row(wb, WP, wave * NC + 16 * ct + l15, 32 * ks + 8 * kq);
-#pragma unroll
-                for (int rt = 0; rt < RT; ++rt) acc[rt][ct] = mma(a[rt], b, acc[rt][ct]);
-            }
-        }
-        if (p == p1 - 1) {
-            // GEMM1 done: Z1 = acc + b1, H = gelu(Z1) -> memory (the backward reads them) and, as bf16, the A operand of GEMM2
-            __syncthreads();                                     // every wave is through with the X image
-#pragma unroll
-            for (int ct = 0; ct < CT; ++ct) {
-                const int col = wave * NC + 16 * ct + l15;
-                const float bias = g.b1[col];
-#pragma unroll
-                for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int r = 16 * rt + 4 * kq + i;
-                        const float z = acc[rt][ct][i] + bias, hv = gelu_f(z);
-                        xs[r * HP + col] = f_to_bf16(hv);
-                        if (row0 + r < g.rows) {
-                            g.z1[(long)(row0 + r) * N1 + col] = z;
-                            g.h[(long)(row0 + r) * N1 + col] = hv;
-                        }
-                        acc[rt][ct][i] = 0.0f;
-                    }
-            }
-        }
+        for (int j = 0; j < NSETS; ++j) PIT_CHAIN_STEP(pb + j, j, XP, (pb + j) * KP);
     }
+    // GEMM1 done: Z1 = acc + b1, H = gelu(Z1) -> memory (the backward reads them) and, as bf16, the A operand of GEMM2
+    __syncthreads();                                             // every wave is through with the X image
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+        const int col = wave * NC + 16 * ct + l15;
+        const float bias = g.b1[col];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = 16 * rt + 4 * kq + i;
+                const float z = acc[rt][ct][i] + bias, hv = gelu_f(z);
+                xs[r * HP + col] = f_to_bf16(hv);
+                if (row0 + r < g.rows) {
+                    g.z1[(long)(row0 + r) * N1 + col] = z;
+                    g.h[(long)(row0 + r) * N1 + col] = hv;
+                }
+                acc[rt][ct][i] = 0.0f;
+            }
+    }
+#pragma unroll
+    for (int j = 0; j < NSETS; ++j) PIT_CHAIN_STEP(p1 + j, j, HP, j * KP);
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) {
         const int col = wave * NC + 16 * ct + l15;
@@ -209,52 +219,63 @@ __global__ __launch_bounds__(256) void mlp_chain_fwd_kernel(ChainArgs g) {
             }
     }
 }
+#undef PIT_CHAIN_STEP
 
 #undef PIT_CHAIN_LOAD
 
 template <int N1>
-__global__ __launch_bounds__(256) void mlp_chain_bwd_kernel(ChainArgs g) {
-    constexpr int NC = N1 / 4, CT = NC / 16, RT = CR / 16, AP = N1 + PADE, WP = N1 + PADE;
+__global__ __launch_bounds__(NT) void mlp_chain_bwd_kernel(ChainArgs g) {
+    constexpr int KP = Kp<N1>::v, NC = N1 / 8, CT = NC / 16, RT = CR / 16, AP = N1 + PADE, WP = N1 + PADE;
     extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
     unsigned short* a2s = smem;                       // [CR][AP]  dZ2
     unsigned short* a1s = a2s + CR * AP;              // [CR][AP]  dZ1
     unsigned short* wp = a1s + CR * AP;               // [2][KP][WP]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, kq = lane >> 4;
     const int row0 = (int)blockIdx.x * CR;
-    constexpr int PW = N1 / KP;                       // panels per [N1 x N1] product
+    constexpr int PW = N1 / KP;                       // panels per [N1 x N1] product (= NSETS)
+    static_assert(PW == NSETS, "a product is one round of the panel pipeline");
     const int chunks = g.n0 / N1, np = PW * (1 + chunks);
-#define PIT_CHAIN_LOAD(p_) bwd_panel_load<N1>((p_) < PW ? g.w2b : g.w1b, (p_) < PW ? N1 : g.n0, ((p_) % PW) * KP, \
-                                             (p_) < PW ? 0 : (((p_) - PW) / PW) * N1, tid, reg)
-    Panel<N1 * KP / 8 / 256> reg;
-    PIT_CHAIN_LOAD(0);
+#define PIT_CHAIN_LOAD(p_, set_) do { const int pp_ = (p_) < np ? (p_) : 0; \
+        bwd_panel_load<N1>(pp_ < PW ? g.w2b : g.w1b, pp_ < PW ? N1 : g.n0, (pp_ % PW) * KP, pp_ < PW ? 0 : ((pp_ - PW) / PW) * N1, tid, reg[set_]); } while (0)
+#define PIT_CHAIN_STEP(p_, j_, A_IMG_)                                                                                \
+    do {                                                                                                              \
+        __syncthreads();                                                                                              \
+        bwd_panel_park<N1>(wp + (((p_) + 1) & 1) * KP * WP, tid, reg[((j_) + 1) % NSETS]);                            \
+        PIT_CHAIN_LOAD((p_) + 1 + NSETS, ((j_) + 1) % NSETS);                                                          \
+        const unsigned short* wb_ = wp + ((p_) & 1) * KP * WP;                                                        \
+        _Pragma("unroll") for (int ks = 0; ks < KP / 32; ++ks) {                                                      \
+            v8s_t a_[RT];                                                                                             \
+            _Pragma("unroll") for (int rt = 0; rt < RT; ++rt) a_[rt] = frag_row(A_IMG_, AP, 16 * rt + l15, (j_) * KP + 32 * ks + 8 * kq); \
+            _Pragma("unroll") for (int ct = 0; ct < CT; ++ct) {                                                       \
+                const v8s_t b_ = frag_tr(wb_, WP, 32 * ks, wave * NC + 16 * ct, l15, kq);                             \
+                _Pragma("unroll") for (int rt = 0; rt < RT; ++rt) acc[rt][ct] = mma(a_[rt], b_, acc[rt][ct]);         \
+            }                                                                                                         \
+        }                                                                                                             \
+    } while (0)
+    Panel<N1 * KP / 8 / NT> reg[NSETS];
+#pragma unroll
+    for (int j = 0; j < NSETS; ++j) PIT_CHAIN_LOAD(j, j);
     // dZ2 = dY gelu'(Z2): memory (the weight-gradient reductions read it) and the bf16 A image
     {
         constexpr int Q4 = N1 / 4, TOTAL = CR * Q4;
-        float4 dy[TOTAL / 256], zz[TOTAL / 256];
+        float4 dy[TOTAL / NT], zz[TOTAL / NT];
 #pragma unroll
-        for (int u = 0; u < TOTAL / 256; ++u) {
-            const int e = tid + 256 * u, r = e / Q4, c = e % Q4;
+        for (int u = 0; u < TOTAL / NT; ++u) {
+            const int e = tid + NT * u, r = e / Q4, c = e % Q4;
             const bool ok = row0 + r < g.rows;
             dy[u] = ldg4_if(g.d_y, (long)(row0 + r) * g.ld_dy + 4 * c, ok);
             zz[u] = ldg4_if(g.z2r, (long)(row0 + r) * N1 + 4 * c, ok);
         }
 #pragma unroll
-        for (int u = 0; u < TOTAL / 256; ++u) {
-            const int e = tid + 256 * u, r = e / Q4, c = e % Q4;
+        for (int u = 0; u < TOTAL / NT; ++u) {
+            const int e = tid + NT * u, r = e / Q4, c = e % Q4;
             const float4 v = make_float4(dy[u].x * gelu_grad_f(zz[u].x), dy[u].y * gelu_grad_f(zz[u].y),
                                          dy[u].z * gelu_grad_f(zz[u].z), dy[u].w * gelu_grad_f(zz[u].w));
             *reinterpret_cast<uint2*>(a2s + r * AP + 4 * c) = pack4(v);
             if (row0 + r < g.rows) *reinterpret_cast<float4*>(g.dz2 + (long)(row0 + r) * N1 + 4 * c) = v;
         }
     }
-    bwd_panel_park<N1>(wp, tid, reg);
-    PIT_CHAIN_LOAD(1);
-    f32x4 acc[RT][CT];
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-        for (int ct = 0; ct < CT; ++ct) acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // Z1 at the accumulator positions of GEMM A's epilogue: requested now, used PW panels later
+    // Z1 at the accumulator positions of GEMM A's epilogue (consumed after the first round)
     float z1v[RT][CT][4];
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
@@ -265,65 +286,57 @@ __global__ __launch_bounds__(256) void mlp_chain_bwd_kernel(ChainArgs g) {
                 const int r = 16 * rt + 4 * kq + i;
                 z1v[rt][ct][i] = buf_load(wide_rsrc(g.z1r), row0 + r < g.rows ? (unsigned)(((long)(row0 + r) * N1 + wave * NC + 16 * ct + l15) * 4) : OOB);
             }
-    for (int p = 0; p < np; ++p) {
-        __syncthreads();
-        if (p + 1 < np) {
-            bwd_panel_park<N1>(wp + ((p + 1) & 1) * KP * WP, tid, reg);
-            if (p + 2 < np) PIT_CHAIN_LOAD(p + 2);
-        }
-        const unsigned short* a_img = p < PW ? a2s : a1s;
-        const int ak0 = (p < PW ? p : (p - PW) % PW) * KP;
-        const unsigned short* wb = wp + (p & 1) * KP * WP;
+    bwd_panel_park<N1>(wp, tid, reg[0]);
+    PIT_CHAIN_LOAD(NSETS, 0);
+    f32x4 acc[RT][CT];
 #pragma unroll
-        for (int ks = 0; ks < KP / 32; ++ks) {
-            v8s_t a[RT];
+    for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-            for (int rt = 0; rt < RT; ++rt) a[rt] = frag_row(a_img, AP, 16 * rt + l15, ak0 + 32 * ks + 8 * kq);
+        for (int ct = 0; ct < CT; ++ct) acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // round 0: dZ1 = (dZ2 W2) gelu'(Z1) -> memory and the bf16 A image of the dX products
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct) {
-                const v8s_t b = frag_tr(wb, WP, 32 * ks, wave * NC + 16 * ct, l15, kq);
+    for (int j = 0; j < NSETS; ++j) PIT_CHAIN_STEP(j, j, a2s);
 #pragma unroll
-                for (int rt = 0; rt < RT; ++rt) acc[rt][ct] = mma(a[rt], b, acc[rt][ct]);
+    for (int ct = 0; ct < CT; ++ct) {
+        const int col = wave * NC + 16 * ct + l15;
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = 16 * rt + 4 * kq + i;
+                const float v = acc[rt][ct][i] * gelu_grad_f(z1v[rt][ct][i]);
+                a1s[r * AP + col] = f_to_bf16(v);               // (nobody reads a1s before the next step's barrier)
+                if (row0 + r < g.rows) g.dz1[(long)(row0 + r) * N1 + col] = v;
+                acc[rt][ct][i] = 0.0f;
             }
-        }
-        if (p == PW - 1) {
-            // dZ1 = (dZ2 W2) gelu'(Z1) -> memory and the bf16 A image of the dX products (nobody reads a1s before the next barrier)
+    }
+    // rounds 1 .. chunks: a column chunk of dX = dZ1 W1 each
+    for (int c = 0; c < chunks; ++c) {
+        const int pb = PW * (1 + c);
+#pragma unroll
+        for (int j = 0; j < NSETS; ++j) PIT_CHAIN_STEP(pb + j, j, a1s);
+        if (g.d_x) {
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) {
-                const int col = wave * NC + 16 * ct + l15;
+                const int col = c * N1 + wave * NC + 16 * ct + l15;
 #pragma unroll
                 for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const int r = 16 * rt + 4 * kq + i;
-                        const float v = acc[rt][ct][i] * gelu_grad_f(z1v[rt][ct][i]);
-                        a1s[r * AP + col] = f_to_bf16(v);
-                        if (row0 + r < g.rows) g.dz1[(long)(row0 + r) * N1 + col] = v;
-                        acc[rt][ct][i] = 0.0f;
+                        if (row0 + r < g.rows) g.d_x[(long)(row0 + r) * g.ld_dx + col] = acc[rt][ct][i];
                     }
             }
-        } else if (p >= PW && (p - PW) % PW == PW - 1) {
-            const int c = (p - PW) / PW;                       // a column chunk of dX is complete
-            if (g.d_x) {
-#pragma unroll
-                for (int ct = 0; ct < CT; ++ct) {
-                    const int col = c * N1 + wave * NC + 16 * ct + l15;
-#pragma unroll
-                    for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            const int r = 16 * rt + 4 * kq + i;
-                            if (row0 + r < g.rows) g.d_x[(long)(row0 + r) * g.ld_dx + col] = acc[rt][ct][i];
-                        }
-                }
-            }
-#pragma unroll
-            for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-                for (int ct = 0; ct < CT; ++ct) acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 }
+#undef PIT_CHAIN_STEP
+
+#undef PIT_CHAIN_LOAD
 
 // bf16 copies of up to 32 weight matrices in ONE launch (the chains read their weights as bf16; the copies are formed once per
 // weight version - inside a captured step once per replay - by the host side, ops.prepare_chain_weights)
@@ -337,14 +350,12 @@ __global__ __launch_bounds__(256) void cast_bf16_multi_kernel(CastArgs g) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) d[i] = pack4(s[i]);
 }
 
-#undef PIT_CHAIN_LOAD
-
 bool chain_shape_ok(int rows, int n0, int n1, int n2) {
-    return rows > 0 && n1 == n2 && (n1 == 128 || n1 == 256) && n0 >= n1 && n0 % n1 == 0 && n0 % KP == 0 && n0 <= 1024 &&
+    return rows > 0 && n1 == n2 && (n1 == 128 || n1 == 256) && n0 >= n1 && n0 % n1 == 0 && n0 <= 1024 &&
            (long)rows * n0 * 4 < (1L << 31) - 65536;
 }
-size_t chain_fwd_smem(int n0, int n1) { return (size_t)(CR * (std::max(n0, n1) + PADE) + 2 * n1 * (KP + PADE)) * 2; }
-size_t chain_bwd_smem(int n1) { return (size_t)(2 * CR * (n1 + PADE) + 2 * KP * (n1 + PADE)) * 2; }
+size_t chain_fwd_smem(int n0, int n1) { return (size_t)(CR * (std::max(n0, n1) + PADE) + 2 * n1 * (n1 / 4 + PADE)) * 2; }
+size_t chain_bwd_smem(int n1) { return (size_t)(2 * CR * (n1 + PADE) + 2 * (n1 / 4) * (n1 + PADE)) * 2; }
 bool a16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace
@@ -371,11 +382,11 @@ extern "C" int pit_mlp_chain_fwd(const float* x, long ldx, int rows, int n0, int
     if (n1 == 256) {
         static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_chain_fwd_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
         (void)once;
-        hipLaunchKernelGGL((mlp_chain_fwd_kernel<256>), grid, dim3(256), sm, s, g);
+        hipLaunchKernelGGL((mlp_chain_fwd_kernel<256>), grid, dim3(NT), sm, s, g);
     } else {
         static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_chain_fwd_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
         (void)once;
-        hipLaunchKernelGGL((mlp_chain_fwd_kernel<128>), grid, dim3(256), sm, s, g);
+        hipLaunchKernelGGL((mlp_chain_fwd_kernel<128>), grid, dim3(NT), sm, s, g);
     }
     PIT_CHECK_LAUNCH();
     return 0;
@@ -398,11 +409,11 @@ extern "C" int pit_mlp_chain_bwd(int rows, int n0, int n1, const unsigned short*
     if (n1 == 256) {
         static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_chain_bwd_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
         (void)once;
-        hipLaunchKernelGGL((mlp_chain_bwd_kernel<256>), grid, dim3(256), sm, s, g);
+        hipLaunchKernelGGL((mlp_chain_bwd_kernel<256>), grid, dim3(NT), sm, s, g);
     } else {
         static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_chain_bwd_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
         (void)once;
-        hipLaunchKernelGGL((mlp_chain_bwd_kernel<128>), grid, dim3(256), sm, s, g);
+        hipLaunchKernelGGL((mlp_chain_bwd_kernel<128>), grid, dim3(NT), sm, s, g);
     }
     PIT_CHECK_LAUNCH();
     return 0;

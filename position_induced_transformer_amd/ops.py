@@ -957,8 +957,6 @@ def posatt_apply(values: torch.Tensor, lmda: torch.Tensor, plan: MeshPlan, n_hea
 # weights at replay time (an optimizer between replays, or inside the graph): the cast is then always part of the graph, once per
 # forward pass (pit.processor requests every block's weights at its entry: prepare_chain_weights).
 CHAIN_MLP = os.environ.get("PIT_CHAIN_MLP", "1") != "0"
-_BF16_W = OrderedDict()          # (data_ptr, numel) -> [bf16 tensor, version, epoch]
-_BF16_W_MAX = 128
 
 
 def chain_mlp_supported(rows: int, n0: int, n1: int, n2: int, out_gelu: bool) -> bool:
@@ -967,45 +965,48 @@ def chain_mlp_supported(rows: int, n0: int, n1: int, n2: int, out_gelu: bool) ->
 
 
 def bf16_weights(tensors, new_pass: bool = False):
-    """bf16 copies (RNE) of contiguous fp32 weight tensors, cached; see the section comment."""
+    """bf16 copies (RNE) of contiguous fp32 weight tensors.  The copy lives ON the tensor object it was made from (``_pit_bf16``:
+    buffer, version counter, parameters_changed() epoch, address) - a key built from the address alone would hand a freed
+    weight's copy to whatever tensor the allocator puts there next.  See the section comment for the capture rule."""
     cap = _capturing()
     if new_pass:
         _STEP.cap_fresh = set()
     fresh = getattr(_STEP, "cap_fresh", None) if cap else None
     out, need = [], []
     for t in tensors:
-        key = (t.data_ptr(), t.numel())
-        ent = _BF16_W.get(key)
-        if ent is None:
-            while len(_BF16_W) >= _BF16_W_MAX:
-                _BF16_W.popitem(last=False)
-            ent = _BF16_W[key] = [torch.empty(t.shape, device=t.device, dtype=torch.bfloat16), -1, -1]
-        else:
-            _BF16_W.move_to_end(key)
+        ent = getattr(t, "_pit_bf16", None)
+        if ent is None or ent[0].shape != t.shape or ent[0].device != t.device:
+            ent = [torch.empty(t.shape, device=t.device, dtype=torch.bfloat16), -1, -1, 0]
+            t._pit_bf16 = ent
         if cap:
-            _pin(ent[0])
-            stale = fresh is None or key not in fresh
+            _pin(ent[0], t)
+            stale = fresh is None or id(t) not in fresh
         else:
-            stale = ent[1] != t._version or ent[2] != _PARAM_EPOCH[0]
+            stale = ent[1] != t._version or ent[2] != _PARAM_EPOCH[0] or ent[3] != t.data_ptr()
         if stale:
-            need.append((t, ent, key))
+            need.append((t, ent))
         out.append(ent[0])
     if need:
         n = len(need)
-        src = (ctypes.c_void_p * n)(*[t.data_ptr() for t, _e, _k in need])
-        dst = (ctypes.c_void_p * n)(*[e[0].data_ptr() for _t, e, _k in need])
-        cnt = (ctypes.c_long * n)(*[t.numel() for t, _e, _k in need])
+        src = (ctypes.c_void_p * n)(*[t.data_ptr() for t, _e in need])
+        dst = (ctypes.c_void_p * n)(*[e[0].data_ptr() for _t, e in need])
+        cnt = (ctypes.c_long * n)(*[t.numel() for t, _e in need])
         rc = _lib.lib().pit_cast_bf16_multi(n, src, dst, cnt, _lib.stream_ptr())
         _lib.check(rc, "pit_cast_bf16_multi")
-        for t, ent, key in need:
+        for t, ent in need:
             if cap:                       # recorded, not executed: the copy in memory is NOT this version
                 ent[1] = ent[2] = -1
                 if fresh is None:
                     fresh = _STEP.cap_fresh = set()
-                fresh.add(key)
+                fresh.add(id(t))
             else:
-                ent[1], ent[2] = t._version, _PARAM_EPOCH[0]
+                ent[1], ent[2], ent[3] = t._version, _PARAM_EPOCH[0], t.data_ptr()
     return out
+
+
+def _chain_weight_ok(w) -> bool:
+    return torch.is_tensor(w) and w.is_cuda and w.dtype == torch.float32 and w.is_contiguous() and w.data_ptr() % 16 == 0 \
+        and w.numel() % 4 == 0
 
 
 def prepare_chain_weights(mlps, rows: int) -> None:
@@ -1013,9 +1014,8 @@ def prepare_chain_weights(mlps, rows: int) -> None:
     ws = []
     for w1, w2 in mlps:
         n1, n0 = w1.shape
-        if w2.shape == (n1, n1) and chain_mlp_supported(rows, n0, n1, n1, True) and w1.is_cuda and w1.is_contiguous() \
-                and w2.is_contiguous() and w1.dtype == torch.float32:
-            ws += [w1.detach(), w2.detach()]
+        if w2.shape == (n1, n1) and chain_mlp_supported(rows, n0, n1, n1, True) and _chain_weight_ok(w1) and _chain_weight_ok(w2):
+            ws += [w1, w2]
     if ws:
         bf16_weights(ws[:32], new_pass=True)
 
@@ -1054,9 +1054,10 @@ class _Mlp(torch.autograd.Function):
         ctx.math = _math_code() | ((IO_X_BF16 | IO_SAVE_BF16 | IO_DX_BF16) if x16 else 0)
         ctx.x16 = x16
         ctx.chain = None
-        if not x16 and chain_mlp_supported(rows, n0, n1, n2, out_gelu) and x2.stride(0) % 4 == 0 and x2.data_ptr() % 16 == 0:
+        if not x16 and chain_mlp_supported(rows, n0, n1, n2, out_gelu) and x2.stride(0) % 4 == 0 and x2.data_ptr() % 16 == 0 \
+                and _chain_weight_ok(w1) and _chain_weight_ok(w2):
             # bf16 mode, hid 128 / 256, a few thousand rows: GEMM1 + gelu + GEMM2 + gelu in ONE launch (csrc/pit_chain.hip)
-            w1b, w2b = bf16_weights([w1c, w2c])
+            w1b, w2b = bf16_weights([w1, w2])
             rc = _lib.lib().pit_mlp_chain_fwd(x2.data_ptr(), x2.stride(0), rows, n0, n1, w1b.data_ptr(), b1c.data_ptr(),
                                               w2b.data_ptr(), b2c.data_ptr(), z1.data_ptr(), h.data_ptr(), z2.data_ptr(),
                                               y.data_ptr(), y.stride(0), _lib.stream_ptr())

@@ -2,11 +2,11 @@
 # Per-configuration evidence for profiles/ (GPU box): for every configuration one rocprofv3 kernel-trace
 # run (--stats) and four PMC passes, EACH IN ITS OWN RUN with --kernel-trace only (MI355X guide:
 # FETCH_SIZE needs 3 TCC slots, WRITE_SIZE 2; never combined with other trace domains).
-#   tools/profile_round.sh <outdir> [config ...]      configs: darcy8 darcy256 vort vort_bf16 elast naca naca_bf16
+#   tools/profile_round.sh <outdir> [config ...]      configs: darcy8 darcy256 vort vort_bf16 elast elast_bf16 naca naca_bf16
 #                                                               rollout20 cyl200 zssr421 (summarised over the whole run)
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$(mkdir -p "$1" && cd "$1" && pwd); shift
-CONFIGS=${@:-darcy8 darcy256 vort vort_bf16 elast naca naca_bf16}
+CONFIGS=${@:-darcy8 darcy256 vort vort_bf16 elast elast_bf16 naca naca_bf16}
 cd /tmp; export TMPDIR=/tmp
 for cfg in $CONFIGS; do
   case $cfg in
@@ -15,6 +15,7 @@ for cfg in $CONFIGS; do
     vort)      ARGS="--task vorticity --batch 20" ;;
     vort_bf16) ARGS="--task vorticity --batch 20 --math bf16" ;;
     elast)     ARGS="--task elasticity --batch 10" ;;
+    elast_bf16) ARGS="--task elasticity --batch 10 --math bf16" ;;
     naca)      ARGS="--task naca --batch 20" ;;
     naca_bf16) ARGS="--task naca --batch 20 --math bf16" ;;
     rollout20) ARGS="--task vorticity --batch 20 --rollout 20"; STEPS="--steps 4 --warmup 1"; MODE=whole ;;
