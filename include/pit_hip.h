@@ -397,7 +397,12 @@ int pit_fold_att_fwd(const pit_slab_plan* plan, const float* vw, long ld_vw, lon
                      const float* pw, void* z, long ld_z, long z_bstride, int max_union, int math_mode, void* stream);
 int pit_fold_att_bwd(const pit_slab_plan* plan, const float* vw, long ld_vw, long vw_bstride, int batch, int n_head, int dim,
                      const float* pw, const float* qw, const void* dz, long ld_dz, long dz_bstride,
-                     float* d_vw, long ld_dvw, long dvw_bstride, double* dscale, int max_union, int math_mode, void* stream);
+                     float* d_vw, long ld_dvw, long dvw_bstride, double* dscale,
+                     float* tiles, const int* rev_ptr, const int* rev_ent, int max_union, int math_mode, void* stream);
+/* tiles != NULL (with d_vw): NO atomics - every (sample, slab) writes its sums into its own tile of `tiles` (batch, n_slabs,
+ * PIT_SLAB_UNION_MAX, dim*n_head floats) and a second launch writes d_vw[b, j, :] = the sum of the tile rows that hold key j, in the
+ * fixed order of the CSR lists rev_ptr (n_in + 1) / rev_ent (entries slab*PIT_SLAB_UNION_MAX + slot, grouped by key): d_vw need not
+ * be zero on entry and is the same bits on every run. */
 /* The rest of `de` (pit.py:21-26 after the first Linear) for out_dim = n2 <= 4 and n1 in {64, 128, 256}:
  *   pit_thin_tail_fwd   y[m][o] = sum_n gelu_erf(z[m][n] + b1[n]) w2[o][n] + b2[o]                      (nothing is saved)
  *   pit_thin_tail_bwd   dz[m][n] = (sum_o d_y[m][o] w2[o][n]) gelu'(z[m][n] + b1[n]), and ADDS d_b1[n] = sum_m dz[m][n],

@@ -80,7 +80,7 @@ SIGNATURES = {
     "pit_fold_supported": [_I, _I, _I, _I, _I],
     "pit_fold_weights": [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P],
     "pit_fold_att_fwd": [_P, _P, _L, _L, _I, _I, _I, _P, _P, _L, _L, _I, _I, _P],
-    "pit_fold_att_bwd": [_P, _P, _L, _L, _I, _I, _I, _P, _P, _P, _L, _L, _P, _L, _L, _P, _I, _I, _P],
+    "pit_fold_att_bwd": [_P, _P, _L, _L, _I, _I, _I, _P, _P, _P, _L, _L, _P, _L, _L, _P, _P, _P, _P, _I, _I, _P],
     "pit_thin_tail_scratch_floats": [],
     "pit_thin_tail_fwd": [_P, _L, _I, _I, _I, _P, _P, _P, _P, _L, _I, _P],
     "pit_thin_tail_bwd": [_P, _L, _I, _I, _I, _P, _P, _P, _L, _P, _L, _P, _P, _P, _P, _I, _P],

@@ -125,8 +125,10 @@ struct FoldArgs {
     const float *pw, *qw;                                // (n_slabs * H, rows, um): the step's weights (pit_fold_weights)
     void* z; long ld_z, z_bstride; int z16;              // forward: out (batch, n_out, dim)
     const void* dz; long ld_dz, dz_bstride; int dz16;    // backward: its gradient
-    float* d_vw; long ld_dvw, dvw_bstride;               // backward: ADDED to (fp32 atomics), layout of vw
+    float* d_vw; long ld_dvw, dvw_bstride;               // backward: ADDED to (fp32 atomics), layout of vw - or, with `tiles`, written
     double* dscale;
+    float* tiles;                                        // backward, optional: (batch, n_slabs, 64 slots, dim * H) per-slab sums (fold_reduce_kernel)
+    const int *rev_ptr, *rev_ent;                        // key -> the (slab * 64 + slot) entries that hold it (CSR over n_in keys)
 };
 
 // workgroup id -> (sample, slab, chunk): all workgroups of a slab on ONE XCD (ids are dealt to the XCDs round-robin) - what they
@@ -384,7 +386,28 @@ __global__ __launch_bounds__(256) void fold_bwd_kernel(FoldArgs g) {
     // the slab's sums leave once: d_vw[b][key(slot)][(chunk 64 + 16 wave + c) H + h].  Two heads: the wave's 16 columns are a run
     // of 32 floats per key row; lane c holds (c, 0) and (c, 1) - position p = 16 half + c of the run is column p >> 1, head p & 1,
     // fetched from lane p >> 1 of the same lane quarter, so that each atomic instruction adds to 64 contiguous bytes per row
-    if (g.d_vw) {
+    if (g.tiles) {
+        // plain stores of the slab's sums into its own tile (no atomics: fold_reduce_kernel adds the few tiles that hold a key, in a
+        // fixed order - the same bits on every run); slots beyond the union are written too and never read
+        float* dst = g.tiles + ((long)(b * g.p.n_slabs + slab) * EU) * ((long)g.dim * H) + (long)(chunk * CW + 16 * wave) * H;
+        const long ldt = (long)g.dim * H;
+#pragma unroll
+        for (int mt = 0; mt < EU / 16; ++mt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int sl = 16 * mt + 4 * kq + i;
+                if (H == 1) {
+                    dst[sl * ldt + l15] = accT[0][mt][i];
+                } else {
+#pragma unroll
+                    for (int half = 0; half < 2; ++half) {
+                        const int pp = 16 * half + l15, src = (lane & 48) | (pp >> 1);
+                        const float t0 = __shfl(accT[0][mt][i], src, 64), t1 = __shfl(accT[H - 1][mt][i], src, 64);
+                        dst[sl * ldt + pp] = (pp & 1) ? t1 : t0;
+                    }
+                }
+            }
+    } else if (g.d_vw) {
         float* dst = g.d_vw + (long)b * g.dvw_bstride + (long)(chunk * CW + 16 * wave) * H;
 #pragma unroll
         for (int mt = 0; mt < EU / 16; ++mt)
@@ -417,6 +440,28 @@ __global__ __launch_bounds__(256) void fold_bwd_kernel(FoldArgs g) {
             for (int w = 0; w < 4; ++w) tot += wred[w * H + tid];
             atomicAdd(g.dscale + (long)tid * PIT_DSCALE_SLOTS + ((int)blockIdx.x & (PIT_DSCALE_SLOTS - 1)), -tot);
         }
+    }
+}
+
+// d_vw[b][key][:] = sum of the tile rows that hold `key` (a key sits in the unions of ~4 tall slabs), in CSR order.  width / 4
+// threads (<= 128) share a key with a float4 each, 128 / (width / 4) keys per workgroup (wider rows: a grid-stride loop).
+__global__ __launch_bounds__(128) void fold_reduce_kernel(FoldArgs g, int n_head) {
+    const long width = (long)g.dim * n_head;
+    const int tpk = (int)(width / 4 < 128 ? width / 4 : 128), kpw = 128 / tpk;
+    const int sub = (int)threadIdx.x / tpk, t = (int)threadIdx.x - sub * tpk;
+    const long row = (long)blockIdx.x * kpw + sub;               // (sample, key) pair
+    if (sub >= kpw || row >= (long)g.batch * g.p.n_in) return;
+    const int b = (int)(row / g.p.n_in), key = (int)(row - (long)b * g.p.n_in);
+    const int beg = g.rev_ptr[key], end = g.rev_ptr[key + 1];
+    const float* tb = g.tiles + (long)b * g.p.n_slabs * EU * width;
+    float* dst = g.d_vw + (long)b * g.dvw_bstride + (long)key * g.ld_dvw;
+    for (long c = 4L * t; c < width; c += 4L * tpk) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int e = beg; e < end; ++e) {
+            const float4 v = *reinterpret_cast<const float4*>(tb + (long)g.rev_ent[e] * width + c);
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+        *reinterpret_cast<float4*>(dst + c) = acc;
     }
 }
 
@@ -673,7 +718,9 @@ extern "C" int pit_fold_att_fwd(const pit_slab_plan* plan, const float* vw, long
 
 extern "C" int pit_fold_att_bwd(const pit_slab_plan* plan, const float* vw, long ld_vw, long vw_bstride, int batch, int n_head, int dim,
                                 const float* pw, const float* qw, const void* dz, long ld_dz, long dz_bstride,
-                                float* d_vw, long ld_dvw, long dvw_bstride, double* dscale, int max_union, int math_mode, void* stream) {
+                                float* d_vw, long ld_dvw, long dvw_bstride, double* dscale,
+                                float* tiles, const int* rev_ptr, const int* rev_ent,
+                                int max_union, int math_mode, void* stream) {
     FoldArgs g;
     if (int rc = fold_fill(g, plan, vw, ld_vw, vw_bstride, batch, n_head, dim, pw, max_union)) return rc;
     if (!qw || !dz || (!d_vw && !dscale)) return PIT_ERR_NULL;
@@ -683,6 +730,11 @@ extern "C" int pit_fold_att_bwd(const pit_slab_plan* plan, const float* vw, long
     if (d_vw && (ld_dvw < (long)n_head * dim)) return PIT_ERR_SIZE;
     g.qw = qw; g.dz = dz; g.ld_dz = ld_dz; g.dz_bstride = dz_bstride; g.dz16 = dz16;
     g.d_vw = d_vw; g.ld_dvw = ld_dvw; g.dvw_bstride = dvw_bstride; g.dscale = dscale;
+    if (tiles && d_vw) {
+        if (!rev_ptr || !rev_ent) return PIT_ERR_NULL;
+        if (!aligned16p(tiles) || !aligned16p(d_vw) || ld_dvw % 4 || dvw_bstride % 4) return PIT_ERR_SIZE;
+        g.tiles = tiles; g.rev_ptr = rev_ptr; g.rev_ent = rev_ent;
+    }
     const bool bf = mode == PIT_MATH_BF16;
     const size_t sm = fold_smem(n_head, bf, g.um, true);
     const dim3 grid(fold_grid(g));
@@ -690,6 +742,12 @@ extern "C" int pit_fold_att_bwd(const pit_slab_plan* plan, const float* vw, long
     if (n_head == 1) { if (bf) hipLaunchKernelGGL((fold_bwd_kernel<1, true>), grid, dim3(256), sm, s, g); else hipLaunchKernelGGL((fold_bwd_kernel<1, false>), grid, dim3(256), sm, s, g); }
     else { if (bf) hipLaunchKernelGGL((fold_bwd_kernel<2, true>), grid, dim3(256), sm, s, g); else hipLaunchKernelGGL((fold_bwd_kernel<2, false>), grid, dim3(256), sm, s, g); }
     PIT_CHECK_LAUNCH();
+    if (g.tiles) {
+        const long width = (long)dim * n_head;
+        const int tpk = (int)(width / 4 < 128 ? width / 4 : 128), kpw = 128 / tpk;
+        hipLaunchKernelGGL(fold_reduce_kernel, dim3((unsigned)(((long)batch * plan->n_in + kpw - 1) / kpw)), dim3(128), 0, s, g, n_head);
+        PIT_CHECK_LAUNCH();
+    }
     return 0;
 }
 

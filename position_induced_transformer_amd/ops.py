@@ -566,8 +566,22 @@ class MeshPlan:
             if built is None:
                 break
             if built[1] <= SLAB_UNION_MAX:
-                self._fold = built
-                return built
+                # key -> the (slab, slot) entries that hold it (CSR, in slab order): the backward's tiles are summed per key in this
+                # fixed order instead of being added to memory with atomics
+                sp, mu, keep, mc = built
+                keys, nkeys = keep[2], keep[3]
+                n_slabs = keys.shape[0]
+                slot = torch.arange(SLAB_UNION_MAX, device=keys.device, dtype=torch.int64)[None, :].expand(n_slabs, -1)
+                valid = slot < nkeys[:, None].long()
+                ent = (torch.arange(n_slabs, device=keys.device, dtype=torch.int64)[:, None] * SLAB_UNION_MAX + slot)[valid]
+                key = keys.long()[valid]
+                order = torch.sort(key, stable=True).indices
+                rev_ent = ent[order].to(torch.int32).contiguous()
+                rev_ptr = torch.zeros((self.n_in + 1,), device=keys.device, dtype=torch.int64)
+                rev_ptr[1:] = torch.cumsum(torch.bincount(key, minlength=self.n_in), 0)
+                rev_ptr = rev_ptr.to(torch.int32).contiguous()
+                self._fold = (sp, mu, keep + (rev_ptr, rev_ent), mc)
+                return self._fold
         self._fold = False
         return None
 
@@ -1790,6 +1804,17 @@ def decoder_apply(values: torch.Tensor, lmda: torch.Tensor, plan: MeshPlan, n_he
 # The (batch, n_out, H*hid) tensor of pit.py:125 and the three GEMMs on its rows are gone; nothing of size n_out x hid is saved
 # except z itself.  PIT_FOLD_DECODER=0: the round-5 path (attention output materialised, kaiming_mlp kernels).
 FOLD_DECODER = os.environ.get("PIT_FOLD_DECODER", "1") != "0"
+# d(values) of the fold attention WITHOUT atomics (per-slab tiles + a fixed-order reduction: the same bits on every run): "auto" - when
+# the tiles take at most 64 MB (Vorticity b=20: 42 MB, no slower than the atomic adds; Darcy b=256: 126 MB, 1.3 % slower) or under
+# torch.use_deterministic_algorithms; "1" always; "0" never (fp32 atomic adds into a zeroed buffer)
+FOLD_TILES = os.environ.get("PIT_FOLD_TILES", "auto")
+FOLD_TILES_MAX_BYTES = 64 << 20
+
+
+def _fold_tiles(nbytes: int) -> bool:
+    if FOLD_TILES in ("0", False):
+        return False
+    return FOLD_TILES in ("1", True) or nbytes <= FOLD_TILES_MAX_BYTES or torch.are_deterministic_algorithms_enabled()
 # hid 32 / 64 models on batch-free meshes: rows (batch x output points) from which pit.decoder prefers the folded decoder to the
 # fused one-launch-per-direction decoder of csrc/pit_edge.hip (which recomputes nothing but pays 16-row slabs: one gather of the
 # union's value rows and one pass of atomic adds per 16 rows)
@@ -1878,7 +1903,7 @@ def fold_att_supported(plan: MeshPlan, n_head: int, dim: int, batch: int) -> boo
     lists whose unions fit a tile for slabs of at least 64 rows, 1-2 heads, a width that is a multiple of 64."""
     if plan.mesh_batch != 1 or plan.self_attn or not plan.masked or plan.nbr_idx is None:
         return False
-    if torch.are_deterministic_algorithms_enabled():         # (d(values): fp32 atomic adds)
+    if torch.are_deterministic_algorithms_enabled() and FOLD_TILES in ("0", False):         # (d(values) as fp32 atomic adds)
         return False
     if not _lib.lib().pit_fold_supported(int(n_head), int(dim), int(batch), int(plan.n_out), int(plan.n_in)):
         return False
@@ -1925,7 +1950,16 @@ class _FoldAtt(torch.autograd.Function):
         need_v, need_h = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         if need_h and w.qw is None:
             raise RuntimeError("fold attention: d(lmda) requested but the forward ran without grad mode")
-        d_vw = torch.zeros((b, j, hd), device=vw.device, dtype=torch.float32) if need_v else None
+        # d(values): per-slab sums into tiles + a fixed-order reduction per key (no atomics, nothing to zero: FOLD_TILES), or fp32
+        # atomic adds into a zeroed buffer
+        fp = plan.fold_plan()
+        tiles = rev_ptr = rev_ent = None
+        if need_v and _fold_tiles(4 * b * fp[0].n_slabs * SLAB_UNION_MAX * hd):
+            tiles = torch.empty((b, fp[0].n_slabs, SLAB_UNION_MAX, hd), device=vw.device, dtype=torch.float32)
+            rev_ptr, rev_ent = fp[2][4], fp[2][5]
+            d_vw = torch.empty((b, j, hd), device=vw.device, dtype=torch.float32)
+        else:
+            d_vw = torch.zeros((b, j, hd), device=vw.device, dtype=torch.float32) if need_v else None
         slot = _grad_slot(ctx.head_param) if need_h else None
         defer = DEFER_HEAD_FINISH and slot is not None
         work = None
@@ -1940,7 +1974,8 @@ class _FoldAtt(torch.autograd.Function):
         qw = w.qw if w.qw is not None else w.pw       # (read only for d(scale))
         rc = _lib.lib().pit_fold_att_bwd(ctypes.byref(sp), vw.data_ptr(), vw.stride(1), vw.stride(0), b, n_head, d, w.pw.data_ptr(),
                                          qw.data_ptr(), dz.data_ptr(), dz.stride(1), dz.stride(0),
-                                         _lib.ptr(d_vw), hd, j * hd, _lib.ptr(work), max_union, ctx.math | io, _lib.stream_ptr())
+                                         _lib.ptr(d_vw), hd, j * hd, _lib.ptr(work), _lib.ptr(tiles), _lib.ptr(rev_ptr),
+                                         _lib.ptr(rev_ent), max_union, ctx.math | io, _lib.stream_ptr())
         _lib.check(rc, "pit_fold_att_bwd")
         d_head = None
         if need_h:

@@ -325,3 +325,36 @@ def test_chain_weights_follow_the_parameters():
     torch.cuda.synchronize()
     assert _rel(y1, ref1) <= 2e-2 and _rel(y2, ref2) <= 2e-2
     assert _rel(y0, y1) > 0.1 and _rel(y1, y2) > 0.1
+
+
+def test_fold_attention_backward_is_reproducible_and_matches_the_atomic_form():
+    """d(values) of the fold attention: per-slab sums into tiles + a fixed-order reduction per key (ops.FOLD_TILES: taken up to 64 MB of tiles) gives
+    the SAME BITS on every pass - the reference's scripts set cudnn.deterministic (pit.py:6) - and agrees with the fp32-atomic form
+    to the atomics' summation order; torch.use_deterministic_algorithms keeps the fold path."""
+    from position_induced_transformer_amd import ops
+    mo, mi, t, d_y = _decoder_case("periodic2d", 64, 16, 256, 2, 3, 0.02, 1)
+    plan = ops.MeshPlan("periodic2d", mo.cuda(), mi.cuda(), 0.02, False)
+    vw = torch.randn(3, mi.shape[0], 512, generator=torch.Generator().manual_seed(4)).cuda()
+    dz = torch.randn(3, mo.shape[0], 256, generator=torch.Generator().manual_seed(5)).cuda()
+    lm = t["lmda"].cuda()
+
+    def run():
+        v = vw.clone().requires_grad_(True)
+        z = ops._FoldAtt.apply(v, lm.reshape(-1), plan, 2, False, None, None, False, False)
+        z.backward(dz)
+        torch.cuda.synchronize()
+        return v.grad.clone()
+    a, b = run(), run()
+    assert torch.equal(a, b)
+    saved = ops.FOLD_TILES
+    ops.FOLD_TILES = "0"
+    try:
+        c = run()
+    finally:
+        ops.FOLD_TILES = saved
+    assert _rel(c, a) <= 1e-6
+    torch.use_deterministic_algorithms(True, warn_only=True)
+    try:
+        assert ops.fold_att_supported(plan, 2, 256, 3)
+    finally:
+        torch.use_deterministic_algorithms(False)
