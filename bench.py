@@ -255,7 +255,7 @@ def pmc_traffic(kernel_key, shape):
     profiles/r03_fetch_calibration.txt).  The committed record is keyed by kernel AND by the shape of the launch it was
     measured on (profiles/r05_pmc_traffic.json: ``shape``): a probe that times another launch of the family gets None,
     never another launch's bytes."""
-    for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json"):
+    for name in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 rec = json.load(f)["kernels"].get(kernel_key)

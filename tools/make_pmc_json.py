@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
-"""profiles/r05_pmc_traffic.json for bench.py's `roofline.traffic` from the per-configuration summaries of
+"""profiles/r06_pmc_traffic.json for bench.py's `roofline.traffic` from the per-configuration summaries of
 tools/profile_round.sh (FETCH_SIZE and WRITE_SIZE collected in separate rocprofv3 --pmc passes, KiB).
 Correction (profiles/r03_fetch_calibration.txt, tools/fetch_calib.sh): on gfx950 FETCH_SIZE reports exactly HALF of the
 bytes for every coalesced read shape these kernels use (2 / 4 / 16 B per lane, row gathers, buffer loads alike - not only
 the 16-B streaming reads MI355X_MICROARCH.md calibrates), WRITE_SIZE is exact: traffic = 2 x FETCH_SIZE + WRITE_SIZE.
-   python tools/make_pmc_json.py <profile_round outdir> profiles/r05_pmc_traffic.json"""
+   python tools/make_pmc_json.py <profile_round outdir> profiles/r06_pmc_traffic.json"""
 import json, os, sys
 
 src, dst = sys.argv[1], sys.argv[2]
