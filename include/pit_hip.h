@@ -465,6 +465,27 @@ int pit_posatt_pre_bwd(const float* e, const float* q, const float* rowstat, int
                        float* d_values, long ld_dvalues, long dvalues_bstride, int add_residual,
                        double* workspace, int math_mode, void* stream);
 
+/* ---- Dense self-attention of the processor on bf16 MFMA (round 6; csrc/pit_satt.hip; bf16 math mode) ---------------------------
+ * posatt.forward (pit.py:37-57) with locality 1.0 on one mesh (per-sample or batch-free): 1-2 heads, dim 128 / 256, 64..2048 points.
+ *   pit_satt_fwd  out[b, n, out_col0 + h*dim + d] = sum_j softmax_j(-c_h m[n, j]) values[b, j, d]; copy_inputs: out[b, n, 0:dim] = values.
+ *                 x16: batch*n_pts*dim bf16 (the rounded values; keep it for the backward); rowstat (mesh_batch, n_head, n_pts, 4) =
+ *                 {-, 0, 1/rowsum, mbar}, scale_out (n_head) = c, as pit_posatt_fwd.
+ *   pit_satt_bwd  d_values[b, j, :] = (add_residual ? d_out[b, j, 0:dim] : 0) + sum_h sum_n P_h[n, j] d_out[b, n, out_col0 + h*dim + :] (NULL: not
+ *                 needed); the layer's d(scale) accumulators (PIT_HEAD_DEFER convention; NULL: not needed).  scale = the forward's c;
+ *                 g16: scratch of batch*n_head*n_pts*dim bf16.
+ * Weights, row sums and the d(scale) reduction are fp32 / fp64; the MFMA operands are bf16 (v_mfma_f32_16x16x32_bf16). */
+int pit_satt_supported(int n_pts, int n_head, int dim, int batch, int mesh_batch);
+int pit_satt_fwd(const float* mesh, int mesh_batch, int n_pts, int space_dim, int metric, float period,
+                 const float* values, long ld_values, long values_bstride, int batch, int dim,
+                 const float* head, int n_head, int head_is_scale, unsigned short* x16,
+                 float* out, long ld_out, long out_bstride, int out_col0, int copy_inputs,
+                 float* rowstat, float* scale_out, void* stream);
+int pit_satt_bwd(const float* mesh, int mesh_batch, int n_pts, int space_dim, int metric, float period,
+                 int batch, int dim, const float* scale, int n_head, const float* rowstat,
+                 const unsigned short* x16, unsigned short* g16,
+                 const float* d_out, long ld_dout, long dout_bstride, int out_col0,
+                 float* d_values, long ld_dvalues, long dvalues_bstride, int add_residual, double* dscale, void* stream);
+
 /* kaiming_mlp.forward (pit.py:21-26): y = W2 * gelu_erf(W1 x + b1) + b2, optionally
  * followed by the trailing gelu of pit.py:111,121 (out_gelu=1).
  *   x (rows, n0) rows ldx apart; w1 (n1,n0), b1 (n1), w2 (n2,n1), b2 (n2) contiguous;

@@ -84,6 +84,9 @@ SIGNATURES = {
     "pit_thin_tail_scratch_floats": [],
     "pit_thin_tail_fwd": [_P, _L, _I, _I, _I, _P, _P, _P, _P, _L, _I, _P],
     "pit_thin_tail_bwd": [_P, _L, _I, _I, _I, _P, _P, _P, _L, _P, _L, _P, _P, _P, _P, _I, _P],
+    "pit_satt_supported": [_I, _I, _I, _I, _I],
+    "pit_satt_fwd": [_P, _I, _I, _I, _I, _F, _P, _L, _L, _I, _I, _P, _I, _I, _P, _P, _L, _L, _I, _I, _P, _P, _P],
+    "pit_satt_bwd": [_P, _I, _I, _I, _I, _F, _I, _I, _P, _I, _P, _P, _P, _P, _L, _L, _I, _P, _L, _L, _I, _P, _P],
     "pit_mlp_chain_supported": [_I, _I, _I, _I],
     "pit_mlp_chain_fwd": [_P, _L, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P],
     "pit_mlp_chain_bwd": [_I, _I, _I, _P, _P, _P, _P, _P, _L, _P, _L, _P, _P],

@@ -13,7 +13,7 @@ CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 # PIT_LIB_OUT: diagnostic builds (PIT_EXTRA_FLAGS=-DPIT_STAMPS ...) go to their OWN library and object directory, so they
 # can never be mistaken for the production library; load them with PIT_LIB_PATH
 LIB = os.environ.get("PIT_LIB_OUT") or os.path.join(CSRC, "libpit_hip.so")
-SOURCES = ("pit_abi.hip", "pit_select.hip", "pit_posatt.hip", "pit_block.hip", "pit_edge.hip", "pit_fold.hip", "pit_chain.hip", "pit_mlp.hip", "pit_mlp_slab.hip", "pit_loss.hip", "pit_norm.hip", "pit_optim.hip")
+SOURCES = ("pit_abi.hip", "pit_select.hip", "pit_posatt.hip", "pit_block.hip", "pit_edge.hip", "pit_fold.hip", "pit_chain.hip", "pit_satt.hip", "pit_mlp.hip", "pit_mlp_slab.hip", "pit_loss.hip", "pit_norm.hip", "pit_optim.hip")
 HEADERS = ("pit_common.h", "pit_gemm_rd.h", "pit_block_dev.h", os.path.join("..", "..", "include", "pit_hip.h"))
 FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17"]
 FLAGS += os.environ.get("PIT_EXTRA_FLAGS", "").split()      # diagnostic builds only (e.g. -DPIT_STAMPS, tools/stamp_tiles.py)

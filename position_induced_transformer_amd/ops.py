@@ -627,6 +627,7 @@ def _row_view(t: torch.Tensor) -> torch.Tensor:
 
 
 UNION_ATT = os.environ.get("PIT_UNION_ATT", "1") != "0"
+SATT = os.environ.get("PIT_SATT", "1") != "0"          # bf16 mode: dense self-attention of hid 128 / 256 on csrc/pit_satt.hip
 
 
 def _union_att_ok(plan: "MeshPlan", n_head: int, d: int, b: int, values: torch.Tensor) -> bool:
@@ -689,6 +690,28 @@ class _PosAtt(torch.autograd.Function):
             ctx.head_param = head_param
             ctx.union = 0
             ctx.save_for_backward(values, head, w.scale, w.scale)
+            return out
+        # round 6, bf16 mode: the processor's dense self-attention (locality 1.0) at hid 128 / 256 on bf16 MFMA with the values rounded
+        # once per layer (csrc/pit_satt.hip)
+        ctx.satt = None
+        if SATT and concat and not coord_dims and plan.self_attn and not plan.masked and ctx.math == MATH_MODES["bf16"] \
+                and values.dtype == torch.float32 and values.stride(1) % 4 == 0 and values.stride(0) % 4 == 0 and values.data_ptr() % 16 == 0 \
+                and _lib.lib().pit_satt_supported(int(plan.n_in), int(n_head), int(d), int(b), int(plan.mesh_batch)):
+            k_head, k_is_scale = (scale_in, True) if scale_in is not None else (head, head_is_scale)
+            out = out_buf if out_buf is not None else torch.empty((b, plan.n_out, (n_head + 1) * d), device=values.device, dtype=torch.float32)
+            x16 = torch.empty((b, j, d), device=values.device, dtype=torch.bfloat16)
+            rowstat = torch.empty((plan.mesh_batch, n_head, plan.n_out, 4), device=values.device, dtype=torch.float32)
+            scale = torch.empty((n_head,), device=values.device, dtype=torch.float32)
+            rc = _lib.lib().pit_satt_fwd(plan.mesh_in.data_ptr(), plan.mesh_batch, plan.n_in, plan.sdim, plan.metric_id, plan.period,
+                                         values.data_ptr(), values.stride(1), values.stride(0), b, d, k_head.data_ptr(), n_head,
+                                         1 if k_is_scale else 0, x16.data_ptr(), out.data_ptr(), out.stride(1), out.stride(0), d,
+                                         1 if out_buf is None else 0, rowstat.data_ptr(), scale.data_ptr(), _lib.stream_ptr())
+            _lib.check(rc, "pit_satt_fwd")
+            ctx.satt = x16
+            ctx.union = 0
+            ctx.plan, ctx.n_head, ctx.concat, ctx.head_is_scale = plan, n_head, concat, head_is_scale
+            ctx.head_param = head_param
+            ctx.save_for_backward(values, head, rowstat, scale)
             return out
         width = (n_head + (1 if concat else 0)) * d
         copy_inputs = 1 if concat else 0
@@ -763,6 +786,26 @@ class _PosAtt(torch.autograd.Function):
         # or the next MLP backward / the end of the pass runs it
         rider = None if (plan.nbr_idx is not None and _dw_pending_rows(values.device) >= BIG_RIDER_ROWS) \
             else _dw_take(values.device)
+        if getattr(ctx, "satt", None) is not None:       # dense self-attention on bf16 MFMA (csrc/pit_satt.hip)
+            if rider is not None:
+                _dw_run(rider)
+            if d_out.dtype != torch.float32 or d_out.stride(1) % 4 or d_out.stride(0) % 4 or d_out.data_ptr() % 16:
+                d_out = d_out.float().contiguous()
+            g16 = torch.empty((b, n_head, j, dv), device=values.device, dtype=torch.bfloat16)
+            rc = _lib.lib().pit_satt_bwd(plan.mesh_in.data_ptr(), plan.mesh_batch, plan.n_in, plan.sdim, plan.metric_id, plan.period,
+                                         b, dv, scale.data_ptr(), n_head, rowstat.data_ptr(), ctx.satt.data_ptr(), g16.data_ptr(),
+                                         d_out.data_ptr(), d_out.stride(1), d_out.stride(0), dv,
+                                         _lib.ptr(d_values), d_values.stride(1) if d_values is not None else 0,
+                                         d_values.stride(0) if d_values is not None else 0, 1,
+                                         work.data_ptr() if need_h else None, _lib.stream_ptr())
+            _lib.check(rc, "pit_satt_bwd")
+            if need_h:
+                flags = (1 if slot is not None else 0) | (4 if ctx.head_is_scale else 0)
+                if defer:
+                    _defer_head_finish(work, d_head, head, scale, n_head, 1 | (4 if ctx.head_is_scale else 0))
+                else:
+                    _finish_heads_now(work, d_head, head, scale, n_head, flags)
+            return d_values, (None if slot is not None else d_head), None, None, None, None, None, None, None, None, None
         if ctx.uatt is not None:                         # the union-tile backward: d_out read once, d(values) added from the tiles
             if rider is not None:
                 _dw_run(rider)

@@ -358,3 +358,55 @@ def test_fold_attention_backward_is_reproducible_and_matches_the_atomic_form():
         assert ops.fold_att_supported(plan, 2, 256, 3)
     finally:
         torch.use_deterministic_algorithms(False)
+
+
+# --------------------------------------------------------------------------- dense self-attention on bf16 MFMA (csrc/pit_satt.hip)
+@pytest.mark.parametrize("metric,batched,L,dim,heads,batch", [
+    ("euclid", True, 972, 256, 2, 2),            # Elasticity's processor layer (train_elasticity.py:67-75): per-sample clouds
+    ("euclid", True, 728, 128, 1, 3),            # NACA's (train_naca.py:79-89)
+    ("periodic2d", False, 256, 256, 2, 3),       # Vorticity's: one 16 x 16 periodic mesh for the batch
+    ("euclid", True, 300, 128, 2, 2),            # a point count that is no multiple of the 64-row tiles / 32-key steps
+    ("periodic1d", False, 256, 128, 1, 2),
+])
+def test_dense_self_attention_on_bf16_mfma_against_the_oracle(metric, batched, L, dim, heads, batch):
+    """posatt.forward (pit.py:37-57, locality 1.0) in the bf16 math mode - pit_satt_fwd / _bwd: values rounded once per layer, weights formed
+    in registers in the A-fragment layout of v_mfma_f32_16x16x32_bf16, a wavefront per 16 rows x all columns - against the oracle's
+    posatt_self at the mode's tolerances; the concat's input columns and their residual gradient are exact."""
+    from position_induced_transformer_amd import ops
+    g = torch.Generator().manual_seed(L + dim)
+    if metric == "euclid":
+        mesh = torch.rand(batch, L, 2, generator=g) if batched else torch.rand(L, 2, generator=g)
+    elif metric == "periodic2d":
+        mesh = orc.grid_mesh_2d(16, False).reshape(-1, 2)
+    else:
+        mesh = orc.line_mesh_1d(L)
+    values = torch.randn(batch, L, dim, generator=g)
+    lmda = torch.rand(heads, 1, 1, generator=g)
+    d_out = torch.randn(batch, L, (1 + heads) * dim, generator=g)
+    v0, l0 = values.clone().requires_grad_(True), lmda.clone().requires_grad_(True)
+    ref = orc.posatt_self(metric, batched, mesh, v0, l0, 1.0)
+    ref.backward(d_out)
+    plan = ops.MeshPlan(metric, mesh.cuda(), mesh.cuda(), 1.0, True)
+    calls = {"n": 0}
+    L_ = ops._lib.lib()
+    real = L_.pit_satt_fwd
+    with ops.math_mode("bf16"), ops.head_scale_route("host"):
+        assert L_.pit_satt_supported(L, heads, dim, batch, plan.mesh_batch)
+        v1, l1 = values.cuda().requires_grad_(True), lmda.cuda().requires_grad_(True)
+        out = ops.posatt_apply(v1, l1, plan, heads, concat=True)
+        out.backward(d_out.cuda())
+        # the same layer on the register-rounding kernels of the earlier rounds: both are the bf16 mode
+        saved = ops.SATT
+        ops.SATT = False
+        try:
+            v2, l2 = values.cuda().requires_grad_(True), lmda.cuda().requires_grad_(True)
+            out2 = ops.posatt_apply(v2, l2, plan, heads, concat=True)
+            out2.backward(d_out.cuda())
+        finally:
+            ops.SATT = saved
+    torch.cuda.synchronize()
+    assert torch.equal(out[..., :dim].cpu(), values)
+    assert _rel(out[..., dim:], ref[..., dim:]) <= 2e-2
+    assert _rel(v1.grad, v0.grad) <= 2e-2
+    assert float((l1.grad.cpu().reshape(-1) - l0.grad.reshape(-1)).norm()) <= 5e-2 * float(l0.grad.norm())
+    assert _rel(out[..., dim:], out2[..., dim:]) <= 1e-2 and _rel(v1.grad, v2.grad) <= 1.5e-2

@@ -10,5 +10,5 @@ for f in $C/*.hip; do
         | grep -E "Function Name|VGPRs:|ScratchSize" | paste - - - | sed 's/\[-Rpass[^ ]*//g')
   total=$(echo "$out" | grep -c "Function Name")
   echo "== $(basename $f): $total kernels"
-  echo "$out" | awk '{ n=""; v=""; s=""; for (i=1;i<=NF;i++) { if ($i=="Name:") n=$(i+1); if ($i=="VGPRs:") v=$(i+1); if ($i=="[bytes/lane]:") s=$(i+1) } if (s+0 > 0) printf "%6d %4d  %s\n", s, v, n }' | while read s v n; do echo "$s $v $(echo $n | /opt/rocm/lib/llvm/bin/llvm-cxxfilt | cut -c1-150)"; done | sort -rn
+  echo "$out" | awk '{ n=""; v=""; s=""; for (i=1;i<=NF;i++) { if ($i=="Name:") n=$(i+1); if ($i=="VGPRs:") v=$(i+1); if ($i=="[bytes/lane]:") s=$(i+1) } if (s+0 > 0) printf "%6d %4d  %s\n", s, v, n }' | sort -rn | c++filt | cut -c1-170
 done
