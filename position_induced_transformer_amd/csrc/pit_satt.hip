@@ -24,7 +24,13 @@ typedef __bf16 v8bf_t __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 
 constexpr int KC = 32;       // keys per step (one v_mfma_f32_16x16x32_bf16 k)
-constexpr int PADE = 8;      // bf16 pad of an LDS tile row
+constexpr int CGS = KC + 1;  // key rows per column group of a B tile in LDS: 33 x 32 B - with 32 the 16-byte stores that park a tile
+                             // (a wavefront = 2 keys x 32 column pieces) hit every column group at the same banks: 16-way conflicts
+#ifndef PIT_SATT_DBG
+#define PIT_SATT_DBG 0       // diagnostic builds (tools/variant_build.sh): 1 no tile loads / parks in the loop, 2 constant weights, 4 no
+                             // fragment reads / MFMAs, 8 no barrier in the loop, 16 no epilogue, 32 two steps only (results are void,
+                             // times are not)
+#endif
 
 struct SattArgs {
     const float* mesh; int mesh_batch, L, sdim, used; float period;
@@ -42,11 +48,16 @@ struct SattArgs {
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t wide_rsrc(const void* p) { return make_rsrc(p, 0x7ffffff0u); }
 constexpr unsigned OOB = 0x7ffffff8u;
 
-__device__ __forceinline__ v8s_t frag_tr(const unsigned short* t, int pitch, int n0, int l15, int kq) {
-    const unsigned short* a0 = t + (8 * kq + (l15 >> 2)) * pitch + n0 + 4 * (l15 & 3);
+// B fragment of column group ct from a tile stored [column group of 16][key 0..31 (+1 pad row)][16 columns].  The k order inside a 32-key step is PERMUTED - lane quarter kq holds keys 4 kq + 0..3 (element 0..3) and
+// 16 + 4 kq + 0..3 (element 4..7); the weights (A operand) are formed for the same keys - so that the two lane quarters of a
+// half-wave read 8 CONSECUTIVE keys = 256 contiguous bytes per ds_read_b64_tr_b16: conflict-free.  (With the natural order,
+// keys 8 kq + j, the quarters read rows 0-3 and 8-11 of any padded row-major image: 2-way conflicts at best - every padding was
+// tried on paper - on the reads that carry most of the kernel's LDS traffic.)
+__device__ __forceinline__ v8s_t frag_tr(const unsigned short* t, int ct, int l15, int kq) {
+    const unsigned short* a0 = t + (ct * CGS + 4 * kq + (l15 >> 2)) * 16 + 4 * (l15 & 3);
     typedef v4s_t __attribute__((address_space(3))) * lds_v4;
     const v4s_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(a0));
-    const v4s_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(a0 + 4 * pitch));
+    const v4s_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(a0 + 16 * 16));
     v8s_t f = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     return f;
 }
@@ -54,53 +65,62 @@ __device__ __forceinline__ f32x4_t mma(v8s_t a, v8s_t b, f32x4_t c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf_t, a), __builtin_bit_cast(v8bf_t, b), c, 0, 0, 0);
 }
 
-// 32 keys x DIM columns of a bf16 row-major tensor (rows beyond `nrows` load zeros): DIM * 32 / 8 / 256 16-byte pieces per thread
-template <int DIM> struct Tile { u32x4_t v[DIM * KC / 8 / 256]; };
-template <int DIM>
-__device__ __forceinline__ void tile_load(const unsigned short* src, long nrows, int k0, int tid, Tile<DIM>& t) {
+// 32 keys x W columns (from column col0 on) of a bf16 row-major tensor of DIM columns (rows beyond `nrows` load zeros):
+// W * 32 / 8 / 256 16-byte pieces per thread
+template <int W> struct Tile { u32x4_t v[W * KC / 8 / 256]; };
+template <int W, int DIM>
+__device__ __forceinline__ void tile_load(const unsigned short* src, long nrows, int k0, int tid, Tile<W>& t) {
     const __amdgpu_buffer_rsrc_t r = wide_rsrc(src);
 #pragma unroll
-    for (int u = 0; u < DIM * KC / 8 / 256; ++u) {
-        const int e = tid + 256 * u, k = e / (DIM / 8), c = e % (DIM / 8);
+    for (int u = 0; u < W * KC / 8 / 256; ++u) {
+        const int e = tid + 256 * u, k = e / (W / 8), c = e % (W / 8);
         const i32x4 q = __builtin_amdgcn_raw_buffer_load_b128(r, (int)((k0 + k) < nrows ? (unsigned)((((long)(k0 + k)) * DIM + 8 * c) * 2) : OOB), 0, 0);
         t.v[u] = u32x4_t{(unsigned)q.x, (unsigned)q.y, (unsigned)q.z, (unsigned)q.w};
     }
 }
-template <int DIM>
-__device__ __forceinline__ void tile_park(unsigned short* dst, int tid, const Tile<DIM>& t) {
+template <int W>
+__device__ __forceinline__ void tile_park(unsigned short* dst, int tid, const Tile<W>& t) {
 #pragma unroll
-    for (int u = 0; u < DIM * KC / 8 / 256; ++u) {
-        const int e = tid + 256 * u, k = e / (DIM / 8), c = e % (DIM / 8);
-        *reinterpret_cast<u32x4_t*>(dst + k * (DIM + PADE) + 8 * c) = t.v[u];
+    for (int u = 0; u < W * KC / 8 / 256; ++u) {
+        const int e = tid + 256 * u, k = e / (W / 8), c = e % (W / 8);               // 8 columns 8 c .. of key k
+        *reinterpret_cast<u32x4_t*>(dst + ((c >> 1) * CGS + k) * 16 + 8 * (c & 1)) = t.v[u];
     }
 }
 
-// MODE 0: out; MODE 1: d(values); MODE 2: d(scale).  NB = B tensors contracted per step (MODE 1: one per head), NA = accumulator sets
+// MODE 0: out; MODE 1: d(values); MODE 2: d(scale).  MODE 0 / 2 run ONE head per workgroup (their accumulators are per head: 64
+// registers instead of 128, two or three workgroups per CU instead of one), MODE 1 both (the heads add into one set of tiles) - and
+// with two heads HALF the columns: both heads' full-width tiles are 84 KB of LDS = one workgroup per CU and, at Elasticity's 160
+// row tiles, 160 of 256 CUs; the halves re-form the weights (vector ALU that the idle CUs had to spare).
+constexpr int satt_width(int H, int DIM, int MODE) { return (MODE == 1 && H == 2) ? DIM / 2 : DIM; }
+
 template <int H, int DIM, int MODE, bool PERIODIC>
-__global__ __launch_bounds__(256) void satt_kernel(SattArgs g) {
-    constexpr int NCT = DIM / 16, TP = DIM + PADE, NB = (MODE == 1) ? H : 1, NA = (MODE == 1) ? 1 : H;
+__global__ __launch_bounds__(256, 2) void satt_kernel(SattArgs g) {
+    constexpr int W = satt_width(H, DIM, MODE), NCS = DIM / W, NCT = W / 16, TSZ = CGS * W, HW = (MODE == 1) ? H : 1, NB = (MODE == 1) ? H : 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float4* keys = reinterpret_cast<float4*>(smem_raw);                        // [Lp] key coordinates (zero-padded to 3)
     const int Lp = (g.L + 2 * KC - 1) / (2 * KC) * (2 * KC);       // whole rounds of two steps: no conditional step (its loads would cost the counted waits)
-    unsigned short* tb = reinterpret_cast<unsigned short*>(keys + Lp);         // [2][NB][KC][TP]
+    unsigned short* tb = reinterpret_cast<unsigned short*>(keys + Lp + KC);    // [2][NB][TSZ]  (keys: one step of zeros beyond Lp - the
+                                                                               // weights of step s + 1 are formed in step s, unconditionally)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, kq = lane >> 4;
     int b, t;
-    if (!slab_of_xcd((int)blockIdx.x, g.batch, g.tiles, b, t)) return;
+    const int hsel = (MODE == 1) ? 0 : (int)blockIdx.x % H;                    // this workgroup's head (MODE 0 / 2)
+    // (consecutive ids - dealt to the XCDs in turn - walk the tiles of a sample: with a sample pinned to one XCD, ten samples put two
+    // on XCDs 0 and 1 and one workgroup per CU made that a second round)
+    const int cs = (MODE == 1) ? (int)blockIdx.x % NCS : 0;                    // this workgroup's column half (MODE 1, two heads)
+    if (!slab_of_linear((MODE == 1) ? (int)blockIdx.x / NCS : (int)blockIdx.x / H, g.batch, g.tiles, b, t)) return;
     const int mb = g.mesh_batch == 1 ? 0 : b;
     const int row = t * 64 + wave * 16 + l15;                                  // the A-fragment row of this lane
     const int rowc = row < g.L ? row : g.L - 1;
     const float* mesh = g.mesh + (long)mb * g.L * g.sdim;
-    // B tensors of this sample
     const unsigned short* bsrc[NB];
 #pragma unroll
-    for (int q = 0; q < NB; ++q) bsrc[q] = g.b16 + ((long)b * NB + q) * g.L * DIM;
-    Tile<DIM> reg[2][NB];
+    for (int q = 0; q < NB; ++q) bsrc[q] = g.b16 + ((long)b * NB + q) * g.L * DIM + cs * W;
+    Tile<W> reg[2][NB];
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
-        for (int q = 0; q < NB; ++q) tile_load<DIM>(bsrc[q], g.L, KC * s, tid, reg[s][q]);
-    // key coordinates -> LDS, this lane's row point, head scales, saved row statistics
-    for (int j = tid; j < Lp; j += 256) {
+        for (int q = 0; q < NB; ++q) tile_load<W, DIM>(bsrc[q], g.L, KC * s, tid, reg[s][q]);
+    for (int j = tid; j < Lp + KC; j += 256) {
         float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
         if (j < g.L) {
             p.x = mesh[(long)j * g.sdim];
@@ -111,57 +131,81 @@ __global__ __launch_bounds__(256) void satt_kernel(SattArgs g) {
     }
     const float rx = mesh[(long)rowc * g.sdim], ry = g.used > 1 ? mesh[(long)rowc * g.sdim + 1] : 0.0f,
                 rz = g.used > 2 ? mesh[(long)rowc * g.sdim + 2] : 0.0f;
-    float c[H], mbar[H];
+    float c[HW], c2[HW], mbar[HW];                                             // c2 = -c log2(e): exp(-c m) = exp2(c2 m), one multiply less per weight
 #pragma unroll
-    for (int h = 0; h < H; ++h) {
-        c[h] = g.head_is_scale ? g.head[h] : head_scale_from_lmda(g.head[h]);
-        mbar[h] = (MODE == 2) ? g.rowstat_r[(((long)mb * H + h) * g.L + rowc) * 4 + 3] : 0.0f;
+    for (int h = 0; h < HW; ++h) {
+        const int hh = hsel + h;
+        c[h] = g.head_is_scale ? g.head[hh] : head_scale_from_lmda(g.head[hh]);
+        c2[h] = -1.4426950408889634f * c[h];
+        mbar[h] = (MODE == 2) ? g.rowstat_r[(((long)mb * H + hh) * g.L + rowc) * 4 + 3] : 0.0f;
     }
 #pragma unroll
-    for (int q = 0; q < NB; ++q) tile_park<DIM>(tb + q * KC * TP, tid, reg[0][q]);
+    for (int q = 0; q < NB; ++q) tile_park<W>(tb + q * TSZ, tid, reg[0][q]);
 #pragma unroll
-    for (int q = 0; q < NB; ++q) tile_load<DIM>(bsrc[q], g.L, 2 * KC, tid, reg[0][q]);
-    f32x4_t acc[NA][NCT];
+    for (int q = 0; q < NB; ++q) tile_load<W, DIM>(bsrc[q], g.L, 2 * KC, tid, reg[0][q]);
+    f32x4_t acc[NCT];
 #pragma unroll
-    for (int a = 0; a < NA; ++a)
-#pragma unroll
-        for (int ct = 0; ct < NCT; ++ct) acc[a][ct] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    float rs[H], sm[H];
-#pragma unroll
-    for (int h = 0; h < H; ++h) { rs[h] = 0.0f; sm[h] = 0.0f; }
-    const int nsteps = Lp / KC;
+    for (int ct = 0; ct < NCT; ++ct) acc[ct] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    float rs = 0.0f, sm = 0.0f;                                               // MODE 0: row sum, sum of weight x distance
+    // the weights of step s_ in the A-fragment layout: element e of lane quarter kq = key 32 s + 16 (e >> 2) + 4 kq + (e & 3)
+#define PIT_SATT_KEYS(s_, kp_)                                                                                         \
+    _Pragma("unroll") for (int e = 0; e < 8; ++e) {                                                                   \
+        const int j = KC * (s_) + 16 * (e >> 2) + 4 * kq + (e & 3);                                                   \
+        kp_[e] = keys[j];                                                                                             \
+    }
+#define PIT_SATT_WEIGHTS(s_, kp_, dst_)                                                                               \
+    do {                                                                                                              \
+        _Pragma("unroll") for (int e = 0; e < 8; ++e) {                                                               \
+            const int j = KC * (s_) + 16 * (e >> 2) + 4 * kq + (e & 3);                                               \
+            const float m = sq_dist3t<PERIODIC>(rx, ry, rz, kp_[e].x, kp_[e].y, kp_[e].z, g.period);                  \
+            _Pragma("unroll") for (int h = 0; h < HW; ++h) {                                                          \
+                float ev = (j < g.L) ? __builtin_amdgcn_exp2f(__fmul_rn(m, c2[h])) : 0.0f;                            \
+                if (MODE == 0) { rs += ev; sm = fmaf(ev, m, sm); }                                                    \
+                if (MODE == 2) ev *= (m - mbar[h]);                                                                   \
+                dst_[h][e] = bf16_bits(ev);                                                                           \
+            }                                                                                                         \
+        }                                                                                                             \
+    } while (0)
+    const int nsteps = (PIT_SATT_DBG & 32) ? 2 : Lp / KC;
+    v8s_t af[2][HW];
+    {
+        float4 kp0[8];
+        __syncthreads();                                                      // (the key coordinates are in LDS)
+        PIT_SATT_KEYS(0, kp0);
+        PIT_SATT_WEIGHTS(0, kp0, af[0]);
+    }
     // step s contracts keys [32 s, 32 s + 32): its B tile(s) sit in buffer s & 1; register set (s + 1) & 1 holds tile s + 1 (parked
-    // now, into the buffer step s - 1 just left) and is re-loaded with tile s + 3; two steps per round: set indices are compile-time
+    // now, into the buffer step s - 1 just left) and is re-loaded with tile s + 3.  LDS reads are ISSUED FIRST - the next step's key
+    // coordinates, then the B fragments one group of column tiles ahead of their MFMAs - and the next step's weights (vector ALU,
+    // independent of this step's MFMAs) are formed while they arrive.  (First version: every key read and every fragment read
+    // directly in front of its use = sixteen exposed LDS round trips per step: 1.4 us per step at NACA's 8 MFMAs.)
+    constexpr int GS = 4 / HW, NG = NCT / GS;                                  // column tiles per fragment group (registers: two groups in flight)
+#define PIT_SATT_FRAGS(tile_, g_, dst_)                                                                               \
+    _Pragma("unroll") for (int u = 0; u < GS; ++u)                                                                    \
+        _Pragma("unroll") for (int h = 0; h < HW; ++h) dst_[u][h] = frag_tr(tile_ + h * TSZ, (g_) * GS + u, l15, kq);
 #define PIT_SATT_STEP(s_, j_)                                                                                          \
     do {                                                                                                              \
-        __syncthreads();                                                                                              \
-        _Pragma("unroll") for (int q = 0; q < NB; ++q) tile_park<DIM>(tb + ((((s_) + 1) & 1) * NB + q) * KC * TP, tid, reg[((j_) + 1) & 1][q]); \
-        _Pragma("unroll") for (int q = 0; q < NB; ++q) tile_load<DIM>(bsrc[q], g.L, KC * ((s_) + 3), tid, reg[((j_) + 1) & 1][q]); \
-        v8s_t af[H];                                                                                                  \
-        {                                                                                                             \
-            float w_[H][8];                                                                                           \
-            _Pragma("unroll") for (int e = 0; e < 8; ++e) {                                                           \
-                const int j = KC * (s_) + 8 * kq + e;                                                                 \
-                const float4 kp = keys[j];                                                                            \
-                const float m = sq_dist3t<PERIODIC>(rx, ry, rz, kp.x, kp.y, kp.z, g.period);                          \
-                _Pragma("unroll") for (int h = 0; h < H; ++h) {                                                       \
-                    float ev = (j < g.L) ? __expf(-__fmul_rn(m, c[h])) : 0.0f;                                        \
-                    if (MODE == 0) { rs[h] += ev; sm[h] = fmaf(ev, m, sm[h]); }                                       \
-                    if (MODE == 2) ev *= (m - mbar[h]);                                                               \
-                    w_[h][e] = ev;                                                                                    \
-                }                                                                                                     \
-            }                                                                                                         \
-            _Pragma("unroll") for (int h = 0; h < H; ++h)                                                             \
-                _Pragma("unroll") for (int e = 0; e < 8; ++e) af[h][e] = bf16_bits(w_[h][e]);                         \
+        if (!(PIT_SATT_DBG & 8)) __syncthreads();                                                                     \
+        if (!(PIT_SATT_DBG & 1)) {                                                                                    \
+        _Pragma("unroll") for (int q = 0; q < NB; ++q) tile_park<W>(tb + ((((s_) + 1) & 1) * NB + q) * TSZ, tid, reg[((j_) + 1) & 1][q]); \
+        _Pragma("unroll") for (int q = 0; q < NB; ++q) tile_load<W, DIM>(bsrc[q], g.L, KC * ((s_) + 3), tid, reg[((j_) + 1) & 1][q]); \
         }                                                                                                             \
-        const unsigned short* tile_ = tb + (((s_) & 1) * NB) * KC * TP;                                               \
-        _Pragma("unroll") for (int ct = 0; ct < NCT; ++ct) {                                                          \
-            if (MODE == 1) {                                                                                          \
-                _Pragma("unroll") for (int h = 0; h < H; ++h)                                                         \
-                    acc[0][ct] = mma(af[h], frag_tr(tile_ + h * KC * TP, TP, 16 * ct, l15, kq), acc[0][ct]);          \
-            } else {                                                                                                  \
-                const v8s_t bf_ = frag_tr(tile_, TP, 16 * ct, l15, kq);                                               \
-                _Pragma("unroll") for (int h = 0; h < H; ++h) acc[h][ct] = mma(af[h], bf_, acc[h][ct]);               \
+        const unsigned short* tile_ = tb + (((s_) & 1) * NB) * TSZ;                                                   \
+        float4 kp_[8];                                                                                                \
+        v8s_t f0_[GS][HW], f1_[GS][HW];                                                                               \
+        if (!(PIT_SATT_DBG & 2)) { PIT_SATT_KEYS((s_) + 1, kp_); }                                                    \
+        if (!(PIT_SATT_DBG & 4)) { PIT_SATT_FRAGS(tile_, 0, f0_); }                                                   \
+        if (!(PIT_SATT_DBG & 2)) { PIT_SATT_WEIGHTS((s_) + 1, kp_, af[((j_) + 1) & 1]); }                             \
+        else { _Pragma("unroll") for (int h = 0; h < HW; ++h) af[((j_) + 1) & 1][h] = af[(j_) & 1][h]; }              \
+        if (!(PIT_SATT_DBG & 4))                                                                                      \
+        _Pragma("unroll") for (int gi = 0; gi < NG; gi += 2) {                                                        \
+            if (gi + 1 < NG) { PIT_SATT_FRAGS(tile_, gi + 1, f1_); }                                                  \
+            _Pragma("unroll") for (int u = 0; u < GS; ++u)                                                            \
+                _Pragma("unroll") for (int h = 0; h < HW; ++h) acc[gi * GS + u] = mma(af[(j_) & 1][h], f0_[u][h], acc[gi * GS + u]); \
+            if (gi + 2 < NG) { PIT_SATT_FRAGS(tile_, gi + 2, f0_); }                                                  \
+            if (gi + 1 < NG) {                                                                                        \
+                _Pragma("unroll") for (int u = 0; u < GS; ++u)                                                        \
+                    _Pragma("unroll") for (int h = 0; h < HW; ++h) acc[(gi + 1) * GS + u] = mma(af[(j_) & 1][h], f1_[u][h], acc[(gi + 1) * GS + u]); \
             }                                                                                                         \
         }                                                                                                             \
     } while (0)
@@ -170,77 +214,67 @@ __global__ __launch_bounds__(256) void satt_kernel(SattArgs g) {
         PIT_SATT_STEP(sb + 1, 1);
     }
 #undef PIT_SATT_STEP
+#undef PIT_SATT_FRAGS
+#undef PIT_SATT_WEIGHTS
+#undef PIT_SATT_KEYS
+    // (the weights of the step beyond the last were formed too: keys >= L give zeros, rs / sm are unchanged by them)
     // ---- epilogues.  Accumulator register i of this lane is row 4 kq + i of the wave's 16, column 16 ct + l15; the per-row
     // quantities live on the lanes whose l15 is the row (summed over the four key quarters)
     const int r0 = t * 64 + wave * 16;
+    if ((PIT_SATT_DBG & 16) && acc[0][0] != 123.456f) return;
     if (MODE == 0) {
-        float inv[H];
+        rs += __shfl_xor(rs, 16, 64); rs += __shfl_xor(rs, 32, 64);
+        sm += __shfl_xor(sm, 16, 64); sm += __shfl_xor(sm, 32, 64);
+        const float inv = 1.0f / rs;
+        if (kq == 0 && row < g.L && (g.mesh_batch > 1 || b == 0)) {
+            float4 st;
+            st.x = 3.0e38f; st.y = 0.0f; st.z = inv; st.w = sm * inv;
+            *reinterpret_cast<float4*>(g.rowstat + (((long)mb * H + hsel) * g.L + row) * 4) = st;
+        }
+        if (blockIdx.x < H && tid == 0 && g.scale_out) g.scale_out[hsel] = c[0];
 #pragma unroll
-        for (int h = 0; h < H; ++h) {
-            rs[h] += __shfl_xor(rs[h], 16, 64); rs[h] += __shfl_xor(rs[h], 32, 64);
-            sm[h] += __shfl_xor(sm[h], 16, 64); sm[h] += __shfl_xor(sm[h], 32, 64);
-            inv[h] = 1.0f / rs[h];
-            if (kq == 0 && row < g.L && (g.mesh_batch > 1 || b == 0)) {
-                float4 st;
-                st.x = 3.0e38f; st.y = 0.0f; st.z = inv[h]; st.w = sm[h] * inv[h];
-                *reinterpret_cast<float4*>(g.rowstat + (((long)mb * H + h) * g.L + row) * 4) = st;
+        for (int i = 0; i < 4; ++i) {
+            const float iv = __shfl(inv, 4 * kq + i, 64);
+            const int n = r0 + 4 * kq + i;
+            if (n < g.L) {
+                float* dst = g.out + (long)b * g.out_bstride + (long)n * g.ld_out + g.out_col0 + hsel * DIM + l15;
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct) dst[16 * ct] = acc[ct][i] * iv;
             }
         }
-        if (blockIdx.x == 0 && tid < H && g.scale_out) g.scale_out[tid] = c[tid];
-#pragma unroll
-        for (int h = 0; h < H; ++h)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float iv = __shfl(inv[h], 4 * kq + i, 64);
-                const int n = r0 + 4 * kq + i;
-                if (n < g.L) {
-                    float* dst = g.out + (long)b * g.out_bstride + (long)n * g.ld_out + g.out_col0 + h * DIM + l15;
-#pragma unroll
-                    for (int ct = 0; ct < NCT; ++ct) dst[16 * ct] = acc[h][ct][i] * iv;
-                }
-            }
     } else if (MODE == 1) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int n = r0 + 4 * kq + i;
             if (n < g.L) {
-                float* dst = g.d_values + (long)b * g.dv_bstride + (long)n * g.ld_dv + l15;
-                const float* res = g.d_out + (long)b * g.dout_bstride + (long)n * g.ld_dout + l15;
+                float* dst = g.d_values + (long)b * g.dv_bstride + (long)n * g.ld_dv + cs * W + l15;
+                const float* res = g.d_out + (long)b * g.dout_bstride + (long)n * g.ld_dout + cs * W + l15;
 #pragma unroll
-                for (int ct = 0; ct < NCT; ++ct) dst[16 * ct] = acc[0][ct][i] + (g.add_residual ? res[16 * ct] : 0.0f);
+                for (int ct = 0; ct < NCT; ++ct) dst[16 * ct] = acc[ct][i] + (g.add_residual ? res[16 * ct] : 0.0f);
             }
         }
     } else {
-        double part[H];
+        double part = 0.0;
+        const float inv_l = g.rowstat_r[(((long)mb * H + hsel) * g.L + rowc) * 4 + 2];
+        const __amdgpu_buffer_rsrc_t rd = wide_rsrc(g.d_out);
 #pragma unroll
-        for (int h = 0; h < H; ++h) {
-            part[h] = 0.0;
-            const float inv_l = g.rowstat_r[(((long)mb * H + h) * g.L + rowc) * 4 + 2];
+        for (int i = 0; i < 4; ++i) {
+            const float iv = __shfl(inv_l, 4 * kq + i, 64);
+            const int n = r0 + 4 * kq + i;
+            float sd = 0.0f;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float iv = __shfl(inv_l, 4 * kq + i, 64);
-                const int n = r0 + 4 * kq + i;
-                const __amdgpu_buffer_rsrc_t rd = wide_rsrc(g.d_out);
-                float s = 0.0f;
-#pragma unroll
-                for (int ct = 0; ct < NCT; ++ct) {
-                    const float dv = buf_load(rd, n < g.L ? (unsigned)(((long)b * g.dout_bstride + (long)n * g.ld_dout + g.out_col0 + h * DIM + 16 * ct + l15) * 4) : OOB);
-                    s = fmaf(acc[h][ct][i], dv, s);
-                }
-                part[h] += (double)s * (double)iv;
+            for (int ct = 0; ct < NCT; ++ct) {
+                const float dv = buf_load(rd, n < g.L ? (unsigned)(((long)b * g.dout_bstride + (long)n * g.ld_dout + g.out_col0 + hsel * DIM + 16 * ct + l15) * 4) : OOB);
+                sd = fmaf(acc[ct][i], dv, sd);
             }
-            part[h] = wave_sum_d(part[h]);
+            part += (double)sd * (double)iv;
         }
-        __shared__ double wred[4][2];
-        if (lane == 0) {
-#pragma unroll
-            for (int h = 0; h < H; ++h) wred[wave][h] = part[h];
-        }
+        part = wave_sum_d(part);
+        __shared__ double wred[4];
+        if (lane == 0) wred[wave] = part;
         __syncthreads();
-        if (tid < H) {
-            const double tot = wred[0][tid] + wred[1][tid] + wred[2][tid] + wred[3][tid];
-            atomicAdd(g.dscale + (long)tid * PIT_DSCALE_SLOTS + ((int)blockIdx.x & (PIT_DSCALE_SLOTS - 1)), -tot);
-        }
+        if (tid == 0)
+            atomicAdd(g.dscale + (long)hsel * PIT_DSCALE_SLOTS + (((int)blockIdx.x / H) & (PIT_DSCALE_SLOTS - 1)), -(wred[0] + wred[1] + wred[2] + wred[3]));
     }
 }
 
@@ -273,13 +307,13 @@ __global__ __launch_bounds__(256) void satt_prep_kernel(PrepArgs g, int bwd) {
     }
 }
 
-size_t satt_smem(int L, int dim, int nb) { return (size_t)((L + 2 * KC - 1) / (2 * KC) * (2 * KC)) * 16 + (size_t)2 * nb * KC * (dim + PADE) * 2; }
+size_t satt_smem(int L, int width, int nb) { return (size_t)((L + 2 * KC - 1) / (2 * KC) * (2 * KC) + KC) * 16 + (size_t)2 * nb * CGS * width * 2; }
 bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 template <int H, int DIM, int MODE>
 void launch_satt(const SattArgs& g, int periodic, hipStream_t s) {
-    const dim3 grid((unsigned)slab_grid(g.batch, g.tiles));
-    const size_t sm = satt_smem(g.L, DIM, MODE == 1 ? H : 1);
+    const dim3 grid((unsigned)(g.batch * g.tiles * (MODE == 1 ? DIM / satt_width(H, DIM, MODE) : H)));
+    const size_t sm = satt_smem(g.L, satt_width(H, DIM, MODE), MODE == 1 ? H : 1);
     if (periodic) {
         static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(satt_kernel<H, DIM, MODE, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024), true);
         (void)once;

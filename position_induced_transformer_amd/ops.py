@@ -627,7 +627,16 @@ def _row_view(t: torch.Tensor) -> torch.Tensor:
 
 
 UNION_ATT = os.environ.get("PIT_UNION_ATT", "1") != "0"
-SATT = os.environ.get("PIT_SATT", "1") != "0"          # bf16 mode: dense self-attention of hid 128 / 256 on csrc/pit_satt.hip
+# bf16 mode: dense self-attention of hid 128 / 256 on csrc/pit_satt.hip.  "auto": where it measured faster than the fp32-era kernels
+# with rounded operands - two heads x hid 256 on >= 512 points (Elasticity: 149 us per layer against 191; NACA 728 x 128 x 1 and
+# Vorticity 256 x 256 x 2 measured 6 / 3 us per layer SLOWER); "1": every supported shape; "0": never
+SATT = os.environ.get("PIT_SATT", "auto")
+
+
+def _satt_pays(n_pts: int, n_head: int, d: int) -> bool:
+    if SATT == "auto":
+        return n_head == 2 and d == 256 and n_pts >= 512
+    return SATT not in ("0", "", False)
 
 
 def _union_att_ok(plan: "MeshPlan", n_head: int, d: int, b: int, values: torch.Tensor) -> bool:
@@ -694,7 +703,7 @@ class _PosAtt(torch.autograd.Function):
         # round 6, bf16 mode: the processor's dense self-attention (locality 1.0) at hid 128 / 256 on bf16 MFMA with the values rounded
         # once per layer (csrc/pit_satt.hip)
         ctx.satt = None
-        if SATT and concat and not coord_dims and plan.self_attn and not plan.masked and ctx.math == MATH_MODES["bf16"] \
+        if _satt_pays(int(plan.n_in), int(n_head), int(d)) and concat and not coord_dims and plan.self_attn and not plan.masked and ctx.math == MATH_MODES["bf16"] \
                 and values.dtype == torch.float32 and values.stride(1) % 4 == 0 and values.stride(0) % 4 == 0 and values.data_ptr() % 16 == 0 \
                 and _lib.lib().pit_satt_supported(int(plan.n_in), int(n_head), int(d), int(b), int(plan.mesh_batch)):
             k_head, k_is_scale = (scale_in, True) if scale_in is not None else (head, head_is_scale)

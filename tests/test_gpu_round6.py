@@ -390,20 +390,32 @@ def test_dense_self_attention_on_bf16_mfma_against_the_oracle(metric, batched, L
     calls = {"n": 0}
     L_ = ops._lib.lib()
     real = L_.pit_satt_fwd
-    with ops.math_mode("bf16"), ops.head_scale_route("host"):
-        assert L_.pit_satt_supported(L, heads, dim, batch, plan.mesh_batch)
-        v1, l1 = values.cuda().requires_grad_(True), lmda.cuda().requires_grad_(True)
-        out = ops.posatt_apply(v1, l1, plan, heads, concat=True)
-        out.backward(d_out.cuda())
-        # the same layer on the register-rounding kernels of the earlier rounds: both are the bf16 mode
-        saved = ops.SATT
-        ops.SATT = False
-        try:
+
+    def counted(*a):
+        calls["n"] += 1
+        return real(*a)
+
+    saved = ops.SATT
+    L_.pit_satt_fwd = counted
+    try:
+        with ops.math_mode("bf16"), ops.head_scale_route("host"):
+            assert L_.pit_satt_supported(L, heads, dim, batch, plan.mesh_batch)
+            ops.SATT = "1"                       # ("auto" keeps these kernels for the shapes where they measured faster: ops._satt_pays)
+            v1, l1 = values.cuda().requires_grad_(True), lmda.cuda().requires_grad_(True)
+            out = ops.posatt_apply(v1, l1, plan, heads, concat=True)
+            out.backward(d_out.cuda())
+            assert calls["n"] == 1
+            # the same layer on the register-rounding kernels of the earlier rounds: both are the bf16 mode
+            ops.SATT = "0"
             v2, l2 = values.cuda().requires_grad_(True), lmda.cuda().requires_grad_(True)
             out2 = ops.posatt_apply(v2, l2, plan, heads, concat=True)
             out2.backward(d_out.cuda())
-        finally:
-            ops.SATT = saved
+            assert calls["n"] == 1
+            ops.SATT = "auto"
+            assert ops._satt_pays(972, 2, 256) and not ops._satt_pays(728, 1, 128) and not ops._satt_pays(256, 2, 256)
+    finally:
+        ops.SATT = saved
+        L_.pit_satt_fwd = real
     torch.cuda.synchronize()
     assert torch.equal(out[..., :dim].cpu(), values)
     assert _rel(out[..., dim:], ref[..., dim:]) <= 2e-2
