@@ -5,7 +5,7 @@
 // Such an MLP ran as two GEMM launches forward (12.7 us each at Vorticity: 2.5 % MFMA busy, 45 vector instructions per MFMA - the
 // fp32 activations are rounded in-kernel, one round trip per 64-k chunk, 160-320 workgroups that each pull their weights through
 // the L1) and three launches for the backward data path (gelu' pass 5.4 + dZ1 15.4 + dX 12.0 us): 58 of a block's 122 us.  Here
-// each direction is ONE launch on 32-row slabs:
+// each direction is ONE launch on 32-row (or 48-row: chain_slab_rows) slabs:
 //   mlp_chain_fwd_kernel   X slab -> LDS (bf16) once; W1 | W2 - bf16 copies formed once per weight version by the host side -
 //                          stream through LDS as 64-k panels, double-buffered, one barrier per panel, the next panel's loads in
 //                          flight under the current panel's v_mfma_f32_16x16x32_bf16; Z1 / H / Z2 / Y leave from the accumulators
@@ -22,7 +22,7 @@ typedef short v4s_t __attribute__((ext_vector_type(4)));
 typedef short v8s_t __attribute__((ext_vector_type(8)));
 typedef __bf16 v8bf_t __attribute__((ext_vector_type(8)));
 
-constexpr int CR = 32;       // rows per workgroup
+// rows per workgroup: the CR template parameter, 32 or 48 (chain_slab_rows below)
 constexpr int PADE = 8;      // pad (bf16 elements) of every LDS row: 16 bytes
 constexpr int NT = 512;      // threads: eight waves, wave w owns rows x columns [w N1 / 8, (w + 1) N1 / 8)
 constexpr int NSETS = 4;     // weight panels in flight in registers (first version: one, 256 threads - every panel waited a full L2
@@ -117,7 +117,7 @@ __device__ __forceinline__ void bwd_panel_park(unsigned short* dst, int tid, con
     }
 }
 
-template <int N1>
+template <int N1, int CR>
 __global__ __launch_bounds__(NT) void mlp_chain_fwd_kernel(ChainArgs g) {
     constexpr int KP = Kp<N1>::v, NC = N1 / 8, CT = NC / 16, RT = CR / 16, WP = KP + PADE, HP = N1 + PADE;
     extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
@@ -223,7 +223,7 @@ __global__ __launch_bounds__(NT) void mlp_chain_fwd_kernel(ChainArgs g) {
 
 #undef PIT_CHAIN_LOAD
 
-template <int N1>
+template <int N1, int CR>
 __global__ __launch_bounds__(NT) void mlp_chain_bwd_kernel(ChainArgs g) {
     constexpr int KP = Kp<N1>::v, NC = N1 / 8, CT = NC / 16, RT = CR / 16, AP = N1 + PADE, WP = N1 + PADE;
     extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
@@ -354,8 +354,28 @@ bool chain_shape_ok(int rows, int n0, int n1, int n2) {
     return rows > 0 && n1 == n2 && (n1 == 128 || n1 == 256) && n0 >= n1 && n0 % n1 == 0 && n0 <= 1024 &&
            (long)rows * n0 * 4 < (1L << 31) - 65536;
 }
-size_t chain_fwd_smem(int n0, int n1) { return (size_t)(CR * (std::max(n0, n1) + PADE) + 2 * n1 * (n1 / 4 + PADE)) * 2; }
-size_t chain_bwd_smem(int n1) { return (size_t)(2 * CR * (n1 + PADE) + 2 * (n1 / 4) * (n1 + PADE)) * 2; }
+size_t chain_fwd_smem(int cr, int n0, int n1) { return (size_t)(cr * (std::max(n0, n1) + PADE) + 2 * n1 * (n1 / 4 + PADE)) * 2; }
+size_t chain_bwd_smem(int cr, int n1) { return (size_t)(2 * cr * (n1 + PADE) + 2 * (n1 / 4) * (n1 + PADE)) * 2; }
+// Rows per workgroup.  A hid-256 workgroup fills a CU's LDS (one per CU) and takes ~19 us whatever its height (its 0.5 MB of weights
+// at the rate one CU pulls from L2): Elasticity's 9 720 rows are 304 slabs of 32 = two rounds on 256 CUs (38 / 35 us measured), 203
+// slabs of 48 = one.  48 when that saves a round and the images still fit; hid 128 runs several workgroups per CU: 32.
+int chain_slab_rows(int rows, int n0, int n1) {
+    if (n1 != 256 || chain_fwd_smem(48, n0, n1) > 160 * 1024) return 32;
+    const int cus = 256, r32 = ((rows + 31) / 32 + cus - 1) / cus, r48 = ((rows + 47) / 48 + cus - 1) / cus;
+    return r48 < r32 ? 48 : 32;
+}
+template <int N1, int CR>
+void chain_launch_fwd(const ChainArgs& g, hipStream_t s) {
+    static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_chain_fwd_kernel<N1, CR>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
+    (void)once;
+    hipLaunchKernelGGL((mlp_chain_fwd_kernel<N1, CR>), dim3((unsigned)((g.rows + CR - 1) / CR)), dim3(NT), chain_fwd_smem(CR, g.n0, N1), s, g);
+}
+template <int N1, int CR>
+void chain_launch_bwd(const ChainArgs& g, hipStream_t s) {
+    static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_chain_bwd_kernel<N1, CR>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
+    (void)once;
+    hipLaunchKernelGGL((mlp_chain_bwd_kernel<N1, CR>), dim3((unsigned)((g.rows + CR - 1) / CR)), dim3(NT), chain_bwd_smem(CR, N1), s, g);
+}
 bool a16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace
@@ -376,18 +396,10 @@ extern "C" int pit_mlp_chain_fwd(const float* x, long ldx, int rows, int n0, int
     ChainArgs g = ChainArgs();
     g.rows = rows; g.n0 = n0; g.n1 = n1; g.x = x; g.ldx = ldx; g.w1b = w1_bf16; g.w2b = w2_bf16; g.b1 = b1; g.b2 = b2;
     g.z1 = z1; g.h = h; g.z2 = z2; g.y = y; g.ldy = ldy;
-    const dim3 grid((unsigned)((rows + CR - 1) / CR));
-    const size_t sm = chain_fwd_smem(n0, n1);
     hipStream_t s = (hipStream_t)stream;
-    if (n1 == 256) {
-        static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_chain_fwd_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
-        (void)once;
-        hipLaunchKernelGGL((mlp_chain_fwd_kernel<256>), grid, dim3(NT), sm, s, g);
-    } else {
-        static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_chain_fwd_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
-        (void)once;
-        hipLaunchKernelGGL((mlp_chain_fwd_kernel<128>), grid, dim3(NT), sm, s, g);
-    }
+    if (n1 == 128) chain_launch_fwd<128, 32>(g, s);
+    else if (chain_slab_rows(rows, n0, n1) == 48) chain_launch_fwd<256, 48>(g, s);
+    else chain_launch_fwd<256, 32>(g, s);
     PIT_CHECK_LAUNCH();
     return 0;
 }
@@ -403,18 +415,10 @@ extern "C" int pit_mlp_chain_bwd(int rows, int n0, int n1, const unsigned short*
     ChainArgs g = ChainArgs();
     g.rows = rows; g.n0 = n0; g.n1 = n1; g.w1b = w1_bf16; g.w2b = w2_bf16; g.z1r = z1; g.z2r = z2; g.d_y = d_y; g.ld_dy = ld_dy;
     g.d_x = d_x; g.ld_dx = ld_dx; g.dz1 = scratch; g.dz2 = scratch + (long)rows * n1;
-    const dim3 grid((unsigned)((rows + CR - 1) / CR));
-    const size_t sm = chain_bwd_smem(n1);
     hipStream_t s = (hipStream_t)stream;
-    if (n1 == 256) {
-        static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_chain_bwd_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
-        (void)once;
-        hipLaunchKernelGGL((mlp_chain_bwd_kernel<256>), grid, dim3(NT), sm, s, g);
-    } else {
-        static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_chain_bwd_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
-        (void)once;
-        hipLaunchKernelGGL((mlp_chain_bwd_kernel<128>), grid, dim3(NT), sm, s, g);
-    }
+    if (n1 == 128) chain_launch_bwd<128, 32>(g, s);
+    else if (chain_slab_rows(rows, n0, n1) == 48) chain_launch_bwd<256, 48>(g, s);
+    else chain_launch_bwd<256, 32>(g, s);
     PIT_CHECK_LAUNCH();
     return 0;
 }
