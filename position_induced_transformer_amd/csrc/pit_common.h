@@ -225,6 +225,11 @@ __device__ __forceinline__ void buf_load4(__amdgpu_buffer_rsrc_t r, unsigned byt
     const i32x4 q = __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0);
     v[0] = __int_as_float(q.x); v[1] = __int_as_float(q.y); v[2] = __int_as_float(q.z); v[3] = __int_as_float(q.w);
 }
+// raw buffer store: an offset at or beyond the resource's size drops the store (row / column tails without a branch, and without the
+// 64-bit per-lane addresses a predicated global store keeps alive - mlp_bwd64 spilled nine of them)
+__device__ __forceinline__ void buf_store(__amdgpu_buffer_rsrc_t r, unsigned byte_off, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(v), r, (int)byte_off, 0, 0);
+}
 // the same with the sc1 cache policy (served by L2 / memory, never by this CU's L1): loads of bytes ANOTHER workgroup of the
 // same launch has stored (csrc/pit_latent.hip)
 __device__ __forceinline__ void buf_load4_sc1(__amdgpu_buffer_rsrc_t r, unsigned byte_off, float (&v)[4]) {

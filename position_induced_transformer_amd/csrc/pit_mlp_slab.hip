@@ -62,10 +62,22 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd64_kernel(SlabFwdArgs g) {
             *reinterpret_cast<float4*>(xs + r * XP + 4 * c4) = make_float4(pre[p][0], pre[p][1], pre[p][2], pre[p][3]);
         }
     };
+    // the accumulator-shaped stores (Z1, H, Z2, Y) through buffer resources sized to the tensors: 32-bit offsets, row tails dropped
+    // by the hardware (mlp_bwd64 below: what the 64-bit per-lane addresses of predicated global stores cost)
+    const unsigned rows64 = (unsigned)g.rows * (BD * 4u), ldy4 = (unsigned)g.ldy * 4u;
+    const __amdgpu_buffer_rsrc_t rz1 = make_rsrc(g.z1, rows64), rh = make_rsrc(g.h, rows64), rz2 = make_rsrc(g.z2, g.z2 ? rows64 : 0u);
+    const __amdgpu_buffer_rsrc_t ry = make_rsrc(g.y, THIN ? 0u : ((unsigned)(g.rows - 1) * (unsigned)g.ldy + BD) * 4u);
+    unsigned row_c1[4], row_y[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        row_c1[i] = (unsigned)((4 * kq + i) * BD + c1) * 4u;
+        row_y[i] = (unsigned)(4 * kq + i) * ldy4 + (unsigned)c1 * 4u;
+    }
     int slab = blockIdx.x;
     if (slab < nslabs) fetch(slab);
     for (; slab < nslabs; slab += gridDim.x) {
         const long m0 = (long)slab * 64;
+        const unsigned slab_off1 = (unsigned)m0 * (BD * 4u);
         park_x();
         __syncthreads();
         if (slab + (int)gridDim.x < nslabs) fetch(slab + gridDim.x);       // the next slab travels while this one is contracted
@@ -87,12 +99,11 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd64_kernel(SlabFwdArgs g) {
                 const float z = a0[i] + a1[i] + bias;
                 const float hv = gelu_erf(z);
                 hs[r * HP + c1] = hv;
-                if (m0 + r < g.rows) {
-                    g.z1[(m0 + r) * BD + c1] = z;
+                const unsigned off = slab_off1 + row_c1[i] + rt * (16 * BD * 4);     // (rows beyond the last: dropped by the resources' size)
+                buf_store(rz1, off, z);
 #ifndef PIT_SLAB_NO_H      // (timing experiment: the hidden activation not stored)
-                    g.h[(m0 + r) * BD + c1] = hv;
+                buf_store(rh, off, hv);
 #endif
-                }
             }
         }
         __syncthreads();
@@ -130,11 +141,9 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd64_kernel(SlabFwdArgs g) {
                 }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const long r = m0 + rt * 16 + 4 * kq + i;
-                    if (r >= g.rows) continue;
                     float v = o0[i] + o1[i] + bias2;
-                    if (g.out_gelu) { g.z2[r * BD + c1] = v; v = gelu_erf(v); }
-                    g.y[r * g.ldy + c1] = v;
+                    if (g.out_gelu) { buf_store(rz2, slab_off1 + row_c1[i] + rt * (16 * BD * 4), v); v = gelu_erf(v); }
+                    buf_store(ry, ((unsigned)m0 + rt * 16) * ldy4 + row_y[i], v);
                 }
             }
         }
@@ -174,6 +183,18 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd64_kernel(SlabBwdArgs g) {
         for (int s = 0; s < 4; ++s)
 #pragma unroll
             for (int e = 0; e < 4; ++e) w1v[t][s][e] = (col < g.n0) ? g.w1[(long)(16 * s + 4 * kq + e) * g.n0 + col] : 0.0f;
+    }
+    // the accumulator-shaped accesses (Z1 in, dZ1 / dX out) go through buffer resources sized to the tensors: 32-bit offsets, row
+    // tails dropped by the hardware.  (As predicated global accesses their 64-bit per-lane addresses were hoisted out of the slab
+    // loop and nine of them spilled: reloaded in front of the dX stores, each reload a full s_waitcnt vmcnt(0).)
+    const __amdgpu_buffer_rsrc_t rz1 = make_rsrc(g.z1, (unsigned)g.rows * (BD * 4u)), rdz1 = make_rsrc(g.dz1, (unsigned)g.rows * (BD * 4u));
+    const unsigned ldx4 = (unsigned)g.ld_dx * 4u;
+    const __amdgpu_buffer_rsrc_t rdx = make_rsrc(g.d_x, g.d_x ? ((unsigned)(g.rows - 1) * (unsigned)g.ld_dx + (unsigned)g.n0) * 4u : 0u);
+    unsigned row_c1[4], row_dx[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        row_c1[i] = (unsigned)((4 * kq + i) * BD + c1) * 4u;
+        row_dx[i] = (unsigned)(4 * kq + i) * ldx4;
     }
     // a thread owns 4 x float4 of the slab's 64 x 64 dY tile: rows (tid >> 4) + 16 p, columns 4 (tid & 15)
     const int pr = tid >> 4, pc = 4 * (tid & 15);
@@ -230,13 +251,11 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd64_kernel(SlabBwdArgs g) {
         }
         // gelu' argument of this wave's dZ1 tiles: requested before the barrier
         float z1v[4][4];
+        const unsigned slab_off1 = (unsigned)m0 * (BD * 4u);       // byte offset of the slab's first row in the (rows, 64) tensors
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const long r = m0 + rt * 16 + 4 * kq + i;
-                z1v[rt][i] = (r < g.rows) ? g.z1[r * BD + c1] : 0.0f;
-            }
+            for (int i = 0; i < 4; ++i) z1v[rt][i] = buf_load(rz1, slab_off1 + row_c1[i] + rt * (16 * BD * 4));
         __syncthreads();
         if (slab + (int)gridDim.x < nslabs) fetch(slab + gridDim.x);
         // ---- dZ1 = (dZ2 W2) * gelu'(Z1)
@@ -264,7 +283,7 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd64_kernel(SlabBwdArgs g) {
                 const int r = rt * 16 + 4 * kq + i;
                 const float v = (a0[i] + a1[i]) * gelu_erf_grad(z1v[rt][i]);
                 ds1[r * P1 + c1] = v;
-                if (m0 + r < g.rows) g.dz1[(m0 + r) * BD + c1] = v;
+                buf_store(rdz1, slab_off1 + row_c1[i] + rt * (16 * BD * 4), v);      // (rows beyond the last: dropped by the resource's size)
             }
         }
         __syncthreads();
@@ -285,13 +304,9 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd64_kernel(SlabBwdArgs g) {
                         o0 = mfma_16x16x4(a.z, w1v[t][s][2], o0);
                         o1 = mfma_16x16x4(a.w, w1v[t][s][3], o1);
                     }
-                    if (col < g.n0) {
+                    const unsigned tile_off = (col < g.n0) ? ((unsigned)m0 + rt * 16) * ldx4 + col * 4u : 0xF8000000u;
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            const long r = m0 + rt * 16 + 4 * kq + i;
-                            if (r < g.rows) g.d_x[r * g.ld_dx + col] = o0[i] + o1[i];
-                        }
-                    }
+                    for (int i = 0; i < 4; ++i) buf_store(rdx, tile_off + row_dx[i], o0[i] + o1[i]);
                 }
             }
         }
@@ -332,6 +347,7 @@ bool try_launch_mlp_fwd64(const float* x, long ldx, int rows, int n0, int n1, in
     if ((reinterpret_cast<uintptr_t>(x) & 15) || ldx % 4 || (reinterpret_cast<uintptr_t>(w1) & 15) || (reinterpret_cast<uintptr_t>(w2) & 15)) return false;
     const bool thin = n2 <= 4;
     if (((unsigned long long)(rows - 1) * ldx + n0) * 4ull > PIT_MAX_BUFFER_BYTES) return false;
+    if ((unsigned long long)rows * std::max<long>(ldy, BD) * 4ull > PIT_MAX_BUFFER_BYTES) return false;
     SlabFwdArgs g;
     g.x = x; g.ldx = ldx; g.rows = rows; g.n0 = n0; g.n2 = n2; g.w1 = w1; g.b1 = b1; g.w2 = w2; g.b2 = b2; g.out_gelu = out_gelu;
     g.z1 = z1; g.h = h; g.z2 = z2; g.y = y; g.ldy = ldy;
@@ -361,6 +377,7 @@ bool try_launch_mlp_bwd64(int rows, int n0, int n1, int n2, const float* w1, con
                           int out_gelu, const float* d_y, long ld_dy, float* d_x, long ld_dx, float* dz1, float* dz2, hipStream_t s) {
     if (!pit_mlp_slab_eligible(rows, n0, n1, n2)) return false;
     const bool thin = n2 <= 4;
+    if ((unsigned long long)rows * std::max<long>(ld_dx, BD) * 4ull > PIT_MAX_BUFFER_BYTES) return false;      // (32-bit buffer offsets)
     if (!thin && ((reinterpret_cast<uintptr_t>(d_y) & 15) || ld_dy % 4 || (z2 && (reinterpret_cast<uintptr_t>(z2) & 15)) ||
                   (reinterpret_cast<uintptr_t>(dz2) & 15))) return false;
     SlabBwdArgs g;
