@@ -119,6 +119,10 @@ template <> struct Fl<true> {
     static __device__ __forceinline__ float get(const T* p) { return bf16_to_f(*p); }
 };
 
+#ifndef PIT_FOLD_DBG
+#define PIT_FOLD_DBG 0       // diagnostic builds (tools/variant_build.sh) of fold_bwd_kernel: 1 no d(scale) contraction, 2 no d(VW) contraction,
+                             // 4 no epilogue, 8 tiles not refreshed in the loop, 16 no union staging (results are void, times are not)
+#endif
 struct FoldArgs {
     pit_slab_plan p; int um, batch, dim, chunks;
     const float* vw; long ld_vw, vw_bstride;             // (batch, n_in, dim * H), head-interleaved: column n * H + h = head h's value for output column n
@@ -132,7 +136,9 @@ struct FoldArgs {
 };
 
 // workgroup id -> (sample, slab, chunk): all workgroups of a slab on ONE XCD (ids are dealt to the XCDs round-robin) - what they
-// share, the slab's weight tiles, is the larger stream (the weights are the same for every sample); a sample's VW rows are small
+// share, the slab's weight tiles, is the larger stream (the weights are the same for every sample); a sample's VW rows are small.
+// (Darcy's last slab is short - 1849 rows = 7 x 256 + 57 - and its XCD gets a quarter of the others' work; dealing sample b slab
+// (x + b) mod 8 instead measured 245.3 against 245.4 us: the dispatcher already fills idle CUs with the later ids.)
 __device__ __forceinline__ bool fold_ids(int id, const FoldArgs& g, int& b, int& slab, int& chunk) {
     const int x = id & 7, k = id >> 3, per = g.batch * g.chunks;
     slab = x + 8 * (k / per);
@@ -148,26 +154,26 @@ __device__ __forceinline__ bool fold_ids(int id, const FoldArgs& g, int& b, int&
 // t owns 16-byte piece e = t + 256 u of the (um rows x 16 H pieces) block and de-interleaves it on its way into the per-head
 // tiles.  The plan pads its key lists with key 0 (a valid row); slots beyond the union load out of range (zeros) -
 // unconditional loads, nothing consumed before all of them are requested.
-template <bool BF, int H>
+template <bool BF, int H, int NT = 256>
 __device__ __forceinline__ void stage_union(const FoldArgs& g, int b, int slab, int chunk, int nk, int umk, typename Fl<BF>::T* vt,
                                             int tid) {
     typedef typename Fl<BF>::T T;
-    constexpr int VP = CW + Fl<BF>::PADE, PPR = 16 * H, NU = EU * PPR / 256;     // pieces per row, pieces per thread
+    constexpr int VP = CW + Fl<BF>::PADE, PPR = 16 * H, NU = EU * PPR / NT;      // pieces per row, pieces per thread
     const int* kp = g.p.keys + (long)slab * g.p.umax;
     int key[NU];
 #pragma unroll
-    for (int u = 0; u < NU; ++u) key[u] = kp[(tid + 256 * u) / PPR];
+    for (int u = 0; u < NU; ++u) key[u] = kp[(tid + NT * u) / PPR];
     const float* vb = g.vw + (long)b * g.vw_bstride + (long)chunk * CW * H;
     float4 v[NU];
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
-        const int e = tid + 256 * u, row = e / PPR, pq = e % PPR;
+        const int e = tid + NT * u, row = e / PPR, pq = e % PPR;
         v[u] = ldg4_if(vb, (long)key[u] * g.ld_vw + 4 * pq, row < nk);
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
-        const int e = tid + 256 * u, row = e / PPR, pq = e % PPR;
+        const int e = tid + NT * u, row = e / PPR, pq = e % PPR;
         if (row >= umk) continue;
         if (H == 1) {
             Fl<BF>::put4(vt + row * VP + 4 * pq, v[u]);
@@ -186,55 +192,59 @@ __device__ __forceinline__ void stage_union(const FoldArgs& g, int b, int slab, 
 }
 
 // A 32-row pass of a weight tensor: (H, 32, um) floats, each head's 32 x um block contiguous in memory, as 16-byte pieces
-template <int H> struct WReq { float4 v[H * SR * EU / 4 / 256]; };
-template <int H>
-__device__ __forceinline__ void wreq(const float* w, const FoldArgs& g, int slab, int sub, int tid, WReq<H>& r) {
+template <int H, int NT = 256> struct WReq { float4 v[H * SR * EU / 4 / NT]; };
+template <int H, int NT = 256>
+__device__ __forceinline__ void wreq(const float* w, const FoldArgs& g, int slab, int sub, int tid, WReq<H, NT>& r) {
     const int perh = SR * g.um / 4, npc = H * perh;
 #pragma unroll
-    for (int u = 0; u < H * SR * EU / 4 / 256; ++u) {
-        const int e = tid + 256 * u, h = e / perh, rem = e - h * perh;
+    for (int u = 0; u < H * SR * EU / 4 / NT; ++u) {
+        const int e = tid + NT * u, h = e / perh, rem = e - h * perh;
         r.v[u] = ldg4_if(w, ((long)(slab * H + h) * g.p.rows + sub * SR) * g.um + 4L * rem, e < npc);
     }
 }
-template <bool BF, int H>
-__device__ __forceinline__ void wpark(typename Fl<BF>::T* tile, int pitch, const FoldArgs& g, int tid, const WReq<H>& r) {
+template <bool BF, int H, int NT = 256>
+__device__ __forceinline__ void wpark(typename Fl<BF>::T* tile, int pitch, const FoldArgs& g, int tid, const WReq<H, NT>& r) {
     const int um4 = g.um / 4, perh = SR * um4, npc = H * perh;
 #pragma unroll
-    for (int u = 0; u < H * SR * EU / 4 / 256; ++u) {
-        const int e = tid + 256 * u, h = e / perh, rem = e - h * perh, row = rem / um4, c4 = rem - row * um4;
+    for (int u = 0; u < H * SR * EU / 4 / NT; ++u) {
+        const int e = tid + NT * u, h = e / perh, rem = e - h * perh, row = rem / um4, c4 = rem - row * um4;
         if (e < npc) Fl<BF>::put4(tile + (h * SR + row) * pitch + 4 * c4, r.v[u]);
     }
 }
 // zero the columns [um, umk) of a weight tile (bf16 flavour, um = 48: the k groups are 32 wide)
-template <bool BF, int H>
+template <bool BF, int H, int NT = 256>
 __device__ __forceinline__ void wpad(typename Fl<BF>::T* tile, int pitch, int um, int umk, int tid) {
     const int padc = umk - um;
-    for (int e = tid; e < H * SR * padc; e += 256) tile[(e / padc) * pitch + um + e % padc] = 0;
+    for (int e = tid; e < H * SR * padc; e += NT) tile[(e / padc) * pitch + um + e % padc] = 0;
 }
 
-// 32 rows x 64 columns of the activation gradient (fp32 or bf16 in memory): two 4-column pieces per thread
-struct DReq { float4 v[SR * CW / 4 / 256]; };
-__device__ __forceinline__ void dreq(const FoldArgs& g, int b, int slab, int chunk, int sub, int tid, DReq& r) {
+// 32 rows x 64 columns of the activation gradient (fp32 or bf16 in memory): 4-column pieces, two (one) per thread
+template <int NT = 256> struct DReq { float4 v[SR * CW / 4 / NT]; };
+template <int NT = 256>
+__device__ __forceinline__ void dreq(const FoldArgs& g, int b, int slab, int chunk, int sub, int tid, DReq<NT>& r) {
 #pragma unroll
-    for (int u = 0; u < SR * CW / 4 / 256; ++u) {
-        const int e = tid + 256 * u, row = e >> 4, q = e & 15;
+    for (int u = 0; u < SR * CW / 4 / NT; ++u) {
+        const int e = tid + NT * u, row = e >> 4, q = e & 15;
         const int n = slab * g.p.rows + sub * SR + row;
         const long o = (long)b * g.dz_bstride + (long)n * g.ld_dz + chunk * CW + 4 * q;
         r.v[u] = g.dz16 ? ldh4_if(g.dz, o, n < g.p.n_out) : ldg4_if(reinterpret_cast<const float*>(g.dz), o, n < g.p.n_out);
     }
 }
-template <bool BF>
-__device__ __forceinline__ void dpark(typename Fl<BF>::T* tile, int tid, const DReq& r) {
+template <bool BF, int NT = 256>
+__device__ __forceinline__ void dpark(typename Fl<BF>::T* tile, int tid, const DReq<NT>& r) {
     constexpr int VP = CW + Fl<BF>::PADE;
 #pragma unroll
-    for (int u = 0; u < SR * CW / 4 / 256; ++u) {
-        const int e = tid + 256 * u;
+    for (int u = 0; u < SR * CW / 4 / NT; ++u) {
+        const int e = tid + NT * u;
         Fl<BF>::put4(tile + (e >> 4) * VP + 4 * (e & 15), r.v[u]);
     }
 }
 
-template <int H, bool BF>
-__global__ __launch_bounds__(256) void fold_fwd_kernel(FoldArgs g) {
+constexpr int NTB = 512;     // threads of the fold kernels: eight wavefronts
+// wave = 4 gsel + w4 owns output columns [16 w4, 16 w4 + 16) of a pass, both heads; NT = 512: rows [16 gsel, 16 gsel + 16) (fp32 flavour:
+// Darcy b=256 134 -> 130 us, Vorticity 67.6 -> 63.0), NT = 256: all 32 rows (bf16 flavour: eight waves measured 35.3 us against 32.5)
+template <int H, bool BF, int NT>
+__global__ __launch_bounds__(NT, 4) void fold_fwd_kernel(FoldArgs g) {
     typedef Fl<BF> F;
     typedef typename F::T T;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -245,43 +255,45 @@ __global__ __launch_bounds__(256) void fold_fwd_kernel(FoldArgs g) {
     T* pt = vt + H * umk * VP;                          // [H][SR][PP]    this pass's weights
     float* zs = reinterpret_cast<float*>(pt + H * SR * PP);      // [SR][ZP]  the pass's output tile on its way to memory
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, kq = lane >> 4;
+    const int gsel = wave >> 2, w4 = wave & 3;
     int b, slab, chunk;
     if (!fold_ids((int)blockIdx.x, g, b, slab, chunk)) return;
     const pit_slab_plan& p = g.p;
     const int nsub = p.rows / SR;
     const int nk = min(p.nkeys[slab], EU);
-    WReq<H> wr;
-    wreq<H>(g.pw, g, slab, 0, tid, wr);
-    stage_union<BF, H>(g, b, slab, chunk, nk, umk, vt, tid);
-    if (BF && umk != um) wpad<BF, H>(pt, PP, um, umk, tid);
-    wpark<BF, H>(pt, PP, g, tid, wr);
+    WReq<H, NT> wr;
+    wreq<H, NT>(g.pw, g, slab, 0, tid, wr);
+    stage_union<BF, H, NT>(g, b, slab, chunk, nk, umk, vt, tid);
+    if (BF && umk != um) wpad<BF, H, NT>(pt, PP, um, umk, tid);
+    wpark<BF, H, NT>(pt, PP, g, tid, wr);
     __syncthreads();
     for (int sub = 0; sub < nsub; ++sub) {
         const int row0 = slab * p.rows + sub * SR;
         if (row0 >= p.n_out) break;                                  // (workgroup-uniform: the mesh ends inside this slab)
         const bool more = sub + 1 < nsub && row0 + SR < p.n_out;
-        if (more) wreq<H>(g.pw, g, slab, sub + 1, tid, wr);          // next pass's weights fly under this pass's contraction
-        f32x4_t acc[SR / 16];
+        if (more) wreq<H, NT>(g.pw, g, slab, sub + 1, tid, wr);     // next pass's weights fly under this pass's contraction
+        constexpr int NRT = SR / 16 / (NT / 256);
+        f32x4_t acc[NRT];
 #pragma unroll
-        for (int rt = 0; rt < SR / 16; ++rt) acc[rt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        for (int rt = 0; rt < NRT; ++rt) acc[rt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int h = 0; h < H; ++h) {
             for (int kg = 0; kg < umk / F::KG; ++kg) {
-                const typename F::Frag bf = F::kfrag(vt + h * umk * VP, VP, kg, 16 * wave, l15, kq);
+                const typename F::Frag bf = F::kfrag(vt + h * umk * VP, VP, kg, 16 * w4, l15, kq);
 #pragma unroll
-                for (int rt = 0; rt < SR / 16; ++rt)
-                    acc[rt] = F::mma(F::rowfrag(pt + h * SR * PP, PP, 16 * rt, kg, l15, kq), bf, acc[rt]);
+                for (int rt = 0; rt < NRT; ++rt)
+                    acc[rt] = F::mma(F::rowfrag(pt + h * SR * PP, PP, 16 * (NRT * gsel + rt), kg, l15, kq), bf, acc[rt]);
             }
         }
 #pragma unroll
-        for (int rt = 0; rt < SR / 16; ++rt)
+        for (int rt = 0; rt < NRT; ++rt)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) zs[(16 * rt + 4 * kq + i) * ZP + 16 * wave + l15] = acc[rt][i];
+            for (int i = 0; i < 4; ++i) zs[(16 * (NRT * gsel + rt) + 4 * kq + i) * ZP + 16 * w4 + l15] = acc[rt][i];
         __syncthreads();
         // the tile to memory as 4-column pieces (16 B of fp32, 8 B of bf16)
 #pragma unroll
-        for (int u = 0; u < SR * CW / 4 / 256; ++u) {
-            const int e = tid + 256 * u, row = e >> 4, q = e & 15, n = row0 + row;
+        for (int u = 0; u < SR * CW / 4 / NT; ++u) {
+            const int e = tid + NT * u, row = e >> 4, q = e & 15, n = row0 + row;
             if (n < p.n_out) {
                 const float4 v = *reinterpret_cast<const float4*>(zs + row * ZP + 4 * q);
                 const long o = (long)b * g.z_bstride + (long)n * g.ld_z + chunk * CW + 4 * q;
@@ -289,26 +301,36 @@ __global__ __launch_bounds__(256) void fold_fwd_kernel(FoldArgs g) {
                 else *reinterpret_cast<float4*>(reinterpret_cast<float*>(g.z) + o) = v;
             }
         }
-        if (more) wpark<BF, H>(pt, PP, g, tid, wr);
+        if (more) wpark<BF, H, NT>(pt, PP, g, tid, wr);
         __syncthreads();
     }
 }
 
+// Eight wavefronts: wave = 4 gsel + w4 owns output columns [16 w4, 16 w4 + 16) and, of the two contractions of a pass,
+//   two heads: head gsel of both (its own d(VW_h) accumulators, its own d(scale_h) sum),
+//   one head:  slots [32 gsel, 32 gsel + 32) of d(VW) and rows [16 gsel, 16 gsel + 16) of the d(scale) product.
+// (First version: four wavefronts, each with both heads - 156 registers, two workgroups = two wavefronts per SIMD, and each of a
+// pass's two dependency chains - operands through LDS into 128 MFMAs, and load -> barrier -> park -> barrier - took ~3.3 us where
+// the MFMAs are 1.9: 280 us at Darcy b=256, 176 of them with the contractions compiled out.  Twice the wavefronts per SIMD with
+// half the accumulators each; a thread requests half the bytes.)
 template <int H, bool BF>
-__global__ __launch_bounds__(256) void fold_bwd_kernel(FoldArgs g) {
+__global__ __launch_bounds__(NTB, 4) void fold_bwd_kernel(FoldArgs g) {
     typedef Fl<BF> F;
     typedef typename F::T T;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int um = g.um, umk = BF ? ((um + 31) & ~31) : um;
     const int PP = umk + F::PADE;
     constexpr int VP = CW + F::PADE;
+    constexpr int NMT = (H == 2) ? EU / 16 : EU / 32, NRT = (H == 2) ? SR / 16 : SR / 32;
     T* vt = reinterpret_cast<T*>(smem_raw);            // [H][umk][VP]   union value rows (for d(scale))
     T* pt = vt + H * umk * VP;                          // [H][SR][PP]    P of this pass, read as the [k = row][i = slot] image
     T* qt = pt + H * SR * PP;                           // [H][SR][PP]    Q = P (m - mbar)
     T* dt = qt + H * SR * PP;                           // [SR][VP]       this pass's rows of dZ
-    double* wred = reinterpret_cast<double*>(dt + SR * VP);      // [4][H]   (dt's end is 16-byte aligned: SR * VP * sizeof(T) is)
-    int* keys_s = reinterpret_cast<int*>(wred + 4 * H);          // [EU]
+    double* wred = reinterpret_cast<double*>(dt + SR * VP);      // [8]      (dt's end is 16-byte aligned: SR * VP * sizeof(T) is)
+    int* keys_s = reinterpret_cast<int*>(wred + 8);              // [EU]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, kq = lane >> 4;
+    const int gsel = wave >> 2, w4 = wave & 3;
+    const int hh = (H == 2) ? gsel : 0, mt0 = (H == 2) ? 0 : NMT * gsel, rt0 = (H == 2) ? 0 : NRT * gsel;
     int b, slab, chunk;
     if (!fold_ids((int)blockIdx.x, g, b, slab, chunk)) return;
     const pit_slab_plan& p = g.p;
@@ -316,130 +338,106 @@ __global__ __launch_bounds__(256) void fold_bwd_kernel(FoldArgs g) {
     const int nk = min(p.nkeys[slab], EU);
     const bool want_scale = g.dscale != nullptr;
     const int akey = p.keys[(long)slab * p.umax + (tid & (EU - 1))];
-    WReq<H> pr, qr;
-    DReq dr;
-    wreq<H>(g.pw, g, slab, 0, tid, pr);
-    wreq<H>(g.qw, g, slab, 0, tid, qr);
-    dreq(g, b, slab, chunk, 0, tid, dr);
-    stage_union<BF, H>(g, b, slab, chunk, nk, umk, vt, tid);
+    WReq<H, NTB> pr, qr;
+    DReq<NTB> dr;
+    wreq<H, NTB>(g.pw, g, slab, 0, tid, pr);
+    wreq<H, NTB>(g.qw, g, slab, 0, tid, qr);
+    dreq<NTB>(g, b, slab, chunk, 0, tid, dr);
+    if (!(PIT_FOLD_DBG & 16)) stage_union<BF, H, NTB>(g, b, slab, chunk, nk, umk, vt, tid);
     if (tid < EU) keys_s[tid] = akey;
-    if (BF && umk != um) { wpad<BF, H>(pt, PP, um, umk, tid); wpad<BF, H>(qt, PP, um, umk, tid); }
-    wpark<BF, H>(pt, PP, g, tid, pr);
-    wpark<BF, H>(qt, PP, g, tid, qr);
-    dpark<BF>(dt, tid, dr);
+    if (BF && umk != um) { wpad<BF, H, NTB>(pt, PP, um, umk, tid); wpad<BF, H, NTB>(qt, PP, um, umk, tid); }
+    wpark<BF, H, NTB>(pt, PP, g, tid, pr);
+    wpark<BF, H, NTB>(qt, PP, g, tid, qr);
+    dpark<BF, NTB>(dt, tid, dr);
     __syncthreads();
-    f32x4_t accT[H][EU / 16];
+    f32x4_t accT[NMT];
 #pragma unroll
-    for (int h = 0; h < H; ++h)
-#pragma unroll
-        for (int mt = 0; mt < EU / 16; ++mt) accT[h][mt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    double part[H];
-#pragma unroll
-    for (int h = 0; h < H; ++h) part[h] = 0.0;
+    for (int mt = 0; mt < NMT; ++mt) accT[mt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    double part = 0.0;
+    const T* pth = pt + hh * SR * PP;
+    const T* qth = qt + hh * SR * PP;
+    const T* vth = vt + hh * umk * VP;
     for (int sub = 0; sub < nsub; ++sub) {
         const int row0 = slab * p.rows + sub * SR;
         if (row0 >= p.n_out) break;
         const bool more = sub + 1 < nsub && row0 + SR < p.n_out;
-        if (more) {
-            wreq<H>(g.pw, g, slab, sub + 1, tid, pr);
-            wreq<H>(g.qw, g, slab, sub + 1, tid, qr);
-            dreq(g, b, slab, chunk, sub + 1, tid, dr);
+        if (more && !(PIT_FOLD_DBG & 8)) {
+            wreq<H, NTB>(g.pw, g, slab, sub + 1, tid, pr);
+            wreq<H, NTB>(g.qw, g, slab, sub + 1, tid, qr);
+            dreq<NTB>(g, b, slab, chunk, sub + 1, tid, dr);
         }
         // d(VW_h)[slot][col] += sum_rows P_h[row][slot] dZ[row][col]
+        if (!(PIT_FOLD_DBG & 2))
 #pragma unroll
         for (int kg = 0; kg < SR / F::KG; ++kg) {
-            const typename F::Frag bf = F::kfrag(dt, VP, kg, 16 * wave, l15, kq);
+            const typename F::Frag bf = F::kfrag(dt, VP, kg, 16 * w4, l15, kq);
 #pragma unroll
-            for (int h = 0; h < H; ++h)
-#pragma unroll
-                for (int mt = 0; mt < EU / 16; ++mt)
-                    if (16 * mt < umk) accT[h][mt] = F::mma(F::kfrag(pt + h * SR * PP, PP, kg, 16 * mt, l15, kq), bf, accT[h][mt]);
+            for (int mt = 0; mt < NMT; ++mt)
+                if (16 * (mt0 + mt) < umk) accT[mt] = F::mma(F::kfrag(pth, PP, kg, 16 * (mt0 + mt), l15, kq), bf, accT[mt]);
         }
         // d(scale_h) -= sum (Q_h VW_h) . dZ
-        if (want_scale) {
+        if (want_scale && !(PIT_FOLD_DBG & 1)) {
+            f32x4_t acc[NRT];
 #pragma unroll
-            for (int h = 0; h < H; ++h) {
-                f32x4_t acc[SR / 16];
+            for (int rt = 0; rt < NRT; ++rt) acc[rt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            for (int kg = 0; kg < umk / F::KG; ++kg) {
+                const typename F::Frag bf = F::kfrag(vth, VP, kg, 16 * w4, l15, kq);
 #pragma unroll
-                for (int rt = 0; rt < SR / 16; ++rt) acc[rt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-                for (int kg = 0; kg < umk / F::KG; ++kg) {
-                    const typename F::Frag bf = F::kfrag(vt + h * umk * VP, VP, kg, 16 * wave, l15, kq);
-#pragma unroll
-                    for (int rt = 0; rt < SR / 16; ++rt)
-                        acc[rt] = F::mma(F::rowfrag(qt + h * SR * PP, PP, 16 * rt, kg, l15, kq), bf, acc[rt]);
-                }
-#pragma unroll
-                for (int rt = 0; rt < SR / 16; ++rt)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        part[h] += (double)acc[rt][i] * (double)F::get(dt + (16 * rt + 4 * kq + i) * VP + 16 * wave + l15);
+                for (int rt = 0; rt < NRT; ++rt)
+                    acc[rt] = F::mma(F::rowfrag(qth, PP, 16 * (rt0 + rt), kg, l15, kq), bf, acc[rt]);
             }
+#pragma unroll
+            for (int rt = 0; rt < NRT; ++rt)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    part += (double)acc[rt][i] * (double)F::get(dt + (16 * (rt0 + rt) + 4 * kq + i) * VP + 16 * w4 + l15);
         }
         __syncthreads();
-        if (more) {
-            wpark<BF, H>(pt, PP, g, tid, pr);
-            wpark<BF, H>(qt, PP, g, tid, qr);
-            dpark<BF>(dt, tid, dr);
+        if (more && !(PIT_FOLD_DBG & 8)) {
+            wpark<BF, H, NTB>(pt, PP, g, tid, pr);
+            wpark<BF, H, NTB>(qt, PP, g, tid, qr);
+            dpark<BF, NTB>(dt, tid, dr);
         }
         __syncthreads();
     }
-    // the slab's sums leave once: d_vw[b][key(slot)][(chunk 64 + 16 wave + c) H + h].  Two heads: the wave's 16 columns are a run
-    // of 32 floats per key row; lane c holds (c, 0) and (c, 1) - position p = 16 half + c of the run is column p >> 1, head p & 1,
-    // fetched from lane p >> 1 of the same lane quarter, so that each atomic instruction adds to 64 contiguous bytes per row
-    if (g.tiles) {
-        // plain stores of the slab's sums into its own tile (no atomics: fold_reduce_kernel adds the few tiles that hold a key, in a
-        // fixed order - the same bits on every run); slots beyond the union are written too and never read
-        float* dst = g.tiles + ((long)(b * g.p.n_slabs + slab) * EU) * ((long)g.dim * H) + (long)(chunk * CW + 16 * wave) * H;
-        const long ldt = (long)g.dim * H;
+    // the slab's sums leave once, through LDS (the tiles are free now): ex[slot][col * H + h] is the head-interleaved row of d_vw, and
+    // the workgroup then moves whole rows - plain 16-byte stores into the slab's own tile (fold_reduce_kernel adds the few tiles that
+    // hold a key, in a fixed order: the same bits on every run; slots beyond the union are written too and never read), or fp32
+    // atomic adds into d_vw[b][key(slot)]
+    if ((PIT_FOLD_DBG & 4) && accT[0][0] != 123.456f) return;
+    constexpr int EW = CW * H, EP = EW + 4;
+    float* ex = reinterpret_cast<float*>(smem_raw);     // [EU][EP]
 #pragma unroll
-        for (int mt = 0; mt < EU / 16; ++mt)
+    for (int mt = 0; mt < NMT; ++mt)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int sl = 16 * mt + 4 * kq + i;
-                if (H == 1) {
-                    dst[sl * ldt + l15] = accT[0][mt][i];
-                } else {
-#pragma unroll
-                    for (int half = 0; half < 2; ++half) {
-                        const int pp = 16 * half + l15, src = (lane & 48) | (pp >> 1);
-                        const float t0 = __shfl(accT[0][mt][i], src, 64), t1 = __shfl(accT[H - 1][mt][i], src, 64);
-                        dst[sl * ldt + pp] = (pp & 1) ? t1 : t0;
-                    }
-                }
-            }
-    } else if (g.d_vw) {
-        float* dst = g.d_vw + (long)b * g.dvw_bstride + (long)(chunk * CW + 16 * wave) * H;
-#pragma unroll
-        for (int mt = 0; mt < EU / 16; ++mt)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int sl = 16 * mt + 4 * kq + i;
-                const bool ok = sl < nk;
-                float* row = dst + (long)keys_s[ok ? sl : 0] * g.ld_dvw;
-                if (H == 1) {
-                    if (ok) atomicAdd(row + l15, accT[0][mt][i]);
-                } else {
-#pragma unroll
-                    for (int half = 0; half < 2; ++half) {
-                        const int pp = 16 * half + l15, src = (lane & 48) | (pp >> 1);
-                        const float t0 = __shfl(accT[0][mt][i], src, 64), t1 = __shfl(accT[H - 1][mt][i], src, 64);
-                        if (ok) atomicAdd(row + pp, (pp & 1) ? t1 : t0);
-                    }
-                }
-            }
-    }
+        for (int i = 0; i < 4; ++i) ex[(16 * (mt0 + mt) + 4 * kq + i) * EP + (16 * w4 + l15) * H + hh] = accT[mt][i];
     if (want_scale) {
+        const double sum = wave_sum_d(part);
+        if (lane == 0) wred[wave] = sum;
+    }
+    __syncthreads();
+    if (g.tiles) {
 #pragma unroll
-        for (int h = 0; h < H; ++h) {
-            const double sum = wave_sum_d(part[h]);
-            if (lane == 0) wred[wave * H + h] = sum;
+        for (int u = 0; u < EU * EW / 4 / NTB; ++u) {
+            const int e = tid + NTB * u, sl = e / (EW / 4), q = e % (EW / 4);
+            *reinterpret_cast<float4*>(g.tiles + ((long)(b * g.p.n_slabs + slab) * EU + sl) * ((long)g.dim * H) + (long)chunk * EW + 4 * q) =
+                *reinterpret_cast<const float4*>(ex + sl * EP + 4 * q);
         }
-        __syncthreads();
-        if (tid < H) {
-            double tot = 0.0;
-            for (int w = 0; w < 4; ++w) tot += wred[w * H + tid];
-            atomicAdd(g.dscale + (long)tid * PIT_DSCALE_SLOTS + ((int)blockIdx.x & (PIT_DSCALE_SLOTS - 1)), -tot);
+    } else if (g.d_vw) {
+        // (one float per lane: a wavefront's atomic instruction adds to 256 contiguous bytes of one key row - as 16-byte pieces per
+        // thread each instruction touched every fourth word of 1 KB: 639 us at Darcy b=256 against 280)
+        float* dst = g.d_vw + (long)b * g.dvw_bstride + (long)chunk * EW;
+#pragma unroll
+        for (int u = 0; u < EU * EW / NTB; ++u) {
+            const int e = tid + NTB * u, sl = e / EW, c = e % EW;
+            if (sl < nk) atomicAdd(dst + (long)keys_s[sl] * g.ld_dvw + c, ex[sl * EP + c]);
         }
+    }
+    if (want_scale && tid < H) {
+        double tot = 0.0;
+        if (H == 2) { for (int w = 0; w < 4; ++w) tot += wred[4 * tid + w]; }
+        else { for (int w = 0; w < 8; ++w) tot += wred[w]; }
+        atomicAdd(g.dscale + (long)tid * PIT_DSCALE_SLOTS + ((int)blockIdx.x & (PIT_DSCALE_SLOTS - 1)), -tot);
     }
 }
 
@@ -469,7 +467,7 @@ size_t fold_smem(int H, bool bf, int um, bool bwd) {
     const int es = bf ? 2 : 4, pade = bf ? 8 : 4, umk = bf ? ((um + 31) & ~31) : um;
     const size_t vt = (size_t)H * umk * (CW + pade) * es, wt = (size_t)H * SR * (umk + pade) * es;
     if (!bwd) return vt + wt + (size_t)SR * (CW + 4) * 4;
-    return vt + 2 * wt + (size_t)SR * (CW + pade) * es + 4 * H * 8 + EU * 4;
+    return std::max(vt + 2 * wt + (size_t)SR * (CW + pade) * es + 8 * 8 + EU * 4, (size_t)EU * (CW * H + 4) * 4);   // (the epilogue's exchange tile)
 }
 
 bool fold_plan_ok(const pit_slab_plan* p) {
@@ -710,8 +708,8 @@ extern "C" int pit_fold_att_fwd(const pit_slab_plan* plan, const float* vw, long
     const size_t sm = fold_smem(n_head, bf, g.um, false);
     const dim3 grid(fold_grid(g));
     hipStream_t s = (hipStream_t)stream;
-    if (n_head == 1) { if (bf) hipLaunchKernelGGL((fold_fwd_kernel<1, true>), grid, dim3(256), sm, s, g); else hipLaunchKernelGGL((fold_fwd_kernel<1, false>), grid, dim3(256), sm, s, g); }
-    else { if (bf) hipLaunchKernelGGL((fold_fwd_kernel<2, true>), grid, dim3(256), sm, s, g); else hipLaunchKernelGGL((fold_fwd_kernel<2, false>), grid, dim3(256), sm, s, g); }
+    if (n_head == 1) { if (bf) hipLaunchKernelGGL((fold_fwd_kernel<1, true, 256>), grid, dim3(256), sm, s, g); else hipLaunchKernelGGL((fold_fwd_kernel<1, false, NTB>), grid, dim3(NTB), sm, s, g); }
+    else { if (bf) hipLaunchKernelGGL((fold_fwd_kernel<2, true, 256>), grid, dim3(256), sm, s, g); else hipLaunchKernelGGL((fold_fwd_kernel<2, false, NTB>), grid, dim3(NTB), sm, s, g); }
     PIT_CHECK_LAUNCH();
     return 0;
 }
@@ -739,8 +737,8 @@ extern "C" int pit_fold_att_bwd(const pit_slab_plan* plan, const float* vw, long
     const size_t sm = fold_smem(n_head, bf, g.um, true);
     const dim3 grid(fold_grid(g));
     hipStream_t s = (hipStream_t)stream;
-    if (n_head == 1) { if (bf) hipLaunchKernelGGL((fold_bwd_kernel<1, true>), grid, dim3(256), sm, s, g); else hipLaunchKernelGGL((fold_bwd_kernel<1, false>), grid, dim3(256), sm, s, g); }
-    else { if (bf) hipLaunchKernelGGL((fold_bwd_kernel<2, true>), grid, dim3(256), sm, s, g); else hipLaunchKernelGGL((fold_bwd_kernel<2, false>), grid, dim3(256), sm, s, g); }
+    if (n_head == 1) { if (bf) hipLaunchKernelGGL((fold_bwd_kernel<1, true>), grid, dim3(NTB), sm, s, g); else hipLaunchKernelGGL((fold_bwd_kernel<1, false>), grid, dim3(NTB), sm, s, g); }
+    else { if (bf) hipLaunchKernelGGL((fold_bwd_kernel<2, true>), grid, dim3(NTB), sm, s, g); else hipLaunchKernelGGL((fold_bwd_kernel<2, false>), grid, dim3(NTB), sm, s, g); }
     PIT_CHECK_LAUNCH();
     if (g.tiles) {
         const long width = (long)dim * n_head;
