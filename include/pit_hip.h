@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PIT_ABI_VERSION 19
+#define PIT_ABI_VERSION 20
 #define PIT_DSCALE_SLOTS 1024 /* fp64 accumulators per head in pit_posatt_bwd's workspace */
 
 /* distance metric (dist2att variants) */
@@ -473,18 +473,23 @@ int pit_posatt_pre_bwd(const float* e, const float* q, const float* rowstat, int
  *   pit_satt_bwd  d_values[b, j, :] = (add_residual ? d_out[b, j, 0:dim] : 0) + sum_h sum_n P_h[n, j] d_out[b, n, out_col0 + h*dim + :] (NULL: not
  *                 needed); the layer's d(scale) accumulators (PIT_HEAD_DEFER convention; NULL: not needed).  scale = the forward's c;
  *                 g16: scratch of batch*n_head*n_pts*dim bf16.
+ *   e_tiles (optional, NULL: none): (mesh_batch, n_head, pit_satt_tiles_elems(n_pts)) bf16 - the forward leaves its rounded weights there
+ *                 in MFMA A-fragment order and pit_satt_bwd's d(values) (the same, symmetric, matrix) reads them instead of forming
+ *                 every weight again.
  * Weights, row sums and the d(scale) reduction are fp32 / fp64; the MFMA operands are bf16 (v_mfma_f32_16x16x32_bf16). */
 int pit_satt_supported(int n_pts, int n_head, int dim, int batch, int mesh_batch);
 int pit_satt_fwd(const float* mesh, int mesh_batch, int n_pts, int space_dim, int metric, float period,
                  const float* values, long ld_values, long values_bstride, int batch, int dim,
                  const float* head, int n_head, int head_is_scale, unsigned short* x16,
                  float* out, long ld_out, long out_bstride, int out_col0, int copy_inputs,
-                 float* rowstat, float* scale_out, void* stream);
+                 float* rowstat, float* scale_out, unsigned short* e_tiles, void* stream);
 int pit_satt_bwd(const float* mesh, int mesh_batch, int n_pts, int space_dim, int metric, float period,
                  int batch, int dim, const float* scale, int n_head, const float* rowstat,
                  const unsigned short* x16, unsigned short* g16,
                  const float* d_out, long ld_dout, long dout_bstride, int out_col0,
-                 float* d_values, long ld_dvalues, long dvalues_bstride, int add_residual, double* dscale, void* stream);
+                 float* d_values, long ld_dvalues, long dvalues_bstride, int add_residual, double* dscale,
+                 const unsigned short* e_tiles, void* stream);
+long pit_satt_tiles_elems(int n_pts);
 
 /* kaiming_mlp.forward (pit.py:21-26): y = W2 * gelu_erf(W1 x + b1) + b2, optionally
  * followed by the trailing gelu of pit.py:111,121 (out_gelu=1).

@@ -85,8 +85,9 @@ SIGNATURES = {
     "pit_thin_tail_fwd": [_P, _L, _I, _I, _I, _P, _P, _P, _P, _L, _I, _P],
     "pit_thin_tail_bwd": [_P, _L, _I, _I, _I, _P, _P, _P, _L, _P, _L, _P, _P, _P, _P, _I, _P],
     "pit_satt_supported": [_I, _I, _I, _I, _I],
-    "pit_satt_fwd": [_P, _I, _I, _I, _I, _F, _P, _L, _L, _I, _I, _P, _I, _I, _P, _P, _L, _L, _I, _I, _P, _P, _P],
-    "pit_satt_bwd": [_P, _I, _I, _I, _I, _F, _I, _I, _P, _I, _P, _P, _P, _P, _L, _L, _I, _P, _L, _L, _I, _P, _P],
+    "pit_satt_fwd": [_P, _I, _I, _I, _I, _F, _P, _L, _L, _I, _I, _P, _I, _I, _P, _P, _L, _L, _I, _I, _P, _P, _P, _P],
+    "pit_satt_bwd": [_P, _I, _I, _I, _I, _F, _I, _I, _P, _I, _P, _P, _P, _P, _L, _L, _I, _P, _L, _L, _I, _P, _P, _P],
+    "pit_satt_tiles_elems": [_I],
     "pit_mlp_chain_supported": [_I, _I, _I, _I],
     "pit_mlp_chain_fwd": [_P, _L, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P],
     "pit_mlp_chain_bwd": [_I, _I, _I, _P, _P, _P, _P, _P, _L, _P, _L, _P, _P],
@@ -126,7 +127,8 @@ SIGNATURES = {
     "pit_debug_mfma_tile": [_P, _P, _P, _P],
 }
 
-ABI_VERSION = 19       # PIT_ABI_VERSION of include/pit_hip.h this binding was written against
+LONG_RETURN = {"pit_satt_tiles_elems"}
+ABI_VERSION = 20       # PIT_ABI_VERSION of include/pit_hip.h this binding was written against
 
 _lib = None
 
@@ -142,7 +144,7 @@ def lib() -> ctypes.CDLL:
         for name, argtypes in SIGNATURES.items():
             fn = getattr(handle, name)       # AttributeError if the ABI lost a symbol
             fn.argtypes = argtypes
-            fn.restype = ctypes.c_char_p if name == "pit_error_string" else _I
+            fn.restype = ctypes.c_char_p if name == "pit_error_string" else (_L if name in LONG_RETURN else _I)
         got = handle.pit_version()           # the default library and a PIT_LIB_PATH override alike
         if got != ABI_VERSION:
             raise RuntimeError(f"{LIB_PATH} implements PIT_ABI_VERSION {got}, this package binds version {ABI_VERSION}: "

@@ -43,6 +43,8 @@ struct SattArgs {
     const float* d_out; long ld_dout, dout_bstride;
     float* d_values; long ld_dv, dv_bstride; int add_residual;
     double* dscale;
+    unsigned short* e_out;                     // MODE 0, optional: the rounded weights as A-fragment tiles (satt_tiles_elems)
+    const unsigned short* e_in;                // MODE 1, PRE: those tiles
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t wide_rsrc(const void* p) { return make_rsrc(p, 0x7ffffff0u); }
@@ -66,23 +68,23 @@ __device__ __forceinline__ f32x4_t mma(v8s_t a, v8s_t b, f32x4_t c) {
 }
 
 // 32 keys x W columns (from column col0 on) of a bf16 row-major tensor of DIM columns (rows beyond `nrows` load zeros):
-// W * 32 / 8 / 256 16-byte pieces per thread
-template <int W> struct Tile { u32x4_t v[W * KC / 8 / 256]; };
-template <int W, int DIM>
-__device__ __forceinline__ void tile_load(const unsigned short* src, long nrows, int k0, int tid, Tile<W>& t) {
+// W * 32 / 8 / NT 16-byte pieces per thread
+template <int W, int NT = 256> struct Tile { u32x4_t v[W * KC / 8 / NT]; };
+template <int W, int DIM, int NT = 256>
+__device__ __forceinline__ void tile_load(const unsigned short* src, long nrows, int k0, int tid, Tile<W, NT>& t) {
     const __amdgpu_buffer_rsrc_t r = wide_rsrc(src);
 #pragma unroll
-    for (int u = 0; u < W * KC / 8 / 256; ++u) {
-        const int e = tid + 256 * u, k = e / (W / 8), c = e % (W / 8);
+    for (int u = 0; u < W * KC / 8 / NT; ++u) {
+        const int e = tid + NT * u, k = e / (W / 8), c = e % (W / 8);
         const i32x4 q = __builtin_amdgcn_raw_buffer_load_b128(r, (int)((k0 + k) < nrows ? (unsigned)((((long)(k0 + k)) * DIM + 8 * c) * 2) : OOB), 0, 0);
         t.v[u] = u32x4_t{(unsigned)q.x, (unsigned)q.y, (unsigned)q.z, (unsigned)q.w};
     }
 }
-template <int W>
-__device__ __forceinline__ void tile_park(unsigned short* dst, int tid, const Tile<W>& t) {
+template <int W, int NT = 256>
+__device__ __forceinline__ void tile_park(unsigned short* dst, int tid, const Tile<W, NT>& t) {
 #pragma unroll
-    for (int u = 0; u < W * KC / 8 / 256; ++u) {
-        const int e = tid + 256 * u, k = e / (W / 8), c = e % (W / 8);               // 8 columns 8 c .. of key k
+    for (int u = 0; u < W * KC / 8 / NT; ++u) {
+        const int e = tid + NT * u, k = e / (W / 8), c = e % (W / 8);                // 8 columns 8 c .. of key k
         *reinterpret_cast<u32x4_t*>(dst + ((c >> 1) * CGS + k) * 16 + 8 * (c & 1)) = t.v[u];
     }
 }
@@ -93,8 +95,13 @@ __device__ __forceinline__ void tile_park(unsigned short* dst, int tid, const Ti
 // row tiles, 160 of 256 CUs; the halves re-form the weights (vector ALU that the idle CUs had to spare).
 constexpr int satt_width(int H, int DIM, int MODE) { return (MODE == 1 && H == 2) ? DIM / 2 : DIM; }
 
-template <int H, int DIM, int MODE, bool PERIODIC>
-__global__ __launch_bounds__(256, 2) void satt_kernel(SattArgs g) {
+// RT: 64-row tiles per workgroup (NT = 256 RT threads).  Two for the PRE d(values) of two heads x hid 256: with the weights read instead
+// of formed, what is left of a step is the B-tile stream - 24 KB per workgroup and step from L2, and the CUs that held two 64-row
+// workgroups pulled 53 GB/s, a CU's practical L2 rate: 0.9 us per step.  128 rows per workgroup = half the workgroups = half the bytes.
+template <int H, int DIM, int MODE, bool PERIODIC, bool PRE = false, int RT = 1>
+__global__ __launch_bounds__(256 * RT, 2) void satt_kernel(SattArgs g) {
+    static_assert(!PRE || MODE == 1, "only d(values) reads the forward's weight tiles");
+    constexpr int NT = 256 * RT;
     constexpr int W = satt_width(H, DIM, MODE), NCS = DIM / W, NCT = W / 16, TSZ = CGS * W, HW = (MODE == 1) ? H : 1, NB = (MODE == 1) ? H : 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float4* keys = reinterpret_cast<float4*>(smem_raw);                        // [Lp] key coordinates (zero-padded to 3)
@@ -107,20 +114,22 @@ __global__ __launch_bounds__(256, 2) void satt_kernel(SattArgs g) {
     // (consecutive ids - dealt to the XCDs in turn - walk the tiles of a sample: with a sample pinned to one XCD, ten samples put two
     // on XCDs 0 and 1 and one workgroup per CU made that a second round)
     const int cs = (MODE == 1) ? (int)blockIdx.x % NCS : 0;                    // this workgroup's column half (MODE 1, two heads)
-    if (!slab_of_linear((MODE == 1) ? (int)blockIdx.x / NCS : (int)blockIdx.x / H, g.batch, g.tiles, b, t)) return;
+    if (!slab_of_linear((MODE == 1) ? (int)blockIdx.x / NCS : (int)blockIdx.x / H, g.batch, (g.tiles + RT - 1) / RT, b, t)) return;
     const int mb = g.mesh_batch == 1 ? 0 : b;
-    const int row = t * 64 + wave * 16 + l15;                                  // the A-fragment row of this lane
+    const int row = t * 64 * RT + wave * 16 + l15;                             // the A-fragment row of this lane
     const int rowc = row < g.L ? row : g.L - 1;
     const float* mesh = g.mesh + (long)mb * g.L * g.sdim;
     const unsigned short* bsrc[NB];
 #pragma unroll
     for (int q = 0; q < NB; ++q) bsrc[q] = g.b16 + ((long)b * NB + q) * g.L * DIM + cs * W;
-    Tile<W> reg[2][NB];
+    constexpr int NR = PRE ? 4 : 2;            // register sets of B tiles in flight: a PRE step is ~0.3 us, two steps of lead are less than an L2 round trip
+    Tile<W, NT> reg[NR][NB];
 #pragma unroll
-    for (int s = 0; s < 2; ++s)
+    for (int s = 0; s < NR; ++s)
 #pragma unroll
-        for (int q = 0; q < NB; ++q) tile_load<W, DIM>(bsrc[q], g.L, KC * s, tid, reg[s][q]);
-    for (int j = tid; j < Lp + KC; j += 256) {
+        for (int q = 0; q < NB; ++q) tile_load<W, DIM, NT>(bsrc[q], g.L, KC * s, tid, reg[s][q]);
+    if (!PRE)
+    for (int j = tid; j < Lp + KC; j += NT) {
         float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
         if (j < g.L) {
             p.x = mesh[(long)j * g.sdim];
@@ -129,8 +138,8 @@ __global__ __launch_bounds__(256, 2) void satt_kernel(SattArgs g) {
         }
         keys[j] = p;
     }
-    const float rx = mesh[(long)rowc * g.sdim], ry = g.used > 1 ? mesh[(long)rowc * g.sdim + 1] : 0.0f,
-                rz = g.used > 2 ? mesh[(long)rowc * g.sdim + 2] : 0.0f;
+    const float rx = PRE ? 0.0f : mesh[(long)rowc * g.sdim], ry = (!PRE && g.used > 1) ? mesh[(long)rowc * g.sdim + 1] : 0.0f,
+                rz = (!PRE && g.used > 2) ? mesh[(long)rowc * g.sdim + 2] : 0.0f;
     float c[HW], c2[HW], mbar[HW];                                             // c2 = -c log2(e): exp(-c m) = exp2(c2 m), one multiply less per weight
 #pragma unroll
     for (int h = 0; h < HW; ++h) {
@@ -140,9 +149,9 @@ __global__ __launch_bounds__(256, 2) void satt_kernel(SattArgs g) {
         mbar[h] = (MODE == 2) ? g.rowstat_r[(((long)mb * H + hh) * g.L + rowc) * 4 + 3] : 0.0f;
     }
 #pragma unroll
-    for (int q = 0; q < NB; ++q) tile_park<W>(tb + q * TSZ, tid, reg[0][q]);
+    for (int q = 0; q < NB; ++q) tile_park<W, NT>(tb + q * TSZ, tid, reg[0][q]);
 #pragma unroll
-    for (int q = 0; q < NB; ++q) tile_load<W, DIM>(bsrc[q], g.L, 2 * KC, tid, reg[0][q]);
+    for (int q = 0; q < NB; ++q) tile_load<W, DIM, NT>(bsrc[q], g.L, NR * KC, tid, reg[0][q]);
     f32x4_t acc[NCT];
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct) acc[ct] = f32x4_t{0.f, 0.f, 0.f, 0.f};
@@ -167,12 +176,26 @@ __global__ __launch_bounds__(256, 2) void satt_kernel(SattArgs g) {
         }                                                                                                             \
     } while (0)
     const int nsteps = (PIT_SATT_DBG & 32) ? 2 : Lp / KC;
+    // MODE 0 leaves its rounded weights behind as A-fragment tiles [mesh sample][head][16-row tile][step][lane][8] (1 KB per wavefront
+    // and step, contiguous): d(values) contracts the same (symmetric) matrix and reads them instead of forming every weight again
+    // (twice, with its column halves).  Unconditional buffer stores: a NULL e_out is a resource of size 0 (every store dropped),
+    // the step beyond the last and the repeated samples of a batch-free mesh go to an out-of-range offset.
+    const long tile_base = (((long)(mb * H + hsel) * (g.tiles * 4) + t * 4 * RT + wave) * nsteps) * 64 + lane;     // in 16-byte units
+    const __amdgpu_buffer_rsrc_t re = make_rsrc(g.e_out, (MODE == 0 && g.e_out) ? 0x7ffffff0u : 0u);
+    const bool e_mine = g.mesh_batch > 1 || b == 0;
+#define PIT_SATT_ESTORE(s_, frag_)                                                                                    \
+    do { if (MODE == 0) {                                                                                             \
+        const u32x4_t w_ = __builtin_bit_cast(u32x4_t, frag_);                                                       \
+        __builtin_amdgcn_raw_buffer_store_b128(i32x4{(int)w_.x, (int)w_.y, (int)w_.z, (int)w_.w}, re,               \
+                                               (int)((e_mine && (s_) < nsteps) ? (unsigned)((tile_base + (long)(s_) * 64) * 16) : OOB), 0, 0); \
+    } } while (0)
     v8s_t af[2][HW];
-    {
+    if constexpr (!PRE) {
         float4 kp0[8];
         __syncthreads();                                                      // (the key coordinates are in LDS)
         PIT_SATT_KEYS(0, kp0);
         PIT_SATT_WEIGHTS(0, kp0, af[0]);
+        PIT_SATT_ESTORE(0, af[0][0]);
     }
     // step s contracts keys [32 s, 32 s + 32): its B tile(s) sit in buffer s & 1; register set (s + 1) & 1 holds tile s + 1 (parked
     // now, into the buffer step s - 1 just left) and is re-loaded with tile s + 3.  LDS reads are ISSUED FIRST - the next step's key
@@ -187,15 +210,15 @@ __global__ __launch_bounds__(256, 2) void satt_kernel(SattArgs g) {
     do {                                                                                                              \
         if (!(PIT_SATT_DBG & 8)) __syncthreads();                                                                     \
         if (!(PIT_SATT_DBG & 1)) {                                                                                    \
-        _Pragma("unroll") for (int q = 0; q < NB; ++q) tile_park<W>(tb + ((((s_) + 1) & 1) * NB + q) * TSZ, tid, reg[((j_) + 1) & 1][q]); \
-        _Pragma("unroll") for (int q = 0; q < NB; ++q) tile_load<W, DIM>(bsrc[q], g.L, KC * ((s_) + 3), tid, reg[((j_) + 1) & 1][q]); \
+        _Pragma("unroll") for (int q = 0; q < NB; ++q) tile_park<W, NT>(tb + ((((s_) + 1) & 1) * NB + q) * TSZ, tid, reg[((j_) + 1) & 1][q]); \
+        _Pragma("unroll") for (int q = 0; q < NB; ++q) tile_load<W, DIM, NT>(bsrc[q], g.L, KC * ((s_) + 3), tid, reg[((j_) + 1) & 1][q]); \
         }                                                                                                             \
         const unsigned short* tile_ = tb + (((s_) & 1) * NB) * TSZ;                                                   \
         float4 kp_[8];                                                                                                \
         v8s_t f0_[GS][HW], f1_[GS][HW];                                                                               \
         if (!(PIT_SATT_DBG & 2)) { PIT_SATT_KEYS((s_) + 1, kp_); }                                                    \
         if (!(PIT_SATT_DBG & 4)) { PIT_SATT_FRAGS(tile_, 0, f0_); }                                                   \
-        if (!(PIT_SATT_DBG & 2)) { PIT_SATT_WEIGHTS((s_) + 1, kp_, af[((j_) + 1) & 1]); }                             \
+        if (!(PIT_SATT_DBG & 2)) { PIT_SATT_WEIGHTS((s_) + 1, kp_, af[((j_) + 1) & 1]); PIT_SATT_ESTORE((s_) + 1, af[((j_) + 1) & 1][0]); } \
         else { _Pragma("unroll") for (int h = 0; h < HW; ++h) af[((j_) + 1) & 1][h] = af[(j_) & 1][h]; }              \
         if (!(PIT_SATT_DBG & 4))                                                                                      \
         _Pragma("unroll") for (int gi = 0; gi < NG; gi += 2) {                                                        \
@@ -209,10 +232,57 @@ __global__ __launch_bounds__(256, 2) void satt_kernel(SattArgs g) {
             }                                                                                                         \
         }                                                                                                             \
     } while (0)
-    for (int sb = 0; sb < nsteps; sb += 2) {
-        PIT_SATT_STEP(sb, 0);
-        PIT_SATT_STEP(sb + 1, 1);
+    // PRE (d(values) on the forward's tiles): the A fragment of a step is ONE 16-byte load per lane and head, requested three steps
+    // ahead into a ring of four register sets; no key coordinates, no vector ALU but the address
+#define PIT_SATT_STEP_PRE(s_, j_)                                                                                      \
+    do {                                                                                                              \
+        __syncthreads();                                                                                              \
+        _Pragma("unroll") for (int q = 0; q < NB; ++q) tile_park<W, NT>(tb + ((((s_) + 1) & 1) * NB + q) * TSZ, tid, reg[((j_) + 1) & 3][q]); \
+        _Pragma("unroll") for (int q = 0; q < NB; ++q) tile_load<W, DIM, NT>(bsrc[q], g.L, KC * ((s_) + 5), tid, reg[((j_) + 1) & 3][q]); \
+        _Pragma("unroll") for (int h = 0; h < HW; ++h) ar[((j_) + 3) & 3][h] = ap[h][(long)min((s_) + 3, nsteps - 1) * 64]; \
+        const unsigned short* tile_ = tb + (((s_) & 1) * NB) * TSZ;                                                   \
+        v8s_t f0_[GS][HW], f1_[GS][HW];                                                                               \
+        PIT_SATT_FRAGS(tile_, 0, f0_);                                                                                \
+        _Pragma("unroll") for (int gi = 0; gi < NG; gi += 2) {                                                        \
+            if (gi + 1 < NG) { PIT_SATT_FRAGS(tile_, gi + 1, f1_); }                                                  \
+            _Pragma("unroll") for (int u = 0; u < GS; ++u)                                                            \
+                _Pragma("unroll") for (int h = 0; h < HW; ++h) acc[gi * GS + u] = mma(__builtin_bit_cast(v8s_t, ar[(j_) & 3][h]), f0_[u][h], acc[gi * GS + u]); \
+            if (gi + 2 < NG) { PIT_SATT_FRAGS(tile_, gi + 2, f0_); }                                                  \
+            if (gi + 1 < NG) {                                                                                        \
+                _Pragma("unroll") for (int u = 0; u < GS; ++u)                                                        \
+                    _Pragma("unroll") for (int h = 0; h < HW; ++h) acc[(gi + 1) * GS + u] = mma(__builtin_bit_cast(v8s_t, ar[(j_) & 3][h]), f1_[u][h], acc[(gi + 1) * GS + u]); \
+            }                                                                                                         \
+        }                                                                                                             \
+    } while (0)
+    if constexpr (PRE) {
+        const u32x4_t* ap[HW];
+#pragma unroll
+        for (int h = 0; h < HW; ++h)
+            ap[h] = reinterpret_cast<const u32x4_t*>(g.e_in) + (((long)(mb * H + h) * (g.tiles * 4) + min(t * 4 * RT + wave, g.tiles * 4 - 1)) * nsteps) * 64 + lane;
+        u32x4_t ar[4][HW];
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+#pragma unroll
+            for (int h = 0; h < HW; ++h) ar[s][h] = ap[h][(long)min(s, nsteps - 1) * 64];
+        int sb = 0;
+        for (; sb + 4 <= nsteps; sb += 4) {
+            PIT_SATT_STEP_PRE(sb, 0);
+            PIT_SATT_STEP_PRE(sb + 1, 1);
+            PIT_SATT_STEP_PRE(sb + 2, 2);
+            PIT_SATT_STEP_PRE(sb + 3, 3);
+        }
+        if (sb < nsteps) {                                                    // (the step count is even)
+            PIT_SATT_STEP_PRE(sb, 0);
+            PIT_SATT_STEP_PRE(sb + 1, 1);
+        }
+    } else {
+        for (int sb = 0; sb < nsteps; sb += 2) {
+            PIT_SATT_STEP(sb, 0);
+            PIT_SATT_STEP(sb + 1, 1);
+        }
     }
+#undef PIT_SATT_STEP_PRE
+#undef PIT_SATT_ESTORE
 #undef PIT_SATT_STEP
 #undef PIT_SATT_FRAGS
 #undef PIT_SATT_WEIGHTS
@@ -220,7 +290,7 @@ __global__ __launch_bounds__(256, 2) void satt_kernel(SattArgs g) {
     // (the weights of the step beyond the last were formed too: keys >= L give zeros, rs / sm are unchanged by them)
     // ---- epilogues.  Accumulator register i of this lane is row 4 kq + i of the wave's 16, column 16 ct + l15; the per-row
     // quantities live on the lanes whose l15 is the row (summed over the four key quarters)
-    const int r0 = t * 64 + wave * 16;
+    const int r0 = t * 64 * RT + wave * 16;
     if ((PIT_SATT_DBG & 16) && acc[0][0] != 123.456f) return;
     if (MODE == 0) {
         rs += __shfl_xor(rs, 16, 64); rs += __shfl_xor(rs, 32, 64);
@@ -243,14 +313,20 @@ __global__ __launch_bounds__(256, 2) void satt_kernel(SattArgs g) {
             }
         }
     } else if (MODE == 1) {
+        // (the residual through a buffer resource, every load requested before the first add: as `add_residual ? res[..] : 0` it was a
+        // branch, a load and s_waitcnt vmcnt(0) per element - 32 dependent round trips, 9 us of the launch)
+        const __amdgpu_buffer_rsrc_t rres = wide_rsrc(g.d_out);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int n = r0 + 4 * kq + i;
+            float rv[NCT];
+            const unsigned roff = (unsigned)(((long)b * g.dout_bstride + (long)n * g.ld_dout + cs * W + l15) * 4);
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) rv[ct] = buf_load(rres, (g.add_residual && n < g.L) ? roff + 64u * ct : OOB);
             if (n < g.L) {
                 float* dst = g.d_values + (long)b * g.dv_bstride + (long)n * g.ld_dv + cs * W + l15;
-                const float* res = g.d_out + (long)b * g.dout_bstride + (long)n * g.ld_dout + cs * W + l15;
 #pragma unroll
-                for (int ct = 0; ct < NCT; ++ct) dst[16 * ct] = acc[ct][i] + (g.add_residual ? res[16 * ct] : 0.0f);
+                for (int ct = 0; ct < NCT; ++ct) dst[16 * ct] = acc[ct][i] + rv[ct];
             }
         }
     } else {
@@ -270,11 +346,15 @@ __global__ __launch_bounds__(256, 2) void satt_kernel(SattArgs g) {
             part += (double)sd * (double)iv;
         }
         part = wave_sum_d(part);
-        __shared__ double wred[4];
+        __shared__ double wred[NT / 64];
         if (lane == 0) wred[wave] = part;
         __syncthreads();
         if (tid == 0)
-            atomicAdd(g.dscale + (long)hsel * PIT_DSCALE_SLOTS + (((int)blockIdx.x / H) & (PIT_DSCALE_SLOTS - 1)), -(wred[0] + wred[1] + wred[2] + wred[3]));
+        {
+            double tot = 0.0;
+            for (int w = 0; w < NT / 64; ++w) tot += wred[w];
+            atomicAdd(g.dscale + (long)hsel * PIT_DSCALE_SLOTS + (((int)blockIdx.x / H) & (PIT_DSCALE_SLOTS - 1)), -tot);
+        }
     }
 }
 
@@ -312,17 +392,24 @@ bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 template <int H, int DIM, int MODE>
 void launch_satt(const SattArgs& g, int periodic, hipStream_t s) {
-    const dim3 grid((unsigned)(g.batch * g.tiles * (MODE == 1 ? DIM / satt_width(H, DIM, MODE) : H)));
+    const int per_tile = MODE == 1 ? DIM / satt_width(H, DIM, MODE) : H;
     const size_t sm = satt_smem(g.L, satt_width(H, DIM, MODE), MODE == 1 ? H : 1);
-    if (periodic) {
-        static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(satt_kernel<H, DIM, MODE, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024), true);
-        (void)once;
-        hipLaunchKernelGGL((satt_kernel<H, DIM, MODE, true>), grid, dim3(256), sm, s, g);
-    } else {
-        static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(satt_kernel<H, DIM, MODE, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024), true);
-        (void)once;
-        hipLaunchKernelGGL((satt_kernel<H, DIM, MODE, false>), grid, dim3(256), sm, s, g);
+#define PIT_SATT_GO(K_, RT_) do {                                                                                      \
+        static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(K_), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024), true); \
+        (void)once;                                                                                                   \
+        hipLaunchKernelGGL(K_, dim3((unsigned)(g.batch * ((g.tiles + (RT_) - 1) / (RT_)) * per_tile)), dim3(256 * (RT_)), sm, s, g); \
+    } while (0)
+    if constexpr (MODE == 1) {
+        if (g.e_in) {
+            if constexpr (H == 2 && DIM == 256) PIT_SATT_GO((satt_kernel<H, DIM, 1, false, true, 2>), 2);
+            else PIT_SATT_GO((satt_kernel<H, DIM, 1, false, true, 1>), 1);
+            return;
+        }
     }
+    if (periodic) PIT_SATT_GO((satt_kernel<H, DIM, MODE, true>), 1);
+    else if (H == 2 && DIM == 256 && (long)g.batch * g.tiles * per_tile > 256) PIT_SATT_GO((satt_kernel<H, DIM, MODE, false, false, 2>), 2);
+    else PIT_SATT_GO((satt_kernel<H, DIM, MODE, false>), 1);
+#undef PIT_SATT_GO
 }
 template <int MODE>
 void dispatch_satt(const SattArgs& g, int periodic, hipStream_t s) {
@@ -349,14 +436,21 @@ extern "C" int pit_satt_supported(int n_pts, int n_head, int dim, int batch, int
     return (long)batch * n_pts * dim * (1 + n_head) * 4 < (1L << 31) - 65536;
 }
 
+// bf16 elements of the weight tiles of ONE (mesh sample, head): pit_satt_fwd's optional e_tiles is (mesh_batch, n_head, this)
+extern "C" long pit_satt_tiles_elems(int n_pts) {
+    const long tiles = (n_pts + 63) / 64;
+    return tiles * 4 * (tiles * 64 / KC) * 512;
+}
+
 // out[b, n, out_col0 + h*dim + d] = sum_j softmax_j(-c_h m[n, j]) values[b, j, d]; copy_inputs: out[b, n, 0:dim] = values.  x16: scratch of
 // batch*n_pts*dim bf16 (kept by the caller for pit_satt_bwd); rowstat (mesh_batch, n_head, n_pts, 4), scale_out (n_head) as pit_posatt_fwd.
 extern "C" int pit_satt_fwd(const float* mesh, int mesh_batch, int n_pts, int space_dim, int metric, float period,
                             const float* values, long ld_values, long values_bstride, int batch, int dim,
                             const float* head, int n_head, int head_is_scale, unsigned short* x16,
                             float* out, long ld_out, long out_bstride, int out_col0, int copy_inputs,
-                            float* rowstat, float* scale_out, void* stream) {
+                            float* rowstat, float* scale_out, unsigned short* e_tiles, void* stream) {
     if (!values || !head || !x16 || !out || !rowstat) return PIT_ERR_NULL;
+    if (e_tiles && !al16(e_tiles)) return PIT_ERR_SIZE;
     if (!pit_satt_supported(n_pts, n_head, dim, batch, mesh_batch) || space_dim < 1 || space_dim > 3) return PIT_ERR_UNSUPPORTED;
     if (ld_values % 4 || values_bstride % 4 || !al16(values) || !al16(x16) || !al16(rowstat) || (copy_inputs && (ld_out % 4 || out_bstride % 4 || !al16(out))))
         return PIT_ERR_SIZE;
@@ -371,7 +465,7 @@ extern "C" int pit_satt_fwd(const float* mesh, int mesh_batch, int n_pts, int sp
     hipLaunchKernelGGL(satt_prep_kernel, dim3((unsigned)std::min<long>((total + 255) / 256, 2048)), dim3(256), 0, s, p, 0);
     PIT_CHECK_LAUNCH();
     g.head = head; g.head_is_scale = head_is_scale; g.b16 = x16; g.out = out; g.ld_out = ld_out; g.out_bstride = out_bstride;
-    g.out_col0 = out_col0; g.rowstat = rowstat; g.scale_out = scale_out;
+    g.out_col0 = out_col0; g.rowstat = rowstat; g.scale_out = scale_out; g.e_out = e_tiles;
     dispatch_satt<0>(g, metric != PIT_METRIC_EUCLID, s);
     PIT_CHECK_LAUNCH();
     return 0;
@@ -385,8 +479,9 @@ extern "C" int pit_satt_bwd(const float* mesh, int mesh_batch, int n_pts, int sp
                             const unsigned short* x16, unsigned short* g16,
                             const float* d_out, long ld_dout, long dout_bstride, int out_col0,
                             float* d_values, long ld_dvalues, long dvalues_bstride, int add_residual,
-                            double* dscale, void* stream) {
+                            double* dscale, const unsigned short* e_tiles, void* stream) {
     if (!scale || !rowstat || !x16 || !g16 || !d_out || (!d_values && !dscale)) return PIT_ERR_NULL;
+    if (e_tiles && !al16(e_tiles)) return PIT_ERR_SIZE;
     if (!pit_satt_supported(n_pts, n_head, dim, batch, mesh_batch) || space_dim < 1 || space_dim > 3) return PIT_ERR_UNSUPPORTED;
     if (ld_dout % 4 || dout_bstride % 4 || out_col0 % 4 || !al16(d_out) || !al16(g16) || !al16(x16)) return PIT_ERR_SIZE;
     SattArgs g;
@@ -402,11 +497,12 @@ extern "C" int pit_satt_bwd(const float* mesh, int mesh_batch, int n_pts, int sp
         hipLaunchKernelGGL(satt_prep_kernel, dim3((unsigned)std::min<long>((total + 255) / 256, 2048)), dim3(256), 0, s, p, 1);
         PIT_CHECK_LAUNCH();
         g.b16 = g16; g.d_values = d_values; g.ld_dv = ld_dvalues; g.dv_bstride = dvalues_bstride; g.add_residual = add_residual;
+        g.e_in = e_tiles;
         dispatch_satt<1>(g, metric != PIT_METRIC_EUCLID, s);
         PIT_CHECK_LAUNCH();
     }
     if (dscale) {
-        g.b16 = x16; g.dscale = dscale;
+        g.b16 = x16; g.dscale = dscale; g.e_in = nullptr;
         dispatch_satt<2>(g, metric != PIT_METRIC_EUCLID, s);
         PIT_CHECK_LAUNCH();
     }

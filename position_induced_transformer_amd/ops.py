@@ -631,6 +631,7 @@ UNION_ATT = os.environ.get("PIT_UNION_ATT", "1") != "0"
 # with rounded operands - two heads x hid 256 on >= 512 points (Elasticity: 149 us per layer against 191; NACA 728 x 128 x 1 and
 # Vorticity 256 x 256 x 2 measured 6 / 3 us per layer SLOWER); "1": every supported shape; "0": never
 SATT = os.environ.get("PIT_SATT", "auto")
+SATT_TILES = os.environ.get("PIT_SATT_TILES", "1") != "0"      # the forward keeps its weights as bf16 tiles for the backward's d(values)
 
 
 def _satt_pays(n_pts: int, n_head: int, d: int) -> bool:
@@ -711,12 +712,17 @@ class _PosAtt(torch.autograd.Function):
             x16 = torch.empty((b, j, d), device=values.device, dtype=torch.bfloat16)
             rowstat = torch.empty((plan.mesh_batch, n_head, plan.n_out, 4), device=values.device, dtype=torch.float32)
             scale = torch.empty((n_head,), device=values.device, dtype=torch.float32)
+            # the forward's rounded weights, kept as MFMA A-fragment tiles for the backward's d(values) (2 MB per sample and head at
+            # Elasticity's 972 points)
+            et = torch.empty((plan.mesh_batch, n_head, int(_lib.lib().pit_satt_tiles_elems(int(plan.n_in)))), device=values.device,
+                             dtype=torch.bfloat16) if SATT_TILES else None
             rc = _lib.lib().pit_satt_fwd(plan.mesh_in.data_ptr(), plan.mesh_batch, plan.n_in, plan.sdim, plan.metric_id, plan.period,
                                          values.data_ptr(), values.stride(1), values.stride(0), b, d, k_head.data_ptr(), n_head,
                                          1 if k_is_scale else 0, x16.data_ptr(), out.data_ptr(), out.stride(1), out.stride(0), d,
-                                         1 if out_buf is None else 0, rowstat.data_ptr(), scale.data_ptr(), _lib.stream_ptr())
+                                         1 if out_buf is None else 0, rowstat.data_ptr(), scale.data_ptr(), _lib.ptr(et), _lib.stream_ptr())
             _lib.check(rc, "pit_satt_fwd")
             ctx.satt = x16
+            ctx.satt_tiles = et
             ctx.union = 0
             ctx.plan, ctx.n_head, ctx.concat, ctx.head_is_scale = plan, n_head, concat, head_is_scale
             ctx.head_param = head_param
@@ -806,7 +812,8 @@ class _PosAtt(torch.autograd.Function):
                                          d_out.data_ptr(), d_out.stride(1), d_out.stride(0), dv,
                                          _lib.ptr(d_values), d_values.stride(1) if d_values is not None else 0,
                                          d_values.stride(0) if d_values is not None else 0, 1,
-                                         work.data_ptr() if need_h else None, _lib.stream_ptr())
+                                         work.data_ptr() if need_h else None, _lib.ptr(getattr(ctx, "satt_tiles", None)),
+                                         _lib.stream_ptr())
             _lib.check(rc, "pit_satt_bwd")
             if need_h:
                 flags = (1 if slot is not None else 0) | (4 if ctx.head_is_scale else 0)

@@ -405,12 +405,23 @@ def test_dense_self_attention_on_bf16_mfma_against_the_oracle(metric, batched, L
             out = ops.posatt_apply(v1, l1, plan, heads, concat=True)
             out.backward(d_out.cuda())
             assert calls["n"] == 1
+            # d(values) on the forward's weight tiles (the default) and with the weights formed again: the same rounded weights
+            tiles_were = ops.SATT_TILES
+            ops.SATT_TILES = False
+            try:
+                v3, l3 = values.cuda().requires_grad_(True), lmda.cuda().requires_grad_(True)
+                out3 = ops.posatt_apply(v3, l3, plan, heads, concat=True)
+                out3.backward(d_out.cuda())
+            finally:
+                ops.SATT_TILES = tiles_were
+            assert calls["n"] == 2 and tiles_were
+            assert torch.equal(out3, out) and _rel(v3.grad, v1.grad) <= 1e-6 and torch.equal(l3.grad, l1.grad)
             # the same layer on the register-rounding kernels of the earlier rounds: both are the bf16 mode
             ops.SATT = "0"
             v2, l2 = values.cuda().requires_grad_(True), lmda.cuda().requires_grad_(True)
             out2 = ops.posatt_apply(v2, l2, plan, heads, concat=True)
             out2.backward(d_out.cuda())
-            assert calls["n"] == 1
+            assert calls["n"] == 2
             ops.SATT = "auto"
             assert ops._satt_pays(972, 2, 256) and not ops._satt_pays(728, 1, 128) and not ops._satt_pays(256, 2, 256)
     finally:
