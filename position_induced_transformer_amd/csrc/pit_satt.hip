@@ -100,8 +100,10 @@ constexpr int satt_width(int H, int DIM, int MODE) { return (MODE == 1 && H == 2
 // workgroups pulled 53 GB/s, a CU's practical L2 rate: 0.9 us per step.  128 rows per workgroup = half the workgroups = half the bytes.
 template <int H, int DIM, int MODE, bool PERIODIC, bool PRE = false, int RT = 1>
 __global__ __launch_bounds__(256 * RT, 2) void satt_kernel(SattArgs g) {
-    static_assert(!PRE || MODE == 1, "only d(values) reads the forward's weight tiles");
+    static_assert(!PRE || MODE != 0, "the backward reads the forward's weight tiles");
     constexpr int NT = 256 * RT;
+    constexpr bool PRE1 = PRE && MODE == 1;    // d(values): the tiles ARE the A operand
+    constexpr bool PRE2 = PRE && MODE == 2;    // d(scale): A = tile x (m - mbar) - the distance again, but no exp2, no padding select
     constexpr int W = satt_width(H, DIM, MODE), NCS = DIM / W, NCT = W / 16, TSZ = CGS * W, HW = (MODE == 1) ? H : 1, NB = (MODE == 1) ? H : 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float4* keys = reinterpret_cast<float4*>(smem_raw);                        // [Lp] key coordinates (zero-padded to 3)
@@ -122,13 +124,13 @@ __global__ __launch_bounds__(256 * RT, 2) void satt_kernel(SattArgs g) {
     const unsigned short* bsrc[NB];
 #pragma unroll
     for (int q = 0; q < NB; ++q) bsrc[q] = g.b16 + ((long)b * NB + q) * g.L * DIM + cs * W;
-    constexpr int NR = PRE ? 4 : 2;            // register sets of B tiles in flight: a PRE step is ~0.3 us, two steps of lead are less than an L2 round trip
+    constexpr int NR = PRE1 ? 4 : 2;            // register sets of B tiles in flight: a PRE step is ~0.3 us, two steps of lead are less than an L2 round trip
     Tile<W, NT> reg[NR][NB];
 #pragma unroll
     for (int s = 0; s < NR; ++s)
 #pragma unroll
         for (int q = 0; q < NB; ++q) tile_load<W, DIM, NT>(bsrc[q], g.L, KC * s, tid, reg[s][q]);
-    if (!PRE)
+    if (!PRE1)
     for (int j = tid; j < Lp + KC; j += NT) {
         float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
         if (j < g.L) {
@@ -138,8 +140,8 @@ __global__ __launch_bounds__(256 * RT, 2) void satt_kernel(SattArgs g) {
         }
         keys[j] = p;
     }
-    const float rx = PRE ? 0.0f : mesh[(long)rowc * g.sdim], ry = (!PRE && g.used > 1) ? mesh[(long)rowc * g.sdim + 1] : 0.0f,
-                rz = (!PRE && g.used > 2) ? mesh[(long)rowc * g.sdim + 2] : 0.0f;
+    const float rx = PRE1 ? 0.0f : mesh[(long)rowc * g.sdim], ry = (!PRE1 && g.used > 1) ? mesh[(long)rowc * g.sdim + 1] : 0.0f,
+                rz = (!PRE1 && g.used > 2) ? mesh[(long)rowc * g.sdim + 2] : 0.0f;
     float c[HW], c2[HW], mbar[HW];                                             // c2 = -c log2(e): exp(-c m) = exp2(c2 m), one multiply less per weight
 #pragma unroll
     for (int h = 0; h < HW; ++h) {
@@ -162,13 +164,15 @@ __global__ __launch_bounds__(256 * RT, 2) void satt_kernel(SattArgs g) {
         const int j = KC * (s_) + 16 * (e >> 2) + 4 * kq + (e & 3);                                                   \
         kp_[e] = keys[j];                                                                                             \
     }
-#define PIT_SATT_WEIGHTS(s_, kp_, dst_)                                                                               \
+#define PIT_SATT_WEIGHTS(s_, kp_, dst_, ring_)                                                                            \
     do {                                                                                                              \
         _Pragma("unroll") for (int e = 0; e < 8; ++e) {                                                               \
             const int j = KC * (s_) + 16 * (e >> 2) + 4 * kq + (e & 3);                                               \
             const float m = sq_dist3t<PERIODIC>(rx, ry, rz, kp_[e].x, kp_[e].y, kp_[e].z, g.period);                  \
             _Pragma("unroll") for (int h = 0; h < HW; ++h) {                                                          \
-                float ev = (j < g.L) ? __builtin_amdgcn_exp2f(__fmul_rn(m, c2[h])) : 0.0f;                            \
+                float ev;                                                                                             \
+                if (PRE2) ev = __uint_as_float((e & 1) ? (er[ring_][e >> 1] & 0xffff0000u) : (er[ring_][e >> 1] << 16));      \
+                else ev = (j < g.L) ? __builtin_amdgcn_exp2f(__fmul_rn(m, c2[h])) : 0.0f;                             \
                 if (MODE == 0) { rs += ev; sm = fmaf(ev, m, sm); }                                                    \
                 if (MODE == 2) ev *= (m - mbar[h]);                                                                   \
                 dst_[h][e] = bf16_bits(ev);                                                                           \
@@ -190,11 +194,18 @@ __global__ __launch_bounds__(256 * RT, 2) void satt_kernel(SattArgs g) {
                                                (int)((e_mine && (s_) < nsteps) ? (unsigned)((tile_base + (long)(s_) * 64) * 16) : OOB), 0, 0); \
     } } while (0)
     v8s_t af[2][HW];
-    if constexpr (!PRE) {
+    // PRE2: the forward's tile of step s in er[s & 3], requested four steps ahead (16 bytes per lane: the lane's eight weights)
+    const u32x4_t* ap2 = reinterpret_cast<const u32x4_t*>(g.e_in) + (PRE2 ? (((long)(mb * H + hsel) * (g.tiles * 4) + min(t * 4 * RT + wave, g.tiles * 4 - 1)) * nsteps) * 64 + lane : 0);
+    u32x4_t er[4];
+    if constexpr (PRE2) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) er[s] = ap2[(long)min(s, nsteps - 1) * 64];
+    }
+    if constexpr (!PRE1) {
         float4 kp0[8];
         __syncthreads();                                                      // (the key coordinates are in LDS)
         PIT_SATT_KEYS(0, kp0);
-        PIT_SATT_WEIGHTS(0, kp0, af[0]);
+        PIT_SATT_WEIGHTS(0, kp0, af[0], 0);
         PIT_SATT_ESTORE(0, af[0][0]);
     }
     // step s contracts keys [32 s, 32 s + 32): its B tile(s) sit in buffer s & 1; register set (s + 1) & 1 holds tile s + 1 (parked
@@ -218,7 +229,8 @@ __global__ __launch_bounds__(256 * RT, 2) void satt_kernel(SattArgs g) {
         v8s_t f0_[GS][HW], f1_[GS][HW];                                                                               \
         if (!(PIT_SATT_DBG & 2)) { PIT_SATT_KEYS((s_) + 1, kp_); }                                                    \
         if (!(PIT_SATT_DBG & 4)) { PIT_SATT_FRAGS(tile_, 0, f0_); }                                                   \
-        if (!(PIT_SATT_DBG & 2)) { PIT_SATT_WEIGHTS((s_) + 1, kp_, af[((j_) + 1) & 1]); PIT_SATT_ESTORE((s_) + 1, af[((j_) + 1) & 1][0]); } \
+        if (PRE2) er[(j_) & 3] = ap2[(long)min((s_) + 4, nsteps - 1) * 64];                                            \
+        if (!(PIT_SATT_DBG & 2)) { PIT_SATT_WEIGHTS((s_) + 1, kp_, af[((j_) + 1) & 1], ((j_) + 1) & 3); PIT_SATT_ESTORE((s_) + 1, af[((j_) + 1) & 1][0]); } \
         else { _Pragma("unroll") for (int h = 0; h < HW; ++h) af[((j_) + 1) & 1][h] = af[(j_) & 1][h]; }              \
         if (!(PIT_SATT_DBG & 4))                                                                                      \
         _Pragma("unroll") for (int gi = 0; gi < NG; gi += 2) {                                                        \
@@ -254,7 +266,7 @@ __global__ __launch_bounds__(256 * RT, 2) void satt_kernel(SattArgs g) {
             }                                                                                                         \
         }                                                                                                             \
     } while (0)
-    if constexpr (PRE) {
+    if constexpr (PRE1) {
         const u32x4_t* ap[HW];
 #pragma unroll
         for (int h = 0; h < HW; ++h)
@@ -274,6 +286,18 @@ __global__ __launch_bounds__(256 * RT, 2) void satt_kernel(SattArgs g) {
         if (sb < nsteps) {                                                    // (the step count is even)
             PIT_SATT_STEP_PRE(sb, 0);
             PIT_SATT_STEP_PRE(sb + 1, 1);
+        }
+    } else if constexpr (PRE2) {
+        int sb = 0;
+        for (; sb + 4 <= nsteps; sb += 4) {
+            PIT_SATT_STEP(sb, 0);
+            PIT_SATT_STEP(sb + 1, 1);
+            PIT_SATT_STEP(sb + 2, 2);
+            PIT_SATT_STEP(sb + 3, 3);
+        }
+        if (sb < nsteps) {
+            PIT_SATT_STEP(sb, 0);
+            PIT_SATT_STEP(sb + 1, 1);
         }
     } else {
         for (int sb = 0; sb < nsteps; sb += 2) {
@@ -406,8 +430,22 @@ void launch_satt(const SattArgs& g, int periodic, hipStream_t s) {
             return;
         }
     }
+    if constexpr (MODE == 2) {
+        if (g.e_in) {
+            if constexpr (H == 2 && DIM == 256) {
+                if (!periodic && (long)g.batch * g.tiles * per_tile > 256) { PIT_SATT_GO((satt_kernel<H, DIM, 2, false, true, 2>), 2); return; }
+            }
+            if (periodic) PIT_SATT_GO((satt_kernel<H, DIM, 2, true, true, 1>), 1);
+            else PIT_SATT_GO((satt_kernel<H, DIM, 2, false, true, 1>), 1);
+            return;
+        }
+    }
+    // (128-row workgroups when the 64-row tiles outnumber the CUs: half the workgroups pull half the bytes from L2 - Elasticity's forward
+    // 44.8 -> 39.1 us)
+    if constexpr (H == 2 && DIM == 256) {
+        if (!periodic && (long)g.batch * g.tiles * per_tile > 256) { PIT_SATT_GO((satt_kernel<H, DIM, MODE, false, false, 2>), 2); return; }
+    }
     if (periodic) PIT_SATT_GO((satt_kernel<H, DIM, MODE, true>), 1);
-    else if (H == 2 && DIM == 256 && (long)g.batch * g.tiles * per_tile > 256) PIT_SATT_GO((satt_kernel<H, DIM, MODE, false, false, 2>), 2);
     else PIT_SATT_GO((satt_kernel<H, DIM, MODE, false>), 1);
 #undef PIT_SATT_GO
 }
@@ -502,7 +540,7 @@ extern "C" int pit_satt_bwd(const float* mesh, int mesh_batch, int n_pts, int sp
         PIT_CHECK_LAUNCH();
     }
     if (dscale) {
-        g.b16 = x16; g.dscale = dscale; g.e_in = nullptr;
+        g.b16 = x16; g.dscale = dscale; g.e_in = e_tiles;
         dispatch_satt<2>(g, metric != PIT_METRIC_EUCLID, s);
         PIT_CHECK_LAUNCH();
     }

@@ -628,15 +628,16 @@ def _row_view(t: torch.Tensor) -> torch.Tensor:
 
 UNION_ATT = os.environ.get("PIT_UNION_ATT", "1") != "0"
 # bf16 mode: dense self-attention of hid 128 / 256 on csrc/pit_satt.hip.  "auto": where it measured faster than the fp32-era kernels
-# with rounded operands - two heads x hid 256 on >= 512 points (Elasticity: 149 us per layer against 191; NACA 728 x 128 x 1 and
-# Vorticity 256 x 256 x 2 measured 6 / 3 us per layer SLOWER); "1": every supported shape; "0": never
+# with rounded operands - layers of >= 512 points (Elasticity 972 x 256 x 2 heads: 114 us per layer against 191; NACA 728 x 128 x 1:
+# 65 against 70; Vorticity's 256 points: 46 against 47 with one launch more - DESIGN.md section 4 round 6); "1": every supported
+# shape; "0": never
 SATT = os.environ.get("PIT_SATT", "auto")
-SATT_TILES = os.environ.get("PIT_SATT_TILES", "1") != "0"      # the forward keeps its weights as bf16 tiles for the backward's d(values)
+SATT_TILES = os.environ.get("PIT_SATT_TILES", "1") != "0"      # the forward keeps its weights as bf16 tiles for the backward
 
 
 def _satt_pays(n_pts: int, n_head: int, d: int) -> bool:
     if SATT == "auto":
-        return n_head == 2 and d == 256 and n_pts >= 512
+        return n_pts >= 512
     return SATT not in ("0", "", False)
 
 

@@ -415,7 +415,8 @@ def test_dense_self_attention_on_bf16_mfma_against_the_oracle(metric, batched, L
             finally:
                 ops.SATT_TILES = tiles_were
             assert calls["n"] == 2 and tiles_were
-            assert torch.equal(out3, out) and _rel(v3.grad, v1.grad) <= 1e-6 and torch.equal(l3.grad, l1.grad)
+            # (d(scale) forms its operand from the tile's rounded weight x (m - mbar): rounded twice, not once)
+            assert torch.equal(out3, out) and _rel(v3.grad, v1.grad) <= 1e-6 and _rel(l3.grad, l1.grad) <= 2e-3
             # the same layer on the register-rounding kernels of the earlier rounds: both are the bf16 mode
             ops.SATT = "0"
             v2, l2 = values.cuda().requires_grad_(True), lmda.cuda().requires_grad_(True)
@@ -423,7 +424,7 @@ def test_dense_self_attention_on_bf16_mfma_against_the_oracle(metric, batched, L
             out2.backward(d_out.cuda())
             assert calls["n"] == 2
             ops.SATT = "auto"
-            assert ops._satt_pays(972, 2, 256) and not ops._satt_pays(728, 1, 128) and not ops._satt_pays(256, 2, 256)
+            assert ops._satt_pays(972, 2, 256) and ops._satt_pays(728, 1, 128) and not ops._satt_pays(256, 2, 256)
     finally:
         ops.SATT = saved
         L_.pit_satt_fwd = real
