@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PIT_ABI_VERSION 20
+#define PIT_ABI_VERSION 21
 #define PIT_DSCALE_SLOTS 1024 /* fp64 accumulators per head in pit_posatt_bwd's workspace */
 
 /* distance metric (dist2att variants) */
@@ -473,6 +473,8 @@ int pit_posatt_pre_bwd(const float* e, const float* q, const float* rowstat, int
  *   pit_satt_bwd  d_values[b, j, :] = (add_residual ? d_out[b, j, 0:dim] : 0) + sum_h sum_n P_h[n, j] d_out[b, n, out_col0 + h*dim + :] (NULL: not
  *                 needed); the layer's d(scale) accumulators (PIT_HEAD_DEFER convention; NULL: not needed).  scale = the forward's c;
  *                 g16: scratch of batch*n_head*n_pts*dim bf16.
+ *   x16_ready / g16_ready: the caller's x16 / g16 already hold bf16(values) / bf16(d_out_h / rowsum_h) - written by the producing
+ *                 pit_mlp_chain_fwd (y16) / pit_mlp_chain_bwd (g16): no prep launch (x16_ready needs copy_inputs = 0).
  *   e_tiles (optional, NULL: none): (mesh_batch, n_head, pit_satt_tiles_elems(n_pts)) bf16 - the forward leaves its rounded weights there
  *                 in MFMA A-fragment order and pit_satt_bwd's d(values) (the same, symmetric, matrix) reads them instead of forming
  *                 every weight again.
@@ -482,13 +484,13 @@ int pit_satt_fwd(const float* mesh, int mesh_batch, int n_pts, int space_dim, in
                  const float* values, long ld_values, long values_bstride, int batch, int dim,
                  const float* head, int n_head, int head_is_scale, unsigned short* x16,
                  float* out, long ld_out, long out_bstride, int out_col0, int copy_inputs,
-                 float* rowstat, float* scale_out, unsigned short* e_tiles, void* stream);
+                 float* rowstat, float* scale_out, unsigned short* e_tiles, int x16_ready, void* stream);
 int pit_satt_bwd(const float* mesh, int mesh_batch, int n_pts, int space_dim, int metric, float period,
                  int batch, int dim, const float* scale, int n_head, const float* rowstat,
                  const unsigned short* x16, unsigned short* g16,
                  const float* d_out, long ld_dout, long dout_bstride, int out_col0,
                  float* d_values, long ld_dvalues, long dvalues_bstride, int add_residual, double* dscale,
-                 const unsigned short* e_tiles, void* stream);
+                 const unsigned short* e_tiles, int g16_ready, void* stream);
 long pit_satt_tiles_elems(int n_pts);
 
 /* kaiming_mlp.forward (pit.py:21-26): y = W2 * gelu_erf(W1 x + b1) + b2, optionally
@@ -509,9 +511,12 @@ int pit_mlp_fwd(const float* x, long ldx, int rows, int n0, int n1, int n2,
  * gelu / gelu' are the polynomial CDF of the bf16 mode (pit_thin_tail_*). */
 int pit_mlp_chain_supported(int rows, int n0, int n1, int n2);
 int pit_mlp_chain_fwd(const float* x, long ldx, int rows, int n0, int n1, const unsigned short* w1_bf16, const float* b1,
-                      const unsigned short* w2_bf16, const float* b2, float* z1, float* h, float* z2, float* y, long ldy, void* stream);
+                      const unsigned short* w2_bf16, const float* b2, float* z1, float* h, float* z2, float* y, long ldy,
+                      unsigned short* y16 /* optional: bf16(y), (rows, n1) - the x16 of the next layer's pit_satt_fwd */, void* stream);
 int pit_mlp_chain_bwd(int rows, int n0, int n1, const unsigned short* w1_bf16, const unsigned short* w2_bf16,
-                      const float* z1, const float* z2, const float* d_y, long ld_dy, float* d_x, long ld_dx, float* scratch, void* stream);
+                      const float* z1, const float* z2, const float* d_y, long ld_dy, float* d_x, long ld_dx, float* scratch,
+                      unsigned short* g16 /* optional: the g16 of the producing layer's pit_satt_bwd: bf16(d_x[:, (1+h) n1 + :] / rowsum_h), (rows / pts, n0 / n1 - 1, pts, n1) */,
+                      const float* rowstat /* that layer's */, int pts, int mesh_batch, void* stream);
 /* dst[i] = bf16(src[i]) (RNE) for n <= 32 tensors of count[i] floats (multiples of 4; 16-byte aligned sources): one launch. */
 int pit_cast_bf16_multi(int n, const float* const* src, unsigned short* const* dst, const long* count, void* stream);
 

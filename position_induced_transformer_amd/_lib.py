@@ -85,12 +85,12 @@ SIGNATURES = {
     "pit_thin_tail_fwd": [_P, _L, _I, _I, _I, _P, _P, _P, _P, _L, _I, _P],
     "pit_thin_tail_bwd": [_P, _L, _I, _I, _I, _P, _P, _P, _L, _P, _L, _P, _P, _P, _P, _I, _P],
     "pit_satt_supported": [_I, _I, _I, _I, _I],
-    "pit_satt_fwd": [_P, _I, _I, _I, _I, _F, _P, _L, _L, _I, _I, _P, _I, _I, _P, _P, _L, _L, _I, _I, _P, _P, _P, _P],
-    "pit_satt_bwd": [_P, _I, _I, _I, _I, _F, _I, _I, _P, _I, _P, _P, _P, _P, _L, _L, _I, _P, _L, _L, _I, _P, _P, _P],
+    "pit_satt_fwd": [_P, _I, _I, _I, _I, _F, _P, _L, _L, _I, _I, _P, _I, _I, _P, _P, _L, _L, _I, _I, _P, _P, _P, _I, _P],
+    "pit_satt_bwd": [_P, _I, _I, _I, _I, _F, _I, _I, _P, _I, _P, _P, _P, _P, _L, _L, _I, _P, _L, _L, _I, _P, _P, _I, _P],
     "pit_satt_tiles_elems": [_I],
     "pit_mlp_chain_supported": [_I, _I, _I, _I],
-    "pit_mlp_chain_fwd": [_P, _L, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P],
-    "pit_mlp_chain_bwd": [_I, _I, _I, _P, _P, _P, _P, _P, _L, _P, _L, _P, _P],
+    "pit_mlp_chain_fwd": [_P, _L, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _P],
+    "pit_mlp_chain_bwd": [_I, _I, _I, _P, _P, _P, _P, _P, _L, _P, _L, _P, _P, _P, _I, _I, _P],
     "pit_cast_bf16_multi": [_I, _P, _P, _P, _P],
     "pit_linear_fwd": [_P, _L, _I, _I, _I, _P, _P, _P, _L, _I, _P],
     "pit_linear_bwd": [_P, _L, _I, _I, _I, _P, _P, _L, _P, _L, _P, _I, _I, _P],
@@ -128,7 +128,7 @@ SIGNATURES = {
 }
 
 LONG_RETURN = {"pit_satt_tiles_elems"}
-ABI_VERSION = 20       # PIT_ABI_VERSION of include/pit_hip.h this binding was written against
+ABI_VERSION = 21       # PIT_ABI_VERSION of include/pit_hip.h this binding was written against
 
 _lib = None
 

@@ -38,6 +38,8 @@ struct ChainArgs {
     const float *z1r, *z2r;
     float* d_x; long ld_dx;
     float *dz1, *dz2;
+    unsigned short* y16;                       // forward, optional: bf16(y), (rows, n1) - the next layer's pit_satt_fwd reads it (no prep launch)
+    unsigned short* g16; const float* rowstat; int pts, mesh_batch;      // backward, optional: what pit_satt_bwd's prep would form from d_x
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t wide_rsrc(const void* p) { return make_rsrc(p, 0x7ffffff0u); }
@@ -212,9 +214,10 @@ __global__ __launch_bounds__(NT) void mlp_chain_fwd_kernel(ChainArgs g) {
             for (int i = 0; i < 4; ++i) {
                 const int r = 16 * rt + 4 * kq + i;
                 if (row0 + r < g.rows) {
-                    const float z = acc[rt][ct][i] + bias;
+                    const float z = acc[rt][ct][i] + bias, yv = gelu_f(z);
                     g.z2[(long)(row0 + r) * N1 + col] = z;
-                    g.y[(long)(row0 + r) * g.ldy + col] = gelu_f(z);
+                    g.y[(long)(row0 + r) * g.ldy + col] = yv;
+                    if (g.y16) g.y16[(long)(row0 + r) * N1 + col] = f_to_bf16(yv);
                 }
             }
     }
@@ -327,6 +330,22 @@ __global__ __launch_bounds__(NT) void mlp_chain_bwd_kernel(ChainArgs g) {
                         if (row0 + r < g.rows) g.d_x[(long)(row0 + r) * g.ld_dx + col] = acc[rt][ct][i];
                     }
             }
+            // the columns of head c - 1 of a self-attention layer's concat buffer: G_h = d_x / rowsum_h as bf16, (batch, H, pts, N1)
+            if (g.g16 && c >= 1) {
+                const int hd = c - 1, nh = chunks - 1;
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int r = row0 + 16 * rt + 4 * kq + i;
+                        if (r >= g.rows) continue;
+                        const int bb = r / g.pts, n = r - bb * g.pts;
+                        const float iv = g.rowstat[(((long)(g.mesh_batch == 1 ? 0 : bb) * nh + hd) * g.pts + n) * 4 + 2];
+                        unsigned short* dst = g.g16 + (((long)bb * nh + hd) * g.pts + n) * N1 + wave * NC + l15;
+#pragma unroll
+                        for (int ct = 0; ct < CT; ++ct) dst[16 * ct] = f_to_bf16(acc[rt][ct][i] * iv);
+                    }
+            }
         }
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt)
@@ -389,13 +408,13 @@ extern "C" int pit_mlp_chain_supported(int rows, int n0, int n1, int n2) {
 
 extern "C" int pit_mlp_chain_fwd(const float* x, long ldx, int rows, int n0, int n1, const unsigned short* w1_bf16, const float* b1,
                                  const unsigned short* w2_bf16, const float* b2, float* z1, float* h, float* z2, float* y, long ldy,
-                                 void* stream) {
+                                 unsigned short* y16, void* stream) {
     if (!x || !w1_bf16 || !b1 || !w2_bf16 || !b2 || !z1 || !h || !z2 || !y) return PIT_ERR_NULL;
     if (!chain_shape_ok(rows, n0, n1, n1) || ldx < n0 || ldy < n1) return PIT_ERR_UNSUPPORTED;
     if (ldx % 4 || !a16(x) || !a16(w1_bf16) || !a16(w2_bf16)) return PIT_ERR_SIZE;
     ChainArgs g = ChainArgs();
     g.rows = rows; g.n0 = n0; g.n1 = n1; g.x = x; g.ldx = ldx; g.w1b = w1_bf16; g.w2b = w2_bf16; g.b1 = b1; g.b2 = b2;
-    g.z1 = z1; g.h = h; g.z2 = z2; g.y = y; g.ldy = ldy;
+    g.z1 = z1; g.h = h; g.z2 = z2; g.y = y; g.ldy = ldy; g.y16 = y16;
     hipStream_t s = (hipStream_t)stream;
     if (n1 == 128) chain_launch_fwd<128, 32>(g, s);
     else if (chain_slab_rows(rows, n0, n1) == 48) chain_launch_fwd<256, 48>(g, s);
@@ -408,13 +427,18 @@ extern "C" int pit_mlp_chain_fwd(const float* x, long ldx, int rows, int n0, int
 // not needed).  d_y rows ld_dy apart.
 extern "C" int pit_mlp_chain_bwd(int rows, int n0, int n1, const unsigned short* w1_bf16, const unsigned short* w2_bf16,
                                  const float* z1, const float* z2, const float* d_y, long ld_dy, float* d_x, long ld_dx,
-                                 float* scratch, void* stream) {
+                                 float* scratch, unsigned short* g16, const float* rowstat, int pts, int mesh_batch, void* stream) {
     if (!w1_bf16 || !w2_bf16 || !z1 || !z2 || !d_y || !scratch) return PIT_ERR_NULL;
     if (!chain_shape_ok(rows, n0, n1, n1) || ld_dy < n1 || (d_x && ld_dx < n0)) return PIT_ERR_UNSUPPORTED;
     if (ld_dy % 4 || !a16(d_y) || !a16(z2) || !a16(w1_bf16) || !a16(w2_bf16) || !a16(scratch)) return PIT_ERR_SIZE;
     ChainArgs g = ChainArgs();
     g.rows = rows; g.n0 = n0; g.n1 = n1; g.w1b = w1_bf16; g.w2b = w2_bf16; g.z1r = z1; g.z2r = z2; g.d_y = d_y; g.ld_dy = ld_dy;
     g.d_x = d_x; g.ld_dx = ld_dx; g.dz1 = scratch; g.dz2 = scratch + (long)rows * n1;
+    if (g16) {
+        if (!rowstat || !d_x) return PIT_ERR_NULL;
+        if (pts <= 0 || rows % pts || n0 < 2 * n1 || (mesh_batch != 1 && mesh_batch != rows / pts)) return PIT_ERR_SIZE;
+        g.g16 = g16; g.rowstat = rowstat; g.pts = pts; g.mesh_batch = mesh_batch;
+    }
     hipStream_t s = (hipStream_t)stream;
     if (n1 == 128) chain_launch_bwd<128, 32>(g, s);
     else if (chain_slab_rows(rows, n0, n1) == 48) chain_launch_bwd<256, 48>(g, s);

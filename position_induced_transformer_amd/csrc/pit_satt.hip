@@ -486,8 +486,9 @@ extern "C" int pit_satt_fwd(const float* mesh, int mesh_batch, int n_pts, int sp
                             const float* values, long ld_values, long values_bstride, int batch, int dim,
                             const float* head, int n_head, int head_is_scale, unsigned short* x16,
                             float* out, long ld_out, long out_bstride, int out_col0, int copy_inputs,
-                            float* rowstat, float* scale_out, unsigned short* e_tiles, void* stream) {
+                            float* rowstat, float* scale_out, unsigned short* e_tiles, int x16_ready, void* stream) {
     if (!values || !head || !x16 || !out || !rowstat) return PIT_ERR_NULL;
+    if (x16_ready && copy_inputs) return PIT_ERR_UNSUPPORTED;                 // (the prep launch is also the concat's copy)
     if (e_tiles && !al16(e_tiles)) return PIT_ERR_SIZE;
     if (!pit_satt_supported(n_pts, n_head, dim, batch, mesh_batch) || space_dim < 1 || space_dim > 3) return PIT_ERR_UNSUPPORTED;
     if (ld_values % 4 || values_bstride % 4 || !al16(values) || !al16(x16) || !al16(rowstat) || (copy_inputs && (ld_out % 4 || out_bstride % 4 || !al16(out))))
@@ -500,8 +501,10 @@ extern "C" int pit_satt_fwd(const float* mesh, int mesh_batch, int n_pts, int sp
     p.mesh_batch = mesh_batch; p.dst = x16;
     if (copy_inputs) { p.copy_dst = out; p.copy_ld = ld_out; p.copy_bstride = out_bstride; }
     const long total = (long)batch * n_pts * (dim / 4);
-    hipLaunchKernelGGL(satt_prep_kernel, dim3((unsigned)std::min<long>((total + 255) / 256, 2048)), dim3(256), 0, s, p, 0);
-    PIT_CHECK_LAUNCH();
+    if (!x16_ready) {
+        hipLaunchKernelGGL(satt_prep_kernel, dim3((unsigned)std::min<long>((total + 255) / 256, 2048)), dim3(256), 0, s, p, 0);
+        PIT_CHECK_LAUNCH();
+    }
     g.head = head; g.head_is_scale = head_is_scale; g.b16 = x16; g.out = out; g.ld_out = ld_out; g.out_bstride = out_bstride;
     g.out_col0 = out_col0; g.rowstat = rowstat; g.scale_out = scale_out; g.e_out = e_tiles;
     dispatch_satt<0>(g, metric != PIT_METRIC_EUCLID, s);
@@ -517,7 +520,7 @@ extern "C" int pit_satt_bwd(const float* mesh, int mesh_batch, int n_pts, int sp
                             const unsigned short* x16, unsigned short* g16,
                             const float* d_out, long ld_dout, long dout_bstride, int out_col0,
                             float* d_values, long ld_dvalues, long dvalues_bstride, int add_residual,
-                            double* dscale, const unsigned short* e_tiles, void* stream) {
+                            double* dscale, const unsigned short* e_tiles, int g16_ready, void* stream) {
     if (!scale || !rowstat || !x16 || !g16 || !d_out || (!d_values && !dscale)) return PIT_ERR_NULL;
     if (e_tiles && !al16(e_tiles)) return PIT_ERR_SIZE;
     if (!pit_satt_supported(n_pts, n_head, dim, batch, mesh_batch) || space_dim < 1 || space_dim > 3) return PIT_ERR_UNSUPPORTED;
@@ -532,8 +535,10 @@ extern "C" int pit_satt_bwd(const float* mesh, int mesh_batch, int n_pts, int sp
         p.src = d_out; p.ld = ld_dout; p.bstride = dout_bstride; p.col0 = out_col0; p.batch = batch; p.L = n_pts; p.dim = dim; p.n_head = n_head;
         p.mesh_batch = mesh_batch; p.dst = g16; p.rowstat = rowstat;
         const long total = (long)batch * n_head * n_pts * (dim / 4);
-        hipLaunchKernelGGL(satt_prep_kernel, dim3((unsigned)std::min<long>((total + 255) / 256, 2048)), dim3(256), 0, s, p, 1);
-        PIT_CHECK_LAUNCH();
+        if (!g16_ready) {
+            hipLaunchKernelGGL(satt_prep_kernel, dim3((unsigned)std::min<long>((total + 255) / 256, 2048)), dim3(256), 0, s, p, 1);
+            PIT_CHECK_LAUNCH();
+        }
         g.b16 = g16; g.d_values = d_values; g.ld_dv = ld_dvalues; g.dv_bstride = dvalues_bstride; g.add_residual = add_residual;
         g.e_in = e_tiles;
         dispatch_satt<1>(g, metric != PIT_METRIC_EUCLID, s);

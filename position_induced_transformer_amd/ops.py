@@ -628,16 +628,17 @@ def _row_view(t: torch.Tensor) -> torch.Tensor:
 
 UNION_ATT = os.environ.get("PIT_UNION_ATT", "1") != "0"
 # bf16 mode: dense self-attention of hid 128 / 256 on csrc/pit_satt.hip.  "auto": where it measured faster than the fp32-era kernels
-# with rounded operands - layers of >= 512 points (Elasticity 972 x 256 x 2 heads: 114 us per layer against 191; NACA 728 x 128 x 1:
-# 65 against 70; Vorticity's 256 points: 46 against 47 with one launch more - DESIGN.md section 4 round 6); "1": every supported
-# shape; "0": never
+# with rounded operands - layers of >= 256 points (per layer, with the weight tiles and the operands written by the neighbouring MLP
+# chains: Elasticity 972 x 256 x 2 heads ~105 us against 191, NACA 728 x 128 x 1 ~55 against 70, Vorticity 256 x 256 x 2 ~36 against
+# 47 - DESIGN.md section 4 round 6; shorter layers: not measured); "1": every supported shape; "0": never
 SATT = os.environ.get("PIT_SATT", "auto")
 SATT_TILES = os.environ.get("PIT_SATT_TILES", "1") != "0"      # the forward keeps its weights as bf16 tiles for the backward
+SATT_FUSE_PREP = os.environ.get("PIT_SATT_FUSE_PREP", "1") != "0"      # the MLP chains either side write the bf16 operands (no prep launches)
 
 
 def _satt_pays(n_pts: int, n_head: int, d: int) -> bool:
     if SATT == "auto":
-        return n_pts >= 512
+        return n_pts >= 256
     return SATT not in ("0", "", False)
 
 
@@ -663,7 +664,7 @@ class _PosAtt(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, values, head, plan: MeshPlan, n_head: int, concat: bool, head_is_scale: bool,
-                head_param=None, out_slot=None, coord_dims: int = 0, scale_in=None, out_bf16: bool = False):
+                head_param=None, out_slot=None, coord_dims: int = 0, scale_in=None, out_bf16: bool = False, link=None):
         _need_gpu(values, head)
         ctx.math = _math_code()
         out_bf16 = bool(out_bf16 and not concat and plan.nbr_idx is not None and ctx.math == MATH_MODES["bf16"])
@@ -710,7 +711,11 @@ class _PosAtt(torch.autograd.Function):
                 and _lib.lib().pit_satt_supported(int(plan.n_in), int(n_head), int(d), int(b), int(plan.mesh_batch)):
             k_head, k_is_scale = (scale_in, True) if scale_in is not None else (head, head_is_scale)
             out = out_buf if out_buf is not None else torch.empty((b, plan.n_out, (n_head + 1) * d), device=values.device, dtype=torch.float32)
-            x16 = torch.empty((b, j, d), device=values.device, dtype=torch.bfloat16)
+            # (the producing MLP chain may already have written bf16(values): link["x16"] - then no prep launch)
+            x16 = link.get("x16") if (link is not None and out_buf is not None) else None
+            x16_ready = x16 is not None and tuple(x16.shape) == (b * j, d) and x16.dtype == torch.bfloat16 and x16.is_contiguous()
+            if not x16_ready:
+                x16 = torch.empty((b, j, d), device=values.device, dtype=torch.bfloat16)
             rowstat = torch.empty((plan.mesh_batch, n_head, plan.n_out, 4), device=values.device, dtype=torch.float32)
             scale = torch.empty((n_head,), device=values.device, dtype=torch.float32)
             # the forward's rounded weights, kept as MFMA A-fragment tiles for the backward's d(values) (2 MB per sample and head at
@@ -720,10 +725,16 @@ class _PosAtt(torch.autograd.Function):
             rc = _lib.lib().pit_satt_fwd(plan.mesh_in.data_ptr(), plan.mesh_batch, plan.n_in, plan.sdim, plan.metric_id, plan.period,
                                          values.data_ptr(), values.stride(1), values.stride(0), b, d, k_head.data_ptr(), n_head,
                                          1 if k_is_scale else 0, x16.data_ptr(), out.data_ptr(), out.stride(1), out.stride(0), d,
-                                         1 if out_buf is None else 0, rowstat.data_ptr(), scale.data_ptr(), _lib.ptr(et), _lib.stream_ptr())
+                                         1 if out_buf is None else 0, rowstat.data_ptr(), scale.data_ptr(), _lib.ptr(et),
+                                         1 if x16_ready else 0, _lib.stream_ptr())
             _lib.check(rc, "pit_satt_fwd")
             ctx.satt = x16
             ctx.satt_tiles = et
+            # what the consuming MLP chain's backward needs to write this layer's G16 beside its d_x (posatt_apply hangs it on `out`)
+            ctx.satt_link = link
+            if link is not None:
+                link.update(rowstat=rowstat, n_head=n_head, pts=int(j), mesh_batch=int(plan.mesh_batch), dim=int(d), batch=int(b), g16=None,
+                            dx_ptr=None)
             ctx.union = 0
             ctx.plan, ctx.n_head, ctx.concat, ctx.head_is_scale = plan, n_head, concat, head_is_scale
             ctx.head_param = head_param
@@ -807,14 +818,20 @@ class _PosAtt(torch.autograd.Function):
                 _dw_run(rider)
             if d_out.dtype != torch.float32 or d_out.stride(1) % 4 or d_out.stride(0) % 4 or d_out.data_ptr() % 16:
                 d_out = d_out.float().contiguous()
-            g16 = torch.empty((b, n_head, j, dv), device=values.device, dtype=torch.bfloat16)
+            lk = getattr(ctx, "satt_link", None)
+            g16 = lk.get("g16") if lk is not None else None
+            g16_ready = g16 is not None and lk.get("dx_ptr") == d_out.data_ptr() and tuple(g16.shape) == (b, n_head, j, dv)
+            if lk is not None:
+                lk["g16"] = None                         # (consumed)
+            if not g16_ready:
+                g16 = torch.empty((b, n_head, j, dv), device=values.device, dtype=torch.bfloat16)
             rc = _lib.lib().pit_satt_bwd(plan.mesh_in.data_ptr(), plan.mesh_batch, plan.n_in, plan.sdim, plan.metric_id, plan.period,
                                          b, dv, scale.data_ptr(), n_head, rowstat.data_ptr(), ctx.satt.data_ptr(), g16.data_ptr(),
                                          d_out.data_ptr(), d_out.stride(1), d_out.stride(0), dv,
                                          _lib.ptr(d_values), d_values.stride(1) if d_values is not None else 0,
                                          d_values.stride(0) if d_values is not None else 0, 1,
                                          work.data_ptr() if need_h else None, _lib.ptr(getattr(ctx, "satt_tiles", None)),
-                                         _lib.stream_ptr())
+                                         1 if g16_ready else 0, _lib.stream_ptr())
             _lib.check(rc, "pit_satt_bwd")
             if need_h:
                 flags = (1 if slot is not None else 0) | (4 if ctx.head_is_scale else 0)
@@ -822,7 +839,7 @@ class _PosAtt(torch.autograd.Function):
                     _defer_head_finish(work, d_head, head, scale, n_head, 1 | (4 if ctx.head_is_scale else 0))
                 else:
                     _finish_heads_now(work, d_head, head, scale, n_head, flags)
-            return d_values, (None if slot is not None else d_head), None, None, None, None, None, None, None, None, None
+            return d_values, (None if slot is not None else d_head), None, None, None, None, None, None, None, None, None, None
         if ctx.uatt is not None:                         # the union-tile backward: d_out read once, d(values) added from the tiles
             if rider is not None:
                 _dw_run(rider)
@@ -842,7 +859,7 @@ class _PosAtt(torch.autograd.Function):
                     _defer_head_finish(work, d_head, head, w.scale, n_head, 1 | (4 if ctx.head_is_scale else 0))
                 else:
                     _finish_heads_now(work, d_head, head, w.scale, n_head, flags)
-            return d_values, (None if slot is not None else d_head), None, None, None, None, None, None, None, None, None
+            return d_values, (None if slot is not None else d_head), None, None, None, None, None, None, None, None, None, None
 
         def launch(dv, dh, stream_ptr, job=None):
             rc = _lib.lib().pit_posatt_bwd(
@@ -864,7 +881,7 @@ class _PosAtt(torch.autograd.Function):
         launch(d_values, d_head, _lib.stream_ptr(), rider)
         if defer:
             _defer_head_finish(work, d_head, head, scale, n_head, 1 | (4 if ctx.head_is_scale else 0))
-        return d_values, (None if slot is not None else d_head), None, None, None, None, None, None, None, None, None
+        return d_values, (None if slot is not None else d_head), None, None, None, None, None, None, None, None, None, None
 
 
 # Where the head scale c = tan(0.25*pi*(1-1e-7)*(1+sin(lmda))) (pit.py:48) is evaluated.
@@ -1021,8 +1038,14 @@ def posatt_apply(values: torch.Tensor, lmda: torch.Tensor, plan: MeshPlan, n_hea
     slot = [out_buf] if out_buf is not None else None
     param = lmda if isinstance(lmda, torch.nn.Parameter) else None
     c = host_head_scale(lmda) if (not head_is_scale and get_head_scale_route() == "host") else None
-    return _PosAtt.apply(values, lmda.reshape(-1), plan, n_head, concat, head_is_scale, param, slot, coord_dims, c,
-                         out_bf16)
+    # the hand-offs between a dense self-attention layer on csrc/pit_satt.hip and the MLP chains either side of it (bf16 mode):
+    # bf16(values) from the producing chain, and - on the way back - G16 from the consuming chain's backward
+    link = {"x16": getattr(values, "_pit_x16", None)} if concat else None
+    out = _PosAtt.apply(values, lmda.reshape(-1), plan, n_head, concat, head_is_scale, param, slot, coord_dims, c,
+                        out_bf16, link)
+    if link is not None and link.get("rowstat") is not None:
+        out._pit_satt = link
+    return out
 
 
 # ---- one-launch MLP chains of the bf16 math mode (csrc/pit_chain.hip): hid 128 / 256 on a few thousand rows ----------------------
@@ -1098,7 +1121,7 @@ class _Mlp(torch.autograd.Function):
     """kaiming_mlp forward/backward, optionally with the trailing gelu of pit.py:111,121."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, out_gelu: bool, concat_heads: int = 0):
+    def forward(ctx, x, w1, b1, w2, b2, out_gelu: bool, concat_heads: int = 0, satt_link=None, y16_slot=None):
         _need_gpu(w1, b1, w2, b2)
         _need_gpu_bf16_ok(x)
         shape = x.shape
@@ -1132,11 +1155,15 @@ class _Mlp(torch.autograd.Function):
                 and _chain_weight_ok(w1) and _chain_weight_ok(w2):
             # bf16 mode, hid 128 / 256, a few thousand rows: GEMM1 + gelu + GEMM2 + gelu in ONE launch (csrc/pit_chain.hip)
             w1b, w2b = bf16_weights([w1, w2])
+            # (feeding a self-attention layer: bf16(y) beside y, so that pit_satt_fwd needs no prep launch)
+            y16 = torch.empty((rows, n2), device=dev, dtype=torch.bfloat16) if (y16_slot is not None and buf is not None and SATT_FUSE_PREP) else None
             rc = _lib.lib().pit_mlp_chain_fwd(x2.data_ptr(), x2.stride(0), rows, n0, n1, w1b.data_ptr(), b1c.data_ptr(),
                                               w2b.data_ptr(), b2c.data_ptr(), z1.data_ptr(), h.data_ptr(), z2.data_ptr(),
-                                              y.data_ptr(), y.stride(0), _lib.stream_ptr())
+                                              y.data_ptr(), y.stride(0), _lib.ptr(y16), _lib.stream_ptr())
             _lib.check(rc, "pit_mlp_chain_fwd")
             ctx.chain = (w1b, w2b)
+            if y16 is not None:
+                y16_slot.append(y16)
         else:
             rc = _lib.lib().pit_mlp_fwd(x2.data_ptr(), x2.stride(0), rows, n0, n1, n2, w1c.data_ptr(), b1c.data_ptr(),
                                         w2c.data_ptr(), b2c.data_ptr(), 1 if out_gelu else 0, z1.data_ptr(),
@@ -1144,6 +1171,7 @@ class _Mlp(torch.autograd.Function):
                                         _lib.stream_ptr())
             _lib.check(rc, "pit_mlp_fwd")
         ctx.out_gelu, ctx.dims, ctx.in_shape = out_gelu, (rows, n0, n1, n2), shape
+        ctx.satt_link = satt_link if ctx.chain is not None else None
         ctx.params = (w1, b1, w2, b2)
         ctx.save_for_backward(x2, w1c, w2c, z1, h, z2 if out_gelu else z1)
         out = y.reshape(*shape[:-1], n2)             # (a view: constant row stride)
@@ -1182,9 +1210,19 @@ class _Mlp(torch.autograd.Function):
         if ctx.chain is not None and d_y2.stride(0) % 4 == 0 and d_y2.data_ptr() % 16 == 0:
             # the data path (dZ2, dZ1, d_x) in ONE launch on the forward's bf16 weight copies, then both weight-gradient reductions
             w1b, w2b = ctx.chain
+            # x is a self-attention layer's concat buffer (csrc/pit_satt.hip): its backward's G16 = bf16(d_x_h / rowsum_h) is written here,
+            # beside d_x - that layer then needs no prep launch (it checks that the d_out it receives IS this d_x)
+            lk, g16 = ctx.satt_link, None
+            if (lk is not None and SATT_FUSE_PREP and d_x is not None and lk.get("rowstat") is not None and lk["dim"] == n1
+                    and (1 + lk["n_head"]) * n1 == n0 and lk["batch"] * lk["pts"] == rows):
+                g16 = torch.empty((lk["batch"], lk["n_head"], lk["pts"], n1), device=dev, dtype=torch.bfloat16)
             rc = L.pit_mlp_chain_bwd(rows, n0, n1, w1b.data_ptr(), w2b.data_ptr(), z1.data_ptr(), z2p, d_y2.data_ptr(),
-                                     d_y2.stride(0), _lib.ptr(d_x), n0, scratch.data_ptr(), _lib.stream_ptr())
+                                     d_y2.stride(0), _lib.ptr(d_x), n0, scratch.data_ptr(), _lib.ptr(g16),
+                                     lk["rowstat"].data_ptr() if g16 is not None else None, lk["pts"] if g16 is not None else 0,
+                                     lk["mesh_batch"] if g16 is not None else 0, _lib.stream_ptr())
             _lib.check(rc, "pit_mlp_chain_bwd")
+            if g16 is not None:
+                lk["g16"], lk["dx_ptr"] = g16, d_x.data_ptr()
             rc = L.pit_mlp_bwd_params(x2.data_ptr(), x2.stride(0), rows, n0, n1, n2, h.data_ptr(), og, d_y2.data_ptr(),
                                       d_y2.stride(0), d_w1.data_ptr(), d_b1.data_ptr(), d_w2.data_ptr(), d_b2.data_ptr(),
                                       1 if inplace else 0, scratch.data_ptr(), ctx.math, _lib.stream_ptr())
@@ -1213,8 +1251,8 @@ class _Mlp(torch.autograd.Function):
             _lib.check(rc, "pit_mlp_bwd")
         dx = d_x.reshape(ctx.in_shape) if need_x else None
         if inplace:
-            return dx, None, None, None, None, None, None
-        return dx, d_w1, d_b1, d_w2, d_b2, None, None
+            return dx, None, None, None, None, None, None, None, None
+        return dx, d_w1, d_b1, d_w2, d_b2, None, None, None, None
 
 
 @torch.compiler.disable
@@ -1223,10 +1261,14 @@ def mlp_apply(x, w1, b1, w2, b2, out_gelu: bool = False, concat_heads: int = 0) 
     self-attention layer with H heads: pit.py:116-121) makes the kernels write the result directly into the
     first columns of that layer's (b, L, (1+H)*n2) concat buffer; the returned tensor is that strided view and
     carries the buffer (``_pit_concat``), so the attention kernel skips copying its inputs (pit.py:44)."""
+    link = getattr(x, "_pit_satt", None)         # x is the output of a dense self-attention layer on csrc/pit_satt.hip
     if concat_heads <= 0 or x.dim() != 3:
-        return _Mlp.apply(x, w1, b1, w2, b2, out_gelu, 0)
-    y, buf = _Mlp.apply(x, w1, b1, w2, b2, out_gelu, int(concat_heads))
+        return _Mlp.apply(x, w1, b1, w2, b2, out_gelu, 0, link, None)
+    y16_slot = []
+    y, buf = _Mlp.apply(x, w1, b1, w2, b2, out_gelu, int(concat_heads), link, y16_slot)
     y._pit_concat = buf
+    if y16_slot:
+        y._pit_x16 = y16_slot[0]
     return y
 
 

@@ -424,7 +424,7 @@ def test_dense_self_attention_on_bf16_mfma_against_the_oracle(metric, batched, L
             out2.backward(d_out.cuda())
             assert calls["n"] == 2
             ops.SATT = "auto"
-            assert ops._satt_pays(972, 2, 256) and ops._satt_pays(728, 1, 128) and not ops._satt_pays(256, 2, 256)
+            assert ops._satt_pays(972, 2, 256) and ops._satt_pays(728, 1, 128) and ops._satt_pays(256, 2, 256) and not ops._satt_pays(128, 2, 256)
     finally:
         ops.SATT = saved
         L_.pit_satt_fwd = real
@@ -434,3 +434,59 @@ def test_dense_self_attention_on_bf16_mfma_against_the_oracle(metric, batched, L
     assert _rel(v1.grad, v0.grad) <= 2e-2
     assert float((l1.grad.cpu().reshape(-1) - l0.grad.reshape(-1)).norm()) <= 5e-2 * float(l0.grad.norm())
     assert _rel(out[..., dim:], out2[..., dim:]) <= 1e-2 and _rel(v1.grad, v2.grad) <= 1.5e-2
+
+
+def test_mlp_chains_write_the_self_attention_operands_and_the_prep_launches_go():
+    """Two processor blocks' worth of pit.py:114-122 in the bf16 mode - kaiming_mlp -> posatt.forward -> kaiming_mlp: the chain in front
+    writes bf16(y) beside y (pit_mlp_chain_fwd's y16 = pit_satt_fwd's x16), the chain behind writes G16 = bf16(d_x_h / rowsum_h) beside d_x
+    (pit_mlp_chain_bwd's g16 = pit_satt_bwd's) - the same bits the two prep launches would have produced, so results are IDENTICAL with
+    the hand-offs on and off; and the hand-offs are really taken (counted on the library entry points' flags)."""
+    from position_induced_transformer_amd import ops
+    torch.manual_seed(11)
+    b, L, d, H = 3, 640, 128, 2
+    mesh = torch.rand(b, L, 2).cuda()
+    plan = ops.MeshPlan("euclid", mesh, mesh, 1.0, True)
+    x0 = torch.randn(b, L, 3 * d).cuda()
+    lm = torch.rand(H, 1, 1).cuda()
+    ws = [(torch.randn(d, 3 * d).cuda() * 0.05, torch.randn(d).cuda() * 0.1, torch.randn(d, d).cuda() * 0.08, torch.randn(d).cuda() * 0.1) for _ in range(2)]
+    d_out = torch.randn(b, L, d).cuda()
+    L_ = ops._lib.lib()
+    real_f, real_b = L_.pit_satt_fwd, L_.pit_satt_bwd
+    seen = {"x16_ready": [], "g16_ready": []}
+
+    def fwd(*a):
+        seen["x16_ready"].append(int(a[-2]))
+        return real_f(*a)
+
+    def bwd(*a):
+        seen["g16_ready"].append(int(a[-2]))
+        return real_b(*a)
+
+    def run(fuse):
+        saved = ops.SATT, ops.SATT_FUSE_PREP
+        ops.SATT, ops.SATT_FUSE_PREP = "1", fuse
+        try:
+            with ops.math_mode("bf16"), ops.head_scale_route("host"):
+                x = x0.clone().requires_grad_(True)
+                l1 = lm.clone().requires_grad_(True)
+                p = [tuple(t.clone().requires_grad_(True) for t in w) for w in ws]
+                y = ops.mlp_apply(x, *p[0], out_gelu=True, concat_heads=H)
+                a = ops.posatt_apply(y, l1, plan, H, concat=True)
+                z = ops.mlp_apply(a, *p[1], out_gelu=True)
+                z.backward(d_out)
+                torch.cuda.synchronize()
+                return [z.detach(), x.grad, l1.grad] + [t.grad for w in p for t in w]
+        finally:
+            ops.SATT, ops.SATT_FUSE_PREP = saved
+
+    L_.pit_satt_fwd, L_.pit_satt_bwd = fwd, bwd
+    try:
+        on = run(True)
+        assert seen == {"x16_ready": [1], "g16_ready": [1]}
+        off = run(False)
+        assert seen == {"x16_ready": [1, 0], "g16_ready": [1, 0]}
+    finally:
+        L_.pit_satt_fwd, L_.pit_satt_bwd = real_f, real_b
+    assert torch.equal(on[0], off[0]) and torch.equal(on[1], off[1])             # prediction, d(input)
+    for u, v in zip(on[2:], off[2:]):                                            # (d(lmda), weight gradients: sums of atomic adds)
+        assert _rel(u, v) <= 1e-5
