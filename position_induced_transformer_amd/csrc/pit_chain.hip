@@ -233,8 +233,13 @@ __global__ __launch_bounds__(NT) void mlp_chain_bwd_kernel(ChainArgs g) {
     unsigned short* a2s = smem;                       // [CR][AP]  dZ2
     unsigned short* a1s = a2s + CR * AP;              // [CR][AP]  dZ1
     unsigned short* wp = a1s + CR * AP;               // [2][KP][WP]
+    float* ivs = reinterpret_cast<float*>(wp + 2 * KP * WP);     // [3][CR]  g16: 1 / rowsum of the slab's rows, per head (n0 <= 4 n1)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, kq = lane >> 4;
     const int row0 = (int)blockIdx.x * CR;
+    if (g.g16 && tid < (g.n0 / N1 - 1) * CR) {        // (read behind several barriers, in the dX epilogues)
+        const int hd = tid / CR, r = min(row0 + tid % CR, g.rows - 1), bb = r / g.pts, n = r - bb * g.pts;
+        ivs[tid] = g.rowstat[(((long)(g.mesh_batch == 1 ? 0 : bb) * (g.n0 / N1 - 1) + hd) * g.pts + n) * 4 + 2];
+    }
     constexpr int PW = N1 / KP;                       // panels per [N1 x N1] product (= NSETS)
     static_assert(PW == NSETS, "a product is one round of the panel pipeline");
     const int chunks = g.n0 / N1, np = PW * (1 + chunks);
@@ -340,7 +345,7 @@ __global__ __launch_bounds__(NT) void mlp_chain_bwd_kernel(ChainArgs g) {
                         const int r = row0 + 16 * rt + 4 * kq + i;
                         if (r >= g.rows) continue;
                         const int bb = r / g.pts, n = r - bb * g.pts;
-                        const float iv = g.rowstat[(((long)(g.mesh_batch == 1 ? 0 : bb) * nh + hd) * g.pts + n) * 4 + 2];
+                        const float iv = ivs[hd * CR + 16 * rt + 4 * kq + i];
                         unsigned short* dst = g.g16 + (((long)bb * nh + hd) * g.pts + n) * N1 + wave * NC + l15;
 #pragma unroll
                         for (int ct = 0; ct < CT; ++ct) dst[16 * ct] = f_to_bf16(acc[rt][ct][i] * iv);
@@ -374,7 +379,7 @@ bool chain_shape_ok(int rows, int n0, int n1, int n2) {
            (long)rows * n0 * 4 < (1L << 31) - 65536;
 }
 size_t chain_fwd_smem(int cr, int n0, int n1) { return (size_t)(cr * (std::max(n0, n1) + PADE) + 2 * n1 * (n1 / 4 + PADE)) * 2; }
-size_t chain_bwd_smem(int cr, int n1) { return (size_t)(2 * cr * (n1 + PADE) + 2 * (n1 / 4) * (n1 + PADE)) * 2; }
+size_t chain_bwd_smem(int cr, int n1) { return (size_t)(2 * cr * (n1 + PADE) + 2 * (n1 / 4) * (n1 + PADE)) * 2 + (size_t)3 * cr * 4; }
 // Rows per workgroup.  A hid-256 workgroup fills a CU's LDS (one per CU) and takes ~19 us whatever its height (its 0.5 MB of weights
 // at the rate one CU pulls from L2): Elasticity's 9 720 rows are 304 slabs of 32 = two rounds on 256 CUs (38 / 35 us measured), 203
 // slabs of 48 = one.  48 when that saves a round and the images still fit; hid 128 runs several workgroups per CU: 32.
