@@ -2378,7 +2378,11 @@ class _RelLpLoss(torch.autograd.Function):
 class _FusedLoss(torch.autograd.Function):
     """The loss node of a step whose decoder launches carry the loss (LossSpec): no launch in either direction.  The forward
     returns the scalar the decoder BACKWARD launch will write (a training step reads its loss after the pass); the backward hands
-    a token tensor down the graph that pit.decoder's backward recognises by its address - it reaches it through views only."""
+    a token tensor down the graph that pit.decoder's backward recognises by its address - it reaches it through views only.
+    THE RETURNED TENSOR IS VALID ONLY AFTER backward() HAS RUN: until then it is uninitialised memory (initialising it would be a
+    launch - the step has fourteen), so nothing may be derived from it in the forward (scaling, logging, a finite check).  Only
+    engine.TrainStep / ops.step_state(loss=...) open this path, and they read the loss after the pass; every other caller of
+    rel_lp_loss gets _RelLpLoss, whose value is computed in the forward."""
 
     @staticmethod
     def forward(ctx, pred, spec: LossSpec):
