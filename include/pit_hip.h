@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PIT_ABI_VERSION 21
+#define PIT_ABI_VERSION 22
 #define PIT_DSCALE_SLOTS 1024 /* fp64 accumulators per head in pit_posatt_bwd's workspace */
 
 /* distance metric (dist2att variants) */
@@ -384,19 +384,21 @@ int pit_union_att_bwd(const pit_slab_plan* plan, const float* values, long ld_va
  * = pit_linear_fwd(values, w = W1's memory read as an (n_head*dim, dim) row-major matrix) - no permuted copy of W1, and the weight
  * gradient of that Linear has W1.grad's layout.  For batch-free mesh pairs:
  *   pit_slab_plan_build(..., rows_per_slab = 64 | 128 | 256)  the plan (tall slabs: their unions must fit PIT_SLAB_UNION_MAX)
- *   pit_fold_weights   pw / qw (n_slabs*n_head, rows, um) for one step, as pit_decoder_weights
+ *   pit_fold_weights   pw / qw (n_slabs*n_head, rows, um) for one step, as pit_decoder_weights; pw16 / qw16 (optional): the same tiles
+ *                      rounded to bf16 - what pit_fold_att_fwd / _bwd take as pw / qw in the bf16 math mode
  *   pit_fold_att_fwd   z[b, n, c] = sum_h sum_j P_h[n][j] vw[b, j, c*n_head + h]        (fp32, or bf16 with PIT_IO_OUT_BF16)
  *   pit_fold_att_bwd   d_vw[b, j, c*n_head + h] += sum_n P_h[n][j] dz[b, n, c] (fp32 atomics, ZERO on entry; NULL: not needed),
  *                      d(scale) accumulators (PIT_HEAD_DEFER convention; NULL: not needed); dz bf16 with PIT_IO_DOUT_BF16
- * math_mode PIT_MATH_FP32: v_mfma_f32_16x16x4_f32; PIT_MATH_BF16: tiles rounded to bf16 in LDS, v_mfma_f32_16x16x32_bf16.
+ * math_mode PIT_MATH_FP32: v_mfma_f32_16x16x4_f32 on the fp32 pw / qw; PIT_MATH_BF16: pw / qw ARE pw16 / qw16 (a workgroup reads half the
+ * bytes per pass and rounds nothing), the value rows rounded to bf16 in LDS, v_mfma_f32_16x16x32_bf16.
  * dim a multiple of 64, n_head 1 or 2, every tensor below 2 GiB (pit_fold_supported). */
 int pit_fold_supported(int n_head, int dim, int batch, int rows_per_sample, int n_in);
 int pit_fold_weights(const pit_slab_plan* plan, const float* head, int head_is_scale, int n_head, int max_union, int max_count,
-                     float* pw, float* qw, float* scale_out, void* stream);
+                     float* pw, float* qw, float* scale_out, unsigned short* pw16, unsigned short* qw16, void* stream);
 int pit_fold_att_fwd(const pit_slab_plan* plan, const float* vw, long ld_vw, long vw_bstride, int batch, int n_head, int dim,
-                     const float* pw, void* z, long ld_z, long z_bstride, int max_union, int math_mode, void* stream);
+                     const void* pw, void* z, long ld_z, long z_bstride, int max_union, int math_mode, void* stream);
 int pit_fold_att_bwd(const pit_slab_plan* plan, const float* vw, long ld_vw, long vw_bstride, int batch, int n_head, int dim,
-                     const float* pw, const float* qw, const void* dz, long ld_dz, long dz_bstride,
+                     const void* pw, const void* qw, const void* dz, long ld_dz, long dz_bstride,
                      float* d_vw, long ld_dvw, long dvw_bstride, double* dscale,
                      float* tiles, const int* rev_ptr, const int* rev_ent, int max_union, int math_mode, void* stream);
 /* tiles != NULL (with d_vw): NO atomics - every (sample, slab) writes its sums into its own tile of `tiles` (batch, n_slabs,

@@ -78,7 +78,7 @@ SIGNATURES = {
     "pit_block_fwd": [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _L, _I, _P],
     "pit_slab_plan_build": [_P, _P, _I, _I, _I, _I, _F, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P],
     "pit_fold_supported": [_I, _I, _I, _I, _I],
-    "pit_fold_weights": [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P],
+    "pit_fold_weights": [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
     "pit_fold_att_fwd": [_P, _P, _L, _L, _I, _I, _I, _P, _P, _L, _L, _I, _I, _P],
     "pit_fold_att_bwd": [_P, _P, _L, _L, _I, _I, _I, _P, _P, _P, _L, _L, _P, _L, _L, _P, _P, _P, _P, _I, _I, _P],
     "pit_thin_tail_scratch_floats": [],
@@ -128,7 +128,7 @@ SIGNATURES = {
 }
 
 LONG_RETURN = {"pit_satt_tiles_elems"}
-ABI_VERSION = 21       # PIT_ABI_VERSION of include/pit_hip.h this binding was written against
+ABI_VERSION = 22       # PIT_ABI_VERSION of include/pit_hip.h this binding was written against
 
 _lib = None
 

@@ -161,6 +161,7 @@ struct DecWArgs {
     pit_slab_plan p;
     const float* head; int head_is_scale, n_head, um, lpr;
     float *pw, *qw, *scale_out;
+    unsigned short *pw16, *qw16;               // optional (pit_fold_weights, bf16 math mode): the same tiles rounded to bf16
     const float* w1; float* w1f; int dim;     // optional: the decoder MLP's W1 (dim, n_head*dim) copied in MFMA-fragment order
     int rb;                                   // rows per slab of the plan (16; pit_fold.hip: 64 / 128 / 256): a workgroup still forms 16 rows
 };
@@ -218,8 +219,11 @@ __device__ __forceinline__ void dec_weights_body(const DecWArgs& g, int slab, fl
         for (int e = 4 * tid; e < per; e += 4 * 256) {
             const int h = e / perh, r = e - h * perh;
             const long o = ((long)(blk * H + h) * g.rb + cg * ER) * um + r;
-            *reinterpret_cast<float4*>(g.pw + o) = *reinterpret_cast<const float4*>(tile + e);
-            if (g.qw) *reinterpret_cast<float4*>(g.qw + o) = *reinterpret_cast<const float4*>(tile + per + e);
+            const float4 pv4 = *reinterpret_cast<const float4*>(tile + e), qv4 = *reinterpret_cast<const float4*>(tile + per + e);
+            *reinterpret_cast<float4*>(g.pw + o) = pv4;
+            if (g.qw) *reinterpret_cast<float4*>(g.qw + o) = qv4;
+            if (g.pw16) *reinterpret_cast<uint2*>(g.pw16 + o) = make_uint2((unsigned)f_to_bf16(pv4.x) | ((unsigned)f_to_bf16(pv4.y) << 16), (unsigned)f_to_bf16(pv4.z) | ((unsigned)f_to_bf16(pv4.w) << 16));
+            if (g.qw16) *reinterpret_cast<uint2*>(g.qw16 + o) = make_uint2((unsigned)f_to_bf16(qv4.x) | ((unsigned)f_to_bf16(qv4.y) << 16), (unsigned)f_to_bf16(qv4.z) | ((unsigned)f_to_bf16(qv4.w) << 16));
         }
     }
     if (slab == 0 && tid < H && g.scale_out) g.scale_out[tid] = c[tid];
@@ -1279,7 +1283,7 @@ int fill_dec_weights(DecWArgs& g, const pit_slab_plan* plan, const float* head, 
 extern "C" int pit_decoder_weights(const pit_slab_plan* plan, const float* head, int head_is_scale, int n_head, int max_union,
                                    int max_count, float* pw, float* qw, float* scale_out, const float* w1, float* w1f, int dim,
                                    void* stream) {
-    DecWArgs g;
+    DecWArgs g = DecWArgs();
     if (int rc = fill_dec_weights(g, plan, head, head_is_scale, n_head, max_union, max_count, pw, qw, scale_out, w1, w1f, dim)) return rc;
     hipLaunchKernelGGL(decoder_weights_kernel, dim3((unsigned)plan->n_slabs), dim3(256), 0, (hipStream_t)stream, g);
     PIT_CHECK_LAUNCH();
@@ -1289,7 +1293,8 @@ extern "C" int pit_decoder_weights(const pit_slab_plan* plan, const float* head,
 // The same weights for a plan whose slabs are 64 / 128 / 256 rows tall (pit_fold.hip): a workgroup still forms 16 rows; head h's
 // rows of slab s are the `rows` x um block at pw + (s * n_head + h) * rows * um.
 extern "C" int pit_fold_weights(const pit_slab_plan* plan, const float* head, int head_is_scale, int n_head, int max_union,
-                                int max_count, float* pw, float* qw, float* scale_out, void* stream) {
+                                int max_count, float* pw, float* qw, float* scale_out, unsigned short* pw16, unsigned short* qw16,
+                                void* stream) {
     if (!plan || !plan->stats || !plan->idx || !plan->cnt || !plan->m || !plan->slot || !plan->keys || !plan->nkeys || !head || !pw)
         return PIT_ERR_NULL;
     if ((plan->rows != 64 && plan->rows != 128 && plan->rows != 256) || plan->umax != EU || plan->cap <= 0 || plan->cap > 64 ||
@@ -1299,7 +1304,7 @@ extern "C" int pit_fold_weights(const pit_slab_plan* plan, const float* head, in
     DecWArgs g = DecWArgs();
     g.p = *plan; g.head = head; g.head_is_scale = head_is_scale; g.n_head = n_head; g.um = union_slots(max_union);
     g.lpr = max_count <= 16 ? 16 : (max_count <= 32 ? 32 : 64);
-    g.pw = pw; g.qw = qw; g.scale_out = scale_out; g.rb = plan->rows;
+    g.pw = pw; g.qw = qw; g.scale_out = scale_out; g.rb = plan->rows; g.pw16 = pw16; g.qw16 = qw16;
     hipLaunchKernelGGL(decoder_weights_kernel, dim3((unsigned)(plan->n_slabs * (plan->rows / ER))), dim3(256), 0, (hipStream_t)stream, g);
     PIT_CHECK_LAUNCH();
     return 0;

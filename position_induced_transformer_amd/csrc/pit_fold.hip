@@ -127,6 +127,7 @@ struct FoldArgs {
     pit_slab_plan p; int um, batch, dim, chunks;
     const float* vw; long ld_vw, vw_bstride;             // (batch, n_in, dim * H), head-interleaved: column n * H + h = head h's value for output column n
     const float *pw, *qw;                                // (n_slabs * H, rows, um): the step's weights (pit_fold_weights)
+    const unsigned short *pw16, *qw16;                   // the same as bf16 (what the bf16 flavour reads: half the bytes per pass, nothing to round)
     void* z; long ld_z, z_bstride; int z16;              // forward: out (batch, n_out, dim)
     const void* dz; long ld_dz, dz_bstride; int dz16;    // backward: its gradient
     float* d_vw; long ld_dvw, dvw_bstride;               // backward: ADDED to (fp32 atomics), layout of vw - or, with `tiles`, written
@@ -211,6 +212,42 @@ __device__ __forceinline__ void wpark(typename Fl<BF>::T* tile, int pitch, const
         if (e < npc) Fl<BF>::put4(tile + (h * SR + row) * pitch + 4 * c4, r.v[u]);
     }
 }
+// the bf16 flavour's weight pass from the bf16 tiles of pit_fold_weights: 16-byte pieces of 8 weights, parked as they are
+typedef unsigned u32x4w_t __attribute__((ext_vector_type(4)));
+template <int H, int NT> struct WReq16 { u32x4w_t v[(H * SR * EU / 8 + NT - 1) / NT]; };
+template <int H, int NT>
+__device__ __forceinline__ void wreq16(const unsigned short* w, const FoldArgs& g, int slab, int sub, int tid, WReq16<H, NT>& r) {
+    const int perh = SR * g.um / 8, npc = H * perh;
+    const __amdgpu_buffer_rsrc_t rw = wide_rsrc(w);
+#pragma unroll
+    for (int u = 0; u < (H * SR * EU / 8 + NT - 1) / NT; ++u) {
+        const int e = tid + NT * u, h = e / perh, rem = e - h * perh;
+        const i32x4 q = __builtin_amdgcn_raw_buffer_load_b128(rw, (int)(e < npc ? (unsigned)((((long)(slab * H + h) * g.p.rows + sub * SR) * g.um + 8L * rem) * 2) : OOB), 0, 0);
+        r.v[u] = u32x4w_t{(unsigned)q.x, (unsigned)q.y, (unsigned)q.z, (unsigned)q.w};
+    }
+}
+template <int H, int NT>
+__device__ __forceinline__ void wpark16(unsigned short* tile, int pitch, const FoldArgs& g, int tid, const WReq16<H, NT>& r) {
+    const int um8 = g.um / 8, perh = SR * um8, npc = H * perh;
+#pragma unroll
+    for (int u = 0; u < (H * SR * EU / 8 + NT - 1) / NT; ++u) {
+        const int e = tid + NT * u, h = e / perh, rem = e - h * perh, row = rem / um8, c8 = rem - row * um8;
+        if (e < npc) *reinterpret_cast<u32x4w_t*>(tile + (h * SR + row) * pitch + 8 * c8) = r.v[u];
+    }
+}
+// one pass's weight request / park of either flavour (fp32 tiles -> fp32 LDS image; bf16 tiles -> bf16 LDS image)
+template <bool BF, int H, int NT> struct WPass { typedef WReq<H, NT> T; };
+template <int H, int NT> struct WPass<true, H, NT> { typedef WReq16<H, NT> T; };
+template <bool BF, int H, int NT>
+__device__ __forceinline__ void wrequest(const FoldArgs& g, bool q, int slab, int sub, int tid, typename WPass<BF, H, NT>::T& r) {
+    if constexpr (BF) wreq16<H, NT>(q ? g.qw16 : g.pw16, g, slab, sub, tid, r);
+    else wreq<H, NT>(q ? g.qw : g.pw, g, slab, sub, tid, r);
+}
+template <bool BF, int H, int NT>
+__device__ __forceinline__ void wstore(typename Fl<BF>::T* tile, int pitch, const FoldArgs& g, int tid, const typename WPass<BF, H, NT>::T& r) {
+    if constexpr (BF) wpark16<H, NT>(tile, pitch, g, tid, r);
+    else wpark<BF, H, NT>(tile, pitch, g, tid, r);
+}
 // zero the columns [um, umk) of a weight tile (bf16 flavour, um = 48: the k groups are 32 wide)
 template <bool BF, int H, int NT = 256>
 __device__ __forceinline__ void wpad(typename Fl<BF>::T* tile, int pitch, int um, int umk, int tid) {
@@ -261,17 +298,17 @@ __global__ __launch_bounds__(NT, 4) void fold_fwd_kernel(FoldArgs g) {
     const pit_slab_plan& p = g.p;
     const int nsub = p.rows / SR;
     const int nk = min(p.nkeys[slab], EU);
-    WReq<H, NT> wr;
-    wreq<H, NT>(g.pw, g, slab, 0, tid, wr);
+    typename WPass<BF, H, NT>::T wr;
+    wrequest<BF, H, NT>(g, false, slab, 0, tid, wr);
     stage_union<BF, H, NT>(g, b, slab, chunk, nk, umk, vt, tid);
     if (BF && umk != um) wpad<BF, H, NT>(pt, PP, um, umk, tid);
-    wpark<BF, H, NT>(pt, PP, g, tid, wr);
+    wstore<BF, H, NT>(pt, PP, g, tid, wr);
     __syncthreads();
     for (int sub = 0; sub < nsub; ++sub) {
         const int row0 = slab * p.rows + sub * SR;
         if (row0 >= p.n_out) break;                                  // (workgroup-uniform: the mesh ends inside this slab)
         const bool more = sub + 1 < nsub && row0 + SR < p.n_out;
-        if (more) wreq<H, NT>(g.pw, g, slab, sub + 1, tid, wr);     // next pass's weights fly under this pass's contraction
+        if (more) wrequest<BF, H, NT>(g, false, slab, sub + 1, tid, wr);     // next pass's weights fly under this pass's contraction
         constexpr int NRT = SR / 16 / (NT / 256);
         f32x4_t acc[NRT];
 #pragma unroll
@@ -301,7 +338,7 @@ __global__ __launch_bounds__(NT, 4) void fold_fwd_kernel(FoldArgs g) {
                 else *reinterpret_cast<float4*>(reinterpret_cast<float*>(g.z) + o) = v;
             }
         }
-        if (more) wpark<BF, H, NT>(pt, PP, g, tid, wr);
+        if (more) wstore<BF, H, NT>(pt, PP, g, tid, wr);
         __syncthreads();
     }
 }
@@ -338,16 +375,16 @@ __global__ __launch_bounds__(NTB, 4) void fold_bwd_kernel(FoldArgs g) {
     const int nk = min(p.nkeys[slab], EU);
     const bool want_scale = g.dscale != nullptr;
     const int akey = p.keys[(long)slab * p.umax + (tid & (EU - 1))];
-    WReq<H, NTB> pr, qr;
+    typename WPass<BF, H, NTB>::T pr, qr;
     DReq<NTB> dr;
-    wreq<H, NTB>(g.pw, g, slab, 0, tid, pr);
-    wreq<H, NTB>(g.qw, g, slab, 0, tid, qr);
+    wrequest<BF, H, NTB>(g, false, slab, 0, tid, pr);
+    wrequest<BF, H, NTB>(g, true, slab, 0, tid, qr);
     dreq<NTB>(g, b, slab, chunk, 0, tid, dr);
     if (!(PIT_FOLD_DBG & 16)) stage_union<BF, H, NTB>(g, b, slab, chunk, nk, umk, vt, tid);
     if (tid < EU) keys_s[tid] = akey;
     if (BF && umk != um) { wpad<BF, H, NTB>(pt, PP, um, umk, tid); wpad<BF, H, NTB>(qt, PP, um, umk, tid); }
-    wpark<BF, H, NTB>(pt, PP, g, tid, pr);
-    wpark<BF, H, NTB>(qt, PP, g, tid, qr);
+    wstore<BF, H, NTB>(pt, PP, g, tid, pr);
+    wstore<BF, H, NTB>(qt, PP, g, tid, qr);
     dpark<BF, NTB>(dt, tid, dr);
     __syncthreads();
     f32x4_t accT[NMT];
@@ -362,8 +399,8 @@ __global__ __launch_bounds__(NTB, 4) void fold_bwd_kernel(FoldArgs g) {
         if (row0 >= p.n_out) break;
         const bool more = sub + 1 < nsub && row0 + SR < p.n_out;
         if (more && !(PIT_FOLD_DBG & 8)) {
-            wreq<H, NTB>(g.pw, g, slab, sub + 1, tid, pr);
-            wreq<H, NTB>(g.qw, g, slab, sub + 1, tid, qr);
+            wrequest<BF, H, NTB>(g, false, slab, sub + 1, tid, pr);
+            wrequest<BF, H, NTB>(g, true, slab, sub + 1, tid, qr);
             dreq<NTB>(g, b, slab, chunk, sub + 1, tid, dr);
         }
         // d(VW_h)[slot][col] += sum_rows P_h[row][slot] dZ[row][col]
@@ -394,8 +431,8 @@ __global__ __launch_bounds__(NTB, 4) void fold_bwd_kernel(FoldArgs g) {
         }
         __syncthreads();
         if (more && !(PIT_FOLD_DBG & 8)) {
-            wpark<BF, H, NTB>(pt, PP, g, tid, pr);
-            wpark<BF, H, NTB>(qt, PP, g, tid, qr);
+            wstore<BF, H, NTB>(pt, PP, g, tid, pr);
+            wstore<BF, H, NTB>(qt, PP, g, tid, qr);
             dpark<BF, NTB>(dt, tid, dr);
         }
         __syncthreads();
@@ -696,8 +733,9 @@ unsigned fold_grid(const FoldArgs& g) { return (unsigned)(8 * ((g.p.n_slabs + 7)
 }  // namespace
 
 extern "C" int pit_fold_att_fwd(const pit_slab_plan* plan, const float* vw, long ld_vw, long vw_bstride, int batch, int n_head, int dim,
-                                const float* pw, void* z, long ld_z, long z_bstride, int max_union, int math_mode, void* stream) {
+                                const void* pw_, void* z, long ld_z, long z_bstride, int max_union, int math_mode, void* stream) {
     FoldArgs g;
+    const float* pw = reinterpret_cast<const float*>(pw_);
     if (int rc = fold_fill(g, plan, vw, ld_vw, vw_bstride, batch, n_head, dim, pw, max_union)) return rc;
     if (!z) return PIT_ERR_NULL;
     const int mode = math_mode & 0xff, z16 = (math_mode & PIT_IO_OUT_BF16) ? 1 : 0;
@@ -705,6 +743,7 @@ extern "C" int pit_fold_att_fwd(const pit_slab_plan* plan, const float* vw, long
     if (ld_z % 4 || z_bstride % 4 || (reinterpret_cast<uintptr_t>(z) & (z16 ? 7 : 15)) || ld_z < dim) return PIT_ERR_SIZE;
     g.z = z; g.ld_z = ld_z; g.z_bstride = z_bstride; g.z16 = z16;
     const bool bf = mode == PIT_MATH_BF16;
+    if (bf) g.pw16 = reinterpret_cast<const unsigned short*>(pw);            // (bf16 math mode: pw IS pit_fold_weights' bf16 tile tensor)
     const size_t sm = fold_smem(n_head, bf, g.um, false);
     const dim3 grid(fold_grid(g));
     hipStream_t s = (hipStream_t)stream;
@@ -715,11 +754,12 @@ extern "C" int pit_fold_att_fwd(const pit_slab_plan* plan, const float* vw, long
 }
 
 extern "C" int pit_fold_att_bwd(const pit_slab_plan* plan, const float* vw, long ld_vw, long vw_bstride, int batch, int n_head, int dim,
-                                const float* pw, const float* qw, const void* dz, long ld_dz, long dz_bstride,
+                                const void* pw_, const void* qw_, const void* dz, long ld_dz, long dz_bstride,
                                 float* d_vw, long ld_dvw, long dvw_bstride, double* dscale,
                                 float* tiles, const int* rev_ptr, const int* rev_ent,
                                 int max_union, int math_mode, void* stream) {
     FoldArgs g;
+    const float *pw = reinterpret_cast<const float*>(pw_), *qw = reinterpret_cast<const float*>(qw_);
     if (int rc = fold_fill(g, plan, vw, ld_vw, vw_bstride, batch, n_head, dim, pw, max_union)) return rc;
     if (!qw || !dz || (!d_vw && !dscale)) return PIT_ERR_NULL;
     const int mode = math_mode & 0xff, dz16 = (math_mode & PIT_IO_DOUT_BF16) ? 1 : 0;
@@ -734,6 +774,7 @@ extern "C" int pit_fold_att_bwd(const pit_slab_plan* plan, const float* vw, long
         g.tiles = tiles; g.rev_ptr = rev_ptr; g.rev_ent = rev_ent;
     }
     const bool bf = mode == PIT_MATH_BF16;
+    if (bf) { g.pw16 = reinterpret_cast<const unsigned short*>(pw); g.qw16 = reinterpret_cast<const unsigned short*>(qw); }
     const size_t sm = fold_smem(n_head, bf, g.um, true);
     const dim3 grid(fold_grid(g));
     hipStream_t s = (hipStream_t)stream;

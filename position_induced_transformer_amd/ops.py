@@ -1981,7 +1981,7 @@ class _Linear(torch.autograd.Function):
 
 class FoldWeights:
     """The softmax weights of one step on a fold plan (pit_fold_weights): pw / qw (n_slabs*H, rows, um), the head scales c."""
-    __slots__ = ("pw", "qw", "scale", "keep")
+    __slots__ = ("pw", "qw", "scale", "keep", "pw16", "qw16")
 
 
 def _new_fold_weights(plan: MeshPlan, head, scale_in, n_head: int, head_is_scale: bool, need_q: bool) -> FoldWeights:
@@ -1994,8 +1994,14 @@ def _new_fold_weights(plan: MeshPlan, head, scale_in, n_head: int, head_is_scale
     w.scale = torch.empty((n_head,), device=dev, dtype=torch.float32)
     k_head = scale_in if scale_in is not None else head
     w.keep = (k_head, plan, sp)
+    # bf16 math mode: the fold launches read the tiles as bf16 (every workgroup of every sample and column chunk used to round the
+    # same fp32 tiles on their way into LDS; now half the bytes per pass and nothing to round)
+    bf = _math_code() == MATH_MODES["bf16"]
+    w.pw16 = torch.empty((sp.n_slabs * n_head, sp.rows, um), device=dev, dtype=torch.bfloat16) if bf else None
+    w.qw16 = torch.empty((sp.n_slabs * n_head, sp.rows, um), device=dev, dtype=torch.bfloat16) if (bf and need_q) else None
     rc = _lib.lib().pit_fold_weights(ctypes.byref(sp), k_head.data_ptr(), 1 if (scale_in is not None or head_is_scale) else 0, n_head,
-                                     max_union, max_count, w.pw.data_ptr(), _lib.ptr(w.qw), w.scale.data_ptr(), _lib.stream_ptr())
+                                     max_union, max_count, w.pw.data_ptr(), _lib.ptr(w.qw), w.scale.data_ptr(), _lib.ptr(w.pw16),
+                                     _lib.ptr(w.qw16), _lib.stream_ptr())
     _lib.check(rc, "pit_fold_weights")
     return w
 
@@ -2030,7 +2036,8 @@ class _FoldAtt(torch.autograd.Function):
         w = _new_fold_weights(plan, head, scale_in, n_head, head_is_scale, need_q)
         sp, max_union = plan.fold_plan()[0], plan.fold_plan()[1]
         z = torch.empty((b, plan.n_out, d), device=vw.device, dtype=torch.bfloat16 if out_bf16 else torch.float32)
-        rc = _lib.lib().pit_fold_att_fwd(ctypes.byref(sp), vw.data_ptr(), vw.stride(1), vw.stride(0), b, n_head, d, w.pw.data_ptr(),
+        rc = _lib.lib().pit_fold_att_fwd(ctypes.byref(sp), vw.data_ptr(), vw.stride(1), vw.stride(0), b, n_head, d,
+                                         (w.pw16 if w.pw16 is not None else w.pw).data_ptr(),
                                          z.data_ptr(), z.stride(1), z.stride(0), max_union,
                                          ctx.math | (IO_OUT_BF16 if out_bf16 else 0), _lib.stream_ptr())
         _lib.check(rc, "pit_fold_att_fwd")
@@ -2073,8 +2080,9 @@ class _FoldAtt(torch.autograd.Function):
         if rider is not None:
             _dw_run(rider)
         sp, max_union = plan.fold_plan()[0], plan.fold_plan()[1]
-        qw = w.qw if w.qw is not None else w.pw       # (read only for d(scale))
-        rc = _lib.lib().pit_fold_att_bwd(ctypes.byref(sp), vw.data_ptr(), vw.stride(1), vw.stride(0), b, n_head, d, w.pw.data_ptr(),
+        pw = w.pw16 if w.pw16 is not None else w.pw    # (bf16 math mode: the bf16 tiles)
+        qw = (w.qw16 if w.qw16 is not None else pw) if w.pw16 is not None else (w.qw if w.qw is not None else w.pw)      # (read only for d(scale))
+        rc = _lib.lib().pit_fold_att_bwd(ctypes.byref(sp), vw.data_ptr(), vw.stride(1), vw.stride(0), b, n_head, d, pw.data_ptr(),
                                          qw.data_ptr(), dz.data_ptr(), dz.stride(1), dz.stride(0),
                                          _lib.ptr(d_vw), hd, j * hd, _lib.ptr(work), _lib.ptr(tiles), _lib.ptr(rev_ptr),
                                          _lib.ptr(rev_ent), max_union, ctx.math | io, _lib.stream_ptr())
