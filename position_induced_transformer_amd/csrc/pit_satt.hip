@@ -9,10 +9,16 @@
 //   * a wavefront owns 16 rows x ALL columns (16 accumulator tiles at hid 256): the softmax weights exp(-c m) of its rows - formed
 //     in registers directly in the A-fragment layout of v_mfma_f32_16x16x32_bf16, 8 keys per lane and step, from key coordinates
 //     staged once per workgroup - are amortised over the whole row, no cross-wave reduction, both heads against the same value tile;
-//   * forward (MODE 0): O_h = (E_h X) / rowsum_h, rowsum and mbar = sum_j P m from the fp32 weights; backward d(values) (MODE 1):
-//     E is symmetric, so d(values) = residual + sum_h E_h G_h is the same contraction with both heads accumulating into ONE set of
-//     tiles; d(scale) (MODE 2): -(sum G_h . (E_h (m - mbar_h)) X), fp64 partial sums into the layer's slots.
-// Distances, c, rowsum, mbar and the d(scale) reduction stay fp32 / fp64; only MFMA operands are bf16.  The fp32 mode never comes here.
+//   * forward (MODE 0): O_h = (E_h X) / rowsum_h, rowsum and mbar = sum_j P m from the fp32 weights - and the ROUNDED weights stay behind
+//     as A-fragment tiles ([mesh sample][head][16-row tile][32-key step][lane][8] bf16: pit_satt_tiles_elems);
+//   * backward d(values) (MODE 1): E is symmetric, so d(values) = residual + sum_h E_h G_h is the same contraction with both heads
+//     accumulating into ONE set of tiles - on the forward's tiles (PRE): 16 bytes per lane and step instead of eight weights formed, and
+//     what is left of a step is its B tiles arriving from L2 (128-row workgroups, RT = 2, halve that stream);
+//   * d(scale) (MODE 2): -(sum G_h . (E_h (m - mbar_h)) X), operand = tile x (m - mbar) (PRE) or formed from scratch, fp64 partial sums
+//     into the layer's slots.
+// The values' bf16 copy (x16) and G16 = bf16(dO_h / rowsum_h) come from the MLP chains either side of the layer (pit_chain.hip) or, for a
+// first layer, from satt_prep_kernel.  Distances, c, rowsum, mbar and the d(scale) reduction stay fp32 / fp64; only MFMA operands are
+// bf16.  The fp32 mode never comes here.
 #include "pit_common.h"
 #include "pit_block_dev.h"
 
