@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PIT_ABI_VERSION 22
+#define PIT_ABI_VERSION 23
 #define PIT_DSCALE_SLOTS 1024 /* fp64 accumulators per head in pit_posatt_bwd's workspace */
 
 /* distance metric (dist2att variants) */
@@ -477,6 +477,8 @@ int pit_posatt_pre_bwd(const float* e, const float* q, const float* rowstat, int
  *                 g16: scratch of batch*n_head*n_pts*dim bf16.
  *   x16_ready / g16_ready: the caller's x16 / g16 already hold bf16(values) / bf16(d_out_h / rowsum_h) - written by the producing
  *                 pit_mlp_chain_fwd (y16) / pit_mlp_chain_bwd (g16): no prep launch (x16_ready needs copy_inputs = 0).
+ *   rider (pit_satt_bwd, optional): the postponed weight-gradient reductions of the MLP whose backward produced d_out (pit_posatt_bwd's
+ *                 convention): carried as extra workgroups of the one backward launch, or run as pit_mlp_bwd_params would.
  *   e_tiles (optional, NULL: none): (mesh_batch, n_head, pit_satt_tiles_elems(n_pts)) bf16 - the forward leaves its rounded weights there
  *                 in MFMA A-fragment order and pit_satt_bwd's d(values) (the same, symmetric, matrix) reads them instead of forming
  *                 every weight again.
@@ -492,7 +494,7 @@ int pit_satt_bwd(const float* mesh, int mesh_batch, int n_pts, int space_dim, in
                  const unsigned short* x16, unsigned short* g16,
                  const float* d_out, long ld_dout, long dout_bstride, int out_col0,
                  float* d_values, long ld_dvalues, long dvalues_bstride, int add_residual, double* dscale,
-                 const unsigned short* e_tiles, int g16_ready, void* stream);
+                 const unsigned short* e_tiles, int g16_ready, const pit_mlp_params_job* rider, void* stream);
 long pit_satt_tiles_elems(int n_pts);
 
 /* kaiming_mlp.forward (pit.py:21-26): y = W2 * gelu_erf(W1 x + b1) + b2, optionally

@@ -86,7 +86,7 @@ SIGNATURES = {
     "pit_thin_tail_bwd": [_P, _L, _I, _I, _I, _P, _P, _P, _L, _P, _L, _P, _P, _P, _P, _I, _P],
     "pit_satt_supported": [_I, _I, _I, _I, _I],
     "pit_satt_fwd": [_P, _I, _I, _I, _I, _F, _P, _L, _L, _I, _I, _P, _I, _I, _P, _P, _L, _L, _I, _I, _P, _P, _P, _I, _P],
-    "pit_satt_bwd": [_P, _I, _I, _I, _I, _F, _I, _I, _P, _I, _P, _P, _P, _P, _L, _L, _I, _P, _L, _L, _I, _P, _P, _I, _P],
+    "pit_satt_bwd": [_P, _I, _I, _I, _I, _F, _I, _I, _P, _I, _P, _P, _P, _P, _L, _L, _I, _P, _L, _L, _I, _P, _P, _I, _P, _P],
     "pit_satt_tiles_elems": [_I],
     "pit_mlp_chain_supported": [_I, _I, _I, _I],
     "pit_mlp_chain_fwd": [_P, _L, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _P],
@@ -128,7 +128,7 @@ SIGNATURES = {
 }
 
 LONG_RETURN = {"pit_satt_tiles_elems"}
-ABI_VERSION = 22       # PIT_ABI_VERSION of include/pit_hip.h this binding was written against
+ABI_VERSION = 23       # PIT_ABI_VERSION of include/pit_hip.h this binding was written against
 
 _lib = None
 

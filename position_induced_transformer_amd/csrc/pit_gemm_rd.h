@@ -56,6 +56,9 @@ constexpr int RR_BK = 64;
 // launch)
 // `allow_rr`: the caller's kernel runs rr1 / rr2 reductions through gemm_rr_tile (>= 64 KiB of LDS, >= 4 waves)
 bool plan_dw_pair(const pit_mlp_params_job& job, int waves, DwPair* out, int target_wgs = 768, bool allow_rr = false);
+// both reductions as gemm_rr_tile tiles (fp32 or - bf16 math mode - bf16 MFMA operands) for a carrying launch that has 64 KiB of LDS
+// and at least four waves (pit_satt.hip's backward launch): any size, `budget_wgs` workgroups in all
+bool plan_rr_rider(const pit_mlp_params_job& job, DwPair* out, int budget_wgs);
 
 }  // namespace pit_detail
 
@@ -410,6 +413,19 @@ __device__ __forceinline__ void rr_rider(const pit_detail::GemmArgs& g, int id, 
     const int kbeg = (int)((long)slab * nchunks / slabs) * pit_detail::RR_BK;
     const int kend = min(g.K, (int)((long)(slab + 1) * nchunks / slabs) * pit_detail::RR_BK);
     gemm_rr_tile<1, 1, pit_detail::RR_BK, false>(g, tile % tx, tile / tx, kbeg, kend, smem, smem + 2 * pit_detail::RR_BK * 64);
+}
+// workgroup `id` of a plan_rr_rider pair (both reductions are tiles; bf16 MFMA operands when the job's math mode says so)
+__device__ __forceinline__ void rr_rider_pair(const pit_detail::DwPair& w, int id, float* smem) {
+    if (threadIdx.x >= 256) return;
+    const bool second = id >= w.n1;
+    if (second) id -= w.n1;
+    const GemmArgs& g = second ? w.g2 : w.g1;
+    const int tx = second ? w.tx2 : w.tx1, tiles = second ? w.tiles2 : w.tiles1, slabs = second ? w.slabs2 : w.slabs1;
+    const int slab = id / tiles, tile = id % tiles;
+    const int kbeg = (int)((long)slab * w.nchunks / slabs) * pit_detail::RR_BK;
+    const int kend = min(g.K, (int)((long)(slab + 1) * w.nchunks / slabs) * pit_detail::RR_BK);
+    if (g.bf16) gemm_rr_tile<1, 1, pit_detail::RR_BK, true>(g, tile % tx, tile / tx, kbeg, kend, smem, smem + 2 * pit_detail::RR_BK * 64);
+    else gemm_rr_tile<1, 1, pit_detail::RR_BK, false>(g, tile % tx, tile / tx, kbeg, kend, smem, smem + 2 * pit_detail::RR_BK * 64);
 }
 // workgroup `id` of a carried pair of weight-gradient reductions; `smem`: the launch's dynamic LDS (64 KiB when the plan
 // allowed rr reductions, see plan_dw_pair)

@@ -1699,6 +1699,40 @@ bool pit_detail::plan_dw_pair(const pit_mlp_params_job& j, int waves, DwPair* ou
     return true;
 }
 
+// the reductions of a postponed pit_mlp_bwd_params as gemm_rr_tile tiles for pit_satt.hip's backward launch: the chain MLPs' dW1 | dW2
+// (Vorticity: 17 us as a launch of their own between the MLP's backward and the attention's, which does not depend on them)
+bool pit_detail::plan_rr_rider(const pit_mlp_params_job& j, DwPair* out, int budget_wgs) {
+    static const bool off = exp_env("PIT_NO_DW_RIDER") != nullptr;
+    if (off || !j.accumulate) return false;
+    if (!j.x || !j.h || !j.d_y || !j.d_w1 || !j.d_b1 || !j.d_w2 || !j.d_b2 || !j.scratch) return false;
+    if (j.rows <= 0 || j.n0 <= 0 || j.n1 <= 0 || j.n2 <= 0 || (j.out_gelu && j.ld_dy != j.n2)) return false;
+    const float* dz2 = j.out_gelu ? j.scratch + (long)j.rows * j.n1 : j.d_y;
+    const long ld_dz2 = j.out_gelu ? j.n2 : j.ld_dy;
+    *out = DwPair();
+    out->g1 = make_dw2(dz2, ld_dz2, j.h, j.rows, j.n1, j.n2, j.d_w2, j.d_b2);
+    out->g2 = make_dw1(j.scratch, j.x, j.ldx, j.rows, j.n0, j.n1, j.d_w1, j.d_b1);
+    const int saved = t_call_math;
+    t_call_math = j.math_mode;
+    GemmLaunch L1, L2;
+    const bool ok = prepare_gemm(out->g1, L1, 1, 4, 768) == 0 && prepare_gemm(out->g2, L2, 1, 4, 768) == 0;
+    t_call_math = saved;
+    if (!ok || !gemm_rr_ok(out->g1) || !gemm_rr_ok(out->g2)) return false;
+    auto tiles_of = [](const GemmArgs& g, int& tx) {
+        const int n_real = g.ones_col >= 0 ? g.N - 1 : g.N;
+        tx = (n_real + 63) / 64;
+        return tx * ((g.M + 63) / 64);
+    };
+    out->tiles1 = tiles_of(out->g1, out->tx1);
+    out->tiles2 = tiles_of(out->g2, out->tx2);
+    out->nchunks = (j.rows + RR_BK - 1) / RR_BK;
+    const int slabs = std::max(1, std::min(std::max(1, out->nchunks / 2), budget_wgs / (out->tiles1 + out->tiles2)));
+    out->rr1 = out->rr2 = 1;
+    out->slabs1 = out->slabs2 = slabs;
+    out->n1 = out->tiles1 * slabs;
+    out->n2 = out->tiles2 * slabs;
+    return true;
+}
+
 // include/pit_hip.h: the shapes whose forward / backward run entirely on the kernels that honour the PIT_IO_* flags (the
 // thin output-layer kernels + gemm_bfl_kernel)
 extern "C" int pit_mlp_bf16_io_supported(int rows, int n0, int n1, int n2, int out_gelu) {

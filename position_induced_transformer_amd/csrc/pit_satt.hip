@@ -21,6 +21,8 @@
 // bf16.  The fp32 mode never comes here.
 #include "pit_common.h"
 #include "pit_block_dev.h"
+#include "pit_gemm_rd.h"
+#include <cstdlib>
 
 namespace {
 
@@ -105,7 +107,7 @@ constexpr int satt_width(int H, int DIM, int MODE) { return (MODE == 1 && H == 2
 // of formed, what is left of a step is the B-tile stream - 24 KB per workgroup and step from L2, and the CUs that held two 64-row
 // workgroups pulled 53 GB/s, a CU's practical L2 rate: 0.9 us per step.  128 rows per workgroup = half the workgroups = half the bytes.
 template <int H, int DIM, int MODE, bool PERIODIC, bool PRE = false, int RT = 1>
-__global__ __launch_bounds__(256 * RT, 2) void satt_kernel(SattArgs g) {
+__device__ __forceinline__ void satt_body(const SattArgs& g, const int bid) {
     static_assert(!PRE || MODE != 0, "the backward reads the forward's weight tiles");
     constexpr int NT = 256 * RT;
     constexpr bool PRE1 = PRE && MODE == 1;    // d(values): the tiles ARE the A operand
@@ -118,11 +120,11 @@ __global__ __launch_bounds__(256 * RT, 2) void satt_kernel(SattArgs g) {
                                                                                // weights of step s + 1 are formed in step s, unconditionally)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, kq = lane >> 4;
     int b, t;
-    const int hsel = (MODE == 1) ? 0 : (int)blockIdx.x % H;                    // this workgroup's head (MODE 0 / 2)
+    const int hsel = (MODE == 1) ? 0 : bid % H;                                // this workgroup's head (MODE 0 / 2)
     // (consecutive ids - dealt to the XCDs in turn - walk the tiles of a sample: with a sample pinned to one XCD, ten samples put two
     // on XCDs 0 and 1 and one workgroup per CU made that a second round)
-    const int cs = (MODE == 1) ? (int)blockIdx.x % NCS : 0;                    // this workgroup's column half (MODE 1, two heads)
-    if (!slab_of_linear((MODE == 1) ? (int)blockIdx.x / NCS : (int)blockIdx.x / H, g.batch, (g.tiles + RT - 1) / RT, b, t)) return;
+    const int cs = (MODE == 1) ? bid % NCS : 0;                                // this workgroup's column half (MODE 1, two heads)
+    if (!slab_of_linear((MODE == 1) ? bid / NCS : bid / H, g.batch, (g.tiles + RT - 1) / RT, b, t)) return;
     const int mb = g.mesh_batch == 1 ? 0 : b;
     const int row = t * 64 * RT + wave * 16 + l15;                             // the A-fragment row of this lane
     const int rowc = row < g.L ? row : g.L - 1;
@@ -331,7 +333,7 @@ __global__ __launch_bounds__(256 * RT, 2) void satt_kernel(SattArgs g) {
             st.x = 3.0e38f; st.y = 0.0f; st.z = inv; st.w = sm * inv;
             *reinterpret_cast<float4*>(g.rowstat + (((long)mb * H + hsel) * g.L + row) * 4) = st;
         }
-        if (blockIdx.x < H && tid == 0 && g.scale_out) g.scale_out[hsel] = c[0];
+        if (bid < H && tid == 0 && g.scale_out) g.scale_out[hsel] = c[0];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const float iv = __shfl(inv, 4 * kq + i, 64);
@@ -383,9 +385,25 @@ __global__ __launch_bounds__(256 * RT, 2) void satt_kernel(SattArgs g) {
         {
             double tot = 0.0;
             for (int w = 0; w < NT / 64; ++w) tot += wred[w];
-            atomicAdd(g.dscale + (long)hsel * PIT_DSCALE_SLOTS + (((int)blockIdx.x / H) & (PIT_DSCALE_SLOTS - 1)), -tot);
+            atomicAdd(g.dscale + (long)hsel * PIT_DSCALE_SLOTS + ((bid / H) & (PIT_DSCALE_SLOTS - 1)), -tot);
         }
     }
+}
+
+template <int H, int DIM, int MODE, bool PERIODIC, bool PRE = false, int RT = 1>
+__global__ __launch_bounds__(256 * RT, 2) void satt_kernel(SattArgs g) {
+    satt_body<H, DIM, MODE, PERIODIC, PRE, RT>(g, (int)blockIdx.x);
+}
+// the backward of a layer in ONE launch (both on the forward's tiles): workgroups [0, n1) are d(values), the rest d(scale) - the two
+// are independent, a few hundred latency-bound workgroups each, and merged they share the chip instead of running back to back
+// ... and, behind them, the weight-gradient reductions of the MLP whose backward produced this layer's d_out (`rider`: tiles of
+// gemm_rr_tile; they depend on that MLP's backward only, and used to be a launch of their own in front of this one)
+template <int H, int DIM, bool PERIODIC, int RT>
+__global__ __launch_bounds__(256 * RT, 2) void satt_bwd_kernel(SattArgs g1, SattArgs g2, int n1, int n_att, pit_detail::DwPair w) {
+    const int bid = (int)blockIdx.x;
+    if (bid >= n_att) { rr_rider_pair(w, bid - n_att, pit_dyn_smem()); return; }
+    if (bid < n1) satt_body<H, DIM, 1, false, true, RT>(g1, bid);
+    else satt_body<H, DIM, 2, PERIODIC, true, RT>(g2, bid - n1);
 }
 
 // X16 = bf16(values[:, :, 0:dim]) (+ the concat's copy of the inputs), G16_h = bf16(d_out_h / rowsum_h): elementwise, 4 columns per thread
@@ -455,6 +473,25 @@ void launch_satt(const SattArgs& g, int periodic, hipStream_t s) {
     else PIT_SATT_GO((satt_kernel<H, DIM, MODE, false>), 1);
 #undef PIT_SATT_GO
 }
+template <int H, int DIM>
+void launch_satt_bwd(const SattArgs& g1, const SattArgs& g2, int periodic, const pit_detail::DwPair& w, hipStream_t s) {
+    constexpr int RT = (H == 2 && DIM == 256) ? 2 : 1;
+    const int tiles = (g1.tiles + RT - 1) / RT;
+    const int n1 = g1.batch * tiles * (DIM / satt_width(H, DIM, 1)), n2 = g1.batch * tiles * H, n_att = n1 + n2, n_r = w.n1 + w.n2;
+    const size_t sm = std::max(std::max(satt_smem(g1.L, satt_width(H, DIM, 1), H), satt_smem(g1.L, DIM, 1)), (size_t)(n_r ? 65536 : 0));
+#define PIT_SATT_GO2(K_) do {                                                                                          \
+        static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(K_), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024), true); \
+        (void)once;                                                                                                   \
+        hipLaunchKernelGGL(K_, dim3((unsigned)(n_att + n_r)), dim3(256 * RT), sm, s, g1, g2, n1, n_att, w);            \
+    } while (0)
+    if (periodic) PIT_SATT_GO2((satt_bwd_kernel<H, DIM, true, RT>));
+    else PIT_SATT_GO2((satt_bwd_kernel<H, DIM, false, RT>));
+#undef PIT_SATT_GO2
+}
+void dispatch_satt_bwd(const SattArgs& g1, const SattArgs& g2, int periodic, const pit_detail::DwPair& w, hipStream_t s) {
+    if (g1.n_head == 1) { if (g1.dim == 128) launch_satt_bwd<1, 128>(g1, g2, periodic, w, s); else launch_satt_bwd<1, 256>(g1, g2, periodic, w, s); }
+    else { if (g1.dim == 128) launch_satt_bwd<2, 128>(g1, g2, periodic, w, s); else launch_satt_bwd<2, 256>(g1, g2, periodic, w, s); }
+}
 template <int MODE>
 void dispatch_satt(const SattArgs& g, int periodic, hipStream_t s) {
     if (g.n_head == 1) { if (g.dim == 128) launch_satt<1, 128, MODE>(g, periodic, s); else launch_satt<1, 256, MODE>(g, periodic, s); }
@@ -518,6 +555,13 @@ extern "C" int pit_satt_fwd(const float* mesh, int mesh_batch, int n_pts, int sp
     return 0;
 }
 
+namespace {
+int run_rider(const pit_mlp_params_job* r, void* stream) {      // (the launches pit_mlp_bwd_params would have made)
+    return pit_mlp_bwd_params(r->x, r->ldx, r->rows, r->n0, r->n1, r->n2, r->h, r->out_gelu, r->d_y, r->ld_dy, r->d_w1, r->d_b1, r->d_w2,
+                              r->d_b2, r->accumulate, const_cast<float*>(r->scratch), r->math_mode, stream);
+}
+}  // namespace
+
 // Backward: d_values[b, j, :] = (add_residual ? d_out[b, j, 0:dim] : 0) + sum_h sum_n P_h[n, j] d_out[b, n, out_col0 + h*dim + :] (NULL: not
 // needed) and the layer's d(scale) accumulators (PIT_HEAD_DEFER convention; NULL: not needed).  scale: the c of the forward; x16: the
 // forward's; g16: scratch of batch*n_head*n_pts*dim bf16.
@@ -526,7 +570,8 @@ extern "C" int pit_satt_bwd(const float* mesh, int mesh_batch, int n_pts, int sp
                             const unsigned short* x16, unsigned short* g16,
                             const float* d_out, long ld_dout, long dout_bstride, int out_col0,
                             float* d_values, long ld_dvalues, long dvalues_bstride, int add_residual,
-                            double* dscale, const unsigned short* e_tiles, int g16_ready, void* stream) {
+                            double* dscale, const unsigned short* e_tiles, int g16_ready, const pit_mlp_params_job* rider,
+                            void* stream) {
     if (!scale || !rowstat || !x16 || !g16 || !d_out || (!d_values && !dscale)) return PIT_ERR_NULL;
     if (e_tiles && !al16(e_tiles)) return PIT_ERR_SIZE;
     if (!pit_satt_supported(n_pts, n_head, dim, batch, mesh_batch) || space_dim < 1 || space_dim > 3) return PIT_ERR_UNSUPPORTED;
@@ -536,6 +581,8 @@ extern "C" int pit_satt_bwd(const float* mesh, int mesh_batch, int n_pts, int sp
     hipStream_t s = (hipStream_t)stream;
     g.head = scale; g.head_is_scale = 1; g.rowstat_r = rowstat; g.d_out = d_out; g.ld_dout = ld_dout; g.dout_bstride = dout_bstride;
     g.out_col0 = out_col0;
+    static const bool split = getenv("PIT_SATT_SPLIT_BWD") != nullptr;          // (A/B: the two launches)
+    const bool merged = d_values && dscale && e_tiles && !split;
     if (d_values) {
         PrepArgs p = PrepArgs();
         p.src = d_out; p.ld = ld_dout; p.bstride = dout_bstride; p.col0 = out_col0; p.batch = batch; p.L = n_pts; p.dim = dim; p.n_head = n_head;
@@ -547,9 +594,24 @@ extern "C" int pit_satt_bwd(const float* mesh, int mesh_batch, int n_pts, int sp
         }
         g.b16 = g16; g.d_values = d_values; g.ld_dv = ld_dvalues; g.dv_bstride = dvalues_bstride; g.add_residual = add_residual;
         g.e_in = e_tiles;
+        if (merged) {
+            SattArgs g2 = g;
+            g2.b16 = x16; g2.dscale = dscale;
+            pit_detail::DwPair w = pit_detail::DwPair();
+            // (carried where the launch's workgroups are four wavefronts: NACA 1.027 -> 1.007 ms; in the eight-wavefront launches of two heads
+            // x hid 256 the tiles' workgroups idle half their waves and compete for the L2 stream: Elasticity 1.153 -> 1.189, Vorticity
+            // 0.731 -> 0.742 - there the reductions stay a launch of their own)
+            const bool riding = rider && !(n_head == 2 && dim == 256) && pit_detail::plan_rr_rider(*rider, &w, 256);
+            if (!riding) w = pit_detail::DwPair();
+            dispatch_satt_bwd(g, g2, metric != PIT_METRIC_EUCLID, w, s);
+            PIT_CHECK_LAUNCH();
+            return (rider && !riding) ? run_rider(rider, stream) : 0;
+        }
+        if (rider) { if (int rc = run_rider(rider, stream)) return rc; rider = nullptr; }
         dispatch_satt<1>(g, metric != PIT_METRIC_EUCLID, s);
         PIT_CHECK_LAUNCH();
     }
+    if (rider) { if (int rc = run_rider(rider, stream)) return rc; }
     if (dscale) {
         g.b16 = x16; g.dscale = dscale; g.e_in = e_tiles;
         dispatch_satt<2>(g, metric != PIT_METRIC_EUCLID, s);

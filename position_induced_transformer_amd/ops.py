@@ -634,6 +634,7 @@ UNION_ATT = os.environ.get("PIT_UNION_ATT", "1") != "0"
 SATT = os.environ.get("PIT_SATT", "auto")
 SATT_TILES = os.environ.get("PIT_SATT_TILES", "1") != "0"      # the forward keeps its weights as bf16 tiles for the backward
 SATT_FUSE_PREP = os.environ.get("PIT_SATT_FUSE_PREP", "1") != "0"      # the MLP chains either side write the bf16 operands (no prep launches)
+SATT_DW_RIDER = os.environ.get("PIT_SATT_DW_RIDER", "1") != "0"        # the consuming MLP's dW / db reductions ride in the layer's backward launch
 
 
 def _satt_pays(n_pts: int, n_head: int, d: int) -> bool:
@@ -814,8 +815,12 @@ class _PosAtt(torch.autograd.Function):
         rider = None if (plan.nbr_idx is not None and _dw_pending_rows(values.device) >= BIG_RIDER_ROWS) \
             else _dw_take(values.device)
         if getattr(ctx, "satt", None) is not None:       # dense self-attention on bf16 MFMA (csrc/pit_satt.hip)
+            job = None
             if rider is not None:
-                _dw_run(rider)
+                if SATT_DW_RIDER:
+                    job = rider                          # (carried by the backward launch below; `rider[1]` keeps its tensors alive)
+                else:
+                    _dw_run(rider)
             if d_out.dtype != torch.float32 or d_out.stride(1) % 4 or d_out.stride(0) % 4 or d_out.data_ptr() % 16:
                 d_out = d_out.float().contiguous()
             lk = getattr(ctx, "satt_link", None)
@@ -831,7 +836,7 @@ class _PosAtt(torch.autograd.Function):
                                          _lib.ptr(d_values), d_values.stride(1) if d_values is not None else 0,
                                          d_values.stride(0) if d_values is not None else 0, 1,
                                          work.data_ptr() if need_h else None, _lib.ptr(getattr(ctx, "satt_tiles", None)),
-                                         1 if g16_ready else 0, _lib.stream_ptr())
+                                         1 if g16_ready else 0, ctypes.byref(job[0]) if job is not None else None, _lib.stream_ptr())
             _lib.check(rc, "pit_satt_bwd")
             if need_h:
                 flags = (1 if slot is not None else 0) | (4 if ctx.head_is_scale else 0)
@@ -1223,10 +1228,18 @@ class _Mlp(torch.autograd.Function):
             _lib.check(rc, "pit_mlp_chain_bwd")
             if g16 is not None:
                 lk["g16"], lk["dx_ptr"] = g16, d_x.data_ptr()
-            rc = L.pit_mlp_bwd_params(x2.data_ptr(), x2.stride(0), rows, n0, n1, n2, h.data_ptr(), og, d_y2.data_ptr(),
-                                      d_y2.stride(0), d_w1.data_ptr(), d_b1.data_ptr(), d_w2.data_ptr(), d_b2.data_ptr(),
-                                      1 if inplace else 0, scratch.data_ptr(), ctx.math, _lib.stream_ptr())
-            _lib.check(rc, "pit_mlp_bwd_params")
+            if lk is not None and inplace and SATT_DW_RIDER and lk.get("rowstat") is not None:
+                # the weight-gradient reductions depend on this launch only: they ride in the attention layer's ONE backward launch
+                # (pit_satt_bwd's rider) instead of standing between the two
+                st = _lib.MlpParamsJob(x2.data_ptr(), x2.stride(0), rows, n0, n1, n2, h.data_ptr(), og, d_y2.data_ptr(),
+                                       d_y2.stride(0), d_w1.data_ptr(), d_b1.data_ptr(), d_w2.data_ptr(), d_b2.data_ptr(),
+                                       1, scratch.data_ptr(), ctx.math)
+                _dw_defer(st, (x2, h, d_y2, scratch, d_w1, d_b1, d_w2, d_b2), dev)
+            else:
+                rc = L.pit_mlp_bwd_params(x2.data_ptr(), x2.stride(0), rows, n0, n1, n2, h.data_ptr(), og, d_y2.data_ptr(),
+                                          d_y2.stride(0), d_w1.data_ptr(), d_b1.data_ptr(), d_w2.data_ptr(), d_b2.data_ptr(),
+                                          1 if inplace else 0, scratch.data_ptr(), ctx.math, _lib.stream_ptr())
+                _lib.check(rc, "pit_mlp_bwd_params")
         elif MLP_PARAMS_RIDER and inplace and _dw_deferrable(rows, n0, n1, n2, og, d_y2.stride(0)):
             # dZ2, dZ1 and d_x now; the weight-gradient reductions ride along with the next attention backward
             rc = L.pit_mlp_bwd_data(rows, n0, n1, n2, w1.data_ptr(), w2.data_ptr(), z1.data_ptr(), z2p, og,

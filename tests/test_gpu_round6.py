@@ -462,7 +462,7 @@ def test_mlp_chains_write_the_self_attention_operands_and_the_prep_launches_go()
         return real_f(*a)
 
     def bwd(*a):
-        seen["g16_ready"].append(int(a[-2]))
+        seen["g16_ready"].append(int(a[-3]))
         return real_b(*a)
 
     def run(fuse):
