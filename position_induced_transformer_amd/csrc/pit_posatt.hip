@@ -1523,10 +1523,27 @@ __global__ __launch_bounds__(512) void posatt_cols_tiles(AttArgs a) {
 
 // the same merge for 2 / 4 column tiles per workgroup (bigger layers: Elasticity, Vorticity), without
 // the register cap - these bodies need their registers, one workgroup per CU
+// (round 6: ... and, behind the attention workgroups, the weight-gradient reductions of the MLP that produced d_out as gemm_rr_tile
+// tiles - `w` from plan_rr_rider; they used to be a launch of their own between that MLP's backward and this one, which does not
+// depend on them; the first four waves of such a workgroup run the tile, in the math mode of the kernel)
 template <int CT, bool MASKED, bool BF, bool IL = false>
 __global__ __launch_bounds__(512) void posatt_bwd_pair_wide_kernel(AttArgs ar, AttArgs ac, int n_cols_wgs, int cgx, int cgy,
-                                                                    int rgx, int rgy) {
+                                                                    int rgx, int rgy, int n_att, pit_detail::DwPair w) {
     int id = blockIdx.x;
+    if (id >= n_att) {
+        if (threadIdx.x >= 256) return;
+        id -= n_att;
+        const bool second = id >= w.n1;
+        if (second) id -= w.n1;
+        const GemmArgs& g = second ? w.g2 : w.g1;
+        const int tx = second ? w.tx2 : w.tx1, tiles = second ? w.tiles2 : w.tiles1, slabs = second ? w.slabs2 : w.slabs1;
+        const int slab = id / tiles, tile = id % tiles;
+        const int kbeg = (int)((long)slab * w.nchunks / slabs) * pit_detail::RR_BK;
+        const int kend = min(g.K, (int)((long)(slab + 1) * w.nchunks / slabs) * pit_detail::RR_BK);
+        float* smem = pit_dyn_smem();
+        gemm_rr_tile<1, 1, pit_detail::RR_BK, BF>(g, tile % tx, tile / tx, kbeg, kend, smem, smem + 2 * pit_detail::RR_BK * 64);
+        return;
+    }
     if (id < n_cols_wgs) {
         posatt_cols_body<CT, MASKED, BF, 0, IL>(ac, id % cgx, (id / cgx) % cgy, id / (cgx * cgy));
     } else {
@@ -1805,18 +1822,36 @@ bool launch_bwd_pair(const AttArgs& a0, hipStream_t s, const pit_mlp_params_job*
         static bool once = ((void)hipFuncSetAttribute((const void*)posatt_bwd_pair_wide_kernel<CT_, M_, BF_>,       \
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 98304), true);    \
         (void)once;                                                                                           \
-        hipLaunchKernelGGL((posatt_bwd_pair_wide_kernel<CT_, M_, BF_>), grid, block, sm, s, ar, ac, (int)cols_wgs, \
-                           ac.colgroups, j_tiles, a0.mesh_batch * ar.colgroups, a0.n_head);                   \
+        hipLaunchKernelGGL((posatt_bwd_pair_wide_kernel<CT_, M_, BF_>), wgrid, block, wsm, s, ar, ac, (int)cols_wgs, \
+                           ac.colgroups, j_tiles, a0.mesh_batch * ar.colgroups, a0.n_head, (int)(rows_wgs + cols_wgs), wdw); \
     } while (0)
 #define PIT_PAIR_IL(M_, BF_)                                                                                  \
     do {                                                                                                      \
         static bool once = ((void)hipFuncSetAttribute((const void*)posatt_bwd_pair_wide_kernel<4, M_, BF_, true>,   \
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 98304), true);    \
         (void)once;                                                                                           \
-        hipLaunchKernelGGL((posatt_bwd_pair_wide_kernel<4, M_, BF_, true>), grid, block, sm, s, ar, ac, (int)cols_wgs, \
-                           ac.colgroups, j_tiles, a0.mesh_batch * ar.colgroups, a0.n_head);                   \
+        hipLaunchKernelGGL((posatt_bwd_pair_wide_kernel<4, M_, BF_, true>), wgrid, block, wsm, s, ar, ac, (int)cols_wgs, \
+                           ac.colgroups, j_tiles, a0.mesh_batch * ar.colgroups, a0.n_head, (int)(rows_wgs + cols_wgs), wdw); \
     } while (0)
     const bool il = ct == 4 && interleave_ok(a0, 1) && interleave_ok(a0, 2);
+    // the wide kernels (four or eight waves, 96 KiB of LDS allowed) carry the job as gemm_rr_tile tiles whatever its size; the tiles contract in
+    // the kernel's math mode, which is the job's
+    pit_detail::DwPair wdw = pit_detail::DwPair();
+    dim3 wgrid = grid;
+    size_t wsm = sm;
+    static const bool no_wide_rider = getenv("PIT_NO_WIDE_DW_RIDER") != nullptr;
+    // (... while the attention itself is latency-bound: same-box A/B per fp32 step, carried / own launch - NACA 728 points x hid 128
+    // 1.419 / 1.465 ms, Vorticity 256 x 256 x 2 heads 1.219 / 1.231, Elasticity 972 x 256 x 2 2.460 / 2.393: there the attention
+    // workgroups run the fp32 matrix pipe at 62 % and the tiles compete for it)
+    const double att_work = (double)a0.n_out * a0.n_in * a0.ncols * a0.n_head * a0.mesh_batch;
+    if (job && rider_done && ct != 1 && nwaves >= 4 && !no_wide_rider && att_work <= 2.5e9 && ((job->math_mode & 0xff) == PIT_MATH_BF16) == (a0.bf16 != 0) &&
+        pit_detail::plan_rr_rider(*job, &wdw, 256)) {
+        wgrid = dim3((unsigned)(rows_wgs + cols_wgs + wdw.n1 + wdw.n2));
+        wsm = std::max(sm, (size_t)65536);
+        *rider_done = true;
+    } else {
+        wdw = pit_detail::DwPair();
+    }
 #define PIT_PAIR_CT(M_, BF_) do { if (ct == 1) PIT_PAIR_K(M_, BF_); else if (ct == 2) PIT_PAIR_W(2, M_, BF_); else if (il) PIT_PAIR_IL(M_, BF_); else PIT_PAIR_W(4, M_, BF_); } while (0)
     if (a0.masked) { if (a0.bf16) PIT_PAIR_CT(true, true); else PIT_PAIR_CT(true, false); }
     else { if (a0.bf16) PIT_PAIR_CT(false, true); else PIT_PAIR_CT(false, false); }

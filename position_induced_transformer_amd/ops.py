@@ -635,6 +635,7 @@ SATT = os.environ.get("PIT_SATT", "auto")
 SATT_TILES = os.environ.get("PIT_SATT_TILES", "1") != "0"      # the forward keeps its weights as bf16 tiles for the backward
 SATT_FUSE_PREP = os.environ.get("PIT_SATT_FUSE_PREP", "1") != "0"      # the MLP chains either side write the bf16 operands (no prep launches)
 SATT_DW_RIDER = os.environ.get("PIT_SATT_DW_RIDER", "1") != "0"        # the consuming MLP's dW / db reductions ride in the layer's backward launch
+WIDE_DW_RIDER = os.environ.get("PIT_WIDE_DW_RIDER", "1") != "0"        # the same for dense layers on posatt_bwd_pair_wide_kernel (fp32 mode, large regime)
 
 
 def _satt_pays(n_pts: int, n_head: int, d: int) -> bool:
@@ -1050,6 +1051,8 @@ def posatt_apply(values: torch.Tensor, lmda: torch.Tensor, plan: MeshPlan, n_hea
                         out_bf16, link)
     if link is not None and link.get("rowstat") is not None:
         out._pit_satt = link
+    elif concat and plan.self_attn and not plan.masked and plan.nbr_idx is None and not coord_dims:
+        out._pit_dense_att = True                # (the MLP behind it may postpone its weight-gradient reductions for this layer's backward)
     return out
 
 
@@ -1126,7 +1129,7 @@ class _Mlp(torch.autograd.Function):
     """kaiming_mlp forward/backward, optionally with the trailing gelu of pit.py:111,121."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, out_gelu: bool, concat_heads: int = 0, satt_link=None, y16_slot=None):
+    def forward(ctx, x, w1, b1, w2, b2, out_gelu: bool, concat_heads: int = 0, satt_link=None, y16_slot=None, after_dense_att: bool = False):
         _need_gpu(w1, b1, w2, b2)
         _need_gpu_bf16_ok(x)
         shape = x.shape
@@ -1177,6 +1180,7 @@ class _Mlp(torch.autograd.Function):
             _lib.check(rc, "pit_mlp_fwd")
         ctx.out_gelu, ctx.dims, ctx.in_shape = out_gelu, (rows, n0, n1, n2), shape
         ctx.satt_link = satt_link if ctx.chain is not None else None
+        ctx.after_dense_att = bool(after_dense_att)
         ctx.params = (w1, b1, w2, b2)
         ctx.save_for_backward(x2, w1c, w2c, z1, h, z2 if out_gelu else z1)
         out = y.reshape(*shape[:-1], n2)             # (a view: constant row stride)
@@ -1253,6 +1257,21 @@ class _Mlp(torch.autograd.Function):
                                    d_y2.stride(0), d_w1.data_ptr(), d_b1.data_ptr(), d_w2.data_ptr(), d_b2.data_ptr(),
                                    1, scratch.data_ptr(), 0)
             _dw_defer(st, (x2, h, d_y2, scratch, d_w1, d_b1, d_w2, d_b2), dev)
+        elif (WIDE_DW_RIDER and inplace and ctx.after_dense_att and not ctx.x16 and rows >= 1024 and n1 >= 128 and n1 % 64 == 0
+              and n2 % 64 == 0 and n0 % 64 == 0 and (not og or d_y2.stride(0) == n2)):
+            # x is the output of a dense self-attention layer (pit.py:116-121): the same split in the large regime - the reductions
+            # (gemm_rr_kernel: 20-44 us between this MLP's backward and the attention's, which does not depend on them) ride in the
+            # attention layer's merged backward launch as tiles (pit_posatt_bwd's rider -> posatt_bwd_pair_wide_kernel); a layer
+            # that takes other kernels runs them as the launch they were.  (hid 128 / 256: at hid 64 the fused call's data path is the
+            # slab kernel of csrc/pit_mlp_slab.hip, which pit_mlp_bwd_data does not take - Darcy b=256 159 k -> 151 k samples/s)
+            rc = L.pit_mlp_bwd_data(rows, n0, n1, n2, w1.data_ptr(), w2.data_ptr(), z1.data_ptr(), z2p, og,
+                                    d_y2.data_ptr(), d_y2.stride(0), _lib.ptr(d_x), n0, scratch.data_ptr(),
+                                    ctx.math, _lib.stream_ptr())
+            _lib.check(rc, "pit_mlp_bwd_data")
+            st = _lib.MlpParamsJob(x2.data_ptr(), x2.stride(0), rows, n0, n1, n2, h.data_ptr(), og, d_y2.data_ptr(),
+                                   d_y2.stride(0), d_w1.data_ptr(), d_b1.data_ptr(), d_w2.data_ptr(), d_b2.data_ptr(),
+                                   1, scratch.data_ptr(), ctx.math)
+            _dw_defer(st, (x2, h, d_y2, scratch, d_w1, d_b1, d_w2, d_b2), dev)
         else:
             # one call: dZ1, then dX and both weight-gradient reductions (merged into one launch when small)
             # (small regime: fp32 in every math mode, like the postponed form above - the two must agree)
@@ -1264,8 +1283,8 @@ class _Mlp(torch.autograd.Function):
             _lib.check(rc, "pit_mlp_bwd")
         dx = d_x.reshape(ctx.in_shape) if need_x else None
         if inplace:
-            return dx, None, None, None, None, None, None, None, None
-        return dx, d_w1, d_b1, d_w2, d_b2, None, None, None, None
+            return dx, None, None, None, None, None, None, None, None, None
+        return dx, d_w1, d_b1, d_w2, d_b2, None, None, None, None, None
 
 
 @torch.compiler.disable
@@ -1275,10 +1294,11 @@ def mlp_apply(x, w1, b1, w2, b2, out_gelu: bool = False, concat_heads: int = 0) 
     first columns of that layer's (b, L, (1+H)*n2) concat buffer; the returned tensor is that strided view and
     carries the buffer (``_pit_concat``), so the attention kernel skips copying its inputs (pit.py:44)."""
     link = getattr(x, "_pit_satt", None)         # x is the output of a dense self-attention layer on csrc/pit_satt.hip
+    dense = bool(getattr(x, "_pit_dense_att", False))      # ... or of one on the fp32-era kernels (posatt_apply)
     if concat_heads <= 0 or x.dim() != 3:
-        return _Mlp.apply(x, w1, b1, w2, b2, out_gelu, 0, link, None)
+        return _Mlp.apply(x, w1, b1, w2, b2, out_gelu, 0, link, None, dense)
     y16_slot = []
-    y, buf = _Mlp.apply(x, w1, b1, w2, b2, out_gelu, int(concat_heads), link, y16_slot)
+    y, buf = _Mlp.apply(x, w1, b1, w2, b2, out_gelu, int(concat_heads), link, y16_slot, dense)
     y._pit_concat = buf
     if y16_slot:
         y._pit_x16 = y16_slot[0]
