@@ -2792,7 +2792,10 @@ __global__ __launch_bounds__(512, (NH == 1 && EPL == 8) ? 4 : 2) void posatt_uni
                     }
                 }
             }
-            // ---- the block's sums to memory: accumulator i of tile mt = slot sp0 + 16 mt + 4 q + i, this lane's column
+            // ---- the block's sums to memory: accumulator i of tile mt = slot sp0 + 16 mt + 4 q + i, this lane's column.  (Round 6: the
+            // same sums through LDS, 64 slots at a time, so that a wavefront's atomic instruction adds 256 contiguous bytes of one key row
+            // - what made pit_fold.hip's epilogue - measured 163 against 145 us here: six more barriers per range, and the adds no longer
+            // trickle out while other waves still contract.)
             if (cvalid) {
                 float* gcol = a.d_values + (long)cb * a.dvalues_bstride + cd;
 #pragma unroll
