@@ -28,6 +28,10 @@ constexpr int NT = 512;      // threads: eight waves, wave w owns rows x columns
 constexpr int NSETS = 4;     // weight panels in flight in registers (first version: one, 256 threads - every panel waited a full L2
                              // round trip behind 16 MFMAs: 27.7 / 23.6 us per launch where the two-GEMM path took 25.4 / 32.8)
 
+#ifndef PIT_CHAIN_DBG
+#define PIT_CHAIN_DBG 0      // diagnostic builds of mlp_chain_fwd_kernel: 1 no X slab loads, 2 no output stores, 4 no MFMAs, 8 no panel loads
+                             // in the loop (results are void, times are not)
+#endif
 struct ChainArgs {
     int rows, n0, n1;
     const float* x; long ldx;
@@ -138,14 +142,15 @@ __global__ __launch_bounds__(NT) void mlp_chain_fwd_kernel(ChainArgs g) {
     do {                                                                                                              \
         __syncthreads();                                                                                              \
         fwd_panel_park<N1>(wp + (((p_) + 1) & 1) * N1 * WP, tid, reg[((j_) + 1) % NSETS]);                            \
-        PIT_CHAIN_LOAD((p_) + 1 + NSETS, ((j_) + 1) % NSETS);                                                          \
+        if (!(PIT_CHAIN_DBG & 8)) PIT_CHAIN_LOAD((p_) + 1 + NSETS, ((j_) + 1) % NSETS);                                \
         const unsigned short* wb_ = wp + ((p_) & 1) * N1 * WP;                                                        \
+        if (!(PIT_CHAIN_DBG & 4))                                                                                     \
         _Pragma("unroll") for (int ks = 0; ks < KP / 32; ++ks) {                                                      \
             v8s_t a_[RT];                                                                                             \
             _Pragma("unroll") for (int rt = 0; rt < RT; ++rt) a_[rt] = frag_row(xs, A_PITCH_, 16 * rt + l15, (A_K0_) + 32 * ks + 8 * kq); \
             _Pragma("unroll") for (int ct = 0; ct < CT; ++ct) {                                                       \
                 const v8s_t b_ = frag_row(wb_, WP, wave * NC + 16 * ct + l15, 32 * ks + 8 * kq);                      \
-                _Pragma("unroll") for (int rt = 0; rt < RT; ++rt) acc[rt][ct] = mma(a_[rt], b_, acc[rt][ct]);         \
+                _Pragma("unroll") for (int rt = 0; rt < RT; ++rt) acc[rt][ct] = mma(b_, a_[rt], acc[rt][ct]);         \
             }                                                                                                         \
         }                                                                                                             \
     } while (0)
@@ -160,7 +165,7 @@ __global__ __launch_bounds__(NT) void mlp_chain_fwd_kernel(ChainArgs g) {
 #pragma unroll
             for (int u = 0; u < 12; ++u) {
                 const int e = base + tid + NT * u, r = e / q4, c = e - r * q4;
-                v[u] = ldg4_if(g.x, (long)(row0 + r) * g.ldx + 4 * c, e < total && row0 + r < g.rows);
+                v[u] = (PIT_CHAIN_DBG & 1) ? make_float4(1.f, 1.f, 1.f, 1.f) : ldg4_if(g.x, (long)(row0 + r) * g.ldx + 4 * c, e < total && row0 + r < g.rows);
             }
 #pragma unroll
             for (int u = 0; u < 12; ++u) {
@@ -182,44 +187,48 @@ __global__ __launch_bounds__(NT) void mlp_chain_fwd_kernel(ChainArgs g) {
 #pragma unroll
         for (int j = 0; j < NSETS; ++j) PIT_CHAIN_STEP(pb + j, j, XP, (pb + j) * KP);
     }
-    // GEMM1 done: Z1 = acc + b1, H = gelu(Z1) -> memory (the backward reads them) and, as bf16, the A operand of GEMM2
+    // GEMM1 done: Z1 = acc + b1, H = gelu(Z1) -> memory (the backward reads them) and, as bf16, the A operand of GEMM2.
+    // The products are formed TRANSPOSED (the weight fragment is the MFMA's A operand, the activation fragment its B: both have the
+    // same register format): accumulator register i of lane (l15, kq) is out[row 16 rt + l15][column 16 ct + 4 kq + i] - four ADJACENT
+    // columns of one row per lane, i.e. 16-byte stores (8-byte for bf16) instead of a 4-byte store per element.  (Diagnostic builds,
+    // -DPIT_CHAIN_DBG, put 6.1 of the forward's 21.1 us on the stores, 5.5 on the MFMAs, 1.7 on the X slab and 0.7 on the weight
+    // panels; the wider stores gave 21.1 -> 20.0 only: what costs is not the instruction count but that the Z1 / H stores sit in front
+    // of GEMM2's counted waits - vmcnt counts stores too - and the Z2 / Y stores drain at the kernel's end, one workgroup per CU.)
     __syncthreads();                                             // every wave is through with the X image
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) {
-        const int col = wave * NC + 16 * ct + l15;
-        const float bias = g.b1[col];
+        const int col0 = wave * NC + 16 * ct + 4 * kq;
+        const float4 bias = *reinterpret_cast<const float4*>(g.b1 + col0);
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int r = 16 * rt + 4 * kq + i;
-                const float z = acc[rt][ct][i] + bias, hv = gelu_f(z);
-                xs[r * HP + col] = f_to_bf16(hv);
-                if (row0 + r < g.rows) {
-                    g.z1[(long)(row0 + r) * N1 + col] = z;
-                    g.h[(long)(row0 + r) * N1 + col] = hv;
-                }
-                acc[rt][ct][i] = 0.0f;
+        for (int rt = 0; rt < RT; ++rt) {
+            const int r = 16 * rt + l15;
+            const float4 z = make_float4(acc[rt][ct][0] + bias.x, acc[rt][ct][1] + bias.y, acc[rt][ct][2] + bias.z, acc[rt][ct][3] + bias.w);
+            const float4 hv = make_float4(gelu_f(z.x), gelu_f(z.y), gelu_f(z.z), gelu_f(z.w));
+            *reinterpret_cast<uint2*>(xs + r * HP + col0) = pack4(hv);
+            if (row0 + r < g.rows && !(PIT_CHAIN_DBG & 2)) {
+                *reinterpret_cast<float4*>(g.z1 + (long)(row0 + r) * N1 + col0) = z;
+                *reinterpret_cast<float4*>(g.h + (long)(row0 + r) * N1 + col0) = hv;
             }
+            acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
     }
 #pragma unroll
     for (int j = 0; j < NSETS; ++j) PIT_CHAIN_STEP(p1 + j, j, HP, j * KP);
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) {
-        const int col = wave * NC + 16 * ct + l15;
-        const float bias = g.b2[col];
+        const int col0 = wave * NC + 16 * ct + 4 * kq;
+        const float4 bias = *reinterpret_cast<const float4*>(g.b2 + col0);
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int r = 16 * rt + 4 * kq + i;
-                if (row0 + r < g.rows) {
-                    const float z = acc[rt][ct][i] + bias, yv = gelu_f(z);
-                    g.z2[(long)(row0 + r) * N1 + col] = z;
-                    g.y[(long)(row0 + r) * g.ldy + col] = yv;
-                    if (g.y16) g.y16[(long)(row0 + r) * N1 + col] = f_to_bf16(yv);
-                }
+        for (int rt = 0; rt < RT; ++rt) {
+            const int r = 16 * rt + l15;
+            if (row0 + r < g.rows && (!(PIT_CHAIN_DBG & 2) || acc[rt][ct][0] == 123.456f)) {
+                const float4 z = make_float4(acc[rt][ct][0] + bias.x, acc[rt][ct][1] + bias.y, acc[rt][ct][2] + bias.z, acc[rt][ct][3] + bias.w);
+                const float4 yv = make_float4(gelu_f(z.x), gelu_f(z.y), gelu_f(z.z), gelu_f(z.w));
+                *reinterpret_cast<float4*>(g.z2 + (long)(row0 + r) * N1 + col0) = z;
+                *reinterpret_cast<float4*>(g.y + (long)(row0 + r) * g.ldy + col0) = yv;
+                if (g.y16) *reinterpret_cast<uint2*>(g.y16 + (long)(row0 + r) * N1 + col0) = pack4(yv);
             }
+        }
     }
 }
 #undef PIT_CHAIN_STEP
@@ -256,7 +265,7 @@ __global__ __launch_bounds__(NT) void mlp_chain_bwd_kernel(ChainArgs g) {
             _Pragma("unroll") for (int rt = 0; rt < RT; ++rt) a_[rt] = frag_row(A_IMG_, AP, 16 * rt + l15, (j_) * KP + 32 * ks + 8 * kq); \
             _Pragma("unroll") for (int ct = 0; ct < CT; ++ct) {                                                       \
                 const v8s_t b_ = frag_tr(wb_, WP, 32 * ks, wave * NC + 16 * ct, l15, kq);                             \
-                _Pragma("unroll") for (int rt = 0; rt < RT; ++rt) acc[rt][ct] = mma(a_[rt], b_, acc[rt][ct]);         \
+                _Pragma("unroll") for (int rt = 0; rt < RT; ++rt) acc[rt][ct] = mma(b_, a_[rt], acc[rt][ct]);         \
             }                                                                                                         \
         }                                                                                                             \
     } while (0)
@@ -283,17 +292,14 @@ __global__ __launch_bounds__(NT) void mlp_chain_bwd_kernel(ChainArgs g) {
             if (row0 + r < g.rows) *reinterpret_cast<float4*>(g.dz2 + (long)(row0 + r) * N1 + 4 * c) = v;
         }
     }
-    // Z1 at the accumulator positions of GEMM A's epilogue (consumed after the first round)
+    // Z1 at the accumulator positions of the first product's epilogue (transposed products, as the forward: row 16 rt + l15, four adjacent
+    // columns from 16 ct + 4 kq), consumed after the first round
     float z1v[RT][CT][4];
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int r = 16 * rt + 4 * kq + i;
-                z1v[rt][ct][i] = buf_load(wide_rsrc(g.z1r), row0 + r < g.rows ? (unsigned)(((long)(row0 + r) * N1 + wave * NC + 16 * ct + l15) * 4) : OOB);
-            }
+            buf_load4(wide_rsrc(g.z1r), row0 + 16 * rt + l15 < g.rows ? (unsigned)(((long)(row0 + 16 * rt + l15) * N1 + wave * NC + 16 * ct + 4 * kq) * 4) : OOB, z1v[rt][ct]);
     bwd_panel_park<N1>(wp, tid, reg[0]);
     PIT_CHAIN_LOAD(NSETS, 0);
     f32x4 acc[RT][CT];
@@ -306,17 +312,16 @@ __global__ __launch_bounds__(NT) void mlp_chain_bwd_kernel(ChainArgs g) {
     for (int j = 0; j < NSETS; ++j) PIT_CHAIN_STEP(j, j, a2s);
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) {
-        const int col = wave * NC + 16 * ct + l15;
+        const int col0 = wave * NC + 16 * ct + 4 * kq;
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int r = 16 * rt + 4 * kq + i;
-                const float v = acc[rt][ct][i] * gelu_grad_f(z1v[rt][ct][i]);
-                a1s[r * AP + col] = f_to_bf16(v);               // (nobody reads a1s before the next step's barrier)
-                if (row0 + r < g.rows) g.dz1[(long)(row0 + r) * N1 + col] = v;
-                acc[rt][ct][i] = 0.0f;
-            }
+        for (int rt = 0; rt < RT; ++rt) {
+            const int r = 16 * rt + l15;
+            const float4 v = make_float4(acc[rt][ct][0] * gelu_grad_f(z1v[rt][ct][0]), acc[rt][ct][1] * gelu_grad_f(z1v[rt][ct][1]),
+                                         acc[rt][ct][2] * gelu_grad_f(z1v[rt][ct][2]), acc[rt][ct][3] * gelu_grad_f(z1v[rt][ct][3]));
+            *reinterpret_cast<uint2*>(a1s + r * AP + col0) = pack4(v);          // (nobody reads a1s before the next step's barrier)
+            if (row0 + r < g.rows) *reinterpret_cast<float4*>(g.dz1 + (long)(row0 + r) * N1 + col0) = v;
+            acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
     }
     // rounds 1 .. chunks: a column chunk of dX = dZ1 W1 each
     for (int c = 0; c < chunks; ++c) {
@@ -326,30 +331,28 @@ __global__ __launch_bounds__(NT) void mlp_chain_bwd_kernel(ChainArgs g) {
         if (g.d_x) {
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) {
-                const int col = c * N1 + wave * NC + 16 * ct + l15;
+                const int col0 = c * N1 + wave * NC + 16 * ct + 4 * kq;
 #pragma unroll
-                for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int r = 16 * rt + 4 * kq + i;
-                        if (row0 + r < g.rows) g.d_x[(long)(row0 + r) * g.ld_dx + col] = acc[rt][ct][i];
-                    }
+                for (int rt = 0; rt < RT; ++rt) {
+                    const int r = 16 * rt + l15;
+                    if (row0 + r < g.rows)
+                        *reinterpret_cast<float4*>(g.d_x + (long)(row0 + r) * g.ld_dx + col0) = make_float4(acc[rt][ct][0], acc[rt][ct][1], acc[rt][ct][2], acc[rt][ct][3]);
+                }
             }
             // the columns of head c - 1 of a self-attention layer's concat buffer: G_h = d_x / rowsum_h as bf16, (batch, H, pts, N1)
             if (g.g16 && c >= 1) {
                 const int hd = c - 1, nh = chunks - 1;
 #pragma unroll
-                for (int rt = 0; rt < RT; ++rt)
+                for (int rt = 0; rt < RT; ++rt) {
+                    const int r = row0 + 16 * rt + l15;
+                    if (r >= g.rows) continue;
+                    const int bb = r / g.pts, n = r - bb * g.pts;
+                    const float iv = ivs[hd * CR + 16 * rt + l15];
+                    unsigned short* dst = g.g16 + (((long)bb * nh + hd) * g.pts + n) * N1 + wave * NC + 4 * kq;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int r = row0 + 16 * rt + 4 * kq + i;
-                        if (r >= g.rows) continue;
-                        const int bb = r / g.pts, n = r - bb * g.pts;
-                        const float iv = ivs[hd * CR + 16 * rt + 4 * kq + i];
-                        unsigned short* dst = g.g16 + (((long)bb * nh + hd) * g.pts + n) * N1 + wave * NC + l15;
-#pragma unroll
-                        for (int ct = 0; ct < CT; ++ct) dst[16 * ct] = f_to_bf16(acc[rt][ct][i] * iv);
-                    }
+                    for (int ct = 0; ct < CT; ++ct)
+                        *reinterpret_cast<uint2*>(dst + 16 * ct) = pack4(make_float4(acc[rt][ct][0] * iv, acc[rt][ct][1] * iv, acc[rt][ct][2] * iv, acc[rt][ct][3] * iv));
+                }
             }
         }
 #pragma unroll
@@ -416,7 +419,8 @@ extern "C" int pit_mlp_chain_fwd(const float* x, long ldx, int rows, int n0, int
                                  unsigned short* y16, void* stream) {
     if (!x || !w1_bf16 || !b1 || !w2_bf16 || !b2 || !z1 || !h || !z2 || !y) return PIT_ERR_NULL;
     if (!chain_shape_ok(rows, n0, n1, n1) || ldx < n0 || ldy < n1) return PIT_ERR_UNSUPPORTED;
-    if (ldx % 4 || !a16(x) || !a16(w1_bf16) || !a16(w2_bf16)) return PIT_ERR_SIZE;
+    if (ldx % 4 || ldy % 4 || !a16(x) || !a16(w1_bf16) || !a16(w2_bf16) || !a16(b1) || !a16(b2) || !a16(z1) || !a16(h) || !a16(z2) || !a16(y) ||
+        (y16 && (reinterpret_cast<uintptr_t>(y16) & 7))) return PIT_ERR_SIZE;
     ChainArgs g = ChainArgs();
     g.rows = rows; g.n0 = n0; g.n1 = n1; g.x = x; g.ldx = ldx; g.w1b = w1_bf16; g.w2b = w2_bf16; g.b1 = b1; g.b2 = b2;
     g.z1 = z1; g.h = h; g.z2 = z2; g.y = y; g.ldy = ldy; g.y16 = y16;
@@ -435,7 +439,8 @@ extern "C" int pit_mlp_chain_bwd(int rows, int n0, int n1, const unsigned short*
                                  float* scratch, unsigned short* g16, const float* rowstat, int pts, int mesh_batch, void* stream) {
     if (!w1_bf16 || !w2_bf16 || !z1 || !z2 || !d_y || !scratch) return PIT_ERR_NULL;
     if (!chain_shape_ok(rows, n0, n1, n1) || ld_dy < n1 || (d_x && ld_dx < n0)) return PIT_ERR_UNSUPPORTED;
-    if (ld_dy % 4 || !a16(d_y) || !a16(z2) || !a16(w1_bf16) || !a16(w2_bf16) || !a16(scratch)) return PIT_ERR_SIZE;
+    if (ld_dy % 4 || ld_dx % 4 || !a16(d_y) || !a16(z1) || !a16(z2) || !a16(w1_bf16) || !a16(w2_bf16) || !a16(scratch) || (d_x && !a16(d_x)) ||
+        (g16 && (reinterpret_cast<uintptr_t>(g16) & 7))) return PIT_ERR_SIZE;
     ChainArgs g = ChainArgs();
     g.rows = rows; g.n0 = n0; g.n1 = n1; g.w1b = w1_bf16; g.w2b = w2_bf16; g.z1r = z1; g.z2r = z2; g.d_y = d_y; g.ld_dy = ld_dy;
     g.d_x = d_x; g.ld_dx = ld_dx; g.dz1 = scratch; g.dz2 = scratch + (long)rows * n1;
