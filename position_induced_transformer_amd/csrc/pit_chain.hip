@@ -193,7 +193,9 @@ __global__ __launch_bounds__(NT) void mlp_chain_fwd_kernel(ChainArgs g) {
     // columns of one row per lane, i.e. 16-byte stores (8-byte for bf16) instead of a 4-byte store per element.  (Diagnostic builds,
     // -DPIT_CHAIN_DBG, put 6.1 of the forward's 21.1 us on the stores, 5.5 on the MFMAs, 1.7 on the X slab and 0.7 on the weight
     // panels; the wider stores gave 21.1 -> 20.0 only: what costs is not the instruction count but that the Z1 / H stores sit in front
-    // of GEMM2's counted waits - vmcnt counts stores too - and the Z2 / Y stores drain at the kernel's end, one workgroup per CU.)
+    // of GEMM2's counted waits - vmcnt counts stores too - and the Z2 / Y stores drain at the kernel's end, one workgroup per CU.
+    // Keeping Z1 in registers and storing Z1 / H behind GEMM2 instead measured 20.0 -> 20.9 us: a CU's store rate is the limit, and in
+    // front of GEMM2 the stores at least overlap its MFMAs.)
     __syncthreads();                                             // every wave is through with the X image
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) {
